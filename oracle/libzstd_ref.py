@@ -1,0 +1,81 @@
+"""TEST INFRASTRUCTURE -- loader for a binary libzstd 1.5.7, the third-party
+library the reference binds (gradle/libs.versions.toml:9,46; call site
+kompressor-zstd--nativelib/src/jvmCommonMain/jni/Wrapper.cpp:112,178).
+
+It is not part of /root/reference and not part of this repo: it is looked up
+on the machine (the Pillow wheel bundles one).  Used to (a) pin the C
+restatement in oracle/zstd_l3_ref.c, (b) generate tests/golden/, and (c) as
+bench.py's cpu_baseline (kind "reference") when present on the GPU box.
+Never imported by the product package.
+"""
+import ctypes
+import glob
+import os
+
+_CANDIDATES = [
+    "/usr/local/lib/python3.10/dist-packages/pillow.libs/libzstd-*.so.1.5.7",
+    "/usr/local/lib/python3*/dist-packages/pillow.libs/libzstd*.so*",
+    "/usr/lib/python3/dist-packages/pillow.libs/libzstd*.so*",
+]
+
+
+def find_libzstd_157():
+    """Return a ctypes handle to a libzstd reporting version 10507, or None."""
+    for pat in _CANDIDATES:
+        for path in sorted(glob.glob(pat)):
+            try:
+                lib = ctypes.CDLL(path)
+                lib.ZSTD_versionNumber.restype = ctypes.c_uint
+                if lib.ZSTD_versionNumber() == 10507:
+                    lib._path = path
+                    return lib
+            except OSError:
+                continue
+    return None
+
+
+class LibZstd:
+    """Mirror of what Kompressor's JNI layer does with libzstd (level param id 100)."""
+
+    def __init__(self):
+        lib = find_libzstd_157()
+        if lib is None:
+            raise RuntimeError("no libzstd 1.5.7 on this machine")
+        self.lib = lib
+        self.path = lib._path
+        lib.ZSTD_createCCtx.restype = ctypes.c_void_p
+        lib.ZSTD_freeCCtx.argtypes = [ctypes.c_void_p]
+        lib.ZSTD_CCtx_setParameter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        lib.ZSTD_CCtx_setParameter.restype = ctypes.c_size_t
+        lib.ZSTD_compress2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                       ctypes.c_void_p, ctypes.c_size_t]
+        lib.ZSTD_compress2.restype = ctypes.c_size_t
+        lib.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+        lib.ZSTD_compressBound.restype = ctypes.c_size_t
+        lib.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        lib.ZSTD_decompress.restype = ctypes.c_size_t
+        lib.ZSTD_isError.argtypes = [ctypes.c_size_t]
+        lib.ZSTD_getErrorName.argtypes = [ctypes.c_size_t]
+        lib.ZSTD_getErrorName.restype = ctypes.c_char_p
+        self.cctx = lib.ZSTD_createCCtx()
+        self.level = None
+
+    def compress(self, data: bytes, level: int = 3) -> bytes:
+        lib = self.lib
+        if self.level != level:
+            lib.ZSTD_CCtx_setParameter(self.cctx, 100, level)
+            self.level = level
+        cap = lib.ZSTD_compressBound(len(data))
+        out = ctypes.create_string_buffer(cap)
+        n = lib.ZSTD_compress2(self.cctx, out, cap, data, len(data))
+        if lib.ZSTD_isError(n):
+            raise RuntimeError(lib.ZSTD_getErrorName(n).decode())
+        return out.raw[:n]
+
+    def decompress(self, frame: bytes, out_size: int) -> bytes:
+        lib = self.lib
+        out = ctypes.create_string_buffer(max(out_size, 1))
+        n = lib.ZSTD_decompress(out, out_size, frame, len(frame))
+        if lib.ZSTD_isError(n):
+            raise RuntimeError(lib.ZSTD_getErrorName(n).decode())
+        return out.raw[:n]

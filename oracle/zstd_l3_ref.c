@@ -1,0 +1,1123 @@
+/*
+ * oracle/zstd_l3_ref.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of what the reference's ZstdCompressor(level=3)
+ * computes for a one-shot slice (reference call site:
+ * kompressor-zstd--nativelib/src/jvmCommonMain/jni/Wrapper.cpp:112,
+ * ZSTD_compressStream2(cctx,&out,&in,ZSTD_e_end), driven by
+ * kompressor-core/.../SliceTransform.kt:33-45 with finish=true).
+ *
+ * The arithmetic lives in a third-party dependency that is ABSENT from
+ * /root/reference: com.ensody.nativebuilds:zstd-libzstd:1.5.7.8
+ * (gradle/libs.versions.toml:9,46) == upstream libzstd 1.5.7.  This file
+ * restates its published algorithm for the level-3 path (strategy "dfast":
+ * two-table greedy LZ, HUF literals, FSE sequences, zstd frame format
+ * RFC 8878) for inputs of at most 128 KiB (a single block).
+ *
+ * Parity pin: byte-for-byte equality with a binary libzstd 1.5.7
+ * (ZSTD_versionNumber()==10507) run in the build container through
+ * oracle/libzstd_ref.py; the resulting vectors are committed under
+ * tests/golden/ (generator: tests/golden/make_golden.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this. The product path never links or calls it.
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <stdlib.h>
+
+#define KREF_API __attribute__((visibility("default")))
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+/* ------------------------------------------------------------------ */
+/* little helpers                                                      */
+/* ------------------------------------------------------------------ */
+static inline u32 rd32(const u8* p) { u32 v; memcpy(&v, p, 4); return v; }
+static inline u64 rd64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }
+static inline void wr16(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); }
+static inline void wr24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); }
+static inline void wr32(u8* p, u32 v) { wr24(p, v); p[3] = (u8)(v >> 24); }
+static inline u32 hb32(u32 v) { return 31u - (u32)__builtin_clz(v); }
+
+/* ------------------------------------------------------------------ */
+/* level-3 compression parameters as a function of the slice size      */
+/* (libzstd: ZSTD_getCParams(3, srcSize, 0) after ZSTD_adjustCParams)  */
+/* ------------------------------------------------------------------ */
+typedef struct { u32 windowLog, chainLog, hashLog, minMatch; } kref_params;
+
+KREF_API void kref_params_l3(size_t srcSize, u32* out4)
+{
+    /* base rows of the level-3 table per size class */
+    u32 W, C, H, mml;
+    if (srcSize <= 16384)        { W = 14; C = 14; H = 15; mml = 4; }
+    else if (srcSize <= 131072)  { W = 17; C = 15; H = 16; mml = 5; }
+    else if (srcSize <= 262144)  { W = 18; C = 16; H = 16; mml = 4; }
+    else                         { W = 21; C = 16; H = 17; mml = 5; }
+    {
+        u32 const srcLog = (srcSize < 64) ? 6 : hb32((u32)(srcSize - 1)) + 1;
+        if (W > srcLog) W = srcLog;
+        if (H > W + 1) H = W + 1;
+        if (C > W) C = W;
+        if (W < 10) W = 10;
+    }
+    out4[0] = W; out4[1] = C; out4[2] = H; out4[3] = mml;
+}
+
+/* ------------------------------------------------------------------ */
+/* sequence store                                                      */
+/* ------------------------------------------------------------------ */
+typedef struct { u32 offBase; u16 litLength; u16 mlBase; } kref_seq;
+
+typedef struct {
+    kref_seq* seqs; size_t nbSeq;
+    u8* lits; size_t litSize;
+    int longLengthType;      /* 0 none, 1 literal length, 2 match length */
+    size_t longLengthPos;
+} seqstore;
+
+static void store_seq(seqstore* ss, size_t litLength, const u8* lit, u32 offBase, size_t matchLength)
+{
+    memcpy(ss->lits + ss->litSize, lit, litLength);
+    ss->litSize += litLength;
+    if (litLength > 0xFFFF) { ss->longLengthType = 1; ss->longLengthPos = ss->nbSeq; }
+    ss->seqs[ss->nbSeq].litLength = (u16)litLength;
+    ss->seqs[ss->nbSeq].offBase = offBase;
+    {
+        size_t const mlBase = matchLength - 3;
+        if (mlBase > 0xFFFF) { ss->longLengthType = 2; ss->longLengthPos = ss->nbSeq; }
+        ss->seqs[ss->nbSeq].mlBase = (u16)mlBase;
+    }
+    ss->nbSeq++;
+}
+
+/* ------------------------------------------------------------------ */
+/* double-fast match finder (noDict, first block of a frame)           */
+/* ------------------------------------------------------------------ */
+static inline size_t hash_long(const u8* p, u32 hBits)
+{
+    return (size_t)((rd64(p) * 0xCF1BBCDCB7A56463ULL) >> (64 - hBits));
+}
+static inline size_t hash_short(const u8* p, u32 hBits, u32 mls)
+{
+    switch (mls) {
+    default:
+    case 4: return (size_t)((rd32(p) * 2654435761U) >> (32 - hBits));
+    case 5: return (size_t)(((rd64(p) << 24) * 889523592379ULL) >> (64 - hBits));
+    case 6: return (size_t)(((rd64(p) << 16) * 227718039650203ULL) >> (64 - hBits));
+    case 7: return (size_t)(((rd64(p) << 8) * 58295818150454627ULL) >> (64 - hBits));
+    }
+}
+static size_t count_eq(const u8* ip, const u8* match, const u8* iend)
+{
+    const u8* const s = ip;
+    while (ip < iend && *ip == *match) { ip++; match++; }
+    return (size_t)(ip - s);
+}
+
+/* Table entries are "indices": index = position + 2 (the first window
+ * index of a fresh libzstd match state is 2); 0 means empty. */
+#define IDX0 2u
+
+static size_t dfast_block(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize,
+                          u32* hashLong, u32 hBitsL, u32* hashSmall, u32 hBitsS, u32 mls)
+{
+    const u8* const base = src - IDX0;
+    const u8* const istart = src;
+    const u8* anchor = istart;
+    u32 const prefixLowestIndex = IDX0;
+    const u8* const prefixLowest = base + prefixLowestIndex;
+    const u8* const iend = istart + srcSize;
+    const u8* const ilimit = iend - 8;
+    u32 offset_1 = rep[0], offset_2 = rep[1];
+    u32 offsetSaved1 = 0, offsetSaved2 = 0;
+    size_t mLength; u32 offset; u32 curr = 0;
+    size_t const kStepIncr = 1 << 8;
+    const u8* nextStep; size_t step;
+    size_t hl0, hl1; u32 idxl0, idxl1;
+    const u8 *matchl0, *matchs0, *matchl1;
+    const u8* ip = istart; const u8* ip1;
+
+    if (srcSize < 8) return srcSize;  /* ilimit would precede istart */
+
+    ip += ((ip - prefixLowest) == 0);
+    {
+        u32 const current = (u32)(ip - base);
+        u32 const maxRep = current - prefixLowestIndex;
+        if (offset_2 > maxRep) { offsetSaved2 = offset_2; offset_2 = 0; }
+        if (offset_1 > maxRep) { offsetSaved1 = offset_1; offset_1 = 0; }
+    }
+
+    for (;;) {
+        step = 1;
+        nextStep = ip + kStepIncr;
+        ip1 = ip + step;
+        if (ip1 > ilimit) goto _cleanup;
+
+        hl0 = hash_long(ip, hBitsL);
+        idxl0 = hashLong[hl0];
+        matchl0 = base + idxl0;
+
+        do {
+            size_t const hs0 = hash_short(ip, hBitsS, mls);
+            u32 const idxs0 = hashSmall[hs0];
+            curr = (u32)(ip - base);
+            matchs0 = base + idxs0;
+
+            hashLong[hl0] = hashSmall[hs0] = curr;
+
+            /* repcode at ip+1 */
+            if ((offset_1 > 0) & (rd32(ip + 1 - offset_1) == rd32(ip + 1))) {
+                mLength = count_eq(ip + 1 + 4, ip + 1 + 4 - offset_1, iend) + 4;
+                ip++;
+                store_seq(ss, (size_t)(ip - anchor), anchor, 1 /*REPCODE1*/, mLength);
+                goto _match_stored;
+            }
+
+            hl1 = hash_long(ip1, hBitsL);
+
+            /* long match at ip */
+            if (idxl0 >= prefixLowestIndex && rd64(matchl0) == rd64(ip)) {
+                mLength = count_eq(ip + 8, matchl0 + 8, iend) + 8;
+                offset = (u32)(ip - matchl0);
+                while (((ip > anchor) & (matchl0 > prefixLowest)) && (ip[-1] == matchl0[-1])) { ip--; matchl0--; mLength++; }
+                goto _match_found;
+            }
+
+            idxl1 = hashLong[hl1];
+            matchl1 = base + idxl1;
+
+            /* short match at ip */
+            if (idxs0 >= prefixLowestIndex && rd32(matchs0) == rd32(ip)) goto _search_next_long;
+
+            if (ip1 >= nextStep) { step++; nextStep += kStepIncr; }
+            ip = ip1;
+            ip1 += step;
+            hl0 = hl1; idxl0 = idxl1; matchl0 = matchl1;
+        } while (ip1 <= ilimit);
+
+_cleanup:
+        offsetSaved2 = ((offsetSaved1 != 0) && (offset_1 != 0)) ? offsetSaved1 : offsetSaved2;
+        rep[0] = offset_1 ? offset_1 : offsetSaved1;
+        rep[1] = offset_2 ? offset_2 : offsetSaved2;
+        return (size_t)(iend - anchor);
+
+_search_next_long:
+        mLength = count_eq(ip + 4, matchs0 + 4, iend) + 4;
+        offset = (u32)(ip - matchs0);
+        if ((idxl1 > prefixLowestIndex) && (rd64(matchl1) == rd64(ip1))) {
+            size_t const l1len = count_eq(ip1 + 8, matchl1 + 8, iend) + 8;
+            if (l1len > mLength) {
+                ip = ip1; mLength = l1len; offset = (u32)(ip - matchl1); matchs0 = matchl1;
+            }
+        }
+        while (((ip > anchor) & (matchs0 > prefixLowest)) && (ip[-1] == matchs0[-1])) { ip--; matchs0--; mLength++; }
+
+_match_found:
+        offset_2 = offset_1;
+        offset_1 = offset;
+        if (step < 4) hashLong[hl1] = (u32)(ip1 - base);
+        store_seq(ss, (size_t)(ip - anchor), anchor, offset + 3, mLength);
+
+_match_stored:
+        ip += mLength;
+        anchor = ip;
+
+        if (ip <= ilimit) {
+            {
+                u32 const indexToInsert = curr + 2;
+                hashLong[hash_long(base + indexToInsert, hBitsL)] = indexToInsert;
+                hashLong[hash_long(ip - 2, hBitsL)] = (u32)(ip - 2 - base);
+                hashSmall[hash_short(base + indexToInsert, hBitsS, mls)] = indexToInsert;
+                hashSmall[hash_short(ip - 1, hBitsS, mls)] = (u32)(ip - 1 - base);
+            }
+            while ((ip <= ilimit) && ((offset_2 > 0) & (rd32(ip) == rd32(ip - offset_2)))) {
+                size_t const rLength = count_eq(ip + 4, ip + 4 - offset_2, iend) + 4;
+                u32 const tmpOff = offset_2; offset_2 = offset_1; offset_1 = tmpOff;
+                hashSmall[hash_short(ip, hBitsS, mls)] = (u32)(ip - base);
+                hashLong[hash_long(ip, hBitsL)] = (u32)(ip - base);
+                store_seq(ss, 0, anchor, 1 /*REPCODE1*/, rLength);
+                ip += rLength;
+                anchor = ip;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* forward bit writer (little-endian, LSB first) with end mark         */
+/* ------------------------------------------------------------------ */
+typedef struct { u64 acc; u32 nb; u8* start; u8* p; u8* end; int overflow; } bitw;
+
+static void bw_init(bitw* b, u8* dst, size_t cap) { b->acc = 0; b->nb = 0; b->start = b->p = dst; b->end = dst + cap; b->overflow = 0; }
+static inline void bw_flush(bitw* b)
+{
+    while (b->nb >= 8) {
+        if (b->p < b->end) *b->p = (u8)b->acc; else b->overflow = 1;
+        b->p++; b->acc >>= 8; b->nb -= 8;
+    }
+}
+static inline void bw_add(bitw* b, u64 v, u32 n)
+{
+    if (n == 0) return;
+    v &= (n >= 64) ? ~0ULL : ((1ULL << n) - 1);
+    b->acc |= v << b->nb; b->nb += n;
+    bw_flush(b);   /* n <= 32 here, acc has headroom: nb < 8 before add */
+}
+/* returns byte size, 0 on overflow */
+static size_t bw_close(bitw* b)
+{
+    bw_add(b, 1, 1);
+    bw_flush(b);
+    if (b->nb) { if (b->p < b->end) *b->p = (u8)b->acc; else b->overflow = 1; b->p++; b->nb = 0; }
+    if (b->overflow) return 0;
+    return (size_t)(b->p - b->start);
+}
+
+/* ------------------------------------------------------------------ */
+/* FSE: table-log choice, normalisation, header, encoding table        */
+/* ------------------------------------------------------------------ */
+#define FSE_MIN_TABLELOG 5
+#define FSE_MAX_TABLELOG 12
+#define KERR ((size_t)-1)
+
+static u32 fse_min_tablelog(size_t srcSize, u32 maxSymbolValue)
+{
+    u32 const minBitsSrc = hb32((u32)srcSize) + 1;
+    u32 const minBitsSymbols = hb32(maxSymbolValue) + 2;
+    return minBitsSrc < minBitsSymbols ? minBitsSrc : minBitsSymbols;
+}
+static u32 fse_optimal_tablelog(u32 maxTableLog, size_t srcSize, u32 maxSymbolValue, u32 minus)
+{
+    u32 const maxBitsSrc = hb32((u32)(srcSize - 1)) - minus;
+    u32 tableLog = maxTableLog;
+    u32 const minBits = fse_min_tablelog(srcSize, maxSymbolValue);
+    if (tableLog == 0) tableLog = 11;
+    if (maxBitsSrc < tableLog) tableLog = maxBitsSrc;
+    if (minBits > tableLog) tableLog = minBits;
+    if (tableLog < FSE_MIN_TABLELOG) tableLog = FSE_MIN_TABLELOG;
+    if (tableLog > FSE_MAX_TABLELOG) tableLog = FSE_MAX_TABLELOG;
+    return tableLog;
+}
+
+static size_t fse_normalize_m2(short* norm, u32 tableLog, const u32* count, size_t total, u32 maxSymbolValue, short lowProbCount)
+{
+    short const NOT_YET_ASSIGNED = -2;
+    u32 s, distributed = 0, ToDistribute;
+    u32 const lowThreshold = (u32)(total >> tableLog);
+    u32 lowOne = (u32)((total * 3) >> (tableLog + 1));
+
+    for (s = 0; s <= maxSymbolValue; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = lowProbCount; distributed++; total -= count[s]; continue; }
+        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        norm[s] = NOT_YET_ASSIGNED;
+    }
+    ToDistribute = (1u << tableLog) - distributed;
+    if (ToDistribute == 0) return 0;
+
+    if ((total / ToDistribute) > lowOne) {
+        lowOne = (u32)((total * 3) / (ToDistribute * 2));
+        for (s = 0; s <= maxSymbolValue; s++) {
+            if ((norm[s] == NOT_YET_ASSIGNED) && (count[s] <= lowOne)) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        }
+        ToDistribute = (1u << tableLog) - distributed;
+    }
+
+    if (distributed == maxSymbolValue + 1) {
+        u32 maxV = 0, maxC = 0;
+        for (s = 0; s <= maxSymbolValue; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
+        norm[maxV] += (short)ToDistribute;
+        return 0;
+    }
+    if (total == 0) {
+        for (s = 0; ToDistribute > 0; s = (s + 1) % (maxSymbolValue + 1)) if (norm[s] > 0) { ToDistribute--; norm[s]++; }
+        return 0;
+    }
+    {
+        u64 const vStepLog = 62 - tableLog;
+        u64 const mid = (1ULL << (vStepLog - 1)) - 1;
+        u64 const rStep = ((((u64)1 << vStepLog) * ToDistribute) + mid) / (u32)total;
+        u64 tmpTotal = mid;
+        for (s = 0; s <= maxSymbolValue; s++) {
+            if (norm[s] == NOT_YET_ASSIGNED) {
+                u64 const end = tmpTotal + (count[s] * rStep);
+                u32 const sStart = (u32)(tmpTotal >> vStepLog);
+                u32 const sEnd = (u32)(end >> vStepLog);
+                u32 const weight = sEnd - sStart;
+                if (weight < 1) return KERR;
+                norm[s] = (short)weight;
+                tmpTotal = end;
+            }
+        }
+    }
+    return 0;
+}
+
+/* returns tableLog, 0 for rle, KERR on error */
+static size_t fse_normalize(short* norm, u32 tableLog, const u32* count, size_t total, u32 maxSymbolValue, u32 useLowProbCount)
+{
+    static u32 const rtbTable[] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
+    if (tableLog == 0) tableLog = 11;
+    if (tableLog < FSE_MIN_TABLELOG) return KERR;
+    if (tableLog > FSE_MAX_TABLELOG) return KERR;
+    if (tableLog < fse_min_tablelog(total, maxSymbolValue)) return KERR;
+    {
+        short const lowProbCount = useLowProbCount ? -1 : 1;
+        u64 const scale = 62 - tableLog;
+        u64 const step = ((u64)1 << 62) / (u32)total;
+        u64 const vStep = 1ULL << (scale - 20);
+        int stillToDistribute = 1 << tableLog;
+        u32 s, largest = 0; short largestP = 0;
+        u32 const lowThreshold = (u32)(total >> tableLog);
+
+        for (s = 0; s <= maxSymbolValue; s++) {
+            if (count[s] == total) return 0;
+            if (count[s] == 0) { norm[s] = 0; continue; }
+            if (count[s] <= lowThreshold) { norm[s] = lowProbCount; stillToDistribute--; }
+            else {
+                short proba = (short)((count[s] * step) >> scale);
+                if (proba < 8) {
+                    u64 const restToBeat = vStep * rtbTable[proba];
+                    proba += (count[s] * step) - ((u64)proba << scale) > restToBeat;
+                }
+                if (proba > largestP) { largestP = proba; largest = s; }
+                norm[s] = proba;
+                stillToDistribute -= proba;
+            }
+        }
+        if (-stillToDistribute >= (norm[largest] >> 1)) {
+            size_t const e = fse_normalize_m2(norm, tableLog, count, total, maxSymbolValue, lowProbCount);
+            if (e == KERR) return KERR;
+        } else norm[largest] += (short)stillToDistribute;
+    }
+    return tableLog;
+}
+
+/* writes the normalised-count header; dst must have room (caller gives >= 512) */
+static size_t fse_write_ncount(u8* dst, size_t cap, const short* norm, u32 maxSymbolValue, u32 tableLog)
+{
+    u8* out = dst; u8* const oend = dst + cap;
+    int nbBits; int const tableSize = 1 << tableLog;
+    int remaining, threshold; u32 bitStream = 0; int bitCount = 0;
+    u32 symbol = 0; u32 const alphabetSize = maxSymbolValue + 1; int previousIs0 = 0;
+
+    bitStream += (tableLog - FSE_MIN_TABLELOG) << bitCount; bitCount += 4;
+    remaining = tableSize + 1; threshold = tableSize; nbBits = (int)tableLog + 1;
+
+    while ((symbol < alphabetSize) && (remaining > 1)) {
+        if (previousIs0) {
+            u32 start = symbol;
+            while ((symbol < alphabetSize) && !norm[symbol]) symbol++;
+            if (symbol == alphabetSize) break;
+            while (symbol >= start + 24) {
+                start += 24;
+                bitStream += 0xFFFFU << bitCount;
+                if (out > oend - 2) return KERR;
+                out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16;
+            }
+            while (symbol >= start + 3) { start += 3; bitStream += 3U << bitCount; bitCount += 2; }
+            bitStream += (symbol - start) << bitCount; bitCount += 2;
+            if (bitCount > 16) {
+                if (out > oend - 2) return KERR;
+                out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16;
+            }
+        }
+        {
+            int count = norm[symbol++];
+            int const max = (2 * threshold - 1) - remaining;
+            remaining -= count < 0 ? -count : count;
+            count++;
+            if (count >= threshold) count += max;
+            bitStream += (u32)count << bitCount;
+            bitCount += nbBits;
+            bitCount -= (count < max);
+            previousIs0 = (count == 1);
+            if (remaining < 1) return KERR;
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+        }
+        if (bitCount > 16) {
+            if (out > oend - 2) return KERR;
+            out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16;
+        }
+    }
+    if (remaining != 1) return KERR;
+    if (out > oend - 2) return KERR;
+    out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8);
+    out += (bitCount + 7) / 8;
+    return (size_t)(out - dst);
+}
+
+/* encoding table: per-symbol (deltaNbBits, deltaFindState) + next-state table */
+typedef struct {
+    u32 tableLog;
+    u16 stateTable[1 << FSE_MAX_TABLELOG];
+    u32 deltaNbBits[256];
+    int deltaFindState[256];
+} fse_ctable;
+
+static void fse_build_ctable(fse_ctable* ct, const short* norm, u32 maxSymbolValue, u32 tableLog)
+{
+    u32 const tableSize = 1u << tableLog, tableMask = tableSize - 1;
+    u32 const step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    u32 const maxSV1 = maxSymbolValue + 1;
+    u16 cumul[258]; u8 tableSymbol[1 << FSE_MAX_TABLELOG];
+    u32 highThreshold = tableSize - 1, u;
+
+    ct->tableLog = tableLog;
+    cumul[0] = 0;
+    for (u = 1; u <= maxSV1; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tableSymbol[highThreshold--] = (u8)(u - 1); }
+        else cumul[u] = cumul[u - 1] + (u16)norm[u - 1];
+    }
+    cumul[maxSV1] = (u16)(tableSize + 1);
+    {
+        u32 position = 0, symbol;
+        for (symbol = 0; symbol < maxSV1; symbol++) {
+            int n; int const freq = norm[symbol];
+            for (n = 0; n < freq; n++) {
+                tableSymbol[position] = (u8)symbol;
+                position = (position + step) & tableMask;
+                while (position > highThreshold) position = (position + step) & tableMask;
+            }
+        }
+    }
+    for (u = 0; u < tableSize; u++) { u8 const s = tableSymbol[u]; ct->stateTable[cumul[s]++] = (u16)(tableSize + u); }
+    {
+        u32 total = 0, s;
+        for (s = 0; s <= maxSymbolValue; s++) {
+            switch (norm[s]) {
+            case 0: ct->deltaNbBits[s] = ((tableLog + 1) << 16) - (1u << tableLog); ct->deltaFindState[s] = 0; break;
+            case -1: case 1:
+                ct->deltaNbBits[s] = (tableLog << 16) - (1u << tableLog);
+                ct->deltaFindState[s] = (int)(total - 1); total++; break;
+            default: {
+                u32 const maxBitsOut = tableLog - hb32((u32)norm[s] - 1);
+                u32 const minStatePlus = (u32)norm[s] << maxBitsOut;
+                ct->deltaNbBits[s] = (maxBitsOut << 16) - minStatePlus;
+                ct->deltaFindState[s] = (int)(total - (u32)norm[s]);
+                total += (u32)norm[s];
+            } }
+        }
+    }
+}
+static void fse_build_ctable_rle(fse_ctable* ct, u8 symbol)
+{
+    ct->tableLog = 0; ct->stateTable[0] = 0; ct->stateTable[1] = 0;
+    ct->deltaNbBits[symbol] = 0; ct->deltaFindState[symbol] = 0;
+}
+static inline u32 fse_init_state(const fse_ctable* ct, u32 symbol)
+{
+    u32 const dnb = ct->deltaNbBits[symbol];
+    u32 const nbBitsOut = (dnb + (1u << 15)) >> 16;
+    u32 const value = (nbBitsOut << 16) - dnb;
+    return ct->stateTable[(value >> nbBitsOut) + ct->deltaFindState[symbol]];
+}
+static inline void fse_encode(bitw* b, const fse_ctable* ct, u32* state, u32 symbol)
+{
+    u32 const nbBitsOut = (*state + ct->deltaNbBits[symbol]) >> 16;
+    bw_add(b, *state, nbBitsOut);
+    *state = ct->stateTable[(*state >> nbBitsOut) + ct->deltaFindState[symbol]];
+}
+
+/* ------------------------------------------------------------------ */
+/* Huffman literals                                                    */
+/* ------------------------------------------------------------------ */
+#define HUF_TABLELOG_MAX 12
+#define LIT_HUF_LOG 11
+
+typedef struct { u32 count; u16 parent; u8 byte; u8 nbBits; } hnode;
+typedef struct { u16 curr, base; } rankpos;
+
+#define RP_TABLE_SIZE 192
+#define RP_LOG_BUCKETS_BEGIN 158
+#define RP_DISTINCT_CUTOFF 165   /* 158 + highbit32(158)=7 */
+
+static u32 huf_get_index(u32 count) { return (count < RP_DISTINCT_CUTOFF) ? count : hb32(count) + RP_LOG_BUCKETS_BEGIN; }
+static void huf_swap(hnode* a, hnode* b) { hnode t = *a; *a = *b; *b = t; }
+static void huf_insertion_sort(hnode* n, int low, int high)
+{
+    int i, size = high - low + 1; n += low;
+    for (i = 1; i < size; ++i) {
+        hnode const key = n[i]; int j = i - 1;
+        while (j >= 0 && n[j].count < key.count) { n[j + 1] = n[j]; j--; }
+        n[j + 1] = key;
+    }
+}
+static int huf_partition(hnode* arr, int low, int high)
+{
+    u32 const pivot = arr[high].count; int i = low - 1, j = low;
+    for (; j < high; j++) if (arr[j].count > pivot) { i++; huf_swap(&arr[i], &arr[j]); }
+    huf_swap(&arr[i + 1], &arr[high]);
+    return i + 1;
+}
+static void huf_quicksort(hnode* arr, int low, int high)
+{
+    if (high - low < 8) { huf_insertion_sort(arr, low, high); return; }
+    while (low < high) {
+        int const idx = huf_partition(arr, low, high);
+        if (idx - low < high - idx) { huf_quicksort(arr, low, idx - 1); low = idx + 1; }
+        else { huf_quicksort(arr, idx + 1, high); high = idx - 1; }
+    }
+}
+static void huf_sort(hnode* huffNode, const u32* count, u32 maxSymbolValue)
+{
+    rankpos rp[RP_TABLE_SIZE]; u32 n; u32 const maxSV1 = maxSymbolValue + 1;
+    memset(rp, 0, sizeof(rp));
+    for (n = 0; n < maxSV1; ++n) rp[huf_get_index(count[n])].base++;
+    for (n = RP_TABLE_SIZE - 1; n > 0; --n) { rp[n - 1].base += rp[n].base; rp[n - 1].curr = rp[n - 1].base; }
+    for (n = 0; n < maxSV1; ++n) {
+        u32 const c = count[n]; u32 const r = huf_get_index(c) + 1; u32 const pos = rp[r].curr++;
+        huffNode[pos].count = c; huffNode[pos].byte = (u8)n;
+    }
+    for (n = RP_DISTINCT_CUTOFF; n < RP_TABLE_SIZE - 1; ++n) {
+        int const bucketSize = rp[n].curr - rp[n].base; u32 const start = rp[n].base;
+        if (bucketSize > 1) huf_quicksort(huffNode + start, 0, bucketSize - 1);
+    }
+}
+
+static u32 huf_set_max_height(hnode* huffNode, u32 lastNonNull, u32 targetNbBits)
+{
+    u32 const largestBits = huffNode[lastNonNull].nbBits;
+    if (largestBits <= targetNbBits) return largestBits;
+    {
+        int totalCost = 0; u32 const baseCost = 1u << (largestBits - targetNbBits);
+        int n = (int)lastNonNull;
+        while (huffNode[n].nbBits > targetNbBits) {
+            totalCost += (int)(baseCost - (1u << (largestBits - huffNode[n].nbBits)));
+            huffNode[n].nbBits = (u8)targetNbBits; n--;
+        }
+        while (huffNode[n].nbBits == targetNbBits) --n;
+        totalCost >>= (largestBits - targetNbBits);
+        {
+            u32 const noSymbol = 0xF0F0F0F0; u32 rankLast[HUF_TABLELOG_MAX + 2];
+            memset(rankLast, 0xF0, sizeof(rankLast));
+            {
+                u32 currentNbBits = targetNbBits; int pos;
+                for (pos = n; pos >= 0; pos--) {
+                    if (huffNode[pos].nbBits >= currentNbBits) continue;
+                    currentNbBits = huffNode[pos].nbBits;
+                    rankLast[targetNbBits - currentNbBits] = (u32)pos;
+                }
+            }
+            while (totalCost > 0) {
+                u32 nBitsToDecrease = hb32((u32)totalCost) + 1;
+                for (; nBitsToDecrease > 1; nBitsToDecrease--) {
+                    u32 const highPos = rankLast[nBitsToDecrease];
+                    u32 const lowPos = rankLast[nBitsToDecrease - 1];
+                    if (highPos == noSymbol) continue;
+                    if (lowPos == noSymbol) break;
+                    { u32 const highTotal = huffNode[highPos].count; u32 const lowTotal = 2 * huffNode[lowPos].count;
+                      if (highTotal <= lowTotal) break; }
+                }
+                while ((nBitsToDecrease <= HUF_TABLELOG_MAX) && (rankLast[nBitsToDecrease] == noSymbol)) nBitsToDecrease++;
+                totalCost -= 1 << (nBitsToDecrease - 1);
+                huffNode[rankLast[nBitsToDecrease]].nbBits++;
+                if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
+                if (rankLast[nBitsToDecrease] == 0) rankLast[nBitsToDecrease] = noSymbol;
+                else {
+                    rankLast[nBitsToDecrease]--;
+                    if (huffNode[rankLast[nBitsToDecrease]].nbBits != targetNbBits - nBitsToDecrease) rankLast[nBitsToDecrease] = noSymbol;
+                }
+            }
+            while (totalCost < 0) {
+                if (rankLast[1] == noSymbol) {
+                    while (huffNode[n].nbBits == targetNbBits) n--;
+                    huffNode[n + 1].nbBits--;
+                    rankLast[1] = (u32)(n + 1);
+                    totalCost++;
+                    continue;
+                }
+                huffNode[rankLast[1] + 1].nbBits--;
+                rankLast[1]++;
+                totalCost++;
+            }
+        }
+    }
+    return targetNbBits;
+}
+
+typedef struct { u16 val[256]; u8 nbBits[256]; } huf_ctable;
+
+/* returns maxNbBits */
+static u32 huf_build_ctable(huf_ctable* ct, const u32* count, u32 maxSymbolValue, u32 maxNbBits)
+{
+    hnode nodeTable[512 + 2]; hnode* const huffNode0 = nodeTable; hnode* const huffNode = huffNode0 + 1;
+    int nonNullRank, lowS, lowN, nodeNb = 256, n, nodeRoot;
+    memset(nodeTable, 0, sizeof(nodeTable));
+    huf_sort(huffNode, count, maxSymbolValue);
+
+    nonNullRank = (int)maxSymbolValue;
+    while (huffNode[nonNullRank].count == 0) nonNullRank--;
+    lowS = nonNullRank; nodeRoot = nodeNb + lowS - 1; lowN = nodeNb;
+    huffNode[nodeNb].count = huffNode[lowS].count + huffNode[lowS - 1].count;
+    huffNode[lowS].parent = huffNode[lowS - 1].parent = (u16)nodeNb;
+    nodeNb++; lowS -= 2;
+    for (n = nodeNb; n <= nodeRoot; n++) huffNode[n].count = (u32)(1U << 30);
+    huffNode0[0].count = (u32)(1U << 31);
+    while (nodeNb <= nodeRoot) {
+        int const n1 = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
+        int const n2 = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
+        huffNode[nodeNb].count = huffNode[n1].count + huffNode[n2].count;
+        huffNode[n1].parent = huffNode[n2].parent = (u16)nodeNb;
+        nodeNb++;
+    }
+    huffNode[nodeRoot].nbBits = 0;
+    for (n = nodeRoot - 1; n >= 256; n--) huffNode[n].nbBits = huffNode[huffNode[n].parent].nbBits + 1;
+    for (n = 0; n <= nonNullRank; n++) huffNode[n].nbBits = huffNode[huffNode[n].parent].nbBits + 1;
+
+    maxNbBits = huf_set_max_height(huffNode, (u32)nonNullRank, maxNbBits);
+    {
+        u16 nbPerRank[HUF_TABLELOG_MAX + 1] = { 0 }; u16 valPerRank[HUF_TABLELOG_MAX + 1] = { 0 };
+        int const alphabetSize = (int)(maxSymbolValue + 1);
+        for (n = 0; n <= nonNullRank; n++) nbPerRank[huffNode[n].nbBits]++;
+        { u16 min = 0; for (n = (int)maxNbBits; n > 0; n--) { valPerRank[n] = min; min += nbPerRank[n]; min >>= 1; } }
+        memset(ct, 0, sizeof(*ct));
+        for (n = 0; n < alphabetSize; n++) ct->nbBits[huffNode[n].byte] = huffNode[n].nbBits;
+        for (n = 0; n < alphabetSize; n++) ct->val[n] = valPerRank[ct->nbBits[n]]++;
+    }
+    return maxNbBits;
+}
+
+/* FSE-compress the Huffman weights; returns 0 if not compressible, 1 if single symbol */
+static size_t huf_compress_weights(u8* dst, size_t dstSize, const u8* weightTable, size_t wtSize)
+{
+    u8* op = dst; u8* const oend = dst + dstSize;
+    u32 maxSymbolValue = HUF_TABLELOG_MAX; u32 tableLog = 6;
+    u32 count[HUF_TABLELOG_MAX + 1]; short norm[HUF_TABLELOG_MAX + 1]; fse_ctable ct;
+    if (wtSize <= 1) return 0;
+    {
+        u32 maxCount = 0; size_t i; u32 s;
+        memset(count, 0, sizeof(count));
+        for (i = 0; i < wtSize; i++) count[weightTable[i]]++;
+        while (!count[maxSymbolValue]) maxSymbolValue--;
+        for (s = 0; s <= maxSymbolValue; s++) if (count[s] > maxCount) maxCount = count[s];
+        if (maxCount == wtSize) return 1;
+        if (maxCount == 1) return 0;
+    }
+    tableLog = fse_optimal_tablelog(tableLog, wtSize, maxSymbolValue, 2);
+    { size_t const e = fse_normalize(norm, tableLog, count, wtSize, maxSymbolValue, 0); if (e == KERR) return KERR; }
+    { size_t const h = fse_write_ncount(op, (size_t)(oend - op), norm, maxSymbolValue, tableLog); if (h == KERR) return KERR; op += h; }
+    fse_build_ctable(&ct, norm, maxSymbolValue, tableLog);
+    {
+        /* FSE_compress_usingCTable: two interleaved states, symbols walked last -> first */
+        bitw b; const u8* ip = weightTable + wtSize; u32 s1, s2; size_t n = wtSize; size_t cSize;
+        if (n <= 2) return 0;
+        bw_init(&b, op, (size_t)(oend - op));
+        if (n & 1) { s1 = fse_init_state(&ct, *--ip); s2 = fse_init_state(&ct, *--ip); fse_encode(&b, &ct, &s1, *--ip); }
+        else { s2 = fse_init_state(&ct, *--ip); s1 = fse_init_state(&ct, *--ip); }
+        while (ip > weightTable) { fse_encode(&b, &ct, &s2, *--ip); fse_encode(&b, &ct, &s1, *--ip); }
+        bw_add(&b, s2, tableLog); bw_add(&b, s1, tableLog);
+        cSize = bw_close(&b);
+        if (cSize == 0) return 0;
+        op += cSize;
+    }
+    return (size_t)(op - dst);
+}
+
+static size_t huf_write_ctable(u8* dst, size_t maxDstSize, const huf_ctable* ct, u32 maxSymbolValue, u32 huffLog)
+{
+    u8 bitsToWeight[HUF_TABLELOG_MAX + 1]; u8 huffWeight[256]; u32 n;
+    bitsToWeight[0] = 0;
+    for (n = 1; n < huffLog + 1; n++) bitsToWeight[n] = (u8)(huffLog + 1 - n);
+    for (n = 0; n < maxSymbolValue; n++) huffWeight[n] = bitsToWeight[ct->nbBits[n]];
+    if (maxDstSize < 1) return KERR;
+    {
+        size_t const hSize = huf_compress_weights(dst + 1, maxDstSize - 1, huffWeight, maxSymbolValue);
+        if (hSize == KERR) return KERR;
+        if ((hSize > 1) & (hSize < maxSymbolValue / 2)) { dst[0] = (u8)hSize; return hSize + 1; }
+    }
+    if (maxSymbolValue > (256 - 128)) return KERR;
+    if (((maxSymbolValue + 1) / 2) + 1 > maxDstSize) return KERR;
+    dst[0] = (u8)(128 + (maxSymbolValue - 1));
+    huffWeight[maxSymbolValue] = 0;
+    for (n = 0; n < maxSymbolValue; n += 2) dst[(n / 2) + 1] = (u8)((huffWeight[n] << 4) + huffWeight[n + 1]);
+    return ((maxSymbolValue + 1) / 2) + 1;
+}
+
+static size_t huf_encode_1x(u8* dst, size_t dstSize, const u8* src, size_t srcSize, const huf_ctable* ct)
+{
+    bitw b; size_t n;
+    if (dstSize < 8) return 0;
+    bw_init(&b, dst, dstSize);
+    for (n = srcSize; n > 0; n--) bw_add(&b, ct->val[src[n - 1]], ct->nbBits[src[n - 1]]);
+    return bw_close(&b);
+}
+static size_t huf_encode_4x(u8* dst, size_t dstSize, const u8* src, size_t srcSize, const huf_ctable* ct)
+{
+    size_t const segmentSize = (srcSize + 3) / 4;
+    const u8* ip = src; const u8* const iend = src + srcSize;
+    u8* op = dst; u8* const oend = dst + dstSize; int i;
+    if (dstSize < 6 + 1 + 1 + 1 + 8) return 0;
+    if (srcSize < 12) return 0;
+    op += 6;
+    for (i = 0; i < 3; i++) {
+        size_t const c = huf_encode_1x(op, (size_t)(oend - op), ip, segmentSize, ct);
+        if (c == 0 || c > 65535) return 0;
+        wr16(dst + 2 * i, (u32)c); op += c; ip += segmentSize;
+    }
+    {
+        size_t const c = huf_encode_1x(op, (size_t)(oend - op), ip, (size_t)(iend - ip), ct);
+        if (c == 0 || c > 65535) return 0;
+        op += c;
+    }
+    return (size_t)(op - dst);
+}
+
+/* HUF_compress{1X,4X}_repeat with no previous table. returns 0 = not compressible,
+ * 1 = single symbol (rle), KERR = error, else compressed size (table + streams). */
+static size_t huf_compress(u8* dst, size_t dstSize, const u8* src, size_t srcSize, int singleStream, int suspectUncompressible)
+{
+    u32 count[256]; u32 maxSymbolValue = 255; u32 huffLog = LIT_HUF_LOG; huf_ctable ct;
+    u8* op = dst; u8* const oend = dst + dstSize; size_t i;
+    if (!srcSize) return 0;
+    if (!dstSize) return 0;
+    if (srcSize > 128 * 1024) return KERR;
+
+    if (suspectUncompressible && srcSize >= (4096 * 10)) {
+        size_t largestTotal = 0; u32 c2[256]; u32 s, m;
+        memset(c2, 0, sizeof(c2)); for (i = 0; i < 4096; i++) c2[src[i]]++;
+        m = 0; for (s = 0; s < 256; s++) if (c2[s] > m) m = c2[s]; largestTotal += m;
+        memset(c2, 0, sizeof(c2)); for (i = 0; i < 4096; i++) c2[src[srcSize - 4096 + i]]++;
+        m = 0; for (s = 0; s < 256; s++) if (c2[s] > m) m = c2[s]; largestTotal += m;
+        if (largestTotal <= ((2 * 4096) >> 7) + 4) return 0;
+    }
+    {
+        u32 largest = 0, s;
+        memset(count, 0, sizeof(count));
+        for (i = 0; i < srcSize; i++) count[src[i]]++;
+        while (!count[maxSymbolValue]) maxSymbolValue--;
+        for (s = 0; s <= maxSymbolValue; s++) if (count[s] > largest) largest = count[s];
+        if (largest == srcSize) { *dst = src[0]; return 1; }
+        if (largest <= (srcSize >> 7) + 4) return 0;
+    }
+    huffLog = fse_optimal_tablelog(huffLog, srcSize, maxSymbolValue, 1);
+    huffLog = huf_build_ctable(&ct, count, maxSymbolValue, huffLog);
+    {
+        size_t const hSize = huf_write_ctable(op, dstSize, &ct, maxSymbolValue, huffLog);
+        if (hSize == KERR) return KERR;
+        if (hSize + 12ul >= srcSize) return 0;
+        op += hSize;
+    }
+    {
+        size_t const cSize = singleStream ? huf_encode_1x(op, (size_t)(oend - op), src, srcSize, &ct)
+                                          : huf_encode_4x(op, (size_t)(oend - op), src, srcSize, &ct);
+        if (cSize == 0) return 0;
+        op += cSize;
+        if ((size_t)(op - dst) >= srcSize - 1) return 0;
+    }
+    return (size_t)(op - dst);
+}
+
+static size_t min_gain(size_t srcSize) { return (srcSize >> 6) + 2; }   /* strategy < btultra */
+
+static size_t lit_raw(u8* dst, size_t cap, const u8* src, size_t srcSize)
+{
+    u32 const flSize = 1 + (srcSize > 31) + (srcSize > 4095);
+    if (srcSize + flSize > cap) return KERR;
+    switch (flSize) {
+    case 1: dst[0] = (u8)(0 + (srcSize << 3)); break;
+    case 2: wr16(dst, (u32)(0 + (1 << 2) + (srcSize << 4))); break;
+    default: wr24(dst, (u32)(0 + (3 << 2) + (srcSize << 4))); break;
+    }
+    memcpy(dst + flSize, src, srcSize);
+    return srcSize + flSize;
+}
+static size_t lit_rle(u8* dst, size_t cap, const u8* src, size_t srcSize)
+{
+    u32 const flSize = 1 + (srcSize > 31) + (srcSize > 4095);
+    if (cap < 4) return KERR;
+    switch (flSize) {
+    case 1: dst[0] = (u8)(1 + (srcSize << 3)); break;
+    case 2: wr16(dst, (u32)(1 + (1 << 2) + (srcSize << 4))); break;
+    default: wr24(dst, (u32)(1 + (3 << 2) + (srcSize << 4))); break;
+    }
+    dst[flSize] = src[0];
+    return flSize + 1;
+}
+
+static size_t compress_literals(u8* dst, size_t cap, const u8* src, size_t srcSize, int suspectUncompressible)
+{
+    size_t const lhSize = 3 + (srcSize >= 1024) + (srcSize >= 16384);
+    int const singleStream = srcSize < 256;
+    size_t cLitSize;
+    if (srcSize < 64) return lit_raw(dst, cap, src, srcSize);   /* ZSTD_minLiteralsToCompress(dfast, no repeat) */
+    if (cap < lhSize + 1) return KERR;
+    cLitSize = huf_compress(dst + lhSize, cap - lhSize, src, srcSize, singleStream, suspectUncompressible);
+    {
+        size_t const minGain = min_gain(srcSize);
+        if ((cLitSize == 0) || (cLitSize >= srcSize - minGain) || cLitSize == KERR) return lit_raw(dst, cap, src, srcSize);
+    }
+    if (cLitSize == 1) return lit_rle(dst, cap, src, srcSize);   /* srcSize >= 64 >= 8 */
+    switch (lhSize) {
+    case 3: wr24(dst, (u32)(2 + ((u32)(!singleStream) << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 14))); break;
+    case 4: wr32(dst, (u32)(2 + (2 << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 18))); break;
+    default: wr32(dst, (u32)(2 + (3 << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 22))); dst[4] = (u8)(cLitSize >> 10); break;
+    }
+    return lhSize + cLitSize;
+}
+
+/* ------------------------------------------------------------------ */
+/* sequences section                                                   */
+/* ------------------------------------------------------------------ */
+static const u8 LL_bits[36] = { 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0, 1,1,1,1,2,2,3,3, 4,6,7,8,9,10,11,12, 13,14,15,16 };
+static const u8 ML_bits[53] = { 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0,
+                                1,1,1,1,2,2,3,3, 4,4,5,7,8,9,10,11, 12,13,14,15,16 };
+static const short LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2, 2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
+static const short ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,
+                                          1,1,1,1,1,1,1,1, 1,1,1,1,1,1,-1,-1, -1,-1,-1,-1,-1 };
+static const short OF_defaultNorm[29] = { 1,1,1,1,1,1,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, -1,-1,-1,-1,-1 };
+
+static u32 ll_code(u32 litLength)
+{
+    static const u8 LL_Code[64] = { 0,1,2,3,4,5,6,7, 8,9,10,11,12,13,14,15, 16,16,17,17,18,18,19,19,
+        20,20,20,20,21,21,21,21, 22,22,22,22,22,22,22,22, 23,23,23,23,23,23,23,23,
+        24,24,24,24,24,24,24,24, 24,24,24,24,24,24,24,24 };
+    return (litLength > 63) ? hb32(litLength) + 19 : LL_Code[litLength];
+}
+static u32 ml_code(u32 mlBase)
+{
+    static const u8 ML_Code[128] = { 0,1,2,3,4,5,6,7, 8,9,10,11,12,13,14,15, 16,17,18,19,20,21,22,23, 24,25,26,27,28,29,30,31,
+        32,32,33,33,34,34,35,35, 36,36,36,36,37,37,37,37, 38,38,38,38,38,38,38,38, 39,39,39,39,39,39,39,39,
+        40,40,40,40,40,40,40,40, 40,40,40,40,40,40,40,40, 41,41,41,41,41,41,41,41, 41,41,41,41,41,41,41,41,
+        42,42,42,42,42,42,42,42, 42,42,42,42,42,42,42,42, 42,42,42,42,42,42,42,42, 42,42,42,42,42,42,42,42 };
+    return (mlBase > 127) ? hb32(mlBase) + 36 : ML_Code[mlBase];
+}
+
+enum { set_basic = 0, set_rle = 1, set_compressed = 2, set_repeat = 3 };
+
+static u32 select_encoding(const u32* count, u32 max, size_t mostFrequent, size_t nbSeq, u32 defaultNormLog, int isDefaultAllowed)
+{
+    (void)count; (void)max;
+    if (mostFrequent == nbSeq) {
+        if (isDefaultAllowed && nbSeq <= 2) return set_basic;
+        return set_rle;
+    }
+    if (isDefaultAllowed) {   /* strategy dfast(2) < lazy */
+        size_t const mult = 10 - 2;
+        size_t const dynamicFse_nbSeq_min = (((size_t)1 << defaultNormLog) * mult) >> 3;
+        if ((nbSeq < dynamicFse_nbSeq_min) || (mostFrequent < (nbSeq >> (defaultNormLog - 1)))) return set_basic;
+    }
+    return set_compressed;
+}
+
+/* returns header bytes written (KERR on error) and fills ct */
+static size_t build_seq_ctable(u8* dst, size_t cap, fse_ctable* ct, u32 FSELog, u32 type, u32* count, u32 max,
+                               const u8* codeTable, size_t nbSeq, const short* defaultNorm, u32 defaultNormLog, u32 defaultMax)
+{
+    switch (type) {
+    case set_rle:
+        fse_build_ctable_rle(ct, (u8)max);
+        if (cap == 0) return KERR;
+        *dst = codeTable[0];
+        return 1;
+    case set_basic:
+        fse_build_ctable(ct, defaultNorm, defaultMax, defaultNormLog);
+        return 0;
+    default: {
+        short norm[64]; size_t nbSeq_1 = nbSeq;
+        u32 const tableLog = fse_optimal_tablelog(FSELog, nbSeq, max, 2);
+        if (count[codeTable[nbSeq - 1]] > 1) { count[codeTable[nbSeq - 1]]--; nbSeq_1--; }
+        if (fse_normalize(norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048) == KERR) return KERR;
+        {
+            size_t const NCountSize = fse_write_ncount(dst, cap, norm, max, tableLog);
+            if (NCountSize == KERR) return KERR;
+            fse_build_ctable(ct, norm, max, tableLog);
+            return NCountSize;
+        }
+    } }
+}
+
+static size_t hist_codes(u32* count, u32* maxp, const u8* codes, size_t n)
+{
+    u32 max = *maxp, s; size_t i, largest = 0;
+    memset(count, 0, (max + 1) * sizeof(u32));
+    for (i = 0; i < n; i++) count[codes[i]]++;
+    while (max > 0 && !count[max]) max--;
+    *maxp = max;
+    for (s = 0; s <= max; s++) if (count[s] > largest) largest = count[s];
+    return largest;
+}
+
+/* returns section size; 0 means "give up, emit raw block"; KERR = error (dst too small) */
+static size_t compress_sequences(u8* dst, size_t cap, const seqstore* ss)
+{
+    size_t const nbSeq = ss->nbSeq;
+    u8* op = dst; u8* const oend = dst + cap;
+    u8 *llCode, *ofCode, *mlCode; size_t i; size_t lastCountSize = 0;
+    static fse_ctable ctLL, ctOF, ctML;   /* oracle is single-threaded per process */
+    u32 count[64];
+
+    if ((size_t)(oend - op) < 3 + 1) return KERR;
+    if (nbSeq < 128) *op++ = (u8)nbSeq;
+    else if (nbSeq < 0x7F00) { op[0] = (u8)((nbSeq >> 8) + 0x80); op[1] = (u8)nbSeq; op += 2; }
+    else { op[0] = 0xFF; wr16(op + 1, (u32)(nbSeq - 0x7F00)); op += 3; }
+    if (nbSeq == 0) return (size_t)(op - dst);
+
+    llCode = (u8*)malloc(3 * nbSeq); ofCode = llCode + nbSeq; mlCode = ofCode + nbSeq;
+    for (i = 0; i < nbSeq; i++) {
+        llCode[i] = (u8)ll_code(ss->seqs[i].litLength);
+        ofCode[i] = (u8)hb32(ss->seqs[i].offBase);
+        mlCode[i] = (u8)ml_code(ss->seqs[i].mlBase);
+    }
+    if (ss->longLengthType == 1) llCode[ss->longLengthPos] = 35;
+    if (ss->longLengthType == 2) mlCode[ss->longLengthPos] = 52;
+    {
+        u8* const seqHead = op++;
+        u32 LLtype, Offtype, MLtype; size_t sz;
+        { u32 max = 35; size_t const mf = hist_codes(count, &max, llCode, nbSeq);
+          LLtype = select_encoding(count, max, mf, nbSeq, 6, 1);
+          sz = build_seq_ctable(op, (size_t)(oend - op), &ctLL, 9, LLtype, count, max, llCode, nbSeq, LL_defaultNorm, 6, 35);
+          if (sz == KERR) { free(llCode); return KERR; }
+          if (LLtype == set_compressed) lastCountSize = sz;
+          op += sz; }
+        { u32 max = 31; size_t const mf = hist_codes(count, &max, ofCode, nbSeq);
+          int const defaultAllowed = (max <= 28);
+          Offtype = select_encoding(count, max, mf, nbSeq, 5, defaultAllowed);
+          sz = build_seq_ctable(op, (size_t)(oend - op), &ctOF, 8, Offtype, count, max, ofCode, nbSeq, OF_defaultNorm, 5, 28);
+          if (sz == KERR) { free(llCode); return KERR; }
+          if (Offtype == set_compressed) lastCountSize = sz;
+          op += sz; }
+        { u32 max = 52; size_t const mf = hist_codes(count, &max, mlCode, nbSeq);
+          MLtype = select_encoding(count, max, mf, nbSeq, 6, 1);
+          sz = build_seq_ctable(op, (size_t)(oend - op), &ctML, 9, MLtype, count, max, mlCode, nbSeq, ML_defaultNorm, 6, 52);
+          if (sz == KERR) { free(llCode); return KERR; }
+          if (MLtype == set_compressed) lastCountSize = sz;
+          op += sz; }
+        *seqHead = (u8)((LLtype << 6) + (Offtype << 4) + (MLtype << 2));
+    }
+    {
+        bitw b; u32 stML, stOF, stLL; size_t n; size_t streamSize;
+        bw_init(&b, op, (size_t)(oend - op));
+        stML = fse_init_state(&ctML, mlCode[nbSeq - 1]);
+        stOF = fse_init_state(&ctOF, ofCode[nbSeq - 1]);
+        stLL = fse_init_state(&ctLL, llCode[nbSeq - 1]);
+        bw_add(&b, ss->seqs[nbSeq - 1].litLength, LL_bits[llCode[nbSeq - 1]]);
+        bw_add(&b, ss->seqs[nbSeq - 1].mlBase, ML_bits[mlCode[nbSeq - 1]]);
+        bw_add(&b, ss->seqs[nbSeq - 1].offBase, ofCode[nbSeq - 1]);
+        for (n = nbSeq - 2; n < nbSeq; n--) {
+            u8 const llc = llCode[n], ofc = ofCode[n], mlc = mlCode[n];
+            fse_encode(&b, &ctOF, &stOF, ofc);
+            fse_encode(&b, &ctML, &stML, mlc);
+            fse_encode(&b, &ctLL, &stLL, llc);
+            bw_add(&b, ss->seqs[n].litLength, LL_bits[llc]);
+            bw_add(&b, ss->seqs[n].mlBase, ML_bits[mlc]);
+            bw_add(&b, ss->seqs[n].offBase, ofc);
+        }
+        bw_add(&b, stML, ctML.tableLog);
+        bw_add(&b, stOF, ctOF.tableLog);
+        bw_add(&b, stLL, ctLL.tableLog);
+        streamSize = bw_close(&b);
+        free(llCode);
+        if (streamSize == 0) return KERR;
+        op += streamSize;
+        if (lastCountSize && (lastCountSize + streamSize) < 4) return 0;
+    }
+    return (size_t)(op - dst);
+}
+
+/* ------------------------------------------------------------------ */
+/* block + frame                                                       */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    u32* hashLong; u32* hashSmall; kref_seq* seqs; u8* lits;
+} kref_wksp;
+
+/* Compressed-block body for one block (<=128 KiB). returns 0 => emit raw block. */
+static size_t compress_block_body(u8* dst, size_t cap, const u8* src, size_t srcSize, const u32* P, kref_wksp* w, seqstore* ssOut)
+{
+    seqstore ss; u32 rep[3] = { 1, 4, 8 };
+    size_t lastLL, litC, seqC, cSize;
+    memset(&ss, 0, sizeof(ss)); ss.seqs = w->seqs; ss.lits = w->lits;
+    if (srcSize < 2 + 3 + 1 + 1) { if (ssOut) *ssOut = ss; return 0; }   /* MIN_CBLOCK_SIZE + blockHeader + 1 + 1 */
+    memset(w->hashLong, 0, sizeof(u32) << P[2]);
+    memset(w->hashSmall, 0, sizeof(u32) << P[1]);
+    lastLL = dfast_block(&ss, rep, src, srcSize, w->hashLong, P[2], w->hashSmall, P[1], P[3]);
+    memcpy(ss.lits + ss.litSize, src + srcSize - lastLL, lastLL); ss.litSize += lastLL;
+    if (ssOut) *ssOut = ss;
+    {
+        int const suspect = (ss.nbSeq == 0) || (ss.litSize / ss.nbSeq >= 20);
+        litC = compress_literals(dst, cap, ss.lits, ss.litSize, suspect);
+        if (litC == KERR) return (srcSize <= cap) ? 0 : KERR;
+    }
+    seqC = compress_sequences(dst + litC, cap - litC, &ss);
+    if (seqC == KERR) return (srcSize <= cap) ? 0 : KERR;
+    if (seqC == 0) return 0;
+    cSize = litC + seqC;
+    { size_t const maxCSize = srcSize - min_gain(srcSize); if (cSize >= maxCSize) return 0; }
+    return cSize;
+}
+
+KREF_API size_t kref_compress_bound(size_t srcSize)
+{
+    return srcSize + (srcSize >> 8) + ((srcSize < (128 << 10)) ? (((128 << 10) - srcSize) >> 11) : 0);
+}
+
+static size_t write_frame_header(u8* dst, size_t srcSize, u32 windowLog)
+{
+    size_t pos = 0;
+    u32 const windowSize = 1u << windowLog;
+    u32 const singleSegment = (windowSize >= srcSize);
+    u32 const fcsCode = (srcSize >= 256) + (srcSize >= 65536 + 256);
+    wr32(dst, 0xFD2FB528u); pos = 4;
+    dst[pos++] = (u8)((singleSegment << 5) + (fcsCode << 6));
+    if (!singleSegment) dst[pos++] = (u8)((windowLog - 10) << 3);
+    switch (fcsCode) {
+    case 0: if (singleSegment) dst[pos++] = (u8)srcSize; break;
+    case 1: wr16(dst + pos, (u32)(srcSize - 256)); pos += 2; break;
+    default: wr32(dst + pos, (u32)srcSize); pos += 4; break;
+    }
+    return pos;
+}
+
+/* One-shot level-3 frame. Returns frame size, or (size_t)-1 if dst is too small
+ * or srcSize is outside this restatement's scope (> 128 KiB). */
+KREF_API size_t kref_zstd_l3_compress(u8* dst, size_t cap, const u8* src, size_t srcSize)
+{
+    u32 P[4]; kref_wksp w; size_t pos, cSize; u8* body;
+    if (srcSize > 131072) return KERR;
+    if (cap < kref_compress_bound(srcSize)) return KERR;
+    kref_params_l3(srcSize, P);
+    pos = write_frame_header(dst, srcSize, P[0]);
+    if (srcSize == 0) { wr24(dst + pos, 1); return pos + 3; }
+    w.hashLong = (u32*)malloc(sizeof(u32) << P[2]);
+    w.hashSmall = (u32*)malloc(sizeof(u32) << P[1]);
+    w.seqs = (kref_seq*)malloc(sizeof(kref_seq) * (srcSize / 3 + 8));
+    w.lits = (u8*)malloc(srcSize + 32);
+    body = dst + pos + 3;
+    cSize = compress_block_body(body, cap - pos - 3, src, srcSize, P, &w, NULL);
+    free(w.hashLong); free(w.hashSmall); free(w.seqs); free(w.lits);
+    if (cSize == KERR) return KERR;
+    if (cSize == 0) {
+        wr24(dst + pos, 1 + (0 << 1) + (u32)(srcSize << 3));
+        memcpy(body, src, srcSize);
+        return pos + 3 + srcSize;
+    }
+    wr24(dst + pos, 1 + (2 << 1) + (u32)(cSize << 3));
+    return pos + 3 + cSize;
+}
+
+/* Stage taps for kernel-by-kernel diffing: the seqStore of the single block.
+ * seqsOut: nbSeq x (offBase u32, litLength u16, mlBase u16); litsOut: literal bytes. */
+KREF_API size_t kref_zstd_l3_seqstore(const u8* src, size_t srcSize, void* seqsOut, size_t* nbSeqOut,
+                                      u8* litsOut, size_t* litSizeOut, int* longType, size_t* longPos)
+{
+    u32 P[4]; kref_wksp w; seqstore ss; u8* tmp; size_t cap = kref_compress_bound(srcSize) + 64; size_t r;
+    if (srcSize > 131072) return KERR;
+    kref_params_l3(srcSize, P);
+    w.hashLong = (u32*)malloc(sizeof(u32) << P[2]);
+    w.hashSmall = (u32*)malloc(sizeof(u32) << P[1]);
+    w.seqs = (kref_seq*)malloc(sizeof(kref_seq) * (srcSize / 3 + 8));
+    w.lits = (u8*)malloc(srcSize + 32);
+    tmp = (u8*)malloc(cap);
+    r = compress_block_body(tmp, cap, src, srcSize, P, &w, &ss);
+    memcpy(seqsOut, ss.seqs, ss.nbSeq * sizeof(kref_seq)); *nbSeqOut = ss.nbSeq;
+    memcpy(litsOut, ss.lits, ss.litSize); *litSizeOut = ss.litSize;
+    *longType = ss.longLengthType; *longPos = ss.longLengthPos;
+    free(w.hashLong); free(w.hashSmall); free(w.seqs); free(w.lits); free(tmp);
+    return r;
+}
