@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its configs[1] workload:
+zstd level-3 compression of a batch of 65 536 x 64 KiB slices (seeded synthetic
+"Silesia-like" mix, kompressor_amd/csrc/corpus.c) per GPU, inputs resident in
+HBM when the timed region starts.  One step = one pass of the whole hot path
+(match kernel + entropy/frame kernel) over the batch.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--slices M]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns its
+own block of slices (weak scaling, no collective on the data path; the frame
+size table is all-gathered over RCCL inside the timed region).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SLICE = 65536
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(host, n_slices, frames_expected):
+    """Times the reference's arithmetic on the host cores: a binary libzstd 1.5.7
+    if this machine has one (kind "reference"), else the oracle's C restatement
+    (kind "port").  Bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cores = min(os.cpu_count() or 1, 64)
+    sample = min(n_slices, 8192)
+    kind, label, workers = None, None, []
+    try:
+        from libzstd_ref import find_libzstd_157
+        lib = find_libzstd_157()
+    except Exception:
+        lib = None
+    if lib is not None:
+        kind = "reference"
+        label = f"libzstd 1.5.7 ({os.path.basename(lib._path)}) ZSTD_compress2 level 3"
+        lib.ZSTD_createCCtx.restype = ctypes.c_void_p
+        lib.ZSTD_CCtx_setParameter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        lib.ZSTD_compress2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        lib.ZSTD_compress2.restype = ctypes.c_size_t
+
+        def make_worker():
+            cctx = lib.ZSTD_createCCtx()
+            lib.ZSTD_CCtx_setParameter(cctx, 100, 3)
+            out = ctypes.create_string_buffer(66000)
+            return lambda ptr: lib.ZSTD_compress2(cctx, out, 66000, ptr, SLICE)
+    else:
+        import helpers
+        k = helpers.oracle().lib
+        kind = "port"
+        label = "oracle/zstd_l3_ref.c (C restatement)"
+
+        def make_worker():
+            out = ctypes.create_string_buffer(66000)
+            return lambda ptr: k.kref_zstd_l3_compress(out, 66000, ctypes.c_char_p(ptr), SLICE)
+    base = host.ctypes.data
+    per = (sample + cores - 1) // cores
+    totals = [0] * cores
+
+    def run(t):
+        w = make_worker()
+        s = 0
+        for i in range(t * per, min(sample, (t + 1) * per)):
+            s += w(base + i * SLICE)
+        totals[t] = s
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(run, range(cores)))
+    dt = time.perf_counter() - t0
+    ok = (frames_expected is None) or (sum(totals) == frames_expected)
+    return {"value": round(sample * SLICE / dt / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": kind,
+            "sample": f"first {sample} slices of the same batch, {label}, {cores} threads, one context per thread, "
+                      f"{dt:.2f} s wall; total frame bytes {'match' if ok else 'DIFFER from'} the GPU's"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--slices", type=int, default=65536, help="slices per GPU (BASELINE configs[1]: 65536)")
+    ap.add_argument("--team", type=int, default=0, help="lanes per slice in the match kernel (0 = library default)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from kompressor_amd import corpus, sharding
+    from kompressor_amd.batch import ZstdBatch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    n = args.slices
+    first = rank * n                                   # this rank's block of the global slice index space
+    host = np.empty(n * SLICE, dtype=np.uint8)
+    corpus.fill(host, first, n, SLICE, corpus.MIX_CONFIG1)
+    src = torch.empty(n * SLICE, dtype=torch.uint8, device=dev)
+    step_copy = 1 << 30
+    for o in range(0, n * SLICE, step_copy):
+        src[o:o + step_copy] = torch.from_numpy(host[o:o + step_copy]).to(dev)
+    in_off = torch.arange(n, dtype=torch.int64, device=dev) * SLICE
+    in_len = torch.full((n,), SLICE, dtype=torch.int32, device=dev)
+    b = ZstdBatch(max_slices=n, max_slice_bytes=SLICE, device=local_rank, team_lanes=args.team)
+    dst = torch.empty(n * b.out_stride + 64, dtype=torch.uint8, device=dev)
+    out_off = torch.arange(n, dtype=torch.int64, device=dev) * b.out_stride
+    out_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    b.set_profiling(True)
+
+    def step():
+        b.compress(src, in_off, in_len, dst, out_off, out_len)
+        if dist is not None:
+            return sharding.gather_frame_sizes(out_len, n * world)
+        return out_len
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    k_match, k_entropy = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP-event durations of the two kernels of this step (events sit on the launch stream)
+        k_match.append(b.last_kernel_ms(0))
+        k_entropy.append(b.last_kernel_ms(1))
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    lens = out_len.cpu().numpy().astype(np.int64)
+    frame_bytes = int(lens.sum())
+    in_bytes = n * SLICE
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = world * in_bytes / (dt / args.steps) / 1e9
+        ms_match = float(np.mean(k_match))
+        ms_entropy = float(np.mean(k_entropy))
+        algo_bytes = in_bytes + frame_bytes + 16 * n      # len_in + len_frame + 16 B metadata per slice
+        achieved = algo_bytes / (ms_match * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("zstd_match_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "zstd level-3 compression throughput, 64 KiB-slice batch (uncompressed input bytes per second)",
+            "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {n} x 64 KiB seeded mixed slices per GPU (T/X/S/B/D/I/Z/R classes), "
+                                   "ZstdCompressor(level=3) one-shot frames, bit-identical to libzstd 1.5.7",
+                       "slices_per_gpu": n, "slice_bytes": SLICE, "ratio": round(in_bytes / frame_bytes, 4),
+                       "team_lanes": b.lib and (args.team or int(os.environ.get("KMP_TEAM_LANES", "8"))), "parallelism": f"slice-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_zstd_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms_match, 3)},
+            "kernels_ms": {"k_zstd_match": round(ms_match, 3), "k_zstd_entropy": round(ms_entropy, 3)},
+        }
+        if not args.no_cpu:
+            sample = min(n, 8192)
+            res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()))
+        print(json.dumps(res), flush=True)
+    b.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

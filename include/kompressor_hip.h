@@ -1,0 +1,149 @@
+/*
+ * kompressor_hip.h -- C ABI of libkompressor_hip.so, the MI355X (gfx950) backend
+ * that plugs in underneath Kompressor's SliceTransform / ZstdCompressor /
+ * ZstdDecompressor API.
+ *
+ * Part 1 mirrors, one to one, what the reference's JNI layer
+ * (kompressor-zstd--nativelib/src/jvmCommonMain/jni/Wrapper.cpp) calls in
+ * libzstd, with the same return-code convention (size_t, errors are
+ * (size_t)-code with libzstd 1.5.7's code numbering), so that Wrapper.cpp can
+ * be re-pointed at this library without touching the Kotlin side
+ * (INTEGRATION.md shows the binding).
+ *
+ * Part 2 is the batched device-pointer API (no reference equivalent: the
+ * reference compresses one slice per JNI call); it is what part 1 runs with
+ * n = 1 and what bench.py measures.
+ *
+ * Plain pointers and sizes only.  Thread rules follow the reference
+ * (SURVEY.md section 8b): a context is used by one thread at a time; different
+ * contexts may be used concurrently; free may come from any thread.
+ */
+#ifndef KOMPRESSOR_HIP_H
+#define KOMPRESSOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMP_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------ */
+/* Part 1: streaming-compatible single-slice API                             */
+/* ------------------------------------------------------------------------ */
+typedef struct kmp_zstd_cctx kmp_zstd_cctx;
+typedef struct kmp_zstd_dctx kmp_zstd_dctx;
+
+/* end_op values == ZSTD_EndDirective (Wrapper.cpp:112 passes e_end / e_continue) */
+#define KMP_ZSTD_e_continue 0
+#define KMP_ZSTD_e_flush    1
+#define KMP_ZSTD_e_end      2
+
+/* parameter ids == ZSTD_cParameter (kompressor-zstd--nativelib/src/commonMain/kotlin/
+ * com/ensody/kompressor/zstd/ZstdParameter.kt:3-24; only 100 is ever set,
+ * ZstdCompressor.jvm.kt:21) */
+#define KMP_ZSTD_c_compressionLevel 100
+
+/* replaces ZSTD_createCCtx            (Wrapper.cpp:10-17)  */
+KMP_API kmp_zstd_cctx* kmp_zstd_create_cctx(void);
+/* replaces ZSTD_freeCCtx              (Wrapper.cpp:19-27)  */
+KMP_API size_t kmp_zstd_free_cctx(kmp_zstd_cctx* cctx);
+/* replaces ZSTD_CCtx_setParameter     (Wrapper.cpp:29-39). Level 3 (and 0 = default = 3)
+ * run on the GPU; other levels return (size_t)-40 "Unsupported parameter". */
+KMP_API size_t kmp_zstd_cctx_set_parameter(kmp_zstd_cctx* cctx, int param, int value);
+/* replaces ZSTD_CCtx_loadDictionary   (Wrapper.cpp:41-56). Dictionaries are out of
+ * scope this round: a non-empty dictionary returns (size_t)-40. */
+KMP_API size_t kmp_zstd_cctx_load_dictionary(kmp_zstd_cctx* cctx, const void* dict, size_t dict_size);
+/* replaces ZSTD_compressStream2       (Wrapper.cpp:75-121, call at :112).
+ * Same buffer semantics as ZSTD_inBuffer / ZSTD_outBuffer: `*_size` is the
+ * end-exclusive index, `*_pos` the cursor, both into the whole array
+ * (Wrapper.cpp:101-110).  Returns 0 when the frame is completely flushed,
+ * >0 = bytes still to flush, or an error code. */
+KMP_API size_t kmp_zstd_compress_stream(kmp_zstd_cctx* cctx,
+                                        void* dst, size_t dst_size, size_t* dst_pos,
+                                        const void* src, size_t src_size, size_t* src_pos,
+                                        int end_op);
+
+/* replaces ZSTD_createDCtx            (Wrapper.cpp:123-130) */
+KMP_API kmp_zstd_dctx* kmp_zstd_create_dctx(void);
+/* replaces ZSTD_freeDCtx              (Wrapper.cpp:132-140) */
+KMP_API size_t kmp_zstd_free_dctx(kmp_zstd_dctx* dctx);
+/* replaces ZSTD_DCtx_loadDictionary   (Wrapper.cpp:58-73) */
+KMP_API size_t kmp_zstd_dctx_load_dictionary(kmp_zstd_dctx* dctx, const void* dict, size_t dict_size);
+/* replaces ZSTD_decompressStream      (Wrapper.cpp:142-187, call at :178).
+ * Returns 0 when a frame is completely decoded and flushed, otherwise a
+ * hint (>0) or an error code. */
+KMP_API size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* dctx,
+                                          void* dst, size_t dst_size, size_t* dst_pos,
+                                          const void* src, size_t src_size, size_t* src_pos);
+
+/* replace ZSTD_isError / ZSTD_getErrorName (Wrapper.cpp:189-196) */
+KMP_API unsigned kmp_zstd_is_error(size_t code);
+KMP_API const char* kmp_zstd_get_error_name(size_t code);
+
+/* ZSTD_compressBound */
+KMP_API size_t kmp_zstd_compress_bound(size_t src_size);
+
+/* ------------------------------------------------------------------------ */
+/* Part 2: batched device API                                                */
+/* ------------------------------------------------------------------------ */
+typedef struct kmp_batch_ctx kmp_batch_ctx;
+
+#define KMP_OK             0
+#define KMP_ERR_HIP       (-1)   /* a HIP call failed: kmp_last_error() has the text */
+#define KMP_ERR_ARG       (-2)
+#define KMP_ERR_CAPACITY  (-3)   /* n or slice size beyond what the context was created for */
+#define KMP_ERR_KERNEL    (-4)   /* a kernel guard tripped (never expected) */
+
+#define KMP_MAX_SLICE_BYTES (128u * 1024u)   /* single-block frames; larger slices: SURVEY.md 8f rank 1 */
+
+/* Workspace for up to max_slices slices of up to max_slice_bytes each on HIP
+ * device `device`.  team_lanes: lanes of a wave that cooperate on one slice in
+ * the match kernel (8, 16, 32 or 64; 0 = default). */
+KMP_API int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_slices,
+                             uint32_t max_slice_bytes, int team_lanes);
+KMP_API void kmp_batch_destroy(kmp_batch_ctx* ctx);
+
+/* zstd level-3 frames for n independent slices.  All pointers are device
+ * pointers; slice i is d_src[d_in_off[i] .. +d_in_len[i]); its frame goes to
+ * d_dst + d_out_off[i] (room for kmp_zstd_compress_bound(len) + 8 bytes) and its
+ * size to d_out_len[i].  Asynchronous on `hip_stream` (a hipStream_t, may be 0). */
+KMP_API int kmp_zstd_compress_batch(kmp_batch_ctx* ctx,
+                                    const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                    uint32_t n,
+                                    void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
+                                    void* hip_stream);
+
+/* Inverse: n zstd frames -> n slices.  Frame i is d_src[d_in_off[i] .. +d_in_len[i]);
+ * its content goes to d_dst + d_out_off[i] (capacity d_out_cap[i]); d_out_len[i]
+ * receives the decoded size and d_status[i] 0 or a libzstd error code (20 =
+ * corruption, 70 = destination too small, 14 = unsupported frame parameter ...). */
+KMP_API int kmp_zstd_decompress_batch(kmp_batch_ctx* ctx,
+                                      const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                      uint32_t n,
+                                      void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                                      uint32_t* d_out_len, uint32_t* d_status,
+                                      void* hip_stream);
+
+/* Dense packing helper: copies frame i from d_src + d_in_off[i] (d_len[i] bytes) to
+ * d_dst + d_out_off[i], where d_out_off is the exclusive prefix sum of d_len that
+ * this call also computes (d_out_off has n+1 entries; the last is the total). */
+KMP_API int kmp_compact_batch(kmp_batch_ctx* ctx, const void* d_src, const uint64_t* d_in_off,
+                              const uint32_t* d_len, uint32_t n, void* d_dst, uint64_t* d_out_off,
+                              void* hip_stream);
+
+/* Per-kernel device time of the last batch call, measured with HIP events on the
+ * launch stream (0 = off, 1 = on).  kmp_batch_last_kernel_ms synchronises. */
+KMP_API int kmp_batch_set_profiling(kmp_batch_ctx* ctx, int on);
+/* which: 0 = zstd_match, 1 = zstd_entropy, 2 = zstd_decode */
+KMP_API int kmp_batch_last_kernel_ms(kmp_batch_ctx* ctx, int which, float* ms);
+
+KMP_API const char* kmp_last_error(void);
+KMP_API const char* kmp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

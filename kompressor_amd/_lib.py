@@ -1,0 +1,62 @@
+"""ctypes binding of libkompressor_hip.so (include/kompressor_hip.h).
+
+There is no fallback: if the HIP library is missing or does not export what
+the header declares, importing the codecs fails loudly."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkompressor_hip.so")
+
+# every symbol include/kompressor_hip.h declares: (name, restype, argtypes)
+_c = ctypes
+_P = _c.c_void_p
+SIGNATURES = [
+    ("kmp_zstd_create_cctx", _P, []),
+    ("kmp_zstd_free_cctx", _c.c_size_t, [_P]),
+    ("kmp_zstd_cctx_set_parameter", _c.c_size_t, [_P, _c.c_int, _c.c_int]),
+    ("kmp_zstd_cctx_load_dictionary", _c.c_size_t, [_P, _P, _c.c_size_t]),
+    ("kmp_zstd_compress_stream", _c.c_size_t,
+     [_P, _P, _c.c_size_t, _c.POINTER(_c.c_size_t), _P, _c.c_size_t, _c.POINTER(_c.c_size_t), _c.c_int]),
+    ("kmp_zstd_create_dctx", _P, []),
+    ("kmp_zstd_free_dctx", _c.c_size_t, [_P]),
+    ("kmp_zstd_dctx_load_dictionary", _c.c_size_t, [_P, _P, _c.c_size_t]),
+    ("kmp_zstd_decompress_stream", _c.c_size_t,
+     [_P, _P, _c.c_size_t, _c.POINTER(_c.c_size_t), _P, _c.c_size_t, _c.POINTER(_c.c_size_t)]),
+    ("kmp_zstd_is_error", _c.c_uint, [_c.c_size_t]),
+    ("kmp_zstd_get_error_name", _c.c_char_p, [_c.c_size_t]),
+    ("kmp_zstd_compress_bound", _c.c_size_t, [_c.c_size_t]),
+    ("kmp_batch_create", _c.c_int, [_c.POINTER(_P), _c.c_int, _c.c_uint32, _c.c_uint32, _c.c_int]),
+    ("kmp_batch_destroy", None, [_P]),
+    ("kmp_zstd_compress_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P]),
+    ("kmp_zstd_decompress_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P, _P, _P]),
+    ("kmp_compact_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P]),
+    ("kmp_batch_set_profiling", _c.c_int, [_P, _c.c_int]),
+    ("kmp_batch_last_kernel_ms", _c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_float)]),
+    ("kmp_last_error", _c.c_char_p, []),
+    ("kmp_version", _c.c_char_p, []),
+]
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the HIP backend. Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m kompressor_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, res, args in SIGNATURES:
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().kmp_last_error().decode()

@@ -1,0 +1,103 @@
+"""Batched device API over torch CUDA(ROCm) tensors.  torch is plumbing here:
+device memory and streams.  All compute happens in libkompressor_hip.so."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def compress_bound(n: int) -> int:
+    return _lib.load().kmp_zstd_compress_bound(n)
+
+
+class ZstdBatch:
+    """Owns the device workspace for batches of up to `max_slices` slices of up to
+    `max_slice_bytes` bytes (<= 128 KiB) on one GPU."""
+
+    def __init__(self, max_slices, max_slice_bytes=65536, device=None, team_lanes=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("kompressor_amd needs a ROCm GPU (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.max_slices = max_slices
+        self.max_slice_bytes = max_slice_bytes
+        h = ctypes.c_void_p()
+        rc = self.lib.kmp_batch_create(ctypes.byref(h), self.device.index, max_slices, max_slice_bytes, team_lanes)
+        if rc != 0:
+            raise RuntimeError(f"kmp_batch_create failed ({rc}): {_lib.last_error()}")
+        self._h = h
+        self.out_stride = (compress_bound(max_slice_bytes) + 8 + 63) & ~63
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.kmp_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_profiling(self, on=True):
+        self.lib.kmp_batch_set_profiling(self._h, 1 if on else 0)
+
+    def last_kernel_ms(self, which):
+        ms = ctypes.c_float()
+        rc = self.lib.kmp_batch_last_kernel_ms(self._h, which, ctypes.byref(ms))
+        if rc != 0:
+            raise RuntimeError(_lib.last_error())
+        return ms.value
+
+    def compress(self, src, in_off, in_len, dst=None, out_off=None, out_len=None):
+        """src: uint8 device tensor; in_off int64, in_len int32 device tensors (n each).
+        Returns (dst, out_off, out_len): frame i = dst[out_off[i] : out_off[i] + out_len[i]]."""
+        n = in_len.numel()
+        if dst is None:
+            dst = torch.empty(n * self.out_stride + 64, dtype=torch.uint8, device=self.device)
+        if out_off is None:
+            out_off = torch.arange(n, dtype=torch.int64, device=self.device) * self.out_stride
+        if out_len is None:
+            out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
+        rc = self.lib.kmp_zstd_compress_batch(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
+                                              _ptr(dst), _ptr(out_off), _ptr(out_len), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"kmp_zstd_compress_batch failed ({rc}): {_lib.last_error()}")
+        return dst, out_off, out_len
+
+    def decompress(self, src, in_off, in_len, out_cap, dst=None, out_off=None):
+        """Frames -> slices.  out_cap: int32 device tensor of per-frame capacities.
+        Returns (dst, out_off, out_len, status)."""
+        n = in_len.numel()
+        if out_off is None:
+            out_off = torch.cumsum(out_cap.to(torch.int64), 0) - out_cap.to(torch.int64)
+        if dst is None:
+            total = int(out_cap.to(torch.int64).sum().item())
+            dst = torch.empty(total + 64, dtype=torch.uint8, device=self.device)
+        out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
+        status = torch.zeros(n, dtype=torch.int32, device=self.device)
+        rc = self.lib.kmp_zstd_decompress_batch(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
+                                                _ptr(dst), _ptr(out_off), _ptr(out_cap), _ptr(out_len), _ptr(status),
+                                                self._stream())
+        if rc != 0:
+            raise RuntimeError(f"kmp_zstd_decompress_batch failed ({rc}): {_lib.last_error()}")
+        return dst, out_off, out_len, status
+
+    def compact(self, src, in_off, lens):
+        """Dense packing of n frames; returns (dst, offsets[n+1])."""
+        n = lens.numel()
+        offs = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        total_cap = int(lens.to(torch.int64).sum().item())
+        dst = torch.empty(total_cap + 64, dtype=torch.uint8, device=self.device)
+        rc = self.lib.kmp_compact_batch(self._h, _ptr(src), _ptr(in_off), _ptr(lens), n, _ptr(dst), _ptr(offs), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"kmp_compact_batch failed ({rc}): {_lib.last_error()}")
+        return dst, offs

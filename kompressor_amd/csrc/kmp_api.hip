@@ -1,0 +1,462 @@
+// kmp_api.hip -- host side of libkompressor_hip.so: kernel entry points for
+// gfx950, workspace management, the batched API and the streaming-compatible
+// single-slice API declared in include/kompressor_hip.h.
+#include "kx_wave.h"
+#include "zstd_match.h"
+#include "zstd_entropy.h"
+#include "zstd_decode.h"
+#include "../../include/kompressor_hip.h"
+
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+// --------------------------------------------------------------------------
+// kernels (one 64-lane wave per workgroup everywhere)
+// --------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(64) void k_zstd_match(KMatchArgs a) { zstd_match_body<G>(a); }
+__global__ __launch_bounds__(64) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
+__global__ __launch_bounds__(64) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
+
+// exclusive prefix sum of u32 lengths into u64 offsets, single workgroup
+__global__ __launch_bounds__(1024) void k_scan_lengths(const u32* len, u32 n, u64* off)
+{
+    __shared__ u64 part[1024];
+    u32 const t = threadIdx.x;
+    u32 const per = (n + 1023) / 1024;
+    u32 const b = t * per, e = (b + per < n) ? b + per : n;
+    u64 s = 0;
+    for (u32 i = b; i < e; i++) s += len[i];
+    part[t] = s;
+    __syncthreads();
+    for (u32 o = 1; o < 1024; o <<= 1) {
+        u64 v = (t >= o) ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    u64 run = (t == 0) ? 0 : part[t - 1];
+    for (u32 i = b; i < e; i++) { off[i] = run; run += len[i]; }
+    if (t == 1023) off[n] = part[1023];
+}
+// one wave per frame, 16 B per lane per step when both sides allow it
+__global__ __launch_bounds__(64) void k_compact(const u8* src, const u64* in_off, const u32* len, u32 n, u8* dst, const u64* out_off)
+{
+    int const lane = threadIdx.x;
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        const u8* s = src + in_off[i]; u8* d = dst + out_off[i]; u32 const L = len[i];
+        u32 k = (u32)lane * 8u;
+        for (; k + 8 <= L; k += 512u) kx_st64(d + k, kx_ld64(s + k));
+        u32 const tail = L & ~7u;
+        if (lane < (int)(L - tail)) d[tail + lane] = s[tail + lane];
+    }
+}
+
+// --------------------------------------------------------------------------
+// errors
+// --------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+static int hip_fail(hipError_t e, const char* what)
+{
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return KMP_ERR_HIP;
+}
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
+
+extern "C" const char* kmp_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* kmp_version(void) { return "kompressor_hip 0.1 (gfx950; zstd level 3 single-block frames)"; }
+
+// --------------------------------------------------------------------------
+// batch context
+// --------------------------------------------------------------------------
+struct kmp_batch_ctx {
+    int device; u32 max_slices, max_slice_bytes; int G; u32 match_blocks, nteams;
+    u32 seq_cap, lit_cap, scratch_words;
+    KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* team_epoch; u32* counter;
+    int profiling; hipEvent_t ev[6]; int ev_valid[3];
+};
+
+static u32 env_u32(const char* name, u32 dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? (u32)strtoul(v, nullptr, 10) : dflt;
+}
+
+extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes)
+{
+    if (!out || max_slices == 0) { g_last_error = "kmp_batch_create: bad argument"; return KMP_ERR_ARG; }
+    if (max_slice_bytes > KMP_MAX_SLICE_BYTES) { g_last_error = "kmp_batch_create: slices above 128 KiB are not supported"; return KMP_ERR_CAPACITY; }
+    if (team_lanes == 0) team_lanes = (int)env_u32("KMP_TEAM_LANES", 8);
+    if (team_lanes != 8 && team_lanes != 16 && team_lanes != 32 && team_lanes != 64) { g_last_error = "team_lanes must be 8, 16, 32 or 64"; return KMP_ERR_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    kmp_batch_ctx* c = new (std::nothrow) kmp_batch_ctx();
+    if (!c) { g_last_error = "out of host memory"; return KMP_ERR_ARG; }
+    memset(c, 0, sizeof(*c));
+    c->device = device; c->max_slices = max_slices; c->max_slice_bytes = max_slice_bytes < 64 ? 64 : max_slice_bytes; c->G = team_lanes;
+    hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
+    u32 const waves_per_cu = env_u32("KMP_MATCH_WAVES_PER_CU", 16);
+    u32 const teams_per_wave = 64 / (u32)team_lanes;
+    u32 blocks = (u32)prop.multiProcessorCount * waves_per_cu;
+    u32 const need = (max_slices + teams_per_wave - 1) / teams_per_wave;
+    if (blocks > need) blocks = need;
+    c->match_blocks = blocks; c->nteams = blocks * teams_per_wave;
+    c->seq_cap = c->max_slice_bytes / 4 + 8; c->lit_cap = c->max_slice_bytes + 64; c->scratch_words = c->max_slice_bytes / 4 + 64;
+    size_t const ns = max_slices;
+    HIP_TRY(hipMalloc((void**)&c->seqs, ns * c->seq_cap * sizeof(KSeq)));
+    HIP_TRY(hipMalloc((void**)&c->lits, ns * c->lit_cap));
+    HIP_TRY(hipMalloc((void**)&c->meta, ns * sizeof(KSliceMeta)));
+    HIP_TRY(hipMalloc((void**)&c->scratch, ns * c->scratch_words * sizeof(u32)));
+    HIP_TRY(hipMalloc((void**)&c->tables, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
+    HIP_TRY(hipMalloc((void**)&c->team_epoch, (size_t)c->nteams * sizeof(u32)));
+    HIP_TRY(hipMalloc((void**)&c->counter, 64));
+    HIP_TRY(hipMemset(c->tables, 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
+    HIP_TRY(hipMemset(c->team_epoch, 0, (size_t)c->nteams * sizeof(u32)));
+    HIP_TRY(hipMemset(c->meta, 0, ns * sizeof(KSliceMeta)));
+    for (int i = 0; i < 6; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+    HIP_TRY(hipDeviceSynchronize());
+    *out = c;
+    return KMP_OK;
+}
+
+extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch);
+    (void)hipFree(c->tables); (void)hipFree(c->team_epoch); (void)hipFree(c->counter);
+    for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+}
+
+extern "C" int kmp_batch_set_profiling(kmp_batch_ctx* c, int on) { if (!c) return KMP_ERR_ARG; c->profiling = on; return KMP_OK; }
+extern "C" int kmp_batch_last_kernel_ms(kmp_batch_ctx* c, int which, float* ms)
+{
+    if (!c || which < 0 || which > 2 || !ms || !c->ev_valid[which]) { g_last_error = "no timing recorded"; return KMP_ERR_ARG; }
+    HIP_TRY(hipEventSynchronize(c->ev[2 * which + 1]));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev[2 * which], c->ev[2 * which + 1]));
+    return KMP_OK;
+}
+
+extern "C" size_t kmp_zstd_compress_bound(size_t n)
+{
+    return n + (n >> 8) + ((n < (128u << 10)) ? (((128u << 10) - n) >> 11) : 0);
+}
+
+extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
+{
+    if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch: null argument"; return KMP_ERR_ARG; }
+    if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
+    if (n == 0) return KMP_OK;
+    hipStream_t const st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->counter, 0, 4, st));
+    KMatchArgs m;
+    m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
+    m.seqs = c->seqs; m.seq_cap = c->seq_cap; m.lits = c->lits; m.lit_cap = c->lit_cap; m.meta = c->meta;
+    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter;
+    u32 const tpw = 64 / (u32)c->G;
+    u32 blocks = (n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], st));
+    switch (c->G) {
+    case 8:  hipLaunchKernelGGL(k_zstd_match<8>, dim3(blocks), dim3(64), 0, st, m); break;
+    case 16: hipLaunchKernelGGL(k_zstd_match<16>, dim3(blocks), dim3(64), 0, st, m); break;
+    case 32: hipLaunchKernelGGL(k_zstd_match<32>, dim3(blocks), dim3(64), 0, st, m); break;
+    default: hipLaunchKernelGGL(k_zstd_match<64>, dim3(blocks), dim3(64), 0, st, m); break;
+    }
+    HIP_TRY(hipGetLastError());
+    if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[1], st)); c->ev_valid[0] = 1; }
+    KEntropyArgs e;
+    e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = d_in_len; e.n_slices = n;
+    e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
+    e.scratch = c->scratch; e.scratch_words = c->scratch_words;
+    e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[2], st));
+    hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), 0, st, e);
+    HIP_TRY(hipGetLastError());
+    if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[3], st)); c->ev_valid[1] = 1; }
+    return KMP_OK;
+}
+
+extern "C" int kmp_zstd_decompress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                         uint32_t n, void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                                         uint32_t* d_out_len, uint32_t* d_status, void* hip_stream)
+{
+    if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_cap || !d_out_len || !d_status))) { g_last_error = "kmp_zstd_decompress_batch: null argument"; return KMP_ERR_ARG; }
+    if (n > c->max_slices) { g_last_error = "kmp_zstd_decompress_batch: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
+    if (n == 0) return KMP_OK;
+    hipStream_t const st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(c->device));
+    KDecodeArgs d;
+    d.src = (const u8*)d_src; d.in_off = d_in_off; d.in_len = d_in_len; d.n_slices = n;
+    d.dst = (u8*)d_dst; d.out_off = d_out_off; d.out_cap = d_out_cap; d.out_len = d_out_len; d.status = d_status;
+    d.lits = c->lits; d.lit_cap = c->lit_cap;
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[4], st));
+    hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), 0, st, d);
+    HIP_TRY(hipGetLastError());
+    if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[5], st)); c->ev_valid[2] = 1; }
+    return KMP_OK;
+}
+
+extern "C" int kmp_compact_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_len, uint32_t n,
+                                 void* d_dst, uint64_t* d_out_off, void* hip_stream)
+{
+    if (!c || !d_src || !d_in_off || !d_len || !d_dst || !d_out_off) { g_last_error = "kmp_compact_batch: null argument"; return KMP_ERR_ARG; }
+    hipStream_t const st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_scan_lengths, dim3(1), dim3(1024), 0, st, d_len, n, d_out_off);
+    HIP_TRY(hipGetLastError());
+    if (n) {
+        u32 const blocks = n < 65536u ? n : 65536u;
+        hipLaunchKernelGGL(k_compact, dim3(blocks), dim3(64), 0, st, (const u8*)d_src, d_in_off, d_len, n, (u8*)d_dst, (const u64*)d_out_off);
+        HIP_TRY(hipGetLastError());
+    }
+    return KMP_OK;
+}
+
+// --------------------------------------------------------------------------
+// streaming-compatible single-slice API (mirrors libzstd's calling convention)
+// --------------------------------------------------------------------------
+#define KERRC(code) ((size_t)0 - (size_t)(code))
+enum { ZE_GENERIC = 1, ZE_prefix_unknown = 10, ZE_frameParameter_unsupported = 14, ZE_corruption_detected = 20,
+       ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 42, ZE_stage_wrong = 60, ZE_memory_allocation = 64,
+       ZE_dstSize_tooSmall = 70, ZE_srcSize_wrong = 72, ZE_maxCode = 120 };
+
+extern "C" unsigned kmp_zstd_is_error(size_t code) { return code > KERRC(ZE_maxCode); }
+extern "C" const char* kmp_zstd_get_error_name(size_t code)
+{
+    if (!kmp_zstd_is_error(code)) return "No error detected";
+    switch ((int)(0 - code)) {
+    case 1: return "Error (generic)";
+    case 10: return "Unknown frame descriptor";
+    case 12: return "Version not supported";
+    case 14: return "Unsupported frame parameter";
+    case 16: return "Frame requires too much memory for decoding";
+    case 20: return "Data corruption detected";
+    case 22: return "Restored data doesn't match checksum";
+    case 24: return "Header of Literals' block doesn't respect format specification";
+    case 30: return "Dictionary is corrupted";
+    case 32: return "Dictionary mismatch";
+    case 34: return "Cannot create Dictionary from provided samples";
+    case 40: return "Unsupported parameter";
+    case 41: return "Unsupported combination of parameters";
+    case 42: return "Parameter is out of bound";
+    case 44: return "tableLog requires too much memory : unsupported";
+    case 46: return "Unsupported max Symbol Value : too large";
+    case 48: return "Specified maxSymbolValue is too small";
+    case 49: return "This mode cannot generate an uncompressed block";
+    case 50: return "pledged buffer stability condition is not respected";
+    case 60: return "Operation not authorized at current processing stage";
+    case 62: return "Context should be init first";
+    case 64: return "Allocation error : not enough memory";
+    case 66: return "workSpace buffer is not large enough";
+    case 70: return "Destination buffer is too small";
+    case 72: return "Src size is incorrect";
+    case 74: return "Operation on NULL destination buffer";
+    case 80: return "Operation made no progress over multiple calls, due to output buffer being full";
+    case 82: return "Operation made no progress over multiple calls, due to input being empty";
+    case 100: return "Frame index is too large";
+    case 102: return "An I/O error occurred when reading/seeking";
+    case 104: return "Destination buffer is wrong";
+    case 105: return "Source buffer is wrong";
+    case 106: return "Block-level external sequence producer returned an error code";
+    case 107: return "External sequences are not valid";
+    default: return "Unspecified error code";
+    }
+}
+
+// device staging shared by the two stream contexts
+struct stream_dev {
+    kmp_batch_ctx* batch; u8* d_in; u8* d_out; u64* d_off; u32* d_len; size_t in_cap, out_cap;
+};
+static size_t stream_dev_init(stream_dev& s)
+{
+    if (s.batch) return 0;
+    if (kmp_batch_create(&s.batch, 0, 1, KMP_MAX_SLICE_BYTES, 8) != KMP_OK) return KERRC(ZE_memory_allocation);
+    s.in_cap = KMP_MAX_SLICE_BYTES + 1024; s.out_cap = KMP_MAX_SLICE_BYTES + 1024;
+    if (hipMalloc((void**)&s.d_in, s.in_cap) != hipSuccess || hipMalloc((void**)&s.d_out, s.out_cap) != hipSuccess ||
+        hipMalloc((void**)&s.d_off, 64) != hipSuccess || hipMalloc((void**)&s.d_len, 64) != hipSuccess) return KERRC(ZE_memory_allocation);
+    return 0;
+}
+static void stream_dev_free(stream_dev& s)
+{
+    if (s.batch) { kmp_batch_destroy(s.batch); (void)hipFree(s.d_in); (void)hipFree(s.d_out); (void)hipFree(s.d_off); (void)hipFree(s.d_len); }
+    memset(&s, 0, sizeof(s));
+}
+
+struct kmp_zstd_cctx {
+    int level; std::vector<u8> in; std::vector<u8> out; size_t out_pos; int stage;   // 0 = collecting, 1 = flushing
+    stream_dev dev;
+};
+
+extern "C" kmp_zstd_cctx* kmp_zstd_create_cctx(void)
+{
+    kmp_zstd_cctx* c = new (std::nothrow) kmp_zstd_cctx();
+    if (!c) return nullptr;
+    c->level = 3; c->out_pos = 0; c->stage = 0; memset(&c->dev, 0, sizeof(c->dev));
+    return c;
+}
+extern "C" size_t kmp_zstd_free_cctx(kmp_zstd_cctx* c) { if (c) { stream_dev_free(c->dev); delete c; } return 0; }
+extern "C" size_t kmp_zstd_cctx_set_parameter(kmp_zstd_cctx* c, int param, int value)
+{
+    if (!c) return KERRC(ZE_GENERIC);
+    if (param != KMP_ZSTD_c_compressionLevel) return KERRC(ZE_parameter_unsupported);
+    if (c->stage != 0 || !c->in.empty()) return KERRC(ZE_stage_wrong);
+    if (value == 0) value = 3;
+    if (value != 3) return KERRC(ZE_parameter_unsupported);
+    c->level = value;
+    return 0;
+}
+extern "C" size_t kmp_zstd_cctx_load_dictionary(kmp_zstd_cctx* c, const void* dict, size_t dict_size)
+{
+    if (!c) return KERRC(ZE_GENERIC);
+    if (dict == nullptr || dict_size == 0) return 0;
+    return KERRC(ZE_parameter_unsupported);
+}
+
+static size_t run_single_compress(kmp_zstd_cctx* c)
+{
+    size_t const n = c->in.size();
+    if (n > KMP_MAX_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
+    { size_t const e = stream_dev_init(c->dev); if (e) return e; }
+    stream_dev& s = c->dev;
+    u64 offs[2] = { 0, 0 }; u32 len = (u32)n, olen = 0;
+    if (n && hipMemcpy(s.d_in, c->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+    if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+    if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+    if (kmp_zstd_compress_batch(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
+    if (hipMemcpy(&olen, s.d_len + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
+    if (olen == 0 || olen > s.out_cap) return KERRC(ZE_GENERIC);
+    c->out.resize(olen);
+    if (hipMemcpy(c->out.data(), s.d_out, olen, hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
+    return 0;
+}
+
+extern "C" size_t kmp_zstd_compress_stream(kmp_zstd_cctx* c, void* dst, size_t dst_size, size_t* dst_pos,
+                                           const void* src, size_t src_size, size_t* src_pos, int end_op)
+{
+    if (!c || !dst_pos || !src_pos) return KERRC(ZE_GENERIC);
+    if (*dst_pos > dst_size) return KERRC(ZE_dstSize_tooSmall);
+    if (*src_pos > src_size) return KERRC(ZE_srcSize_wrong);
+    if ((unsigned)end_op > 2u) return KERRC(ZE_parameter_outOfBound);
+    if (c->stage == 0) {
+        // one-shot semantics (finish=true from the first call, SliceTransform.kt:33-45): the whole
+        // slice arrives before the frame can be produced, so input is collected until e_end
+        size_t const avail = src_size - *src_pos;
+        if (avail) { const u8* p = (const u8*)src + *src_pos; c->in.insert(c->in.end(), p, p + avail); *src_pos = src_size; }
+        if (c->in.size() > KMP_MAX_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
+        if (end_op != KMP_ZSTD_e_end) return 0;
+        size_t const e = run_single_compress(c);
+        if (e) return e;
+        c->stage = 1; c->out_pos = 0;
+    } else if (*src_pos != src_size) {
+        return KERRC(ZE_stage_wrong);      // new input while a finished frame is still being flushed
+    }
+    {
+        size_t const room = dst_size - *dst_pos, left = c->out.size() - c->out_pos;
+        size_t const k = room < left ? room : left;
+        if (k) { memcpy((u8*)dst + *dst_pos, c->out.data() + c->out_pos, k); *dst_pos += k; c->out_pos += k; }
+        size_t const remaining = c->out.size() - c->out_pos;
+        if (remaining == 0) { c->stage = 0; c->in.clear(); c->out.clear(); c->out_pos = 0; }
+        return remaining;
+    }
+}
+
+struct kmp_zstd_dctx {
+    std::vector<u8> in; std::vector<u8> out; size_t out_pos; int stage;   // 0 = collecting a frame, 1 = flushing
+    stream_dev dev; u32* d_status;
+};
+
+extern "C" kmp_zstd_dctx* kmp_zstd_create_dctx(void)
+{
+    kmp_zstd_dctx* d = new (std::nothrow) kmp_zstd_dctx();
+    if (!d) return nullptr;
+    d->out_pos = 0; d->stage = 0; memset(&d->dev, 0, sizeof(d->dev)); d->d_status = nullptr;
+    return d;
+}
+extern "C" size_t kmp_zstd_free_dctx(kmp_zstd_dctx* d) { if (d) { stream_dev_free(d->dev); delete d; } return 0; }
+extern "C" size_t kmp_zstd_dctx_load_dictionary(kmp_zstd_dctx* d, const void* dict, size_t dict_size)
+{
+    if (!d) return KERRC(ZE_GENERIC);
+    if (dict == nullptr || dict_size == 0) return 0;
+    return KERRC(ZE_parameter_unsupported);
+}
+
+// Size of the complete frame at p (n bytes available): 0 = need more input, KERRC(..) = malformed
+static size_t frame_total_size(const u8* p, size_t n, size_t* contentSize)
+{
+    if (n < 5) return 0;
+    if (p[0] != 0x28 || p[1] != 0xB5 || p[2] != 0x2F || p[3] != 0xFD) return KERRC(ZE_prefix_unknown);
+    u32 const fhd = p[4]; u32 const dictID = fhd & 3, checksum = (fhd >> 2) & 1, single = (fhd >> 5) & 1, fcsId = fhd >> 6;
+    if (fhd & 0x08) return KERRC(ZE_frameParameter_unsupported);
+    size_t pos = 5 + (single ? 0 : 1);
+    static const u32 didSize[4] = { 0, 1, 2, 4 };
+    pos += didSize[dictID];
+    u32 const fcsSize = fcsId == 0 ? single : (fcsId == 1 ? 2 : fcsId == 2 ? 4 : 8);
+    if (n < pos + fcsSize) return 0;
+    u64 cs = (u64)-1;
+    if (fcsSize == 1) cs = p[pos]; else if (fcsSize == 2) cs = (u64)(p[pos] | (p[pos + 1] << 8)) + 256;
+    else if (fcsSize == 4) { u32 v; memcpy(&v, p + pos, 4); cs = v; } else if (fcsSize == 8) memcpy(&cs, p + pos, 8);
+    *contentSize = (size_t)cs;
+    pos += fcsSize;
+    for (;;) {
+        if (n < pos + 3) return 0;
+        u32 const bh = p[pos] | (p[pos + 1] << 8) | (p[pos + 2] << 16);
+        u32 const last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
+        if (type == 3) return KERRC(ZE_corruption_detected);
+        pos += 3 + (type == 1 ? 1 : bsz);
+        if (last) break;
+    }
+    pos += checksum ? 4 : 0;
+    if (n < pos) return 0;
+    return pos;
+}
+
+extern "C" size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* d, void* dst, size_t dst_size, size_t* dst_pos,
+                                             const void* src, size_t src_size, size_t* src_pos)
+{
+    if (!d || !dst_pos || !src_pos) return KERRC(ZE_GENERIC);
+    if (*dst_pos > dst_size) return KERRC(ZE_dstSize_tooSmall);
+    if (*src_pos > src_size) return KERRC(ZE_srcSize_wrong);
+    if (d->stage == 0) {
+        // take input until one whole frame is buffered
+        size_t content = (size_t)-1;
+        {   // take everything offered, then hand back what lies beyond the frame's end
+            size_t const avail = src_size - *src_pos;
+            const u8* p = (const u8*)src + *src_pos;
+            d->in.insert(d->in.end(), p, p + avail); *src_pos = src_size;
+        }
+        size_t const total = frame_total_size(d->in.data(), d->in.size(), &content);
+        if (kmp_zstd_is_error(total)) return total;
+        if (total && total < d->in.size()) { *src_pos -= d->in.size() - total; d->in.resize(total); }
+        if (total == 0) return 3;                              // hint: more input expected
+        if (d->in.size() > KMP_MAX_SLICE_BYTES + 1024) return KERRC(ZE_frameParameter_unsupported);
+        { size_t const e = stream_dev_init(d->dev); if (e) return e; }
+        stream_dev& s = d->dev;
+        if (!d->d_status && hipMalloc((void**)&d->d_status, 64) != hipSuccess) return KERRC(ZE_memory_allocation);
+        u64 offs[2] = { 0, 0 }; u32 lens[2] = { (u32)total, (u32)s.out_cap }; u32 res[2] = { 0, 0 };
+        if (hipMemcpy(s.d_in, d->in.data(), total, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+        if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+        if (hipMemcpy(s.d_len, lens, sizeof(lens), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+        if (kmp_zstd_decompress_batch(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1,
+                                      d->d_status, d->d_status + 1, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
+        if (hipMemcpy(res, d->d_status, 8, hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
+        if (res[1]) return KERRC(res[1]);
+        d->out.resize(res[0]);
+        if (res[0] && hipMemcpy(d->out.data(), s.d_out, res[0], hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
+        d->in.clear(); d->stage = 1; d->out_pos = 0;
+    }
+    {
+        size_t const room = dst_size - *dst_pos, left = d->out.size() - d->out_pos;
+        size_t const k = room < left ? room : left;
+        if (k) { memcpy((u8*)dst + *dst_pos, d->out.data() + d->out_pos, k); *dst_pos += k; d->out_pos += k; }
+        size_t const remaining = d->out.size() - d->out_pos;
+        if (remaining == 0) { d->stage = 0; d->out.clear(); d->out_pos = 0; }
+        return remaining;
+    }
+}

@@ -1,0 +1,60 @@
+// kx_wave.h -- wave64 primitives for gfx950 (CDNA4) used by every kernel body.
+//
+// Kernel bodies (zstd_match.h, zstd_entropy.h, zstd_decode.h) are written
+// against this small vocabulary only, so that tests/emu/ can run the very
+// same bodies lane-for-lane on the CPU (a lock-step fiber emulator that
+// shadows this header) and diff every stage against oracle/.  This file is
+// the product definition: plain HIP for gfx950, nothing else.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define KX_DEV __device__ __forceinline__
+#define KX_DEV_NOINLINE __device__ __noinline__
+#define KX_SHARED __shared__
+
+// ---- identity ---------------------------------------------------------
+KX_DEV int kx_lane() { return (int)(threadIdx.x & 63); }
+KX_DEV u32 kx_block() { return blockIdx.x; }
+KX_DEV u32 kx_nblocks() { return gridDim.x; }
+
+// ---- cross-lane (must be called from wave-uniform control flow) -------
+KX_DEV u64 kx_ballot(bool p) { return __ballot(p); }
+KX_DEV bool kx_any(bool p) { return __ballot(p) != 0ull; }
+KX_DEV bool kx_all(bool p) { return __ballot(!p) == 0ull; }
+// value held by lane `src` (0..63); ds_bpermute_b32
+KX_DEV u32 kx_shfl(u32 v, int src) { return (u32)__builtin_amdgcn_ds_bpermute((src & 63) << 2, (int)v); }
+// orders LDS/global traffic between the lanes of the (single-wave) workgroup
+KX_DEV void kx_sync() { __syncthreads(); }
+// The lanes of a wave execute in lock step and the vector-memory pipeline keeps
+// one wave's accesses to an address in program order, so memory written by some
+// lanes in one instruction is visible to other lanes of the same wave in a later
+// one; this only stops the compiler from moving code across the point.
+KX_DEV void kx_lockstep() { __builtin_amdgcn_wave_barrier(); }
+
+// ---- memory -----------------------------------------------------------
+// gfx950 global memory takes unaligned dword/dwordx2 accesses; hipcc emits
+// one global_load_dwordx2 for these.
+KX_DEV u64 kx_ld64(const u8* p) { u64 v; __builtin_memcpy(&v, p, 8); return v; }
+KX_DEV u32 kx_ld32(const u8* p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }
+KX_DEV u32 kx_ld16(const u8* p) { u16 v; __builtin_memcpy(&v, p, 2); return v; }
+KX_DEV void kx_st64(u8* p, u64 v) { __builtin_memcpy(p, &v, 8); }
+KX_DEV void kx_st32(u8* p, u32 v) { __builtin_memcpy(p, &v, 4); }
+KX_DEV void kx_st16(u8* p, u32 v) { u16 x = (u16)v; __builtin_memcpy(p, &x, 2); }
+
+KX_DEV u32 kx_atomic_add(u32* p, u32 v) { return atomicAdd(p, v); }
+KX_DEV void kx_atomic_or(u32* p, u32 v) { atomicOr(p, v); }
+KX_DEV void kx_lds_inc(u32* p) { atomicAdd(p, 1u); }
+
+// ---- bit tricks -------------------------------------------------------
+KX_DEV u32 kx_umulhi(u32 a, u32 b) { return __umulhi(a, b); }
+KX_DEV u32 kx_ctz32(u32 v) { return (u32)__builtin_ctz(v); }
+KX_DEV u32 kx_ctz64(u64 v) { return (u32)__builtin_ctzll(v); }
+KX_DEV u32 kx_clz32(u32 v) { return (u32)__builtin_clz(v); }
+KX_DEV u32 kx_hb32(u32 v) { return 31u - (u32)__builtin_clz(v); }
+KX_DEV u32 kx_popc64(u64 v) { return (u32)__builtin_popcountll(v); }

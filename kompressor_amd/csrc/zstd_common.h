@@ -1,0 +1,79 @@
+// zstd_common.h -- structs and small helpers shared by the zstd kernels and
+// the host launcher.  Requires kx_wave.h (product) or the emulator's shadow.
+#pragma once
+// (the including translation unit provides kx_wave.h: csrc/ for gfx950, tests/emu/ for the CPU emulator)
+
+// One LZ sequence as the match kernel hands it to the entropy kernel.
+// Same meaning as libzstd's seqStore entry behind ZSTD_compressStream2
+// (reference call site: kompressor-zstd--nativelib/src/jvmCommonMain/jni/Wrapper.cpp:112).
+struct KSeq { u32 offBase; u16 litLength; u16 mlBase; };
+
+struct KSliceMeta {
+    u32 nbSeq;      // sequences stored
+    u32 litSize;    // literal bytes stored by the match kernel (last literals excluded)
+    u32 lastLL;     // trailing literals: src[n-lastLL, n)
+    u32 longType;   // 0 none, 1 litLength > 65535 at longPos, 2 matchLength-3 > 65535 at longPos
+    u32 longPos;
+    u32 status;     // 0 ok, else kernel guard tripped
+    u32 pad[2];
+};
+
+// Hash-table entry = (epoch << KX_IDX_BITS) | index, index = position + 2 (0 = empty).
+#define KX_IDX_BITS 18
+#define KX_IDX_MASK ((1u << KX_IDX_BITS) - 1)
+#define KX_EPOCH_MAX ((1u << (32 - KX_IDX_BITS)) - 1)
+#define KX_TBL_LONG  (1u << 16)
+#define KX_TBL_SHORT (1u << 15)    /* chainLog <= 15 for slices <= 128 KiB */
+#define KX_TBL_ENTRIES (KX_TBL_LONG + KX_TBL_SHORT)
+#define KX_MAX_SLICE (128u * 1024u)
+
+// level-3 parameters of a one-shot slice of n bytes (n <= 128 KiB here):
+// what ZSTD_getCParams(3, n, 0) yields after size adjustment.
+struct KParams { u32 windowLog, chainLog, hashLog, minMatch; };
+
+KX_DEV KParams kx_params_l3(u32 n)
+{
+    KParams p;
+    if (n <= 16384) { p.windowLog = 14; p.chainLog = 14; p.hashLog = 15; p.minMatch = 4; }
+    else            { p.windowLog = 17; p.chainLog = 15; p.hashLog = 16; p.minMatch = 5; }
+    u32 const srcLog = (n < 64) ? 6 : kx_hb32(n - 1) + 1;
+    if (p.windowLog > srcLog) p.windowLog = srcLog;
+    if (p.hashLog > p.windowLog + 1) p.hashLog = p.windowLog + 1;
+    if (p.chainLog > p.windowLog) p.chainLog = p.windowLog;
+    if (p.windowLog < 10) p.windowLog = 10;
+    return p;
+}
+
+KX_DEV u32 kx_frame_header_size(u32 n)
+{
+    // magic(4) + FHD(1) + FCS; single-segment always holds (windowSize >= n)
+    return 5 + ((n < 256) ? 1 : (n < 65536 + 256) ? 2 : 4);
+}
+
+// 64-bit multiplicative hashes, top bits. Written with 32-bit pieces: only the
+// high dword of the low 64 bits of the product is needed.
+KX_DEV u32 kx_mulhi64_hi32(u32 w0, u32 w1, u32 p0, u32 p1)
+{
+    return kx_umulhi(w0, p0) + w0 * p1 + w1 * p0;
+}
+KX_DEV u32 kx_hash_long(u64 w, u32 hBits)
+{
+    u32 const hi = kx_mulhi64_hi32((u32)w, (u32)(w >> 32), 0xB7A56463u, 0xCF1BBCDCu);
+    return hi >> (32 - hBits);
+}
+KX_DEV u32 kx_hash_short(u64 w, u32 hBits, u32 mls)
+{
+    if (mls == 4) return ((u32)w * 2654435761u) >> (32 - hBits);
+    // mls == 5: ((w << 24) * 889523592379) >> (64 - hBits)
+    u64 const x = w << 24;
+    u32 const hi = kx_mulhi64_hi32((u32)x, (u32)(x >> 32), 0x1BBCDCBBu, 0xCFu);
+    return hi >> (32 - hBits);
+}
+
+// 8 bytes at position p of a slice of n bytes without touching bytes >= n
+// (p < n, n >= 8): bytes past the end read as zero.
+KX_DEV u64 kx_ld64_clamped(const u8* src, int p, int n)
+{
+    if (p + 8 <= n) return kx_ld64(src + p);
+    return kx_ld64(src + n - 8) >> (8 * (p + 8 - n));
+}

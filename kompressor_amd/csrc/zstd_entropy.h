@@ -1,0 +1,891 @@
+// zstd_entropy.h -- entropy stage + frame writer of zstd level 3, one wave per
+// slice: literals section (raw / RLE / Huffman 1 or 4 streams, weights FSE- or
+// 4-bit-coded), sequences section (predefined / RLE / FSE tables, interleaved
+// tANS bitstream), compressed-vs-raw block decision, block + frame headers.
+//
+// Replaces the second half of what libzstd 1.5.7 does behind the reference's
+// ZSTD_compressStream2(..., ZSTD_e_end) call
+// (kompressor-zstd--nativelib/src/jvmCommonMain/jni/Wrapper.cpp:112); the bytes
+// must equal that library's frame exactly, so every heuristic (table-log
+// choice, count normalisation, Huffman depth limiting and tie order, encoding
+// type selection, minimum-gain tests) follows the published algorithm.
+//
+// Execution shape: histograms, literal bit-packing and copies are wave-parallel
+// (64 lanes, LDS atomics, shuffle scans, atomic-OR bit placement); the tiny
+// table constructions (<= 256 symbols) and the tANS state chain are run by
+// lane 0 while the other 8191 resident waves of the chip hide its latency.
+#pragma once
+#include "zstd_common.h"
+
+struct KEntropyArgs {
+    const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
+    const KSeq* seqs; u32 seq_cap; u8* lits; u32 lit_cap; const KSliceMeta* meta;
+    u32* scratch; u32 scratch_words;         // per slice: Huffman stream staging (u32 aligned)
+    u8* dst; const u64* out_off; u32* out_len;
+};
+
+#define KXE_ERR 0xFFFFFFFFu
+
+struct KHNode { u32 count; u16 parent; u8 byte; u8 nbBits; };
+
+// ---- LDS of one entropy wave ------------------------------------------
+struct KEntropyLds {
+    u32 hist[256];            // literal histogram / sequence-code histograms (3 x 64)
+    u32 ct[256];              // Huffman code table: val | nbBits << 16
+    KHNode node[516];         // Huffman tree nodes ([0] is the sentinel before huffNode[0])
+    u32 rank[192];            // bucket sort positions: curr | base << 16
+    u32 qstack[40];           // explicit quicksort stack
+    u16 state[3][512];        // FSE next-state tables (LL, OF, ML) ; [0] reused for the weights
+    u32 dnb[3][64];           // FSE deltaNbBits
+    int dfs[3][64];           // FSE deltaFindState
+    short norm[64];
+    u32 cnt[64];
+    u16 cumul[66];
+    u8 tsym[512];             // FSE spread scratch
+    u8 weight[256];
+    u32 stage[192];           // 64 staged sequences for the tANS walk
+};
+
+// ======================= lane-0 serial helpers ==========================
+struct KBitW { u64 acc; u32 nb; u8* p; };
+KX_DEV void kbw_init(KBitW& b, u8* dst) { b.acc = 0; b.nb = 0; b.p = dst; }
+KX_DEV void kbw_add(KBitW& b, u32 v, u32 n)
+{
+    if (n == 0) return;
+    u64 const m = (n >= 32) ? 0xFFFFFFFFull : ((1ull << n) - 1ull);
+    b.acc |= ((u64)v & m) << b.nb; b.nb += n;
+    if (b.nb >= 32) { kx_st32(b.p, (u32)b.acc); b.p += 4; b.acc >>= 32; b.nb -= 32; }
+}
+KX_DEV u32 kbw_close(KBitW& b, u8* start)
+{
+    kbw_add(b, 1, 1);
+    while (b.nb > 0) { *b.p++ = (u8)b.acc; b.acc >>= 8; b.nb = (b.nb >= 8) ? b.nb - 8 : 0; }
+    return (u32)(b.p - start);
+}
+
+KX_DEV u32 kfse_min_tablelog(u32 srcSize, u32 maxSymbolValue)
+{
+    u32 const a = kx_hb32(srcSize) + 1, b = kx_hb32(maxSymbolValue) + 2;
+    return a < b ? a : b;
+}
+KX_DEV u32 kfse_optimal_tablelog(u32 maxTableLog, u32 srcSize, u32 maxSymbolValue, u32 minus)
+{
+    u32 const maxBitsSrc = kx_hb32(srcSize - 1) - minus;
+    u32 tableLog = maxTableLog;
+    u32 const minBits = kfse_min_tablelog(srcSize, maxSymbolValue);
+    if (maxBitsSrc < tableLog) tableLog = maxBitsSrc;
+    if (minBits > tableLog) tableLog = minBits;
+    if (tableLog < 5) tableLog = 5;
+    if (tableLog > 12) tableLog = 12;
+    return tableLog;
+}
+
+KX_DEV u32 kfse_normalize_m2(short* norm, u32 tableLog, const u32* count, u32 total, u32 maxSymbolValue, short lowProbCount)
+{
+    short const NOT_YET_ASSIGNED = -2;
+    u32 s, distributed = 0, ToDistribute;
+    u32 const lowThreshold = total >> tableLog;
+    u32 lowOne = (u32)(((u64)total * 3) >> (tableLog + 1));
+    for (s = 0; s <= maxSymbolValue; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = lowProbCount; distributed++; total -= count[s]; continue; }
+        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        norm[s] = NOT_YET_ASSIGNED;
+    }
+    ToDistribute = (1u << tableLog) - distributed;
+    if (ToDistribute == 0) return 0;
+    if ((total / ToDistribute) > lowOne) {
+        lowOne = (u32)(((u64)total * 3) / (ToDistribute * 2));
+        for (s = 0; s <= maxSymbolValue; s++) {
+            if ((norm[s] == NOT_YET_ASSIGNED) && (count[s] <= lowOne)) { norm[s] = 1; distributed++; total -= count[s]; }
+        }
+        ToDistribute = (1u << tableLog) - distributed;
+    }
+    if (distributed == maxSymbolValue + 1) {
+        u32 maxV = 0, maxC = 0;
+        for (s = 0; s <= maxSymbolValue; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
+        norm[maxV] += (short)ToDistribute;
+        return 0;
+    }
+    if (total == 0) {
+        for (s = 0; ToDistribute > 0; s = (s + 1) % (maxSymbolValue + 1)) if (norm[s] > 0) { ToDistribute--; norm[s]++; }
+        return 0;
+    }
+    {
+        u64 const vStepLog = 62 - tableLog;
+        u64 const mid = (1ull << (vStepLog - 1)) - 1;
+        u64 const rStep = (((1ull << vStepLog) * ToDistribute) + mid) / total;
+        u64 tmpTotal = mid;
+        for (s = 0; s <= maxSymbolValue; s++) {
+            if (norm[s] == NOT_YET_ASSIGNED) {
+                u64 const end = tmpTotal + (count[s] * rStep);
+                u32 const weight = (u32)(end >> vStepLog) - (u32)(tmpTotal >> vStepLog);
+                if (weight < 1) return KXE_ERR;
+                norm[s] = (short)weight;
+                tmpTotal = end;
+            }
+        }
+    }
+    return 0;
+}
+
+// returns tableLog, 0 for "one symbol only", KXE_ERR on error
+KX_DEV u32 kfse_normalize(short* norm, u32 tableLog, const u32* count, u32 total, u32 maxSymbolValue, u32 useLowProbCount)
+{
+    if (tableLog < 5 || tableLog > 12) return KXE_ERR;
+    if (tableLog < kfse_min_tablelog(total, maxSymbolValue)) return KXE_ERR;
+    short const lowProbCount = useLowProbCount ? -1 : 1;
+    u64 const scale = 62 - tableLog;
+    u64 const step = (1ull << 62) / total;
+    u64 const vStep = 1ull << (scale - 20);
+    int stillToDistribute = 1 << tableLog;
+    u32 s, largest = 0; short largestP = 0;
+    u32 const lowThreshold = total >> tableLog;
+    for (s = 0; s <= maxSymbolValue; s++) {
+        if (count[s] == total) return 0;
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = lowProbCount; stillToDistribute--; }
+        else {
+            short proba = (short)((count[s] * step) >> scale);
+            if (proba < 8) {
+                u32 const rtb = proba == 0 ? 0u : proba == 1 ? 473195u : proba == 2 ? 504333u : proba == 3 ? 520860u
+                              : proba == 4 ? 550000u : proba == 5 ? 700000u : proba == 6 ? 750000u : 830000u;
+                u64 const restToBeat = vStep * rtb;
+                proba += (count[s] * step) - ((u64)proba << scale) > restToBeat;
+            }
+            if (proba > largestP) { largestP = proba; largest = s; }
+            norm[s] = proba;
+            stillToDistribute -= proba;
+        }
+    }
+    if (-stillToDistribute >= (norm[largest] >> 1)) {
+        if (kfse_normalize_m2(norm, tableLog, count, total, maxSymbolValue, lowProbCount) == KXE_ERR) return KXE_ERR;
+    } else norm[largest] += (short)stillToDistribute;
+    return tableLog;
+}
+
+// writes the normalised counts header; returns its size (KXE_ERR on a malformed distribution)
+KX_DEV u32 kfse_write_ncount(u8* dst, const short* norm, u32 maxSymbolValue, u32 tableLog)
+{
+    u8* out = dst;
+    int nbBits; int const tableSize = 1 << tableLog;
+    int remaining, threshold; u32 bitStream = 0; int bitCount = 0;
+    u32 symbol = 0; u32 const alphabetSize = maxSymbolValue + 1; int previousIs0 = 0;
+    bitStream += (tableLog - 5) << bitCount; bitCount += 4;
+    remaining = tableSize + 1; threshold = tableSize; nbBits = (int)tableLog + 1;
+    while ((symbol < alphabetSize) && (remaining > 1)) {
+        if (previousIs0) {
+            u32 start = symbol;
+            while ((symbol < alphabetSize) && !norm[symbol]) symbol++;
+            if (symbol == alphabetSize) break;
+            while (symbol >= start + 24) {
+                start += 24;
+                bitStream += 0xFFFFu << bitCount;
+                out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16;
+            }
+            while (symbol >= start + 3) { start += 3; bitStream += 3u << bitCount; bitCount += 2; }
+            bitStream += (symbol - start) << bitCount; bitCount += 2;
+            if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+        }
+        {
+            int count = norm[symbol++];
+            int const max = (2 * threshold - 1) - remaining;
+            remaining -= count < 0 ? -count : count;
+            count++;
+            if (count >= threshold) count += max;
+            bitStream += (u32)count << bitCount;
+            bitCount += nbBits;
+            bitCount -= (count < max);
+            previousIs0 = (count == 1);
+            if (remaining < 1) return KXE_ERR;
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+        }
+        if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+    }
+    if (remaining != 1) return KXE_ERR;
+    out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8);
+    out += (bitCount + 7) / 8;
+    return (u32)(out - dst);
+}
+
+struct KFseCT { u16* state; u32* dnb; int* dfs; u32 tableLog; };
+
+KX_DEV void kfse_build_ctable(KFseCT& ct, const short* norm, u32 maxSymbolValue, u32 tableLog, u16* cumul, u8* tableSymbol)
+{
+    u32 const tableSize = 1u << tableLog, tableMask = tableSize - 1;
+    u32 const step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    u32 const maxSV1 = maxSymbolValue + 1;
+    u32 highThreshold = tableSize - 1, u;
+    ct.tableLog = tableLog;
+    cumul[0] = 0;
+    for (u = 1; u <= maxSV1; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tableSymbol[highThreshold--] = (u8)(u - 1); }
+        else cumul[u] = cumul[u - 1] + (u16)norm[u - 1];
+    }
+    cumul[maxSV1] = (u16)(tableSize + 1);
+    {
+        u32 position = 0, symbol;
+        for (symbol = 0; symbol < maxSV1; symbol++) {
+            int const freq = norm[symbol];
+            for (int i = 0; i < freq; i++) {
+                tableSymbol[position] = (u8)symbol;
+                position = (position + step) & tableMask;
+                while (position > highThreshold) position = (position + step) & tableMask;
+            }
+        }
+    }
+    for (u = 0; u < tableSize; u++) { u8 const s = tableSymbol[u]; ct.state[cumul[s]++] = (u16)(tableSize + u); }
+    {
+        u32 total = 0, s;
+        for (s = 0; s <= maxSymbolValue; s++) {
+            int const nc = norm[s];
+            if (nc == 0) { ct.dnb[s] = ((tableLog + 1) << 16) - (1u << tableLog); ct.dfs[s] = 0; }
+            else if (nc == -1 || nc == 1) { ct.dnb[s] = (tableLog << 16) - (1u << tableLog); ct.dfs[s] = (int)(total - 1); total++; }
+            else {
+                u32 const maxBitsOut = tableLog - kx_hb32((u32)nc - 1);
+                u32 const minStatePlus = (u32)nc << maxBitsOut;
+                ct.dnb[s] = (maxBitsOut << 16) - minStatePlus;
+                ct.dfs[s] = (int)(total - (u32)nc);
+                total += (u32)nc;
+            }
+        }
+    }
+}
+KX_DEV void kfse_build_ctable_rle(KFseCT& ct, u32 symbol)
+{
+    ct.tableLog = 0; ct.state[0] = 0; ct.state[1] = 0; ct.dnb[symbol] = 0; ct.dfs[symbol] = 0;
+}
+KX_DEV u32 kfse_init_state(const KFseCT& ct, u32 symbol)
+{
+    u32 const dnb = ct.dnb[symbol];
+    u32 const nbBitsOut = (dnb + (1u << 15)) >> 16;
+    u32 const value = (nbBitsOut << 16) - dnb;
+    return ct.state[(value >> nbBitsOut) + ct.dfs[symbol]];
+}
+KX_DEV void kfse_encode(KBitW& b, const KFseCT& ct, u32& state, u32 symbol)
+{
+    u32 const nbBitsOut = (state + ct.dnb[symbol]) >> 16;
+    kbw_add(b, state, nbBitsOut);
+    state = ct.state[(state >> nbBitsOut) + ct.dfs[symbol]];
+}
+
+// ---- Huffman table construction (lane 0) -----------------------------
+KX_DEV u32 khuf_get_index(u32 count) { return (count < 165u) ? count : kx_hb32(count) + 158u; }
+
+KX_DEV void khuf_insertion_sort(KHNode* n, int low, int high)
+{
+    int const size = high - low + 1; n += low;
+    for (int i = 1; i < size; ++i) {
+        KHNode const key = n[i]; int j = i - 1;
+        while (j >= 0 && n[j].count < key.count) { n[j + 1] = n[j]; j--; }
+        n[j + 1] = key;
+    }
+}
+KX_DEV int khuf_partition(KHNode* arr, int low, int high)
+{
+    u32 const pivot = arr[high].count; int i = low - 1;
+    for (int j = low; j < high; j++) if (arr[j].count > pivot) { i++; KHNode t = arr[i]; arr[i] = arr[j]; arr[j] = t; }
+    { KHNode t = arr[i + 1]; arr[i + 1] = arr[high]; arr[high] = t; }
+    return i + 1;
+}
+// the published sort: quicksort, last element as pivot, insertion sort below 8
+// elements on entry; the explicit stack replays the recursion order
+KX_DEV void khuf_quicksort(KHNode* arr, int lo0, int hi0, u32* stack)
+{
+    int sp = 0;
+    stack[sp++] = (u32)lo0 | ((u32)hi0 << 10) | (1u << 20);
+    while (sp > 0) {
+        u32 const f = stack[--sp];
+        int low = (int)(f & 1023u), high = (int)((f >> 10) & 1023u) ; bool const fresh = (f >> 20) & 1u;
+        if ((f >> 21) & 1u) high = -1;                 // encoded "high = low - 1" underflow
+        if (fresh && high - low < 8) { khuf_insertion_sort(arr, low, high); continue; }
+        if (!(low < high)) continue;
+        int const idx = khuf_partition(arr, low, high);
+        u32 a, b;   // b is run first
+        if (idx - low < high - idx) {
+            a = (u32)(idx + 1) | ((u32)high << 10);                                   // continue the loop
+            b = (idx - 1 < 0) ? ((u32)low | (1u << 20) | (1u << 21)) : ((u32)low | ((u32)(idx - 1) << 10) | (1u << 20));
+        } else {
+            a = (idx - 1 < 0) ? ((u32)low | (1u << 21)) : ((u32)low | ((u32)(idx - 1) << 10));
+            b = (u32)(idx + 1) | ((u32)high << 10) | (1u << 20);
+        }
+        stack[sp++] = a; stack[sp++] = b;
+    }
+}
+
+KX_DEV void khuf_sort(KHNode* huffNode, const u32* count, u32 maxSymbolValue, u32* rank, u32* qstack)
+{
+    u32 n; u32 const maxSV1 = maxSymbolValue + 1;
+    // rank[i] = curr | base << 16
+    for (n = 0; n < 192; n++) rank[n] = 0;
+    for (n = 0; n < maxSV1; ++n) rank[khuf_get_index(count[n])] += 1u << 16;
+    for (n = 191; n > 0; --n) {
+        u32 const b = (rank[n - 1] >> 16) + (rank[n] >> 16);
+        rank[n - 1] = b | (b << 16);
+    }
+    for (n = 0; n < maxSV1; ++n) {
+        u32 const c = count[n]; u32 const r = khuf_get_index(c) + 1;
+        u32 const pos = rank[r] & 0xFFFFu; rank[r] += 1;
+        huffNode[pos].count = c; huffNode[pos].byte = (u8)n;
+    }
+    for (n = 165; n < 191; ++n) {
+        int const bucketSize = (int)(rank[n] & 0xFFFFu) - (int)(rank[n] >> 16);
+        u32 const start = rank[n] >> 16;
+        if (bucketSize > 1) khuf_quicksort(huffNode + start, 0, bucketSize - 1, qstack);
+    }
+}
+
+KX_DEV u32 khuf_set_max_height(KHNode* huffNode, u32 lastNonNull, u32 targetNbBits)
+{
+    u32 const largestBits = huffNode[lastNonNull].nbBits;
+    if (largestBits <= targetNbBits) return largestBits;
+    int totalCost = 0; u32 const baseCost = 1u << (largestBits - targetNbBits);
+    int n = (int)lastNonNull;
+    while (huffNode[n].nbBits > targetNbBits) {
+        totalCost += (int)(baseCost - (1u << (largestBits - huffNode[n].nbBits)));
+        huffNode[n].nbBits = (u8)targetNbBits; n--;
+    }
+    while (huffNode[n].nbBits == targetNbBits) --n;
+    totalCost >>= (largestBits - targetNbBits);
+    u32 const noSymbol = 0xF0F0F0F0u; u32 rankLast[14];
+    for (int i = 0; i < 14; i++) rankLast[i] = noSymbol;
+    {
+        u32 currentNbBits = targetNbBits;
+        for (int pos = n; pos >= 0; pos--) {
+            if (huffNode[pos].nbBits >= currentNbBits) continue;
+            currentNbBits = huffNode[pos].nbBits;
+            rankLast[targetNbBits - currentNbBits] = (u32)pos;
+        }
+    }
+    while (totalCost > 0) {
+        u32 nBitsToDecrease = kx_hb32((u32)totalCost) + 1;
+        for (; nBitsToDecrease > 1; nBitsToDecrease--) {
+            u32 const highPos = rankLast[nBitsToDecrease];
+            u32 const lowPos = rankLast[nBitsToDecrease - 1];
+            if (highPos == noSymbol) continue;
+            if (lowPos == noSymbol) break;
+            if (huffNode[highPos].count <= 2 * huffNode[lowPos].count) break;
+        }
+        while ((nBitsToDecrease <= 12) && (rankLast[nBitsToDecrease] == noSymbol)) nBitsToDecrease++;
+        totalCost -= 1 << (nBitsToDecrease - 1);
+        huffNode[rankLast[nBitsToDecrease]].nbBits++;
+        if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
+        if (rankLast[nBitsToDecrease] == 0) rankLast[nBitsToDecrease] = noSymbol;
+        else {
+            rankLast[nBitsToDecrease]--;
+            if (huffNode[rankLast[nBitsToDecrease]].nbBits != targetNbBits - nBitsToDecrease) rankLast[nBitsToDecrease] = noSymbol;
+        }
+    }
+    while (totalCost < 0) {
+        if (rankLast[1] == noSymbol) {
+            while (huffNode[n].nbBits == targetNbBits) n--;
+            huffNode[n + 1].nbBits--;
+            rankLast[1] = (u32)(n + 1);
+            totalCost++;
+            continue;
+        }
+        huffNode[rankLast[1] + 1].nbBits--;
+        rankLast[1]++;
+        totalCost++;
+    }
+    return targetNbBits;
+}
+
+// builds lds.ct from lds.hist; returns the table's depth
+KX_DEV u32 khuf_build_ctable(KEntropyLds& lds, u32 maxSymbolValue, u32 maxNbBits)
+{
+    KHNode* const huffNode0 = lds.node; KHNode* const huffNode = huffNode0 + 1;
+    for (int i = 0; i < 516; i++) { KHNode z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; lds.node[i] = z; }
+    khuf_sort(huffNode, lds.hist, maxSymbolValue, lds.rank, lds.qstack);
+    int nonNullRank = (int)maxSymbolValue;
+    while (huffNode[nonNullRank].count == 0) nonNullRank--;
+    int lowS = nonNullRank, nodeNb = 256; int const nodeRoot = nodeNb + lowS - 1; int lowN = nodeNb, n;
+    huffNode[nodeNb].count = huffNode[lowS].count + huffNode[lowS - 1].count;
+    huffNode[lowS].parent = huffNode[lowS - 1].parent = (u16)nodeNb;
+    nodeNb++; lowS -= 2;
+    for (n = nodeNb; n <= nodeRoot; n++) huffNode[n].count = 1u << 30;
+    huffNode0[0].count = 1u << 31;
+    while (nodeNb <= nodeRoot) {
+        int const n1 = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
+        int const n2 = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
+        huffNode[nodeNb].count = huffNode[n1].count + huffNode[n2].count;
+        huffNode[n1].parent = huffNode[n2].parent = (u16)nodeNb;
+        nodeNb++;
+    }
+    huffNode[nodeRoot].nbBits = 0;
+    for (n = nodeRoot - 1; n >= 256; n--) huffNode[n].nbBits = (u8)(huffNode[huffNode[n].parent].nbBits + 1);
+    for (n = 0; n <= nonNullRank; n++) huffNode[n].nbBits = (u8)(huffNode[huffNode[n].parent].nbBits + 1);
+    maxNbBits = khuf_set_max_height(huffNode, (u32)nonNullRank, maxNbBits);
+    {
+        u32 nbPerRank[13], valPerRank[13];
+        for (n = 0; n < 13; n++) { nbPerRank[n] = 0; valPerRank[n] = 0; }
+        int const alphabetSize = (int)(maxSymbolValue + 1);
+        for (n = 0; n <= nonNullRank; n++) nbPerRank[huffNode[n].nbBits]++;
+        { u32 min = 0; for (n = (int)maxNbBits; n > 0; n--) { valPerRank[n] = min; min += nbPerRank[n]; min >>= 1; } }
+        for (n = 0; n < 256; n++) lds.ct[n] = 0;
+        for (n = 0; n < alphabetSize; n++) lds.ct[huffNode[n].byte] = (u32)huffNode[n].nbBits << 16;
+        for (n = 0; n < alphabetSize; n++) { u32 const nb = lds.ct[n] >> 16; lds.ct[n] = (nb << 16) | (valPerRank[nb]++ & 0xFFFFu); }
+    }
+    return maxNbBits;
+}
+
+// FSE-compress the Huffman weights. 0 = not compressible, 1 = single symbol, KXE_ERR = error
+KX_DEV u32 khuf_compress_weights(u8* dst, KEntropyLds& lds, u32 wtSize)
+{
+    u8* op = dst; u32 maxSymbolValue = 12; u32 tableLog = 6;
+    const u8* const weightTable = lds.weight;
+    if (wtSize <= 1) return 0;
+    {
+        u32 maxCount = 0;
+        for (u32 s = 0; s <= 12; s++) lds.cnt[s] = 0;
+        for (u32 i = 0; i < wtSize; i++) lds.cnt[weightTable[i]]++;
+        while (!lds.cnt[maxSymbolValue]) maxSymbolValue--;
+        for (u32 s = 0; s <= maxSymbolValue; s++) if (lds.cnt[s] > maxCount) maxCount = lds.cnt[s];
+        if (maxCount == wtSize) return 1;
+        if (maxCount == 1) return 0;
+    }
+    tableLog = kfse_optimal_tablelog(tableLog, wtSize, maxSymbolValue, 2);
+    if (kfse_normalize(lds.norm, tableLog, lds.cnt, wtSize, maxSymbolValue, 0) == KXE_ERR) return KXE_ERR;
+    { u32 const h = kfse_write_ncount(op, lds.norm, maxSymbolValue, tableLog); if (h == KXE_ERR) return KXE_ERR; op += h; }
+    KFseCT ct; ct.state = lds.state[0]; ct.dnb = lds.dnb[0]; ct.dfs = lds.dfs[0];
+    kfse_build_ctable(ct, lds.norm, maxSymbolValue, tableLog, lds.cumul, lds.tsym);
+    {
+        KBitW b; const u8* ip = weightTable + wtSize; u32 s1, s2;
+        if (wtSize <= 2) return 0;
+        kbw_init(b, op);
+        if (wtSize & 1) { s1 = kfse_init_state(ct, *--ip); s2 = kfse_init_state(ct, *--ip); kfse_encode(b, ct, s1, *--ip); }
+        else { s2 = kfse_init_state(ct, *--ip); s1 = kfse_init_state(ct, *--ip); }
+        while (ip > weightTable) { kfse_encode(b, ct, s2, *--ip); kfse_encode(b, ct, s1, *--ip); }
+        kbw_add(b, s2, tableLog); kbw_add(b, s1, tableLog);
+        op += kbw_close(b, op);
+    }
+    return (u32)(op - dst);
+}
+
+// Huffman tree description; returns its size or KXE_ERR
+KX_DEV u32 khuf_write_ctable(u8* dst, KEntropyLds& lds, u32 maxSymbolValue, u32 huffLog)
+{
+    for (u32 n = 0; n < maxSymbolValue; n++) { u32 const nb = lds.ct[n] >> 16; lds.weight[n] = (u8)(nb ? huffLog + 1 - nb : 0); }
+    {
+        u32 const hSize = khuf_compress_weights(dst + 1, lds, maxSymbolValue);
+        if (hSize == KXE_ERR) return KXE_ERR;
+        if ((hSize > 1) & (hSize < maxSymbolValue / 2)) { dst[0] = (u8)hSize; return hSize + 1; }
+    }
+    if (maxSymbolValue > (256 - 128)) return KXE_ERR;
+    dst[0] = (u8)(128 + (maxSymbolValue - 1));
+    lds.weight[maxSymbolValue] = 0;
+    for (u32 n = 0; n < maxSymbolValue; n += 2) dst[(n / 2) + 1] = (u8)((lds.weight[n] << 4) + lds.weight[n + 1]);
+    return ((maxSymbolValue + 1) / 2) + 1;
+}
+
+// ======================= wave-parallel pieces ===========================
+KX_DEV u32 kx_wave_max(u32 v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { u32 const t = kx_shfl(v, lane ^ o); v = t > v ? t : v; }
+    return v;
+}
+KX_DEV u32 kx_wave_sum(u32 v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += kx_shfl(v, lane ^ o);
+    return v;
+}
+
+// byte histogram of p[0..n) into lds.hist (zeroed here); returns the largest count
+KX_DEV u32 kx_wave_hist(KEntropyLds& lds, const u8* p, u32 n, int lane)
+{
+    for (int i = lane; i < 256; i += 64) lds.hist[i] = 0;
+    kx_sync();
+    for (u32 i = (u32)lane * 8u; i + 8 <= n; i += 512u) {
+        u64 const w = kx_ld64(p + i);
+#pragma unroll
+        for (int b = 0; b < 8; b++) kx_lds_inc(&lds.hist[(w >> (8 * b)) & 0xFF]);
+    }
+    if (lane < (int)(n & 7u)) kx_lds_inc(&lds.hist[p[(n & ~7u) + lane]]);
+    kx_sync();
+    u32 m = 0;
+    for (int s = lane; s < 256; s += 64) { u32 const c = lds.hist[s]; m = c > m ? c : m; }
+    return kx_wave_max(m, lane);
+}
+
+KX_DEV void kx_wave_copy(u8* dst, const u8* src, u32 n, int lane)
+{
+    u32 i = (u32)lane * 8u;
+    for (; i + 8 <= n; i += 512u) kx_st64(dst + i, kx_ld64(src + i));
+    u32 const tail = n & ~7u;
+    if (lane < (int)(n - tail)) dst[tail + lane] = src[tail + lane];
+}
+
+KX_DEV u32 kx_min_gain(u32 srcSize) { return (srcSize >> 6) + 2; }
+
+KX_DEV u32 klit_header_raw_rle(u8* dst, u32 type, u32 litSize)
+{
+    u32 const flSize = 1 + (litSize > 31) + (litSize > 4095);
+    if (flSize == 1) dst[0] = (u8)(type + (litSize << 3));
+    else if (flSize == 2) kx_st16(dst, type + (1u << 2) + (litSize << 4));
+    else { u32 const h = type + (3u << 2) + (litSize << 4); dst[0] = (u8)h; dst[1] = (u8)(h >> 8); dst[2] = (u8)(h >> 16); }
+    return flSize;
+}
+
+// Huffman-code `lits[0..litSize)` into `op` (after the tree description of hSize
+// bytes that lane 0 already wrote at op - hSize).  Returns the stream bytes
+// (incl. jump table), 0 if a stream does not fit its 16-bit size field.
+KX_DEV u32 khuf_encode_streams(KEntropyLds& lds, u8* op, const u8* lits, u32 litSize, bool single,
+                               u32* scratch, int lane)
+{
+    int const LPS = single ? 64 : 16;
+    int const s = lane / LPS, j = lane % LPS;
+    u32 const seg = single ? litSize : (litSize + 3) / 4;
+    u32 const sBeg = (u32)s * seg;
+    u32 const sEnd = single ? litSize : ((s == 3) ? litSize : sBeg + seg);
+    u32 const ns = sEnd - sBeg;
+    u32 const chunk = (ns + (u32)LPS - 1) / (u32)LPS;
+    u32 b0 = sBeg + (u32)j * chunk; if (b0 > sEnd) b0 = sEnd;
+    u32 b1 = b0 + chunk; if (b1 > sEnd) b1 = sEnd;
+    // pass 1: bits of my chunk
+    u32 bits = 0;
+    {
+        u32 i = b0;
+        for (; i + 8 <= b1; i += 8) {
+            u64 const w = kx_ld64(lits + i);
+#pragma unroll
+            for (int b = 0; b < 8; b++) bits += lds.ct[(w >> (8 * b)) & 0xFF] >> 16;
+        }
+        for (; i < b1; i++) bits += lds.ct[lits[i]] >> 16;
+    }
+    // suffix sums inside the stream's lane group
+    u32 v = bits;
+    for (int o = 1; o < LPS; o <<= 1) { u32 const t = kx_shfl(v, lane + o); if (j + o < LPS) v += t; }
+    u32 const after = v - bits;
+    u32 const c0 = (kx_shfl(v, 0) + 8) >> 3;
+    u32 const c1 = (kx_shfl(v, 16) + 8) >> 3;
+    u32 const c2 = (kx_shfl(v, 32) + 8) >> 3;
+    u32 const c3 = (kx_shfl(v, 48) + 8) >> 3;
+    u32 total, soff;
+    if (single) { total = c0; soff = 0; }
+    else {
+        if (c0 > 65535 || c1 > 65535 || c2 > 65535 || c3 > 65535) return 0;
+        total = c0 + c1 + c2 + c3;
+        soff = (s > 0 ? c0 : 0) + (s > 1 ? c1 : 0) + (s > 2 ? c2 : 0);
+    }
+    u32 const words = (total + 3) >> 2;
+    for (u32 w = (u32)lane; w < words; w += 64) scratch[w] = 0;
+    kx_sync();
+    // pass 2: place my chunk's codes, last symbol first, LSB first
+    {
+        u32 const absBit = 8u * soff + after;
+        u32 wi = absBit >> 5; u32 fill = absBit & 31u; u64 acc = 0; bool first = true;
+#define KX_PUT_SYM(sym) { u32 const ce = lds.ct[(sym)]; acc |= (u64)(ce & 0xFFFFu) << fill; fill += ce >> 16; \
+            if (fill >= 32) { if (first) kx_atomic_or(&scratch[wi], (u32)acc); else scratch[wi] = (u32)acc; \
+                              first = false; wi++; acc >>= 32; fill -= 32; } }
+        u32 i = b1;
+        for (; i >= b0 + 8; i -= 8) {
+            u64 const w = kx_ld64(lits + i - 8);
+#pragma unroll
+            for (int b = 7; b >= 0; b--) KX_PUT_SYM((w >> (8 * b)) & 0xFF)
+        }
+        for (; i > b0; i--) KX_PUT_SYM(lits[i - 1])
+        if (j == 0) { acc |= 1ull << fill; fill++; }        // end mark of the stream
+        if (fill >= 32) { if (first) kx_atomic_or(&scratch[wi], (u32)acc); else scratch[wi] = (u32)acc; first = false; wi++; acc >>= 32; fill -= 32; }
+#undef KX_PUT_SYM
+        if (fill > 0 && (u32)acc != 0) kx_atomic_or(&scratch[wi], (u32)acc);
+    }
+    kx_sync();
+    // move to the frame
+    u8* const sdst = single ? op : op + 6;
+    if (!single && lane == 0) { kx_st16(op, c0); kx_st16(op + 2, c1); kx_st16(op + 4, c2); }
+    for (u32 w = (u32)lane; w < (total >> 2); w += 64) kx_st32(sdst + 4 * w, scratch[w]);
+    if (lane < (int)(total & 3u)) sdst[(total & ~3u) + lane] = (u8)(scratch[total >> 2] >> (8 * lane));
+    return single ? total : total + 6;
+}
+
+// literals section at `dst`; returns its size (uniform across the wave)
+KX_DEV u32 kzstd_literals(KEntropyLds& lds, u8* dst, const u8* lits, u32 litSize, bool suspect, u32* scratch, int lane)
+{
+    u32 const lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
+    bool const single = litSize < 256;
+    u32 cLit = 0;      // 0 => raw, 1 => rle
+    if (litSize >= 64) {
+        bool go = true;
+        if (suspect && litSize >= 40960) {
+            u32 const lb = kx_wave_hist(lds, lits, 4096, lane);
+            u32 const le = kx_wave_hist(lds, lits + litSize - 4096, 4096, lane);
+            if (lb + le <= ((2 * 4096) >> 7) + 4) go = false;
+        }
+        if (go) {
+            u32 const largest = kx_wave_hist(lds, lits, litSize, lane);
+            if (largest == litSize) cLit = 1;
+            else if (largest > (litSize >> 7) + 4) {
+                u32 hSize = 0;
+                if (lane == 0) {
+                    u32 maxSymbolValue = 255;
+                    while (!lds.hist[maxSymbolValue]) maxSymbolValue--;
+                    u32 huffLog = kfse_optimal_tablelog(11, litSize, maxSymbolValue, 1);
+                    huffLog = khuf_build_ctable(lds, maxSymbolValue, huffLog);
+                    hSize = khuf_write_ctable(dst + lhSize, lds, maxSymbolValue, huffLog);
+                }
+                hSize = kx_shfl(hSize, 0);
+                kx_sync();
+                if (hSize != KXE_ERR && hSize + 12 < litSize) {
+                    u32 const sz = khuf_encode_streams(lds, dst + lhSize + hSize, lits, litSize, single, scratch, lane);
+                    if (sz != 0 && hSize + sz < litSize - 1) cLit = hSize + sz;
+                }
+            }
+        }
+        if (cLit != 1 && (cLit == 0 || cLit >= litSize - kx_min_gain(litSize))) cLit = 0;
+    }
+    if (cLit == 0) {
+        u32 fl = 0;
+        if (lane == 0) fl = klit_header_raw_rle(dst, 0, litSize);
+        fl = kx_shfl(fl, 0);
+        kx_sync();
+        kx_wave_copy(dst + fl, lits, litSize, lane);
+        return fl + litSize;
+    }
+    if (cLit == 1) {
+        u32 fl = 0;
+        if (lane == 0) { fl = klit_header_raw_rle(dst, 1, litSize); dst[fl] = lits[0]; }
+        fl = kx_shfl(fl, 0);
+        return fl + 1;
+    }
+    if (lane == 0) {
+        if (lhSize == 3) { u32 const h = 2u + ((u32)(!single) << 2) + (litSize << 4) + (cLit << 14); dst[0] = (u8)h; dst[1] = (u8)(h >> 8); dst[2] = (u8)(h >> 16); }
+        else if (lhSize == 4) kx_st32(dst, 2u + (2u << 2) + (litSize << 4) + (cLit << 18));
+        else { kx_st32(dst, 2u + (3u << 2) + (litSize << 4) + (cLit << 22)); dst[4] = (u8)(cLit >> 10); }
+    }
+    return lhSize + cLit;
+}
+
+// ---- sequences -----------------------------------------------------------
+KX_DEV u32 kx_ll_code(u32 litLength)
+{
+    static const u8 LL_Code[64] = { 0,1,2,3,4,5,6,7, 8,9,10,11,12,13,14,15, 16,16,17,17,18,18,19,19,
+        20,20,20,20,21,21,21,21, 22,22,22,22,22,22,22,22, 23,23,23,23,23,23,23,23,
+        24,24,24,24,24,24,24,24, 24,24,24,24,24,24,24,24 };
+    return (litLength > 63) ? kx_hb32(litLength) + 19 : LL_Code[litLength];
+}
+KX_DEV u32 kx_ml_code(u32 mlBase)
+{
+    static const u8 ML_Code[128] = { 0,1,2,3,4,5,6,7, 8,9,10,11,12,13,14,15, 16,17,18,19,20,21,22,23, 24,25,26,27,28,29,30,31,
+        32,32,33,33,34,34,35,35, 36,36,36,36,37,37,37,37, 38,38,38,38,38,38,38,38, 39,39,39,39,39,39,39,39,
+        40,40,40,40,40,40,40,40, 40,40,40,40,40,40,40,40, 41,41,41,41,41,41,41,41, 41,41,41,41,41,41,41,41,
+        42,42,42,42,42,42,42,42, 42,42,42,42,42,42,42,42, 42,42,42,42,42,42,42,42, 42,42,42,42,42,42,42,42 };
+    return (mlBase > 127) ? kx_hb32(mlBase) + 36 : ML_Code[mlBase];
+}
+KX_DEV u32 kx_ll_bits(u32 c)
+{
+    static const u8 LL_bits[36] = { 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0, 1,1,1,1,2,2,3,3, 4,6,7,8,9,10,11,12, 13,14,15,16 };
+    return LL_bits[c];
+}
+KX_DEV u32 kx_ml_bits(u32 c)
+{
+    static const u8 ML_bits[53] = { 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0,
+        1,1,1,1,2,2,3,3, 4,4,5,7,8,9,10,11, 12,13,14,15,16 };
+    return ML_bits[c];
+}
+
+struct KSeqCodes { u32 ll, of, ml; };
+KX_DEV KSeqCodes kx_seq_codes(const KSeq& q, u32 idx, u32 longType, u32 longPos)
+{
+    KSeqCodes c;
+    c.ll = kx_ll_code(q.litLength); c.of = kx_hb32(q.offBase); c.ml = kx_ml_code(q.mlBase);
+    if (longType == 1 && idx == longPos) c.ll = 35;
+    if (longType == 2 && idx == longPos) c.ml = 52;
+    return c;
+}
+
+enum { KSET_BASIC = 0, KSET_RLE = 1, KSET_COMPRESSED = 2 };
+
+KX_DEV u32 kx_select_encoding(u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, bool isDefaultAllowed)
+{
+    if (mostFrequent == nbSeq) return (isDefaultAllowed && nbSeq <= 2) ? KSET_BASIC : KSET_RLE;
+    if (isDefaultAllowed) {
+        u32 const dynamicFse_nbSeq_min = ((1u << defaultNormLog) * 8u) >> 3;     // strategy dfast: mult = 10 - 2
+        if ((nbSeq < dynamicFse_nbSeq_min) || (mostFrequent < (nbSeq >> (defaultNormLog - 1)))) return KSET_BASIC;
+    }
+    return KSET_COMPRESSED;
+}
+
+// lane 0: choose the mode for one symbol type, write its table description at
+// op, build its encoding table. Returns header bytes (KXE_ERR on error).
+KX_DEV u32 kx_build_seq_table(KEntropyLds& lds, int t, u8* op, u32* count, u32 maxCode, u32 FSELog,
+                              u32 defaultNormLog, u32 defaultMax, u32 nbSeq, u32 lastCode, u32 firstCode,
+                              u32& typeOut, KFseCT& ct)
+{
+    static const short LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2, 2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
+    static const short ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,
+                                              1,1,1,1,1,1,1,1, 1,1,1,1,1,1,-1,-1, -1,-1,-1,-1,-1 };
+    static const short OF_defaultNorm[29] = { 1,1,1,1,1,1,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, -1,-1,-1,-1,-1 };
+    u32 max = maxCode, mostFrequent = 0;
+    while (max > 0 && !count[max]) max--;
+    for (u32 s = 0; s <= max; s++) if (count[s] > mostFrequent) mostFrequent = count[s];
+    bool const defaultAllowed = (t != 1) || (max <= 28);
+    u32 const type = kx_select_encoding(mostFrequent, nbSeq, defaultNormLog, defaultAllowed);
+    typeOut = type;
+    ct.state = lds.state[t]; ct.dnb = lds.dnb[t]; ct.dfs = lds.dfs[t];
+    if (type == KSET_RLE) { kfse_build_ctable_rle(ct, max); *op = (u8)firstCode; return 1; }
+    if (type == KSET_BASIC) {
+        const short* dn = (t == 0) ? LL_defaultNorm : (t == 1) ? OF_defaultNorm : ML_defaultNorm;
+        for (u32 s = 0; s <= defaultMax; s++) lds.norm[s] = dn[s];
+        kfse_build_ctable(ct, lds.norm, defaultMax, defaultNormLog, lds.cumul, lds.tsym);
+        return 0;
+    }
+    {
+        u32 nbSeq_1 = nbSeq;
+        u32 const tableLog = kfse_optimal_tablelog(FSELog, nbSeq, max, 2);
+        if (count[lastCode] > 1) { count[lastCode]--; nbSeq_1--; }
+        if (kfse_normalize(lds.norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048) == KXE_ERR) return KXE_ERR;
+        u32 const NCountSize = kfse_write_ncount(op, lds.norm, max, tableLog);
+        if (NCountSize == KXE_ERR) return KXE_ERR;
+        kfse_build_ctable(ct, lds.norm, max, tableLog, lds.cumul, lds.tsym);
+        return NCountSize;
+    }
+}
+
+// sequences section at dst; returns size, 0 => "emit a raw block instead"
+KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSeq, u32 longType, u32 longPos, int lane)
+{
+    u32 hdr = 0;
+    if (lane == 0) {
+        if (nbSeq < 128) { dst[0] = (u8)nbSeq; hdr = 1; }
+        else if (nbSeq < 0x7F00) { dst[0] = (u8)((nbSeq >> 8) + 0x80); dst[1] = (u8)nbSeq; hdr = 2; }
+        else { dst[0] = 0xFF; kx_st16(dst + 1, nbSeq - 0x7F00); hdr = 3; }
+    }
+    hdr = kx_shfl(hdr, 0);
+    if (nbSeq == 0) return hdr;
+    // code histograms: LL at [0,64), OF at [64,128), ML at [128,192)
+    for (int i = lane; i < 192; i += 64) lds.hist[i] = 0;
+    kx_sync();
+    for (u32 i = (u32)lane; i < nbSeq; i += 64) {
+        KSeqCodes const c = kx_seq_codes(seqs[i], i, longType, longPos);
+        kx_lds_inc(&lds.hist[c.ll]); kx_lds_inc(&lds.hist[64 + c.of]); kx_lds_inc(&lds.hist[128 + c.ml]);
+    }
+    kx_sync();
+    u32 total = 0; bool err = false; u32 lastCountSize = 0;
+    KFseCT ctLL, ctOF, ctML; u8* op = dst + hdr;
+    ctLL.state = lds.state[0]; ctLL.dnb = lds.dnb[0]; ctLL.dfs = lds.dfs[0]; ctLL.tableLog = 0;
+    ctOF.state = lds.state[1]; ctOF.dnb = lds.dnb[1]; ctOF.dfs = lds.dfs[1]; ctOF.tableLog = 0;
+    ctML.state = lds.state[2]; ctML.dnb = lds.dnb[2]; ctML.dfs = lds.dfs[2]; ctML.tableLog = 0;
+    if (lane == 0) {
+        u8* const seqHead = op++;
+        u32 tLL = 0, tOF = 0, tML = 0;
+        KSeqCodes const cl = kx_seq_codes(seqs[nbSeq - 1], nbSeq - 1, longType, longPos);
+        KSeqCodes const cf = kx_seq_codes(seqs[0], 0, longType, longPos);
+        {
+            u32 const sz = kx_build_seq_table(lds, 0, op, lds.hist, 35, 9, 6, 35, nbSeq, cl.ll, cf.ll, tLL, ctLL);
+            if (sz == KXE_ERR) err = true; else { if (tLL == KSET_COMPRESSED) lastCountSize = sz; op += sz; }
+        }
+        if (!err) {
+            u32 const sz = kx_build_seq_table(lds, 1, op, lds.hist + 64, 31, 8, 5, 28, nbSeq, cl.of, cf.of, tOF, ctOF);
+            if (sz == KXE_ERR) err = true; else { if (tOF == KSET_COMPRESSED) lastCountSize = sz; op += sz; }
+        }
+        if (!err) {
+            u32 const sz = kx_build_seq_table(lds, 2, op, lds.hist + 128, 52, 9, 6, 52, nbSeq, cl.ml, cf.ml, tML, ctML);
+            if (sz == KXE_ERR) err = true; else { if (tML == KSET_COMPRESSED) lastCountSize = sz; op += sz; }
+        }
+        *seqHead = (u8)((tLL << 6) + (tOF << 4) + (tML << 2));
+    }
+    // the tANS chain: all lanes stage 64 sequences (+codes) in LDS, lane 0 walks them last -> first
+    KBitW b; kbw_init(b, op); u8* const streamStart = op;
+    u32 stML = 0, stOF = 0, stLL = 0; bool started = false;
+    for (u32 hi = nbSeq; hi > 0; ) {
+        u32 const lo = hi > 64 ? hi - 64 : 0;
+        u32 const i = lo + (u32)lane;
+        if (i < hi) {
+            KSeq const q = seqs[i];
+            KSeqCodes const c = kx_seq_codes(q, i, longType, longPos);
+            lds.stage[3 * lane + 0] = q.offBase;
+            lds.stage[3 * lane + 1] = (u32)q.litLength | ((u32)q.mlBase << 16);
+            lds.stage[3 * lane + 2] = c.ll | (c.of << 8) | (c.ml << 16);
+        }
+        kx_sync();
+        if (lane == 0 && !err) {
+            for (u32 t = hi - lo; t-- > 0; ) {
+                u32 const offBase = lds.stage[3 * t], lm = lds.stage[3 * t + 1], cc = lds.stage[3 * t + 2];
+                u32 const llc = cc & 0xFF, ofc = (cc >> 8) & 0xFF, mlc = cc >> 16;
+                if (!started) {
+                    stML = kfse_init_state(ctML, mlc); stOF = kfse_init_state(ctOF, ofc); stLL = kfse_init_state(ctLL, llc);
+                    started = true;
+                } else {
+                    kfse_encode(b, ctOF, stOF, ofc);
+                    kfse_encode(b, ctML, stML, mlc);
+                    kfse_encode(b, ctLL, stLL, llc);
+                }
+                kbw_add(b, lm & 0xFFFFu, kx_ll_bits(llc));
+                kbw_add(b, lm >> 16, kx_ml_bits(mlc));
+                kbw_add(b, offBase, ofc);
+            }
+        }
+        kx_sync();
+        hi = lo;
+    }
+    if (lane == 0 && !err) {
+        kbw_add(b, stML, ctML.tableLog);
+        kbw_add(b, stOF, ctOF.tableLog);
+        kbw_add(b, stLL, ctLL.tableLog);
+        u32 const streamSize = kbw_close(b, streamStart);
+        if (!(lastCountSize && (lastCountSize + streamSize) < 4)) total = (u32)(streamStart + streamSize - dst);
+    }
+    total = kx_shfl(total, 0);
+    kx_sync();
+    return total;
+}
+
+// ---- one slice -> one frame ---------------------------------------------
+KX_DEV void zstd_entropy_slice(const KEntropyArgs& a, KEntropyLds& lds, u32 slice, int lane)
+{
+    const u8* const src = a.src + a.in_off[slice];
+    u32 const n = a.in_len[slice];
+    u8* const dst = a.dst + a.out_off[slice];
+    u32 const fh = kx_frame_header_size(n);
+    if (lane == 0) {
+        u32 const fcsCode = (n >= 256) + (n >= 65536 + 256);
+        kx_st32(dst, 0xFD2FB528u);
+        dst[4] = (u8)((1u << 5) + (fcsCode << 6));
+        if (fcsCode == 0) dst[5] = (u8)n;
+        else if (fcsCode == 1) kx_st16(dst + 5, n - 256);
+        else kx_st32(dst + 5, n);
+    }
+    u8* const bh = dst + fh; u8* const body = bh + 3;
+    if (n == 0) {
+        if (lane == 0) { bh[0] = 1; bh[1] = 0; bh[2] = 0; a.out_len[slice] = fh + 3; }
+        return;
+    }
+    u32 cSize = 0;
+    if (n >= 7) {
+        KSliceMeta const mm = a.meta[slice];
+        const KSeq* const seqs = a.seqs + (size_t)slice * a.seq_cap;
+        u8* const lits = a.lits + (size_t)slice * a.lit_cap;
+        u32 const litSize = mm.litSize + mm.lastLL;
+        // complete the literal buffer with the trailing literals
+        kx_wave_copy(lits + mm.litSize, src + (n - mm.lastLL), mm.lastLL, lane);
+        kx_sync();
+        bool const suspect = (mm.nbSeq == 0) || (litSize / mm.nbSeq >= 20);
+        u32 const litSec = kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane);
+        kx_sync();
+        u32 const seqSec = kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane);
+        if (seqSec != 0) {
+            cSize = litSec + seqSec;
+            if (cSize >= n - kx_min_gain(n)) cSize = 0;
+        }
+    }
+    kx_sync();
+    if (cSize == 0) {
+        kx_wave_copy(body, src, n, lane);
+        if (lane == 0) { u32 const h = 1u + (0u << 1) + (n << 3); bh[0] = (u8)h; bh[1] = (u8)(h >> 8); bh[2] = (u8)(h >> 16); a.out_len[slice] = fh + 3 + n; }
+    } else if (lane == 0) {
+        u32 const h = 1u + (2u << 1) + (cSize << 3); bh[0] = (u8)h; bh[1] = (u8)(h >> 8); bh[2] = (u8)(h >> 16);
+        a.out_len[slice] = fh + 3 + cSize;
+    }
+}
+
+KX_DEV void zstd_entropy_body(const KEntropyArgs& a)
+{
+    KX_SHARED KEntropyLds lds;
+    int const lane = kx_lane();
+    for (u32 slice = kx_block(); slice < a.n_slices; slice += kx_nblocks()) {
+        zstd_entropy_slice(a, lds, slice, lane);
+        kx_sync();
+    }
+}

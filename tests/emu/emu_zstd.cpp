@@ -1,0 +1,69 @@
+// TEST INFRASTRUCTURE: runs the product kernel bodies on the CPU wave emulator.
+#include "kx_wave.h"
+#include "emu_core.h"
+#include "zstd_match.h"
+#include <stdlib.h>
+#include <vector>
+
+extern "C" __attribute__((visibility("default")))
+int emu_zstd_match(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
+                   KSeq* seqs, u32 seq_cap, u8* lits, u32 lit_cap, KSliceMeta* meta, u32 start_epoch)
+{
+    u32 const nteams = nblocks * (64 / G);
+    std::vector<u32> tables((size_t)nteams * KX_TBL_ENTRIES, 0xDEADBEEFu & 0x0003FFFFu);   // stale junk with epoch 0
+    std::vector<u32> epoch(nteams, start_epoch);
+    u32 counter = 0;
+    KMatchArgs a;
+    a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
+    a.seqs = seqs; a.seq_cap = seq_cap; a.lits = lits; a.lit_cap = lit_cap; a.meta = meta;
+    a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter;
+    kxemu::failed = 0;
+    switch (G) {
+    case 8:  kxemu::launch(nblocks, [&]() { zstd_match_body<8>(a); }); break;
+    case 16: kxemu::launch(nblocks, [&]() { zstd_match_body<16>(a); }); break;
+    case 32: kxemu::launch(nblocks, [&]() { zstd_match_body<32>(a); }); break;
+    case 64: kxemu::launch(nblocks, [&]() { zstd_match_body<64>(a); }); break;
+    default: return -2;
+    }
+    return kxemu::failed ? -1 : 0;
+}
+
+#include "zstd_entropy.h"
+
+// Full compress pipeline (match kernel + entropy kernel) on the emulator.
+extern "C" __attribute__((visibility("default")))
+int emu_zstd_compress(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
+                      u8* dst, const u64* out_off, u32* out_len, u32 slice_cap)
+{
+    u32 const seq_cap = slice_cap / 4 + 8, lit_cap = slice_cap + 64, scratch_words = slice_cap / 4 + 64;
+    std::vector<KSeq> seqs((size_t)n * seq_cap);
+    std::vector<u8> lits((size_t)n * lit_cap);
+    std::vector<KSliceMeta> meta(n);
+    std::vector<u32> scratch((size_t)n * scratch_words, 0xA5A5A5A5u);
+    int r = emu_zstd_match(src, in_off, in_len, n, G, nblocks, seqs.data(), seq_cap, lits.data(), lit_cap, meta.data(), 7);
+    if (r) return r;
+    for (u32 i = 0; i < n; i++) if (meta[i].status) return -3;
+    KEntropyArgs e;
+    e.src = src; e.in_off = in_off; e.in_len = in_len; e.n_slices = n;
+    e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
+    e.scratch = scratch.data(); e.scratch_words = scratch_words;
+    e.dst = dst; e.out_off = out_off; e.out_len = out_len;
+    kxemu::failed = 0;
+    kxemu::launch(nblocks, [&]() { zstd_entropy_body(e); });
+    return kxemu::failed ? -1 : 0;
+}
+
+#include "zstd_decode.h"
+extern "C" __attribute__((visibility("default")))
+int emu_zstd_decompress(const u8* src, const u64* in_off, const u32* in_len, u32 n, u32 nblocks,
+                        u8* dst, const u64* out_off, const u32* out_cap, u32* out_len, u32* status, u32 lit_cap)
+{
+    std::vector<u8> lits((size_t)n * lit_cap, 0xEE);
+    KDecodeArgs d;
+    d.src = src; d.in_off = in_off; d.in_len = in_len; d.n_slices = n;
+    d.dst = dst; d.out_off = out_off; d.out_cap = out_cap; d.out_len = out_len; d.status = status;
+    d.lits = lits.data(); d.lit_cap = lit_cap;
+    kxemu::failed = 0;
+    kxemu::launch(nblocks, [&]() { zstd_decode_body(d); });
+    return kxemu::failed ? -1 : 0;
+}

@@ -1,0 +1,183 @@
+"""Shared test plumbing: seeded/special inputs, the oracle (CPU restatement,
+oracle/zstd_l3_ref.c), the optional live libzstd 1.5.7, and the CPU wave
+emulator build of the kernel bodies (tests/emu)."""
+import ctypes
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN_PATH = os.path.join(ROOT, "tests", "golden", "zstd_l3_golden.json")
+
+
+def special_inputs():
+    """Hand-made edge inputs (same dict tests/golden/make_golden.py used)."""
+    return {
+        "empty": b"",
+        "one_byte": b"a",
+        "hello": b"hello compression world",
+        "zeros_64k": bytes(65536),
+        "zeros_128k": bytes(131072),
+        "ab_64k": (b"ab" * 32768),
+        "abc_100": (b"abc" * 34)[:100],
+        "ramp_64k": bytes(range(256)) * 256,
+        "long_literals_then_match": bytes((i * 7 + (i >> 8) * 13) & 0xFF for i in range(70000)) + bytes(1000),
+        "all_same_but_last": bytes(65535) + b"\x01",
+        "two_symbols": bytes((0x41 if (i * 2654435761) & 0x10000 else 0x42) for i in range(65536)),
+    }
+
+
+def golden():
+    with open(GOLDEN_PATH) as fh:
+        return json.load(fh)
+
+
+def sha256(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+# ---------------------------------------------------------------- oracle ----
+_ORACLE = None
+
+
+def build_oracle():
+    src = os.path.join(ROOT, "oracle", "zstd_l3_ref.c")
+    out_dir = os.path.join(ROOT, "oracle", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(out_dir, "libkref.so")
+    if _newer(lib, [src]):
+        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-fvisibility=hidden", "-o", lib, src], check=True)
+    return lib
+
+
+class Oracle:
+    """ctypes view of the C restatement (test infrastructure only)."""
+
+    def __init__(self):
+        k = self.lib = ctypes.CDLL(build_oracle())
+        k.kref_zstd_l3_compress.restype = ctypes.c_size_t
+        k.kref_zstd_l3_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+        k.kref_compress_bound.restype = ctypes.c_size_t
+        k.kref_compress_bound.argtypes = [ctypes.c_size_t]
+        k.kref_zstd_l3_seqstore.restype = ctypes.c_size_t
+        k.kref_params_l3.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)]
+
+    def compress(self, d: bytes) -> bytes:
+        cap = self.lib.kref_compress_bound(len(d)) + 64
+        o = ctypes.create_string_buffer(cap)
+        n = self.lib.kref_zstd_l3_compress(o, cap, d, len(d))
+        if n == 2 ** 64 - 1:
+            raise RuntimeError("oracle: input outside the restatement's scope")
+        return o.raw[:n]
+
+    def params(self, n):
+        a = (ctypes.c_uint32 * 4)()
+        self.lib.kref_params_l3(n, a)
+        return tuple(a)
+
+
+def oracle():
+    global _ORACLE
+    if _ORACLE is None:
+        _ORACLE = Oracle()
+    return _ORACLE
+
+
+def live_libzstd():
+    """A libzstd 1.5.7 found on this machine, or None (never required)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        from libzstd_ref import LibZstd
+        return LibZstd()
+    except Exception:
+        return None
+
+
+# -------------------------------------------------------------- emulator ----
+_EMU = None
+
+
+def build_emu():
+    emu = os.path.join(ROOT, "tests", "emu")
+    csrc = os.path.join(ROOT, "kompressor_amd", "csrc")
+    lib = os.path.join(emu, "libkxemu.so")
+    srcs = [os.path.join(emu, f) for f in os.listdir(emu) if f.endswith((".cpp", ".h"))]
+    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
+    if _newer(lib, srcs):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I" + emu, "-I" + csrc, "-o", lib,
+                        os.path.join(emu, "emu_core.cpp"), os.path.join(emu, "emu_zstd.cpp")], check=True)
+    return lib
+
+
+def emu():
+    global _EMU
+    if _EMU is None:
+        _EMU = ctypes.CDLL(build_emu())
+    return _EMU
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def compress_bound(n):
+    return n + (n >> 8) + ((((128 << 10) - n) >> 11) if n < (128 << 10) else 0)
+
+
+def emu_compress(datas, G=8, nblocks=2):
+    """Run the match + entropy kernel bodies on the CPU wave emulator."""
+    n = len(datas)
+    lens = np.array([len(d) for d in datas], dtype=np.uint32)
+    offs = np.zeros(n, dtype=np.uint64)
+    pos = 0
+    for i, d in enumerate(datas):
+        offs[i] = pos
+        pos += len(d)
+    buf = np.zeros(pos + 64, dtype=np.uint8)
+    for i, d in enumerate(datas):
+        buf[int(offs[i]):int(offs[i]) + len(d)] = np.frombuffer(d, dtype=np.uint8)
+    cap = max([len(d) for d in datas] + [64])
+    stride = (compress_bound(cap) + 64 + 15) & ~15
+    out = np.zeros(n * stride, dtype=np.uint8)
+    ooff = np.arange(n, dtype=np.uint64) * stride
+    olen = np.zeros(n, dtype=np.uint32)
+    r = emu().emu_zstd_compress(_vp(buf), _vp(offs), _vp(lens), n, G, nblocks, _vp(out), _vp(ooff), _vp(olen), cap)
+    assert r == 0, f"emulator reported {r}"
+    return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
+
+
+def emu_decompress(frames, caps, nblocks=2):
+    n = len(frames)
+    lens = np.array([len(f) for f in frames], dtype=np.uint32)
+    offs = np.zeros(n, dtype=np.uint64)
+    pos = 16
+    for i, f in enumerate(frames):
+        offs[i] = pos
+        pos += (len(f) + 31) & ~15
+    buf = np.zeros(pos + 64, dtype=np.uint8)
+    for i, f in enumerate(frames):
+        buf[int(offs[i]):int(offs[i]) + len(f)] = np.frombuffer(f, dtype=np.uint8)
+    caps = np.array(caps, dtype=np.uint32)
+    ooff = np.zeros(n, dtype=np.uint64)
+    t = 0
+    for i in range(n):
+        ooff[i] = t
+        t += int(caps[i]) + 16
+    out = np.zeros(t + 64, dtype=np.uint8)
+    olen = np.zeros(n, dtype=np.uint32)
+    st = np.zeros(n, dtype=np.uint32)
+    r = emu().emu_zstd_decompress(_vp(buf), _vp(offs), _vp(lens), n, nblocks, _vp(out), _vp(ooff), _vp(caps), _vp(olen), _vp(st),
+                                  128 * 1024 + 64)
+    assert r == 0, f"emulator reported {r}"
+    return [out[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)], [int(x) for x in st]

@@ -1,0 +1,122 @@
+"""C-ABI surface + host logic, no GPU: the library loads and exports every
+symbol include/kompressor_hip.h declares; error names/numbers follow libzstd;
+the SliceTransform mirror obeys the reference's contract (its tests use a fake
+XOR codec: kompressor-kotlinx-io/src/jvmTest/.../XorSliceTransformTest.kt:67-77)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import helpers
+from kompressor_amd import _lib, build
+from kompressor_amd.slice_transform import ByteArraySlice, SliceTransform
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_all()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(helpers.ROOT, "include", "kompressor_hip.h")).read()
+    declared = set(re.findall(r"KMP_API[^;(]*?\b(kmp_\w+)\s*\(", hdr))
+    assert len(declared) >= 20
+    bound = {name for name, _, _ in _lib.SIGNATURES}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_error_convention_matches_libzstd(lib):
+    # numbering / names of libzstd 1.5.7 (ZSTD_getErrorName), so the reference's
+    # "Bad zstd result code ...: name" messages (ZstdCompressor.jvm.kt:45-51) are unchanged
+    names = {1: "Error (generic)", 10: "Unknown frame descriptor", 14: "Unsupported frame parameter",
+             20: "Data corruption detected", 22: "Restored data doesn't match checksum", 40: "Unsupported parameter",
+             42: "Parameter is out of bound", 60: "Operation not authorized at current processing stage",
+             64: "Allocation error : not enough memory", 70: "Destination buffer is too small", 72: "Src size is incorrect"}
+    for code, name in names.items():
+        v = (1 << 64) - code
+        assert lib.kmp_zstd_is_error(v) == 1
+        assert lib.kmp_zstd_get_error_name(v).decode() == name
+    for ok in (0, 1, 65536, (1 << 64) - 121):
+        assert lib.kmp_zstd_is_error(ok) == 0
+        assert lib.kmp_zstd_get_error_name(ok).decode() == "No error detected"
+    z = helpers.live_libzstd()
+    if z is not None:
+        for code in range(0, 125):
+            v = (1 << 64) - code
+            assert lib.kmp_zstd_get_error_name(v) == z.lib.ZSTD_getErrorName(ctypes.c_size_t(v)), code
+
+
+def test_compress_bound(lib):
+    for n, b in [(0, 64), (1, 64), (65536, 65824), (131072, 131584), (1 << 20, (1 << 20) + 4096)]:
+        assert lib.kmp_zstd_compress_bound(n) == b
+    z = helpers.live_libzstd()
+    if z is not None:
+        for n in [0, 5, 1000, 65536, 100000, 131072, 500000]:
+            assert lib.kmp_zstd_compress_bound(n) == z.lib.ZSTD_compressBound(n)
+
+
+def test_parameter_and_argument_errors_need_no_gpu(lib):
+    c = lib.kmp_zstd_create_cctx()
+    assert c
+    assert lib.kmp_zstd_cctx_set_parameter(c, 100, 3) == 0
+    assert lib.kmp_zstd_cctx_set_parameter(c, 100, 0) == 0              # 0 = default level = 3
+    assert lib.kmp_zstd_get_error_name(lib.kmp_zstd_cctx_set_parameter(c, 100, 19)).decode() == "Unsupported parameter"
+    assert lib.kmp_zstd_get_error_name(lib.kmp_zstd_cctx_set_parameter(c, 101, 20)).decode() == "Unsupported parameter"
+    assert lib.kmp_zstd_cctx_load_dictionary(c, None, 0) == 0
+    assert lib.kmp_zstd_is_error(lib.kmp_zstd_cctx_load_dictionary(c, b"abc", 3))
+    # cursor sanity (positions are absolute indices, Wrapper.cpp:101-110)
+    buf = ctypes.create_string_buffer(16)
+    dp, sp = ctypes.c_size_t(17), ctypes.c_size_t(0)
+    r = lib.kmp_zstd_compress_stream(c, buf, 16, ctypes.byref(dp), buf, 16, ctypes.byref(sp), 2)
+    assert lib.kmp_zstd_get_error_name(r).decode() == "Destination buffer is too small"
+    lib.kmp_zstd_free_cctx(c)
+    assert lib.kmp_batch_create(None, 0, 1, 65536, 8) == -2
+    h = ctypes.c_void_p()
+    assert lib.kmp_batch_create(ctypes.byref(h), 0, 1, 1 << 20, 8) == -3   # > 128 KiB slices: out of scope
+    assert b"128 KiB" in lib.kmp_last_error()
+
+
+class XorSliceTransform(SliceTransform):
+    """The reference's fake codec (XorSliceTransformTest.kt:67-77)."""
+
+    def transform(self, input, output, finish):     # noqa: A002
+        n = min(input.remaining_read, output.remaining_write)
+        for i in range(n):
+            output.data[output.write_start + i] = input.data[input.read_start + i] ^ 0x5A
+        input.read_start += n
+        output.write_start += n
+        output.insufficient = input.has_data
+
+
+def test_slice_transform_contract_with_fake_codec():
+    data = bytes((i * 31) & 0xFF for i in range(16 * 1024 + 3))
+    x = XorSliceTransform()
+    enc = x.transform_bytes(data)
+    assert enc == bytes(b ^ 0x5A for b in data)
+    assert x.transform_bytes(enc) == data
+    s = ByteArraySlice(8)
+    assert s.remaining_read == 0 and s.remaining_write == 8 and not s.has_data and not s.is_full
+    i = ByteArraySlice(bytearray(b"abcdef"))
+    x.transform(i, s, True)
+    assert i.read_start == 6 and s.write_start == 6 and not s.insufficient
+    i = ByteArraySlice(bytearray(b"0123456789"))
+    s = ByteArraySlice(4)
+    x.transform(i, s, True)
+    assert s.is_full and s.insufficient and i.remaining_read == 6
+    assert XorSliceTransform().transform_bytes(b"") == b""
+
+
+def test_product_modules_never_touch_the_oracle():
+    # the oracle (and any libzstd) is test infrastructure: nothing under kompressor_amd/ may load or call it
+    pkg = os.path.join(helpers.ROOT, "kompressor_amd")
+    banned = ("kref_", "libkref", "libzstd_ref", "import oracle", "from oracle", "dlopen", "find_library", "pillow.libs")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".c", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for b in banned:
+                    assert b not in txt, (f, b)

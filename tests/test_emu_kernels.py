@@ -1,0 +1,90 @@
+"""The kernel bodies (kompressor_amd/csrc/zstd_match.h, zstd_entropy.h,
+zstd_decode.h) executed lane for lane on the CPU wave emulator (tests/emu)
+against the golden vectors.  This is host-side coverage of the device
+algorithm; the -m gpu tests are the parity tests proper."""
+import base64
+
+import pytest
+
+import helpers
+from kompressor_amd import corpus
+
+
+@pytest.fixture(scope="module")
+def G():
+    return helpers.golden()
+
+
+@pytest.mark.parametrize("team", [8, 16, 64])
+def test_emulated_compress_matches_golden_64k(G, team):
+    rows = G["config1"][:16] if team == 8 else G["config1"][16:24]
+    S = 65536
+    first = rows[0][0]
+    buf = corpus.make(first, len(rows), S)
+    frames = helpers.emu_compress([buf[k * S:(k + 1) * S].tobytes() for k in range(len(rows))], G=team)
+    for (i, cls, flen, sha), f in zip(rows, frames):
+        assert len(f) == flen and helpers.sha256(f) == sha, f"slice {i} class {cls} team {team}"
+
+
+def test_emulated_compress_ladder_ragged_batch(G):
+    # one batch with every ladder size at once: ragged lengths, empty input, 128 KiB maximum
+    rows = [r for r in G["ladder"] if r["index"] in (1000, 1003)]
+    datas = []
+    for r in rows:
+        S, k = r["size"], r["index"] - 1000
+        datas.append(corpus.make(1000, 8, S)[k * S:(k + 1) * S].tobytes() if S else b"")
+    frames = helpers.emu_compress(datas, G=8, nblocks=3)
+    for r, f in zip(rows, frames):
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r
+
+
+def test_emulated_compress_specials(G):
+    sp = helpers.special_inputs()
+    rows = G["special"]
+    frames = helpers.emu_compress([sp[r["name"]] for r in rows], G=16)
+    for r, f in zip(rows, frames):
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r["name"]
+
+
+def test_emulated_decoder(G):
+    kat = base64.b64decode(G["reference_kats"]["zstd_sampleHello_frame_b64"])        # ZstdTest.kt:84-91
+    outs, st = helpers.emu_decompress([kat], [64])
+    assert st == [0] and outs[0].decode() == G["reference_kats"]["zstd_sampleHello_plain"]
+    # frames with a payload kept in the fixture
+    frames, plains = [], []
+    sp = helpers.special_inputs()
+    for r in G["special"]:
+        if "frame" in r:
+            frames.append(base64.b64decode(r["frame"]))
+            plains.append(sp[r["name"]])
+    outs, st = helpers.emu_decompress(frames, [max(len(p), 1) for p in plains])
+    assert st == [0] * len(frames)
+    assert outs == plains
+    # other levels and multi-block frames (treeless literals, repeat tables, window descriptor)
+    d = G["decode_only"]
+    outs, st = helpers.emu_decompress([base64.b64decode(r["frame"]) for r in d], [r["size"] for r in d])
+    for r, o, s in zip(d, outs, st):
+        assert s == 0 and helpers.sha256(o) == r["plain_sha256"], r["index"]
+
+
+def test_emulated_decoder_rejects_bad_frames(G):
+    good = base64.b64decode(next(r["frame"] for r in G["special"] if r["name"] == "ramp_64k"))
+    bad_magic = b"\x00" + good[1:]
+    truncated = good[:-3]
+    flipped = bytearray(good)
+    flipped[len(good) // 2] ^= 0x40
+    small_cap = good
+    outs, st = helpers.emu_decompress([bad_magic, truncated, bytes(flipped), small_cap], [65536, 65536, 65536, 100])
+    assert st[0] == 10                      # Unknown frame descriptor
+    assert st[1] in (20, 72)                # corruption / src size
+    assert st[2] != 0 or outs[2] != bytes(range(256)) * 256
+    assert st[3] == 70                      # Destination buffer is too small
+
+
+def test_emulated_roundtrip_property():
+    S = 40000
+    buf = corpus.make(7000, 8, S)
+    datas = [buf[k * S:(k + 1) * S].tobytes() for k in range(8)]
+    frames = helpers.emu_compress(datas, G=8)
+    outs, st = helpers.emu_decompress(frames, [S] * 8)
+    assert st == [0] * 8 and outs == datas

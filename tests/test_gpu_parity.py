@@ -1,0 +1,224 @@
+"""Parity tests proper: the HIP path, called through the C ABI
+(include/kompressor_hip.h), against the committed golden vectors, against the
+oracle on the same seeded inputs, and -- at BASELINE.json's full batch size --
+through size-independent properties (encode -> decode round trip, checksum of
+checksums).  Byte work: everything is bit-exact, no tolerance."""
+import base64
+import hashlib
+
+import numpy as np
+import pytest
+
+import helpers
+from kompressor_amd import corpus
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def G():
+    return helpers.golden()
+
+
+@pytest.fixture(scope="module")
+def batch():
+    from kompressor_amd.batch import ZstdBatch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    b = ZstdBatch(max_slices=4096, max_slice_bytes=131072)
+    yield b
+    b.close()
+
+
+def gpu_compress(batch, datas):
+    n = len(datas)
+    lens = np.array([len(d) for d in datas], dtype=np.int32)
+    offs = np.zeros(n, dtype=np.int64)
+    pos = 0
+    for i, d in enumerate(datas):
+        offs[i] = pos
+        pos += len(d)
+    host = np.zeros(pos + 64, dtype=np.uint8)
+    for i, d in enumerate(datas):
+        host[offs[i]:offs[i] + len(d)] = np.frombuffer(d, dtype=np.uint8)
+    src = torch.from_numpy(host).cuda()
+    dst, ooff, olen = batch.compress(src, torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda())
+    torch.cuda.synchronize()
+    dst, ooff, olen = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+    return [dst[ooff[i]:ooff[i] + olen[i]].tobytes() for i in range(n)]
+
+
+def gpu_decompress(batch, frames, caps):
+    n = len(frames)
+    lens = np.array([len(f) for f in frames], dtype=np.int32)
+    offs = np.zeros(n, dtype=np.int64)
+    pos = 16
+    for i, f in enumerate(frames):
+        offs[i] = pos
+        pos += (len(f) + 31) & ~15
+    host = np.zeros(pos + 64, dtype=np.uint8)
+    for i, f in enumerate(frames):
+        host[offs[i]:offs[i] + len(f)] = np.frombuffer(f, dtype=np.uint8)
+    cap = torch.tensor(caps, dtype=torch.int32).cuda()
+    dst, ooff, olen, st = batch.decompress(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(),
+                                           torch.from_numpy(lens).cuda(), cap)
+    torch.cuda.synchronize()
+    dst, ooff, olen, st = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy(), st.cpu().numpy()
+    return [dst[ooff[i]:ooff[i] + olen[i]].tobytes() for i in range(n)], [int(x) for x in st]
+
+
+def test_golden_config1_2048_slices(G, batch):
+    rows = G["config1"]
+    S = 65536
+    buf = corpus.make(0, len(rows), S)
+    frames = gpu_compress(batch, [buf[i * S:(i + 1) * S].tobytes() for i in range(len(rows))])
+    bad = [(i, cls) for (i, cls, flen, sha), f in zip(rows, frames) if len(f) != flen or helpers.sha256(f) != sha]
+    assert not bad, f"{len(bad)} of {len(rows)} frames differ from libzstd 1.5.7, first: {bad[:5]}"
+
+
+def test_golden_ladder_ragged_batch(G, batch):
+    rows = G["ladder"]
+    datas = []
+    for r in rows:
+        S, k = r["size"], r["index"] - 1000
+        datas.append(corpus.make(1000, 8, S)[k * S:(k + 1) * S].tobytes() if S else b"")
+    frames = gpu_compress(batch, datas)          # one ragged batch: sizes 0 .. 128 KiB mixed
+    for r, f in zip(rows, frames):
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r
+        if "frame" in r:
+            assert f == base64.b64decode(r["frame"])
+
+
+def test_golden_specials_and_config0(G, batch):
+    sp = helpers.special_inputs()
+    rows = G["special"]
+    frames = gpu_compress(batch, [sp[r["name"]] for r in rows])
+    for r, f in zip(rows, frames):
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r["name"]
+    d = corpus.make(0, 1, 131072, mix=ord("R")).tobytes()
+    f = gpu_compress(batch, [d])[0]
+    assert len(f) == 131084 and helpers.sha256(f) == G["config0"]["sha256"]
+
+
+@pytest.mark.parametrize("team", [8, 16, 32, 64])
+def test_every_team_width_against_oracle(team):
+    from kompressor_amd.batch import ZstdBatch
+    o = helpers.oracle()
+    b = ZstdBatch(max_slices=512, max_slice_bytes=65536, team_lanes=team)
+    S = 65536
+    buf = corpus.make(20000, 256, S)
+    datas = [buf[i * S:(i + 1) * S].tobytes() for i in range(256)]
+    datas += [buf[i * S:i * S + 1 + (i * 977) % 60000].tobytes() for i in range(128)]      # ragged
+    frames = gpu_compress(b, datas)
+    b.close()
+    for i, (d, f) in enumerate(zip(datas, frames)):
+        assert f == o.compress(d), f"team {team} slice {i} len {len(d)}"
+
+
+def test_repeated_calls_reuse_tables_without_clearing(batch):
+    # hash tables are epoch-tagged, never cleared: a second batch must not see the first one's entries
+    o = helpers.oracle()
+    S = 65536
+    for first in (30000, 30064, 30000):
+        buf = corpus.make(first, 64, S)
+        datas = [buf[i * S:(i + 1) * S].tobytes() for i in range(64)]
+        frames = gpu_compress(batch, datas)
+        for d, f in zip(datas, frames):
+            assert f == o.compress(d)
+
+
+def test_decoder_kat_and_golden_frames(G, batch):
+    kat = base64.b64decode(G["reference_kats"]["zstd_sampleHello_frame_b64"])      # reference ZstdTest.kt:84-91
+    outs, st = gpu_decompress(batch, [kat], [64])
+    assert st == [0] and outs[0].decode() == "hello compression world"
+    d = G["decode_only"]
+    outs, st = gpu_decompress(batch, [base64.b64decode(r["frame"]) for r in d], [r["size"] for r in d])
+    for r, o, s in zip(d, outs, st):
+        assert s == 0 and helpers.sha256(o) == r["plain_sha256"], r
+
+
+def test_decoder_error_codes(G, batch):
+    good = base64.b64decode(next(r["frame"] for r in G["special"] if r["name"] == "ramp_64k"))
+    flipped = bytearray(good)
+    flipped[len(good) // 2] ^= 0x40
+    outs, st = gpu_decompress(batch, [b"\x00" + good[1:], good[:-3], bytes(flipped), good, good], [65536, 65536, 65536, 100, 65536])
+    assert st[0] == 10 and st[1] in (20, 72) and st[3] == 70 and st[4] == 0
+    assert st[2] != 0 or outs[2] != bytes(range(256)) * 256
+    assert outs[4] == bytes(range(256)) * 256
+
+
+def test_full_batch_roundtrip_and_checksum_of_checksums():
+    """BASELINE.json configs[1] size: 65 536 x 64 KiB.  Properties that need no
+    per-frame oracle: decode(encode(x)) == x for every slice, and the 2 048
+    slices the golden manifest covers hash to the manifest's values inside the
+    big batch (so batch position does not change a frame)."""
+    from kompressor_amd.batch import ZstdBatch
+    G = helpers.golden()
+    n, S = 65536, 65536
+    b = ZstdBatch(max_slices=n, max_slice_bytes=S)
+    src = torch.empty(n * S, dtype=torch.uint8, device="cuda")
+    chunk = 4096
+    for c in range(0, n, chunk):
+        src[c * S:(c + chunk) * S] = torch.from_numpy(corpus.make(c, chunk, S)).cuda()
+    in_off = torch.arange(n, dtype=torch.int64, device="cuda") * S
+    in_len = torch.full((n,), S, dtype=torch.int32, device="cuda")
+    dst, ooff, olen = b.compress(src, in_off, in_len)
+    torch.cuda.synchronize()
+    lens = olen.cpu().numpy()
+    assert lens.min() >= 13 and lens.max() <= 65546
+    head = dst[: 2048 * b.out_stride].cpu().numpy()
+    for i, cls, flen, sha in G["config1"]:
+        f = head[i * b.out_stride:i * b.out_stride + lens[i]].tobytes()
+        assert len(f) == flen and helpers.sha256(f) == sha, i
+    cap = torch.full((n,), S, dtype=torch.int32, device="cuda")
+    out, o2, l2, st = b.decompress(dst, ooff, olen, cap, out_off=in_off)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum().item()) == 0
+    assert int((l2 != S).sum().item()) == 0
+    assert torch.equal(out[: n * S], src)
+    ratio = n * S / float(lens.astype(np.int64).sum())
+    assert 2.3 < ratio < 2.7, ratio
+    # dense packing helper: offsets are the exclusive scan, bytes unchanged
+    packed, offs = b.compact(dst, ooff, olen)
+    torch.cuda.synchronize()
+    offs = offs.cpu().numpy()
+    assert offs[0] == 0 and offs[-1] == lens.astype(np.int64).sum()
+    assert np.array_equal(np.diff(offs), lens.astype(np.int64))
+    for i in (0, 1, 777, n - 1):
+        a = packed[offs[i]:offs[i + 1]].cpu().numpy().tobytes()
+        assert a == dst[int(ooff[i]):int(ooff[i]) + int(lens[i])].cpu().numpy().tobytes()
+    b.close()
+
+
+def test_streaming_abi_one_shot_like_the_reference(G):
+    """ZstdCompressor(3).transform(bytes) / ZstdDecompressor().transform(frame) with the
+    reference's driver loop (SliceTransform.kt:33-45) over the C ABI."""
+    from kompressor_amd import ZstdCompressor, ZstdDecompressor
+    sp = helpers.special_inputs()
+    byname = {r["name"]: r for r in G["special"]}
+    for name in ("empty", "one_byte", "hello", "abc_100", "ramp_64k", "zeros_128k", "two_symbols"):
+        d = sp[name]
+        f = ZstdCompressor(compression_level=3).transform_bytes(d)
+        assert helpers.sha256(f) == byname[name]["sha256"], name
+        assert ZstdDecompressor().transform_bytes(f) == d
+    # configs[0]: 128 KiB random -> 131 084-byte frame (9 B header + raw block), 13 107-byte output chunks
+    d = corpus.make(0, 1, 131072, mix=ord("R")).tobytes()
+    f = ZstdCompressor(3).transform_bytes(d)
+    assert len(f) == 131084 and helpers.sha256(f) == G["config0"]["sha256"]
+    assert ZstdDecompressor().transform_bytes(f) == d
+    # tinySample (ZstdTest.kt:19-25): 9000 random bytes round trip
+    rnd = np.random.default_rng(1).integers(0, 256, 9000, dtype=np.uint8).tobytes()
+    c = ZstdCompressor(3)
+    assert ZstdDecompressor().transform_bytes(c.transform_bytes(rnd)) == rnd
+    # a context is reusable for the next slice once a frame is flushed
+    assert c.transform_bytes(sp["hello"]) == base64.b64decode(byname["hello"]["frame"])
+    # reference decode KAT through the streaming ABI
+    kat = base64.b64decode(G["reference_kats"]["zstd_sampleHello_frame_b64"])
+    assert ZstdDecompressor().transform_bytes(kat) == b"hello compression world"
+    # errors surface like the reference's IllegalStateException text
+    with pytest.raises(RuntimeError, match="Bad zstd result code -40: Unsupported parameter"):
+        ZstdCompressor(compression_level=19)
+    with pytest.raises(RuntimeError, match="Unknown frame descriptor"):
+        ZstdDecompressor().transform_bytes(b"\x00" * 32)
+    with pytest.raises(RuntimeError, match="Src size is incorrect"):
+        ZstdCompressor(3).transform_bytes(bytes(131073))          # multi-block slices: next round
