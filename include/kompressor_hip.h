@@ -101,7 +101,7 @@ typedef struct kmp_batch_ctx kmp_batch_ctx;
 
 /* Workspace for up to max_slices slices of up to max_slice_bytes each on HIP
  * device `device`.  team_lanes: lanes of a wave that cooperate on one slice in
- * the match kernel (8, 16, 32 or 64; 0 = default). */
+ * the match kernel (4, 8, 16, 32 or 64; 0 = default). */
 KMP_API int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_slices,
                              uint32_t max_slice_bytes, int team_lanes);
 KMP_API void kmp_batch_destroy(kmp_batch_ctx* ctx);

@@ -20,7 +20,7 @@
 // --------------------------------------------------------------------------
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match(KMatchArgs a) { zstd_match_body<G>(a); }
-__global__ __launch_bounds__(64) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
+__global__ __launch_bounds__(64, 3) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
 __global__ __launch_bounds__(64) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
 
 // exclusive prefix sum of u32 lengths into u64 offsets, single workgroup
@@ -92,7 +92,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     if (!out || max_slices == 0) { g_last_error = "kmp_batch_create: bad argument"; return KMP_ERR_ARG; }
     if (max_slice_bytes > KMP_MAX_SLICE_BYTES) { g_last_error = "kmp_batch_create: slices above 128 KiB are not supported"; return KMP_ERR_CAPACITY; }
     if (team_lanes == 0) team_lanes = (int)env_u32("KMP_TEAM_LANES", 8);
-    if (team_lanes != 8 && team_lanes != 16 && team_lanes != 32 && team_lanes != 64) { g_last_error = "team_lanes must be 8, 16, 32 or 64"; return KMP_ERR_ARG; }
+    if (team_lanes != 4 && team_lanes != 8 && team_lanes != 16 && team_lanes != 32 && team_lanes != 64) { g_last_error = "team_lanes must be 4, 8, 16, 32 or 64"; return KMP_ERR_ARG; }
     HIP_TRY(hipSetDevice(device));
     kmp_batch_ctx* c = new (std::nothrow) kmp_batch_ctx();
     if (!c) { g_last_error = "out of host memory"; return KMP_ERR_ARG; }
@@ -164,6 +164,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     u32 blocks = (n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], st));
     switch (c->G) {
+    case 4:  hipLaunchKernelGGL(k_zstd_match<4>, dim3(blocks), dim3(64), 0, st, m); break;
     case 8:  hipLaunchKernelGGL(k_zstd_match<8>, dim3(blocks), dim3(64), 0, st, m); break;
     case 16: hipLaunchKernelGGL(k_zstd_match<16>, dim3(blocks), dim3(64), 0, st, m); break;
     case 32: hipLaunchKernelGGL(k_zstd_match<32>, dim3(blocks), dim3(64), 0, st, m); break;

@@ -50,6 +50,7 @@ KX_DEV void kx_st16(u8* p, u32 v) { u16 x = (u16)v; __builtin_memcpy(p, &x, 2); 
 KX_DEV u32 kx_atomic_add(u32* p, u32 v) { return atomicAdd(p, v); }
 KX_DEV void kx_atomic_or(u32* p, u32 v) { atomicOr(p, v); }
 KX_DEV void kx_lds_inc(u32* p) { atomicAdd(p, 1u); }
+KX_DEV void kx_lds_or(u32* p, u32 v) { atomicOr(p, v); }
 
 // ---- bit tricks -------------------------------------------------------
 KX_DEV u32 kx_umulhi(u32 a, u32 b) { return __umulhi(a, b); }

@@ -32,18 +32,27 @@ struct KHNode { u32 count; u16 parent; u8 byte; u8 nbBits; };
 struct KEntropyLds {
     u32 hist[256];            // literal histogram / sequence-code histograms (3 x 64)
     u32 ct[256];              // Huffman code table: val | nbBits << 16
-    KHNode node[516];         // Huffman tree nodes ([0] is the sentinel before huffNode[0])
-    u32 rank[192];            // bucket sort positions: curr | base << 16
-    u32 qstack[40];           // explicit quicksort stack
-    u16 state[3][512];        // FSE next-state tables (LL, OF, ML) ; [0] reused for the weights
-    u32 dnb[3][64];           // FSE deltaNbBits
-    int dfs[3][64];           // FSE deltaFindState
-    short norm[64];
+    union {
+        struct {              // literal phase: Huffman tree construction
+            KHNode node[516]; // ([0] is the sentinel before huffNode[0])
+            u32 rank[192];    // bucket sort positions: curr | base << 16
+            u32 qstack[40];   // explicit quicksort stack
+        } huf;
+        struct {              // sequence phase (state[0]/dnb[0]/dfs[0] also serve the Huffman-weight FSE)
+            u16 state[3][512];   // FSE next-state tables (LL, OF, ML)
+            u32 dnb[3][64];      // FSE deltaNbBits
+            int dfs[3][64];      // FSE deltaFindState
+            u32 stage[64];       // codes of 64 staged sequences: ll | of << 8 | ml << 16
+            u32 sbits[3][64];    // per staged sequence and stream: state bits value | count << 16
+            u32 cbuf[192];       // bit assembly buffer of one 64-sequence chunk
+        } seq;
+    } u;
+    short norm[3][64];
+    u16 cumul[3][66];
+    u8 tsym[3][512];          // FSE spread scratch
+    u8 ncbuf[3][96];          // table descriptions of the three symbol types, before concatenation
     u32 cnt[64];
-    u16 cumul[66];
-    u8 tsym[512];             // FSE spread scratch
     u8 weight[256];
-    u32 stage[192];           // 64 staged sequences for the tANS walk
 };
 
 // ======================= lane-0 serial helpers ==========================
@@ -394,9 +403,9 @@ KX_DEV u32 khuf_set_max_height(KHNode* huffNode, u32 lastNonNull, u32 targetNbBi
 // builds lds.ct from lds.hist; returns the table's depth
 KX_DEV u32 khuf_build_ctable(KEntropyLds& lds, u32 maxSymbolValue, u32 maxNbBits)
 {
-    KHNode* const huffNode0 = lds.node; KHNode* const huffNode = huffNode0 + 1;
-    for (int i = 0; i < 516; i++) { KHNode z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; lds.node[i] = z; }
-    khuf_sort(huffNode, lds.hist, maxSymbolValue, lds.rank, lds.qstack);
+    KHNode* const huffNode0 = lds.u.huf.node; KHNode* const huffNode = huffNode0 + 1;
+    for (int i = 0; i < 516; i++) { KHNode z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; lds.u.huf.node[i] = z; }
+    khuf_sort(huffNode, lds.hist, maxSymbolValue, lds.u.huf.rank, lds.u.huf.qstack);
     int nonNullRank = (int)maxSymbolValue;
     while (huffNode[nonNullRank].count == 0) nonNullRank--;
     int lowS = nonNullRank, nodeNb = 256; int const nodeRoot = nodeNb + lowS - 1; int lowN = nodeNb, n;
@@ -445,10 +454,10 @@ KX_DEV u32 khuf_compress_weights(u8* dst, KEntropyLds& lds, u32 wtSize)
         if (maxCount == 1) return 0;
     }
     tableLog = kfse_optimal_tablelog(tableLog, wtSize, maxSymbolValue, 2);
-    if (kfse_normalize(lds.norm, tableLog, lds.cnt, wtSize, maxSymbolValue, 0) == KXE_ERR) return KXE_ERR;
-    { u32 const h = kfse_write_ncount(op, lds.norm, maxSymbolValue, tableLog); if (h == KXE_ERR) return KXE_ERR; op += h; }
-    KFseCT ct; ct.state = lds.state[0]; ct.dnb = lds.dnb[0]; ct.dfs = lds.dfs[0];
-    kfse_build_ctable(ct, lds.norm, maxSymbolValue, tableLog, lds.cumul, lds.tsym);
+    if (kfse_normalize(lds.norm[0], tableLog, lds.cnt, wtSize, maxSymbolValue, 0) == KXE_ERR) return KXE_ERR;
+    { u32 const h = kfse_write_ncount(op, lds.norm[0], maxSymbolValue, tableLog); if (h == KXE_ERR) return KXE_ERR; op += h; }
+    KFseCT ct; ct.state = lds.u.seq.state[0]; ct.dnb = lds.u.seq.dnb[0]; ct.dfs = lds.u.seq.dfs[0];
+    kfse_build_ctable(ct, lds.norm[0], maxSymbolValue, tableLog, lds.cumul[0], lds.tsym[0]);
     {
         KBitW b; const u8* ip = weightTable + wtSize; u32 s1, s2;
         if (wtSize <= 2) return 0;
@@ -707,40 +716,55 @@ KX_DEV u32 kx_select_encoding(u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, b
     return KSET_COMPRESSED;
 }
 
-// lane 0: choose the mode for one symbol type, write its table description at
-// op, build its encoding table. Returns header bytes (KXE_ERR on error).
-KX_DEV u32 kx_build_seq_table(KEntropyLds& lds, int t, u8* op, u32* count, u32 maxCode, u32 FSELog,
-                              u32 defaultNormLog, u32 defaultMax, u32 nbSeq, u32 lastCode, u32 firstCode,
+// one lane per symbol type (t = 0 LL, 1 OF, 2 ML): choose the mode, write the table
+// description into lds.ncbuf[t], build the encoding table. Returns description
+// bytes (KXE_ERR on error).
+KX_DEV u32 kx_build_seq_table(KEntropyLds& lds, int t, u32* count, u32 nbSeq, u32 lastCode, u32 firstCode,
                               u32& typeOut, KFseCT& ct)
 {
     static const short LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2, 2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
     static const short ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,
                                               1,1,1,1,1,1,1,1, 1,1,1,1,1,1,-1,-1, -1,-1,-1,-1,-1 };
     static const short OF_defaultNorm[29] = { 1,1,1,1,1,1,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, -1,-1,-1,-1,-1 };
+    u32 const maxCode = (t == 0) ? 35u : (t == 1) ? 31u : 52u;
+    u32 const FSELog = (t == 1) ? 8u : 9u;
+    u32 const defaultNormLog = (t == 1) ? 5u : 6u;
+    u32 const defaultMax = (t == 0) ? 35u : (t == 1) ? 28u : 52u;
+    u8* const op = lds.ncbuf[t]; short* const norm = lds.norm[t];
     u32 max = maxCode, mostFrequent = 0;
     while (max > 0 && !count[max]) max--;
     for (u32 s = 0; s <= max; s++) if (count[s] > mostFrequent) mostFrequent = count[s];
     bool const defaultAllowed = (t != 1) || (max <= 28);
     u32 const type = kx_select_encoding(mostFrequent, nbSeq, defaultNormLog, defaultAllowed);
     typeOut = type;
-    ct.state = lds.state[t]; ct.dnb = lds.dnb[t]; ct.dfs = lds.dfs[t];
+    ct.state = lds.u.seq.state[t]; ct.dnb = lds.u.seq.dnb[t]; ct.dfs = lds.u.seq.dfs[t]; ct.tableLog = 0;
     if (type == KSET_RLE) { kfse_build_ctable_rle(ct, max); *op = (u8)firstCode; return 1; }
     if (type == KSET_BASIC) {
         const short* dn = (t == 0) ? LL_defaultNorm : (t == 1) ? OF_defaultNorm : ML_defaultNorm;
-        for (u32 s = 0; s <= defaultMax; s++) lds.norm[s] = dn[s];
-        kfse_build_ctable(ct, lds.norm, defaultMax, defaultNormLog, lds.cumul, lds.tsym);
+        for (u32 s = 0; s <= defaultMax; s++) norm[s] = dn[s];
+        kfse_build_ctable(ct, norm, defaultMax, defaultNormLog, lds.cumul[t], lds.tsym[t]);
         return 0;
     }
     {
         u32 nbSeq_1 = nbSeq;
         u32 const tableLog = kfse_optimal_tablelog(FSELog, nbSeq, max, 2);
         if (count[lastCode] > 1) { count[lastCode]--; nbSeq_1--; }
-        if (kfse_normalize(lds.norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048) == KXE_ERR) return KXE_ERR;
-        u32 const NCountSize = kfse_write_ncount(op, lds.norm, max, tableLog);
+        if (kfse_normalize(norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048) == KXE_ERR) return KXE_ERR;
+        u32 const NCountSize = kfse_write_ncount(op, norm, max, tableLog);
         if (NCountSize == KXE_ERR) return KXE_ERR;
-        kfse_build_ctable(ct, lds.norm, max, tableLog, lds.cumul, lds.tsym);
+        kfse_build_ctable(ct, norm, max, tableLog, lds.cumul[t], lds.tsym[t]);
         return NCountSize;
     }
+}
+
+// OR `n` (<= 32) bits of v into the LDS bit buffer at bit position pos
+KX_DEV void kx_cbuf_put(u32* cbuf, u32 pos, u32 v, u32 n)
+{
+    if (n == 0) return;
+    u64 const x = ((u64)v & ((n >= 32) ? 0xFFFFFFFFull : ((1ull << n) - 1ull))) << (pos & 31u);
+    u32 const w = pos >> 5;
+    kx_lds_or(&cbuf[w], (u32)x);
+    if ((u32)(x >> 32)) kx_lds_or(&cbuf[w + 1], (u32)(x >> 32));
 }
 
 // sequences section at dst; returns size, 0 => "emit a raw block instead"
@@ -762,74 +786,109 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
         kx_lds_inc(&lds.hist[c.ll]); kx_lds_inc(&lds.hist[64 + c.of]); kx_lds_inc(&lds.hist[128 + c.ml]);
     }
     kx_sync();
-    u32 total = 0; bool err = false; u32 lastCountSize = 0;
-    KFseCT ctLL, ctOF, ctML; u8* op = dst + hdr;
-    ctLL.state = lds.state[0]; ctLL.dnb = lds.dnb[0]; ctLL.dfs = lds.dfs[0]; ctLL.tableLog = 0;
-    ctOF.state = lds.state[1]; ctOF.dnb = lds.dnb[1]; ctOF.dfs = lds.dfs[1]; ctOF.tableLog = 0;
-    ctML.state = lds.state[2]; ctML.dnb = lds.dnb[2]; ctML.dfs = lds.dfs[2]; ctML.tableLog = 0;
-    if (lane == 0) {
-        u8* const seqHead = op++;
-        u32 tLL = 0, tOF = 0, tML = 0;
+    // the three tables, one lane each
+    KFseCT ct; ct.state = lds.u.seq.state[0]; ct.dnb = lds.u.seq.dnb[0]; ct.dfs = lds.u.seq.dfs[0]; ct.tableLog = 0;
+    u32 mySz = 0, myType = 0;
+    {
         KSeqCodes const cl = kx_seq_codes(seqs[nbSeq - 1], nbSeq - 1, longType, longPos);
         KSeqCodes const cf = kx_seq_codes(seqs[0], 0, longType, longPos);
-        {
-            u32 const sz = kx_build_seq_table(lds, 0, op, lds.hist, 35, 9, 6, 35, nbSeq, cl.ll, cf.ll, tLL, ctLL);
-            if (sz == KXE_ERR) err = true; else { if (tLL == KSET_COMPRESSED) lastCountSize = sz; op += sz; }
+        if (lane < 3) {
+            u32 const lastCode = lane == 0 ? cl.ll : lane == 1 ? cl.of : cl.ml;
+            u32 const firstCode = lane == 0 ? cf.ll : lane == 1 ? cf.of : cf.ml;
+            mySz = kx_build_seq_table(lds, lane, lds.hist + 64 * lane, nbSeq, lastCode, firstCode, myType, ct);
         }
-        if (!err) {
-            u32 const sz = kx_build_seq_table(lds, 1, op, lds.hist + 64, 31, 8, 5, 28, nbSeq, cl.of, cf.of, tOF, ctOF);
-            if (sz == KXE_ERR) err = true; else { if (tOF == KSET_COMPRESSED) lastCountSize = sz; op += sz; }
-        }
-        if (!err) {
-            u32 const sz = kx_build_seq_table(lds, 2, op, lds.hist + 128, 52, 9, 6, 52, nbSeq, cl.ml, cf.ml, tML, ctML);
-            if (sz == KXE_ERR) err = true; else { if (tML == KSET_COMPRESSED) lastCountSize = sz; op += sz; }
-        }
-        *seqHead = (u8)((tLL << 6) + (tOF << 4) + (tML << 2));
     }
-    // the tANS chain: all lanes stage 64 sequences (+codes) in LDS, lane 0 walks them last -> first
-    KBitW b; kbw_init(b, op); u8* const streamStart = op;
-    u32 stML = 0, stOF = 0, stLL = 0; bool started = false;
+    kx_sync();
+    u32 const sz0 = kx_shfl(mySz, 0), sz1 = kx_shfl(mySz, 1), sz2 = kx_shfl(mySz, 2);
+    u32 const ty0 = kx_shfl(myType, 0), ty1 = kx_shfl(myType, 1), ty2 = kx_shfl(myType, 2);
+    u32 const tl0 = kx_shfl(ct.tableLog, 0), tl1 = kx_shfl(ct.tableLog, 1), tl2 = kx_shfl(ct.tableLog, 2);
+    if (sz0 == KXE_ERR || sz1 == KXE_ERR || sz2 == KXE_ERR) return 0;
+    u8* op = dst + hdr;
+    if (lane == 0) *op = (u8)((ty0 << 6) + (ty1 << 4) + (ty2 << 2));
+    op++;
+    if ((u32)lane < sz0) op[lane] = lds.ncbuf[0][lane];
+    if ((u32)lane < sz1) op[sz0 + lane] = lds.ncbuf[1][lane];
+    if ((u32)lane < sz2) op[sz0 + sz1 + lane] = lds.ncbuf[2][lane];
+    if ((u32)lane + 64 < sz0) op[lane + 64] = lds.ncbuf[0][lane + 64];
+    if ((u32)lane + 64 < sz1) op[sz0 + lane + 64] = lds.ncbuf[1][lane + 64];
+    if ((u32)lane + 64 < sz2) op[sz0 + sz1 + lane + 64] = lds.ncbuf[2][lane + 64];
+    op += sz0 + sz1 + sz2;
+    u32 const lastCountSize = (ty2 == KSET_COMPRESSED) ? sz2 : (ty1 == KSET_COMPRESSED) ? sz1 : (ty0 == KSET_COMPRESSED) ? sz0 : 0;
+
+    // tANS bitstream. Per 64-sequence chunk (walked last -> first): every lane stages one
+    // sequence's codes; lanes 0..2 run the LL / OF / ML state chains; then every lane packs
+    // its sequence's bits into an LDS buffer at a scanned bit offset; whole words go out.
+    u8* const streamStart = op;
+    u32* const cbuf = lds.u.seq.cbuf;
+    for (int i = lane; i < 192; i += 64) cbuf[i] = 0;
+    u32 state = 0; bool started = false; u32 bitpos = 0;
     for (u32 hi = nbSeq; hi > 0; ) {
-        u32 const lo = hi > 64 ? hi - 64 : 0;
-        u32 const i = lo + (u32)lane;
-        if (i < hi) {
-            KSeq const q = seqs[i];
-            KSeqCodes const c = kx_seq_codes(q, i, longType, longPos);
-            lds.stage[3 * lane + 0] = q.offBase;
-            lds.stage[3 * lane + 1] = (u32)q.litLength | ((u32)q.mlBase << 16);
-            lds.stage[3 * lane + 2] = c.ll | (c.of << 8) | (c.ml << 16);
+        u32 const cnt = hi > 64 ? 64u : hi;
+        bool const valid = (u32)lane < cnt;
+        KSeq q; q.offBase = 1; q.litLength = 0; q.mlBase = 0; KSeqCodes c; c.ll = 0; c.of = 0; c.ml = 0;
+        if (valid) {
+            u32 const idx = hi - 1 - (u32)lane;            // lane order == stream order
+            q = seqs[idx]; c = kx_seq_codes(q, idx, longType, longPos);
+            lds.u.seq.stage[lane] = c.ll | (c.of << 8) | (c.ml << 16);
         }
         kx_sync();
-        if (lane == 0 && !err) {
-            for (u32 t = hi - lo; t-- > 0; ) {
-                u32 const offBase = lds.stage[3 * t], lm = lds.stage[3 * t + 1], cc = lds.stage[3 * t + 2];
-                u32 const llc = cc & 0xFF, ofc = (cc >> 8) & 0xFF, mlc = cc >> 16;
-                if (!started) {
-                    stML = kfse_init_state(ctML, mlc); stOF = kfse_init_state(ctOF, ofc); stLL = kfse_init_state(ctLL, llc);
-                    started = true;
-                } else {
-                    kfse_encode(b, ctOF, stOF, ofc);
-                    kfse_encode(b, ctML, stML, mlc);
-                    kfse_encode(b, ctLL, stLL, llc);
+        if (lane < 3) {
+            u32 const sh = 8u * (u32)lane;
+            for (u32 s = 0; s < cnt; s++) {
+                u32 const code = (lds.u.seq.stage[s] >> sh) & 0xFFu;
+                if (!started) { state = kfse_init_state(ct, code); lds.u.seq.sbits[lane][s] = 0; started = true; }
+                else {
+                    u32 const nb = (state + ct.dnb[code]) >> 16;
+                    lds.u.seq.sbits[lane][s] = (state & ((1u << nb) - 1u)) | (nb << 16);
+                    state = ct.state[(state >> nb) + ct.dfs[code]];
                 }
-                kbw_add(b, lm & 0xFFFFu, kx_ll_bits(llc));
-                kbw_add(b, lm >> 16, kx_ml_bits(mlc));
-                kbw_add(b, offBase, ofc);
             }
         }
         kx_sync();
-        hi = lo;
+        u32 const sLL = valid ? lds.u.seq.sbits[0][lane] : 0u, sOF = valid ? lds.u.seq.sbits[1][lane] : 0u, sML = valid ? lds.u.seq.sbits[2][lane] : 0u;
+        u32 const nLL = sLL >> 16, nOF = sOF >> 16, nML = sML >> 16;
+        u32 const llb = valid ? kx_ll_bits(c.ll) : 0u, mlb = valid ? kx_ml_bits(c.ml) : 0u, ofb = valid ? c.of : 0u;
+        u32 const mybits = nLL + nOF + nML + llb + mlb + ofb;
+        u32 v = mybits;                                           // inclusive prefix sum over lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { u32 const t = kx_shfl(v, lane - o); if (lane >= o) v += t; }
+        u32 const total = kx_shfl(v, 63);
+        u32 pos = (bitpos & 31u) + (v - mybits);
+        if (valid) {
+            // order inside a sequence: OF state, ML state, LL state, LL extra, ML extra, OF extra
+            u32 const a = (sOF & 0xFFFFu) | ((sML & 0xFFFFu) << nOF) | ((sLL & 0xFFFFu) << (nOF + nML));
+            kx_cbuf_put(cbuf, pos, a, nOF + nML + nLL); pos += nOF + nML + nLL;
+            kx_cbuf_put(cbuf, pos, q.litLength, llb); pos += llb;
+            kx_cbuf_put(cbuf, pos, q.mlBase, mlb); pos += mlb;
+            kx_cbuf_put(cbuf, pos, q.offBase, ofb);
+        }
+        kx_sync();
+        u32 const nbits = (bitpos & 31u) + total; u32 const nfull = nbits >> 5;
+        u8* const wbase = streamStart + 4u * (bitpos >> 5);
+        for (u32 w = (u32)lane; w < nfull; w += 64) kx_st32(wbase + 4u * w, cbuf[w]);
+        u32 const carry = cbuf[nfull];
+        kx_sync();
+        for (u32 w = (u32)lane; w <= nfull; w += 64) cbuf[w] = (w == 0) ? carry : 0u;
+        kx_sync();
+        bitpos += total;
+        hi -= cnt;
     }
-    if (lane == 0 && !err) {
-        kbw_add(b, stML, ctML.tableLog);
-        kbw_add(b, stOF, ctOF.tableLog);
-        kbw_add(b, stLL, ctLL.tableLog);
-        u32 const streamSize = kbw_close(b, streamStart);
-        if (!(lastCountSize && (lastCountSize + streamSize) < 4)) total = (u32)(streamStart + streamSize - dst);
+    // final states (ML, OF, LL) then the end mark
+    {
+        u32 const base = bitpos & 31u;
+        if (lane == 2) kx_cbuf_put(cbuf, base, state, tl2);
+        if (lane == 1) kx_cbuf_put(cbuf, base + tl2, state, tl1);
+        if (lane == 0) { kx_cbuf_put(cbuf, base + tl2 + tl1, state, tl0); kx_cbuf_put(cbuf, base + tl2 + tl1 + tl0, 1u, 1u); }
+        kx_sync();
+        u32 const endbits = bitpos + tl2 + tl1 + tl0 + 1;
+        u32 const streamSize = (endbits + 7) >> 3;
+        u8* const wbase = streamStart + 4u * (bitpos >> 5);
+        u32 const tailBytes = streamSize - 4u * (bitpos >> 5);
+        if ((u32)lane < tailBytes) wbase[lane] = (u8)(cbuf[lane >> 2] >> (8 * (lane & 3)));
+        kx_sync();
+        if (lastCountSize && (lastCountSize + streamSize) < 4) return 0;
+        return (u32)(streamStart + streamSize - dst);
     }
-    total = kx_shfl(total, 0);
-    kx_sync();
-    return total;
 }
 
 // ---- one slice -> one frame ---------------------------------------------

@@ -43,6 +43,7 @@ KX_DEV void kx_st16(u8* p, u32 v) { u16 x = (u16)v; memcpy(p, &x, 2); }
 KX_DEV u32 kx_atomic_add(u32* p, u32 v) { u32 o = *p; *p = o + v; return o; }
 KX_DEV void kx_atomic_or(u32* p, u32 v) { *p |= v; }
 KX_DEV void kx_lds_inc(u32* p) { *p += 1; }
+KX_DEV void kx_lds_or(u32* p, u32 v) { *p |= v; }
 
 KX_DEV u32 kx_umulhi(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
 KX_DEV u32 kx_ctz32(u32 v) { return (u32)__builtin_ctz(v); }

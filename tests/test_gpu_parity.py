@@ -100,7 +100,7 @@ def test_golden_specials_and_config0(G, batch):
     assert len(f) == 131084 and helpers.sha256(f) == G["config0"]["sha256"]
 
 
-@pytest.mark.parametrize("team", [8, 16, 32, 64])
+@pytest.mark.parametrize("team", [4, 8, 16, 32, 64])
 def test_every_team_width_against_oracle(team):
     from kompressor_amd.batch import ZstdBatch
     o = helpers.oracle()
