@@ -183,7 +183,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: {n} x 64 KiB seeded mixed slices per GPU (T/X/S/B/D/I/Z/R classes), "
                                    "ZstdCompressor(level=3) one-shot frames, bit-identical to libzstd 1.5.7",
                        "slices_per_gpu": n, "slice_bytes": SLICE, "ratio": round(in_bytes / frame_bytes, 4),
-                       "team_lanes": b.lib and (args.team or int(os.environ.get("KMP_TEAM_LANES", "8"))), "parallelism": f"slice-sharded x{world}"},
+                       "team_lanes": b.lib and (args.team or int(os.environ.get("KMP_TEAM_LANES", "4"))), "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_zstd_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms_match, 3)},

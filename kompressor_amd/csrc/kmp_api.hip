@@ -91,7 +91,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
 {
     if (!out || max_slices == 0) { g_last_error = "kmp_batch_create: bad argument"; return KMP_ERR_ARG; }
     if (max_slice_bytes > KMP_MAX_SLICE_BYTES) { g_last_error = "kmp_batch_create: slices above 128 KiB are not supported"; return KMP_ERR_CAPACITY; }
-    if (team_lanes == 0) team_lanes = (int)env_u32("KMP_TEAM_LANES", 8);
+    if (team_lanes == 0) team_lanes = (int)env_u32("KMP_TEAM_LANES", 4);
     if (team_lanes != 4 && team_lanes != 8 && team_lanes != 16 && team_lanes != 32 && team_lanes != 64) { g_last_error = "team_lanes must be 4, 8, 16, 32 or 64"; return KMP_ERR_ARG; }
     HIP_TRY(hipSetDevice(device));
     kmp_batch_ctx* c = new (std::nothrow) kmp_batch_ctx();
@@ -99,7 +99,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     memset(c, 0, sizeof(*c));
     c->device = device; c->max_slices = max_slices; c->max_slice_bytes = max_slice_bytes < 64 ? 64 : max_slice_bytes; c->G = team_lanes;
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
-    u32 const waves_per_cu = env_u32("KMP_MATCH_WAVES_PER_CU", 16);
+    u32 const waves_per_cu = env_u32("KMP_MATCH_WAVES_PER_CU", 12);
     u32 const teams_per_wave = 64 / (u32)team_lanes;
     u32 blocks = (u32)prop.multiProcessorCount * waves_per_cu;
     u32 const need = (max_slices + teams_per_wave - 1) / teams_per_wave;
@@ -159,7 +159,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     KMatchArgs m;
     m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
     m.seqs = c->seqs; m.seq_cap = c->seq_cap; m.lits = c->lits; m.lit_cap = c->lit_cap; m.meta = c->meta;
-    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter;
+    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter; m.flags = env_u32("KMP_MATCH_FLAGS", 2);
     u32 const tpw = 64 / (u32)c->G;
     u32 blocks = (n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], st));

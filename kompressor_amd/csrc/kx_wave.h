@@ -47,6 +47,8 @@ KX_DEV void kx_st64(u8* p, u64 v) { __builtin_memcpy(p, &v, 8); }
 KX_DEV void kx_st32(u8* p, u32 v) { __builtin_memcpy(p, &v, 4); }
 KX_DEV void kx_st16(u8* p, u32 v) { u16 x = (u16)v; __builtin_memcpy(p, &x, 2); }
 
+KX_DEV u32 kx_ld_nt(const u32* p) { return __builtin_nontemporal_load(p); }
+KX_DEV void kx_st_nt(u32* p, u32 v) { __builtin_nontemporal_store(v, p); }
 KX_DEV u32 kx_atomic_add(u32* p, u32 v) { return atomicAdd(p, v); }
 KX_DEV void kx_atomic_or(u32* p, u32 v) { atomicOr(p, v); }
 KX_DEV void kx_lds_inc(u32* p) { atomicAdd(p, 1u); }

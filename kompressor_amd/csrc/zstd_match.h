@@ -29,6 +29,7 @@ struct KMatchArgs {
     u32* tables;                     // per team: KX_TBL_ENTRIES
     u32* team_epoch;                 // per team
     u32* counter;                    // work queue head (zeroed by the host)
+    u32 flags;                       // experiment switches: 1 = non-temporal table loads, 2 = non-temporal table stores
 };
 
 enum { KST_IDLE = 0, KST_SEARCH = 1, KST_REPCHECK = 2, KST_MATCH = 3, KST_CLEANUP = 4, KST_DONE = 5 };
@@ -196,7 +197,9 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             if (prov) {
                 w = kx_ld64(src + pos);
                 hl = kx_hash_long(w, hbL); hs = kx_hash_short(w, hbS, mls);
-                el = L[hl]; es = S[hs];
+                // the lane after the last candidate only provides the long-table lookup of "ip1"
+                if (a.flags & 1u) { el = kx_ld_nt(&L[hl]); if (cand) es = kx_ld_nt(&S[hs]); }
+                else { el = L[hl]; if (cand) es = S[hs]; }
             }
             u32 idxl = ((el & ~KX_IDX_MASK) == tag) ? (el & KX_IDX_MASK) : 0u;
             u32 idxs = ((es & ~KX_IDX_MASK) == tag) ? (es & KX_IDX_MASK) : 0u;
@@ -245,8 +248,8 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             }
             if (ins) {
                 u32 const v = tag | (u32)(pos + 2);
-                if (!supL) L[hl] = v;
-                if (!supS) S[hs] = v;
+                if (a.flags & 2u) { if (!supL) kx_st_nt(&L[hl], v); if (!supS) kx_st_nt(&S[hs], v); }
+                else { if (!supL) L[hl] = v; if (!supS) S[hs] = v; }
             }
 
             // winner data, broadcast inside the team
