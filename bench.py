@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--slices", type=int, default=65536, help="slices per GPU (BASELINE configs[1]: 65536)")
     ap.add_argument("--team", type=int, default=0, help="lanes per slice in the match kernel (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--mode", choices=["compress", "decompress"], default="compress",
+                    help="compress = BASELINE configs[1] (the headline); decompress = configs[2] over the same frames")
     args = ap.parse_args()
 
     import numpy as np
@@ -161,6 +163,38 @@ def main():
     lens = out_len.cpu().numpy().astype(np.int64)
     frame_bytes = int(lens.sum())
     in_bytes = n * SLICE
+    if args.mode == "decompress":
+        # configs[2]: ZstdDecompressor over the level-3 frames just produced (strided layout), decoded in place of a fresh buffer
+        cap = torch.full((n,), SLICE, dtype=torch.int32, device=dev)
+        back = torch.empty(n * SLICE + 64, dtype=torch.uint8, device=dev)
+        for _ in range(args.warmup):
+            b.decompress(dst, out_off, out_len, cap, dst=back, out_off=in_off)
+        fence()
+        kd = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            _, _, l2, st = b.decompress(dst, out_off, out_len, cap, dst=back, out_off=in_off)
+            kd.append(b.last_kernel_ms(2))
+        fence()
+        dt = time.perf_counter() - t0
+        ok = bool(int(st.abs().sum().item()) == 0 and torch.equal(back[: n * SLICE], src))
+        if rank == 0:
+            ms_dec = float(np.mean(kd))
+            algo = in_bytes + frame_bytes + 16 * n
+            print(json.dumps({
+                "metric": "zstd decompression throughput, level-3 frames of 64 KiB slices (decoded bytes per second)",
+                "value": round(world * in_bytes / (dt / args.steps) / 1e9, 3), "unit": "GB/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                "config": {"workload": f"BASELINE configs[2]: ZstdDecompressor over the {n} level-3 frames of configs[1]", "roundtrip_ok": ok},
+                "roofline": {"bound": "hbm", "kernel": "k_zstd_decode", "achieved": round(algo / (ms_dec * 1e-3) / 1e9, 2),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (ms_dec * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None},
+                "kernels_ms": {"k_zstd_decode": round(ms_dec, 3)}}), flush=True)
+        b.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * in_bytes / (dt / args.steps) / 1e9

@@ -196,9 +196,9 @@ extern "C" int kmp_zstd_decompress_batch(kmp_batch_ctx* c, const void* d_src, co
     KDecodeArgs d;
     d.src = (const u8*)d_src; d.in_off = d_in_off; d.in_len = d_in_len; d.n_slices = n;
     d.dst = (u8*)d_dst; d.out_off = d_out_off; d.out_cap = d_out_cap; d.out_len = d_out_len; d.status = d_status;
-    d.lits = c->lits; d.lit_cap = c->lit_cap;
+    d.lits = c->lits; d.lit_cap = c->lit_cap; d.flags = env_u32("KMP_DECODE_FLAGS", 0);
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[4], st));
-    hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), env_u32("KMP_DECODE_PAD_LDS", 0), st, d);   // padding = occupancy experiment only
     HIP_TRY(hipGetLastError());
     if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[5], st)); c->ev_valid[2] = 1; }
     return KMP_OK;

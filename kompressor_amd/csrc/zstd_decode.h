@@ -20,21 +20,34 @@ struct KDecodeArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
     u8* dst; const u64* out_off; const u32* out_cap; u32* out_len; u32* status;
     u8* lits; u32 lit_cap;                 // per frame: decoded literals of one block
+    u32 flags;                             // timing-only ablations (results wrong): 1 skip Huffman walk, 2 skip sequences, 4 skip copies
 };
 
 enum { KZE_GENERIC = 1, KZE_PREFIX = 10, KZE_FRAMEPARAM = 14, KZE_WINDOW = 16, KZE_CORRUPT = 20, KZE_CHECKSUM = 22,
        KZE_LITHDR = 24, KZE_DICT = 32, KZE_DSTSMALL = 70, KZE_SRCSIZE = 72 };
 
 struct KDecodeLds {
-    u16 huf[4096];          // Huffman decoding table: symbol | nbBits << 8
-    u32 fse[3][512];        // LL, OF, ML: newStateBase | nbBits << 16 | symbol << 24
+    union {                     // phase-shared region (4 KiB)
+        u16 huf[2048];          // literal phase: Huffman decoding table (depth <= 11, RFC 8878): symbol | nbBits << 8
+        struct {                // table construction (weights' FSE table, spread scratch)
+            u32 tmp32[512];
+            u8 tsym[512];
+        } b;
+        struct {                // sequence phase
+            u32 sbuf[512];      // staged words of the sequence bitstream (2 zero words + 510)
+            u32 stage[194];     // 64 x (litLength, matchLength, offset) + error flag
+        } q;
+    } u;
+    u32 fseLL[512];             // sequence decoding tables: newStateBase | nbBits << 16 | code << 24
+    u32 fseML[512];
+    u32 fseOF[256];
+    u32 llx[36];                // per code: baseValue | extraBits << 24
+    u32 mlx[53];
     short norm[64];
     u16 symnext[64];
-    u8 tsym[512];
-    u8 weights[256];
+    u8 weights[256];            // kept so a tree-less block can rebuild the Huffman table
     u32 rank[16];
-    u32 stage[194];         // 64 x (litLength, matchLength, offset) + count + error
-    u32 bc[16];             // lane 0 -> wave broadcast slots
+    u32 bc[16];                 // lane 0 -> wave broadcast slots
 };
 
 // ---- forward (LSB-first) bit reader over bytes, for table descriptions ----
@@ -138,7 +151,25 @@ KX_DEV u32 kbb_peek(const KBackBits& b, u32 n)
 }
 
 // ---- Huffman table description -> LDS decoding table; returns bytes consumed, 0 on error
-KX_DEV u32 khuf_read_dtable(KDecodeLds& lds, const u8* p, u32 size, u32* tableLogOut)
+// weights[0..nw) -> decoding table (lane 0). false on an invalid weight set
+KX_DEV bool khuf_fill_dtable(KDecodeLds& lds, u32 nw, u32 tableLog)
+{
+    for (u32 i = 0; i < 16; i++) lds.rank[i] = 0;
+    for (u32 i = 0; i < nw; i++) lds.rank[lds.weights[i]]++;
+    if (lds.rank[1] < 2 || (lds.rank[1] & 1)) return false;
+    u32 next = 0;
+    for (u32 w = 1; w <= tableLog; w++) { u32 const cur = next; next += lds.rank[w] << (w - 1); lds.rank[w] = cur; }
+    for (u32 s = 0; s < nw; s++) {
+        u32 const w = lds.weights[s];
+        if (!w) continue;
+        u32 const len = 1u << (w - 1); u32 const start = lds.rank[w]; u32 const nb = tableLog + 1 - w;
+        for (u32 i = 0; i < len; i++) lds.u.huf[start + i] = (u16)(s | (nb << 8));
+        lds.rank[w] += len;
+    }
+    return true;
+}
+
+KX_DEV u32 khuf_read_dtable(KDecodeLds& lds, const u8* p, u32 size, u32* tableLogOut, u32* nwOut)
 {
     if (size < 1) return 0;
     u32 const hb = p[0]; u32 nw = 0, used;
@@ -152,7 +183,7 @@ KX_DEV u32 khuf_read_dtable(KDecodeLds& lds, const u8* p, u32 size, u32* tableLo
         u32 maxSV = 12, tl = 0;
         u32 const h = kfse_read_ncount(lds.norm, &maxSV, &tl, p + 1, hb, 6);
         if (h == 0 || maxSV > 12) return 0;
-        kfse_build_dtable(lds.fse[0], lds.norm, maxSV, tl, lds.symnext, lds.tsym);
+        kfse_build_dtable(lds.u.b.tmp32, lds.norm, maxSV, tl, lds.symnext, lds.u.b.tsym);
         KBackBits b;
         if (!kbb_init(b, p + 1 + h, hb - h)) return 0;
         if (b.bits < (int)(2 * tl)) return 0;
@@ -160,42 +191,30 @@ KX_DEV u32 khuf_read_dtable(KDecodeLds& lds, const u8* p, u32 size, u32* tableLo
         u32 s2 = kbb_peek(b, tl); b.bits -= (int)tl;
         for (;;) {
             if (nw >= 255) return 0;
-            u32 const e1 = lds.fse[0][s1];
+            u32 const e1 = lds.u.b.tmp32[s1];
             lds.weights[nw++] = (u8)(e1 >> 24);
             u32 const nb1 = (e1 >> 16) & 0xFF;
-            if (b.bits < (int)nb1) { if (nw >= 255) return 0; lds.weights[nw++] = (u8)(lds.fse[0][s2] >> 24); break; }
+            if (b.bits < (int)nb1) { if (nw >= 255) return 0; lds.weights[nw++] = (u8)(lds.u.b.tmp32[s2] >> 24); break; }
             s1 = (e1 & 0xFFFFu) + kbb_peek(b, nb1); b.bits -= (int)nb1;
             if (nw >= 255) return 0;
-            u32 const e2 = lds.fse[0][s2];
+            u32 const e2 = lds.u.b.tmp32[s2];
             lds.weights[nw++] = (u8)(e2 >> 24);
             u32 const nb2 = (e2 >> 16) & 0xFF;
-            if (b.bits < (int)nb2) { if (nw >= 255) return 0; lds.weights[nw++] = (u8)(lds.fse[0][s1] >> 24); break; }
+            if (b.bits < (int)nb2) { if (nw >= 255) return 0; lds.weights[nw++] = (u8)(lds.u.b.tmp32[s1] >> 24); break; }
             s2 = (e2 & 0xFFFFu) + kbb_peek(b, nb2); b.bits -= (int)nb2;
         }
     }
     // last weight is implied: total must complete a power of two
     u32 total = 0;
-    for (u32 i = 0; i < 16; i++) lds.rank[i] = 0;
-    for (u32 i = 0; i < nw; i++) { u32 const w = lds.weights[i]; if (w > 12) return 0; lds.rank[w]++; if (w) total += 1u << (w - 1); }
+    for (u32 i = 0; i < nw; i++) { u32 const w = lds.weights[i]; if (w > 12) return 0; if (w) total += 1u << (w - 1); }
     if (total == 0) return 0;
     u32 const tableLog = kx_hb32(total) + 1;
-    if (tableLog > 12) return 0;
+    if (tableLog > 11) return 0;
     u32 const rest = (1u << tableLog) - total;
     if (rest & (rest - 1)) return 0;              // must be a power of two
-    u32 const lastW = kx_hb32(rest) + 1;
-    lds.weights[nw] = (u8)lastW; lds.rank[lastW]++; nw++;
-    if (lds.rank[1] < 2 || (lds.rank[1] & 1)) return 0;
-    // starting index of every weight, then fill
-    u32 next = 0;
-    for (u32 w = 1; w <= tableLog; w++) { u32 const cur = next; next += lds.rank[w] << (w - 1); lds.rank[w] = cur; }
-    for (u32 s = 0; s < nw; s++) {
-        u32 const w = lds.weights[s];
-        if (!w) continue;
-        u32 const len = 1u << (w - 1); u32 const start = lds.rank[w]; u32 const nb = tableLog + 1 - w;
-        for (u32 i = 0; i < len; i++) lds.huf[start + i] = (u16)(s | (nb << 8));
-        lds.rank[w] += len;
-    }
-    *tableLogOut = tableLog;
+    lds.weights[nw] = (u8)(kx_hb32(rest) + 1); nw++;
+    if (!khuf_fill_dtable(lds, nw, tableLog)) return 0;
+    *tableLogOut = tableLog; *nwOut = nw;
     return used;
 }
 
@@ -217,7 +236,7 @@ KX_DEV bool khuf_decode_stream(const KDecodeLds& lds, u32 tableLog, const u8* p,
         int used = 0;
         while (i < count) {
             if (used + (int)tableLog > avail && !tail) break;                // refill
-            u32 const e = lds.huf[(u32)(w >> (64 - tableLog))];
+            u32 const e = lds.u.huf[(u32)(w >> (64 - tableLog))];
             int const nb = (int)(e >> 8);
             if (used + nb > avail) return false;
             out[i++] = (u8)e; w <<= nb; used += nb;
@@ -278,7 +297,10 @@ KX_DEV u32 kxd_ml_bits(u32 c)
     return ML_bits[c];
 }
 
-// lane 0: set up the decoding table of one symbol type. returns bytes consumed, KXD_FAIL on error
+KX_DEV u32* kxd_seq_dst(KDecodeLds& lds, int t) { return t == 0 ? lds.fseLL : t == 1 ? lds.fseOF : lds.fseML; }
+
+// lane 0: read one symbol type's table description and build its decoding table (mode 3
+// keeps the previous one). Returns bytes consumed, KXD_FAIL on error.
 #define KXD_FAIL 0xFFFFFFFFu
 KX_DEV u32 kxd_seq_table(KDecodeLds& lds, int t, u32 mode, const u8* p, u32 size, u32* tableLog, bool* valid)
 {
@@ -292,13 +314,13 @@ KX_DEV u32 kxd_seq_table(KDecodeLds& lds, int t, u32 mode, const u8* p, u32 size
         const short* dn = (t == 0) ? LL_defaultNorm : (t == 1) ? OF_defaultNorm : ML_defaultNorm;
         u32 const dmax = (t == 0) ? 35 : (t == 1) ? 28 : 52; u32 const dlog = (t == 1) ? 5 : 6;
         for (u32 s = 0; s <= dmax; s++) lds.norm[s] = dn[s];
-        kfse_build_dtable(lds.fse[t], lds.norm, dmax, dlog, lds.symnext, lds.tsym);
+        kfse_build_dtable(kxd_seq_dst(lds, t), lds.norm, dmax, dlog, lds.symnext, lds.u.b.tsym);
         *tableLog = dlog; *valid = true;
         return 0;
     }
     if (mode == 1) {
         if (size < 1 || p[0] > maxSym) return KXD_FAIL;
-        lds.fse[t][0] = (u32)p[0] << 24;          // nbBits 0, next state 0
+        kxd_seq_dst(lds, t)[0] = (u32)p[0] << 24;          // nbBits 0, next state 0
         *tableLog = 0; *valid = true;
         return 1;
     }
@@ -306,7 +328,7 @@ KX_DEV u32 kxd_seq_table(KDecodeLds& lds, int t, u32 mode, const u8* p, u32 size
         u32 maxSV = maxSym, tl = 0;
         u32 const h = kfse_read_ncount(lds.norm, &maxSV, &tl, p, size, maxLog);
         if (h == 0) return KXD_FAIL;
-        kfse_build_dtable(lds.fse[t], lds.norm, maxSV, tl, lds.symnext, lds.tsym);
+        kfse_build_dtable(kxd_seq_dst(lds, t), lds.norm, maxSV, tl, lds.symnext, lds.u.b.tsym);
         *tableLog = tl; *valid = true;
         return h;
     }
@@ -368,7 +390,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
     // ---- blocks -----------------------------------------------------------
     u32 op = 0;                       // bytes produced
     u32 rep1 = 1, rep2 = 4, rep3 = 8;
-    u32 hufLog = 0; bool hufValid = false;
+    u32 hufLog = 0, hufNw = 0; bool hufValid = false;
     u32 tlLL = 0, tlOF = 0, tlML = 0; bool vLL = false, vOF = false, vML = false;
     bool last = false;
     while (!err && !last) {
@@ -424,16 +446,21 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             u32 hused = 0;
             if (ltype == 2) {
                 u32 r = 0;
-                if (lane == 0) { u32 tl = 0; r = khuf_read_dtable(lds, bp + lpos, comp, &tl); lds.bc[0] = r; lds.bc[1] = tl; }
+                if (lane == 0) { u32 tl = 0, nw = 0; r = khuf_read_dtable(lds, bp + lpos, comp, &tl, &nw); lds.bc[0] = r; lds.bc[1] = tl; lds.bc[2] = nw; }
                 kx_sync();
                 r = lds.bc[0];
                 if (r == 0) { err = KZE_CORRUPT; break; }
-                hused = r; hufLog = lds.bc[1]; hufValid = true;
-            } else if (!hufValid) { err = KZE_CORRUPT; break; }
+                hused = r; hufLog = lds.bc[1]; hufNw = lds.bc[2]; hufValid = true;
+            } else {
+                if (!hufValid) { err = KZE_CORRUPT; break; }
+                // tree-less block: the table's LDS was reused by the previous block's sequence phase
+                if (lane == 0) khuf_fill_dtable(lds, hufNw, hufLog);
+                kx_sync();
+            }
             const u8* const sp = bp + lpos + hused; u32 const ssize = comp - hused;
             bool ok = true;
             if (nstreams == 1) {
-                if (lane == 0) ok = khuf_decode_stream(lds, hufLog, sp, ssize, lits, regen);
+                if (lane == 0 && !(a.flags & 1u)) ok = khuf_decode_stream(lds, hufLog, sp, ssize, lits, regen);
             } else {
                 if (ssize < 10) { err = KZE_CORRUPT; break; }
                 u32 const c0 = kx_ld16(sp), c1 = kx_ld16(sp + 2), c2 = kx_ld16(sp + 4);
@@ -441,7 +468,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                 u32 const c3 = ssize - 6 - c0 - c1 - c2;
                 u32 const seg = (regen + 3) / 4;
                 if (3 * seg > regen) { err = KZE_CORRUPT; break; }
-                if (lane < 4) {
+                if (lane < 4 && !(a.flags & 1u)) {
                     u32 const so = 6 + (lane > 0 ? c0 : 0) + (lane > 1 ? c1 : 0) + (lane > 2 ? c2 : 0);
                     u32 const sz = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : c3;
                     u32 const cnt = lane < 3 ? seg : regen - 3 * seg;
@@ -453,9 +480,9 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             kx_sync();
         }
         kx_sync();
-        // sequences header + tables (lane 0)
+        // sequences header, then the three tables (lane 0)
         if (lane == 0) {
-            u32 e = 0, nbSeq = 0, p2 = lpos;
+            u32 e = 0, nbSeq = 0, p2 = lpos, modes = 0;
             if (p2 >= bend) e = KZE_CORRUPT;
             if (!e) {
                 u32 const b0 = bp[p2++];
@@ -465,110 +492,196 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             }
             if (!e && nbSeq) {
                 if (p2 >= bend) e = KZE_CORRUPT;
-                else {
-                    u32 const modes = bp[p2++];
-                    if (modes & 3) e = KZE_CORRUPT;
-                    u32 r;
-                    if (!e) { r = kxd_seq_table(lds, 0, modes >> 6, bp + p2, bend - p2, &tlLL, &vLL); if (r == KXD_FAIL) e = KZE_CORRUPT; else p2 += r; }
-                    if (!e) { r = kxd_seq_table(lds, 1, (modes >> 4) & 3, bp + p2, bend - p2, &tlOF, &vOF); if (r == KXD_FAIL) e = KZE_CORRUPT; else p2 += r; }
-                    if (!e) { r = kxd_seq_table(lds, 2, (modes >> 2) & 3, bp + p2, bend - p2, &tlML, &vML); if (r == KXD_FAIL) e = KZE_CORRUPT; else p2 += r; }
-                    if (!e && p2 >= bend) e = KZE_CORRUPT;
-                }
+                else { modes = bp[p2++]; if (modes & 3) e = KZE_CORRUPT; }
             }
-            lds.bc[0] = e; lds.bc[1] = nbSeq; lds.bc[2] = p2;
+            lds.bc[0] = e; lds.bc[1] = nbSeq; lds.bc[2] = p2; lds.bc[3] = modes;
         }
         kx_sync();
         if (lds.bc[0]) { err = lds.bc[0]; break; }
-        u32 const nbSeq = lds.bc[1]; u32 const spos = lds.bc[2];
+        u32 const nbSeq = lds.bc[1]; u32 spos = lds.bc[2]; u32 const modes = lds.bc[3];
+        if (nbSeq) {
+            for (int t = 0; t < 3 && !err; t++) {
+                u32 const mode = (modes >> (6 - 2 * t)) & 3u;
+                if (lane == 0) {
+                    u32 r;
+                    if (t == 0) r = kxd_seq_table(lds, 0, mode, bp + spos, bend - spos, &tlLL, &vLL);
+                    else if (t == 1) r = kxd_seq_table(lds, 1, mode, bp + spos, bend - spos, &tlOF, &vOF);
+                    else r = kxd_seq_table(lds, 2, mode, bp + spos, bend - spos, &tlML, &vML);
+                    lds.bc[4] = r; lds.bc[5] = (t == 0) ? tlLL : (t == 1) ? tlOF : tlML;
+                }
+                kx_sync();
+                u32 const r = lds.bc[4];
+                if (r == KXD_FAIL) { err = KZE_CORRUPT; break; }
+                spos += r;
+                kx_sync();
+            }
+            if (err) break;
+            if (spos >= bend) { err = KZE_CORRUPT; break; }
+        }
         // lane 0 keeps the table logs / validity for later blocks; share them
         tlLL = kx_shfl(tlLL, 0); tlOF = kx_shfl(tlOF, 0); tlML = kx_shfl(tlML, 0);
         vLL = kx_shfl((u32)vLL, 0) != 0; vOF = kx_shfl((u32)vOF, 0) != 0; vML = kx_shfl((u32)vML, 0) != 0;
         u32 litUsed = 0;
-        if (nbSeq) {
-            KBackBits b; u32 sLL = 0, sOF = 0, sML = 0; bool bad = false;
-            if (lane == 0) {
-                if (!kbb_init(b, bp + spos, bend - spos)) bad = true;
-                else if (b.bits < (int)(tlLL + tlOF + tlML)) bad = true;
-                else {
-                    sLL = kbb_peek(b, tlLL); b.bits -= (int)tlLL;
-                    sOF = kbb_peek(b, tlOF); b.bits -= (int)tlOF;
-                    sML = kbb_peek(b, tlML); b.bits -= (int)tlML;
-                }
-            }
+        if (nbSeq && !(a.flags & 2u)) {
+            const u8* const sq = bp + spos; u32 const ssz = bend - spos;
+            u32 const lastByte = sq[ssz - 1];
+            if (lastByte == 0) { err = KZE_CORRUPT; break; }
+            int const totalWords = (int)((ssz + 3) >> 2);
+            // lane 0's backward reader: bitPos = unread bits. Every sequence builds a 64-bit container
+            // (top bit = next unread bit) from three LDS words that are requested together with the three
+            // state-table entries; fields then cost two shifts each. sbuf keeps two zero words below
+            // the stream start so no read is conditional.
+            int bitPos = (int)(8 * (ssz - 1) + kx_hb32(lastByte));
+            u32 sLL = 0, sOF = 0, sML = 0; bool bad = false, primed = false;
+            int sbLo = -1;                       // first stream word held in lds.u.q.sbuf[2..] (uniform)
+#define KXD_WORD(i) lds.u.q.sbuf[(i) - sbLo + 2]
+#define KXD_CONTAINER(C_) u64 C_; { int const topw_ = (bitPos - 1) >> 5; \
+                u32 const hi_ = KXD_WORD(topw_), mid_ = KXD_WORD(topw_ - 1), lo_ = KXD_WORD(topw_ - 2); \
+                u32 const used_ = (u32)(32 * (topw_ + 1) - bitPos); \
+                C_ = ((((u64)hi_ << 32) | mid_) << used_) | ((u64)lo_ >> (32u - used_)); }
+#define KXD_GET(dst_, C_, n_) { u32 const n__ = (n_); dst_ = (u32)(((C_) >> 1) >> (63u - n__)); (C_) <<= n__; }
+// n bits that start c bits below the container's top; independent of the other fields
+#define KXD_AT(C_, c_, n_) ((u32)((((C_) << (c_)) >> 1) >> (63u - (n_))))
             for (u32 done = 0; done < nbSeq && !err; ) {
                 u32 const cnt = (nbSeq - done) < 64 ? (nbSeq - done) : 64;
-                if (lane == 0) {
-                    u32 i = 0;
-                    for (; i < cnt && !bad; i++) {
-                        u32 const eLL = lds.fse[0][sLL], eOF = lds.fse[1][sOF], eML = lds.fse[2][sML];
-                        u32 const llc = eLL >> 24, ofc = eOF >> 24, mlc = eML >> 24;
-                        if (ofc > 31 || llc > 35 || mlc > 52) { bad = true; break; }
-                        u32 const llb = kxd_ll_bits(llc), mlb = kxd_ml_bits(mlc);
-                        if (b.bits < (int)(ofc + mlb + llb)) { bad = true; break; }
-                        u32 const ofv = (1u << ofc) + kbb_peek(b, ofc); b.bits -= (int)ofc;
-                        u32 const ml = kx_ml_base(mlc) + kbb_peek(b, mlb); b.bits -= (int)mlb;
-                        u32 const ll = kx_ll_base(llc) + kbb_peek(b, llb); b.bits -= (int)llb;
-                        u32 off;
-                        if (ofv > 3) { off = ofv - 3; rep3 = rep2; rep2 = rep1; rep1 = off; }
-                        else {
-                            u32 const idx = ofv - 1 + (ll == 0);
-                            if (idx == 0) off = rep1;
-                            else {
-                                off = idx == 1 ? rep2 : idx == 2 ? rep3 : rep1 - 1;
-                                if (off == 0) off = 1;
-                                if (idx != 1) rep3 = rep2;
-                                rep2 = rep1; rep1 = off;
-                            }
+                // keep >= 176 words (64 sequences x <= 88 bits) of stream below the read position in LDS
+                int const curWord = (int)kx_shfl((u32)bitPos, 0) >> 5;
+                if (sbLo < 0 || (sbLo > 0 && curWord - sbLo < 176)) {
+                    int newLo = curWord + 2 - 510; if (newLo < 0) newLo = 0;
+                    int hiW = curWord + 2; if (hiW > totalWords) hiW = totalWords;
+                    kx_sync();
+                    for (int i = newLo - 2 + lane; i < hiW; i += 64) {
+                        int const o = 4 * i; u32 v = 0;
+                        if (i >= 0) {
+                            if (o + 4 <= (int)ssz) v = kx_ld32(sq + o);
+                            else for (int k = 0; o + k < (int)ssz; k++) v |= (u32)sq[o + k] << (8 * k);
                         }
-                        lds.stage[3 * i] = ll; lds.stage[3 * i + 1] = ml; lds.stage[3 * i + 2] = off;
-                        if (done + i + 1 < nbSeq) {
-                            u32 const nLL = (eLL >> 16) & 0xFF, nML = (eML >> 16) & 0xFF, nOF = (eOF >> 16) & 0xFF;
-                            if (b.bits < (int)(nLL + nML + nOF)) { bad = true; break; }
-                            sLL = (eLL & 0xFFFFu) + kbb_peek(b, nLL); b.bits -= (int)nLL;
-                            sML = (eML & 0xFFFFu) + kbb_peek(b, nML); b.bits -= (int)nML;
-                            sOF = (eOF & 0xFFFFu) + kbb_peek(b, nOF); b.bits -= (int)nOF;
-                        } else if (b.bits != 0) bad = true;
+                        lds.u.q.sbuf[i - newLo + 2] = v;
                     }
-                    lds.stage[192] = bad ? 1u : 0u;
+                    sbLo = newLo;
+                    kx_sync();
+                }
+                if (lane == 0) {
+                    if (!primed) {
+                        if (bitPos < (int)(tlLL + tlOF + tlML)) bad = true;
+                        else { KXD_CONTAINER(C0) KXD_GET(sLL, C0, tlLL) KXD_GET(sOF, C0, tlOF) KXD_GET(sML, C0, tlML) bitPos -= (int)(tlLL + tlOF + tlML); }
+                        primed = true;
+                    }
+                    bool const lastChunk = done + cnt == nbSeq;
+                    u32 const full = lastChunk ? cnt - 1 : cnt;       // the block's final sequence updates no state
+                    for (u32 i = 0; i < cnt && !bad; i++) {
+                        KXD_CONTAINER(C)
+                        u32 const lLL = lds.fseLL[sLL], lML = lds.fseML[sML], lOF = lds.fseOF[sOF];
+                        u32 const cLL = lLL >> 24, cML = lML >> 24, aOF = lOF >> 24;
+                        // small codes carry no extra bits (base = code, resp. code + 3); the rest come from a table
+                        u32 bLL = cLL, aLL = 0, bML = cML + 3, aML = 0;
+                        if (cLL >= 16) { u32 const x = lds.llx[cLL]; bLL = x & 0xFFFFFFu; aLL = x >> 24; }
+                        if (cML >= 32) { u32 const x = lds.mlx[cML]; bML = x & 0xFFFFFFu; aML = x >> 24; }
+                        u32 const nLL = (lLL >> 16) & 0xFF, nML = (lML >> 16) & 0xFF, nOF = (lOF >> 16) & 0xFF;
+                        u32 const needA = aOF + aML + aLL, needB = (i < full) ? nLL + nML + nOF : 0u;
+                        if (bitPos < (int)(needA + needB)) { bad = true; break; }
+                        u32 xo, xm, xl, yl, ym, yo;
+                        xo = KXD_AT(C, 0u, aOF); xm = KXD_AT(C, aOF, aML); xl = KXD_AT(C, aOF + aML, aLL);
+                        if (needA + needB <= 64) {
+                            yl = KXD_AT(C, needA, nLL); ym = KXD_AT(C, needA + nLL, nML); yo = KXD_AT(C, needA + nLL + nML, nOF);
+                        } else {
+                            bitPos -= (int)needA; KXD_CONTAINER(C2) bitPos += (int)needA;
+                            yl = KXD_AT(C2, 0u, nLL); ym = KXD_AT(C2, nLL, nML); yo = KXD_AT(C2, nLL + nML, nOF);
+                        }
+                        bitPos -= (int)(needA + needB);
+                        u32 const ofv = (1u << aOF) + xo, ml = bML + xm, ll = bLL + xl;
+                        // repeat-offset rules, branch-free
+                        bool const isRep = ofv <= 3;
+                        u32 const idx = ofv - 1 + (ll == 0);                       // meaningful when isRep
+                        u32 const rm1 = (rep1 - 1) ? rep1 - 1 : 1u;
+                        u32 const roff = idx == 0 ? rep1 : idx == 1 ? rep2 : idx == 2 ? rep3 : rm1;
+                        u32 const off = isRep ? roff : ofv - 3;
+                        bool const sh2 = !isRep || idx >= 2, sh1 = !isRep || idx >= 1;
+                        rep3 = sh2 ? rep2 : rep3; rep2 = sh1 ? rep1 : rep2; rep1 = off;
+                        lds.u.q.stage[3 * i] = ll; lds.u.q.stage[3 * i + 1] = ml; lds.u.q.stage[3 * i + 2] = off;
+                        if (i < full) { sLL = (lLL & 0xFFFFu) + yl; sML = (lML & 0xFFFFu) + ym; sOF = (lOF & 0xFFFFu) + yo; }
+                    }
+                    if (lastChunk && !bad && bitPos != 0) bad = true;
+                    lds.u.q.stage[192] = bad ? 1u : 0u;
                 }
                 kx_sync();
-                if (lds.stage[192]) { err = KZE_CORRUPT; break; }
-                // execute the staged sequences, all lanes
-                for (u32 i = 0; i < cnt; i++) {
-                    u32 const ll = lds.stage[3 * i], ml = lds.stage[3 * i + 1], off = lds.stage[3 * i + 2];
-                    if (litUsed + ll > regen) { err = KZE_CORRUPT; break; }
-                    if ((u64)op + ll + ml > cap) { err = KZE_DSTSMALL; break; }
-                    if (off > op + ll) { err = KZE_CORRUPT; break; }
-                    kxd_wave_copy(dst + op, litPtr + litUsed, ll, lane);
-                    op += ll; litUsed += ll;
-                    kx_lockstep();
-                    const u8* const ms = dst + op - off;
-                    if (off >= 64) {
-                        for (u32 base = 0; base < ml; base += 64) {
-                            u32 const k = base + (u32)lane;
-                            if (k < ml) dst[op + k] = ms[k];
+                if (lds.u.q.stage[192]) { err = KZE_CORRUPT; break; }
+                // ---- execute the chunk: lane i owns sequence i -----------------
+                bool const own = (u32)lane < cnt;
+                u32 const ll = own ? lds.u.q.stage[3 * lane] : 0u, ml = own ? lds.u.q.stage[3 * lane + 1] : 0u, off = own ? lds.u.q.stage[3 * lane + 2] : 1u;
+                u32 sl = ll, st = ll + ml;                    // inclusive scans over the lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    u32 const a1 = kx_shfl(sl, lane - o), a2 = kx_shfl(st, lane - o);
+                    if (lane >= o) { sl += a1; st += a2; }
+                }
+                u32 const totLit = kx_shfl(sl, 63), totOut = kx_shfl(st, 63);
+                if (litUsed + totLit > regen) { err = KZE_CORRUPT; break; }
+                if ((u64)op + totOut > cap) { err = KZE_DSTSMALL; break; }
+                u32 const lp = litUsed + (sl - ll);           // my literals in the literal buffer
+                u32 const dlit = op + (st - ll - ml);         // where they go
+                u32 const dmat = dlit + ll;                   // where my match goes
+                if (kx_any(own && off > dmat)) { err = KZE_CORRUPT; break; }
+                // literals: short runs lane-serially (exact length), long runs by the whole wave
+                if (a.flags & 4u) { op += totOut; litUsed += totLit; kx_sync(); done += cnt; continue; }
+                if (own && ll <= 32) {
+                    const u8* const s_ = litPtr + lp; u8* const d_ = dst + dlit; u32 k = 0;
+                    for (; k + 8 <= ll; k += 8) kx_st64(d_ + k, kx_ld64(s_ + k));
+                    for (; k < ll; k++) d_[k] = s_[k];
+                }
+                for (u64 longs = kx_ballot(own && ll > 32); longs; longs &= longs - 1) {
+                    int const e = (int)kx_ctz64(longs);
+                    kxd_wave_copy(dst + kx_shfl(dlit, e), litPtr + kx_shfl(lp, e), kx_shfl(ll, e), lane);
+                }
+                kx_lockstep();
+                // matches in dependency rounds: a short match with offset >= 8 whose source lies before
+                // the earliest pending match's destination is copied by its own lane; the earliest pending
+                // one is always runnable; long or small-offset matches are copied by the whole wave in order
+                for (u64 P = kx_ballot(own); P; ) {
+                    int const e = (int)kx_ctz64(P);
+                    u32 const mlE = kx_shfl(ml, e), offE = kx_shfl(off, e), dE = kx_shfl(dmat, e);
+                    if (mlE > 32 || offE < 8) {
+                        const u8* const ms = dst + dE - offE;
+                        if (offE >= 64) {
+                            for (u32 base = 0; base < mlE; base += 64) {
+                                u32 const k = base + (u32)lane;
+                                if (k < mlE) dst[dE + k] = ms[k];
+                                kx_lockstep();
+                            }
+                        } else {
+                            u32 const chunk = (64 / offE) * offE; u32 const m = (u32)lane % offE;
+                            u8 v = 0;
+                            if ((u32)lane < chunk) v = ms[m];
+                            for (u32 base = 0; base < mlE; base += chunk) {
+                                u32 const k = base + (u32)lane;
+                                if ((u32)lane < chunk && k < mlE) dst[dE + k] = v;
+                            }
                             kx_lockstep();
                         }
-                    } else {
-                        // overlapping copy: replicate the off-byte pattern, a multiple of off per step
-                        u32 const chunk = (64 / off) * off;
-                        u32 const m = (u32)lane % off;
-                        for (u32 base = 0; base < ml; base += chunk) {
-                            u32 const k = base + (u32)lane;
-                            u8 v = 0;
-                            if ((u32)lane < chunk && k < ml) v = ms[m];
-                            if ((u32)lane < chunk && k < ml) dst[op + k] = v;
-                        }
-                        kx_lockstep();
+                        P &= P - 1;
+                        continue;
                     }
-                    op += ml;
+                    bool const safe = ((P >> lane) & 1ull) && ml <= 32 && off >= 8 && (lane == e || dmat - off + ml <= dE);
+                    if (safe) {
+                        const u8* const s_ = dst + dmat - off; u8* const d_ = dst + dmat; u32 k = 0;
+                        for (; k + 8 <= ml; k += 8) kx_st64(d_ + k, kx_ld64(s_ + k));
+                        for (; k < ml; k++) d_[k] = s_[k];
+                    }
+                    P &= ~kx_ballot(safe);
+                    kx_lockstep();
                 }
+                op += totOut; litUsed += totLit;
                 kx_sync();
                 done += cnt;
             }
+#undef KXD_AT
+#undef KXD_GET
+#undef KXD_CONTAINER
+#undef KXD_WORD
             if (err) break;
         }
         // remaining literals
+        if (a.flags & 2u) litUsed = 0;
         if (litUsed > regen || (u64)op + (regen - litUsed) > cap) { err = (litUsed > regen) ? KZE_CORRUPT : KZE_DSTSMALL; break; }
         kxd_wave_copy(dst + op, litPtr + litUsed, regen - litUsed, lane);
         op += regen - litUsed;
@@ -593,6 +706,9 @@ KX_DEV void zstd_decode_body(const KDecodeArgs& a)
 {
     KX_SHARED KDecodeLds lds;
     int const lane = kx_lane();
+    if (lane < 36) lds.llx[lane] = kx_ll_base((u32)lane) | (kxd_ll_bits((u32)lane) << 24);
+    if (lane < 53) lds.mlx[lane] = kx_ml_base((u32)lane) | (kxd_ml_bits((u32)lane) << 24);
+    kx_sync();
     for (u32 f = kx_block(); f < a.n_slices; f += kx_nblocks()) {
         zstd_decode_frame(a, lds, f, lane);
         kx_sync();

@@ -63,7 +63,7 @@ int emu_zstd_decompress(const u8* src, const u64* in_off, const u32* in_len, u32
     KDecodeArgs d;
     d.src = src; d.in_off = in_off; d.in_len = in_len; d.n_slices = n;
     d.dst = dst; d.out_off = out_off; d.out_cap = out_cap; d.out_len = out_len; d.status = status;
-    d.lits = lits.data(); d.lit_cap = lit_cap;
+    d.lits = lits.data(); d.lit_cap = lit_cap; d.flags = 0;
     kxemu::failed = 0;
     kxemu::launch(nblocks, [&]() { zstd_decode_body(d); });
     return kxemu::failed ? -1 : 0;
