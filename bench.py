@@ -92,8 +92,8 @@ def main():
     ap.add_argument("--slices", type=int, default=65536, help="slices per GPU (BASELINE configs[1]: 65536)")
     ap.add_argument("--team", type=int, default=0, help="lanes per slice in the match kernel (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--mode", choices=["compress", "decompress"], default="compress",
-                    help="compress = BASELINE configs[1] (the headline); decompress = configs[2] over the same frames")
+    ap.add_argument("--mode", choices=["compress", "decompress", "deflate"], default="compress",
+                    help="compress = BASELINE configs[1] (the headline); decompress = configs[2] over the same frames; deflate = configs[4] (raw DEFLATE level 6)")
     args = ap.parse_args()
 
     import numpy as np
@@ -131,6 +131,43 @@ def main():
     out_off = torch.arange(n, dtype=torch.int64, device=dev) * b.out_stride
     out_len = torch.zeros(n, dtype=torch.int32, device=dev)
     b.set_profiling(True)
+
+    if args.mode == "deflate":
+        # configs[4]: ZlibCompressor(ZlibFormat.Raw, 6) over the same slices
+        for _ in range(args.warmup):
+            b.deflate(src, in_off, in_len, dst, out_off, out_len)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            b.deflate(src, in_off, in_len, dst, out_off, out_len)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kms = b.deflate_kernel_ms()
+        lens = out_len.cpu().numpy().astype(np.int64)
+        # spot check against the host's zlib
+        import zlib as _z
+        ok = True
+        for i in (0, 1, 5, 777 % n, n - 1):
+            f = dst[int(out_off[i]):int(out_off[i]) + int(lens[i])].cpu().numpy().tobytes()
+            ok = ok and _z.decompress(f, -15) == host[i * SLICE:(i + 1) * SLICE].tobytes()
+        t1 = time.perf_counter()
+        sample = min(n, 2048)
+        for i in range(sample):
+            c = _z.compressobj(6, _z.DEFLATED, -15, 8, 0)
+            c.compress(host[i * SLICE:(i + 1) * SLICE].tobytes()); c.flush()
+        cpu = sample * SLICE / (time.perf_counter() - t1) / 1e9
+        print(json.dumps({
+            "metric": "raw DEFLATE level-6 compression throughput, 64 KiB-slice batch (uncompressed input bytes per second)",
+            "value": round(n * SLICE / (dt / args.steps) / 1e9, 3), "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: {n} x 64 KiB slices, raw DEFLATE level 6 (windowBits 15, memLevel 8)",
+                       "ratio": round(n * SLICE / float(lens.sum()), 4), "inflate_spot_check_ok": ok},
+            "kernels_ms_first_chunk_of_16384": {k: round(v, 3) for k, v in kms.items()},
+            "cpu_baseline": {"value": round(cpu, 4), "unit": "GB/s", "cores": 1, "kind": "reference",
+                             "sample": f"first {sample} slices, zlib {_z.ZLIB_RUNTIME_VERSION} via Python, one thread"}}), flush=True)
+        b.close()
+        return
 
     def step():
         b.compress(src, in_off, in_len, dst, out_off, out_len)

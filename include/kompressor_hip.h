@@ -79,6 +79,20 @@ KMP_API size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* dctx,
                                           void* dst, size_t dst_size, size_t* dst_pos,
                                           const void* src, size_t src_size, size_t* src_pos);
 
+/* zlib twin of the above (kompressor-zlib--nativelib/src/jvmCommonMain/jni/Wrapper.cpp):
+ * createCompressor :10-26 (deflateInit2), freeCompressor :28-38 (deflateEnd), compressStream :40-82
+ * (deflate, call at :73).  Same cursor semantics; the return value is zlib's: Z_OK 0, Z_STREAM_END 1,
+ * Z_BUF_ERROR -5 are benign for the Kotlin side (ZlibCompressor.jvm.kt:49-56).  The GPU path implements
+ * level 6 (or -1), windowBits -15 (ZlibFormat.Raw), memLevel 8, strategy 0 and slices <= 64 KiB; other
+ * settings make create return NULL.  The decompressor half (inflate) is not built yet. */
+typedef struct kmp_zlib_cstream kmp_zlib_cstream;
+KMP_API kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bits, int mem_level, int strategy);
+KMP_API int kmp_zlib_free_compressor(kmp_zlib_cstream* stream);
+KMP_API int kmp_zlib_compress_stream(kmp_zlib_cstream* stream,
+                                     void* dst, size_t dst_size, size_t* dst_pos,
+                                     const void* src, size_t src_size, size_t* src_pos,
+                                     int finish);
+
 /* replace ZSTD_isError / ZSTD_getErrorName (Wrapper.cpp:189-196) */
 KMP_API unsigned kmp_zstd_is_error(size_t code);
 KMP_API const char* kmp_zstd_get_error_name(size_t code);
@@ -126,6 +140,20 @@ KMP_API int kmp_zstd_decompress_batch(kmp_batch_ctx* ctx,
                                       void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                       uint32_t* d_out_len, uint32_t* d_status,
                                       void* hip_stream);
+
+/* Raw DEFLATE (RFC 1951) streams as zlib level 6 / windowBits 15 / memLevel 8 / strategy 0 writes
+ * them: the batched form of deflateInit2(6, Z_DEFLATED, -15, 8, 0) + deflate(Z_FINISH)
+ * (reference: kompressor-zlib--nativelib/src/jvmCommonMain/jni/Wrapper.cpp:20,73; Kotlin
+ * ZlibCompressor(ZlibFormat.Raw, 6)).  Slices of at most 64 KiB; stream i goes to
+ * d_dst + d_out_off[i] (room for kmp_deflate_bound(len)), its size to d_out_len[i]. */
+KMP_API size_t kmp_deflate_bound(size_t src_size);
+KMP_API int kmp_deflate_compress_batch(kmp_batch_ctx* ctx,
+                                       const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                       uint32_t n,
+                                       void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
+                                       void* hip_stream);
+/* ms4[0..3] = k_deflate_chains, k_deflate_best, k_deflate_parse, k_deflate_encode of the last batch */
+KMP_API int kmp_deflate_last_kernel_ms(kmp_batch_ctx* ctx, float* ms4);
 
 /* Dense packing helper: copies frame i from d_src + d_in_off[i] (d_len[i] bytes) to
  * d_dst + d_out_off[i], where d_out_off is the exclusive prefix sum of d_len that

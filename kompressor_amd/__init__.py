@@ -11,6 +11,9 @@ def __getattr__(name):
     if name in ("ZstdCompressor", "ZstdDecompressor"):
         from . import zstd
         return getattr(zstd, name)
+    if name in ("ZlibCompressor", "ZlibFormat"):
+        from . import zlib
+        return getattr(zlib, name)
     if name in ("ZstdBatch", "compress_bound"):
         from . import batch
         return getattr(batch, name)

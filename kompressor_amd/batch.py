@@ -91,6 +91,28 @@ class ZstdBatch:
             raise RuntimeError(f"kmp_zstd_decompress_batch failed ({rc}): {_lib.last_error()}")
         return dst, out_off, out_len, status
 
+    def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None):
+        """Raw DEFLATE streams (zlib level 6, windowBits 15, memLevel 8) for slices of at most 64 KiB."""
+        n = in_len.numel()
+        stride = (self.lib.kmp_deflate_bound(min(self.max_slice_bytes, 65536)) + 63) & ~63
+        if dst is None:
+            dst = torch.empty(n * stride + 64, dtype=torch.uint8, device=self.device)
+        if out_off is None:
+            out_off = torch.arange(n, dtype=torch.int64, device=self.device) * stride
+        if out_len is None:
+            out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
+        rc = self.lib.kmp_deflate_compress_batch(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
+                                                 _ptr(dst), _ptr(out_off), _ptr(out_len), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"kmp_deflate_compress_batch failed ({rc}): {_lib.last_error()}")
+        return dst, out_off, out_len
+
+    def deflate_kernel_ms(self):
+        ms = (ctypes.c_float * 4)()
+        if self.lib.kmp_deflate_last_kernel_ms(self._h, ms) != 0:
+            raise RuntimeError(_lib.last_error())
+        return dict(zip(("k_deflate_chains", "k_deflate_best", "k_deflate_parse", "k_deflate_encode"), (float(x) for x in ms)))
+
     def compact(self, src, in_off, lens):
         """Dense packing of n frames; returns (dst, offsets[n+1])."""
         n = lens.numel()

@@ -1,0 +1,215 @@
+// deflate_match.h -- the LZ77 half of zlib level 6 ("deflate_slow": 15-bit hash of
+// 3 bytes, hash chains, lazy matching, good/lazy/nice/chain = 8/16/128/128) for many
+// independent slices of at most 64 KiB.
+//
+// Replaces zlib's deflate() behind the reference's ZlibCompressor(ZlibFormat.Raw, 6)
+// (kompressor-zlib--nativelib/src/jvmCommonMain/jni/Wrapper.cpp:20,73; Kotlin side
+// .../zlib/ZlibCompressor.jvm.kt:19-47).  The stream must equal zlib's byte for byte.
+//
+// Unlike zstd's double-fast parse, zlib inserts EVERY position into its hash chains,
+// so the candidate list of a position does not depend on the parse.  That splits the
+// work into three kernels:
+//   k_deflate_chains : link[p] = previous position with the same 3-byte hash
+//                      (one 256-thread workgroup per slice, head table in LDS)
+//   k_deflate_best   : for every position, the match zlib's longest_match would
+//                      return after 32 and after 128 chain steps (1024 threads per
+//                      slice, chain links + source bytes of the 32 KiB window in LDS)
+//   k_deflate_parse  : the lazy-evaluation decision chain, one LANE per slice, which
+//                      now only looks results up; emits the symbol list and the
+//                      block boundaries (every 16383 symbols)
+#pragma once
+#include "zstd_common.h"
+
+#define KD_MIN_MATCH 3
+#define KD_MAX_MATCH 258
+#define KD_MIN_LOOKAHEAD 262
+#define KD_WSIZE 32768
+#define KD_MAX_DIST (KD_WSIZE - KD_MIN_LOOKAHEAD)       /* 32506 */
+#define KD_TOO_FAR 4096
+#define KD_LIT_BUFSIZE 16384
+#define KD_MAX_SLICE 65536u
+#define KD_MAX_BLOCKS 8
+
+KX_DEV u32 kd_hash3(u32 b0, u32 b1, u32 b2) { return ((b0 << 10) ^ (b1 << 5) ^ b2) & 0x7FFFu; }
+
+// per position: what longest_match returns with a full chain (128 steps) and with the
+// shortened chain (32 steps, used when the previous match is >= good_match)
+struct KdBest { u16 len128, pos128, len32, pos32; };
+
+struct KdBlockInfo { u32 nsym_end; u32 end_pos; u32 start_pos; u32 stored_ok; };   // symbols [prev nsym_end, nsym_end)
+struct KdSliceMeta { u32 nblocks; u32 nsym; u32 pad[2]; KdBlockInfo blk[KD_MAX_BLOCKS]; };
+
+struct KdArgs {
+    const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
+    u16* link;          // per slice: 65536 entries
+    KdBest* best;       // per slice: 65536 entries
+    u32* syms;          // per slice: 65536 entries: dist | lc << 16
+    KdSliceMeta* meta;
+    u8* dst; const u64* out_off; u32* out_len;
+};
+
+// ---------------------------------------------------------------------------
+// k_deflate_chains: 256 threads per workgroup, head[32768] in LDS
+// ---------------------------------------------------------------------------
+KX_DEV void deflate_chains_body(const KdArgs& a)
+{
+    KX_SHARED u16 head[32768];
+    int const lane = kx_lane(); int const wv = kx_wave(); int const nw = kx_nwaves(); int const tid = wv * 64 + lane; int const nthreads = nw * 64;
+    for (u32 slice = kx_block(); slice < a.n_slices; slice += kx_nblocks()) {
+        const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
+        u16* const link = a.link + (size_t)slice * 65536u;
+        for (int i = tid; i < 32768; i += nthreads) head[i] = 0;
+        kx_block_sync();
+        u32 const nIns = n >= 3 ? n - 2 : 0;                // positions 0 .. n-3 enter the chains, in order
+        for (u32 base = 0; base < nIns; base += (u32)nthreads) {
+            for (int w = 0; w < nw; w++) {
+                if (wv == w) {
+                    u32 const p = base + (u32)w * 64u + (u32)lane; bool const valid = p < nIns;
+                    u32 h = 0x8000u + (u32)lane;             // distinct dummy for idle lanes
+                    if (valid) h = kd_hash3(src[p], src[p + 1], src[p + 2]);
+                    u32 const old = valid ? head[h] : 0u;
+                    kx_lockstep();
+                    if (valid) head[h] = (u16)p;
+                    kx_lockstep();
+                    u32 const chk = valid ? head[h] : p;
+                    u32 lk = old;
+                    if (kx_any(valid && chk != (p & 0xFFFFu))) {
+                        // two lanes of this wave share a bucket: nearest lower lane is the predecessor,
+                        // and the highest lane of each bucket must be the one left in the table
+                        bool found = false, hasHigher = false;
+                        for (int d = 1; d < 64; d++) {
+                            u32 const hl = kx_shfl(h, lane - d), hh = kx_shfl(h, lane + d);
+                            if (lane >= d && hl == h && !found) { lk = p - (u32)d; found = true; }
+                            if (lane + d < 64 && hh == h) hasHigher = true;
+                        }
+                        kx_lockstep();
+                        if (valid && !hasHigher) head[h] = (u16)p;
+                    }
+                    if (valid) link[p] = (u16)lk;
+                }
+                kx_block_sync();
+            }
+        }
+        kx_block_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_deflate_best: 1024 threads per workgroup; 8192-position chunks with their
+// 32 KiB history (links + bytes) staged in LDS
+// ---------------------------------------------------------------------------
+#define KD_CHUNK 8192
+#define KD_HIST 32512                                   /* >= MAX_DIST, multiple of 64 */
+struct KdBestLds { u16 lnk[KD_CHUNK + KD_HIST]; u8 sb[KD_CHUNK + KD_HIST + 272]; };
+
+KX_DEV void deflate_best_body(const KdArgs& a)
+{
+    KX_SHARED KdBestLds lds;
+    int const tid = kx_wave() * 64 + kx_lane(); int const nthreads = kx_nwaves() * 64;
+    for (u32 slice = kx_block(); slice < a.n_slices; slice += kx_nblocks()) {
+        const u8* const src = a.src + a.in_off[slice]; int const n = (int)a.in_len[slice];
+        const u16* const link = a.link + (size_t)slice * 65536u;
+        KdBest* const best = a.best + (size_t)slice * 65536u;
+        for (int cb = 0; cb < n; cb += KD_CHUNK) {
+            int const lo = cb > KD_HIST ? cb - KD_HIST : 0;                 // first position staged
+            int const hiP = (cb + KD_CHUNK < n) ? cb + KD_CHUNK : n;        // positions [cb, hiP) are searched
+            int const hiB = (hiP + 264 < n) ? hiP + 264 : n;                // bytes staged up to here
+            kx_block_sync();
+            for (int i = lo + tid; i < hiP; i += nthreads) lds.lnk[i - lo] = (i + 2 < n) ? link[i] : (u16)0;
+            for (int i = lo + tid; i < hiB; i += nthreads) lds.sb[i - lo] = src[i];
+            kx_block_sync();
+            for (int p = cb + tid; p < hiP; p += nthreads) {
+                KdBest r; r.len128 = 0; r.pos128 = 0; r.len32 = 0; r.pos32 = 0;
+                int const lookahead = n - p;
+                if (lookahead >= KD_MIN_MATCH) {
+                    int const limit = p > KD_MAX_DIST ? p - KD_MAX_DIST : 0;
+                    int c = lds.lnk[p - lo];
+                    if (c != 0 && p - c <= KD_MAX_DIST) {
+                        int const nice = lookahead < 128 ? lookahead : 128;
+                        int const maxlen = lookahead < KD_MAX_MATCH ? lookahead : KD_MAX_MATCH;
+                        const u8* const scan = lds.sb + (p - lo);
+                        int bestLen = 2, bestPos = 0; int steps = 0; bool done = false;
+                        u8 se1 = scan[1], se = scan[2];                     // scan[best-1], scan[best]
+                        do {
+                            const u8* const m = lds.sb + (c - lo);
+                            steps++;
+                            // the candidate can only win if it also matches at the current best length
+                            if ((bestLen < maxlen ? m[bestLen] == se : true) && m[bestLen - 1] == se1 && m[0] == scan[0] && m[1] == scan[1]) {
+                                int len = 2;
+                                while (len < maxlen && m[len] == scan[len]) len++;
+                                if (len > bestLen) {
+                                    bestLen = len; bestPos = c;
+                                    if (len >= nice) done = true;
+                                    else { se1 = scan[bestLen - 1]; se = scan[bestLen]; }
+                                }
+                            }
+                            if (steps == 32 || (done && steps < 32)) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
+                            if (done) break;
+                            c = lds.lnk[c - lo];
+                        } while (c > limit && steps < 128);
+                        if (steps < 32 && !done) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
+                        r.len128 = (u16)(bestLen > 2 ? bestLen : 0); r.pos128 = (u16)bestPos;
+                    }
+                }
+                best[p] = r;
+            }
+        }
+        kx_block_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_deflate_parse: one lane per slice (64 slices per wave)
+// ---------------------------------------------------------------------------
+KX_DEV void deflate_parse_body(const KdArgs& a)
+{
+    u32 const slice = kx_block() * 64u + (u32)kx_lane();
+    if (slice >= a.n_slices) return;
+    const u8* const src = a.src + a.in_off[slice]; int const n = (int)a.in_len[slice];
+    const KdBest* const best = a.best + (size_t)slice * 65536u;
+    u32* const syms = a.syms + (size_t)slice * 65536u;
+    KdSliceMeta mm; mm.nblocks = 0; mm.nsym = 0; mm.pad[0] = 0; mm.pad[1] = 0;
+    for (int i = 0; i < KD_MAX_BLOCKS; i++) { mm.blk[i].nsym_end = 0; mm.blk[i].end_pos = 0; mm.blk[i].start_pos = 0; mm.blk[i].stored_ok = 0; }
+    int strstart = 0; int match_length = 2, prev_length = 2; int match_start = 0, prev_match = 0; bool match_available = false;
+    u32 nsym = 0, blockSyms = 0; int block_start = 0; int slide = 0;        // slide = 32768 once zlib's window has moved
+#define KD_FLUSH(last_) { KdBlockInfo& b_ = mm.blk[mm.nblocks < KD_MAX_BLOCKS ? mm.nblocks : KD_MAX_BLOCKS - 1]; \
+        b_.nsym_end = nsym; b_.end_pos = (u32)strstart; b_.start_pos = (u32)block_start; b_.stored_ok = (block_start - slide >= 0) ? 1u : 0u; \
+        mm.nblocks++; block_start = strstart; blockSyms = 0; }
+#define KD_TALLY(dist_, lc_) { syms[nsym++] = (u32)(dist_) | ((u32)(lc_) << 16); blockSyms++; }
+    for (;;) {
+        int const lookahead = n - strstart;
+        if (lookahead < KD_MIN_LOOKAHEAD) {
+            if (strstart >= KD_WSIZE + KD_MAX_DIST && !slide) slide = KD_WSIZE;       // fill_window moves the window once
+            if (lookahead == 0) break;
+        }
+        prev_length = match_length; prev_match = match_start;
+        match_length = KD_MIN_MATCH - 1;
+        if (lookahead >= KD_MIN_MATCH && prev_length < 16) {
+            // longest_match starts from best_len = prev_length, so only a longer match changes anything;
+            // a previous match >= good_match (8) shortens the chain walk to 32 steps
+            KdBest const r = best[strstart];
+            int const len = prev_length >= 8 ? r.len32 : r.len128, pos = prev_length >= 8 ? r.pos32 : r.pos128;
+            if (len > prev_length) {
+                match_length = len; match_start = pos;
+                if (match_length == KD_MIN_MATCH && strstart - match_start > KD_TOO_FAR) match_length = KD_MIN_MATCH - 1;
+            }
+        }
+        if (prev_length >= KD_MIN_MATCH && match_length <= prev_length) {
+            KD_TALLY(strstart - 1 - prev_match, prev_length - KD_MIN_MATCH)
+            bool const bflush = blockSyms == KD_LIT_BUFSIZE - 1;
+            strstart += prev_length - 1;
+            match_available = false; match_length = KD_MIN_MATCH - 1;
+            if (bflush) KD_FLUSH(0)
+        } else if (match_available) {
+            KD_TALLY(0, src[strstart - 1])
+            if (blockSyms == KD_LIT_BUFSIZE - 1) KD_FLUSH(0)
+            strstart++;
+        } else { match_available = true; strstart++; }
+    }
+    if (match_available) KD_TALLY(0, src[strstart - 1])
+    KD_FLUSH(1)
+    mm.nsym = nsym;
+    a.meta[slice] = mm;
+#undef KD_TALLY
+#undef KD_FLUSH
+}

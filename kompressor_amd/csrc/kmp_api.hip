@@ -5,6 +5,8 @@
 #include "zstd_match.h"
 #include "zstd_entropy.h"
 #include "zstd_decode.h"
+#include "deflate_match.h"
+#include "deflate_encode.h"
 #include "../../include/kompressor_hip.h"
 
 #include <mutex>
@@ -22,6 +24,11 @@ template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match(KMatchArgs a) { zstd_match_body<G>(a); }
 __global__ __launch_bounds__(64, 3) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
 __global__ __launch_bounds__(64) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
+
+__global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chains_body(a); }
+__global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_body(a); }
+__global__ __launch_bounds__(64) void k_deflate_parse(KdArgs a) { deflate_parse_body(a); }
+__global__ __launch_bounds__(64) void k_deflate_encode(KdArgs a) { deflate_encode_body(a); }
 
 // exclusive prefix sum of u32 lengths into u64 offsets, single workgroup
 __global__ __launch_bounds__(1024) void k_scan_lengths(const u32* len, u32 n, u64* off)
@@ -78,7 +85,9 @@ struct kmp_batch_ctx {
     int device; u32 max_slices, max_slice_bytes; int G; u32 match_blocks, nteams;
     u32 seq_cap, lit_cap, scratch_words;
     KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* team_epoch; u32* counter;
-    int profiling; hipEvent_t ev[6]; int ev_valid[3];
+    int profiling; hipEvent_t ev[14]; int ev_valid[7];
+    // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
+    u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta;
 };
 
 static u32 env_u32(const char* name, u32 dflt)
@@ -117,7 +126,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     HIP_TRY(hipMemset(c->tables, 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
     HIP_TRY(hipMemset(c->team_epoch, 0, (size_t)c->nteams * sizeof(u32)));
     HIP_TRY(hipMemset(c->meta, 0, ns * sizeof(KSliceMeta)));
-    for (int i = 0; i < 6; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+    for (int i = 0; i < 14; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return KMP_OK;
@@ -129,14 +138,15 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch);
     (void)hipFree(c->tables); (void)hipFree(c->team_epoch); (void)hipFree(c->counter);
-    for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta);
     delete c;
 }
 
 extern "C" int kmp_batch_set_profiling(kmp_batch_ctx* c, int on) { if (!c) return KMP_ERR_ARG; c->profiling = on; return KMP_OK; }
 extern "C" int kmp_batch_last_kernel_ms(kmp_batch_ctx* c, int which, float* ms)
 {
-    if (!c || which < 0 || which > 2 || !ms || !c->ev_valid[which]) { g_last_error = "no timing recorded"; return KMP_ERR_ARG; }
+    if (!c || which < 0 || which > 6 || !ms || !c->ev_valid[which]) { g_last_error = "no timing recorded"; return KMP_ERR_ARG; }
     HIP_TRY(hipEventSynchronize(c->ev[2 * which + 1]));
     HIP_TRY(hipEventElapsedTime(ms, c->ev[2 * which], c->ev[2 * which + 1]));
     return KMP_OK;
@@ -201,6 +211,56 @@ extern "C" int kmp_zstd_decompress_batch(kmp_batch_ctx* c, const void* d_src, co
     hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), env_u32("KMP_DECODE_PAD_LDS", 0), st, d);   // padding = occupancy experiment only
     HIP_TRY(hipGetLastError());
     if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[5], st)); c->ev_valid[2] = 1; }
+    return KMP_OK;
+}
+
+extern "C" size_t kmp_deflate_bound(size_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 13 + 8; }
+
+extern "C" int kmp_deflate_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                          uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
+{
+    if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_deflate_compress_batch: null argument"; return KMP_ERR_ARG; }
+    if (n > c->max_slices) { g_last_error = "kmp_deflate_compress_batch: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
+    if (n == 0) return KMP_OK;
+    hipStream_t const st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->dfl_link) {
+        u32 const chunk = c->max_slices < 16384u ? c->max_slices : 16384u;
+        HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)chunk * 65536u * sizeof(u16)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)chunk * 65536u * sizeof(KdBest)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_syms, (size_t)chunk * 65536u * sizeof(u32)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_meta, (size_t)chunk * sizeof(KdSliceMeta)));
+        c->dfl_chunk = chunk;
+    }
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[6], st));
+    for (u32 first = 0; first < n; first += c->dfl_chunk) {
+        u32 const m = (n - first < c->dfl_chunk) ? n - first : c->dfl_chunk;
+        KdArgs a;
+        a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = d_in_len + first; a.n_slices = m;
+        a.link = c->dfl_link; a.best = c->dfl_best; a.syms = c->dfl_syms; a.meta = c->dfl_meta;
+        a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first;
+        bool const prof = c->profiling && first == 0;      // per-kernel events for the first chunk
+        if (prof) HIP_TRY(hipEventRecord(c->ev[8], st));
+        hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(256), 0, st, a);
+        if (prof) HIP_TRY(hipEventRecord(c->ev[9], st));
+        hipLaunchKernelGGL(k_deflate_best, dim3(m), dim3(1024), 0, st, a);
+        if (prof) HIP_TRY(hipEventRecord(c->ev[10], st));
+        hipLaunchKernelGGL(k_deflate_parse, dim3((m + 63) / 64), dim3(64), 0, st, a);
+        if (prof) HIP_TRY(hipEventRecord(c->ev[11], st));
+        hipLaunchKernelGGL(k_deflate_encode, dim3(m), dim3(64), 0, st, a);
+        if (prof) HIP_TRY(hipEventRecord(c->ev[12], st));
+        HIP_TRY(hipGetLastError());
+    }
+    if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[7], st)); c->ev_valid[3] = 1; }
+    return KMP_OK;
+}
+
+// per-kernel milliseconds of the first workspace chunk of the last deflate batch: chains, best, parse, encode
+extern "C" int kmp_deflate_last_kernel_ms(kmp_batch_ctx* c, float* ms4)
+{
+    if (!c || !ms4 || !c->ev_valid[3]) { g_last_error = "no deflate timing recorded"; return KMP_ERR_ARG; }
+    HIP_TRY(hipEventSynchronize(c->ev[12]));
+    for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&ms4[i], c->ev[8 + i], c->ev[9 + i]));
     return KMP_OK;
 }
 
@@ -366,6 +426,52 @@ extern "C" size_t kmp_zstd_compress_stream(kmp_zstd_cctx* c, void* dst, size_t d
         if (remaining == 0) { c->stage = 0; c->in.clear(); c->out.clear(); c->out_pos = 0; }
         return remaining;
     }
+}
+
+// ---- zlib-compatible one-shot compressor (raw deflate, level 6) ---------------------------------
+struct kmp_zlib_cstream { int level, window_bits, mem_level, strategy; std::vector<u8> in; std::vector<u8> out; size_t out_pos; int stage; stream_dev dev; };
+
+extern "C" kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bits, int mem_level, int strategy)
+{
+    // what deflateInit2 would accept; the GPU path implements raw deflate (-15), level 6 (-1 = default = 6), memLevel 8, strategy 0
+    if (level == -1) level = 6;
+    if (level != 6 || window_bits != -15 || mem_level != 8 || strategy != 0) return nullptr;
+    kmp_zlib_cstream* z = new (std::nothrow) kmp_zlib_cstream();
+    if (!z) return nullptr;
+    z->level = level; z->window_bits = window_bits; z->mem_level = mem_level; z->strategy = strategy; z->out_pos = 0; z->stage = 0;
+    memset(&z->dev, 0, sizeof(z->dev));
+    return z;
+}
+extern "C" int kmp_zlib_free_compressor(kmp_zlib_cstream* z) { if (z) { stream_dev_free(z->dev); delete z; } return 0; }
+
+extern "C" int kmp_zlib_compress_stream(kmp_zlib_cstream* z, void* dst, size_t dst_size, size_t* dst_pos,
+                                        const void* src, size_t src_size, size_t* src_pos, int finish)
+{
+    enum { Z_OK_ = 0, Z_STREAM_END_ = 1, Z_STREAM_ERROR_ = -2, Z_DATA_ERROR_ = -3, Z_MEM_ERROR_ = -4, Z_BUF_ERROR_ = -5 };
+    if (!z || !dst_pos || !src_pos || *dst_pos > dst_size || *src_pos > src_size) return Z_STREAM_ERROR_;
+    if (z->stage == 0) {
+        size_t const avail = src_size - *src_pos;
+        if (avail) { const u8* p = (const u8*)src + *src_pos; z->in.insert(z->in.end(), p, p + avail); *src_pos = src_size; }
+        if (z->in.size() > KD_MAX_SLICE) return Z_MEM_ERROR_;          // slices above 64 KiB: not on the GPU path yet
+        if (!finish) return avail ? Z_OK_ : Z_BUF_ERROR_;
+        if (stream_dev_init(z->dev)) return Z_MEM_ERROR_;
+        stream_dev& s = z->dev;
+        u64 offs[2] = { 0, 0 }; u32 len = (u32)z->in.size(), olen = 0;
+        if (len && hipMemcpy(s.d_in, z->in.data(), len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
+        if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
+        if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
+        if (kmp_deflate_compress_batch(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, nullptr) != KMP_OK) return Z_MEM_ERROR_;
+        if (hipMemcpy(&olen, s.d_len + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR_;
+        if (olen == 0 || olen > s.out_cap) return Z_DATA_ERROR_;
+        z->out.resize(olen);
+        if (hipMemcpy(z->out.data(), s.d_out, olen, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR_;
+        z->stage = 1; z->out_pos = 0;
+    }
+    size_t const room = dst_size - *dst_pos, left = z->out.size() - z->out_pos;
+    size_t const k = room < left ? room : left;
+    if (k) { memcpy((u8*)dst + *dst_pos, z->out.data() + z->out_pos, k); *dst_pos += k; z->out_pos += k; }
+    if (z->out_pos == z->out.size()) { z->stage = 2; return Z_STREAM_END_; }
+    return k ? Z_OK_ : Z_BUF_ERROR_;
 }
 
 struct kmp_zstd_dctx {

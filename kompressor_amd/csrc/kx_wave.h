@@ -22,6 +22,9 @@ typedef uint64_t u64;
 KX_DEV int kx_lane() { return (int)(threadIdx.x & 63); }
 KX_DEV u32 kx_block() { return blockIdx.x; }
 KX_DEV u32 kx_nblocks() { return gridDim.x; }
+KX_DEV int kx_wave() { return (int)(threadIdx.x >> 6); }         // wave index inside the workgroup
+KX_DEV int kx_nwaves() { return (int)(blockDim.x >> 6); }
+KX_DEV void kx_block_sync() { __syncthreads(); }                 // workgroup barrier (multi-wave kernels)
 
 // ---- cross-lane (must be called from wave-uniform control flow) -------
 KX_DEV u64 kx_ballot(bool p) { return __ballot(p); }

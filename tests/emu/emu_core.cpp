@@ -1,10 +1,12 @@
 // TEST INFRASTRUCTURE: lock-step wave64 emulator.  Each lane is a fiber; a
-// cross-lane primitive parks the lane until every live lane of the wave has
-// reached the same primitive (anything else is reported as a divergence bug).
+// cross-lane primitive parks the lane until every live lane of its wave has
+// reached the same primitive (anything else is reported as a divergence bug);
+// a workgroup barrier parks it until every live lane of the workgroup arrived.
 #include "kx_wave.h"
 #include "emu_core.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 extern "C" void kx_switch(void** save_sp, void* new_sp);
 asm(R"(
@@ -30,59 +32,73 @@ kx_switch:
 )");
 
 namespace kxemu {
-int cur_lane; u32 cur_block, num_blocks;
-static const size_t STACK = 256 * 1024;
-static void* sp[64]; static void* sched_sp; static bool alive[64];
-static int op[64]; static u64 argA[64], argB[64], res[64];
-static u8* stacks = nullptr;
+int cur_lane; u32 cur_block, num_blocks; int cur_wave, waves_per_block = 1;
+static const size_t STACK = 128 * 1024;
+enum { F_DEAD = 0, F_READY = 1, F_WAIT = 2 };
+struct Fiber { void* sp; int state; int op; u64 a, b, res; };
+static std::vector<Fiber> fib;
+static void* sched_sp; static int cur_fiber;
+static u8* stacks = nullptr; static size_t stacks_n = 0;
 static const std::function<void()>* cur_fn;
 int failed = 0;
 
 u64 arrive(int o, u64 a, u64 b)
 {
-    int const l = cur_lane;
-    op[l] = o; argA[l] = a; argB[l] = b;
-    kx_switch(&sp[l], sched_sp);
-    return res[l];
+    Fiber& f = fib[cur_fiber];
+    f.op = o; f.a = a; f.b = b; f.state = F_WAIT;
+    kx_switch(&f.sp, sched_sp);
+    return fib[cur_fiber].res;
 }
 static void trampoline()
 {
     (*cur_fn)();
-    alive[cur_lane] = false; op[cur_lane] = 0;
-    kx_switch(&sp[cur_lane], sched_sp);
+    fib[cur_fiber].state = F_DEAD;
+    kx_switch(&fib[cur_fiber].sp, sched_sp);
     abort();
 }
-static void run_wave()
+static void run_block(int W)
 {
-    if (!stacks) stacks = (u8*)aligned_alloc(64, STACK * 64);
-    for (int l = 0; l < 64; l++) {
-        u64* top = (u64*)(stacks + STACK * (l + 1));
-        top -= 2; top[0] = (u64)(void*)&trampoline; top[1] = 0;   // ret addr, then fake caller slot
-        top -= 6; for (int i = 0; i < 6; i++) top[i] = 0;
-        sp[l] = top; alive[l] = true; op[l] = 0;
+    int const N = W * 64;
+    if (stacks_n < (size_t)N) { free(stacks); stacks = (u8*)aligned_alloc(64, STACK * N); stacks_n = N; }
+    fib.assign(N, Fiber());
+    for (int i = 0; i < N; i++) {
+        u64* top = (u64*)(stacks + STACK * (i + 1));
+        top -= 2; top[0] = (u64)(void*)&trampoline; top[1] = 0;
+        top -= 6; for (int k = 0; k < 6; k++) top[k] = 0;
+        fib[i].sp = top; fib[i].state = F_READY;
     }
     for (;;) {
-        int nalive = 0;
-        for (int l = 0; l < 64; l++) if (alive[l]) { cur_lane = l; kx_switch(&sched_sp, sp[l]); }
-        int o = 0; u64 mask = 0;
-        for (int l = 0; l < 64; l++) if (alive[l]) {
-            nalive++;
-            if (!o) o = op[l];
-            else if (op[l] != o) { if (!failed) fprintf(stderr, "kxemu: lanes diverged at a cross-lane primitive (lane %d op %d vs %d)\n", l, op[l], o); failed = 1; }
-            if (op[l] == OP_BALLOT && argA[l]) mask |= 1ull << l;
+        bool ran = false;
+        for (int i = 0; i < N; i++) if (fib[i].state == F_READY) {
+            cur_fiber = i; cur_wave = i / 64; cur_lane = i % 64;
+            kx_switch(&sched_sp, fib[i].sp);
+            ran = true;
         }
-        if (!nalive) break;
-        if (failed) { break; }
-        for (int l = 0; l < 64; l++) if (alive[l]) {
-            if (o == OP_BALLOT) res[l] = mask;
-            else if (o == OP_SHFL) { int s = (int)argB[l]; res[l] = alive[s] ? argA[s] : 0; }
-            else res[l] = 0;
+        int alive = 0, at_block_sync = 0; bool resolved = false;
+        for (int i = 0; i < N; i++) if (fib[i].state != F_DEAD) { alive++; if (fib[i].state == F_WAIT && fib[i].op == OP_BLOCK_SYNC) at_block_sync++; }
+        if (!alive) break;
+        if (at_block_sync == alive) { for (int i = 0; i < N; i++) if (fib[i].state == F_WAIT) { fib[i].res = 0; fib[i].state = F_READY; } resolved = true; }
+        else for (int w = 0; w < W; w++) {
+            int o = 0, n = 0, waiting = 0; u64 mask = 0; bool mixed = false;
+            for (int l = 0; l < 64; l++) { Fiber& f = fib[w * 64 + l]; if (f.state == F_DEAD) continue; n++;
+                if (f.state == F_WAIT && f.op != OP_BLOCK_SYNC) { waiting++; if (!o) o = f.op; else if (f.op != o) mixed = true; if (f.op == OP_BALLOT && f.a) mask |= 1ull << l; } }
+            if (!n || waiting != n) continue;
+            if (mixed) { if (!failed) fprintf(stderr, "kxemu: lanes of wave %d diverged at a cross-lane primitive\n", w); failed = 1; break; }
+            for (int l = 0; l < 64; l++) { Fiber& f = fib[w * 64 + l]; if (f.state != F_WAIT) continue;
+                if (o == OP_BALLOT) f.res = mask;
+                else if (o == OP_SHFL) { Fiber& s = fib[w * 64 + (int)f.b]; f.res = (s.state == F_WAIT) ? s.a : 0; }
+                else f.res = 0; }
+            for (int l = 0; l < 64; l++) if (fib[w * 64 + l].state == F_WAIT && fib[w * 64 + l].op != OP_BLOCK_SYNC) fib[w * 64 + l].state = F_READY;
+            resolved = true;
         }
+        if (failed) break;
+        if (!ran && !resolved) { fprintf(stderr, "kxemu: deadlock (some lanes wait at a barrier others never reach)\n"); failed = 1; break; }
     }
 }
-void launch(u32 nblocks, const std::function<void()>& fn)
+void launch(u32 nblocks, const std::function<void()>& fn) { launch_block(nblocks, 1, fn); }
+void launch_block(u32 nblocks, int waves, const std::function<void()>& fn)
 {
-    cur_fn = &fn; num_blocks = nblocks;
-    for (u32 b = 0; b < nblocks && !failed; b++) { cur_block = b; run_wave(); }
+    cur_fn = &fn; num_blocks = nblocks; waves_per_block = waves;
+    for (u32 b = 0; b < nblocks && !failed; b++) { cur_block = b; run_block(waves); }
 }
 }

@@ -68,3 +68,32 @@ int emu_zstd_decompress(const u8* src, const u64* in_off, const u32* in_len, u32
     kxemu::launch(nblocks, [&]() { zstd_decode_body(d); });
     return kxemu::failed ? -1 : 0;
 }
+
+#include "deflate_match.h"
+#include "deflate_encode.h"
+// raw DEFLATE level 6 pipeline (chains -> best -> parse -> encode) on the emulator
+extern "C" __attribute__((visibility("default")))
+int emu_deflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* dst, const u64* out_off, u32* out_len,
+                u16* link_out, KdBest* best_out)
+{
+    std::vector<u16> link((size_t)n * 65536u, 0xEEEE);
+    std::vector<KdBest> best((size_t)n * 65536u);
+    std::vector<u32> syms((size_t)n * 65536u, 0xDDDDDDDDu);
+    std::vector<KdSliceMeta> meta(n);
+    KdArgs a;
+    a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
+    a.link = link.data(); a.best = best.data(); a.syms = syms.data(); a.meta = meta.data();
+    a.dst = dst; a.out_off = out_off; a.out_len = out_len;
+    kxemu::failed = 0;
+    kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_chains_body(a); });
+    if (kxemu::failed) return -1;
+    kxemu::launch_block(n < 2 ? n : 2, 16, [&]() { deflate_best_body(a); });
+    if (kxemu::failed) return -2;
+    kxemu::launch((n + 63) / 64, [&]() { deflate_parse_body(a); });
+    if (kxemu::failed) return -3;
+    kxemu::launch(n < 3 ? n : 3, [&]() { deflate_encode_body(a); });
+    if (kxemu::failed) return -4;
+    if (link_out) memcpy(link_out, link.data(), link.size() * 2);
+    if (best_out) memcpy(best_out, best.data(), best.size() * sizeof(KdBest));
+    return 0;
+}

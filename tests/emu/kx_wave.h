@@ -17,14 +17,17 @@ typedef uint64_t u64;
 #define KX_SHARED static
 
 namespace kxemu {
-enum { OP_BALLOT = 1, OP_SHFL = 2, OP_SYNC = 3 };
-extern int cur_lane; extern u32 cur_block, num_blocks;
+enum { OP_BALLOT = 1, OP_SHFL = 2, OP_SYNC = 3, OP_BLOCK_SYNC = 4 };
+extern int cur_lane, cur_wave, waves_per_block; extern u32 cur_block, num_blocks;
 u64 arrive(int op, u64 a, u64 b);
 }
 
 KX_DEV int kx_lane() { return kxemu::cur_lane; }
 KX_DEV u32 kx_block() { return kxemu::cur_block; }
 KX_DEV u32 kx_nblocks() { return kxemu::num_blocks; }
+KX_DEV int kx_wave() { return kxemu::cur_wave; }                 // wave index inside the workgroup
+KX_DEV int kx_nwaves() { return kxemu::waves_per_block; }
+KX_DEV void kx_block_sync() { kxemu::arrive(kxemu::OP_BLOCK_SYNC, 0, 0); }   // workgroup barrier (multi-wave kernels)
 
 KX_DEV u64 kx_ballot(bool p) { return kxemu::arrive(kxemu::OP_BALLOT, p ? 1 : 0, 0); }
 KX_DEV bool kx_any(bool p) { return kx_ballot(p) != 0; }

@@ -93,6 +93,44 @@ def oracle():
     return _ORACLE
 
 
+class DeflateOracle:
+    """ctypes view of oracle/deflate_l6_ref.c (test infrastructure only)."""
+
+    def __init__(self):
+        src = os.path.join(ROOT, "oracle", "deflate_l6_ref.c")
+        out_dir = os.path.join(ROOT, "oracle", "_build")
+        os.makedirs(out_dir, exist_ok=True)
+        lib = os.path.join(out_dir, "libdref.so")
+        if _newer(lib, [src]):
+            subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-fvisibility=hidden", "-o", lib, src], check=True)
+        d = self.lib = ctypes.CDLL(lib)
+        d.dref_deflate_l6_raw.restype = ctypes.c_size_t
+        d.dref_deflate_l6_raw.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+
+    def compress(self, d: bytes) -> bytes:
+        cap = len(d) + len(d) // 100 + 256
+        o = ctypes.create_string_buffer(cap)
+        n = self.lib.dref_deflate_l6_raw(o, cap, d, len(d))
+        if n == 2 ** 64 - 1:
+            raise RuntimeError("deflate oracle: output did not fit")
+        return o.raw[:n]
+
+
+_DORACLE = None
+
+
+def deflate_oracle():
+    global _DORACLE
+    if _DORACLE is None:
+        _DORACLE = DeflateOracle()
+    return _DORACLE
+
+
+def deflate_golden():
+    with open(os.path.join(ROOT, "tests", "golden", "deflate_l6_golden.json")) as fh:
+        return json.load(fh)
+
+
 def live_libzstd():
     """A libzstd 1.5.7 found on this machine, or None (never required)."""
     import sys
@@ -153,6 +191,27 @@ def emu_compress(datas, G=8, nblocks=2):
     ooff = np.arange(n, dtype=np.uint64) * stride
     olen = np.zeros(n, dtype=np.uint32)
     r = emu().emu_zstd_compress(_vp(buf), _vp(offs), _vp(lens), n, G, nblocks, _vp(out), _vp(ooff), _vp(olen), cap)
+    assert r == 0, f"emulator reported {r}"
+    return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
+
+
+def emu_deflate(datas):
+    """chains -> best -> parse -> encode kernel bodies on the CPU wave emulator."""
+    n = len(datas)
+    lens = np.array([len(d) for d in datas], dtype=np.uint32)
+    offs = np.zeros(n, dtype=np.uint64)
+    pos = 0
+    for i, d in enumerate(datas):
+        offs[i] = pos
+        pos += len(d)
+    buf = np.zeros(pos + 64, dtype=np.uint8)
+    for i, d in enumerate(datas):
+        buf[int(offs[i]):int(offs[i]) + len(d)] = np.frombuffer(d, dtype=np.uint8)
+    stride = 66000
+    out = np.zeros(n * stride, dtype=np.uint8)
+    ooff = np.arange(n, dtype=np.uint64) * stride
+    olen = np.zeros(n, dtype=np.uint32)
+    r = emu().emu_deflate(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(olen), None, None)
     assert r == 0, f"emulator reported {r}"
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
 

@@ -1,0 +1,74 @@
+"""Raw DEFLATE level 6 (BASELINE configs[4]) without a GPU: the oracle
+(oracle/deflate_l6_ref.c) against the committed golden vectors made by this
+machine's zlib and against Python's zlib live, and the kernel bodies
+(kompressor_amd/csrc/deflate_*.h) on the CPU wave emulator."""
+import base64
+import zlib
+
+import numpy as np
+
+import helpers
+from kompressor_amd import corpus
+
+
+def raw6(d):
+    c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, 0)
+    return c.compress(d) + c.flush()
+
+
+def test_oracle_matches_golden_and_reference_kat():
+    G = helpers.deflate_golden()
+    o = helpers.deflate_oracle()
+    S = 65536
+    rows = G["config4"][:256]
+    buf = corpus.make(0, len(rows), S)
+    for i, cls, flen, sha in rows:
+        f = o.compress(buf[i * S:(i + 1) * S].tobytes())
+        assert len(f) == flen and helpers.sha256(f) == sha, f"slice {i} class {cls}"
+    for r in G["ladder"]:
+        S, k = r["size"], r["index"] - 1000
+        d = corpus.make(1000, 8, S)[k * S:(k + 1) * S].tobytes() if S else b""
+        f = o.compress(d)
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r
+    sp = helpers.special_inputs()
+    for r in G["special"]:
+        f = o.compress(sp[r["name"]])
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r["name"]
+    # reference ZlibTest.kt:66-84 (zlib format, default level): the raw body is level-6 raw deflate
+    kat = G["reference_kat"]
+    assert o.compress(kat["plain"].encode()) == base64.b64decode(kat["raw_body_b64"])
+    assert base64.b64decode(kat["zlib_b64"])[2:-4] == base64.b64decode(kat["raw_body_b64"])
+
+
+def test_oracle_against_live_zlib_on_larger_inputs():
+    o = helpers.deflate_oracle()
+    rng = np.random.default_rng(3)
+    for n in [70000, 98304, 131072, 200000]:           # several window slides
+        d = corpus.make(4000, 1, n).tobytes()
+        assert o.compress(d) == raw6(d), n
+        d = rng.integers(0, 3, n, dtype=np.uint8).tobytes()
+        assert o.compress(d) == raw6(d), n
+
+
+def test_emulated_deflate_kernels_match_golden():
+    G = helpers.deflate_golden()
+    S = 65536
+    rows = G["config4"][:8]
+    buf = corpus.make(0, len(rows), S)
+    outs = helpers.emu_deflate([buf[i * S:(i + 1) * S].tobytes() for i in range(len(rows))])
+    for (i, cls, flen, sha), f in zip(rows, outs):
+        assert len(f) == flen and helpers.sha256(f) == sha, f"slice {i} class {cls}"
+    rows = [r for r in G["ladder"] if r["index"] in (1000, 1005)]
+    datas = []
+    for r in rows:
+        S2, k = r["size"], r["index"] - 1000
+        datas.append(corpus.make(1000, 8, S2)[k * S2:(k + 1) * S2].tobytes() if S2 else b"")
+    outs = helpers.emu_deflate(datas)                   # ragged batch incl. empty input and the window-slide sizes
+    for r, f in zip(rows, outs):
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r
+    sp = helpers.special_inputs()
+    rows = G["special"]
+    outs = helpers.emu_deflate([sp[r["name"]] for r in rows])
+    for r, f in zip(rows, outs):
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r["name"]
+        assert zlib.decompress(f, -15) == sp[r["name"]]

@@ -1,0 +1,87 @@
+"""Raw DEFLATE level 6 on the GPU through the C ABI: golden vectors, oracle on the same
+seeded inputs, inflate round trip (Python zlib) at the full BASELINE configs[4] size,
+and the zlib-compatible streaming entry points."""
+import base64
+import zlib
+
+import numpy as np
+import pytest
+
+import helpers
+from kompressor_amd import corpus
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def gpu_deflate(batch, datas):
+    n = len(datas)
+    lens = np.array([len(d) for d in datas], dtype=np.int32)
+    offs = np.zeros(n, dtype=np.int64)
+    pos = 0
+    for i, d in enumerate(datas):
+        offs[i] = pos
+        pos += len(d)
+    host = np.zeros(pos + 64, dtype=np.uint8)
+    for i, d in enumerate(datas):
+        host[offs[i]:offs[i] + len(d)] = np.frombuffer(d, dtype=np.uint8)
+    dst, ooff, olen = batch.deflate(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda())
+    torch.cuda.synchronize()
+    dst, ooff, olen = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+    return [dst[ooff[i]:ooff[i] + olen[i]].tobytes() for i in range(n)]
+
+
+@pytest.fixture(scope="module")
+def batch():
+    from kompressor_amd.batch import ZstdBatch
+    b = ZstdBatch(max_slices=2048, max_slice_bytes=65536)
+    yield b
+    b.close()
+
+
+def test_deflate_golden(batch):
+    G = helpers.deflate_golden()
+    S = 65536
+    rows = G["config4"]
+    buf = corpus.make(0, len(rows), S)
+    outs = gpu_deflate(batch, [buf[i * S:(i + 1) * S].tobytes() for i in range(len(rows))])
+    bad = [(i, cls) for (i, cls, flen, sha), f in zip(rows, outs) if len(f) != flen or helpers.sha256(f) != sha]
+    assert not bad, f"{len(bad)} of {len(rows)} streams differ from zlib, first: {bad[:5]}"
+    rows = G["ladder"]
+    datas = []
+    for r in rows:
+        S2, k = r["size"], r["index"] - 1000
+        datas.append(corpus.make(1000, 8, S2)[k * S2:(k + 1) * S2].tobytes() if S2 else b"")
+    for r, f in zip(rows, gpu_deflate(batch, datas)):
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r
+    sp = helpers.special_inputs()
+    rows = G["special"]
+    for r, f in zip(rows, gpu_deflate(batch, [sp[r["name"]] for r in rows])):
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r["name"]
+
+
+def test_deflate_against_oracle_and_inflate(batch):
+    o = helpers.deflate_oracle()
+    S = 65536
+    buf = corpus.make(40000, 256, S)
+    datas = [buf[i * S:(i + 1) * S].tobytes() for i in range(256)]
+    datas += [buf[i * S:i * S + 1 + (i * 977) % 65000].tobytes() for i in range(128)]
+    for i, (d, f) in enumerate(zip(datas, gpu_deflate(batch, datas))):
+        assert f == o.compress(d), i
+        assert zlib.decompress(f, -15) == d
+
+
+def test_zlib_streaming_abi_like_the_reference():
+    from kompressor_amd.zlib import ZlibCompressor, ZlibFormat
+    G = helpers.deflate_golden()
+    kat = G["reference_kat"]
+    out = ZlibCompressor(ZlibFormat.Raw, compression_level=6).transform_bytes(kat["plain"].encode())
+    assert out == base64.b64decode(kat["raw_body_b64"])
+    d = corpus.make(77, 1, 65536).tobytes()
+    out = ZlibCompressor(ZlibFormat.Raw, 6).transform_bytes(d)
+    assert zlib.decompress(out, -15) == d and helpers.sha256(out) == helpers.sha256(helpers.deflate_oracle().compress(d))
+    assert ZlibCompressor(ZlibFormat.Raw, -1).transform_bytes(b"") == b"\x03\x00"
+    with pytest.raises(RuntimeError, match="Failed allocating zlib stream"):
+        ZlibCompressor(ZlibFormat.Zlib, 6)                 # zlib/gzip wrappers: next
+    with pytest.raises(RuntimeError, match="Bad zlib result code -4: Z_MEM_ERROR"):
+        ZlibCompressor(ZlibFormat.Raw, 6).transform_bytes(bytes(65537))
