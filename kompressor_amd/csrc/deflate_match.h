@@ -62,17 +62,20 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
         kx_block_sync();
         u32 const nIns = n >= 3 ? n - 2 : 0;                // positions 0 .. n-3 enter the chains, in order
         for (u32 base = 0; base < nIns; base += (u32)nthreads) {
+            // every wave hashes its 64 positions up front (global loads outside the serialised part) ...
+            u32 const p = base + (u32)wv * 64u + (u32)lane; bool const valid = p < nIns;
+            u32 h = 0x8000u + (u32)lane;                     // distinct dummy for idle lanes
+            if (valid) h = kd_hash3(src[p], src[p + 1], src[p + 2]);
+            u32 lk = 0;
+            // ... then the waves take turns on the LDS head table, in position order
             for (int w = 0; w < nw; w++) {
                 if (wv == w) {
-                    u32 const p = base + (u32)w * 64u + (u32)lane; bool const valid = p < nIns;
-                    u32 h = 0x8000u + (u32)lane;             // distinct dummy for idle lanes
-                    if (valid) h = kd_hash3(src[p], src[p + 1], src[p + 2]);
                     u32 const old = valid ? head[h] : 0u;
                     kx_lockstep();
                     if (valid) head[h] = (u16)p;
                     kx_lockstep();
                     u32 const chk = valid ? head[h] : p;
-                    u32 lk = old;
+                    lk = old;
                     if (kx_any(valid && chk != (p & 0xFFFFu))) {
                         // two lanes of this wave share a bucket: nearest lower lane is the predecessor,
                         // and the highest lane of each bucket must be the one left in the table
@@ -85,10 +88,10 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
                         kx_lockstep();
                         if (valid && !hasHigher) head[h] = (u16)p;
                     }
-                    if (valid) link[p] = (u16)lk;
                 }
                 kx_block_sync();
             }
+            if (valid) link[p] = (u16)lk;
         }
         kx_block_sync();
     }
@@ -100,7 +103,10 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
 // ---------------------------------------------------------------------------
 #define KD_CHUNK 8192
 #define KD_HIST 32512                                   /* >= MAX_DIST, multiple of 64 */
-struct KdBestLds { u16 lnk[KD_CHUNK + KD_HIST]; u8 sb[KD_CHUNK + KD_HIST + 272]; };
+struct KdBestLds { u16 lnk[KD_CHUNK + KD_HIST]; u32 sw[(KD_CHUNK + KD_HIST + 272 + 8) / 4]; };   // sw = staged bytes, read as aligned words
+
+// 4 bytes at byte offset `o` of the staged window: two aligned LDS words + a funnel shift
+KX_DEV u32 kd_ld32(const u32* sw, int o) { u32 const a = sw[o >> 2], b = sw[(o >> 2) + 1]; return kx_alignbyte(b, a, (u32)o & 3u); }
 
 KX_DEV void deflate_best_body(const KdArgs& a)
 {
@@ -116,7 +122,15 @@ KX_DEV void deflate_best_body(const KdArgs& a)
             int const hiB = (hiP + 264 < n) ? hiP + 264 : n;                // bytes staged up to here
             kx_block_sync();
             for (int i = lo + tid; i < hiP; i += nthreads) lds.lnk[i - lo] = (i + 2 < n) ? link[i] : (u16)0;
-            for (int i = lo + tid; i < hiB; i += nthreads) lds.sb[i - lo] = src[i];
+            {   // bytes [lo, hiB) as little-endian words; bytes past n read as 0 and never count (lengths are capped by lookahead)
+                int const nwords = (hiB - lo + 3 + 8) >> 2;
+                for (int wi = tid; wi < nwords; wi += nthreads) {
+                    int const o = lo + 4 * wi; u32 v = 0;
+                    if (o + 4 <= n) v = kx_ld32(src + o);
+                    else for (int k = 0; o + k < n; k++) v |= (u32)src[o + k] << (8 * k);
+                    lds.sw[wi] = v;
+                }
+            }
             kx_block_sync();
             for (int p = cb + tid; p < hiP; p += nthreads) {
                 KdBest r; r.len128 = 0; r.pos128 = 0; r.len32 = 0; r.pos32 = 0;
@@ -127,20 +141,30 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                     if (c != 0 && p - c <= KD_MAX_DIST) {
                         int const nice = lookahead < 128 ? lookahead : 128;
                         int const maxlen = lookahead < KD_MAX_MATCH ? lookahead : KD_MAX_MATCH;
-                        const u8* const scan = lds.sb + (p - lo);
+                        int const so = p - lo;                              // scan offset in the staged window
+                        u32 const scan01 = kd_ld32(lds.sw, so) & 0xFFFFu;
                         int bestLen = 2, bestPos = 0; int steps = 0; bool done = false;
-                        u8 se1 = scan[1], se = scan[2];                     // scan[best-1], scan[best]
+                        u32 scanEnd = kd_ld32(lds.sw, so + 1) & 0xFFFFu;      // scan[best-1], scan[best]
                         do {
-                            const u8* const m = lds.sb + (c - lo);
+                            int const mo = c - lo;
                             steps++;
-                            // the candidate can only win if it also matches at the current best length
-                            if ((bestLen < maxlen ? m[bestLen] == se : true) && m[bestLen - 1] == se1 && m[0] == scan[0] && m[1] == scan[1]) {
+                            // the candidate can only win if it matches at the current best length too
+                            u32 const m01 = kd_ld32(lds.sw, mo) & 0xFFFFu;
+                            u32 const mEnd = kd_ld32(lds.sw, mo + bestLen - 1) & 0xFFFFu;
+                            bool const endOk = (bestLen < maxlen) ? (mEnd == scanEnd) : ((mEnd & 0xFFu) == (scanEnd & 0xFFu));
+                            if (endOk && m01 == scan01) {
                                 int len = 2;
-                                while (len < maxlen && m[len] == scan[len]) len++;
+                                for (;;) {                                  // 4 bytes per step
+                                    u32 const d = kd_ld32(lds.sw, mo + len) ^ kd_ld32(lds.sw, so + len);
+                                    if (d) { len += (int)(kx_ctz32(d) >> 3); break; }
+                                    len += 4;
+                                    if (len >= maxlen) break;
+                                }
+                                if (len > maxlen) len = maxlen;
                                 if (len > bestLen) {
                                     bestLen = len; bestPos = c;
                                     if (len >= nice) done = true;
-                                    else { se1 = scan[bestLen - 1]; se = scan[bestLen]; }
+                                    else scanEnd = kd_ld32(lds.sw, so + bestLen - 1) & 0xFFFFu;
                                 }
                             }
                             if (steps == 32 || (done && steps < 32)) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }

@@ -58,6 +58,7 @@ KX_DEV void kx_lds_inc(u32* p) { atomicAdd(p, 1u); }
 KX_DEV void kx_lds_or(u32* p, u32 v) { atomicOr(p, v); }
 
 // ---- bit tricks -------------------------------------------------------
+KX_DEV u32 kx_alignbyte(u32 hi, u32 lo, u32 bytes) { return __builtin_amdgcn_alignbyte(hi, lo, bytes); }   // ({hi,lo} >> 8*bytes) & 0xffffffff
 KX_DEV u32 kx_umulhi(u32 a, u32 b) { return __umulhi(a, b); }
 KX_DEV u32 kx_ctz32(u32 v) { return (u32)__builtin_ctz(v); }
 KX_DEV u32 kx_ctz64(u64 v) { return (u32)__builtin_ctzll(v); }

@@ -50,6 +50,7 @@ KX_DEV void kx_atomic_or(u32* p, u32 v) { *p |= v; }
 KX_DEV void kx_lds_inc(u32* p) { *p += 1; }
 KX_DEV void kx_lds_or(u32* p, u32 v) { *p |= v; }
 
+KX_DEV u32 kx_alignbyte(u32 hi, u32 lo, u32 bytes) { return (u32)((((u64)hi << 32) | lo) >> (8 * (bytes & 3))); }
 KX_DEV u32 kx_umulhi(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
 KX_DEV u32 kx_ctz32(u32 v) { return (u32)__builtin_ctz(v); }
 KX_DEV u32 kx_ctz64(u64 v) { return (u32)__builtin_ctzll(v); }
