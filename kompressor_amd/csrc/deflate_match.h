@@ -46,6 +46,7 @@ struct KdArgs {
     u32* syms;          // per slice: 65536 entries: dist | lc << 16
     KdSliceMeta* meta;
     u8* dst; const u64* out_off; u32* out_len;
+    u32 flags;          // timing-only ablations (results wrong): 1 = no match extension, 2 = at most 16 chain steps
 };
 
 // ---------------------------------------------------------------------------
@@ -103,10 +104,16 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
 // ---------------------------------------------------------------------------
 #define KD_CHUNK 8192
 #define KD_HIST 32512                                   /* >= MAX_DIST, multiple of 64 */
-struct KdBestLds { u16 lnk[KD_CHUNK + KD_HIST]; u32 sw[(KD_CHUNK + KD_HIST + 272 + 8) / 4]; };   // sw = staged bytes, read as aligned words
+struct KdBestLds { u16 lnk[KD_CHUNK + KD_HIST]; u32 sw[(KD_CHUNK + KD_HIST + 272 + 16) / 4]; };   // sw = staged bytes, read as aligned words
 
 // 4 bytes at byte offset `o` of the staged window: two aligned LDS words + a funnel shift
 KX_DEV u32 kd_ld32(const u32* sw, int o) { u32 const a = sw[o >> 2], b = sw[(o >> 2) + 1]; return kx_alignbyte(b, a, (u32)o & 3u); }
+// 8 bytes: three aligned words
+KX_DEV u64 kd_ld64(const u32* sw, int o)
+{
+    u32 const a = sw[o >> 2], b = sw[(o >> 2) + 1], c = sw[(o >> 2) + 2]; u32 const sh = (u32)o & 3u;
+    return (u64)kx_alignbyte(b, a, sh) | ((u64)kx_alignbyte(c, b, sh) << 32);
+}
 
 KX_DEV void deflate_best_body(const KdArgs& a)
 {
@@ -123,7 +130,7 @@ KX_DEV void deflate_best_body(const KdArgs& a)
             kx_block_sync();
             for (int i = lo + tid; i < hiP; i += nthreads) lds.lnk[i - lo] = (i + 2 < n) ? link[i] : (u16)0;
             {   // bytes [lo, hiB) as little-endian words; bytes past n read as 0 and never count (lengths are capped by lookahead)
-                int const nwords = (hiB - lo + 3 + 8) >> 2;
+                int const nwords = (hiB - lo + 3 + 16) >> 2;
                 for (int wi = tid; wi < nwords; wi += nthreads) {
                     int const o = lo + 4 * wi; u32 v = 0;
                     if (o + 4 <= n) v = kx_ld32(src + o);
@@ -147,17 +154,18 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                         u32 scanEnd = kd_ld32(lds.sw, so + 1) & 0xFFFFu;      // scan[best-1], scan[best]
                         do {
                             int const mo = c - lo;
+                            int const cnext = lds.lnk[mo];                       // next hop requested before this one is judged
                             steps++;
-                            // the candidate can only win if it matches at the current best length too
-                            u32 const m01 = kd_ld32(lds.sw, mo) & 0xFFFFu;
+                            // the candidate can only win if it matches at the current best length too (most fail here)
                             u32 const mEnd = kd_ld32(lds.sw, mo + bestLen - 1) & 0xFFFFu;
                             bool const endOk = (bestLen < maxlen) ? (mEnd == scanEnd) : ((mEnd & 0xFFu) == (scanEnd & 0xFFu));
-                            if (endOk && m01 == scan01) {
+                            if (endOk && (kd_ld32(lds.sw, mo) & 0xFFFFu) == scan01) {
                                 int len = 2;
-                                for (;;) {                                  // 4 bytes per step
-                                    u32 const d = kd_ld32(lds.sw, mo + len) ^ kd_ld32(lds.sw, so + len);
-                                    if (d) { len += (int)(kx_ctz32(d) >> 3); break; }
-                                    len += 4;
+                                if (a.flags & 1u) len = 3; else
+                                for (;;) {                                  // 8 bytes per step
+                                    u64 const d = kd_ld64(lds.sw, mo + len) ^ kd_ld64(lds.sw, so + len);
+                                    if (d) { len += (int)(kx_ctz64(d) >> 3); break; }
+                                    len += 8;
                                     if (len >= maxlen) break;
                                 }
                                 if (len > maxlen) len = maxlen;
@@ -169,8 +177,8 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                             }
                             if (steps == 32 || (done && steps < 32)) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
                             if (done) break;
-                            c = lds.lnk[c - lo];
-                        } while (c > limit && steps < 128);
+                            c = cnext;
+                        } while (c > limit && steps < ((a.flags & 2u) ? 16 : 128));
                         if (steps < 32 && !done) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
                         r.len128 = (u16)(bestLen > 2 ? bestLen : 0); r.pos128 = (u16)bestPos;
                     }

@@ -238,7 +238,7 @@ extern "C" int kmp_deflate_compress_batch(kmp_batch_ctx* c, const void* d_src, c
         KdArgs a;
         a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = d_in_len + first; a.n_slices = m;
         a.link = c->dfl_link; a.best = c->dfl_best; a.syms = c->dfl_syms; a.meta = c->dfl_meta;
-        a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first;
+        a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = env_u32("KMP_DEFLATE_FLAGS", 0);
         bool const prof = c->profiling && first == 0;      // per-kernel events for the first chunk
         if (prof) HIP_TRY(hipEventRecord(c->ev[8], st));
         hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(256), 0, st, a);

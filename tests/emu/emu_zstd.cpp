@@ -83,7 +83,7 @@ int emu_deflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* 
     KdArgs a;
     a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
     a.link = link.data(); a.best = best.data(); a.syms = syms.data(); a.meta = meta.data();
-    a.dst = dst; a.out_off = out_off; a.out_len = out_len;
+    a.dst = dst; a.out_off = out_off; a.out_len = out_len; a.flags = 0;
     kxemu::failed = 0;
     kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_chains_body(a); });
     if (kxemu::failed) return -1;
