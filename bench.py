@@ -107,7 +107,7 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("KMP_BENCH_FORCE_DIST"):      # the env switch lets a 1-rank launch exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -83,15 +83,27 @@ KMP_API size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* dctx,
  * createCompressor :10-26 (deflateInit2), freeCompressor :28-38 (deflateEnd), compressStream :40-82
  * (deflate, call at :73).  Same cursor semantics; the return value is zlib's: Z_OK 0, Z_STREAM_END 1,
  * Z_BUF_ERROR -5 are benign for the Kotlin side (ZlibCompressor.jvm.kt:49-56).  The GPU path implements
- * level 6 (or -1), windowBits -15 (ZlibFormat.Raw), memLevel 8, strategy 0 and slices <= 64 KiB; other
- * settings make create return NULL.  The decompressor half (inflate) is not built yet. */
+ * level 6 (or -1), windowBits -15
+ * (ZlibFormat.Raw) or 15 (ZlibFormat.Zlib: 78 9C header + Adler-32), memLevel 8, strategy 0 and slices
+ * <= 64 KiB; other settings (gzip, other levels) make create return NULL. */
 typedef struct kmp_zlib_cstream kmp_zlib_cstream;
+typedef struct kmp_zlib_dstream kmp_zlib_dstream;
 KMP_API kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bits, int mem_level, int strategy);
 KMP_API int kmp_zlib_free_compressor(kmp_zlib_cstream* stream);
 KMP_API int kmp_zlib_compress_stream(kmp_zlib_cstream* stream,
                                      void* dst, size_t dst_size, size_t* dst_pos,
                                      const void* src, size_t src_size, size_t* src_pos,
                                      int finish);
+/* createDecompressor :84-98 (inflateInit2), freeDecompressor :100-110 (inflateEnd), decompressStream :112-153
+ * (inflate, call at :144).  windowBits -15..-8 = raw, 8..15 = zlib wrapper (Adler-32 verified); gzip and
+ * auto-detection (ZlibFormat.Gzip / Auto) make create return NULL for now.  The stream is decoded when the
+ * caller passes finish (the one-shot driver always does); any block types, any compression level. */
+KMP_API kmp_zlib_dstream* kmp_zlib_create_decompressor(int window_bits);
+KMP_API int kmp_zlib_free_decompressor(kmp_zlib_dstream* stream);
+KMP_API int kmp_zlib_decompress_stream(kmp_zlib_dstream* stream,
+                                       void* dst, size_t dst_size, size_t* dst_pos,
+                                       const void* src, size_t src_size, size_t* src_pos,
+                                       int finish);
 
 /* replace ZSTD_isError / ZSTD_getErrorName (Wrapper.cpp:189-196) */
 KMP_API unsigned kmp_zstd_is_error(size_t code);
@@ -152,6 +164,18 @@ KMP_API int kmp_deflate_compress_batch(kmp_batch_ctx* ctx,
                                        uint32_t n,
                                        void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                        void* hip_stream);
+/* same, with the RFC 1950 zlib wrapper (what ZlibFormat.Zlib at the default level produces) */
+KMP_API int kmp_zlib_compress_batch(kmp_batch_ctx* ctx,
+                                    const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                    uint32_t n,
+                                    void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
+                                    void* hip_stream);
+/* inflate: n raw-deflate (zlib_wrapper = 0) or zlib (1) streams -> d_dst + d_out_off[i] (capacity d_out_cap[i]);
+ * d_status[i] = 0, -3 (Z_DATA_ERROR) or -5 (Z_BUF_ERROR: capacity too small or input truncated) */
+KMP_API int kmp_inflate_batch(kmp_batch_ctx* ctx,
+                              const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
+                              void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                              uint32_t* d_out_len, int32_t* d_status, int zlib_wrapper, void* hip_stream);
 /* ms4[0..3] = k_deflate_chains, k_deflate_best, k_deflate_parse, k_deflate_encode of the last batch */
 KMP_API int kmp_deflate_last_kernel_ms(kmp_batch_ctx* ctx, float* ms4);
 

@@ -11,7 +11,7 @@ def __getattr__(name):
     if name in ("ZstdCompressor", "ZstdDecompressor"):
         from . import zstd
         return getattr(zstd, name)
-    if name in ("ZlibCompressor", "ZlibFormat"):
+    if name in ("ZlibCompressor", "ZlibDecompressor", "ZlibFormat"):
         from . import zlib
         return getattr(zlib, name)
     if name in ("ZstdBatch", "compress_bound"):

@@ -91,8 +91,23 @@ class ZstdBatch:
             raise RuntimeError(f"kmp_zstd_decompress_batch failed ({rc}): {_lib.last_error()}")
         return dst, out_off, out_len, status
 
-    def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None):
-        """Raw DEFLATE streams (zlib level 6, windowBits 15, memLevel 8) for slices of at most 64 KiB."""
+    def inflate(self, src, in_off, in_len, out_cap, zlib_wrapper=False, dst=None, out_off=None):
+        """n raw-deflate (or zlib-wrapped) streams -> slices. Returns (dst, out_off, out_len, status)."""
+        n = in_len.numel()
+        if out_off is None:
+            out_off = torch.cumsum(out_cap.to(torch.int64), 0) - out_cap.to(torch.int64)
+        if dst is None:
+            dst = torch.empty(int(out_cap.to(torch.int64).sum().item()) + 64, dtype=torch.uint8, device=self.device)
+        out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
+        status = torch.zeros(n, dtype=torch.int32, device=self.device)
+        rc = self.lib.kmp_inflate_batch(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n, _ptr(dst), _ptr(out_off), _ptr(out_cap),
+                                        _ptr(out_len), _ptr(status), 1 if zlib_wrapper else 0, self._stream())
+        if rc != 0:
+            raise RuntimeError(f"kmp_inflate_batch failed ({rc}): {_lib.last_error()}")
+        return dst, out_off, out_len, status
+
+    def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, zlib_wrapper=False):
+        """DEFLATE streams (zlib level 6, windowBits 15, memLevel 8), raw or zlib-wrapped, for slices of at most 64 KiB."""
         n = in_len.numel()
         stride = (self.lib.kmp_deflate_bound(min(self.max_slice_bytes, 65536)) + 63) & ~63
         if dst is None:
@@ -101,8 +116,8 @@ class ZstdBatch:
             out_off = torch.arange(n, dtype=torch.int64, device=self.device) * stride
         if out_len is None:
             out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
-        rc = self.lib.kmp_deflate_compress_batch(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
-                                                 _ptr(dst), _ptr(out_off), _ptr(out_len), self._stream())
+        fn = self.lib.kmp_zlib_compress_batch if zlib_wrapper else self.lib.kmp_deflate_compress_batch
+        rc = fn(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n, _ptr(dst), _ptr(out_off), _ptr(out_len), self._stream())
         if rc != 0:
             raise RuntimeError(f"kmp_deflate_compress_batch failed ({rc}): {_lib.last_error()}")
         return dst, out_off, out_len

@@ -202,14 +202,31 @@ KX_DEV void kd_cbuf_put(u32* cbuf, u32 pos, u64 v, u32 n)
     if (sh + n > 64) { u32 const hi = (u32)(v >> (64 - sh)); if (hi) kx_lds_or(&cbuf[wi + 2], hi); }
 }
 
+// Adler-32 of p[0..n), all lanes get the value
+KX_DEV u32 kx_wave_adler32(const u8* p, u32 n, int lane)
+{
+    u32 const chunk = (n + 63) / 64; u32 const b0 = (u32)lane * chunk; u32 b1 = b0 + chunk; if (b1 > n) b1 = n;
+    u32 s1 = 0, s2 = 0;
+    for (u32 i = (b0 < n ? b0 : n); i < b1; i++) { s1 += p[i]; s2 += s1; if ((i & 2047u) == 2047u) { s1 %= 65521u; s2 %= 65521u; } }
+    s1 %= 65521u; s2 %= 65521u;
+    // A = 1 + sum a_i ; B = n + sum (b_i + a_i * bytes after chunk i)
+    u32 const after = (b1 < n) ? n - b1 : 0u;
+    u32 A = s1, B = (s2 + (u32)(((u64)s1 * (after % 65521u)) % 65521u)) % 65521u;
+    for (int o = 1; o < 64; o <<= 1) { A = (A + kx_shfl(A, lane ^ o)) % 65521u; B = (B + kx_shfl(B, lane ^ o)) % 65521u; }
+    A = (A + 1u) % 65521u; B = (B + n % 65521u) % 65521u;
+    return (B << 16) | A;
+}
+
 KX_DEV void deflate_encode_slice(const KdArgs& a, KdEncLds& lds, u32 slice, int lane)
 {
     const u8* const src = a.src + a.in_off[slice];
     u8* const dst = a.dst + a.out_off[slice];
     const u32* const syms = a.syms + (size_t)slice * 65536u;
     KdSliceMeta const mm = a.meta[slice];
-    u32 bitpos = 0;                                 // bits written so far; lds.cbuf[0] holds the pending partial word
-    for (int i = lane; i < 128; i += 64) lds.cbuf[i] = 0;
+    // bits written so far; lds.cbuf[0] holds the pending partial word. The zlib wrapper's header for
+    // level 6 / 32 KiB window is 78 9C (CMF 0x78, FLG: level flags 2, check bits so that CMF*256+FLG % 31 == 0)
+    u32 bitpos = a.format == 1 ? 16u : 0u;
+    for (int i = lane; i < 128; i += 64) lds.cbuf[i] = (i == 0 && a.format == 1) ? 0x9C78u : 0u;
     kx_sync();
     u32 s0 = 0;
     for (u32 b = 0; b < mm.nblocks; b++) {
@@ -323,10 +340,12 @@ KX_DEV void deflate_encode_slice(const KdArgs& a, KdEncLds& lds, u32 slice, int 
         s0 = s1;
     }
     // bi_windup of the last block: flush the pending partial word
-    u32 const total_bytes = (bitpos + 7) >> 3;
+    u32 total_bytes = (bitpos + 7) >> 3;
+    u32 const adler = (a.format == 1) ? kx_wave_adler32(src, a.in_len[slice], lane) : 0u;
     if (lane == 0) {
         u32 const wb = 4u * (bitpos >> 5); u32 const v = lds.cbuf[0];
         for (u32 k = wb; k < total_bytes; k++) dst[k] = (u8)(v >> (8 * (k - wb)));
+        if (a.format == 1) { dst[total_bytes] = (u8)(adler >> 24); dst[total_bytes + 1] = (u8)(adler >> 16); dst[total_bytes + 2] = (u8)(adler >> 8); dst[total_bytes + 3] = (u8)adler; total_bytes += 4; }
         a.out_len[slice] = total_bytes;
     }
 }

@@ -47,6 +47,7 @@ struct KdArgs {
     KdSliceMeta* meta;
     u8* dst; const u64* out_off; u32* out_len;
     u32 flags;          // timing-only ablations (results wrong): 1 = no match extension, 2 = at most 16 chain steps
+    u32 format;         // 0 = raw deflate, 1 = zlib wrapper (78 9C header, Adler-32 trailer)
 };
 
 // ---------------------------------------------------------------------------

@@ -7,6 +7,7 @@
 #include "zstd_decode.h"
 #include "deflate_match.h"
 #include "deflate_encode.h"
+#include "deflate_decode.h"
 #include "../../include/kompressor_hip.h"
 
 #include <mutex>
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chai
 __global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_parse(KdArgs a) { deflate_parse_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_encode(KdArgs a) { deflate_encode_body(a); }
+__global__ __launch_bounds__(64) void k_inflate(KiArgs a) { inflate_body(a); }
 
 // exclusive prefix sum of u32 lengths into u64 offsets, single workgroup
 __global__ __launch_bounds__(1024) void k_scan_lengths(const u32* len, u32 n, u64* off)
@@ -216,8 +218,33 @@ extern "C" int kmp_zstd_decompress_batch(kmp_batch_ctx* c, const void* d_src, co
 
 extern "C" size_t kmp_deflate_bound(size_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 13 + 8; }
 
+static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream);
 extern "C" int kmp_deflate_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                           uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
+{ return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, 0, hip_stream); }
+extern "C" int kmp_zlib_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
+{ return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, 1, hip_stream); }
+
+extern "C" int kmp_inflate_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
+                                 void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap, uint32_t* d_out_len, int32_t* d_status,
+                                 int zlib_wrapper, void* hip_stream)
+{
+    if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_cap || !d_out_len || !d_status))) { g_last_error = "kmp_inflate_batch: null argument"; return KMP_ERR_ARG; }
+    if (n == 0) return KMP_OK;
+    hipStream_t const st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(c->device));
+    KiArgs a;
+    a.src = (const u8*)d_src; a.in_off = d_in_off; a.in_len = d_in_len; a.n_slices = n;
+    a.dst = (u8*)d_dst; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_len = d_out_len; a.status = d_status; a.format = zlib_wrapper ? 1u : 0u;
+    hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return KMP_OK;
+}
+
+static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream)
 {
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_deflate_compress_batch: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_deflate_compress_batch: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
@@ -238,7 +265,7 @@ extern "C" int kmp_deflate_compress_batch(kmp_batch_ctx* c, const void* d_src, c
         KdArgs a;
         a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = d_in_len + first; a.n_slices = m;
         a.link = c->dfl_link; a.best = c->dfl_best; a.syms = c->dfl_syms; a.meta = c->dfl_meta;
-        a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = env_u32("KMP_DEFLATE_FLAGS", 0);
+        a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = env_u32("KMP_DEFLATE_FLAGS", 0); a.format = format;
         bool const prof = c->profiling && first == 0;      // per-kernel events for the first chunk
         if (prof) HIP_TRY(hipEventRecord(c->ev[8], st));
         hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(256), 0, st, a);
@@ -435,7 +462,7 @@ extern "C" kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bi
 {
     // what deflateInit2 would accept; the GPU path implements raw deflate (-15), level 6 (-1 = default = 6), memLevel 8, strategy 0
     if (level == -1) level = 6;
-    if (level != 6 || window_bits != -15 || mem_level != 8 || strategy != 0) return nullptr;
+    if (level != 6 || (window_bits != -15 && window_bits != 15) || mem_level != 8 || strategy != 0) return nullptr;
     kmp_zlib_cstream* z = new (std::nothrow) kmp_zlib_cstream();
     if (!z) return nullptr;
     z->level = level; z->window_bits = window_bits; z->mem_level = mem_level; z->strategy = strategy; z->out_pos = 0; z->stage = 0;
@@ -460,11 +487,69 @@ extern "C" int kmp_zlib_compress_stream(kmp_zlib_cstream* z, void* dst, size_t d
         if (len && hipMemcpy(s.d_in, z->in.data(), len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
         if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
         if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
-        if (kmp_deflate_compress_batch(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, nullptr) != KMP_OK) return Z_MEM_ERROR_;
+        if (deflate_batch_impl(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, z->window_bits > 0 ? 1u : 0u, nullptr) != KMP_OK) return Z_MEM_ERROR_;
         if (hipMemcpy(&olen, s.d_len + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR_;
         if (olen == 0 || olen > s.out_cap) return Z_DATA_ERROR_;
         z->out.resize(olen);
         if (hipMemcpy(z->out.data(), s.d_out, olen, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR_;
+        z->stage = 1; z->out_pos = 0;
+    }
+    size_t const room = dst_size - *dst_pos, left = z->out.size() - z->out_pos;
+    size_t const k = room < left ? room : left;
+    if (k) { memcpy((u8*)dst + *dst_pos, z->out.data() + z->out_pos, k); *dst_pos += k; z->out_pos += k; }
+    if (z->out_pos == z->out.size()) { z->stage = 2; return Z_STREAM_END_; }
+    return k ? Z_OK_ : Z_BUF_ERROR_;
+}
+
+struct kmp_zlib_dstream { int window_bits; std::vector<u8> in; std::vector<u8> out; size_t out_pos; int stage; kmp_batch_ctx* batch; };
+
+extern "C" kmp_zlib_dstream* kmp_zlib_create_decompressor(int window_bits)
+{
+    // inflateInit2 semantics served here: -15..-8 raw, 8..15 zlib wrapper (gzip / auto-detect: not yet)
+    bool const raw = window_bits <= -8 && window_bits >= -15, zl = window_bits >= 8 && window_bits <= 15;
+    if (!raw && !zl) return nullptr;
+    kmp_zlib_dstream* z = new (std::nothrow) kmp_zlib_dstream();
+    if (!z) return nullptr;
+    z->window_bits = window_bits; z->out_pos = 0; z->stage = 0; z->batch = nullptr;
+    return z;
+}
+extern "C" int kmp_zlib_free_decompressor(kmp_zlib_dstream* z) { if (z) { if (z->batch) kmp_batch_destroy(z->batch); delete z; } return 0; }
+
+extern "C" int kmp_zlib_decompress_stream(kmp_zlib_dstream* z, void* dst, size_t dst_size, size_t* dst_pos,
+                                          const void* src, size_t src_size, size_t* src_pos, int finish)
+{
+    enum { Z_OK_ = 0, Z_STREAM_END_ = 1, Z_STREAM_ERROR_ = -2, Z_DATA_ERROR_ = -3, Z_MEM_ERROR_ = -4, Z_BUF_ERROR_ = -5 };
+    if (!z || !dst_pos || !src_pos || *dst_pos > dst_size || *src_pos > src_size) return Z_STREAM_ERROR_;
+    if (z->stage == 0) {
+        size_t const avail = src_size - *src_pos;
+        if (avail) { const u8* p = (const u8*)src + *src_pos; z->in.insert(z->in.end(), p, p + avail); *src_pos = src_size; }
+        if (!finish) return avail ? Z_OK_ : Z_BUF_ERROR_;           // the stream is decoded when the caller finishes it
+        if (!z->batch && kmp_batch_create(&z->batch, 0, 1, 65536, 8) != KMP_OK) return Z_MEM_ERROR_;
+        size_t const n = z->in.size();
+        u8* d_in = nullptr; u8* d_out = nullptr; u64* d_off = nullptr; u32* d_len = nullptr; int rc = Z_MEM_ERROR_;
+        if (hipMalloc((void**)&d_in, n + 64) == hipSuccess && hipMalloc((void**)&d_off, 64) == hipSuccess && hipMalloc((void**)&d_len, 64) == hipSuccess) {
+            // the decoded size is not known in advance: grow the capacity until the stream fits
+            for (size_t cap = 256u << 10; cap <= (256u << 20); cap <<= 2) {
+                if (d_out) { (void)hipFree(d_out); d_out = nullptr; }
+                if (hipMalloc((void**)&d_out, cap + 64) != hipSuccess) break;
+                u64 offs[2] = { 0, 0 }; u32 lens[4] = { (u32)n, (u32)cap, 0, 0 };
+                if ((n && hipMemcpy(d_in, z->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) ||
+                    hipMemcpy(d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(d_len, lens, sizeof(lens), hipMemcpyHostToDevice) != hipSuccess) break;
+                if (kmp_inflate_batch(z->batch, d_in, d_off, d_len, 1, d_out, d_off + 1, d_len + 1, d_len + 2, (int32_t*)(d_len + 3),
+                                      z->window_bits > 0, nullptr) != KMP_OK) break;
+                if (hipMemcpy(lens, d_len, sizeof(lens), hipMemcpyDeviceToHost) != hipSuccess) break;
+                int const st = (int)lens[3];
+                if (st == Z_BUF_ERROR_) continue;                    // output did not fit: next capacity
+                if (st != 0) { rc = st; break; }
+                z->out.resize(lens[2]);
+                if (lens[2] && hipMemcpy(z->out.data(), d_out, lens[2], hipMemcpyDeviceToHost) != hipSuccess) break;
+                rc = Z_OK_;
+                break;
+            }
+        }
+        (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_off); (void)hipFree(d_len);
+        if (rc != Z_OK_) return rc == Z_MEM_ERROR_ ? Z_MEM_ERROR_ : Z_DATA_ERROR_;
         z->stage = 1; z->out_pos = 0;
     }
     size_t const room = dst_size - *dst_pos, left = z->out.size() - z->out_pos;

@@ -4,8 +4,8 @@
   ZlibFormat          .../commonMain/.../ZlibFormat.kt:32-57 (Raw negates windowBits)
   ZlibWrapper externs .../zlib/ZlibWrapper.kt:24-54 (-> jni/Wrapper.cpp)
 
-The GPU path covers ZlibFormat.Raw at level 6 (BASELINE configs[4]); the zlib / gzip
-wrappers and the decompressor are next."""
+The GPU path covers ZlibFormat.Raw and ZlibFormat.Zlib at level 6 (BASELINE configs[4] and the
+reference's deflate KAT) and inflate for both; gzip / auto-detect are next."""
 import ctypes
 import weakref
 
@@ -61,3 +61,29 @@ class ZlibCompressor(SliceTransform):
         output.write_start = dst_pos.value
         _check_error_result(result)
         output.insufficient = input.has_data or (finish and result != Z_STREAM_END)
+
+
+class ZlibDecompressor(SliceTransform):
+    """ZlibDecompressorImpl (kompressor-zlib--nativelib/.../zlib/ZlibDecompressor.jvm.kt) over kmp_zlib_decompress_stream."""
+
+    def __init__(self, format=ZlibFormat.Zlib, window_bits=15):   # noqa: A002
+        lib = self._lib = _lib.load()
+        wb = -window_bits if format == ZlibFormat.Raw else window_bits + 16 if format == ZlibFormat.Gzip else window_bits
+        self._stream = lib.kmp_zlib_create_decompressor(wb)
+        if not self._stream:
+            raise RuntimeError("Failed allocating zlib stream")
+        self._cleaner = weakref.finalize(self, lib.kmp_zlib_free_decompressor, self._stream)
+
+    def transform(self, input, output, finish):            # noqa: A002
+        lib = self._lib
+        src_pos = ctypes.c_size_t(input.read_start)
+        dst_pos = ctypes.c_size_t(output.write_start)
+        result = lib.kmp_zlib_decompress_stream(
+            self._stream,
+            ctypes.cast(_buf(output.data), ctypes.c_void_p), output.write_limit, ctypes.byref(dst_pos),
+            ctypes.cast(_buf(input.data), ctypes.c_void_p), input.write_start, ctypes.byref(src_pos),
+            1 if finish else 0)
+        input.read_start = src_pos.value
+        output.write_start = dst_pos.value
+        _check_error_result(result)
+        output.insufficient = output.is_full and result != Z_STREAM_END

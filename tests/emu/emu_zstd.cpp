@@ -74,7 +74,7 @@ int emu_zstd_decompress(const u8* src, const u64* in_off, const u32* in_len, u32
 // raw DEFLATE level 6 pipeline (chains -> best -> parse -> encode) on the emulator
 extern "C" __attribute__((visibility("default")))
 int emu_deflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* dst, const u64* out_off, u32* out_len,
-                u16* link_out, KdBest* best_out)
+                u16* link_out, KdBest* best_out, u32 format)
 {
     std::vector<u16> link((size_t)n * 65536u, 0xEEEE);
     std::vector<KdBest> best((size_t)n * 65536u);
@@ -83,7 +83,7 @@ int emu_deflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* 
     KdArgs a;
     a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
     a.link = link.data(); a.best = best.data(); a.syms = syms.data(); a.meta = meta.data();
-    a.dst = dst; a.out_off = out_off; a.out_len = out_len; a.flags = 0;
+    a.dst = dst; a.out_off = out_off; a.out_len = out_len; a.flags = 0; a.format = format;
     kxemu::failed = 0;
     kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_chains_body(a); });
     if (kxemu::failed) return -1;
@@ -96,4 +96,17 @@ int emu_deflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* 
     if (link_out) memcpy(link_out, link.data(), link.size() * 2);
     if (best_out) memcpy(best_out, best.data(), best.size() * sizeof(KdBest));
     return 0;
+}
+
+#include "deflate_decode.h"
+extern "C" __attribute__((visibility("default")))
+int emu_inflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* dst, const u64* out_off, const u32* out_cap,
+                u32* out_len, int* status, u32 format)
+{
+    KiArgs a;
+    a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
+    a.dst = dst; a.out_off = out_off; a.out_cap = out_cap; a.out_len = out_len; a.status = status; a.format = format;
+    kxemu::failed = 0;
+    kxemu::launch(n < 3 ? n : 3, [&]() { inflate_body(a); });
+    return kxemu::failed ? -1 : 0;
 }

@@ -195,7 +195,7 @@ def emu_compress(datas, G=8, nblocks=2):
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
 
 
-def emu_deflate(datas):
+def emu_deflate(datas, zlib_wrapper=False):
     """chains -> best -> parse -> encode kernel bodies on the CPU wave emulator."""
     n = len(datas)
     lens = np.array([len(d) for d in datas], dtype=np.uint32)
@@ -211,9 +211,34 @@ def emu_deflate(datas):
     out = np.zeros(n * stride, dtype=np.uint8)
     ooff = np.arange(n, dtype=np.uint64) * stride
     olen = np.zeros(n, dtype=np.uint32)
-    r = emu().emu_deflate(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(olen), None, None)
+    r = emu().emu_deflate(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(olen), None, None, 1 if zlib_wrapper else 0)
     assert r == 0, f"emulator reported {r}"
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
+
+
+def emu_inflate(streams, caps, zlib_wrapper=False):
+    n = len(streams)
+    lens = np.array([len(f) for f in streams], dtype=np.uint32)
+    offs = np.zeros(n, dtype=np.uint64)
+    pos = 16
+    for i, f in enumerate(streams):
+        offs[i] = pos
+        pos += (len(f) + 31) & ~15
+    buf = np.zeros(pos + 64, dtype=np.uint8)
+    for i, f in enumerate(streams):
+        buf[int(offs[i]):int(offs[i]) + len(f)] = np.frombuffer(f, dtype=np.uint8)
+    caps = np.array(caps, dtype=np.uint32)
+    ooff = np.zeros(n, dtype=np.uint64)
+    t = 0
+    for i in range(n):
+        ooff[i] = t
+        t += int(caps[i]) + 16
+    out = np.zeros(t + 64, dtype=np.uint8)
+    olen = np.zeros(n, dtype=np.uint32)
+    st = np.zeros(n, dtype=np.int32)
+    r = emu().emu_inflate(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(caps), _vp(olen), _vp(st), 1 if zlib_wrapper else 0)
+    assert r == 0, f"emulator reported {r}"
+    return [out[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)], [int(x) for x in st]
 
 
 def emu_decompress(frames, caps, nblocks=2):

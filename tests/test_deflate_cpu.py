@@ -72,3 +72,29 @@ def test_emulated_deflate_kernels_match_golden():
     for r, f in zip(rows, outs):
         assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r["name"]
         assert zlib.decompress(f, -15) == sp[r["name"]]
+
+
+def test_emulated_zlib_wrapper_and_inflate():
+    G = helpers.deflate_golden()
+    kat = G["reference_kat"]
+    # the reference's compress-side known-answer vector, byte for byte (ZlibTest.kt:66-84)
+    out = helpers.emu_deflate([kat["plain"].encode()], zlib_wrapper=True)[0]
+    assert out == base64.b64decode(kat["zlib_b64"])
+    d = corpus.make(123, 1, 30000).tobytes()
+    assert helpers.emu_deflate([d], zlib_wrapper=True)[0] == zlib.compress(d, 6)
+    # inflate: every block type and level, raw and wrapped, plus error codes
+    datas = [corpus.make(3000 + k, 1, s).tobytes() for k, s in enumerate([0, 1, 100, 5000, 40000, 65536])]
+    for lvl, strat in [(6, 0), (1, 0), (9, 0), (6, zlib.Z_FIXED), (0, 0)]:
+        streams = []
+        for x in datas:
+            c = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, strat)
+            streams.append(c.compress(x) + c.flush())
+        outs, st = helpers.emu_inflate(streams, [max(len(x), 1) for x in datas])
+        assert st == [0] * len(datas) and outs == datas, (lvl, strat)
+    outs, st = helpers.emu_inflate([zlib.compress(x, 6) for x in datas], [max(len(x), 1) for x in datas], zlib_wrapper=True)
+    assert st == [0] * len(datas) and outs == datas
+    good = zlib.compress(datas[3], 6)
+    bad = bytearray(good)
+    bad[-1] ^= 1
+    outs, st = helpers.emu_inflate([bytes(bad), good, good[:-9]], [5000, 100, 5000], zlib_wrapper=True)
+    assert st[0] == -3 and st[1] == -5 and st[2] != 0

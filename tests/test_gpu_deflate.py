@@ -81,7 +81,58 @@ def test_zlib_streaming_abi_like_the_reference():
     out = ZlibCompressor(ZlibFormat.Raw, 6).transform_bytes(d)
     assert zlib.decompress(out, -15) == d and helpers.sha256(out) == helpers.sha256(helpers.deflate_oracle().compress(d))
     assert ZlibCompressor(ZlibFormat.Raw, -1).transform_bytes(b"") == b"\x03\x00"
+    # the reference's compress-side known-answer vector, byte for byte (ZlibTest.kt:66-84: zlib format, default level)
+    from kompressor_amd.zlib import ZlibDecompressor
+    assert ZlibCompressor(ZlibFormat.Zlib).transform_bytes(kat["plain"].encode()) == base64.b64decode(kat["zlib_b64"])
+    assert ZlibDecompressor(ZlibFormat.Zlib).transform_bytes(base64.b64decode(kat["zlib_b64"])) == kat["plain"].encode()
+    zd = ZlibCompressor(ZlibFormat.Zlib, 6).transform_bytes(d)
+    assert zd == zlib.compress(d, 6)
+    assert ZlibDecompressor(ZlibFormat.Zlib).transform_bytes(zd) == d
+    assert ZlibDecompressor(ZlibFormat.Raw).transform_bytes(out) == d
+    big = corpus.make(900, 1, 1 << 20).tobytes()           # decoder is not limited to 64 KiB (capacity grows)
+    assert ZlibDecompressor(ZlibFormat.Zlib).transform_bytes(zlib.compress(big, 9)) == big
+    with pytest.raises(RuntimeError, match="Bad zlib result code -3: Z_DATA_ERROR"):
+        ZlibDecompressor(ZlibFormat.Zlib).transform_bytes(zd[:-1] + bytes([zd[-1] ^ 1]))
     with pytest.raises(RuntimeError, match="Failed allocating zlib stream"):
-        ZlibCompressor(ZlibFormat.Zlib, 6)                 # zlib/gzip wrappers: next
+        ZlibCompressor(ZlibFormat.Gzip, 6)                 # gzip wrapper: next
     with pytest.raises(RuntimeError, match="Bad zlib result code -4: Z_MEM_ERROR"):
         ZlibCompressor(ZlibFormat.Raw, 6).transform_bytes(bytes(65537))
+
+
+def test_inflate_batch_roundtrip_and_foreign_streams(batch):
+    S = 65536
+    buf = corpus.make(50000, 512, S)
+    datas = [buf[i * S:(i + 1) * S].tobytes() for i in range(512)]
+    # our own streams back through the GPU inflate
+    lens = np.full(512, S, dtype=np.int32)
+    src = torch.from_numpy(buf).cuda()
+    in_off = torch.arange(512, dtype=torch.int64, device="cuda") * S
+    dst, ooff, olen = batch.deflate(src, in_off, torch.from_numpy(lens).cuda(), zlib_wrapper=True)
+    cap = torch.full((512,), S, dtype=torch.int32, device="cuda")
+    out, o2, l2, st = batch.inflate(dst, ooff, olen, cap, zlib_wrapper=True, out_off=in_off)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum().item()) == 0 and int((l2 != S).sum().item()) == 0
+    assert torch.equal(out[: 512 * S], src)
+    # streams written by the host zlib at other levels / strategies (stored, fixed, dynamic blocks)
+    streams, plains = [], []
+    for k, (lvl, strat) in enumerate([(1, 0), (9, 0), (6, zlib.Z_FIXED), (0, 0), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)]):
+        for d in datas[k * 8:(k + 1) * 8]:
+            c = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, strat)
+            streams.append(c.compress(d) + c.flush())
+            plains.append(d)
+    n = len(streams)
+    slen = np.array([len(x) for x in streams], dtype=np.int32)
+    soff = np.zeros(n, dtype=np.int64)
+    pos = 0
+    for i, x in enumerate(streams):
+        soff[i] = pos
+        pos += (len(x) + 15) & ~15
+    host = np.zeros(pos + 64, dtype=np.uint8)
+    for i, x in enumerate(streams):
+        host[soff[i]:soff[i] + len(x)] = np.frombuffer(x, dtype=np.uint8)
+    cap = torch.full((n,), S, dtype=torch.int32, device="cuda")
+    out, o2, l2, st = batch.inflate(torch.from_numpy(host).cuda(), torch.from_numpy(soff).cuda(), torch.from_numpy(slen).cuda(), cap)
+    torch.cuda.synchronize()
+    out, o2, l2, st = out.cpu().numpy(), o2.cpu().numpy(), l2.cpu().numpy(), st.cpu().numpy()
+    for i in range(n):
+        assert st[i] == 0 and out[o2[i]:o2[i] + l2[i]].tobytes() == plains[i], i
