@@ -23,7 +23,7 @@
 // --------------------------------------------------------------------------
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match(KMatchArgs a) { zstd_match_body<G>(a); }
-__global__ __launch_bounds__(64, 3) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
+__global__ __launch_bounds__(64, 4) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
 __global__ __launch_bounds__(64) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
 
 __global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chains_body(a); }
@@ -190,7 +190,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     e.scratch = c->scratch; e.scratch_words = c->scratch_words;
     e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[2], st));
-    hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), 0, st, e);
+    hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), env_u32("KMP_ENTROPY_PAD_LDS", 0), st, e);   // padding = occupancy experiment only
     HIP_TRY(hipGetLastError());
     if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[3], st)); c->ev_valid[1] = 1; }
     return KMP_OK;

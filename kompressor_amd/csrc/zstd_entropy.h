@@ -38,22 +38,29 @@ struct KEntropyLds {
             u32 rank[192];    // bucket sort positions: curr | base << 16
             u32 qstack[40];   // explicit quicksort stack
         } huf;
-        struct {              // sequence phase (state[0]/dnb[0]/dfs[0] also serve the Huffman-weight FSE)
-            u16 state[3][512];   // FSE next-state tables (LL, OF, ML)
+        struct {              // sequence phase (stateLL/dnb[0]/dfs[0] also serve the Huffman-weight FSE)
+            u16 stateLL[512];    // FSE next-state tables
+            u16 stateML[512];
+            u16 stateOF[256];
             u32 dnb[3][64];      // FSE deltaNbBits
             int dfs[3][64];      // FSE deltaFindState
             u32 stage[64];       // codes of 64 staged sequences: ll | of << 8 | ml << 16
-            u32 sbits[3][64];    // per staged sequence and stream: state bits value | count << 16
+            u16 sbits[3][64];    // per staged sequence and stream: state bits value | count << 12
             u32 cbuf[192];       // bit assembly buffer of one 64-sequence chunk
         } seq;
     } u;
     short norm[3][64];
     u16 cumul[3][66];
-    u8 tsym[3][512];          // FSE spread scratch
-    u8 ncbuf[3][96];          // table descriptions of the three symbol types, before concatenation
-    u32 cnt[64];
+    u8 tsymLL[512];           // FSE spread scratch (LL / weights, ML, OF)
+    u8 tsymML[512];
+    u8 tsymOF[256];
+    u8 ncbuf[3][80];          // table descriptions of the three symbol types, before concatenation
+    u32 cnt[16];
     u8 weight[256];
 };
+
+KX_DEV u16* kxe_state(KEntropyLds& lds, int t) { return t == 0 ? lds.u.seq.stateLL : t == 1 ? lds.u.seq.stateOF : lds.u.seq.stateML; }
+KX_DEV u8* kxe_tsym(KEntropyLds& lds, int t) { return t == 0 ? lds.tsymLL : t == 1 ? lds.tsymOF : lds.tsymML; }
 
 // ======================= lane-0 serial helpers ==========================
 struct KBitW { u64 acc; u32 nb; u8* p; };
@@ -456,8 +463,8 @@ KX_DEV u32 khuf_compress_weights(u8* dst, KEntropyLds& lds, u32 wtSize)
     tableLog = kfse_optimal_tablelog(tableLog, wtSize, maxSymbolValue, 2);
     if (kfse_normalize(lds.norm[0], tableLog, lds.cnt, wtSize, maxSymbolValue, 0) == KXE_ERR) return KXE_ERR;
     { u32 const h = kfse_write_ncount(op, lds.norm[0], maxSymbolValue, tableLog); if (h == KXE_ERR) return KXE_ERR; op += h; }
-    KFseCT ct; ct.state = lds.u.seq.state[0]; ct.dnb = lds.u.seq.dnb[0]; ct.dfs = lds.u.seq.dfs[0];
-    kfse_build_ctable(ct, lds.norm[0], maxSymbolValue, tableLog, lds.cumul[0], lds.tsym[0]);
+    KFseCT ct; ct.state = lds.u.seq.stateLL; ct.dnb = lds.u.seq.dnb[0]; ct.dfs = lds.u.seq.dfs[0];
+    kfse_build_ctable(ct, lds.norm[0], maxSymbolValue, tableLog, lds.cumul[0], lds.tsymLL);
     {
         KBitW b; const u8* ip = weightTable + wtSize; u32 s1, s2;
         if (wtSize <= 2) return 0;
@@ -737,12 +744,12 @@ KX_DEV u32 kx_build_seq_table(KEntropyLds& lds, int t, u32* count, u32 nbSeq, u3
     bool const defaultAllowed = (t != 1) || (max <= 28);
     u32 const type = kx_select_encoding(mostFrequent, nbSeq, defaultNormLog, defaultAllowed);
     typeOut = type;
-    ct.state = lds.u.seq.state[t]; ct.dnb = lds.u.seq.dnb[t]; ct.dfs = lds.u.seq.dfs[t]; ct.tableLog = 0;
+    ct.state = kxe_state(lds, t); ct.dnb = lds.u.seq.dnb[t]; ct.dfs = lds.u.seq.dfs[t]; ct.tableLog = 0;
     if (type == KSET_RLE) { kfse_build_ctable_rle(ct, max); *op = (u8)firstCode; return 1; }
     if (type == KSET_BASIC) {
         const short* dn = (t == 0) ? LL_defaultNorm : (t == 1) ? OF_defaultNorm : ML_defaultNorm;
         for (u32 s = 0; s <= defaultMax; s++) norm[s] = dn[s];
-        kfse_build_ctable(ct, norm, defaultMax, defaultNormLog, lds.cumul[t], lds.tsym[t]);
+        kfse_build_ctable(ct, norm, defaultMax, defaultNormLog, lds.cumul[t], kxe_tsym(lds, t));
         return 0;
     }
     {
@@ -752,7 +759,7 @@ KX_DEV u32 kx_build_seq_table(KEntropyLds& lds, int t, u32* count, u32 nbSeq, u3
         if (kfse_normalize(norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048) == KXE_ERR) return KXE_ERR;
         u32 const NCountSize = kfse_write_ncount(op, norm, max, tableLog);
         if (NCountSize == KXE_ERR) return KXE_ERR;
-        kfse_build_ctable(ct, norm, max, tableLog, lds.cumul[t], lds.tsym[t]);
+        kfse_build_ctable(ct, norm, max, tableLog, lds.cumul[t], kxe_tsym(lds, t));
         return NCountSize;
     }
 }
@@ -787,7 +794,7 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
     }
     kx_sync();
     // the three tables, one lane each
-    KFseCT ct; ct.state = lds.u.seq.state[0]; ct.dnb = lds.u.seq.dnb[0]; ct.dfs = lds.u.seq.dfs[0]; ct.tableLog = 0;
+    KFseCT ct; ct.state = lds.u.seq.stateLL; ct.dnb = lds.u.seq.dnb[0]; ct.dfs = lds.u.seq.dfs[0]; ct.tableLog = 0;
     u32 mySz = 0, myType = 0;
     {
         KSeqCodes const cl = kx_seq_codes(seqs[nbSeq - 1], nbSeq - 1, longType, longPos);
@@ -839,14 +846,14 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
                 if (!started) { state = kfse_init_state(ct, code); lds.u.seq.sbits[lane][s] = 0; started = true; }
                 else {
                     u32 const nb = (state + ct.dnb[code]) >> 16;
-                    lds.u.seq.sbits[lane][s] = (state & ((1u << nb) - 1u)) | (nb << 16);
+                    lds.u.seq.sbits[lane][s] = (u16)((state & ((1u << nb) - 1u)) | (nb << 12));
                     state = ct.state[(state >> nb) + ct.dfs[code]];
                 }
             }
         }
         kx_sync();
         u32 const sLL = valid ? lds.u.seq.sbits[0][lane] : 0u, sOF = valid ? lds.u.seq.sbits[1][lane] : 0u, sML = valid ? lds.u.seq.sbits[2][lane] : 0u;
-        u32 const nLL = sLL >> 16, nOF = sOF >> 16, nML = sML >> 16;
+        u32 const nLL = sLL >> 12, nOF = sOF >> 12, nML = sML >> 12;
         u32 const llb = valid ? kx_ll_bits(c.ll) : 0u, mlb = valid ? kx_ml_bits(c.ml) : 0u, ofb = valid ? c.of : 0u;
         u32 const mybits = nLL + nOF + nML + llb + mlb + ofb;
         u32 v = mybits;                                           // inclusive prefix sum over lanes
@@ -856,7 +863,7 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
         u32 pos = (bitpos & 31u) + (v - mybits);
         if (valid) {
             // order inside a sequence: OF state, ML state, LL state, LL extra, ML extra, OF extra
-            u32 const a = (sOF & 0xFFFFu) | ((sML & 0xFFFFu) << nOF) | ((sLL & 0xFFFFu) << (nOF + nML));
+            u32 const a = (sOF & 0xFFFu) | ((sML & 0xFFFu) << nOF) | ((sLL & 0xFFFu) << (nOF + nML));
             kx_cbuf_put(cbuf, pos, a, nOF + nML + nLL); pos += nOF + nML + nLL;
             kx_cbuf_put(cbuf, pos, q.litLength, llb); pos += llb;
             kx_cbuf_put(cbuf, pos, q.mlBase, mlb); pos += mlb;
