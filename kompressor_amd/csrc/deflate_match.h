@@ -63,13 +63,14 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
         for (int i = tid; i < 32768; i += nthreads) head[i] = 0;
         kx_block_sync();
         u32 const nIns = n >= 3 ? n - 2 : 0;                // positions 0 .. n-3 enter the chains, in order
+        // every wave hashes its 64 positions of the NEXT block while the current block takes its turns on
+        // the LDS head table (global loads stay outside the serialised part)
+        u32 hN = 0x8000u + (u32)lane; bool validN = false;
+        { u32 const p0 = (u32)wv * 64u + (u32)lane; validN = p0 < nIns; if (validN) hN = kd_hash3(src[p0], src[p0 + 1], src[p0 + 2]); }
         for (u32 base = 0; base < nIns; base += (u32)nthreads) {
-            // every wave hashes its 64 positions up front (global loads outside the serialised part) ...
-            u32 const p = base + (u32)wv * 64u + (u32)lane; bool const valid = p < nIns;
-            u32 h = 0x8000u + (u32)lane;                     // distinct dummy for idle lanes
-            if (valid) h = kd_hash3(src[p], src[p + 1], src[p + 2]);
+            u32 const p = base + (u32)wv * 64u + (u32)lane; bool const valid = validN; u32 const h = hN;
+            { u32 const pn = p + (u32)nthreads; validN = pn < nIns; hN = 0x8000u + (u32)lane; if (validN) hN = kd_hash3(src[pn], src[pn + 1], src[pn + 2]); }
             u32 lk = 0;
-            // ... then the waves take turns on the LDS head table, in position order
             for (int w = 0; w < nw; w++) {
                 if (wv == w) {
                     u32 const old = valid ? head[h] : 0u;
@@ -78,17 +79,18 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
                     kx_lockstep();
                     u32 const chk = valid ? head[h] : p;
                     lk = old;
-                    if (kx_any(valid && chk != (p & 0xFFFFu))) {
-                        // two lanes of this wave share a bucket: nearest lower lane is the predecessor,
-                        // and the highest lane of each bucket must be the one left in the table
-                        bool found = false, hasHigher = false;
-                        for (int d = 1; d < 64; d++) {
-                            u32 const hl = kx_shfl(h, lane - d), hh = kx_shfl(h, lane + d);
-                            if (lane >= d && hl == h && !found) { lk = p - (u32)d; found = true; }
-                            if (lane + d < 64 && hh == h) hasHigher = true;
+                    // lanes of this wave that share a bucket: one bucket per round; inside a bucket the nearest
+                    // lower lane is the predecessor and the highest lane is the one left in the table
+                    for (u64 losers = kx_ballot(valid && chk != (p & 0xFFFFu)); losers; ) {
+                        int const L = (int)kx_ctz64(losers);
+                        u32 const hL = kx_shfl(h, L);
+                        u64 const grp = kx_ballot(valid && h == hL);
+                        if (valid && h == hL) {
+                            u64 const below = grp & ((1ull << lane) - 1ull);
+                            if (below) lk = p - (u32)(lane - (63 - (int)__builtin_clzll(below)));
+                            if ((grp >> lane) == 1ull) head[h] = (u16)p;          // highest lane of the bucket
                         }
-                        kx_lockstep();
-                        if (valid && !hasHigher) head[h] = (u16)p;
+                        losers &= ~grp;
                     }
                 }
                 kx_block_sync();
