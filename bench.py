@@ -243,7 +243,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("zstd_match_hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                # counters were collected for the default configuration only
+                if pj.get("slices") == n and args.team in (0, 4):
+                    traffic = pj.get("zstd_match_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         res = {
