@@ -67,11 +67,17 @@ def cpu_baseline(host, n_slices, frames_expected):
     per = (sample + cores - 1) // cores
     totals = [0] * cores
 
+    errors = [0] * cores
+
     def run(t):
         w = make_worker()
         s = 0
         for i in range(t * per, min(sample, (t + 1) * per)):
-            s += w(base + i * SLICE)
+            r = w(base + i * SLICE)
+            if r == 0 or r > (1 << 40):          # libzstd error codes are (size_t)-code
+                errors[t] += 1
+            else:
+                s += r
         totals[t] = s
 
     t0 = time.perf_counter()
@@ -79,6 +85,8 @@ def cpu_baseline(host, n_slices, frames_expected):
         list(ex.map(run, range(cores)))
     dt = time.perf_counter() - t0
     ok = (frames_expected is None) or (sum(totals) == frames_expected)
+    if sum(errors):
+        label += f" [{sum(errors)} of {sample} CPU calls returned an error]"
     return {"value": round(sample * SLICE / dt / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": kind,
             "sample": f"first {sample} slices of the same batch, {label}, {cores} threads, one context per thread, "
                       f"{dt:.2f} s wall; total frame bytes {'match' if ok else 'DIFFER from'} the GPU's"}

@@ -24,7 +24,9 @@ def find_libzstd_157():
     for pat in _CANDIDATES:
         for path in sorted(glob.glob(pat)):
             try:
-                lib = ctypes.CDLL(path)
+                # RTLD_DEEPBIND: the library must bind its internal calls to itself even when another libzstd
+                # (e.g. the system 1.4.8 pulled in by a profiler's preloaded tool) is already in the process
+                lib = ctypes.CDLL(path, mode=os.RTLD_LOCAL | getattr(os, "RTLD_DEEPBIND", 0))
                 lib.ZSTD_versionNumber.restype = ctypes.c_uint
                 if lib.ZSTD_versionNumber() == 10507:
                     lib._path = path
