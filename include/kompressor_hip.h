@@ -83,9 +83,9 @@ KMP_API size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* dctx,
  * createCompressor :10-26 (deflateInit2), freeCompressor :28-38 (deflateEnd), compressStream :40-82
  * (deflate, call at :73).  Same cursor semantics; the return value is zlib's: Z_OK 0, Z_STREAM_END 1,
  * Z_BUF_ERROR -5 are benign for the Kotlin side (ZlibCompressor.jvm.kt:49-56).  The GPU path implements
- * level 6 (or -1), windowBits -15
- * (ZlibFormat.Raw) or 15 (ZlibFormat.Zlib: 78 9C header + Adler-32), memLevel 8, strategy 0 and slices
- * <= 64 KiB; other settings (gzip, other levels) make create return NULL. */
+ * level 6 (or -1), windowBits -15 (ZlibFormat.Raw), 15 (ZlibFormat.Zlib: 78 9C header + Adler-32) or
+ * 31 (ZlibFormat.Gzip: 10-byte header, CRC-32 + ISIZE), memLevel 8, strategy 0 and slices <= 64 KiB;
+ * other settings (other levels, smaller windows) make create return NULL. */
 typedef struct kmp_zlib_cstream kmp_zlib_cstream;
 typedef struct kmp_zlib_dstream kmp_zlib_dstream;
 KMP_API kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bits, int mem_level, int strategy);
@@ -95,8 +95,8 @@ KMP_API int kmp_zlib_compress_stream(kmp_zlib_cstream* stream,
                                      const void* src, size_t src_size, size_t* src_pos,
                                      int finish);
 /* createDecompressor :84-98 (inflateInit2), freeDecompressor :100-110 (inflateEnd), decompressStream :112-153
- * (inflate, call at :144).  windowBits -15..-8 = raw, 8..15 = zlib wrapper (Adler-32 verified); gzip and
- * auto-detection (ZlibFormat.Gzip / Auto) make create return NULL for now.  The stream is decoded when the
+ * (inflate, call at :144).  windowBits -15..-8 = raw, 8..15 = zlib wrapper (Adler-32 verified), 24..31 = gzip
+ * (CRC-32 and length verified), 40..47 = zlib or gzip by the header (ZlibFormat.AutoDetectZlibGzip).  The stream is decoded when the
  * caller passes finish (the one-shot driver always does); any block types, any compression level. */
 KMP_API kmp_zlib_dstream* kmp_zlib_create_decompressor(int window_bits);
 KMP_API int kmp_zlib_free_decompressor(kmp_zlib_dstream* stream);
@@ -170,12 +170,21 @@ KMP_API int kmp_zlib_compress_batch(kmp_batch_ctx* ctx,
                                     uint32_t n,
                                     void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                     void* hip_stream);
-/* inflate: n raw-deflate (zlib_wrapper = 0) or zlib (1) streams -> d_dst + d_out_off[i] (capacity d_out_cap[i]);
+/* same, with the RFC 1952 gzip wrapper (ZlibFormat.Gzip -> windowBits + 16, ZlibFormat.kt:41-44): the 10-byte header
+ * zlib writes on Linux (no name, MTIME 0, XFL 0, OS 3), CRC-32 and ISIZE trailer */
+KMP_API int kmp_gzip_compress_batch(kmp_batch_ctx* ctx,
+                                    const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                    uint32_t n,
+                                    void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
+                                    void* hip_stream);
+/* inflate: n streams -> d_dst + d_out_off[i] (capacity d_out_cap[i]); format 0 = raw deflate, 1 = zlib,
+ * 2 = gzip, 3 = zlib or gzip decided per stream by its first bytes (ZlibFormat.AutoDetectZlibGzip,
+ * ZlibFormat.kt:52-55); checksums are verified;
  * d_status[i] = 0, -3 (Z_DATA_ERROR) or -5 (Z_BUF_ERROR: capacity too small or input truncated) */
 KMP_API int kmp_inflate_batch(kmp_batch_ctx* ctx,
                               const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
                               void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
-                              uint32_t* d_out_len, int32_t* d_status, int zlib_wrapper, void* hip_stream);
+                              uint32_t* d_out_len, int32_t* d_status, int format, void* hip_stream);
 /* ms4[0..3] = k_deflate_chains, k_deflate_best, k_deflate_parse, k_deflate_encode of the last batch */
 KMP_API int kmp_deflate_last_kernel_ms(kmp_batch_ctx* ctx, float* ms4);
 

@@ -91,8 +91,12 @@ class ZstdBatch:
             raise RuntimeError(f"kmp_zstd_decompress_batch failed ({rc}): {_lib.last_error()}")
         return dst, out_off, out_len, status
 
-    def inflate(self, src, in_off, in_len, out_cap, zlib_wrapper=False, dst=None, out_off=None):
-        """n raw-deflate (or zlib-wrapped) streams -> slices. Returns (dst, out_off, out_len, status)."""
+    _FORMATS = {"raw": 0, "zlib": 1, "gzip": 2, "auto": 3}
+
+    def inflate(self, src, in_off, in_len, out_cap, zlib_wrapper=False, dst=None, out_off=None, format=None):   # noqa: A002
+        """n DEFLATE streams -> slices; format "raw" / "zlib" / "gzip" / "auto" (zlib or gzip per stream).
+        Returns (dst, out_off, out_len, status)."""
+        fmt = self._FORMATS[format] if format is not None else (1 if zlib_wrapper else 0)
         n = in_len.numel()
         if out_off is None:
             out_off = torch.cumsum(out_cap.to(torch.int64), 0) - out_cap.to(torch.int64)
@@ -101,13 +105,16 @@ class ZstdBatch:
         out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
         status = torch.zeros(n, dtype=torch.int32, device=self.device)
         rc = self.lib.kmp_inflate_batch(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n, _ptr(dst), _ptr(out_off), _ptr(out_cap),
-                                        _ptr(out_len), _ptr(status), 1 if zlib_wrapper else 0, self._stream())
+                                        _ptr(out_len), _ptr(status), fmt, self._stream())
         if rc != 0:
             raise RuntimeError(f"kmp_inflate_batch failed ({rc}): {_lib.last_error()}")
         return dst, out_off, out_len, status
 
-    def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, zlib_wrapper=False):
-        """DEFLATE streams (zlib level 6, windowBits 15, memLevel 8), raw or zlib-wrapped, for slices of at most 64 KiB."""
+    def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, zlib_wrapper=False, format=None):   # noqa: A002
+        """DEFLATE streams (zlib level 6, windowBits 15, memLevel 8), format "raw" / "zlib" / "gzip", for slices of at most 64 KiB."""
+        fmt = self._FORMATS[format] if format is not None else (1 if zlib_wrapper else 0)
+        if fmt == 3:
+            raise ValueError("Compression can't be used with auto-detection")       # ZlibFormat.kt:28
         n = in_len.numel()
         stride = (self.lib.kmp_deflate_bound(min(self.max_slice_bytes, 65536)) + 63) & ~63
         if dst is None:
@@ -116,7 +123,7 @@ class ZstdBatch:
             out_off = torch.arange(n, dtype=torch.int64, device=self.device) * stride
         if out_len is None:
             out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
-        fn = self.lib.kmp_zlib_compress_batch if zlib_wrapper else self.lib.kmp_deflate_compress_batch
+        fn = (self.lib.kmp_deflate_compress_batch, self.lib.kmp_zlib_compress_batch, self.lib.kmp_gzip_compress_batch)[fmt]
         rc = fn(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n, _ptr(dst), _ptr(out_off), _ptr(out_len), self._stream())
         if rc != 0:
             raise RuntimeError(f"kmp_deflate_compress_batch failed ({rc}): {_lib.last_error()}")

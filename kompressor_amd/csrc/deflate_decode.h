@@ -13,7 +13,8 @@
 struct KiArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
     u8* dst; const u64* out_off; const u32* out_cap; u32* out_len; int* status;
-    u32 format;                 // 0 = raw deflate, 1 = zlib wrapper (2-byte header, Adler-32 trailer)
+    u32 format;                 // 0 = raw deflate, 1 = zlib wrapper (2-byte header, Adler-32 trailer),
+                                // 2 = gzip (RFC 1952 header, CRC-32 + ISIZE trailer), 3 = zlib or gzip by the first bytes
 };
 
 enum { KI_OK = 0, KI_DATA_ERROR = -3, KI_BUF_ERROR = -5 };
@@ -64,7 +65,22 @@ KX_DEV void inflate_stream(const KiArgs& a, KiLds& lds, u32 f, int lane)
     u8* const dst = a.dst + a.out_off[f]; u32 const cap = a.out_cap[f];
     int err = 0; u32 op = 0;
     u32 spos = 0, send = srcSize;                 // deflate data = src[spos, send)
-    if (a.format == 1) {
+    u32 fmt = a.format;
+    if (fmt == 3) fmt = (srcSize >= 2 && src[0] == 0x1F && src[1] == 0x8B) ? 2u : 1u;     // inflateInit2(windowBits + 32)
+    if (fmt == 2) {
+        // gzip member header: ID1 ID2 CM FLG MTIME(4) XFL OS [FEXTRA] [FNAME] [FCOMMENT] [FHCRC]
+        if (srcSize < 18 || src[0] != 0x1F || src[1] != 0x8B || src[2] != 8 || (src[3] & 0xE0)) err = KI_DATA_ERROR;
+        else {
+            u32 const flg = src[3]; u32 p = 10; u32 const lim = srcSize - 8;
+            if (flg & 4u) { if (p + 2 > lim) err = KI_DATA_ERROR; else p += 2u + ((u32)src[p] | ((u32)src[p + 1] << 8)); }
+            if (!err && (flg & 8u)) { while (p < lim && src[p]) p++; p++; }
+            if (!err && (flg & 16u)) { while (p < lim && src[p]) p++; p++; }
+            if (!err && (flg & 2u)) p += 2;
+            if (err || p > lim) err = KI_DATA_ERROR;
+            spos = p; send = lim;
+        }
+    }
+    if (fmt == 1) {
         if (srcSize < 6) err = KI_DATA_ERROR;
         else {
             u32 const cmf = src[0], flg = src[1];
@@ -263,7 +279,12 @@ KX_DEV void inflate_stream(const KiArgs& a, KiLds& lds, u32 f, int lane)
     }
 #undef KI_TAKE
 #undef KI_NEED
-    if (!err && a.format == 1) {
+    if (!err && fmt == 2) {
+        // CRC-32 and length (mod 2^32) of the output against the little-endian trailer
+        u32 const got = kx_wave_crc32(dst, op, lds.inw, lane);
+        if (got != kx_ld32(src + srcSize - 8) || op != kx_ld32(src + srcSize - 4)) err = KI_DATA_ERROR;
+    }
+    if (!err && fmt == 1) {
         // Adler-32 of the output against the big-endian trailer
         u32 const got = kx_wave_adler32(dst, op, lane);
         u32 const want = ((u32)src[srcSize - 4] << 24) | ((u32)src[srcSize - 3] << 16) | ((u32)src[srcSize - 2] << 8) | src[srcSize - 1];

@@ -217,6 +217,40 @@ KX_DEV u32 kx_wave_adler32(const u8* p, u32 n, int lane)
     return (B << 16) | A;
 }
 
+// CRC-32 (gzip trailer, polynomial 0xEDB88320 reflected) of p[0..n), all lanes get the value.
+// Every lane runs the byte-table recurrence over its own chunk (lane 0 takes the ragged first one),
+// then the 64 chunk CRCs are folded pairwise: crc(A||B) = crc(A) * x^(8|B|) mod P  xor  crc(B),
+// products of polynomials by shift-and-add (zlib's crc32_combine identity).  tab = 256 LDS words.
+KX_DEV u32 kx_crc_mul(u32 a, u32 b)
+{
+    u32 p = 0;
+    for (int i = 0; i < 32; i++) { if (a & 0x80000000u) p ^= b; a <<= 1; b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u); }
+    return p;
+}
+KX_DEV u32 kx_wave_crc32(const u8* p, u32 n, u32* tab, int lane)
+{
+    kx_sync();
+    for (int i = lane; i < 256; i += 64) { u32 c = (u32)i; for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u); tab[i] = c; }
+    kx_sync();
+    u32 const L = n / 64u, r = n - 63u * L;
+    u32 const b0 = lane == 0 ? 0u : r + (u32)(lane - 1) * L, b1 = lane == 0 ? r : b0 + L;
+    u32 c = 0xFFFFFFFFu; u32 i = b0;
+    for (; i + 8 <= b1; i += 8) {
+        u64 w = kx_ld64(p + i);
+        for (int k = 0; k < 8; k++) { c = tab[(c ^ (u32)w) & 0xFFu] ^ (c >> 8); w >>= 8; }
+    }
+    for (; i < b1; i++) c = tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    c ^= 0xFFFFFFFFu;
+    u32 X = 0x80000000u, base = 0x00800000u;            // x^0, x^8
+    for (u32 e = L; e; e >>= 1) { if (e & 1u) X = kx_crc_mul(base, X); base = kx_crc_mul(base, base); }
+    for (int o = 1; o < 64; o <<= 1) {
+        u32 const right = kx_shfl(c, lane + o);
+        if ((lane & (2 * o - 1)) == 0) c = kx_crc_mul(X, c) ^ right;
+        X = kx_crc_mul(X, X);
+    }
+    return kx_shfl(c, 0);
+}
+
 KX_DEV void deflate_encode_slice(const KdArgs& a, KdEncLds& lds, u32 slice, int lane)
 {
     const u8* const src = a.src + a.in_off[slice];
@@ -225,8 +259,10 @@ KX_DEV void deflate_encode_slice(const KdArgs& a, KdEncLds& lds, u32 slice, int 
     KdSliceMeta const mm = a.meta[slice];
     // bits written so far; lds.cbuf[0] holds the pending partial word. The zlib wrapper's header for
     // level 6 / 32 KiB window is 78 9C (CMF 0x78, FLG: level flags 2, check bits so that CMF*256+FLG % 31 == 0)
-    u32 bitpos = a.format == 1 ? 16u : 0u;
-    for (int i = lane; i < 128; i += 64) lds.cbuf[i] = (i == 0 && a.format == 1) ? 0x9C78u : 0u;
+    // gzip (format 2): 1F 8B, CM 8, no flags, MTIME 0, XFL 0 (level 6), OS 3 (what zlib writes on Linux)
+    u32 bitpos = a.format == 1 ? 16u : (a.format == 2 ? 80u : 0u);
+    for (int i = lane; i < 128; i += 64) lds.cbuf[i] = (i != 0) ? 0u : (a.format == 1 ? 0x9C78u : (a.format == 2 ? 0x0300u : 0u));
+    if (a.format == 2 && lane == 0) { kx_st32(dst, 0x00088B1Fu); kx_st32(dst + 4, 0u); }
     kx_sync();
     u32 s0 = 0;
     for (u32 b = 0; b < mm.nblocks; b++) {
@@ -342,10 +378,12 @@ KX_DEV void deflate_encode_slice(const KdArgs& a, KdEncLds& lds, u32 slice, int 
     // bi_windup of the last block: flush the pending partial word
     u32 total_bytes = (bitpos + 7) >> 3;
     u32 const adler = (a.format == 1) ? kx_wave_adler32(src, a.in_len[slice], lane) : 0u;
+    u32 const crc = (a.format == 2) ? kx_wave_crc32(src, a.in_len[slice], lds.lfreq, lane) : 0u;
     if (lane == 0) {
         u32 const wb = 4u * (bitpos >> 5); u32 const v = lds.cbuf[0];
         for (u32 k = wb; k < total_bytes; k++) dst[k] = (u8)(v >> (8 * (k - wb)));
         if (a.format == 1) { dst[total_bytes] = (u8)(adler >> 24); dst[total_bytes + 1] = (u8)(adler >> 16); dst[total_bytes + 2] = (u8)(adler >> 8); dst[total_bytes + 3] = (u8)adler; total_bytes += 4; }
+        if (a.format == 2) { kx_st32(dst + total_bytes, crc); kx_st32(dst + total_bytes + 4, a.in_len[slice]); total_bytes += 8; }
         a.out_len[slice] = total_bytes;
     }
 }

@@ -86,7 +86,7 @@ extern "C" const char* kmp_version(void) { return "kompressor_hip 0.1 (gfx950; z
 struct kmp_batch_ctx {
     int device; u32 max_slices, max_slice_bytes; int G; u32 match_blocks, nteams;
     u32 seq_cap, lit_cap, scratch_words;
-    KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* team_epoch; u32* counter;
+    KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* shadow; u32* team_epoch; u32* counter;
     int profiling; hipEvent_t ev[14]; int ev_valid[7];
     // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
     u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta;
@@ -116,7 +116,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     u32 const need = (max_slices + teams_per_wave - 1) / teams_per_wave;
     if (blocks > need) blocks = need;
     c->match_blocks = blocks; c->nteams = blocks * teams_per_wave;
-    c->seq_cap = c->max_slice_bytes / 4 + 8; c->lit_cap = c->max_slice_bytes + 64; c->scratch_words = c->max_slice_bytes / 4 + 64;
+    c->seq_cap = (c->max_slice_bytes / 4 + 8 + 15) & ~15u; c->lit_cap = c->max_slice_bytes + 64; c->scratch_words = c->max_slice_bytes / 4 + 64;
     size_t const ns = max_slices;
     HIP_TRY(hipMalloc((void**)&c->seqs, ns * c->seq_cap * sizeof(KSeq)));
     HIP_TRY(hipMalloc((void**)&c->lits, ns * c->lit_cap));
@@ -124,6 +124,11 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     HIP_TRY(hipMalloc((void**)&c->scratch, ns * c->scratch_words * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->tables, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->team_epoch, (size_t)c->nteams * sizeof(u32)));
+    c->shadow = nullptr;
+    if (env_u32("KMP_MATCH_FLAGS", 2) & 12u) {     // cost-probe experiment only
+        HIP_TRY(hipMalloc((void**)&c->shadow, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
+        HIP_TRY(hipMemset(c->shadow, 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
+    }
     HIP_TRY(hipMalloc((void**)&c->counter, 64));
     HIP_TRY(hipMemset(c->tables, 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
     HIP_TRY(hipMemset(c->team_epoch, 0, (size_t)c->nteams * sizeof(u32)));
@@ -139,7 +144,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch);
-    (void)hipFree(c->tables); (void)hipFree(c->team_epoch); (void)hipFree(c->counter);
+    (void)hipFree(c->tables); (void)hipFree(c->shadow); (void)hipFree(c->team_epoch); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta);
     delete c;
@@ -170,8 +175,8 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     HIP_TRY(hipMemsetAsync(c->counter, 0, 4, st));
     KMatchArgs m;
     m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
-    m.seqs = c->seqs; m.seq_cap = c->seq_cap; m.lits = c->lits; m.lit_cap = c->lit_cap; m.meta = c->meta;
-    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter; m.flags = env_u32("KMP_MATCH_FLAGS", 2);
+    m.seqs = c->seqs; m.seq_cap = c->seq_cap; m.meta = c->meta;
+    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter; m.flags = env_u32("KMP_MATCH_FLAGS", 2); m.shadow = c->shadow;
     u32 const tpw = 64 / (u32)c->G;
     u32 blocks = (n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], st));
@@ -226,18 +231,22 @@ extern "C" int kmp_deflate_compress_batch(kmp_batch_ctx* c, const void* d_src, c
 extern "C" int kmp_zlib_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                        uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
 { return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, 1, hip_stream); }
+extern "C" int kmp_gzip_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
+{ return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, 2, hip_stream); }
 
 extern "C" int kmp_inflate_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
                                  void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap, uint32_t* d_out_len, int32_t* d_status,
-                                 int zlib_wrapper, void* hip_stream)
+                                 int format, void* hip_stream)
 {
+    if (format < 0 || format > 3) { g_last_error = "kmp_inflate_batch: format must be 0 (raw), 1 (zlib), 2 (gzip) or 3 (zlib or gzip)"; return KMP_ERR_ARG; }
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_cap || !d_out_len || !d_status))) { g_last_error = "kmp_inflate_batch: null argument"; return KMP_ERR_ARG; }
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
     KiArgs a;
     a.src = (const u8*)d_src; a.in_off = d_in_off; a.in_len = d_in_len; a.n_slices = n;
-    a.dst = (u8*)d_dst; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_len = d_out_len; a.status = d_status; a.format = zlib_wrapper ? 1u : 0u;
+    a.dst = (u8*)d_dst; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_len = d_out_len; a.status = d_status; a.format = (u32)format;
     hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return KMP_OK;
@@ -462,7 +471,8 @@ extern "C" kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bi
 {
     // what deflateInit2 would accept; the GPU path implements raw deflate (-15), level 6 (-1 = default = 6), memLevel 8, strategy 0
     if (level == -1) level = 6;
-    if (level != 6 || (window_bits != -15 && window_bits != 15) || mem_level != 8 || strategy != 0) return nullptr;
+    // windowBits: -15 raw, 15 zlib wrapper, 31 (15 + 16) gzip wrapper
+    if (level != 6 || (window_bits != -15 && window_bits != 15 && window_bits != 31) || mem_level != 8 || strategy != 0) return nullptr;
     kmp_zlib_cstream* z = new (std::nothrow) kmp_zlib_cstream();
     if (!z) return nullptr;
     z->level = level; z->window_bits = window_bits; z->mem_level = mem_level; z->strategy = strategy; z->out_pos = 0; z->stage = 0;
@@ -487,7 +497,7 @@ extern "C" int kmp_zlib_compress_stream(kmp_zlib_cstream* z, void* dst, size_t d
         if (len && hipMemcpy(s.d_in, z->in.data(), len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
         if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
         if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
-        if (deflate_batch_impl(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, z->window_bits > 0 ? 1u : 0u, nullptr) != KMP_OK) return Z_MEM_ERROR_;
+        if (deflate_batch_impl(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, z->window_bits == 31 ? 2u : (z->window_bits > 0 ? 1u : 0u), nullptr) != KMP_OK) return Z_MEM_ERROR_;
         if (hipMemcpy(&olen, s.d_len + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR_;
         if (olen == 0 || olen > s.out_cap) return Z_DATA_ERROR_;
         z->out.resize(olen);
@@ -505,9 +515,10 @@ struct kmp_zlib_dstream { int window_bits; std::vector<u8> in; std::vector<u8> o
 
 extern "C" kmp_zlib_dstream* kmp_zlib_create_decompressor(int window_bits)
 {
-    // inflateInit2 semantics served here: -15..-8 raw, 8..15 zlib wrapper (gzip / auto-detect: not yet)
+    // inflateInit2 semantics: -15..-8 raw, 8..15 zlib wrapper, 24..31 gzip, 40..47 zlib or gzip by the header
     bool const raw = window_bits <= -8 && window_bits >= -15, zl = window_bits >= 8 && window_bits <= 15;
-    if (!raw && !zl) return nullptr;
+    bool const gz = window_bits >= 24 && window_bits <= 31, any = window_bits >= 40 && window_bits <= 47;
+    if (!raw && !zl && !gz && !any) return nullptr;
     kmp_zlib_dstream* z = new (std::nothrow) kmp_zlib_dstream();
     if (!z) return nullptr;
     z->window_bits = window_bits; z->out_pos = 0; z->stage = 0; z->batch = nullptr;
@@ -537,7 +548,7 @@ extern "C" int kmp_zlib_decompress_stream(kmp_zlib_dstream* z, void* dst, size_t
                     hipMemcpy(d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess ||
                     hipMemcpy(d_len, lens, sizeof(lens), hipMemcpyHostToDevice) != hipSuccess) break;
                 if (kmp_inflate_batch(z->batch, d_in, d_off, d_len, 1, d_out, d_off + 1, d_len + 1, d_len + 2, (int32_t*)(d_len + 3),
-                                      z->window_bits > 0, nullptr) != KMP_OK) break;
+                                      z->window_bits < 0 ? 0 : (z->window_bits <= 15 ? 1 : (z->window_bits <= 31 ? 2 : 3)), nullptr) != KMP_OK) break;
                 if (hipMemcpy(lens, d_len, sizeof(lens), hipMemcpyDeviceToHost) != hipSuccess) break;
                 int const st = (int)lens[3];
                 if (st == Z_BUF_ERROR_) continue;                    // output did not fit: next capacity

@@ -49,6 +49,9 @@ KX_DEV u32 kx_ld16(const u8* p) { u16 v; __builtin_memcpy(&v, p, 2); return v; }
 KX_DEV void kx_st64(u8* p, u64 v) { __builtin_memcpy(p, &v, 8); }
 KX_DEV void kx_st32(u8* p, u32 v) { __builtin_memcpy(p, &v, 4); }
 KX_DEV void kx_st16(u8* p, u32 v) { u16 x = (u16)v; __builtin_memcpy(p, &x, 2); }
+// 16-byte aligned store (one global_store_dwordx4): four neighbouring lanes fill a whole 64-byte line
+struct alignas(16) KxU128 { u64 a, b; };
+KX_DEV void kx_st128(void* p, u64 a, u64 b) { KxU128 v; v.a = a; v.b = b; *(KxU128*)p = v; }
 
 KX_DEV u32 kx_ld_nt(const u32* p) { return __builtin_nontemporal_load(p); }
 KX_DEV void kx_st_nt(u32* p, u32 v) { __builtin_nontemporal_store(v, p); }

@@ -898,6 +898,51 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
     }
 }
 
+// ---- literals: gathered from the source ------------------------------------
+// The match kernel stores no literals.  Sequence i's literals are
+// src[P_i, P_i + ll_i) with P_i = sum over j < i of (ll_j + ml_j); 64 sequences
+// per round, two shuffle scans give every lane its source and literal offsets.
+KX_DEV void kx_gather_literals(u8* lits, const u8* src, u32 n, const KSeq* seqs, u32 nbSeq, u32 longType, u32 longPos, int lane)
+{
+    u32 sp = 0, lp = 0;
+    for (u32 base = 0; base < nbSeq; base += 64u) {
+        u32 const i = base + (u32)lane;
+        u32 ll = 0, adv = 0;
+        if (i < nbSeq) {
+            KSeq const q = seqs[i];
+            ll = q.litLength; adv = (u32)q.mlBase + 3u;
+            if (i == longPos) { if (longType == 1) ll += 0x10000u; if (longType == 2) adv += 0x10000u; }
+            adv += ll;
+        }
+        u32 sl = ll, sa = adv;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            u32 const tl = kx_shfl(sl, lane - o), ta = kx_shfl(sa, lane - o);
+            if (lane >= o) { sl += tl; sa += ta; }
+        }
+        u32 const myL = lp + sl - ll, myS = sp + sa - adv;
+        // long runs: the whole wave copies
+        u64 big = kx_ballot(ll > 32u);
+        while (big) {
+            int const j = (int)kx_ctz64(big); big &= big - 1ull;
+            kx_wave_copy(lits + kx_shfl(myL, j), src + kx_shfl(myS, j), kx_shfl(ll, j), lane);
+        }
+        if (ll > 0 && ll <= 32u) {
+            u8* const d = lits + myL;
+            u32 c = 0;
+            for (; c + 8u <= ll; c += 8u) kx_st64(d + c, kx_ld64(src + myS + c));
+            if (c < ll) {
+                u64 w = kx_ld64_clamped(src, (int)(myS + c), (int)n);
+                u32 const rem = ll - c;
+                if (rem & 4u) { kx_st32(d + c, (u32)w); w >>= 32; c += 4u; }
+                if (rem & 2u) { kx_st16(d + c, (u32)w); w >>= 16; c += 2u; }
+                if (rem & 1u) d[c] = (u8)w;
+            }
+        }
+        lp += kx_shfl(sl, 63); sp += kx_shfl(sa, 63);
+    }
+}
+
 // ---- one slice -> one frame ---------------------------------------------
 KX_DEV void zstd_entropy_slice(const KEntropyArgs& a, KEntropyLds& lds, u32 slice, int lane)
 {
@@ -924,6 +969,7 @@ KX_DEV void zstd_entropy_slice(const KEntropyArgs& a, KEntropyLds& lds, u32 slic
         const KSeq* const seqs = a.seqs + (size_t)slice * a.seq_cap;
         u8* const lits = a.lits + (size_t)slice * a.lit_cap;
         u32 const litSize = mm.litSize + mm.lastLL;
+        kx_gather_literals(lits, src, n, seqs, mm.nbSeq, mm.longType, mm.longPos, lane);
         // complete the literal buffer with the trailing literals
         kx_wave_copy(lits + mm.litSize, src + (n - mm.lastLL), mm.lastLL, lane);
         kx_sync();

@@ -13,7 +13,9 @@
 //  * one search step examines up to G-1 consecutive search positions at once
 //    (lane k speculates that lanes < k found nothing); the first lane with a
 //    hit wins, lanes before it commit their table inserts, the rest discard;
-//  * match extension, backward catch-up and literal copy are team-cooperative;
+//  * match extension and backward catch-up are team-cooperative; literals are not
+//    copied (the entropy kernel gathers them from the source), sequences leave in
+//    whole 16-byte pieces;
 //  * hash tables live in global memory (one pair per team, tagged with an
 //    epoch so they are never cleared between slices).
 //
@@ -24,12 +26,13 @@
 struct KMatchArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
     KSeq* seqs; u32 seq_cap;         // per slice
-    u8* lits; u32 lit_cap;           // per slice
     KSliceMeta* meta;                // per slice
     u32* tables;                     // per team: KX_TBL_ENTRIES
     u32* team_epoch;                 // per team
     u32* counter;                    // work queue head (zeroed by the host)
-    u32 flags;                       // experiment switches: 1 = non-temporal table loads, 2 = non-temporal table stores
+    u32 flags;                       // experiment switches: 1 = non-temporal table loads, 2 = non-temporal table stores,
+                                     // 4 / 8 = also store / load a shadow table (cost probes; needs `shadow`)
+    u32* shadow;                     // per team: KX_TBL_ENTRIES, or null
 };
 
 enum { KST_IDLE = 0, KST_SEARCH = 1, KST_REPCHECK = 2, KST_MATCH = 3, KST_CLEANUP = 4, KST_DONE = 5 };
@@ -122,10 +125,13 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
     const u8* src = a.src; int n = 0; int ilimit = 0; u32 slice = 0;
     int ip = 0, anchor = 0; u32 off1 = 0, off2 = 0; int step = 1; int nextStep = 0;
     u32 nseq = 0, nlit = 0; u32 tag = 0; u32 hbL = 16, hbS = 15, mls = 5;
-    u32 longType = 0, longPos = 0; u32 guard = 0; u32 status = 0;
-    KSeq* seqs = a.seqs; u8* lits = a.lits;
+    u32 longType = 0, longPos = 0; u32 guard = 0; u32 status = 0; u32 shacc = 0;
+    u32* const SH = a.shadow ? a.shadow + (size_t)team * KX_TBL_ENTRIES : L;
+    KSeq* seqs = a.seqs;
     // pending match
     int m_type = 0, m_pos = 0, m_start = 0, m_mpos = 0; u32 m_len0 = 0, m_off = 0, m_idxl1 = 0; u64 m_w1 = 0;
+    // sequences wait in registers (two per lane) until the team can store whole 16-byte pieces of a line
+    u64 sq0 = 0, sq1 = 0;
 
     for (;;) {
         // ================= fetch the next slice =======================
@@ -147,7 +153,6 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     src = a.src + a.in_off[s];
                     n = (int)a.in_len[s];
                     seqs = a.seqs + (size_t)s * a.seq_cap;
-                    lits = a.lits + (size_t)s * a.lit_cap;
                     KParams const P = kx_params_l3((u32)n);
                     hbL = P.hashLog; hbS = P.chainLog; mls = P.minMatch;
                     nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = 0;
@@ -200,6 +205,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 // the lane after the last candidate only provides the long-table lookup of "ip1"
                 if (a.flags & 1u) { el = kx_ld_nt(&L[hl]); if (cand) es = kx_ld_nt(&S[hs]); }
                 else { el = L[hl]; if (cand) es = S[hs]; }
+                if (a.flags & 8u) { shacc |= kx_ld_nt(&SH[hl]); if (cand) shacc |= kx_ld_nt(&SH[KX_TBL_LONG + hs]); }
             }
             u32 idxl = ((el & ~KX_IDX_MASK) == tag) ? (el & KX_IDX_MASK) : 0u;
             u32 idxs = ((es & ~KX_IDX_MASK) == tag) ? (es & KX_IDX_MASK) : 0u;
@@ -250,6 +256,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 u32 const v = tag | (u32)(pos + 2);
                 if (a.flags & 2u) { if (!supL) kx_st_nt(&L[hl], v); if (!supS) kx_st_nt(&S[hs], v); }
                 else { if (!supL) L[hl] = v; if (!supS) S[hs] = v; }
+                if (a.flags & 4u) { kx_st_nt(&SH[hl], 0u); kx_st_nt(&SH[KX_TBL_LONG + hs], 0u); }
             }
 
             // winner data, broadcast inside the team
@@ -306,10 +313,12 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 if (bw) { m_start -= (int)back; m_mpos -= (int)back; lenA += back; off2 = off1; off1 = m_off; offBase = m_off + 3; }
                 else if (m_type == KMT_REP0) { u32 const t = off2; off2 = off1; off1 = t; }
                 int const ll = m_start - anchor;
-                for (int c = 8 * k; c < ll; c += 8 * G) kx_st64(lits + nlit + c, kx_ld64_clamped(src, anchor + c, n));
-                if (k == 0) {
-                    KSeq q; q.offBase = offBase; q.litLength = (u16)ll; q.mlBase = (u16)(lenA - 3);
-                    seqs[nseq] = q;
+                // literals are not copied here: k_zstd_entropy gathers them from the source with the sequence list
+                {
+                    u64 const q = (u64)offBase | ((u64)(u16)ll << 32) | ((u64)(u16)(lenA - 3) << 48);   // KSeq
+                    u32 const slot = nseq & (2u * G - 1u);
+                    if ((u32)k == (slot >> 1)) { if (slot & 1u) sq1 = q; else sq0 = q; }
+                    if (slot == 2u * G - 1u) kx_st128(seqs + (nseq - slot) + 2u * (u32)k, sq0, sq1);
                 }
                 if (ll > 0xFFFF) { longType = 1; longPos = nseq; }
                 if (lenA - 3 > 0xFFFF) { longType = 2; longPos = nseq; }
@@ -334,10 +343,16 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
         // ================= finish the slice ===========================
         if (kx_any(state == KST_CLEANUP)) {
             if (state == KST_CLEANUP) {
+                {
+                    u32 const cnt = nseq & (2u * G - 1u);       // sequences still in registers
+                    u64* const sp = (u64*)(seqs + (nseq - cnt));
+                    if (2u * (u32)k < cnt) sp[2 * k] = sq0;
+                    if (2u * (u32)k + 1u < cnt) sp[2 * k + 1] = sq1;
+                }
                 if (k == 0) {
                     KSliceMeta mm;
                     mm.nbSeq = nseq; mm.litSize = nlit; mm.lastLL = (u32)(n - anchor);
-                    mm.longType = longType; mm.longPos = longPos; mm.status = status; mm.pad[0] = 0; mm.pad[1] = 0;
+                    mm.longType = longType; mm.longPos = longPos; mm.status = status | (shacc == 0xFFFFFFFFu ? 4u : 0u); mm.pad[0] = 0; mm.pad[1] = 0;
                     a.meta[slice] = mm;
                 }
                 state = KST_IDLE;

@@ -4,8 +4,8 @@
   ZlibFormat          .../commonMain/.../ZlibFormat.kt:32-57 (Raw negates windowBits)
   ZlibWrapper externs .../zlib/ZlibWrapper.kt:24-54 (-> jni/Wrapper.cpp)
 
-The GPU path covers ZlibFormat.Raw and ZlibFormat.Zlib at level 6 (BASELINE configs[4] and the
-reference's deflate KAT) and inflate for both; gzip / auto-detect are next."""
+The GPU path covers ZlibFormat.Raw, Zlib and Gzip at level 6 (BASELINE configs[4] and the reference's
+deflate KAT) and inflate for all of them plus AutoDetectZlibGzip."""
 import ctypes
 import weakref
 
@@ -18,14 +18,33 @@ _RESULT_NAMES = {0: "Z_OK", 1: "Z_STREAM_END", 2: "Z_NEED_DICT", -1: "Z_ERRNO", 
 
 
 class ZlibFormat:
-    Zlib, Gzip, Raw = "zlib", "gzip", "raw"
+    """ZlibFormat.kt:7-57: how windowBits selects the wrapper."""
+    Zlib, Gzip, Raw, AutoDetectZlibGzip, UnmodifiedWindowBits = "zlib", "gzip", "raw", "auto", "unmodified"
 
     @staticmethod
     def adjust_window_bits_for_compression(fmt, window_bits):
-        if fmt == ZlibFormat.Raw:
-            return -window_bits              # ZlibFormat.kt:44-47
+        if fmt == ZlibFormat.AutoDetectZlibGzip:
+            raise RuntimeError("Compression can't be used with auto-detection")       # ZlibFormat.kt:28
+        return ZlibFormat.adjust_window_bits_for_decompression(fmt, window_bits)
+
+    @staticmethod
+    def adjust_window_bits_for_decompression(fmt, window_bits):
+        if fmt == ZlibFormat.Zlib:
+            if not 9 <= window_bits <= 15:
+                raise ValueError("windowBits must be between 9..15")
+            return window_bits
         if fmt == ZlibFormat.Gzip:
-            return window_bits + 16
+            if not 8 <= window_bits <= 15:
+                raise ValueError("windowBits must be between 8..15")
+            return window_bits + 16          # ZlibFormat.kt:39-42
+        if fmt == ZlibFormat.Raw:
+            if not 8 <= window_bits <= 15:
+                raise ValueError("windowBits must be between 8..15")
+            return -window_bits              # ZlibFormat.kt:44-47
+        if fmt == ZlibFormat.AutoDetectZlibGzip:
+            if not 9 <= window_bits <= 15:
+                raise ValueError("windowBits must be between 8..15")
+            return window_bits + 32          # ZlibFormat.kt:52-55
         return window_bits
 
 
@@ -68,7 +87,7 @@ class ZlibDecompressor(SliceTransform):
 
     def __init__(self, format=ZlibFormat.Zlib, window_bits=15):   # noqa: A002
         lib = self._lib = _lib.load()
-        wb = -window_bits if format == ZlibFormat.Raw else window_bits + 16 if format == ZlibFormat.Gzip else window_bits
+        wb = ZlibFormat.adjust_window_bits_for_decompression(format, window_bits)
         self._stream = lib.kmp_zlib_create_decompressor(wb)
         if not self._stream:
             raise RuntimeError("Failed allocating zlib stream")

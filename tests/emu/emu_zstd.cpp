@@ -7,7 +7,7 @@
 
 extern "C" __attribute__((visibility("default")))
 int emu_zstd_match(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
-                   KSeq* seqs, u32 seq_cap, u8* lits, u32 lit_cap, KSliceMeta* meta, u32 start_epoch)
+                   KSeq* seqs, u32 seq_cap, KSliceMeta* meta, u32 start_epoch)
 {
     u32 const nteams = nblocks * (64 / G);
     std::vector<u32> tables((size_t)nteams * KX_TBL_ENTRIES, 0xDEADBEEFu & 0x0003FFFFu);   // stale junk with epoch 0
@@ -15,8 +15,8 @@ int emu_zstd_match(const u8* src, const u64* in_off, const u32* in_len, u32 n, i
     u32 counter = 0;
     KMatchArgs a;
     a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
-    a.seqs = seqs; a.seq_cap = seq_cap; a.lits = lits; a.lit_cap = lit_cap; a.meta = meta;
-    a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter; a.flags = 0;
+    a.seqs = seqs; a.seq_cap = seq_cap; a.meta = meta;
+    a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter; a.flags = 0; a.shadow = nullptr;
     kxemu::failed = 0;
     switch (G) {
     case 4:  kxemu::launch(nblocks, [&]() { zstd_match_body<4>(a); }); break;
@@ -36,12 +36,12 @@ extern "C" __attribute__((visibility("default")))
 int emu_zstd_compress(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
                       u8* dst, const u64* out_off, u32* out_len, u32 slice_cap)
 {
-    u32 const seq_cap = slice_cap / 4 + 8, lit_cap = slice_cap + 64, scratch_words = slice_cap / 4 + 64;
+    u32 const seq_cap = (slice_cap / 4 + 8 + 15) & ~15u, lit_cap = slice_cap + 64, scratch_words = slice_cap / 4 + 64;
     std::vector<KSeq> seqs((size_t)n * seq_cap);
-    std::vector<u8> lits((size_t)n * lit_cap);
+    std::vector<u8> lits((size_t)n * lit_cap, 0xEE);
     std::vector<KSliceMeta> meta(n);
     std::vector<u32> scratch((size_t)n * scratch_words, 0xA5A5A5A5u);
-    int r = emu_zstd_match(src, in_off, in_len, n, G, nblocks, seqs.data(), seq_cap, lits.data(), lit_cap, meta.data(), 7);
+    int r = emu_zstd_match(src, in_off, in_len, n, G, nblocks, seqs.data(), seq_cap, meta.data(), 7);
     if (r) return r;
     for (u32 i = 0; i < n; i++) if (meta[i].status) return -3;
     KEntropyArgs e;

@@ -42,6 +42,7 @@ KX_DEV u32 kx_ld16(const u8* p) { u16 v; memcpy(&v, p, 2); return v; }
 KX_DEV void kx_st64(u8* p, u64 v) { memcpy(p, &v, 8); }
 KX_DEV void kx_st32(u8* p, u32 v) { memcpy(p, &v, 4); }
 KX_DEV void kx_st16(u8* p, u32 v) { u16 x = (u16)v; memcpy(p, &x, 2); }
+KX_DEV void kx_st128(void* p, u64 a, u64 b) { memcpy(p, &a, 8); memcpy((u8*)p + 8, &b, 8); }
 
 KX_DEV u32 kx_ld_nt(const u32* p) { return *p; }
 KX_DEV void kx_st_nt(u32* p, u32 v) { *p = v; }

@@ -195,7 +195,7 @@ def emu_compress(datas, G=8, nblocks=2):
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
 
 
-def emu_deflate(datas, zlib_wrapper=False):
+def emu_deflate(datas, zlib_wrapper=False, fmt=None):
     """chains -> best -> parse -> encode kernel bodies on the CPU wave emulator."""
     n = len(datas)
     lens = np.array([len(d) for d in datas], dtype=np.uint32)
@@ -211,12 +211,12 @@ def emu_deflate(datas, zlib_wrapper=False):
     out = np.zeros(n * stride, dtype=np.uint8)
     ooff = np.arange(n, dtype=np.uint64) * stride
     olen = np.zeros(n, dtype=np.uint32)
-    r = emu().emu_deflate(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(olen), None, None, 1 if zlib_wrapper else 0)
+    r = emu().emu_deflate(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(olen), None, None, fmt if fmt is not None else (1 if zlib_wrapper else 0))
     assert r == 0, f"emulator reported {r}"
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
 
 
-def emu_inflate(streams, caps, zlib_wrapper=False):
+def emu_inflate(streams, caps, zlib_wrapper=False, fmt=None):
     n = len(streams)
     lens = np.array([len(f) for f in streams], dtype=np.uint32)
     offs = np.zeros(n, dtype=np.uint64)
@@ -236,7 +236,7 @@ def emu_inflate(streams, caps, zlib_wrapper=False):
     out = np.zeros(t + 64, dtype=np.uint8)
     olen = np.zeros(n, dtype=np.uint32)
     st = np.zeros(n, dtype=np.int32)
-    r = emu().emu_inflate(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(caps), _vp(olen), _vp(st), 1 if zlib_wrapper else 0)
+    r = emu().emu_inflate(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(caps), _vp(olen), _vp(st), fmt if fmt is not None else (1 if zlib_wrapper else 0))
     assert r == 0, f"emulator reported {r}"
     return [out[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)], [int(x) for x in st]
 

@@ -98,3 +98,41 @@ def test_emulated_zlib_wrapper_and_inflate():
     bad[-1] ^= 1
     outs, st = helpers.emu_inflate([bytes(bad), good, good[:-9]], [5000, 100, 5000], zlib_wrapper=True)
     assert st[0] == -3 and st[1] == -5 and st[2] != 0
+
+
+def _gzip6(x):
+    c = zlib.compressobj(6, zlib.DEFLATED, 31, 8, 0)       # deflateInit2(6, Z_DEFLATED, 15 + 16, 8, 0): ZlibFormat.Gzip
+    return c.compress(x) + c.flush()
+
+
+def test_emulated_gzip_wrapper_and_autodetect():
+    """ZlibFormat.Gzip / AutoDetectZlibGzip (ZlibFormat.kt:39-55): header, CRC-32 and ISIZE as zlib writes them."""
+    import gzip
+    datas = [corpus.make(4100 + k, 1, s).tobytes() for k, s in enumerate([0, 1, 63, 64, 100, 5000, 40001, 65536])]
+    outs = helpers.emu_deflate(datas, fmt=2)
+    for x, f in zip(datas, outs):
+        assert f == _gzip6(x), len(x)
+    # decode: our own members, members from the gzip module (other XFL / OS / MTIME), optional header fields
+    dec, st = helpers.emu_inflate(outs, [max(len(x), 1) for x in datas], fmt=2)
+    assert st == [0] * len(datas) and dec == datas
+    foreign = [gzip.compress(x, 9, mtime=1234567) for x in datas]
+    dec, st = helpers.emu_inflate(foreign, [max(len(x), 1) for x in datas], fmt=2)
+    assert st == [0] * len(datas) and dec == datas
+    body = _gzip6(datas[5])[10:]
+    fancy = bytes([0x1F, 0x8B, 8, 4 | 8 | 16 | 2, 1, 2, 3, 4, 0, 3]) + bytes([5, 0]) + b"extra" + b"name.txt\0" + b"a comment\0" + b"\x12\x34" + body
+    dec, st = helpers.emu_inflate([fancy], [5000], fmt=2)
+    assert st == [0] and dec[0] == datas[5]
+    # the reference's gzip decode vector (ZlibTest.kt:86-98), also through auto-detection
+    kat = base64.b64decode("H4sIAIUNSGkAA8tIzcnJV0jOzy0oSi0uzszPUyjPL8pJAQDFwzyrFwAAAA==")
+    zl = base64.b64decode(helpers.deflate_golden()["reference_kat"]["zlib_b64"])
+    dec, st = helpers.emu_inflate([kat, kat, zl], [100, 100, 100], fmt=3)
+    assert st == [0, 0, 0] and dec == [b"hello compression world"] * 3
+    dec, st = helpers.emu_inflate([kat], [100], fmt=2)
+    assert st == [0] and dec[0] == b"hello compression world"
+    # errors: wrong CRC, wrong ISIZE, not gzip, truncated, capacity
+    good = outs[5]
+    bad_crc = bytearray(good); bad_crc[-5] ^= 0x40
+    bad_len = bytearray(good); bad_len[-1] ^= 1
+    not_gz = bytearray(good); not_gz[1] = 0x8C
+    dec, st = helpers.emu_inflate([bytes(bad_crc), bytes(bad_len), bytes(not_gz), good[:-12], good], [5000, 5000, 5000, 5000, 100], fmt=2)
+    assert st[0] == -3 and st[1] == -3 and st[2] == -3 and st[3] != 0 and st[4] == -5

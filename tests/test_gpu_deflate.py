@@ -94,7 +94,7 @@ def test_zlib_streaming_abi_like_the_reference():
     with pytest.raises(RuntimeError, match="Bad zlib result code -3: Z_DATA_ERROR"):
         ZlibDecompressor(ZlibFormat.Zlib).transform_bytes(zd[:-1] + bytes([zd[-1] ^ 1]))
     with pytest.raises(RuntimeError, match="Failed allocating zlib stream"):
-        ZlibCompressor(ZlibFormat.Gzip, 6)                 # gzip wrapper: next
+        ZlibCompressor(ZlibFormat.Zlib, 9)                 # other levels stay on the CPU library
     with pytest.raises(RuntimeError, match="Bad zlib result code -4: Z_MEM_ERROR"):
         ZlibCompressor(ZlibFormat.Raw, 6).transform_bytes(bytes(65537))
 
@@ -136,3 +136,44 @@ def test_inflate_batch_roundtrip_and_foreign_streams(batch):
     out, o2, l2, st = out.cpu().numpy(), o2.cpu().numpy(), l2.cpu().numpy(), st.cpu().numpy()
     for i in range(n):
         assert st[i] == 0 and out[o2[i]:o2[i] + l2[i]].tobytes() == plains[i], i
+
+
+def test_gzip_format_and_autodetect(batch):
+    """ZlibFormat.Gzip / AutoDetectZlibGzip (ZlibFormat.kt:39-55) through the batch and the streaming entry points."""
+    import gzip
+    from kompressor_amd.zlib import ZlibCompressor, ZlibDecompressor, ZlibFormat
+
+    def gz6(x):
+        c = zlib.compressobj(6, zlib.DEFLATED, 31, 8, 0)
+        return c.compress(x) + c.flush()
+
+    S = 65536
+    n = 256
+    buf = corpus.make(61000, n, S)
+    datas = [buf[i * S:(i + 1) * S].tobytes() for i in range(n)]
+    src = torch.from_numpy(buf).cuda()
+    in_off = torch.arange(n, dtype=torch.int64, device="cuda") * S
+    in_len = torch.full((n,), S, dtype=torch.int32, device="cuda")
+    dst, ooff, olen = batch.deflate(src, in_off, in_len, format="gzip")
+    torch.cuda.synchronize()
+    h_dst, h_off, h_len = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+    for i in range(n):
+        f = h_dst[int(h_off[i]):int(h_off[i]) + int(h_len[i])].tobytes()
+        assert f == gz6(datas[i]), i
+    cap = torch.full((n,), S, dtype=torch.int32, device="cuda")
+    for fmt in ("gzip", "auto"):
+        out, o2, l2, st = batch.inflate(dst, ooff, olen, cap, format=fmt, out_off=in_off)
+        torch.cuda.synchronize()
+        assert int(st.abs().sum().item()) == 0 and torch.equal(out[: n * S], src), fmt
+    # streaming entry points, the reference's gzip vector (ZlibTest.kt:86-98) and a foreign member
+    kat = base64.b64decode("H4sIAIUNSGkAA8tIzcnJV0jOzy0oSi0uzszPUyjPL8pJAQDFwzyrFwAAAA==")
+    assert ZlibDecompressor(ZlibFormat.Gzip).transform_bytes(kat) == b"hello compression world"
+    assert ZlibDecompressor(ZlibFormat.AutoDetectZlibGzip).transform_bytes(kat) == b"hello compression world"
+    assert ZlibDecompressor(ZlibFormat.AutoDetectZlibGzip).transform_bytes(zlib.compress(datas[0], 6)) == datas[0]
+    g = ZlibCompressor(ZlibFormat.Gzip).transform_bytes(datas[1])
+    assert g == gz6(datas[1]) and gzip.decompress(g) == datas[1]
+    assert ZlibDecompressor(ZlibFormat.Gzip).transform_bytes(gzip.compress(datas[2], 9, mtime=99)) == datas[2]
+    with pytest.raises(RuntimeError, match="Bad zlib result code -3: Z_DATA_ERROR"):
+        ZlibDecompressor(ZlibFormat.Gzip).transform_bytes(g[:-6] + bytes([g[-6] ^ 1]) + g[-5:])
+    with pytest.raises(RuntimeError, match="auto-detection"):
+        ZlibCompressor(ZlibFormat.AutoDetectZlibGzip)
