@@ -245,7 +245,10 @@ def main():
         value = world * in_bytes / (dt / args.steps) / 1e9
         ms_match = float(np.mean(k_match))
         ms_entropy = float(np.mean(k_entropy))
-        algo_bytes = in_bytes + frame_bytes + 16 * n      # len_in + len_frame + 16 B metadata per slice
+        # len_in + len_frame + 16 B metadata per slice; the batch goes through `launches` launches of each
+        # kernel (chunks), ms_match is the mean launch duration
+        launches = max(1, b.last_chunks())
+        algo_bytes = (in_bytes + frame_bytes + 16 * n) // launches
         achieved = algo_bytes / (ms_match * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
@@ -253,7 +256,7 @@ def main():
             try:
                 pj = json.load(open(pmc))
                 # counters were collected for the default configuration only
-                if pj.get("slices") == n and args.team in (0, 4):
+                if pj.get("slices") == n and pj.get("launches", 1) == launches and (args.team or 4) == pj.get("team", 4):
                     traffic = pj.get("zstd_match_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -268,7 +271,7 @@ def main():
                        "team_lanes": b.lib and (args.team or int(os.environ.get("KMP_TEAM_LANES", "4"))), "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_zstd_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms_match, 3)},
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms_match, 3), "launches_per_step": launches},
             "kernels_ms": {"k_zstd_match": round(ms_match, 3), "k_zstd_entropy": round(ms_entropy, 3)},
         }
         if not args.no_cpu:

@@ -198,8 +198,12 @@ KMP_API int kmp_compact_batch(kmp_batch_ctx* ctx, const void* d_src, const uint6
 /* Per-kernel device time of the last batch call, measured with HIP events on the
  * launch stream (0 = off, 1 = on).  kmp_batch_last_kernel_ms synchronises. */
 KMP_API int kmp_batch_set_profiling(kmp_batch_ctx* ctx, int on);
-/* which: 0 = zstd_match, 1 = zstd_entropy, 2 = zstd_decode */
+/* which: 0 = zstd_match, 1 = zstd_entropy (mean over the launches of the last compress batch), 2 = zstd_decode */
 KMP_API int kmp_batch_last_kernel_ms(kmp_batch_ctx* ctx, int which, float* ms);
+/* kmp_zstd_compress_batch cuts a large batch into chunks so that k_zstd_entropy of one chunk runs beside
+ * k_zstd_match of the next (second HIP stream inside the context; the caller's stream still sees the whole
+ * batch finished).  Returns how many launches of each kernel the last batch used. */
+KMP_API int kmp_batch_last_chunks(kmp_batch_ctx* ctx);
 
 KMP_API const char* kmp_last_error(void);
 KMP_API const char* kmp_version(void);

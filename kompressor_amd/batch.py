@@ -57,6 +57,10 @@ class ZstdBatch:
             raise RuntimeError(_lib.last_error())
         return ms.value
 
+    def last_chunks(self):
+        """Launches of each zstd compress kernel in the last batch."""
+        return int(self.lib.kmp_batch_last_chunks(self._h))
+
     def compress(self, src, in_off, in_len, dst=None, out_off=None, out_len=None):
         """src: uint8 device tensor; in_off int64, in_len int32 device tensors (n each).
         Returns (dst, out_off, out_len): frame i = dst[out_off[i] : out_off[i] + out_len[i]]."""

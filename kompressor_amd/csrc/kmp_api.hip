@@ -83,11 +83,14 @@ extern "C" const char* kmp_version(void) { return "kompressor_hip 0.1 (gfx950; z
 // --------------------------------------------------------------------------
 // batch context
 // --------------------------------------------------------------------------
+enum { KMP_MAX_CHUNKS = 4 };
 struct kmp_batch_ctx {
     int device; u32 max_slices, max_slice_bytes; int G; u32 match_blocks, nteams;
     u32 seq_cap, lit_cap, scratch_words;
     KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* shadow; u32* team_epoch; u32* counter;
     int profiling; hipEvent_t ev[14]; int ev_valid[7];
+    // zstd compress pipeline: entropy coding of chunk i (second stream) runs beside the match kernel of chunk i+1
+    hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join; u32 last_chunks;
     // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
     u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta;
 };
@@ -103,7 +106,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     if (!out || max_slices == 0) { g_last_error = "kmp_batch_create: bad argument"; return KMP_ERR_ARG; }
     if (max_slice_bytes > KMP_MAX_SLICE_BYTES) { g_last_error = "kmp_batch_create: slices above 128 KiB are not supported"; return KMP_ERR_CAPACITY; }
     if (team_lanes == 0) team_lanes = (int)env_u32("KMP_TEAM_LANES", 4);
-    if (team_lanes != 4 && team_lanes != 8 && team_lanes != 16 && team_lanes != 32 && team_lanes != 64) { g_last_error = "team_lanes must be 4, 8, 16, 32 or 64"; return KMP_ERR_ARG; }
+    if (team_lanes != 2 && team_lanes != 4 && team_lanes != 8 && team_lanes != 16 && team_lanes != 32 && team_lanes != 64) { g_last_error = "team_lanes must be 2, 4, 8, 16, 32 or 64"; return KMP_ERR_ARG; }
     HIP_TRY(hipSetDevice(device));
     kmp_batch_ctx* c = new (std::nothrow) kmp_batch_ctx();
     if (!c) { g_last_error = "out of host memory"; return KMP_ERR_ARG; }
@@ -134,6 +137,9 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     HIP_TRY(hipMemset(c->team_epoch, 0, (size_t)c->nteams * sizeof(u32)));
     HIP_TRY(hipMemset(c->meta, 0, ns * sizeof(KSliceMeta)));
     for (int i = 0; i < 14; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+    HIP_TRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+    for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { HIP_TRY(hipEventCreate(&c->evm[i][j])); HIP_TRY(hipEventCreate(&c->eve[i][j])); }
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return KMP_OK;
@@ -146,6 +152,9 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch);
     (void)hipFree(c->tables); (void)hipFree(c->shadow); (void)hipFree(c->team_epoch); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { if (c->evm[i][j]) (void)hipEventDestroy(c->evm[i][j]); if (c->eve[i][j]) (void)hipEventDestroy(c->eve[i][j]); }
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->st2) (void)hipStreamDestroy(c->st2);
     (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta);
     delete c;
 }
@@ -154,10 +163,24 @@ extern "C" int kmp_batch_set_profiling(kmp_batch_ctx* c, int on) { if (!c) retur
 extern "C" int kmp_batch_last_kernel_ms(kmp_batch_ctx* c, int which, float* ms)
 {
     if (!c || which < 0 || which > 6 || !ms || !c->ev_valid[which]) { g_last_error = "no timing recorded"; return KMP_ERR_ARG; }
+    if (which <= 1) {
+        // zstd compress: mean duration of the k_zstd_match (0) / k_zstd_entropy (1) launches of the last batch
+        float sum = 0;
+        for (u32 i = 0; i < c->last_chunks; i++) {
+            hipEvent_t* const e = which == 0 ? c->evm[i] : c->eve[i]; float t = 0;
+            HIP_TRY(hipEventSynchronize(e[1]));
+            HIP_TRY(hipEventElapsedTime(&t, e[0], e[1]));
+            sum += t;
+        }
+        *ms = sum / (float)c->last_chunks;
+        return KMP_OK;
+    }
     HIP_TRY(hipEventSynchronize(c->ev[2 * which + 1]));
     HIP_TRY(hipEventElapsedTime(ms, c->ev[2 * which], c->ev[2 * which + 1]));
     return KMP_OK;
 }
+/* launches of each zstd compress kernel in the last batch (the batch is cut into that many chunks) */
+extern "C" int kmp_batch_last_chunks(kmp_batch_ctx* c) { return c ? (int)c->last_chunks : 0; }
 
 extern "C" size_t kmp_zstd_compress_bound(size_t n)
 {
@@ -172,32 +195,48 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(c->counter, 0, 4, st));
-    KMatchArgs m;
-    m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
-    m.seqs = c->seqs; m.seq_cap = c->seq_cap; m.meta = c->meta;
-    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter; m.flags = env_u32("KMP_MATCH_FLAGS", 2); m.shadow = c->shadow;
+    // Chunks: the match kernel of chunk i+1 (memory-transaction bound) runs beside the entropy kernel of
+    // chunk i (latency bound) on a second stream; the caller's stream sees everything finished.
+    u32 chunks = env_u32("KMP_ZSTD_CHUNKS", n >= 32768u ? 2u : 1u);
+    if (chunks < 1) chunks = 1; if (chunks > KMP_MAX_CHUNKS) chunks = KMP_MAX_CHUNKS; if (chunks > n) chunks = 1;
+    HIP_TRY(hipMemsetAsync(c->counter, 0, 4 * KMP_MAX_CHUNKS, st));
     u32 const tpw = 64 / (u32)c->G;
-    u32 blocks = (n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
-    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[0], st));
-    switch (c->G) {
-    case 4:  hipLaunchKernelGGL(k_zstd_match<4>, dim3(blocks), dim3(64), 0, st, m); break;
-    case 8:  hipLaunchKernelGGL(k_zstd_match<8>, dim3(blocks), dim3(64), 0, st, m); break;
-    case 16: hipLaunchKernelGGL(k_zstd_match<16>, dim3(blocks), dim3(64), 0, st, m); break;
-    case 32: hipLaunchKernelGGL(k_zstd_match<32>, dim3(blocks), dim3(64), 0, st, m); break;
-    default: hipLaunchKernelGGL(k_zstd_match<64>, dim3(blocks), dim3(64), 0, st, m); break;
+    u32 const match_flags = env_u32("KMP_MATCH_FLAGS", 2), entropy_pad = env_u32("KMP_ENTROPY_PAD_LDS", 0);   // experiments only
+    u32 const per = (n + chunks - 1) / chunks;
+    bool forked = false;
+    for (u32 ci = 0; ci < chunks; ci++) {
+        u32 const first = ci * per, m_n = (n - first < per) ? n - first : per;
+        KMatchArgs m;
+        m.src = (const u8*)d_src; m.in_off = d_in_off + first; m.in_len = d_in_len + first; m.n_slices = m_n;
+        m.seqs = c->seqs + (size_t)first * c->seq_cap; m.seq_cap = c->seq_cap; m.meta = c->meta + first;
+        m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter + ci; m.flags = match_flags; m.shadow = c->shadow;
+        u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
+        if (c->profiling) HIP_TRY(hipEventRecord(c->evm[ci][0], st));
+        switch (c->G) {
+        case 2:  hipLaunchKernelGGL(k_zstd_match<2>, dim3(blocks), dim3(64), 0, st, m); break;
+        case 4:  hipLaunchKernelGGL(k_zstd_match<4>, dim3(blocks), dim3(64), 0, st, m); break;
+        case 8:  hipLaunchKernelGGL(k_zstd_match<8>, dim3(blocks), dim3(64), 0, st, m); break;
+        case 16: hipLaunchKernelGGL(k_zstd_match<16>, dim3(blocks), dim3(64), 0, st, m); break;
+        case 32: hipLaunchKernelGGL(k_zstd_match<32>, dim3(blocks), dim3(64), 0, st, m); break;
+        default: hipLaunchKernelGGL(k_zstd_match<64>, dim3(blocks), dim3(64), 0, st, m); break;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->evm[ci][1], st));
+        KEntropyArgs e;
+        e.src = (const u8*)d_src; e.in_off = d_in_off + first; e.in_len = d_in_len + first; e.n_slices = m_n;
+        e.seqs = m.seqs; e.seq_cap = c->seq_cap; e.lits = c->lits + (size_t)first * c->lit_cap; e.lit_cap = c->lit_cap; e.meta = m.meta;
+        e.scratch = c->scratch + (size_t)first * c->scratch_words; e.scratch_words = c->scratch_words;
+        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first;
+        hipStream_t es = st;
+        if (ci + 1 < chunks) { es = c->st2; HIP_TRY(hipStreamWaitEvent(es, c->evm[ci][1], 0)); forked = true; }
+        if (c->profiling) HIP_TRY(hipEventRecord(c->eve[ci][0], es));
+        hipLaunchKernelGGL(k_zstd_entropy, dim3(m_n), dim3(64), entropy_pad, es, e);
+        HIP_TRY(hipGetLastError());
+        if (c->profiling) HIP_TRY(hipEventRecord(c->eve[ci][1], es));
     }
-    HIP_TRY(hipGetLastError());
-    if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[1], st)); c->ev_valid[0] = 1; }
-    KEntropyArgs e;
-    e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = d_in_len; e.n_slices = n;
-    e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
-    e.scratch = c->scratch; e.scratch_words = c->scratch_words;
-    e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
-    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[2], st));
-    hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), env_u32("KMP_ENTROPY_PAD_LDS", 0), st, e);   // padding = occupancy experiment only
-    HIP_TRY(hipGetLastError());
-    if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[3], st)); c->ev_valid[1] = 1; }
+    if (forked) { HIP_TRY(hipEventRecord(c->ev_join, c->st2)); HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0)); }
+    c->last_chunks = chunks;
+    if (c->profiling) { c->ev_valid[0] = 1; c->ev_valid[1] = 1; }
     return KMP_OK;
 }
 

@@ -132,6 +132,8 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
     int m_type = 0, m_pos = 0, m_start = 0, m_mpos = 0; u32 m_len0 = 0, m_off = 0, m_idxl1 = 0; u64 m_w1 = 0;
     // sequences wait in registers (two per lane) until the team can store whole 16-byte pieces of a line
     u64 sq0 = 0, sq1 = 0;
+    // long-table lookup of the first position of the next step, when the last step's extra lane already made it
+    bool carry = false; u32 carry_idxl = 0;
 
     for (;;) {
         // ================= fetch the next slice =======================
@@ -163,7 +165,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     tag = ep << KX_IDX_BITS;
                     anchor = 0; ilimit = n - 8;
                     ip = 1; off1 = 1; off2 = 0;     // rep {1,4,8}: 4 exceeds the 1 byte of history at ip=1
-                    step = 1; nextStep = ip + 256;
+                    step = 1; nextStep = ip + 256; carry = false;
                     state = (n < 8 || ip + 1 > ilimit) ? KST_CLEANUP : KST_SEARCH;
                 }
             }
@@ -186,7 +188,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     m_type = KMT_REP0; m_pos = ip; m_start = ip; m_mpos = ip - (int)off2; m_len0 = 4;
                     state = KST_MATCH;
                 } else {
-                    step = 1; nextStep = ip + 256;
+                    step = 1; nextStep = ip + 256; carry = false;
                     state = (ip + 1 > ilimit) ? KST_CLEANUP : KST_SEARCH;
                 }
             }
@@ -203,12 +205,14 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 w = kx_ld64(src + pos);
                 hl = kx_hash_long(w, hbL); hs = kx_hash_short(w, hbS, mls);
                 // the lane after the last candidate only provides the long-table lookup of "ip1"
-                if (a.flags & 1u) { el = kx_ld_nt(&L[hl]); if (cand) es = kx_ld_nt(&S[hs]); }
-                else { el = L[hl]; if (cand) es = S[hs]; }
+                bool const haveL = carry && k == 0;
+                if (a.flags & 1u) { if (!haveL) el = kx_ld_nt(&L[hl]); if (cand) es = kx_ld_nt(&S[hs]); }
+                else { if (!haveL) el = L[hl]; if (cand) es = S[hs]; }
                 if (a.flags & 8u) { shacc |= kx_ld_nt(&SH[hl]); if (cand) shacc |= kx_ld_nt(&SH[KX_TBL_LONG + hs]); }
             }
             u32 idxl = ((el & ~KX_IDX_MASK) == tag) ? (el & KX_IDX_MASK) : 0u;
             u32 idxs = ((es & ~KX_IDX_MASK) == tag) ? (es & KX_IDX_MASK) : 0u;
+            if (srch && carry && k == 0) idxl = carry_idxl;
             // what lanes < k of this team would have inserted before lane k looks up
             u32 const hpack = hl | (hs << 16);
             int predL = -1, predS = -1;
@@ -269,11 +273,15 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             u32 const n_whi = kx_shfl((u32)(w >> 32), wsrc + 1);
             u32 const n_idxl = kx_shfl(idxl, wsrc + 1);
             u32 const n_hl = kx_shfl(hl, wsrc + 1);
+            // after a step without a hit the next step starts where the extra lane (lane K) looked
+            u32 const p_idxl = kx_shfl(idxl, tbase + K);
+            bool const p_prov = kx_shfl((u32)prov, tbase + K) != 0u;
 
             if (srch) {
                 guard++;
                 if (!th) {
                     ip += K * step;
+                    carry = p_prov && K > 0; carry_idxl = p_idxl;
                     if (ip >= nextStep) { step++; nextStep += 256; }
                     if (ip + step > ilimit) state = KST_CLEANUP;
                     if (K == 0 || guard > 2u * (u32)n + 64u) { status = 1; state = KST_CLEANUP; }
@@ -287,6 +295,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                         m_idxl1 = n_idxl; m_w1 = (u64)n_wlo | ((u64)n_whi << 32);
                         if (step < 4 && k == 0) L[n_hl] = tag | (u32)(m_pos + step + 2);
                     }
+                    carry = false;
                     state = KST_MATCH;
                 }
             }

@@ -19,6 +19,7 @@ int emu_zstd_match(const u8* src, const u64* in_off, const u32* in_len, u32 n, i
     a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter; a.flags = 0; a.shadow = nullptr;
     kxemu::failed = 0;
     switch (G) {
+    case 2:  kxemu::launch(nblocks, [&]() { zstd_match_body<2>(a); }); break;
     case 4:  kxemu::launch(nblocks, [&]() { zstd_match_body<4>(a); }); break;
     case 8:  kxemu::launch(nblocks, [&]() { zstd_match_body<8>(a); }); break;
     case 16: kxemu::launch(nblocks, [&]() { zstd_match_body<16>(a); }); break;

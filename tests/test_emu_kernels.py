@@ -15,7 +15,7 @@ def G():
     return helpers.golden()
 
 
-@pytest.mark.parametrize("team", [4, 8, 16, 64])
+@pytest.mark.parametrize("team", [2, 4, 8, 16, 64])
 def test_emulated_compress_matches_golden_64k(G, team):
     rows = G["config1"][:16] if team == 8 else G["config1"][16:32] if team == 4 else G["config1"][32:40]
     S = 65536
