@@ -12,7 +12,9 @@
  * (gradle/libs.versions.toml:9,46) == upstream libzstd 1.5.7.  This file
  * restates its published algorithm for the level-3 path (strategy "dfast":
  * two-table greedy LZ, HUF literals, FSE sequences, zstd frame format
- * RFC 8878) for inputs of at most 128 KiB (a single block).
+ * RFC 8878): single-block frames up to 128 KiB, and multi-block frames up to
+ * 2 MiB (block pre-splitter, repcodes and Huffman table carried from block to
+ * block, "treeless" literal sections, RLE blocks).
  *
  * Parity pin: byte-for-byte equality with a binary libzstd 1.5.7
  * (ZSTD_versionNumber()==10507) run in the build container through
@@ -123,10 +125,14 @@ static size_t count_eq(const u8* ip, const u8* match, const u8* iend)
  * index of a fresh libzstd match state is 2); 0 means empty. */
 #define IDX0 2u
 
-static size_t dfast_block(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize,
+/* One block src[blockStart, blockStart + srcSize) of an input whose first byte has index 2; the input is
+ * never larger than the window (callers guarantee it), so the lowest valid index is always 2
+ * (ZSTD_getLowestPrefixIndex with endIndex - dictLimit <= 1 << windowLog). */
+static size_t dfast_block(seqstore* ss, u32 rep[3], const u8* input, size_t blockStart, size_t srcSize,
                           u32* hashLong, u32 hBitsL, u32* hashSmall, u32 hBitsS, u32 mls)
 {
-    const u8* const base = src - IDX0;
+    const u8* const base = input - IDX0;
+    const u8* const src = input + blockStart;
     const u8* const istart = src;
     const u8* anchor = istart;
     u32 const prefixLowestIndex = IDX0;
@@ -768,12 +774,27 @@ static size_t huf_encode_4x(u8* dst, size_t dstSize, const u8* src, size_t srcSi
     return (size_t)(op - dst);
 }
 
-/* HUF_compress{1X,4X}_repeat with no previous table. returns 0 = not compressible,
+/* HUF_compress{1X,4X}_repeat.  `old` = table of the previous compressed literals section of the frame
+ * (NULL/oldValid 0 for the first one: HUF_repeat_none; afterwards libzstd holds HUF_repeat_check, never
+ * _valid without a dictionary).  *usedOld is set when the old table was kept ("treeless" section);
+ * when a new table is used it is copied to *old.  returns 0 = not compressible,
  * 1 = single symbol (rle), KERR = error, else compressed size (table + streams). */
-static size_t huf_compress(u8* dst, size_t dstSize, const u8* src, size_t srcSize, int singleStream, int suspectUncompressible)
+static size_t huf_encode_with(u8* ostart, u8* op, u8* oend, const u8* src, size_t srcSize, int singleStream, const huf_ctable* ct)
+{
+    size_t const cSize = singleStream ? huf_encode_1x(op, (size_t)(oend - op), src, srcSize, ct)
+                                      : huf_encode_4x(op, (size_t)(oend - op), src, srcSize, ct);
+    if (cSize == 0) return 0;
+    op += cSize;
+    if ((size_t)(op - ostart) >= srcSize - 1) return 0;
+    return (size_t)(op - ostart);
+}
+static size_t huf_compress(u8* dst, size_t dstSize, const u8* src, size_t srcSize, int singleStream, int suspectUncompressible,
+                           huf_ctable* old, int oldValid, int preferRepeat, int* usedOld)
 {
     u32 count[256]; u32 maxSymbolValue = 255; u32 huffLog = LIT_HUF_LOG; huf_ctable ct;
     u8* op = dst; u8* const oend = dst + dstSize; size_t i;
+    int repeat = oldValid;          /* HUF_repeat_check */
+    *usedOld = 0;
     if (!srcSize) return 0;
     if (!dstSize) return 0;
     if (srcSize > 128 * 1024) return KERR;
@@ -795,22 +816,30 @@ static size_t huf_compress(u8* dst, size_t dstSize, const u8* src, size_t srcSiz
         if (largest == srcSize) { *dst = src[0]; return 1; }
         if (largest <= (srcSize >> 7) + 4) return 0;
     }
+    /* HUF_validateCTable: every symbol present must have a code in the old table */
+    if (repeat) { u32 s; for (s = 0; s <= maxSymbolValue; s++) if (count[s] != 0 && old->nbBits[s] == 0) { repeat = 0; break; } }
+    /* small inputs: keep the old table */
+    if (preferRepeat && repeat) { *usedOld = 1; return huf_encode_with(dst, op, oend, src, srcSize, singleStream, old); }
+
     huffLog = fse_optimal_tablelog(huffLog, srcSize, maxSymbolValue, 1);
     huffLog = huf_build_ctable(&ct, count, maxSymbolValue, huffLog);
     {
         size_t const hSize = huf_write_ctable(op, dstSize, &ct, maxSymbolValue, huffLog);
         if (hSize == KERR) return KERR;
+        if (repeat) {
+            /* HUF_estimateCompressedSize of both tables */
+            size_t oldBits = 0, newBits = 0; u32 s;
+            for (s = 0; s <= maxSymbolValue; s++) { oldBits += (size_t)old->nbBits[s] * count[s]; newBits += (size_t)ct.nbBits[s] * count[s]; }
+            if ((oldBits >> 3) <= hSize + (newBits >> 3) || hSize + 12 >= srcSize) {
+                *usedOld = 1;
+                return huf_encode_with(dst, op, oend, src, srcSize, singleStream, old);
+            }
+        }
         if (hSize + 12ul >= srcSize) return 0;
         op += hSize;
+        if (old) *old = ct;          /* "Save new table" -- kept by the frame only if the block ends up compressed */
     }
-    {
-        size_t const cSize = singleStream ? huf_encode_1x(op, (size_t)(oend - op), src, srcSize, &ct)
-                                          : huf_encode_4x(op, (size_t)(oend - op), src, srcSize, &ct);
-        if (cSize == 0) return 0;
-        op += cSize;
-        if ((size_t)(op - dst) >= srcSize - 1) return 0;
-    }
-    return (size_t)(op - dst);
+    return huf_encode_with(dst, op, oend, src, srcSize, singleStream, &ct);
 }
 
 static size_t min_gain(size_t srcSize) { return (srcSize >> 6) + 2; }   /* strategy < btultra */
@@ -840,23 +869,32 @@ static size_t lit_rle(u8* dst, size_t cap, const u8* src, size_t srcSize)
     return flSize + 1;
 }
 
-static size_t compress_literals(u8* dst, size_t cap, const u8* src, size_t srcSize, int suspectUncompressible)
+/* ZSTD_compressLiterals.  prev/next: Huffman state before / after this block (next takes effect only if
+ * the block is emitted compressed).  hufValid = a table exists (repeatMode HUF_repeat_check). */
+typedef struct { huf_ctable ct; int valid; } kref_hufstate;
+
+static size_t compress_literals(u8* dst, size_t cap, const u8* src, size_t srcSize, int suspectUncompressible,
+                                const kref_hufstate* prev, kref_hufstate* next)
 {
     size_t const lhSize = 3 + (srcSize >= 1024) + (srcSize >= 16384);
     int const singleStream = srcSize < 256;
-    size_t cLitSize;
-    if (srcSize < 64) return lit_raw(dst, cap, src, srcSize);   /* ZSTD_minLiteralsToCompress(dfast, no repeat) */
+    size_t cLitSize; int usedOld = 0; u32 hType = 2;
+    *next = *prev;
+    if (srcSize < 64) return lit_raw(dst, cap, src, srcSize);   /* ZSTD_minLiteralsToCompress(dfast, repeat != valid) */
     if (cap < lhSize + 1) return KERR;
-    cLitSize = huf_compress(dst + lhSize, cap - lhSize, src, srcSize, singleStream, suspectUncompressible);
+    cLitSize = huf_compress(dst + lhSize, cap - lhSize, src, srcSize, singleStream, suspectUncompressible,
+                            &next->ct, prev->valid, srcSize <= 1024 /* strategy < lazy */, &usedOld);
+    if (usedOld) hType = 3;       /* set_repeat */
     {
         size_t const minGain = min_gain(srcSize);
-        if ((cLitSize == 0) || (cLitSize >= srcSize - minGain) || cLitSize == KERR) return lit_raw(dst, cap, src, srcSize);
+        if ((cLitSize == 0) || (cLitSize >= srcSize - minGain) || cLitSize == KERR) { *next = *prev; return lit_raw(dst, cap, src, srcSize); }
     }
-    if (cLitSize == 1) return lit_rle(dst, cap, src, srcSize);   /* srcSize >= 64 >= 8 */
+    if (cLitSize == 1) { *next = *prev; return lit_rle(dst, cap, src, srcSize); }   /* srcSize >= 64 >= 8 */
+    if (hType == 2) next->valid = 1;
     switch (lhSize) {
-    case 3: wr24(dst, (u32)(2 + ((u32)(!singleStream) << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 14))); break;
-    case 4: wr32(dst, (u32)(2 + (2 << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 18))); break;
-    default: wr32(dst, (u32)(2 + (3 << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 22))); dst[4] = (u8)(cLitSize >> 10); break;
+    case 3: wr24(dst, (u32)(hType + ((u32)(!singleStream) << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 14))); break;
+    case 4: wr32(dst, (u32)(hType + (2 << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 18))); break;
+    default: wr32(dst, (u32)(hType + (3 << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 22))); dst[4] = (u8)(cLitSize >> 10); break;
     }
     return lhSize + cLitSize;
 }
@@ -1021,34 +1059,97 @@ static size_t compress_sequences(u8* dst, size_t cap, const seqstore* ss)
 }
 
 /* ------------------------------------------------------------------ */
+/* block pre-splitter (libzstd 1.5.7 zstd_preSplit.c, ZSTD_splitBlock   */
+/* level 1 == "byChunks" with sampling rate 43 and the byte value as    */
+/* the event: what ZSTD_optimalBlockSize picks for strategy dfast)      */
+/* ------------------------------------------------------------------ */
+typedef struct { u32 events[256]; size_t nbEvents; } kref_fp;
+
+static void fp_record(kref_fp* fp, const u8* p, size_t srcSize)
+{
+    size_t const limit = srcSize - 2 + 1; size_t n;       /* HASHLENGTH 2 */
+    memset(fp, 0, sizeof(*fp));
+    for (n = 0; n < limit; n += 43) fp->events[p[n]]++;
+    fp->nbEvents = limit / 43;
+}
+static int fp_differ(const kref_fp* ref, const kref_fp* nw, int penalty)
+{
+    u64 const p50 = (u64)ref->nbEvents * (u64)nw->nbEvents;
+    u64 deviation = 0; u64 threshold; int n;
+    for (n = 0; n < 256; n++) {
+        int64_t const d = (int64_t)ref->events[n] * (int64_t)nw->nbEvents - (int64_t)nw->events[n] * (int64_t)ref->nbEvents;
+        deviation += (u64)(d < 0 ? -d : d);
+    }
+    threshold = p50 * (u64)(14 + penalty) / 16;            /* THRESHOLD_BASE 14, THRESHOLD_PENALTY_RATE 16 */
+    return deviation >= threshold;
+}
+static size_t split_block_by_chunks(const u8* p)            /* block of exactly 128 KiB */
+{
+    kref_fp past, nw; int penalty = 3; size_t pos; int n;
+    size_t const blockSize = 128 << 10, chunk = 8 << 10;
+    fp_record(&past, p, chunk);
+    for (pos = chunk; pos <= blockSize - chunk; pos += chunk) {
+        fp_record(&nw, p + pos, chunk);
+        if (fp_differ(&past, &nw, penalty)) return pos;
+        for (n = 0; n < 256; n++) past.events[n] += nw.events[n];
+        past.nbEvents += nw.nbEvents;
+        if (penalty > 0) penalty--;
+    }
+    return blockSize;
+}
+/* ZSTD_optimalBlockSize for level 3 */
+KREF_API size_t kref_optimal_block_size(const u8* src, size_t remaining, int64_t savings)
+{
+    size_t const blockSizeMax = 128 << 10;
+    if (remaining < blockSizeMax) return remaining;
+    if (savings < 3) return blockSizeMax;
+    return split_block_by_chunks(src);
+}
+
+/* ------------------------------------------------------------------ */
 /* block + frame                                                       */
 /* ------------------------------------------------------------------ */
 typedef struct {
     u32* hashLong; u32* hashSmall; kref_seq* seqs; u8* lits;
 } kref_wksp;
 
-/* Compressed-block body for one block (<=128 KiB). returns 0 => emit raw block. */
-static size_t compress_block_body(u8* dst, size_t cap, const u8* src, size_t srcSize, const u32* P, kref_wksp* w, seqstore* ssOut)
+/* per-frame state carried from block to block (ZSTD_compressedBlockState_t): repcodes and the Huffman
+ * table; the FSE tables never reach FSE_repeat_valid without a dictionary, so they are not state. */
+typedef struct { u32 rep[3]; kref_hufstate huf; int isFirstBlock; } kref_frame_state;
+
+/* ZSTD_compressBlock_internal for the block input[blockStart, +srcSize).
+ * returns 0 => emit a raw block, 1 => RLE block, else the compressed-block body size. */
+static size_t compress_block_body(u8* dst, size_t cap, const u8* input, size_t blockStart, size_t srcSize, const u32* P,
+                                  kref_wksp* w, kref_frame_state* fs, seqstore* ssOut)
 {
-    seqstore ss; u32 rep[3] = { 1, 4, 8 };
+    seqstore ss; u32 rep[3]; kref_hufstate nextHuf;
+    const u8* const src = input + blockStart;
     size_t lastLL, litC, seqC, cSize;
     memset(&ss, 0, sizeof(ss)); ss.seqs = w->seqs; ss.lits = w->lits;
     if (srcSize < 2 + 3 + 1 + 1) { if (ssOut) *ssOut = ss; return 0; }   /* MIN_CBLOCK_SIZE + blockHeader + 1 + 1 */
-    memset(w->hashLong, 0, sizeof(u32) << P[2]);
-    memset(w->hashSmall, 0, sizeof(u32) << P[1]);
-    lastLL = dfast_block(&ss, rep, src, srcSize, w->hashLong, P[2], w->hashSmall, P[1], P[3]);
+    memcpy(rep, fs->rep, sizeof(rep));
+    lastLL = dfast_block(&ss, rep, input, blockStart, srcSize, w->hashLong, P[2], w->hashSmall, P[1], P[3]);
     memcpy(ss.lits + ss.litSize, src + srcSize - lastLL, lastLL); ss.litSize += lastLL;
     if (ssOut) *ssOut = ss;
+    cSize = 0;
     {
         int const suspect = (ss.nbSeq == 0) || (ss.litSize / ss.nbSeq >= 20);
-        litC = compress_literals(dst, cap, ss.lits, ss.litSize, suspect);
-        if (litC == KERR) return (srcSize <= cap) ? 0 : KERR;
+        litC = compress_literals(dst, cap, ss.lits, ss.litSize, suspect, &fs->huf, &nextHuf);
+        if (litC == KERR) { if (srcSize > cap) return KERR; goto _entropy_done; }
+        seqC = compress_sequences(dst + litC, cap - litC, &ss);
+        if (seqC == KERR) { if (srcSize > cap) return KERR; goto _entropy_done; }
+        if (seqC == 0) goto _entropy_done;
+        cSize = litC + seqC;
+        { size_t const maxCSize = srcSize - min_gain(srcSize); if (cSize >= maxCSize) cSize = 0; }
     }
-    seqC = compress_sequences(dst + litC, cap - litC, &ss);
-    if (seqC == KERR) return (srcSize <= cap) ? 0 : KERR;
-    if (seqC == 0) return 0;
-    cSize = litC + seqC;
-    { size_t const maxCSize = srcSize - min_gain(srcSize); if (cSize >= maxCSize) return 0; }
+_entropy_done:
+    /* a block that is one repeated byte becomes an RLE block, except the first block of a frame */
+    if (!fs->isFirstBlock && ss.nbSeq < 4 && ss.litSize < 10) {
+        size_t i; int same = 1;
+        for (i = 1; i < srcSize; i++) if (src[i] != src[0]) { same = 0; break; }
+        if (same) { dst[0] = src[0]; cSize = 1; }
+    }
+    if (cSize > 1) { memcpy(fs->rep, rep, sizeof(rep)); fs->huf = nextHuf; }   /* confirmRepcodesAndEntropyTables */
     return cSize;
 }
 
@@ -1074,50 +1175,80 @@ static size_t write_frame_header(u8* dst, size_t srcSize, u32 windowLog)
     return pos;
 }
 
-/* One-shot level-3 frame. Returns frame size, or (size_t)-1 if dst is too small
- * or srcSize is outside this restatement's scope (> 128 KiB). */
-KREF_API size_t kref_zstd_l3_compress(u8* dst, size_t cap, const u8* src, size_t srcSize)
+#define KREF_MAX_SRC (2u << 20)       /* window never slides: srcSize <= 1 << windowLog */
+
+static int wksp_alloc(kref_wksp* w, const u32* P)
 {
-    u32 P[4]; kref_wksp w; size_t pos, cSize; u8* body;
-    if (srcSize > 131072) return KERR;
+    w->hashLong = (u32*)calloc((size_t)1 << P[2], sizeof(u32));
+    w->hashSmall = (u32*)calloc((size_t)1 << P[1], sizeof(u32));
+    w->seqs = (kref_seq*)malloc(sizeof(kref_seq) * ((128 << 10) / 3 + 8));
+    w->lits = (u8*)malloc((128 << 10) + 32);
+    return w->hashLong && w->hashSmall && w->seqs && w->lits;
+}
+static void wksp_free(kref_wksp* w) { free(w->hashLong); free(w->hashSmall); free(w->seqs); free(w->lits); }
+
+/* One-shot level-3 frame (ZSTD_compress2 with the size known). Returns the frame size, or (size_t)-1 if
+ * dst is too small or srcSize is outside this restatement's scope (> 2 MiB).  blockSizesOut (optional,
+ * room for srcSize / 8192 + 2 entries) receives the sizes of the input blocks, *nbBlocksOut their number. */
+KREF_API size_t kref_zstd_l3_compress_blocks(u8* dst, size_t cap, const u8* src, size_t srcSize, u32* blockSizesOut, u32* nbBlocksOut)
+{
+    u32 P[4]; kref_wksp w; kref_frame_state fs; size_t pos, ipos = 0; int64_t savings = 0; u32 nb = 0;
+    if (nbBlocksOut) *nbBlocksOut = 0;
+    if (srcSize > KREF_MAX_SRC) return KERR;
     if (cap < kref_compress_bound(srcSize)) return KERR;
     kref_params_l3(srcSize, P);
     pos = write_frame_header(dst, srcSize, P[0]);
     if (srcSize == 0) { wr24(dst + pos, 1); return pos + 3; }
-    w.hashLong = (u32*)malloc(sizeof(u32) << P[2]);
-    w.hashSmall = (u32*)malloc(sizeof(u32) << P[1]);
-    w.seqs = (kref_seq*)malloc(sizeof(kref_seq) * (srcSize / 3 + 8));
-    w.lits = (u8*)malloc(srcSize + 32);
-    body = dst + pos + 3;
-    cSize = compress_block_body(body, cap - pos - 3, src, srcSize, P, &w, NULL);
-    free(w.hashLong); free(w.hashSmall); free(w.seqs); free(w.lits);
-    if (cSize == KERR) return KERR;
-    if (cSize == 0) {
-        wr24(dst + pos, 1 + (0 << 1) + (u32)(srcSize << 3));
-        memcpy(body, src, srcSize);
-        return pos + 3 + srcSize;
+    if (!wksp_alloc(&w, P)) { wksp_free(&w); return KERR; }
+    fs.rep[0] = 1; fs.rep[1] = 4; fs.rep[2] = 8; fs.huf.valid = 0; memset(&fs.huf.ct, 0, sizeof(fs.huf.ct)); fs.isFirstBlock = 1;
+    while (ipos < srcSize) {
+        size_t const remaining = srcSize - ipos;
+        size_t const blockSize = kref_optimal_block_size(src + ipos, remaining, savings);
+        u32 const lastBlock = (blockSize == remaining);
+        u8* const body = dst + pos + 3;
+        size_t cSize = compress_block_body(body, cap - pos - 3, src, ipos, blockSize, P, &w, &fs, NULL);
+        if (cSize == KERR) { wksp_free(&w); return KERR; }
+        if (cSize == 0) {
+            wr24(dst + pos, lastBlock + (0 << 1) + (u32)(blockSize << 3));
+            memcpy(body, src + ipos, blockSize);
+            cSize = 3 + blockSize;
+        } else if (cSize == 1) {
+            wr24(dst + pos, lastBlock + (1 << 1) + (u32)(blockSize << 3));
+            cSize = 3 + 1;
+        } else {
+            wr24(dst + pos, lastBlock + (2 << 1) + (u32)(cSize << 3));
+            cSize += 3;
+        }
+        savings += (int64_t)blockSize - (int64_t)cSize;
+        if (blockSizesOut) blockSizesOut[nb] = (u32)blockSize;
+        nb++;
+        ipos += blockSize; pos += cSize; fs.isFirstBlock = 0;
     }
-    wr24(dst + pos, 1 + (2 << 1) + (u32)(cSize << 3));
-    return pos + 3 + cSize;
+    wksp_free(&w);
+    if (nbBlocksOut) *nbBlocksOut = nb;
+    return pos;
 }
 
-/* Stage taps for kernel-by-kernel diffing: the seqStore of the single block.
+KREF_API size_t kref_zstd_l3_compress(u8* dst, size_t cap, const u8* src, size_t srcSize)
+{
+    return kref_zstd_l3_compress_blocks(dst, cap, src, srcSize, NULL, NULL);
+}
+
+/* Stage taps for kernel-by-kernel diffing: the seqStore of the single block of a slice <= 128 KiB.
  * seqsOut: nbSeq x (offBase u32, litLength u16, mlBase u16); litsOut: literal bytes. */
 KREF_API size_t kref_zstd_l3_seqstore(const u8* src, size_t srcSize, void* seqsOut, size_t* nbSeqOut,
                                       u8* litsOut, size_t* litSizeOut, int* longType, size_t* longPos)
 {
-    u32 P[4]; kref_wksp w; seqstore ss; u8* tmp; size_t cap = kref_compress_bound(srcSize) + 64; size_t r;
+    u32 P[4]; kref_wksp w; seqstore ss; kref_frame_state fs; u8* tmp; size_t cap = kref_compress_bound(srcSize) + 64; size_t r;
     if (srcSize > 131072) return KERR;
     kref_params_l3(srcSize, P);
-    w.hashLong = (u32*)malloc(sizeof(u32) << P[2]);
-    w.hashSmall = (u32*)malloc(sizeof(u32) << P[1]);
-    w.seqs = (kref_seq*)malloc(sizeof(kref_seq) * (srcSize / 3 + 8));
-    w.lits = (u8*)malloc(srcSize + 32);
+    if (!wksp_alloc(&w, P)) { wksp_free(&w); return KERR; }
+    fs.rep[0] = 1; fs.rep[1] = 4; fs.rep[2] = 8; fs.huf.valid = 0; memset(&fs.huf.ct, 0, sizeof(fs.huf.ct)); fs.isFirstBlock = 1;
     tmp = (u8*)malloc(cap);
-    r = compress_block_body(tmp, cap, src, srcSize, P, &w, &ss);
+    r = compress_block_body(tmp, cap, src, 0, srcSize, P, &w, &fs, &ss);
     memcpy(seqsOut, ss.seqs, ss.nbSeq * sizeof(kref_seq)); *nbSeqOut = ss.nbSeq;
     memcpy(litsOut, ss.lits, ss.litSize); *litSizeOut = ss.litSize;
     *longType = ss.longLengthType; *longPos = ss.longLengthPos;
-    free(w.hashLong); free(w.hashSmall); free(w.seqs); free(w.lits); free(tmp);
+    wksp_free(&w); free(tmp);
     return r;
 }

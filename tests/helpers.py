@@ -30,6 +30,67 @@ def special_inputs():
     }
 
 
+def multiblock_inputs():
+    """Seeded inputs above 128 KiB (multi-block frames): (name, bytes).  Same list the generator
+    tests/golden/make_golden_multiblock.py used.  Segments of different corpus classes, byte runs and short
+    periods, so that libzstd's block pre-splitter cuts blocks and emits raw / RLE / treeless-literals blocks."""
+    import random
+    from kompressor_amd import corpus
+    out = [("zeros_1m", bytes(1 << 20)), ("zeros_300k", bytes(300000)), ("run_128k_plus_5", b"\x07" * (131072 + 5)),
+           ("period256_1m", bytes(range(256)) * 4096),
+           ("random_1m", corpus.make(9001, 1, 1 << 20, mix=ord("R")).tobytes()),
+           ("random_zero_alternating", corpus.make(9002, 1, 131072, mix=ord("R")).tobytes() + bytes(131072)
+            + corpus.make(9003, 1, 131072, mix=ord("R")).tobytes() + bytes(70000))]
+    for t in range(1, 9):
+        out.append((f"text_256k_plus_{t}", corpus.make(500 + t, 1, 262144 + t, mix=ord("T")).tobytes()))
+    for cls in "TXSBDIZ":
+        out.append((f"class_{cls}_1m", corpus.make(9100 + ord(cls), 1, 1 << 20, mix=ord(cls)).tobytes()))
+    rng = random.Random(20260517)
+    for k in range(24):
+        total = rng.choice([131073, 140000, 262144, 262145, 300000, 524288, 1 << 20, 777777, 1500000, 2 << 20])
+        parts, have = [], 0
+        while have < total:
+            cls = rng.choice("TXSBDIZR")
+            n = rng.choice([100, 700, 1000, 3000, 9000, 20000, 60000, 140000])
+            r = rng.random()
+            if r < 0.1:
+                seg = bytes([rng.randrange(256)]) * n
+            elif r < 0.2:
+                unit = corpus.make(rng.randrange(1 << 30), 1, rng.choice([10, 300]), mix=ord("R")).tobytes()
+                seg = unit * (n // len(unit) + 1)
+            else:
+                seg = corpus.make(rng.randrange(1 << 30), 1, n, mix=ord(cls)).tobytes()
+            parts.append(seg)
+            have += len(seg)
+        out.append((f"mixed_{k}_{total}", b"".join(parts)[:total]))
+    return out
+
+
+def parse_frame_blocks(f):
+    """[(block type, header size field, literals type or -1)] of a zstd frame (RFC 8878 section 3.1.1)."""
+    fhd = f[4]
+    pos = 5
+    ss = (fhd >> 5) & 1
+    if not ss:
+        pos += 1
+    pos += [1 if ss else 0, 2, 4, 8][fhd >> 6]
+    out = []
+    while True:
+        h = f[pos] | (f[pos + 1] << 8) | (f[pos + 2] << 16)
+        pos += 3
+        t, sz = (h >> 1) & 3, h >> 3
+        out.append((t, sz, (f[pos] & 3) if t == 2 else -1))
+        pos += 1 if t == 1 else sz
+        if h & 1:
+            break
+    return out
+
+
+def multiblock_golden():
+    with open(os.path.join(os.path.dirname(GOLDEN_PATH), "zstd_l3_multiblock_golden.json")) as fh:
+        return json.load(fh)
+
+
 def golden():
     with open(GOLDEN_PATH) as fh:
         return json.load(fh)

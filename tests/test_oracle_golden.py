@@ -63,6 +63,29 @@ def test_oracle_matches_golden_specials_and_config0(G):
     assert len(f) == c0["len"] == 131084 and helpers.sha256(f) == c0["sha256"] and f[:12].hex() == c0["head"]
 
 
+def test_oracle_matches_golden_multiblock():
+    """Frames above 128 KiB: block pre-splitter, state carried between blocks, raw / RLE / treeless blocks."""
+    o = helpers.oracle()
+    rows = helpers.multiblock_golden()["rows"]
+    seen = set()
+    for (name, d), row in zip(helpers.multiblock_inputs(), rows):
+        assert name == row["name"] and len(d) == row["size"] and helpers.sha256(d) == row["input_sha256"], name
+        f = o.compress(d)
+        assert len(f) == row["len"] and helpers.sha256(f) == row["sha256"], name
+        assert [list(b) for b in helpers.parse_frame_blocks(f)] == row["blocks"], name
+        seen.update((b[0], b[2]) for b in row["blocks"])
+    # the vectors exercise raw, RLE and compressed blocks with raw, Huffman and treeless literals
+    assert {(0, -1), (1, -1), (2, 0), (2, 2), (2, 3)} <= seen
+
+
+def test_params_above_128k():
+    o = helpers.oracle()
+    expect = {131073: (18, 16, 16, 4), 262144: (18, 16, 16, 4), 262145: (19, 16, 17, 5), 524288: (19, 16, 17, 5),
+              1 << 20: (20, 16, 17, 5), (1 << 20) + 1: (21, 16, 17, 5), 2 << 20: (21, 16, 17, 5)}
+    for n, p in expect.items():
+        assert o.params(n) == p, n
+
+
 def test_oracle_against_live_libzstd_if_present():
     z = helpers.live_libzstd()
     if z is None:
