@@ -123,7 +123,9 @@ typedef struct kmp_batch_ctx kmp_batch_ctx;
 #define KMP_ERR_CAPACITY  (-3)   /* n or slice size beyond what the context was created for */
 #define KMP_ERR_KERNEL    (-4)   /* a kernel guard tripped (never expected) */
 
-#define KMP_MAX_SLICE_BYTES (128u * 1024u)   /* single-block frames; larger slices: SURVEY.md 8f rank 1 */
+#define KMP_MAX_SLICE_BYTES (128u * 1024u)        /* one block per frame: the batched fast path */
+#define KMP_MAX_BIG_SLICE_BYTES (2u << 20)       /* frames of several blocks (context created with max_slice_bytes above
+                                                  * 128 KiB): the level-3 window (<= 2 MiB) never slides */
 
 /* Workspace for up to max_slices slices of up to max_slice_bytes each on HIP
  * device `device`.  team_lanes: lanes of a wave that cooperate on one slice in
@@ -204,6 +206,9 @@ KMP_API int kmp_batch_last_kernel_ms(kmp_batch_ctx* ctx, int which, float* ms);
  * k_zstd_match of the next (second HIP stream inside the context; the caller's stream still sees the whole
  * batch finished).  Returns how many launches of each kernel the last batch used. */
 KMP_API int kmp_batch_last_chunks(kmp_batch_ctx* ctx);
+/* A context for slices above 128 KiB compresses block by block (libzstd decides each block's size from the bytes
+ * produced so far): block rounds of the last batch. */
+KMP_API int kmp_batch_last_rounds(kmp_batch_ctx* ctx);
 
 KMP_API const char* kmp_last_error(void);
 KMP_API const char* kmp_version(void);

@@ -24,6 +24,26 @@
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match(KMatchArgs a) { zstd_match_body<G>(a); }
 __global__ __launch_bounds__(64, 4) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
+// frames of several blocks (slices above 128 KiB): one block of every unfinished slice per launch
+template <int G>
+__global__ __launch_bounds__(64) void k_zstd_match_blk(KMatchArgs a) { zstd_match_body<G, true>(a); }
+__global__ __launch_bounds__(64, 4) void k_zstd_frame(KFrameArgs a) { zstd_frame_body(a); }
+// ... or the whole chain of blocks of a slice by one wave (no host rounds)
+template <int G>
+__global__ __launch_bounds__(64, 3) void k_zstd_big(KBigArgs a) { zstd_big_body<G>(a); }
+// first block size, repcodes {1,4,8}, no Huffman table; an empty slice is a header and an empty raw block
+__global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 n, KFrameState* fs, u8* dst, const u64* out_off, u32* out_len, u32* remaining)
+{
+    u32 const i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    KFrameState s; u32 const len = in_len[i];
+    s.ipos = 0; s.opos = 0; s.blockSize = len < KX_BLOCK_MAX ? len : KX_BLOCK_MAX; s.first = 1;
+    s.rep[0] = 1; s.rep[1] = 4; s.rep[2] = 8; s.hufValid = 0; s.hufSel = 0; s.savings = 0;
+    for (int k = 0; k < 6; k++) s.pad[k] = 0;
+    fs[i] = s;
+    if (len == 0) { u8* d = dst + out_off[i]; kx_st32(d, 0xFD2FB528u); d[4] = 0x20; d[5] = 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
+    else atomicAdd(remaining, 1u);
+}
 __global__ __launch_bounds__(64) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
 
 __global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chains_body(a); }
@@ -78,7 +98,7 @@ static int hip_fail(hipError_t e, const char* what)
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
 
 extern "C" const char* kmp_last_error(void) { return g_last_error.c_str(); }
-extern "C" const char* kmp_version(void) { return "kompressor_hip 0.1 (gfx950; zstd level 3 single-block frames)"; }
+extern "C" const char* kmp_version(void) { return "kompressor_hip 0.2 (gfx950; zstd level 3 frames up to 2 MiB, deflate level 6)"; }
 
 // --------------------------------------------------------------------------
 // batch context
@@ -93,6 +113,8 @@ struct kmp_batch_ctx {
     hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join; u32 last_chunks;
     // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
     u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta;
+    // frames of several blocks (max_slice_bytes above 128 KiB): per-slice state carried between the block rounds
+    int big; int big_G; KFrameState* fstate; u32* hufct; u32* big_tables; u32* remaining; u32* big_counters; u32 last_rounds;
 };
 
 static u32 env_u32(const char* name, u32 dflt)
@@ -104,7 +126,7 @@ static u32 env_u32(const char* name, u32 dflt)
 extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes)
 {
     if (!out || max_slices == 0) { g_last_error = "kmp_batch_create: bad argument"; return KMP_ERR_ARG; }
-    if (max_slice_bytes > KMP_MAX_SLICE_BYTES) { g_last_error = "kmp_batch_create: slices above 128 KiB are not supported"; return KMP_ERR_CAPACITY; }
+    if (max_slice_bytes > KMP_MAX_BIG_SLICE_BYTES) { g_last_error = "kmp_batch_create: slices above 2 MiB are not supported"; return KMP_ERR_CAPACITY; }
     if (team_lanes == 0) team_lanes = (int)env_u32("KMP_TEAM_LANES", 4);
     if (team_lanes != 2 && team_lanes != 4 && team_lanes != 8 && team_lanes != 16 && team_lanes != 32 && team_lanes != 64) { g_last_error = "team_lanes must be 2, 4, 8, 16, 32 or 64"; return KMP_ERR_ARG; }
     HIP_TRY(hipSetDevice(device));
@@ -119,8 +141,19 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     u32 const need = (max_slices + teams_per_wave - 1) / teams_per_wave;
     if (blocks > need) blocks = need;
     c->match_blocks = blocks; c->nteams = blocks * teams_per_wave;
-    c->seq_cap = (c->max_slice_bytes / 4 + 8 + 15) & ~15u; c->lit_cap = c->max_slice_bytes + 64; c->scratch_words = c->max_slice_bytes / 4 + 64;
+    c->big = c->max_slice_bytes > KMP_MAX_SLICE_BYTES;
+    u32 const block_cap = c->big ? KMP_MAX_SLICE_BYTES : c->max_slice_bytes;     // the sequence / literal workspaces hold one block
+    c->seq_cap = (block_cap / 4 + 8 + 15) & ~15u; c->lit_cap = block_cap + 64; c->scratch_words = block_cap / 4 + 64;
     size_t const ns = max_slices;
+    if (c->big) {
+        c->big_G = (int)env_u32("KMP_BIG_TEAM_LANES", 8);
+        if (c->big_G != 2 && c->big_G != 4 && c->big_G != 8 && c->big_G != 16 && c->big_G != 32 && c->big_G != 64) c->big_G = 8;
+        HIP_TRY(hipMalloc((void**)&c->fstate, ns * sizeof(KFrameState)));
+        HIP_TRY(hipMalloc((void**)&c->hufct, ns * 512 * sizeof(u32)));
+        HIP_TRY(hipMalloc((void**)&c->big_tables, ns * KX_BIG_TBL_ENTRIES * sizeof(u32)));
+        HIP_TRY(hipMalloc((void**)&c->remaining, 64));
+        HIP_TRY(hipMalloc((void**)&c->big_counters, ns * 4));
+    }
     HIP_TRY(hipMalloc((void**)&c->seqs, ns * c->seq_cap * sizeof(KSeq)));
     HIP_TRY(hipMalloc((void**)&c->lits, ns * c->lit_cap));
     HIP_TRY(hipMalloc((void**)&c->meta, ns * sizeof(KSliceMeta)));
@@ -150,7 +183,8 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch);
-    (void)hipFree(c->tables); (void)hipFree(c->shadow); (void)hipFree(c->team_epoch); (void)hipFree(c->counter);
+    (void)hipFree(c->tables); (void)hipFree(c->shadow); (void)hipFree(c->team_epoch);
+    (void)hipFree(c->fstate); (void)hipFree(c->hufct); (void)hipFree(c->big_tables); (void)hipFree(c->remaining); (void)hipFree(c->big_counters); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { if (c->evm[i][j]) (void)hipEventDestroy(c->evm[i][j]); if (c->eve[i][j]) (void)hipEventDestroy(c->eve[i][j]); }
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -187,6 +221,78 @@ extern "C" size_t kmp_zstd_compress_bound(size_t n)
     return n + (n >> 8) + ((n < (128u << 10)) ? (((128u << 10) - n) >> 11) : 0);
 }
 
+// Slices above 128 KiB: frames of several blocks.  Every round runs the match kernel and the frame kernel over
+// one block of every unfinished slice; block sizes depend on the bytes already produced (ZSTD_optimalBlockSize),
+// so the rounds are sequential and the host only reads back how many frames are still open.
+static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st)
+{
+    HIP_TRY(hipMemsetAsync(c->big_tables, 0, (size_t)n * KX_BIG_TBL_ENTRIES * sizeof(u32), st));
+    HIP_TRY(hipMemsetAsync(c->remaining, 0, 4, st));
+    hipLaunchKernelGGL(k_zstd_frame_init, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, c->fstate, (u8*)d_dst, d_out_off, d_out_len, c->remaining);
+    HIP_TRY(hipGetLastError());
+    KMatchArgs m;
+    m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
+    m.seqs = c->seqs; m.seq_cap = c->seq_cap; m.meta = c->meta;
+    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter; m.flags = 2; m.shadow = nullptr;
+    m.fstate = c->fstate; m.big_tables = c->big_tables;
+    KFrameArgs e;
+    e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = d_in_len; e.n_slices = n;
+    e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
+    e.scratch = c->scratch; e.scratch_words = c->scratch_words;
+    e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
+    e.fstate = c->fstate; e.hufct = c->hufct; e.remaining = c->remaining;
+    if (env_u32("KMP_BIG_ROUNDS", 0) == 0) {
+        // one wave per slice walks its chain of blocks
+        // few slices: one per wave (most waves); many: up to 64 / G per wave so that all of them are in flight
+        KBigArgs g; g.m = m; g.e = e; g.counters = c->big_counters;
+        u32 const resident = 12u * 256u;
+        u32 spw = env_u32("KMP_BIG_SLICES_PER_WAVE", (n + resident - 1) / resident);
+        if (spw < 1) spw = 1; if (spw > 64u / (u32)c->big_G) spw = 64u / (u32)c->big_G;
+        g.spw = spw;
+        u32 const grid = (n + spw - 1) / spw;
+        HIP_TRY(hipMemsetAsync(c->big_counters, 0, (size_t)n * 4, st));
+        switch (c->big_G) {
+        case 2:  hipLaunchKernelGGL(k_zstd_big<2>, dim3(grid), dim3(64), 0, st, g); break;
+        case 4:  hipLaunchKernelGGL(k_zstd_big<4>, dim3(grid), dim3(64), 0, st, g); break;
+        case 8:  hipLaunchKernelGGL(k_zstd_big<8>, dim3(grid), dim3(64), 0, st, g); break;
+        case 16: hipLaunchKernelGGL(k_zstd_big<16>, dim3(grid), dim3(64), 0, st, g); break;
+        case 32: hipLaunchKernelGGL(k_zstd_big<32>, dim3(grid), dim3(64), 0, st, g); break;
+        default: hipLaunchKernelGGL(k_zstd_big<64>, dim3(grid), dim3(64), 0, st, g); break;
+        }
+        HIP_TRY(hipGetLastError());
+        c->last_rounds = 0; c->last_chunks = 1;
+        return KMP_OK;
+    }
+    // (experiment switch KMP_BIG_ROUNDS=1) the same steps as separate launches per round of blocks
+    u32 const tpw = 64 / (u32)c->big_G;
+    u32 const blocks = (n + tpw - 1) / tpw;
+    u32 rounds = 0;
+    for (;;) {
+        u32 left = 0;
+        HIP_TRY(hipMemcpyAsync(&left, c->remaining, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (left == 0) break;
+        if (++rounds > KMP_MAX_BIG_SLICE_BYTES / 8192u + 2u) { g_last_error = "kmp_zstd_compress_batch: block rounds did not finish"; return KMP_ERR_KERNEL; }
+        HIP_TRY(hipMemsetAsync(c->counter, 0, 4, st));
+        switch (c->big_G) {
+        case 2:  hipLaunchKernelGGL(k_zstd_match_blk<2>, dim3(blocks), dim3(64), 0, st, m); break;
+        case 4:  hipLaunchKernelGGL(k_zstd_match_blk<4>, dim3(blocks), dim3(64), 0, st, m); break;
+        case 8:  hipLaunchKernelGGL(k_zstd_match_blk<8>, dim3(blocks), dim3(64), 0, st, m); break;
+        case 16: hipLaunchKernelGGL(k_zstd_match_blk<16>, dim3(blocks), dim3(64), 0, st, m); break;
+        case 32: hipLaunchKernelGGL(k_zstd_match_blk<32>, dim3(blocks), dim3(64), 0, st, m); break;
+        default: hipLaunchKernelGGL(k_zstd_match_blk<64>, dim3(blocks), dim3(64), 0, st, m); break;
+        }
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_zstd_frame, dim3(n), dim3(64), 0, st, e);
+        HIP_TRY(hipGetLastError());
+    }
+    c->last_rounds = rounds; c->last_chunks = 1;
+    return KMP_OK;
+}
+/* block rounds of the last batch of a context for slices above 128 KiB */
+extern "C" int kmp_batch_last_rounds(kmp_batch_ctx* c) { return c ? (int)c->last_rounds : 0; }
+
 extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                        uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
 {
@@ -195,6 +301,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->big) return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st);
     // Chunks: the match kernel of chunk i+1 (memory-transaction bound) runs beside the entropy kernel of
     // chunk i (latency bound) on a second stream; the caller's stream sees everything finished.
     u32 chunks = env_u32("KMP_ZSTD_CHUNKS", n >= 32768u ? 2u : 1u);
@@ -410,11 +517,16 @@ extern "C" const char* kmp_zstd_get_error_name(size_t code)
 struct stream_dev {
     kmp_batch_ctx* batch; u8* d_in; u8* d_out; u64* d_off; u32* d_len; size_t in_cap, out_cap;
 };
-static size_t stream_dev_init(stream_dev& s)
+static void stream_dev_free(stream_dev& s);
+// staging for one slice / frame of at most `bytes` on either side: the 128 KiB tier first, the 2 MiB tier
+// (frames of several blocks) when a larger one shows up
+static size_t stream_dev_init(stream_dev& s, size_t bytes = 0)
 {
-    if (s.batch) return 0;
-    if (kmp_batch_create(&s.batch, 0, 1, KMP_MAX_SLICE_BYTES, 8) != KMP_OK) return KERRC(ZE_memory_allocation);
-    s.in_cap = KMP_MAX_SLICE_BYTES + 1024; s.out_cap = KMP_MAX_SLICE_BYTES + 1024;
+    if (s.batch && bytes + 1024 <= s.in_cap) return 0;
+    if (s.batch) stream_dev_free(s);
+    u32 const tier = (bytes + 1024 <= KMP_MAX_SLICE_BYTES + 1024) ? KMP_MAX_SLICE_BYTES : KMP_MAX_BIG_SLICE_BYTES;
+    if (kmp_batch_create(&s.batch, 0, 1, tier, 8) != KMP_OK) return KERRC(ZE_memory_allocation);
+    s.in_cap = tier + (tier >> 7) + 1024; s.out_cap = tier + (tier >> 7) + 1024;
     if (hipMalloc((void**)&s.d_in, s.in_cap) != hipSuccess || hipMalloc((void**)&s.d_out, s.out_cap) != hipSuccess ||
         hipMalloc((void**)&s.d_off, 64) != hipSuccess || hipMalloc((void**)&s.d_len, 64) != hipSuccess) return KERRC(ZE_memory_allocation);
     return 0;
@@ -458,8 +570,8 @@ extern "C" size_t kmp_zstd_cctx_load_dictionary(kmp_zstd_cctx* c, const void* di
 static size_t run_single_compress(kmp_zstd_cctx* c)
 {
     size_t const n = c->in.size();
-    if (n > KMP_MAX_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
-    { size_t const e = stream_dev_init(c->dev); if (e) return e; }
+    if (n > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
+    { size_t const e = stream_dev_init(c->dev, n); if (e) return e; }
     stream_dev& s = c->dev;
     u64 offs[2] = { 0, 0 }; u32 len = (u32)n, olen = 0;
     if (n && hipMemcpy(s.d_in, c->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
@@ -485,7 +597,7 @@ extern "C" size_t kmp_zstd_compress_stream(kmp_zstd_cctx* c, void* dst, size_t d
         // slice arrives before the frame can be produced, so input is collected until e_end
         size_t const avail = src_size - *src_pos;
         if (avail) { const u8* p = (const u8*)src + *src_pos; c->in.insert(c->in.end(), p, p + avail); *src_pos = src_size; }
-        if (c->in.size() > KMP_MAX_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
+        if (c->in.size() > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
         if (end_op != KMP_ZSTD_e_end) return 0;
         size_t const e = run_single_compress(c);
         if (e) return e;
@@ -677,8 +789,12 @@ extern "C" size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* d, void* dst, size_t
         if (kmp_zstd_is_error(total)) return total;
         if (total && total < d->in.size()) { *src_pos -= d->in.size() - total; d->in.resize(total); }
         if (total == 0) return 3;                              // hint: more input expected
-        if (d->in.size() > KMP_MAX_SLICE_BYTES + 1024) return KERRC(ZE_frameParameter_unsupported);
-        { size_t const e = stream_dev_init(d->dev); if (e) return e; }
+        {
+            // frames of up to 2 MiB of content (content size unknown: the staging tier decides)
+            size_t const want = content == (size_t)-1 ? d->in.size() : (content > d->in.size() ? content : d->in.size());
+            if (want > KMP_MAX_BIG_SLICE_BYTES + (KMP_MAX_BIG_SLICE_BYTES >> 7)) return KERRC(ZE_frameParameter_unsupported);
+            size_t const e = stream_dev_init(d->dev, want); if (e) return e;
+        }
         stream_dev& s = d->dev;
         if (!d->d_status && hipMalloc((void**)&d->d_status, 64) != hipSuccess) return KERRC(ZE_memory_allocation);
         u64 offs[2] = { 0, 0 }; u32 lens[2] = { (u32)total, (u32)s.out_cap }; u32 res[2] = { 0, 0 };

@@ -27,15 +27,36 @@ struct KSliceMeta {
 #define KX_TBL_ENTRIES (KX_TBL_LONG + KX_TBL_SHORT)
 #define KX_MAX_SLICE (128u * 1024u)
 
-// level-3 parameters of a one-shot slice of n bytes (n <= 128 KiB here):
-// what ZSTD_getCParams(3, n, 0) yields after size adjustment.
+// ---- frames of several blocks (slices above 128 KiB, up to KX_MAX_BIG_SLICE) -------------------------
+// The slice is compressed block by block; what libzstd carries from one block of a frame to the next
+// (ZSTD_compressedBlockState_t, window, hash tables) lives in HBM between the rounds.
+#define KX_MAX_BIG_SLICE (2u << 20)          /* the window (<= 2 MiB at level 3) never slides */
+#define KX_BLOCK_MAX (128u * 1024u)
+#define KX_BIG_TBL_LONG  (1u << 17)
+#define KX_BIG_TBL_SHORT (1u << 16)
+#define KX_BIG_TBL_ENTRIES (KX_BIG_TBL_LONG + KX_BIG_TBL_SHORT)     /* per slice, plain indices, zeroed per batch */
+struct KFrameState {
+    u32 ipos;          // input consumed = start of the next block
+    u32 opos;          // frame bytes written
+    u32 blockSize;     // size of the next block (0 = frame finished)
+    u32 first;         // 1 until the first block is out
+    u32 rep[3];        // repcodes confirmed by the last compressed block
+    u32 hufValid;      // a Huffman table of an earlier block exists (HUF_repeat_check)
+    u32 hufSel;        // which of the two table slots holds it
+    int savings;       // input bytes - frame bytes of the blocks so far (ZSTD_compress_frameChunk)
+    u32 pad[6];
+};
+
+// level-3 parameters of a one-shot slice of n bytes: what ZSTD_getCParams(3, n, 0) yields after size adjustment.
 struct KParams { u32 windowLog, chainLog, hashLog, minMatch; };
 
 KX_DEV KParams kx_params_l3(u32 n)
 {
     KParams p;
-    if (n <= 16384) { p.windowLog = 14; p.chainLog = 14; p.hashLog = 15; p.minMatch = 4; }
-    else            { p.windowLog = 17; p.chainLog = 15; p.hashLog = 16; p.minMatch = 5; }
+    if (n <= 16384)       { p.windowLog = 14; p.chainLog = 14; p.hashLog = 15; p.minMatch = 4; }
+    else if (n <= 131072) { p.windowLog = 17; p.chainLog = 15; p.hashLog = 16; p.minMatch = 5; }
+    else if (n <= 262144) { p.windowLog = 18; p.chainLog = 16; p.hashLog = 16; p.minMatch = 4; }
+    else                  { p.windowLog = 21; p.chainLog = 16; p.hashLog = 17; p.minMatch = 5; }
     u32 const srcLog = (n < 64) ? 6 : kx_hb32(n - 1) + 1;
     if (p.windowLog > srcLog) p.windowLog = srcLog;
     if (p.hashLog > p.windowLog + 1) p.hashLog = p.windowLog + 1;

@@ -16,6 +16,7 @@
 // lane 0 while the other 8191 resident waves of the chip hide its latency.
 #pragma once
 #include "zstd_common.h"
+#include "zstd_match.h"
 
 struct KEntropyArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
@@ -616,11 +617,17 @@ KX_DEV u32 khuf_encode_streams(KEntropyLds& lds, u8* op, const u8* lits, u32 lit
     return single ? total : total + 6;
 }
 
+// Huffman table of an earlier block of the same frame (block mode only; libzstd: prevCBlock->entropy.huf with
+// repeatMode HUF_repeat_check).  `newCt` receives the table built for this block when it is the one used.
+struct KHufPrev { const u32* ct; bool valid; u32* newCt; u32 outcome; };    // outcome: 0 raw/rle, 2 new table, 3 old table kept
+
 // literals section at `dst`; returns its size (uniform across the wave)
-KX_DEV u32 kzstd_literals(KEntropyLds& lds, u8* dst, const u8* lits, u32 litSize, bool suspect, u32* scratch, int lane)
+KX_DEV u32 kzstd_literals(KEntropyLds& lds, u8* dst, const u8* lits, u32 litSize, bool suspect, u32* scratch, int lane,
+                          KHufPrev* prev = nullptr)
 {
     u32 const lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
     bool const single = litSize < 256;
+    u32 hType = 2;
     u32 cLit = 0;      // 0 => raw, 1 => rle
     if (litSize >= 64) {
         bool go = true;
@@ -633,17 +640,33 @@ KX_DEV u32 kzstd_literals(KEntropyLds& lds, u8* dst, const u8* lits, u32 litSize
             u32 const largest = kx_wave_hist(lds, lits, litSize, lane);
             if (largest == litSize) cLit = 1;
             else if (largest > (litSize >> 7) + 4) {
-                u32 hSize = 0;
+                u32 hSize = 0, useOld = 0;
                 if (lane == 0) {
                     u32 maxSymbolValue = 255;
                     while (!lds.hist[maxSymbolValue]) maxSymbolValue--;
-                    u32 huffLog = kfse_optimal_tablelog(11, litSize, maxSymbolValue, 1);
-                    huffLog = khuf_build_ctable(lds, maxSymbolValue, huffLog);
-                    hSize = khuf_write_ctable(dst + lhSize, lds, maxSymbolValue, huffLog);
+                    // HUF_validateCTable: the old table must code every symbol present
+                    bool repeat = prev && prev->valid;
+                    if (repeat) for (u32 sy = 0; sy <= maxSymbolValue; sy++) if (lds.hist[sy] != 0 && (prev->ct[sy] >> 16) == 0) { repeat = false; break; }
+                    if (repeat && litSize <= 1024) useOld = 1;          // HUF_flags_preferRepeat (strategy < lazy)
+                    else {
+                        u32 huffLog = kfse_optimal_tablelog(11, litSize, maxSymbolValue, 1);
+                        huffLog = khuf_build_ctable(lds, maxSymbolValue, huffLog);
+                        hSize = khuf_write_ctable(dst + lhSize, lds, maxSymbolValue, huffLog);
+                        if (repeat && hSize != KXE_ERR) {
+                            // HUF_estimateCompressedSize of both tables
+                            u32 oldBits = 0, newBits = 0;
+                            for (u32 sy = 0; sy <= maxSymbolValue; sy++) { oldBits += (prev->ct[sy] >> 16) * lds.hist[sy]; newBits += (lds.ct[sy] >> 16) * lds.hist[sy]; }
+                            if ((oldBits >> 3) <= hSize + (newBits >> 3) || hSize + 12 >= litSize) useOld = 1;
+                        }
+                        if (!useOld && prev && hSize != KXE_ERR && hSize + 12 < litSize)
+                            for (int sy = 0; sy < 256; sy++) prev->newCt[sy] = lds.ct[sy];       // "save new table"
+                    }
+                    if (useOld) { for (int sy = 0; sy < 256; sy++) lds.ct[sy] = prev->ct[sy]; hSize = 0; }
                 }
-                hSize = kx_shfl(hSize, 0);
+                hSize = kx_shfl(hSize, 0); useOld = kx_shfl(useOld, 0);
+                if (useOld) hType = 3;
                 kx_sync();
-                if (hSize != KXE_ERR && hSize + 12 < litSize) {
+                if (hSize != KXE_ERR && (useOld || hSize + 12 < litSize)) {
                     u32 const sz = khuf_encode_streams(lds, dst + lhSize + hSize, lits, litSize, single, scratch, lane);
                     if (sz != 0 && hSize + sz < litSize - 1) cLit = hSize + sz;
                 }
@@ -651,6 +674,7 @@ KX_DEV u32 kzstd_literals(KEntropyLds& lds, u8* dst, const u8* lits, u32 litSize
         }
         if (cLit != 1 && (cLit == 0 || cLit >= litSize - kx_min_gain(litSize))) cLit = 0;
     }
+    if (prev) prev->outcome = (cLit > 1) ? hType : 0u;
     if (cLit == 0) {
         u32 fl = 0;
         if (lane == 0) fl = klit_header_raw_rle(dst, 0, litSize);
@@ -666,9 +690,9 @@ KX_DEV u32 kzstd_literals(KEntropyLds& lds, u8* dst, const u8* lits, u32 litSize
         return fl + 1;
     }
     if (lane == 0) {
-        if (lhSize == 3) { u32 const h = 2u + ((u32)(!single) << 2) + (litSize << 4) + (cLit << 14); dst[0] = (u8)h; dst[1] = (u8)(h >> 8); dst[2] = (u8)(h >> 16); }
-        else if (lhSize == 4) kx_st32(dst, 2u + (2u << 2) + (litSize << 4) + (cLit << 18));
-        else { kx_st32(dst, 2u + (3u << 2) + (litSize << 4) + (cLit << 22)); dst[4] = (u8)(cLit >> 10); }
+        if (lhSize == 3) { u32 const h = hType + ((u32)(!single) << 2) + (litSize << 4) + (cLit << 14); dst[0] = (u8)h; dst[1] = (u8)(h >> 8); dst[2] = (u8)(h >> 16); }
+        else if (lhSize == 4) kx_st32(dst, hType + (2u << 2) + (litSize << 4) + (cLit << 18));
+        else { kx_st32(dst, hType + (3u << 2) + (litSize << 4) + (cLit << 22)); dst[4] = (u8)(cLit >> 10); }
     }
     return lhSize + cLit;
 }
@@ -989,6 +1013,182 @@ KX_DEV void zstd_entropy_slice(const KEntropyArgs& a, KEntropyLds& lds, u32 slic
     } else if (lane == 0) {
         u32 const h = 1u + (2u << 1) + (cSize << 3); bh[0] = (u8)h; bh[1] = (u8)(h >> 8); bh[2] = (u8)(h >> 16);
         a.out_len[slice] = fh + 3 + cSize;
+    }
+}
+
+// ---- frames of several blocks: one block of one slice ---------------------------------
+// libzstd 1.5.7 ZSTD_compress_frameChunk / ZSTD_compressBlock_internal for level 3.  The match kernel (block
+// mode) has parsed the block [ipos, ipos + blockSize); this writes the block (compressed / raw / RLE) behind the
+// frame bytes so far, carries repcodes and the Huffman table forward when the block came out compressed, and
+// chooses the size of the next block (the pre-splitter, zstd_preSplit.c "byChunks" at sampling rate 43).
+struct KFrameArgs {
+    const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
+    const KSeq* seqs; u32 seq_cap; u8* lits; u32 lit_cap; const KSliceMeta* meta;
+    u32* scratch; u32 scratch_words;
+    u8* dst; const u64* out_off; u32* out_len;
+    KFrameState* fstate; u32* hufct;         // per slice: state, two Huffman table slots of 256 words
+    u32* remaining;                          // frames not finished yet (decremented here)
+};
+
+// ZSTD_splitBlock_byChunks(level 0) on the 128 KiB at p: where the byte statistics change, in steps of 8 KiB.
+// Uses lds.hist (new chunk) and lds.ct (chunks so far).
+KX_DEV u32 kx_split_block(KEntropyLds& lds, const u8* p, int lane)
+{
+    u32 nbPast = 8191u / 43u; int penalty = 3; u32 result = KX_BLOCK_MAX;
+    for (int i = lane; i < 256; i += 64) lds.ct[i] = 0;
+    kx_sync();
+    for (u32 j = (u32)lane; j * 43u < 8191u; j += 64) kx_lds_inc(&lds.ct[p[j * 43u]]);
+    kx_sync();
+    for (u32 pos = 8192u; pos <= KX_BLOCK_MAX - 8192u; pos += 8192u) {
+        for (int i = lane; i < 256; i += 64) lds.hist[i] = 0;
+        kx_sync();
+        for (u32 j = (u32)lane; j * 43u < 8191u; j += 64) kx_lds_inc(&lds.hist[p[pos + j * 43u]]);
+        kx_sync();
+        u32 const nbNew = 8191u / 43u;
+        u32 dev = 0;
+        for (int i = lane; i < 256; i += 64) {
+            int const d = (int)(lds.ct[i] * nbNew) - (int)(lds.hist[i] * nbPast);
+            dev += (u32)(d < 0 ? -d : d);
+        }
+        dev = kx_wave_sum(dev, lane);
+        u32 const threshold = nbPast * nbNew * (u32)(14 + penalty) / 16u;
+        if (dev >= threshold) { result = pos; break; }
+        for (int i = lane; i < 256; i += 64) lds.ct[i] += lds.hist[i];
+        nbPast += nbNew;
+        if (penalty > 0) penalty--;
+        kx_sync();
+    }
+    kx_sync();
+    return result;
+}
+
+KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, int lane)
+{
+    KFrameState fs = a.fstate[slice];
+    if (fs.blockSize == 0) return;                       // frame finished in an earlier round
+    const u8* const src = a.src + a.in_off[slice];
+    u32 const n = a.in_len[slice];
+    u8* const dst = a.dst + a.out_off[slice];
+    u32* const hufct = a.hufct + (size_t)slice * 512u;
+    if (fs.ipos == 0) {
+        // frame header: single segment (the window covers the slice), content size
+        if (lane == 0) {
+            u32 const fcsCode = (n >= 256) + (n >= 65536 + 256);
+            kx_st32(dst, 0xFD2FB528u);
+            dst[4] = (u8)((1u << 5) + (fcsCode << 6));
+            if (fcsCode == 0) dst[5] = (u8)n;
+            else if (fcsCode == 1) kx_st16(dst + 5, n - 256);
+            else kx_st32(dst + 5, n);
+        }
+        fs.opos = kx_frame_header_size(n);
+    }
+    u32 const bs = fs.blockSize;
+    const u8* const bsrc = src + fs.ipos;
+    bool const lastBlock = fs.ipos + bs == n;
+    u8* const bh = dst + fs.opos; u8* const body = bh + 3;
+    u32 cSize = 0;
+    KSliceMeta mm; mm.nbSeq = 0; mm.litSize = 0; mm.lastLL = bs; mm.longType = 0; mm.longPos = 0; mm.status = 0; mm.pad[0] = fs.rep[0]; mm.pad[1] = fs.rep[1];
+    KHufPrev hp; hp.ct = hufct + 256u * fs.hufSel; hp.valid = fs.hufValid != 0; hp.newCt = hufct + 256u * (fs.hufSel ^ 1u); hp.outcome = 0;
+    if (bs >= 7) {                                       // MIN_CBLOCK_SIZE + block header + 1 + 1
+        mm = a.meta[slice];
+        const KSeq* const seqs = a.seqs + (size_t)slice * a.seq_cap;
+        u8* const lits = a.lits + (size_t)slice * a.lit_cap;
+        u32 const litSize = mm.litSize + mm.lastLL;
+        kx_gather_literals(lits, bsrc, bs, seqs, mm.nbSeq, mm.longType, mm.longPos, lane);
+        kx_wave_copy(lits + mm.litSize, bsrc + (bs - mm.lastLL), mm.lastLL, lane);
+        kx_sync();
+        bool const suspect = (mm.nbSeq == 0) || (litSize / mm.nbSeq >= 20);
+        u32 const litSec = kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane, &hp);
+        kx_sync();
+        u32 const seqSec = kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane);
+        if (seqSec != 0) {
+            cSize = litSec + seqSec;
+            if (cSize >= bs - kx_min_gain(bs)) cSize = 0;
+        }
+        // a block of one repeated byte becomes an RLE block, except the first block of a frame
+        if (!fs.first && mm.nbSeq < 4 && litSize < 10) {
+            u32 const b0 = bsrc[0]; bool diff = false;
+            for (u32 i = (u32)lane; i < bs; i += 64) diff |= bsrc[i] != b0;
+            if (!kx_any(diff)) cSize = 1;
+        }
+    }
+    kx_sync();
+    u32 outSize;
+    if (cSize == 0) {
+        kx_wave_copy(body, bsrc, bs, lane);
+        if (lane == 0) { u32 const h = (u32)lastBlock + (0u << 1) + (bs << 3); bh[0] = (u8)h; bh[1] = (u8)(h >> 8); bh[2] = (u8)(h >> 16); }
+        outSize = 3 + bs;
+    } else if (cSize == 1) {
+        if (lane == 0) { u32 const h = (u32)lastBlock + (1u << 1) + (bs << 3); bh[0] = (u8)h; bh[1] = (u8)(h >> 8); bh[2] = (u8)(h >> 16); body[0] = bsrc[0]; }
+        outSize = 3 + 1;
+    } else {
+        if (lane == 0) { u32 const h = (u32)lastBlock + (2u << 1) + (cSize << 3); bh[0] = (u8)h; bh[1] = (u8)(h >> 8); bh[2] = (u8)(h >> 16); }
+        outSize = 3 + cSize;
+        // ZSTD_blockState_confirmRepcodesAndEntropyTables
+        fs.rep[0] = mm.pad[0]; fs.rep[1] = mm.pad[1];
+        if (hp.outcome == 2) { fs.hufSel ^= 1u; fs.hufValid = 1; }
+    }
+    fs.savings += (int)bs - (int)outSize;
+    fs.ipos += bs; fs.opos += outSize; fs.first = 0;
+    // ZSTD_optimalBlockSize for the next block
+    u32 next = 0;
+    if (!lastBlock) {
+        u32 const remaining = n - fs.ipos;
+        if (remaining < KX_BLOCK_MAX) next = remaining;
+        else if (fs.savings < 3) next = KX_BLOCK_MAX;
+        else next = kx_split_block(lds, src + fs.ipos, lane);
+    }
+    fs.blockSize = next;
+    if (lane == 0) {
+        a.fstate[slice] = fs;
+        if (next == 0) { a.out_len[slice] = fs.opos; kx_atomic_add(a.remaining, 0xFFFFFFFFu); }
+    }
+}
+
+KX_DEV void zstd_frame_body(const KFrameArgs& a)
+{
+    KX_SHARED KEntropyLds lds;
+    int const lane = kx_lane();
+    for (u32 slice = kx_block(); slice < a.n_slices; slice += kx_nblocks()) {
+        zstd_frame_block(a, lds, slice, lane);
+        kx_sync();
+    }
+}
+
+// ---- a whole frame of several blocks by one wave ------------------------------------------------
+// Every block's size depends on the bytes the blocks before it produced, so a slice is a chain
+// split -> parse -> entropy-code -> split ...; slices are independent of each other.  One wave owns a slice
+// and walks the chain; the parse is the block-mode match body run by the wave's first team.
+// (kx_sync = wait for the wave's stores + barrier: what one step wrote to HBM is what the next one reads.)
+struct KBigArgs { KMatchArgs m; KFrameArgs e; u32* counters; u32 spw; };   // counters: one work-queue head per workgroup
+                                                                           // spw: slices per wave, 1 .. 64 / G
+
+template <int G>
+KX_DEV void zstd_big_body(const KBigArgs& a)
+{
+    KX_SHARED KEntropyLds lds;
+    int const lane = kx_lane();
+    u32 const spw = a.spw;
+    u32 const ngroups = (a.e.n_slices + spw - 1) / spw;
+    for (u32 grp = kx_block(); grp < ngroups; grp += kx_nblocks()) {
+        // this wave's slices: their blocks are parsed side by side (one team each), then coded one after the other
+        u32 const base = grp * spw;
+        u32 const cnt = (a.e.n_slices - base < spw) ? a.e.n_slices - base : spw;
+        KMatchArgs m = a.m;
+        m.in_off += base; m.in_len += base; m.n_slices = cnt;
+        m.seqs += (size_t)base * m.seq_cap; m.meta += base; m.fstate += base;
+        m.big_tables += (size_t)base * KX_BIG_TBL_ENTRIES;
+        m.counter = a.counters + kx_block();
+        for (u32 guard = 0; guard < KX_MAX_BIG_SLICE / 8192u + 4u; guard++) {
+            bool open = false;
+            for (u32 t = 0; t < cnt; t++) open |= a.e.fstate[base + t].blockSize != 0;
+            if (!open) break;
+            if (lane == 0) *m.counter = 0;
+            kx_sync();
+            zstd_match_body<G, true>(m);
+            kx_sync();
+            for (u32 t = 0; t < cnt; t++) { zstd_frame_block(a.e, lds, base + t, lane); kx_sync(); }
+        }
     }
 }
 

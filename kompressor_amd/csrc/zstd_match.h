@@ -33,6 +33,9 @@ struct KMatchArgs {
     u32 flags;                       // experiment switches: 1 = non-temporal table loads, 2 = non-temporal table stores,
                                      // 4 / 8 = also store / load a shadow table (cost probes; needs `shadow`)
     u32* shadow;                     // per team: KX_TBL_ENTRIES, or null
+    // block mode (frames of several blocks): one block of every unfinished slice per launch
+    const KFrameState* fstate;       // per slice
+    u32* big_tables;                 // per slice: KX_BIG_TBL_ENTRIES
 };
 
 enum { KST_IDLE = 0, KST_SEARCH = 1, KST_REPCHECK = 2, KST_MATCH = 3, KST_CLEANUP = 4, KST_DONE = 5 };
@@ -108,16 +111,21 @@ KX_DEV u32 kx_team_backward(bool act, const u8* src, int s, int m, int maxback, 
     return back;
 }
 
-template <int G>
+// BLK = false: every slice is one block (<= 128 KiB); tables per team, epoch-tagged.
+// BLK = true:  the block [ipos, ipos + blockSize) of every slice whose frame is unfinished; tables per slice
+//              (they persist from block to block), repcodes come from and go back to the frame state.
+template <int G, bool BLK = false>
 KX_DEV void zstd_match_body(const KMatchArgs& a)
 {
     constexpr int NT = 64 / G;
+    constexpr u32 IDXM = BLK ? 0xFFFFFFFFu : KX_IDX_MASK;
     int const lane = kx_lane();
     int const k = lane & (G - 1);
     int const tbase = lane - k;
     u32 const team = kx_block() * NT + (u32)(lane / G);
-    u32* const L = a.tables + (size_t)team * KX_TBL_ENTRIES;
-    u32* const S = L + KX_TBL_LONG;
+    u32* L = BLK ? a.big_tables : a.tables + (size_t)team * KX_TBL_ENTRIES;
+    u32* S = L + (BLK ? KX_BIG_TBL_LONG : KX_TBL_LONG);
+    int bstart = 0; u32 saved1 = 0, saved2 = 0;          // block mode: block start, repcodes set aside at block start
     u64 const tmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
 
     // ---- team state (uniform across the team's lanes) -------------------
@@ -141,7 +149,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             u32 s = 0, ep = 0;
             if (state == KST_IDLE && k == 0) {
                 s = kx_atomic_add(a.counter, 1u);
-                if (s < a.n_slices) {
+                if (!BLK && s < a.n_slices) {
                     ep = a.team_epoch[team] + 1;
                     if (ep > KX_EPOCH_MAX) ep = 0;          // 0 = "clear the tables, restart at 1"
                     a.team_epoch[team] = ep ? ep : 1u;
@@ -150,7 +158,27 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             s = kx_shfl(s, tbase); ep = kx_shfl(ep, tbase);
             if (state == KST_IDLE) {
                 if (s >= a.n_slices) state = KST_DONE;
-                else {
+                else if (BLK) {
+                    KFrameState const fs = a.fstate[s];
+                    if (fs.blockSize != 0) {           // else: frame finished, fetch the next slice
+                        slice = s;
+                        src = a.src + a.in_off[s];
+                        seqs = a.seqs + (size_t)s * a.seq_cap;
+                        L = a.big_tables + (size_t)s * KX_BIG_TBL_ENTRIES; S = L + KX_BIG_TBL_LONG;
+                        KParams const P = kx_params_l3(a.in_len[s]);
+                        hbL = P.hashLog; hbS = P.chainLog; mls = P.minMatch;
+                        nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = 0; tag = 0;
+                        bstart = (int)fs.ipos; n = bstart + (int)fs.blockSize;       // n = end of the block
+                        anchor = bstart; ilimit = n - 8;
+                        ip = bstart + (bstart == 0 ? 1 : 0);
+                        // repcodes longer than the history so far are set aside (ZSTD_compressBlock_doubleFast: offsetSaved)
+                        off1 = fs.rep[0]; off2 = fs.rep[1]; saved1 = 0; saved2 = 0;
+                        if (off2 > (u32)ip) { saved2 = off2; off2 = 0; }
+                        if (off1 > (u32)ip) { saved1 = off1; off1 = 0; }
+                        step = 1; nextStep = ip + 256; carry = false;
+                        state = (fs.blockSize < 8 || ip + 1 > ilimit) ? KST_CLEANUP : KST_SEARCH;
+                    }
+                } else {
                     slice = s;
                     src = a.src + a.in_off[s];
                     n = (int)a.in_len[s];
@@ -210,18 +238,24 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 else { if (!haveL) el = L[hl]; if (cand) es = S[hs]; }
                 if (a.flags & 8u) { shacc |= kx_ld_nt(&SH[hl]); if (cand) shacc |= kx_ld_nt(&SH[KX_TBL_LONG + hs]); }
             }
-            u32 idxl = ((el & ~KX_IDX_MASK) == tag) ? (el & KX_IDX_MASK) : 0u;
-            u32 idxs = ((es & ~KX_IDX_MASK) == tag) ? (es & KX_IDX_MASK) : 0u;
+            u32 idxl = ((el & ~IDXM) == tag) ? (el & IDXM) : 0u;
+            u32 idxs = ((es & ~IDXM) == tag) ? (es & IDXM) : 0u;
             if (srch && carry && k == 0) idxl = carry_idxl;
             // what lanes < k of this team would have inserted before lane k looks up
-            u32 const hpack = hl | (hs << 16);
+            u32 const hpack = hl | (hs << 16);       // hashLog <= 16 and chainLog <= 15 without BLK
             int predL = -1, predS = -1;
 #pragma unroll
             for (int d = 1; d < G; d++) {
-                u32 const hp = kx_shfl(hpack, lane - d);
                 bool const ok = prov && k >= d;
-                if (ok && predL < 0 && (hp & 0xFFFFu) == hl) predL = k - d;
-                if (ok && predS < 0 && (hp >> 16) == hs) predS = k - d;
+                if (BLK) {                           // hashLog 17 / chainLog 16: two shuffles
+                    u32 const pl = kx_shfl(hl, lane - d), ps = kx_shfl(hs, lane - d);
+                    if (ok && predL < 0 && pl == hl) predL = k - d;
+                    if (ok && predS < 0 && ps == hs) predS = k - d;
+                } else {
+                    u32 const hp = kx_shfl(hpack, lane - d);
+                    if (ok && predL < 0 && (hp & 0xFFFFu) == hl) predL = k - d;
+                    if (ok && predS < 0 && (hp >> 16) == hs) predS = k - d;
+                }
             }
             if (predL >= 0) idxl = (u32)(pos - (k - predL) * step) + 2u;
             if (predS >= 0) idxs = (u32)(pos - (k - predS) * step) + 2u;
@@ -362,6 +396,11 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     KSliceMeta mm;
                     mm.nbSeq = nseq; mm.litSize = nlit; mm.lastLL = (u32)(n - anchor);
                     mm.longType = longType; mm.longPos = longPos; mm.status = status | (shacc == 0xFFFFFFFFu ? 4u : 0u); mm.pad[0] = 0; mm.pad[1] = 0;
+                    if (BLK) {
+                        // repcodes this block leaves behind (taken over by the frame only if the block is emitted compressed)
+                        u32 const s2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;
+                        mm.pad[0] = off1 ? off1 : saved1; mm.pad[1] = off2 ? off2 : s2;
+                    }
                     a.meta[slice] = mm;
                 }
                 state = KST_IDLE;

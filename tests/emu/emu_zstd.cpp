@@ -16,7 +16,7 @@ int emu_zstd_match(const u8* src, const u64* in_off, const u32* in_len, u32 n, i
     KMatchArgs a;
     a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
     a.seqs = seqs; a.seq_cap = seq_cap; a.meta = meta;
-    a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter; a.flags = 0; a.shadow = nullptr;
+    a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter; a.flags = 0; a.shadow = nullptr; a.fstate = nullptr; a.big_tables = nullptr;
     kxemu::failed = 0;
     switch (G) {
     case 2:  kxemu::launch(nblocks, [&]() { zstd_match_body<2>(a); }); break;
@@ -53,6 +53,78 @@ int emu_zstd_compress(const u8* src, const u64* in_off, const u32* in_len, u32 n
     kxemu::failed = 0;
     kxemu::launch(nblocks, [&]() { zstd_entropy_body(e); });
     return kxemu::failed ? -1 : 0;
+}
+
+// Frames of several blocks (slices above 128 KiB): the host-side round loop of kmp_api.hip restated for the emulator.
+extern "C" __attribute__((visibility("default")))
+int emu_zstd_compress_big(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
+                          u8* dst, const u64* out_off, u32* out_len, u32* rounds_out)
+{
+    u32 const block_cap = 128u * 1024u;
+    u32 const seq_cap = (block_cap / 4 + 8 + 15) & ~15u, lit_cap = block_cap + 64, scratch_words = block_cap / 4 + 64;
+    std::vector<KSeq> seqs((size_t)n * seq_cap);
+    std::vector<u8> lits((size_t)n * lit_cap, 0xEE);
+    std::vector<KSliceMeta> meta(n);
+    std::vector<u32> scratch((size_t)n * scratch_words, 0xA5A5A5A5u);
+    std::vector<KFrameState> fstate(n);
+    std::vector<u32> hufct((size_t)n * 512, 0xDEADBEEFu);
+    std::vector<u32> big_tables((size_t)n * KX_BIG_TBL_ENTRIES, 0u);
+    u32 remaining = 0, counter = 0;
+    for (u32 i = 0; i < n; i++) {
+        KFrameState s; memset(&s, 0, sizeof(s));
+        s.blockSize = in_len[i] < KX_BLOCK_MAX ? in_len[i] : KX_BLOCK_MAX; s.first = 1; s.rep[0] = 1; s.rep[1] = 4; s.rep[2] = 8;
+        fstate[i] = s;
+        if (in_len[i] == 0) { u8* d = dst + out_off[i]; u32 const magic = 0xFD2FB528u; memcpy(d, &magic, 4); d[4] = 0x20; d[5] = 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
+        else remaining++;
+    }
+    KMatchArgs m;
+    m.src = src; m.in_off = in_off; m.in_len = in_len; m.n_slices = n;
+    m.seqs = seqs.data(); m.seq_cap = seq_cap; m.meta = meta.data();
+    m.tables = nullptr; m.team_epoch = nullptr; m.counter = &counter; m.flags = 0; m.shadow = nullptr;
+    m.fstate = fstate.data(); m.big_tables = big_tables.data();
+    KFrameArgs e;
+    e.src = src; e.in_off = in_off; e.in_len = in_len; e.n_slices = n;
+    e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
+    e.scratch = scratch.data(); e.scratch_words = scratch_words;
+    e.dst = dst; e.out_off = out_off; e.out_len = out_len;
+    e.fstate = fstate.data(); e.hufct = hufct.data(); e.remaining = &remaining;
+    if (!rounds_out) {
+        // product path: one wave per slice walks its chain of blocks
+        std::vector<u32> counters(nblocks, 0u);
+        KBigArgs g; g.m = m; g.e = e; g.counters = counters.data(); g.spw = (n > 2 && 64 / G >= 2) ? 2 : 1;
+        kxemu::failed = 0;
+        switch (G) {
+        case 2:  kxemu::launch(nblocks, [&]() { zstd_big_body<2>(g); }); break;
+        case 4:  kxemu::launch(nblocks, [&]() { zstd_big_body<4>(g); }); break;
+        case 8:  kxemu::launch(nblocks, [&]() { zstd_big_body<8>(g); }); break;
+        case 16: kxemu::launch(nblocks, [&]() { zstd_big_body<16>(g); }); break;
+        case 32: kxemu::launch(nblocks, [&]() { zstd_big_body<32>(g); }); break;
+        case 64: kxemu::launch(nblocks, [&]() { zstd_big_body<64>(g); }); break;
+        default: return -2;
+        }
+        if (kxemu::failed) return -1;
+        return remaining == 0 ? 0 : -5;
+    }
+    u32 rounds = 0;
+    while (remaining != 0) {
+        if (++rounds > 300) return -4;
+        counter = 0; kxemu::failed = 0;
+        switch (G) {
+        case 2:  kxemu::launch(nblocks, [&]() { zstd_match_body<2, true>(m); }); break;
+        case 4:  kxemu::launch(nblocks, [&]() { zstd_match_body<4, true>(m); }); break;
+        case 8:  kxemu::launch(nblocks, [&]() { zstd_match_body<8, true>(m); }); break;
+        case 16: kxemu::launch(nblocks, [&]() { zstd_match_body<16, true>(m); }); break;
+        case 32: kxemu::launch(nblocks, [&]() { zstd_match_body<32, true>(m); }); break;
+        case 64: kxemu::launch(nblocks, [&]() { zstd_match_body<64, true>(m); }); break;
+        default: return -2;
+        }
+        if (kxemu::failed) return -1;
+        for (u32 i = 0; i < n; i++) if (fstate[i].blockSize >= 8 && meta[i].status) return -3;
+        kxemu::launch(nblocks, [&]() { zstd_frame_body(e); });
+        if (kxemu::failed) return -1;
+    }
+    if (rounds_out) *rounds_out = rounds;
+    return 0;
 }
 
 #include "zstd_decode.h"

@@ -88,3 +88,28 @@ def test_emulated_roundtrip_property():
     frames = helpers.emu_compress(datas, G=8)
     outs, st = helpers.emu_decompress(frames, [S] * 8)
     assert st == [0] * 8 and outs == datas
+
+
+def test_emulated_multiblock_frames():
+    """Frames of several blocks (slices above 128 KiB) against the libzstd 1.5.7 goldens: block-mode match kernel
+    + frame kernel; a few of the smaller vectors keep the CPU suite short (the GPU suite runs all of them)."""
+    rows = helpers.multiblock_golden()["rows"]
+    inputs = helpers.multiblock_inputs()
+    pick = [i for i, (name, d) in enumerate(inputs) if name in ("zeros_300k", "run_128k_plus_5", "text_256k_plus_3",
+                                                                  "mixed_1_300000", "mixed_17_262145", "mixed_7_140000")]
+    assert len(pick) == 6
+    frames, _ = helpers.emu_compress_big([inputs[i][1] for i in pick], G=16)
+    for i, f in zip(pick, frames):
+        assert len(f) == rows[i]["len"] and helpers.sha256(f) == rows[i]["sha256"], inputs[i][0]
+    # the same steps as separate launches per round of blocks (the experiment switch of the library)
+    frames, rounds = helpers.emu_compress_big([inputs[i][1] for i in pick[:3]], G=8, by_rounds=True)
+    for i, f in zip(pick, frames):
+        assert helpers.sha256(f) == rows[i]["sha256"], inputs[i][0]
+    assert rounds >= 3
+    # another team width, and small slices through the block path give the single-block frames
+    o = helpers.oracle()
+    small = [corpus.make(88000 + k, 1, s).tobytes() for k, s in enumerate([0, 5, 7, 8, 300, 20000])]
+    frames, _ = helpers.emu_compress_big(small + [inputs[pick[-1]][1]], G=4)
+    for d, f in zip(small, frames):
+        assert f == o.compress(d), len(d)
+    assert helpers.sha256(frames[-1]) == rows[pick[-1]]["sha256"]

@@ -220,5 +220,49 @@ def test_streaming_abi_one_shot_like_the_reference(G):
         ZstdCompressor(compression_level=19)
     with pytest.raises(RuntimeError, match="Unknown frame descriptor"):
         ZstdDecompressor().transform_bytes(b"\x00" * 32)
+    # sampleRoundtrip (ZstdTest.kt:27-32): 1 MiB + 3 random bytes -> frame of several blocks, and back
+    big = np.random.default_rng(2).integers(0, 256, (1 << 20) + 3, dtype=np.uint8).tobytes()
+    c2 = ZstdCompressor(3)
+    fb = c2.transform_bytes(big)
+    assert fb == helpers.oracle().compress(big) and ZstdDecompressor().transform_bytes(fb) == big
+    txt = corpus.make(4242, 1, 700001, mix=ord("T")).tobytes()
+    ft = c2.transform_bytes(txt)                                  # the context grows its staging once, then is reused
+    assert ft == helpers.oracle().compress(txt) and ZstdDecompressor().transform_bytes(ft) == txt
+    assert c2.transform_bytes(sp["hello"]) == base64.b64decode(byname["hello"]["frame"])
     with pytest.raises(RuntimeError, match="Src size is incorrect"):
-        ZstdCompressor(3).transform_bytes(bytes(131073))          # multi-block slices: next round
+        ZstdCompressor(3).transform_bytes(bytes((2 << 20) + 1))   # above 2 MiB the level-3 window would slide: CPU library
+
+
+def test_multiblock_frames_match_libzstd():
+    """Slices above 128 KiB: frames of several blocks, bit-identical to libzstd 1.5.7 -- block
+    pre-splitter, repcodes / Huffman table carried between blocks, raw, RLE and treeless-literals blocks --
+    and back through the GPU decoder."""
+    from kompressor_amd.batch import ZstdBatch
+    rows = helpers.multiblock_golden()["rows"]
+    inputs = helpers.multiblock_inputs()
+    datas = [d for _, d in inputs]
+    # small slices through the same context: the block path must produce the single-block frames too
+    small = [corpus.make(77000 + k, 1, s).tobytes() for k, s in enumerate([0, 1, 7, 300, 65536, 131072])]
+    o = helpers.oracle()
+    b = ZstdBatch(max_slices=len(datas) + len(small), max_slice_bytes=2 << 20)
+    try:
+        frames = gpu_compress(b, datas + small)
+        for (name, d), row, f in zip(inputs, rows, frames):
+            assert len(f) == row["len"] and helpers.sha256(f) == row["sha256"], name
+        for d, f in zip(small, frames[len(datas):]):
+            assert f == o.compress(d), len(d)
+        # several slices per wave, and the same steps as separate launches per round of blocks (experiment switches)
+        import os
+        for key, val in (("KMP_BIG_SLICES_PER_WAVE", "4"), ("KMP_BIG_ROUNDS", "1")):
+            os.environ[key] = val
+            try:
+                again = gpu_compress(b, datas + small)
+            finally:
+                del os.environ[key]
+            assert again == frames, key
+        assert b.lib.kmp_batch_last_rounds(b._h) >= 16
+        back, st = gpu_decompress(b, frames, [max(len(d), 1) for d in datas + small])
+        assert st == [0] * len(frames)
+        assert back == datas + small
+    finally:
+        b.close()
