@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof/ (written on the GPU box by tools/profile_round.sh: rocprofv3 result databases + bench lines)
+into profiles/<name>.txt and profiles/pmc_latest.json.
+
+    python tools/summarize_profiles.py r01_final
+"""
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "gpurun_out", "prof")
+
+
+def top(db, limit=6):
+    rows = sqlite3.connect(db).execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()
+    out = ["Name,Calls,TotalDurationUs,AverageUs,Percentage"]
+    for name, calls, tot, avg, pct in rows[:limit]:
+        if len(name) > 90:
+            name = name[:87] + "..."
+        out.append(f"{name},{calls},{tot:.1f},{avg:.1f},{pct:.2f}")
+    return out
+
+
+def counters(db):
+    rows = sqlite3.connect(db).execute(
+        "select kernel_name,counter_name,sum(value),count(*) from counters_collection group by kernel_name,counter_name").fetchall()
+    return [(k, c, v, n) for k, c, v, n in rows if k.startswith("void k_") or k.startswith("k_")]
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+    lines = [f"# {name}: MI355X, 1 GPU; collected on the GPU box by tools/profile_round.sh, summarised by tools/summarize_profiles.py.",
+             "# Durations in microseconds (rocprofv3 --kernel-trace --stats, result database view top_kernels).", ""]
+    runs = [("compress", "python3 bench.py --steps 5 --warmup 1      (compress, BASELINE configs[1])"),
+            ("decompress", "python3 bench.py --mode decompress --steps 3 --warmup 1 --no-cpu   (configs[2]; the frames are compressed first)"),
+            ("deflate", "python3 bench.py --mode deflate --steps 1 --warmup 0 --slices 16384   (configs[4], one workspace chunk)"),
+            ("big1m", "python3 bench.py --slice-kib 1024 --slices 8192 --steps 2 --warmup 1   (north_star slice-size sweep: 1 MiB slices, frames of several blocks)")]
+    for key, cmd in runs:
+        db = os.path.join(P, key, "run_results.db")
+        if not os.path.exists(db):
+            continue
+        lines.append(f"## rocprofv3 --kernel-trace --stats -- {cmd}")
+        lines += top(db)
+        lines.append("bench line of the same run:")
+        lines.append(open(os.path.join(P, key + ".json")).read().strip())
+        lines.append("")
+    lines.append("## PMC passes (each its own run: rocprofv3 --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu); sums over the launches of a kernel")
+    allc = {}
+    for d in sorted(os.listdir(P)):
+        db = os.path.join(P, d, "run_results.db")
+        if d.startswith("pmc_") and os.path.exists(db):
+            for k, c, v, n in counters(db):
+                allc[(k, c)] = (v, n)
+                lines.append(f"{k:40s} {c:24s} {v:.6g}   ({n} launches)")
+    open(os.path.join(ROOT, "profiles", name + ".txt"), "w").write("\n".join(lines) + "\n")
+    mk = [k for (k, c) in allc if "k_zstd_match" in k and c == "FETCH_SIZE"]
+    if mk:
+        k = mk[0]
+        fetch, nl = allc[(k, "FETCH_SIZE")]
+        write, _ = allc[(k, "WRITE_SIZE")]
+        line = json.loads(open(os.path.join(P, "compress.json")).read())
+        pj = {"source": f"profiles/{name}.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, bench.py --steps 1)",
+              "slices": line["config"]["slices_per_gpu"], "team": line["config"]["team_lanes"], "launches": nl,
+              "zstd_match_fetch_kib": fetch, "zstd_match_write_kib": write,
+              "zstd_match_hbm_bytes_per_launch": int((fetch + write) * 1024 / nl),
+              "note": "(FETCH_SIZE+WRITE_SIZE)*1024 / launches; the guide's x2 correction for wide coalesced reads is not applied: "
+                      "this kernel's reads are scattered 4- and 8-byte probes (TCC_EA0_RDREQ_32B = 0, RDREQ*64 = FETCH_SIZE)"}
+        json.dump(pj, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+    print("\n".join(lines[:60]))
+
+
+if __name__ == "__main__":
+    main()
