@@ -799,7 +799,9 @@ KX_DEV void kx_cbuf_put(u32* cbuf, u32 pos, u32 v, u32 n)
 }
 
 // sequences section at dst; returns size, 0 => "emit a raw block instead"
-KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSeq, u32 longType, u32 longPos, int lane)
+// `cap`: bytes the section may take before the block is certain to be emitted raw (block size minus the literals
+// section): the writer stops there, so a pathological block can never run past the slice's output room.
+KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSeq, u32 longType, u32 longPos, int lane, u32 cap)
 {
     u32 hdr = 0;
     if (lane == 0) {
@@ -884,6 +886,7 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { u32 const t = kx_shfl(v, lane - o); if (lane >= o) v += t; }
         u32 const total = kx_shfl(v, 63);
+        if ((u32)(streamStart - dst) + ((bitpos + total) >> 3) >= cap) return 0;            // larger than the block: raw block for certain
         u32 pos = (bitpos & 31u) + (v - mybits);
         if (valid) {
             // order inside a sequence: OF state, ML state, LL state, LL extra, ML extra, OF extra
@@ -1000,7 +1003,7 @@ KX_DEV void zstd_entropy_slice(const KEntropyArgs& a, KEntropyLds& lds, u32 slic
         bool const suspect = (mm.nbSeq == 0) || (litSize / mm.nbSeq >= 20);
         u32 const litSec = kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane);
         kx_sync();
-        u32 const seqSec = kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane);
+        u32 const seqSec = kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < n ? n - litSec : 0u);
         if (seqSec != 0) {
             cSize = litSec + seqSec;
             if (cSize >= n - kx_min_gain(n)) cSize = 0;
@@ -1100,7 +1103,7 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
         bool const suspect = (mm.nbSeq == 0) || (litSize / mm.nbSeq >= 20);
         u32 const litSec = kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane, &hp);
         kx_sync();
-        u32 const seqSec = kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane);
+        u32 const seqSec = kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < bs ? bs - litSec : 0u);
         if (seqSec != 0) {
             cSize = litSec + seqSec;
             if (cSize >= bs - kx_min_gain(bs)) cSize = 0;
