@@ -110,7 +110,7 @@ struct kmp_batch_ctx {
     KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* shadow; u32* team_epoch; u32* counter;
     int profiling; hipEvent_t ev[14]; int ev_valid[7];
     // zstd compress pipeline: entropy coding of chunk i (second stream) runs beside the match kernel of chunk i+1
-    hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join; u32 last_chunks;
+    hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join, ev_last_match; int have_last_match; u32 last_chunks;
     // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
     u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta;
     // frames of several blocks (max_slice_bytes above 128 KiB): per-slice state carried between the block rounds
@@ -173,6 +173,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     HIP_TRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { HIP_TRY(hipEventCreate(&c->evm[i][j])); HIP_TRY(hipEventCreate(&c->eve[i][j])); }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_last_match, hipEventDisableTiming));
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return KMP_OK;
@@ -188,6 +189,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { if (c->evm[i][j]) (void)hipEventDestroy(c->evm[i][j]); if (c->eve[i][j]) (void)hipEventDestroy(c->eve[i][j]); }
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_last_match) (void)hipEventDestroy(c->ev_last_match);
     if (c->st2) (void)hipStreamDestroy(c->st2);
     (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta);
     delete c;
@@ -306,6 +308,9 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     // chunk i (latency bound) on a second stream; the caller's stream sees everything finished.
     u32 chunks = env_u32("KMP_ZSTD_CHUNKS", n >= 32768u ? 2u : 1u);
     if (chunks < 1) chunks = 1; if (chunks > KMP_MAX_CHUNKS) chunks = KMP_MAX_CHUNKS; if (chunks > n) chunks = 1;
+    // Batches may be queued on alternating caller streams: the match kernels of consecutive batches share the team
+    // tables and run in order, but a batch's last entropy launch no longer holds up the next batch's match kernel.
+    if (c->have_last_match) HIP_TRY(hipStreamWaitEvent(st, c->ev_last_match, 0));
     HIP_TRY(hipMemsetAsync(c->counter, 0, 4 * KMP_MAX_CHUNKS, st));
     u32 const tpw = 64 / (u32)c->G;
     u32 const match_flags = env_u32("KMP_MATCH_FLAGS", 2), entropy_pad = env_u32("KMP_ENTROPY_PAD_LDS", 0);   // experiments only
@@ -329,6 +334,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->evm[ci][1], st));
+        if (ci + 1 == chunks) { HIP_TRY(hipEventRecord(c->ev_last_match, st)); c->have_last_match = 1; }
         KEntropyArgs e;
         e.src = (const u8*)d_src; e.in_off = d_in_off + first; e.in_len = d_in_len + first; e.n_slices = m_n;
         e.seqs = m.seqs; e.seq_cap = c->seq_cap; e.lits = c->lits + (size_t)first * c->lit_cap; e.lit_cap = c->lit_cap; e.meta = m.meta;
