@@ -107,7 +107,7 @@ enum { KMP_MAX_CHUNKS = 4 };
 struct kmp_batch_ctx {
     int device; u32 max_slices, max_slice_bytes; int G; u32 match_blocks, nteams;
     u32 seq_cap, lit_cap, scratch_words;
-    KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* shadow; u32* team_epoch; u32* counter;
+    KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* team_epoch; u32* counter;
     int profiling; hipEvent_t ev[14]; int ev_valid[7];
     // zstd compress pipeline: entropy coding of chunk i (second stream) runs beside the match kernel of chunk i+1
     hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join, ev_last_match; int have_last_match; u32 last_chunks;
@@ -160,11 +160,6 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     HIP_TRY(hipMalloc((void**)&c->scratch, ns * c->scratch_words * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->tables, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->team_epoch, (size_t)c->nteams * sizeof(u32)));
-    c->shadow = nullptr;
-    if (env_u32("KMP_MATCH_FLAGS", 2) & 12u) {     // cost-probe experiment only
-        HIP_TRY(hipMalloc((void**)&c->shadow, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
-        HIP_TRY(hipMemset(c->shadow, 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
-    }
     HIP_TRY(hipMalloc((void**)&c->counter, 64));
     HIP_TRY(hipMemset(c->tables, 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
     HIP_TRY(hipMemset(c->team_epoch, 0, (size_t)c->nteams * sizeof(u32)));
@@ -184,7 +179,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch);
-    (void)hipFree(c->tables); (void)hipFree(c->shadow); (void)hipFree(c->team_epoch);
+    (void)hipFree(c->tables); (void)hipFree(c->team_epoch);
     (void)hipFree(c->fstate); (void)hipFree(c->hufct); (void)hipFree(c->big_tables); (void)hipFree(c->remaining); (void)hipFree(c->big_counters); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { if (c->evm[i][j]) (void)hipEventDestroy(c->evm[i][j]); if (c->eve[i][j]) (void)hipEventDestroy(c->eve[i][j]); }
@@ -236,7 +231,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     KMatchArgs m;
     m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
     m.seqs = c->seqs; m.seq_cap = c->seq_cap; m.meta = c->meta;
-    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter; m.flags = 2; m.shadow = nullptr;
+    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter; m.flags = 2;
     m.fstate = c->fstate; m.big_tables = c->big_tables;
     KFrameArgs e;
     e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = d_in_len; e.n_slices = n;
@@ -321,7 +316,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         KMatchArgs m;
         m.src = (const u8*)d_src; m.in_off = d_in_off + first; m.in_len = d_in_len + first; m.n_slices = m_n;
         m.seqs = c->seqs + (size_t)first * c->seq_cap; m.seq_cap = c->seq_cap; m.meta = c->meta + first;
-        m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter + ci; m.flags = match_flags; m.shadow = c->shadow;
+        m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter + ci; m.flags = match_flags;
         u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
         if (c->profiling) HIP_TRY(hipEventRecord(c->evm[ci][0], st));
         switch (c->G) {

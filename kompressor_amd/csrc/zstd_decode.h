@@ -27,28 +27,29 @@ enum { KZE_GENERIC = 1, KZE_PREFIX = 10, KZE_FRAMEPARAM = 14, KZE_WINDOW = 16, K
        KZE_LITHDR = 24, KZE_DICT = 32, KZE_DSTSMALL = 70, KZE_SRCSIZE = 72 };
 
 struct KDecodeLds {
-    union {                     // phase-shared region (4 KiB)
+    union {                     // phase-shared region: the phases of a block never overlap in time
         u16 huf[2048];          // literal phase: Huffman decoding table (depth <= 11, RFC 8878): symbol | nbBits << 8
-        struct {                // table construction (weights' FSE table, spread scratch)
-            u32 tmp32[512];
-            u8 tsym[512];
+        struct {                // Huffman table description: the weights' FSE table (tableLog <= 6) + spread scratch
+            u16 wb[64]; u8 wc[64]; u8 tsym[64];
         } b;
         struct {                // sequence phase
-            u32 sbuf[512];      // staged words of the sequence bitstream (2 zero words + 510)
+            u16 fb[1280];       // FSE decoding tables LL [0,512) ML [512,1024) OF [1024,1280): newStateBase | nbBits << 12
+            u8 fc[1280];        //   ... and the symbol (code) of each state
+            u32 sbuf[256];      // staged words of the sequence bitstream (2 zero words + 254); also the spread scratch
             u32 stage[194];     // 64 x (litLength, matchLength, offset) + error flag
         } q;
     } u;
-    u32 fseLL[512];             // sequence decoding tables: newStateBase | nbBits << 16 | code << 24
-    u32 fseML[512];
-    u32 fseOF[256];
     u32 llx[36];                // per code: baseValue | extraBits << 24
     u32 mlx[53];
     short norm[64];
     u16 symnext[64];
     u8 weights[256];            // kept so a tree-less block can rebuild the Huffman table
+    // what a later block's "repeat" mode needs to rebuild a sequence table (they share LDS with the Huffman table):
+    short keepNorm[3][64]; u32 keepKind[3], keepLog[3], keepMax[3];      // kind 0 none, 1 RLE (symbol in keepMax), 2 FSE counts
     u32 rank[16];
     u32 bc[16];                 // lane 0 -> wave broadcast slots
 };
+enum { KXD_LL0 = 0, KXD_ML0 = 512, KXD_OF0 = 1024 };
 
 // ---- forward (LSB-first) bit reader over bytes, for table descriptions ----
 struct KFwdBits { const u8* p; u32 size; u32 bit; };
@@ -99,8 +100,8 @@ KX_DEV u32 kfse_read_ncount(short* norm, u32* maxSymbolValuePtr, u32* tableLogPt
     return used;
 }
 
-// FSE decoding table: entry = newStateBase | nbBits << 16 | symbol << 24
-KX_DEV void kfse_build_dtable(u32* dt, const short* norm, u32 maxSymbolValue, u32 tableLog, u16* symnext, u8* tsym)
+// FSE decoding table: db[state] = newStateBase | nbBits << 12, dc[state] = symbol
+KX_DEV void kfse_build_dtable(u16* db, u8* dc, const short* norm, u32 maxSymbolValue, u32 tableLog, u16* symnext, u8* tsym)
 {
     u32 const tableSize = 1u << tableLog, mask = tableSize - 1;
     u32 const step = (tableSize >> 1) + (tableSize >> 3) + 3;
@@ -120,7 +121,7 @@ KX_DEV void kfse_build_dtable(u32* dt, const short* norm, u32 maxSymbolValue, u3
     for (u32 u = 0; u < tableSize; u++) {
         u32 const s = tsym[u]; u32 const next = symnext[s]++;
         u32 const nb = tableLog - kx_hb32(next);
-        dt[u] = (((next << nb) - tableSize) & 0xFFFFu) | (nb << 16) | (s << 24);
+        db[u] = (u16)((((next << nb) - tableSize) & 0xFFFu) | (nb << 12)); dc[u] = (u8)s;
     }
 }
 
@@ -183,7 +184,7 @@ KX_DEV u32 khuf_read_dtable(KDecodeLds& lds, const u8* p, u32 size, u32* tableLo
         u32 maxSV = 12, tl = 0;
         u32 const h = kfse_read_ncount(lds.norm, &maxSV, &tl, p + 1, hb, 6);
         if (h == 0 || maxSV > 12) return 0;
-        kfse_build_dtable(lds.u.b.tmp32, lds.norm, maxSV, tl, lds.symnext, lds.u.b.tsym);
+        kfse_build_dtable(lds.u.b.wb, lds.u.b.wc, lds.norm, maxSV, tl, lds.symnext, lds.u.b.tsym);
         KBackBits b;
         if (!kbb_init(b, p + 1 + h, hb - h)) return 0;
         if (b.bits < (int)(2 * tl)) return 0;
@@ -191,17 +192,17 @@ KX_DEV u32 khuf_read_dtable(KDecodeLds& lds, const u8* p, u32 size, u32* tableLo
         u32 s2 = kbb_peek(b, tl); b.bits -= (int)tl;
         for (;;) {
             if (nw >= 255) return 0;
-            u32 const e1 = lds.u.b.tmp32[s1];
-            lds.weights[nw++] = (u8)(e1 >> 24);
-            u32 const nb1 = (e1 >> 16) & 0xFF;
-            if (b.bits < (int)nb1) { if (nw >= 255) return 0; lds.weights[nw++] = (u8)(lds.u.b.tmp32[s2] >> 24); break; }
-            s1 = (e1 & 0xFFFFu) + kbb_peek(b, nb1); b.bits -= (int)nb1;
+            u32 const e1 = lds.u.b.wb[s1];
+            lds.weights[nw++] = lds.u.b.wc[s1];
+            u32 const nb1 = e1 >> 12;
+            if (b.bits < (int)nb1) { if (nw >= 255) return 0; lds.weights[nw++] = lds.u.b.wc[s2]; break; }
+            s1 = (e1 & 0xFFFu) + kbb_peek(b, nb1); b.bits -= (int)nb1;
             if (nw >= 255) return 0;
-            u32 const e2 = lds.u.b.tmp32[s2];
-            lds.weights[nw++] = (u8)(e2 >> 24);
-            u32 const nb2 = (e2 >> 16) & 0xFF;
-            if (b.bits < (int)nb2) { if (nw >= 255) return 0; lds.weights[nw++] = (u8)(lds.u.b.tmp32[s1] >> 24); break; }
-            s2 = (e2 & 0xFFFFu) + kbb_peek(b, nb2); b.bits -= (int)nb2;
+            u32 const e2 = lds.u.b.wb[s2];
+            lds.weights[nw++] = lds.u.b.wc[s2];
+            u32 const nb2 = e2 >> 12;
+            if (b.bits < (int)nb2) { if (nw >= 255) return 0; lds.weights[nw++] = lds.u.b.wc[s1]; break; }
+            s2 = (e2 & 0xFFFu) + kbb_peek(b, nb2); b.bits -= (int)nb2;
         }
     }
     // last weight is implied: total must complete a power of two
@@ -297,12 +298,13 @@ KX_DEV u32 kxd_ml_bits(u32 c)
     return ML_bits[c];
 }
 
-KX_DEV u32* kxd_seq_dst(KDecodeLds& lds, int t) { return t == 0 ? lds.fseLL : t == 1 ? lds.fseOF : lds.fseML; }
+KX_DEV int kxd_seq_base(int t) { return t == 0 ? KXD_LL0 : t == 1 ? KXD_OF0 : KXD_ML0; }
 
-// lane 0: read one symbol type's table description and build its decoding table (mode 3
-// keeps the previous one). Returns bytes consumed, KXD_FAIL on error.
+// lane 0: read one symbol type's table description and build its decoding table in lds.u.q (the region is shared
+// with the Huffman table, so every block builds its tables; "repeat" rebuilds from what the last table was made of).
+// Returns bytes consumed, KXD_FAIL on error.
 #define KXD_FAIL 0xFFFFFFFFu
-KX_DEV u32 kxd_seq_table(KDecodeLds& lds, int t, u32 mode, const u8* p, u32 size, u32* tableLog, bool* valid)
+KX_DEV u32 kxd_seq_table(KDecodeLds& lds, int t, u32 mode, const u8* p, u32 size, u32* tableLog)
 {
     static const short LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2, 2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
     static const short ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,
@@ -310,29 +312,29 @@ KX_DEV u32 kxd_seq_table(KDecodeLds& lds, int t, u32 mode, const u8* p, u32 size
     static const short OF_defaultNorm[29] = { 1,1,1,1,1,1,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, -1,-1,-1,-1,-1 };
     u32 const maxSym = (t == 0) ? 35 : (t == 1) ? 31 : 52;
     u32 const maxLog = (t == 0) ? 9 : (t == 1) ? 8 : 9;
+    u16* const db = lds.u.q.fb + kxd_seq_base(t); u8* const dc = lds.u.q.fc + kxd_seq_base(t);
+    u8* const spread = (u8*)lds.u.q.sbuf;               // free until the bitstream is staged
+    u32 used = 0;
     if (mode == 0) {
         const short* dn = (t == 0) ? LL_defaultNorm : (t == 1) ? OF_defaultNorm : ML_defaultNorm;
         u32 const dmax = (t == 0) ? 35 : (t == 1) ? 28 : 52; u32 const dlog = (t == 1) ? 5 : 6;
-        for (u32 s = 0; s <= dmax; s++) lds.norm[s] = dn[s];
-        kfse_build_dtable(kxd_seq_dst(lds, t), lds.norm, dmax, dlog, lds.symnext, lds.u.b.tsym);
-        *tableLog = dlog; *valid = true;
-        return 0;
-    }
-    if (mode == 1) {
+        for (u32 s = 0; s <= dmax; s++) lds.keepNorm[t][s] = dn[s];
+        lds.keepKind[t] = 2; lds.keepLog[t] = dlog; lds.keepMax[t] = dmax;
+    } else if (mode == 1) {
         if (size < 1 || p[0] > maxSym) return KXD_FAIL;
-        kxd_seq_dst(lds, t)[0] = (u32)p[0] << 24;          // nbBits 0, next state 0
-        *tableLog = 0; *valid = true;
-        return 1;
-    }
-    if (mode == 2) {
+        lds.keepKind[t] = 1; lds.keepLog[t] = 0; lds.keepMax[t] = p[0];
+        used = 1;
+    } else if (mode == 2) {
         u32 maxSV = maxSym, tl = 0;
-        u32 const h = kfse_read_ncount(lds.norm, &maxSV, &tl, p, size, maxLog);
-        if (h == 0) return KXD_FAIL;
-        kfse_build_dtable(kxd_seq_dst(lds, t), lds.norm, maxSV, tl, lds.symnext, lds.u.b.tsym);
-        *tableLog = tl; *valid = true;
-        return h;
-    }
-    return *valid ? 0 : KXD_FAIL;                // repeat
+        u32 const h = kfse_read_ncount(lds.keepNorm[t], &maxSV, &tl, p, size, maxLog);
+        if (h == 0) { lds.keepKind[t] = 0; return KXD_FAIL; }
+        lds.keepKind[t] = 2; lds.keepLog[t] = tl; lds.keepMax[t] = maxSV;
+        used = h;
+    } else if (lds.keepKind[t] == 0) return KXD_FAIL;    // repeat without a previous table
+    if (lds.keepKind[t] == 1) { db[0] = 0; dc[0] = (u8)lds.keepMax[t]; }          // nbBits 0, next state 0
+    else kfse_build_dtable(db, dc, lds.keepNorm[t], lds.keepMax[t], lds.keepLog[t], lds.symnext, spread);
+    *tableLog = lds.keepLog[t];
+    return used;
 }
 
 KX_DEV void kxd_wave_copy(u8* dst, const u8* src, u32 n, int lane)
@@ -391,7 +393,9 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
     u32 op = 0;                       // bytes produced
     u32 rep1 = 1, rep2 = 4, rep3 = 8;
     u32 hufLog = 0, hufNw = 0; bool hufValid = false;
-    u32 tlLL = 0, tlOF = 0, tlML = 0; bool vLL = false, vOF = false, vML = false;
+    u32 tlLL = 0, tlOF = 0, tlML = 0;
+    if (lane < 3) lds.keepKind[lane] = 0;
+    kx_sync();
     bool last = false;
     while (!err && !last) {
         if (pos + 3 > srcSize) { err = KZE_SRCSIZE; break; }
@@ -504,9 +508,9 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                 u32 const mode = (modes >> (6 - 2 * t)) & 3u;
                 if (lane == 0) {
                     u32 r;
-                    if (t == 0) r = kxd_seq_table(lds, 0, mode, bp + spos, bend - spos, &tlLL, &vLL);
-                    else if (t == 1) r = kxd_seq_table(lds, 1, mode, bp + spos, bend - spos, &tlOF, &vOF);
-                    else r = kxd_seq_table(lds, 2, mode, bp + spos, bend - spos, &tlML, &vML);
+                    if (t == 0) r = kxd_seq_table(lds, 0, mode, bp + spos, bend - spos, &tlLL);
+                    else if (t == 1) r = kxd_seq_table(lds, 1, mode, bp + spos, bend - spos, &tlOF);
+                    else r = kxd_seq_table(lds, 2, mode, bp + spos, bend - spos, &tlML);
                     lds.bc[4] = r; lds.bc[5] = (t == 0) ? tlLL : (t == 1) ? tlOF : tlML;
                 }
                 kx_sync();
@@ -520,7 +524,6 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
         }
         // lane 0 keeps the table logs / validity for later blocks; share them
         tlLL = kx_shfl(tlLL, 0); tlOF = kx_shfl(tlOF, 0); tlML = kx_shfl(tlML, 0);
-        vLL = kx_shfl((u32)vLL, 0) != 0; vOF = kx_shfl((u32)vOF, 0) != 0; vML = kx_shfl((u32)vML, 0) != 0;
         u32 litUsed = 0;
         if (nbSeq && !(a.flags & 2u)) {
             const u8* const sq = bp + spos; u32 const ssz = bend - spos;
@@ -544,10 +547,10 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
 #define KXD_AT(C_, c_, n_) ((u32)((((C_) << (c_)) >> 1) >> (63u - (n_))))
             for (u32 done = 0; done < nbSeq && !err; ) {
                 u32 const cnt = (nbSeq - done) < 64 ? (nbSeq - done) : 64;
-                // keep >= 176 words (64 sequences x <= 88 bits) of stream below the read position in LDS
+                // keep >= 176 words (64 sequences x <= 88 bits) of stream below the read position in LDS (254 staged)
                 int const curWord = (int)kx_shfl((u32)bitPos, 0) >> 5;
                 if (sbLo < 0 || (sbLo > 0 && curWord - sbLo < 176)) {
-                    int newLo = curWord + 2 - 510; if (newLo < 0) newLo = 0;
+                    int newLo = curWord + 2 - 254; if (newLo < 0) newLo = 0;
                     int hiW = curWord + 2; if (hiW > totalWords) hiW = totalWords;
                     kx_sync();
                     for (int i = newLo - 2 + lane; i < hiW; i += 64) {
@@ -571,13 +574,13 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                     u32 const full = lastChunk ? cnt - 1 : cnt;       // the block's final sequence updates no state
                     for (u32 i = 0; i < cnt && !bad; i++) {
                         KXD_CONTAINER(C)
-                        u32 const lLL = lds.fseLL[sLL], lML = lds.fseML[sML], lOF = lds.fseOF[sOF];
-                        u32 const cLL = lLL >> 24, cML = lML >> 24, aOF = lOF >> 24;
+                        u32 const lLL = lds.u.q.fb[KXD_LL0 + sLL], lML = lds.u.q.fb[KXD_ML0 + sML], lOF = lds.u.q.fb[KXD_OF0 + sOF];
+                        u32 const cLL = lds.u.q.fc[KXD_LL0 + sLL], cML = lds.u.q.fc[KXD_ML0 + sML], aOF = lds.u.q.fc[KXD_OF0 + sOF];
                         // small codes carry no extra bits (base = code, resp. code + 3); the rest come from a table
                         u32 bLL = cLL, aLL = 0, bML = cML + 3, aML = 0;
                         if (cLL >= 16) { u32 const x = lds.llx[cLL]; bLL = x & 0xFFFFFFu; aLL = x >> 24; }
                         if (cML >= 32) { u32 const x = lds.mlx[cML]; bML = x & 0xFFFFFFu; aML = x >> 24; }
-                        u32 const nLL = (lLL >> 16) & 0xFF, nML = (lML >> 16) & 0xFF, nOF = (lOF >> 16) & 0xFF;
+                        u32 const nLL = lLL >> 12, nML = lML >> 12, nOF = lOF >> 12;
                         u32 const needA = aOF + aML + aLL, needB = (i < full) ? nLL + nML + nOF : 0u;
                         if (bitPos < (int)(needA + needB)) { bad = true; break; }
                         u32 xo, xm, xl, yl, ym, yo;
@@ -599,7 +602,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                         bool const sh2 = !isRep || idx >= 2, sh1 = !isRep || idx >= 1;
                         rep3 = sh2 ? rep2 : rep3; rep2 = sh1 ? rep1 : rep2; rep1 = off;
                         lds.u.q.stage[3 * i] = ll; lds.u.q.stage[3 * i + 1] = ml; lds.u.q.stage[3 * i + 2] = off;
-                        if (i < full) { sLL = (lLL & 0xFFFFu) + yl; sML = (lML & 0xFFFFu) + ym; sOF = (lOF & 0xFFFFu) + yo; }
+                        if (i < full) { sLL = (lLL & 0xFFFu) + yl; sML = (lML & 0xFFFu) + ym; sOF = (lOF & 0xFFFu) + yo; }
                     }
                     if (lastChunk && !bad && bitPos != 0) bad = true;
                     lds.u.q.stage[192] = bad ? 1u : 0u;

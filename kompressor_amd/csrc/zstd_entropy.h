@@ -52,16 +52,15 @@ struct KEntropyLds {
     } u;
     short norm[3][64];
     u16 cumul[3][66];
-    u8 tsymLL[512];           // FSE spread scratch (LL / weights, ML, OF)
-    u8 tsymML[512];
-    u8 tsymOF[256];
     u8 ncbuf[3][80];          // table descriptions of the three symbol types, before concatenation
     u32 cnt[16];
     u8 weight[256];
 };
 
 KX_DEV u16* kxe_state(KEntropyLds& lds, int t) { return t == 0 ? lds.u.seq.stateLL : t == 1 ? lds.u.seq.stateOF : lds.u.seq.stateML; }
-KX_DEV u8* kxe_tsym(KEntropyLds& lds, int t) { return t == 0 ? lds.tsymLL : t == 1 ? lds.tsymOF : lds.tsymML; }
+// FSE spread scratch (LL / weights 512 B, ML 512 B, OF 256 B): the staging area of the bitstream loop (stage, sbits,
+// cbuf: 1408 contiguous bytes), which is idle while tables are built
+KX_DEV u8* kxe_tsym(KEntropyLds& lds, int t) { return (u8*)lds.u.seq.stage + (t == 0 ? 0 : t == 1 ? 1024 : 512); }
 
 // ======================= lane-0 serial helpers ==========================
 struct KBitW { u64 acc; u32 nb; u8* p; };
@@ -465,7 +464,7 @@ KX_DEV u32 khuf_compress_weights(u8* dst, KEntropyLds& lds, u32 wtSize)
     if (kfse_normalize(lds.norm[0], tableLog, lds.cnt, wtSize, maxSymbolValue, 0) == KXE_ERR) return KXE_ERR;
     { u32 const h = kfse_write_ncount(op, lds.norm[0], maxSymbolValue, tableLog); if (h == KXE_ERR) return KXE_ERR; op += h; }
     KFseCT ct; ct.state = lds.u.seq.stateLL; ct.dnb = lds.u.seq.dnb[0]; ct.dfs = lds.u.seq.dfs[0];
-    kfse_build_ctable(ct, lds.norm[0], maxSymbolValue, tableLog, lds.cumul[0], lds.tsymLL);
+    kfse_build_ctable(ct, lds.norm[0], maxSymbolValue, tableLog, lds.cumul[0], kxe_tsym(lds, 0));
     {
         KBitW b; const u8* ip = weightTable + wtSize; u32 s1, s2;
         if (wtSize <= 2) return 0;

@@ -30,9 +30,7 @@ struct KMatchArgs {
     u32* tables;                     // per team: KX_TBL_ENTRIES
     u32* team_epoch;                 // per team
     u32* counter;                    // work queue head (zeroed by the host)
-    u32 flags;                       // experiment switches: 1 = non-temporal table loads, 2 = non-temporal table stores,
-                                     // 4 / 8 = also store / load a shadow table (cost probes; needs `shadow`)
-    u32* shadow;                     // per team: KX_TBL_ENTRIES, or null
+    u32 flags;                       // 1 = non-temporal table loads, 2 = non-temporal table stores (the default)
     // block mode (frames of several blocks): one block of every unfinished slice per launch
     const KFrameState* fstate;       // per slice
     u32* big_tables;                 // per slice: KX_BIG_TBL_ENTRIES
@@ -133,8 +131,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
     const u8* src = a.src; int n = 0; int ilimit = 0; u32 slice = 0;
     int ip = 0, anchor = 0; u32 off1 = 0, off2 = 0; int step = 1; int nextStep = 0;
     u32 nseq = 0, nlit = 0; u32 tag = 0; u32 hbL = 16, hbS = 15, mls = 5;
-    u32 longType = 0, longPos = 0; u32 guard = 0; u32 status = 0; u32 shacc = 0;
-    u32* const SH = a.shadow ? a.shadow + (size_t)team * KX_TBL_ENTRIES : L;
+    u32 longType = 0, longPos = 0; u32 guard = 0; u32 status = 0;
     KSeq* seqs = a.seqs;
     // pending match
     int m_type = 0, m_pos = 0, m_start = 0, m_mpos = 0; u32 m_len0 = 0, m_off = 0, m_idxl1 = 0; u64 m_w1 = 0;
@@ -236,7 +233,6 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 bool const haveL = carry && k == 0;
                 if (a.flags & 1u) { if (!haveL) el = kx_ld_nt(&L[hl]); if (cand) es = kx_ld_nt(&S[hs]); }
                 else { if (!haveL) el = L[hl]; if (cand) es = S[hs]; }
-                if (a.flags & 8u) { shacc |= kx_ld_nt(&SH[hl]); if (cand) shacc |= kx_ld_nt(&SH[KX_TBL_LONG + hs]); }
             }
             u32 idxl = ((el & ~IDXM) == tag) ? (el & IDXM) : 0u;
             u32 idxs = ((es & ~IDXM) == tag) ? (es & IDXM) : 0u;
@@ -294,7 +290,6 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 u32 const v = tag | (u32)(pos + 2);
                 if (a.flags & 2u) { if (!supL) kx_st_nt(&L[hl], v); if (!supS) kx_st_nt(&S[hs], v); }
                 else { if (!supL) L[hl] = v; if (!supS) S[hs] = v; }
-                if (a.flags & 4u) { kx_st_nt(&SH[hl], 0u); kx_st_nt(&SH[KX_TBL_LONG + hs], 0u); }
             }
 
             // winner data, broadcast inside the team
@@ -395,7 +390,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 if (k == 0) {
                     KSliceMeta mm;
                     mm.nbSeq = nseq; mm.litSize = nlit; mm.lastLL = (u32)(n - anchor);
-                    mm.longType = longType; mm.longPos = longPos; mm.status = status | (shacc == 0xFFFFFFFFu ? 4u : 0u); mm.pad[0] = 0; mm.pad[1] = 0;
+                    mm.longType = longType; mm.longPos = longPos; mm.status = status; mm.pad[0] = 0; mm.pad[1] = 0;
                     if (BLK) {
                         // repcodes this block leaves behind (taken over by the frame only if the block is emitted compressed)
                         u32 const s2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;

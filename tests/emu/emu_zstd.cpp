@@ -16,7 +16,7 @@ int emu_zstd_match(const u8* src, const u64* in_off, const u32* in_len, u32 n, i
     KMatchArgs a;
     a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
     a.seqs = seqs; a.seq_cap = seq_cap; a.meta = meta;
-    a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter; a.flags = 0; a.shadow = nullptr; a.fstate = nullptr; a.big_tables = nullptr;
+    a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter; a.flags = 0; a.fstate = nullptr; a.big_tables = nullptr;
     kxemu::failed = 0;
     switch (G) {
     case 2:  kxemu::launch(nblocks, [&]() { zstd_match_body<2>(a); }); break;
@@ -80,7 +80,7 @@ int emu_zstd_compress_big(const u8* src, const u64* in_off, const u32* in_len, u
     KMatchArgs m;
     m.src = src; m.in_off = in_off; m.in_len = in_len; m.n_slices = n;
     m.seqs = seqs.data(); m.seq_cap = seq_cap; m.meta = meta.data();
-    m.tables = nullptr; m.team_epoch = nullptr; m.counter = &counter; m.flags = 0; m.shadow = nullptr;
+    m.tables = nullptr; m.team_epoch = nullptr; m.counter = &counter; m.flags = 0;
     m.fstate = fstate.data(); m.big_tables = big_tables.data();
     KFrameArgs e;
     e.src = src; e.in_off = in_off; e.in_len = in_len; e.n_slices = n;
