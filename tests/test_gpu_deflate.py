@@ -177,3 +177,34 @@ def test_gzip_format_and_autodetect(batch):
         ZlibDecompressor(ZlibFormat.Gzip).transform_bytes(g[:-6] + bytes([g[-6] ^ 1]) + g[-5:])
     with pytest.raises(RuntimeError, match="auto-detection"):
         ZlibCompressor(ZlibFormat.AutoDetectZlibGzip)
+
+
+def test_fuzz_ragged_sizes_against_zlib(batch):
+    """1 536 slices of arbitrary sizes 0 .. 64 KiB (every class, byte runs, short periods, class changes inside a slice):
+    the GPU's raw DEFLATE stream against the host zlib's, byte for byte, and back through the GPU inflate."""
+    import random
+    rng = random.Random(4321)
+
+    def piece(n):
+        r = rng.random()
+        if r < 0.08:
+            return bytes([rng.randrange(256)]) * n
+        if r < 0.16:
+            unit = corpus.make(rng.randrange(1 << 30), 1, rng.choice([2, 3, 7, 40, 300]), mix=ord("R")).tobytes()
+            return (unit * (n // len(unit) + 1))[:n]
+        return corpus.make(rng.randrange(1 << 30), 1, n, mix=ord(rng.choice("TXSBDIZR"))).tobytes()
+
+    def blob(total):
+        parts, have = [], 0
+        while have < total:
+            n = min(total - have, rng.choice([1, 5, 64, 500, 4000, 20000, 70000]))
+            parts.append(piece(n))
+            have += n
+        return b"".join(parts)
+
+    sizes = [rng.choice([rng.randrange(0, 64), rng.randrange(0, 2000), rng.randrange(0, 20000), rng.randrange(0, 65537)]) for _ in range(1536)]
+    datas = [blob(sz) for sz in sizes]
+    outs = gpu_deflate(batch, datas)
+    for i, (d, f) in enumerate(zip(datas, outs)):
+        c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, 0)
+        assert f == c.compress(d) + c.flush(), (i, len(d))

@@ -266,3 +266,45 @@ def test_multiblock_frames_match_libzstd():
         assert back == datas + small
     finally:
         b.close()
+
+
+def test_fuzz_ragged_sizes_against_oracle(batch):
+    """2 048 slices of arbitrary sizes 0 .. 128 KiB (every class, byte runs, short periods, class changes inside a
+    slice) through the batched path, each compared with the oracle's frame; then a ragged batch of 96 slices of
+    128 KiB+1 .. 1.5 MiB through the block-chain path."""
+    import random
+    from kompressor_amd.batch import ZstdBatch
+    rng = random.Random(777)
+    o = helpers.oracle()
+
+    def piece(n):
+        r = rng.random()
+        if r < 0.08:
+            return bytes([rng.randrange(256)]) * n
+        if r < 0.16:
+            unit = corpus.make(rng.randrange(1 << 30), 1, rng.choice([2, 3, 7, 40, 300]), mix=ord("R")).tobytes()
+            return (unit * (n // len(unit) + 1))[:n]
+        return corpus.make(rng.randrange(1 << 30), 1, n, mix=ord(rng.choice("TXSBDIZR"))).tobytes()
+
+    def blob(total):
+        parts, have = [], 0
+        while have < total:
+            n = min(total - have, rng.choice([1, 5, 64, 500, 4000, 20000, 70000, 200000]))
+            parts.append(piece(n))
+            have += n
+        return b"".join(parts)
+
+    sizes = [rng.choice([rng.randrange(0, 64), rng.randrange(0, 2000), rng.randrange(0, 20000), rng.randrange(0, 131073)]) for _ in range(2048)]
+    datas = [blob(sz) for sz in sizes]
+    for i, (d, f) in enumerate(zip(datas, gpu_compress(batch, datas))):
+        assert f == o.compress(d), (i, len(d))
+    big = [blob(rng.randrange(131073, 1536 * 1024)) for _ in range(96)]
+    b = ZstdBatch(max_slices=len(big), max_slice_bytes=2 << 20)
+    try:
+        frames = gpu_compress(b, big)
+        for i, (d, f) in enumerate(zip(big, frames)):
+            assert f == o.compress(d), (i, len(d))
+        back, st = gpu_decompress(b, frames, [len(d) for d in big])
+        assert st == [0] * len(big) and back == big
+    finally:
+        b.close()
