@@ -276,6 +276,7 @@ def main():
         algo_bytes = (in_bytes + frame_bytes + 16 * n) // launches
         achieved = algo_bytes / (ms_match * 1e-3) / 1e9
         traffic = None
+        random_access = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
@@ -283,6 +284,14 @@ def main():
                 # counters were collected for the default configuration only
                 if pj.get("slices") == n and pj.get("launches", 1) == launches and (args.team or 4) == pj.get("team", 4):
                     traffic = pj.get("zstd_match_hbm_bytes_per_launch")
+                    rd, wr = pj.get("zstd_match_read_requests_per_launch"), pj.get("zstd_match_write_requests_per_launch")
+                    if rd and wr:
+                        # the bound that does apply: random 64-byte transactions, priced with tools/randgather.hip on this
+                        # GPU (profiles/r01_random_access.txt): a probe + insert into one line 20 G/s, further reads 54 G/s
+                        floor_ms = (wr / 20e9 + max(0, rd - wr) / 54e9) * 1e3
+                        random_access = {"read_requests_per_launch": rd, "write_requests_per_launch": wr,
+                                         "floor_ms": round(floor_ms, 1), "frac": round(floor_ms / ms_match, 3),
+                                         "source": "TCC_EA0_RDREQ / WRREQ from profiles/pmc_latest.json; rates from profiles/r01_random_access.txt"}
             except Exception:
                 traffic = None
         res = {
@@ -299,6 +308,8 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms_match, 3), "launches_per_step": launches},
             "kernels_ms": {"k_zstd_match": round(ms_match, 3), "k_zstd_entropy": round(ms_entropy, 3)},
         }
+        if random_access:
+            res["random_access_roofline"] = random_access
         if not args.no_cpu:
             sample = min(n, 8192)
             res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()))

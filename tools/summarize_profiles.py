@@ -65,6 +65,8 @@ def main():
               "slices": line["config"]["slices_per_gpu"], "team": line["config"]["team_lanes"], "launches": nl,
               "zstd_match_fetch_kib": fetch, "zstd_match_write_kib": write,
               "zstd_match_hbm_bytes_per_launch": int((fetch + write) * 1024 / nl),
+              "zstd_match_read_requests_per_launch": int(allc.get((k, "TCC_EA0_RDREQ_sum"), (0, 1))[0] / nl),
+              "zstd_match_write_requests_per_launch": int(allc.get((k, "TCC_EA0_WRREQ_sum"), (0, 1))[0] / nl),
               "note": "(FETCH_SIZE+WRITE_SIZE)*1024 / launches; the guide's x2 correction for wide coalesced reads is not applied: "
                       "this kernel's reads are scattered 4- and 8-byte probes (TCC_EA0_RDREQ_32B = 0, RDREQ*64 = FETCH_SIZE)"}
         json.dump(pj, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
