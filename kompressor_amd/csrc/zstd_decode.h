@@ -572,26 +572,23 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                     }
                     bool const lastChunk = done + cnt == nbSeq;
                     u32 const full = lastChunk ? cnt - 1 : cnt;       // the block's final sequence updates no state
-                    for (u32 i = 0; i < cnt && !bad; i++) {
+                    // one sequence per iteration, written without data-dependent branches (a corrupt stream only sets
+                    // `bad`; states stay inside their tables by construction and bitPos is clamped at 0)
+                    for (u32 i = 0; i < cnt; i++) {
                         KXD_CONTAINER(C)
                         u32 const lLL = lds.u.q.fb[KXD_LL0 + sLL], lML = lds.u.q.fb[KXD_ML0 + sML], lOF = lds.u.q.fb[KXD_OF0 + sOF];
                         u32 const cLL = lds.u.q.fc[KXD_LL0 + sLL], cML = lds.u.q.fc[KXD_ML0 + sML], aOF = lds.u.q.fc[KXD_OF0 + sOF];
-                        // small codes carry no extra bits (base = code, resp. code + 3); the rest come from a table
-                        u32 bLL = cLL, aLL = 0, bML = cML + 3, aML = 0;
-                        if (cLL >= 16) { u32 const x = lds.llx[cLL]; bLL = x & 0xFFFFFFu; aLL = x >> 24; }
-                        if (cML >= 32) { u32 const x = lds.mlx[cML]; bML = x & 0xFFFFFFu; aML = x >> 24; }
-                        u32 const nLL = lLL >> 12, nML = lML >> 12, nOF = lOF >> 12;
-                        u32 const needA = aOF + aML + aLL, needB = (i < full) ? nLL + nML + nOF : 0u;
-                        if (bitPos < (int)(needA + needB)) { bad = true; break; }
-                        u32 xo, xm, xl, yl, ym, yo;
-                        xo = KXD_AT(C, 0u, aOF); xm = KXD_AT(C, aOF, aML); xl = KXD_AT(C, aOF + aML, aLL);
-                        if (needA + needB <= 64) {
-                            yl = KXD_AT(C, needA, nLL); ym = KXD_AT(C, needA + nLL, nML); yo = KXD_AT(C, needA + nLL + nML, nOF);
-                        } else {
-                            bitPos -= (int)needA; KXD_CONTAINER(C2) bitPos += (int)needA;
-                            yl = KXD_AT(C2, 0u, nLL); ym = KXD_AT(C2, nLL, nML); yo = KXD_AT(C2, nLL + nML, nOF);
-                        }
-                        bitPos -= (int)(needA + needB);
+                        u32 const xLL = lds.llx[cLL], xML = lds.mlx[cML];          // baseValue | extraBits << 24
+                        u32 const bLL = xLL & 0xFFFFFFu, aLL = xLL >> 24, bML = xML & 0xFFFFFFu, aML = xML >> 24;
+                        bool const upd = i < full;                                  // the block's final sequence updates no state
+                        u32 const nLL = upd ? lLL >> 12 : 0u, nML = upd ? lML >> 12 : 0u, nOF = upd ? lOF >> 12 : 0u;
+                        u32 const needA = aOF + aML + aLL, needB = nLL + nML + nOF;
+                        bad |= bitPos < (int)(needA + needB);
+                        u32 const xo = KXD_AT(C, 0u, aOF), xm = KXD_AT(C, aOF, aML), xl = KXD_AT(C, aOF + aML, aLL);
+                        u64 Cs = C; u32 cs = needA;
+                        if (needA + needB > 64) { bitPos -= (int)needA; KXD_CONTAINER(C2) bitPos += (int)needA; Cs = C2; cs = 0; }   // rare
+                        u32 const yl = KXD_AT(Cs, cs, nLL), ym = KXD_AT(Cs, cs + nLL, nML), yo = KXD_AT(Cs, cs + nLL + nML, nOF);
+                        bitPos -= (int)(needA + needB); bitPos = bitPos < 0 ? 0 : bitPos;
                         u32 const ofv = (1u << aOF) + xo, ml = bML + xm, ll = bLL + xl;
                         // repeat-offset rules, branch-free
                         bool const isRep = ofv <= 3;
@@ -602,7 +599,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                         bool const sh2 = !isRep || idx >= 2, sh1 = !isRep || idx >= 1;
                         rep3 = sh2 ? rep2 : rep3; rep2 = sh1 ? rep1 : rep2; rep1 = off;
                         lds.u.q.stage[3 * i] = ll; lds.u.q.stage[3 * i + 1] = ml; lds.u.q.stage[3 * i + 2] = off;
-                        if (i < full) { sLL = (lLL & 0xFFFu) + yl; sML = (lML & 0xFFFu) + ym; sOF = (lOF & 0xFFFu) + yo; }
+                        sLL = (lLL & 0xFFFu) + yl; sML = (lML & 0xFFFu) + ym; sOF = (lOF & 0xFFFu) + yo;
                     }
                     if (lastChunk && !bad && bitPos != 0) bad = true;
                     lds.u.q.stage[192] = bad ? 1u : 0u;
