@@ -230,7 +230,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     HIP_TRY(hipGetLastError());
     KMatchArgs m;
     m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
-    m.seqs = c->seqs; m.seq_cap = c->seq_cap; m.meta = c->meta;
+    m.seqs = c->seqs; m.seq_cap = c->seq_cap; m.meta = c->meta; m.lits = c->lits; m.lit_cap = c->lit_cap;
     m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter; m.flags = 2;
     m.fstate = c->fstate; m.big_tables = c->big_tables;
     KFrameArgs e;
@@ -308,7 +308,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     if (c->have_last_match) HIP_TRY(hipStreamWaitEvent(st, c->ev_last_match, 0));
     HIP_TRY(hipMemsetAsync(c->counter, 0, 4 * KMP_MAX_CHUNKS, st));
     u32 const tpw = 64 / (u32)c->G;
-    u32 const match_flags = env_u32("KMP_MATCH_FLAGS", 2), entropy_pad = env_u32("KMP_ENTROPY_PAD_LDS", 0);   // experiments only
+    u32 const match_flags = env_u32("KMP_MATCH_FLAGS", 6), entropy_pad = env_u32("KMP_ENTROPY_PAD_LDS", 0);   // experiments only
     u32 const per = (n + chunks - 1) / chunks;
     bool forked = false;
     for (u32 ci = 0; ci < chunks; ci++) {
@@ -316,6 +316,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         KMatchArgs m;
         m.src = (const u8*)d_src; m.in_off = d_in_off + first; m.in_len = d_in_len + first; m.n_slices = m_n;
         m.seqs = c->seqs + (size_t)first * c->seq_cap; m.seq_cap = c->seq_cap; m.meta = c->meta + first;
+        m.lits = c->lits + (size_t)first * c->lit_cap; m.lit_cap = c->lit_cap;
         m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter + ci; m.flags = match_flags;
         u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
         if (c->profiling) HIP_TRY(hipEventRecord(c->evm[ci][0], st));
@@ -334,7 +335,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         e.src = (const u8*)d_src; e.in_off = d_in_off + first; e.in_len = d_in_len + first; e.n_slices = m_n;
         e.seqs = m.seqs; e.seq_cap = c->seq_cap; e.lits = c->lits + (size_t)first * c->lit_cap; e.lit_cap = c->lit_cap; e.meta = m.meta;
         e.scratch = c->scratch + (size_t)first * c->scratch_words; e.scratch_words = c->scratch_words;
-        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first;
+        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = env_u32("KMP_ENTROPY_FLAGS", 0) | ((match_flags & 4u) ? 8u : 0u);
         hipStream_t es = st;
         if (ci + 1 < chunks) { es = c->st2; HIP_TRY(hipStreamWaitEvent(es, c->evm[ci][1], 0)); forked = true; }
         if (c->profiling) HIP_TRY(hipEventRecord(c->eve[ci][0], es));

@@ -23,6 +23,8 @@ struct KEntropyArgs {
     const KSeq* seqs; u32 seq_cap; u8* lits; u32 lit_cap; const KSliceMeta* meta;
     u32* scratch; u32 scratch_words;         // per slice: Huffman stream staging (u32 aligned)
     u8* dst; const u64* out_off; u32* out_len;
+    u32 flags;                               // timing experiments only (results become wrong): 1 no literal coding, 2 no sequence coding (timing experiments, results become wrong);
+                                             // 8: the match kernel copied no literals, gather them here
 };
 
 #define KXE_ERR 0xFFFFFFFFu
@@ -48,6 +50,8 @@ struct KEntropyLds {
             u32 stage[64];       // codes of 64 staged sequences: ll | of << 8 | ml << 16
             u16 sbits[3][64];    // per staged sequence and stream: state bits value | count << 12
             u32 cbuf[192];       // bit assembly buffer of one 64-sequence chunk
+            u32 pnb[3][65];      // per staged sequence and stream: deltaNbBits / deltaFindState of its code, looked up by
+            int pfs[3][65];      //   all lanes at once so that the state chains only wait for the state table
         } seq;
     } u;
     short norm[3][64];
@@ -862,18 +866,25 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
             u32 const idx = hi - 1 - (u32)lane;            // lane order == stream order
             q = seqs[idx]; c = kx_seq_codes(q, idx, longType, longPos);
             lds.u.seq.stage[lane] = c.ll | (c.of << 8) | (c.ml << 16);
+            lds.u.seq.pnb[0][lane] = lds.u.seq.dnb[0][c.ll]; lds.u.seq.pfs[0][lane] = lds.u.seq.dfs[0][c.ll];
+            lds.u.seq.pnb[1][lane] = lds.u.seq.dnb[1][c.of]; lds.u.seq.pfs[1][lane] = lds.u.seq.dfs[1][c.of];
+            lds.u.seq.pnb[2][lane] = lds.u.seq.dnb[2][c.ml]; lds.u.seq.pfs[2][lane] = lds.u.seq.dfs[2][c.ml];
         }
         kx_sync();
         if (lane < 3) {
-            u32 const sh = 8u * (u32)lane;
-            for (u32 s = 0; s < cnt; s++) {
-                u32 const code = (lds.u.seq.stage[s] >> sh) & 0xFFu;
-                if (!started) { state = kfse_init_state(ct, code); lds.u.seq.sbits[lane][s] = 0; started = true; }
-                else {
-                    u32 const nb = (state + ct.dnb[code]) >> 16;
-                    lds.u.seq.sbits[lane][s] = (u16)((state & ((1u << nb) - 1u)) | (nb << 12));
-                    state = ct.state[(state >> nb) + ct.dfs[code]];
-                }
+            u32 s = 0;
+            if (!started) {
+                state = kfse_init_state(ct, (lds.u.seq.stage[0] >> (8u * (u32)lane)) & 0xFFu);
+                lds.u.seq.sbits[lane][0] = 0; started = true; s = 1;
+            }
+            // the only load a step waits for is the state table's: the next step's deltas are requested before it
+            u32 dn = lds.u.seq.pnb[lane][s]; int df = lds.u.seq.pfs[lane][s];
+            for (; s < cnt; s++) {
+                u32 const dn1 = lds.u.seq.pnb[lane][s + 1]; int const df1 = lds.u.seq.pfs[lane][s + 1];
+                u32 const nb = (state + dn) >> 16;
+                lds.u.seq.sbits[lane][s] = (u16)((state & ((1u << nb) - 1u)) | (nb << 12));
+                state = ct.state[(state >> nb) + df];
+                dn = dn1; df = df1;
             }
         }
         kx_sync();
@@ -995,14 +1006,14 @@ KX_DEV void zstd_entropy_slice(const KEntropyArgs& a, KEntropyLds& lds, u32 slic
         const KSeq* const seqs = a.seqs + (size_t)slice * a.seq_cap;
         u8* const lits = a.lits + (size_t)slice * a.lit_cap;
         u32 const litSize = mm.litSize + mm.lastLL;
-        kx_gather_literals(lits, src, n, seqs, mm.nbSeq, mm.longType, mm.longPos, lane);
+        if (a.flags & 8u) kx_gather_literals(lits, src, n, seqs, mm.nbSeq, mm.longType, mm.longPos, lane);
         // complete the literal buffer with the trailing literals
         kx_wave_copy(lits + mm.litSize, src + (n - mm.lastLL), mm.lastLL, lane);
         kx_sync();
         bool const suspect = (mm.nbSeq == 0) || (litSize / mm.nbSeq >= 20);
-        u32 const litSec = kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane);
+        u32 const litSec = (a.flags & 1u) ? 3u : kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane);
         kx_sync();
-        u32 const seqSec = kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < n ? n - litSec : 0u);
+        u32 const seqSec = (a.flags & 2u) ? 0u : kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < n ? n - litSec : 0u);
         if (seqSec != 0) {
             cSize = litSec + seqSec;
             if (cSize >= n - kx_min_gain(n)) cSize = 0;
@@ -1096,7 +1107,6 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
         const KSeq* const seqs = a.seqs + (size_t)slice * a.seq_cap;
         u8* const lits = a.lits + (size_t)slice * a.lit_cap;
         u32 const litSize = mm.litSize + mm.lastLL;
-        kx_gather_literals(lits, bsrc, bs, seqs, mm.nbSeq, mm.longType, mm.longPos, lane);
         kx_wave_copy(lits + mm.litSize, bsrc + (bs - mm.lastLL), mm.lastLL, lane);
         kx_sync();
         bool const suspect = (mm.nbSeq == 0) || (litSize / mm.nbSeq >= 20);
@@ -1178,7 +1188,7 @@ KX_DEV void zstd_big_body(const KBigArgs& a)
         u32 const cnt = (a.e.n_slices - base < spw) ? a.e.n_slices - base : spw;
         KMatchArgs m = a.m;
         m.in_off += base; m.in_len += base; m.n_slices = cnt;
-        m.seqs += (size_t)base * m.seq_cap; m.meta += base; m.fstate += base;
+        m.seqs += (size_t)base * m.seq_cap; m.lits += (size_t)base * m.lit_cap; m.meta += base; m.fstate += base;
         m.big_tables += (size_t)base * KX_BIG_TBL_ENTRIES;
         m.counter = a.counters + kx_block();
         for (u32 guard = 0; guard < KX_MAX_BIG_SLICE / 8192u + 4u; guard++) {

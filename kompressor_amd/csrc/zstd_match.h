@@ -13,9 +13,8 @@
 //  * one search step examines up to G-1 consecutive search positions at once
 //    (lane k speculates that lanes < k found nothing); the first lane with a
 //    hit wins, lanes before it commit their table inserts, the rest discard;
-//  * match extension and backward catch-up are team-cooperative; literals are not
-//    copied (the entropy kernel gathers them from the source), sequences leave in
-//    whole 16-byte pieces;
+//  * match extension, backward catch-up and literal copy are team-cooperative;
+//    sequences leave in whole 16-byte pieces;
 //  * hash tables live in global memory (one pair per team, tagged with an
 //    epoch so they are never cleared between slices).
 //
@@ -26,11 +25,13 @@
 struct KMatchArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
     KSeq* seqs; u32 seq_cap;         // per slice
+    u8* lits; u32 lit_cap;           // per slice: the literals, in order
     KSliceMeta* meta;                // per slice
     u32* tables;                     // per team: KX_TBL_ENTRIES
     u32* team_epoch;                 // per team
     u32* counter;                    // work queue head (zeroed by the host)
-    u32 flags;                       // 1 = non-temporal table loads, 2 = non-temporal table stores (the default)
+    u32 flags;                       // 1 = non-temporal table loads, 2 = non-temporal table stores (the default),
+                                     // 4 = copy no literals (the entropy kernel gathers them; A/B switch)
     // block mode (frames of several blocks): one block of every unfinished slice per launch
     const KFrameState* fstate;       // per slice
     u32* big_tables;                 // per slice: KX_BIG_TBL_ENTRIES
@@ -132,7 +133,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
     int ip = 0, anchor = 0; u32 off1 = 0, off2 = 0; int step = 1; int nextStep = 0;
     u32 nseq = 0, nlit = 0; u32 tag = 0; u32 hbL = 16, hbS = 15, mls = 5;
     u32 longType = 0, longPos = 0; u32 guard = 0; u32 status = 0;
-    KSeq* seqs = a.seqs;
+    KSeq* seqs = a.seqs; u8* lits = a.lits;
     // pending match
     int m_type = 0, m_pos = 0, m_start = 0, m_mpos = 0; u32 m_len0 = 0, m_off = 0, m_idxl1 = 0; u64 m_w1 = 0;
     // sequences wait in registers (two per lane) until the team can store whole 16-byte pieces of a line
@@ -160,7 +161,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     if (fs.blockSize != 0) {           // else: frame finished, fetch the next slice
                         slice = s;
                         src = a.src + a.in_off[s];
-                        seqs = a.seqs + (size_t)s * a.seq_cap;
+                        seqs = a.seqs + (size_t)s * a.seq_cap; lits = a.lits + (size_t)s * a.lit_cap;
                         L = a.big_tables + (size_t)s * KX_BIG_TBL_ENTRIES; S = L + KX_BIG_TBL_LONG;
                         KParams const P = kx_params_l3(a.in_len[s]);
                         hbL = P.hashLog; hbS = P.chainLog; mls = P.minMatch;
@@ -179,7 +180,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     slice = s;
                     src = a.src + a.in_off[s];
                     n = (int)a.in_len[s];
-                    seqs = a.seqs + (size_t)s * a.seq_cap;
+                    seqs = a.seqs + (size_t)s * a.seq_cap; lits = a.lits + (size_t)s * a.lit_cap;
                     KParams const P = kx_params_l3((u32)n);
                     hbL = P.hashLog; hbS = P.chainLog; mls = P.minMatch;
                     nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = 0;
@@ -351,7 +352,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 if (bw) { m_start -= (int)back; m_mpos -= (int)back; lenA += back; off2 = off1; off1 = m_off; offBase = m_off + 3; }
                 else if (m_type == KMT_REP0) { u32 const t = off2; off2 = off1; off1 = t; }
                 int const ll = m_start - anchor;
-                // literals are not copied here: k_zstd_entropy gathers them from the source with the sequence list
+                if (!(a.flags & 4u)) for (int c = 8 * k; c < ll; c += 8 * G) kx_st64(lits + nlit + c, kx_ld64_clamped(src, anchor + c, n));
                 {
                     u64 const q = (u64)offBase | ((u64)(u16)ll << 32) | ((u64)(u16)(lenA - 3) << 48);   // KSeq
                     u32 const slot = nseq & (2u * G - 1u);

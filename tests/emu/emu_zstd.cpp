@@ -7,7 +7,7 @@
 
 extern "C" __attribute__((visibility("default")))
 int emu_zstd_match(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
-                   KSeq* seqs, u32 seq_cap, KSliceMeta* meta, u32 start_epoch)
+                   KSeq* seqs, u32 seq_cap, u8* lits, u32 lit_cap, KSliceMeta* meta, u32 start_epoch)
 {
     u32 const nteams = nblocks * (64 / G);
     std::vector<u32> tables((size_t)nteams * KX_TBL_ENTRIES, 0xDEADBEEFu & 0x0003FFFFu);   // stale junk with epoch 0
@@ -15,7 +15,7 @@ int emu_zstd_match(const u8* src, const u64* in_off, const u32* in_len, u32 n, i
     u32 counter = 0;
     KMatchArgs a;
     a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
-    a.seqs = seqs; a.seq_cap = seq_cap; a.meta = meta;
+    a.seqs = seqs; a.seq_cap = seq_cap; a.lits = lits; a.lit_cap = lit_cap; a.meta = meta;
     a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter; a.flags = 0; a.fstate = nullptr; a.big_tables = nullptr;
     kxemu::failed = 0;
     switch (G) {
@@ -42,14 +42,14 @@ int emu_zstd_compress(const u8* src, const u64* in_off, const u32* in_len, u32 n
     std::vector<u8> lits((size_t)n * lit_cap, 0xEE);
     std::vector<KSliceMeta> meta(n);
     std::vector<u32> scratch((size_t)n * scratch_words, 0xA5A5A5A5u);
-    int r = emu_zstd_match(src, in_off, in_len, n, G, nblocks, seqs.data(), seq_cap, meta.data(), 7);
+    int r = emu_zstd_match(src, in_off, in_len, n, G, nblocks, seqs.data(), seq_cap, lits.data(), lit_cap, meta.data(), 7);
     if (r) return r;
     for (u32 i = 0; i < n; i++) if (meta[i].status) return -3;
     KEntropyArgs e;
     e.src = src; e.in_off = in_off; e.in_len = in_len; e.n_slices = n;
     e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
     e.scratch = scratch.data(); e.scratch_words = scratch_words;
-    e.dst = dst; e.out_off = out_off; e.out_len = out_len;
+    e.dst = dst; e.out_off = out_off; e.out_len = out_len; e.flags = 0;
     kxemu::failed = 0;
     kxemu::launch(nblocks, [&]() { zstd_entropy_body(e); });
     return kxemu::failed ? -1 : 0;
@@ -79,7 +79,7 @@ int emu_zstd_compress_big(const u8* src, const u64* in_off, const u32* in_len, u
     }
     KMatchArgs m;
     m.src = src; m.in_off = in_off; m.in_len = in_len; m.n_slices = n;
-    m.seqs = seqs.data(); m.seq_cap = seq_cap; m.meta = meta.data();
+    m.seqs = seqs.data(); m.seq_cap = seq_cap; m.lits = lits.data(); m.lit_cap = lit_cap; m.meta = meta.data();
     m.tables = nullptr; m.team_epoch = nullptr; m.counter = &counter; m.flags = 0;
     m.fstate = fstate.data(); m.big_tables = big_tables.data();
     KFrameArgs e;
