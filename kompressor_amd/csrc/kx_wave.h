@@ -33,6 +33,8 @@ KX_DEV bool kx_all(bool p) { return __ballot(!p) == 0ull; }
 // value held by lane `src` (0..63); ds_bpermute_b32
 KX_DEV u32 kx_shfl(u32 v, int src) { return (u32)__builtin_amdgcn_ds_bpermute((src & 63) << 2, (int)v); }
 // orders LDS/global traffic between the lanes of the (single-wave) workgroup
+// value held by lane k (a compile-time constant): v_readlane_b32, the result is wave-uniform
+KX_DEV u32 kx_bcast(u32 v, int k) { return (u32)__builtin_amdgcn_readlane((int)v, k); }
 KX_DEV void kx_sync() { __syncthreads(); }
 // The lanes of a wave execute in lock step and the vector-memory pipeline keeps
 // one wave's accesses to an address in program order, so memory written by some

@@ -535,7 +535,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             // state-table entries; fields then cost two shifts each. sbuf keeps two zero words below
             // the stream start so no read is conditional.
             int bitPos = (int)(8 * (ssz - 1) + kx_hb32(lastByte));
-            u32 sLL = 0, sOF = 0, sML = 0; bool bad = false, primed = false;
+            u32 st3 = 0; bool bad = false, primed = false;       // st3: this lane's FSE state (lane 0 OF, 1 ML, 2.. LL)
             int sbLo = -1;                       // first stream word held in lds.u.q.sbuf[2..] (uniform)
 #define KXD_WORD(i) lds.u.q.sbuf[(i) - sbLo + 2]
 #define KXD_CONTAINER(C_) u64 C_; { int const topw_ = (bitPos - 1) >> 5; \
@@ -564,33 +564,50 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                     sbLo = newLo;
                     kx_sync();
                 }
-                if (lane == 0) {
+                {
+                    // Every lane runs the loop (the cost of an instruction does not depend on how many lanes are active);
+                    // lanes 0, 1, 2 decode the OF, ML and LL field of a sequence at once: one table look-up, one extra-bits
+                    // field and one state update per lane instead of three in a row on one lane.  Lanes >= 3 shadow lane 2.
+                    // The three lanes' bit counts and values are exchanged with kx_bcast (v_readlane: uniform values, so
+                    // the repeat-offset rules run on the scalar unit).
+                    u32 const role = lane < 3 ? (u32)lane : 2u;
+                    u32 const tb = role == 0 ? (u32)KXD_OF0 : role == 1 ? (u32)KXD_ML0 : (u32)KXD_LL0;
+                    const u32* const xt = role == 1 ? lds.mlx : lds.llx;
                     if (!primed) {
-                        if (bitPos < (int)(tlLL + tlOF + tlML)) bad = true;
-                        else { KXD_CONTAINER(C0) KXD_GET(sLL, C0, tlLL) KXD_GET(sOF, C0, tlOF) KXD_GET(sML, C0, tlML) bitPos -= (int)(tlLL + tlOF + tlML); }
+                        u32 const need0 = tlLL + tlOF + tlML;
+                        bad |= bitPos < (int)need0;
+                        KXD_CONTAINER(C0)
+                        // initial states in stream order LL, OF, ML
+                        st3 = role == 2 ? KXD_AT(C0, 0u, tlLL) : role == 0 ? KXD_AT(C0, tlLL, tlOF) : KXD_AT(C0, tlLL + tlOF, tlML);
+                        bitPos -= (int)need0; bitPos = bitPos < 0 ? 0 : bitPos;
                         primed = true;
                     }
                     bool const lastChunk = done + cnt == nbSeq;
                     u32 const full = lastChunk ? cnt - 1 : cnt;       // the block's final sequence updates no state
-                    // one sequence per iteration, written without data-dependent branches (a corrupt stream only sets
-                    // `bad`; states stay inside their tables by construction and bitPos is clamped at 0)
+                    // a corrupt stream only sets `bad`: states stay inside their tables by construction, bitPos is clamped at 0
                     for (u32 i = 0; i < cnt; i++) {
                         KXD_CONTAINER(C)
-                        u32 const lLL = lds.u.q.fb[KXD_LL0 + sLL], lML = lds.u.q.fb[KXD_ML0 + sML], lOF = lds.u.q.fb[KXD_OF0 + sOF];
-                        u32 const cLL = lds.u.q.fc[KXD_LL0 + sLL], cML = lds.u.q.fc[KXD_ML0 + sML], aOF = lds.u.q.fc[KXD_OF0 + sOF];
-                        u32 const xLL = lds.llx[cLL], xML = lds.mlx[cML];          // baseValue | extraBits << 24
-                        u32 const bLL = xLL & 0xFFFFFFu, aLL = xLL >> 24, bML = xML & 0xFFFFFFu, aML = xML >> 24;
-                        bool const upd = i < full;                                  // the block's final sequence updates no state
-                        u32 const nLL = upd ? lLL >> 12 : 0u, nML = upd ? lML >> 12 : 0u, nOF = upd ? lOF >> 12 : 0u;
-                        u32 const needA = aOF + aML + aLL, needB = nLL + nML + nOF;
+                        u32 const e = lds.u.q.fb[tb + st3], code = lds.u.q.fc[tb + st3];
+                        u32 const x = xt[code];                                     // baseValue | extraBits << 24 (LL, ML)
+                        u32 const a = role == 0 ? code : x >> 24;
+                        u32 const base = role == 0 ? (1u << code) : (x & 0xFFFFFFu);
+                        u32 const n = (i < full) ? e >> 12 : 0u;
+                        u32 const aO = kx_bcast(a, 0), aM = kx_bcast(a, 1), aL = kx_bcast(a, 2);
+                        u32 const nO = kx_bcast(n, 0), nM = kx_bcast(n, 1), nL = kx_bcast(n, 2);
+                        u32 const needA = aO + aM + aL, needB = nL + nM + nO;
                         bad |= bitPos < (int)(needA + needB);
-                        u32 const xo = KXD_AT(C, 0u, aOF), xm = KXD_AT(C, aOF, aML), xl = KXD_AT(C, aOF + aML, aLL);
-                        u64 Cs = C; u32 cs = needA;
-                        if (needA + needB > 64) { bitPos -= (int)needA; KXD_CONTAINER(C2) bitPos += (int)needA; Cs = C2; cs = 0; }   // rare
-                        u32 const yl = KXD_AT(Cs, cs, nLL), ym = KXD_AT(Cs, cs + nLL, nML), yo = KXD_AT(Cs, cs + nLL + nML, nOF);
+                        // bit order inside a sequence: OF extra, ML extra, LL extra, then LL state, ML state, OF state
+                        u32 const offA = role == 0 ? 0u : role == 1 ? aO : aO + aM;
+                        u32 offB = role == 2 ? 0u : role == 1 ? nL : nL + nM;
+                        u32 const xv = KXD_AT(C, offA, a);
+                        u64 Cs = C;
+                        if (needA + needB > 64) { bitPos -= (int)needA; KXD_CONTAINER(C2) bitPos += (int)needA; Cs = C2; }   // rare
+                        else offB += needA;
+                        u32 const yv = KXD_AT(Cs, offB, n);
                         bitPos -= (int)(needA + needB); bitPos = bitPos < 0 ? 0 : bitPos;
-                        u32 const ofv = (1u << aOF) + xo, ml = bML + xm, ll = bLL + xl;
-                        // repeat-offset rules, branch-free
+                        u32 const val = base + xv;
+                        u32 const ofv = kx_bcast(val, 0), ml = kx_bcast(val, 1), ll = kx_bcast(val, 2);
+                        // repeat-offset rules
                         bool const isRep = ofv <= 3;
                         u32 const idx = ofv - 1 + (ll == 0);                       // meaningful when isRep
                         u32 const rm1 = (rep1 - 1) ? rep1 - 1 : 1u;
@@ -598,11 +615,11 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                         u32 const off = isRep ? roff : ofv - 3;
                         bool const sh2 = !isRep || idx >= 2, sh1 = !isRep || idx >= 1;
                         rep3 = sh2 ? rep2 : rep3; rep2 = sh1 ? rep1 : rep2; rep1 = off;
-                        lds.u.q.stage[3 * i] = ll; lds.u.q.stage[3 * i + 1] = ml; lds.u.q.stage[3 * i + 2] = off;
-                        sLL = (lLL & 0xFFFu) + yl; sML = (lML & 0xFFFu) + ym; sOF = (lOF & 0xFFFu) + yo;
+                        if (lane == 0) { lds.u.q.stage[3 * i] = ll; lds.u.q.stage[3 * i + 1] = ml; lds.u.q.stage[3 * i + 2] = off; }
+                        st3 = (e & 0xFFFu) + yv;
                     }
                     if (lastChunk && !bad && bitPos != 0) bad = true;
-                    lds.u.q.stage[192] = bad ? 1u : 0u;
+                    if (lane == 0) lds.u.q.stage[192] = bad ? 1u : 0u;
                 }
                 kx_sync();
                 if (lds.u.q.stage[192]) { err = KZE_CORRUPT; break; }

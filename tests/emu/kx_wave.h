@@ -33,6 +33,7 @@ KX_DEV u64 kx_ballot(bool p) { return kxemu::arrive(kxemu::OP_BALLOT, p ? 1 : 0,
 KX_DEV bool kx_any(bool p) { return kx_ballot(p) != 0; }
 KX_DEV bool kx_all(bool p) { return kx_ballot(!p) == 0; }
 KX_DEV u32 kx_shfl(u32 v, int src) { return (u32)kxemu::arrive(kxemu::OP_SHFL, v, (u64)(src & 63)); }
+KX_DEV u32 kx_bcast(u32 v, int k) { return kx_shfl(v, k); }
 KX_DEV void kx_sync() { kxemu::arrive(kxemu::OP_SYNC, 0, 0); }
 KX_DEV void kx_lockstep() { kxemu::arrive(kxemu::OP_SYNC, 1, 0); }
 
