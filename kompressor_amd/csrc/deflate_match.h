@@ -107,7 +107,7 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
 // ---------------------------------------------------------------------------
 #define KD_CHUNK 8192
 #define KD_HIST 32512                                   /* >= MAX_DIST, multiple of 64 */
-struct KdBestLds { u16 lnk[KD_CHUNK + KD_HIST]; u32 sw[(KD_CHUNK + KD_HIST + 272 + 16) / 4]; };   // sw = staged bytes, read as aligned words
+struct KdBestLds { u16 lnk[KD_CHUNK + KD_HIST]; u32 sw[(KD_CHUNK + KD_HIST + 272 + 16) / 4]; u32 next; };   // sw = staged bytes, read as aligned words; next = position counter
 
 // 4 bytes at byte offset `o` of the staged window: two aligned LDS words + a funnel shift
 KX_DEV u32 kd_ld32(const u32* sw, int o) { u32 const a = sw[o >> 2], b = sw[(o >> 2) + 1]; return kx_alignbyte(b, a, (u32)o & 3u); }
@@ -141,52 +141,86 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                     lds.sw[wi] = v;
                 }
             }
+            if (tid == 0) lds.next = (u32)cb;
             kx_block_sync();
-            for (int p = cb + tid; p < hiP; p += nthreads) {
-                KdBest r; r.len128 = 0; r.pos128 = 0; r.len32 = 0; r.pos32 = 0;
-                int const lookahead = n - p;
-                if (lookahead >= KD_MIN_MATCH) {
-                    int const limit = p > KD_MAX_DIST ? p - KD_MAX_DIST : 0;
-                    int c = lds.lnk[p - lo];
-                    if (c != 0 && p - c <= KD_MAX_DIST) {
-                        int const nice = lookahead < 128 ? lookahead : 128;
-                        int const maxlen = lookahead < KD_MAX_MATCH ? lookahead : KD_MAX_MATCH;
-                        int const so = p - lo;                              // scan offset in the staged window
-                        u32 const scan01 = kd_ld32(lds.sw, so) & 0xFFFFu;
-                        int bestLen = 2, bestPos = 0; int steps = 0; bool done = false;
-                        u32 scanEnd = kd_ld32(lds.sw, so + 1) & 0xFFFFu;      // scan[best-1], scan[best]
-                        do {
-                            int const mo = c - lo;
-                            int const cnext = lds.lnk[mo];                       // next hop requested before this one is judged
-                            steps++;
-                            // the candidate can only win if it matches at the current best length too (most fail here)
-                            u32 const mEnd = kd_ld32(lds.sw, mo + bestLen - 1) & 0xFFFFu;
-                            bool const endOk = (bestLen < maxlen) ? (mEnd == scanEnd) : ((mEnd & 0xFFu) == (scanEnd & 0xFFu));
-                            if (endOk && (kd_ld32(lds.sw, mo) & 0xFFFFu) == scan01) {
-                                int len = 2;
-                                if (a.flags & 1u) len = 3; else
-                                for (;;) {                                  // 8 bytes per step
-                                    u64 const d = kd_ld64(lds.sw, mo + len) ^ kd_ld64(lds.sw, so + len);
-                                    if (d) { len += (int)(kx_ctz64(d) >> 3); break; }
-                                    len += 8;
-                                    if (len >= maxlen) break;
+            // Chains have very different lengths (0 .. 128 steps) and a wave that owns 64 fixed positions runs as long as
+            // its longest one.  Instead every lane walks one chain at a time and idle lanes are handed new positions
+            // from a counter as soon as 16 of them are free: a wave step then carries ~56 useful lanes instead of ~30.
+            {
+                bool active = false, drained = false;
+                int p = 0, c = 0, steps = 0, bestLen = 2, bestPos = 0, so = 0, maxlen = 0, nice = 0, limit = 0;
+                u32 scan01 = 0, scanEnd = 0; KdBest r; r.len128 = 0; r.pos128 = 0; r.len32 = 0; r.pos32 = 0;
+                int const lane = kx_lane();
+                int const maxSteps = (a.flags & 2u) ? 16 : 128;
+                int const refillAt = (a.flags >> 8) ? (int)(a.flags >> 8) : 16;      // idle lanes that trigger a refill (tuning switch)
+                for (;;) {
+                    u64 const idle = kx_ballot(!active);
+                    int const nidle = (int)kx_popc64(idle);
+                    if (!drained && (nidle >= refillAt)) {
+                        int const first = (int)kx_ctz64(idle);
+                        u32 base = 0;
+                        if (lane == first) base = kx_lds_add(&lds.next, (u32)nidle);
+                        base = kx_shfl(base, first);
+                        if (!active) {
+                            int const np = (int)base + (int)kx_popc64(idle & ((1ull << lane) - 1ull));
+                            if (np < hiP) {
+                                p = np;
+                                r.len128 = 0; r.pos128 = 0; r.len32 = 0; r.pos32 = 0;
+                                int const lookahead = n - p;
+                                bool go = false;
+                                if (lookahead >= KD_MIN_MATCH) {
+                                    limit = p > KD_MAX_DIST ? p - KD_MAX_DIST : 0;
+                                    c = lds.lnk[p - lo];
+                                    if (c != 0 && p - c <= KD_MAX_DIST) {
+                                        nice = lookahead < 128 ? lookahead : 128;
+                                        maxlen = lookahead < KD_MAX_MATCH ? lookahead : KD_MAX_MATCH;
+                                        so = p - lo;                              // scan offset in the staged window
+                                        scan01 = kd_ld32(lds.sw, so) & 0xFFFFu;
+                                        bestLen = 2; bestPos = 0; steps = 0;
+                                        scanEnd = kd_ld32(lds.sw, so + 1) & 0xFFFFu;      // scan[best-1], scan[best]
+                                        go = true;
+                                    }
                                 }
-                                if (len > maxlen) len = maxlen;
-                                if (len > bestLen) {
-                                    bestLen = len; bestPos = c;
-                                    if (len >= nice) done = true;
-                                    else scanEnd = kd_ld32(lds.sw, so + bestLen - 1) & 0xFFFFu;
-                                }
+                                if (go) active = true; else best[p] = r;          // no candidate at all: done already
                             }
-                            if (steps == 32 || (done && steps < 32)) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
-                            if (done) break;
-                            c = cnext;
-                        } while (c > limit && steps < ((a.flags & 2u) ? 16 : 128));
-                        if (steps < 32 && !done) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
-                        r.len128 = (u16)(bestLen > 2 ? bestLen : 0); r.pos128 = (u16)bestPos;
+                        }
+                        if ((int)base + nidle >= hiP) drained = true;
+                    }
+                    if (!kx_any(active)) { if (drained) break; continue; }
+                    if (active) {
+                        int const mo = c - lo;
+                        int const cnext = lds.lnk[mo];
+                        bool done = false;
+                        steps++;
+                        // the candidate can only win if it matches at the current best length too (most fail here)
+                        u32 const mEnd = kd_ld32(lds.sw, mo + bestLen - 1) & 0xFFFFu;
+                        bool const endOk = (bestLen < maxlen) ? (mEnd == scanEnd) : ((mEnd & 0xFFu) == (scanEnd & 0xFFu));
+                        if (endOk && (kd_ld32(lds.sw, mo) & 0xFFFFu) == scan01) {
+                            int len = 2;
+                            if (a.flags & 1u) len = 3; else
+                            for (;;) {                                  // 8 bytes per step
+                                u64 const d = kd_ld64(lds.sw, mo + len) ^ kd_ld64(lds.sw, so + len);
+                                if (d) { len += (int)(kx_ctz64(d) >> 3); break; }
+                                len += 8;
+                                if (len >= maxlen) break;
+                            }
+                            if (len > maxlen) len = maxlen;
+                            if (len > bestLen) {
+                                bestLen = len; bestPos = c;
+                                if (len >= nice) done = true;
+                                else scanEnd = kd_ld32(lds.sw, so + bestLen - 1) & 0xFFFFu;
+                            }
+                        }
+                        if (steps == 32 || (done && steps < 32)) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
+                        c = cnext;
+                        if (done || !(c > limit && steps < maxSteps)) {
+                            if (steps < 32 && !done) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
+                            r.len128 = (u16)(bestLen > 2 ? bestLen : 0); r.pos128 = (u16)bestPos;
+                            best[p] = r;
+                            active = false;
+                        }
                     }
                 }
-                best[p] = r;
             }
         }
         kx_block_sync();

@@ -60,6 +60,7 @@ KX_DEV void kx_st_nt(u32* p, u32 v) { __builtin_nontemporal_store(v, p); }
 KX_DEV u32 kx_atomic_add(u32* p, u32 v) { return atomicAdd(p, v); }
 KX_DEV void kx_atomic_or(u32* p, u32 v) { atomicOr(p, v); }
 KX_DEV void kx_lds_inc(u32* p) { atomicAdd(p, 1u); }
+KX_DEV u32 kx_lds_add(u32* p, u32 v) { return atomicAdd(p, v); }   // returns the value before
 KX_DEV void kx_lds_or(u32* p, u32 v) { atomicOr(p, v); }
 
 // ---- bit tricks -------------------------------------------------------

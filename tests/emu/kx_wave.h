@@ -50,6 +50,7 @@ KX_DEV void kx_st_nt(u32* p, u32 v) { *p = v; }
 KX_DEV u32 kx_atomic_add(u32* p, u32 v) { u32 o = *p; *p = o + v; return o; }
 KX_DEV void kx_atomic_or(u32* p, u32 v) { *p |= v; }
 KX_DEV void kx_lds_inc(u32* p) { *p += 1; }
+KX_DEV u32 kx_lds_add(u32* p, u32 v) { u32 const o = *p; *p = o + v; return o; }
 KX_DEV void kx_lds_or(u32* p, u32 v) { *p |= v; }
 
 KX_DEV u32 kx_alignbyte(u32 hi, u32 lo, u32 bytes) { return (u32)((((u64)hi << 32) | lo) >> (8 * (bytes & 3))); }
