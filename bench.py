@@ -165,6 +165,16 @@ def main():
         for i in (0, 1, 5, 777 % n, n - 1):
             f = dst[int(out_off[i]):int(out_off[i]) + int(lens[i])].cpu().numpy().tobytes()
             ok = ok and _z.decompress(f, -15) == host[i * SLICE:(i + 1) * SLICE].tobytes()
+        # and back: k_inflate over the streams just written (ZlibDecompressor(ZlibFormat.Raw) batch)
+        cap = torch.full((n,), SLICE, dtype=torch.int32, device=dev)
+        back = torch.empty(n * SLICE + 64, dtype=torch.uint8, device=dev)
+        b.inflate(dst, out_off, out_len, cap, dst=back, out_off=in_off)
+        torch.cuda.synchronize()
+        ti = time.perf_counter()
+        _, _, l2, st = b.inflate(dst, out_off, out_len, cap, dst=back, out_off=in_off)
+        torch.cuda.synchronize()
+        inflate_s = time.perf_counter() - ti
+        inflate_ok = bool(int(st.abs().sum().item()) == 0 and torch.equal(back[: n * SLICE], src))
         t1 = time.perf_counter()
         sample = min(n, 2048)
         for i in range(sample):
@@ -177,8 +187,9 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[4]: {n} x 64 KiB slices, raw DEFLATE level 6 (windowBits 15, memLevel 8)",
-                       "ratio": round(n * SLICE / float(lens.sum()), 4), "inflate_spot_check_ok": ok},
-            "kernels_ms_first_chunk_of_16384": {k: round(v, 3) for k, v in kms.items()},
+                       "ratio": round(n * SLICE / float(lens.sum()), 4), "inflate_spot_check_ok": ok,
+                       "gpu_inflate_GBps": round(n * SLICE / inflate_s / 1e9, 3), "gpu_inflate_roundtrip_ok": inflate_ok},
+            "kernels_ms_first_workspace_chunk": {k: round(v, 3) for k, v in kms.items()},
             "cpu_baseline": {"value": round(cpu, 4), "unit": "GB/s", "cores": 1, "kind": "reference",
                              "sample": f"first {sample} slices, zlib {_z.ZLIB_RUNTIME_VERSION} via Python, one thread"}}), flush=True)
         b.close()

@@ -409,7 +409,10 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->dfl_link) {
-        u32 const chunk = c->max_slices < 16384u ? c->max_slices : 16384u;
+        // workspace for up to 65 536 slices at once (56 GiB of the 288 GB): the lane-per-slice parse kernel is pure latency,
+        // one launch over the whole batch costs what one over a quarter costs
+        u32 const cap = env_u32("KMP_DEFLATE_CHUNK", 65536u);
+        u32 const chunk = c->max_slices < cap ? c->max_slices : cap;
         HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)chunk * 65536u * sizeof(u16)));
         HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)chunk * 65536u * sizeof(KdBest)));
         HIP_TRY(hipMalloc((void**)&c->dfl_syms, (size_t)chunk * 65536u * sizeof(u32)));

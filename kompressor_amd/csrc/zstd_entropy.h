@@ -804,7 +804,7 @@ KX_DEV void kx_cbuf_put(u32* cbuf, u32 pos, u32 v, u32 n)
 // sequences section at dst; returns size, 0 => "emit a raw block instead"
 // `cap`: bytes the section may take before the block is certain to be emitted raw (block size minus the literals
 // section): the writer stops there, so a pathological block can never run past the slice's output room.
-KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSeq, u32 longType, u32 longPos, int lane, u32 cap)
+KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSeq, u32 longType, u32 longPos, int lane, u32 cap, u32 xflags = 0)
 {
     u32 hdr = 0;
     if (lane == 0) {
@@ -854,6 +854,7 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
     // tANS bitstream. Per 64-sequence chunk (walked last -> first): every lane stages one
     // sequence's codes; lanes 0..2 run the LL / OF / ML state chains; then every lane packs
     // its sequence's bits into an LDS buffer at a scanned bit offset; whole words go out.
+    if (xflags & 16u) return 0;                       // timing experiment: tables only
     u8* const streamStart = op;
     u32* const cbuf = lds.u.seq.cbuf;
     for (int i = lane; i < 192; i += 64) cbuf[i] = 0;
@@ -1013,7 +1014,7 @@ KX_DEV void zstd_entropy_slice(const KEntropyArgs& a, KEntropyLds& lds, u32 slic
         bool const suspect = (mm.nbSeq == 0) || (litSize / mm.nbSeq >= 20);
         u32 const litSec = (a.flags & 1u) ? 3u : kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane);
         kx_sync();
-        u32 const seqSec = (a.flags & 2u) ? 0u : kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < n ? n - litSec : 0u);
+        u32 const seqSec = (a.flags & 2u) ? 0u : kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < n ? n - litSec : 0u, a.flags);
         if (seqSec != 0) {
             cSize = litSec + seqSec;
             if (cSize >= n - kx_min_gain(n)) cSize = 0;
