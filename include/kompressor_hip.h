@@ -70,7 +70,8 @@ KMP_API size_t kmp_zstd_compress_stream(kmp_zstd_cctx* cctx,
 KMP_API kmp_zstd_dctx* kmp_zstd_create_dctx(void);
 /* replaces ZSTD_freeDCtx              (Wrapper.cpp:132-140) */
 KMP_API size_t kmp_zstd_free_dctx(kmp_zstd_dctx* dctx);
-/* replaces ZSTD_DCtx_loadDictionary   (Wrapper.cpp:58-73) */
+/* replaces ZSTD_DCtx_loadDictionary   (Wrapper.cpp:58-73): raw-content dictionaries (no zstd dictionary magic) are
+ * served; a formatted dictionary returns (size_t)-40 */
 KMP_API size_t kmp_zstd_dctx_load_dictionary(kmp_zstd_dctx* dctx, const void* dict, size_t dict_size);
 /* replaces ZSTD_decompressStream      (Wrapper.cpp:142-187, call at :178).
  * Returns 0 when a frame is completely decoded and flushed, otherwise a
@@ -154,6 +155,16 @@ KMP_API int kmp_zstd_decompress_batch(kmp_batch_ctx* ctx,
                                       void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                       uint32_t* d_out_len, uint32_t* d_status,
                                       void* hip_stream);
+/* same with a raw-content dictionary shared by all n frames: d_dict[0 .. dict_size) is the history before the first
+ * byte of every frame (what ZSTD_DCtx_loadDictionary gives a decoder for a dictionary without the zstd magic;
+ * reference: ZstdDecompressor(dictionary), Wrapper.cpp:58-73, test ZstdTest.kt:49-65) */
+KMP_API int kmp_zstd_decompress_batch_dict(kmp_batch_ctx* ctx,
+                                           const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                           uint32_t n,
+                                           void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                                           uint32_t* d_out_len, uint32_t* d_status,
+                                           const void* d_dict, uint32_t dict_size,
+                                           void* hip_stream);
 
 /* Raw DEFLATE (RFC 1951) streams as zlib level 6 / windowBits 15 / memLevel 8 / strategy 0 writes
  * them: the batched form of deflateInit2(6, Z_DEFLATED, -15, 8, 0) + deflate(Z_FINISH)

@@ -30,6 +30,7 @@ SIGNATURES = [
     ("kmp_batch_destroy", None, [_P]),
     ("kmp_zstd_compress_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P]),
     ("kmp_zstd_decompress_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P, _P, _P]),
+    ("kmp_zstd_decompress_batch_dict", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P, _P, _P, _c.c_uint32, _P]),
     ("kmp_deflate_bound", _c.c_size_t, [_c.c_size_t]),
     ("kmp_deflate_compress_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P]),
     ("kmp_zlib_compress_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P]),

@@ -77,9 +77,9 @@ class ZstdBatch:
             raise RuntimeError(f"kmp_zstd_compress_batch failed ({rc}): {_lib.last_error()}")
         return dst, out_off, out_len
 
-    def decompress(self, src, in_off, in_len, out_cap, dst=None, out_off=None):
-        """Frames -> slices.  out_cap: int32 device tensor of per-frame capacities.
-        Returns (dst, out_off, out_len, status)."""
+    def decompress(self, src, in_off, in_len, out_cap, dst=None, out_off=None, dictionary=None):
+        """Frames -> slices.  out_cap: int32 device tensor of per-frame capacities.  dictionary: uint8 device tensor
+        with a raw-content dictionary shared by all frames.  Returns (dst, out_off, out_len, status)."""
         n = in_len.numel()
         if out_off is None:
             out_off = torch.cumsum(out_cap.to(torch.int64), 0) - out_cap.to(torch.int64)
@@ -88,9 +88,14 @@ class ZstdBatch:
             dst = torch.empty(total + 64, dtype=torch.uint8, device=self.device)
         out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
         status = torch.zeros(n, dtype=torch.int32, device=self.device)
-        rc = self.lib.kmp_zstd_decompress_batch(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
-                                                _ptr(dst), _ptr(out_off), _ptr(out_cap), _ptr(out_len), _ptr(status),
-                                                self._stream())
+        if dictionary is not None:
+            rc = self.lib.kmp_zstd_decompress_batch_dict(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
+                                                         _ptr(dst), _ptr(out_off), _ptr(out_cap), _ptr(out_len), _ptr(status),
+                                                         _ptr(dictionary), dictionary.numel(), self._stream())
+        else:
+            rc = self.lib.kmp_zstd_decompress_batch(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
+                                                    _ptr(dst), _ptr(out_off), _ptr(out_cap), _ptr(out_len), _ptr(status),
+                                                    self._stream())
         if rc != 0:
             raise RuntimeError(f"kmp_zstd_decompress_batch failed ({rc}): {_lib.last_error()}")
         return dst, out_off, out_len, status

@@ -349,9 +349,9 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     return KMP_OK;
 }
 
-extern "C" int kmp_zstd_decompress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                                         uint32_t n, void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
-                                         uint32_t* d_out_len, uint32_t* d_status, void* hip_stream)
+static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                uint32_t n, void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                                uint32_t* d_out_len, uint32_t* d_status, const void* d_dict, uint32_t dict_size, void* hip_stream)
 {
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_cap || !d_out_len || !d_status))) { g_last_error = "kmp_zstd_decompress_batch: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_decompress_batch: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
@@ -362,12 +362,22 @@ extern "C" int kmp_zstd_decompress_batch(kmp_batch_ctx* c, const void* d_src, co
     d.src = (const u8*)d_src; d.in_off = d_in_off; d.in_len = d_in_len; d.n_slices = n;
     d.dst = (u8*)d_dst; d.out_off = d_out_off; d.out_cap = d_out_cap; d.out_len = d_out_len; d.status = d_status;
     d.lits = c->lits; d.lit_cap = c->lit_cap; d.flags = env_u32("KMP_DECODE_FLAGS", 0);
+    d.dict = (const u8*)d_dict; d.dict_size = d_dict ? dict_size : 0u;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[4], st));
     hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), env_u32("KMP_DECODE_PAD_LDS", 0), st, d);   // padding = occupancy experiment only
     HIP_TRY(hipGetLastError());
     if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[5], st)); c->ev_valid[2] = 1; }
     return KMP_OK;
 }
+
+extern "C" int kmp_zstd_decompress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                         uint32_t n, void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                                         uint32_t* d_out_len, uint32_t* d_status, void* hip_stream)
+{ return zstd_decompress_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_cap, d_out_len, d_status, nullptr, 0, hip_stream); }
+extern "C" int kmp_zstd_decompress_batch_dict(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                              uint32_t n, void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                                              uint32_t* d_out_len, uint32_t* d_status, const void* d_dict, uint32_t dict_size, void* hip_stream)
+{ return zstd_decompress_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_cap, d_out_len, d_status, d_dict, dict_size, hip_stream); }
 
 extern "C" size_t kmp_deflate_bound(size_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 13 + 8; }
 
@@ -729,21 +739,31 @@ extern "C" int kmp_zlib_decompress_stream(kmp_zlib_dstream* z, void* dst, size_t
 struct kmp_zstd_dctx {
     std::vector<u8> in; std::vector<u8> out; size_t out_pos; int stage;   // 0 = collecting a frame, 1 = flushing
     stream_dev dev; u32* d_status;
+    std::vector<u8> dict; u8* d_dict;                  // raw-content dictionary (ZSTD_DCtx_loadDictionary), host copy + device copy
 };
 
 extern "C" kmp_zstd_dctx* kmp_zstd_create_dctx(void)
 {
     kmp_zstd_dctx* d = new (std::nothrow) kmp_zstd_dctx();
     if (!d) return nullptr;
-    d->out_pos = 0; d->stage = 0; memset(&d->dev, 0, sizeof(d->dev)); d->d_status = nullptr;
+    d->out_pos = 0; d->stage = 0; memset(&d->dev, 0, sizeof(d->dev)); d->d_status = nullptr; d->d_dict = nullptr;
     return d;
 }
-extern "C" size_t kmp_zstd_free_dctx(kmp_zstd_dctx* d) { if (d) { stream_dev_free(d->dev); delete d; } return 0; }
+extern "C" size_t kmp_zstd_free_dctx(kmp_zstd_dctx* d) { if (d) { stream_dev_free(d->dev); if (d->d_dict) (void)hipFree(d->d_dict); if (d->d_status) (void)hipFree(d->d_status); delete d; } return 0; }
 extern "C" size_t kmp_zstd_dctx_load_dictionary(kmp_zstd_dctx* d, const void* dict, size_t dict_size)
 {
     if (!d) return KERRC(ZE_GENERIC);
+    // raw-content dictionary: its bytes are the history before every frame decoded by this context (Wrapper.cpp:58-73)
+    if (d->stage != 0 || !d->in.empty()) return KERRC(ZE_stage_wrong);
+    if (d->d_dict) { (void)hipFree(d->d_dict); d->d_dict = nullptr; }
+    d->dict.clear();
     if (dict == nullptr || dict_size == 0) return 0;
-    return KERRC(ZE_parameter_unsupported);
+    if (dict_size >= 8 && memcmp(dict, "\x37\xA4\x30\xEC", 4) == 0) return KERRC(ZE_parameter_unsupported);   // formatted zstd dictionary: CPU library
+    if (dict_size > (8u << 20)) return KERRC(ZE_memory_allocation);
+    d->dict.assign((const u8*)dict, (const u8*)dict + dict_size);
+    if (hipMalloc((void**)&d->d_dict, dict_size + 64) != hipSuccess) { d->d_dict = nullptr; d->dict.clear(); return KERRC(ZE_memory_allocation); }
+    if (hipMemcpy(d->d_dict, d->dict.data(), dict_size, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+    return 0;
 }
 
 // Size of the complete frame at p (n bytes available): 0 = need more input, KERRC(..) = malformed
@@ -806,8 +826,8 @@ extern "C" size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* d, void* dst, size_t
         if (hipMemcpy(s.d_in, d->in.data(), total, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
         if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
         if (hipMemcpy(s.d_len, lens, sizeof(lens), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
-        if (kmp_zstd_decompress_batch(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1,
-                                      d->d_status, d->d_status + 1, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
+        if (kmp_zstd_decompress_batch_dict(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1,
+                                           d->d_status, d->d_status + 1, d->d_dict, (u32)d->dict.size(), nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
         if (hipMemcpy(res, d->d_status, 8, hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
         if (res[1]) return KERRC(res[1]);
         d->out.resize(res[0]);

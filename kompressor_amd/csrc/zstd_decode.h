@@ -21,6 +21,7 @@ struct KDecodeArgs {
     u8* dst; const u64* out_off; const u32* out_cap; u32* out_len; u32* status;
     u8* lits; u32 lit_cap;                 // per frame: decoded literals of one block
     u32 flags;                             // timing-only ablations (results wrong): 1 skip Huffman walk, 2 skip sequences, 4 skip copies
+    const u8* dict; u32 dict_size;         // raw-content dictionary shared by the batch (history before every frame), or null / 0
 };
 
 enum { KZE_GENERIC = 1, KZE_PREFIX = 10, KZE_FRAMEPARAM = 14, KZE_WINDOW = 16, KZE_CORRUPT = 20, KZE_CHECKSUM = 22,
@@ -638,7 +639,8 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                 u32 const lp = litUsed + (sl - ll);           // my literals in the literal buffer
                 u32 const dlit = op + (st - ll - ml);         // where they go
                 u32 const dmat = dlit + ll;                   // where my match goes
-                if (kx_any(own && off > dmat)) { err = KZE_CORRUPT; break; }
+                // a match may start inside the dictionary (the history before the frame's first byte)
+                if (kx_any(own && off > dmat + a.dict_size)) { err = KZE_CORRUPT; break; }
                 // literals: short runs lane-serially (exact length), long runs by the whole wave
                 if (a.flags & 4u) { op += totOut; litUsed += totLit; kx_sync(); done += cnt; continue; }
                 if (own && ll <= 32) {
@@ -657,6 +659,23 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                 for (u64 P = kx_ballot(own); P; ) {
                     int const e = (int)kx_ctz64(P);
                     u32 const mlE = kx_shfl(ml, e), offE = kx_shfl(off, e), dE = kx_shfl(dmat, e);
+                    if (offE > dE) {
+                        // starts in the dictionary: byte k comes from dict[dict_size - (offE - dE) + k] while that is inside
+                        // the dictionary, then from the frame's own output
+                        u32 const inDict = offE - dE; const u8* const dsrc = a.dict + (a.dict_size - inDict);
+                        if (offE >= 64) {
+                            for (u32 base = 0; base < mlE; base += 64) {
+                                u32 const k = base + (u32)lane;
+                                if (k < mlE) dst[dE + k] = (k < inDict) ? dsrc[k] : dst[dE + k - offE];
+                                kx_lockstep();
+                            }
+                        } else if (lane == 0) {
+                            for (u32 k = 0; k < mlE; k++) dst[dE + k] = (k < inDict) ? dsrc[k] : dst[dE + k - offE];
+                        }
+                        kx_lockstep();
+                        P &= P - 1;
+                        continue;
+                    }
                     if (mlE > 32 || offE < 8) {
                         const u8* const ms = dst + dE - offE;
                         if (offE >= 64) {
@@ -678,7 +697,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                         P &= P - 1;
                         continue;
                     }
-                    bool const safe = ((P >> lane) & 1ull) && ml <= 32 && off >= 8 && (lane == e || dmat - off + ml <= dE);
+                    bool const safe = ((P >> lane) & 1ull) && ml <= 32 && off >= 8 && off <= dmat && (lane == e || dmat - off + ml <= dE);
                     if (safe) {
                         const u8* const s_ = dst + dmat - off; u8* const d_ = dst + dmat; u32 k = 0;
                         for (; k + 8 <= ml; k += 8) kx_st64(d_ + k, kx_ld64(s_ + k));

@@ -74,6 +74,27 @@ class LibZstd:
             raise RuntimeError(lib.ZSTD_getErrorName(n).decode())
         return out.raw[:n]
 
+    def compress_with_dict(self, data: bytes, dictionary: bytes, level: int = 3) -> bytes:
+        """What Kompressor's ZstdCompressor(level, dictionary) does: ZSTD_CCtx_loadDictionary on a fresh context
+        (Wrapper.cpp:41-56), then the one-shot compress."""
+        lib = self.lib
+        lib.ZSTD_CCtx_loadDictionary.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        lib.ZSTD_CCtx_loadDictionary.restype = ctypes.c_size_t
+        cctx = lib.ZSTD_createCCtx()
+        try:
+            lib.ZSTD_CCtx_setParameter(cctx, 100, level)
+            r = lib.ZSTD_CCtx_loadDictionary(cctx, dictionary, len(dictionary))
+            if lib.ZSTD_isError(r):
+                raise RuntimeError(lib.ZSTD_getErrorName(r).decode())
+            cap = lib.ZSTD_compressBound(len(data))
+            out = ctypes.create_string_buffer(cap)
+            n = lib.ZSTD_compress2(cctx, out, cap, data, len(data))
+            if lib.ZSTD_isError(n):
+                raise RuntimeError(lib.ZSTD_getErrorName(n).decode())
+            return out.raw[:n]
+        finally:
+            lib.ZSTD_freeCCtx(cctx)
+
     def decompress(self, frame: bytes, out_size: int) -> bytes:
         lib = self.lib
         out = ctypes.create_string_buffer(max(out_size, 1))

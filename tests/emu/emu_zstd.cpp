@@ -129,14 +129,23 @@ int emu_zstd_compress_big(const u8* src, const u64* in_off, const u32* in_len, u
 
 #include "zstd_decode.h"
 extern "C" __attribute__((visibility("default")))
+int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len, u32 n, u32 nblocks,
+                             u8* dst, const u64* out_off, const u32* out_cap, u32* out_len, u32* status, u32 lit_cap,
+                             const u8* dict, u32 dict_size);
+extern "C" __attribute__((visibility("default")))
 int emu_zstd_decompress(const u8* src, const u64* in_off, const u32* in_len, u32 n, u32 nblocks,
                         u8* dst, const u64* out_off, const u32* out_cap, u32* out_len, u32* status, u32 lit_cap)
+{ return emu_zstd_decompress_dict(src, in_off, in_len, n, nblocks, dst, out_off, out_cap, out_len, status, lit_cap, nullptr, 0); }
+extern "C" __attribute__((visibility("default")))
+int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len, u32 n, u32 nblocks,
+                             u8* dst, const u64* out_off, const u32* out_cap, u32* out_len, u32* status, u32 lit_cap,
+                             const u8* dict, u32 dict_size)
 {
     std::vector<u8> lits((size_t)n * lit_cap, 0xEE);
     KDecodeArgs d;
     d.src = src; d.in_off = in_off; d.in_len = in_len; d.n_slices = n;
     d.dst = dst; d.out_off = out_off; d.out_cap = out_cap; d.out_len = out_len; d.status = status;
-    d.lits = lits.data(); d.lit_cap = lit_cap; d.flags = 0;
+    d.lits = lits.data(); d.lit_cap = lit_cap; d.flags = 0; d.dict = dict; d.dict_size = dict ? dict_size : 0;
     kxemu::failed = 0;
     kxemu::launch(nblocks, [&]() { zstd_decode_body(d); });
     return kxemu::failed ? -1 : 0;

@@ -327,7 +327,25 @@ def emu_inflate(streams, caps, zlib_wrapper=False, fmt=None):
     return [out[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)], [int(x) for x in st]
 
 
-def emu_decompress(frames, caps, nblocks=2):
+def dict_cases():
+    """(name, dictionary, plain) triples for the decoder's raw-content dictionary support: the plain text shares
+    material with the dictionary, so libzstd's frames hold matches that start inside it.  Seeded; the frames libzstd
+    1.5.7 made from them are committed in tests/golden/zstd_dict_golden.json (make_golden_dict.py)."""
+    from kompressor_amd import corpus
+    out = []
+    for k, (cls, dsz, psz) in enumerate([("T", 4096, 3000), ("T", 16384, 12000), ("X", 8192, 20000), ("S", 32768, 8000),
+                                        ("B", 2048, 5000), ("T", 65536, 40000), ("D", 1000, 700), ("T", 300, 64)]):
+        base = corpus.make(31000 + k, 1, dsz + psz, mix=ord(cls)).tobytes()
+        d = base[:dsz]
+        # plain = fresh material interleaved with pieces lifted from the dictionary (also from its very start and end)
+        fresh = corpus.make(32000 + k, 1, psz, mix=ord(cls)).tobytes()
+        third = max(1, psz // 3)
+        plain = (d[-min(dsz, 200):] + fresh[:third] + d[:min(dsz, 300)] + fresh[third:2 * third] + d[dsz // 2:dsz // 2 + min(dsz // 2, 500)] + fresh[2 * third:])[:psz]
+        out.append((f"{cls}_{dsz}_{psz}", d, plain))
+    return out
+
+
+def emu_decompress(frames, caps, nblocks=2, dictionary=None):
     n = len(frames)
     lens = np.array([len(f) for f in frames], dtype=np.uint32)
     offs = np.zeros(n, dtype=np.uint64)
@@ -347,7 +365,12 @@ def emu_decompress(frames, caps, nblocks=2):
     out = np.zeros(t + 64, dtype=np.uint8)
     olen = np.zeros(n, dtype=np.uint32)
     st = np.zeros(n, dtype=np.uint32)
-    r = emu().emu_zstd_decompress(_vp(buf), _vp(offs), _vp(lens), n, nblocks, _vp(out), _vp(ooff), _vp(caps), _vp(olen), _vp(st),
-                                  128 * 1024 + 64)
+    if dictionary is not None:
+        dbuf = np.frombuffer(dictionary, dtype=np.uint8).copy()
+        r = emu().emu_zstd_decompress_dict(_vp(buf), _vp(offs), _vp(lens), n, nblocks, _vp(out), _vp(ooff), _vp(caps), _vp(olen), _vp(st),
+                                           128 * 1024 + 64, _vp(dbuf), len(dictionary))
+    else:
+        r = emu().emu_zstd_decompress(_vp(buf), _vp(offs), _vp(lens), n, nblocks, _vp(out), _vp(ooff), _vp(caps), _vp(olen), _vp(st),
+                                      128 * 1024 + 64)
     assert r == 0, f"emulator reported {r}"
     return [out[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)], [int(x) for x in st]

@@ -113,3 +113,19 @@ def test_emulated_multiblock_frames():
     for d, f in zip(small, frames):
         assert f == o.compress(d), len(d)
     assert helpers.sha256(frames[-1]) == rows[pick[-1]]["sha256"]
+
+
+def test_emulated_decoder_with_raw_dictionary():
+    """ZstdDecompressor(dictionary) (Wrapper.cpp:58-73, ZstdTest.kt:49-65): frames libzstd 1.5.7 made with a raw-content
+    dictionary decode with it, and fail (or decode to something else) without it."""
+    import base64
+    import json
+    import os
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "zstd_dict_golden.json")))["rows"]
+    for (name, d, plain), row in zip(helpers.dict_cases(), rows):
+        assert name == row["name"] and helpers.sha256(d) == row["dict_sha256"] and helpers.sha256(plain) == row["plain_sha256"]
+        frame = base64.b64decode(row["frame"])
+        outs, st = helpers.emu_decompress([frame], [len(plain)], dictionary=d)
+        assert st == [0] and outs[0] == plain, name
+        outs, st = helpers.emu_decompress([frame], [len(plain)])
+        assert st[0] != 0 or outs[0] != plain, name            # the reference's test expects a failure without the dictionary

@@ -308,3 +308,32 @@ def test_fuzz_ragged_sizes_against_oracle(batch):
         assert st == [0] * len(big) and back == big
     finally:
         b.close()
+
+
+def test_decoder_with_raw_dictionary(batch):
+    """ZstdDecompressor(dictionary) over frames libzstd 1.5.7 compressed with a raw-content dictionary: batch entry point
+    (one dictionary for the batch) and the streaming entry point; without the dictionary the frames fail."""
+    import json
+    import os
+    from kompressor_amd import ZstdDecompressor
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "zstd_dict_golden.json")))["rows"]
+    for (name, d, plain), row in zip(helpers.dict_cases(), rows):
+        frame = base64.b64decode(row["frame"])
+        lens = torch.tensor([len(frame)] * 3, dtype=torch.int32).cuda()
+        host = np.zeros(3 * 70000 + 64, dtype=np.uint8)
+        for k in range(3):
+            host[k * 70000:k * 70000 + len(frame)] = np.frombuffer(frame, dtype=np.uint8)
+        offs = (torch.arange(3, dtype=torch.int64) * 70000).cuda()
+        cap = torch.full((3,), max(len(plain), 1), dtype=torch.int32).cuda()
+        dd = torch.from_numpy(np.frombuffer(d, dtype=np.uint8).copy()).cuda()
+        out, ooff, olen, st = batch.decompress(torch.from_numpy(host).cuda(), offs, lens, cap, dictionary=dd)
+        torch.cuda.synchronize()
+        out, ooff, olen, st = out.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy(), st.cpu().numpy()
+        for k in range(3):
+            assert int(st[k]) == 0 and out[ooff[k]:ooff[k] + olen[k]].tobytes() == plain, (name, k)
+        assert ZstdDecompressor(dictionary=d).transform_bytes(frame) == plain, name
+        try:
+            wrong = ZstdDecompressor().transform_bytes(frame)
+        except RuntimeError:
+            wrong = None
+        assert wrong != plain, name
