@@ -321,7 +321,7 @@ def main():
         }
         if random_access:
             res["random_access_roofline"] = random_access
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:          # the CPU baseline is a rank-0, N = 1 figure
             sample = min(n, 8192)
             res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()))
         print(json.dumps(res), flush=True)
