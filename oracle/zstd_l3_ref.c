@@ -1252,3 +1252,397 @@ KREF_API size_t kref_zstd_l3_seqstore(const u8* src, size_t srcSize, void* seqsO
     wksp_free(&w); free(tmp);
     return r;
 }
+
+/* ================================================================== */
+/* Compressing with a raw-content dictionary                           */
+/* (Kompressor: ZstdCompressor(level, dictionary) -> loadCompressor-    */
+/* Dictionary, Wrapper.cpp:41-56 = ZSTD_CCtx_loadDictionary, then the   */
+/* one-shot ZSTD_compressStream2(..., ZSTD_e_end)).                     */
+/* libzstd 1.5.7 turns the dictionary into a CDict whose tables are     */
+/* sized for the DICTIONARY (+513 bytes), then either copies those      */
+/* tables into the context and parses with the "extDict" double-fast    */
+/* variant (input above 16 KiB), or attaches the CDict and parses with  */
+/* the "dictMatchState" variant (input up to 16 KiB).  One block        */
+/* (input <= 128 KiB), dictionary of 8 bytes .. 128 KiB.                */
+/* ================================================================== */
+#define KREF_UNKNOWN ((u64)-1)
+typedef struct { u32 W, C, H, mml; } kref_cpar;
+
+static kref_cpar cpar_row(u64 rSize)
+{
+    kref_cpar p;
+    if (rSize <= 16384)       { p.W = 14; p.C = 14; p.H = 15; p.mml = 4; }
+    else if (rSize <= 131072) { p.W = 17; p.C = 15; p.H = 16; p.mml = 5; }
+    else if (rSize <= 262144) { p.W = 18; p.C = 16; p.H = 16; p.mml = 4; }
+    else                      { p.W = 21; p.C = 16; p.H = 17; p.mml = 5; }
+    return p;
+}
+static u32 dict_and_window_log(u32 windowLog, u64 srcSize, u64 dictSize)
+{
+    if (dictSize == 0) return windowLog;
+    {
+        u64 const windowSize = 1ULL << windowLog;
+        u64 const dictAndWindowSize = dictSize + windowSize;
+        if (windowSize >= dictSize + srcSize) return windowLog;
+        if (dictAndWindowSize >= (1ULL << 31)) return 31;
+        return hb32((u32)dictAndWindowSize - 1) + 1;
+    }
+}
+enum { CPM_NOATTACH = 0, CPM_ATTACH = 1, CPM_CREATECDICT = 2 };
+/* ZSTD_adjustCParams_internal */
+static kref_cpar adjust_cpar(kref_cpar p, u64 srcSize, u64 dictSize, int mode)
+{
+    if (mode == CPM_CREATECDICT && dictSize && srcSize == KREF_UNKNOWN) srcSize = 513;
+    if (mode == CPM_ATTACH) dictSize = 0;
+    if (srcSize <= (1ULL << 30) && dictSize <= (1ULL << 30)) {
+        u32 const tSize = (u32)(srcSize + dictSize);
+        u32 const srcLog = (tSize < 64) ? 6 : hb32(tSize - 1) + 1;
+        if (p.W > srcLog) p.W = srcLog;
+    }
+    if (srcSize != KREF_UNKNOWN) {
+        u32 const dawl = dict_and_window_log(p.W, srcSize, dictSize);
+        if (p.H > dawl + 1) p.H = dawl + 1;
+        if (p.C > dawl) p.C -= (p.C - dawl);
+    }
+    if (p.W < 10) p.W = 10;
+    return p;
+}
+/* ZSTD_getCParams_internal(3, srcSizeHint, dictSize, mode) */
+static kref_cpar get_cpar(u64 srcSizeHint, u64 dictSize, int mode)
+{
+    u64 rSize;
+    if (mode == CPM_ATTACH) dictSize = 0;
+    {
+        int const unknown = srcSizeHint == KREF_UNKNOWN;
+        u64 const added = (unknown && dictSize > 0) ? 500 : 0;
+        rSize = (unknown && dictSize == 0) ? KREF_UNKNOWN : srcSizeHint + dictSize + added;
+    }
+    return adjust_cpar(cpar_row(rSize), srcSizeHint, dictSize, mode);
+}
+
+static size_t count_2segments(const u8* ip, const u8* match, const u8* iEnd, const u8* mEnd, const u8* iStart)
+{
+    const u8* const vEnd = (ip + (mEnd - match) < iEnd) ? ip + (mEnd - match) : iEnd;
+    size_t const matchLength = count_eq(ip, match, vEnd);
+    if (match + matchLength != mEnd) return matchLength;
+    return matchLength + count_eq(ip + matchLength, iStart, iEnd);
+}
+static int index_overlap_check(u32 prefixLowestIndex, u32 repIndex) { return ((u32)((prefixLowestIndex - 1) - repIndex) >= 3); }
+
+/* ZSTD_compressBlock_doubleFast_extDict_generic: dictionary = indices [2, 2 + D) behind dictBase, input from index 2 + D */
+static size_t dfast_extdict(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize, const u8* dict, size_t D,
+                            u32* hashLong, u32 hBitsL, u32* hashSmall, u32 hBitsS, u32 mls)
+{
+    const u8* const istart = src; const u8* ip = istart; const u8* anchor = istart;
+    const u8* const iend = istart + srcSize; const u8* const ilimit = iend - 8;
+    u32 const prefixStartIndex = (u32)(IDX0 + D);
+    const u8* const base = src - prefixStartIndex;
+    u32 const dictStartIndex = IDX0;
+    const u8* const prefixStart = base + prefixStartIndex;
+    const u8* const dictBase = dict - IDX0;
+    const u8* const dictStart = dictBase + dictStartIndex;
+    const u8* const dictEnd = dictBase + prefixStartIndex;
+    u32 offset_1 = rep[0], offset_2 = rep[1];
+
+    if (srcSize >= 8) while (ip < ilimit) {
+        size_t const hSmall = hash_short(ip, hBitsS, mls);
+        u32 const matchIndex = hashSmall[hSmall];
+        const u8* const matchBase = matchIndex < prefixStartIndex ? dictBase : base;
+        const u8* match = matchBase + matchIndex;
+        size_t const hLong = hash_long(ip, hBitsL);
+        u32 const matchLongIndex = hashLong[hLong];
+        const u8* const matchLongBase = matchLongIndex < prefixStartIndex ? dictBase : base;
+        const u8* matchLong = matchLongBase + matchLongIndex;
+        u32 const curr = (u32)(ip - base);
+        u32 const repIndex = curr + 1 - offset_1;
+        const u8* const repBase = repIndex < prefixStartIndex ? dictBase : base;
+        const u8* const repMatch = repBase + repIndex;
+        size_t mLength;
+        hashSmall[hSmall] = hashLong[hLong] = curr;
+
+        if ((index_overlap_check(prefixStartIndex, repIndex) & (offset_1 <= curr + 1 - dictStartIndex))
+            && (rd32(repMatch) == rd32(ip + 1))) {
+            const u8* repMatchEnd = repIndex < prefixStartIndex ? dictEnd : iend;
+            mLength = count_2segments(ip + 1 + 4, repMatch + 4, iend, repMatchEnd, prefixStart) + 4;
+            ip++;
+            store_seq(ss, (size_t)(ip - anchor), anchor, 1, mLength);
+        } else {
+            if ((matchLongIndex > dictStartIndex) && (rd64(matchLong) == rd64(ip))) {
+                const u8* const matchEnd = matchLongIndex < prefixStartIndex ? dictEnd : iend;
+                const u8* const lowMatchPtr = matchLongIndex < prefixStartIndex ? dictStart : prefixStart;
+                u32 offset;
+                mLength = count_2segments(ip + 8, matchLong + 8, iend, matchEnd, prefixStart) + 8;
+                offset = curr - matchLongIndex;
+                while (((ip > anchor) & (matchLong > lowMatchPtr)) && (ip[-1] == matchLong[-1])) { ip--; matchLong--; mLength++; }
+                offset_2 = offset_1; offset_1 = offset;
+                store_seq(ss, (size_t)(ip - anchor), anchor, offset + 3, mLength);
+            } else if ((matchIndex > dictStartIndex) && (rd32(match) == rd32(ip))) {
+                size_t const h3 = hash_long(ip + 1, hBitsL);
+                u32 const matchIndex3 = hashLong[h3];
+                const u8* const match3Base = matchIndex3 < prefixStartIndex ? dictBase : base;
+                const u8* match3 = match3Base + matchIndex3;
+                u32 offset;
+                hashLong[h3] = curr + 1;
+                if ((matchIndex3 > dictStartIndex) && (rd64(match3) == rd64(ip + 1))) {
+                    const u8* const matchEnd = matchIndex3 < prefixStartIndex ? dictEnd : iend;
+                    const u8* const lowMatchPtr = matchIndex3 < prefixStartIndex ? dictStart : prefixStart;
+                    mLength = count_2segments(ip + 9, match3 + 8, iend, matchEnd, prefixStart) + 8;
+                    ip++;
+                    offset = curr + 1 - matchIndex3;
+                    while (((ip > anchor) & (match3 > lowMatchPtr)) && (ip[-1] == match3[-1])) { ip--; match3--; mLength++; }
+                } else {
+                    const u8* const matchEnd = matchIndex < prefixStartIndex ? dictEnd : iend;
+                    const u8* const lowMatchPtr = matchIndex < prefixStartIndex ? dictStart : prefixStart;
+                    mLength = count_2segments(ip + 4, match + 4, iend, matchEnd, prefixStart) + 4;
+                    offset = curr - matchIndex;
+                    while (((ip > anchor) & (match > lowMatchPtr)) && (ip[-1] == match[-1])) { ip--; match--; mLength++; }
+                }
+                offset_2 = offset_1; offset_1 = offset;
+                store_seq(ss, (size_t)(ip - anchor), anchor, offset + 3, mLength);
+            } else {
+                ip += ((ip - anchor) >> 8) + 1;
+                continue;
+            }
+        }
+        ip += mLength;
+        anchor = ip;
+        if (ip <= ilimit) {
+            u32 const indexToInsert = curr + 2;
+            hashLong[hash_long(base + indexToInsert, hBitsL)] = indexToInsert;
+            hashLong[hash_long(ip - 2, hBitsL)] = (u32)(ip - 2 - base);
+            hashSmall[hash_short(base + indexToInsert, hBitsS, mls)] = indexToInsert;
+            hashSmall[hash_short(ip - 1, hBitsS, mls)] = (u32)(ip - 1 - base);
+            while (ip <= ilimit) {
+                u32 const current2 = (u32)(ip - base);
+                u32 const repIndex2 = current2 - offset_2;
+                const u8* repMatch2 = repIndex2 < prefixStartIndex ? dictBase + repIndex2 : base + repIndex2;
+                if ((index_overlap_check(prefixStartIndex, repIndex2) & (offset_2 <= current2 - dictStartIndex))
+                    && (rd32(repMatch2) == rd32(ip))) {
+                    const u8* const repEnd2 = repIndex2 < prefixStartIndex ? dictEnd : iend;
+                    size_t const repLength2 = count_2segments(ip + 4, repMatch2 + 4, iend, repEnd2, prefixStart) + 4;
+                    u32 const tmpOffset = offset_2; offset_2 = offset_1; offset_1 = tmpOffset;
+                    store_seq(ss, 0, anchor, 1, repLength2);
+                    hashSmall[hash_short(ip, hBitsS, mls)] = current2;
+                    hashLong[hash_long(ip, hBitsL)] = current2;
+                    ip += repLength2;
+                    anchor = ip;
+                    continue;
+                }
+                break;
+            }
+        }
+    }
+    rep[0] = offset_1; rep[1] = offset_2;
+    return (size_t)(iend - anchor);
+}
+
+/* ZSTD_compressBlock_doubleFast_dictMatchState_generic: the CDict keeps its own (tagged) tables dl / ds; the working
+ * tables start empty; index space as above (dictIndexDelta = 0) */
+static size_t dfast_dms(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize, const u8* dict, size_t D,
+                        u32* hashLong, u32 hBitsL, u32* hashSmall, u32 hBitsS, u32 mls,
+                        const u32* dictHashLong, u32 dictHBitsL, const u32* dictHashSmall, u32 dictHBitsS)
+{
+    const u8* const istart = src; const u8* ip = istart; const u8* anchor = istart;
+    const u8* const iend = istart + srcSize; const u8* const ilimit = iend - 8;
+    u32 const prefixLowestIndex = (u32)(IDX0 + D);
+    const u8* const base = src - prefixLowestIndex;
+    const u8* const prefixLowest = base + prefixLowestIndex;
+    const u8* const dictBase = dict - IDX0;
+    const u8* const dictStart = dictBase + IDX0;
+    const u8* const dictEnd = dictBase + prefixLowestIndex;
+    u32 const dictIndexDelta = 0;
+    u32 const dictAndPrefixLength = (u32)((ip - prefixLowest) + (dictEnd - dictStart));
+    u32 offset_1 = rep[0], offset_2 = rep[1];
+    ip += (dictAndPrefixLength == 0);
+
+    if (srcSize >= 8) while (ip < ilimit) {
+        size_t mLength; u32 offset;
+        size_t const h2 = hash_long(ip, hBitsL);
+        size_t const h = hash_short(ip, hBitsS, mls);
+        size_t const dictHashAndTagL = hash_long(ip, dictHBitsL);
+        size_t const dictHashAndTagS = hash_short(ip, dictHBitsS, mls);
+        u32 const dictMatchIndexAndTagL = dictHashLong[dictHashAndTagL >> 8];
+        u32 const dictMatchIndexAndTagS = dictHashSmall[dictHashAndTagS >> 8];
+        int const dictTagsMatchL = (dictMatchIndexAndTagL & 0xFF) == (dictHashAndTagL & 0xFF);
+        int const dictTagsMatchS = (dictMatchIndexAndTagS & 0xFF) == (dictHashAndTagS & 0xFF);
+        u32 const curr = (u32)(ip - base);
+        u32 const matchIndexL = hashLong[h2];
+        u32 matchIndexS = hashSmall[h];
+        const u8* matchLong = base + matchIndexL;
+        const u8* match = base + matchIndexS;
+        u32 const repIndex = curr + 1 - offset_1;
+        const u8* repMatch = (repIndex < prefixLowestIndex) ? dictBase + (repIndex - dictIndexDelta) : base + repIndex;
+        hashLong[h2] = hashSmall[h] = curr;
+
+        if (index_overlap_check(prefixLowestIndex, repIndex) && (rd32(repMatch) == rd32(ip + 1))) {
+            const u8* repMatchEnd = repIndex < prefixLowestIndex ? dictEnd : iend;
+            mLength = count_2segments(ip + 1 + 4, repMatch + 4, iend, repMatchEnd, prefixLowest) + 4;
+            ip++;
+            store_seq(ss, (size_t)(ip - anchor), anchor, 1, mLength);
+            goto _match_stored;
+        }
+        if ((matchIndexL >= prefixLowestIndex) && (rd64(matchLong) == rd64(ip))) {
+            mLength = count_eq(ip + 8, matchLong + 8, iend) + 8;
+            offset = (u32)(ip - matchLong);
+            while (((ip > anchor) & (matchLong > prefixLowest)) && (ip[-1] == matchLong[-1])) { ip--; matchLong--; mLength++; }
+            goto _match_found;
+        } else if (dictTagsMatchL) {
+            u32 const dictMatchIndexL = dictMatchIndexAndTagL >> 8;
+            const u8* dictMatchL = dictBase + dictMatchIndexL;
+            if (dictMatchL > dictStart && rd64(dictMatchL) == rd64(ip)) {
+                mLength = count_2segments(ip + 8, dictMatchL + 8, iend, dictEnd, prefixLowest) + 8;
+                offset = (u32)(curr - dictMatchIndexL - dictIndexDelta);
+                while (((ip > anchor) & (dictMatchL > dictStart)) && (ip[-1] == dictMatchL[-1])) { ip--; dictMatchL--; mLength++; }
+                goto _match_found;
+            }
+        }
+        if (matchIndexS > prefixLowestIndex) {
+            if (rd32(match) == rd32(ip)) goto _search_next_long;
+        } else if (dictTagsMatchS) {
+            u32 const dictMatchIndexS = dictMatchIndexAndTagS >> 8;
+            match = dictBase + dictMatchIndexS;
+            matchIndexS = dictMatchIndexS + dictIndexDelta;
+            if (match > dictStart && rd32(match) == rd32(ip)) goto _search_next_long;
+        }
+        ip += ((ip - anchor) >> 8) + 1;
+        continue;
+
+_search_next_long:
+        {
+            size_t const hl3 = hash_long(ip + 1, hBitsL);
+            size_t const dictHashAndTagL3 = hash_long(ip + 1, dictHBitsL);
+            u32 const matchIndexL3 = hashLong[hl3];
+            u32 const dictMatchIndexAndTagL3 = dictHashLong[dictHashAndTagL3 >> 8];
+            int const dictTagsMatchL3 = (dictMatchIndexAndTagL3 & 0xFF) == (dictHashAndTagL3 & 0xFF);
+            const u8* matchL3 = base + matchIndexL3;
+            hashLong[hl3] = curr + 1;
+            if ((matchIndexL3 >= prefixLowestIndex) && (rd64(matchL3) == rd64(ip + 1))) {
+                mLength = count_eq(ip + 9, matchL3 + 8, iend) + 8;
+                ip++;
+                offset = (u32)(ip - matchL3);
+                while (((ip > anchor) & (matchL3 > prefixLowest)) && (ip[-1] == matchL3[-1])) { ip--; matchL3--; mLength++; }
+                goto _match_found;
+            } else if (dictTagsMatchL3) {
+                u32 const dictMatchIndexL3 = dictMatchIndexAndTagL3 >> 8;
+                const u8* dictMatchL3 = dictBase + dictMatchIndexL3;
+                if (dictMatchL3 > dictStart && rd64(dictMatchL3) == rd64(ip + 1)) {
+                    mLength = count_2segments(ip + 1 + 8, dictMatchL3 + 8, iend, dictEnd, prefixLowest) + 8;
+                    ip++;
+                    offset = (u32)(curr + 1 - dictMatchIndexL3 - dictIndexDelta);
+                    while (((ip > anchor) & (dictMatchL3 > dictStart)) && (ip[-1] == dictMatchL3[-1])) { ip--; dictMatchL3--; mLength++; }
+                    goto _match_found;
+                }
+            }
+        }
+        if (matchIndexS < prefixLowestIndex) {
+            mLength = count_2segments(ip + 4, match + 4, iend, dictEnd, prefixLowest) + 4;
+            offset = (u32)(curr - matchIndexS);
+            while (((ip > anchor) & (match > dictStart)) && (ip[-1] == match[-1])) { ip--; match--; mLength++; }
+        } else {
+            mLength = count_eq(ip + 4, match + 4, iend) + 4;
+            offset = (u32)(ip - match);
+            while (((ip > anchor) & (match > prefixLowest)) && (ip[-1] == match[-1])) { ip--; match--; mLength++; }
+        }
+
+_match_found:
+        offset_2 = offset_1; offset_1 = offset;
+        store_seq(ss, (size_t)(ip - anchor), anchor, offset + 3, mLength);
+
+_match_stored:
+        ip += mLength;
+        anchor = ip;
+        if (ip <= ilimit) {
+            u32 const indexToInsert = curr + 2;
+            hashLong[hash_long(base + indexToInsert, hBitsL)] = indexToInsert;
+            hashLong[hash_long(ip - 2, hBitsL)] = (u32)(ip - 2 - base);
+            hashSmall[hash_short(base + indexToInsert, hBitsS, mls)] = indexToInsert;
+            hashSmall[hash_short(ip - 1, hBitsS, mls)] = (u32)(ip - 1 - base);
+            while (ip <= ilimit) {
+                u32 const current2 = (u32)(ip - base);
+                u32 const repIndex2 = current2 - offset_2;
+                const u8* repMatch2 = repIndex2 < prefixLowestIndex ? dictBase + repIndex2 - dictIndexDelta : base + repIndex2;
+                if (index_overlap_check(prefixLowestIndex, repIndex2) && (rd32(repMatch2) == rd32(ip))) {
+                    const u8* const repEnd2 = repIndex2 < prefixLowestIndex ? dictEnd : iend;
+                    size_t const repLength2 = count_2segments(ip + 4, repMatch2 + 4, iend, repEnd2, prefixLowest) + 4;
+                    u32 const tmpOffset = offset_2; offset_2 = offset_1; offset_1 = tmpOffset;
+                    store_seq(ss, 0, anchor, 1, repLength2);
+                    hashSmall[hash_short(ip, hBitsS, mls)] = current2;
+                    hashLong[hash_long(ip, hBitsL)] = current2;
+                    ip += repLength2;
+                    anchor = ip;
+                    continue;
+                }
+                break;
+            }
+        }
+    }
+    rep[0] = offset_1; rep[1] = offset_2;
+    return (size_t)(iend - anchor);
+}
+
+/* ZSTD_fillDoubleHashTableForCDict (dtlm_full): tagged entries (index << 8 | tag), tables of 1 << (log + 8) hash bits */
+static void fill_cdict_tables(u32* hashLarge, u32 hLog, u32* hashSmall, u32 cLog, u32 mls, const u8* dict, size_t D, size_t from)
+{
+    const u8* const base = dict - IDX0;
+    const u8* ip = dict + from;
+    const u8* const iend = dict + D - 8;
+    for (; ip + 3 - 1 <= iend; ip += 3) {
+        u32 const curr = (u32)(ip - base); u32 i;
+        for (i = 0; i < 3; ++i) {
+            size_t const smHashAndTag = hash_short(ip + i, cLog + 8, mls);
+            size_t const lgHashAndTag = hash_long(ip + i, hLog + 8);
+            if (i == 0) hashSmall[smHashAndTag >> 8] = ((curr + i) << 8) | (u32)(smHashAndTag & 0xFF);
+            if (i == 0 || hashLarge[lgHashAndTag >> 8] == 0) hashLarge[lgHashAndTag >> 8] = ((curr + i) << 8) | (u32)(lgHashAndTag & 0xFF);
+        }
+    }
+}
+
+/* One-shot level-3 frame with a raw-content dictionary; srcSize <= 128 KiB, 8 <= dictSize <= 128 KiB.
+ * modeOut (optional): 1 = CDict attached (dictMatchState parse), 0 = CDict tables copied (extDict parse). */
+KREF_API size_t kref_zstd_l3_compress_dict(u8* dst, size_t cap, const u8* src, size_t srcSize, const u8* dict, size_t dictSize, int* modeOut)
+{
+    kref_cpar cd, fp; kref_wksp w; seqstore ss; u32 rep[3] = { 1, 4, 8 }; kref_hufstate h0, h1;
+    u32 *dl, *ds; size_t pos, lastLL, litC, seqC, cSize = 0, loaded = dictSize, from = 0; u8* body; int attach;
+    if (srcSize > 131072 || dictSize < 8 || dictSize > 131072 || srcSize == 0) return KERR;
+    if (cap < kref_compress_bound(srcSize)) return KERR;
+    /* CDict: parameters for the dictionary alone, content loaded, tables filled */
+    cd = get_cpar(KREF_UNKNOWN, dictSize, CPM_CREATECDICT);
+    { size_t const maxDict = (size_t)1 << ((cd.H + 3 > cd.C + 1) ? cd.H + 3 : cd.C + 1); if (loaded > maxDict) { from = loaded - maxDict; } }
+    dl = (u32*)calloc((size_t)1 << cd.H, sizeof(u32)); ds = (u32*)calloc((size_t)1 << cd.C, sizeof(u32));
+    if (dictSize - from > 8) fill_cdict_tables(dl, cd.H, ds, cd.C, cd.mml, dict, dictSize, from);
+    attach = srcSize <= 16 * 1024;                        /* attachDictSizeCutoffs[ZSTD_dfast] */
+    if (modeOut) *modeOut = attach;
+    fp = get_cpar(srcSize, dictSize, attach ? CPM_ATTACH : CPM_NOATTACH);      /* the frame's window */
+    pos = write_frame_header(dst, srcSize, fp.W);
+    body = dst + pos + 3;
+    w.seqs = (kref_seq*)malloc(sizeof(kref_seq) * ((128 << 10) / 3 + 8)); w.lits = (u8*)malloc((128 << 10) + 32);
+    memset(&ss, 0, sizeof(ss)); ss.seqs = w.seqs; ss.lits = w.lits;
+    if (srcSize >= 7) {
+        if (attach) {
+            kref_cpar wp = adjust_cpar(cd, srcSize, dictSize, CPM_ATTACH);       /* working tables: resized for the input only */
+            w.hashLong = (u32*)calloc((size_t)1 << wp.H, sizeof(u32)); w.hashSmall = (u32*)calloc((size_t)1 << wp.C, sizeof(u32));
+            lastLL = dfast_dms(&ss, rep, src, srcSize, dict, dictSize, w.hashLong, wp.H, w.hashSmall, wp.C, wp.mml, dl, cd.H + 8, ds, cd.C + 8);
+        } else {
+            size_t i;
+            w.hashLong = (u32*)calloc((size_t)1 << cd.H, sizeof(u32)); w.hashSmall = (u32*)calloc((size_t)1 << cd.C, sizeof(u32));
+            for (i = 0; i < ((size_t)1 << cd.H); i++) w.hashLong[i] = dl[i] >> 8;      /* ZSTD_copyCDictTableIntoCCtx */
+            for (i = 0; i < ((size_t)1 << cd.C); i++) w.hashSmall[i] = ds[i] >> 8;
+            lastLL = dfast_extdict(&ss, rep, src, srcSize, dict, dictSize, w.hashLong, cd.H, w.hashSmall, cd.C, cd.mml);
+        }
+        memcpy(ss.lits + ss.litSize, src + srcSize - lastLL, lastLL); ss.litSize += lastLL;
+        h0.valid = 0; memset(&h0.ct, 0, sizeof(h0.ct));
+        {
+            int const suspect = (ss.nbSeq == 0) || (ss.litSize / ss.nbSeq >= 20);
+            litC = compress_literals(body, cap - pos - 3, ss.lits, ss.litSize, suspect, &h0, &h1);
+            if (litC != KERR) {
+                seqC = compress_sequences(body + litC, cap - pos - 3 - litC, &ss);
+                if (seqC != KERR && seqC != 0) { cSize = litC + seqC; if (cSize >= srcSize - min_gain(srcSize)) cSize = 0; }
+            }
+        }
+        free(w.hashLong); free(w.hashSmall);
+    }
+    free(w.seqs); free(w.lits); free(dl); free(ds);
+    if (cSize == 0) { wr24(dst + pos, 1 + (0 << 1) + (u32)(srcSize << 3)); memcpy(body, src, srcSize); return pos + 3 + srcSize; }
+    wr24(dst + pos, 1 + (2 << 1) + (u32)(cSize << 3));
+    return pos + 3 + cSize;
+}

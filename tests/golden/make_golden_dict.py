@@ -30,9 +30,14 @@ def main():
         assert len(f) < len(z.compress(plain, 3)), name          # the dictionary helps, as in the reference's test
         rows.append({"name": name, "dict_sha256": hashlib.sha256(d).hexdigest(), "plain_sha256": hashlib.sha256(plain).hexdigest(),
                      "plain_size": len(plain), "frame": base64.b64encode(f).decode()})
+    # compress side: length + sha256 of the frame libzstd makes of each seeded (dictionary, plain) pair
+    comp = []
+    for d, plain in helpers.dict_compress_cases():
+        f = z.compress_with_dict(plain, d, 3)
+        comp.append([len(d), len(plain), hashlib.sha256(d + plain).hexdigest()[:16], len(f), hashlib.sha256(f).hexdigest()])
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zstd_dict_golden.json")
     with open(path, "w") as fh:
-        json.dump({"libzstd": "1.5.7", "level": 3, "rows": rows}, fh, separators=(",", ":"))
+        json.dump({"libzstd": "1.5.7", "level": 3, "rows": rows, "compress": comp}, fh, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes", len(rows), "frames")
 
 

@@ -141,6 +141,20 @@ class Oracle:
             raise RuntimeError("oracle: input outside the restatement's scope")
         return o.raw[:n]
 
+    def compress_dict(self, d: bytes, dictionary: bytes):
+        """Frame of ZstdCompressor(3, dictionary) (raw-content dictionary); returns (frame, attached)."""
+        k = self.lib
+        k.kref_zstd_l3_compress_dict.restype = ctypes.c_size_t
+        k.kref_zstd_l3_compress_dict.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                                 ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+        cap = k.kref_compress_bound(len(d)) + 64
+        o = ctypes.create_string_buffer(cap)
+        mode = ctypes.c_int(-1)
+        n = k.kref_zstd_l3_compress_dict(o, cap, d, len(d), dictionary, len(dictionary), ctypes.byref(mode))
+        if n == 2 ** 64 - 1:
+            raise RuntimeError("oracle: input outside the restatement's scope")
+        return o.raw[:n], bool(mode.value)
+
     def params(self, n):
         a = (ctypes.c_uint32 * 4)()
         self.lib.kref_params_l3(n, a)
@@ -342,6 +356,44 @@ def dict_cases():
         third = max(1, psz // 3)
         plain = (d[-min(dsz, 200):] + fresh[:third] + d[:min(dsz, 300)] + fresh[third:2 * third] + d[dsz // 2:dsz // 2 + min(dsz // 2, 500)] + fresh[2 * third:])[:psz]
         out.append((f"{cls}_{dsz}_{psz}", d, plain))
+    return out
+
+
+def dict_compress_cases():
+    """Seeded (dictionary, plain) pairs for the compress side with a dictionary: dictionary sizes 8 B .. 128 KiB, inputs
+    1 B .. 128 KiB on both sides of the 16 KiB attach / copy cut-off; plain text unrelated to the dictionary, equal to
+    it, runs, and mixtures of dictionary pieces and fresh material.  tests/golden/make_golden_dict.py stores what
+    libzstd 1.5.7 makes of them."""
+    import random
+    from kompressor_amd import corpus
+    rng = random.Random(60317)
+    out = []
+    for t in range(160):
+        cls = rng.choice("TXSBDIZR")
+        dsz = rng.choice([8, 12, 33, 255, 777, 3000, 8192, 16384, 16385, 40000, 100000, 131072])
+        psz = rng.randrange(1, 131073) if rng.random() < 0.5 else rng.choice([1, 6, 7, 8, 9, 63, 64, 65, 1024, 16383, 16384, 16385, 16386, 65535, 131071, 131072])
+        r = rng.random()
+        d = corpus.make(rng.randrange(1 << 30), 1, dsz, mix=ord(cls)).tobytes()
+        if r < 0.3:
+            plain = corpus.make(rng.randrange(1 << 30), 1, psz, mix=ord(rng.choice("TXSBDIZR"))).tobytes()
+        elif r < 0.4:
+            plain = (d * (psz // dsz + 1))[:psz]
+        elif r < 0.5:
+            plain = bytes(psz) if rng.random() < 0.5 else (d[-3:] * psz)[:psz]
+        else:
+            fresh = corpus.make(rng.randrange(1 << 30), 1, psz, mix=ord(cls)).tobytes()
+            parts, have = [], 0
+            while have < psz:
+                if rng.random() < 0.5:
+                    a0 = rng.randrange(dsz)
+                    seg = d[a0:a0 + rng.choice([4, 9, 40, 300, 5000])]
+                else:
+                    a0 = rng.randrange(psz)
+                    seg = fresh[a0:a0 + rng.choice([1, 3, 20, 200, 3000])]
+                parts.append(seg)
+                have += len(seg)
+            plain = b"".join(parts)[:psz]
+        out.append((d, plain))
     return out
 
 
