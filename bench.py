@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--slices", type=int, default=65536, help="slices per GPU (BASELINE configs[1]: 65536)")
     ap.add_argument("--team", type=int, default=0, help="lanes per slice in the match kernel (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dict-kib", type=int, default=0,
+                    help="compress with a raw-content dictionary of this many KiB shared by all slices (ZstdCompressor(3, dictionary))")
     ap.add_argument("--slice-kib", type=int, default=64,
                     help="slice size in KiB (64 = BASELINE configs[1]; above 128 the frames have several blocks, up to 2048)")
     ap.add_argument("--mode", choices=["compress", "decompress", "deflate"], default="compress",
@@ -195,8 +197,13 @@ def main():
         b.close()
         return
 
+    dictionary = None
+    if args.dict_kib:
+        dictionary = corpus.make(123456789, 1, args.dict_kib * 1024, mix=ord("T")).tobytes()
+        big = True                      # same reporting as the other one-launch-per-step paths (no per-kernel events)
+
     def step():
-        b.compress(src, in_off, in_len, dst, out_off, out_len)
+        b.compress(src, in_off, in_len, dst, out_off, out_len, dictionary=dictionary)
         if dist is not None:
             return sharding.gather_frame_sizes(out_len, n * world)
         return out_len
@@ -267,12 +274,16 @@ def main():
                "value": round(world * in_bytes / (dt / args.steps) / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u8", "data": "synthetic",
-               "config": {"workload": f"north_star slice-size sweep: {n} x {args.slice_kib} KiB seeded mixed slices per GPU, ZstdCompressor(level=3) "
-                                      "one-shot frames of several blocks, bit-identical to libzstd 1.5.7",
+               "config": {"workload": (f"{n} x {args.slice_kib} KiB seeded mixed slices per GPU, ZstdCompressor(level=3, dictionary of {args.dict_kib} KiB), "
+                                       "bit-identical to libzstd 1.5.7") if dictionary else
+                                      (f"north_star slice-size sweep: {n} x {args.slice_kib} KiB seeded mixed slices per GPU, ZstdCompressor(level=3) "
+                                       "one-shot frames of several blocks, bit-identical to libzstd 1.5.7"),
                           "slices_per_gpu": n, "slice_bytes": SLICE, "ratio": round(in_bytes / frame_bytes, 4)},
                "roofline": {"bound": "hbm", "kernel": "k_zstd_big (one launch per step: every wave walks the block chains of its slices)", "achieved": round(algo_bytes / (ms_step * 1e-3) / 1e9, 2),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}}
-        if not args.no_cpu:
+        if dictionary:
+            res["roofline"]["kernel"] = "k_zstd_match_dict + k_zstd_entropy (one launch each per step)"
+        if not args.no_cpu and not dictionary:
             sample = min(n, max(64, (1 << 29) // SLICE))
             res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()), sample)
         print(json.dumps(res), flush=True)

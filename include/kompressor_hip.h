@@ -53,8 +53,9 @@ KMP_API size_t kmp_zstd_free_cctx(kmp_zstd_cctx* cctx);
 /* replaces ZSTD_CCtx_setParameter     (Wrapper.cpp:29-39). Level 3 (and 0 = default = 3)
  * run on the GPU; other levels return (size_t)-40 "Unsupported parameter". */
 KMP_API size_t kmp_zstd_cctx_set_parameter(kmp_zstd_cctx* cctx, int param, int value);
-/* replaces ZSTD_CCtx_loadDictionary   (Wrapper.cpp:41-56). Dictionaries are out of
- * scope this round: a non-empty dictionary returns (size_t)-40. */
+/* replaces ZSTD_CCtx_loadDictionary   (Wrapper.cpp:41-56). Served:
+ * raw-content dictionaries of 8 .. 130 560 bytes (no zstd dictionary magic) for slices <= 128 KiB; a formatted
+ * dictionary or one outside that range returns (size_t)-40. */
 KMP_API size_t kmp_zstd_cctx_load_dictionary(kmp_zstd_cctx* cctx, const void* dict, size_t dict_size);
 /* replaces ZSTD_compressStream2       (Wrapper.cpp:75-121, call at :112).
  * Same buffer semantics as ZSTD_inBuffer / ZSTD_outBuffer: `*_size` is the
@@ -144,6 +145,17 @@ KMP_API int kmp_zstd_compress_batch(kmp_batch_ctx* ctx,
                                     uint32_t n,
                                     void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                     void* hip_stream);
+
+/* same with a raw-content dictionary shared by all n slices (what ZstdCompressor(level, dictionary) does per slice:
+ * ZSTD_CCtx_loadDictionary, Wrapper.cpp:41-56, then the one-shot compress): frames are the ones libzstd 1.5.7 writes --
+ * its CDict is built here on the host once per dictionary; slices up to 16 KiB are parsed against the attached CDict,
+ * larger ones against its copied tables.  h_dict is HOST memory, 8 .. 130 560 bytes; slices <= 128 KiB. */
+KMP_API int kmp_zstd_compress_batch_dict(kmp_batch_ctx* ctx,
+                                         const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                         uint32_t n,
+                                         void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
+                                         const void* h_dict, uint32_t dict_size,
+                                         void* hip_stream);
 
 /* Inverse: n zstd frames -> n slices.  Frame i is d_src[d_in_off[i] .. +d_in_len[i]);
  * its content goes to d_dst + d_out_off[i] (capacity d_out_cap[i]); d_out_len[i]

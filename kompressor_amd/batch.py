@@ -61,8 +61,9 @@ class ZstdBatch:
         """Launches of each zstd compress kernel in the last batch."""
         return int(self.lib.kmp_batch_last_chunks(self._h))
 
-    def compress(self, src, in_off, in_len, dst=None, out_off=None, out_len=None):
-        """src: uint8 device tensor; in_off int64, in_len int32 device tensors (n each).
+    def compress(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, dictionary=None):
+        """src: uint8 device tensor; in_off int64, in_len int32 device tensors (n each).  dictionary: bytes of a
+        raw-content dictionary shared by all slices (host memory; its tables are built once per dictionary).
         Returns (dst, out_off, out_len): frame i = dst[out_off[i] : out_off[i] + out_len[i]]."""
         n = in_len.numel()
         if dst is None:
@@ -71,8 +72,12 @@ class ZstdBatch:
             out_off = torch.arange(n, dtype=torch.int64, device=self.device) * self.out_stride
         if out_len is None:
             out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
-        rc = self.lib.kmp_zstd_compress_batch(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
-                                              _ptr(dst), _ptr(out_off), _ptr(out_len), self._stream())
+        if dictionary is not None:
+            rc = self.lib.kmp_zstd_compress_batch_dict(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
+                                                       _ptr(dst), _ptr(out_off), _ptr(out_len), bytes(dictionary), len(dictionary), self._stream())
+        else:
+            rc = self.lib.kmp_zstd_compress_batch(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
+                                                  _ptr(dst), _ptr(out_off), _ptr(out_len), self._stream())
         if rc != 0:
             raise RuntimeError(f"kmp_zstd_compress_batch failed ({rc}): {_lib.last_error()}")
         return dst, out_off, out_len

@@ -4,6 +4,8 @@
 #include "kx_wave.h"
 #include "zstd_match.h"
 #include "zstd_entropy.h"
+#include "zstd_match_dict.h"
+#include "zstd_cdict_host.h"
 #include "zstd_decode.h"
 #include "deflate_match.h"
 #include "deflate_encode.h"
@@ -24,6 +26,9 @@
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match(KMatchArgs a) { zstd_match_body<G>(a); }
 __global__ __launch_bounds__(64, 4) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
+// the parse when the context holds a raw-content dictionary
+template <int G>
+__global__ __launch_bounds__(64) void k_zstd_match_dict(KDictArgs a) { zstd_match_dict_body<G>(a); }
 // frames of several blocks (slices above 128 KiB): one block of every unfinished slice per launch
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match_blk(KMatchArgs a) { zstd_match_body<G, true>(a); }
@@ -114,6 +119,8 @@ struct kmp_batch_ctx {
     // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
     u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta;
     // frames of several blocks (max_slice_bytes above 128 KiB): per-slice state carried between the block rounds
+    // raw-content dictionary of the last kmp_zstd_compress_batch_dict call: device copy + CDict tables (built on the host)
+    u8* d_dict; u32* d_dictL; u32* d_dictS; u32 dict_size; u64 dict_hash; u32 cdW, cdH, cdC, cdM;
     int big; int big_G; KFrameState* fstate; u32* hufct; u32* big_tables; u32* remaining; u32* big_counters; u32 last_rounds;
 };
 
@@ -180,6 +187,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch);
     (void)hipFree(c->tables); (void)hipFree(c->team_epoch);
+    (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS);
     (void)hipFree(c->fstate); (void)hipFree(c->hufct); (void)hipFree(c->big_tables); (void)hipFree(c->remaining); (void)hipFree(c->big_counters); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { if (c->evm[i][j]) (void)hipEventDestroy(c->evm[i][j]); if (c->eve[i][j]) (void)hipEventDestroy(c->eve[i][j]); }
@@ -216,6 +224,66 @@ extern "C" int kmp_batch_last_chunks(kmp_batch_ctx* c) { return c ? (int)c->last
 extern "C" size_t kmp_zstd_compress_bound(size_t n)
 {
     return n + (n >> 8) + ((n < (128u << 10)) ? (((128u << 10) - n) >> 11) : 0);
+}
+
+// ---- compressing with a raw-content dictionary ------------------------------------------------------
+// libzstd's CDict for the dictionary: parameters of ZSTD_getCParams(3, unknown source size, dictSize) in
+// "create CDict" mode, then ZSTD_fillDoubleHashTableForCDict over the dictionary (tagged entries: index << 8 | tag).
+extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                            uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
+                                            const void* h_dict, uint32_t dict_size, void* hip_stream)
+{
+    if (!c || !h_dict || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_dict: null argument"; return KMP_ERR_ARG; }
+    if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_dict: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
+    if (c->big) { g_last_error = "kmp_zstd_compress_batch_dict: slices above 128 KiB are not served with a dictionary"; return KMP_ERR_CAPACITY; }
+    if (dict_size < 8 || dict_size > KX_MAX_DICT) { g_last_error = "kmp_zstd_compress_batch_dict: dictionary of 8 .. 130560 bytes expected"; return KMP_ERR_CAPACITY; }
+    if (n == 0) return KMP_OK;
+    hipStream_t const st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(c->device));
+    // (re)build the CDict when the dictionary changed
+    u64 hsh = 1469598103934665603ull; for (u32 i = 0; i < dict_size; i++) { hsh ^= ((const u8*)h_dict)[i]; hsh *= 1099511628211ull; }
+    if (!c->d_dict || c->dict_size != dict_size || c->dict_hash != hsh) {
+        HIP_TRY(hipStreamSynchronize(st));
+        (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS); c->d_dict = nullptr; c->d_dictL = nullptr; c->d_dictS = nullptr;
+        cdict_params(dict_size, &c->cdW, &c->cdC, &c->cdH, &c->cdM);
+        std::vector<u32> tl, ts;
+        cdict_fill(tl, c->cdH, ts, c->cdC, c->cdM, (const u8*)h_dict, dict_size);
+        HIP_TRY(hipMalloc((void**)&c->d_dict, dict_size + 64));
+        HIP_TRY(hipMalloc((void**)&c->d_dictL, tl.size() * 4)); HIP_TRY(hipMalloc((void**)&c->d_dictS, ts.size() * 4));
+        HIP_TRY(hipMemcpy(c->d_dict, h_dict, dict_size, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_dictL, tl.data(), tl.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_dictS, ts.data(), ts.size() * 4, hipMemcpyHostToDevice));
+        c->dict_size = dict_size; c->dict_hash = hsh;
+    }
+    if (c->have_last_match) HIP_TRY(hipStreamWaitEvent(st, c->ev_last_match, 0));
+    HIP_TRY(hipMemsetAsync(c->counter, 0, 4, st));
+    KDictArgs g;
+    g.m.src = (const u8*)d_src; g.m.in_off = d_in_off; g.m.in_len = d_in_len; g.m.n_slices = n;
+    g.m.seqs = c->seqs; g.m.seq_cap = c->seq_cap; g.m.lits = c->lits; g.m.lit_cap = c->lit_cap; g.m.meta = c->meta;
+    g.m.tables = c->tables; g.m.team_epoch = c->team_epoch; g.m.counter = c->counter; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
+    g.dict = c->d_dict; g.dict_size = dict_size; g.dictL = c->d_dictL; g.dictS = c->d_dictS;
+    g.dWindowLog = c->cdW; g.dHashLog = c->cdH; g.dChainLog = c->cdC; g.dMinMatch = c->cdM;
+    u32 const tpw = 64 / (u32)c->G;
+    u32 blocks = (n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
+    switch (c->G) {
+    case 2:  hipLaunchKernelGGL(k_zstd_match_dict<2>, dim3(blocks), dim3(64), 0, st, g); break;
+    case 4:  hipLaunchKernelGGL(k_zstd_match_dict<4>, dim3(blocks), dim3(64), 0, st, g); break;
+    case 8:  hipLaunchKernelGGL(k_zstd_match_dict<8>, dim3(blocks), dim3(64), 0, st, g); break;
+    case 16: hipLaunchKernelGGL(k_zstd_match_dict<16>, dim3(blocks), dim3(64), 0, st, g); break;
+    case 32: hipLaunchKernelGGL(k_zstd_match_dict<32>, dim3(blocks), dim3(64), 0, st, g); break;
+    default: hipLaunchKernelGGL(k_zstd_match_dict<64>, dim3(blocks), dim3(64), 0, st, g); break;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_last_match, st)); c->have_last_match = 1;
+    KEntropyArgs e;
+    e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = d_in_len; e.n_slices = n;
+    e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
+    e.scratch = c->scratch; e.scratch_words = c->scratch_words;
+    e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len; e.flags = 8u;       // literals are gathered by the entropy kernel
+    hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), 0, st, e);
+    HIP_TRY(hipGetLastError());
+    c->last_chunks = 1;
+    return KMP_OK;
 }
 
 // Slices above 128 KiB: frames of several blocks.  Every round runs the match kernel and the frame kernel over
@@ -555,6 +623,7 @@ static void stream_dev_free(stream_dev& s)
 struct kmp_zstd_cctx {
     int level; std::vector<u8> in; std::vector<u8> out; size_t out_pos; int stage;   // 0 = collecting, 1 = flushing
     stream_dev dev;
+    std::vector<u8> dict;                       // raw-content dictionary (ZSTD_CCtx_loadDictionary keeps a copy too)
 };
 
 extern "C" kmp_zstd_cctx* kmp_zstd_create_cctx(void)
@@ -578,8 +647,13 @@ extern "C" size_t kmp_zstd_cctx_set_parameter(kmp_zstd_cctx* c, int param, int v
 extern "C" size_t kmp_zstd_cctx_load_dictionary(kmp_zstd_cctx* c, const void* dict, size_t dict_size)
 {
     if (!c) return KERRC(ZE_GENERIC);
+    if (c->stage != 0 || !c->in.empty()) return KERRC(ZE_stage_wrong);
+    c->dict.clear();
     if (dict == nullptr || dict_size == 0) return 0;
-    return KERRC(ZE_parameter_unsupported);
+    if (dict_size >= 8 && memcmp(dict, "\x37\xA4\x30\xEC", 4) == 0) return KERRC(ZE_parameter_unsupported);   // formatted zstd dictionary: CPU library
+    if (dict_size < 8 || dict_size > KX_MAX_DICT) return KERRC(ZE_parameter_unsupported);
+    c->dict.assign((const u8*)dict, (const u8*)dict + dict_size);
+    return 0;
 }
 
 static size_t run_single_compress(kmp_zstd_cctx* c)
@@ -592,6 +666,11 @@ static size_t run_single_compress(kmp_zstd_cctx* c)
     if (n && hipMemcpy(s.d_in, c->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+    if (!c->dict.empty()) {
+        if (n > KMP_MAX_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);          // frames of several blocks with a dictionary: CPU library
+        if (kmp_zstd_compress_batch_dict(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1,
+                                         c->dict.data(), (u32)c->dict.size(), nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
+    } else
     if (kmp_zstd_compress_batch(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
     if (hipMemcpy(&olen, s.d_len + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
     if (olen == 0 || olen > s.out_cap) return KERRC(ZE_GENERIC);

@@ -129,3 +129,22 @@ def test_emulated_decoder_with_raw_dictionary():
         assert st == [0] and outs[0] == plain, name
         outs, st = helpers.emu_decompress([frame], [len(plain)])
         assert st[0] != 0 or outs[0] != plain, name            # the reference's test expects a failure without the dictionary
+
+
+def test_emulated_compress_with_raw_dictionary():
+    """ZstdCompressor(3, dictionary) (Wrapper.cpp:41-56): the dictionary match kernel (attached CDict up to 16 KiB of
+    input, copied-table variant above) + entropy kernel against the frames of libzstd 1.5.7."""
+    import json
+    import os
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "zstd_dict_golden.json")))["compress"]
+    cases = helpers.dict_compress_cases()
+    picked = 0
+    modes = set()
+    for (d, plain), (dsz, psz, tag, flen, sha) in zip(cases, G):
+        if dsz > 130560 or psz > 40000 or picked >= 28:
+            continue
+        f = helpers.emu_compress_dict([plain], d, G=(4, 2, 8, 16)[picked % 4])[0]
+        assert len(f) == flen and helpers.sha256(f) == sha, (dsz, psz)
+        modes.add(psz <= 16384)
+        picked += 1
+    assert picked == 28 and modes == {True, False}

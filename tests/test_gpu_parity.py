@@ -337,3 +337,48 @@ def test_decoder_with_raw_dictionary(batch):
         except RuntimeError:
             wrong = None
         assert wrong != plain, name
+
+
+def test_compress_with_raw_dictionary(batch):
+    """ZstdCompressor(3, dictionary): every seeded (dictionary, input) pair against the frame libzstd 1.5.7 wrote (both
+    parser variants), a 512-slice batch sharing one dictionary against the oracle, and the reference's dictionaryRoundtrip
+    (ZstdTest.kt:49-65) through the streaming entry points."""
+    import json
+    import os
+    from kompressor_amd import ZstdCompressor, ZstdDecompressor
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "zstd_dict_golden.json")))["compress"]
+    n_checked = 0
+    for (d, plain), (dsz, psz, tag, flen, sha) in zip(helpers.dict_compress_cases(), G):
+        if dsz > 130560:
+            continue
+        src = torch.from_numpy(np.frombuffer(plain + bytes(64), dtype=np.uint8).copy()).cuda()
+        off = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ln = torch.tensor([len(plain)], dtype=torch.int32, device="cuda")
+        dst, ooff, olen = batch.compress(src, off, ln, dictionary=d)
+        torch.cuda.synchronize()
+        f = dst[: int(olen[0])].cpu().numpy().tobytes()
+        assert len(f) == flen and helpers.sha256(f) == sha, (dsz, psz)
+        n_checked += 1
+    assert n_checked >= 140
+    # one dictionary, many slices of both size classes
+    o = helpers.oracle()
+    d = corpus.make(5550, 1, 20000, mix=ord("T")).tobytes()
+    datas = [corpus.make(5600 + i, 1, (65536, 12000, 131072, 300)[i % 4], mix=ord("TXS"[i % 3])).tobytes() for i in range(512)]
+    lens = np.array([len(x) for x in datas], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64)
+    host = np.frombuffer(b"".join(datas) + bytes(64), dtype=np.uint8).copy()
+    dst, ooff, olen = batch.compress(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), dictionary=d)
+    torch.cuda.synchronize()
+    hd, ho, hl = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+    for i, x in enumerate(datas):
+        assert hd[ho[i]:ho[i] + hl[i]].tobytes() == o.compress_dict(x, d)[0], i
+    # dictionaryRoundtrip: smaller with the dictionary, decodes only with it
+    sample = datas[1]
+    with_d = ZstdCompressor(3, dictionary=d).transform_bytes(sample)
+    assert with_d == o.compress_dict(sample, d)[0] and len(with_d) < len(ZstdCompressor(3).transform_bytes(sample))
+    assert ZstdDecompressor(dictionary=d).transform_bytes(with_d) == sample
+    try:
+        wrong = ZstdDecompressor().transform_bytes(with_d)
+    except RuntimeError:
+        wrong = None
+    assert wrong != sample
