@@ -80,6 +80,7 @@ typedef struct {
     u8* lits; size_t litSize;
     int longLengthType;      /* 0 none, 1 literal length, 2 match length */
     size_t longLengthPos;
+    int strategy;            /* 0 = dfast (levels 3), 1 = fast (levels 1, 2): only the encoding-type heuristic looks at it */
 } seqstore;
 
 static void store_seq(seqstore* ss, size_t litLength, const u8* lit, u32 offBase, size_t matchLength)
@@ -928,15 +929,15 @@ static u32 ml_code(u32 mlBase)
 
 enum { set_basic = 0, set_rle = 1, set_compressed = 2, set_repeat = 3 };
 
-static u32 select_encoding(const u32* count, u32 max, size_t mostFrequent, size_t nbSeq, u32 defaultNormLog, int isDefaultAllowed)
+static u32 select_encoding(const u32* count, u32 max, size_t mostFrequent, size_t nbSeq, u32 defaultNormLog, int isDefaultAllowed, int strategy)
 {
     (void)count; (void)max;
     if (mostFrequent == nbSeq) {
         if (isDefaultAllowed && nbSeq <= 2) return set_basic;
         return set_rle;
     }
-    if (isDefaultAllowed) {   /* strategy dfast(2) < lazy */
-        size_t const mult = 10 - 2;
+    if (isDefaultAllowed) {   /* strategy fast(1) / dfast(2) < lazy */
+        size_t const mult = 10 - (size_t)(strategy ? strategy : 2);
         size_t const dynamicFse_nbSeq_min = (((size_t)1 << defaultNormLog) * mult) >> 3;
         if ((nbSeq < dynamicFse_nbSeq_min) || (mostFrequent < (nbSeq >> (defaultNormLog - 1)))) return set_basic;
     }
@@ -1008,20 +1009,20 @@ static size_t compress_sequences(u8* dst, size_t cap, const seqstore* ss)
         u8* const seqHead = op++;
         u32 LLtype, Offtype, MLtype; size_t sz;
         { u32 max = 35; size_t const mf = hist_codes(count, &max, llCode, nbSeq);
-          LLtype = select_encoding(count, max, mf, nbSeq, 6, 1);
+          LLtype = select_encoding(count, max, mf, nbSeq, 6, 1, ss->strategy);
           sz = build_seq_ctable(op, (size_t)(oend - op), &ctLL, 9, LLtype, count, max, llCode, nbSeq, LL_defaultNorm, 6, 35);
           if (sz == KERR) { free(llCode); return KERR; }
           if (LLtype == set_compressed) lastCountSize = sz;
           op += sz; }
         { u32 max = 31; size_t const mf = hist_codes(count, &max, ofCode, nbSeq);
           int const defaultAllowed = (max <= 28);
-          Offtype = select_encoding(count, max, mf, nbSeq, 5, defaultAllowed);
+          Offtype = select_encoding(count, max, mf, nbSeq, 5, defaultAllowed, ss->strategy);
           sz = build_seq_ctable(op, (size_t)(oend - op), &ctOF, 8, Offtype, count, max, ofCode, nbSeq, OF_defaultNorm, 5, 28);
           if (sz == KERR) { free(llCode); return KERR; }
           if (Offtype == set_compressed) lastCountSize = sz;
           op += sz; }
         { u32 max = 52; size_t const mf = hist_codes(count, &max, mlCode, nbSeq);
-          MLtype = select_encoding(count, max, mf, nbSeq, 6, 1);
+          MLtype = select_encoding(count, max, mf, nbSeq, 6, 1, ss->strategy);
           sz = build_seq_ctable(op, (size_t)(oend - op), &ctML, 9, MLtype, count, max, mlCode, nbSeq, ML_defaultNorm, 6, 52);
           if (sz == KERR) { free(llCode); return KERR; }
           if (MLtype == set_compressed) lastCountSize = sz;
@@ -1642,6 +1643,172 @@ KREF_API size_t kref_zstd_l3_compress_dict(u8* dst, size_t cap, const u8* src, s
         free(w.hashLong); free(w.hashSmall);
     }
     free(w.seqs); free(w.lits); free(dl); free(ds);
+    if (cSize == 0) { wr24(dst + pos, 1 + (0 << 1) + (u32)(srcSize << 3)); memcpy(body, src, srcSize); return pos + 3 + srcSize; }
+    wr24(dst + pos, 1 + (2 << 1) + (u32)(cSize << 3));
+    return pos + 3 + cSize;
+}
+
+
+/* ================================================================== */
+/* Levels 1 and 2: strategy "fast" (one hash table), slices <= 128 KiB  */
+/* (Ktor's ZstdContentEncoder default is level 1: kompressor-zstd-ktor  */
+/* ZstdContentEncoder.kt:11).                         */
+/* libzstd 1.5.7 ZSTD_compressBlock_fast_noDict_generic: positions are  */
+/* searched in adjacent pairs, the repcode is tried two positions ahead */
+/* of the first of a pair, the pair distance grows after 128 bytes      */
+/* without a match.                                                     */
+/* ================================================================== */
+KREF_API void kref_params_fast(int level, size_t srcSize, u32* out4)   /* windowLog, (unused), hashLog, minMatch */
+{
+    u32 W, H, mml;
+    if (level == 1) {
+        if (srcSize <= 16384)        { W = 14; H = 15; mml = 5; }
+        else if (srcSize <= 131072)  { W = 17; H = 13; mml = 6; }
+        else if (srcSize <= 262144)  { W = 18; H = 14; mml = 6; }
+        else                         { W = 19; H = 14; mml = 7; }
+    } else {
+        if (srcSize <= 16384)        { W = 14; H = 15; mml = 4; }
+        else if (srcSize <= 131072)  { W = 17; H = 15; mml = 5; }
+        else if (srcSize <= 262144)  { W = 18; H = 14; mml = 5; }
+        else                         { W = 20; H = 16; mml = 6; }
+    }
+    {
+        u32 const srcLog = (srcSize < 64) ? 6 : hb32((u32)(srcSize - 1)) + 1;
+        if (W > srcLog) W = srcLog;
+        if (H > W + 1) H = W + 1;
+        if (W < 10) W = 10;
+    }
+    out4[0] = W; out4[1] = 0; out4[2] = H; out4[3] = mml;
+}
+
+static size_t fast_block(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize, u32* hashTable, u32 hlog, u32 mls)
+{
+    const u8* const base = src - IDX0;
+    const u8* const istart = src;
+    u32 const prefixStartIndex = IDX0;
+    const u8* const prefixStart = base + prefixStartIndex;
+    const u8* const iend = istart + srcSize;
+    const u8* const ilimit = iend - 8;
+    const u8* anchor = istart; const u8* ip0 = istart; const u8 *ip1, *ip2, *ip3;
+    u32 current0 = 0;
+    u32 rep_offset1 = rep[0], rep_offset2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0;
+    size_t hash0, hash1; u32 matchIdx; u32 offcode; const u8* match0; size_t mLength;
+    size_t const stepSize = 2; size_t step; const u8* nextStep; size_t const kStepIncr = 1 << 7;
+
+    if (srcSize < 8) return srcSize;
+    ip0 += (ip0 == prefixStart);
+    {
+        u32 const curr = (u32)(ip0 - base); u32 const maxRep = curr - prefixStartIndex;
+        if (rep_offset2 > maxRep) { offsetSaved2 = rep_offset2; rep_offset2 = 0; }
+        if (rep_offset1 > maxRep) { offsetSaved1 = rep_offset1; rep_offset1 = 0; }
+    }
+_start:
+    step = stepSize;
+    nextStep = ip0 + kStepIncr;
+    ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
+    if (ip3 >= ilimit) goto _cleanup;
+    hash0 = hash_short(ip0, hlog, mls);
+    hash1 = hash_short(ip1, hlog, mls);
+    matchIdx = hashTable[hash0];
+    do {
+        u32 const rval = rd32(ip2 - rep_offset1);
+        current0 = (u32)(ip0 - base);
+        hashTable[hash0] = current0;
+        if ((rd32(ip2) == rval) & (rep_offset1 > 0)) {
+            ip0 = ip2;
+            match0 = ip0 - rep_offset1;
+            mLength = ip0[-1] == match0[-1];
+            ip0 -= mLength; match0 -= mLength;
+            offcode = 1;
+            mLength += 4;
+            hashTable[hash1] = (u32)(ip1 - base);
+            goto _match;
+        }
+        if (matchIdx >= prefixStartIndex && rd32(base + matchIdx) == rd32(ip0)) {
+            hashTable[hash1] = (u32)(ip1 - base);
+            goto _offset;
+        }
+        matchIdx = hashTable[hash1];
+        hash0 = hash1;
+        hash1 = hash_short(ip2, hlog, mls);
+        ip0 = ip1; ip1 = ip2; ip2 = ip3;
+        current0 = (u32)(ip0 - base);
+        hashTable[hash0] = current0;
+        if (matchIdx >= prefixStartIndex && rd32(base + matchIdx) == rd32(ip0)) {
+            if (step <= 4) hashTable[hash1] = (u32)(ip1 - base);
+            goto _offset;
+        }
+        matchIdx = hashTable[hash1];
+        hash0 = hash1;
+        hash1 = hash_short(ip2, hlog, mls);
+        ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+        if (ip2 >= nextStep) { step++; nextStep += kStepIncr; }
+    } while (ip3 < ilimit);
+
+_cleanup:
+    offsetSaved2 = ((offsetSaved1 != 0) && (rep_offset1 != 0)) ? offsetSaved1 : offsetSaved2;
+    rep[0] = rep_offset1 ? rep_offset1 : offsetSaved1;
+    rep[1] = rep_offset2 ? rep_offset2 : offsetSaved2;
+    return (size_t)(iend - anchor);
+
+_offset:
+    match0 = base + matchIdx;
+    rep_offset2 = rep_offset1;
+    rep_offset1 = (u32)(ip0 - match0);
+    offcode = rep_offset1 + 3;
+    mLength = 4;
+    while (((ip0 > anchor) & (match0 > prefixStart)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
+
+_match:
+    mLength += count_eq(ip0 + mLength, match0 + mLength, iend);
+    store_seq(ss, (size_t)(ip0 - anchor), anchor, offcode, mLength);
+    ip0 += mLength;
+    anchor = ip0;
+    if (ip0 <= ilimit) {
+        hashTable[hash_short(base + current0 + 2, hlog, mls)] = current0 + 2;
+        hashTable[hash_short(ip0 - 2, hlog, mls)] = (u32)(ip0 - 2 - base);
+        if (rep_offset2 > 0) {
+            while ((ip0 <= ilimit) && (rd32(ip0) == rd32(ip0 - rep_offset2))) {
+                size_t const rLength = count_eq(ip0 + 4, ip0 + 4 - rep_offset2, iend) + 4;
+                { u32 const tmpOff = rep_offset2; rep_offset2 = rep_offset1; rep_offset1 = tmpOff; }
+                hashTable[hash_short(ip0, hlog, mls)] = (u32)(ip0 - base);
+                ip0 += rLength;
+                store_seq(ss, 0, anchor, 1, rLength);
+                anchor = ip0;
+            }
+        }
+    }
+    goto _start;
+}
+
+/* One-shot frame at level 1 or 2 (strategy fast), srcSize <= 128 KiB (one block). */
+KREF_API size_t kref_zstd_fast_compress(u8* dst, size_t cap, const u8* src, size_t srcSize, int level)
+{
+    u32 P[4]; kref_wksp w; seqstore ss; u32 rep[3] = { 1, 4, 8 }; kref_hufstate h0, h1;
+    size_t pos, lastLL, litC, seqC, cSize = 0; u8* body;
+    if (srcSize > 131072 || (level != 1 && level != 2)) return KERR;
+    if (cap < kref_compress_bound(srcSize)) return KERR;
+    kref_params_fast(level, srcSize, P);
+    pos = write_frame_header(dst, srcSize, P[0]);
+    if (srcSize == 0) { wr24(dst + pos, 1); return pos + 3; }
+    body = dst + pos + 3;
+    w.hashLong = (u32*)calloc((size_t)1 << P[2], sizeof(u32));
+    w.seqs = (kref_seq*)malloc(sizeof(kref_seq) * ((128 << 10) / 3 + 8)); w.lits = (u8*)malloc((128 << 10) + 32);
+    memset(&ss, 0, sizeof(ss)); ss.seqs = w.seqs; ss.lits = w.lits; ss.strategy = 1;
+    if (srcSize >= 7) {
+        lastLL = fast_block(&ss, rep, src, srcSize, w.hashLong, P[2], P[3]);
+        memcpy(ss.lits + ss.litSize, src + srcSize - lastLL, lastLL); ss.litSize += lastLL;
+        h0.valid = 0; memset(&h0.ct, 0, sizeof(h0.ct));
+        {
+            int const suspect = (ss.nbSeq == 0) || (ss.litSize / ss.nbSeq >= 20);
+            litC = compress_literals(body, cap - pos - 3, ss.lits, ss.litSize, suspect, &h0, &h1);
+            if (litC != KERR) {
+                seqC = compress_sequences(body + litC, cap - pos - 3 - litC, &ss);
+                if (seqC != KERR && seqC != 0) { cSize = litC + seqC; if (cSize >= srcSize - min_gain(srcSize)) cSize = 0; }
+            }
+        }
+    }
+    free(w.hashLong); free(w.seqs); free(w.lits);
     if (cSize == 0) { wr24(dst + pos, 1 + (0 << 1) + (u32)(srcSize << 3)); memcpy(body, src, srcSize); return pos + 3 + srcSize; }
     wr24(dst + pos, 1 + (2 << 1) + (u32)(cSize << 3));
     return pos + 3 + cSize;

@@ -86,6 +86,11 @@ def parse_frame_blocks(f):
     return out
 
 
+def levels_golden():
+    with open(os.path.join(os.path.dirname(GOLDEN_PATH), "zstd_levels_golden.json")) as fh:
+        return json.load(fh)
+
+
 def multiblock_golden():
     with open(os.path.join(os.path.dirname(GOLDEN_PATH), "zstd_l3_multiblock_golden.json")) as fh:
         return json.load(fh)
@@ -154,6 +159,18 @@ class Oracle:
         if n == 2 ** 64 - 1:
             raise RuntimeError("oracle: input outside the restatement's scope")
         return o.raw[:n], bool(mode.value)
+
+    def compress_level(self, d: bytes, level: int) -> bytes:
+        """Frame at level 1 or 2 (strategy "fast")."""
+        k = self.lib
+        k.kref_zstd_fast_compress.restype = ctypes.c_size_t
+        k.kref_zstd_fast_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+        cap = k.kref_compress_bound(len(d)) + 64
+        o = ctypes.create_string_buffer(cap)
+        n = k.kref_zstd_fast_compress(o, cap, d, len(d), level)
+        if n == 2 ** 64 - 1:
+            raise RuntimeError("oracle: input outside the restatement's scope")
+        return o.raw[:n]
 
     def params(self, n):
         a = (ctypes.c_uint32 * 4)()

@@ -99,6 +99,24 @@ def test_oracle_with_dictionary_matches_golden():
     assert seen == {True, False}
 
 
+def test_oracle_levels_1_and_2_match_golden():
+    """Strategy "fast" (levels 1 and 2; level 1 = the reference's Ktor encoder default, ZstdContentEncoder.kt:11)."""
+    o = helpers.oracle()
+    G = helpers.levels_golden()
+    for S, k, l1, s1, l2, s2 in G["ladder"]:
+        d = corpus.make(1000, 8, S)[k * S:(k + 1) * S].tobytes() if S else b""
+        for lvl, flen, sha in ((1, l1, s1), (2, l2, s2)):
+            f = o.compress_level(d, lvl)
+            assert len(f) == flen and helpers.sha256(f) == sha, (S, k, lvl)
+    S = 65536
+    buf = corpus.make(0, 256, S)
+    for i, l1, s1, l2, s2 in G["config1"]:
+        d = buf[i * S:(i + 1) * S].tobytes()
+        for lvl, flen, sha in ((1, l1, s1), (2, l2, s2)):
+            f = o.compress_level(d, lvl)
+            assert len(f) == flen and helpers.sha256(f) == sha, (i, lvl)
+
+
 def test_params_above_128k():
     o = helpers.oracle()
     expect = {131073: (18, 16, 16, 4), 262144: (18, 16, 16, 4), 262145: (19, 16, 17, 5), 524288: (19, 16, 17, 5),
