@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--slices", type=int, default=65536, help="slices per GPU (BASELINE configs[1]: 65536)")
     ap.add_argument("--team", type=int, default=0, help="lanes per slice in the match kernel (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--level", type=int, default=3, help="zstd level: 3 (BASELINE configs), or 1 / 2 (strategy fast)")
     ap.add_argument("--dict-kib", type=int, default=0,
                     help="compress with a raw-content dictionary of this many KiB shared by all slices (ZstdCompressor(3, dictionary))")
     ap.add_argument("--slice-kib", type=int, default=64,
@@ -202,8 +203,11 @@ def main():
         dictionary = corpus.make(123456789, 1, args.dict_kib * 1024, mix=ord("T")).tobytes()
         big = True                      # same reporting as the other one-launch-per-step paths (no per-kernel events)
 
+    if args.level != 3:
+        big = True
+
     def step():
-        b.compress(src, in_off, in_len, dst, out_off, out_len, dictionary=dictionary)
+        b.compress(src, in_off, in_len, dst, out_off, out_len, dictionary=dictionary, level=args.level)
         if dist is not None:
             return sharding.gather_frame_sizes(out_len, n * world)
         return out_len
@@ -283,7 +287,11 @@ def main():
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}}
         if dictionary:
             res["roofline"]["kernel"] = "k_zstd_match_dict + k_zstd_entropy (one launch each per step)"
-        if not args.no_cpu and not dictionary:
+        if args.level != 3:
+            res["roofline"]["kernel"] = "k_zstd_match_fast + k_zstd_entropy (one launch each per step)"
+            res["config"]["workload"] = f"{n} x {args.slice_kib} KiB seeded mixed slices per GPU, ZstdCompressor(level={args.level}), bit-identical to libzstd 1.5.7"
+            res["metric"] = f"zstd level-{args.level} compression throughput (uncompressed input bytes per second)"
+        if not args.no_cpu and not dictionary and args.level == 3:
             sample = min(n, max(64, (1 << 29) // SLICE))
             res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()), sample)
         print(json.dumps(res), flush=True)

@@ -50,8 +50,8 @@ typedef struct kmp_zstd_dctx kmp_zstd_dctx;
 KMP_API kmp_zstd_cctx* kmp_zstd_create_cctx(void);
 /* replaces ZSTD_freeCCtx              (Wrapper.cpp:19-27)  */
 KMP_API size_t kmp_zstd_free_cctx(kmp_zstd_cctx* cctx);
-/* replaces ZSTD_CCtx_setParameter     (Wrapper.cpp:29-39). Level 3 (and 0 = default = 3)
- * run on the GPU; other levels return (size_t)-40 "Unsupported parameter". */
+/* replaces ZSTD_CCtx_setParameter     (Wrapper.cpp:29-39). Levels 1, 2, 3 (and 0 = default = 3)
+ * run on the GPU (1 and 2: slices <= 128 KiB, no dictionary); other levels return (size_t)-40 "Unsupported parameter". */
 KMP_API size_t kmp_zstd_cctx_set_parameter(kmp_zstd_cctx* cctx, int param, int value);
 /* replaces ZSTD_CCtx_loadDictionary   (Wrapper.cpp:41-56). Served:
  * raw-content dictionaries of 8 .. 130 560 bytes (no zstd dictionary magic) for slices <= 128 KiB; a formatted
@@ -146,6 +146,14 @@ KMP_API int kmp_zstd_compress_batch(kmp_batch_ctx* ctx,
                                     void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                     void* hip_stream);
 
+/* same at another compression level: 1 and 2 (libzstd's one-table "fast" strategy; level 1 is what the reference's Ktor
+ * ZstdContentEncoder asks for, kompressor-zstd-ktor ZstdContentEncoder.kt:11) for slices <= 128 KiB; 3 (or 0) = the
+ * call above.  Frames are the ones libzstd 1.5.7 writes at that level. */
+KMP_API int kmp_zstd_compress_batch_level(kmp_batch_ctx* ctx,
+                                          const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                          uint32_t n,
+                                          void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
+                                          int level, void* hip_stream);
 /* same with a raw-content dictionary shared by all n slices (what ZstdCompressor(level, dictionary) does per slice:
  * ZSTD_CCtx_loadDictionary, Wrapper.cpp:41-56, then the one-shot compress): frames are the ones libzstd 1.5.7 writes --
  * its CDict is built here on the host once per dictionary; slices up to 16 KiB are parsed against the attached CDict,

@@ -5,6 +5,7 @@
 #include "zstd_match.h"
 #include "zstd_entropy.h"
 #include "zstd_match_dict.h"
+#include "zstd_match_fast.h"
 #include "zstd_cdict_host.h"
 #include "zstd_decode.h"
 #include "deflate_match.h"
@@ -26,6 +27,9 @@
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match(KMatchArgs a) { zstd_match_body<G>(a); }
 __global__ __launch_bounds__(64, 4) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
+// levels 1 and 2 (strategy "fast")
+template <int G>
+__global__ __launch_bounds__(64) void k_zstd_match_fast(KFastArgs a) { zstd_match_fast_body<G>(a); }
 // the parse when the context holds a raw-content dictionary
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match_dict(KDictArgs a) { zstd_match_dict_body<G>(a); }
@@ -224,6 +228,48 @@ extern "C" int kmp_batch_last_chunks(kmp_batch_ctx* c) { return c ? (int)c->last
 extern "C" size_t kmp_zstd_compress_bound(size_t n)
 {
     return n + (n >> 8) + ((n < (128u << 10)) ? (((128u << 10) - n) >> 11) : 0);
+}
+
+// ---- levels 1 and 2 -------------------------------------------------------------------------------------
+extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int level, void* hip_stream)
+{
+    if (level == 3 || level == 0) return kmp_zstd_compress_batch(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, hip_stream);
+    if (level != 1 && level != 2) { g_last_error = "kmp_zstd_compress_batch_level: levels 1, 2 and 3 are served"; return KMP_ERR_ARG; }
+    if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_level: null argument"; return KMP_ERR_ARG; }
+    if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_level: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
+    if (c->big) { g_last_error = "kmp_zstd_compress_batch_level: slices above 128 KiB are served at level 3 only"; return KMP_ERR_CAPACITY; }
+    if (n == 0) return KMP_OK;
+    hipStream_t const st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->have_last_match) HIP_TRY(hipStreamWaitEvent(st, c->ev_last_match, 0));
+    HIP_TRY(hipMemsetAsync(c->counter, 0, 4, st));
+    KFastArgs g;
+    g.m.src = (const u8*)d_src; g.m.in_off = d_in_off; g.m.in_len = d_in_len; g.m.n_slices = n;
+    g.m.seqs = c->seqs; g.m.seq_cap = c->seq_cap; g.m.lits = c->lits; g.m.lit_cap = c->lit_cap; g.m.meta = c->meta;
+    g.m.tables = c->tables; g.m.team_epoch = c->team_epoch; g.m.counter = c->counter; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
+    g.level = (u32)level;
+    u32 const tpw = 64 / (u32)c->G;
+    u32 blocks = (n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
+    switch (c->G) {
+    case 2:  hipLaunchKernelGGL(k_zstd_match_fast<2>, dim3(blocks), dim3(64), 0, st, g); break;
+    case 4:  hipLaunchKernelGGL(k_zstd_match_fast<4>, dim3(blocks), dim3(64), 0, st, g); break;
+    case 8:  hipLaunchKernelGGL(k_zstd_match_fast<8>, dim3(blocks), dim3(64), 0, st, g); break;
+    case 16: hipLaunchKernelGGL(k_zstd_match_fast<16>, dim3(blocks), dim3(64), 0, st, g); break;
+    case 32: hipLaunchKernelGGL(k_zstd_match_fast<32>, dim3(blocks), dim3(64), 0, st, g); break;
+    default: hipLaunchKernelGGL(k_zstd_match_fast<64>, dim3(blocks), dim3(64), 0, st, g); break;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_last_match, st)); c->have_last_match = 1;
+    KEntropyArgs e;
+    e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = d_in_len; e.n_slices = n;
+    e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
+    e.scratch = c->scratch; e.scratch_words = c->scratch_words;
+    e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len; e.flags = 8u | 32u;   // gather literals; strategy "fast"
+    hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), 0, st, e);
+    HIP_TRY(hipGetLastError());
+    c->last_chunks = 1;
+    return KMP_OK;
 }
 
 // ---- compressing with a raw-content dictionary ------------------------------------------------------
@@ -640,7 +686,7 @@ extern "C" size_t kmp_zstd_cctx_set_parameter(kmp_zstd_cctx* c, int param, int v
     if (param != KMP_ZSTD_c_compressionLevel) return KERRC(ZE_parameter_unsupported);
     if (c->stage != 0 || !c->in.empty()) return KERRC(ZE_stage_wrong);
     if (value == 0) value = 3;
-    if (value != 3) return KERRC(ZE_parameter_unsupported);
+    if (value < 1 || value > 3) return KERRC(ZE_parameter_unsupported);
     c->level = value;
     return 0;
 }
@@ -666,6 +712,10 @@ static size_t run_single_compress(kmp_zstd_cctx* c)
     if (n && hipMemcpy(s.d_in, c->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+    if (c->level != 3) {
+        if (n > KMP_MAX_SLICE_BYTES || !c->dict.empty()) return KERRC(ZE_parameter_unsupported);   // levels 1, 2: one block, no dictionary
+        if (kmp_zstd_compress_batch_level(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->level, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
+    } else
     if (!c->dict.empty()) {
         if (n > KMP_MAX_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);          // frames of several blocks with a dictionary: CPU library
         if (kmp_zstd_compress_batch_dict(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1,

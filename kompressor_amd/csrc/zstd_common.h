@@ -91,6 +91,14 @@ KX_DEV u32 kx_hash_short(u64 w, u32 hBits, u32 mls)
     return hi >> (32 - hBits);
 }
 
+// minMatch 4..7 (levels 1 and 2 use 5, 6 and 7)
+KX_DEV u32 kx_hash_short_any(u64 w, u32 hBits, u32 mls)
+{
+    if (mls <= 5) return kx_hash_short(w, hBits, mls);
+    if (mls == 6) { u64 const x = w << 16; return kx_mulhi64_hi32((u32)x, (u32)(x >> 32), 0xBCDCBF9Bu, 0xCF1Bu /* 227718039650203 */) >> (32 - hBits); }
+    { u64 const x = w << 8; return kx_mulhi64_hi32((u32)x, (u32)(x >> 32), 0xDCBFA563u, 0xCF1BBCu /* 58295818150454627 */) >> (32 - hBits); }
+}
+
 // 8 bytes at position p of a slice of n bytes without touching bytes >= n
 // (p < n, n >= 8): bytes past the end read as zero.
 KX_DEV u64 kx_ld64_clamped(const u8* src, int p, int n)

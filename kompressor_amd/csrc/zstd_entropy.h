@@ -24,7 +24,7 @@ struct KEntropyArgs {
     u32* scratch; u32 scratch_words;         // per slice: Huffman stream staging (u32 aligned)
     u8* dst; const u64* out_off; u32* out_len;
     u32 flags;                               // timing experiments only (results become wrong): 1 no literal coding, 2 no sequence coding (timing experiments, results become wrong);
-                                             // 8: the match kernel copied no literals, gather them here
+                                             // 8: the match kernel copied no literals, gather them here; 32: strategy "fast" (levels 1, 2)
 };
 
 #define KXE_ERR 0xFFFFFFFFu
@@ -740,11 +740,11 @@ KX_DEV KSeqCodes kx_seq_codes(const KSeq& q, u32 idx, u32 longType, u32 longPos)
 
 enum { KSET_BASIC = 0, KSET_RLE = 1, KSET_COMPRESSED = 2 };
 
-KX_DEV u32 kx_select_encoding(u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, bool isDefaultAllowed)
+KX_DEV u32 kx_select_encoding(u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, bool isDefaultAllowed, u32 mult)
 {
     if (mostFrequent == nbSeq) return (isDefaultAllowed && nbSeq <= 2) ? KSET_BASIC : KSET_RLE;
     if (isDefaultAllowed) {
-        u32 const dynamicFse_nbSeq_min = ((1u << defaultNormLog) * 8u) >> 3;     // strategy dfast: mult = 10 - 2
+        u32 const dynamicFse_nbSeq_min = ((1u << defaultNormLog) * mult) >> 3;   // mult = 10 - strategy: 8 for dfast (level 3), 9 for fast (levels 1, 2)
         if ((nbSeq < dynamicFse_nbSeq_min) || (mostFrequent < (nbSeq >> (defaultNormLog - 1)))) return KSET_BASIC;
     }
     return KSET_COMPRESSED;
@@ -754,7 +754,7 @@ KX_DEV u32 kx_select_encoding(u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, b
 // description into lds.ncbuf[t], build the encoding table. Returns description
 // bytes (KXE_ERR on error).
 KX_DEV u32 kx_build_seq_table(KEntropyLds& lds, int t, u32* count, u32 nbSeq, u32 lastCode, u32 firstCode,
-                              u32& typeOut, KFseCT& ct)
+                              u32& typeOut, KFseCT& ct, u32 mult)
 {
     static const short LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2, 2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
     static const short ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,
@@ -769,7 +769,7 @@ KX_DEV u32 kx_build_seq_table(KEntropyLds& lds, int t, u32* count, u32 nbSeq, u3
     while (max > 0 && !count[max]) max--;
     for (u32 s = 0; s <= max; s++) if (count[s] > mostFrequent) mostFrequent = count[s];
     bool const defaultAllowed = (t != 1) || (max <= 28);
-    u32 const type = kx_select_encoding(mostFrequent, nbSeq, defaultNormLog, defaultAllowed);
+    u32 const type = kx_select_encoding(mostFrequent, nbSeq, defaultNormLog, defaultAllowed, mult);
     typeOut = type;
     ct.state = kxe_state(lds, t); ct.dnb = lds.u.seq.dnb[t]; ct.dfs = lds.u.seq.dfs[t]; ct.tableLog = 0;
     if (type == KSET_RLE) { kfse_build_ctable_rle(ct, max); *op = (u8)firstCode; return 1; }
@@ -831,7 +831,7 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
         if (lane < 3) {
             u32 const lastCode = lane == 0 ? cl.ll : lane == 1 ? cl.of : cl.ml;
             u32 const firstCode = lane == 0 ? cf.ll : lane == 1 ? cf.of : cf.ml;
-            mySz = kx_build_seq_table(lds, lane, lds.hist + 64 * lane, nbSeq, lastCode, firstCode, myType, ct);
+            mySz = kx_build_seq_table(lds, lane, lds.hist + 64 * lane, nbSeq, lastCode, firstCode, myType, ct, (xflags & 32u) ? 9u : 8u);
         }
     }
     kx_sync();

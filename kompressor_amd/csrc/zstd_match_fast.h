@@ -1,0 +1,222 @@
+// zstd_match_fast.h -- the LZ stage of zstd levels 1 and 2 (strategy "fast": one hash table) for slices of at most
+// 128 KiB.  Level 1 is what the reference's Ktor encoder asks for (kompressor-zstd-ktor ZstdContentEncoder.kt:11;
+// SURVEY 8f rank 4); the arithmetic is libzstd 1.5.7's ZSTD_compressBlock_fast_noDict_generic: positions are searched
+// in adjacent pairs (ip0, ip0+1), the repcode is tried at ip0 + step before ip0's own candidate, the pair distance
+// grows by one after every 128 bytes without a match, and which position gets inserted after a hit depends on the
+// phase.  One team of G lanes per slice as in zstd_match.h; the search is not speculative (lane 0 walks the pairs,
+// the team extends matches).  All cross-lane primitives are called from wave-uniform control flow.
+#pragma once
+#include "zstd_match.h"
+
+struct KFastArgs { KMatchArgs m; u32 level; };     // level 1 or 2
+
+// ZSTD_getCParams(level, n, 0) for the fast rows: hashLog, minMatch
+KX_DEV void kx_params_fast(u32 level, u32 n, u32& hashLog, u32& mml)
+{
+    u32 W;
+    if (level == 1) {
+        if (n <= 16384) { W = 14; hashLog = 15; mml = 5; } else { W = 17; hashLog = 13; mml = 6; }
+    } else {
+        if (n <= 16384) { W = 14; hashLog = 15; mml = 4; } else { W = 17; hashLog = 15; mml = 5; }
+    }
+    u32 const srcLog = (n < 64) ? 6 : kx_hb32(n - 1) + 1;
+    if (W > srcLog) W = srcLog;
+    if (hashLog > W + 1) hashLog = W + 1;
+}
+
+enum { KFS_IDLE = 0, KFS_START = 1, KFS_PAIR = 2, KFS_REPLOOP = 3, KFS_MATCH = 4, KFS_CLEANUP = 5, KFS_DONE = 6 };
+
+template <int G>
+KX_DEV void zstd_match_fast_body(const KFastArgs& f)
+{
+    constexpr int NT = 64 / G;
+    const KMatchArgs& a = f.m;
+    int const lane = kx_lane();
+    int const k = lane & (G - 1);
+    int const tbase = lane - k;
+    u32 const team = kx_block() * NT + (u32)(lane / G);
+    u32* const H = a.tables + (size_t)team * KX_TBL_ENTRIES;
+    u64 const tmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+
+    int state = KFS_IDLE;
+    const u8* src = a.src; int n = 0, ilimit = 0; u32 slice = 0;
+    int ip0 = 0, anchor = 0; u32 rep1 = 1, rep2 = 0; u32 nseq = 0, nlit = 0, tag = 0, hlog = 13, mls = 6;
+    int step = 2, gap = 2, nextStep = 0; u32 hash0 = 0, hash1 = 0, matchIdx = 0; int current0 = 0;     // gap = distance from the pair to the next one
+    u32 longType = 0, longPos = 0, guard = 0, status = 0;
+    KSeq* seqs = a.seqs; u64 sq0 = 0, sq1 = 0;
+    int m_start = 0, m_mpos = 0; u32 m_len0 = 0, m_off = 0; bool m_back = false, m_fill = false;
+
+    for (;;) {
+        if (kx_any(state == KFS_IDLE)) {
+            u32 s = 0, ep = 0;
+            if (state == KFS_IDLE && k == 0) {
+                s = kx_atomic_add(a.counter, 1u);
+                if (s < a.n_slices) {
+                    ep = a.team_epoch[team] + 1;
+                    if (ep > KX_EPOCH_MAX) ep = 0;
+                    a.team_epoch[team] = ep ? ep : 1u;
+                }
+            }
+            s = kx_shfl(s, tbase); ep = kx_shfl(ep, tbase);
+            if (state == KFS_IDLE) {
+                if (s >= a.n_slices) state = KFS_DONE;
+                else {
+                    slice = s;
+                    src = a.src + a.in_off[s]; n = (int)a.in_len[s];
+                    seqs = a.seqs + (size_t)s * a.seq_cap;
+                    kx_params_fast(f.level, (u32)n, hlog, mls);
+                    nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = 0;
+                    if (ep == 0) {
+                        for (u32 i = (u32)k; i < KX_TBL_ENTRIES; i += G) H[i] = 0;
+                        ep = 1;
+                    }
+                    tag = ep << KX_IDX_BITS;
+                    anchor = 0; ilimit = n - 8;
+                    ip0 = 1; rep1 = 1; rep2 = 0;             // rep {1,4,8}: 4 exceeds the 1 byte of history at ip0 = 1
+                    state = (n < 8) ? KFS_CLEANUP : KFS_START;
+                }
+            }
+        }
+        if (kx_all(state == KFS_DONE)) break;
+
+        // ================= "_start": a new run of pairs =====================
+        if (kx_any(state == KFS_START)) {
+            if (state == KFS_START) {
+                step = 2; gap = 2; nextStep = ip0 + 128;
+                if (ip0 + 3 >= ilimit) state = KFS_CLEANUP;
+                else {
+                    u32 e = 0, h0 = 0, h1 = 0;
+                    if (k == 0) {
+                        h0 = kx_hash_short_any(kx_ld64(src + ip0), hlog, mls);
+                        h1 = kx_hash_short_any(kx_ld64(src + ip0 + 1), hlog, mls);
+                        e = H[h0];
+                    }
+                    hash0 = h0; hash1 = h1;                  // lane 0's copies are the ones used
+                    matchIdx = ((e & ~KX_IDX_MASK) == tag) ? (e & KX_IDX_MASK) : 0u;
+                    state = KFS_PAIR;
+                }
+            }
+        }
+
+        // ================= one pair (lane 0 of the team walks it) ===========
+        if (kx_any(state == KFS_PAIR)) {
+            bool const pr = state == KFS_PAIR;
+            u32 kind = 0;            // 0 no hit, 1 repcode at ip0 + step, 2 candidate of the pair's first position, 3 of its second
+            int n_ip0 = ip0, n_step = step, n_gap = gap, n_next = nextStep, n_cur = current0; u32 n_mi = matchIdx;
+            if (pr && k == 0) {
+                int ip1 = ip0 + 1, ip2 = ip0 + gap, ip3 = ip2 + 1;
+                u32 const rval = kx_ld32(src + ip2 - (int)rep1);
+                n_cur = ip0;
+                H[hash0] = tag | (u32)(ip0 + 2);
+                if (kx_ld32(src + ip2) == rval && rep1 > 0) { kind = 1; H[hash1] = tag | (u32)(ip1 + 2); n_ip0 = ip2; }
+                else if (matchIdx >= 2u && kx_ld32(src + matchIdx - 2) == kx_ld32(src + ip0)) { kind = 2; H[hash1] = tag | (u32)(ip1 + 2); }
+                else {
+                    u32 e = H[hash1];
+                    u32 mi = ((e & ~KX_IDX_MASK) == tag) ? (e & KX_IDX_MASK) : 0u;
+                    hash0 = hash1; hash1 = kx_hash_short_any(kx_ld64(src + ip2), hlog, mls);
+                    int const q0 = ip1; ip1 = ip2; ip2 = ip3;
+                    n_cur = q0;
+                    H[hash0] = tag | (u32)(q0 + 2);
+                    if (mi >= 2u && kx_ld32(src + mi - 2) == kx_ld32(src + q0)) {
+                        kind = 3; n_ip0 = q0; n_mi = mi;
+                        if (step <= 4) H[hash1] = tag | (u32)(ip1 + 2);
+                    } else {
+                        e = H[hash1];
+                        n_mi = ((e & ~KX_IDX_MASK) == tag) ? (e & KX_IDX_MASK) : 0u;
+                        hash0 = hash1; hash1 = kx_hash_short_any(kx_ld64(src + ip2), hlog, mls);
+                        n_ip0 = ip1;                          // the next pair starts `step` behind this one's second half
+                        n_gap = step;
+                        if (n_ip0 + step >= nextStep) { n_step = step + 1; n_next = nextStep + 128; }
+                    }
+                }
+            }
+            kind = kx_shfl(kind, tbase); n_ip0 = (int)kx_shfl((u32)n_ip0, tbase); n_step = (int)kx_shfl((u32)n_step, tbase);
+            n_next = (int)kx_shfl((u32)n_next, tbase); n_cur = (int)kx_shfl((u32)n_cur, tbase); n_mi = kx_shfl(n_mi, tbase);
+            n_gap = (int)kx_shfl((u32)n_gap, tbase);
+            u32 const mi0 = kx_shfl(matchIdx, tbase);
+            if (pr) {
+                guard++;
+                current0 = n_cur;
+                if (kind == 0) {
+                    // ip0 = old ip2, ip1 = old ip3 = ip0 + 1 again; ip3 of the new pair decides whether the run goes on
+                    ip0 = n_ip0; matchIdx = n_mi; gap = n_gap; step = n_step; nextStep = n_next;
+                    if (!(ip0 + 1 + gap < ilimit)) state = KFS_CLEANUP;
+                    if (guard > 2u * (u32)n + 64u) { status = 1; state = KFS_CLEANUP; }
+                } else if (kind == 1) {
+                    int const mp = n_ip0 - (int)rep1;
+                    bool const b1 = mp >= 1 && src[n_ip0 - 1] == src[mp - 1];
+                    m_start = n_ip0 - (b1 ? 1 : 0); m_mpos = mp - (b1 ? 1 : 0); m_len0 = 4u + (b1 ? 1u : 0u); m_back = false; m_fill = true; m_off = 0;
+                    state = KFS_MATCH;
+                } else {
+                    m_start = n_ip0; m_mpos = (int)((kind == 2) ? mi0 : n_mi) - 2; m_len0 = 4; m_back = true; m_fill = true;
+                    m_off = (u32)(m_start - m_mpos);
+                    state = KFS_MATCH;
+                }
+            }
+        }
+
+        // ================= immediate repcode =================================
+        if (kx_any(state == KFS_REPLOOP)) {
+            bool const inrep = state == KFS_REPLOOP;
+            bool hit = false;
+            if (inrep && ip0 <= ilimit && rep2 > 0) hit = kx_ld32(src + ip0) == kx_ld32(src + ip0 - (int)rep2);
+            if (inrep) {
+                if (hit) {
+                    if (k == 0) H[kx_hash_short_any(kx_ld64(src + ip0), hlog, mls)] = tag | (u32)(ip0 + 2);
+                    u32 const t = rep2; rep2 = rep1; rep1 = t;
+                    m_start = ip0; m_mpos = ip0 - (int)rep1; m_len0 = 4; m_back = false; m_fill = false; m_off = 0;
+                    state = KFS_MATCH;
+                } else state = KFS_START;
+            }
+        }
+
+        // ================= take the match ====================================
+        if (kx_any(state == KFS_MATCH)) {
+            bool const mt = state == KFS_MATCH;
+            u32 lenA = kx_team_extend<G>(mt, src, n, m_start, m_mpos, m_len0, k, tbase, tmask);
+            int const mb = (m_start - anchor < m_mpos) ? m_start - anchor : m_mpos;
+            u32 const back = kx_team_backward<G>(mt && m_back, src, m_start, m_mpos, mb, k, tbase, tmask);
+            if (mt) {
+                u32 offBase = 1;
+                if (m_back) { m_start -= (int)back; lenA += back; rep2 = rep1; rep1 = m_off; offBase = m_off + 3; }
+                int const ll = m_start - anchor;
+                {
+                    u64 const q = (u64)offBase | ((u64)(u16)ll << 32) | ((u64)(u16)(lenA - 3) << 48);   // KSeq
+                    u32 const slot = nseq & (2u * G - 1u);
+                    if ((u32)k == (slot >> 1)) { if (slot & 1u) sq1 = q; else sq0 = q; }
+                    if (slot == 2u * G - 1u) kx_st128(seqs + (nseq - slot) + 2u * (u32)k, sq0, sq1);
+                }
+                if (ll > 0xFFFF) { longType = 1; longPos = nseq; }
+                if (lenA - 3 > 0xFFFF) { longType = 2; longPos = nseq; }
+                nseq++; nlit += (u32)ll;
+                ip0 = m_start + (int)lenA; anchor = ip0;
+                if (m_fill && ip0 <= ilimit && k == 0) {
+                    // fill: current0 + 2 and ip0 - 2
+                    H[kx_hash_short_any(kx_ld64(src + current0 + 2), hlog, mls)] = tag | (u32)(current0 + 2 + 2);
+                    H[kx_hash_short_any(kx_ld64(src + ip0 - 2), hlog, mls)] = tag | (u32)(ip0 - 2 + 2);
+                }
+                if (++guard > 2u * (u32)n + 64u) { status = 2; state = KFS_CLEANUP; }
+                else state = (ip0 <= ilimit) ? KFS_REPLOOP : KFS_START;
+            }
+        }
+
+        // ================= finish the slice ==================================
+        if (kx_any(state == KFS_CLEANUP)) {
+            if (state == KFS_CLEANUP) {
+                {
+                    u32 const cnt = nseq & (2u * G - 1u);
+                    u64* const sp = (u64*)(seqs + (nseq - cnt));
+                    if (2u * (u32)k < cnt) sp[2 * k] = sq0;
+                    if (2u * (u32)k + 1u < cnt) sp[2 * k + 1] = sq1;
+                }
+                if (k == 0) {
+                    KSliceMeta mm;
+                    mm.nbSeq = nseq; mm.litSize = nlit; mm.lastLL = (u32)(n - anchor);
+                    mm.longType = longType; mm.longPos = longPos; mm.status = status; mm.pad[0] = 0; mm.pad[1] = 0;
+                    a.meta[slice] = mm;
+                }
+                state = KFS_IDLE;
+            }
+        }
+    }
+}

@@ -55,6 +55,45 @@ int emu_zstd_compress(const u8* src, const u64* in_off, const u32* in_len, u32 n
     return kxemu::failed ? -1 : 0;
 }
 
+#include "zstd_match_fast.h"
+// Levels 1 and 2 (strategy fast): fast match kernel + entropy kernel on the emulator.
+extern "C" __attribute__((visibility("default")))
+int emu_zstd_compress_level(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
+                            u8* dst, const u64* out_off, u32* out_len, u32 slice_cap, int level)
+{
+    u32 const seq_cap = (slice_cap / 4 + 8 + 15) & ~15u, lit_cap = slice_cap + 64, scratch_words = slice_cap / 4 + 64;
+    std::vector<KSeq> seqs((size_t)n * seq_cap);
+    std::vector<u8> lits((size_t)n * lit_cap, 0xEE);
+    std::vector<KSliceMeta> meta(n);
+    std::vector<u32> scratch((size_t)n * scratch_words, 0xA5A5A5A5u);
+    u32 const nteams = nblocks * (64 / G);
+    std::vector<u32> tables((size_t)nteams * KX_TBL_ENTRIES, 0xDEADBEEFu & 0x0003FFFFu);
+    std::vector<u32> epoch(nteams, 7);
+    u32 counter = 0;
+    KFastArgs g;
+    g.m.src = src; g.m.in_off = in_off; g.m.in_len = in_len; g.m.n_slices = n;
+    g.m.seqs = seqs.data(); g.m.seq_cap = seq_cap; g.m.lits = lits.data(); g.m.lit_cap = lit_cap; g.m.meta = meta.data();
+    g.m.tables = tables.data(); g.m.team_epoch = epoch.data(); g.m.counter = &counter; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
+    g.level = (u32)level;
+    kxemu::failed = 0;
+    switch (G) {
+    case 2:  kxemu::launch(nblocks, [&]() { zstd_match_fast_body<2>(g); }); break;
+    case 4:  kxemu::launch(nblocks, [&]() { zstd_match_fast_body<4>(g); }); break;
+    case 8:  kxemu::launch(nblocks, [&]() { zstd_match_fast_body<8>(g); }); break;
+    case 16: kxemu::launch(nblocks, [&]() { zstd_match_fast_body<16>(g); }); break;
+    default: return -2;
+    }
+    if (kxemu::failed) return -1;
+    for (u32 i = 0; i < n; i++) if (meta[i].status) return -3;
+    KEntropyArgs e;
+    e.src = src; e.in_off = in_off; e.in_len = in_len; e.n_slices = n;
+    e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
+    e.scratch = scratch.data(); e.scratch_words = scratch_words;
+    e.dst = dst; e.out_off = out_off; e.out_len = out_len; e.flags = 8u | 32u;
+    kxemu::launch(nblocks, [&]() { zstd_entropy_body(e); });
+    return kxemu::failed ? -1 : 0;
+}
+
 #include "zstd_match_dict.h"
 #include "zstd_cdict_host.h"
 // Compress with a raw-content dictionary: dictionary match kernel + entropy kernel on the emulator.

@@ -287,6 +287,28 @@ def emu_compress(datas, G=8, nblocks=2):
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
 
 
+def emu_compress_level(datas, level, G=4, nblocks=2):
+    """Levels 1 / 2 (strategy fast): fast match kernel + entropy kernel on the emulator."""
+    n = len(datas)
+    lens = np.array([len(d) for d in datas], dtype=np.uint32)
+    offs = np.zeros(n, dtype=np.uint64)
+    pos = 0
+    for i, d in enumerate(datas):
+        offs[i] = pos
+        pos += len(d)
+    buf = np.zeros(pos + 64, dtype=np.uint8)
+    for i, d in enumerate(datas):
+        buf[int(offs[i]):int(offs[i]) + len(d)] = np.frombuffer(d, dtype=np.uint8)
+    cap = max([len(d) for d in datas] + [64])
+    stride = (compress_bound(cap) + 64 + 15) & ~15
+    out = np.zeros(n * stride, dtype=np.uint8)
+    ooff = np.arange(n, dtype=np.uint64) * stride
+    olen = np.zeros(n, dtype=np.uint32)
+    r = emu().emu_zstd_compress_level(_vp(buf), _vp(offs), _vp(lens), n, G, nblocks, _vp(out), _vp(ooff), _vp(olen), cap, level)
+    assert r == 0, f"emulator reported {r}"
+    return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
+
+
 def emu_compress_dict(datas, dictionary, G=4, nblocks=2):
     """Dictionary match kernel + entropy kernel on the emulator: frames of ZstdCompressor(3, dictionary)."""
     n = len(datas)

@@ -148,3 +148,17 @@ def test_emulated_compress_with_raw_dictionary():
         modes.add(psz <= 16384)
         picked += 1
     assert picked == 28 and modes == {True, False}
+
+
+def test_emulated_levels_1_and_2():
+    """Strategy "fast" (levels 1 and 2): fast match kernel + entropy kernel against the frames of libzstd 1.5.7 (every
+    fifth row of the size ladder, both levels, rotating team widths)."""
+    G = helpers.levels_golden()
+    n = 0
+    for S, k, l1, s1, l2, s2 in G["ladder"][::5]:
+        d = corpus.make(1000, 8, S)[k * S:(k + 1) * S].tobytes() if S else b""
+        for lvl, flen, sha in ((1, l1, s1), (2, l2, s2)):
+            f = helpers.emu_compress_level([d], lvl, G=(4, 2, 8, 16)[n % 4])[0]
+            assert len(f) == flen and helpers.sha256(f) == sha, (S, k, lvl)
+            n += 1
+    assert n == 128

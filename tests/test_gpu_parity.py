@@ -218,6 +218,8 @@ def test_streaming_abi_one_shot_like_the_reference(G):
     # errors surface like the reference's IllegalStateException text
     with pytest.raises(RuntimeError, match="Bad zstd result code -40: Unsupported parameter"):
         ZstdCompressor(compression_level=19)
+    with pytest.raises(RuntimeError, match="Bad zstd result code -40: Unsupported parameter"):
+        ZstdCompressor(compression_level=1).transform_bytes(bytes(131073))      # levels 1, 2: one block
     with pytest.raises(RuntimeError, match="Unknown frame descriptor"):
         ZstdDecompressor().transform_bytes(b"\x00" * 32)
     # sampleRoundtrip (ZstdTest.kt:27-32): 1 MiB + 3 random bytes -> frame of several blocks, and back
@@ -382,3 +384,40 @@ def test_compress_with_raw_dictionary(batch):
     except RuntimeError:
         wrong = None
     assert wrong != sample
+
+
+def test_levels_1_and_2(batch):
+    """ZstdCompressor(level = 1 / 2) (the Ktor encoder's default is 1: ZstdContentEncoder.kt:11): the whole size ladder in
+    one ragged batch and 256 slices of the 64 KiB mix per level against libzstd 1.5.7, decoded back on the GPU, and the
+    streaming entry point."""
+    from kompressor_amd import ZstdCompressor, ZstdDecompressor
+    G = helpers.levels_golden()
+
+    def run(datas, level):
+        n = len(datas)
+        lens = np.array([len(d) for d in datas], dtype=np.int32)
+        offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64) if n > 1 else np.zeros(1, dtype=np.int64)
+        host = np.frombuffer(b"".join(datas) + bytes(64), dtype=np.uint8).copy()
+        dst, ooff, olen = batch.compress(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), level=level)
+        torch.cuda.synchronize()
+        hd, ho, hl = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+        return [hd[ho[i]:ho[i] + hl[i]].tobytes() for i in range(n)]
+
+    ladder = [corpus.make(1000, 8, S)[k * S:(k + 1) * S].tobytes() if S else b"" for S, k, *_ in G["ladder"]]
+    S = 65536
+    buf = corpus.make(0, 256, S)
+    mix = [buf[i * S:(i + 1) * S].tobytes() for i in range(256)]
+    for lvl in (1, 2):
+        frames = run(ladder, lvl)
+        for row, f in zip(G["ladder"], frames):
+            flen, sha = (row[2], row[3]) if lvl == 1 else (row[4], row[5])
+            assert len(f) == flen and helpers.sha256(f) == sha, (row[0], row[1], lvl)
+        back, st = gpu_decompress(batch, frames, [max(len(d), 1) for d in ladder])
+        assert st == [0] * len(frames) and back == ladder
+        frames = run(mix, lvl)
+        for row, f in zip(G["config1"], frames):
+            flen, sha = (row[1], row[2]) if lvl == 1 else (row[3], row[4])
+            assert len(f) == flen and helpers.sha256(f) == sha, (row[0], lvl)
+    o = helpers.oracle()
+    f1 = ZstdCompressor(compression_level=1).transform_bytes(mix[3])
+    assert f1 == o.compress_level(mix[3], 1) and ZstdDecompressor().transform_bytes(f1) == mix[3]
