@@ -95,6 +95,37 @@ class LibZstd:
         finally:
             lib.ZSTD_freeCCtx(cctx)
 
+    def compress_streaming(self, data: bytes, cuts, out_chunk: int = 8192, level: int = 3) -> bytes:
+        """What the reference's streaming callers do (SliceTransformRawSource.kt:32-55): data[cuts[i]:cuts[i+1]] is fed with
+        ZSTD_e_continue (finish = false), the last piece with ZSTD_e_end; output drained through out_chunk-byte buffers."""
+        lib = self.lib
+
+        class Buf(ctypes.Structure):
+            _fields_ = [("p", ctypes.c_void_p), ("size", ctypes.c_size_t), ("pos", ctypes.c_size_t)]
+        lib.ZSTD_compressStream2.argtypes = [ctypes.c_void_p, ctypes.POINTER(Buf), ctypes.POINTER(Buf), ctypes.c_int]
+        lib.ZSTD_compressStream2.restype = ctypes.c_size_t
+        cctx = lib.ZSTD_createCCtx()
+        lib.ZSTD_CCtx_setParameter(cctx, 100, level)
+        src = ctypes.create_string_buffer(data, len(data) + 1)
+        out = ctypes.create_string_buffer(out_chunk)
+        res = bytearray()
+        pieces = list(zip(cuts[:-1], cuts[1:]))
+        try:
+            for j, (a, b) in enumerate(pieces):
+                end = j == len(pieces) - 1
+                ib = Buf(ctypes.cast(src, ctypes.c_void_p).value, b, a)
+                while True:
+                    ob = Buf(ctypes.cast(out, ctypes.c_void_p).value, out_chunk, 0)
+                    r = lib.ZSTD_compressStream2(cctx, ctypes.byref(ob), ctypes.byref(ib), 2 if end else 0)
+                    if lib.ZSTD_isError(r):
+                        raise RuntimeError(lib.ZSTD_getErrorName(r).decode())
+                    res += out.raw[:ob.pos]
+                    if (end and r == 0) or (not end and ib.pos == ib.size and ob.pos < out_chunk):
+                        break
+        finally:
+            lib.ZSTD_freeCCtx(cctx)
+        return bytes(res)
+
     def decompress(self, frame: bytes, out_size: int) -> bytes:
         lib = self.lib
         out = ctypes.create_string_buffer(max(out_size, 1))

@@ -1813,3 +1813,51 @@ KREF_API size_t kref_zstd_fast_compress(u8* dst, size_t cap, const u8* src, size
     wr24(dst + pos, 1 + (2 << 1) + (u32)(cSize << 3));
     return pos + 3 + cSize;
 }
+
+
+/* ================================================================== */
+/* Streaming frames: input fed with ZSTD_e_continue, then ZSTD_e_end    */
+/* (the reference's kotlinx-io / Ktor callers: SliceTransformRawSource  */
+/* .kt:32-55, BaseSliceTransformContentEncoder.kt:23-54, through        */
+/* Wrapper.cpp:112 with finish = false).  The size is unknown when the   */
+/* frame starts: level-3 parameters of the "unknown size" row (window    */
+/* 2^21, hash 2^17, chain 2^16, minMatch 5), a header with a window      */
+/* descriptor and no content size; the library buffers the input and     */
+/* compresses it in chunks of 128 KiB, so the pre-splitter only ever     */
+/* sees one chunk.  If the stream stops exactly at a chunk boundary and  */
+/* the final call brings no data, an empty last block closes the frame.  */
+/* Total input <= 2 MiB (the window never slides).                       */
+/* ================================================================== */
+KREF_API size_t kref_zstd_l3_compress_stream(u8* dst, size_t cap, const u8* src, size_t srcSize, int emptyEnd)
+{
+    u32 const P[4] = { 21, 16, 17, 5 };
+    kref_wksp w; kref_frame_state fs; size_t pos, ipos = 0; int64_t savings = 0;
+    size_t const blockSizeMax = 128 << 10;
+    if (srcSize > KREF_MAX_SRC) return KERR;
+    if (cap < kref_compress_bound(srcSize) + 16) return KERR;
+    wr32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)((P[0] - 10) << 3); pos = 6;
+    if (!wksp_alloc(&w, P)) { wksp_free(&w); return KERR; }
+    fs.rep[0] = 1; fs.rep[1] = 4; fs.rep[2] = 8; fs.huf.valid = 0; memset(&fs.huf.ct, 0, sizeof(fs.huf.ct)); fs.isFirstBlock = 1;
+    if (srcSize % blockSizeMax != 0 || srcSize == 0) emptyEnd = (srcSize == 0);
+    while (ipos < srcSize) {
+        size_t const chunkEnd = (ipos + blockSizeMax < srcSize) ? ipos + blockSizeMax : srcSize;     /* chunks start at multiples of 128 KiB */
+        int const lastChunk = (chunkEnd == srcSize) && !emptyEnd;
+        if (ipos != 0 && ipos % blockSizeMax == 0 && ipos == blockSizeMax) savings -= 6;             /* the frame header counts as produced from the second chunk on */
+        while (ipos < chunkEnd) {
+            size_t const remaining = chunkEnd - ipos;
+            size_t const blockSize = kref_optimal_block_size(src + ipos, remaining, savings);
+            u32 const lastBlock = lastChunk && (blockSize == remaining);
+            u8* const body = dst + pos + 3;
+            size_t cSize = compress_block_body(body, cap - pos - 3, src, ipos, blockSize, P, &w, &fs, NULL);
+            if (cSize == KERR) { wksp_free(&w); return KERR; }
+            if (cSize == 0) { wr24(dst + pos, lastBlock + (0 << 1) + (u32)(blockSize << 3)); memcpy(body, src + ipos, blockSize); cSize = 3 + blockSize; }
+            else if (cSize == 1) { wr24(dst + pos, lastBlock + (1 << 1) + (u32)(blockSize << 3)); cSize = 3 + 1; }
+            else { wr24(dst + pos, lastBlock + (2 << 1) + (u32)(cSize << 3)); cSize += 3; }
+            savings += (int64_t)blockSize - (int64_t)cSize;
+            ipos += blockSize; pos += cSize; fs.isFirstBlock = 0;
+        }
+    }
+    wksp_free(&w);
+    if (emptyEnd) { wr24(dst + pos, 1); pos += 3; }
+    return pos;
+}

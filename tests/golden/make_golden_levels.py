@@ -45,6 +45,13 @@ def main():
             f = z.compress(d, lvl)
             row += [len(f), hashlib.sha256(f).hexdigest()]
         out["config1"].append(row)
+    # streaming frames (unknown size while compressing): the reference's finish = false ... finish = true call pattern
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    out["stream"] = []
+    for d, cuts in helpers.stream_cases():
+        f = z.compress_streaming(d, cuts, 8192)
+        out["stream"].append([len(d), cuts[-2], len(f), hashlib.sha256(f).hexdigest()])
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zstd_levels_golden.json")
     with open(path, "w") as fh:
         json.dump(out, fh, separators=(",", ":"))

@@ -86,6 +86,26 @@ def parse_frame_blocks(f):
     return out
 
 
+def stream_cases():
+    """(data, cut points) for streaming frames: the pieces data[cuts[i]:cuts[i+1]] are fed with finish = false, the last one
+    with finish = true.  Uses the multi-block inputs (sizes 128 KiB+1 .. 2 MiB) and a few smaller ones; cut points seeded."""
+    import random
+    rng = random.Random(424242)
+    out = []
+    datas = [d for _, d in multiblock_inputs()][:30] + [special_inputs()[k] for k in ("hello", "ramp_64k", "zeros_128k", "two_symbols")]
+    for d in datas:
+        n = len(d)
+        r = rng.random()
+        if r < 0.3:
+            cuts = [0, n, n]
+        elif r < 0.6:
+            cuts = [0, rng.randrange(1, n), n]
+        else:
+            cuts = sorted(set([0, n] + [rng.randrange(1, n) for _ in range(rng.randrange(2, 6))]))
+        out.append((d, cuts))
+    return out
+
+
 def levels_golden():
     with open(os.path.join(os.path.dirname(GOLDEN_PATH), "zstd_levels_golden.json")) as fh:
         return json.load(fh)
@@ -168,6 +188,19 @@ class Oracle:
         cap = k.kref_compress_bound(len(d)) + 64
         o = ctypes.create_string_buffer(cap)
         n = k.kref_zstd_fast_compress(o, cap, d, len(d), level)
+        if n == 2 ** 64 - 1:
+            raise RuntimeError("oracle: input outside the restatement's scope")
+        return o.raw[:n]
+
+    def compress_stream(self, d: bytes, empty_end: bool) -> bytes:
+        """Frame of a stream fed with finish = false calls and closed with finish = true (unknown size while compressing);
+        empty_end: the closing call brought no data."""
+        k = self.lib
+        k.kref_zstd_l3_compress_stream.restype = ctypes.c_size_t
+        k.kref_zstd_l3_compress_stream.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+        cap = k.kref_compress_bound(len(d)) + 64
+        o = ctypes.create_string_buffer(cap)
+        n = k.kref_zstd_l3_compress_stream(o, cap, d, len(d), 1 if empty_end else 0)
         if n == 2 ** 64 - 1:
             raise RuntimeError("oracle: input outside the restatement's scope")
         return o.raw[:n]

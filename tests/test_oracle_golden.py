@@ -117,6 +117,17 @@ def test_oracle_levels_1_and_2_match_golden():
             assert len(f) == flen and helpers.sha256(f) == sha, (i, lvl)
 
 
+def test_oracle_streaming_frames_match_golden():
+    """finish = false ... finish = true (SliceTransformRawSource.kt:32-55): frames without content size, window 2^21,
+    the input cut at multiples of 128 KiB before the pre-splitter sees it."""
+    o = helpers.oracle()
+    rows = helpers.levels_golden()["stream"]
+    for (d, cuts), (n, fed, flen, sha) in zip(helpers.stream_cases(), rows):
+        assert len(d) == n and cuts[-2] == fed
+        f = o.compress_stream(d, cuts[-1] == cuts[-2])
+        assert len(f) == flen and helpers.sha256(f) == sha, (n, cuts)
+
+
 def test_params_above_128k():
     o = helpers.oracle()
     expect = {131073: (18, 16, 16, 4), 262144: (18, 16, 16, 4), 262145: (19, 16, 17, 5), 524288: (19, 16, 17, 5),
