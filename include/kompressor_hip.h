@@ -146,6 +146,17 @@ KMP_API int kmp_zstd_compress_batch(kmp_batch_ctx* ctx,
                                     void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                     void* hip_stream);
 
+/* Streaming frames: what libzstd writes when a slice arrives through ZSTD_e_continue calls (finish = false:
+ * SliceTransformRawSource.kt:32-55, BaseSliceTransformContentEncoder.kt:23-54) and is closed with ZSTD_e_end -- the size
+ * is unknown when the frame starts: window 2^21, no content size in the header, the input taken in chunks of 128 KiB.
+ * empty_end != 0: the closing call brought no data (then a stream that stops on a chunk boundary ends with an empty
+ * block).  Slices <= 2 MiB; the context must have been created with max_slice_bytes above 128 KiB.
+ * kmp_zstd_compress_stream produces these frames by itself when data arrived with KMP_ZSTD_e_continue. */
+KMP_API int kmp_zstd_compress_batch_stream(kmp_batch_ctx* ctx,
+                                           const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                           uint32_t n,
+                                           void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
+                                           int empty_end, void* hip_stream);
 /* same at another compression level: 1 and 2 (libzstd's one-table "fast" strategy; level 1 is what the reference's Ktor
  * ZstdContentEncoder asks for, kompressor-zstd-ktor ZstdContentEncoder.kt:11) for slices <= 128 KiB; 3 (or 0) = the
  * call above.  Frames are the ones libzstd 1.5.7 writes at that level. */

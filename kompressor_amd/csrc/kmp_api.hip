@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64, 4) void k_zstd_frame(KFrameArgs a) { zstd_frame
 template <int G>
 __global__ __launch_bounds__(64, 3) void k_zstd_big(KBigArgs a) { zstd_big_body<G>(a); }
 // first block size, repcodes {1,4,8}, no Huffman table; an empty slice is a header and an empty raw block
-__global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 n, KFrameState* fs, u8* dst, const u64* out_off, u32* out_len, u32* remaining)
+__global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 n, KFrameState* fs, u8* dst, const u64* out_off, u32* out_len, u32* remaining, u32 stream)
 {
     u32 const i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 
     s.rep[0] = 1; s.rep[1] = 4; s.rep[2] = 8; s.hufValid = 0; s.hufSel = 0; s.savings = 0;
     for (int k = 0; k < 6; k++) s.pad[k] = 0;
     fs[i] = s;
-    if (len == 0) { u8* d = dst + out_off[i]; kx_st32(d, 0xFD2FB528u); d[4] = 0x20; d[5] = 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
+    if (len == 0) { u8* d = dst + out_off[i]; kx_st32(d, 0xFD2FB528u); d[4] = stream ? 0x00 : 0x20; d[5] = stream ? 0x58 : 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
     else atomicAdd(remaining, 1u);
 }
 __global__ __launch_bounds__(64) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
@@ -336,23 +336,23 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
 // one block of every unfinished slice; block sizes depend on the bytes already produced (ZSTD_optimalBlockSize),
 // so the rounds are sequential and the host only reads back how many frames are still open.
 static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st)
+                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream = 0)
 {
     HIP_TRY(hipMemsetAsync(c->big_tables, 0, (size_t)n * KX_BIG_TBL_ENTRIES * sizeof(u32), st));
     HIP_TRY(hipMemsetAsync(c->remaining, 0, 4, st));
-    hipLaunchKernelGGL(k_zstd_frame_init, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, c->fstate, (u8*)d_dst, d_out_off, d_out_len, c->remaining);
+    hipLaunchKernelGGL(k_zstd_frame_init, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, c->fstate, (u8*)d_dst, d_out_off, d_out_len, c->remaining, stream);
     HIP_TRY(hipGetLastError());
     KMatchArgs m;
     m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
     m.seqs = c->seqs; m.seq_cap = c->seq_cap; m.meta = c->meta; m.lits = c->lits; m.lit_cap = c->lit_cap;
-    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter; m.flags = 2;
+    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter; m.flags = 2u | (stream ? 8u : 0u);
     m.fstate = c->fstate; m.big_tables = c->big_tables;
     KFrameArgs e;
     e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = d_in_len; e.n_slices = n;
     e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
     e.scratch = c->scratch; e.scratch_words = c->scratch_words;
     e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
-    e.fstate = c->fstate; e.hufct = c->hufct; e.remaining = c->remaining;
+    e.fstate = c->fstate; e.hufct = c->hufct; e.remaining = c->remaining; e.stream = stream;
     if (env_u32("KMP_BIG_ROUNDS", 0) == 0) {
         // one wave per slice walks its chain of blocks
         // few slices: one per wave (most waves); many: up to 64 / G per wave so that all of them are in flight
@@ -400,6 +400,19 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     }
     c->last_rounds = rounds; c->last_chunks = 1;
     return KMP_OK;
+}
+/* Streaming frames: what libzstd writes when a slice arrives through finish = false calls and is closed with
+ * finish = true (size unknown when the frame starts).  empty_end: the closing calls brought no data.  The context must
+ * have been created for slices above 128 KiB (the block-chain path and its 2^17 / 2^16 tables serve every size here). */
+extern "C" int kmp_zstd_compress_batch_stream(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int empty_end, void* hip_stream)
+{
+    if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_stream: null argument"; return KMP_ERR_ARG; }
+    if (!c->big) { g_last_error = "kmp_zstd_compress_batch_stream: the context must be created with max_slice_bytes above 128 KiB"; return KMP_ERR_CAPACITY; }
+    if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_stream: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
+    if (n == 0) return KMP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, empty_end ? 2u : 1u);
 }
 /* block rounds of the last batch of a context for slices above 128 KiB */
 extern "C" int kmp_batch_last_rounds(kmp_batch_ctx* c) { return c ? (int)c->last_rounds : 0; }
@@ -670,13 +683,15 @@ struct kmp_zstd_cctx {
     int level; std::vector<u8> in; std::vector<u8> out; size_t out_pos; int stage;   // 0 = collecting, 1 = flushing
     stream_dev dev;
     std::vector<u8> dict;                       // raw-content dictionary (ZSTD_CCtx_loadDictionary keeps a copy too)
+    size_t fed_continue;                        // bytes that arrived with ZSTD_e_continue: > 0 makes it a streaming frame
+    int end_was_empty;                          // the closing calls brought no data
 };
 
 extern "C" kmp_zstd_cctx* kmp_zstd_create_cctx(void)
 {
     kmp_zstd_cctx* c = new (std::nothrow) kmp_zstd_cctx();
     if (!c) return nullptr;
-    c->level = 3; c->out_pos = 0; c->stage = 0; memset(&c->dev, 0, sizeof(c->dev));
+    c->level = 3; c->out_pos = 0; c->stage = 0; memset(&c->dev, 0, sizeof(c->dev)); c->fed_continue = 0; c->end_was_empty = 0;
     return c;
 }
 extern "C" size_t kmp_zstd_free_cctx(kmp_zstd_cctx* c) { if (c) { stream_dev_free(c->dev); delete c; } return 0; }
@@ -706,12 +721,17 @@ static size_t run_single_compress(kmp_zstd_cctx* c)
 {
     size_t const n = c->in.size();
     if (n > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
-    { size_t const e = stream_dev_init(c->dev, n); if (e) return e; }
+    bool const streaming = c->fed_continue > 0;          // data arrived with finish = false: libzstd did not know the size
+    if (streaming && (c->level != 3 || !c->dict.empty())) return KERRC(ZE_parameter_unsupported);
+    { size_t const e = stream_dev_init(c->dev, streaming && n <= KMP_MAX_SLICE_BYTES ? KMP_MAX_SLICE_BYTES + 1 : n); if (e) return e; }
     stream_dev& s = c->dev;
     u64 offs[2] = { 0, 0 }; u32 len = (u32)n, olen = 0;
     if (n && hipMemcpy(s.d_in, c->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+    if (streaming) {
+        if (kmp_zstd_compress_batch_stream(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->end_was_empty, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
+    } else
     if (c->level != 3) {
         if (n > KMP_MAX_SLICE_BYTES || !c->dict.empty()) return KERRC(ZE_parameter_unsupported);   // levels 1, 2: one block, no dictionary
         if (kmp_zstd_compress_batch_level(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->level, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
@@ -742,7 +762,8 @@ extern "C" size_t kmp_zstd_compress_stream(kmp_zstd_cctx* c, void* dst, size_t d
         size_t const avail = src_size - *src_pos;
         if (avail) { const u8* p = (const u8*)src + *src_pos; c->in.insert(c->in.end(), p, p + avail); *src_pos = src_size; }
         if (c->in.size() > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
-        if (end_op != KMP_ZSTD_e_end) return 0;
+        if (end_op != KMP_ZSTD_e_end) { c->fed_continue += avail; return 0; }
+        c->end_was_empty = avail == 0;
         size_t const e = run_single_compress(c);
         if (e) return e;
         c->stage = 1; c->out_pos = 0;
@@ -754,7 +775,7 @@ extern "C" size_t kmp_zstd_compress_stream(kmp_zstd_cctx* c, void* dst, size_t d
         size_t const k = room < left ? room : left;
         if (k) { memcpy((u8*)dst + *dst_pos, c->out.data() + c->out_pos, k); *dst_pos += k; c->out_pos += k; }
         size_t const remaining = c->out.size() - c->out_pos;
-        if (remaining == 0) { c->stage = 0; c->in.clear(); c->out.clear(); c->out_pos = 0; }
+        if (remaining == 0) { c->stage = 0; c->in.clear(); c->out.clear(); c->out_pos = 0; c->fed_continue = 0; c->end_was_empty = 0; }
         return remaining;
     }
 }
@@ -945,7 +966,8 @@ extern "C" size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* d, void* dst, size_t
         if (total == 0) return 3;                              // hint: more input expected
         {
             // frames of up to 2 MiB of content (content size unknown: the staging tier decides)
-            size_t const want = content == (size_t)-1 ? d->in.size() : (content > d->in.size() ? content : d->in.size());
+            // no content size in the header (streaming frames): stage for the largest content served
+            size_t const want = content == (size_t)-1 ? (size_t)KMP_MAX_BIG_SLICE_BYTES : (content > d->in.size() ? content : d->in.size());
             if (want > KMP_MAX_BIG_SLICE_BYTES + (KMP_MAX_BIG_SLICE_BYTES >> 7)) return KERRC(ZE_frameParameter_unsupported);
             size_t const e = stream_dev_init(d->dev, want); if (e) return e;
         }

@@ -1042,6 +1042,9 @@ struct KFrameArgs {
     u8* dst; const u64* out_off; u32* out_len;
     KFrameState* fstate; u32* hufct;         // per slice: state, two Huffman table slots of 256 words
     u32* remaining;                          // frames not finished yet (decremented here)
+    u32 stream;                              // 0: one-shot frames (size known); 1: streaming frames (finish = false ... finish = true:
+                                             // no content size, window 2^21, input taken in chunks of 128 KiB); 2: same, and the
+                                             // closing call brought no data (an empty last block closes a frame that ends on a chunk boundary)
 };
 
 // ZSTD_splitBlock_byChunks(level 0) on the 128 KiB at p: where the byte statistics change, in steps of 8 KiB.
@@ -1084,7 +1087,12 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
     u32 const n = a.in_len[slice];
     u8* const dst = a.dst + a.out_off[slice];
     u32* const hufct = a.hufct + (size_t)slice * 512u;
-    if (fs.ipos == 0) {
+    bool const emptyEnd = a.stream == 2 && (n % KX_BLOCK_MAX) == 0;
+    if (fs.ipos == 0 && a.stream) {
+        // streaming frame header: no content size, window descriptor for 2^21
+        if (lane == 0) { kx_st32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)((21 - 10) << 3); }
+        fs.opos = 6;
+    } else if (fs.ipos == 0) {
         // frame header: single segment (the window covers the slice), content size
         if (lane == 0) {
             u32 const fcsCode = (n >= 256) + (n >= 65536 + 256);
@@ -1098,7 +1106,7 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
     }
     u32 const bs = fs.blockSize;
     const u8* const bsrc = src + fs.ipos;
-    bool const lastBlock = fs.ipos + bs == n;
+    bool const lastBlock = fs.ipos + bs == n && !emptyEnd;
     u8* const bh = dst + fs.opos; u8* const body = bh + 3;
     u32 cSize = 0;
     KSliceMeta mm; mm.nbSeq = 0; mm.litSize = 0; mm.lastLL = bs; mm.longType = 0; mm.longPos = 0; mm.status = 0; mm.pad[0] = fs.rep[0]; mm.pad[1] = fs.rep[1];
@@ -1143,16 +1151,20 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
     }
     fs.savings += (int)bs - (int)outSize;
     fs.ipos += bs; fs.opos += outSize; fs.first = 0;
-    // ZSTD_optimalBlockSize for the next block
+    // ZSTD_optimalBlockSize for the next block (a stream is compressed in chunks of 128 KiB of input; the frame header
+    // counts as produced from the second chunk on)
     u32 next = 0;
-    if (!lastBlock) {
-        u32 const remaining = n - fs.ipos;
+    if (a.stream && fs.ipos == KX_BLOCK_MAX) fs.savings -= 6;
+    if (fs.ipos < n) {
+        u32 remaining = n - fs.ipos;
+        if (a.stream) { u32 const chunkEnd = (fs.ipos / KX_BLOCK_MAX + 1u) * KX_BLOCK_MAX; if (chunkEnd < n) remaining = chunkEnd - fs.ipos; }
         if (remaining < KX_BLOCK_MAX) next = remaining;
         else if (fs.savings < 3) next = KX_BLOCK_MAX;
         else next = kx_split_block(lds, src + fs.ipos, lane);
     }
     fs.blockSize = next;
     if (lane == 0) {
+        if (next == 0 && emptyEnd) { u8* const e = dst + fs.opos; e[0] = 1; e[1] = 0; e[2] = 0; fs.opos += 3; }
         a.fstate[slice] = fs;
         if (next == 0) { a.out_len[slice] = fs.opos; kx_atomic_add(a.remaining, 0xFFFFFFFFu); }
     }

@@ -31,7 +31,8 @@ struct KMatchArgs {
     u32* team_epoch;                 // per team
     u32* counter;                    // work queue head (zeroed by the host)
     u32 flags;                       // 1 = non-temporal table loads, 2 = non-temporal table stores (the default),
-                                     // 4 = copy no literals (the entropy kernel gathers them; A/B switch)
+                                     // 4 = copy no literals (the entropy kernel gathers them; A/B switch),
+                                     // 8 = block mode with the parameters of a stream of unknown size
     // block mode (frames of several blocks): one block of every unfinished slice per launch
     const KFrameState* fstate;       // per slice
     u32* big_tables;                 // per slice: KX_BIG_TBL_ENTRIES
@@ -163,7 +164,8 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                         src = a.src + a.in_off[s];
                         seqs = a.seqs + (size_t)s * a.seq_cap; lits = a.lits + (size_t)s * a.lit_cap;
                         L = a.big_tables + (size_t)s * KX_BIG_TBL_ENTRIES; S = L + KX_BIG_TBL_LONG;
-                        KParams const P = kx_params_l3(a.in_len[s]);
+                        KParams P = kx_params_l3(a.in_len[s]);
+                        if (a.flags & 8u) { P.windowLog = 21; P.chainLog = 16; P.hashLog = 17; P.minMatch = 5; }   // streaming frame: size unknown when it starts
                         hbL = P.hashLog; hbS = P.chainLog; mls = P.minMatch;
                         nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = 0; tag = 0;
                         bstart = (int)fs.ipos; n = bstart + (int)fs.blockSize;       // n = end of the block

@@ -140,8 +140,15 @@ int emu_zstd_compress_dict(const u8* src, const u64* in_off, const u32* in_len, 
 
 // Frames of several blocks (slices above 128 KiB): the host-side round loop of kmp_api.hip restated for the emulator.
 extern "C" __attribute__((visibility("default")))
+int emu_zstd_compress_big_ex(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
+                             u8* dst, const u64* out_off, u32* out_len, u32* rounds_out, u32 stream);
+extern "C" __attribute__((visibility("default")))
 int emu_zstd_compress_big(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
                           u8* dst, const u64* out_off, u32* out_len, u32* rounds_out)
+{ return emu_zstd_compress_big_ex(src, in_off, in_len, n, G, nblocks, dst, out_off, out_len, rounds_out, 0); }
+extern "C" __attribute__((visibility("default")))
+int emu_zstd_compress_big_ex(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
+                             u8* dst, const u64* out_off, u32* out_len, u32* rounds_out, u32 stream)
 {
     u32 const block_cap = 128u * 1024u;
     u32 const seq_cap = (block_cap / 4 + 8 + 15) & ~15u, lit_cap = block_cap + 64, scratch_words = block_cap / 4 + 64;
@@ -157,20 +164,20 @@ int emu_zstd_compress_big(const u8* src, const u64* in_off, const u32* in_len, u
         KFrameState s; memset(&s, 0, sizeof(s));
         s.blockSize = in_len[i] < KX_BLOCK_MAX ? in_len[i] : KX_BLOCK_MAX; s.first = 1; s.rep[0] = 1; s.rep[1] = 4; s.rep[2] = 8;
         fstate[i] = s;
-        if (in_len[i] == 0) { u8* d = dst + out_off[i]; u32 const magic = 0xFD2FB528u; memcpy(d, &magic, 4); d[4] = 0x20; d[5] = 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
+        if (in_len[i] == 0) { u8* d = dst + out_off[i]; u32 const magic = 0xFD2FB528u; memcpy(d, &magic, 4); d[4] = stream ? 0x00 : 0x20; d[5] = stream ? 0x58 : 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
         else remaining++;
     }
     KMatchArgs m;
     m.src = src; m.in_off = in_off; m.in_len = in_len; m.n_slices = n;
     m.seqs = seqs.data(); m.seq_cap = seq_cap; m.lits = lits.data(); m.lit_cap = lit_cap; m.meta = meta.data();
-    m.tables = nullptr; m.team_epoch = nullptr; m.counter = &counter; m.flags = 0;
+    m.tables = nullptr; m.team_epoch = nullptr; m.counter = &counter; m.flags = stream ? 8u : 0u;
     m.fstate = fstate.data(); m.big_tables = big_tables.data();
     KFrameArgs e;
     e.src = src; e.in_off = in_off; e.in_len = in_len; e.n_slices = n;
     e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
     e.scratch = scratch.data(); e.scratch_words = scratch_words;
     e.dst = dst; e.out_off = out_off; e.out_len = out_len;
-    e.fstate = fstate.data(); e.hufct = hufct.data(); e.remaining = &remaining;
+    e.fstate = fstate.data(); e.hufct = hufct.data(); e.remaining = &remaining; e.stream = stream;
     if (!rounds_out) {
         // product path: one wave per slice walks its chain of blocks
         std::vector<u32> counters(nblocks, 0u);

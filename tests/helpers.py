@@ -365,7 +365,7 @@ def emu_compress_dict(datas, dictionary, G=4, nblocks=2):
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
 
 
-def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False):
+def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False, stream=0):
     """Frames of several blocks (slices above 128 KiB) on the emulator: the product's one-wave-per-slice kernel body,
     or (by_rounds) the same steps as separate launches per round of blocks.  Returns (frames, rounds)."""
     n = len(datas)
@@ -384,8 +384,8 @@ def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False):
     ooff = np.arange(n, dtype=np.uint64) * stride
     olen = np.zeros(n, dtype=np.uint32)
     rounds = ctypes.c_uint32(0)
-    r = emu().emu_zstd_compress_big(_vp(buf), _vp(offs), _vp(lens), n, G, nblocks, _vp(out), _vp(ooff), _vp(olen),
-                                    ctypes.byref(rounds) if by_rounds else None)
+    r = emu().emu_zstd_compress_big_ex(_vp(buf), _vp(offs), _vp(lens), n, G, nblocks, _vp(out), _vp(ooff), _vp(olen),
+                                       ctypes.byref(rounds) if by_rounds else None, stream)
     assert r == 0, f"emulator reported {r}"
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)], rounds.value
 

@@ -162,3 +162,18 @@ def test_emulated_levels_1_and_2():
             assert len(f) == flen and helpers.sha256(f) == sha, (S, k, lvl)
             n += 1
     assert n == 128
+
+
+def test_emulated_streaming_frames():
+    """Frames of slices that arrive through finish = false calls (size unknown while compressing): block-chain kernel in
+    stream mode against libzstd 1.5.7's streaming API (the smaller vectors; the GPU suite runs all)."""
+    rows = helpers.levels_golden()["stream"]
+    n = 0
+    for (d, cuts), (size, fed, flen, sha) in zip(helpers.stream_cases(), rows):
+        if len(d) > 300000:
+            continue
+        empty = cuts[-1] == cuts[-2]
+        f = helpers.emu_compress_big([d], G=8, stream=2 if empty else 1)[0][0]
+        assert len(f) == flen and helpers.sha256(f) == sha, (size, cuts)
+        n += 1
+    assert n >= 12

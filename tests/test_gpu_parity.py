@@ -421,3 +421,46 @@ def test_levels_1_and_2(batch):
     o = helpers.oracle()
     f1 = ZstdCompressor(compression_level=1).transform_bytes(mix[3])
     assert f1 == o.compress_level(mix[3], 1) and ZstdDecompressor().transform_bytes(f1) == mix[3]
+
+
+def test_streaming_frames_finish_false_then_true():
+    """The reference's streaming callers (SliceTransformRawSource.kt:32-55): input in several finish = false calls, then
+    finish = true.  libzstd does not know the size then: the frames (no content size, window 2^21, 128 KiB input chunks)
+    must equal what its streaming API writes -- through the batch entry point and through kmp_zstd_compress_stream."""
+    import ctypes
+    from kompressor_amd import _lib, ZstdDecompressor
+    from kompressor_amd.batch import ZstdBatch
+    rows = helpers.levels_golden()["stream"]
+    cases = helpers.stream_cases()
+    b = ZstdBatch(max_slices=8, max_slice_bytes=2 << 20)
+    try:
+        for (d, cuts), (size, fed, flen, sha) in zip(cases, rows):
+            empty = cuts[-1] == cuts[-2]
+            src = torch.from_numpy(np.frombuffer(d + bytes(64), dtype=np.uint8).copy()).cuda()
+            dst, ooff, olen = b.compress(src, torch.zeros(1, dtype=torch.int64, device="cuda"),
+                                         torch.tensor([len(d)], dtype=torch.int32, device="cuda"), streaming="empty" if empty else "data")
+            torch.cuda.synchronize()
+            f = dst[: int(olen[0])].cpu().numpy().tobytes()
+            assert len(f) == flen and helpers.sha256(f) == sha, (size, cuts)
+    finally:
+        b.close()
+    # the C ABI's streaming entry point with the reference's call pattern and 8 KiB output slices
+    lib = _lib.load()
+    for (d, cuts), (size, fed, flen, sha) in list(zip(cases, rows))[:12]:
+        cctx = lib.kmp_zstd_create_cctx()
+        out = bytearray()
+        obuf = ctypes.create_string_buffer(8192)
+        pieces = list(zip(cuts[:-1], cuts[1:]))
+        for j, (a0, a1) in enumerate(pieces):
+            end = j == len(pieces) - 1
+            sp = ctypes.c_size_t(a0)
+            while True:
+                dp = ctypes.c_size_t(0)
+                r = lib.kmp_zstd_compress_stream(cctx, obuf, 8192, ctypes.byref(dp), d, a1, ctypes.byref(sp), 2 if end else 0)
+                assert not lib.kmp_zstd_is_error(r), lib.kmp_zstd_get_error_name(r)
+                out += obuf.raw[:dp.value]
+                if (end and r == 0) or (not end and sp.value == a1):
+                    break
+        lib.kmp_zstd_free_cctx(cctx)
+        assert len(out) == flen and helpers.sha256(bytes(out)) == sha, (size, cuts)
+        assert ZstdDecompressor().transform_bytes(bytes(out)) == d
