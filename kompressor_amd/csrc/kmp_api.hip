@@ -114,7 +114,7 @@ extern "C" const char* kmp_version(void) { return "kompressor_hip 0.2 (gfx950; z
 // --------------------------------------------------------------------------
 enum { KMP_MAX_CHUNKS = 4 };
 struct kmp_batch_ctx {
-    int device; u32 max_slices, max_slice_bytes; int G; u32 match_blocks, nteams;
+    int device; u32 max_slices, max_slice_bytes; int G; u32 match_blocks, match_blocks_l3, nteams;
     u32 seq_cap, lit_cap, scratch_words;
     KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* team_epoch; u32* counter;
     int profiling; hipEvent_t ev[14]; int ev_valid[7];
@@ -146,12 +146,15 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     memset(c, 0, sizeof(*c));
     c->device = device; c->max_slices = max_slices; c->max_slice_bytes = max_slice_bytes < 64 ? 64 : max_slice_bytes; c->G = team_lanes;
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
-    u32 const waves_per_cu = env_u32("KMP_MATCH_WAVES_PER_CU", 12);
+    u32 const waves_per_cu = env_u32("KMP_MATCH_WAVES_PER_CU", 16);     // 16 x 16 teams x 256 CUs = 65 536 slices in flight at team width 4
     u32 const teams_per_wave = 64 / (u32)team_lanes;
     u32 blocks = (u32)prop.multiProcessorCount * waves_per_cu;
     u32 const need = (max_slices + teams_per_wave - 1) / teams_per_wave;
     if (blocks > need) blocks = need;
     c->match_blocks = blocks; c->nteams = blocks * teams_per_wave;
+    // the level-3 parser is transaction bound and a little faster with 12 waves per CU; the one-position-per-step parsers
+    // (levels 1 / 2, dictionary) are latency bound and want every slice in flight
+    { u32 const l3 = (u32)prop.multiProcessorCount * env_u32("KMP_MATCH_WAVES_PER_CU_L3", 12); c->match_blocks_l3 = l3 < blocks ? l3 : blocks; }
     c->big = c->max_slice_bytes > KMP_MAX_SLICE_BYTES;
     u32 const block_cap = c->big ? KMP_MAX_SLICE_BYTES : c->max_slice_bytes;     // the sequence / literal workspaces hold one block
     c->seq_cap = (block_cap / 4 + 8 + 15) & ~15u; c->lit_cap = block_cap + 64; c->scratch_words = block_cap / 4 + 64;
@@ -445,7 +448,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         m.seqs = c->seqs + (size_t)first * c->seq_cap; m.seq_cap = c->seq_cap; m.meta = c->meta + first;
         m.lits = c->lits + (size_t)first * c->lit_cap; m.lit_cap = c->lit_cap;
         m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter + ci; m.flags = match_flags;
-        u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
+        u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > c->match_blocks_l3) blocks = c->match_blocks_l3;
         if (c->profiling) HIP_TRY(hipEventRecord(c->evm[ci][0], st));
         switch (c->G) {
         case 2:  hipLaunchKernelGGL(k_zstd_match<2>, dim3(blocks), dim3(64), 0, st, m); break;
