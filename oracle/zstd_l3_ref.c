@@ -1191,13 +1191,13 @@ static void wksp_free(kref_wksp* w) { free(w->hashLong); free(w->hashSmall); fre
 /* One-shot level-3 frame (ZSTD_compress2 with the size known). Returns the frame size, or (size_t)-1 if
  * dst is too small or srcSize is outside this restatement's scope (> 2 MiB).  blockSizesOut (optional,
  * room for srcSize / 8192 + 2 entries) receives the sizes of the input blocks, *nbBlocksOut their number. */
-KREF_API size_t kref_zstd_l3_compress_blocks(u8* dst, size_t cap, const u8* src, size_t srcSize, u32* blockSizesOut, u32* nbBlocksOut)
+static size_t compress_blocks_dfast(u8* dst, size_t cap, const u8* src, size_t srcSize, u32* blockSizesOut, u32* nbBlocksOut, const u32* Pin)
 {
     u32 P[4]; kref_wksp w; kref_frame_state fs; size_t pos, ipos = 0; int64_t savings = 0; u32 nb = 0;
     if (nbBlocksOut) *nbBlocksOut = 0;
     if (srcSize > KREF_MAX_SRC) return KERR;
     if (cap < kref_compress_bound(srcSize)) return KERR;
-    kref_params_l3(srcSize, P);
+    if (Pin) memcpy(P, Pin, sizeof(P)); else kref_params_l3(srcSize, P);
     pos = write_frame_header(dst, srcSize, P[0]);
     if (srcSize == 0) { wr24(dst + pos, 1); return pos + 3; }
     if (!wksp_alloc(&w, P)) { wksp_free(&w); return KERR; }
@@ -1230,9 +1230,13 @@ KREF_API size_t kref_zstd_l3_compress_blocks(u8* dst, size_t cap, const u8* src,
     return pos;
 }
 
+KREF_API size_t kref_zstd_l3_compress_blocks(u8* dst, size_t cap, const u8* src, size_t srcSize, u32* blockSizesOut, u32* nbBlocksOut)
+{
+    return compress_blocks_dfast(dst, cap, src, srcSize, blockSizesOut, nbBlocksOut, NULL);
+}
 KREF_API size_t kref_zstd_l3_compress(u8* dst, size_t cap, const u8* src, size_t srcSize)
 {
-    return kref_zstd_l3_compress_blocks(dst, cap, src, srcSize, NULL, NULL);
+    return compress_blocks_dfast(dst, cap, src, srcSize, NULL, NULL, NULL);
 }
 
 /* Stage taps for kernel-by-kernel diffing: the seqStore of the single block of a slice <= 128 KiB.
@@ -1861,3 +1865,202 @@ KREF_API size_t kref_zstd_l3_compress_stream(u8* dst, size_t cap, const u8* src,
     if (emptyEnd) { wr24(dst + pos, 1); pos += 3; }
     return pos;
 }
+
+
+/* ================================================================== */
+/* Levels 1 and 2 above 128 KiB: frames of several blocks              */
+/* (one-shot, and the streaming frames of finish = false callers --     */
+/* the Ktor encoder's case: level 1, size unknown).  The pre-splitter   */
+/* for strategy "fast" is ZSTD_splitBlock level 0 ("fromBorders": byte  */
+/* histograms of the first, last and middle 512 bytes of the 128 KiB).  */
+/* Input no larger than the window (512 KiB at level 1 unknown size).   */
+/* ================================================================== */
+static void hist512(u32* h, const u8* p) { int i; memset(h, 0, 256 * sizeof(u32)); for (i = 0; i < 512; i++) h[p[i]]++; }
+static u64 fp_dist512(const u32* a, const u32* b)
+{
+    u64 d = 0; int n;
+    for (n = 0; n < 256; n++) { int64_t const x = (int64_t)a[n] * 512 - (int64_t)b[n] * 512; d += (u64)(x < 0 ? -x : x); }
+    return d;
+}
+static size_t split_block_from_borders(const u8* p)          /* block of exactly 128 KiB */
+{
+    u32 first[256], last[256], mid[256];
+    size_t const blockSize = 128 << 10;
+    hist512(first, p); hist512(last, p + blockSize - 512);
+    { u64 const p50 = 512ull * 512ull; if (!(fp_dist512(first, last) >= p50 * 14 / 16)) return blockSize; }
+    hist512(mid, p + blockSize / 2 - 256);
+    {
+        u64 const dB = fp_dist512(first, mid), dE = fp_dist512(last, mid);
+        u64 const minDistance = 512 * 512 / 3;
+        int64_t const diff = (int64_t)dB - (int64_t)dE;
+        if ((u64)(diff < 0 ? -diff : diff) < minDistance) return 64 << 10;
+        return (dB > dE) ? (32 << 10) : (96 << 10);
+    }
+}
+
+/* fast_block for a block inside a larger input (tables and repcodes carried) */
+static size_t fast_block_at(seqstore* ss, u32 rep[3], const u8* input, size_t blockStart, size_t srcSize, u32* hashTable, u32 hlog, u32 mls);
+
+KREF_API size_t kref_zstd_fast_compress_big(u8* dst, size_t cap, const u8* src, size_t srcSize, int level, int stream, int emptyEnd)
+{
+    u32 P[4]; kref_wksp w; seqstore ss; kref_frame_state fs; kref_hufstate nextHuf;
+    size_t pos, ipos = 0; int64_t savings = 0; size_t const blockSizeMax = 128 << 10;
+    if (level != 1 && level != 2) return KERR;
+    if (level == 2 && !stream && srcSize > 131072 && srcSize <= 262144) {
+        /* level 2's row for this size class is a double-fast one: window 18, chain 14, hash 14, minMatch 5 */
+        u32 const Pd[4] = { 18, 14, 14, 5 };
+        return compress_blocks_dfast(dst, cap, src, srcSize, NULL, NULL, Pd);
+    }
+    if (stream) { P[0] = (level == 1) ? 19 : 20; P[2] = (level == 1) ? 14 : 16; P[3] = (level == 1) ? 7 : 6; }
+    else kref_params_fast(level, srcSize, P);
+    if (srcSize > ((size_t)1 << P[0])) return KERR;                  /* the window would slide */
+    if (cap < kref_compress_bound(srcSize) + 16) return KERR;
+    if (stream) { wr32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)((P[0] - 10) << 3); pos = 6; }
+    else pos = write_frame_header(dst, srcSize, P[0]);
+    if (!stream && srcSize == 0) { wr24(dst + pos, 1); return pos + 3; }
+    w.hashLong = (u32*)calloc((size_t)1 << P[2], sizeof(u32)); w.hashSmall = NULL;
+    w.seqs = (kref_seq*)malloc(sizeof(kref_seq) * ((128 << 10) / 3 + 8)); w.lits = (u8*)malloc((128 << 10) + 32);
+    fs.rep[0] = 1; fs.rep[1] = 4; fs.rep[2] = 8; fs.huf.valid = 0; memset(&fs.huf.ct, 0, sizeof(fs.huf.ct)); fs.isFirstBlock = 1;
+    if (!stream) emptyEnd = 0; else if (srcSize % blockSizeMax != 0 || srcSize == 0) emptyEnd = (srcSize == 0);
+    while (ipos < srcSize) {
+        size_t const chunkEnd = (stream && ipos + blockSizeMax < srcSize) ? (ipos / blockSizeMax + 1) * blockSizeMax : srcSize;
+        int const lastChunk = (chunkEnd == srcSize) && !emptyEnd;
+        if (stream && ipos == blockSizeMax) savings -= 6;
+        while (ipos < chunkEnd) {
+            size_t const remaining = chunkEnd - ipos;
+            size_t const blockSize = (remaining < blockSizeMax) ? remaining : (savings < 3) ? blockSizeMax : split_block_from_borders(src + ipos);
+            u32 const lastBlock = lastChunk && (blockSize == remaining);
+            u8* const body = dst + pos + 3; const u8* const bsrc = src + ipos;
+            size_t cSize = 0, lastLL, litC, seqC; u32 rep[3];
+            memset(&ss, 0, sizeof(ss)); ss.seqs = w.seqs; ss.lits = w.lits; ss.strategy = 1;
+            if (blockSize >= 7) {
+                memcpy(rep, fs.rep, sizeof(rep));
+                lastLL = fast_block_at(&ss, rep, src, ipos, blockSize, w.hashLong, P[2], P[3]);
+                memcpy(ss.lits + ss.litSize, bsrc + blockSize - lastLL, lastLL); ss.litSize += lastLL;
+                {
+                    int const suspect = (ss.nbSeq == 0) || (ss.litSize / ss.nbSeq >= 20);
+                    litC = compress_literals(body, cap - pos - 3, ss.lits, ss.litSize, suspect, &fs.huf, &nextHuf);
+                    if (litC != KERR) {
+                        seqC = compress_sequences(body + litC, cap - pos - 3 - litC, &ss);
+                        if (seqC != KERR && seqC != 0) { cSize = litC + seqC; if (cSize >= blockSize - min_gain(blockSize)) cSize = 0; }
+                    }
+                }
+                if (!fs.isFirstBlock && ss.nbSeq < 4 && ss.litSize < 10) {
+                    size_t i; int same = 1;
+                    for (i = 1; i < blockSize; i++) if (bsrc[i] != bsrc[0]) { same = 0; break; }
+                    if (same) { body[0] = bsrc[0]; cSize = 1; }
+                }
+                if (cSize > 1) { memcpy(fs.rep, rep, sizeof(rep)); fs.huf = nextHuf; }
+            }
+            if (cSize == 0) { wr24(dst + pos, lastBlock + (0 << 1) + (u32)(blockSize << 3)); memcpy(body, bsrc, blockSize); cSize = 3 + blockSize; }
+            else if (cSize == 1) { wr24(dst + pos, lastBlock + (1 << 1) + (u32)(blockSize << 3)); cSize = 3 + 1; }
+            else { wr24(dst + pos, lastBlock + (2 << 1) + (u32)(cSize << 3)); cSize += 3; }
+            savings += (int64_t)blockSize - (int64_t)cSize;
+            ipos += blockSize; pos += cSize; fs.isFirstBlock = 0;
+        }
+    }
+    free(w.hashLong); free(w.seqs); free(w.lits);
+    if (emptyEnd) { wr24(dst + pos, 1); pos += 3; }
+    return pos;
+}
+static size_t fast_block_at(seqstore* ss, u32 rep[3], const u8* input, size_t blockStart, size_t srcSize, u32* hashTable, u32 hlog, u32 mls)
+{
+    const u8* const base = input - IDX0;
+    const u8* const src = input + blockStart;
+    const u8* const istart = src;
+    u32 const prefixStartIndex = IDX0;
+    const u8* const prefixStart = base + prefixStartIndex;
+    const u8* const iend = istart + srcSize;
+    const u8* const ilimit = iend - 8;
+    const u8* anchor = istart; const u8* ip0 = istart; const u8 *ip1, *ip2, *ip3;
+    u32 current0 = 0;
+    u32 rep_offset1 = rep[0], rep_offset2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0;
+    size_t hash0, hash1; u32 matchIdx; u32 offcode; const u8* match0; size_t mLength;
+    size_t const stepSize = 2; size_t step; const u8* nextStep; size_t const kStepIncr = 1 << 7;
+
+    if (srcSize < 8) return srcSize;   /* (libzstd runs into _cleanup at once: repcodes unchanged) */
+    ip0 += (ip0 == prefixStart);
+    {
+        u32 const curr = (u32)(ip0 - base); u32 const maxRep = curr - prefixStartIndex;
+        if (rep_offset2 > maxRep) { offsetSaved2 = rep_offset2; rep_offset2 = 0; }
+        if (rep_offset1 > maxRep) { offsetSaved1 = rep_offset1; rep_offset1 = 0; }
+    }
+_start:
+    step = stepSize;
+    nextStep = ip0 + kStepIncr;
+    ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
+    if (ip3 >= ilimit) goto _cleanup;
+    hash0 = hash_short(ip0, hlog, mls);
+    hash1 = hash_short(ip1, hlog, mls);
+    matchIdx = hashTable[hash0];
+    do {
+        u32 const rval = rd32(ip2 - rep_offset1);
+        current0 = (u32)(ip0 - base);
+        hashTable[hash0] = current0;
+        if ((rd32(ip2) == rval) & (rep_offset1 > 0)) {
+            ip0 = ip2;
+            match0 = ip0 - rep_offset1;
+            mLength = ip0[-1] == match0[-1];
+            ip0 -= mLength; match0 -= mLength;
+            offcode = 1;
+            mLength += 4;
+            hashTable[hash1] = (u32)(ip1 - base);
+            goto _match;
+        }
+        if (matchIdx >= prefixStartIndex && rd32(base + matchIdx) == rd32(ip0)) {
+            hashTable[hash1] = (u32)(ip1 - base);
+            goto _offset;
+        }
+        matchIdx = hashTable[hash1];
+        hash0 = hash1;
+        hash1 = hash_short(ip2, hlog, mls);
+        ip0 = ip1; ip1 = ip2; ip2 = ip3;
+        current0 = (u32)(ip0 - base);
+        hashTable[hash0] = current0;
+        if (matchIdx >= prefixStartIndex && rd32(base + matchIdx) == rd32(ip0)) {
+            if (step <= 4) hashTable[hash1] = (u32)(ip1 - base);
+            goto _offset;
+        }
+        matchIdx = hashTable[hash1];
+        hash0 = hash1;
+        hash1 = hash_short(ip2, hlog, mls);
+        ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+        if (ip2 >= nextStep) { step++; nextStep += kStepIncr; }
+    } while (ip3 < ilimit);
+
+_cleanup:
+    offsetSaved2 = ((offsetSaved1 != 0) && (rep_offset1 != 0)) ? offsetSaved1 : offsetSaved2;
+    rep[0] = rep_offset1 ? rep_offset1 : offsetSaved1;
+    rep[1] = rep_offset2 ? rep_offset2 : offsetSaved2;
+    return (size_t)(iend - anchor);
+
+_offset:
+    match0 = base + matchIdx;
+    rep_offset2 = rep_offset1;
+    rep_offset1 = (u32)(ip0 - match0);
+    offcode = rep_offset1 + 3;
+    mLength = 4;
+    while (((ip0 > anchor) & (match0 > prefixStart)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
+
+_match:
+    mLength += count_eq(ip0 + mLength, match0 + mLength, iend);
+    store_seq(ss, (size_t)(ip0 - anchor), anchor, offcode, mLength);
+    ip0 += mLength;
+    anchor = ip0;
+    if (ip0 <= ilimit) {
+        hashTable[hash_short(base + current0 + 2, hlog, mls)] = current0 + 2;
+        hashTable[hash_short(ip0 - 2, hlog, mls)] = (u32)(ip0 - 2 - base);
+        if (rep_offset2 > 0) {
+            while ((ip0 <= ilimit) && (rd32(ip0) == rd32(ip0 - rep_offset2))) {
+                size_t const rLength = count_eq(ip0 + 4, ip0 + 4 - rep_offset2, iend) + 4;
+                { u32 const tmpOff = rep_offset2; rep_offset2 = rep_offset1; rep_offset1 = tmpOff; }
+                hashTable[hash_short(ip0, hlog, mls)] = (u32)(ip0 - base);
+                ip0 += rLength;
+                store_seq(ss, 0, anchor, 1, rLength);
+                anchor = ip0;
+            }
+        }
+    }
+    goto _start;
+}
+
