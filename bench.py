@@ -288,7 +288,8 @@ def main():
         if dictionary:
             res["roofline"]["kernel"] = "k_zstd_match_dict + k_zstd_entropy (one launch each per step)"
         if args.level != 3:
-            res["roofline"]["kernel"] = "k_zstd_match_fast + k_zstd_entropy (one launch each per step)"
+            res["roofline"]["kernel"] = ("k_zstd_big_fast (one launch per step: every wave walks the block chains of its slices)" if SLICE > 128 * 1024
+                                         else "k_zstd_match_fast + k_zstd_entropy (one launch each per step)")
             res["config"]["workload"] = f"{n} x {args.slice_kib} KiB seeded mixed slices per GPU, ZstdCompressor(level={args.level}), bit-identical to libzstd 1.5.7"
             res["metric"] = f"zstd level-{args.level} compression throughput (uncompressed input bytes per second)"
         if not args.no_cpu and not dictionary and args.level == 3:

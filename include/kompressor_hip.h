@@ -157,9 +157,17 @@ KMP_API int kmp_zstd_compress_batch_stream(kmp_batch_ctx* ctx,
                                            uint32_t n,
                                            void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                            int empty_end, void* hip_stream);
-/* same at another compression level: 1 and 2 (libzstd's one-table "fast" strategy; level 1 is what the reference's Ktor
- * ZstdContentEncoder asks for, kompressor-zstd-ktor ZstdContentEncoder.kt:11) for slices <= 128 KiB; 3 (or 0) = the
- * call above.  Frames are the ones libzstd 1.5.7 writes at that level. */
+/* ... at level 3 (or 0: the call above) or level 1 -- the reference's Ktor ZstdContentEncoder streams at level 1
+ * (kompressor-zstd-ktor ZstdContentEncoder.kt:11): window 2^19, so streams <= 512 KiB and a context created with
+ * max_slice_bytes in (128 KiB, 512 KiB]. */
+KMP_API int kmp_zstd_compress_batch_stream_level(kmp_batch_ctx* ctx,
+                                                 const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                                 uint32_t n,
+                                                 void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
+                                                 int empty_end, int level, void* hip_stream);
+/* One-shot frames at another compression level: 1 and 2 (libzstd's one-table "fast" strategy) for slices <= 128 KiB;
+ * level 1 also as frames of several blocks for slices <= 512 KiB (context created with max_slice_bytes in
+ * (128 KiB, 512 KiB]); 3 (or 0) = kmp_zstd_compress_batch.  Frames are the ones libzstd 1.5.7 writes at that level. */
 KMP_API int kmp_zstd_compress_batch_level(kmp_batch_ctx* ctx,
                                           const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                           uint32_t n,

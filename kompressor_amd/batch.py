@@ -64,9 +64,10 @@ class ZstdBatch:
     def compress(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, dictionary=None, level=3, streaming=None):
         """src: uint8 device tensor; in_off int64, in_len int32 device tensors (n each).  dictionary: bytes of a
         raw-content dictionary shared by all slices (host memory; its tables are built once per dictionary).
-        level: 3 (default), or 1 / 2 for slices of at most 128 KiB without a dictionary.
+        level: 3 (default), or 1 / 2 for slices of at most 128 KiB without a dictionary; level 1 also for slices up to
+        512 KiB (context created for slice sizes in (128 KiB, 512 KiB]).
         streaming: None = one-shot frames; "data" / "empty" = the frames of slices that arrived through finish = false
-        calls, closed by a call with / without data (context created for slices above 128 KiB).
+        calls, closed by a call with / without data (context created for slices above 128 KiB; levels 3 and 1).
         Returns (dst, out_off, out_len): frame i = dst[out_off[i] : out_off[i] + out_len[i]]."""
         n = in_len.numel()
         if dst is None:
@@ -76,8 +77,8 @@ class ZstdBatch:
         if out_len is None:
             out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
         if streaming is not None:
-            rc = self.lib.kmp_zstd_compress_batch_stream(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
-                                                         _ptr(dst), _ptr(out_off), _ptr(out_len), 1 if streaming == "empty" else 0, self._stream())
+            rc = self.lib.kmp_zstd_compress_batch_stream_level(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
+                                                               _ptr(dst), _ptr(out_off), _ptr(out_len), 1 if streaming == "empty" else 0, level, self._stream())
         elif level not in (0, 3):
             if dictionary is not None:
                 raise ValueError("levels 1 and 2 are served without a dictionary")

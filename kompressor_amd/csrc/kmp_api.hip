@@ -40,6 +40,8 @@ __global__ __launch_bounds__(64, 4) void k_zstd_frame(KFrameArgs a) { zstd_frame
 // ... or the whole chain of blocks of a slice by one wave (no host rounds)
 template <int G>
 __global__ __launch_bounds__(64, 3) void k_zstd_big(KBigArgs a) { zstd_big_body<G>(a); }
+template <int G>
+__global__ __launch_bounds__(64, 3) void k_zstd_big_fast(KBigArgs a) { zstd_big_body<G, true>(a); }
 // first block size, repcodes {1,4,8}, no Huffman table; an empty slice is a header and an empty raw block
 __global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 n, KFrameState* fs, u8* dst, const u64* out_off, u32* out_len, u32* remaining, u32 stream)
 {
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 
     s.rep[0] = 1; s.rep[1] = 4; s.rep[2] = 8; s.hufValid = 0; s.hufSel = 0; s.savings = 0;
     for (int k = 0; k < 6; k++) s.pad[k] = 0;
     fs[i] = s;
-    if (len == 0) { u8* d = dst + out_off[i]; kx_st32(d, 0xFD2FB528u); d[4] = stream ? 0x00 : 0x20; d[5] = stream ? 0x58 : 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
+    if (len == 0) { u8* d = dst + out_off[i]; kx_st32(d, 0xFD2FB528u); d[4] = stream ? 0x00 : 0x20; d[5] = (u8)stream; /* the window descriptor byte of a streaming frame, 0 = one-shot */ d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
     else atomicAdd(remaining, 1u);
 }
 __global__ __launch_bounds__(64) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
@@ -234,6 +236,8 @@ extern "C" size_t kmp_zstd_compress_bound(size_t n)
 }
 
 // ---- levels 1 and 2 -------------------------------------------------------------------------------------
+static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy);
 extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int level, void* hip_stream)
 {
@@ -241,10 +245,14 @@ extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src
     if (level != 1 && level != 2) { g_last_error = "kmp_zstd_compress_batch_level: levels 1, 2 and 3 are served"; return KMP_ERR_ARG; }
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_level: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_level: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
-    if (c->big) { g_last_error = "kmp_zstd_compress_batch_level: slices above 128 KiB are served at level 3 only"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->big) {
+        // frames of several blocks: level 1 only, slices up to its 512 KiB window
+        if (level != 1 || c->max_slice_bytes > (512u << 10)) { g_last_error = "kmp_zstd_compress_batch_level: above 128 KiB level 1 is served for slices up to 512 KiB (context max_slice_bytes <= 512 KiB)"; return KMP_ERR_CAPACITY; }
+        return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st, 0, 1);
+    }
     if (c->have_last_match) HIP_TRY(hipStreamWaitEvent(st, c->ev_last_match, 0));
     HIP_TRY(hipMemsetAsync(c->counter, 0, 4, st));
     KFastArgs g;
@@ -339,11 +347,11 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
 // one block of every unfinished slice; block sizes depend on the bytes already produced (ZSTD_optimalBlockSize),
 // so the rounds are sequential and the host only reads back how many frames are still open.
 static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream = 0)
+                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy)
 {
     HIP_TRY(hipMemsetAsync(c->big_tables, 0, (size_t)n * KX_BIG_TBL_ENTRIES * sizeof(u32), st));
     HIP_TRY(hipMemsetAsync(c->remaining, 0, 4, st));
-    hipLaunchKernelGGL(k_zstd_frame_init, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, c->fstate, (u8*)d_dst, d_out_off, d_out_len, c->remaining, stream);
+    hipLaunchKernelGGL(k_zstd_frame_init, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, c->fstate, (u8*)d_dst, d_out_off, d_out_len, c->remaining, stream ? (strategy ? 0x48u : 0x58u) : 0u);
     HIP_TRY(hipGetLastError());
     KMatchArgs m;
     m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
@@ -355,8 +363,8 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
     e.scratch = c->scratch; e.scratch_words = c->scratch_words;
     e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
-    e.fstate = c->fstate; e.hufct = c->hufct; e.remaining = c->remaining; e.stream = stream;
-    if (env_u32("KMP_BIG_ROUNDS", 0) == 0) {
+    e.fstate = c->fstate; e.hufct = c->hufct; e.remaining = c->remaining; e.stream = stream; e.strategy = strategy;
+    if (strategy || env_u32("KMP_BIG_ROUNDS", 0) == 0) {
         // one wave per slice walks its chain of blocks
         // few slices: one per wave (most waves); many: up to 64 / G per wave so that all of them are in flight
         KBigArgs g; g.m = m; g.e = e; g.counters = c->big_counters;
@@ -366,7 +374,15 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
         g.spw = spw;
         u32 const grid = (n + spw - 1) / spw;
         HIP_TRY(hipMemsetAsync(c->big_counters, 0, (size_t)n * 4, st));
-        switch (c->big_G) {
+        if (strategy) switch (c->big_G) {
+        case 2:  hipLaunchKernelGGL(k_zstd_big_fast<2>, dim3(grid), dim3(64), 0, st, g); break;
+        case 4:  hipLaunchKernelGGL(k_zstd_big_fast<4>, dim3(grid), dim3(64), 0, st, g); break;
+        case 8:  hipLaunchKernelGGL(k_zstd_big_fast<8>, dim3(grid), dim3(64), 0, st, g); break;
+        case 16: hipLaunchKernelGGL(k_zstd_big_fast<16>, dim3(grid), dim3(64), 0, st, g); break;
+        case 32: hipLaunchKernelGGL(k_zstd_big_fast<32>, dim3(grid), dim3(64), 0, st, g); break;
+        default: hipLaunchKernelGGL(k_zstd_big_fast<64>, dim3(grid), dim3(64), 0, st, g); break;
+        }
+        else switch (c->big_G) {
         case 2:  hipLaunchKernelGGL(k_zstd_big<2>, dim3(grid), dim3(64), 0, st, g); break;
         case 4:  hipLaunchKernelGGL(k_zstd_big<4>, dim3(grid), dim3(64), 0, st, g); break;
         case 8:  hipLaunchKernelGGL(k_zstd_big<8>, dim3(grid), dim3(64), 0, st, g); break;
@@ -407,15 +423,24 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
 /* Streaming frames: what libzstd writes when a slice arrives through finish = false calls and is closed with
  * finish = true (size unknown when the frame starts).  empty_end: the closing calls brought no data.  The context must
  * have been created for slices above 128 KiB (the block-chain path and its 2^17 / 2^16 tables serve every size here). */
+extern "C" int kmp_zstd_compress_batch_stream_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                                    uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int empty_end, int level, void* hip_stream);
 extern "C" int kmp_zstd_compress_batch_stream(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                               uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int empty_end, void* hip_stream)
+{ return kmp_zstd_compress_batch_stream_level(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, empty_end, 3, hip_stream); }
+/* level 3 (streams <= 2 MiB) or level 1 (the Ktor encoder's: streams <= 512 KiB, its window) */
+extern "C" int kmp_zstd_compress_batch_stream_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                                    uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int empty_end, int level, void* hip_stream)
 {
+    if (level == 0) level = 3;
+    if (level != 1 && level != 3) { g_last_error = "kmp_zstd_compress_batch_stream_level: levels 1 and 3 are served"; return KMP_ERR_ARG; }
+    if (c && level == 1 && c->max_slice_bytes > (512u << 10)) { g_last_error = "kmp_zstd_compress_batch_stream_level: level 1 streams up to 512 KiB (context max_slice_bytes <= 512 KiB)"; return KMP_ERR_CAPACITY; }
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_stream: null argument"; return KMP_ERR_ARG; }
     if (!c->big) { g_last_error = "kmp_zstd_compress_batch_stream: the context must be created with max_slice_bytes above 128 KiB"; return KMP_ERR_CAPACITY; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_stream: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, empty_end ? 2u : 1u);
+    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, empty_end ? 2u : 1u, level == 1 ? 1u : 0u);
 }
 /* block rounds of the last batch of a context for slices above 128 KiB */
 extern "C" int kmp_batch_last_rounds(kmp_batch_ctx* c) { return c ? (int)c->last_rounds : 0; }
@@ -428,7 +453,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
-    if (c->big) return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st);
+    if (c->big) return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st, 0, 0);
     // Chunks: the match kernel of chunk i+1 (memory-transaction bound) runs beside the entropy kernel of
     // chunk i (latency bound) on a second stream; the caller's stream sees everything finished.
     u32 chunks = env_u32("KMP_ZSTD_CHUNKS", n >= 32768u ? 2u : 1u);
@@ -660,16 +685,19 @@ extern "C" const char* kmp_zstd_get_error_name(size_t code)
 
 // device staging shared by the two stream contexts
 struct stream_dev {
-    kmp_batch_ctx* batch; u8* d_in; u8* d_out; u64* d_off; u32* d_len; size_t in_cap, out_cap;
+    kmp_batch_ctx* batch; u8* d_in; u8* d_out; u64* d_off; u32* d_len; size_t in_cap, out_cap; u32 tier;
 };
 static void stream_dev_free(stream_dev& s);
 // staging for one slice / frame of at most `bytes` on either side: the 128 KiB tier first, the 2 MiB tier
 // (frames of several blocks) when a larger one shows up
-static size_t stream_dev_init(stream_dev& s, size_t bytes = 0)
+// (level 1 above 128 KiB wants a context of exactly its 512 KiB window: `exact` = that tier)
+static size_t stream_dev_init(stream_dev& s, size_t bytes = 0, u32 exact = 0)
 {
-    if (s.batch && bytes + 1024 <= s.in_cap) return 0;
+    if (s.batch && exact && s.tier == exact) return 0;
+    if (s.batch && !exact && bytes + 1024 <= s.in_cap) return 0;
     if (s.batch) stream_dev_free(s);
-    u32 const tier = (bytes + 1024 <= KMP_MAX_SLICE_BYTES + 1024) ? KMP_MAX_SLICE_BYTES : KMP_MAX_BIG_SLICE_BYTES;
+    u32 const tier = exact ? exact : (bytes + 1024 <= KMP_MAX_SLICE_BYTES + 1024) ? KMP_MAX_SLICE_BYTES : KMP_MAX_BIG_SLICE_BYTES;
+    s.tier = tier;
     if (kmp_batch_create(&s.batch, 0, 1, tier, 8) != KMP_OK) return KERRC(ZE_memory_allocation);
     s.in_cap = tier + (tier >> 7) + 1024; s.out_cap = tier + (tier >> 7) + 1024;
     if (hipMalloc((void**)&s.d_in, s.in_cap) != hipSuccess || hipMalloc((void**)&s.d_out, s.out_cap) != hipSuccess ||
@@ -725,18 +753,20 @@ static size_t run_single_compress(kmp_zstd_cctx* c)
     size_t const n = c->in.size();
     if (n > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
     bool const streaming = c->fed_continue > 0;          // data arrived with finish = false: libzstd did not know the size
-    if (streaming && (c->level != 3 || !c->dict.empty())) return KERRC(ZE_parameter_unsupported);
-    { size_t const e = stream_dev_init(c->dev, streaming && n <= KMP_MAX_SLICE_BYTES ? KMP_MAX_SLICE_BYTES + 1 : n); if (e) return e; }
+    if (streaming && (c->level == 2 || !c->dict.empty())) return KERRC(ZE_parameter_unsupported);
+    bool const l1big = c->level == 1 && (streaming || n > KMP_MAX_SLICE_BYTES);      // level 1, frame of several blocks / stream
+    if (l1big && n > (512u << 10)) return KERRC(ZE_parameter_unsupported);             // beyond its window: CPU library
+    { size_t const e = stream_dev_init(c->dev, streaming && n <= KMP_MAX_SLICE_BYTES ? KMP_MAX_SLICE_BYTES + 1 : n, l1big ? (512u << 10) : 0u); if (e) return e; }
     stream_dev& s = c->dev;
     u64 offs[2] = { 0, 0 }; u32 len = (u32)n, olen = 0;
     if (n && hipMemcpy(s.d_in, c->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (streaming) {
-        if (kmp_zstd_compress_batch_stream(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->end_was_empty, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
+        if (kmp_zstd_compress_batch_stream_level(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->end_was_empty, c->level, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
     } else
     if (c->level != 3) {
-        if (n > KMP_MAX_SLICE_BYTES || !c->dict.empty()) return KERRC(ZE_parameter_unsupported);   // levels 1, 2: one block, no dictionary
+        if ((n > KMP_MAX_SLICE_BYTES && !l1big) || !c->dict.empty()) return KERRC(ZE_parameter_unsupported);   // level 2: one block; no dictionary
         if (kmp_zstd_compress_batch_level(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->level, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
     } else
     if (!c->dict.empty()) {

@@ -17,6 +17,7 @@
 #pragma once
 #include "zstd_common.h"
 #include "zstd_match.h"
+#include "zstd_match_fast.h"
 
 struct KEntropyArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
@@ -1042,6 +1043,7 @@ struct KFrameArgs {
     u8* dst; const u64* out_off; u32* out_len;
     KFrameState* fstate; u32* hufct;         // per slice: state, two Huffman table slots of 256 words
     u32* remaining;                          // frames not finished yet (decremented here)
+    u32 strategy;                            // 0: level 3 (double-fast); 1: level 1 (fast): other pre-splitter, other encoding-type constant, window 2^19
     u32 stream;                              // 0: one-shot frames (size known); 1: streaming frames (finish = false ... finish = true:
                                              // no content size, window 2^21, input taken in chunks of 128 KiB); 2: same, and the
                                              // closing call brought no data (an empty last block closes a frame that ends on a chunk boundary)
@@ -1079,6 +1081,30 @@ KX_DEV u32 kx_split_block(KEntropyLds& lds, const u8* p, int lane)
     return result;
 }
 
+// ZSTD_splitBlock level 0 ("fromBorders", what strategy fast gets): byte histograms of the first, the last and the middle
+// 512 bytes of the 128 KiB at p.  Uses lds.hist (first), lds.ct (last) and lds.u.seq.cbuf.. (middle: 256 words of the union).
+KX_DEV u32 kx_split_block_borders(KEntropyLds& lds, const u8* p, int lane)
+{
+    u32* const hF = lds.hist; u32* const hL = lds.ct; u32* const hM = (u32*)lds.u.huf.node;      // the union is idle here
+    for (int i = lane; i < 256; i += 64) { hF[i] = 0; hL[i] = 0; hM[i] = 0; }
+    kx_sync();
+    for (int i = lane; i < 512; i += 64) {
+        kx_lds_inc(&hF[p[i]]); kx_lds_inc(&hL[p[KX_BLOCK_MAX - 512 + i]]); kx_lds_inc(&hM[p[KX_BLOCK_MAX / 2 - 256 + i]]);
+    }
+    kx_sync();
+    u32 dFL = 0, dFM = 0, dLM = 0;
+    for (int i = lane; i < 256; i += 64) {
+        int const f = (int)hF[i], l = (int)hL[i], m = (int)hM[i];
+        dFL += (u32)((f > l ? f - l : l - f) * 512); dFM += (u32)((f > m ? f - m : m - f) * 512); dLM += (u32)((l > m ? l - m : m - l) * 512);
+    }
+    dFL = kx_wave_sum(dFL, lane); dFM = kx_wave_sum(dFM, lane); dLM = kx_wave_sum(dLM, lane);
+    kx_sync();
+    if (!(dFL >= 512u * 512u * 14u / 16u)) return KX_BLOCK_MAX;
+    u32 const diff = dFM > dLM ? dFM - dLM : dLM - dFM;
+    if (diff < 512u * 512u / 3u) return 64u << 10;
+    return (dFM > dLM) ? (32u << 10) : (96u << 10);
+}
+
 KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, int lane)
 {
     KFrameState fs = a.fstate[slice];
@@ -1090,7 +1116,7 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
     bool const emptyEnd = a.stream == 2 && (n % KX_BLOCK_MAX) == 0;
     if (fs.ipos == 0 && a.stream) {
         // streaming frame header: no content size, window descriptor for 2^21
-        if (lane == 0) { kx_st32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)((21 - 10) << 3); }
+        if (lane == 0) { kx_st32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)(((a.strategy ? 19 : 21) - 10) << 3); }
         fs.opos = 6;
     } else if (fs.ipos == 0) {
         // frame header: single segment (the window covers the slice), content size
@@ -1116,12 +1142,13 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
         const KSeq* const seqs = a.seqs + (size_t)slice * a.seq_cap;
         u8* const lits = a.lits + (size_t)slice * a.lit_cap;
         u32 const litSize = mm.litSize + mm.lastLL;
+        if (a.strategy) kx_gather_literals(lits, bsrc, bs, seqs, mm.nbSeq, mm.longType, mm.longPos, lane);   // the level-1 parse stores no literals
         kx_wave_copy(lits + mm.litSize, bsrc + (bs - mm.lastLL), mm.lastLL, lane);
         kx_sync();
         bool const suspect = (mm.nbSeq == 0) || (litSize / mm.nbSeq >= 20);
         u32 const litSec = kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane, &hp);
         kx_sync();
-        u32 const seqSec = kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < bs ? bs - litSec : 0u);
+        u32 const seqSec = kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < bs ? bs - litSec : 0u, a.strategy ? 32u : 0u);
         if (seqSec != 0) {
             cSize = litSec + seqSec;
             if (cSize >= bs - kx_min_gain(bs)) cSize = 0;
@@ -1160,7 +1187,7 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
         if (a.stream) { u32 const chunkEnd = (fs.ipos / KX_BLOCK_MAX + 1u) * KX_BLOCK_MAX; if (chunkEnd < n) remaining = chunkEnd - fs.ipos; }
         if (remaining < KX_BLOCK_MAX) next = remaining;
         else if (fs.savings < 3) next = KX_BLOCK_MAX;
-        else next = kx_split_block(lds, src + fs.ipos, lane);
+        else next = a.strategy ? kx_split_block_borders(lds, src + fs.ipos, lane) : kx_split_block(lds, src + fs.ipos, lane);
     }
     fs.blockSize = next;
     if (lane == 0) {
@@ -1188,7 +1215,7 @@ KX_DEV void zstd_frame_body(const KFrameArgs& a)
 struct KBigArgs { KMatchArgs m; KFrameArgs e; u32* counters; u32 spw; };   // counters: one work-queue head per workgroup
                                                                            // spw: slices per wave, 1 .. 64 / G
 
-template <int G>
+template <int G, bool FAST = false>      // FAST: the level-1 parse (a.e.strategy == 1)
 KX_DEV void zstd_big_body(const KBigArgs& a)
 {
     KX_SHARED KEntropyLds lds;
@@ -1210,7 +1237,8 @@ KX_DEV void zstd_big_body(const KBigArgs& a)
             if (!open) break;
             if (lane == 0) *m.counter = 0;
             kx_sync();
-            zstd_match_body<G, true>(m);
+            if (FAST) { KFastArgs fa; fa.m = m; fa.level = 1; zstd_match_fast_body<G, true>(fa); }
+            else zstd_match_body<G, true>(m);
             kx_sync();
             for (u32 t = 0; t < cnt; t++) { zstd_frame_block(a.e, lds, base + t, lane); kx_sync(); }
         }

@@ -8,14 +8,15 @@
 #pragma once
 #include "zstd_match.h"
 
-struct KFastArgs { KMatchArgs m; u32 level; };     // level 1 or 2
+struct KFastArgs { KMatchArgs m; u32 level; };     // level 1 or 2 (block mode: level 1; m.flags bit 8 = stream of unknown size)
 
 // ZSTD_getCParams(level, n, 0) for the fast rows: hashLog, minMatch
 KX_DEV void kx_params_fast(u32 level, u32 n, u32& hashLog, u32& mml)
 {
     u32 W;
     if (level == 1) {
-        if (n <= 16384) { W = 14; hashLog = 15; mml = 5; } else { W = 17; hashLog = 13; mml = 6; }
+        if (n <= 16384) { W = 14; hashLog = 15; mml = 5; } else if (n <= 131072) { W = 17; hashLog = 13; mml = 6; }
+        else if (n <= 262144) { W = 18; hashLog = 14; mml = 6; } else { W = 19; hashLog = 14; mml = 7; }
     } else {
         if (n <= 16384) { W = 14; hashLog = 15; mml = 4; } else { W = 17; hashLog = 15; mml = 5; }
     }
@@ -26,16 +27,20 @@ KX_DEV void kx_params_fast(u32 level, u32 n, u32& hashLog, u32& mml)
 
 enum { KFS_IDLE = 0, KFS_START = 1, KFS_PAIR = 2, KFS_REPLOOP = 3, KFS_MATCH = 4, KFS_CLEANUP = 5, KFS_DONE = 6 };
 
-template <int G>
+// BLK as in zstd_match.h: the block [ipos, ipos + blockSize) of every unfinished slice, per-slice table, repcodes from
+// and back to the frame state.
+template <int G, bool BLK = false>
 KX_DEV void zstd_match_fast_body(const KFastArgs& f)
 {
+    constexpr u32 IDXM = BLK ? 0xFFFFFFFFu : KX_IDX_MASK;
     constexpr int NT = 64 / G;
     const KMatchArgs& a = f.m;
     int const lane = kx_lane();
     int const k = lane & (G - 1);
     int const tbase = lane - k;
     u32 const team = kx_block() * NT + (u32)(lane / G);
-    u32* const H = a.tables + (size_t)team * KX_TBL_ENTRIES;
+    u32* H = BLK ? a.big_tables : a.tables + (size_t)team * KX_TBL_ENTRIES;
+    int bstart = 0; u32 saved1 = 0, saved2 = 0;
     u64 const tmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
 
     int state = KFS_IDLE;
@@ -51,7 +56,7 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
             u32 s = 0, ep = 0;
             if (state == KFS_IDLE && k == 0) {
                 s = kx_atomic_add(a.counter, 1u);
-                if (s < a.n_slices) {
+                if (!BLK && s < a.n_slices) {
                     ep = a.team_epoch[team] + 1;
                     if (ep > KX_EPOCH_MAX) ep = 0;
                     a.team_epoch[team] = ep ? ep : 1u;
@@ -60,7 +65,25 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
             s = kx_shfl(s, tbase); ep = kx_shfl(ep, tbase);
             if (state == KFS_IDLE) {
                 if (s >= a.n_slices) state = KFS_DONE;
-                else {
+                else if (BLK) {
+                    KFrameState const fs = a.fstate[s];
+                    if (fs.blockSize != 0) {
+                        slice = s;
+                        src = a.src + a.in_off[s];
+                        seqs = a.seqs + (size_t)s * a.seq_cap;
+                        H = a.big_tables + (size_t)s * KX_BIG_TBL_ENTRIES;
+                        kx_params_fast(f.level, a.in_len[s], hlog, mls);
+                        if (a.flags & 8u) { hlog = 14; mls = 7; }              // level 1, size unknown: window 19, hash 14, minMatch 7
+                        nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = 0; tag = 0;
+                        bstart = (int)fs.ipos; n = bstart + (int)fs.blockSize;   // n = end of the block
+                        anchor = bstart; ilimit = n - 8;
+                        ip0 = bstart + (bstart == 0 ? 1 : 0);
+                        rep1 = fs.rep[0]; rep2 = fs.rep[1]; saved1 = 0; saved2 = 0;
+                        if (rep2 > (u32)ip0) { saved2 = rep2; rep2 = 0; }
+                        if (rep1 > (u32)ip0) { saved1 = rep1; rep1 = 0; }
+                        state = (fs.blockSize < 8) ? KFS_CLEANUP : KFS_START;
+                    }
+                } else {
                     slice = s;
                     src = a.src + a.in_off[s]; n = (int)a.in_len[s];
                     seqs = a.seqs + (size_t)s * a.seq_cap;
@@ -92,7 +115,7 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                         e = H[h0];
                     }
                     hash0 = h0; hash1 = h1;                  // lane 0's copies are the ones used
-                    matchIdx = ((e & ~KX_IDX_MASK) == tag) ? (e & KX_IDX_MASK) : 0u;
+                    matchIdx = ((e & ~IDXM) == tag) ? (e & IDXM) : 0u;
                     state = KFS_PAIR;
                 }
             }
@@ -112,7 +135,7 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                 else if (matchIdx >= 2u && kx_ld32(src + matchIdx - 2) == kx_ld32(src + ip0)) { kind = 2; H[hash1] = tag | (u32)(ip1 + 2); }
                 else {
                     u32 e = H[hash1];
-                    u32 mi = ((e & ~KX_IDX_MASK) == tag) ? (e & KX_IDX_MASK) : 0u;
+                    u32 mi = ((e & ~IDXM) == tag) ? (e & IDXM) : 0u;
                     hash0 = hash1; hash1 = kx_hash_short_any(kx_ld64(src + ip2), hlog, mls);
                     int const q0 = ip1; ip1 = ip2; ip2 = ip3;
                     n_cur = q0;
@@ -122,7 +145,7 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                         if (step <= 4) H[hash1] = tag | (u32)(ip1 + 2);
                     } else {
                         e = H[hash1];
-                        n_mi = ((e & ~KX_IDX_MASK) == tag) ? (e & KX_IDX_MASK) : 0u;
+                        n_mi = ((e & ~IDXM) == tag) ? (e & IDXM) : 0u;
                         hash0 = hash1; hash1 = kx_hash_short_any(kx_ld64(src + ip2), hlog, mls);
                         n_ip0 = ip1;                          // the next pair starts `step` behind this one's second half
                         n_gap = step;
@@ -213,6 +236,10 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                     KSliceMeta mm;
                     mm.nbSeq = nseq; mm.litSize = nlit; mm.lastLL = (u32)(n - anchor);
                     mm.longType = longType; mm.longPos = longPos; mm.status = status; mm.pad[0] = 0; mm.pad[1] = 0;
+                    if (BLK) {
+                        u32 const s2 = (saved1 != 0 && rep1 != 0) ? saved1 : saved2;
+                        mm.pad[0] = rep1 ? rep1 : saved1; mm.pad[1] = rep2 ? rep2 : s2;
+                    }
                     a.meta[slice] = mm;
                 }
                 state = KFS_IDLE;

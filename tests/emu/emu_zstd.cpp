@@ -148,8 +148,9 @@ int emu_zstd_compress_big(const u8* src, const u64* in_off, const u32* in_len, u
 { return emu_zstd_compress_big_ex(src, in_off, in_len, n, G, nblocks, dst, out_off, out_len, rounds_out, 0); }
 extern "C" __attribute__((visibility("default")))
 int emu_zstd_compress_big_ex(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
-                             u8* dst, const u64* out_off, u32* out_len, u32* rounds_out, u32 stream)
+                             u8* dst, const u64* out_off, u32* out_len, u32* rounds_out, u32 stream_and_strategy)
 {
+    u32 const stream = stream_and_strategy & 0xFFu, strategy = stream_and_strategy >> 8;     // strategy 1: level 1 (fast)
     u32 const block_cap = 128u * 1024u;
     u32 const seq_cap = (block_cap / 4 + 8 + 15) & ~15u, lit_cap = block_cap + 64, scratch_words = block_cap / 4 + 64;
     std::vector<KSeq> seqs((size_t)n * seq_cap);
@@ -164,7 +165,7 @@ int emu_zstd_compress_big_ex(const u8* src, const u64* in_off, const u32* in_len
         KFrameState s; memset(&s, 0, sizeof(s));
         s.blockSize = in_len[i] < KX_BLOCK_MAX ? in_len[i] : KX_BLOCK_MAX; s.first = 1; s.rep[0] = 1; s.rep[1] = 4; s.rep[2] = 8;
         fstate[i] = s;
-        if (in_len[i] == 0) { u8* d = dst + out_off[i]; u32 const magic = 0xFD2FB528u; memcpy(d, &magic, 4); d[4] = stream ? 0x00 : 0x20; d[5] = stream ? 0x58 : 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
+        if (in_len[i] == 0) { u8* d = dst + out_off[i]; u32 const magic = 0xFD2FB528u; memcpy(d, &magic, 4); d[4] = stream ? 0x00 : 0x20; d[5] = stream ? (strategy ? 0x48 : 0x58) : 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
         else remaining++;
     }
     KMatchArgs m;
@@ -177,13 +178,23 @@ int emu_zstd_compress_big_ex(const u8* src, const u64* in_off, const u32* in_len
     e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
     e.scratch = scratch.data(); e.scratch_words = scratch_words;
     e.dst = dst; e.out_off = out_off; e.out_len = out_len;
-    e.fstate = fstate.data(); e.hufct = hufct.data(); e.remaining = &remaining; e.stream = stream;
+    e.fstate = fstate.data(); e.hufct = hufct.data(); e.remaining = &remaining; e.stream = stream; e.strategy = strategy;
+    if (strategy && rounds_out) return -6;
     if (!rounds_out) {
         // product path: one wave per slice walks its chain of blocks
         std::vector<u32> counters(nblocks, 0u);
         KBigArgs g; g.m = m; g.e = e; g.counters = counters.data(); g.spw = (n > 2 && 64 / G >= 2) ? 2 : 1;
         kxemu::failed = 0;
-        switch (G) {
+        if (strategy) switch (G) {
+        case 2:  kxemu::launch(nblocks, [&]() { zstd_big_body<2, true>(g); }); break;
+        case 4:  kxemu::launch(nblocks, [&]() { zstd_big_body<4, true>(g); }); break;
+        case 8:  kxemu::launch(nblocks, [&]() { zstd_big_body<8, true>(g); }); break;
+        case 16: kxemu::launch(nblocks, [&]() { zstd_big_body<16, true>(g); }); break;
+        case 32: kxemu::launch(nblocks, [&]() { zstd_big_body<32, true>(g); }); break;
+        case 64: kxemu::launch(nblocks, [&]() { zstd_big_body<64, true>(g); }); break;
+        default: return -2;
+        }
+        else switch (G) {
         case 2:  kxemu::launch(nblocks, [&]() { zstd_big_body<2>(g); }); break;
         case 4:  kxemu::launch(nblocks, [&]() { zstd_big_body<4>(g); }); break;
         case 8:  kxemu::launch(nblocks, [&]() { zstd_big_body<8>(g); }); break;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generates tests/golden/zstd_levels_golden.json with a binary libzstd 1.5.7: frame length + sha256 at levels 1 and 2
 (strategy "fast"; level 1 is what the reference's Ktor ZstdContentEncoder uses: ZstdContentEncoder.kt:11) for the size
-ladder of make_golden.py (8 slices per size, indices 1000..1007) and the first 256 slices of the 64 KiB mix.
+ladder of make_golden.py (8 slices per size, indices 1000..1007) and the first 256 slices of the 64 KiB mix; streaming
+frames at level 3; level-1 frames of several blocks (128 KiB < size <= 512 KiB) one-shot and streamed.
 Run in the build container only:
 
     python tests/golden/make_golden_levels.py
@@ -52,6 +53,17 @@ def main():
     for d, cuts in helpers.stream_cases():
         f = z.compress_streaming(d, cuts, 8192)
         out["stream"].append([len(d), cuts[-2], len(f), hashlib.sha256(f).hexdigest()])
+    # level 1 above 128 KiB (frames of several blocks, up to its 512 KiB window), one-shot and as streams
+    out["l1_multiblock"] = []
+    for name, d in helpers.multiblock_inputs():
+        if len(d) <= 512 * 1024:
+            f = z.compress(d, 1)
+            out["l1_multiblock"].append([name, len(d), len(f), hashlib.sha256(f).hexdigest()])
+    out["l1_stream"] = []
+    for d, cuts in helpers.stream_cases():
+        if len(d) <= 512 * 1024:
+            f = z.compress_streaming(d, cuts, 8192, 1)
+            out["l1_stream"].append([len(d), cuts[-2], len(f), hashlib.sha256(f).hexdigest()])
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "zstd_levels_golden.json")
     with open(path, "w") as fh:
         json.dump(out, fh, separators=(",", ":"))

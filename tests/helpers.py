@@ -205,6 +205,18 @@ class Oracle:
             raise RuntimeError("oracle: input outside the restatement's scope")
         return o.raw[:n]
 
+    def compress_level_big(self, d: bytes, level: int, stream: bool = False, empty_end: bool = False) -> bytes:
+        """Level 1 or 2 frame of several blocks (any size the window holds), one-shot or as a stream."""
+        k = self.lib
+        k.kref_zstd_fast_compress_big.restype = ctypes.c_size_t
+        k.kref_zstd_fast_compress_big.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        cap = k.kref_compress_bound(len(d)) + 64
+        o = ctypes.create_string_buffer(cap)
+        n = k.kref_zstd_fast_compress_big(o, cap, d, len(d), level, 1 if stream else 0, 1 if empty_end else 0)
+        if n == 2 ** 64 - 1:
+            raise RuntimeError("oracle: input outside the restatement's scope")
+        return o.raw[:n]
+
     def params(self, n):
         a = (ctypes.c_uint32 * 4)()
         self.lib.kref_params_l3(n, a)
@@ -365,7 +377,7 @@ def emu_compress_dict(datas, dictionary, G=4, nblocks=2):
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
 
 
-def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False, stream=0):
+def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False, stream=0, level=3):
     """Frames of several blocks (slices above 128 KiB) on the emulator: the product's one-wave-per-slice kernel body,
     or (by_rounds) the same steps as separate launches per round of blocks.  Returns (frames, rounds)."""
     n = len(datas)
@@ -385,7 +397,7 @@ def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False, stream=0):
     olen = np.zeros(n, dtype=np.uint32)
     rounds = ctypes.c_uint32(0)
     r = emu().emu_zstd_compress_big_ex(_vp(buf), _vp(offs), _vp(lens), n, G, nblocks, _vp(out), _vp(ooff), _vp(olen),
-                                       ctypes.byref(rounds) if by_rounds else None, stream)
+                                       ctypes.byref(rounds) if by_rounds else None, stream | ((1 if level == 1 else 0) << 8))
     assert r == 0, f"emulator reported {r}"
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)], rounds.value
 

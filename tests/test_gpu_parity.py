@@ -219,7 +219,9 @@ def test_streaming_abi_one_shot_like_the_reference(G):
     with pytest.raises(RuntimeError, match="Bad zstd result code -40: Unsupported parameter"):
         ZstdCompressor(compression_level=19)
     with pytest.raises(RuntimeError, match="Bad zstd result code -40: Unsupported parameter"):
-        ZstdCompressor(compression_level=1).transform_bytes(bytes(131073))      # levels 1, 2: one block
+        ZstdCompressor(compression_level=2).transform_bytes(bytes(131073))      # level 2: one block
+    with pytest.raises(RuntimeError, match="Bad zstd result code -40: Unsupported parameter"):
+        ZstdCompressor(compression_level=1).transform_bytes(bytes((512 << 10) + 1))      # level 1: up to its 512 KiB window
     with pytest.raises(RuntimeError, match="Unknown frame descriptor"):
         ZstdDecompressor().transform_bytes(b"\x00" * 32)
     # sampleRoundtrip (ZstdTest.kt:27-32): 1 MiB + 3 random bytes -> frame of several blocks, and back
@@ -464,3 +466,70 @@ def test_streaming_frames_finish_false_then_true():
         lib.kmp_zstd_free_cctx(cctx)
         assert len(out) == flen and helpers.sha256(bytes(out)) == sha, (size, cuts)
         assert ZstdDecompressor().transform_bytes(bytes(out)) == d
+
+
+def test_level1_multiblock_and_streaming_frames():
+    """Level 1 above 128 KiB (up to its 512 KiB window): frames of several blocks one-shot, and the streaming frames the
+    reference's Ktor ZstdContentEncoder (level 1, ZstdContentEncoder.kt:11) produces -- batch entry points and the
+    kmp_zstd_compress_stream call pattern, against libzstd 1.5.7, decoded back on the GPU."""
+    import ctypes
+    from kompressor_amd import _lib, ZstdDecompressor
+    from kompressor_amd.batch import ZstdBatch
+    G = helpers.levels_golden()
+    ins = dict(helpers.multiblock_inputs())
+    rows = G["l1_multiblock"]
+    datas = [ins[r[0]] for r in rows]
+    lens = np.array([len(d) for d in datas], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum((lens[:-1] + 63) & ~63, dtype=np.int64)]).astype(np.int64)
+    host = np.zeros(int(offs[-1]) + int(lens[-1]) + 64, dtype=np.uint8)
+    for o_, d in zip(offs, datas):
+        host[int(o_):int(o_) + len(d)] = np.frombuffer(d, dtype=np.uint8)
+    b = ZstdBatch(max_slices=len(datas), max_slice_bytes=512 << 10)
+    try:
+        dst, ooff, olen = b.compress(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), level=1)
+        torch.cuda.synchronize()
+        hd, ho, hl = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+        frames = [hd[ho[i]:ho[i] + hl[i]].tobytes() for i in range(len(datas))]
+        for (name, n, flen, sha), f in zip(rows, frames):
+            assert len(f) == flen and helpers.sha256(f) == sha, name
+        back, st = gpu_decompress(b, frames, [len(d) for d in datas])
+        assert st == [0] * len(frames) and back == datas
+        cases = [(d, cuts) for d, cuts in helpers.stream_cases() if len(d) <= 512 * 1024]
+        for (d, cuts), (size, fed, flen, sha) in zip(cases, G["l1_stream"]):
+            empty = cuts[-1] == cuts[-2]
+            src = torch.from_numpy(np.frombuffer(d + bytes(64), dtype=np.uint8).copy()).cuda()
+            dst, ooff, olen = b.compress(src, torch.zeros(1, dtype=torch.int64, device="cuda"),
+                                         torch.tensor([len(d)], dtype=torch.int32, device="cuda"), level=1, streaming="empty" if empty else "data")
+            torch.cuda.synchronize()
+            f = dst[: int(olen[0])].cpu().numpy().tobytes()
+            assert len(f) == flen and helpers.sha256(f) == sha, (size, cuts)
+        # level 2 above 128 KiB and level 1 on a 2 MiB context are refused, not served differently
+        with pytest.raises(RuntimeError):
+            b.compress(src, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.tensor([len(d)], dtype=torch.int32, device="cuda"), level=2)
+    finally:
+        b.close()
+    lib = _lib.load()
+    for (d, cuts), (size, fed, flen, sha) in list(zip(cases, G["l1_stream"]))[:10]:
+        cctx = lib.kmp_zstd_create_cctx()
+        assert lib.kmp_zstd_cctx_set_parameter(cctx, 100, 1) == 0
+        out = bytearray()
+        obuf = ctypes.create_string_buffer(8192)
+        pieces = list(zip(cuts[:-1], cuts[1:]))
+        for j, (a0, a1) in enumerate(pieces):
+            end = j == len(pieces) - 1
+            sp = ctypes.c_size_t(a0)
+            while True:
+                dp = ctypes.c_size_t(0)
+                r = lib.kmp_zstd_compress_stream(cctx, obuf, 8192, ctypes.byref(dp), d, a1, ctypes.byref(sp), 2 if end else 0)
+                assert not lib.kmp_zstd_is_error(r), lib.kmp_zstd_get_error_name(r)
+                out += obuf.raw[:dp.value]
+                if (end and r == 0) or (not end and sp.value == a1):
+                    break
+        lib.kmp_zstd_free_cctx(cctx)
+        assert len(out) == flen and helpers.sha256(bytes(out)) == sha, (size, cuts)
+        assert ZstdDecompressor().transform_bytes(bytes(out)) == d
+    # one-shot level 1 above 128 KiB through the streaming ABI (finish = true from the first call)
+    from kompressor_amd import ZstdCompressor
+    name, n, flen, sha = rows[3]
+    f = ZstdCompressor(compression_level=1).transform_bytes(ins[name])
+    assert len(f) == flen and helpers.sha256(f) == sha

@@ -128,6 +128,24 @@ def test_oracle_streaming_frames_match_golden():
         assert len(f) == flen and helpers.sha256(f) == sha, (n, cuts)
 
 
+def test_oracle_level1_multiblock_and_streams_match_golden():
+    """Level 1 above 128 KiB: the "fromBorders" pre-splitter, the table and repcodes carried from block to block, and the
+    level-1 streaming frames (window 2^19) the reference's Ktor encoder produces (ZstdContentEncoder.kt:11)."""
+    o = helpers.oracle()
+    G = helpers.levels_golden()
+    ins = dict(helpers.multiblock_inputs())
+    assert len(G["l1_multiblock"]) >= 20
+    for name, n, flen, sha in G["l1_multiblock"]:
+        f = o.compress_level_big(ins[name], 1)
+        assert len(ins[name]) == n and len(f) == flen and helpers.sha256(f) == sha, name
+    cases = [(d, cuts) for d, cuts in helpers.stream_cases() if len(d) <= 512 * 1024]
+    assert len(cases) == len(G["l1_stream"]) >= 12
+    for (d, cuts), (n, fed, flen, sha) in zip(cases, G["l1_stream"]):
+        assert len(d) == n and cuts[-2] == fed
+        f = o.compress_level_big(d, 1, True, cuts[-1] == cuts[-2])
+        assert len(f) == flen and helpers.sha256(f) == sha, (n, cuts)
+
+
 def test_params_above_128k():
     o = helpers.oracle()
     expect = {131073: (18, 16, 16, 4), 262144: (18, 16, 16, 4), 262145: (19, 16, 17, 5), 524288: (19, 16, 17, 5),
