@@ -187,7 +187,11 @@ KMP_API int kmp_zstd_compress_batch_dict(kmp_batch_ctx* ctx,
 /* Inverse: n zstd frames -> n slices.  Frame i is d_src[d_in_off[i] .. +d_in_len[i]);
  * its content goes to d_dst + d_out_off[i] (capacity d_out_cap[i]); d_out_len[i]
  * receives the decoded size and d_status[i] 0 or a libzstd error code (20 =
- * corruption, 70 = destination too small, 14 = unsupported frame parameter ...). */
+ * corruption, 70 = destination too small, 72 = source size wrong / truncated, 10 = no zstd magic,
+ * 14 = unsupported frame parameter ...).  An entry may hold several frames back to back, with skippable frames
+ * between them: their contents are concatenated, as ZSTD_decompress does; an empty entry decodes to nothing.
+ * Nothing outside [d_in_off[i], +d_in_len[i]) is read and nothing outside [d_out_off[i], +d_out_cap[i]) is
+ * written, whatever the bytes of the entry are (tests/fuzz_decoders.py). */
 KMP_API int kmp_zstd_decompress_batch(kmp_batch_ctx* ctx,
                                       const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                       uint32_t n,

@@ -279,6 +279,13 @@ KX_DEV void inflate_stream(const KiArgs& a, KiLds& lds, u32 f, int lane)
     }
 #undef KI_TAKE
 #undef KI_NEED
+    if (!err) {
+        // the final block must end inside the last byte of the deflate data: bits past the end read as zero and would
+        // otherwise pass for codes (a truncated stream is Z_BUF_ERROR in zlib); bytes left over are not accepted either
+        u32 const bitsUsed = 32u * kx_shfl((u32)br.wp, 0) - kx_shfl((u32)br.cnt, 0);
+        u32 const bytesUsed = (bitsUsed + 7u) >> 3;
+        if (bytesUsed > (u32)nbytes) err = KI_BUF_ERROR; else if (bytesUsed < (u32)nbytes) err = KI_DATA_ERROR;
+    }
     if (!err && fmt == 2) {
         // CRC-32 and length (mod 2^32) of the output against the little-endian trailer
         u32 const got = kx_wave_crc32(dst, op, lds.inw, lane);

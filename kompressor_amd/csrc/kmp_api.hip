@@ -953,6 +953,12 @@ extern "C" size_t kmp_zstd_dctx_load_dictionary(kmp_zstd_dctx* d, const void* di
 static size_t frame_total_size(const u8* p, size_t n, size_t* contentSize)
 {
     if (n < 5) return 0;
+    if ((p[0] & 0xF0) == 0x50 && p[1] == 0x2A && p[2] == 0x4D && p[3] == 0x18) {       // skippable frame: magic, size, payload
+        if (n < 8) return 0;
+        u32 sz; memcpy(&sz, p + 4, 4);
+        *contentSize = 0;
+        return n < 8 + (size_t)sz ? 0 : 8 + (size_t)sz;
+    }
     if (p[0] != 0x28 || p[1] != 0xB5 || p[2] != 0x2F || p[3] != 0xFD) return KERRC(ZE_prefix_unknown);
     u32 const fhd = p[4]; u32 const dictID = fhd & 3, checksum = (fhd >> 2) & 1, single = (fhd >> 5) & 1, fcsId = fhd >> 6;
     if (fhd & 0x08) return KERRC(ZE_frameParameter_unsupported);

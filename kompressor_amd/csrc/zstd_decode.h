@@ -355,23 +355,40 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
     u8* const lits = a.lits + (size_t)f * a.lit_cap;
     u32 err = 0;
 
+    // One entry may hold several frames back to back (and skippable frames between them): their contents are
+    // concatenated, as ZSTD_decompress / ZSTD_decompressStream do (ZSTD_decompressMultiFrame).
+    u32 pos = 0;                      // bytes of the entry consumed
+    u32 op = 0;                       // bytes produced
+    u32 nframes = 0;
+    for (;;) {
     // ---- frame header (every lane computes the same thing) ---------------
-    u32 pos = 0; u32 hasContent = 0, checksum = 0; u64 contentSize = 0; u64 windowSize = 0;
-    if (srcSize < 5) err = KZE_SRCSIZE;
-    else if (kx_ld32(src) != 0xFD2FB528u) err = KZE_PREFIX;
-    if (!err) {
-        u32 const fhd = src[4]; u32 const dictId = fhd & 3, single = (fhd >> 5) & 1, fcsId = fhd >> 6;
+    u32 hasContent = 0, checksum = 0; u64 contentSize = 0; u64 windowSize = 0;
+    u32 const fstart = pos, fbase = op;       // this frame's first input byte / first output byte
+    if (srcSize - pos < 5) { if (srcSize != pos) err = KZE_SRCSIZE; break; }      // an empty entry decodes to nothing, as ZSTD_decompress has it
+    {
+        u32 const magic = kx_ld32(src + pos);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                // skippable frame: magic, 4-byte size, payload
+            if (srcSize - pos < 8) { err = KZE_SRCSIZE; break; }
+            u32 const sz = kx_ld32(src + pos + 4);
+            if (sz > srcSize - pos - 8) { err = KZE_SRCSIZE; break; }
+            pos += 8 + sz; nframes++;
+            continue;
+        }
+        if (magic != 0xFD2FB528u) { err = nframes ? KZE_SRCSIZE : KZE_PREFIX; break; }   // garbage after a complete frame: "Src size is incorrect"
+    }
+    {
+        u32 const fhd = src[pos + 4]; u32 const dictId = fhd & 3, single = (fhd >> 5) & 1, fcsId = fhd >> 6;
         checksum = (fhd >> 2) & 1;
         if (fhd & 0x08) err = KZE_FRAMEPARAM;
-        pos = 5;
+        pos += 5;
+        u32 const didSize = dictId == 3 ? 4 : dictId;
+        u32 const fcsSize = fcsId == 0 ? single : (fcsId == 1 ? 2 : fcsId == 2 ? 4 : 8);
+        if (!err && pos + (single ? 0u : 1u) + didSize + fcsSize > srcSize) err = KZE_SRCSIZE;
         if (!err && !single) {
             u32 const wd = src[pos++]; u32 const wlog = 10 + (wd >> 3);
             if (wlog > 31) err = KZE_WINDOW;
             else { windowSize = 1ull << wlog; windowSize += (windowSize >> 3) * (wd & 7); }
         }
-        u32 const didSize = dictId == 3 ? 4 : dictId;
-        u32 const fcsSize = fcsId == 0 ? single : (fcsId == 1 ? 2 : fcsId == 2 ? 4 : 8);
-        if (!err && pos + didSize + fcsSize > srcSize) err = KZE_SRCSIZE;
         if (!err) {
             u32 did = 0;
             for (u32 i = 0; i < didSize; i++) did |= (u32)src[pos + i] << (8 * i);
@@ -385,13 +402,13 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                 else contentSize = kx_ld64(src + pos);
                 pos += fcsSize;
                 if (single) windowSize = contentSize;
-                if (!err && contentSize > cap) err = KZE_DSTSMALL;
+                if (!err && contentSize > cap - op) err = KZE_DSTSMALL;
             }
         }
     }
+    (void)fstart; (void)windowSize;
 
     // ---- blocks -----------------------------------------------------------
-    u32 op = 0;                       // bytes produced
     u32 rep1 = 1, rep2 = 4, rep3 = 8;
     u32 hufLog = 0, hufNw = 0; bool hufValid = false;
     u32 tlLL = 0, tlOF = 0, tlML = 0;
@@ -420,7 +437,8 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             continue;
         }
         // ---- compressed block --------------------------------------------
-        if (bsize > 128u * 1024u || pos + bsize > srcSize || bsize < 2) { err = KZE_CORRUPT; break; }
+        if (pos + bsize > srcSize || bsize > 128u * 1024u) { err = KZE_SRCSIZE; break; }     // libzstd: "Src size is incorrect" for both
+        if (bsize < 2) { err = KZE_CORRUPT; break; }
         const u8* const bp = src + pos; u32 const bend = bsize;
         // literals section header
         u32 const lh0 = bp[0]; u32 const ltype = lh0 & 3, sf = (lh0 >> 2) & 3;
@@ -640,7 +658,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                 u32 const dlit = op + (st - ll - ml);         // where they go
                 u32 const dmat = dlit + ll;                   // where my match goes
                 // a match may start inside the dictionary (the history before the frame's first byte)
-                if (kx_any(own && off > dmat + a.dict_size)) { err = KZE_CORRUPT; break; }
+                if (kx_any(own && off > dmat - fbase + a.dict_size)) { err = KZE_CORRUPT; break; }
                 // literals: short runs lane-serially (exact length), long runs by the whole wave
                 if (a.flags & 4u) { op += totOut; litUsed += totLit; kx_sync(); done += cnt; continue; }
                 if (own && ll <= 32) {
@@ -659,10 +677,10 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                 for (u64 P = kx_ballot(own); P; ) {
                     int const e = (int)kx_ctz64(P);
                     u32 const mlE = kx_shfl(ml, e), offE = kx_shfl(off, e), dE = kx_shfl(dmat, e);
-                    if (offE > dE) {
-                        // starts in the dictionary: byte k comes from dict[dict_size - (offE - dE) + k] while that is inside
+                    if (offE > dE - fbase) {
+                        // starts in the dictionary: byte k comes from dict[dict_size - inDict + k] while that is inside
                         // the dictionary, then from the frame's own output
-                        u32 const inDict = offE - dE; const u8* const dsrc = a.dict + (a.dict_size - inDict);
+                        u32 const inDict = offE - (dE - fbase); const u8* const dsrc = a.dict + (a.dict_size - inDict);
                         if (offE >= 64) {
                             for (u32 base = 0; base < mlE; base += 64) {
                                 u32 const k = base + (u32)lane;
@@ -697,7 +715,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                         P &= P - 1;
                         continue;
                     }
-                    bool const safe = ((P >> lane) & 1ull) && ml <= 32 && off >= 8 && off <= dmat && (lane == e || dmat - off + ml <= dE);
+                    bool const safe = ((P >> lane) & 1ull) && ml <= 32 && off >= 8 && off <= dmat - fbase && (lane == e || dmat - off + ml <= dE);
                     if (safe) {
                         const u8* const s_ = dst + dmat - off; u8* const d_ = dst + dmat; u32 k = 0;
                         for (; k + 8 <= ml; k += 8) kx_st64(d_ + k, kx_ld64(s_ + k));
@@ -725,16 +743,20 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
         kx_sync();
     }
     kx_sync();
-    if (!err && hasContent && contentSize != op) err = KZE_CORRUPT;
+    if (!err && hasContent && contentSize != op - fbase) err = KZE_CORRUPT;
     if (!err && checksum) {
         if (pos + 4 > srcSize) err = KZE_SRCSIZE;
         else {
             u32 bad = 0;
-            if (lane == 0) bad = ((u32)kxxh64(dst, op) != kx_ld32(src + pos)) ? 1u : 0u;
+            if (lane == 0) bad = ((u32)kxxh64(dst + fbase, op - fbase) != kx_ld32(src + pos)) ? 1u : 0u;
             bad = kx_shfl(bad, 0);
             if (bad) err = KZE_CHECKSUM;
+            pos += 4;
         }
     }
+    if (err) break;
+    nframes++;
+    }   // next frame of the entry
     if (lane == 0) { a.status[f] = err; a.out_len[f] = err ? 0u : op; }
 }
 

@@ -198,3 +198,53 @@ def test_emulated_level1_multiblock_and_streams():
         assert len(f) == flen and helpers.sha256(f) == sha, (size, cuts)
         n += 1
     assert n >= 6
+
+
+def test_decoder_concatenated_and_skippable_frames():
+    """One entry with several frames back to back, skippable frames between them, an empty entry and garbage after a frame:
+    the semantics of ZSTD_decompress / ZSTD_decompressStream (ZSTD_decompressMultiFrame), which the reference's
+    ZstdDecompressor inherits (Wrapper.cpp:130-147)."""
+    import struct
+    o = helpers.oracle()
+    a = corpus.make(31, 1, 5000, mix=ord("T")).tobytes()
+    b = corpus.make(32, 1, 70000, mix=ord("X")).tobytes()
+    c = b"hello compression world"
+    fa, fb, fc = o.compress(a), o.compress(b), o.compress(c)
+    skip = struct.pack("<II", 0x184D2A53, 7) + b"ignored"
+    skip0 = struct.pack("<II", 0x184D2A50, 0)
+    cases = [
+        (fa + fb, a + b, 0), (fa + skip + fc + fb, a + c + b, 0), (skip0 + fc, c, 0), (fc + skip, c, 0), (skip, b"", 0),
+        (b"", b"", 0),                                   # nothing in, nothing out
+        (fa + b"\x01\x02\x03", None, 72),                # fewer than a header's bytes left over: "Src size is incorrect"
+        (fa + b"garbage!!", None, 72),                    # a frame was decoded, then no magic: same code
+        (b"garbage!!", None, 10),                         # no frame at all: "Unknown frame descriptor"
+        (fa + fb[:-5], None, 72),                         # second frame truncated
+        (fa + struct.pack("<II", 0x184D2A51, 100) + b"short", None, 72),
+    ]
+    outs, st = helpers.emu_decompress([f for f, _, _ in cases], [len(a) + len(b) + len(c) + 8] * len(cases))
+    z = helpers.live_libzstd()
+    for (f, want, code), out, s in zip(cases, outs, st):
+        assert s == code, (len(f), s, code)
+        if want is not None:
+            assert out == want
+        if z is not None:
+            try:
+                ref = z.decompress(f, len(a) + len(b) + len(c) + 8)
+            except RuntimeError:
+                ref = None
+            assert ref == want
+    # the second frame may not reach back into the first one's output, and capacity is shared
+    outs, st = helpers.emu_decompress([fa + fb], [len(a) + len(b) - 1])
+    assert st == [70]
+
+
+@pytest.mark.parametrize("which", ["zstd", "inflate"])
+def test_decoders_survive_mutated_input(which):
+    """tests/fuzz_decoders.py, a short run: mutated frames / streams decoded by the kernel bodies with the input and output
+    buffers placed against guard pages (no byte read or written outside them), differentially against libzstd / zlib."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_decoders.py"),
+                        "--which", which, "--iters", "200", "--seed", "11"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and ("FUZZ OK" in r.stdout or "FUZZ SKIP" in r.stdout), r.stdout[-2000:] + r.stderr[-2000:]

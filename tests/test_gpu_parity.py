@@ -533,3 +533,25 @@ def test_level1_multiblock_and_streaming_frames():
     name, n, flen, sha = rows[3]
     f = ZstdCompressor(compression_level=1).transform_bytes(ins[name])
     assert len(f) == flen and helpers.sha256(f) == sha
+
+
+def test_concatenated_and_skippable_frames(batch):
+    """Several frames (and skippable frames) in one entry decode to the concatenated contents, as ZSTD_decompress and the
+    reference's ZstdDecompressor (ZSTD_decompressStream, Wrapper.cpp:130-147) have it; garbage after a frame is an error."""
+    import struct
+    from kompressor_amd import ZstdCompressor, ZstdDecompressor
+    a = corpus.make(31, 1, 5000, mix=ord("T")).tobytes()
+    b = corpus.make(32, 1, 70000, mix=ord("X")).tobytes()
+    c = b"hello compression world"
+    comp = ZstdCompressor(3)
+    fa, fb, fc = comp.transform_bytes(a), comp.transform_bytes(b), comp.transform_bytes(c)
+    skip = struct.pack("<II", 0x184D2A53, 7) + b"ignored"
+    cases = [(fa + fb, a + b, 0), (fa + skip + fc + fb, a + c + b, 0), (skip + fc, c, 0), (b"", b"", 0),
+             (fa + b"garbage!!", None, 72), (b"garbage!!", None, 10), (fa + fb[:-5], None, 72)]
+    outs, st = gpu_decompress(batch, [f for f, _, _ in cases], [len(a) + len(b) + len(c) + 8] * len(cases))
+    for (f, want, code), out, s in zip(cases, outs, st):
+        assert s == code, (len(f), s, code)
+        if want is not None:
+            assert out == want
+    # the streaming entry point takes them frame by frame, like ZSTD_decompressStream
+    assert ZstdDecompressor().transform_bytes(fa + skip + fc + fb) == a + c + b
