@@ -248,3 +248,15 @@ def test_decoders_survive_mutated_input(which):
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_decoders.py"),
                         "--which", which, "--iters", "200", "--seed", "11"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and ("FUZZ OK" in r.stdout or "FUZZ SKIP" in r.stdout), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("which", ["zstd", "l1", "deflate"])
+def test_compressors_stay_inside_their_buffers(which):
+    """tests/guard_pages_compress.py --quick: slices that end exactly at an unmapped page, outputs bounded by
+    kmp_zstd_compress_bound + 1024: the compressor kernel bodies read and write nothing outside."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "guard_pages_compress.py"), which, "--quick"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "GUARD OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
