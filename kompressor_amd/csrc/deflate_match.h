@@ -46,7 +46,7 @@ struct KdArgs {
     u32* syms;          // per slice: 65536 entries: dist | lc << 16
     KdSliceMeta* meta;
     u8* dst; const u64* out_off; u32* out_len;
-    u32 flags;          // timing-only ablations (results wrong): 1 = no match extension, 2 = at most 16 chain steps
+    u32 flags;          // timing-only ablations (results wrong): 1 = no match extension, 2 = at most 16 chain steps; 4 = chunks of 8192 positions (results right); bits 8.. = refill threshold
     u32 format;         // 0 = raw deflate, 1 = zlib wrapper (78 9C header, Adler-32 trailer)
 };
 
@@ -105,18 +105,15 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
 // k_deflate_best: 1024 threads per workgroup; 8192-position chunks with their
 // 32 KiB history (links + bytes) staged in LDS
 // ---------------------------------------------------------------------------
-#define KD_CHUNK 8192
+#define KD_CHUNK 16384                                  /* positions searched per staging phase (flags bit 2: 8192, the earlier setting) */
 #define KD_HIST 32512                                   /* >= MAX_DIST, multiple of 64 */
 struct KdBestLds { u16 lnk[KD_CHUNK + KD_HIST]; u32 sw[(KD_CHUNK + KD_HIST + 272 + 16) / 4]; u32 next; };   // sw = staged bytes, read as aligned words; next = position counter
 
-// 4 bytes at byte offset `o` of the staged window: two aligned LDS words + a funnel shift
-KX_DEV u32 kd_ld32(const u32* sw, int o) { u32 const a = sw[o >> 2], b = sw[(o >> 2) + 1]; return kx_alignbyte(b, a, (u32)o & 3u); }
-// 8 bytes: three aligned words
-KX_DEV u64 kd_ld64(const u32* sw, int o)
-{
-    u32 const a = sw[o >> 2], b = sw[(o >> 2) + 1], c = sw[(o >> 2) + 2]; u32 const sh = (u32)o & 3u;
-    return (u64)kx_alignbyte(b, a, sh) | ((u64)kx_alignbyte(c, b, sh) << 32);
-}
+// 2 / 4 / 8 bytes at byte offset `o` of the staged window.  gfx950 serves unaligned LDS reads (the compiler emits one
+// ds_read_u16 / _b32 / _b64 for these), so no word pairs and funnel shifts are needed.
+KX_DEV u32 kd_ld16(const u32* sw, int o) { u16 v; __builtin_memcpy(&v, (const u8*)sw + o, 2); return v; }
+KX_DEV u32 kd_ld32(const u32* sw, int o) { u32 v; __builtin_memcpy(&v, (const u8*)sw + o, 4); return v; }
+KX_DEV u64 kd_ld64(const u32* sw, int o) { u64 v; __builtin_memcpy(&v, (const u8*)sw + o, 8); return v; }
 
 KX_DEV void deflate_best_body(const KdArgs& a)
 {
@@ -126,9 +123,10 @@ KX_DEV void deflate_best_body(const KdArgs& a)
         const u8* const src = a.src + a.in_off[slice]; int const n = (int)a.in_len[slice];
         const u16* const link = a.link + (size_t)slice * 65536u;
         KdBest* const best = a.best + (size_t)slice * 65536u;
-        for (int cb = 0; cb < n; cb += KD_CHUNK) {
+        int const chunk = (a.flags & 4u) ? 8192 : KD_CHUNK;
+        for (int cb = 0; cb < n; cb += chunk) {
             int const lo = cb > KD_HIST ? cb - KD_HIST : 0;                 // first position staged
-            int const hiP = (cb + KD_CHUNK < n) ? cb + KD_CHUNK : n;        // positions [cb, hiP) are searched
+            int const hiP = (cb + chunk < n) ? cb + chunk : n;        // positions [cb, hiP) are searched
             int const hiB = (hiP + 264 < n) ? hiP + 264 : n;                // bytes staged up to here
             kx_block_sync();
             for (int i = lo + tid; i < hiP; i += nthreads) lds.lnk[i - lo] = (i + 2 < n) ? link[i] : (u16)0;
@@ -175,9 +173,9 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                                         nice = lookahead < 128 ? lookahead : 128;
                                         maxlen = lookahead < KD_MAX_MATCH ? lookahead : KD_MAX_MATCH;
                                         so = p - lo;                              // scan offset in the staged window
-                                        scan01 = kd_ld32(lds.sw, so) & 0xFFFFu;
+                                        scan01 = kd_ld16(lds.sw, so);
                                         bestLen = 2; bestPos = 0; steps = 0;
-                                        scanEnd = kd_ld32(lds.sw, so + 1) & 0xFFFFu;      // scan[best-1], scan[best]
+                                        scanEnd = kd_ld16(lds.sw, so + 1);      // scan[best-1], scan[best]
                                         go = true;
                                     }
                                 }
@@ -193,9 +191,9 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                         bool done = false;
                         steps++;
                         // the candidate can only win if it matches at the current best length too (most fail here)
-                        u32 const mEnd = kd_ld32(lds.sw, mo + bestLen - 1) & 0xFFFFu;
+                        u32 const mEnd = kd_ld16(lds.sw, mo + bestLen - 1);
                         bool const endOk = (bestLen < maxlen) ? (mEnd == scanEnd) : ((mEnd & 0xFFu) == (scanEnd & 0xFFu));
-                        if (endOk && (kd_ld32(lds.sw, mo) & 0xFFFFu) == scan01) {
+                        if (endOk && kd_ld16(lds.sw, mo) == scan01) {
                             int len = 2;
                             if (a.flags & 1u) len = 3; else
                             for (;;) {                                  // 8 bytes per step
@@ -208,7 +206,7 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                             if (len > bestLen) {
                                 bestLen = len; bestPos = c;
                                 if (len >= nice) done = true;
-                                else scanEnd = kd_ld32(lds.sw, so + bestLen - 1) & 0xFFFFu;
+                                else scanEnd = kd_ld16(lds.sw, so + bestLen - 1);
                             }
                         }
                         if (steps == 32 || (done && steps < 32)) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
