@@ -6,7 +6,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkompressor_hip.so")
+LIB_PATH = os.environ.get("KMP_LIB_PATH") or os.path.join(HERE, "libkompressor_hip.so")    # KMP_LIB_PATH: another build of the same library (A/B timing)
 
 # every symbol include/kompressor_hip.h declares: (name, restype, argtypes)
 _c = ctypes

@@ -55,13 +55,13 @@ __global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 
     if (len == 0) { u8* d = dst + out_off[i]; kx_st32(d, 0xFD2FB528u); d[4] = stream ? 0x00 : 0x20; d[5] = (u8)stream; /* the window descriptor byte of a streaming frame, 0 = one-shot */ d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
     else atomicAdd(remaining, 1u);
 }
-__global__ __launch_bounds__(64) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
+__global__ __launch_bounds__(64, 6) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
 
 __global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chains_body(a); }
 __global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_parse(KdArgs a) { deflate_parse_body(a); }
-__global__ __launch_bounds__(64) void k_deflate_encode(KdArgs a) { deflate_encode_body(a); }
-__global__ __launch_bounds__(64) void k_inflate(KiArgs a) { inflate_body(a); }
+__global__ __launch_bounds__(64, 4) void k_deflate_encode(KdArgs a) { deflate_encode_body(a); }
+__global__ __launch_bounds__(64, 5) void k_inflate(KiArgs a) { inflate_body(a); }
 
 // exclusive prefix sum of u32 lengths into u64 offsets, single workgroup
 __global__ __launch_bounds__(1024) void k_scan_lengths(const u32* len, u32 n, u64* off)
@@ -162,8 +162,8 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     c->seq_cap = (block_cap / 4 + 8 + 15) & ~15u; c->lit_cap = block_cap + 64; c->scratch_words = block_cap / 4 + 64;
     size_t const ns = max_slices;
     if (c->big) {
-        c->big_G = (int)env_u32("KMP_BIG_TEAM_LANES", 8);
-        if (c->big_G != 2 && c->big_G != 4 && c->big_G != 8 && c->big_G != 16 && c->big_G != 32 && c->big_G != 64) c->big_G = 8;
+        c->big_G = (int)env_u32("KMP_BIG_TEAM_LANES", 0);      // 0 = by batch size (zstd_compress_big)
+        if (c->big_G != 0 && c->big_G != 2 && c->big_G != 4 && c->big_G != 8 && c->big_G != 16 && c->big_G != 32 && c->big_G != 64) c->big_G = 0;
         HIP_TRY(hipMalloc((void**)&c->fstate, ns * sizeof(KFrameState)));
         HIP_TRY(hipMalloc((void**)&c->hufct, ns * 512 * sizeof(u32)));
         HIP_TRY(hipMalloc((void**)&c->big_tables, ns * KX_BIG_TBL_ENTRIES * sizeof(u32)));
@@ -368,13 +368,16 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
         // one wave per slice walks its chain of blocks
         // few slices: one per wave (most waves); many: up to 64 / G per wave so that all of them are in flight
         KBigArgs g; g.m = m; g.e = e; g.counters = c->big_counters;
+        // lanes per slice: every slice of the batch should be in flight (its block chain is serial), and a parse team
+        // gains little beyond 8 lanes -- measured on 1 MiB and 256 KiB slices: 8 lanes up to 16 K slices, 4 above
+        int const bigG = c->big_G ? c->big_G : (n >= 16384u ? 4 : 8);
         u32 const resident = 12u * 256u;
         u32 spw = env_u32("KMP_BIG_SLICES_PER_WAVE", (n + resident - 1) / resident);
-        if (spw < 1) spw = 1; if (spw > 64u / (u32)c->big_G) spw = 64u / (u32)c->big_G;
+        if (spw < 1) spw = 1; if (spw > 64u / (u32)bigG) spw = 64u / (u32)bigG;
         g.spw = spw;
         u32 const grid = (n + spw - 1) / spw;
         HIP_TRY(hipMemsetAsync(c->big_counters, 0, (size_t)n * 4, st));
-        if (strategy) switch (c->big_G) {
+        if (strategy) switch (bigG) {
         case 2:  hipLaunchKernelGGL(k_zstd_big_fast<2>, dim3(grid), dim3(64), 0, st, g); break;
         case 4:  hipLaunchKernelGGL(k_zstd_big_fast<4>, dim3(grid), dim3(64), 0, st, g); break;
         case 8:  hipLaunchKernelGGL(k_zstd_big_fast<8>, dim3(grid), dim3(64), 0, st, g); break;
@@ -382,7 +385,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
         case 32: hipLaunchKernelGGL(k_zstd_big_fast<32>, dim3(grid), dim3(64), 0, st, g); break;
         default: hipLaunchKernelGGL(k_zstd_big_fast<64>, dim3(grid), dim3(64), 0, st, g); break;
         }
-        else switch (c->big_G) {
+        else switch (bigG) {
         case 2:  hipLaunchKernelGGL(k_zstd_big<2>, dim3(grid), dim3(64), 0, st, g); break;
         case 4:  hipLaunchKernelGGL(k_zstd_big<4>, dim3(grid), dim3(64), 0, st, g); break;
         case 8:  hipLaunchKernelGGL(k_zstd_big<8>, dim3(grid), dim3(64), 0, st, g); break;
@@ -395,7 +398,8 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
         return KMP_OK;
     }
     // (experiment switch KMP_BIG_ROUNDS=1) the same steps as separate launches per round of blocks
-    u32 const tpw = 64 / (u32)c->big_G;
+    int const bigR = c->big_G ? c->big_G : 8;
+    u32 const tpw = 64 / (u32)bigR;
     u32 const blocks = (n + tpw - 1) / tpw;
     u32 rounds = 0;
     for (;;) {
@@ -405,7 +409,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
         if (left == 0) break;
         if (++rounds > KMP_MAX_BIG_SLICE_BYTES / 8192u + 2u) { g_last_error = "kmp_zstd_compress_batch: block rounds did not finish"; return KMP_ERR_KERNEL; }
         HIP_TRY(hipMemsetAsync(c->counter, 0, 4, st));
-        switch (c->big_G) {
+        switch (bigR) {
         case 2:  hipLaunchKernelGGL(k_zstd_match_blk<2>, dim3(blocks), dim3(64), 0, st, m); break;
         case 4:  hipLaunchKernelGGL(k_zstd_match_blk<4>, dim3(blocks), dim3(64), 0, st, m); break;
         case 8:  hipLaunchKernelGGL(k_zstd_match_blk<8>, dim3(blocks), dim3(64), 0, st, m); break;
