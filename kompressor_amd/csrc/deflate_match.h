@@ -158,7 +158,7 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                         int const first = (int)kx_ctz64(idle);
                         u32 base = 0;
                         if (lane == first) base = kx_lds_add(&lds.next, (u32)nidle);
-                        base = kx_shfl(base, first);
+                        base = kx_bcast(base, first);                // v_readlane: base, and with it `drained`, stay on the scalar unit
                         if (!active) {
                             int const np = (int)base + (int)kx_popc64(idle & ((1ull << lane) - 1ull));
                             if (np < hiP) {

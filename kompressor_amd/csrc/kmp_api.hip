@@ -123,7 +123,8 @@ struct kmp_batch_ctx {
     // zstd compress pipeline: entropy coding of chunk i (second stream) runs beside the match kernel of chunk i+1
     hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join, ev_last_match; int have_last_match; u32 last_chunks;
     // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
-    u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta;
+    u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta;      // two halves of dfl_chunk slices each
+    hipEvent_t dfl_searched[2], dfl_done[2]; int dfl_events;
     // frames of several blocks (max_slice_bytes above 128 KiB): per-slice state carried between the block rounds
     // raw-content dictionary of the last kmp_zstd_compress_batch_dict call: device copy + CDict tables (built on the host)
     u8* d_dict; u32* d_dictL; u32* d_dictS; u32 dict_size; u64 dict_hash; u32 cdW, cdH, cdC, cdM;
@@ -204,6 +205,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     if (c->ev_last_match) (void)hipEventDestroy(c->ev_last_match);
     if (c->st2) (void)hipStreamDestroy(c->st2);
     (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta);
+    if (c->dfl_events) for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->dfl_searched[i]); (void)hipEventDestroy(c->dfl_done[i]); }
     delete c;
 }
 
@@ -578,34 +580,53 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->dfl_link) {
-        // workspace for up to 65 536 slices at once (56 GiB of the 288 GB): the lane-per-slice parse kernel is pure latency,
-        // one launch over the whole batch costs what one over a quarter costs
-        u32 const cap = env_u32("KMP_DEFLATE_CHUNK", 65536u);
+        // Two workspace halves of up to 16 384 slices each (28 GiB of the 288 GB for both): while the search kernels
+        // (chains, best: LDS-bound) work on one piece of the batch, the parse (one lane per slice, pure latency, no LDS)
+        // and the encoder of the previous piece run beside them on the context's second stream.
+        u32 const cap = env_u32("KMP_DEFLATE_CHUNK", 16384u);
         u32 const chunk = c->max_slices < cap ? c->max_slices : cap;
-        HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)chunk * 65536u * sizeof(u16)));
-        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)chunk * 65536u * sizeof(KdBest)));
-        HIP_TRY(hipMalloc((void**)&c->dfl_syms, (size_t)chunk * 65536u * sizeof(u32)));
-        HIP_TRY(hipMalloc((void**)&c->dfl_meta, (size_t)chunk * sizeof(KdSliceMeta)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)2 * chunk * 65536u * sizeof(u16)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * chunk * 65536u * sizeof(KdBest)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_syms, (size_t)2 * chunk * 65536u * sizeof(u32)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_meta, (size_t)2 * chunk * sizeof(KdSliceMeta)));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipEventCreateWithFlags(&c->dfl_searched[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->dfl_done[i], hipEventDisableTiming));
+        }
+        c->dfl_events = 1;
         c->dfl_chunk = chunk;
     }
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[6], st));
-    for (u32 first = 0; first < n; first += c->dfl_chunk) {
+    bool const serial = env_u32("KMP_DEFLATE_SERIAL", 0) != 0;          // experiment switch: everything on the caller's stream
+    u32 piece = 0;
+    for (u32 first = 0; first < n; first += c->dfl_chunk, piece++) {
         u32 const m = (n - first < c->dfl_chunk) ? n - first : c->dfl_chunk;
+        u32 const h = piece & 1u;                                        // workspace half
         KdArgs a;
         a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = d_in_len + first; a.n_slices = m;
-        a.link = c->dfl_link; a.best = c->dfl_best; a.syms = c->dfl_syms; a.meta = c->dfl_meta;
+        a.link = c->dfl_link + (size_t)h * c->dfl_chunk * 65536u; a.best = c->dfl_best + (size_t)h * c->dfl_chunk * 65536u;
+        a.syms = c->dfl_syms + (size_t)h * c->dfl_chunk * 65536u; a.meta = c->dfl_meta + (size_t)h * c->dfl_chunk;
         a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = env_u32("KMP_DEFLATE_FLAGS", 0); a.format = format;
-        bool const prof = c->profiling && first == 0;      // per-kernel events for the first chunk
+        bool const prof = c->profiling && first == 0;      // per-kernel events for the first piece
+        hipStream_t const s2 = serial ? st : c->st2;
+        if (!serial && piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[h], 0));      // this half's previous piece has been encoded
         if (prof) HIP_TRY(hipEventRecord(c->ev[8], st));
         hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(256), 0, st, a);
         if (prof) HIP_TRY(hipEventRecord(c->ev[9], st));
         hipLaunchKernelGGL(k_deflate_best, dim3(m), dim3(1024), 0, st, a);
         if (prof) HIP_TRY(hipEventRecord(c->ev[10], st));
-        hipLaunchKernelGGL(k_deflate_parse, dim3((m + 63) / 64), dim3(64), 0, st, a);
-        if (prof) HIP_TRY(hipEventRecord(c->ev[11], st));
-        hipLaunchKernelGGL(k_deflate_encode, dim3(m), dim3(64), 0, st, a);
-        if (prof) HIP_TRY(hipEventRecord(c->ev[12], st));
+        if (!serial) { HIP_TRY(hipEventRecord(c->dfl_searched[h], st)); HIP_TRY(hipStreamWaitEvent(s2, c->dfl_searched[h], 0)); }
+        if (prof) HIP_TRY(hipEventRecord(c->ev[13], s2));
+        hipLaunchKernelGGL(k_deflate_parse, dim3((m + 63) / 64), dim3(64), 0, s2, a);
+        if (prof) HIP_TRY(hipEventRecord(c->ev[11], s2));
+        hipLaunchKernelGGL(k_deflate_encode, dim3(m), dim3(64), 0, s2, a);
+        if (prof) HIP_TRY(hipEventRecord(c->ev[12], s2));
         HIP_TRY(hipGetLastError());
+        if (!serial) HIP_TRY(hipEventRecord(c->dfl_done[h], s2));
+    }
+    if (!serial) {                                                        // the caller's stream continues when every piece is out
+        HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[0], 0));
+        if (piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[1], 0));
     }
     if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[7], st)); c->ev_valid[3] = 1; }
     return KMP_OK;
@@ -616,7 +637,8 @@ extern "C" int kmp_deflate_last_kernel_ms(kmp_batch_ctx* c, float* ms4)
 {
     if (!c || !ms4 || !c->ev_valid[3]) { g_last_error = "no deflate timing recorded"; return KMP_ERR_ARG; }
     HIP_TRY(hipEventSynchronize(c->ev[12]));
-    for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&ms4[i], c->ev[8 + i], c->ev[9 + i]));
+    static const int from[4] = { 8, 9, 13, 11 }, to[4] = { 9, 10, 11, 12 };
+    for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&ms4[i], c->ev[from[i]], c->ev[to[i]]));
     return KMP_OK;
 }
 

@@ -208,3 +208,22 @@ def test_fuzz_ragged_sizes_against_zlib(batch):
     for i, (d, f) in enumerate(zip(datas, outs)):
         c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, 0)
         assert f == c.compress(d) + c.flush(), (i, len(d))
+
+
+def test_batches_larger_than_the_workspace_go_through_in_pieces(monkeypatch):
+    """The search kernels of one piece of a batch run beside the parse + encode of the previous one (two workspace halves,
+    two streams).  With the piece size forced down to 37 slices a 300-slice batch takes nine pieces: every stream must
+    still equal zlib's, twice in a row on the same context (the halves are reused)."""
+    from kompressor_amd.batch import ZstdBatch
+    monkeypatch.setenv("KMP_DEFLATE_CHUNK", "37")
+    rng = np.random.default_rng(99)
+    datas = [corpus.make(7000 + i, 1, int(rng.integers(0, 30000)), mix=ord("TXSBDIZR"[i % 8])).tobytes() for i in range(300)]
+    b = ZstdBatch(max_slices=300, max_slice_bytes=65536)
+    try:
+        for _ in range(2):
+            outs = gpu_deflate(b, datas)
+            for i, (d, f) in enumerate(zip(datas, outs)):
+                c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, 0)
+                assert f == c.compress(d) + c.flush(), (i, len(d))
+    finally:
+        b.close()
