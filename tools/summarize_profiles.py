@@ -35,8 +35,10 @@ def main():
              "# Durations in microseconds (rocprofv3 --kernel-trace --stats, result database view top_kernels).", ""]
     runs = [("compress", "python3 bench.py --steps 5 --warmup 1      (compress, BASELINE configs[1])"),
             ("decompress", "python3 bench.py --mode decompress --steps 3 --warmup 1 --no-cpu   (configs[2]; the frames are compressed first)"),
-            ("deflate", "python3 bench.py --mode deflate --steps 1 --warmup 0 --slices 16384   (configs[4], one workspace chunk)"),
-            ("big1m", "python3 bench.py --slice-kib 1024 --slices 8192 --steps 2 --warmup 1   (north_star slice-size sweep: 1 MiB slices, frames of several blocks)")]
+            ("deflate", "python3 bench.py --mode deflate --steps 1 --warmup 0   (configs[4]: four pieces of 16 384 slices, search of one beside parse + encode of the previous)"),
+            ("big1m", "python3 bench.py --slice-kib 1024 --slices 8192 --steps 2 --warmup 1   (north_star slice-size sweep: 1 MiB slices, frames of several blocks)"),
+            ("big256k", "python3 bench.py --slice-kib 256 --slices 32768 --steps 2 --warmup 1 --no-cpu   (slice-size sweep: 256 KiB slices)"),
+            ("level1", "python3 bench.py --level 1 --steps 3 --warmup 1 --no-cpu   (65 536 x 64 KiB at level 1, the Ktor encoder's level)")]
     for key, cmd in runs:
         db = os.path.join(P, key, "run_results.db")
         if not os.path.exists(db):
