@@ -230,6 +230,8 @@ def main():
             k_entropy.append(b.last_kernel_ms(1))
     fence()
     dt = time.perf_counter() - t0
+    if os.environ.get("KMP_BENCH_DEBUG") and k_match:
+        print("per-step k_zstd_match ms:", [round(x, 1) for x in k_match], file=sys.stderr)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

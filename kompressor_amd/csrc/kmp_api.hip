@@ -471,9 +471,14 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     u32 const tpw = 64 / (u32)c->G;
     u32 const match_flags = env_u32("KMP_MATCH_FLAGS", 6), entropy_pad = env_u32("KMP_ENTROPY_PAD_LDS", 0);   // experiments only
     u32 const per = (n + chunks - 1) / chunks;
+    u32 starts[KMP_MAX_CHUNKS + 1];
+    for (u32 ci = 0; ci <= chunks; ci++) starts[ci] = (ci * per < n) ? ci * per : n;
+    // two chunks: the last entropy launch is the only one nothing runs beside, so the second chunk is the smaller one
+    if (chunks == 2) { u32 const pm = env_u32("KMP_ZSTD_FIRST_PERMILLE", 500); if (pm >= 100 && pm <= 950) starts[1] = (u32)((u64)n * pm / 1000u) & ~63u; if (starts[1] == 0 || starts[1] >= n) starts[1] = per; }
     bool forked = false;
     for (u32 ci = 0; ci < chunks; ci++) {
-        u32 const first = ci * per, m_n = (n - first < per) ? n - first : per;
+        u32 const first = starts[ci], m_n = starts[ci + 1] - first;
+        if (m_n == 0) continue;
         KMatchArgs m;
         m.src = (const u8*)d_src; m.in_off = d_in_off + first; m.in_len = d_in_len + first; m.n_slices = m_n;
         m.seqs = c->seqs + (size_t)first * c->seq_cap; m.seq_cap = c->seq_cap; m.meta = c->meta + first;
