@@ -10,7 +10,7 @@
 // so the candidate list of a position does not depend on the parse.  That splits the
 // work into three kernels:
 //   k_deflate_chains : link[p] = previous position with the same 3-byte hash
-//                      (one 256-thread workgroup per slice, head table in LDS)
+//                      (one workgroup of 1 .. 4 waves per slice, head table in LDS)
 //   k_deflate_best   : for every position, the match zlib's longest_match would
 //                      return after 32 and after 128 chain steps (1024 threads per
 //                      slice, chain links + source bytes of the 32 KiB window in LDS)
@@ -63,39 +63,59 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
         for (int i = tid; i < 32768; i += nthreads) head[i] = 0;
         kx_block_sync();
         u32 const nIns = n >= 3 ? n - 2 : 0;                // positions 0 .. n-3 enter the chains, in order
-        // every wave hashes its 64 positions of the NEXT block while the current block takes its turns on
-        // the LDS head table (global loads stay outside the serialised part)
-        u32 hN = 0x8000u + (u32)lane; bool validN = false;
-        { u32 const p0 = (u32)wv * 64u + (u32)lane; validN = p0 < nIns; if (validN) hN = kd_hash3(src[p0], src[p0 + 1], src[p0 + 2]); }
-        for (u32 base = 0; base < nIns; base += (u32)nthreads) {
-            u32 const p = base + (u32)wv * 64u + (u32)lane; bool const valid = validN; u32 const h = hN;
-            { u32 const pn = p + (u32)nthreads; validN = pn < nIns; hN = 0x8000u + (u32)lane; if (validN) hN = kd_hash3(src[pn], src[pn + 1], src[pn + 2]); }
-            u32 lk = 0;
-            for (int w = 0; w < nw; w++) {
-                if (wv == w) {
-                    u32 const old = valid ? head[h] : 0u;
-                    kx_lockstep();
-                    if (valid) head[h] = (u16)p;
-                    kx_lockstep();
-                    u32 const chk = valid ? head[h] : p;
-                    lk = old;
-                    // lanes of this wave that share a bucket: one bucket per round; inside a bucket the nearest
-                    // lower lane is the predecessor and the highest lane is the one left in the table
-                    for (u64 losers = kx_ballot(valid && chk != (p & 0xFFFFu)); losers; ) {
-                        int const L = (int)kx_ctz64(losers);
-                        u32 const hL = kx_shfl(h, L);
-                        u64 const grp = kx_ballot(valid && h == hL);
-                        if (valid && h == hL) {
-                            u64 const below = grp & ((1ull << lane) - 1ull);
-                            if (below) lk = p - (u32)(lane - (63 - (int)__builtin_clzll(below)));
-                            if ((grp >> lane) == 1ull) head[h] = (u16)p;          // highest lane of the bucket
-                        }
-                        losers &= ~grp;
-                    }
-                }
-                kx_block_sync();
+        // The turns on the LDS head table are short (three LDS round trips); what a wave would wait for is the global
+        // load of its source bytes.  So the bytes are fetched a GROUP of four rounds ahead: the loads of group g + 1
+        // are in flight while the turns of group g are taken (the hash is computed when the bytes are used).
+        u32 hq[4]; bool vq[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 const p0 = (u32)k * (u32)nthreads + (u32)wv * 64u + (u32)lane;
+            vq[k] = p0 < nIns; hq[k] = 0;
+            if (vq[k]) hq[k] = (p0 + 4 <= n) ? kx_ld32(src + p0) : ((u32)src[p0] | ((u32)src[p0 + 1] << 8) | ((u32)src[p0 + 2] << 16));
+        }
+        for (u32 gbase = 0; gbase < nIns; gbase += 4u * (u32)nthreads) {
+            u32 hn[4]; bool vn[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u32 const pn = gbase + (4u + (u32)k) * (u32)nthreads + (u32)wv * 64u + (u32)lane;
+                vn[k] = pn < nIns; hn[k] = 0;
+                if (vn[k]) hn[k] = (pn + 4 <= n) ? kx_ld32(src + pn) : ((u32)src[pn] | ((u32)src[pn + 1] << 8) | ((u32)src[pn + 2] << 16));
             }
-            if (valid) link[p] = (u16)lk;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u32 const base = gbase + (u32)k * (u32)nthreads;
+                if (base >= nIns) break;                    // uniform over the workgroup
+                u32 const p = base + (u32)wv * 64u + (u32)lane; bool const valid = vq[k];
+                u32 const h = valid ? kd_hash3(hq[k] & 0xFFu, (hq[k] >> 8) & 0xFFu, (hq[k] >> 16) & 0xFFu) : 0x8000u + (u32)lane;   // the bytes were fetched a group ago
+                u32 lk = 0;
+                for (int w = 0; w < nw; w++) {
+                    if (wv == w) {
+                        u32 const old = valid ? head[h] : 0u;
+                        kx_lockstep();
+                        if (valid) head[h] = (u16)p;
+                        kx_lockstep();
+                        u32 const chk = valid ? head[h] : p;
+                        lk = old;
+                        // lanes of this wave that share a bucket: one bucket per round; inside a bucket the nearest
+                        // lower lane is the predecessor and the highest lane is the one left in the table
+                        for (u64 losers = kx_ballot(valid && chk != (p & 0xFFFFu)); losers; ) {
+                            int const L = (int)kx_ctz64(losers);
+                            u32 const hL = kx_bcast(h, L);                       // v_readlane: L is uniform
+                            u64 const grp = kx_ballot(valid && h == hL);
+                            if (valid && h == hL) {
+                                u64 const below = grp & ((1ull << lane) - 1ull);
+                                if (below) lk = p - (u32)(lane - (63 - (int)__builtin_clzll(below)));
+                                if ((grp >> lane) == 1ull) head[h] = (u16)p;          // highest lane of the bucket
+                            }
+                            losers &= ~grp;
+                        }
+                    }
+                    if (nw > 1) kx_block_sync();
+                }
+                if (valid) link[p] = (u16)lk;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { hq[k] = hn[k]; vq[k] = vn[k]; }
         }
         kx_block_sync();
     }

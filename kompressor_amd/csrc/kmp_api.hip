@@ -602,6 +602,7 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
         c->dfl_chunk = chunk;
     }
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[6], st));
+    u32 chain_waves = env_u32("KMP_DEFLATE_CHAIN_WAVES", 4); if (chain_waves < 1 || chain_waves > 4) chain_waves = 4;
     bool const serial = env_u32("KMP_DEFLATE_SERIAL", 0) != 0;          // experiment switch: everything on the caller's stream
     u32 piece = 0;
     for (u32 first = 0; first < n; first += c->dfl_chunk, piece++) {
@@ -616,7 +617,7 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
         hipStream_t const s2 = serial ? st : c->st2;
         if (!serial && piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[h], 0));      // this half's previous piece has been encoded
         if (prof) HIP_TRY(hipEventRecord(c->ev[8], st));
-        hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(64u * chain_waves), 0, st, a);
         if (prof) HIP_TRY(hipEventRecord(c->ev[9], st));
         hipLaunchKernelGGL(k_deflate_best, dim3(m), dim3(1024), 0, st, a);
         if (prof) HIP_TRY(hipEventRecord(c->ev[10], st));
