@@ -94,7 +94,7 @@ KX_DEV void inflate_stream(const KiArgs& a, KiLds& lds, u32 f, int lane)
     bool last = false; bool inBlock = false; int btype = 0; u32 storedLeft = 0;
     // loop of "batches": each batch decodes until 64 matches are queued, 384 words are consumed, or the block ends
     while (!err) {
-        int const curW = (int)kx_shfl((u32)br.wp, 0);
+        int const curW = (int)kx_bcast((u32)br.wp, 0);
         {   // restage 640 words from the read position (a batch consumes at most ~530)
             kx_sync();
             int const lo = curW > 2 ? curW - 2 : 0;
@@ -249,7 +249,7 @@ KX_DEV void inflate_stream(const KiArgs& a, KiLds& lds, u32 f, int lane)
             u32 const dmat = own ? lds.stage[3 * lane] : 0u, ml = own ? lds.stage[3 * lane + 1] : 0u, off = own ? lds.stage[3 * lane + 2] : 8u;
             for (u64 P = kx_ballot(own); P; ) {
                 int const e2 = (int)kx_ctz64(P);
-                u32 const mlE = kx_shfl(ml, e2), offE = kx_shfl(off, e2), dE = kx_shfl(dmat, e2);
+                u32 const mlE = kx_bcast(ml, e2), offE = kx_bcast(off, e2), dE = kx_bcast(dmat, e2);
                 if (mlE > 32 || offE < 8) {
                     const u8* const ms = dst + dE - offE;
                     if (offE >= 64) {

@@ -360,7 +360,7 @@ KX_DEV void deflate_encode_slice(const KdArgs& a, KdEncLds& lds, u32 slice, int 
                 u32 sc = nb;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { u32 const t = kx_shfl(sc, lane - o); if (lane >= o) sc += t; }
-                u32 const tot = kx_shfl(sc, 63);
+                u32 const tot = kx_bcast(sc, 63);
                 kd_cbuf_put(lds.cbuf, (bitpos & 31u) + (sc - nb), v, nb);
                 kx_sync();
                 u32 const nbits = (bitpos & 31u) + tot, nfull = nbits >> 5;

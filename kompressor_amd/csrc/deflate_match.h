@@ -171,6 +171,7 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                 int const lane = kx_lane();
                 int const maxSteps = (a.flags & 2u) ? 16 : 128;
                 int const refillAt = (a.flags >> 8) ? (int)(a.flags >> 8) : 16;      // idle lanes that trigger a refill (tuning switch)
+                int const reps = ((a.flags >> 4) & 15u) ? (int)((a.flags >> 4) & 15u) : 8;   // flags bits 4..7: candidate steps per refill check (1: 349 ms, 2: 332, 4: 325, 8: 320 per 16 384 slices)
                 for (;;) {
                     u64 const idle = kx_ballot(!active);
                     int const nidle = (int)kx_popc64(idle);
@@ -205,37 +206,41 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                         if ((int)base + nidle >= hiP) drained = true;
                     }
                     if (!kx_any(active)) { if (drained) break; continue; }
-                    if (active) {
-                        int const mo = c - lo;
-                        int const cnext = lds.lnk[mo];
-                        bool done = false;
-                        steps++;
-                        // the candidate can only win if it matches at the current best length too (most fail here)
-                        u32 const mEnd = kd_ld16(lds.sw, mo + bestLen - 1);
-                        bool const endOk = (bestLen < maxlen) ? (mEnd == scanEnd) : ((mEnd & 0xFFu) == (scanEnd & 0xFFu));
-                        if (endOk && kd_ld16(lds.sw, mo) == scan01) {
-                            int len = 2;
-                            if (a.flags & 1u) len = 3; else
-                            for (;;) {                                  // 8 bytes per step
-                                u64 const d = kd_ld64(lds.sw, mo + len) ^ kd_ld64(lds.sw, so + len);
-                                if (d) { len += (int)(kx_ctz64(d) >> 3); break; }
-                                len += 8;
-                                if (len >= maxlen) break;
+                    // `reps` candidate steps between two looks at the refill counter: the kernel is bound by instruction issue and
+                    // the bookkeeping above costs as much as a step (a lane that finishes early idles for <= reps - 1 steps)
+                    for (int rep = 0; rep < reps; rep++) {
+                        if (active) {
+                            int const mo = c - lo;
+                            int const cnext = lds.lnk[mo];
+                            bool done = false;
+                            steps++;
+                            // the candidate can only win if it matches at the current best length too (most fail here)
+                            u32 const mEnd = kd_ld16(lds.sw, mo + bestLen - 1);
+                            bool const endOk = (bestLen < maxlen) ? (mEnd == scanEnd) : ((mEnd & 0xFFu) == (scanEnd & 0xFFu));
+                            if (endOk && kd_ld16(lds.sw, mo) == scan01) {
+                                int len = 2;
+                                if (a.flags & 1u) len = 3; else
+                                for (;;) {                                  // 8 bytes per step
+                                    u64 const d = kd_ld64(lds.sw, mo + len) ^ kd_ld64(lds.sw, so + len);
+                                    if (d) { len += (int)(kx_ctz64(d) >> 3); break; }
+                                    len += 8;
+                                    if (len >= maxlen) break;
+                                }
+                                if (len > maxlen) len = maxlen;
+                                if (len > bestLen) {
+                                    bestLen = len; bestPos = c;
+                                    if (len >= nice) done = true;
+                                    else scanEnd = kd_ld16(lds.sw, so + bestLen - 1);
+                                }
                             }
-                            if (len > maxlen) len = maxlen;
-                            if (len > bestLen) {
-                                bestLen = len; bestPos = c;
-                                if (len >= nice) done = true;
-                                else scanEnd = kd_ld16(lds.sw, so + bestLen - 1);
+                            if (steps == 32 || (done && steps < 32)) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
+                            c = cnext;
+                            if (done || !(c > limit && steps < maxSteps)) {
+                                if (steps < 32 && !done) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
+                                r.len128 = (u16)(bestLen > 2 ? bestLen : 0); r.pos128 = (u16)bestPos;
+                                best[p] = r;
+                                active = false;
                             }
-                        }
-                        if (steps == 32 || (done && steps < 32)) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
-                        c = cnext;
-                        if (done || !(c > limit && steps < maxSteps)) {
-                            if (steps < 32 && !done) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
-                            r.len128 = (u16)(bestLen > 2 ? bestLen : 0); r.pos128 = (u16)bestPos;
-                            best[p] = r;
-                            active = false;
                         }
                     }
                 }

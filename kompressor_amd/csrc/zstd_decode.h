@@ -542,7 +542,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             if (spos >= bend) { err = KZE_CORRUPT; break; }
         }
         // lane 0 keeps the table logs / validity for later blocks; share them
-        tlLL = kx_shfl(tlLL, 0); tlOF = kx_shfl(tlOF, 0); tlML = kx_shfl(tlML, 0);
+        tlLL = kx_bcast(tlLL, 0); tlOF = kx_bcast(tlOF, 0); tlML = kx_bcast(tlML, 0);
         u32 litUsed = 0;
         if (nbSeq && !(a.flags & 2u)) {
             const u8* const sq = bp + spos; u32 const ssz = bend - spos;
@@ -567,7 +567,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             for (u32 done = 0; done < nbSeq && !err; ) {
                 u32 const cnt = (nbSeq - done) < 64 ? (nbSeq - done) : 64;
                 // keep >= 176 words (64 sequences x <= 88 bits) of stream below the read position in LDS (254 staged)
-                int const curWord = (int)kx_shfl((u32)bitPos, 0) >> 5;
+                int const curWord = (int)kx_bcast((u32)bitPos, 0) >> 5;
                 if (sbLo < 0 || (sbLo > 0 && curWord - sbLo < 176)) {
                     int newLo = curWord + 2 - 254; if (newLo < 0) newLo = 0;
                     int hiW = curWord + 2; if (hiW > totalWords) hiW = totalWords;
@@ -651,7 +651,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                     u32 const a1 = kx_shfl(sl, lane - o), a2 = kx_shfl(st, lane - o);
                     if (lane >= o) { sl += a1; st += a2; }
                 }
-                u32 const totLit = kx_shfl(sl, 63), totOut = kx_shfl(st, 63);
+                u32 const totLit = kx_bcast(sl, 63), totOut = kx_bcast(st, 63);
                 if (litUsed + totLit > regen) { err = KZE_CORRUPT; break; }
                 if ((u64)op + totOut > cap) { err = KZE_DSTSMALL; break; }
                 u32 const lp = litUsed + (sl - ll);           // my literals in the literal buffer
@@ -668,7 +668,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                 }
                 for (u64 longs = kx_ballot(own && ll > 32); longs; longs &= longs - 1) {
                     int const e = (int)kx_ctz64(longs);
-                    kxd_wave_copy(dst + kx_shfl(dlit, e), litPtr + kx_shfl(lp, e), kx_shfl(ll, e), lane);
+                    kxd_wave_copy(dst + kx_bcast(dlit, e), litPtr + kx_bcast(lp, e), kx_bcast(ll, e), lane);      // e is uniform: v_readlane, no LDS permute
                 }
                 kx_lockstep();
                 // matches in dependency rounds: a short match with offset >= 8 whose source lies before
@@ -676,7 +676,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                 // one is always runnable; long or small-offset matches are copied by the whole wave in order
                 for (u64 P = kx_ballot(own); P; ) {
                     int const e = (int)kx_ctz64(P);
-                    u32 const mlE = kx_shfl(ml, e), offE = kx_shfl(off, e), dE = kx_shfl(dmat, e);
+                    u32 const mlE = kx_bcast(ml, e), offE = kx_bcast(off, e), dE = kx_bcast(dmat, e);
                     if (offE > dE - fbase) {
                         // starts in the dictionary: byte k comes from dict[dict_size - inDict + k] while that is inside
                         // the dictionary, then from the frame's own output

@@ -897,7 +897,7 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
         u32 v = mybits;                                           // inclusive prefix sum over lanes
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { u32 const t = kx_shfl(v, lane - o); if (lane >= o) v += t; }
-        u32 const total = kx_shfl(v, 63);
+        u32 const total = kx_bcast(v, 63);
         if ((u32)(streamStart - dst) + ((bitpos + total) >> 3) >= cap) return 0;            // larger than the block: raw block for certain
         u32 pos = (bitpos & 31u) + (v - mybits);
         if (valid) {
@@ -964,7 +964,7 @@ KX_DEV void kx_gather_literals(u8* lits, const u8* src, u32 n, const KSeq* seqs,
         u64 big = kx_ballot(ll > 32u);
         while (big) {
             int const j = (int)kx_ctz64(big); big &= big - 1ull;
-            kx_wave_copy(lits + kx_shfl(myL, j), src + kx_shfl(myS, j), kx_shfl(ll, j), lane);
+            kx_wave_copy(lits + kx_bcast(myL, j), src + kx_bcast(myS, j), kx_bcast(ll, j), lane);
         }
         if (ll > 0 && ll <= 32u) {
             u8* const d = lits + myL;
@@ -978,7 +978,7 @@ KX_DEV void kx_gather_literals(u8* lits, const u8* src, u32 n, const KSeq* seqs,
                 if (rem & 1u) d[c] = (u8)w;
             }
         }
-        lp += kx_shfl(sl, 63); sp += kx_shfl(sa, 63);
+        lp += kx_bcast(sl, 63); sp += kx_bcast(sa, 63);
     }
 }
 
