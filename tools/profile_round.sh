@@ -17,5 +17,17 @@ for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY 
   echo "== pmc $ctr" >> $O/log.txt
   timeout -k 10 300 rocprofv3 --pmc $ctr -d $d -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu > $d.out 2>> $O/log.txt || echo "pmc pass $ctr failed" >> $O/log.txt
 done
-ls -R $O | head -50 >> $O/log.txt
+# HBM bytes of the decoder and of the DEFLATE kernels (same counters, their own runs)
+for mode in decompress deflate; do
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    d=$O/pmc2_${mode}_$ctr
+    echo "== pmc $mode $ctr" >> $O/log.txt
+    if [ $mode = deflate ]; then extra="--slices 16384"; else extra=""; fi
+    timeout -k 10 300 rocprofv3 --pmc $ctr -d $d -o run -- python3 $R/bench.py --mode $mode --steps 1 --warmup 0 --no-cpu $extra > $d.out 2>> $O/log.txt || echo "pmc pass $mode $ctr failed" >> $O/log.txt
+  done
+done
+ls -R $O | head -80 >> $O/log.txt
+# summarise here (the result databases exceed what gpurun carries back), keep only text
+cd $R && python3 tools/summarize_profiles.py r01_final $R/gpurun_out/prof_summary > /dev/null 2>> $O/log.txt
+find $O -name 'run_results.db' -delete
 echo done

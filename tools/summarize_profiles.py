@@ -31,6 +31,10 @@ def counters(db):
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+    # on the GPU box the result databases are too large to travel back: profile_round.sh runs this script there with an
+    # output directory under gpurun_out/ and deletes the databases; here the two files are then copied into profiles/
+    outdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
+    os.makedirs(outdir, exist_ok=True)
     lines = [f"# {name}: MI355X, 1 GPU; collected on the GPU box by tools/profile_round.sh, summarised by tools/summarize_profiles.py.",
              "# Durations in microseconds (rocprofv3 --kernel-trace --stats, result database view top_kernels).", ""]
     runs = [("compress", "python3 bench.py --steps 5 --warmup 1      (compress, BASELINE configs[1])"),
@@ -56,7 +60,17 @@ def main():
             for k, c, v, n in counters(db):
                 allc[(k, c)] = (v, n)
                 lines.append(f"{k:40s} {c:24s} {v:.6g}   ({n} launches)")
-    open(os.path.join(ROOT, "profiles", name + ".txt"), "w").write("\n".join(lines) + "\n")
+    lines.append("")
+    lines.append("## HBM bytes of the other kernels (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own runs: bench.py --mode decompress --steps 1 --warmup 0; --mode deflate --slices 16384 --steps 1 --warmup 0)")
+    other = {}
+    for d in sorted(os.listdir(P)):
+        db = os.path.join(P, d, "run_results.db")
+        if d.startswith("pmc2_") and os.path.exists(db):
+            for k, c, v, n in counters(db):
+                if "k_zstd_decode" in k or "k_deflate" in k or "k_inflate" in k:
+                    other[(k.split("(")[0], c)] = (v, n)
+                    lines.append(f"{k:40s} {c:24s} {v:.6g}   ({n} launches)")
+    open(os.path.join(outdir, name + ".txt"), "w").write("\n".join(lines) + "\n")
     mk = [k for (k, c) in allc if "k_zstd_match" in k and c == "FETCH_SIZE"]
     if mk:
         k = mk[0]
@@ -71,7 +85,13 @@ def main():
               "zstd_match_write_requests_per_launch": int(allc.get((k, "TCC_EA0_WRREQ_sum"), (0, 1))[0] / nl),
               "note": "(FETCH_SIZE+WRITE_SIZE)*1024 / launches; the guide's x2 correction for wide coalesced reads is not applied: "
                       "this kernel's reads are scattered 4- and 8-byte probes (TCC_EA0_RDREQ_32B = 0, RDREQ*64 = FETCH_SIZE)"}
-        json.dump(pj, open(os.path.join(ROOT, "profiles", "pmc_latest.json"), "w"), indent=1)
+        for kern in ("k_zstd_decode", "k_deflate_chains", "k_deflate_best", "k_deflate_parse", "k_deflate_encode", "k_inflate"):
+            if (kern, "FETCH_SIZE") in other and (kern, "WRITE_SIZE") in other:
+                f, nl2 = other[(kern, "FETCH_SIZE")]
+                w, _ = other[(kern, "WRITE_SIZE")]
+                pj[kern + "_hbm_bytes_per_launch"] = int((f + w) * 1024 / nl2)
+        pj["note_other_kernels"] = "k_zstd_decode: 65536 frames per launch; k_deflate_* / k_inflate: 16384 slices per launch; (FETCH_SIZE+WRITE_SIZE)*1024 / launches"
+        json.dump(pj, open(os.path.join(outdir, "pmc_latest.json"), "w"), indent=1)
     print("\n".join(lines[:60]))
 
 
