@@ -127,27 +127,38 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
             u32 kind = 0;            // 0 no hit, 1 repcode at ip0 + step, 2 candidate of the pair's first position, 3 of its second
             int n_ip0 = ip0, n_step = step, n_gap = gap, n_next = nextStep, n_cur = current0; u32 n_mi = matchIdx;
             if (pr && k == 0) {
-                int ip1 = ip0 + 1, ip2 = ip0 + gap, ip3 = ip2 + 1;
+                int const ip1 = ip0 + 1, ip2 = ip0 + gap, ip3 = ip2 + 1;
+                // Everything the pair can ask for is requested up front (the step is a chain of memory latencies, not of
+                // instructions): the table slots of ip1 and ip2, the bytes of all four positions, the repcode bytes.  libzstd
+                // reads those slots AFTER it has written ip0 (and ip1) into the table; where the slots coincide the value it
+                // would have seen is put back by hand.
+                u32 const e1raw = H[hash1];
+                u64 const w2 = kx_ld64(src + ip2), w3 = kx_ld64(src + ip3);
                 u32 const rval = kx_ld32(src + ip2 - (int)rep1);
+                u32 const c0 = kx_ld32(src + (matchIdx >= 2u ? (int)matchIdx - 2 : 0));
+                u32 const s0 = kx_ld32(src + ip0), s1 = kx_ld32(src + ip1);
+                u32 const hash2 = kx_hash_short_any(w2, hlog, mls), hash3 = kx_hash_short_any(w3, hlog, mls);
+                u32 const e2raw = H[hash2];
+                u32 const e1 = (hash1 == hash0) ? (tag | (u32)(ip0 + 2)) : e1raw;
+                u32 const e2 = (hash2 == hash1) ? (tag | (u32)(ip1 + 2)) : (hash2 == hash0) ? (tag | (u32)(ip0 + 2)) : e2raw;
+                u32 const mi1 = ((e1 & ~IDXM) == tag) ? (e1 & IDXM) : 0u;
+                u32 const mi2 = ((e2 & ~IDXM) == tag) ? (e2 & IDXM) : 0u;
+                u32 const c1 = kx_ld32(src + (mi1 >= 2u ? (int)mi1 - 2 : 0));
                 n_cur = ip0;
                 H[hash0] = tag | (u32)(ip0 + 2);
-                if (kx_ld32(src + ip2) == rval && rep1 > 0) { kind = 1; H[hash1] = tag | (u32)(ip1 + 2); n_ip0 = ip2; }
-                else if (matchIdx >= 2u && kx_ld32(src + matchIdx - 2) == kx_ld32(src + ip0)) { kind = 2; H[hash1] = tag | (u32)(ip1 + 2); }
+                H[hash1] = tag | (u32)(ip1 + 2);                 // every branch below stores ip1 (as the pair's second position)
+                if ((u32)w2 == rval && rep1 > 0) { kind = 1; n_ip0 = ip2; }
+                else if (matchIdx >= 2u && c0 == s0) { kind = 2; }
                 else {
-                    u32 e = H[hash1];
-                    u32 mi = ((e & ~IDXM) == tag) ? (e & IDXM) : 0u;
-                    hash0 = hash1; hash1 = kx_hash_short_any(kx_ld64(src + ip2), hlog, mls);
-                    int const q0 = ip1; ip1 = ip2; ip2 = ip3;
-                    n_cur = q0;
-                    H[hash0] = tag | (u32)(q0 + 2);
-                    if (mi >= 2u && kx_ld32(src + mi - 2) == kx_ld32(src + q0)) {
-                        kind = 3; n_ip0 = q0; n_mi = mi;
-                        if (step <= 4) H[hash1] = tag | (u32)(ip1 + 2);
+                    n_cur = ip1;
+                    if (mi1 >= 2u && c1 == s1) {
+                        kind = 3; n_ip0 = ip1; n_mi = mi1;
+                        if (step <= 4) H[hash2] = tag | (u32)(ip2 + 2);
+                        hash0 = hash1; hash1 = hash2;
                     } else {
-                        e = H[hash1];
-                        n_mi = ((e & ~IDXM) == tag) ? (e & IDXM) : 0u;
-                        hash0 = hash1; hash1 = kx_hash_short_any(kx_ld64(src + ip2), hlog, mls);
-                        n_ip0 = ip1;                          // the next pair starts `step` behind this one's second half
+                        n_mi = mi2;
+                        hash0 = hash2; hash1 = hash3;
+                        n_ip0 = ip2;                          // the next pair starts `step` behind this one's second half
                         n_gap = step;
                         if (n_ip0 + step >= nextStep) { n_step = step + 1; n_next = nextStep + 128; }
                     }
