@@ -169,19 +169,24 @@ KX_DEV void zstd_match_dict_body(const KDictArgs& d)
                 u64 const w1 = kv_ld64(v, sv + 1);
                 u32 const hL = kx_hash_long(w0, hbL), hS = kx_hash_short(w0, hbS, mls);
                 u32 const curr = P + (u32)ip;
+                // Every table slot of this position is requested at once -- the slice's working tables and the CDict's -- and,
+                // once they are known, the candidates' bytes (below): the step is a chain of memory latencies.  The decisions
+                // keep libzstd's order.
                 u32 const eL = L[hL], eS = S[hS];
+                u32 hl = 0, hs = 0;
+                if (attach) { hl = kx_hash_long(w0, d.dHashLog + 8); hs = kx_hash_short(w0, d.dChainLog + 8, mls); }
+                u32 const xL = attach ? d.dictL[hl >> 8] : d.dictL[hL];
+                u32 const xS = attach ? d.dictS[hs >> 8] : d.dictS[hS];
                 u32 idxL = ((eL & ~KX_IDX_MASK) == tag) ? (eL & KX_IDX_MASK) : 0u;
                 u32 idxS = ((eS & ~KX_IDX_MASK) == tag) ? (eS & KX_IDX_MASK) : 0u;
                 // dictionary side
                 u32 dIdxL = 0, dIdxS = 0; bool dTagL = false, dTagS = false;
                 if (attach) {
-                    u32 const hl = kx_hash_long(w0, d.dHashLog + 8), hs = kx_hash_short(w0, d.dChainLog + 8, mls);
-                    u32 const xL = d.dictL[hl >> 8], xS = d.dictS[hs >> 8];
                     dTagL = (xL & 0xFFu) == (hl & 0xFFu); dTagS = (xS & 0xFFu) == (hs & 0xFFu);
                     dIdxL = xL >> 8; dIdxS = xS >> 8;
                 } else {
-                    if (idxL == 0) idxL = d.dictL[hL] >> 8;       // "copied" tables: the CDict entry until this slice overwrites it
-                    if (idxS == 0) idxS = d.dictS[hS] >> 8;
+                    if (idxL == 0) idxL = xL >> 8;       // "copied" tables: the CDict entry until this slice overwrites it
+                    if (idxS == 0) idxS = xS >> 8;
                 }
                 // repcode at ip + 1
                 u32 const repIndex = curr + 1u - off1;
@@ -189,20 +194,29 @@ KX_DEV void zstd_match_dict_body(const KDictArgs& d)
                 bool const repOk = ((u32)((P - 1u) - repIndex) >= 3u) && off1 <= curr - 1u;
                 u32 const t = tag | curr;
                 L[hL] = t; S[hS] = t;
-                if (repOk && kv_ld32(v, (int)repIndex - 2) == (u32)(w0 >> 8)) { kind = 1; mIdx = repIndex; }
+                // copied tables (slices above 16 KiB): the three candidates' bytes are requested together; attached CDict
+                // (small slices, two candidates per table): one after the other, as measured faster there
+                bool const l1ok = !attach && idxL > 2u, s1ok = !attach && idxS > 2u;
+                u32 cR = 0, cS1 = 0; u64 cL1 = 0;
+                if (!attach) {
+                    cR = kv_ld32(v, repOk ? (int)repIndex - 2 : 0);
+                    cL1 = kv_ld64(v, l1ok ? (int)idxL - 2 : 0);
+                    cS1 = kv_ld32(v, s1ok ? (int)idxS - 2 : 0);
+                } else if (repOk) cR = kv_ld32(v, (int)repIndex - 2);
+                if (repOk && cR == (u32)(w0 >> 8)) { kind = 1; mIdx = repIndex; }
                 else {
                     bool longHit = false;
                     if (attach) {
                         if (idxL >= P && kv_ld64(v, (int)idxL - 2) == w0) { longHit = true; mIdx = idxL; }
                         else if (dTagL && dIdxL > 2u && kv_ld64(v, (int)dIdxL - 2) == w0) { longHit = true; mIdx = dIdxL; }
-                    } else if (idxL > 2u && kv_ld64(v, (int)idxL - 2) == w0) { longHit = true; mIdx = idxL; }
+                    } else if (l1ok && cL1 == w0) { longHit = true; mIdx = idxL; }
                     if (longHit) kind = 2;
                     else {
                         bool shortHit = false; u32 sIdx = 0;
                         if (attach) {
                             if (idxS > P) { if (kv_ld32(v, (int)idxS - 2) == (u32)w0) { shortHit = true; sIdx = idxS; } }
                             else if (dTagS && dIdxS > 2u && kv_ld32(v, (int)dIdxS - 2) == (u32)w0) { shortHit = true; sIdx = dIdxS; }
-                        } else if (idxS > 2u && kv_ld32(v, (int)idxS - 2) == (u32)w0) { shortHit = true; sIdx = idxS; }
+                        } else if (s1ok && cS1 == (u32)w0) { shortHit = true; sIdx = idxS; }
                         if (shortHit) {
                             // look for a long match at ip + 1 first (and always insert that position)
                             u32 const h3 = kx_hash_long(w1, hbL);
