@@ -116,7 +116,7 @@ extern "C" const char* kmp_version(void) { return "kompressor_hip 0.2 (gfx950; z
 // --------------------------------------------------------------------------
 enum { KMP_MAX_CHUNKS = 4 };
 struct kmp_batch_ctx {
-    int device; u32 max_slices, max_slice_bytes; int G; u32 match_blocks, match_blocks_l3, nteams;
+    int device; u32 max_slices, max_slice_bytes; int G; u32 match_blocks, match_blocks_l3, nteams, l3_team_slots;
     u32 seq_cap, lit_cap, scratch_words;
     KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* team_epoch; u32* counter;
     int profiling; hipEvent_t ev[14]; int ev_valid[7];
@@ -157,7 +157,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     c->match_blocks = blocks; c->nteams = blocks * teams_per_wave;
     // the level-3 parser is transaction bound and a little faster with 12 waves per CU; the one-position-per-step parsers
     // (levels 1 / 2, dictionary) are latency bound and want every slice in flight
-    { u32 const l3 = (u32)prop.multiProcessorCount * env_u32("KMP_MATCH_WAVES_PER_CU_L3", 12); c->match_blocks_l3 = l3 < blocks ? l3 : blocks; }
+    { u32 const l3 = (u32)prop.multiProcessorCount * env_u32("KMP_MATCH_WAVES_PER_CU_L3", 12); c->match_blocks_l3 = l3 < blocks ? l3 : blocks; c->l3_team_slots = l3 * teams_per_wave; }
     c->big = c->max_slice_bytes > KMP_MAX_SLICE_BYTES;
     u32 const block_cap = c->big ? KMP_MAX_SLICE_BYTES : c->max_slice_bytes;     // the sequence / literal workspaces hold one block
     c->seq_cap = (block_cap / 4 + 8 + 15) & ~15u; c->lit_cap = block_cap + 64; c->scratch_words = block_cap / 4 + 64;
@@ -462,7 +462,10 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     if (c->big) return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st, 0, 0);
     // Chunks: the match kernel of chunk i+1 (memory-transaction bound) runs beside the entropy kernel of
     // chunk i (latency bound) on a second stream; the caller's stream sees everything finished.
-    u32 chunks = env_u32("KMP_ZSTD_CHUNKS", n >= 32768u ? 2u : 1u);
+    // (two chunks only when each still fills at least half of the match kernel's team slots: 65 536 x 64 KiB -> 2,
+    // 32 768 x 128 KiB -> 1: 17.7 GB/s against 13.1 with two half-empty launches)
+    u32 const team_slots = c->l3_team_slots;                 // what the device holds, whatever this context's max_slices
+    u32 chunks = env_u32("KMP_ZSTD_CHUNKS", n > team_slots ? 2u : 1u);       // measured: 49 152 slices (= the slots) 16.4 GB/s in one launch, 15.5 in two; 57 344: 15.2 / 16.2
     if (chunks < 1) chunks = 1; if (chunks > KMP_MAX_CHUNKS) chunks = KMP_MAX_CHUNKS; if (chunks > n) chunks = 1;
     // Batches may be queued on alternating caller streams: the match kernels of consecutive batches share the team
     // tables and run in order, but a batch's last entropy launch no longer holds up the next batch's match kernel.
