@@ -132,42 +132,77 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                 // instructions): the table slots of ip1 and ip2, the bytes of all four positions, the repcode bytes.  libzstd
                 // reads those slots AFTER it has written ip0 (and ip1) into the table; where the slots coincide the value it
                 // would have seen is put back by hand.
+                // Two pairs out of three end without a hit, so the NEXT pair (B: first position ip2, second ip3, probe
+                // ip2 + step) is walked in the same step, on the assumption that this one (A) finds nothing: its loads
+                // travel with A's, its table writes and results only count when A indeed found nothing.
+                bool const canB = ip2 + 1 + step < ilimit;          // the condition under which the run would go on to B
+                int const ip2B = canB ? ip2 + step : ip2, ip3B = ip2B + 1;
                 u32 const e1raw = H[hash1];
                 u64 const w2 = kx_ld64(src + ip2), w3 = kx_ld64(src + ip3);
-                u32 const rval = kx_ld32(src + ip2 - (int)rep1);
+                u64 const w2B = kx_ld64(src + ip2B), w3B = kx_ld64(src + ip3B);
+                u32 const rval = kx_ld32(src + ip2 - (int)rep1), rvalB = kx_ld32(src + ip2B - (int)rep1);
                 u32 const c0 = kx_ld32(src + (matchIdx >= 2u ? (int)matchIdx - 2 : 0));
                 u32 const s0 = kx_ld32(src + ip0), s1 = kx_ld32(src + ip1);
                 u32 const hash2 = kx_hash_short_any(w2, hlog, mls), hash3 = kx_hash_short_any(w3, hlog, mls);
-                u32 const e2raw = H[hash2];
-                u32 const e1 = (hash1 == hash0) ? (tag | (u32)(ip0 + 2)) : e1raw;
-                u32 const e2 = (hash2 == hash1) ? (tag | (u32)(ip1 + 2)) : (hash2 == hash0) ? (tag | (u32)(ip0 + 2)) : e2raw;
+                u32 const hash2B = kx_hash_short_any(w2B, hlog, mls), hash3B = kx_hash_short_any(w3B, hlog, mls);
+                u32 const e2raw = H[hash2], e3raw = H[hash3], e2Braw = H[hash2B];
+                u32 const t0 = tag | (u32)(ip0 + 2), t1 = tag | (u32)(ip1 + 2), t2 = tag | (u32)(ip2 + 2), t3 = tag | (u32)(ip3 + 2);
+                u32 const e1 = (hash1 == hash0) ? t0 : e1raw;
+                u32 const e2 = (hash2 == hash1) ? t1 : (hash2 == hash0) ? t0 : e2raw;
+                u32 const e3 = (hash3 == hash2) ? t2 : (hash3 == hash1) ? t1 : (hash3 == hash0) ? t0 : e3raw;
+                u32 const e2B = (hash2B == hash3) ? t3 : (hash2B == hash2) ? t2 : (hash2B == hash1) ? t1 : (hash2B == hash0) ? t0 : e2Braw;
                 u32 const mi1 = ((e1 & ~IDXM) == tag) ? (e1 & IDXM) : 0u;
                 u32 const mi2 = ((e2 & ~IDXM) == tag) ? (e2 & IDXM) : 0u;
+                u32 const mi3 = ((e3 & ~IDXM) == tag) ? (e3 & IDXM) : 0u;
+                u32 const mi2B = ((e2B & ~IDXM) == tag) ? (e2B & IDXM) : 0u;
                 u32 const c1 = kx_ld32(src + (mi1 >= 2u ? (int)mi1 - 2 : 0));
+                u32 const c0B = kx_ld32(src + (mi2 >= 2u ? (int)mi2 - 2 : 0));
+                u32 const c1B = kx_ld32(src + (mi3 >= 2u ? (int)mi3 - 2 : 0));
                 n_cur = ip0;
-                H[hash0] = tag | (u32)(ip0 + 2);
-                H[hash1] = tag | (u32)(ip1 + 2);                 // every branch below stores ip1 (as the pair's second position)
+                H[hash0] = t0;
+                H[hash1] = t1;                                   // every branch below stores ip1 (as the pair's second position)
                 if ((u32)w2 == rval && rep1 > 0) { kind = 1; n_ip0 = ip2; }
-                else if (matchIdx >= 2u && c0 == s0) { kind = 2; }
+                else if (matchIdx >= 2u && c0 == s0) { kind = 2; n_mi = matchIdx; }
                 else {
                     n_cur = ip1;
                     if (mi1 >= 2u && c1 == s1) {
                         kind = 3; n_ip0 = ip1; n_mi = mi1;
-                        if (step <= 4) H[hash2] = tag | (u32)(ip2 + 2);
+                        if (step <= 4) H[hash2] = t2;
                         hash0 = hash1; hash1 = hash2;
                     } else {
-                        n_mi = mi2;
-                        hash0 = hash2; hash1 = hash3;
-                        n_ip0 = ip2;                          // the next pair starts `step` behind this one's second half
-                        n_gap = step;
-                        if (n_ip0 + step >= nextStep) { n_step = step + 1; n_next = nextStep + 128; }
+                        // pair A found nothing: the state the next step would start from ...
+                        int stepB = step, nextB = nextStep;
+                        if (ip2 + step >= nextStep) { stepB = step + 1; nextB = nextStep + 128; }
+                        n_mi = mi2; hash0 = hash2; hash1 = hash3;
+                        n_ip0 = ip2;                              // the next pair starts `step` behind this one's second half
+                        n_gap = step; n_step = stepB; n_next = nextB;
+                        if (canB) {
+                            // ... and that step itself: pair B
+                            n_cur = ip2;
+                            H[hash2] = t2;
+                            H[hash3] = t3;
+                            if ((u32)w2B == rvalB && rep1 > 0) { kind = 1; n_ip0 = ip2B; }
+                            else if (mi2 >= 2u && c0B == (u32)w2) { kind = 2; n_ip0 = ip2; n_mi = mi2; }
+                            else {
+                                n_cur = ip3;
+                                if (mi3 >= 2u && c1B == (u32)w3) {
+                                    kind = 3; n_ip0 = ip3; n_mi = mi3;
+                                    if (stepB <= 4) H[hash2B] = tag | (u32)(ip2B + 2);
+                                    hash0 = hash3; hash1 = hash2B;
+                                } else {
+                                    n_mi = mi2B; hash0 = hash2B; hash1 = hash3B;
+                                    n_ip0 = ip2B;
+                                    n_gap = stepB;
+                                    if (ip2B + stepB >= nextB) { n_step = stepB + 1; n_next = nextB + 128; }
+                                }
+                            }
+                        }
                     }
                 }
             }
             kind = kx_shfl(kind, tbase); n_ip0 = (int)kx_shfl((u32)n_ip0, tbase); n_step = (int)kx_shfl((u32)n_step, tbase);
             n_next = (int)kx_shfl((u32)n_next, tbase); n_cur = (int)kx_shfl((u32)n_cur, tbase); n_mi = kx_shfl(n_mi, tbase);
             n_gap = (int)kx_shfl((u32)n_gap, tbase);
-            u32 const mi0 = kx_shfl(matchIdx, tbase);
             if (pr) {
                 guard++;
                 current0 = n_cur;
@@ -182,7 +217,7 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                     m_start = n_ip0 - (b1 ? 1 : 0); m_mpos = mp - (b1 ? 1 : 0); m_len0 = 4u + (b1 ? 1u : 0u); m_back = false; m_fill = true; m_off = 0;
                     state = KFS_MATCH;
                 } else {
-                    m_start = n_ip0; m_mpos = (int)((kind == 2) ? mi0 : n_mi) - 2; m_len0 = 4; m_back = true; m_fill = true;
+                    m_start = n_ip0; m_mpos = (int)n_mi - 2; m_len0 = 4; m_back = true; m_fill = true;
                     m_off = (u32)(m_start - m_mpos);
                     state = KFS_MATCH;
                 }
