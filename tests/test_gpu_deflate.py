@@ -227,3 +227,55 @@ def test_batches_larger_than_the_workspace_go_through_in_pieces(monkeypatch):
                 assert f == c.compress(d) + c.flush(), (i, len(d))
     finally:
         b.close()
+
+
+@pytest.mark.timeout(300)
+def test_mutated_streams_on_the_gpu(batch):
+    """768 damaged DEFLATE / zlib / gzip streams inflated in one batch: a status for every entry, agreement with zlib on
+    what is a valid stream and on its bytes."""
+    import random
+    import fuzz_decoders as F
+    rng = random.Random(77)
+    srcs = [d for d in F.sources(rng, 16) if len(d) <= 65536]
+    for fmt, wbits in ((0, -15), (1, 15), (2, 31)):
+        streams = []
+        for d in srcs:
+            for lvl in (1, 6, 9):
+                c = zlib.compressobj(lvl, zlib.DEFLATED, wbits, 8)
+                streams.append((c.compress(d) + c.flush(), d))
+        only = [s for s, _ in streams]
+        cases = []
+        for it in range(256):
+            s0, d = rng.choice(streams)
+            s, what = (s0, "intact") if it % 32 == 0 else F.mutate(rng, s0, only)
+            cap = len(d) + rng.choice((0, 0, 1, 64)) if rng.random() < 0.85 else rng.randrange(0, len(d) + 1)
+            cases.append((s, d, max(cap, 1), what))
+        n = len(cases)
+        lens = np.array([len(c[0]) for c in cases], dtype=np.int32)
+        offs = np.zeros(n, dtype=np.int64)
+        pos = 0
+        for i, c in enumerate(cases):
+            offs[i] = pos
+            pos += len(c[0])
+        host = np.zeros(pos + 64, dtype=np.uint8)
+        for i, c in enumerate(cases):
+            host[offs[i]:offs[i] + len(c[0])] = np.frombuffer(c[0], dtype=np.uint8)
+        cap_t = torch.tensor([c[2] for c in cases], dtype=torch.int32).cuda()
+        dst, ooff, olen, st = batch.inflate(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), cap_t, format=("raw", "zlib", "gzip")[fmt])
+        torch.cuda.synchronize()
+        dst, ooff, olen, st = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy(), st.cpu().numpy()
+        ok = 0
+        for i, (s, d, cap, what) in enumerate(cases):
+            try:
+                o = zlib.decompressobj(wbits)
+                ref = o.decompress(s, cap + 1)
+                if not o.eof or len(ref) > cap or o.unused_data:
+                    ref = None
+            except zlib.error:
+                ref = None
+            if st[i] == 0:
+                ok += 1
+                assert ref is not None and dst[ooff[i]:ooff[i] + olen[i]].tobytes() == ref, (fmt, what, len(s), cap)
+            else:
+                assert ref is None, (fmt, what, len(s), cap, int(st[i]))
+        assert ok >= 3          # the intact streams whose capacity was not cut

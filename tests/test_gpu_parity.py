@@ -555,3 +555,39 @@ def test_concatenated_and_skippable_frames(batch):
             assert out == want
     # the streaming entry point takes them frame by frame, like ZSTD_decompressStream
     assert ZstdDecompressor().transform_bytes(fa + skip + fc + fb) == a + c + b
+
+
+@pytest.mark.timeout(300)
+def test_mutated_frames_on_the_gpu(batch):
+    """768 damaged frames (tests/fuzz_decoders.py's mutations: bit flips, truncation, splices, header bytes ...) decoded in
+    one batch: every entry ends with a status, never with a hang or a fault; what the decoder accepts is what libzstd
+    1.5.7 decodes, and what it rejects libzstd rejects too (or turns into other bytes than the original: its fast Huffman
+    loop does not check that the literal streams end where they should, this decoder does)."""
+    import random
+    import fuzz_decoders as F
+    z = helpers.live_libzstd()
+    if z is None:
+        pytest.skip("no libzstd 1.5.7 on this machine")
+    rng = random.Random(2025)
+    srcs = F.sources(rng, 16)
+    frames = [(z.compress(d, lvl), d) for d in srcs for lvl in ((1, 3, 19) if len(d) < 100000 else (3,))]
+    only = [f for f, _ in frames]
+    cases = []
+    for it in range(768):
+        f0, d = rng.choice(frames)
+        f, what = (f0, "intact") if it % 32 == 0 else F.mutate(rng, f0, only)
+        cap = len(d) + rng.choice((0, 0, 1, 64)) if rng.random() < 0.85 else rng.randrange(0, len(d) + 1)
+        cases.append((f, d, max(cap, 1), what))
+    outs, st = gpu_decompress(batch, [c[0] for c in cases], [c[2] for c in cases])
+    accepted = 0
+    for (f, d, cap, what), out, s in zip(cases, outs, st):
+        try:
+            ref = z.decompress(f, cap)
+        except RuntimeError:
+            ref = None
+        if s == 0:
+            accepted += 1
+            assert ref is not None and out == ref, (what, len(f), cap)
+        else:
+            assert ref is None or s == 14 or (s == 20 and ref != d), (what, len(f), cap, s)
+    assert accepted >= 24          # the intact ones at least
