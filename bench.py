@@ -94,6 +94,40 @@ def cpu_baseline(host, n_slices, frames_expected, sample=None):
                       f"{dt:.2f} s wall; total frame bytes {'match' if ok else 'DIFFER from'} the GPU's"}
 
 
+def cpu_decode_baseline(frames_host, offs, lens, n_slices, sample=32768):
+    """libzstd 1.5.7 ZSTD_decompress over the first `sample` frames the GPU produced, on the host threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        from libzstd_ref import find_libzstd_157
+        lib = find_libzstd_157()
+    except Exception:
+        lib = None
+    if lib is None:
+        return None
+    cores = min(os.cpu_count() or 1, 64)
+    sample = min(n_slices, sample)
+    lib.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    lib.ZSTD_decompress.restype = ctypes.c_size_t
+    base = frames_host.ctypes.data
+    per = (sample + cores - 1) // cores
+    bad = [0] * cores
+
+    def run(t):
+        out = ctypes.create_string_buffer(SLICE)
+        for i in range(t * per, min(sample, (t + 1) * per)):
+            if lib.ZSTD_decompress(out, SLICE, base + int(offs[i]), int(lens[i])) != SLICE:
+                bad[t] += 1
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(run, range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": round(sample * SLICE / dt / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "reference",
+            "sample": f"first {sample} frames of the same batch, libzstd 1.5.7 ZSTD_decompress, {cores} threads, {dt:.2f} s wall"
+                      + (f" [{sum(bad)} calls failed]" if sum(bad) else "")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -285,6 +319,11 @@ def main():
                     traffic_dec = pj.get("k_zstd_decode_hbm_bytes_per_launch")
             except Exception:
                 traffic_dec = None
+            cpu_dec = None
+            if not args.no_cpu and world == 1:
+                ns = min(n, 32768)
+                end = int(out_off[ns - 1].item()) + int(out_len[ns - 1].item())
+                cpu_dec = cpu_decode_baseline(dst[:end].cpu().numpy(), out_off[:ns].cpu().numpy(), out_len[:ns].cpu().numpy(), n)
             print(json.dumps({
                 "metric": "zstd decompression throughput, level-3 frames of 64 KiB slices (decoded bytes per second)",
                 "value": round(world * in_bytes / (dt / args.steps) / 1e9, 3), "unit": "GB/s", "n_gpus": world,
@@ -293,7 +332,8 @@ def main():
                 "config": {"workload": f"BASELINE configs[2]: ZstdDecompressor over the {n} level-3 frames of configs[1]", "roundtrip_ok": ok},
                 "roofline": {"bound": "hbm", "kernel": "k_zstd_decode", "achieved": round(algo / (ms_dec * 1e-3) / 1e9, 2),
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (ms_dec * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic_dec},
-                "kernels_ms": {"k_zstd_decode": round(ms_dec, 3)}}), flush=True)
+                "kernels_ms": {"k_zstd_decode": round(ms_dec, 3)},
+                "cpu_baseline": cpu_dec}), flush=True)
         b.close()
         if dist is not None:
             dist.barrier()
