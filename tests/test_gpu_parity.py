@@ -591,3 +591,55 @@ def test_mutated_frames_on_the_gpu(batch):
         else:
             assert ref is None or s == 14 or (s == 20 and ref != d), (what, len(f), cap, s)
     assert accepted >= 24          # the intact ones at least
+
+
+def test_fuzz_ragged_sizes_levels_1_and_2(batch):
+    """1 024 slices of arbitrary sizes 0 .. 128 KiB per level (every class, byte runs, short periods, class changes inside a
+    slice) at levels 1 and 2 against the oracle's frames (pinned to libzstd 1.5.7 by the golden vectors), and 48 slices of
+    128 KiB+1 .. 512 KiB at level 1 through the block-chain path."""
+    import random
+    from kompressor_amd.batch import ZstdBatch
+    rng = random.Random(31337)
+    o = helpers.oracle()
+
+    def piece(n):
+        r = rng.random()
+        if r < 0.08:
+            return bytes([rng.randrange(256)]) * n
+        if r < 0.16:
+            unit = corpus.make(rng.randrange(1 << 30), 1, rng.choice([2, 3, 7, 40, 300]), mix=ord("R")).tobytes()
+            return (unit * (n // len(unit) + 1))[:n]
+        return corpus.make(rng.randrange(1 << 30), 1, n, mix=ord(rng.choice("TXSBDIZR"))).tobytes()
+
+    def blob(total):
+        parts, have = [], 0
+        while have < total:
+            n = min(total - have, rng.choice([1, 5, 64, 500, 4000, 20000, 70000, 200000]))
+            parts.append(piece(n))
+            have += n
+        return b"".join(parts)
+
+    def run(b, datas, level):
+        n = len(datas)
+        lens = np.array([len(d) for d in datas], dtype=np.int32)
+        offs = np.concatenate([[0], np.cumsum(((lens[:-1] + 63) & ~63).astype(np.int64))]).astype(np.int64)
+        host = np.zeros(int(offs[-1]) + int(lens[-1]) + 64, dtype=np.uint8)
+        for o_, d in zip(offs, datas):
+            host[int(o_):int(o_) + len(d)] = np.frombuffer(d, dtype=np.uint8)
+        dst, ooff, olen = b.compress(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), level=level)
+        torch.cuda.synchronize()
+        hd, ho, hl = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+        return [hd[ho[i]:ho[i] + hl[i]].tobytes() for i in range(n)]
+
+    sizes = [rng.choice([rng.randrange(0, 64), rng.randrange(0, 2000), rng.randrange(0, 20000), rng.randrange(0, 131073)]) for _ in range(1024)]
+    datas = [blob(sz) for sz in sizes]
+    for lvl in (1, 2):
+        for i, (d, f) in enumerate(zip(datas, run(batch, datas, lvl))):
+            assert f == o.compress_level(d, lvl), (lvl, i, len(d))
+    big = [blob(rng.randrange(131073, 512 * 1024 + 1)) for _ in range(48)]
+    b = ZstdBatch(max_slices=len(big), max_slice_bytes=512 << 10)
+    try:
+        for i, (d, f) in enumerate(zip(big, run(b, big, 1))):
+            assert f == o.compress_level_big(d, 1), (i, len(d))
+    finally:
+        b.close()
