@@ -154,9 +154,13 @@ def run_zstd(args):
                 stats["both_valid_same"] += 1
         else:
             stats["rejected"] += 1
-            # 14 = unsupported (reserved header bit ...).  libzstd's fast Huffman loop (table log 11, x86-64) does not check that the four literal streams end
-            # exactly where they should, so it "decodes" some damaged frames to garbage; this decoder checks and says 20.
-            # A damaged frame is only a finding when libzstd still restores the ORIGINAL content from it.
+            # 14 = unsupported (reserved header bit ...).  libzstd accepts some damaged Huffman streams that RFC 8878 calls
+            # faulty ("not entirely and exactly consumed"): its fast loop (1.5.x, table log 11, x86-64) does not test the
+            # end of the four literal streams, and its double-symbol decoder (every version) clamps the bit count of a
+            # stream's last symbol, swallowing up to a symbol's worth of left-over bits (checked case: 5 bits left after
+            # the 2047th symbol of a stream; libzstd 1.4.8 and 1.5.7 both decode it, to other bytes than the original).
+            # This decoder checks the exact end and says 20.  A damaged frame is only a finding when libzstd still
+            # restores the ORIGINAL content from it.
             if ref is not None and int(st[0]) == 20 and ref != d:
                 stats["stricter"] = stats.get("stricter", 0) + 1
             elif ref is not None and int(st[0]) not in (14,):
