@@ -36,7 +36,8 @@ struct KDecodeLds {
         struct {                // sequence phase
             u16 fb[1280];       // FSE decoding tables LL [0,512) ML [512,1024) OF [1024,1280): newStateBase | nbBits << 12
             u8 fc[1280];        //   ... and the symbol (code) of each state
-            u32 sbuf[256];      // staged words of the sequence bitstream (2 zero words + 254); also the spread scratch
+            u32 sbuf[258];      // staged words of the sequence bitstream (3 words below the first, zero at the stream start, + 254
+                                //   + 1 spare); also the spread scratch
             u32 stage[194];     // 64 x (litLength, matchLength, offset) + error flag
         } q;
     } u;
@@ -555,8 +556,8 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             // the stream start so no read is conditional.
             int bitPos = (int)(8 * (ssz - 1) + kx_hb32(lastByte));
             u32 st3 = 0; bool bad = false, primed = false;       // st3: this lane's FSE state (lane 0 OF, 1 ML, 2.. LL)
-            int sbLo = -1;                       // first stream word held in lds.u.q.sbuf[2..] (uniform)
-#define KXD_WORD(i) lds.u.q.sbuf[(i) - sbLo + 2]
+            int sbLo = -1;                       // first stream word held in lds.u.q.sbuf[3..] (uniform)
+#define KXD_WORD(i) lds.u.q.sbuf[(i) - sbLo + 3]     /* i >= sbLo - 3: the container of an exhausted stream (bitPos 0) reaches word -3 */
 #define KXD_CONTAINER(C_) u64 C_; { int const topw_ = (bitPos - 1) >> 5; \
                 u32 const hi_ = KXD_WORD(topw_), mid_ = KXD_WORD(topw_ - 1), lo_ = KXD_WORD(topw_ - 2); \
                 u32 const used_ = (u32)(32 * (topw_ + 1) - bitPos); \
@@ -572,13 +573,13 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                     int newLo = curWord + 2 - 254; if (newLo < 0) newLo = 0;
                     int hiW = curWord + 2; if (hiW > totalWords) hiW = totalWords;
                     kx_sync();
-                    for (int i = newLo - 2 + lane; i < hiW; i += 64) {
+                    for (int i = newLo - 3 + lane; i < hiW; i += 64) {
                         int const o = 4 * i; u32 v = 0;
                         if (i >= 0) {
                             if (o + 4 <= (int)ssz) v = kx_ld32(sq + o);
                             else for (int k = 0; o + k < (int)ssz; k++) v |= (u32)sq[o + k] << (8 * k);
                         }
-                        lds.u.q.sbuf[i - newLo + 2] = v;
+                        lds.u.q.sbuf[i - newLo + 3] = v;
                     }
                     sbLo = newLo;
                     kx_sync();

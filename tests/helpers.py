@@ -298,7 +298,8 @@ def build_emu():
 def emu():
     global _EMU
     if _EMU is None:
-        _EMU = ctypes.CDLL(build_emu())
+        # KXEMU_LIB: another build of the emulator, e.g. one compiled with -fsanitize=undefined (tests/emu/README)
+        _EMU = ctypes.CDLL(os.environ.get("KXEMU_LIB") or build_emu())
     return _EMU
 
 
