@@ -18,10 +18,18 @@ struct KSliceMeta {
     u32 pad[2];
 };
 
-// Hash-table entry = (epoch << KX_IDX_BITS) | index, index = position + 2 (0 = empty).
+// Hash-table entry = epoch << 23 | check << 18 | index, index = position + 2 (0 = empty).  check: 5 bits derived from
+// the bytes a candidate is compared on (the level-3 parser: 8 bytes for the long table, 4 for the short one); an entry
+// whose check differs from the current position's cannot pass the compare, so its source line is never fetched.  The
+// other parsers leave the field zero and ignore it.
 #define KX_IDX_BITS 18
 #define KX_IDX_MASK ((1u << KX_IDX_BITS) - 1)
-#define KX_EPOCH_MAX ((1u << (32 - KX_IDX_BITS)) - 1)
+#define KX_CHK_SHIFT KX_IDX_BITS
+#define KX_CHK_BITS 5
+#define KX_TAG_SHIFT (KX_IDX_BITS + KX_CHK_BITS)
+#define KX_CHK_MASK (((1u << KX_CHK_BITS) - 1u) << KX_CHK_SHIFT)
+#define KX_TAG_MASK (~((1u << KX_TAG_SHIFT) - 1u))
+#define KX_EPOCH_MAX ((1u << (32 - KX_TAG_SHIFT)) - 1)
 #define KX_TBL_LONG  (1u << 16)
 #define KX_TBL_SHORT (1u << 15)    /* chainLog <= 15 for slices <= 128 KiB */
 #define KX_TBL_ENTRIES (KX_TBL_LONG + KX_TBL_SHORT)
@@ -82,6 +90,15 @@ KX_DEV u32 kx_hash_long(u64 w, u32 hBits)
     u32 const hi = kx_mulhi64_hi32((u32)w, (u32)(w >> 32), 0xB7A56463u, 0xCF1BBCDCu);
     return hi >> (32 - hBits);
 }
+// check bits of a long-table entry: the 5 bits below the hash in the same product (all 8 bytes take part)
+KX_DEV u32 kx_chk_long(u64 w, u32 hBits)
+{
+    u32 const hi = kx_mulhi64_hi32((u32)w, (u32)(w >> 32), 0xB7A56463u, 0xCF1BBCDCu);
+    return (hi >> (32 - hBits - KX_CHK_BITS)) & ((1u << KX_CHK_BITS) - 1u);
+}
+// ... of a short-table entry: from the first 4 bytes only -- libzstd accepts a short candidate on 4 equal bytes even
+// where the table hashes 5
+KX_DEV u32 kx_chk_short(u64 w) { return ((u32)w * 2654435761u) >> (32 - KX_CHK_BITS); }
 KX_DEV u32 kx_hash_short(u64 w, u32 hBits, u32 mls)
 {
     if (mls == 4) return ((u32)w * 2654435761u) >> (32 - hBits);

@@ -119,6 +119,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
 {
     constexpr int NT = 64 / G;
     constexpr u32 IDXM = BLK ? 0xFFFFFFFFu : KX_IDX_MASK;
+    constexpr u32 TAGM = BLK ? 0u : KX_TAG_MASK;            // block mode: plain indices, no epoch, no check bits
     int const lane = kx_lane();
     int const k = lane & (G - 1);
     int const tbase = lane - k;
@@ -190,7 +191,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                         for (u32 i = (u32)k; i < KX_TBL_ENTRIES; i += G) L[i] = 0;
                         ep = 1;
                     }
-                    tag = ep << KX_IDX_BITS;
+                    tag = ep << KX_TAG_SHIFT;
                     anchor = 0; ilimit = n - 8;
                     ip = 1; off1 = 1; off2 = 0;     // rep {1,4,8}: 4 exceeds the 1 byte of history at ip=1
                     step = 1; nextStep = ip + 256; carry = false;
@@ -210,8 +211,8 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     if (k == 0) {
                         u64 const w = kx_ld64(src + ip);
                         u32 const v = tag | (u32)(ip + 2);
-                        S[kx_hash_short(w, hbS, mls)] = v;
-                        L[kx_hash_long(w, hbL)] = v;
+                        S[kx_hash_short(w, hbS, mls)] = BLK ? v : v | (kx_chk_short(w) << KX_CHK_SHIFT);
+                        L[kx_hash_long(w, hbL)] = BLK ? v : v | (kx_chk_long(w, hbL) << KX_CHK_SHIFT);
                     }
                     m_type = KMT_REP0; m_pos = ip; m_start = ip; m_mpos = ip - (int)off2; m_len0 = 4;
                     state = KST_MATCH;
@@ -237,8 +238,15 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 if (a.flags & 1u) { if (!haveL) el = kx_ld_nt(&L[hl]); if (cand) es = kx_ld_nt(&S[hs]); }
                 else { if (!haveL) el = L[hl]; if (cand) es = S[hs]; }
             }
-            u32 idxl = ((el & ~IDXM) == tag) ? (el & IDXM) : 0u;
-            u32 idxs = ((es & ~IDXM) == tag) ? (es & IDXM) : 0u;
+            u32 idxl = ((el & TAGM) == tag) ? (el & IDXM) : 0u;
+            u32 idxs = ((es & TAGM) == tag) ? (es & IDXM) : 0u;
+            u32 ckl = 0, cks = 0;                    // this position's check bits (also stored with its inserts)
+            if (!BLK) {
+                ckl = kx_chk_long(w, hbL) << KX_CHK_SHIFT; cks = kx_chk_short(w) << KX_CHK_SHIFT;
+                // an entry with other check bits cannot pass the 8- / 4-byte compare: no candidate, no source line fetched
+                if ((el & KX_CHK_MASK) != ckl) idxl = 0;
+                if ((es & KX_CHK_MASK) != cks) idxs = 0;
+            }
             if (srch && carry && k == 0) idxl = carry_idxl;
             // what lanes < k of this team would have inserted before lane k looks up
             u32 const hpack = hl | (hs << 16);       // hashLog <= 16 and chainLog <= 15 without BLK
@@ -291,8 +299,8 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             }
             if (ins) {
                 u32 const v = tag | (u32)(pos + 2);
-                if (a.flags & 2u) { if (!supL) kx_st_nt(&L[hl], v); if (!supS) kx_st_nt(&S[hs], v); }
-                else { if (!supL) L[hl] = v; if (!supS) S[hs] = v; }
+                if (a.flags & 2u) { if (!supL) kx_st_nt(&L[hl], v | ckl); if (!supS) kx_st_nt(&S[hs], v | cks); }
+                else { if (!supL) L[hl] = v | ckl; if (!supS) S[hs] = v | cks; }
             }
 
             // winner data, broadcast inside the team
@@ -325,7 +333,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                         else { m_start = m_pos; m_mpos = (int)b_idxs - 2; m_len0 = 4; }
                         m_off = (u32)(m_start - m_mpos);
                         m_idxl1 = n_idxl; m_w1 = (u64)n_wlo | ((u64)n_whi << 32);
-                        if (step < 4 && k == 0) L[n_hl] = tag | (u32)(m_pos + step + 2);
+                        if (step < 4 && k == 0) L[n_hl] = tag | (u32)(m_pos + step + 2) | (BLK ? 0u : kx_chk_long(m_w1, hbL) << KX_CHK_SHIFT);
                     }
                     carry = false;
                     state = KST_MATCH;
@@ -371,10 +379,10 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     u64 const wb = kx_ld64(src + ip - 2);
                     u64 const wc = kx_ld64(src + ip - 1);
                     u32 const va = tag | (u32)(m_pos + 2 + 2);
-                    L[kx_hash_long(wa, hbL)] = va;
-                    L[kx_hash_long(wb, hbL)] = tag | (u32)(ip - 2 + 2);
-                    S[kx_hash_short(wa, hbS, mls)] = va;
-                    S[kx_hash_short(wc, hbS, mls)] = tag | (u32)(ip - 1 + 2);
+                    L[kx_hash_long(wa, hbL)] = BLK ? va : va | (kx_chk_long(wa, hbL) << KX_CHK_SHIFT);
+                    L[kx_hash_long(wb, hbL)] = (tag | (u32)(ip - 2 + 2)) | (BLK ? 0u : kx_chk_long(wb, hbL) << KX_CHK_SHIFT);
+                    S[kx_hash_short(wa, hbS, mls)] = BLK ? va : va | (kx_chk_short(wa) << KX_CHK_SHIFT);
+                    S[kx_hash_short(wc, hbS, mls)] = (tag | (u32)(ip - 1 + 2)) | (BLK ? 0u : kx_chk_short(wc) << KX_CHK_SHIFT);
                 }
                 if (++guard > 2u * (u32)n + 64u) { status = 2; state = KST_CLEANUP; }
                 else state = KST_REPCHECK;

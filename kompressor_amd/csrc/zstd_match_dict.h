@@ -150,7 +150,7 @@ KX_DEV void zstd_match_dict_body(const KDictArgs& d)
                         for (u32 i = (u32)k; i < KX_TBL_ENTRIES; i += G) L[i] = 0;
                         ep = 1;
                     }
-                    tag = ep << KX_IDX_BITS;
+                    tag = ep << KX_TAG_SHIFT;
                     anchor = 0; ip = 0; ilimit = n - 8; off1 = 1; off2 = 4;
                     state = (n < 8 || ip >= ilimit) ? KDS_CLEANUP : KDS_SEARCH;
                 }
@@ -177,8 +177,8 @@ KX_DEV void zstd_match_dict_body(const KDictArgs& d)
                 if (attach) { hl = kx_hash_long(w0, d.dHashLog + 8); hs = kx_hash_short(w0, d.dChainLog + 8, mls); }
                 u32 const xL = attach ? d.dictL[hl >> 8] : d.dictL[hL];
                 u32 const xS = attach ? d.dictS[hs >> 8] : d.dictS[hS];
-                u32 idxL = ((eL & ~KX_IDX_MASK) == tag) ? (eL & KX_IDX_MASK) : 0u;
-                u32 idxS = ((eS & ~KX_IDX_MASK) == tag) ? (eS & KX_IDX_MASK) : 0u;
+                u32 idxL = ((eL & KX_TAG_MASK) == tag) ? (eL & KX_IDX_MASK) : 0u;
+                u32 idxS = ((eS & KX_TAG_MASK) == tag) ? (eS & KX_IDX_MASK) : 0u;
                 // dictionary side
                 u32 dIdxL = 0, dIdxS = 0; bool dTagL = false, dTagS = false;
                 if (attach) {
@@ -221,7 +221,7 @@ KX_DEV void zstd_match_dict_body(const KDictArgs& d)
                             // look for a long match at ip + 1 first (and always insert that position)
                             u32 const h3 = kx_hash_long(w1, hbL);
                             u32 const e3 = L[h3];
-                            u32 idx3 = ((e3 & ~KX_IDX_MASK) == tag) ? (e3 & KX_IDX_MASK) : 0u;
+                            u32 idx3 = ((e3 & KX_TAG_MASK) == tag) ? (e3 & KX_IDX_MASK) : 0u;
                             if (h3 == hL) idx3 = curr;                       // this step's own insert
                             bool hit3 = false; u32 m3 = 0;
                             if (attach) {

@@ -33,6 +33,7 @@ template <int G, bool BLK = false>
 KX_DEV void zstd_match_fast_body(const KFastArgs& f)
 {
     constexpr u32 IDXM = BLK ? 0xFFFFFFFFu : KX_IDX_MASK;
+    constexpr u32 TAGM = BLK ? 0u : KX_TAG_MASK;            // block mode: plain indices, no epoch
     constexpr int NT = 64 / G;
     const KMatchArgs& a = f.m;
     int const lane = kx_lane();
@@ -93,7 +94,7 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                         for (u32 i = (u32)k; i < KX_TBL_ENTRIES; i += G) H[i] = 0;
                         ep = 1;
                     }
-                    tag = ep << KX_IDX_BITS;
+                    tag = ep << KX_TAG_SHIFT;
                     anchor = 0; ilimit = n - 8;
                     ip0 = 1; rep1 = 1; rep2 = 0;             // rep {1,4,8}: 4 exceeds the 1 byte of history at ip0 = 1
                     state = (n < 8) ? KFS_CLEANUP : KFS_START;
@@ -115,7 +116,7 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                         e = H[h0];
                     }
                     hash0 = h0; hash1 = h1;                  // lane 0's copies are the ones used
-                    matchIdx = ((e & ~IDXM) == tag) ? (e & IDXM) : 0u;
+                    matchIdx = ((e & TAGM) == tag) ? (e & IDXM) : 0u;
                     state = KFS_PAIR;
                 }
             }
@@ -151,10 +152,10 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                 u32 const e2 = (hash2 == hash1) ? t1 : (hash2 == hash0) ? t0 : e2raw;
                 u32 const e3 = (hash3 == hash2) ? t2 : (hash3 == hash1) ? t1 : (hash3 == hash0) ? t0 : e3raw;
                 u32 const e2B = (hash2B == hash3) ? t3 : (hash2B == hash2) ? t2 : (hash2B == hash1) ? t1 : (hash2B == hash0) ? t0 : e2Braw;
-                u32 const mi1 = ((e1 & ~IDXM) == tag) ? (e1 & IDXM) : 0u;
-                u32 const mi2 = ((e2 & ~IDXM) == tag) ? (e2 & IDXM) : 0u;
-                u32 const mi3 = ((e3 & ~IDXM) == tag) ? (e3 & IDXM) : 0u;
-                u32 const mi2B = ((e2B & ~IDXM) == tag) ? (e2B & IDXM) : 0u;
+                u32 const mi1 = ((e1 & TAGM) == tag) ? (e1 & IDXM) : 0u;
+                u32 const mi2 = ((e2 & TAGM) == tag) ? (e2 & IDXM) : 0u;
+                u32 const mi3 = ((e3 & TAGM) == tag) ? (e3 & IDXM) : 0u;
+                u32 const mi2B = ((e2B & TAGM) == tag) ? (e2B & IDXM) : 0u;
                 u32 const c1 = kx_ld32(src + (mi1 >= 2u ? (int)mi1 - 2 : 0));
                 u32 const c0B = kx_ld32(src + (mi2 >= 2u ? (int)mi2 - 2 : 0));
                 u32 const c1B = kx_ld32(src + (mi3 >= 2u ? (int)mi3 - 2 : 0));
