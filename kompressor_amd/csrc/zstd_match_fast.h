@@ -34,6 +34,8 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
 {
     constexpr u32 IDXM = BLK ? 0xFFFFFFFFu : KX_IDX_MASK;
     constexpr u32 TAGM = BLK ? 0u : KX_TAG_MASK;            // block mode: plain indices, no epoch
+    constexpr u32 CHKM = BLK ? 0u : KX_CHK_MASK;            // check bits (first 4 bytes of the position, what a candidate is compared on)
+#define KFS_CK(bytes4_) (BLK ? 0u : kx_chk_short((u64)(bytes4_)) << KX_CHK_SHIFT)
     constexpr int NT = 64 / G;
     const KMatchArgs& a = f.m;
     int const lane = kx_lane();
@@ -109,14 +111,15 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                 step = 2; gap = 2; nextStep = ip0 + 128;
                 if (ip0 + 3 >= ilimit) state = KFS_CLEANUP;
                 else {
-                    u32 e = 0, h0 = 0, h1 = 0;
+                    u32 e = 0, h0 = 0, h1 = 0, ck0 = 0;
                     if (k == 0) {
-                        h0 = kx_hash_short_any(kx_ld64(src + ip0), hlog, mls);
+                        u64 const w0 = kx_ld64(src + ip0);
+                        h0 = kx_hash_short_any(w0, hlog, mls);
                         h1 = kx_hash_short_any(kx_ld64(src + ip0 + 1), hlog, mls);
-                        e = H[h0];
+                        e = H[h0]; ck0 = KFS_CK(w0);
                     }
                     hash0 = h0; hash1 = h1;                  // lane 0's copies are the ones used
-                    matchIdx = ((e & TAGM) == tag) ? (e & IDXM) : 0u;
+                    matchIdx = ((e & TAGM) == tag && (e & CHKM) == ck0) ? (e & IDXM) : 0u;
                     state = KFS_PAIR;
                 }
             }
@@ -147,15 +150,17 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                 u32 const hash2 = kx_hash_short_any(w2, hlog, mls), hash3 = kx_hash_short_any(w3, hlog, mls);
                 u32 const hash2B = kx_hash_short_any(w2B, hlog, mls), hash3B = kx_hash_short_any(w3B, hlog, mls);
                 u32 const e2raw = H[hash2], e3raw = H[hash3], e2Braw = H[hash2B];
-                u32 const t0 = tag | (u32)(ip0 + 2), t1 = tag | (u32)(ip1 + 2), t2 = tag | (u32)(ip2 + 2), t3 = tag | (u32)(ip3 + 2);
+                u32 const k0 = KFS_CK(s0), k1 = KFS_CK(s1), k2 = KFS_CK(w2), k3 = KFS_CK(w3), k2B = KFS_CK(w2B);
+                u32 const t0 = tag | k0 | (u32)(ip0 + 2), t1 = tag | k1 | (u32)(ip1 + 2), t2 = tag | k2 | (u32)(ip2 + 2), t3 = tag | k3 | (u32)(ip3 + 2);
                 u32 const e1 = (hash1 == hash0) ? t0 : e1raw;
                 u32 const e2 = (hash2 == hash1) ? t1 : (hash2 == hash0) ? t0 : e2raw;
                 u32 const e3 = (hash3 == hash2) ? t2 : (hash3 == hash1) ? t1 : (hash3 == hash0) ? t0 : e3raw;
                 u32 const e2B = (hash2B == hash3) ? t3 : (hash2B == hash2) ? t2 : (hash2B == hash1) ? t1 : (hash2B == hash0) ? t0 : e2Braw;
-                u32 const mi1 = ((e1 & TAGM) == tag) ? (e1 & IDXM) : 0u;
-                u32 const mi2 = ((e2 & TAGM) == tag) ? (e2 & IDXM) : 0u;
-                u32 const mi3 = ((e3 & TAGM) == tag) ? (e3 & IDXM) : 0u;
-                u32 const mi2B = ((e2B & TAGM) == tag) ? (e2B & IDXM) : 0u;
+                // an entry whose check bits differ from the position's cannot pass the 4-byte compare: no candidate, no fetch
+                u32 const mi1 = ((e1 & TAGM) == tag && (e1 & CHKM) == k1) ? (e1 & IDXM) : 0u;
+                u32 const mi2 = ((e2 & TAGM) == tag && (e2 & CHKM) == k2) ? (e2 & IDXM) : 0u;
+                u32 const mi3 = ((e3 & TAGM) == tag && (e3 & CHKM) == k3) ? (e3 & IDXM) : 0u;
+                u32 const mi2B = ((e2B & TAGM) == tag && (e2B & CHKM) == k2B) ? (e2B & IDXM) : 0u;
                 u32 const c1 = kx_ld32(src + (mi1 >= 2u ? (int)mi1 - 2 : 0));
                 u32 const c0B = kx_ld32(src + (mi2 >= 2u ? (int)mi2 - 2 : 0));
                 u32 const c1B = kx_ld32(src + (mi3 >= 2u ? (int)mi3 - 2 : 0));
@@ -188,7 +193,7 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                                 n_cur = ip3;
                                 if (mi3 >= 2u && c1B == (u32)w3) {
                                     kind = 3; n_ip0 = ip3; n_mi = mi3;
-                                    if (stepB <= 4) H[hash2B] = tag | (u32)(ip2B + 2);
+                                    if (stepB <= 4) H[hash2B] = tag | k2B | (u32)(ip2B + 2);
                                     hash0 = hash3; hash1 = hash2B;
                                 } else {
                                     n_mi = mi2B; hash0 = hash2B; hash1 = hash3B;
@@ -232,7 +237,7 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
             if (inrep && ip0 <= ilimit && rep2 > 0) hit = kx_ld32(src + ip0) == kx_ld32(src + ip0 - (int)rep2);
             if (inrep) {
                 if (hit) {
-                    if (k == 0) H[kx_hash_short_any(kx_ld64(src + ip0), hlog, mls)] = tag | (u32)(ip0 + 2);
+                    if (k == 0) { u64 const wr = kx_ld64(src + ip0); H[kx_hash_short_any(wr, hlog, mls)] = tag | KFS_CK(wr) | (u32)(ip0 + 2); }
                     u32 const t = rep2; rep2 = rep1; rep1 = t;
                     m_start = ip0; m_mpos = ip0 - (int)rep1; m_len0 = 4; m_back = false; m_fill = false; m_off = 0;
                     state = KFS_MATCH;
@@ -262,8 +267,9 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                 ip0 = m_start + (int)lenA; anchor = ip0;
                 if (m_fill && ip0 <= ilimit && k == 0) {
                     // fill: current0 + 2 and ip0 - 2
-                    H[kx_hash_short_any(kx_ld64(src + current0 + 2), hlog, mls)] = tag | (u32)(current0 + 2 + 2);
-                    H[kx_hash_short_any(kx_ld64(src + ip0 - 2), hlog, mls)] = tag | (u32)(ip0 - 2 + 2);
+                    u64 const wf0 = kx_ld64(src + current0 + 2), wf1 = kx_ld64(src + ip0 - 2);
+                    H[kx_hash_short_any(wf0, hlog, mls)] = tag | KFS_CK(wf0) | (u32)(current0 + 2 + 2);
+                    H[kx_hash_short_any(wf1, hlog, mls)] = tag | KFS_CK(wf1) | (u32)(ip0 - 2 + 2);
                 }
                 if (++guard > 2u * (u32)n + 64u) { status = 2; state = KFS_CLEANUP; }
                 else state = (ip0 <= ilimit) ? KFS_REPLOOP : KFS_START;
@@ -294,3 +300,4 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
         }
     }
 }
+#undef KFS_CK
