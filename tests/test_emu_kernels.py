@@ -260,3 +260,15 @@ def test_compressors_stay_inside_their_buffers(which):
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "guard_pages_compress.py"), which, "--quick"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "GUARD OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_epoch_wrap_clears_the_team_tables():
+    """A team's epoch has 9 bits (the rest of a table entry: 5 check bits, 18 index bits): four teams take 2 300 small slices
+    in one launch, so every team passes the wrap (tables cleared, epoch restarts at 1) -- frames stay the oracle's, at
+    level 3 and at level 1."""
+    o = helpers.oracle()
+    datas = [corpus.make(9000 + i, 1, 200 + (i % 7) * 37, mix=ord("TXSB"[i % 4])).tobytes() for i in range(2300)]
+    for f, d in zip(helpers.emu_compress(datas, G=16, nblocks=1), datas):
+        assert f == o.compress(d)
+    for f, d in zip(helpers.emu_compress_level(datas, 1, G=16, nblocks=1), datas):
+        assert f == o.compress_level(d, 1)
