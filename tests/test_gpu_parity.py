@@ -643,3 +643,20 @@ def test_fuzz_ragged_sizes_levels_1_and_2(batch):
             assert f == o.compress_level_big(d, 1), (i, len(d))
     finally:
         b.close()
+
+
+def test_epoch_wrap_on_the_gpu():
+    """A context for 64 slices has 64 teams; 560 batches of 64 small slices take every team past its 9-bit epoch (tables
+    cleared on the device, epoch restarts): the frames of the batches around the wrap and of the last one are the oracle's."""
+    from kompressor_amd.batch import ZstdBatch
+    o = helpers.oracle()
+    b = ZstdBatch(max_slices=64, max_slice_bytes=65536)
+    try:
+        for r in range(560):
+            datas = [corpus.make(20000 + 64 * (r % 5) + i, 1, 150 + ((r + i) % 9) * 31, mix=ord("TXSB"[i % 4])).tobytes() for i in range(64)]
+            frames = gpu_compress(b, datas)
+            if r in (0, 509, 510, 511, 512, 513, 559):
+                for d, f in zip(datas, frames):
+                    assert f == o.compress(d), r
+    finally:
+        b.close()
