@@ -30,6 +30,10 @@ struct KSliceMeta {
 #define KX_CHK_MASK (((1u << KX_CHK_BITS) - 1u) << KX_CHK_SHIFT)
 #define KX_TAG_MASK (~((1u << KX_TAG_SHIFT) - 1u))
 #define KX_EPOCH_MAX ((1u << (32 - KX_TAG_SHIFT)) - 1)
+// block mode (slices up to 2 MiB, per-slice tables zeroed per batch, no epoch): entry = check << 22 | index
+#define KX_BLK_IDX_BITS 22
+#define KX_BLK_IDX_MASK ((1u << KX_BLK_IDX_BITS) - 1)
+#define KX_BLK_CHK_MASK (((1u << KX_CHK_BITS) - 1u) << KX_BLK_IDX_BITS)
 #define KX_TBL_LONG  (1u << 16)
 #define KX_TBL_SHORT (1u << 15)    /* chainLog <= 15 for slices <= 128 KiB */
 #define KX_TBL_ENTRIES (KX_TBL_LONG + KX_TBL_SHORT)

@@ -118,8 +118,10 @@ template <int G, bool BLK = false>
 KX_DEV void zstd_match_body(const KMatchArgs& a)
 {
     constexpr int NT = 64 / G;
-    constexpr u32 IDXM = BLK ? 0xFFFFFFFFu : KX_IDX_MASK;
-    constexpr u32 TAGM = BLK ? 0u : KX_TAG_MASK;            // block mode: plain indices, no epoch, no check bits
+    constexpr u32 IDXM = BLK ? KX_BLK_IDX_MASK : KX_IDX_MASK;
+    constexpr u32 TAGM = BLK ? 0u : KX_TAG_MASK;            // block mode: no epoch (tag stays 0)
+    constexpr u32 CHKS = BLK ? KX_BLK_IDX_BITS : KX_CHK_SHIFT;
+    constexpr u32 CHKM = BLK ? KX_BLK_CHK_MASK : KX_CHK_MASK;
     int const lane = kx_lane();
     int const k = lane & (G - 1);
     int const tbase = lane - k;
@@ -211,8 +213,8 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     if (k == 0) {
                         u64 const w = kx_ld64(src + ip);
                         u32 const v = tag | (u32)(ip + 2);
-                        S[kx_hash_short(w, hbS, mls)] = BLK ? v : v | (kx_chk_short(w) << KX_CHK_SHIFT);
-                        L[kx_hash_long(w, hbL)] = BLK ? v : v | (kx_chk_long(w, hbL) << KX_CHK_SHIFT);
+                        S[kx_hash_short(w, hbS, mls)] = v | (kx_chk_short(w) << CHKS);
+                        L[kx_hash_long(w, hbL)] = v | (kx_chk_long(w, hbL) << CHKS);
                     }
                     m_type = KMT_REP0; m_pos = ip; m_start = ip; m_mpos = ip - (int)off2; m_len0 = 4;
                     state = KST_MATCH;
@@ -241,11 +243,11 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             u32 idxl = ((el & TAGM) == tag) ? (el & IDXM) : 0u;
             u32 idxs = ((es & TAGM) == tag) ? (es & IDXM) : 0u;
             u32 ckl = 0, cks = 0;                    // this position's check bits (also stored with its inserts)
-            if (!BLK) {
-                ckl = kx_chk_long(w, hbL) << KX_CHK_SHIFT; cks = kx_chk_short(w) << KX_CHK_SHIFT;
+            {
+                ckl = kx_chk_long(w, hbL) << CHKS; cks = kx_chk_short(w) << CHKS;
                 // an entry with other check bits cannot pass the 8- / 4-byte compare: no candidate, no source line fetched
-                if ((el & KX_CHK_MASK) != ckl) idxl = 0;
-                if ((es & KX_CHK_MASK) != cks) idxs = 0;
+                if ((el & CHKM) != ckl) idxl = 0;
+                if ((es & CHKM) != cks) idxs = 0;
             }
             if (srch && carry && k == 0) idxl = carry_idxl;
             // what lanes < k of this team would have inserted before lane k looks up
@@ -333,7 +335,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                         else { m_start = m_pos; m_mpos = (int)b_idxs - 2; m_len0 = 4; }
                         m_off = (u32)(m_start - m_mpos);
                         m_idxl1 = n_idxl; m_w1 = (u64)n_wlo | ((u64)n_whi << 32);
-                        if (step < 4 && k == 0) L[n_hl] = tag | (u32)(m_pos + step + 2) | (BLK ? 0u : kx_chk_long(m_w1, hbL) << KX_CHK_SHIFT);
+                        if (step < 4 && k == 0) L[n_hl] = tag | (u32)(m_pos + step + 2) | (kx_chk_long(m_w1, hbL) << CHKS);
                     }
                     carry = false;
                     state = KST_MATCH;
@@ -379,10 +381,10 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     u64 const wb = kx_ld64(src + ip - 2);
                     u64 const wc = kx_ld64(src + ip - 1);
                     u32 const va = tag | (u32)(m_pos + 2 + 2);
-                    L[kx_hash_long(wa, hbL)] = BLK ? va : va | (kx_chk_long(wa, hbL) << KX_CHK_SHIFT);
-                    L[kx_hash_long(wb, hbL)] = (tag | (u32)(ip - 2 + 2)) | (BLK ? 0u : kx_chk_long(wb, hbL) << KX_CHK_SHIFT);
-                    S[kx_hash_short(wa, hbS, mls)] = BLK ? va : va | (kx_chk_short(wa) << KX_CHK_SHIFT);
-                    S[kx_hash_short(wc, hbS, mls)] = (tag | (u32)(ip - 1 + 2)) | (BLK ? 0u : kx_chk_short(wc) << KX_CHK_SHIFT);
+                    L[kx_hash_long(wa, hbL)] = va | (kx_chk_long(wa, hbL) << CHKS);
+                    L[kx_hash_long(wb, hbL)] = (tag | (u32)(ip - 2 + 2)) | (kx_chk_long(wb, hbL) << CHKS);
+                    S[kx_hash_short(wa, hbS, mls)] = va | (kx_chk_short(wa) << CHKS);
+                    S[kx_hash_short(wc, hbS, mls)] = (tag | (u32)(ip - 1 + 2)) | (kx_chk_short(wc) << CHKS);
                 }
                 if (++guard > 2u * (u32)n + 64u) { status = 2; state = KST_CLEANUP; }
                 else state = KST_REPCHECK;

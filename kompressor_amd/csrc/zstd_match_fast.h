@@ -32,10 +32,10 @@ enum { KFS_IDLE = 0, KFS_START = 1, KFS_PAIR = 2, KFS_REPLOOP = 3, KFS_MATCH = 4
 template <int G, bool BLK = false>
 KX_DEV void zstd_match_fast_body(const KFastArgs& f)
 {
-    constexpr u32 IDXM = BLK ? 0xFFFFFFFFu : KX_IDX_MASK;
+    constexpr u32 IDXM = BLK ? KX_BLK_IDX_MASK : KX_IDX_MASK;
     constexpr u32 TAGM = BLK ? 0u : KX_TAG_MASK;            // block mode: plain indices, no epoch
-    constexpr u32 CHKM = BLK ? 0u : KX_CHK_MASK;            // check bits (first 4 bytes of the position, what a candidate is compared on)
-#define KFS_CK(bytes4_) (BLK ? 0u : kx_chk_short((u64)(bytes4_)) << KX_CHK_SHIFT)
+    constexpr u32 CHKM = BLK ? KX_BLK_CHK_MASK : KX_CHK_MASK;      // check bits (first 4 bytes of the position, what a candidate is compared on)
+#define KFS_CK(bytes4_) (kx_chk_short((u64)(bytes4_)) << (BLK ? KX_BLK_IDX_BITS : KX_CHK_SHIFT))
     constexpr int NT = 64 / G;
     const KMatchArgs& a = f.m;
     int const lane = kx_lane();
