@@ -5,17 +5,24 @@ zstd level-3 compression of a batch of 65 536 x 64 KiB slices (seeded synthetic
 HBM when the timed region starts.  One step = one pass of the whole hot path
 (match kernel + entropy/frame kernel) over the batch.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--slices M]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|3] [--slices M]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; every rank owns its
-own block of slices (weak scaling, no collective on the data path; the frame
-size table is all-gathered over RCCL inside the timed region).
+N > 1: one rank per GPU over RCCL.  Started by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) the process is a rank; started plainly with --gpus N > 1 it starts those N ranks itself as child
+processes (before anything touches a GPU) and exits with their code.  Every rank owns its own block of slices
+(weak scaling, no collective on the data path); a step compresses the block, packs the frames densely and
+all-gathers the frame size table.  With N > 1 a second figure is measured for the same work with the batch starting
+and ending on rank 0: root scatter of the slices + the step + gather-v of the frames inside the timed region
+(key "with_scatter_gather").  --config 3 = BASELINE configs[3]'s per-GPU share: 131 072 slices per GPU, text and
+binary classes alternating.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -128,12 +135,35 @@ def cpu_decode_baseline(frames_host, offs, lens, n_slices, sample=32768):
                       + (f" [{sum(bad)} calls failed]" if sum(bad) else "")}
 
 
+def launch_ranks(n):
+    """--gpus N > 1 without a launcher: start the N ranks as children of this process (which has not touched a GPU:
+    torch.cuda.device_count() does not initialise HIP) and hand back their exit code."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("KMP_BENCH_REHEARSAL"):
+        print(f"bench.py: --gpus {n} but this machine shows {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--slices", type=int, default=65536, help="slices per GPU (BASELINE configs[1]: 65536)")
+    ap.add_argument("--config", type=int, choices=[1, 3], default=1,
+                    help="BASELINE.json configs index: 1 = 65 536 mixed-class slices per GPU (the headline), "
+                         "3 = 131 072 text / binary slices per GPU (1 Mi slices on 8 GPUs)")
+    ap.add_argument("--slices", type=int, default=0, help="slices per GPU (default: 65536 for --config 1, 131072 for --config 3)")
+    ap.add_argument("--no-exchange", action="store_true", help="N > 1: skip the second figure (root scatter + gather-v inside the timed region)")
+    ap.add_argument("--no-pcie", action="store_true", help="N = 1: skip the end-to-end figure that includes the host copies over PCIe")
     ap.add_argument("--team", type=int, default=0, help="lanes per slice in the match kernel (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--level", type=int, default=3, help="zstd level: 3 (BASELINE configs), or 1 / 2 (strategy fast)")
@@ -144,6 +174,10 @@ def main():
     ap.add_argument("--mode", choices=["compress", "decompress", "deflate"], default="compress",
                     help="compress = BASELINE configs[1] (the headline); decompress = configs[2] over the same frames; deflate = configs[4] (raw DEFLATE level 6)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    if args.slices <= 0:
+        args.slices = 131072 if args.config == 3 else 65536
 
     import numpy as np
     import torch
@@ -153,8 +187,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
     dist = None
     if world > 1 or os.environ.get("KMP_BENCH_FORCE_DIST"):      # the env switch lets a 1-rank launch exercise the RCCL path
         import torch.distributed as dist
@@ -176,12 +211,20 @@ def main():
     big = SLICE > 131072
     n = args.slices
     first = rank * n                                   # this rank's block of the global slice index space
-    host = np.empty(n * SLICE, dtype=np.uint8)
-    corpus.fill(host, first, n, SLICE, corpus.MIX_CONFIG1)
+    mix = corpus.MIX_TEXT_BINARY if args.config == 3 else corpus.MIX_CONFIG1
+    # rank-local generation from seeds, in pieces of 1 GiB; the host keeps the whole block only up to 4 GiB
+    # (the CPU baseline and the spot checks read the first slices)
     src = torch.empty(n * SLICE, dtype=torch.uint8, device=dev)
-    step_copy = 1 << 30
-    for o in range(0, n * SLICE, step_copy):
-        src[o:o + step_copy] = torch.from_numpy(host[o:o + step_copy]).to(dev)
+    piece = max(1, (1 << 30) // SLICE)
+    keep = n if n * SLICE <= (4 << 30) else piece
+    host = np.empty(keep * SLICE, dtype=np.uint8)
+    tmp = np.empty(piece * SLICE, dtype=np.uint8) if keep < n else None
+    for lo in range(0, n, piece):
+        cnt = min(piece, n - lo)
+        buf = host[lo * SLICE:(lo + cnt) * SLICE] if lo + cnt <= keep else tmp[: cnt * SLICE]
+        corpus.fill(buf, first + lo, cnt, SLICE, mix)
+        src[lo * SLICE:(lo + cnt) * SLICE] = torch.from_numpy(buf).to(dev)
+    del tmp
     in_off = torch.arange(n, dtype=torch.int64, device=dev) * SLICE
     in_len = torch.full((n,), SLICE, dtype=torch.int32, device=dev)
     b = ZstdBatch(max_slices=n, max_slice_bytes=SLICE, device=local_rank, team_lanes=args.team)
@@ -270,8 +313,13 @@ def main():
     if args.level != 3:
         big = True
 
-    def step():
-        b.compress(src, in_off, in_len, dst, out_off, out_len, dictionary=dictionary, level=args.level)
+    # the frames leave a step densely packed ("all kernels incl. compaction")
+    dense = torch.empty(n * b.out_stride + 64, dtype=torch.uint8, device=dev)
+    dense_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+
+    def step(inp=src):
+        b.compress(inp, in_off, in_len, dst, out_off, out_len, dictionary=dictionary, level=args.level)
+        b.compact_into(dst, out_off, out_len, dense, dense_off)
         if dist is not None:
             return sharding.gather_frame_sizes(out_len, n * world)
         return out_len
@@ -304,6 +352,73 @@ def main():
     lens = out_len.cpu().numpy().astype(np.int64)
     frame_bytes = int(lens.sum())
     in_bytes = n * SLICE
+
+    # ---- second figure, N > 1: the batch starts and ends on rank 0 -------------------------------
+    # untimed setup: the blocks every rank generated are collected on the root, as a caller's batch would sit there;
+    # timed: root scatter of the slices (point-to-point sends over xGMI), the step above (compress + pack + size
+    # all_gather is replaced by gather_frames, which contains it), gather-v of the dense frames to the root.
+    exchange = None
+    if dist is not None and args.mode == "compress" and not args.no_exchange:
+        n_all = n * world
+        everything = sharding.gather_slices(src, n_all, SLICE)
+        src2 = torch.empty(n * SLICE, dtype=torch.uint8, device=dev)
+        stream_buf = torch.empty(int(frame_bytes * world * 1.05) + (1 << 20), dtype=torch.uint8, device=dev) if rank == 0 else None
+
+        def xstep():
+            mine = sharding.scatter_slices(everything, src2, n_all, SLICE)
+            b.compress(mine, in_off, in_len, dst, out_off, out_len, dictionary=dictionary, level=args.level)
+            b.compact_into(dst, out_off, out_len, dense, dense_off)
+            return sharding.gather_frames(dense, out_len, n_all, out=stream_buf)
+
+        xsteps = max(1, min(args.steps, 3))
+        xstep()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(xsteps):
+            stream, all_sizes, offs = xstep()
+        fence()
+        xdt = time.perf_counter() - t0
+        t = torch.tensor([xdt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        xdt = float(t.item())
+        # what arrived is what was generated locally, and the root's stream holds every rank's frames where the size table says
+        ok = torch.tensor([int(torch.equal(src2, src))], dtype=torch.int64, device=dev)
+        local_sum = dense[: int(dense_off[n].item())].sum(dtype=torch.int64).reshape(1)
+        sums = [torch.zeros_like(local_sum) for _ in range(world)]
+        dist.all_gather(sums, local_sum)
+        if rank == 0:
+            total = int(all_sizes.to(torch.int64).sum().item())
+            ok &= int(stream.numel() == total and int(stream.sum(dtype=torch.int64).item()) == sum(int(x.item()) for x in sums))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        exchange = {"value": round(n_all * SLICE / (xdt / xsteps) / 1e9, 3), "unit": "GB/s", "ms_per_step": round(xdt / xsteps * 1e3, 3),
+                    "steps": xsteps, "verified": bool(ok.item()),
+                    "what": "root scatter of the slices + compress + dense packing + all_gather of frame sizes + gather-v of the frames "
+                            "to the root, all inside the timed region (point-to-point send/recv, " + dist.get_backend() + ")"}
+        del everything, src2, stream_buf
+
+    # ---- second line of SURVEY 8d, N = 1: the same step with the host copies over PCIe included (never `value`) --------
+    pcie = None
+    if dist is None and args.mode == "compress" and not args.no_pcie and not big:
+        pin_in = torch.from_numpy(host[: n * SLICE]).pin_memory() if host.size >= n * SLICE else None
+        if pin_in is not None:
+            pin_out = torch.empty(frame_bytes + 64, dtype=torch.uint8).pin_memory()
+            src2 = torch.empty(n * SLICE, dtype=torch.uint8, device=dev)
+
+            def pstep():
+                src2.copy_(pin_in, non_blocking=True)
+                step(src2)
+                pin_out[:frame_bytes].copy_(dense[:frame_bytes], non_blocking=True)
+
+            pstep()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pstep()
+            torch.cuda.synchronize()
+            pdt = time.perf_counter() - t0
+            pcie = {"value": round(in_bytes / pdt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(pdt * 1e3, 3),
+                    "what": "pinned host slices -> HBM, the step, dense frames -> pinned host memory, one pass, copies not overlapped with the kernels"}
+            del src2, pin_in, pin_out
+
     if args.mode == "decompress":
         # configs[2]: ZstdDecompressor over the level-3 frames just produced (strided layout), decoded in place of a fresh buffer
         cap = torch.full((n,), SLICE, dtype=torch.int32, device=dev)
@@ -374,6 +489,8 @@ def main():
         if not args.no_cpu and not dictionary and args.level == 3:
             sample = min(n, max(64, (1 << 29) // SLICE))
             res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()), sample)
+        if exchange:
+            res["with_scatter_gather"] = exchange
         print(json.dumps(res), flush=True)
     elif rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -405,12 +522,15 @@ def main():
             except Exception:
                 traffic = None
         res = {
-            "metric": "zstd level-3 compression throughput, 64 KiB-slice batch (uncompressed input bytes per second)",
+            "metric": f"zstd level-3 compression throughput, {args.slice_kib} KiB-slice batch (uncompressed input bytes per second)",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {n} x 64 KiB seeded mixed slices per GPU (T/X/S/B/D/I/Z/R classes), "
-                                   "ZstdCompressor(level=3) one-shot frames, bit-identical to libzstd 1.5.7",
+            "config": {"workload": (f"BASELINE configs[3], this job's share: {n} x {args.slice_kib} KiB slices per GPU x {world} GPU(s) "
+                                    f"(1 048 576 slices on 8), text and binary classes alternating, " if args.config == 3 else
+                                    (f"BASELINE configs[1]: {n} x 64 KiB" if args.slice_kib == 64 else f"configs[1]'s mix at another slice size: {n} x {args.slice_kib} KiB")
+                                    + " seeded mixed slices per GPU (T/X/S/B/D/I/Z/R classes), ")
+                                   + "ZstdCompressor(level=3) one-shot frames, bit-identical to libzstd 1.5.7",
                        "slices_per_gpu": n, "slice_bytes": SLICE, "ratio": round(in_bytes / frame_bytes, 4),
                        "team_lanes": b.lib and (args.team or int(os.environ.get("KMP_TEAM_LANES", "4"))), "parallelism": f"slice-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_zstd_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -420,6 +540,10 @@ def main():
         }
         if random_access:
             res["random_access_roofline"] = random_access
+        if exchange:
+            res["with_scatter_gather"] = exchange
+        if pcie:
+            res["end_to_end_pcie"] = pcie
         if not args.no_cpu and world == 1:          # the CPU baseline is a rank-0, N = 1 figure
             sample = min(n, 8192)
             res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()))

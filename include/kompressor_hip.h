@@ -125,6 +125,11 @@ typedef struct kmp_batch_ctx kmp_batch_ctx;
 #define KMP_ERR_CAPACITY  (-3)   /* n or slice size beyond what the context was created for */
 #define KMP_ERR_KERNEL    (-4)   /* a kernel guard tripped (never expected) */
 
+/* Per-slice lengths are device data, so what the host cannot check before it launches is reported afterwards: the
+ * slice gets d_out_len[i] = 0 (a frame or stream is never empty) and the context's status word collects these bits. */
+#define KMP_STATUS_SLICE_TOO_LARGE 1u   /* a d_in_len[i] above the context's max_slice_bytes (DEFLATE: above 64 KiB) */
+#define KMP_STATUS_KERNEL_GUARD    2u   /* a parser's loop guard tripped (never expected) */
+
 #define KMP_MAX_SLICE_BYTES (128u * 1024u)        /* one block per frame: the batched fast path */
 #define KMP_MAX_BIG_SLICE_BYTES (2u << 20)       /* frames of several blocks (context created with max_slice_bytes above
                                                   * 128 KiB): the level-3 window (<= 2 MiB) never slides */
@@ -135,6 +140,10 @@ typedef struct kmp_batch_ctx kmp_batch_ctx;
 KMP_API int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_slices,
                              uint32_t max_slice_bytes, int team_lanes);
 KMP_API void kmp_batch_destroy(kmp_batch_ctx* ctx);
+/* Status bits (KMP_STATUS_*) raised by the batches run on this context since the last call; waits for `hip_stream`,
+ * then clears them.  Returns KMP_OK, KMP_ERR_CAPACITY (a slice was too large) or KMP_ERR_KERNEL; *bits may be NULL.
+ * A context runs one batch at a time: a batch queued on another stream waits for the previous one's last kernel. */
+KMP_API int kmp_batch_status(kmp_batch_ctx* ctx, uint32_t* bits, void* hip_stream);
 
 /* zstd level-3 frames for n independent slices.  All pointers are device
  * pointers; slice i is d_src[d_in_off[i] .. +d_in_len[i]); its frame goes to
@@ -213,7 +222,8 @@ KMP_API int kmp_zstd_decompress_batch_dict(kmp_batch_ctx* ctx,
  * them: the batched form of deflateInit2(6, Z_DEFLATED, -15, 8, 0) + deflate(Z_FINISH)
  * (reference: kompressor-zlib--nativelib/src/jvmCommonMain/jni/Wrapper.cpp:20,73; Kotlin
  * ZlibCompressor(ZlibFormat.Raw, 6)).  Slices of at most 64 KiB; stream i goes to
- * d_dst + d_out_off[i] (room for kmp_deflate_bound(len)), its size to d_out_len[i]. */
+ * d_dst + d_out_off[i] (room for kmp_deflate_bound(len), which covers all three formats: stored blocks of 5 + n
+ * bytes per 65 535, the 18 bytes of a gzip header and trailer), its size to d_out_len[i]. */
 KMP_API size_t kmp_deflate_bound(size_t src_size);
 KMP_API int kmp_deflate_compress_batch(kmp_batch_ctx* ctx,
                                        const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,

@@ -28,6 +28,7 @@ SIGNATURES = [
     ("kmp_zstd_compress_bound", _c.c_size_t, [_c.c_size_t]),
     ("kmp_batch_create", _c.c_int, [_c.POINTER(_P), _c.c_int, _c.c_uint32, _c.c_uint32, _c.c_int]),
     ("kmp_batch_destroy", None, [_P]),
+    ("kmp_batch_status", _c.c_int, [_P, _c.POINTER(_c.c_uint32), _P]),
     ("kmp_zstd_compress_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P]),
     ("kmp_zstd_compress_batch_stream", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_int, _P]),
     ("kmp_zstd_compress_batch_stream_level", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_int, _c.c_int, _P]),

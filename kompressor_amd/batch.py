@@ -47,6 +47,13 @@ class ZstdBatch:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def status(self):
+        """Waits for the batches queued so far and returns (rc, bits): KMP_STATUS_* bits raised on the device since the
+        last call (1 = a slice longer than the context holds, 2 = a parser guard tripped); such slices have out_len 0."""
+        bits = ctypes.c_uint32()
+        rc = self.lib.kmp_batch_status(self._h, ctypes.byref(bits), self._stream())
+        return rc, bits.value
+
     def set_profiling(self, on=True):
         self.lib.kmp_batch_set_profiling(self._h, 1 if on else 0)
 
@@ -160,6 +167,17 @@ class ZstdBatch:
         if self.lib.kmp_deflate_last_kernel_ms(self._h, ms) != 0:
             raise RuntimeError(_lib.last_error())
         return dict(zip(("k_deflate_chains", "k_deflate_best", "k_deflate_parse", "k_deflate_encode"), (float(x) for x in ms)))
+
+    def compact_into(self, src, in_off, lens, dst, offs):
+        """Dense packing into caller-owned buffers, no host round trip: frame i goes to dst[offs[i] : offs[i] + lens[i]],
+        offs (int64, n + 1 entries) = exclusive scan of lens, offs[n] = total bytes.  dst must hold sum(lens) bytes."""
+        n = lens.numel()
+        if offs.numel() < n + 1:
+            raise ValueError("offs needs n + 1 entries")
+        rc = self.lib.kmp_compact_batch(self._h, _ptr(src), _ptr(in_off), _ptr(lens), n, _ptr(dst), _ptr(offs), self._stream())
+        if rc != 0:
+            raise RuntimeError(f"kmp_compact_batch failed ({rc}): {_lib.last_error()}")
+        return dst, offs
 
     def compact(self, src, in_off, lens):
         """Dense packing of n frames; returns (dst, offsets[n+1])."""

@@ -97,6 +97,27 @@ __global__ __launch_bounds__(64) void k_compact(const u8* src, const u64* in_off
     }
 }
 
+// Per-slice lengths live on the device, so the host cannot check them against the workspace before it launches.
+// Every batch entry point therefore runs its kernels on a sanitised copy: a slice longer than the context (or the
+// codec) holds is processed as an empty one, then loses its frame again (out_len = 0: a real frame is never empty) and
+// raises the context's status word, which kmp_batch_status hands to the host.
+__global__ __launch_bounds__(256) void k_len_guard(const u32* in_len, u32 n, u32 cap, u32* len_ok, u32* status)
+{
+    u32 const i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    u32 const len = in_len[i];
+    len_ok[i] = len > cap ? 0u : len;
+    if (len > cap) atomicOr(status, (u32)KMP_STATUS_SLICE_TOO_LARGE);
+}
+// meta: the one-block zstd parsers' per-slice record (a tripped loop guard there also voids the frame), or null
+__global__ __launch_bounds__(256) void k_len_guard_finish(const u32* in_len, u32 n, u32 cap, u32* out_len, const KSliceMeta* meta, u32* status)
+{
+    u32 const i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    if (in_len[i] > cap) out_len[i] = 0;
+    else if (meta && in_len[i] >= 8 && meta[i].status != 0) { out_len[i] = 0; atomicOr(status, (u32)KMP_STATUS_KERNEL_GUARD); }
+}
+
 // --------------------------------------------------------------------------
 // errors
 // --------------------------------------------------------------------------
@@ -129,6 +150,13 @@ struct kmp_batch_ctx {
     // raw-content dictionary of the last kmp_zstd_compress_batch_dict call: device copy + CDict tables (built on the host)
     u8* d_dict; u32* d_dictL; u32* d_dictS; u32 dict_size; u64 dict_hash; u32 cdW, cdH, cdC, cdM;
     int big; int big_G; KFrameState* fstate; u32* hufct; u32* big_tables; u32* remaining; u32* big_counters; u32 last_rounds;
+    u32 cus;                                   // compute units of the device
+    u32* len_ok; u32* d_status;                // sanitised slice lengths of the running batch; status word (KMP_STATUS_*)
+    // one batch at a time per context: a batch queued on another stream waits for the previous one's last kernel
+    hipEvent_t ev_done; int have_done;
+    // experiment switches, read from the environment once, when the context is created
+    struct { u32 chunks, match_flags, entropy_pad, first_permille, entropy_flags, decode_flags, decode_pad, big_rounds, big_spw,
+                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags; } knob;
 };
 
 static u32 env_u32(const char* name, u32 dflt)
@@ -186,6 +214,17 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { HIP_TRY(hipEventCreate(&c->evm[i][j])); HIP_TRY(hipEventCreate(&c->eve[i][j])); }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_last_match, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    c->cus = (u32)prop.multiProcessorCount;
+    HIP_TRY(hipMalloc((void**)&c->len_ok, ns * sizeof(u32)));
+    HIP_TRY(hipMalloc((void**)&c->d_status, 64));
+    HIP_TRY(hipMemset(c->d_status, 0, 64));
+    c->knob.chunks = env_u32("KMP_ZSTD_CHUNKS", 0); c->knob.match_flags = env_u32("KMP_MATCH_FLAGS", 6); c->knob.entropy_pad = env_u32("KMP_ENTROPY_PAD_LDS", 0);
+    c->knob.first_permille = env_u32("KMP_ZSTD_FIRST_PERMILLE", 500); c->knob.entropy_flags = env_u32("KMP_ENTROPY_FLAGS", 0);
+    c->knob.decode_flags = env_u32("KMP_DECODE_FLAGS", 0); c->knob.decode_pad = env_u32("KMP_DECODE_PAD_LDS", 0);
+    c->knob.big_rounds = env_u32("KMP_BIG_ROUNDS", 0); c->knob.big_spw = env_u32("KMP_BIG_SLICES_PER_WAVE", 0);
+    c->knob.dfl_chunk = env_u32("KMP_DEFLATE_CHUNK", 16384u); c->knob.dfl_chain_waves = env_u32("KMP_DEFLATE_CHAIN_WAVES", 4);
+    c->knob.dfl_serial = env_u32("KMP_DEFLATE_SERIAL", 0); c->knob.dfl_flags = env_u32("KMP_DEFLATE_FLAGS", 0);
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return KMP_OK;
@@ -203,6 +242,8 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { if (c->evm[i][j]) (void)hipEventDestroy(c->evm[i][j]); if (c->eve[i][j]) (void)hipEventDestroy(c->eve[i][j]); }
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_last_match) (void)hipEventDestroy(c->ev_last_match);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    (void)hipFree(c->len_ok); (void)hipFree(c->d_status);
     if (c->st2) (void)hipStreamDestroy(c->st2);
     (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta);
     if (c->dfl_events) for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->dfl_searched[i]); (void)hipEventDestroy(c->dfl_done[i]); }
@@ -232,6 +273,44 @@ extern "C" int kmp_batch_last_kernel_ms(kmp_batch_ctx* c, int which, float* ms)
 /* launches of each zstd compress kernel in the last batch (the batch is cut into that many chunks) */
 extern "C" int kmp_batch_last_chunks(kmp_batch_ctx* c) { return c ? (int)c->last_chunks : 0; }
 
+extern "C" int kmp_batch_status(kmp_batch_ctx* c, uint32_t* bits, void* hip_stream)
+{
+    if (!c) { g_last_error = "kmp_batch_status: null context"; return KMP_ERR_ARG; }
+    hipStream_t const st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->have_done) HIP_TRY(hipStreamWaitEvent(st, c->ev_done, 0));
+    u32 v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, c->d_status, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemsetAsync(c->d_status, 0, 4, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (bits) *bits = v;
+    if (v & KMP_STATUS_SLICE_TOO_LARGE) { g_last_error = "a slice is larger than the context was created for: its out_len is 0"; return KMP_ERR_CAPACITY; }
+    if (v & KMP_STATUS_KERNEL_GUARD) { g_last_error = "a parser's loop guard tripped: the slice's out_len is 0"; return KMP_ERR_KERNEL; }
+    return KMP_OK;
+}
+
+// A batch begins: it waits for the previous batch of this context (whatever stream that ran on), and its kernels get
+// the sanitised lengths (k_len_guard).  A batch ends: oversized slices lose their frames, the event is recorded.
+static int batch_begin(kmp_batch_ctx* c, hipStream_t st, const u32* d_in_len, u32 n, u32 cap)
+{
+    if (c->have_done) HIP_TRY(hipStreamWaitEvent(st, c->ev_done, 0));
+    if (d_in_len) {
+        hipLaunchKernelGGL(k_len_guard, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, cap, c->len_ok, c->d_status);
+        HIP_TRY(hipGetLastError());
+    }
+    return KMP_OK;
+}
+static int batch_end(kmp_batch_ctx* c, hipStream_t st, const u32* d_in_len, u32 n, u32 cap, u32* d_out_len, const KSliceMeta* meta)
+{
+    if (d_in_len) {
+        hipLaunchKernelGGL(k_len_guard_finish, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, cap, d_out_len, meta, c->d_status);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev_done, st)); c->have_done = 1;
+    return KMP_OK;
+}
+#define KMP_TRY(x) do { int r_ = (x); if (r_ != KMP_OK) return r_; } while (0)
+
 extern "C" size_t kmp_zstd_compress_bound(size_t n)
 {
     return n + (n >> 8) + ((n < (128u << 10)) ? (((128u << 10) - n) >> 11) : 0);
@@ -255,10 +334,10 @@ extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src
         if (level != 1 || c->max_slice_bytes > (512u << 10)) { g_last_error = "kmp_zstd_compress_batch_level: above 128 KiB level 1 is served for slices up to 512 KiB (context max_slice_bytes <= 512 KiB)"; return KMP_ERR_CAPACITY; }
         return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st, 0, 1);
     }
-    if (c->have_last_match) HIP_TRY(hipStreamWaitEvent(st, c->ev_last_match, 0));
+    KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
     HIP_TRY(hipMemsetAsync(c->counter, 0, 4, st));
     KFastArgs g;
-    g.m.src = (const u8*)d_src; g.m.in_off = d_in_off; g.m.in_len = d_in_len; g.m.n_slices = n;
+    g.m.src = (const u8*)d_src; g.m.in_off = d_in_off; g.m.in_len = c->len_ok; g.m.n_slices = n;
     g.m.seqs = c->seqs; g.m.seq_cap = c->seq_cap; g.m.lits = c->lits; g.m.lit_cap = c->lit_cap; g.m.meta = c->meta;
     g.m.tables = c->tables; g.m.team_epoch = c->team_epoch; g.m.counter = c->counter; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
     g.level = (u32)level;
@@ -273,16 +352,15 @@ extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src
     default: hipLaunchKernelGGL(k_zstd_match_fast<64>, dim3(blocks), dim3(64), 0, st, g); break;
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_last_match, st)); c->have_last_match = 1;
     KEntropyArgs e;
-    e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = d_in_len; e.n_slices = n;
+    e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = c->len_ok; e.n_slices = n;
     e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
     e.scratch = c->scratch; e.scratch_words = c->scratch_words;
     e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len; e.flags = 8u | 32u;   // gather literals; strategy "fast"
     hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), 0, st, e);
     HIP_TRY(hipGetLastError());
     c->last_chunks = 1;
-    return KMP_OK;
+    return batch_end(c, st, d_in_len, n, c->max_slice_bytes, d_out_len, c->meta);
 }
 
 // ---- compressing with a raw-content dictionary ------------------------------------------------------
@@ -314,10 +392,10 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
         HIP_TRY(hipMemcpy(c->d_dictS, ts.data(), ts.size() * 4, hipMemcpyHostToDevice));
         c->dict_size = dict_size; c->dict_hash = hsh;
     }
-    if (c->have_last_match) HIP_TRY(hipStreamWaitEvent(st, c->ev_last_match, 0));
+    KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
     HIP_TRY(hipMemsetAsync(c->counter, 0, 4, st));
     KDictArgs g;
-    g.m.src = (const u8*)d_src; g.m.in_off = d_in_off; g.m.in_len = d_in_len; g.m.n_slices = n;
+    g.m.src = (const u8*)d_src; g.m.in_off = d_in_off; g.m.in_len = c->len_ok; g.m.n_slices = n;
     g.m.seqs = c->seqs; g.m.seq_cap = c->seq_cap; g.m.lits = c->lits; g.m.lit_cap = c->lit_cap; g.m.meta = c->meta;
     g.m.tables = c->tables; g.m.team_epoch = c->team_epoch; g.m.counter = c->counter; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
     g.dict = c->d_dict; g.dict_size = dict_size; g.dictL = c->d_dictL; g.dictS = c->d_dictS;
@@ -333,16 +411,15 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
     default: hipLaunchKernelGGL(k_zstd_match_dict<64>, dim3(blocks), dim3(64), 0, st, g); break;
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev_last_match, st)); c->have_last_match = 1;
     KEntropyArgs e;
-    e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = d_in_len; e.n_slices = n;
+    e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = c->len_ok; e.n_slices = n;
     e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
     e.scratch = c->scratch; e.scratch_words = c->scratch_words;
     e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len; e.flags = 8u;       // literals are gathered by the entropy kernel
     hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), 0, st, e);
     HIP_TRY(hipGetLastError());
     c->last_chunks = 1;
-    return KMP_OK;
+    return batch_end(c, st, d_in_len, n, c->max_slice_bytes, d_out_len, c->meta);
 }
 
 // Slices above 128 KiB: frames of several blocks.  Every round runs the match kernel and the frame kernel over
@@ -351,6 +428,9 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
 static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy)
 {
+    const uint32_t* const d_in_len_caller = d_in_len;
+    KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
+    d_in_len = c->len_ok;
     HIP_TRY(hipMemsetAsync(c->big_tables, 0, (size_t)n * KX_BIG_TBL_ENTRIES * sizeof(u32), st));
     HIP_TRY(hipMemsetAsync(c->remaining, 0, 4, st));
     hipLaunchKernelGGL(k_zstd_frame_init, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, c->fstate, (u8*)d_dst, d_out_off, d_out_len, c->remaining, stream ? (strategy ? 0x48u : 0x58u) : 0u);
@@ -366,15 +446,15 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     e.scratch = c->scratch; e.scratch_words = c->scratch_words;
     e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
     e.fstate = c->fstate; e.hufct = c->hufct; e.remaining = c->remaining; e.stream = stream; e.strategy = strategy;
-    if (strategy || env_u32("KMP_BIG_ROUNDS", 0) == 0) {
+    if (strategy || c->knob.big_rounds == 0) {
         // one wave per slice walks its chain of blocks
         // few slices: one per wave (most waves); many: up to 64 / G per wave so that all of them are in flight
         KBigArgs g; g.m = m; g.e = e; g.counters = c->big_counters;
         // lanes per slice: every slice of the batch should be in flight (its block chain is serial), and a parse team
         // gains little beyond 8 lanes -- measured on 1 MiB and 256 KiB slices: 8 lanes up to 16 K slices, 4 above
         int const bigG = c->big_G ? c->big_G : (n >= 16384u ? 4 : 8);
-        u32 const resident = 12u * 256u;
-        u32 spw = env_u32("KMP_BIG_SLICES_PER_WAVE", (n + resident - 1) / resident);
+        u32 const resident = 12u * c->cus;
+        u32 spw = c->knob.big_spw ? c->knob.big_spw : (n + resident - 1) / resident;
         if (spw < 1) spw = 1; if (spw > 64u / (u32)bigG) spw = 64u / (u32)bigG;
         g.spw = spw;
         u32 const grid = (n + spw - 1) / spw;
@@ -397,7 +477,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
         }
         HIP_TRY(hipGetLastError());
         c->last_rounds = 0; c->last_chunks = 1;
-        return KMP_OK;
+        return batch_end(c, st, d_in_len_caller, n, c->max_slice_bytes, d_out_len, nullptr);
     }
     // (experiment switch KMP_BIG_ROUNDS=1) the same steps as separate launches per round of blocks
     int const bigR = c->big_G ? c->big_G : 8;
@@ -424,7 +504,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
         HIP_TRY(hipGetLastError());
     }
     c->last_rounds = rounds; c->last_chunks = 1;
-    return KMP_OK;
+    return batch_end(c, st, d_in_len_caller, n, c->max_slice_bytes, d_out_len, nullptr);
 }
 /* Streaming frames: what libzstd writes when a slice arrives through finish = false calls and is closed with
  * finish = true (size unknown when the frame starts).  empty_end: the closing calls brought no data.  The context must
@@ -465,25 +545,26 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     // (two chunks only when each still fills at least half of the match kernel's team slots: 65 536 x 64 KiB -> 2,
     // 32 768 x 128 KiB -> 1: 17.7 GB/s against 13.1 with two half-empty launches)
     u32 const team_slots = c->l3_team_slots;                 // what the device holds, whatever this context's max_slices
-    u32 chunks = env_u32("KMP_ZSTD_CHUNKS", n > team_slots ? 2u : 1u);       // measured: 49 152 slices (= the slots) 16.4 GB/s in one launch, 15.5 in two; 57 344: 15.2 / 16.2
+    u32 chunks = c->knob.chunks ? c->knob.chunks : (n > team_slots ? 2u : 1u);       // measured: 49 152 slices (= the slots) 16.4 GB/s in one launch, 15.5 in two; 57 344: 15.2 / 16.2
     if (chunks < 1) chunks = 1; if (chunks > KMP_MAX_CHUNKS) chunks = KMP_MAX_CHUNKS; if (chunks > n) chunks = 1;
-    // Batches may be queued on alternating caller streams: the match kernels of consecutive batches share the team
-    // tables and run in order, but a batch's last entropy launch no longer holds up the next batch's match kernel.
-    if (c->have_last_match) HIP_TRY(hipStreamWaitEvent(st, c->ev_last_match, 0));
+    // One batch at a time per context (the sequence / literal / scratch workspaces and the team tables are shared): a
+    // batch queued on another stream waits for the last kernel of the previous one.  (Letting the next batch's match
+    // kernel start beside this batch's last entropy launch was measured and gave nothing: DESIGN.md section 8.)
+    KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
     HIP_TRY(hipMemsetAsync(c->counter, 0, 4 * KMP_MAX_CHUNKS, st));
     u32 const tpw = 64 / (u32)c->G;
-    u32 const match_flags = env_u32("KMP_MATCH_FLAGS", 6), entropy_pad = env_u32("KMP_ENTROPY_PAD_LDS", 0);   // experiments only
+    u32 const match_flags = c->knob.match_flags, entropy_pad = c->knob.entropy_pad;   // experiments only
     u32 const per = (n + chunks - 1) / chunks;
     u32 starts[KMP_MAX_CHUNKS + 1];
     for (u32 ci = 0; ci <= chunks; ci++) starts[ci] = (ci * per < n) ? ci * per : n;
     // two chunks: the last entropy launch is the only one nothing runs beside, so the second chunk is the smaller one
-    if (chunks == 2) { u32 const pm = env_u32("KMP_ZSTD_FIRST_PERMILLE", 500); if (pm >= 100 && pm <= 950) starts[1] = (u32)((u64)n * pm / 1000u) & ~63u; if (starts[1] == 0 || starts[1] >= n) starts[1] = per; }
+    if (chunks == 2) { u32 const pm = c->knob.first_permille; if (pm >= 100 && pm <= 950) starts[1] = (u32)((u64)n * pm / 1000u) & ~63u; if (starts[1] == 0 || starts[1] >= n) starts[1] = per; }
     bool forked = false;
     for (u32 ci = 0; ci < chunks; ci++) {
         u32 const first = starts[ci], m_n = starts[ci + 1] - first;
         if (m_n == 0) continue;
         KMatchArgs m;
-        m.src = (const u8*)d_src; m.in_off = d_in_off + first; m.in_len = d_in_len + first; m.n_slices = m_n;
+        m.src = (const u8*)d_src; m.in_off = d_in_off + first; m.in_len = c->len_ok + first; m.n_slices = m_n;
         m.seqs = c->seqs + (size_t)first * c->seq_cap; m.seq_cap = c->seq_cap; m.meta = c->meta + first;
         m.lits = c->lits + (size_t)first * c->lit_cap; m.lit_cap = c->lit_cap;
         m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter + ci; m.flags = match_flags;
@@ -499,12 +580,11 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->evm[ci][1], st));
-        if (ci + 1 == chunks) { HIP_TRY(hipEventRecord(c->ev_last_match, st)); c->have_last_match = 1; }
         KEntropyArgs e;
-        e.src = (const u8*)d_src; e.in_off = d_in_off + first; e.in_len = d_in_len + first; e.n_slices = m_n;
+        e.src = (const u8*)d_src; e.in_off = d_in_off + first; e.in_len = c->len_ok + first; e.n_slices = m_n;
         e.seqs = m.seqs; e.seq_cap = c->seq_cap; e.lits = c->lits + (size_t)first * c->lit_cap; e.lit_cap = c->lit_cap; e.meta = m.meta;
         e.scratch = c->scratch + (size_t)first * c->scratch_words; e.scratch_words = c->scratch_words;
-        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = env_u32("KMP_ENTROPY_FLAGS", 0) | ((match_flags & 4u) ? 8u : 0u);
+        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = c->knob.entropy_flags | ((match_flags & 4u) ? 8u : 0u);
         hipStream_t es = st;
         if (ci + 1 < chunks) { es = c->st2; HIP_TRY(hipStreamWaitEvent(es, c->evm[ci][1], 0)); forked = true; }
         if (c->profiling) HIP_TRY(hipEventRecord(c->eve[ci][0], es));
@@ -515,7 +595,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     if (forked) { HIP_TRY(hipEventRecord(c->ev_join, c->st2)); HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0)); }
     c->last_chunks = chunks;
     if (c->profiling) { c->ev_valid[0] = 1; c->ev_valid[1] = 1; }
-    return KMP_OK;
+    return batch_end(c, st, d_in_len, n, c->max_slice_bytes, d_out_len, c->meta);
 }
 
 static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
@@ -530,13 +610,14 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
     KDecodeArgs d;
     d.src = (const u8*)d_src; d.in_off = d_in_off; d.in_len = d_in_len; d.n_slices = n;
     d.dst = (u8*)d_dst; d.out_off = d_out_off; d.out_cap = d_out_cap; d.out_len = d_out_len; d.status = d_status;
-    d.lits = c->lits; d.lit_cap = c->lit_cap; d.flags = env_u32("KMP_DECODE_FLAGS", 0);
+    d.lits = c->lits; d.lit_cap = c->lit_cap; d.flags = c->knob.decode_flags;
+    KMP_TRY(batch_begin(c, st, nullptr, n, 0));            // the decoder checks every length itself; lits is shared with the compressors
     d.dict = (const u8*)d_dict; d.dict_size = d_dict ? dict_size : 0u;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[4], st));
-    hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), env_u32("KMP_DECODE_PAD_LDS", 0), st, d);   // padding = occupancy experiment only
+    hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), c->knob.decode_pad, st, d);   // padding = occupancy experiment only
     HIP_TRY(hipGetLastError());
     if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[5], st)); c->ev_valid[2] = 1; }
-    return KMP_OK;
+    return batch_end(c, st, nullptr, n, 0, nullptr, nullptr);
 }
 
 extern "C" int kmp_zstd_decompress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
@@ -548,7 +629,9 @@ extern "C" int kmp_zstd_decompress_batch_dict(kmp_batch_ctx* c, const void* d_sr
                                               uint32_t* d_out_len, uint32_t* d_status, const void* d_dict, uint32_t dict_size, void* hip_stream)
 { return zstd_decompress_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_cap, d_out_len, d_status, d_dict, dict_size, hip_stream); }
 
-extern "C" size_t kmp_deflate_bound(size_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 13 + 8; }
+// zlib's deflateBound for the default parameters plus the largest wrapper: stored blocks (5 bytes each per 16 383-symbol
+// block at worst) + 7 for the end of the stream + 18 for a gzip header and trailer (zlib wrapper: 6, raw: 0)
+extern "C" size_t kmp_deflate_bound(size_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 7 + 18; }
 
 static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                               uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream);
@@ -574,9 +657,10 @@ extern "C" int kmp_inflate_batch(kmp_batch_ctx* c, const void* d_src, const uint
     KiArgs a;
     a.src = (const u8*)d_src; a.in_off = d_in_off; a.in_len = d_in_len; a.n_slices = n;
     a.dst = (u8*)d_dst; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_len = d_out_len; a.status = d_status; a.format = (u32)format;
+    KMP_TRY(batch_begin(c, st, nullptr, n, 0));
     hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
-    return KMP_OK;
+    return batch_end(c, st, nullptr, n, 0, nullptr, nullptr);
 }
 
 static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
@@ -591,7 +675,7 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
         // Two workspace halves of up to 16 384 slices each (28 GiB of the 288 GB for both): while the search kernels
         // (chains, best: LDS-bound) work on one piece of the batch, the parse (one lane per slice, pure latency, no LDS)
         // and the encoder of the previous piece run beside them on the context's second stream.
-        u32 const cap = env_u32("KMP_DEFLATE_CHUNK", 16384u);
+        u32 const cap = c->knob.dfl_chunk ? c->knob.dfl_chunk : 16384u;
         u32 const chunk = c->max_slices < cap ? c->max_slices : cap;
         HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)2 * chunk * 65536u * sizeof(u16)));
         HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * chunk * 65536u * sizeof(KdBest)));
@@ -604,18 +688,19 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
         c->dfl_events = 1;
         c->dfl_chunk = chunk;
     }
+    KMP_TRY(batch_begin(c, st, d_in_len, n, KD_MAX_SLICE));
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[6], st));
-    u32 chain_waves = env_u32("KMP_DEFLATE_CHAIN_WAVES", 4); if (chain_waves < 1 || chain_waves > 4) chain_waves = 4;
-    bool const serial = env_u32("KMP_DEFLATE_SERIAL", 0) != 0;          // experiment switch: everything on the caller's stream
+    u32 chain_waves = c->knob.dfl_chain_waves; if (chain_waves < 1 || chain_waves > 4) chain_waves = 4;
+    bool const serial = c->knob.dfl_serial != 0;          // experiment switch: everything on the caller's stream
     u32 piece = 0;
     for (u32 first = 0; first < n; first += c->dfl_chunk, piece++) {
         u32 const m = (n - first < c->dfl_chunk) ? n - first : c->dfl_chunk;
         u32 const h = piece & 1u;                                        // workspace half
         KdArgs a;
-        a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = d_in_len + first; a.n_slices = m;
+        a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = c->len_ok + first; a.n_slices = m;
         a.link = c->dfl_link + (size_t)h * c->dfl_chunk * 65536u; a.best = c->dfl_best + (size_t)h * c->dfl_chunk * 65536u;
         a.syms = c->dfl_syms + (size_t)h * c->dfl_chunk * 65536u; a.meta = c->dfl_meta + (size_t)h * c->dfl_chunk;
-        a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = env_u32("KMP_DEFLATE_FLAGS", 0); a.format = format;
+        a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
         bool const prof = c->profiling && first == 0;      // per-kernel events for the first piece
         hipStream_t const s2 = serial ? st : c->st2;
         if (!serial && piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[h], 0));      // this half's previous piece has been encoded
@@ -638,7 +723,7 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
         if (piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[1], 0));
     }
     if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[7], st)); c->ev_valid[3] = 1; }
-    return KMP_OK;
+    return batch_end(c, st, d_in_len, n, KD_MAX_SLICE, d_out_len, nullptr);
 }
 
 // per-kernel milliseconds of the first workspace chunk of the last deflate batch: chains, best, parse, encode
@@ -722,6 +807,9 @@ extern "C" const char* kmp_zstd_get_error_name(size_t code)
 struct stream_dev {
     kmp_batch_ctx* batch; u8* d_in; u8* d_out; u64* d_off; u32* d_len; size_t in_cap, out_cap; u32 tier;
 };
+// the staging buffers live on the device the context was first used on: later calls may come from a thread whose
+// current device is another one (the reference frees contexts on a cleaner thread, Cleaner.jvm.kt:23-36)
+static bool stream_dev_select(const stream_dev& s) { return !s.batch || hipSetDevice(s.batch->device) == hipSuccess; }
 static void stream_dev_free(stream_dev& s);
 // staging for one slice / frame of at most `bytes` on either side: the 128 KiB tier first, the 2 MiB tier
 // (frames of several blocks) when a larger one shows up
@@ -733,7 +821,9 @@ static size_t stream_dev_init(stream_dev& s, size_t bytes = 0, u32 exact = 0)
     if (s.batch) stream_dev_free(s);
     u32 const tier = exact ? exact : (bytes + 1024 <= KMP_MAX_SLICE_BYTES + 1024) ? KMP_MAX_SLICE_BYTES : KMP_MAX_BIG_SLICE_BYTES;
     s.tier = tier;
-    if (kmp_batch_create(&s.batch, 0, 1, tier, 8) != KMP_OK) return KERRC(ZE_memory_allocation);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return KERRC(ZE_GENERIC);          // the caller's current device, as a libzstd context lives where its caller runs
+    if (kmp_batch_create(&s.batch, dev, 1, tier, 8) != KMP_OK) return KERRC(ZE_memory_allocation);
     s.in_cap = tier + (tier >> 7) + 1024; s.out_cap = tier + (tier >> 7) + 1024;
     if (hipMalloc((void**)&s.d_in, s.in_cap) != hipSuccess || hipMalloc((void**)&s.d_out, s.out_cap) != hipSuccess ||
         hipMalloc((void**)&s.d_off, 64) != hipSuccess || hipMalloc((void**)&s.d_len, 64) != hipSuccess) return KERRC(ZE_memory_allocation);
@@ -741,7 +831,7 @@ static size_t stream_dev_init(stream_dev& s, size_t bytes = 0, u32 exact = 0)
 }
 static void stream_dev_free(stream_dev& s)
 {
-    if (s.batch) { kmp_batch_destroy(s.batch); (void)hipFree(s.d_in); (void)hipFree(s.d_out); (void)hipFree(s.d_off); (void)hipFree(s.d_len); }
+    if (s.batch) { (void)hipSetDevice(s.batch->device); kmp_batch_destroy(s.batch); (void)hipFree(s.d_in); (void)hipFree(s.d_out); (void)hipFree(s.d_off); (void)hipFree(s.d_len); }
     memset(&s, 0, sizeof(s));
 }
 
@@ -791,6 +881,7 @@ static size_t run_single_compress(kmp_zstd_cctx* c)
     if (streaming && (c->level == 2 || !c->dict.empty())) return KERRC(ZE_parameter_unsupported);
     bool const l1big = c->level == 1 && (streaming || n > KMP_MAX_SLICE_BYTES);      // level 1, frame of several blocks / stream
     if (l1big && n > (512u << 10)) return KERRC(ZE_parameter_unsupported);             // beyond its window: CPU library
+    if (!stream_dev_select(c->dev)) return KERRC(ZE_GENERIC);
     { size_t const e = stream_dev_init(c->dev, streaming && n <= KMP_MAX_SLICE_BYTES ? KMP_MAX_SLICE_BYTES + 1 : n, l1big ? (512u << 10) : 0u); if (e) return e; }
     stream_dev& s = c->dev;
     u64 offs[2] = { 0, 0 }; u32 len = (u32)n, olen = 0;
@@ -875,7 +966,7 @@ extern "C" int kmp_zlib_compress_stream(kmp_zlib_cstream* z, void* dst, size_t d
         if (avail) { const u8* p = (const u8*)src + *src_pos; z->in.insert(z->in.end(), p, p + avail); *src_pos = src_size; }
         if (z->in.size() > KD_MAX_SLICE) return Z_MEM_ERROR_;          // slices above 64 KiB: not on the GPU path yet
         if (!finish) return avail ? Z_OK_ : Z_BUF_ERROR_;
-        if (stream_dev_init(z->dev)) return Z_MEM_ERROR_;
+        if (!stream_dev_select(z->dev) || stream_dev_init(z->dev)) return Z_MEM_ERROR_;
         stream_dev& s = z->dev;
         u64 offs[2] = { 0, 0 }; u32 len = (u32)z->in.size(), olen = 0;
         if (len && hipMemcpy(s.d_in, z->in.data(), len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
@@ -919,7 +1010,10 @@ extern "C" int kmp_zlib_decompress_stream(kmp_zlib_dstream* z, void* dst, size_t
         size_t const avail = src_size - *src_pos;
         if (avail) { const u8* p = (const u8*)src + *src_pos; z->in.insert(z->in.end(), p, p + avail); *src_pos = src_size; }
         if (!finish) return avail ? Z_OK_ : Z_BUF_ERROR_;           // the stream is decoded when the caller finishes it
-        if (!z->batch && kmp_batch_create(&z->batch, 0, 1, 65536, 8) != KMP_OK) return Z_MEM_ERROR_;
+        if (!z->batch) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || kmp_batch_create(&z->batch, dev, 1, 65536, 8) != KMP_OK) return Z_MEM_ERROR_;
+        }
         size_t const n = z->in.size();
         u8* d_in = nullptr; u8* d_out = nullptr; u64* d_off = nullptr; u32* d_len = nullptr; int rc = Z_MEM_ERROR_;
         if (hipMalloc((void**)&d_in, n + 64) == hipSuccess && hipMalloc((void**)&d_off, 64) == hipSuccess && hipMalloc((void**)&d_len, 64) == hipSuccess) {
@@ -1029,23 +1123,31 @@ extern "C" size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* d, void* dst, size_t
     if (d->stage == 0) {
         // take input until one whole frame is buffered
         size_t content = (size_t)-1;
-        {   // take everything offered, then hand back what lies beyond the frame's end
-            size_t const avail = src_size - *src_pos;
+        // the largest frame this path stages: 2 MiB of content, whose frame is at most that + 1/128 + block headers
+        size_t const frame_max = (size_t)KMP_MAX_BIG_SLICE_BYTES + (KMP_MAX_BIG_SLICE_BYTES >> 7) + 1024;
+        {   // take what is offered (never more than one largest frame beyond what is buffered), then hand back what lies beyond the frame's end
+            size_t avail = src_size - *src_pos;
+            if (d->in.size() >= frame_max) return KERRC(ZE_frameParameter_unsupported);      // still no complete frame: larger than served here
+            if (avail > frame_max - d->in.size()) avail = frame_max - d->in.size();
             const u8* p = (const u8*)src + *src_pos;
-            d->in.insert(d->in.end(), p, p + avail); *src_pos = src_size;
+            d->in.insert(d->in.end(), p, p + avail); *src_pos += avail;
         }
         size_t const total = frame_total_size(d->in.data(), d->in.size(), &content);
         if (kmp_zstd_is_error(total)) return total;
+        // a declared content size beyond what is served is refused as soon as the header is in
+        if (content != (size_t)-1 && content > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_frameParameter_unsupported);
         if (total && total < d->in.size()) { *src_pos -= d->in.size() - total; d->in.resize(total); }
-        if (total == 0) return 3;                              // hint: more input expected
+        if (total == 0) return d->in.size() >= frame_max ? KERRC(ZE_frameParameter_unsupported) : 3;      // hint: more input expected
         {
             // frames of up to 2 MiB of content (content size unknown: the staging tier decides)
             // no content size in the header (streaming frames): stage for the largest content served
             size_t const want = content == (size_t)-1 ? (size_t)KMP_MAX_BIG_SLICE_BYTES : (content > d->in.size() ? content : d->in.size());
-            if (want > KMP_MAX_BIG_SLICE_BYTES + (KMP_MAX_BIG_SLICE_BYTES >> 7)) return KERRC(ZE_frameParameter_unsupported);
+            if (want > frame_max) return KERRC(ZE_frameParameter_unsupported);
+            if (!stream_dev_select(d->dev)) return KERRC(ZE_GENERIC);
             size_t const e = stream_dev_init(d->dev, want); if (e) return e;
         }
         stream_dev& s = d->dev;
+        if (total > s.in_cap) return KERRC(ZE_frameParameter_unsupported);
         if (!d->d_status && hipMalloc((void**)&d->d_status, 64) != hipSuccess) return KERRC(ZE_memory_allocation);
         u64 offs[2] = { 0, 0 }; u32 lens[2] = { (u32)total, (u32)s.out_cap }; u32 res[2] = { 0, 0 };
         if (hipMemcpy(s.d_in, d->in.data(), total, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);

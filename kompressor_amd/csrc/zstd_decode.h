@@ -25,7 +25,7 @@ struct KDecodeArgs {
 };
 
 enum { KZE_GENERIC = 1, KZE_PREFIX = 10, KZE_FRAMEPARAM = 14, KZE_WINDOW = 16, KZE_CORRUPT = 20, KZE_CHECKSUM = 22,
-       KZE_LITHDR = 24, KZE_DICT = 32, KZE_DSTSMALL = 70, KZE_SRCSIZE = 72 };
+       KZE_LITHDR = 24, KZE_DICT = 32, KZE_WORKSPACE = 66, KZE_DSTSMALL = 70, KZE_SRCSIZE = 72 };
 
 struct KDecodeLds {
     union {                     // phase-shared region: the phases of a block never overlap in time
@@ -455,7 +455,9 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             else if (sf == 2) { lhSize = 4; regen = (w >> 4) & 0x3FFF; comp = w >> 18; nstreams = 4; }
             else { lhSize = 5; regen = (w >> 4) & 0x3FFFF; comp = (w >> 22) + ((u32)bp[4] << 10); nstreams = 4; }
         }
-        if (regen > 128u * 1024u || regen > a.lit_cap) { err = KZE_CORRUPT; break; }
+        if (regen > 128u * 1024u) { err = KZE_CORRUPT; break; }
+        // the literal buffer belongs to a context created for smaller slices: not the frame's fault (raw literals are read in place)
+        if (ltype != 0 && regen > a.lit_cap) { err = KZE_WORKSPACE; break; }
         const u8* litPtr = lits; u32 lpos = lhSize;
         if (ltype == 0) {
             if (lpos + regen > bend) { err = KZE_CORRUPT; break; }

@@ -279,3 +279,57 @@ def test_mutated_streams_on_the_gpu(batch):
             else:
                 assert ref is None, (fmt, what, len(s), cap, int(st[i]))
         assert ok >= 3          # the intact streams whose capacity was not cut
+
+
+def test_bound_sized_strides_hold_incompressible_slices_in_all_formats():
+    """kmp_deflate_bound(len) is promised to be room enough for every format: incompressible slices of 0 .. 300 bytes and
+    around 4 KiB / 16 KiB / 64 KiB packed at exactly bound-sized offsets, guard bytes between them must survive and
+    every stream must be zlib's (gzip: stored block 5 + n, header and trailer 18)."""
+    from kompressor_amd.batch import ZstdBatch
+    rng = np.random.default_rng(4242)
+    sizes = list(range(0, 301)) + [4090, 4095, 4096, 4097, 16383, 16384, 65535, 65536]
+    datas = [rng.integers(0, 256, sz, dtype=np.uint8).tobytes() for sz in sizes]
+    n = len(datas)
+    b = ZstdBatch(max_slices=n, max_slice_bytes=65536)
+    try:
+        lens = np.array(sizes, dtype=np.int32)
+        in_off = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64)
+        host = np.frombuffer(b"".join(datas) + bytes(64), dtype=np.uint8).copy()
+        bounds = np.array([b.lib.kmp_deflate_bound(sz) for sz in sizes], dtype=np.int64)
+        out_off = np.concatenate([[0], np.cumsum(bounds[:-1] + 1)]).astype(np.int64)       # one guard byte after every slot
+        total = int(out_off[-1] + bounds[-1] + 1)
+        for fmt, wbits in (("raw", -15), ("zlib", 15), ("gzip", 31)):
+            dst = torch.full((total + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+            _, _, olen = b.deflate(torch.from_numpy(host).cuda(), torch.from_numpy(in_off).cuda(), torch.from_numpy(lens).cuda(),
+                                   dst=dst, out_off=torch.from_numpy(out_off).cuda(), format=fmt)
+            torch.cuda.synchronize()
+            d, ol = dst.cpu().numpy(), olen.cpu().numpy()
+            for i, data in enumerate(datas):
+                assert ol[i] <= bounds[i], (fmt, sizes[i], int(ol[i]), int(bounds[i]))
+                assert d[out_off[i] + bounds[i]] == 0xA5, (fmt, sizes[i])                  # the guard byte behind the slot
+                c = zlib.compressobj(6, zlib.DEFLATED, wbits, 8, 0)
+                assert d[out_off[i]:out_off[i] + ol[i]].tobytes() == c.compress(data) + c.flush(), (fmt, sizes[i])
+            assert b.status() == (0, 0)
+    finally:
+        b.close()
+
+
+def test_oversized_slices_are_refused_not_overrun():
+    """Lengths live on the device: a slice above 64 KiB handed to deflate gets out_len 0 and raises the context's status
+    word; its neighbours come out right."""
+    from kompressor_amd.batch import ZstdBatch
+    b = ZstdBatch(max_slices=8, max_slice_bytes=131072)
+    try:
+        datas = [corpus.make(5 + i, 1, sz).tobytes() for i, sz in enumerate([1000, 70000, 65536, 131072, 3])]
+        outs = gpu_deflate(b, datas)
+        rc, bits = b.status()
+        assert rc == -3 and bits == 1                     # KMP_ERR_CAPACITY, KMP_STATUS_SLICE_TOO_LARGE
+        for d, f in zip(datas, outs):
+            if len(d) > 65536:
+                assert f == b""
+            else:
+                c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, 0)
+                assert f == c.compress(d) + c.flush()
+        assert b.status() == (0, 0)                       # cleared by the read
+    finally:
+        b.close()

@@ -257,14 +257,20 @@ def test_multiblock_frames_match_libzstd():
             assert f == o.compress(d), len(d)
         # several slices per wave, and the same steps as separate launches per round of blocks (experiment switches)
         import os
+        # (the switches are read when a context is created)
         for key, val in (("KMP_BIG_SLICES_PER_WAVE", "4"), ("KMP_BIG_ROUNDS", "1")):
             os.environ[key] = val
             try:
-                again = gpu_compress(b, datas + small)
+                b2 = ZstdBatch(max_slices=len(datas) + len(small), max_slice_bytes=2 << 20)
             finally:
                 del os.environ[key]
-            assert again == frames, key
-        assert b.lib.kmp_batch_last_rounds(b._h) >= 16
+            try:
+                again = gpu_compress(b2, datas + small)
+                assert again == frames, key
+                if key == "KMP_BIG_ROUNDS":
+                    assert b2.lib.kmp_batch_last_rounds(b2._h) >= 16
+            finally:
+                b2.close()
         back, st = gpu_decompress(b, frames, [max(len(d), 1) for d in datas + small])
         assert st == [0] * len(frames)
         assert back == datas + small
@@ -660,3 +666,65 @@ def test_epoch_wrap_on_the_gpu():
                     assert f == o.compress(d), r
     finally:
         b.close()
+
+
+def test_slices_longer_than_the_context_are_refused_not_overrun():
+    """A slice above the context's max_slice_bytes gets out_len 0 and raises the status word on every compress path
+    (level 3, levels 1 / 2, dictionary, frames of several blocks); the other slices of the batch are untouched."""
+    from kompressor_amd.batch import ZstdBatch
+    o = helpers.oracle()
+    b = ZstdBatch(max_slices=8, max_slice_bytes=16384)
+    try:
+        datas = [corpus.make(50 + i, 1, sz).tobytes() for i, sz in enumerate([16384, 16385, 100, 65536, 0])]
+
+        def run(**kw):
+            n = len(datas)
+            lens = np.array([len(d) for d in datas], dtype=np.int32)
+            offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64)
+            host = np.frombuffer(b"".join(datas) + bytes(64), dtype=np.uint8).copy()
+            # strides sized for the largest slice so that a refused slice cannot be told from an overrun by accident
+            stride = 70000
+            dst = torch.zeros(n * stride + 64, dtype=torch.uint8, device="cuda")
+            ooff = torch.arange(n, dtype=torch.int64, device="cuda") * stride
+            _, _, olen = b.compress(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), dst=dst, out_off=ooff, **kw)
+            torch.cuda.synchronize()
+            d, ol = dst.cpu().numpy(), olen.cpu().numpy()
+            return [d[i * stride:i * stride + ol[i]].tobytes() for i in range(n)]
+
+        for kw, ref in (({}, o.compress), ({"level": 1}, lambda d: o.compress_level(d, 1)),
+                        ({"dictionary": corpus.make(9, 1, 4096).tobytes()}, None)):
+            frames = run(**kw)
+            assert b.status() == (-3, 1), kw
+            for d, f in zip(datas, frames):
+                if len(d) > 16384:
+                    assert f == b"", (kw, len(d))
+                elif ref is not None:
+                    assert f == ref(d), (kw, len(d))
+                else:
+                    assert len(f) > 0
+        assert b.status() == (0, 0)
+    finally:
+        b.close()
+    b = ZstdBatch(max_slices=4, max_slice_bytes=300000)
+    try:
+        datas = [corpus.make(60 + i, 1, sz).tobytes() for i, sz in enumerate([300000, 300001, 140000])]
+        frames = gpu_compress(b, datas)
+        assert b.status() == (-3, 1)
+        assert frames[1] == b"" and frames[0] == o.compress(datas[0]) and frames[2] == o.compress(datas[2])
+    finally:
+        b.close()
+
+
+def test_streaming_decoder_refuses_frames_beyond_its_staging():
+    """kmp_zstd_decompress_stream stages at most a 2 MiB frame: a larger declared content size is refused when the
+    header arrives, a frame without content size when its bytes exceed the staging buffer -- never copied past it."""
+    import zlib as _z   # noqa: F401
+    from kompressor_amd.zstd import ZstdDecompressor
+    # 3 MiB declared in the header (fcs 4 bytes, single segment), nothing else needed to refuse it
+    hdr = bytes([0x28, 0xB5, 0x2F, 0xFD, 0xA0]) + (3 << 20).to_bytes(4, "little") + bytes([0x01, 0x00, 0x00])
+    with pytest.raises(RuntimeError, match="Unsupported frame parameter"):
+        ZstdDecompressor().transform_bytes(hdr)
+    # no content size: 20 raw blocks of 128 KiB after a window descriptor
+    body = b"".join((((131072 << 3) | (1 if k == 19 else 0)).to_bytes(3, "little") + bytes(131072)) for k in range(20))
+    with pytest.raises(RuntimeError, match="Unsupported frame parameter"):
+        ZstdDecompressor().transform_bytes(bytes([0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x58]) + body)

@@ -56,3 +56,72 @@ def test_two_rank_size_exchange_gloo():
     for rank, allsz, end, total in res:
         assert allsz == sizes
         assert end == sum(sizes) == total
+
+
+# ---- payload movement: root scatter -> per-rank compress (the oracle stands in for the device step) -> gather-v ----
+def _payload_worker(rank, world, port, n, S, q):
+    import numpy as np
+    from kompressor_amd import corpus
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = sharding.shard_range(n, rank, world)
+    everything = torch.from_numpy(corpus.make(0, n, S, corpus.MIX_TEXT_BINARY, threads=1)) if rank == 0 else None
+    local = torch.empty(max(1, (hi - lo) * S), dtype=torch.uint8)
+    mine = sharding.scatter_slices(everything, local, n, S)
+    # the block that arrived is the block this rank would have generated itself (configs[3]: rank-local generation)
+    assert mine.numpy().tobytes() == corpus.make(lo, hi - lo, S, corpus.MIX_TEXT_BINARY, threads=1).tobytes()
+    o = helpers.oracle()
+    frames = [o.compress(mine[i * S:(i + 1) * S].numpy().tobytes()) for i in range(hi - lo)]
+    dense = torch.frombuffer(bytearray(b"".join(frames) + b"\0"), dtype=torch.uint8)
+    sizes = torch.tensor([len(f) for f in frames], dtype=torch.int32)
+    stream, all_sizes, offs = sharding.gather_frames(dense, sizes, n)
+    q.put((rank, None if stream is None else stream.numpy().tobytes(), all_sizes.tolist(), offs.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_scatter_compress_gather_payload_gloo():
+    import numpy as np
+    from kompressor_amd import corpus
+    n, S = 13, 4096                                  # odd count: ragged shards (7 + 6)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_payload_worker, args=(r, 2, port, n, S, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=180)
+        res[r[0]] = r
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-rank answer: every slice through the oracle, frames back to back
+    host = corpus.make(0, n, S, corpus.MIX_TEXT_BINARY, threads=1)
+    o = helpers.oracle()
+    frames = [o.compress(host[i * S:(i + 1) * S].tobytes()) for i in range(n)]
+    assert res[0][1] == b"".join(frames)              # the root's dense stream
+    assert res[1][1] is None
+    for r in (0, 1):
+        assert res[r][2] == [len(f) for f in frames]
+        assert res[r][3] == list(np.cumsum([0] + [len(f) for f in frames[:-1]]))
+
+
+def test_gather_frames_with_an_empty_shard_gloo():
+    # more ranks than slices: rank 1 of 2 owns nothing when n = 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_payload_worker, args=(r, 2, port, 1, 2048, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=180)
+        res[r[0]] = r
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert len(res[0][2]) == 1 and len(res[0][1]) == res[0][2][0]
