@@ -51,8 +51,44 @@ def build_corpus(force=False):
     return CORPUS_LIB
 
 
+def find_jni_include():
+    """Directories holding a JDK's jni.h and jni_md.h, or None (the build image has no JDK: SURVEY.md section 8c)."""
+    roots = [os.environ.get("JAVA_HOME"), "/usr/lib/jvm/default-java", "/usr/lib/jvm/default"]
+    if os.path.isdir("/usr/lib/jvm"):
+        roots += sorted(os.path.join("/usr/lib/jvm", d) for d in os.listdir("/usr/lib/jvm"))
+    for r in roots:
+        inc = r and os.path.join(r, "include")
+        if inc and os.path.exists(os.path.join(inc, "jni.h")):
+            return [inc] + [os.path.join(inc, d) for d in ("linux", "darwin") if os.path.isdir(os.path.join(inc, d))]
+    return None
+
+
+JNI_SHIMS = {"libzstd-jni.so": os.path.join(ROOT, "jni", "zstd", "Wrapper.cpp"),       # the names ZstdWrapper.kt:10-17 /
+             "libz-jni.so": os.path.join(ROOT, "jni", "zlib", "Wrapper.cpp")}          # ZlibWrapper.kt load
+
+
+def build_jni(force=False):
+    """The JNI shims over libkompressor_hip.so (jni/*/Wrapper.cpp), built only where a JDK provides jni.h.
+    Returns the list of libraries built (empty without a JDK)."""
+    inc = find_jni_include()
+    if inc is None:
+        return []
+    out = []
+    for name, src in JNI_SHIMS.items():
+        target = os.path.join(HERE, name)
+        deps = [src, os.path.join(ROOT, "jni", "common", "kmp_jni.h"), os.path.join(ROOT, "include", "kompressor_hip.h")]
+        if force or _newer(target, deps):
+            cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden"] + [f"-I{d}" for d in inc] + \
+                  ["-o", target, src, f"-L{HERE}", "-lkompressor_hip", "-Wl,-rpath,$ORIGIN"]
+            subprocess.run(cmd, check=True)
+        out.append(target)
+    return out
+
+
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_corpus(force)
+    libs = build_hip(force, verbose), build_corpus(force)
+    build_jni(force)
+    return libs
 
 
 if __name__ == "__main__":

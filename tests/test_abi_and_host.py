@@ -120,3 +120,31 @@ def test_product_modules_never_touch_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 for b in banned:
                     assert b not in txt, (f, b)
+
+
+def test_jni_shims_export_what_the_kotlin_side_binds():
+    """jni/zstd/Wrapper.cpp and jni/zlib/Wrapper.cpp carry every Java_... export of the reference's JNI libraries
+    (ZstdWrapper.kt:24-60: ten, ZlibWrapper.kt:24-54: six), call only functions the C ABI header declares, and parse
+    as C++ (against test-only JNI declarations: the image has no JDK; with one, build.py builds the real libraries)."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "kompressor_hip.h")).read()
+    declared = set(re.findall(r"KMP_API[^;(]*?\b(kmp_\w+)\s*\(", hdr))
+    want = {
+        "zstd": ("com_ensody_kompressor_zstd_ZstdWrapper",
+                 {"createCompressor", "freeCompressor", "setParameter", "loadCompressorDictionary", "loadDecompressorDictionary",
+                  "compressStream", "createDecompressor", "freeDecompressor", "decompressStream", "getErrorName"}),
+        "zlib": ("com_ensody_kompressor_zlib_ZlibWrapper",
+                 {"createCompressor", "freeCompressor", "compressStream", "createDecompressor", "freeDecompressor", "decompressStream"}),
+    }
+    for lib, (prefix, names) in want.items():
+        path = os.path.join(root, "jni", lib, "Wrapper.cpp")
+        src = open(path).read()
+        assert set(re.findall(r"Java_" + prefix + r"_(\w+)\s*\(", src)) == names
+        called = set(re.findall(r"\b(kmp_(?:zstd|zlib)_\w+)\s*\(", src))
+        assert called and called <= declared, called - declared
+        subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(root, "tests", "jni_stub"), path], check=True)
+    from kompressor_amd import build
+    if build.find_jni_include() is None:
+        assert build.build_jni() == []
