@@ -116,6 +116,11 @@ def multiblock_golden():
         return json.load(fh)
 
 
+def fullsize_golden():
+    with open(os.path.join(os.path.dirname(GOLDEN_PATH), "fullsize_golden.json")) as fh:
+        return json.load(fh)
+
+
 def golden():
     with open(GOLDEN_PATH) as fh:
         return json.load(fh)

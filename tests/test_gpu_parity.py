@@ -147,11 +147,12 @@ def test_decoder_error_codes(G, batch):
     assert outs[4] == bytes(range(256)) * 256
 
 
+@pytest.mark.timeout(600)
 def test_full_batch_roundtrip_and_checksum_of_checksums():
-    """BASELINE.json configs[1] size: 65 536 x 64 KiB.  Properties that need no
-    per-frame oracle: decode(encode(x)) == x for every slice, and the 2 048
-    slices the golden manifest covers hash to the manifest's values inside the
-    big batch (so batch position does not change a frame)."""
+    """BASELINE.json configs[1] size: 65 536 x 64 KiB.  decode(encode(x)) == x for every slice; the 2 048 slices the
+    golden manifest covers hash to the manifest's values inside the big batch (batch position does not change a frame);
+    and every one of the 65 536 frames -- and of configs[4]'s 65 536 DEFLATE streams, and of 16 384 slices of
+    configs[3]'s mix -- equals the reference library's, checked through one sha256 per 4 096-slice group."""
     from kompressor_amd.batch import ZstdBatch
     G = helpers.golden()
     n, S = 65536, 65536
@@ -187,6 +188,38 @@ def test_full_batch_roundtrip_and_checksum_of_checksums():
     for i in (0, 1, 777, n - 1):
         a = packed[offs[i]:offs[i + 1]].cpu().numpy().tobytes()
         assert a == dst[int(ooff[i]):int(ooff[i]) + int(lens[i])].cpu().numpy().tobytes()
+    # ALL 65 536 frames against libzstd 1.5.7: sha256 of the frames of every group of 4 096 slices, back to back
+    # (tests/golden/fullsize_golden.json, generated by make_golden_fullsize.py from the binary library)
+    F = helpers.fullsize_golden()
+    assert F["slice_bytes"] == S
+    host = packed.cpu().numpy()
+    for g, total, sha in F["config1_zstd3"]:
+        lo, hi = int(offs[g * F["group"]]), int(offs[(g + 1) * F["group"]])
+        assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"group {g} differs from libzstd 1.5.7"
+    del host, packed
+    # ... and all 65 536 raw DEFLATE level-6 streams of configs[4] against zlib, the same way
+    ddst, doff, dlen = b.deflate(src, in_off, in_len)
+    dpacked, doffs = b.compact(ddst, doff, dlen)
+    torch.cuda.synchronize()
+    assert b.status() == (0, 0)
+    doffs = doffs.cpu().numpy()
+    host = dpacked.cpu().numpy()
+    for g, total, sha in F["config4_deflate6"]:
+        lo, hi = int(doffs[g * F["group"]]), int(doffs[(g + 1) * F["group"]])
+        assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"group {g} differs from zlib {F['zlib']}"
+    del host, dpacked, ddst
+    # configs[3]: the first 16 384 slices of rank 0's block (text / binary alternating), reusing the context
+    n3 = 16384
+    for c in range(0, n3, chunk):
+        src[c * S:(c + chunk) * S] = torch.from_numpy(corpus.make(c, chunk, S, corpus.MIX_TEXT_BINARY)).cuda()
+    dst, ooff, olen = b.compress(src, in_off[:n3], in_len[:n3])
+    packed, offs = b.compact(dst, ooff, olen)
+    torch.cuda.synchronize()
+    offs = offs.cpu().numpy()
+    host = packed.cpu().numpy()
+    for g, total, sha in F["config3_zstd3_first_16384"]:
+        lo, hi = int(offs[g * F["group"]]), int(offs[(g + 1) * F["group"]])
+        assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"configs[3] group {g} differs from libzstd 1.5.7"
     b.close()
 
 
