@@ -101,6 +101,14 @@ static void store_seq(seqstore* ss, size_t litLength, const u8* lit, u32 offBase
 /* ------------------------------------------------------------------ */
 /* double-fast match finder (noDict, first block of a frame)           */
 /* ------------------------------------------------------------------ */
+/* Optional event trace of the hash-table traffic (tools/table_traffic_model.c defines KREF_TRACE and the hook before
+ * including this file): table 0 = long, 1 = short; kind 0 = probe, 1 = insert of the searched position, 2 = long-table
+ * insert of ip+1, 3 = complementary insert after a match, 4 = insert at an immediate-repcode position. */
+#ifdef KREF_TRACE
+#define KREF_EV(table, bucket, kind) kref_trace_event((table), (u32)(bucket), (kind))
+#else
+#define KREF_EV(table, bucket, kind) ((void)0)
+#endif
 static inline size_t hash_long(const u8* p, u32 hBits)
 {
     return (size_t)((rd64(p) * 0xCF1BBCDCB7A56463ULL) >> (64 - hBits));
@@ -166,16 +174,16 @@ static size_t dfast_block(seqstore* ss, u32 rep[3], const u8* input, size_t bloc
         if (ip1 > ilimit) goto _cleanup;
 
         hl0 = hash_long(ip, hBitsL);
-        idxl0 = hashLong[hl0];
+        idxl0 = hashLong[hl0]; KREF_EV(0, hl0, 0);
         matchl0 = base + idxl0;
 
         do {
             size_t const hs0 = hash_short(ip, hBitsS, mls);
-            u32 const idxs0 = hashSmall[hs0];
+            u32 const idxs0 = hashSmall[hs0]; KREF_EV(1, hs0, 0);
             curr = (u32)(ip - base);
             matchs0 = base + idxs0;
 
-            hashLong[hl0] = hashSmall[hs0] = curr;
+            hashLong[hl0] = hashSmall[hs0] = curr; KREF_EV(0, hl0, 1); KREF_EV(1, hs0, 1);
 
             /* repcode at ip+1 */
             if ((offset_1 > 0) & (rd32(ip + 1 - offset_1) == rd32(ip + 1))) {
@@ -195,7 +203,7 @@ static size_t dfast_block(seqstore* ss, u32 rep[3], const u8* input, size_t bloc
                 goto _match_found;
             }
 
-            idxl1 = hashLong[hl1];
+            idxl1 = hashLong[hl1]; KREF_EV(0, hl1, 0);
             matchl1 = base + idxl1;
 
             /* short match at ip */
@@ -227,7 +235,7 @@ _search_next_long:
 _match_found:
         offset_2 = offset_1;
         offset_1 = offset;
-        if (step < 4) hashLong[hl1] = (u32)(ip1 - base);
+        if (step < 4) { hashLong[hl1] = (u32)(ip1 - base); KREF_EV(0, hl1, 2); }
         store_seq(ss, (size_t)(ip - anchor), anchor, offset + 3, mLength);
 
 _match_stored:
@@ -241,12 +249,15 @@ _match_stored:
                 hashLong[hash_long(ip - 2, hBitsL)] = (u32)(ip - 2 - base);
                 hashSmall[hash_short(base + indexToInsert, hBitsS, mls)] = indexToInsert;
                 hashSmall[hash_short(ip - 1, hBitsS, mls)] = (u32)(ip - 1 - base);
+                KREF_EV(0, hash_long(base + indexToInsert, hBitsL), 3); KREF_EV(0, hash_long(ip - 2, hBitsL), 3);
+                KREF_EV(1, hash_short(base + indexToInsert, hBitsS, mls), 3); KREF_EV(1, hash_short(ip - 1, hBitsS, mls), 3);
             }
             while ((ip <= ilimit) && ((offset_2 > 0) & (rd32(ip) == rd32(ip - offset_2)))) {
                 size_t const rLength = count_eq(ip + 4, ip + 4 - offset_2, iend) + 4;
                 u32 const tmpOff = offset_2; offset_2 = offset_1; offset_1 = tmpOff;
                 hashSmall[hash_short(ip, hBitsS, mls)] = (u32)(ip - base);
                 hashLong[hash_long(ip, hBitsL)] = (u32)(ip - base);
+                KREF_EV(1, hash_short(ip, hBitsS, mls), 4); KREF_EV(0, hash_long(ip, hBitsL), 4);
                 store_seq(ss, 0, anchor, 1 /*REPCODE1*/, rLength);
                 ip += rLength;
                 anchor = ip;
