@@ -134,17 +134,26 @@ static size_t count_eq(const u8* ip, const u8* match, const u8* iend)
  * index of a fresh libzstd match state is 2); 0 means empty. */
 #define IDX0 2u
 
-/* One block src[blockStart, blockStart + srcSize) of an input whose first byte has index 2; the input is
- * never larger than the window (callers guarantee it), so the lowest valid index is always 2
- * (ZSTD_getLowestPrefixIndex with endIndex - dictLimit <= 1 << windowLog). */
+/* One block src[blockStart, blockStart + srcSize) of an input whose first byte has index 2.  The lowest valid index is
+ * ZSTD_getLowestPrefixIndex(ms, curr, windowLog) = max(dictLimit, curr - maxDist): 2 while the input fits the window,
+ * above it once the window has slid (the buffered frames further down) -- taken at the END of the block for the
+ * candidates, at the first searched position for the repcodes. */
+static size_t dfast_block_low(seqstore* ss, u32 rep[3], const u8* input, size_t blockStart, size_t srcSize,
+                              u32* hashLong, u32 hBitsL, u32* hashSmall, u32 hBitsS, u32 mls, u32 dictLimit, u32 maxDist);
 static size_t dfast_block(seqstore* ss, u32 rep[3], const u8* input, size_t blockStart, size_t srcSize,
                           u32* hashLong, u32 hBitsL, u32* hashSmall, u32 hBitsS, u32 mls)
 {
+    return dfast_block_low(ss, rep, input, blockStart, srcSize, hashLong, hBitsL, hashSmall, hBitsS, mls, IDX0, 0xFFFFFFFFu);
+}
+static size_t dfast_block_low(seqstore* ss, u32 rep[3], const u8* input, size_t blockStart, size_t srcSize,
+                              u32* hashLong, u32 hBitsL, u32* hashSmall, u32 hBitsS, u32 mls, u32 dictLimit, u32 maxDist)
+{
+    u32 const endIndex = (u32)(blockStart + srcSize) + IDX0;
+    u32 const prefixLowestIndex = (endIndex - dictLimit > maxDist) ? endIndex - maxDist : dictLimit;
     const u8* const base = input - IDX0;
     const u8* const src = input + blockStart;
     const u8* const istart = src;
     const u8* anchor = istart;
-    u32 const prefixLowestIndex = IDX0;
     const u8* const prefixLowest = base + prefixLowestIndex;
     const u8* const iend = istart + srcSize;
     const u8* const ilimit = iend - 8;
@@ -162,7 +171,8 @@ static size_t dfast_block(seqstore* ss, u32 rep[3], const u8* input, size_t bloc
     ip += ((ip - prefixLowest) == 0);
     {
         u32 const current = (u32)(ip - base);
-        u32 const maxRep = current - prefixLowestIndex;
+        u32 const windowLow = (current - dictLimit > maxDist) ? current - maxDist : dictLimit;
+        u32 const maxRep = current - windowLow;
         if (offset_2 > maxRep) { offsetSaved2 = offset_2; offset_2 = 0; }
         if (offset_1 > maxRep) { offsetSaved1 = offset_1; offset_1 = 0; }
     }
@@ -1131,8 +1141,21 @@ typedef struct { u32 rep[3]; kref_hufstate huf; int isFirstBlock; } kref_frame_s
 
 /* ZSTD_compressBlock_internal for the block input[blockStart, +srcSize).
  * returns 0 => emit a raw block, 1 => RLE block, else the compressed-block body size. */
+/* what the window looks like to one block (indices = stream position + 2): ext = 1 selects the extDict variant with the
+ * older segment [dictStartIndex, prefixStartIndex), else the regular variant with its lowest valid index */
+typedef struct { int ext; u32 dictStartIndex, prefixStartIndex, dictLimit, maxDist; } kref_blockwin;
+static size_t compress_block_body_win(u8* dst, size_t cap, const u8* input, size_t blockStart, size_t srcSize, const u32* P,
+                                      kref_wksp* w, kref_frame_state* fs, seqstore* ssOut, const kref_blockwin* win);
 static size_t compress_block_body(u8* dst, size_t cap, const u8* input, size_t blockStart, size_t srcSize, const u32* P,
                                   kref_wksp* w, kref_frame_state* fs, seqstore* ssOut)
+{
+    return compress_block_body_win(dst, cap, input, blockStart, srcSize, P, w, fs, ssOut, NULL);
+}
+static size_t dfast_extdict_seg(seqstore* ss, u32 rep[3], const u8* istart, size_t srcSize, const u8* base, const u8* dictBase,
+                                u32 dictStartIndex, u32 prefixStartIndex,
+                                u32* hashLong, u32 hBitsL, u32* hashSmall, u32 hBitsS, u32 mls);
+static size_t compress_block_body_win(u8* dst, size_t cap, const u8* input, size_t blockStart, size_t srcSize, const u32* P,
+                                      kref_wksp* w, kref_frame_state* fs, seqstore* ssOut, const kref_blockwin* win)
 {
     seqstore ss; u32 rep[3]; kref_hufstate nextHuf;
     const u8* const src = input + blockStart;
@@ -1140,7 +1163,12 @@ static size_t compress_block_body(u8* dst, size_t cap, const u8* input, size_t b
     memset(&ss, 0, sizeof(ss)); ss.seqs = w->seqs; ss.lits = w->lits;
     if (srcSize < 2 + 3 + 1 + 1) { if (ssOut) *ssOut = ss; return 0; }   /* MIN_CBLOCK_SIZE + blockHeader + 1 + 1 */
     memcpy(rep, fs->rep, sizeof(rep));
-    lastLL = dfast_block(&ss, rep, input, blockStart, srcSize, w->hashLong, P[2], w->hashSmall, P[1], P[3]);
+    if (win && win->ext)          /* the whole stream is contiguous here, so both segments sit behind the same base */
+        lastLL = dfast_extdict_seg(&ss, rep, src, srcSize, input - IDX0, input - IDX0, win->dictStartIndex, win->prefixStartIndex,
+                                   w->hashLong, P[2], w->hashSmall, P[1], P[3]);
+    else
+        lastLL = dfast_block_low(&ss, rep, input, blockStart, srcSize, w->hashLong, P[2], w->hashSmall, P[1], P[3],
+                                 win ? win->dictLimit : IDX0, win ? win->maxDist : 0xFFFFFFFFu);
     memcpy(ss.lits + ss.litSize, src + srcSize - lastLL, lastLL); ss.litSize += lastLL;
     if (ssOut) *ssOut = ss;
     cSize = 0;
@@ -1345,17 +1373,25 @@ static size_t count_2segments(const u8* ip, const u8* match, const u8* iEnd, con
 }
 static int index_overlap_check(u32 prefixLowestIndex, u32 repIndex) { return ((u32)((prefixLowestIndex - 1) - repIndex) >= 3); }
 
-/* ZSTD_compressBlock_doubleFast_extDict_generic: dictionary = indices [2, 2 + D) behind dictBase, input from index 2 + D */
+/* ZSTD_compressBlock_doubleFast_extDict_generic over the block [istart, istart + srcSize): indices below
+ * prefixStartIndex live behind dictBase (the older segment, valid from dictStartIndex on), the others behind base. */
+static size_t dfast_extdict_seg(seqstore* ss, u32 rep[3], const u8* istart, size_t srcSize, const u8* base, const u8* dictBase,
+                                u32 dictStartIndex, u32 prefixStartIndex,
+                                u32* hashLong, u32 hBitsL, u32* hashSmall, u32 hBitsS, u32 mls);
+/* ... with a dictionary: dictionary = indices [2, 2 + D) behind dictBase, input from index 2 + D */
 static size_t dfast_extdict(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize, const u8* dict, size_t D,
                             u32* hashLong, u32 hBitsL, u32* hashSmall, u32 hBitsS, u32 mls)
 {
-    const u8* const istart = src; const u8* ip = istart; const u8* anchor = istart;
-    const u8* const iend = istart + srcSize; const u8* const ilimit = iend - 8;
     u32 const prefixStartIndex = (u32)(IDX0 + D);
-    const u8* const base = src - prefixStartIndex;
-    u32 const dictStartIndex = IDX0;
+    return dfast_extdict_seg(ss, rep, src, srcSize, src - prefixStartIndex, dict - IDX0, IDX0, prefixStartIndex, hashLong, hBitsL, hashSmall, hBitsS, mls);
+}
+static size_t dfast_extdict_seg(seqstore* ss, u32 rep[3], const u8* istart, size_t srcSize, const u8* base, const u8* dictBase,
+                                u32 dictStartIndex, u32 prefixStartIndex,
+                                u32* hashLong, u32 hBitsL, u32* hashSmall, u32 hBitsS, u32 mls)
+{
+    const u8* ip = istart; const u8* anchor = istart;
+    const u8* const iend = istart + srcSize; const u8* const ilimit = iend - 8;
     const u8* const prefixStart = base + prefixStartIndex;
-    const u8* const dictBase = dict - IDX0;
     const u8* const dictStart = dictBase + dictStartIndex;
     const u8* const dictEnd = dictBase + prefixStartIndex;
     u32 offset_1 = rep[0], offset_2 = rep[1];
@@ -1871,6 +1907,123 @@ KREF_API size_t kref_zstd_l3_compress_stream(u8* dst, size_t cap, const u8* src,
             savings += (int64_t)blockSize - (int64_t)cSize;
             ipos += blockSize; pos += cSize; fs.isFirstBlock = 0;
         }
+    }
+    wksp_free(&w);
+    if (emptyEnd) { wr24(dst + pos, 1); pos += 3; }
+    return pos;
+}
+
+
+/* ================================================================== */
+/* Level-3 frames as the reference really obtains them above 128 KiB:  */
+/* SliceTransform.transform(ByteArray) hands ZSTD_compressStream2 output */
+/* slices of max(8192, n / 10) bytes (SliceTransform.kt:33-56), less     */
+/* than ZSTD_compressBound(n), so libzstd does NOT compress the caller's */
+/* array in place: it stages the input in its own buffer of              */
+/* windowSize + 128 KiB bytes and compresses it in chunks of 128 KiB     */
+/* (ZSTD_compressStream_generic, buffered mode).  Consequences restated  */
+/* here: the block pre-splitter only sees one chunk; the frame header    */
+/* counts as produced from the second chunk on; once the stream is longer */
+/* than the buffer the chunks wrap to its start, the previous lap becomes */
+/* an "extDict" segment that the new chunks overwrite from the front      */
+/* (ZSTD_window_update), blocks are then parsed by the extDict variant    */
+/* of the double-fast loop, and the window's low limit follows            */
+/* ZSTD_window_enforceMaxDist / ZSTD_getLowestMatchIndex.                 */
+/* knownSize = 1: finish = true from the first call (size pledged: header */
+/* with content size, parameters by size); 0: data arrived with           */
+/* finish = false first (kref_zstd_l3_compress_stream's frames, any length). */
+/* One more thing follows from the output slices: whenever libzstd's       */
+/* staging buffer is empty (right after a wrap) and the room left in the   */
+/* CURRENT output slice is at least ZSTD_compressBound(what is left of the */
+/* input it can see), it compresses that rest straight from the caller's   */
+/* memory (ZSTD_compressEnd): one chunk however long, a new segment that   */
+/* does not overwrite the staged lap.  outChunk = size of the output slices */
+/* of the one-shot driver (max(8192, n / 10); every call fills its slice,   */
+/* so the room at a wrap is outChunk - produced % outChunk); tailDirect =   */
+/* for a stream, the bytes the closing call brought when that applied to    */
+/* it (they must start on a lap boundary), else 0.                          */
+/* ================================================================== */
+typedef struct { u32 lowLimit, dictLimit; } kref_window;
+
+KREF_API size_t kref_zstd_l3_compress_buffered(u8* dst, size_t cap, const u8* src, size_t srcSize, int knownSize, int emptyEnd,
+                                               size_t outChunk, size_t tailDirect)
+{
+    int tail = 0;
+    u32 P[4]; kref_wksp w; kref_frame_state fs; size_t pos, ipos = 0, hdr; int64_t savings = 0;
+    size_t const blockSizeMax = 128 << 10;
+    kref_window win; size_t windowSize, inBuffSize, bufPos = 0, extBase = 0; u32 maxDist; int haveExt = 0;
+    if (srcSize >= 0xF0000000u) return KERR;
+    if (cap < kref_compress_bound(srcSize) + 16) return KERR;
+    if (knownSize) { kref_params_l3(srcSize, P); pos = write_frame_header(dst, srcSize, P[0]); emptyEnd = 0; }
+    else { P[0] = 21; P[1] = 16; P[2] = 17; P[3] = 5; wr32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)((P[0] - 10) << 3); pos = 6; }
+    hdr = pos;
+    if (knownSize && srcSize == 0) { wr24(dst + pos, 1); return pos + 3; }
+    if (!wksp_alloc(&w, P)) { wksp_free(&w); return KERR; }
+    fs.rep[0] = 1; fs.rep[1] = 4; fs.rep[2] = 8; fs.huf.valid = 0; memset(&fs.huf.ct, 0, sizeof(fs.huf.ct)); fs.isFirstBlock = 1;
+    if (srcSize % blockSizeMax != 0 || srcSize == 0) emptyEnd = (!knownSize && srcSize == 0);
+    maxDist = 1u << P[0];
+    windowSize = (knownSize && srcSize < ((size_t)1 << P[0])) ? (srcSize ? srcSize : 1) : ((size_t)1 << P[0]);
+    inBuffSize = windowSize + (blockSizeMax < windowSize ? blockSizeMax : windowSize);
+    win.lowLimit = IDX0; win.dictLimit = IDX0;
+    while (ipos < srcSize) {
+        size_t chunkEnd, chunkLen; int lastChunk;
+        /* the staging buffer is empty and the rest fits the output slice: compressed in place, as one chunk */
+        if (ipos != 0 && bufPos == 0 && !tail) {
+            if (knownSize && outChunk) {
+                size_t const room = outChunk - pos % outChunk, r = srcSize - ipos;
+                if (room >= r + (r >> 8) + (r < blockSizeMax ? (blockSizeMax - r) >> 11 : 0)) tail = 1;
+            } else if (!knownSize && tailDirect && ipos + tailDirect == srcSize) tail = 1;
+        }
+        chunkEnd = (!tail && ipos + blockSizeMax < srcSize) ? ipos + blockSizeMax : srcSize;     /* chunks start at multiples of 128 KiB */
+        chunkLen = chunkEnd - ipos;
+        lastChunk = (chunkEnd == srcSize) && !emptyEnd;
+        if (ipos == blockSizeMax) savings -= (int64_t)hdr;                /* the frame header counts as produced from the second chunk on */
+        /* ZSTD_window_update for the chunk at inBuff + bufPos */
+        if (ipos != 0 && bufPos == 0) {                                     /* the chunk is not contiguous with the previous one: new segment */
+            win.lowLimit = win.dictLimit;
+            win.dictLimit = (u32)ipos + IDX0;
+            if (win.dictLimit - win.lowLimit < 8) win.lowLimit = win.dictLimit;
+            haveExt = 1;                                                    /* the older segment: stream position extBase sat at inBuff + 0 */
+        }
+        if (haveExt && !tail) {
+            /* input and older segment overlap in the buffer: the overwritten front of the segment is given up */
+            size_t const extLoPhys = (size_t)(win.lowLimit - IDX0) - extBase, extHiPhys = (size_t)(win.dictLimit - IDX0) - extBase;
+            if (bufPos + chunkLen > extLoPhys && bufPos < extHiPhys) {
+                size_t const high = extBase + bufPos + chunkLen + IDX0;
+                win.lowLimit = high > win.dictLimit ? win.dictLimit : (u32)high;
+            }
+        }
+        while (ipos < chunkEnd) {
+            size_t const remaining = chunkEnd - ipos;
+            size_t const blockSize = kref_optimal_block_size(src + ipos, remaining, savings);
+            u32 const lastBlock = lastChunk && (blockSize == remaining);
+            u8* const body = dst + pos + 3;
+            size_t cSize; kref_blockwin bw;
+            u32 const startIdx = (u32)ipos + IDX0, endIdx = (u32)(ipos + blockSize) + IDX0;
+            /* ZSTD_window_enforceMaxDist(window, blockStart, maxDist) */
+            if (startIdx > maxDist) {
+                u32 const newLow = startIdx - maxDist;
+                if (win.lowLimit < newLow) win.lowLimit = newLow;
+                if (win.dictLimit < win.lowLimit) win.dictLimit = win.lowLimit;
+            }
+            bw.ext = 0; bw.dictStartIndex = 0; bw.prefixStartIndex = 0;
+            bw.dictLimit = win.dictLimit; bw.maxDist = maxDist;                /* the regular variant takes ZSTD_getLowestPrefixIndex itself */
+            if (win.lowLimit < win.dictLimit) {                               /* ZSTD_window_hasExtDict: the extDict variant */
+                u32 const low = (endIdx - win.lowLimit > maxDist) ? endIdx - maxDist : win.lowLimit;            /* ZSTD_getLowestMatchIndex */
+                u32 const prefixStart = win.dictLimit > low ? win.dictLimit : low;
+                if (prefixStart != low) { bw.ext = 1; bw.dictStartIndex = low; bw.prefixStartIndex = prefixStart; }
+            }
+            cSize = compress_block_body_win(body, cap - pos - 3, src, ipos, blockSize, P, &w, &fs, NULL, &bw);
+            if (cSize == KERR) { wksp_free(&w); return KERR; }
+            if (cSize == 0) { wr24(dst + pos, lastBlock + (0 << 1) + (u32)(blockSize << 3)); memcpy(body, src + ipos, blockSize); cSize = 3 + blockSize; }
+            else if (cSize == 1) { wr24(dst + pos, lastBlock + (1 << 1) + (u32)(blockSize << 3)); cSize = 3 + 1; }
+            else { wr24(dst + pos, lastBlock + (2 << 1) + (u32)(cSize << 3)); cSize += 3; }
+            savings += (int64_t)blockSize - (int64_t)cSize;
+            ipos += blockSize; pos += cSize; fs.isFirstBlock = 0;
+        }
+        /* prepare the next chunk's place: inBuffTarget = inBuffPos + 128 KiB must fit the buffer */
+        bufPos += chunkLen;
+        if (bufPos + blockSizeMax > inBuffSize) { extBase = ipos - bufPos; bufPos = 0; }
     }
     wksp_free(&w);
     if (emptyEnd) { wr24(dst + pos, 1); pos += 3; }

@@ -66,6 +66,38 @@ def multiblock_inputs():
     return out
 
 
+def beyond_window_inputs():
+    """Seeded inputs longer than the level-3 window (2 MiB) and than libzstd's staging buffer (2 MiB + 128 KiB): sizes
+    around the window, the buffer's wrap points (multiples of 17 x 128 KiB) and chunk boundaries; pieces of every class,
+    byte runs and copies of earlier pieces at any distance, so that matches and repcodes straddle the window limit and
+    the segment boundaries.  (name, bytes); same list tests/golden/make_golden_buffered.py used."""
+    import random
+    from kompressor_amd import corpus
+    lap = 17 * 131072
+    rng = random.Random(20261004)
+
+    def build(n):
+        out = bytearray()
+        while len(out) < n:
+            r = rng.random()
+            if r < 0.3 and len(out) > 1000:
+                a = rng.randrange(0, len(out))
+                out += out[a:a + rng.randrange(10, 300000)]
+            elif r < 0.35:
+                out += bytes([rng.randrange(256)]) * rng.randrange(1, 300000)
+            else:
+                out += corpus.make(rng.randrange(1 << 30), 1, rng.randrange(1000, 400000), mix=ord(rng.choice("TXSBDIZR"))).tobytes()
+        return bytes(out[:n])
+
+    sizes = [(2 << 20) + 1, (2 << 20) + 65536, lap - 1, lap, lap + 1, lap + 131072 + 7, 20 * 131072 + 2, 3000000, 2 * lap - 3, 2 * lap + 50000, 5000000, 3 * lap + 4097]
+    return [(f"beyond_{n}", build(n)) for n in sizes]
+
+
+def buffered_golden():
+    with open(os.path.join(os.path.dirname(GOLDEN_PATH), "zstd_l3_buffered_golden.json")) as fh:
+        return json.load(fh)
+
+
 def parse_frame_blocks(f):
     """[(block type, header size field, literals type or -1)] of a zstd frame (RFC 8878 section 3.1.1)."""
     fhd = f[4]
@@ -206,6 +238,25 @@ class Oracle:
         cap = k.kref_compress_bound(len(d)) + 64
         o = ctypes.create_string_buffer(cap)
         n = k.kref_zstd_l3_compress_stream(o, cap, d, len(d), 1 if empty_end else 0)
+        if n == 2 ** 64 - 1:
+            raise RuntimeError("oracle: input outside the restatement's scope")
+        return o.raw[:n]
+
+    def compress_buffered(self, d: bytes, known_size: bool = True, empty_end: bool = False, out_chunk=None, tail_direct: int = 0) -> bytes:
+        """The frame ZstdCompressor(3) really produces above 128 KiB (libzstd stages the input in chunks of 128 KiB because
+        the reference's output slices are smaller than ZSTD_compressBound): known_size = finish = true from the first
+        call, out_chunk = the driver's output slice size; False = a stream fed with finish = false first (tail_direct: the
+        bytes its closing call brought, when they arrived on an empty staging buffer with room for their bound).
+        Any length (the window slides)."""
+        k = self.lib
+        k.kref_zstd_l3_compress_buffered.restype = ctypes.c_size_t
+        k.kref_zstd_l3_compress_buffered.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_size_t, ctypes.c_size_t]
+        cap = k.kref_compress_bound(len(d)) + 64
+        o = ctypes.create_string_buffer(cap)
+        if out_chunk is None:
+            out_chunk = max(8192, len(d) // 10)              # SliceTransform.kt:47-56 getOutput
+        n = k.kref_zstd_l3_compress_buffered(o, cap, d, len(d), 1 if known_size else 0, 1 if empty_end else 0, out_chunk, tail_direct)
         if n == 2 ** 64 - 1:
             raise RuntimeError("oracle: input outside the restatement's scope")
         return o.raw[:n]

@@ -168,3 +168,41 @@ def test_oracle_against_live_libzstd_if_present():
     for n in [3, 17, 100, 777, 5000, 33333, 70001, 131072]:
         d = rng.integers(0, 4, n, dtype=np.uint8).tobytes()      # low-entropy bytes
         assert o.compress(d) == z.compress(d), n
+
+
+def test_oracle_matches_the_reference_call_pattern_above_128k_and_beyond_the_window():
+    """Above 128 KiB the reference's output slices (max(8192, n / 10) bytes) are smaller than ZSTD_compressBound, so libzstd
+    stages the input in 128 KiB chunks; beyond 2 MiB + 128 KiB its staging buffer wraps and the window slides.  The
+    restatement of that path against frames a binary libzstd 1.5.7 produced under exactly those calls
+    (tests/golden/make_golden_buffered.py): one-shot driver and streamed, 57 inputs of 128 KiB+1 .. 6.7 MiB."""
+    o = helpers.oracle()
+    B = helpers.buffered_golden()
+    inputs = dict(helpers.multiblock_inputs() + helpers.beyond_window_inputs())
+    assert len(B["rows"]) == len(inputs)
+    for row in B["rows"]:
+        d = inputs[row["name"]]
+        assert len(d) == row["size"] and helpers.sha256(d) == row["input_sha256"], row["name"]
+        f = o.compress_buffered(d, known_size=True)
+        assert len(f) == row["oneshot_len"] and helpers.sha256(f) == row["oneshot_sha256"], ("oneshot", row["name"])
+        f = o.compress_buffered(d, known_size=False)
+        assert len(f) == row["stream_len"] and helpers.sha256(f) == row["stream_sha256"], ("stream", row["name"])
+    base = helpers.beyond_window_inputs()[-1][1]
+    lap = 17 * 131072
+    for row in B["tails"]:
+        d = base[: row["laps"] * lap + row["tail"]]
+        f = o.compress_buffered(d, known_size=False, tail_direct=row["tail"])
+        assert len(f) == row["len"] and helpers.sha256(f) == row["sha256"], row["name"]
+
+
+def test_buffered_oracle_against_live_libzstd_random_cuts():
+    z = helpers.live_libzstd()
+    if z is None:
+        pytest.skip("no binary libzstd 1.5.7 on this machine")
+    import random
+    o = helpers.oracle()
+    rng = random.Random(99)
+    for name, d in helpers.beyond_window_inputs()[:5] + helpers.multiblock_inputs()[20:26]:
+        n = len(d)
+        assert o.compress_buffered(d, True) == z.compress_streaming(d, [0, n], out_chunk=max(8192, n // 10)), name
+        cuts = sorted({0, n, rng.randrange(1, n), rng.randrange(1, n), rng.randrange(1, n)})
+        assert o.compress_buffered(d, False) == z.compress_streaming(d, cuts, out_chunk=8192), name
