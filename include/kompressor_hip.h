@@ -131,8 +131,8 @@ typedef struct kmp_batch_ctx kmp_batch_ctx;
 #define KMP_STATUS_KERNEL_GUARD    2u   /* a parser's loop guard tripped (never expected) */
 
 #define KMP_MAX_SLICE_BYTES (128u * 1024u)        /* one block per frame: the batched fast path */
-#define KMP_MAX_BIG_SLICE_BYTES (2u << 20)       /* frames of several blocks (context created with max_slice_bytes above
-                                                  * 128 KiB): the level-3 window (<= 2 MiB) never slides */
+#define KMP_MAX_BIG_SLICE_BYTES (1u << 30)       /* frames of several blocks (context created with max_slice_bytes above
+                                                  * 128 KiB); beyond the level-3 window (2 MiB) it slides as libzstd's does */
 
 /* Workspace for up to max_slices slices of up to max_slice_bytes each on HIP
  * device `device`.  team_lanes: lanes of a wave that cooperate on one slice in
@@ -148,7 +148,10 @@ KMP_API int kmp_batch_status(kmp_batch_ctx* ctx, uint32_t* bits, void* hip_strea
 /* zstd level-3 frames for n independent slices.  All pointers are device
  * pointers; slice i is d_src[d_in_off[i] .. +d_in_len[i]); its frame goes to
  * d_dst + d_out_off[i] (room for kmp_zstd_compress_bound(len) + 8 bytes) and its
- * size to d_out_len[i].  Asynchronous on `hip_stream` (a hipStream_t, may be 0). */
+ * size to d_out_len[i].  Asynchronous on `hip_stream` (a hipStream_t, may be 0).
+ * The frames are the ones ZSTD_compress2 writes into a buffer of ZSTD_compressBound bytes.  Up to 128 KiB (one block)
+ * that is also what the reference's ZstdCompressor(3).transform(ByteArray) returns; above, see
+ * kmp_zstd_compress_batch_reference. */
 KMP_API int kmp_zstd_compress_batch(kmp_batch_ctx* ctx,
                                     const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                     uint32_t n,
@@ -159,7 +162,9 @@ KMP_API int kmp_zstd_compress_batch(kmp_batch_ctx* ctx,
  * SliceTransformRawSource.kt:32-55, BaseSliceTransformContentEncoder.kt:23-54) and is closed with ZSTD_e_end -- the size
  * is unknown when the frame starts: window 2^21, no content size in the header, the input taken in chunks of 128 KiB.
  * empty_end != 0: the closing call brought no data (then a stream that stops on a chunk boundary ends with an empty
- * block).  Slices <= 2 MiB; the context must have been created with max_slice_bytes above 128 KiB.
+ * block).  Any length the context holds (beyond 2 MiB + 128 KiB libzstd's staging buffer wraps: the lap before becomes
+ * an older segment and the blocks are parsed by its extDict variant, restated here); the context must have been created
+ * with max_slice_bytes above 128 KiB.
  * kmp_zstd_compress_stream produces these frames by itself when data arrived with KMP_ZSTD_e_continue. */
 KMP_API int kmp_zstd_compress_batch_stream(kmp_batch_ctx* ctx,
                                            const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
@@ -174,6 +179,18 @@ KMP_API int kmp_zstd_compress_batch_stream_level(kmp_batch_ctx* ctx,
                                                  uint32_t n,
                                                  void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                                  int empty_end, int level, void* hip_stream);
+/* The frames Kompressor's ZstdCompressor(level).transform(ByteArray) returns, for slices of any size the context holds.
+ * Its driver (SliceTransform.kt:33-56) hands ZSTD_compressStream2 (Wrapper.cpp:112) output slices of max(8192, n / 10)
+ * bytes: from 128 KiB + 1 on that is less than ZSTD_compressBound(n), so libzstd does not compress the array in place
+ * but stages it in chunks of 128 KiB -- the block pre-splitter sees one chunk at a time, and beyond the window + 128 KiB
+ * the staging buffer wraps and the window slides.  Frames differ from kmp_zstd_compress_batch's
+ * wherever the pre-splitter cuts; up to 128 KiB they are the same.  level 3 (or 0), or 1 with a context created for
+ * slices <= 512 KiB.  out_chunk: size of the caller's output slices if it is not the reference's (0 = max(8192, n / 10)). */
+KMP_API int kmp_zstd_compress_batch_reference(kmp_batch_ctx* ctx,
+                                              const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                              uint32_t n,
+                                              void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
+                                              int level, uint32_t out_chunk, void* hip_stream);
 /* One-shot frames at another compression level: 1 and 2 (libzstd's one-table "fast" strategy) for slices <= 128 KiB;
  * level 1 also as frames of several blocks for slices <= 512 KiB (context created with max_slice_bytes in
  * (128 KiB, 512 KiB]); 3 (or 0) = kmp_zstd_compress_batch.  Frames are the ones libzstd 1.5.7 writes at that level. */

@@ -33,6 +33,7 @@ SIGNATURES = [
     ("kmp_zstd_compress_batch_stream", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_int, _P]),
     ("kmp_zstd_compress_batch_stream_level", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_int, _c.c_int, _P]),
     ("kmp_zstd_compress_batch_level", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_int, _P]),
+    ("kmp_zstd_compress_batch_reference", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_int, _c.c_uint32, _P]),
     ("kmp_zstd_compress_batch_dict", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_char_p, _c.c_uint32, _P]),
     ("kmp_zstd_decompress_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P, _P, _P]),
     ("kmp_zstd_decompress_batch_dict", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P, _P, _P, _c.c_uint32, _P]),

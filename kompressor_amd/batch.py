@@ -68,13 +68,16 @@ class ZstdBatch:
         """Launches of each zstd compress kernel in the last batch."""
         return int(self.lib.kmp_batch_last_chunks(self._h))
 
-    def compress(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, dictionary=None, level=3, streaming=None):
+    def compress(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, dictionary=None, level=3, streaming=None, reference=False):
         """src: uint8 device tensor; in_off int64, in_len int32 device tensors (n each).  dictionary: bytes of a
         raw-content dictionary shared by all slices (host memory; its tables are built once per dictionary).
         level: 3 (default), or 1 / 2 for slices of at most 128 KiB without a dictionary; level 1 also for slices up to
         512 KiB (context created for slice sizes in (128 KiB, 512 KiB]).
         streaming: None = one-shot frames; "data" / "empty" = the frames of slices that arrived through finish = false
         calls, closed by a call with / without data (context created for slices above 128 KiB; levels 3 and 1).
+        reference: the frames ZstdCompressor(level).transform(bytes) returns -- above 128 KiB the reference's output slices
+        make libzstd stage the input in 128 KiB chunks, so they differ from ZSTD_compress2's (the default here) wherever
+        the block pre-splitter cuts (levels 3 and 1, no dictionary); up to 128 KiB both are the same.
         Returns (dst, out_off, out_len): frame i = dst[out_off[i] : out_off[i] + out_len[i]]."""
         n = in_len.numel()
         if dst is None:
@@ -83,7 +86,12 @@ class ZstdBatch:
             out_off = torch.arange(n, dtype=torch.int64, device=self.device) * self.out_stride
         if out_len is None:
             out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
-        if streaming is not None:
+        if reference and streaming is None:
+            if dictionary is not None:
+                raise ValueError("reference=True is served without a dictionary")
+            rc = self.lib.kmp_zstd_compress_batch_reference(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
+                                                            _ptr(dst), _ptr(out_off), _ptr(out_len), level, 0, self._stream())
+        elif streaming is not None:
             rc = self.lib.kmp_zstd_compress_batch_stream_level(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
                                                                _ptr(dst), _ptr(out_off), _ptr(out_len), 1 if streaming == "empty" else 0, level, self._stream())
         elif level not in (0, 3):

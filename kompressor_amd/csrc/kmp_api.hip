@@ -35,24 +35,31 @@ template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match_dict(KDictArgs a) { zstd_match_dict_body<G>(a); }
 // frames of several blocks (slices above 128 KiB): one block of every unfinished slice per launch
 template <int G>
-__global__ __launch_bounds__(64) void k_zstd_match_blk(KMatchArgs a) { zstd_match_body<G, true>(a); }
+__global__ __launch_bounds__(64) void k_zstd_match_blk(KMatchArgs a)
+{
+    zstd_match_body<G, true>(a);
+    a.counter += 1;                          // second work queue: the blocks libzstd parses with the extDict variant
+    zstd_match_ext_body<G>(a);
+}
 __global__ __launch_bounds__(64, 4) void k_zstd_frame(KFrameArgs a) { zstd_frame_body(a); }
 // ... or the whole chain of blocks of a slice by one wave (no host rounds)
 template <int G>
 __global__ __launch_bounds__(64, 3) void k_zstd_big(KBigArgs a) { zstd_big_body<G>(a); }
 template <int G>
 __global__ __launch_bounds__(64, 3) void k_zstd_big_fast(KBigArgs a) { zstd_big_body<G, true>(a); }
-// first block size, repcodes {1,4,8}, no Huffman table; an empty slice is a header and an empty raw block
-__global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 n, KFrameState* fs, u8* dst, const u64* out_off, u32* out_len, u32* remaining, u32 stream)
+// first block size, repcodes {1,4,8}, no Huffman table, a fresh window; an empty slice is a header and an empty raw block
+// chunked: the input is taken in chunks of 128 KiB (KFrameArgs.stream != 0); wd: window descriptor byte of a streaming frame, 0 = one-shot
+__global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 n, KFrameState* fs, u8* dst, const u64* out_off, u32* out_len, u32* remaining, u32 wd, u32 chunked)
 {
     u32 const i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     KFrameState s; u32 const len = in_len[i];
     s.ipos = 0; s.opos = 0; s.blockSize = len < KX_BLOCK_MAX ? len : KX_BLOCK_MAX; s.first = 1;
     s.rep[0] = 1; s.rep[1] = 4; s.rep[2] = 8; s.hufValid = 0; s.hufSel = 0; s.savings = 0;
-    for (int k = 0; k < 6; k++) s.pad[k] = 0;
+    s.lowLimit = 2; s.dictLimit = 2; s.bufPos = 0; s.extBase = 0; s.wflags = 0;
+    s.chunkEnd = (chunked && len > KX_BLOCK_MAX) ? KX_BLOCK_MAX : len;
     fs[i] = s;
-    if (len == 0) { u8* d = dst + out_off[i]; kx_st32(d, 0xFD2FB528u); d[4] = stream ? 0x00 : 0x20; d[5] = (u8)stream; /* the window descriptor byte of a streaming frame, 0 = one-shot */ d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
+    if (len == 0) { u8* d = dst + out_off[i]; kx_st32(d, 0xFD2FB528u); d[4] = wd ? 0x00 : 0x20; d[5] = (u8)wd; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
     else atomicAdd(remaining, 1u);
 }
 __global__ __launch_bounds__(64, 6) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
@@ -168,7 +175,7 @@ static u32 env_u32(const char* name, u32 dflt)
 extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes)
 {
     if (!out || max_slices == 0) { g_last_error = "kmp_batch_create: bad argument"; return KMP_ERR_ARG; }
-    if (max_slice_bytes > KMP_MAX_BIG_SLICE_BYTES) { g_last_error = "kmp_batch_create: slices above 2 MiB are not supported"; return KMP_ERR_CAPACITY; }
+    if (max_slice_bytes > KMP_MAX_BIG_SLICE_BYTES) { g_last_error = "kmp_batch_create: slices above 1 GiB are not supported"; return KMP_ERR_CAPACITY; }
     if (team_lanes == 0) team_lanes = (int)env_u32("KMP_TEAM_LANES", 4);
     if (team_lanes != 2 && team_lanes != 4 && team_lanes != 8 && team_lanes != 16 && team_lanes != 32 && team_lanes != 64) { g_last_error = "team_lanes must be 2, 4, 8, 16, 32 or 64"; return KMP_ERR_ARG; }
     HIP_TRY(hipSetDevice(device));
@@ -318,7 +325,7 @@ extern "C" size_t kmp_zstd_compress_bound(size_t n)
 
 // ---- levels 1 and 2 -------------------------------------------------------------------------------------
 static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy);
+                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct = 0);
 extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int level, void* hip_stream)
 {
@@ -425,20 +432,23 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
 // Slices above 128 KiB: frames of several blocks.  Every round runs the match kernel and the frame kernel over
 // one block of every unfinished slice; block sizes depend on the bytes already produced (ZSTD_optimalBlockSize),
 // so the rounds are sequential and the host only reads back how many frames are still open.
+// stream: KFrameArgs.stream (0 ZSTD_compress2's frames, 1 / 2 streaming frames, 3 the reference's one-shot driver)
 static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy)
+                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct)
 {
+    bool const streaming = stream == 1 || stream == 2;
     const uint32_t* const d_in_len_caller = d_in_len;
     KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
     d_in_len = c->len_ok;
     HIP_TRY(hipMemsetAsync(c->big_tables, 0, (size_t)n * KX_BIG_TBL_ENTRIES * sizeof(u32), st));
     HIP_TRY(hipMemsetAsync(c->remaining, 0, 4, st));
-    hipLaunchKernelGGL(k_zstd_frame_init, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, c->fstate, (u8*)d_dst, d_out_off, d_out_len, c->remaining, stream ? (strategy ? 0x48u : 0x58u) : 0u);
+    hipLaunchKernelGGL(k_zstd_frame_init, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, c->fstate, (u8*)d_dst, d_out_off, d_out_len, c->remaining, streaming ? (strategy ? 0x48u : 0x58u) : 0u, stream != 0 ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     KMatchArgs m;
     m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
     m.seqs = c->seqs; m.seq_cap = c->seq_cap; m.meta = c->meta; m.lits = c->lits; m.lit_cap = c->lit_cap;
-    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter; m.flags = 2u | (stream ? 8u : 0u);
+    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter;
+    m.flags = 2u | (streaming ? 8u : 0u) | (c->max_slice_bytes >= KX_BLK_WIDE_FROM ? 16u : 0u);
     m.fstate = c->fstate; m.big_tables = c->big_tables;
     KFrameArgs e;
     e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = d_in_len; e.n_slices = n;
@@ -446,6 +456,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     e.scratch = c->scratch; e.scratch_words = c->scratch_words;
     e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
     e.fstate = c->fstate; e.hufct = c->hufct; e.remaining = c->remaining; e.stream = stream; e.strategy = strategy;
+    e.tail_direct = stream == 3 ? 0u : tail_direct; e.out_chunk = stream == 3 ? tail_direct : 0u;      // (one parameter: the mode says which it is)
     if (strategy || c->knob.big_rounds == 0) {
         // one wave per slice walks its chain of blocks
         // few slices: one per wave (most waves); many: up to 64 / G per wave so that all of them are in flight
@@ -489,8 +500,8 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
         HIP_TRY(hipMemcpyAsync(&left, c->remaining, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (left == 0) break;
-        if (++rounds > KMP_MAX_BIG_SLICE_BYTES / 8192u + 2u) { g_last_error = "kmp_zstd_compress_batch: block rounds did not finish"; return KMP_ERR_KERNEL; }
-        HIP_TRY(hipMemsetAsync(c->counter, 0, 4, st));
+        if (++rounds > KMP_MAX_BIG_SLICE_BYTES / 64u) { g_last_error = "kmp_zstd_compress_batch: block rounds did not finish"; return KMP_ERR_KERNEL; }
+        HIP_TRY(hipMemsetAsync(c->counter, 0, 8, st));
         switch (bigR) {
         case 2:  hipLaunchKernelGGL(k_zstd_match_blk<2>, dim3(blocks), dim3(64), 0, st, m); break;
         case 4:  hipLaunchKernelGGL(k_zstd_match_blk<4>, dim3(blocks), dim3(64), 0, st, m); break;
@@ -527,6 +538,22 @@ extern "C" int kmp_zstd_compress_batch_stream_level(kmp_batch_ctx* c, const void
     if (n == 0) return KMP_OK;
     HIP_TRY(hipSetDevice(c->device));
     return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, empty_end ? 2u : 1u, level == 1 ? 1u : 0u);
+}
+/* What ZstdCompressor(level).transform(ByteArray) returns: above 128 KiB libzstd stages the input in chunks of 128 KiB
+ * because the reference's output slices are smaller than ZSTD_compressBound (include/kompressor_hip.h). */
+extern "C" int kmp_zstd_compress_batch_reference(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                                 uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int level, uint32_t out_chunk, void* hip_stream)
+{
+    if (level == 0) level = 3;
+    if (!c) { g_last_error = "kmp_zstd_compress_batch_reference: null argument"; return KMP_ERR_ARG; }
+    if (!c->big) return kmp_zstd_compress_batch_level(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, level, hip_stream);   // one block: one chunk
+    if (level != 1 && level != 3) { g_last_error = "kmp_zstd_compress_batch_reference: above 128 KiB levels 1 and 3 are served"; return KMP_ERR_ARG; }
+    if (level == 1 && c->max_slice_bytes > (512u << 10)) { g_last_error = "kmp_zstd_compress_batch_reference: level 1 up to 512 KiB (context max_slice_bytes <= 512 KiB)"; return KMP_ERR_CAPACITY; }
+    if (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len)) { g_last_error = "kmp_zstd_compress_batch_reference: null argument"; return KMP_ERR_ARG; }
+    if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_reference: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
+    if (n == 0) return KMP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, 3u, level == 1 ? 1u : 0u, out_chunk);
 }
 /* block rounds of the last batch of a context for slices above 128 KiB */
 extern "C" int kmp_batch_last_rounds(kmp_batch_ctx* c) { return c ? (int)c->last_rounds : 0; }
@@ -819,7 +846,9 @@ static size_t stream_dev_init(stream_dev& s, size_t bytes = 0, u32 exact = 0)
     if (s.batch && exact && s.tier == exact) return 0;
     if (s.batch && !exact && bytes + 1024 <= s.in_cap) return 0;
     if (s.batch) stream_dev_free(s);
-    u32 const tier = exact ? exact : (bytes + 1024 <= KMP_MAX_SLICE_BYTES + 1024) ? KMP_MAX_SLICE_BYTES : KMP_MAX_BIG_SLICE_BYTES;
+    // 128 KiB, 2 MiB, then the next power of two that holds the slice
+    u32 tier = exact ? exact : (bytes <= KMP_MAX_SLICE_BYTES) ? KMP_MAX_SLICE_BYTES : (2u << 20);
+    while (!exact && (size_t)tier < bytes && tier < KMP_MAX_BIG_SLICE_BYTES) tier <<= 1;
     s.tier = tier;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return KERRC(ZE_GENERIC);          // the caller's current device, as a libzstd context lives where its caller runs
@@ -873,11 +902,20 @@ extern "C" size_t kmp_zstd_cctx_load_dictionary(kmp_zstd_cctx* c, const void* di
     return 0;
 }
 
-static size_t run_single_compress(kmp_zstd_cctx* c)
+// first_room: room in the output slice of the call that closed the stream; end_avail: the bytes that call brought
+static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t end_avail)
 {
     size_t const n = c->in.size();
     if (n > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
     bool const streaming = c->fed_continue > 0;          // data arrived with finish = false: libzstd did not know the size
+    // libzstd compresses the caller's memory in place when its staging buffer is empty and the output slice has room for
+    // ZSTD_compressBound of what the call brought; otherwise it stages the input in chunks of 128 KiB (kmp_zstd_compress_batch_reference)
+    bool const in_place = first_room >= kmp_zstd_compress_bound(end_avail);
+    u32 tail_direct = 0;
+    if (streaming && in_place && end_avail != 0) {
+        size_t const lap = 17u * (size_t)KX_BLOCK_MAX;                  // level-3 stream: window 2 MiB + one block
+        if (c->level == 3 && (n - end_avail) % lap == 0) tail_direct = (u32)end_avail;
+    }
     if (streaming && (c->level == 2 || !c->dict.empty())) return KERRC(ZE_parameter_unsupported);
     bool const l1big = c->level == 1 && (streaming || n > KMP_MAX_SLICE_BYTES);      // level 1, frame of several blocks / stream
     if (l1big && n > (512u << 10)) return KERRC(ZE_parameter_unsupported);             // beyond its window: CPU library
@@ -889,7 +927,14 @@ static size_t run_single_compress(kmp_zstd_cctx* c)
     if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (streaming) {
+        if (tail_direct) {
+            if (zstd_compress_big(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, nullptr, 1u, 0u, tail_direct) != KMP_OK) return KERRC(ZE_GENERIC);
+        } else
         if (kmp_zstd_compress_batch_stream_level(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->end_was_empty, c->level, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
+    } else
+    if (n > KMP_MAX_SLICE_BYTES && !in_place && c->dict.empty() && (c->level == 3 || l1big)) {
+        // the reference's one-shot driver above 128 KiB: staged input
+        if (kmp_zstd_compress_batch_reference(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->level, (u32)first_room, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
     } else
     if (c->level != 3) {
         if ((n > KMP_MAX_SLICE_BYTES && !l1big) || !c->dict.empty()) return KERRC(ZE_parameter_unsupported);   // level 2: one block; no dictionary
@@ -923,7 +968,7 @@ extern "C" size_t kmp_zstd_compress_stream(kmp_zstd_cctx* c, void* dst, size_t d
         if (c->in.size() > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
         if (end_op != KMP_ZSTD_e_end) { c->fed_continue += avail; return 0; }
         c->end_was_empty = avail == 0;
-        size_t const e = run_single_compress(c);
+        size_t const e = run_single_compress(c, dst_size - *dst_pos, avail);
         if (e) return e;
         c->stage = 1; c->out_pos = 0;
     } else if (*src_pos != src_size) {
@@ -1123,7 +1168,7 @@ extern "C" size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* d, void* dst, size_t
     if (d->stage == 0) {
         // take input until one whole frame is buffered
         size_t content = (size_t)-1;
-        // the largest frame this path stages: 2 MiB of content, whose frame is at most that + 1/128 + block headers
+        // the largest frame this path stages: 1 GiB of content, whose frame is at most that + 1/128 + block headers
         size_t const frame_max = (size_t)KMP_MAX_BIG_SLICE_BYTES + (KMP_MAX_BIG_SLICE_BYTES >> 7) + 1024;
         {   // take what is offered (never more than one largest frame beyond what is buffered), then hand back what lies beyond the frame's end
             size_t avail = src_size - *src_pos;
@@ -1138,24 +1183,29 @@ extern "C" size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* d, void* dst, size_t
         if (content != (size_t)-1 && content > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_frameParameter_unsupported);
         if (total && total < d->in.size()) { *src_pos -= d->in.size() - total; d->in.resize(total); }
         if (total == 0) return d->in.size() >= frame_max ? KERRC(ZE_frameParameter_unsupported) : 3;      // hint: more input expected
-        {
-            // frames of up to 2 MiB of content (content size unknown: the staging tier decides)
-            // no content size in the header (streaming frames): stage for the largest content served
-            size_t const want = content == (size_t)-1 ? (size_t)KMP_MAX_BIG_SLICE_BYTES : (content > d->in.size() ? content : d->in.size());
-            if (want > frame_max) return KERRC(ZE_frameParameter_unsupported);
+        if (!d->d_status && hipMalloc((void**)&d->d_status, 64) != hipSuccess) return KERRC(ZE_memory_allocation);
+        u32 res[2] = { 0, 0 };
+        // content size in the header: staged for exactly that; none (streaming frames): for 4 x the frame (2 MiB at least),
+        // and again for 4 x as much while the decoder answers "destination too small", up to the 1 GiB served here
+        size_t want = content != (size_t)-1 ? (content > d->in.size() ? content : d->in.size())
+                                            : (4 * total > (size_t)(2u << 20) ? 4 * total : (size_t)(2u << 20));
+        for (;;) {
+            if (want > KMP_MAX_BIG_SLICE_BYTES) want = KMP_MAX_BIG_SLICE_BYTES;
             if (!stream_dev_select(d->dev)) return KERRC(ZE_GENERIC);
-            size_t const e = stream_dev_init(d->dev, want); if (e) return e;
+            { size_t const e = stream_dev_init(d->dev, want > total ? want : total); if (e) return e; }
+            stream_dev& s = d->dev;
+            if (total > s.in_cap) return KERRC(ZE_frameParameter_unsupported);
+            u64 offs[2] = { 0, 0 }; u32 lens[2] = { (u32)total, (u32)s.out_cap };
+            if (hipMemcpy(s.d_in, d->in.data(), total, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+            if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+            if (hipMemcpy(s.d_len, lens, sizeof(lens), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
+            if (kmp_zstd_decompress_batch_dict(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1,
+                                               d->d_status, d->d_status + 1, d->d_dict, (u32)d->dict.size(), nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
+            if (hipMemcpy(res, d->d_status, 8, hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
+            if (res[1] == (u32)ZE_dstSize_tooSmall && content == (size_t)-1 && want < KMP_MAX_BIG_SLICE_BYTES) { want *= 4; continue; }
+            break;
         }
         stream_dev& s = d->dev;
-        if (total > s.in_cap) return KERRC(ZE_frameParameter_unsupported);
-        if (!d->d_status && hipMalloc((void**)&d->d_status, 64) != hipSuccess) return KERRC(ZE_memory_allocation);
-        u64 offs[2] = { 0, 0 }; u32 lens[2] = { (u32)total, (u32)s.out_cap }; u32 res[2] = { 0, 0 };
-        if (hipMemcpy(s.d_in, d->in.data(), total, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
-        if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
-        if (hipMemcpy(s.d_len, lens, sizeof(lens), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
-        if (kmp_zstd_decompress_batch_dict(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1,
-                                           d->d_status, d->d_status + 1, d->d_dict, (u32)d->dict.size(), nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
-        if (hipMemcpy(res, d->d_status, 8, hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
         if (res[1]) return KERRC(res[1]);
         d->out.resize(res[0]);
         if (res[0] && hipMemcpy(d->out.data(), s.d_out, res[0], hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);

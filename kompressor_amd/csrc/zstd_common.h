@@ -42,7 +42,8 @@ struct KSliceMeta {
 // ---- frames of several blocks (slices above 128 KiB, up to KX_MAX_BIG_SLICE) -------------------------
 // The slice is compressed block by block; what libzstd carries from one block of a frame to the next
 // (ZSTD_compressedBlockState_t, window, hash tables) lives in HBM between the rounds.
-#define KX_MAX_BIG_SLICE (2u << 20)          /* the window (<= 2 MiB at level 3) never slides */
+#define KX_MAX_BIG_SLICE (1u << 30)          /* level 3; beyond the window (2 MiB) it slides as libzstd's does (KFrameState) */
+#define KX_BLK_WIDE_FROM ((4u << 20) - 64u)  /* slices from this size on: table entries are plain 32-bit indices (no check bits) */
 #define KX_BLOCK_MAX (128u * 1024u)
 #define KX_BIG_TBL_LONG  (1u << 17)
 #define KX_BIG_TBL_SHORT (1u << 16)
@@ -56,8 +57,34 @@ struct KFrameState {
     u32 hufValid;      // a Huffman table of an earlier block exists (HUF_repeat_check)
     u32 hufSel;        // which of the two table slots holds it
     int savings;       // input bytes - frame bytes of the blocks so far (ZSTD_compress_frameChunk)
-    u32 pad[6];
+    // libzstd's window as it stands for the next block (indices = stream position + 2; ZSTD_window_t after
+    // ZSTD_window_update for the block's chunk and ZSTD_window_enforceMaxDist for the block) ...
+    u32 lowLimit, dictLimit;
+    // ... and where libzstd's staging buffer stands (the buffered frames: input taken in chunks of 128 KiB into a buffer of
+    // window + 128 KiB bytes that wraps; the lap before the current one is the "extDict" segment)
+    u32 bufPos;        // offset of the current chunk in the staging buffer
+    u32 extBase;       // stream position that sat at offset 0 of the buffer during the previous lap
+    u32 chunkEnd;      // end of the current chunk (stream position)
+    u32 wflags;        // 1: an older segment exists; 2: the rest of the input is compressed in place (one chunk, new segment)
 };
+
+// How one block sees the window: ext = libzstd parses it with the extDict variant of the double-fast loop, the older
+// segment being [dictStartIndex, prefixStartIndex); else the regular variant, whose lowest valid index follows from
+// dictLimit and maxDist (ZSTD_getLowestPrefixIndex).
+struct KBlockWin { u32 ext, dictStartIndex, prefixStartIndex, dictLimit, maxDist; };
+KX_DEV KBlockWin kx_block_window(u32 lowLimit, u32 dictLimit, u32 ipos, u32 blockSize, u32 windowLog)
+{
+    KBlockWin w; w.ext = 0; w.dictStartIndex = 0; w.prefixStartIndex = 0; w.dictLimit = dictLimit; w.maxDist = 1u << windowLog;
+    if (lowLimit < dictLimit) {                                 // ZSTD_window_hasExtDict
+        u32 const endIdx = ipos + blockSize + 2u;
+        u32 const low = (endIdx - lowLimit > w.maxDist) ? endIdx - w.maxDist : lowLimit;      // ZSTD_getLowestMatchIndex
+        u32 const ps = dictLimit > low ? dictLimit : low;
+        if (ps != low) { w.ext = 1; w.dictStartIndex = low; w.prefixStartIndex = ps; }
+    }
+    return w;
+}
+// max(dictLimit, curr - maxDist): ZSTD_getLowestPrefixIndex
+KX_DEV u32 kx_lowest_prefix(u32 curr, u32 dictLimit, u32 maxDist) { return (curr - dictLimit > maxDist) ? curr - maxDist : dictLimit; }
 
 // level-3 parameters of a one-shot slice of n bytes: what ZSTD_getCParams(3, n, 0) yields after size adjustment.
 struct KParams { u32 windowLog, chainLog, hashLog, minMatch; };
@@ -79,8 +106,23 @@ KX_DEV KParams kx_params_l3(u32 n)
 
 KX_DEV u32 kx_frame_header_size(u32 n)
 {
-    // magic(4) + FHD(1) + FCS; single-segment always holds (windowSize >= n)
-    return 5 + ((n < 256) ? 1 : (n < 65536 + 256) ? 2 : 4);
+    // magic(4) + FHD(1) + FCS; single segment while the window (2 MiB at most, level 3) covers the content, else a window
+    // descriptor byte as well
+    return 5 + ((n < 256) ? 1 : (n < 65536 + 256) ? 2 : 4) + (n > (2u << 20) ? 1u : 0u);
+}
+// frame header of a one-shot level-3 frame (content size known): returns its size
+KX_DEV u32 kx_write_frame_header(u8* dst, u32 n)
+{
+    u32 const fcsCode = (n >= 256) + (n >= 65536 + 256);
+    bool const single = n <= (2u << 20);
+    kx_st32(dst, 0xFD2FB528u);
+    dst[4] = (u8)((single ? 1u << 5 : 0u) + (fcsCode << 6));
+    u32 p = 5;
+    if (!single) dst[p++] = (u8)((21 - 10) << 3);
+    if (fcsCode == 0) dst[p++] = (u8)n;
+    else if (fcsCode == 1) { kx_st16(dst + p, n - 256); p += 2; }
+    else { kx_st32(dst + p, n); p += 4; }
+    return p;
 }
 
 // 64-bit multiplicative hashes, top bits. Written with 32-bit pieces: only the

@@ -17,6 +17,7 @@
 #pragma once
 #include "zstd_common.h"
 #include "zstd_match.h"
+#include "zstd_match_ext.h"
 #include "zstd_match_fast.h"
 
 struct KEntropyArgs {
@@ -1044,10 +1045,68 @@ struct KFrameArgs {
     KFrameState* fstate; u32* hufct;         // per slice: state, two Huffman table slots of 256 words
     u32* remaining;                          // frames not finished yet (decremented here)
     u32 strategy;                            // 0: level 3 (double-fast); 1: level 1 (fast): other pre-splitter, other encoding-type constant, window 2^19
-    u32 stream;                              // 0: one-shot frames (size known); 1: streaming frames (finish = false ... finish = true:
+    u32 stream;                              // 0: one-shot frames as ZSTD_compress2 writes them into a bound-sized buffer (size known, the
+                                             // caller's array compressed in place); 1: streaming frames (finish = false ... finish = true:
                                              // no content size, window 2^21, input taken in chunks of 128 KiB); 2: same, and the
-                                             // closing call brought no data (an empty last block closes a frame that ends on a chunk boundary)
+                                             // closing call brought no data (an empty last block closes a frame that ends on a chunk boundary);
+                                             // 3: one-shot frames as the reference's driver gets them (SliceTransform.kt:33-56: output slices of
+                                             // max(8192, n / 10) bytes, below ZSTD_compressBound: size known, input staged in chunks of 128 KiB)
+    u32 tail_direct;                         // streams: bytes the closing call brought onto an empty staging buffer with room for
+                                             // their bound in its output slice (compressed in place as one chunk); else 0
+    u32 out_chunk;                           // stream == 3: size of the driver's output slices; 0 = the reference's max(8192, n / 10)
 };
+
+// The block before fs.ipos is out: libzstd's staging buffer and window move on to the block that starts there
+// (ZSTD_compressStream_generic's buffered path, ZSTD_window_update per chunk, ZSTD_window_enforceMaxDist per block;
+// restated on the CPU in oracle/zstd_l3_ref.c, kref_zstd_l3_compress_buffered).  Returns what is left of the chunk: the
+// input the pre-splitter may look at.  fs.ipos < n.
+KX_DEV u32 kx_frame_window_step(KFrameState& fs, u32 n, u32 mode, u32 windowLog, u32 tailDirect, u32 outChunkArg)
+{
+    u32 const maxDist = 1u << windowLog;
+    if (mode != 0 && fs.ipos == fs.chunkEnd) {
+        // a chunk of 128 KiB is done; the next one goes behind it in the staging buffer (window + 128 KiB bytes, the window
+        // being the content size when that is known and smaller) or, when it would not fit, to the buffer's start
+        u32 const windowSize = (mode == 3 && n < maxDist) ? n : maxDist;
+        u32 const inBuffSize = windowSize + (KX_BLOCK_MAX < windowSize ? KX_BLOCK_MAX : windowSize);
+        fs.bufPos += KX_BLOCK_MAX;
+        if (fs.bufPos + KX_BLOCK_MAX > inBuffSize) { fs.extBase = fs.ipos - fs.bufPos; fs.bufPos = 0; }
+        bool tail = false;
+        if (fs.bufPos == 0) {
+            // empty staging buffer: if the current output slice has room for the bound of everything still to come,
+            // libzstd compresses that rest where it lies (ZSTD_compressEnd), as one chunk
+            if (mode == 3) {
+                u32 const outChunk = outChunkArg ? outChunkArg : (n / 10u > 8192u ? n / 10u : 8192u);     // SliceTransform.kt:47-56
+                u32 const room = outChunk - fs.opos % outChunk, r = n - fs.ipos;       // every earlier call filled its slice
+                tail = room >= r + (r >> 8) + (r < KX_BLOCK_MAX ? (KX_BLOCK_MAX - r) >> 11 : 0u);
+            } else tail = tailDirect != 0 && fs.ipos + tailDirect == n;
+        }
+        fs.chunkEnd = (!tail && fs.ipos + KX_BLOCK_MAX < n) ? fs.ipos + KX_BLOCK_MAX : n;
+        if (tail) fs.wflags |= 2u;
+        // ZSTD_window_update: a chunk that does not follow its predecessor in memory starts a new segment ...
+        if (fs.bufPos == 0) {
+            fs.lowLimit = fs.dictLimit; fs.dictLimit = fs.ipos + 2u;
+            if (fs.dictLimit - fs.lowLimit < 8u) fs.lowLimit = fs.dictLimit;
+            fs.wflags |= 1u;
+        }
+        // ... and the front of the older segment that the chunk overwrites in the buffer is given up
+        if ((fs.wflags & 1u) && !tail) {
+            u32 const chunkLen = fs.chunkEnd - fs.ipos;
+            u32 const extLo = (fs.lowLimit - 2u) - fs.extBase, extHi = (fs.dictLimit - 2u) - fs.extBase;
+            if (fs.bufPos + chunkLen > extLo && fs.bufPos < extHi) {
+                u32 const high = fs.extBase + fs.bufPos + chunkLen + 2u;
+                fs.lowLimit = high > fs.dictLimit ? fs.dictLimit : high;
+            }
+        }
+    }
+    // ZSTD_window_enforceMaxDist(window, block start, maxDist)
+    u32 const startIdx = fs.ipos + 2u;
+    if (startIdx > maxDist) {
+        u32 const newLow = startIdx - maxDist;
+        if (fs.lowLimit < newLow) fs.lowLimit = newLow;
+        if (fs.dictLimit < fs.lowLimit) fs.dictLimit = fs.lowLimit;
+    }
+    return fs.chunkEnd - fs.ipos;
+}
 
 // ZSTD_splitBlock_byChunks(level 0) on the 128 KiB at p: where the byte statistics change, in steps of 8 KiB.
 // Uses lds.hist (new chunk) and lds.ct (chunks so far).
@@ -1113,21 +1172,15 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
     u32 const n = a.in_len[slice];
     u8* const dst = a.dst + a.out_off[slice];
     u32* const hufct = a.hufct + (size_t)slice * 512u;
+    bool const streaming = a.stream == 1 || a.stream == 2;       // size unknown when the frame starts
     bool const emptyEnd = a.stream == 2 && (n % KX_BLOCK_MAX) == 0;
-    if (fs.ipos == 0 && a.stream) {
+    if (fs.ipos == 0 && streaming) {
         // streaming frame header: no content size, window descriptor for 2^21
         if (lane == 0) { kx_st32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)(((a.strategy ? 19 : 21) - 10) << 3); }
         fs.opos = 6;
     } else if (fs.ipos == 0) {
-        // frame header: single segment (the window covers the slice), content size
-        if (lane == 0) {
-            u32 const fcsCode = (n >= 256) + (n >= 65536 + 256);
-            kx_st32(dst, 0xFD2FB528u);
-            dst[4] = (u8)((1u << 5) + (fcsCode << 6));
-            if (fcsCode == 0) dst[5] = (u8)n;
-            else if (fcsCode == 1) kx_st16(dst + 5, n - 256);
-            else kx_st32(dst + 5, n);
-        }
+        // frame header: content size; single segment while the window covers the slice
+        if (lane == 0) kx_write_frame_header(dst, n);
         fs.opos = kx_frame_header_size(n);
     }
     u32 const bs = fs.blockSize;
@@ -1178,13 +1231,14 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
     }
     fs.savings += (int)bs - (int)outSize;
     fs.ipos += bs; fs.opos += outSize; fs.first = 0;
-    // ZSTD_optimalBlockSize for the next block (a stream is compressed in chunks of 128 KiB of input; the frame header
-    // counts as produced from the second chunk on)
+    // ZSTD_optimalBlockSize for the next block (staged input is compressed in chunks of 128 KiB; the frame header counts
+    // as produced from the second chunk on)
     u32 next = 0;
-    if (a.stream && fs.ipos == KX_BLOCK_MAX) fs.savings -= 6;
+    if (a.stream && fs.ipos == KX_BLOCK_MAX) fs.savings -= streaming ? 6 : (int)kx_frame_header_size(n);
     if (fs.ipos < n) {
-        u32 remaining = n - fs.ipos;
-        if (a.stream) { u32 const chunkEnd = (fs.ipos / KX_BLOCK_MAX + 1u) * KX_BLOCK_MAX; if (chunkEnd < n) remaining = chunkEnd - fs.ipos; }
+        // (level 1 is served up to its window: nothing slides there)
+        u32 const windowLog = a.strategy ? 30u : (streaming ? 21u : kx_params_l3(n).windowLog);
+        u32 const remaining = kx_frame_window_step(fs, n, a.stream, windowLog, a.tail_direct, a.out_chunk);
         if (remaining < KX_BLOCK_MAX) next = remaining;
         else if (fs.savings < 3) next = KX_BLOCK_MAX;
         else next = a.strategy ? kx_split_block_borders(lds, src + fs.ipos, lane) : kx_split_block(lds, src + fs.ipos, lane);
@@ -1231,14 +1285,28 @@ KX_DEV void zstd_big_body(const KBigArgs& a)
         m.seqs += (size_t)base * m.seq_cap; m.lits += (size_t)base * m.lit_cap; m.meta += base; m.fstate += base;
         m.big_tables += (size_t)base * KX_BIG_TBL_ENTRIES;
         m.counter = a.counters + kx_block();
-        for (u32 guard = 0; guard < KX_MAX_BIG_SLICE / 8192u + 4u; guard++) {
+        for (u32 guard = 0; guard < KX_MAX_BIG_SLICE / 64u; guard++) {         // (a block is at least 8 KiB unless it ends a chunk)
             bool open = false;
             for (u32 t = 0; t < cnt; t++) open |= a.e.fstate[base + t].blockSize != 0;
             if (!open) break;
             if (lane == 0) *m.counter = 0;
             kx_sync();
             if (FAST) { KFastArgs fa; fa.m = m; fa.level = 1; zstd_match_fast_body<G, true>(fa); }
-            else zstd_match_body<G, true>(m);
+            else {
+                zstd_match_body<G, true>(m);
+                // blocks behind a wrap of libzstd's staging buffer: the extDict variant of the parse
+                bool ext = false;
+                for (u32 t = 0; t < cnt; t++) {
+                    KFrameState const& f = a.e.fstate[base + t];
+                    if (f.blockSize != 0 && f.lowLimit < f.dictLimit) ext = true;
+                }
+                if (ext) {
+                    kx_sync();
+                    if (lane == 0) *m.counter = 0;
+                    kx_sync();
+                    zstd_match_ext_body<G>(m);
+                }
+            }
             kx_sync();
             for (u32 t = 0; t < cnt; t++) { zstd_frame_block(a.e, lds, base + t, lane); kx_sync(); }
         }

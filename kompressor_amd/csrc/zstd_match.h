@@ -32,7 +32,8 @@ struct KMatchArgs {
     u32* counter;                    // work queue head (zeroed by the host)
     u32 flags;                       // 1 = non-temporal table loads, 2 = non-temporal table stores (the default),
                                      // 4 = copy no literals (the entropy kernel gathers them; A/B switch),
-                                     // 8 = block mode with the parameters of a stream of unknown size
+                                     // 8 = block mode with the parameters of a stream of unknown size,
+                                     // 16 = block mode, slices of 4 MiB and more: table entries are plain 32-bit indices
     // block mode (frames of several blocks): one block of every unfinished slice per launch
     const KFrameState* fstate;       // per slice
     u32* big_tables;                 // per slice: KX_BIG_TBL_ENTRIES
@@ -118,10 +119,13 @@ template <int G, bool BLK = false>
 KX_DEV void zstd_match_body(const KMatchArgs& a)
 {
     constexpr int NT = 64 / G;
-    constexpr u32 IDXM = BLK ? KX_BLK_IDX_MASK : KX_IDX_MASK;
+    bool const wide = BLK && (a.flags & 16u);               // entries without check bits (indices need all 32 bits)
+    u32 const IDXM = BLK ? (wide ? 0xFFFFFFFFu : KX_BLK_IDX_MASK) : KX_IDX_MASK;
     constexpr u32 TAGM = BLK ? 0u : KX_TAG_MASK;            // block mode: no epoch (tag stays 0)
     constexpr u32 CHKS = BLK ? KX_BLK_IDX_BITS : KX_CHK_SHIFT;
-    constexpr u32 CHKM = BLK ? KX_BLK_CHK_MASK : KX_CHK_MASK;
+    u32 const CHKM = BLK ? (wide ? 0u : KX_BLK_CHK_MASK) : KX_CHK_MASK;
+    // lowest valid index (position + 2) of the running block: 2 unless the window has slid (block mode, long slices)
+    u32 lowIdx = 2u;
     int const lane = kx_lane();
     int const k = lane & (G - 1);
     int const tbase = lane - k;
@@ -162,22 +166,29 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 if (s >= a.n_slices) state = KST_DONE;
                 else if (BLK) {
                     KFrameState const fs = a.fstate[s];
-                    if (fs.blockSize != 0) {           // else: frame finished, fetch the next slice
+                    KParams P0 = kx_params_l3(a.in_len[s]);
+                    if (a.flags & 8u) { P0.windowLog = 21; P0.chainLog = 16; P0.hashLog = 17; P0.minMatch = 5; }   // streaming frame: size unknown when it starts
+                    KBlockWin const bw = kx_block_window(fs.lowLimit, fs.dictLimit, fs.ipos, fs.blockSize, P0.windowLog);
+                    // (a block that libzstd parses with the extDict variant is left to zstd_match_ext_body)
+                    if (fs.blockSize != 0 && !bw.ext) {           // else: frame finished, fetch the next slice
                         slice = s;
                         src = a.src + a.in_off[s];
                         seqs = a.seqs + (size_t)s * a.seq_cap; lits = a.lits + (size_t)s * a.lit_cap;
                         L = a.big_tables + (size_t)s * KX_BIG_TBL_ENTRIES; S = L + KX_BIG_TBL_LONG;
-                        KParams P = kx_params_l3(a.in_len[s]);
-                        if (a.flags & 8u) { P.windowLog = 21; P.chainLog = 16; P.hashLog = 17; P.minMatch = 5; }   // streaming frame: size unknown when it starts
+                        KParams const P = P0;
                         hbL = P.hashLog; hbS = P.chainLog; mls = P.minMatch;
                         nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = 0; tag = 0;
                         bstart = (int)fs.ipos; n = bstart + (int)fs.blockSize;       // n = end of the block
                         anchor = bstart; ilimit = n - 8;
-                        ip = bstart + (bstart == 0 ? 1 : 0);
-                        // repcodes longer than the history so far are set aside (ZSTD_compressBlock_doubleFast: offsetSaved)
+                        // candidates: valid from ZSTD_getLowestPrefixIndex at the block's END on ...
+                        lowIdx = kx_lowest_prefix((u32)n + 2u, bw.dictLimit, bw.maxDist);
+                        ip = bstart + ((u32)bstart + 2u == lowIdx ? 1 : 0);
+                        // ... repcodes longer than the history (at the first searched position) are set aside
+                        // (ZSTD_compressBlock_doubleFast: offsetSaved)
                         off1 = fs.rep[0]; off2 = fs.rep[1]; saved1 = 0; saved2 = 0;
-                        if (off2 > (u32)ip) { saved2 = off2; off2 = 0; }
-                        if (off1 > (u32)ip) { saved1 = off1; off1 = 0; }
+                        u32 const maxRep = ((u32)ip + 2u) - kx_lowest_prefix((u32)ip + 2u, bw.dictLimit, bw.maxDist);
+                        if (off2 > maxRep) { saved2 = off2; off2 = 0; }
+                        if (off1 > maxRep) { saved1 = off1; off1 = 0; }
                         step = 1; nextStep = ip + 256; carry = false;
                         state = (fs.blockSize < 8 || ip + 1 > ilimit) ? KST_CLEANUP : KST_SEARCH;
                     }
@@ -213,8 +224,8 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     if (k == 0) {
                         u64 const w = kx_ld64(src + ip);
                         u32 const v = tag | (u32)(ip + 2);
-                        S[kx_hash_short(w, hbS, mls)] = v | (kx_chk_short(w) << CHKS);
-                        L[kx_hash_long(w, hbL)] = v | (kx_chk_long(w, hbL) << CHKS);
+                        S[kx_hash_short(w, hbS, mls)] = v | (wide ? 0u : kx_chk_short(w) << CHKS);
+                        L[kx_hash_long(w, hbL)] = v | (wide ? 0u : kx_chk_long(w, hbL) << CHKS);
                     }
                     m_type = KMT_REP0; m_pos = ip; m_start = ip; m_mpos = ip - (int)off2; m_len0 = 4;
                     state = KST_MATCH;
@@ -244,7 +255,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             u32 idxs = ((es & TAGM) == tag) ? (es & IDXM) : 0u;
             u32 ckl = 0, cks = 0;                    // this position's check bits (also stored with its inserts)
             {
-                ckl = kx_chk_long(w, hbL) << CHKS; cks = kx_chk_short(w) << CHKS;
+                ckl = wide ? 0u : kx_chk_long(w, hbL) << CHKS; cks = wide ? 0u : kx_chk_short(w) << CHKS;
                 // an entry with other check bits cannot pass the 8- / 4-byte compare: no candidate, no source line fetched
                 if ((el & CHKM) != ckl) idxl = 0;
                 if ((es & CHKM) != cks) idxs = 0;
@@ -272,14 +283,14 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             bool repHit = false, longHit = false, shortHit = false;
             if (cand) {
                 int const pr = (off1 > 0) ? pos + 1 - (int)off1 : pos;
-                int const pl = (idxl >= 2) ? (int)idxl - 2 : pos;
-                int const ps = (idxs >= 2) ? (int)idxs - 2 : pos;
+                int const pl = (idxl >= lowIdx) ? (int)idxl - 2 : pos;
+                int const ps = (idxs >= lowIdx) ? (int)idxs - 2 : pos;
                 u32 const vr = kx_ld32(src + pr);
                 u64 const vl = kx_ld64(src + pl);
                 u32 const vs = kx_ld32(src + ps);
                 repHit = (off1 > 0) && vr == (u32)(w >> 8);
-                longHit = (idxl >= 2) && vl == w;
-                shortHit = (idxs >= 2) && vs == (u32)w;
+                longHit = (idxl >= lowIdx) && vl == w;
+                shortHit = (idxs >= lowIdx) && vs == (u32)w;
             }
             bool const hit = repHit | longHit | shortHit;
             u64 const th = (kx_ballot(hit) >> tbase) & tmask;
@@ -335,7 +346,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                         else { m_start = m_pos; m_mpos = (int)b_idxs - 2; m_len0 = 4; }
                         m_off = (u32)(m_start - m_mpos);
                         m_idxl1 = n_idxl; m_w1 = (u64)n_wlo | ((u64)n_whi << 32);
-                        if (step < 4 && k == 0) L[n_hl] = tag | (u32)(m_pos + step + 2) | (kx_chk_long(m_w1, hbL) << CHKS);
+                        if (step < 4 && k == 0) L[n_hl] = tag | (u32)(m_pos + step + 2) | (wide ? 0u : kx_chk_long(m_w1, hbL) << CHKS);
                     }
                     carry = false;
                     state = KST_MATCH;
@@ -347,7 +358,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
         if (kx_any(state == KST_MATCH)) {
             bool const mt = state == KST_MATCH;
             bool l1ok = false; int s1 = 0, m1 = 0;
-            if (mt && m_type == KMT_SHORT && m_idxl1 > 2) {
+            if (mt && m_type == KMT_SHORT && m_idxl1 > lowIdx) {
                 m1 = (int)m_idxl1 - 2; s1 = m_pos + step;
                 l1ok = kx_ld64(src + m1) == m_w1;
             }
@@ -357,7 +368,8 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 if (l1ok && lenB > lenA) { m_start = s1; m_mpos = m1; lenA = lenB; m_off = (u32)(s1 - m1); }
             }
             bool const bw = mt && (m_type == KMT_LONG || m_type == KMT_SHORT);
-            int const mb = (m_start - anchor < m_mpos) ? m_start - anchor : m_mpos;
+            int const mlow = m_mpos - ((int)lowIdx - 2);               // the match may grow backwards down to the lowest valid position
+            int const mb = (m_start - anchor < mlow) ? m_start - anchor : mlow;
             u32 const back = kx_team_backward<G>(bw, src, m_start, m_mpos, mb, k, tbase, tmask);
             if (mt) {
                 u32 offBase = 1;
@@ -381,10 +393,10 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     u64 const wb = kx_ld64(src + ip - 2);
                     u64 const wc = kx_ld64(src + ip - 1);
                     u32 const va = tag | (u32)(m_pos + 2 + 2);
-                    L[kx_hash_long(wa, hbL)] = va | (kx_chk_long(wa, hbL) << CHKS);
-                    L[kx_hash_long(wb, hbL)] = (tag | (u32)(ip - 2 + 2)) | (kx_chk_long(wb, hbL) << CHKS);
-                    S[kx_hash_short(wa, hbS, mls)] = va | (kx_chk_short(wa) << CHKS);
-                    S[kx_hash_short(wc, hbS, mls)] = (tag | (u32)(ip - 1 + 2)) | (kx_chk_short(wc) << CHKS);
+                    L[kx_hash_long(wa, hbL)] = va | (wide ? 0u : kx_chk_long(wa, hbL) << CHKS);
+                    L[kx_hash_long(wb, hbL)] = (tag | (u32)(ip - 2 + 2)) | (wide ? 0u : kx_chk_long(wb, hbL) << CHKS);
+                    S[kx_hash_short(wa, hbS, mls)] = va | (wide ? 0u : kx_chk_short(wa) << CHKS);
+                    S[kx_hash_short(wc, hbS, mls)] = (tag | (u32)(ip - 1 + 2)) | (wide ? 0u : kx_chk_short(wc) << CHKS);
                 }
                 if (++guard > 2u * (u32)n + 64u) { status = 2; state = KST_CLEANUP; }
                 else state = KST_REPCHECK;

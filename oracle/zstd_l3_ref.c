@@ -2067,29 +2067,35 @@ static size_t fast_block_at(seqstore* ss, u32 rep[3], const u8* input, size_t bl
 
 KREF_API size_t kref_zstd_fast_compress_big(u8* dst, size_t cap, const u8* src, size_t srcSize, int level, int stream, int emptyEnd)
 {
+    /* stream: 0 = the caller's array compressed in place (ZSTD_compress2 into a bound-sized buffer); 1 = streaming frame
+     * (size unknown); 3 = one-shot through the reference's driver (size known, but its output slices are smaller than
+     * the bound, so the input is staged in chunks of 128 KiB like a stream's) */
     u32 P[4]; kref_wksp w; seqstore ss; kref_frame_state fs; kref_hufstate nextHuf;
-    size_t pos, ipos = 0; int64_t savings = 0; size_t const blockSizeMax = 128 << 10;
+    size_t pos, ipos = 0, hdr; int64_t savings = 0; size_t const blockSizeMax = 128 << 10;
+    int const chunked = stream != 0, unknown = stream == 1 || stream == 2;
     if (level != 1 && level != 2) return KERR;
-    if (level == 2 && !stream && srcSize > 131072 && srcSize <= 262144) {
+    if (level == 2 && !unknown && srcSize > 131072 && srcSize <= 262144) {
+        if (stream == 3) return KERR;
         /* level 2's row for this size class is a double-fast one: window 18, chain 14, hash 14, minMatch 5 */
         u32 const Pd[4] = { 18, 14, 14, 5 };
         return compress_blocks_dfast(dst, cap, src, srcSize, NULL, NULL, Pd);
     }
-    if (stream) { P[0] = (level == 1) ? 19 : 20; P[2] = (level == 1) ? 14 : 16; P[3] = (level == 1) ? 7 : 6; }
+    if (unknown) { P[0] = (level == 1) ? 19 : 20; P[2] = (level == 1) ? 14 : 16; P[3] = (level == 1) ? 7 : 6; }
     else kref_params_fast(level, srcSize, P);
     if (srcSize > ((size_t)1 << P[0])) return KERR;                  /* the window would slide */
     if (cap < kref_compress_bound(srcSize) + 16) return KERR;
-    if (stream) { wr32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)((P[0] - 10) << 3); pos = 6; }
+    if (unknown) { wr32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)((P[0] - 10) << 3); pos = 6; }
     else pos = write_frame_header(dst, srcSize, P[0]);
-    if (!stream && srcSize == 0) { wr24(dst + pos, 1); return pos + 3; }
+    hdr = pos;
+    if (!unknown && srcSize == 0) { wr24(dst + pos, 1); return pos + 3; }
     w.hashLong = (u32*)calloc((size_t)1 << P[2], sizeof(u32)); w.hashSmall = NULL;
     w.seqs = (kref_seq*)malloc(sizeof(kref_seq) * ((128 << 10) / 3 + 8)); w.lits = (u8*)malloc((128 << 10) + 32);
     fs.rep[0] = 1; fs.rep[1] = 4; fs.rep[2] = 8; fs.huf.valid = 0; memset(&fs.huf.ct, 0, sizeof(fs.huf.ct)); fs.isFirstBlock = 1;
-    if (!stream) emptyEnd = 0; else if (srcSize % blockSizeMax != 0 || srcSize == 0) emptyEnd = (srcSize == 0);
+    if (!unknown) emptyEnd = 0; else if (srcSize % blockSizeMax != 0 || srcSize == 0) emptyEnd = (srcSize == 0);
     while (ipos < srcSize) {
-        size_t const chunkEnd = (stream && ipos + blockSizeMax < srcSize) ? (ipos / blockSizeMax + 1) * blockSizeMax : srcSize;
+        size_t const chunkEnd = (chunked && ipos + blockSizeMax < srcSize) ? (ipos / blockSizeMax + 1) * blockSizeMax : srcSize;
         int const lastChunk = (chunkEnd == srcSize) && !emptyEnd;
-        if (stream && ipos == blockSizeMax) savings -= 6;
+        if (chunked && ipos == blockSizeMax) savings -= (int64_t)hdr;
         while (ipos < chunkEnd) {
             size_t const remaining = chunkEnd - ipos;
             size_t const blockSize = (remaining < blockSizeMax) ? remaining : (savings < 3) ? blockSizeMax : split_block_from_borders(src + ipos);

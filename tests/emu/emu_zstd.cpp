@@ -147,10 +147,20 @@ int emu_zstd_compress_big(const u8* src, const u64* in_off, const u32* in_len, u
                           u8* dst, const u64* out_off, u32* out_len, u32* rounds_out)
 { return emu_zstd_compress_big_ex(src, in_off, in_len, n, G, nblocks, dst, out_off, out_len, rounds_out, 0); }
 extern "C" __attribute__((visibility("default")))
+int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
+                              u8* dst, const u64* out_off, u32* out_len, u32* rounds_out, u32 stream_and_strategy, u32 tail_or_chunk, u32 wide);
+extern "C" __attribute__((visibility("default")))
 int emu_zstd_compress_big_ex(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
                              u8* dst, const u64* out_off, u32* out_len, u32* rounds_out, u32 stream_and_strategy)
+{ return emu_zstd_compress_big_ex2(src, in_off, in_len, n, G, nblocks, dst, out_off, out_len, rounds_out, stream_and_strategy, 0, 0); }
+// stream (low byte): KFrameArgs.stream, 0 .. 3; tail_or_chunk: tail_direct of a stream, out_chunk of the one-shot driver (mode 3);
+// wide: table entries without check bits (what contexts for slices of 4 MiB and more use)
+extern "C" __attribute__((visibility("default")))
+int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
+                              u8* dst, const u64* out_off, u32* out_len, u32* rounds_out, u32 stream_and_strategy, u32 tail_or_chunk, u32 wide)
 {
     u32 const stream = stream_and_strategy & 0xFFu, strategy = stream_and_strategy >> 8;     // strategy 1: level 1 (fast)
+    bool const streaming = stream == 1 || stream == 2;
     u32 const block_cap = 128u * 1024u;
     u32 const seq_cap = (block_cap / 4 + 8 + 15) & ~15u, lit_cap = block_cap + 64, scratch_words = block_cap / 4 + 64;
     std::vector<KSeq> seqs((size_t)n * seq_cap);
@@ -164,14 +174,15 @@ int emu_zstd_compress_big_ex(const u8* src, const u64* in_off, const u32* in_len
     for (u32 i = 0; i < n; i++) {
         KFrameState s; memset(&s, 0, sizeof(s));
         s.blockSize = in_len[i] < KX_BLOCK_MAX ? in_len[i] : KX_BLOCK_MAX; s.first = 1; s.rep[0] = 1; s.rep[1] = 4; s.rep[2] = 8;
+        s.lowLimit = 2; s.dictLimit = 2; s.chunkEnd = (stream != 0 && in_len[i] > KX_BLOCK_MAX) ? KX_BLOCK_MAX : in_len[i];
         fstate[i] = s;
-        if (in_len[i] == 0) { u8* d = dst + out_off[i]; u32 const magic = 0xFD2FB528u; memcpy(d, &magic, 4); d[4] = stream ? 0x00 : 0x20; d[5] = stream ? (strategy ? 0x48 : 0x58) : 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
+        if (in_len[i] == 0) { u8* d = dst + out_off[i]; u32 const magic = 0xFD2FB528u; memcpy(d, &magic, 4); d[4] = streaming ? 0x00 : 0x20; d[5] = streaming ? (strategy ? 0x48 : 0x58) : 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
         else remaining++;
     }
     KMatchArgs m;
     m.src = src; m.in_off = in_off; m.in_len = in_len; m.n_slices = n;
     m.seqs = seqs.data(); m.seq_cap = seq_cap; m.lits = lits.data(); m.lit_cap = lit_cap; m.meta = meta.data();
-    m.tables = nullptr; m.team_epoch = nullptr; m.counter = &counter; m.flags = stream ? 8u : 0u;
+    m.tables = nullptr; m.team_epoch = nullptr; m.counter = &counter; m.flags = (streaming ? 8u : 0u) | (wide ? 16u : 0u);
     m.fstate = fstate.data(); m.big_tables = big_tables.data();
     KFrameArgs e;
     e.src = src; e.in_off = in_off; e.in_len = in_len; e.n_slices = n;
@@ -179,6 +190,7 @@ int emu_zstd_compress_big_ex(const u8* src, const u64* in_off, const u32* in_len
     e.scratch = scratch.data(); e.scratch_words = scratch_words;
     e.dst = dst; e.out_off = out_off; e.out_len = out_len;
     e.fstate = fstate.data(); e.hufct = hufct.data(); e.remaining = &remaining; e.stream = stream; e.strategy = strategy;
+    e.tail_direct = stream == 3 ? 0u : tail_or_chunk; e.out_chunk = stream == 3 ? tail_or_chunk : 0u;
     if (strategy && rounds_out) return -6;
     if (!rounds_out) {
         // product path: one wave per slice walks its chain of blocks
@@ -208,7 +220,7 @@ int emu_zstd_compress_big_ex(const u8* src, const u64* in_off, const u32* in_len
     }
     u32 rounds = 0;
     while (remaining != 0) {
-        if (++rounds > 300) return -4;
+        if (++rounds > 20000) return -4;
         counter = 0; kxemu::failed = 0;
         switch (G) {
         case 2:  kxemu::launch(nblocks, [&]() { zstd_match_body<2, true>(m); }); break;
@@ -218,6 +230,17 @@ int emu_zstd_compress_big_ex(const u8* src, const u64* in_off, const u32* in_len
         case 32: kxemu::launch(nblocks, [&]() { zstd_match_body<32, true>(m); }); break;
         case 64: kxemu::launch(nblocks, [&]() { zstd_match_body<64, true>(m); }); break;
         default: return -2;
+        }
+        if (kxemu::failed) return -1;
+        // the blocks libzstd parses with the extDict variant (behind a wrap of its staging buffer)
+        counter = 0;
+        switch (G) {
+        case 2:  kxemu::launch(nblocks, [&]() { zstd_match_ext_body<2>(m); }); break;
+        case 4:  kxemu::launch(nblocks, [&]() { zstd_match_ext_body<4>(m); }); break;
+        case 8:  kxemu::launch(nblocks, [&]() { zstd_match_ext_body<8>(m); }); break;
+        case 16: kxemu::launch(nblocks, [&]() { zstd_match_ext_body<16>(m); }); break;
+        case 32: kxemu::launch(nblocks, [&]() { zstd_match_ext_body<32>(m); }); break;
+        default: kxemu::launch(nblocks, [&]() { zstd_match_ext_body<64>(m); }); break;
         }
         if (kxemu::failed) return -1;
         for (u32 i = 0; i < n; i++) if (fstate[i].blockSize >= 8 && meta[i].status) return -3;

@@ -37,9 +37,13 @@ def main():
         one = z.compress_streaming(d, [0, n], out_chunk=max(8192, n // 10))
         cuts = sorted({0, n, rng.randrange(1, n), rng.randrange(1, n)})
         stream = z.compress_streaming(d, cuts, out_chunk=8192)
-        rows.append({"name": name, "size": n, "input_sha256": hashlib.sha256(d).hexdigest(),
-                     "oneshot_len": len(one), "oneshot_sha256": hashlib.sha256(one).hexdigest(),
-                     "stream_len": len(stream), "stream_sha256": hashlib.sha256(stream).hexdigest()})
+        row = {"name": name, "size": n, "input_sha256": hashlib.sha256(d).hexdigest(),
+               "oneshot_len": len(one), "oneshot_sha256": hashlib.sha256(one).hexdigest(),
+               "stream_len": len(stream), "stream_sha256": hashlib.sha256(stream).hexdigest()}
+        if n <= (512 << 10):             # level 1 (the Ktor encoder's level) through the same one-shot driver, up to its window
+            l1 = z.compress_streaming(d, [0, n], out_chunk=max(8192, n // 10), level=1)
+            row["l1_oneshot_len"], row["l1_oneshot_sha256"] = len(l1), hashlib.sha256(l1).hexdigest()
+        rows.append(row)
     # streams whose closing call brings a few bytes right after the staging buffer wrapped (they are compressed in place)
     tails = []
     for k, t in ((1, 1), (1, 4000), (2, 777)):

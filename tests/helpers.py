@@ -262,13 +262,14 @@ class Oracle:
         return o.raw[:n]
 
     def compress_level_big(self, d: bytes, level: int, stream: bool = False, empty_end: bool = False) -> bytes:
-        """Level 1 or 2 frame of several blocks (any size the window holds), one-shot or as a stream."""
+        """Level 1 or 2 frame of several blocks (any size the window holds): stream False / 0 = ZSTD_compress2's frame,
+        True / 1 = a stream's, 3 = the one-shot frame the reference's driver gets (input staged in 128 KiB chunks)."""
         k = self.lib
         k.kref_zstd_fast_compress_big.restype = ctypes.c_size_t
         k.kref_zstd_fast_compress_big.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         cap = k.kref_compress_bound(len(d)) + 64
         o = ctypes.create_string_buffer(cap)
-        n = k.kref_zstd_fast_compress_big(o, cap, d, len(d), level, 1 if stream else 0, 1 if empty_end else 0)
+        n = k.kref_zstd_fast_compress_big(o, cap, d, len(d), level, int(stream), 1 if empty_end else 0)
         if n == 2 ** 64 - 1:
             raise RuntimeError("oracle: input outside the restatement's scope")
         return o.raw[:n]
@@ -434,9 +435,11 @@ def emu_compress_dict(datas, dictionary, G=4, nblocks=2):
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
 
 
-def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False, stream=0, level=3):
+def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False, stream=0, level=3, tail_or_chunk=0, wide=False):
     """Frames of several blocks (slices above 128 KiB) on the emulator: the product's one-wave-per-slice kernel body,
-    or (by_rounds) the same steps as separate launches per round of blocks.  Returns (frames, rounds)."""
+    or (by_rounds) the same steps as separate launches per round of blocks.  stream: 0 ZSTD_compress2's frames, 1 / 2
+    streaming frames, 3 the reference's one-shot driver (tail_or_chunk: a stream's tail_direct / the driver's output
+    slice size, 0 = max(8192, n / 10)); wide: table entries without check bits.  Returns (frames, rounds)."""
     n = len(datas)
     lens = np.array([len(d) for d in datas], dtype=np.uint32)
     offs = np.zeros(n, dtype=np.uint64)
@@ -453,8 +456,9 @@ def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False, stream=0, level=3)
     ooff = np.arange(n, dtype=np.uint64) * stride
     olen = np.zeros(n, dtype=np.uint32)
     rounds = ctypes.c_uint32(0)
-    r = emu().emu_zstd_compress_big_ex(_vp(buf), _vp(offs), _vp(lens), n, G, nblocks, _vp(out), _vp(ooff), _vp(olen),
-                                       ctypes.byref(rounds) if by_rounds else None, stream | ((1 if level == 1 else 0) << 8))
+    r = emu().emu_zstd_compress_big_ex2(_vp(buf), _vp(offs), _vp(lens), n, G, nblocks, _vp(out), _vp(ooff), _vp(olen),
+                                        ctypes.byref(rounds) if by_rounds else None, stream | ((1 if level == 1 else 0) << 8),
+                                        tail_or_chunk, 1 if wide else 0)
     assert r == 0, f"emulator reported {r}"
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)], rounds.value
 

@@ -48,6 +48,23 @@ def gpu_compress(batch, datas):
     return [dst[ooff[i]:ooff[i] + olen[i]].tobytes() for i in range(n)]
 
 
+gpu_compress_kw_last = [None]
+
+
+def gpu_compress_kw(batch, datas, **kw):
+    """gpu_compress with the keyword arguments of ZstdBatch.compress (level, reference, streaming ...)."""
+    n = len(datas)
+    lens = np.array([len(d) for d in datas], dtype=np.int32)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
+    host = np.frombuffer(b"".join(datas) + bytes(64), dtype=np.uint8).copy()
+    dst, ooff, olen = batch.compress(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), **kw)
+    torch.cuda.synchronize()
+    dd, oo, ol = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+    frames = [dd[oo[i]:oo[i] + ol[i]].tobytes() for i in range(n)]
+    gpu_compress_kw_last[0] = frames[-1] if frames else None
+    return frames
+
+
 def gpu_decompress(batch, frames, caps):
     n = len(frames)
     lens = np.array([len(f) for f in frames], dtype=np.int32)
@@ -749,15 +766,142 @@ def test_slices_longer_than_the_context_are_refused_not_overrun():
 
 
 def test_streaming_decoder_refuses_frames_beyond_its_staging():
-    """kmp_zstd_decompress_stream stages at most a 2 MiB frame: a larger declared content size is refused when the
-    header arrives, a frame without content size when its bytes exceed the staging buffer -- never copied past it."""
-    import zlib as _z   # noqa: F401
+    """kmp_zstd_decompress_stream stages frames of up to 1 GiB of content: a larger declared content size is refused when
+    the header arrives; a frame without content size is decoded into a staging buffer that grows until it fits."""
     from kompressor_amd.zstd import ZstdDecompressor
-    # 3 MiB declared in the header (fcs 4 bytes, single segment), nothing else needed to refuse it
-    hdr = bytes([0x28, 0xB5, 0x2F, 0xFD, 0xA0]) + (3 << 20).to_bytes(4, "little") + bytes([0x01, 0x00, 0x00])
+    # 2 GiB declared in the header (fcs 4 bytes, single segment), nothing else needed to refuse it
+    hdr = bytes([0x28, 0xB5, 0x2F, 0xFD, 0xA0]) + (2 << 30).to_bytes(4, "little") + bytes([0x01, 0x00, 0x00])
     with pytest.raises(RuntimeError, match="Unsupported frame parameter"):
         ZstdDecompressor().transform_bytes(hdr)
-    # no content size: 20 raw blocks of 128 KiB after a window descriptor
-    body = b"".join((((131072 << 3) | (1 if k == 19 else 0)).to_bytes(3, "little") + bytes(131072)) for k in range(20))
-    with pytest.raises(RuntimeError, match="Unsupported frame parameter"):
-        ZstdDecompressor().transform_bytes(bytes([0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x58]) + body)
+    # no content size: 20 raw blocks of 128 KiB after a window descriptor (2.5 MiB: the first staging guess is 10 MiB;
+    # 100 RLE blocks: 12.5 MiB from a 400-byte frame: the staging grows twice)
+    body = b"".join((((131072 << 3) | (1 if k == 19 else 0)).to_bytes(3, "little") + bytes([k]) * 131072) for k in range(20))
+    out = ZstdDecompressor().transform_bytes(bytes([0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x58]) + body)
+    assert out == b"".join(bytes([k]) * 131072 for k in range(20))
+    rle = b"".join((((131072 << 3) | 2 | (1 if k == 99 else 0)).to_bytes(3, "little") + bytes([k])) for k in range(100))
+    out = ZstdDecompressor().transform_bytes(bytes([0x28, 0xB5, 0x2F, 0xFD, 0x00, 0x58]) + rle)
+    assert out == b"".join(bytes([k]) * 131072 for k in range(100))
+
+
+@pytest.mark.timeout(900)
+def test_reference_driver_frames_above_128k_and_beyond_the_window():
+    """What ZstdCompressor(3).transform(bytes) REALLY returns above 128 KiB: the reference's output slices
+    (max(8192, n / 10) bytes, SliceTransform.kt:47-56) are smaller than ZSTD_compressBound, so libzstd stages the input in
+    128 KiB chunks, and beyond 2 MiB + 128 KiB its staging buffer wraps (older lap = extDict segment, sliding window).
+    57 inputs of 128 KiB + 1 .. 6.7 MiB against frames a binary libzstd 1.5.7 wrote under exactly those calls
+    (tests/golden/make_golden_buffered.py): the one-shot driver and streamed, batch entry points; then the streaming C ABI
+    with the reference's own driver loop, the in-place tail of a stream, and the decoder on all of it."""
+    import ctypes
+    from kompressor_amd import _lib, ZstdCompressor, ZstdDecompressor
+    from kompressor_amd.batch import ZstdBatch
+    B = helpers.buffered_golden()
+    inputs = helpers.multiblock_inputs() + helpers.beyond_window_inputs()
+    rows = {r["name"]: r for r in B["rows"]}
+    small = [(nm, d) for nm, d in inputs if len(d) <= (2 << 20)]
+    # contexts for <= 2 MiB use table entries with check bits, the 8 MiB one plain 32-bit indices
+    for group, cap in ((small, 2 << 20), (inputs, 8 << 20)):
+        datas = [d for _, d in group]
+        b = ZstdBatch(max_slices=len(datas), max_slice_bytes=cap)
+        try:
+            for key, kw in (("oneshot", {"reference": True}), ("stream", {"streaming": "data"})):
+                n = len(datas)
+                lens = np.array([len(d) for d in datas], dtype=np.int32)
+                offs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
+                host = np.frombuffer(b"".join(datas) + bytes(64), dtype=np.uint8).copy()
+                dst, ooff, olen = b.compress(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), **kw)
+                torch.cuda.synchronize()
+                assert b.status() == (0, 0)
+                dd, oo, ol = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+                frames = [dd[oo[i]:oo[i] + ol[i]].tobytes() for i in range(n)]
+                for (nm, d), f in zip(group, frames):
+                    r = rows[nm]
+                    assert len(f) == r[key + "_len"] and helpers.sha256(f) == r[key + "_sha256"], (cap, key, nm)
+                if key == "oneshot":
+                    back, st = gpu_decompress(b, frames, [len(d) for d in datas])
+                    assert st == [0] * n and back == datas
+        finally:
+            b.close()
+    # level 1 (the Ktor encoder's level) through the same driver, up to its 512 KiB window
+    l1 = [(nm, d) for nm, d in inputs if len(d) <= (512 << 10)]
+    b = ZstdBatch(max_slices=len(l1), max_slice_bytes=512 << 10)
+    try:
+        for (nm, d), f in zip(l1, gpu_compress_kw(b, [d for _, d in l1], level=1, reference=True)):
+            assert len(f) == rows[nm]["l1_oneshot_len"] and helpers.sha256(f) == rows[nm]["l1_oneshot_sha256"], ("level 1", nm)
+    finally:
+        b.close()
+    # the streaming C ABI driven by the reference's one-shot loop: output slices of max(8192, n / 10) bytes
+    assert ZstdCompressor(1).transform_bytes(l1[-1][1]) == gpu_compress_kw_last[0]
+    for nm in ("mixed_1_300000", "class_B_1m", "beyond_2228225", "beyond_3000000"):
+        d = dict(inputs)[nm]
+        f = ZstdCompressor(3).transform_bytes(d)
+        assert len(f) == rows[nm]["oneshot_len"] and helpers.sha256(f) == rows[nm]["oneshot_sha256"], nm
+        assert ZstdDecompressor().transform_bytes(f) == d
+    # ... and with room for ZSTD_compressBound in the first output slice libzstd compresses in place: ZSTD_compress2's frame
+    lib = _lib.load()
+    d = dict(inputs)["class_B_1m"]
+    cctx = lib.kmp_zstd_create_cctx()
+    cap = lib.kmp_zstd_compress_bound(len(d))
+    obuf = ctypes.create_string_buffer(cap)
+    dp, sp = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert lib.kmp_zstd_compress_stream(cctx, obuf, cap, ctypes.byref(dp), d, len(d), ctypes.byref(sp), 2) == 0
+    lib.kmp_zstd_free_cctx(cctx)
+    g = next(r for r in helpers.multiblock_golden()["rows"] if r["name"] == "class_B_1m")
+    assert dp.value == g["len"] and helpers.sha256(obuf.raw[:dp.value]) == g["sha256"]
+    # a stream whose closing call brings a few bytes right after libzstd's staging buffer wrapped: compressed in place
+    base = helpers.beyond_window_inputs()[-1][1]
+    lap = 17 * 131072
+    for row in B["tails"]:
+        d = base[: row["laps"] * lap + row["tail"]]
+        cctx = lib.kmp_zstd_create_cctx()
+        out = bytearray()
+        obuf = ctypes.create_string_buffer(8192)
+        for a0, a1, end in ((0, row["laps"] * lap, False), (row["laps"] * lap, len(d), True)):
+            sp = ctypes.c_size_t(a0)
+            while True:
+                dp = ctypes.c_size_t(0)
+                r = lib.kmp_zstd_compress_stream(cctx, obuf, 8192, ctypes.byref(dp), d, a1, ctypes.byref(sp), 2 if end else 0)
+                assert not lib.kmp_zstd_is_error(r), lib.kmp_zstd_get_error_name(r)
+                out += obuf.raw[:dp.value]
+                if (end and r == 0) or (not end and sp.value == a1):
+                    break
+        lib.kmp_zstd_free_cctx(cctx)
+        assert len(out) == row["len"] and helpers.sha256(bytes(out)) == row["sha256"], row["name"]
+
+
+@pytest.mark.timeout(900)
+def test_large_stream_like_the_reference_largeSample():
+    """ZstdTest.largeSample (ZstdTest.kt:67-82) pipes 256 MiB + 3 random bytes through ZstdCompressor(3) and
+    ZstdDecompressor in 8 KiB pieces.  Same shape here at 24 MiB + 3 (random bytes: every block raw, eleven laps of
+    libzstd's staging buffer), finish = false pieces then finish = true, and the frame must be libzstd's."""
+    import ctypes
+    from kompressor_amd import _lib, ZstdDecompressor
+    lib = _lib.load()
+    n = (24 << 20) + 3
+    d = np.random.default_rng(42).integers(0, 256, n, dtype=np.uint8).tobytes()
+    cctx = lib.kmp_zstd_create_cctx()
+    out = bytearray()
+    obuf = ctypes.create_string_buffer(8192)
+    piece = 1 << 20                              # (8 KiB pieces in the reference; the staging is the same)
+    pos = 0
+    while pos < n:
+        a1 = min(n, pos + piece)
+        sp, dp = ctypes.c_size_t(pos), ctypes.c_size_t(0)
+        r = lib.kmp_zstd_compress_stream(cctx, obuf, 8192, ctypes.byref(dp), d, a1, ctypes.byref(sp), 0)
+        assert not lib.kmp_zstd_is_error(r) and sp.value == a1 and dp.value == 0
+        pos = a1
+    while True:
+        sp, dp = ctypes.c_size_t(n), ctypes.c_size_t(0)
+        r = lib.kmp_zstd_compress_stream(cctx, obuf, 8192, ctypes.byref(dp), d, n, ctypes.byref(sp), 2)
+        assert not lib.kmp_zstd_is_error(r), lib.kmp_zstd_get_error_name(r)
+        out += obuf.raw[:dp.value]
+        if r == 0:
+            break
+    lib.kmp_zstd_free_cctx(cctx)
+    f = bytes(out)
+    # random bytes: a header, raw blocks of 128 KiB, the 3-byte tail
+    nblocks = (n + 131071) // 131072
+    assert len(f) == 6 + n + 3 * nblocks
+    z = helpers.live_libzstd()
+    if z is not None:
+        assert f == z.compress_streaming(d, [0, n // 2, n], out_chunk=8192)
+    assert hashlib.sha256(ZstdDecompressor().transform_bytes(f)).digest() == hashlib.sha256(d).digest()
