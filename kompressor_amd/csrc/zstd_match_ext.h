@@ -30,7 +30,7 @@ KX_DEV void zstd_match_ext_body(const KMatchArgs& a)
     constexpr u32 CHKS = KX_BLK_IDX_BITS;
 
     int state = KXS_IDLE;
-    const u8* src = a.src; u32* L = a.big_tables; u32* S = a.big_tables; KSeq* seqs = a.seqs;
+    const u8* src = a.src; u32* L = a.big_tables; u32* S = a.big_tables; KSeq* seqs = a.seqs; u8* lits = a.lits;
     int n = 0, ilimit = 0, ip = 0, anchor = 0; u32 slice = 0; u32 off1 = 1, off2 = 4;
     u32 nseq = 0, nlit = 0, longType = 0, longPos = 0, guard = 0, status = 0; u32 hbL = 17, hbS = 16, mls = 5;
     u32 dsi = 2, psi = 2;                       // dictStartIndex, prefixStartIndex of the block
@@ -53,7 +53,7 @@ KX_DEV void zstd_match_ext_body(const KMatchArgs& a)
                     if (fs.blockSize != 0 && bw.ext) {
                         slice = s;
                         src = a.src + a.in_off[s];
-                        seqs = a.seqs + (size_t)s * a.seq_cap;
+                        seqs = a.seqs + (size_t)s * a.seq_cap; lits = a.lits + (size_t)s * a.lit_cap;
                         L = a.big_tables + (size_t)s * KX_BIG_TBL_ENTRIES; S = L + KX_BIG_TBL_LONG;
                         hbL = P.hashLog; hbS = P.chainLog; mls = P.minMatch;
                         dsi = bw.dictStartIndex; psi = bw.prefixStartIndex;
@@ -155,6 +155,8 @@ KX_DEV void zstd_match_ext_body(const KMatchArgs& a)
                 u32 offBase = 1;
                 if (m_back) { m_start -= (int)back; lenA += back; off2 = off1; off1 = m_off; offBase = m_off + 3; }
                 int const ll = m_start - anchor;
+                // the literals in front of the match (the block-chain kernel codes them from this buffer)
+                if (!(a.flags & 4u)) for (int c = 8 * k; c < ll; c += 8 * G) kx_st64(lits + nlit + c, kx_ld64_clamped(src, anchor + c, n));
                 {
                     u64 const q = (u64)offBase | ((u64)(u16)ll << 32) | ((u64)(u16)(lenA - 3) << 48);   // KSeq
                     u32 const slot = nseq & (2u * G - 1u);

@@ -77,7 +77,7 @@ def test_parameter_and_argument_errors_need_no_gpu(lib):
     assert lib.kmp_batch_create(None, 0, 1, 65536, 8) == -2
     h = ctypes.c_void_p()
     assert lib.kmp_batch_create(ctypes.byref(h), 0, 1, (1 << 30) + 1, 8) == -3   # slices up to 1 GiB
-    assert b"2 MiB" in lib.kmp_last_error()
+    assert b"1 GiB" in lib.kmp_last_error()
 
 
 class XorSliceTransform(SliceTransform):

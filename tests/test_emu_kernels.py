@@ -272,3 +272,17 @@ def test_epoch_wrap_clears_the_team_tables():
         assert f == o.compress(d)
     for f, d in zip(helpers.emu_compress_level(datas, 1, G=16, nblocks=1), datas):
         assert f == o.compress_level(d, 1)
+
+
+def test_reference_driver_frames_and_a_wrapped_staging_buffer_on_the_emulator():
+    """The block-chain kernel body in the modes the reference really exercises above 128 KiB (libzstd stages the input in
+    128 KiB chunks; tests/golden/zstd_l3_buffered_golden.json): a 300 000-byte slice one-shot and streamed, and a slice one
+    byte longer than libzstd's staging buffer (2 MiB + 128 KiB + 1: the buffer wraps, the last block is parsed by the
+    extDict variant, the window's low limit has moved)."""
+    rows = {r["name"]: r for r in helpers.buffered_golden()["rows"]}
+    inputs = dict(helpers.multiblock_inputs() + helpers.beyond_window_inputs())
+    for name, modes in (("mixed_1_300000", ((3, "oneshot"), (1, "stream"))), ("beyond_2228225", ((3, "oneshot"),))):
+        d = inputs[name]
+        for mode, key in modes:
+            f, _ = helpers.emu_compress_big([d], G=16, nblocks=1, stream=mode)
+            assert len(f[0]) == rows[name][key + "_len"] and helpers.sha256(f[0]) == rows[name][key + "_sha256"], (name, key)
