@@ -76,7 +76,7 @@ def cpu_baseline(host, n_slices, frames_expected, sample=None):
             op = ctypes.cast(out, ctypes.c_void_p).value
             label_holder.append(f"ZSTD_compressStream2(e_end), {chunk}-byte output slices")
 
-            def one(ptr):
+            def one(ptr, _keep=out):                 # (the closure keeps the output buffer alive)
                 ib = _Buf(ptr, SLICE, 0)
                 total = 0
                 while True:
