@@ -152,12 +152,13 @@ class ZstdBatch:
         return dst, out_off, out_len, status
 
     def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, zlib_wrapper=False, format=None):   # noqa: A002
-        """DEFLATE streams (zlib level 6, windowBits 15, memLevel 8), format "raw" / "zlib" / "gzip", for slices of at most 64 KiB."""
+        """DEFLATE streams (zlib level 6, windowBits 15, memLevel 8), format "raw" / "zlib" / "gzip", for slices up to the
+        context's max_slice_bytes (64 KiB at least)."""
         fmt = self._FORMATS[format] if format is not None else (1 if zlib_wrapper else 0)
         if fmt == 3:
             raise ValueError("Compression can't be used with auto-detection")       # ZlibFormat.kt:28
         n = in_len.numel()
-        stride = (self.lib.kmp_deflate_bound(min(self.max_slice_bytes, 65536)) + 63) & ~63
+        stride = (self.lib.kmp_deflate_bound(max(self.max_slice_bytes, 65536)) + 63) & ~63
         if dst is None:
             dst = torch.empty(n * stride + 64, dtype=torch.uint8, device=self.device)
         if out_off is None:

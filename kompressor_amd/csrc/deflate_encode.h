@@ -255,8 +255,9 @@ KX_DEV void deflate_encode_slice(const KdArgs& a, KdEncLds& lds, u32 slice, int 
 {
     const u8* const src = a.src + a.in_off[slice];
     u8* const dst = a.dst + a.out_off[slice];
-    const u32* const syms = a.syms + (size_t)slice * 65536u;
+    const u32* const syms = a.syms + (size_t)slice * a.pos_cap;
     KdSliceMeta const mm = a.meta[slice];
+    const KdBlockInfo* const blocks = a.blocks + (size_t)slice * a.blk_cap;
     // bits written so far; lds.cbuf[0] holds the pending partial word. The zlib wrapper's header for
     // level 6 / 32 KiB window is 78 9C (CMF 0x78, FLG: level flags 2, check bits so that CMF*256+FLG % 31 == 0)
     // gzip (format 2): 1F 8B, CM 8, no flags, MTIME 0, XFL 0 (level 6), OS 3 (what zlib writes on Linux)
@@ -266,7 +267,7 @@ KX_DEV void deflate_encode_slice(const KdArgs& a, KdEncLds& lds, u32 slice, int 
     kx_sync();
     u32 s0 = 0;
     for (u32 b = 0; b < mm.nblocks; b++) {
-        KdBlockInfo const bi = mm.blk[b];
+        KdBlockInfo const bi = blocks[b];
         u32 const s1 = bi.nsym_end; int const last = (b + 1 == mm.nblocks) ? 1 : 0;
         u32 const stored_len = bi.end_pos - bi.start_pos;
         // ---- symbol statistics --------------------------------------------------

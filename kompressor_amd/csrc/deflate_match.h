@@ -1,6 +1,6 @@
 // deflate_match.h -- the LZ77 half of zlib level 6 ("deflate_slow": 15-bit hash of
 // 3 bytes, hash chains, lazy matching, good/lazy/nice/chain = 8/16/128/128) for many
-// independent slices of at most 64 KiB.
+// independent slices (positions are 32-bit; match candidates are kept as distances, which zlib's 32 KiB window bounds).
 //
 // Replaces zlib's deflate() behind the reference's ZlibCompressor(ZlibFormat.Raw, 6)
 // (kompressor-zlib--nativelib/src/jvmCommonMain/jni/Wrapper.cpp:20,73; Kotlin side
@@ -27,24 +27,27 @@
 #define KD_MAX_DIST (KD_WSIZE - KD_MIN_LOOKAHEAD)       /* 32506 */
 #define KD_TOO_FAR 4096
 #define KD_LIT_BUFSIZE 16384
-#define KD_MAX_SLICE 65536u
-#define KD_MAX_BLOCKS 8
+#define KD_MAX_SLICE (1u << 30)
 
 KX_DEV u32 kd_hash3(u32 b0, u32 b1, u32 b2) { return ((b0 << 10) ^ (b1 << 5) ^ b2) & 0x7FFFu; }
 
 // per position: what longest_match returns with a full chain (128 steps) and with the
-// shortened chain (32 steps, used when the previous match is >= good_match)
-struct KdBest { u16 len128, pos128, len32, pos32; };
+// shortened chain (32 steps, used when the previous match is >= good_match); dist = position - match start (<= MAX_DIST)
+struct KdBest { u16 len128, dist128, len32, dist32; };
 
 struct KdBlockInfo { u32 nsym_end; u32 end_pos; u32 start_pos; u32 stored_ok; };   // symbols [prev nsym_end, nsym_end)
-struct KdSliceMeta { u32 nblocks; u32 nsym; u32 pad[2]; KdBlockInfo blk[KD_MAX_BLOCKS]; };
+struct KdSliceMeta { u32 nblocks; u32 nsym; u32 pad[2]; };
+// blocks a slice of n bytes can have: one per 16 383 symbols (a symbol covers at least one byte), the last one may be short
+KX_DEV u32 kd_block_cap(u32 n) { return n / (KD_LIT_BUFSIZE - 1) + 2u; }
 
 struct KdArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
-    u16* link;          // per slice: 65536 entries
-    KdBest* best;       // per slice: 65536 entries
-    u32* syms;          // per slice: 65536 entries: dist | lc << 16
+    u32 pos_cap;        // positions of the per-slice arrays below (the context's max_slice_bytes, rounded up to 64)
+    u16* link;          // per slice: pos_cap entries: distance to the previous position with the same hash, 0 = none
+    KdBest* best;       // per slice: pos_cap entries
+    u32* syms;          // per slice: pos_cap entries: dist | lc << 16
     KdSliceMeta* meta;
+    KdBlockInfo* blocks; u32 blk_cap;    // per slice: blk_cap entries
     u8* dst; const u64* out_off; u32* out_len;
     u32 flags;          // timing-only ablations (results wrong): 1 = no match extension, 2 = at most 16 chain steps; 4 = chunks of 8192 positions (results right); bits 8.. = refill threshold
     u32 format;         // 0 = raw deflate, 1 = zlib wrapper (78 9C header, Adler-32 trailer)
@@ -55,11 +58,11 @@ struct KdArgs {
 // ---------------------------------------------------------------------------
 KX_DEV void deflate_chains_body(const KdArgs& a)
 {
-    KX_SHARED u16 head[32768];
+    KX_SHARED u32 head[32768];                                   // position + 1 of the last string with that hash, 0 = none
     int const lane = kx_lane(); int const wv = kx_wave(); int const nw = kx_nwaves(); int const tid = wv * 64 + lane; int const nthreads = nw * 64;
     for (u32 slice = kx_block(); slice < a.n_slices; slice += kx_nblocks()) {
         const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
-        u16* const link = a.link + (size_t)slice * 65536u;
+        u16* const link = a.link + (size_t)slice * a.pos_cap;
         for (int i = tid; i < 32768; i += nthreads) head[i] = 0;
         kx_block_sync();
         u32 const nIns = n >= 3 ? n - 2 : 0;                // positions 0 .. n-3 enter the chains, in order
@@ -87,32 +90,33 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
                 if (base >= nIns) break;                    // uniform over the workgroup
                 u32 const p = base + (u32)wv * 64u + (u32)lane; bool const valid = vq[k];
                 u32 const h = valid ? kd_hash3(hq[k] & 0xFFu, (hq[k] >> 8) & 0xFFu, (hq[k] >> 16) & 0xFFu) : 0x8000u + (u32)lane;   // the bytes were fetched a group ago
-                u32 lk = 0;
+                u32 lk = 0;                                  // previous position + 1, 0 = none
                 for (int w = 0; w < nw; w++) {
                     if (wv == w) {
                         u32 const old = valid ? head[h] : 0u;
                         kx_lockstep();
-                        if (valid) head[h] = (u16)p;
+                        if (valid) head[h] = p + 1u;
                         kx_lockstep();
-                        u32 const chk = valid ? head[h] : p;
+                        u32 const chk = valid ? head[h] : p + 1u;
                         lk = old;
                         // lanes of this wave that share a bucket: one bucket per round; inside a bucket the nearest
                         // lower lane is the predecessor and the highest lane is the one left in the table
-                        for (u64 losers = kx_ballot(valid && chk != (p & 0xFFFFu)); losers; ) {
+                        for (u64 losers = kx_ballot(valid && chk != p + 1u); losers; ) {
                             int const L = (int)kx_ctz64(losers);
                             u32 const hL = kx_bcast(h, L);                       // v_readlane: L is uniform
                             u64 const grp = kx_ballot(valid && h == hL);
                             if (valid && h == hL) {
                                 u64 const below = grp & ((1ull << lane) - 1ull);
-                                if (below) lk = p - (u32)(lane - (63 - (int)__builtin_clzll(below)));
-                                if ((grp >> lane) == 1ull) head[h] = (u16)p;          // highest lane of the bucket
+                                if (below) lk = p + 1u - (u32)(lane - (63 - (int)__builtin_clzll(below)));
+                                if ((grp >> lane) == 1ull) head[h] = p + 1u;          // highest lane of the bucket
                             }
                             losers &= ~grp;
                         }
                     }
                     if (nw > 1) kx_block_sync();
                 }
-                if (valid) link[p] = (u16)lk;
+                // zlib's NIL is position 0: a string there is never a candidate; chains end beyond MAX_DIST anyway
+                if (valid) { u32 const d = (lk > 1u) ? p - (lk - 1u) : 0u; link[p] = (u16)(d <= KD_MAX_DIST ? d : 0u); }
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) { hq[k] = hn[k]; vq[k] = vn[k]; }
@@ -141,8 +145,8 @@ KX_DEV void deflate_best_body(const KdArgs& a)
     int const tid = kx_wave() * 64 + kx_lane(); int const nthreads = kx_nwaves() * 64;
     for (u32 slice = kx_block(); slice < a.n_slices; slice += kx_nblocks()) {
         const u8* const src = a.src + a.in_off[slice]; int const n = (int)a.in_len[slice];
-        const u16* const link = a.link + (size_t)slice * 65536u;
-        KdBest* const best = a.best + (size_t)slice * 65536u;
+        const u16* const link = a.link + (size_t)slice * a.pos_cap;
+        KdBest* const best = a.best + (size_t)slice * a.pos_cap;
         int const chunk = (a.flags & 4u) ? 8192 : KD_CHUNK;
         for (int cb = 0; cb < n; cb += chunk) {
             int const lo = cb > KD_HIST ? cb - KD_HIST : 0;                 // first position staged
@@ -167,7 +171,7 @@ KX_DEV void deflate_best_body(const KdArgs& a)
             {
                 bool active = false, drained = false;
                 int p = 0, c = 0, steps = 0, bestLen = 2, bestPos = 0, so = 0, maxlen = 0, nice = 0, limit = 0;
-                u32 scan01 = 0, scanEnd = 0; KdBest r; r.len128 = 0; r.pos128 = 0; r.len32 = 0; r.pos32 = 0;
+                u32 scan01 = 0, scanEnd = 0; KdBest r; r.len128 = 0; r.dist128 = 0; r.len32 = 0; r.dist32 = 0;
                 int const lane = kx_lane();
                 int const maxSteps = (a.flags & 2u) ? 16 : 128;
                 int const refillAt = (a.flags >> 8) ? (int)(a.flags >> 8) : 16;      // idle lanes that trigger a refill (tuning switch)
@@ -184,13 +188,14 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                             int const np = (int)base + (int)kx_popc64(idle & ((1ull << lane) - 1ull));
                             if (np < hiP) {
                                 p = np;
-                                r.len128 = 0; r.pos128 = 0; r.len32 = 0; r.pos32 = 0;
+                                r.len128 = 0; r.dist128 = 0; r.len32 = 0; r.dist32 = 0;
                                 int const lookahead = n - p;
                                 bool go = false;
                                 if (lookahead >= KD_MIN_MATCH) {
                                     limit = p > KD_MAX_DIST ? p - KD_MAX_DIST : 0;
-                                    c = lds.lnk[p - lo];
-                                    if (c != 0 && p - c <= KD_MAX_DIST) {
+                                    int const d0 = lds.lnk[p - lo];
+                                    c = p - d0;
+                                    if (d0 != 0) {
                                         nice = lookahead < 128 ? lookahead : 128;
                                         maxlen = lookahead < KD_MAX_MATCH ? lookahead : KD_MAX_MATCH;
                                         so = p - lo;                              // scan offset in the staged window
@@ -211,7 +216,8 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                     for (int rep = 0; rep < reps; rep++) {
                         if (active) {
                             int const mo = c - lo;
-                            int const cnext = lds.lnk[mo];
+                            int const dn = lds.lnk[mo];
+                            int const cnext = dn ? c - dn : 0;                 // 0: the chain ends (position 0 is zlib's NIL)
                             bool done = false;
                             steps++;
                             // the candidate can only win if it matches at the current best length too (most fail here)
@@ -233,11 +239,11 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                                     else scanEnd = kd_ld16(lds.sw, so + bestLen - 1);
                                 }
                             }
-                            if (steps == 32 || (done && steps < 32)) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
+                            if (steps == 32 || (done && steps < 32)) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.dist32 = (u16)(p - bestPos); }
                             c = cnext;
                             if (done || !(c > limit && steps < maxSteps)) {
-                                if (steps < 32 && !done) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.pos32 = (u16)bestPos; }
-                                r.len128 = (u16)(bestLen > 2 ? bestLen : 0); r.pos128 = (u16)bestPos;
+                                if (steps < 32 && !done) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.dist32 = (u16)(p - bestPos); }
+                                r.len128 = (u16)(bestLen > 2 ? bestLen : 0); r.dist128 = (u16)(p - bestPos);
                                 best[p] = r;
                                 active = false;
                             }
@@ -258,36 +264,46 @@ KX_DEV void deflate_parse_body(const KdArgs& a)
     u32 const slice = kx_block() * 64u + (u32)kx_lane();
     if (slice >= a.n_slices) return;
     const u8* const src = a.src + a.in_off[slice]; int const n = (int)a.in_len[slice];
-    const KdBest* const best = a.best + (size_t)slice * 65536u;
-    u32* const syms = a.syms + (size_t)slice * 65536u;
+    const KdBest* const best = a.best + (size_t)slice * a.pos_cap;
+    u32* const syms = a.syms + (size_t)slice * a.pos_cap;
+    KdBlockInfo* const blocks = a.blocks + (size_t)slice * a.blk_cap;
     KdSliceMeta mm; mm.nblocks = 0; mm.nsym = 0; mm.pad[0] = 0; mm.pad[1] = 0;
-    for (int i = 0; i < KD_MAX_BLOCKS; i++) { mm.blk[i].nsym_end = 0; mm.blk[i].end_pos = 0; mm.blk[i].start_pos = 0; mm.blk[i].stored_ok = 0; }
-    int strstart = 0; int match_length = 2, prev_length = 2; int match_start = 0, prev_match = 0; bool match_available = false;
-    u32 nsym = 0, blockSyms = 0; int block_start = 0; int slide = 0;        // slide = 32768 once zlib's window has moved
-#define KD_FLUSH(last_) { KdBlockInfo& b_ = mm.blk[mm.nblocks < KD_MAX_BLOCKS ? mm.nblocks : KD_MAX_BLOCKS - 1]; \
-        b_.nsym_end = nsym; b_.end_pos = (u32)strstart; b_.start_pos = (u32)block_start; b_.stored_ok = (block_start - slide >= 0) ? 1u : 0u; \
+    int strstart = 0; int match_length = 2, prev_length = 2; int match_dist = 0, prev_dist = 0; bool match_available = false;
+    u32 nsym = 0, blockSyms = 0; int block_start = 0;
+    // zlib's 64 KiB window buffer: it holds the bytes [base, dataEnd) of the slice; fill_window tops it up when fewer than
+    // MIN_LOOKAHEAD bytes lie ahead, after moving everything down by 32 KiB once strstart has reached WSIZE + MAX_DIST.
+    // Only one thing depends on it here: a block whose start has left the buffer cannot be emitted as a stored block.
+    int base = 0, dataEnd = n < 2 * KD_WSIZE ? n : 2 * KD_WSIZE;
+#define KD_FLUSH(last_) { KdBlockInfo b_; \
+        b_.nsym_end = nsym; b_.end_pos = (u32)strstart; b_.start_pos = (u32)block_start; b_.stored_ok = (block_start - base >= 0) ? 1u : 0u; \
+        if (mm.nblocks < a.blk_cap) blocks[mm.nblocks] = b_; \
         mm.nblocks++; block_start = strstart; blockSyms = 0; }
 #define KD_TALLY(dist_, lc_) { syms[nsym++] = (u32)(dist_) | ((u32)(lc_) << 16); blockSyms++; }
     for (;;) {
-        int const lookahead = n - strstart;
-        if (lookahead < KD_MIN_LOOKAHEAD) {
-            if (strstart >= KD_WSIZE + KD_MAX_DIST && !slide) slide = KD_WSIZE;       // fill_window moves the window once
-            if (lookahead == 0) break;
+        if (dataEnd - strstart < KD_MIN_LOOKAHEAD) {
+            do {                                                                       // fill_window
+                int more = 2 * KD_WSIZE - (dataEnd - base);
+                if (strstart - base >= KD_WSIZE + KD_MAX_DIST) { base += KD_WSIZE; more += KD_WSIZE; }
+                if (dataEnd == n) break;
+                dataEnd += (n - dataEnd < more) ? n - dataEnd : more;
+            } while (dataEnd - strstart < KD_MIN_LOOKAHEAD && dataEnd != n);
+            if (dataEnd == strstart) break;
         }
-        prev_length = match_length; prev_match = match_start;
+        int const lookahead = n - strstart;          // (what lies ahead in the buffer is this, or at least MIN_LOOKAHEAD > MAX_MATCH)
+        prev_length = match_length; prev_dist = match_dist;
         match_length = KD_MIN_MATCH - 1;
         if (lookahead >= KD_MIN_MATCH && prev_length < 16) {
             // longest_match starts from best_len = prev_length, so only a longer match changes anything;
             // a previous match >= good_match (8) shortens the chain walk to 32 steps
             KdBest const r = best[strstart];
-            int const len = prev_length >= 8 ? r.len32 : r.len128, pos = prev_length >= 8 ? r.pos32 : r.pos128;
+            int const len = prev_length >= 8 ? r.len32 : r.len128, dist = prev_length >= 8 ? r.dist32 : r.dist128;
             if (len > prev_length) {
-                match_length = len; match_start = pos;
-                if (match_length == KD_MIN_MATCH && strstart - match_start > KD_TOO_FAR) match_length = KD_MIN_MATCH - 1;
+                match_length = len; match_dist = dist;
+                if (match_length == KD_MIN_MATCH && match_dist > KD_TOO_FAR) match_length = KD_MIN_MATCH - 1;
             }
         }
         if (prev_length >= KD_MIN_MATCH && match_length <= prev_length) {
-            KD_TALLY(strstart - 1 - prev_match, prev_length - KD_MIN_MATCH)
+            KD_TALLY(prev_dist, prev_length - KD_MIN_MATCH)
             bool const bflush = blockSyms == KD_LIT_BUFSIZE - 1;
             strstart += prev_length - 1;
             match_available = false; match_length = KD_MIN_MATCH - 1;

@@ -152,6 +152,7 @@ struct kmp_batch_ctx {
     hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join, ev_last_match; int have_last_match; u32 last_chunks;
     // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
     u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta;      // two halves of dfl_chunk slices each
+    u32 dfl_pos_cap, dfl_blk_cap; KdBlockInfo* dfl_blocks;                                      // positions / blocks per slice in them
     hipEvent_t dfl_searched[2], dfl_done[2]; int dfl_events;
     // frames of several blocks (max_slice_bytes above 128 KiB): per-slice state carried between the block rounds
     // raw-content dictionary of the last kmp_zstd_compress_batch_dict call: device copy + CDict tables (built on the host)
@@ -252,7 +253,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     (void)hipFree(c->len_ok); (void)hipFree(c->d_status);
     if (c->st2) (void)hipStreamDestroy(c->st2);
-    (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta);
+    (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta); (void)hipFree(c->dfl_blocks);
     if (c->dfl_events) for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->dfl_searched[i]); (void)hipEventDestroy(c->dfl_done[i]); }
     delete c;
 }
@@ -702,12 +703,18 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
         // Two workspace halves of up to 16 384 slices each (28 GiB of the 288 GB for both): while the search kernels
         // (chains, best: LDS-bound) work on one piece of the batch, the parse (one lane per slice, pure latency, no LDS)
         // and the encoder of the previous piece run beside them on the context's second stream.
-        u32 const cap = c->knob.dfl_chunk ? c->knob.dfl_chunk : 16384u;
+        // (14 bytes of workspace per position: link, best, symbol; the pieces hold 2^30 positions each at most)
+        u32 const pos_cap = ((c->max_slice_bytes < 65536u ? 65536u : c->max_slice_bytes) + 63u) & ~63u;
+        u32 cap = c->knob.dfl_chunk ? c->knob.dfl_chunk : 16384u;
+        if ((u64)cap * pos_cap > (1ull << 30)) cap = (u32)((1ull << 30) / pos_cap);
+        if (cap < 1) cap = 1;
         u32 const chunk = c->max_slices < cap ? c->max_slices : cap;
-        HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)2 * chunk * 65536u * sizeof(u16)));
-        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * chunk * 65536u * sizeof(KdBest)));
-        HIP_TRY(hipMalloc((void**)&c->dfl_syms, (size_t)2 * chunk * 65536u * sizeof(u32)));
+        c->dfl_pos_cap = pos_cap; c->dfl_blk_cap = pos_cap / (KD_LIT_BUFSIZE - 1) + 2u;
+        HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)2 * chunk * pos_cap * sizeof(u16)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * chunk * pos_cap * sizeof(KdBest)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_syms, (size_t)2 * chunk * pos_cap * sizeof(u32)));
         HIP_TRY(hipMalloc((void**)&c->dfl_meta, (size_t)2 * chunk * sizeof(KdSliceMeta)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_blocks, (size_t)2 * chunk * c->dfl_blk_cap * sizeof(KdBlockInfo)));
         for (int i = 0; i < 2; i++) {
             HIP_TRY(hipEventCreateWithFlags(&c->dfl_searched[i], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&c->dfl_done[i], hipEventDisableTiming));
@@ -715,7 +722,8 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
         c->dfl_events = 1;
         c->dfl_chunk = chunk;
     }
-    KMP_TRY(batch_begin(c, st, d_in_len, n, KD_MAX_SLICE));
+    u32 const dfl_cap = c->max_slice_bytes < 65536u ? 65536u : c->max_slice_bytes;       // a context for smaller slices still takes 64 KiB ones
+    KMP_TRY(batch_begin(c, st, d_in_len, n, dfl_cap));
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[6], st));
     u32 chain_waves = c->knob.dfl_chain_waves; if (chain_waves < 1 || chain_waves > 4) chain_waves = 4;
     bool const serial = c->knob.dfl_serial != 0;          // experiment switch: everything on the caller's stream
@@ -725,8 +733,10 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
         u32 const h = piece & 1u;                                        // workspace half
         KdArgs a;
         a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = c->len_ok + first; a.n_slices = m;
-        a.link = c->dfl_link + (size_t)h * c->dfl_chunk * 65536u; a.best = c->dfl_best + (size_t)h * c->dfl_chunk * 65536u;
-        a.syms = c->dfl_syms + (size_t)h * c->dfl_chunk * 65536u; a.meta = c->dfl_meta + (size_t)h * c->dfl_chunk;
+        size_t const half = (size_t)h * c->dfl_chunk;
+        a.pos_cap = c->dfl_pos_cap; a.blk_cap = c->dfl_blk_cap;
+        a.link = c->dfl_link + half * c->dfl_pos_cap; a.best = c->dfl_best + half * c->dfl_pos_cap;
+        a.syms = c->dfl_syms + half * c->dfl_pos_cap; a.meta = c->dfl_meta + half; a.blocks = c->dfl_blocks + half * c->dfl_blk_cap;
         a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
         bool const prof = c->profiling && first == 0;      // per-kernel events for the first piece
         hipStream_t const s2 = serial ? st : c->st2;
@@ -750,7 +760,7 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
         if (piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[1], 0));
     }
     if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[7], st)); c->ev_valid[3] = 1; }
-    return batch_end(c, st, d_in_len, n, KD_MAX_SLICE, d_out_len, nullptr);
+    return batch_end(c, st, d_in_len, n, dfl_cap, d_out_len, nullptr);
 }
 
 // per-kernel milliseconds of the first workspace chunk of the last deflate batch: chains, best, parse, encode
@@ -1009,9 +1019,9 @@ extern "C" int kmp_zlib_compress_stream(kmp_zlib_cstream* z, void* dst, size_t d
     if (z->stage == 0) {
         size_t const avail = src_size - *src_pos;
         if (avail) { const u8* p = (const u8*)src + *src_pos; z->in.insert(z->in.end(), p, p + avail); *src_pos = src_size; }
-        if (z->in.size() > KD_MAX_SLICE) return Z_MEM_ERROR_;          // slices above 64 KiB: not on the GPU path yet
+        if (z->in.size() > KD_MAX_SLICE) return Z_MEM_ERROR_;          // streams above 1 GiB are not served
         if (!finish) return avail ? Z_OK_ : Z_BUF_ERROR_;
-        if (!stream_dev_select(z->dev) || stream_dev_init(z->dev)) return Z_MEM_ERROR_;
+        if (!stream_dev_select(z->dev) || stream_dev_init(z->dev, z->in.size())) return Z_MEM_ERROR_;
         stream_dev& s = z->dev;
         u64 offs[2] = { 0, 0 }; u32 len = (u32)z->in.size(), olen = 0;
         if (len && hipMemcpy(s.d_in, z->in.data(), len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;

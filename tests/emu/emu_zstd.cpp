@@ -282,12 +282,17 @@ extern "C" __attribute__((visibility("default")))
 int emu_deflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* dst, const u64* out_off, u32* out_len,
                 u16* link_out, KdBest* best_out, u32 format)
 {
-    std::vector<u16> link((size_t)n * 65536u, 0xEEEE);
-    std::vector<KdBest> best((size_t)n * 65536u);
-    std::vector<u32> syms((size_t)n * 65536u, 0xDDDDDDDDu);
+    u32 maxlen = 65536u;
+    for (u32 i = 0; i < n; i++) if (in_len[i] > maxlen) maxlen = in_len[i];
+    u32 const pos_cap = (maxlen + 63u) & ~63u, blk_cap = pos_cap / (KD_LIT_BUFSIZE - 1) + 2u;
+    std::vector<u16> link((size_t)n * pos_cap, 0xEEEE);
+    std::vector<KdBest> best((size_t)n * pos_cap);
+    std::vector<u32> syms((size_t)n * pos_cap, 0xDDDDDDDDu);
     std::vector<KdSliceMeta> meta(n);
+    std::vector<KdBlockInfo> blocks((size_t)n * blk_cap);
     KdArgs a;
     a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
+    a.pos_cap = pos_cap; a.blk_cap = blk_cap; a.blocks = blocks.data();
     a.link = link.data(); a.best = best.data(); a.syms = syms.data(); a.meta = meta.data();
     a.dst = dst; a.out_off = out_off; a.out_len = out_len; a.flags = 0; a.format = format;
     kxemu::failed = 0;

@@ -55,6 +55,12 @@ def main():
         if len(f) <= 400:
             row["stream"] = base64.b64encode(f).decode()
         out["special"].append(row)
+    # slices above 64 KiB: zlib's window slides (helpers.deflate_long_inputs)
+    from helpers import deflate_long_inputs
+    out["long"] = []
+    for name, d in deflate_long_inputs():
+        f = raw6(d)
+        out["long"].append({"name": name, "size": len(d), "input_sha256": hashlib.sha256(d).hexdigest(), "len": len(f), "sha256": hashlib.sha256(f).hexdigest()})
     # the reference's only compress-side known-answer vector (ZlibTest.kt:66-84): zlib format, default level;
     # its raw DEFLATE body is what level 6 raw must produce for the same text
     kat = base64.b64decode("eJzLSM3JyVdIzs8tKEotLs7Mz1Mozy/KSQEAbW0JLw==")

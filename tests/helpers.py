@@ -93,6 +93,34 @@ def beyond_window_inputs():
     return [(f"beyond_{n}", build(n)) for n in sizes]
 
 
+def deflate_long_inputs():
+    """Seeded DEFLATE inputs above 64 KiB (zlib's window slides many times): sizes around the slide points
+    (k x 32 KiB + 32 506), the reference's own round-trip size (1 MiB + 3 random bytes, ZlibTest.kt:16,28-33), runs, far
+    copies.  (name, bytes); same list tests/golden/make_golden_deflate.py used."""
+    import random
+    from kompressor_amd import corpus
+    rng = random.Random(20261005)
+
+    def build(n):
+        out = bytearray()
+        while len(out) < n:
+            r = rng.random()
+            if r < 0.25 and len(out) > 1000:
+                a = rng.randrange(0, len(out))
+                out += out[a:a + rng.randrange(10, 100000)]
+            elif r < 0.32:
+                out += bytes([rng.randrange(256)]) * rng.randrange(1, 100000)
+            else:
+                out += corpus.make(rng.randrange(1 << 30), 1, rng.randrange(100, 200000), mix=ord(rng.choice("TXSBDIZR"))).tobytes()
+        return bytes(out[:n])
+
+    sizes = [65537, 65274 + 262, 98042, 98043, 131072, 200000, 300001, 32768 * 9 + 32506, 777777, 1 << 20]
+    out = [(f"long_{n}", build(n)) for n in sizes]
+    out.append(("random_1m_plus_3", np.random.default_rng(1).integers(0, 256, (1 << 20) + 3, dtype=np.uint8).tobytes()))
+    out.append(("zeros_1m", bytes(1 << 20)))
+    return out
+
+
 def buffered_golden():
     with open(os.path.join(os.path.dirname(GOLDEN_PATH), "zstd_l3_buffered_golden.json")) as fh:
         return json.load(fh)
@@ -475,7 +503,8 @@ def emu_deflate(datas, zlib_wrapper=False, fmt=None):
     buf = np.zeros(pos + 64, dtype=np.uint8)
     for i, d in enumerate(datas):
         buf[int(offs[i]):int(offs[i]) + len(d)] = np.frombuffer(d, dtype=np.uint8)
-    stride = 66000
+    big = max([len(d) for d in datas] + [65536])
+    stride = (big + (big >> 12) + (big >> 14) + 64 + 63) & ~63
     out = np.zeros(n * stride, dtype=np.uint8)
     ooff = np.arange(n, dtype=np.uint64) * stride
     olen = np.zeros(n, dtype=np.uint32)

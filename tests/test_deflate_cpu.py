@@ -136,3 +136,29 @@ def test_emulated_gzip_wrapper_and_autodetect():
     not_gz = bytearray(good); not_gz[1] = 0x8C
     dec, st = helpers.emu_inflate([bytes(bad_crc), bytes(bad_len), bytes(not_gz), good[:-12], good], [5000, 5000, 5000, 5000, 100], fmt=2)
     assert st[0] == -3 and st[1] == -3 and st[2] == -3 and st[3] != 0 and st[4] == -5
+
+
+def test_long_slices_oracle_and_emulated_kernels_match_zlib():
+    """Slices above 64 KiB: zlib's window slides every 32 KiB (candidates end at MAX_DIST, a block whose start has left the
+    buffer cannot be stored).  The oracle and the four kernel bodies (links and match records as distances, 32-bit
+    positions, the parse's model of fill_window) against the committed zlib streams of 12 inputs up to 1 MiB + 3 -- the
+    reference's own round-trip size (ZlibTest.kt:16,28-33) -- and against Python's zlib live."""
+    G = helpers.deflate_golden()
+    o = helpers.deflate_oracle()
+    inputs = helpers.deflate_long_inputs()
+    rows = {r["name"]: r for r in G["long"]}
+    for name, d in inputs:
+        r = rows[name]
+        assert len(d) == r["size"] and helpers.sha256(d) == r["input_sha256"], name
+        f = o.compress(d)
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], ("oracle", name)
+        if zlib.ZLIB_RUNTIME_VERSION == G["zlib"]:
+            assert f == raw6(d), name
+    outs = helpers.emu_deflate([d for _, d in inputs])
+    for (name, d), f in zip(inputs, outs):
+        assert len(f) == rows[name]["len"] and helpers.sha256(f) == rows[name]["sha256"], ("kernels", name)
+    # the wrappers' checksums run over the whole slice
+    d = inputs[5][1]
+    assert helpers.emu_deflate([d], fmt=1)[0] == zlib.compress(d, 6)
+    c = zlib.compressobj(6, zlib.DEFLATED, 31, 8, 0)
+    assert helpers.emu_deflate([d], fmt=2)[0] == c.compress(d) + c.flush()

@@ -95,8 +95,10 @@ def test_zlib_streaming_abi_like_the_reference():
         ZlibDecompressor(ZlibFormat.Zlib).transform_bytes(zd[:-1] + bytes([zd[-1] ^ 1]))
     with pytest.raises(RuntimeError, match="Failed allocating zlib stream"):
         ZlibCompressor(ZlibFormat.Zlib, 9)                 # other levels stay on the CPU library
-    with pytest.raises(RuntimeError, match="Bad zlib result code -4: Z_MEM_ERROR"):
-        ZlibCompressor(ZlibFormat.Raw, 6).transform_bytes(bytes(65537))
+    # above 64 KiB zlib's window slides; the reference's own round trip is 1 MiB + 3 random bytes (ZlibTest.kt:16,28-33)
+    rnd = np.random.default_rng(1).integers(0, 256, (1 << 20) + 3, dtype=np.uint8).tobytes()
+    zr = ZlibCompressor(ZlibFormat.Zlib, 6).transform_bytes(rnd)
+    assert zr == zlib.compress(rnd, 6) and ZlibDecompressor(ZlibFormat.Zlib).transform_bytes(zr) == rnd
 
 
 def test_inflate_batch_roundtrip_and_foreign_streams(batch):
@@ -318,7 +320,7 @@ def test_oversized_slices_are_refused_not_overrun():
     """Lengths live on the device: a slice above 64 KiB handed to deflate gets out_len 0 and raises the context's status
     word; its neighbours come out right."""
     from kompressor_amd.batch import ZstdBatch
-    b = ZstdBatch(max_slices=8, max_slice_bytes=131072)
+    b = ZstdBatch(max_slices=8, max_slice_bytes=65536)
     try:
         datas = [corpus.make(5 + i, 1, sz).tobytes() for i, sz in enumerate([1000, 70000, 65536, 131072, 3])]
         outs = gpu_deflate(b, datas)
@@ -331,5 +333,40 @@ def test_oversized_slices_are_refused_not_overrun():
                 c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, 0)
                 assert f == c.compress(d) + c.flush()
         assert b.status() == (0, 0)                       # cleared by the read
+    finally:
+        b.close()
+
+
+def test_long_slices_match_zlib_on_the_gpu():
+    """Slices above 64 KiB (zlib's window slides): the 12 committed long inputs (tests/golden/deflate_l6_golden.json "long",
+    up to 1 MiB + 3) and a ragged batch of 64 slices of 64 KiB .. 700 KiB against the host's zlib, all three formats for
+    some; inflate brings them back."""
+    from kompressor_amd.batch import ZstdBatch
+    G = helpers.deflate_golden()
+    inputs = helpers.deflate_long_inputs()
+    rows = {r["name"]: r for r in G["long"]}
+    rng = np.random.default_rng(77)
+    ragged = [corpus.make(9000 + i, 1, int(rng.integers(65536, 700000)), mix=ord("TXSBDIZR"[i % 8])).tobytes() for i in range(64)]
+    b = ZstdBatch(max_slices=80, max_slice_bytes=(1 << 20) + 64)
+    try:
+        outs = gpu_deflate(b, [d for _, d in inputs] + ragged)
+        assert b.status() == (0, 0)
+        for (name, d), f in zip(inputs, outs):
+            assert len(f) == rows[name]["len"] and helpers.sha256(f) == rows[name]["sha256"], name
+        for d, f in zip(ragged, outs[len(inputs):]):
+            c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, 0)
+            assert f == c.compress(d) + c.flush(), len(d)
+        # back through the GPU inflate
+        n = len(outs)
+        lens = np.array([len(f) for f in outs], dtype=np.int32)
+        offs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
+        host = np.frombuffer(b"".join(outs) + bytes(64), dtype=np.uint8).copy()
+        caps = torch.tensor([len(d) for _, d in inputs] + [len(d) for d in ragged], dtype=torch.int32).cuda()
+        dst, ooff, olen, st = b.inflate(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), caps)
+        torch.cuda.synchronize()
+        assert int(st.abs().sum().item()) == 0
+        dd, oo, ol = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+        for i, d in enumerate([d for _, d in inputs] + ragged):
+            assert dd[oo[i]:oo[i] + ol[i]].tobytes() == d, i
     finally:
         b.close()
