@@ -61,7 +61,13 @@ KMP_API size_t kmp_zstd_cctx_load_dictionary(kmp_zstd_cctx* cctx, const void* di
  * Same buffer semantics as ZSTD_inBuffer / ZSTD_outBuffer: `*_size` is the
  * end-exclusive index, `*_pos` the cursor, both into the whole array
  * (Wrapper.cpp:101-110).  Returns 0 when the frame is completely flushed,
- * >0 = bytes still to flush, or an error code. */
+ * >0 = bytes still to flush, or an error code.
+ * The frame is the one libzstd 1.5.7 writes under the same calls, which above 128 KiB depends on them: when the call
+ * that ends the input (e_end) finds libzstd's staging buffer empty and room for ZSTD_compressBound of what it brought,
+ * the caller's memory is compressed in place (ZSTD_compress2's frame); otherwise -- the reference's driver, whose output
+ * slices hold max(8192, n / 10) bytes -- the input is staged in chunks of 128 KiB (kmp_zstd_compress_batch_reference),
+ * and data that arrived with e_continue makes it a streaming frame (no content size).  Input is collected until e_end;
+ * streams up to 1 GiB (level 1: 512 KiB, level 2: 128 KiB one-shot). */
 KMP_API size_t kmp_zstd_compress_stream(kmp_zstd_cctx* cctx,
                                         void* dst, size_t dst_size, size_t* dst_pos,
                                         const void* src, size_t src_size, size_t* src_pos,
@@ -76,7 +82,7 @@ KMP_API size_t kmp_zstd_free_dctx(kmp_zstd_dctx* dctx);
 KMP_API size_t kmp_zstd_dctx_load_dictionary(kmp_zstd_dctx* dctx, const void* dict, size_t dict_size);
 /* replaces ZSTD_decompressStream      (Wrapper.cpp:142-187, call at :178).
  * Returns 0 when a frame is completely decoded and flushed, otherwise a
- * hint (>0) or an error code. */
+ * hint (>0) or an error code.  A frame is decoded when all of it has arrived; content up to 1 GiB. */
 KMP_API size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* dctx,
                                           void* dst, size_t dst_size, size_t* dst_pos,
                                           const void* src, size_t src_size, size_t* src_pos);
@@ -86,8 +92,8 @@ KMP_API size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* dctx,
  * (deflate, call at :73).  Same cursor semantics; the return value is zlib's: Z_OK 0, Z_STREAM_END 1,
  * Z_BUF_ERROR -5 are benign for the Kotlin side (ZlibCompressor.jvm.kt:49-56).  The GPU path implements
  * level 6 (or -1), windowBits -15 (ZlibFormat.Raw), 15 (ZlibFormat.Zlib: 78 9C header + Adler-32) or
- * 31 (ZlibFormat.Gzip: 10-byte header, CRC-32 + ISIZE), memLevel 8, strategy 0 and slices <= 64 KiB;
- * other settings (other levels, smaller windows) make create return NULL. */
+ * 31 (ZlibFormat.Gzip: 10-byte header, CRC-32 + ISIZE), memLevel 8, strategy 0, streams up to 1 GiB (the stream is
+ * compressed when the caller finishes it); other settings (other levels, smaller windows) make create return NULL. */
 typedef struct kmp_zlib_cstream kmp_zlib_cstream;
 typedef struct kmp_zlib_dstream kmp_zlib_dstream;
 KMP_API kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bits, int mem_level, int strategy);
