@@ -510,6 +510,18 @@ def main():
                           "slices_per_gpu": n, "slice_bytes": SLICE, "ratio": round(in_bytes / frame_bytes, 4)},
                "roofline": {"bound": "hbm", "kernel": "k_zstd_big (one launch per step: every wave walks the block chains of its slices)", "achieved": round(algo_bytes / (ms_step * 1e-3) / 1e9, 2),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}}
+        # HBM bytes from the PMC passes of tools/profile_round.sh, when this is the configuration they were collected on
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+            tag, kern = None, None
+            if dictionary and args.dict_kib == 16 and n == 65536 and SLICE == 65536: tag, kern = "dict16", "k_zstd_match_dict"
+            elif args.level == 1 and n == 65536 and SLICE == 65536: tag, kern = "level1", "k_zstd_match_fast"
+            elif args.level == 3 and not dictionary and SLICE == 262144 and n == 32768: tag, kern = "big256k", "k_zstd_big"
+            elif args.level == 3 and not dictionary and SLICE == 1048576 and n == 8192: tag, kern = "big1m", "k_zstd_big"
+            if tag:
+                res["roofline"]["traffic"] = pj.get(f"{tag}:{kern}_hbm_bytes_per_launch")
+        except Exception:
+            pass
         if dictionary:
             res["roofline"]["kernel"] = "k_zstd_match_dict + k_zstd_entropy (one launch each per step)"
         if args.level != 3:

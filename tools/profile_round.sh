@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round profile on the GPU box: rocprofv3 kernel stats for each bench mode + separate PMC passes for the compress step.
-# Usage (through gpurun): bash tools/profile_round.sh   -> gpurun_out/prof/
+# Usage (through gpurun): bash tools/profile_round.sh [name]   -> gpurun_out/prof/, summary gpurun_out/prof_summary/<name>.txt
+NAME=${1:-r02_final}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
@@ -26,8 +27,17 @@ for mode in decompress deflate; do
     timeout -k 10 300 rocprofv3 --pmc $ctr -d $d -o run -- python3 $R/bench.py --mode $mode --steps 1 --warmup 0 --no-cpu $extra > $d.out 2>> $O/log.txt || echo "pmc pass $mode $ctr failed" >> $O/log.txt
   done
 done
-ls -R $O | head -80 >> $O/log.txt
+# ... and of the other parsers: levels 1 / 2 ("fast"), the dictionary parser, the block-chain kernel (frames of several blocks)
+pmc3() { tag=$1; shift; for ctr in FETCH_SIZE WRITE_SIZE; do
+    d=$O/pmc3_${tag}_$ctr; echo "== pmc $tag $ctr" >> $O/log.txt
+    timeout -k 10 300 rocprofv3 --pmc $ctr -d $d -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu "$@" > $d.out 2>> $O/log.txt || echo "pmc pass $tag $ctr failed" >> $O/log.txt
+  done; }
+pmc3 level1 --level 1
+pmc3 dict16 --dict-kib 16
+pmc3 big256k --slice-kib 256 --slices 32768
+pmc3 big1m --slice-kib 1024 --slices 8192
+ls -R $O | head -120 >> $O/log.txt
 # summarise here (the result databases exceed what gpurun carries back), keep only text
-cd $R && python3 tools/summarize_profiles.py r01_final $R/gpurun_out/prof_summary > /dev/null 2>> $O/log.txt
+cd $R && python3 tools/summarize_profiles.py $NAME $R/gpurun_out/prof_summary > /dev/null 2>> $O/log.txt
 find $O -name 'run_results.db' -delete
 echo done

@@ -30,7 +30,7 @@ def counters(db):
 
 
 def main():
-    name = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
+    name = sys.argv[1] if len(sys.argv) > 1 else "r02_final"
     # on the GPU box the result databases are too large to travel back: profile_round.sh runs this script there with an
     # output directory under gpurun_out/ and deletes the databases; here the two files are then copied into profiles/
     outdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
@@ -70,6 +70,17 @@ def main():
                 if "k_zstd_decode" in k or "k_deflate" in k or "k_inflate" in k:
                     other[(k.split("(")[0], c)] = (v, n)
                     lines.append(f"{k:40s} {c:24s} {v:.6g}   ({n} launches)")
+    lines.append("")
+    lines.append("## HBM bytes of the other parsers (own runs, bench.py --steps 1 --warmup 0 --no-cpu + --level 1 | --dict-kib 16 | --slice-kib 256 --slices 32768 | --slice-kib 1024 --slices 8192)")
+    third = {}
+    for d in sorted(os.listdir(P)):
+        db = os.path.join(P, d, "run_results.db")
+        if d.startswith("pmc3_") and os.path.exists(db):
+            tag = d[len("pmc3_"):].rsplit("_", 2)[0]
+            for k, c, v, n in counters(db):
+                if any(x in k for x in ("k_zstd_match_fast", "k_zstd_match_dict", "k_zstd_big", "k_zstd_entropy")):
+                    third[(tag, k.split("(")[0].replace("void ", "").split("<")[0], c)] = (v, n)
+                    lines.append(f"[{tag}] {k:50s} {c:14s} {v:.6g}   ({n} launches)")
     open(os.path.join(outdir, name + ".txt"), "w").write("\n".join(lines) + "\n")
     mk = [k for (k, c) in allc if "k_zstd_match" in k and c == "FETCH_SIZE"]
     if mk:
@@ -90,6 +101,11 @@ def main():
                 f, nl2 = other[(kern, "FETCH_SIZE")]
                 w, _ = other[(kern, "WRITE_SIZE")]
                 pj[kern + "_hbm_bytes_per_launch"] = int((f + w) * 1024 / nl2)
+        for (tag, kern, ctr) in list(third):
+            if ctr == "FETCH_SIZE" and (tag, kern, "WRITE_SIZE") in third:
+                f, nl3 = third[(tag, kern, "FETCH_SIZE")]
+                w, _ = third[(tag, kern, "WRITE_SIZE")]
+                pj[f"{tag}:{kern}_hbm_bytes_per_launch"] = int((f + w) * 1024 / nl3)
         pj["note_other_kernels"] = "k_zstd_decode: 65536 frames per launch; k_deflate_* / k_inflate: 16384 slices per launch; (FETCH_SIZE+WRITE_SIZE)*1024 / launches"
         json.dump(pj, open(os.path.join(outdir, "pmc_latest.json"), "w"), indent=1)
     print("\n".join(lines[:60]))
