@@ -89,7 +89,8 @@ def main():
         write, _ = allc[(k, "WRITE_SIZE")]
         line = json.loads(open(os.path.join(P, "compress.json")).read())
         pj = {"source": f"profiles/{name}.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, bench.py --steps 1)",
-              "slices": line["config"]["slices_per_gpu"], "team": line["config"]["team_lanes"], "launches": nl,
+              "slices": line["config"]["slices_per_gpu"], "team": line["config"]["team_lanes"],
+              "launches": line["roofline"].get("launches_per_step", 2), "launches_in_the_counter_pass": nl,
               "zstd_match_fetch_kib": fetch, "zstd_match_write_kib": write,
               "zstd_match_hbm_bytes_per_launch": int((fetch + write) * 1024 / nl),
               "zstd_match_read_requests_per_launch": int(allc.get((k, "TCC_EA0_RDREQ_sum"), (0, 1))[0] / nl),
