@@ -8,6 +8,7 @@
 #include "zstd_match_fast.h"
 #include "zstd_cdict_host.h"
 #include "zstd_decode.h"
+#include "zstd_predecode.h"
 #include "deflate_match.h"
 #include "deflate_encode.h"
 #include "deflate_decode.h"
@@ -63,6 +64,10 @@ __global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 
     else atomicAdd(remaining, 1u);
 }
 __global__ __launch_bounds__(64, 6) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
+// the sequence bitstreams decoded ahead of it, one lane per frame (32 frames per workgroup: their FSE tables fill the LDS)
+__global__ __launch_bounds__(64 * KXP_WAVES) void k_zstd_seq_predecode(KPreArgs a) { zstd_seq_predecode_body(a); }
+// ... and the Huffman-coded literals, one lane per stream (32 frames per workgroup of 128 threads)
+__global__ __launch_bounds__(128) void k_zstd_lit_predecode(KLitArgs a) { zstd_lit_predecode_body(a); }
 
 __global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chains_body(a); }
 __global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_body(a); }
@@ -159,12 +164,15 @@ struct kmp_batch_ctx {
     u8* d_dict; u32* d_dictL; u32* d_dictS; u32 dict_size; u64 dict_hash; u32 cdW, cdH, cdC, cdM;
     int big; int big_G; KFrameState* fstate; u32* hufct; u32* big_tables; u32* remaining; u32* big_counters; u32 last_rounds;
     u32 cus;                                   // compute units of the device
+    // decoder: sequences decoded ahead of k_zstd_decode (allocated on first use; pre_tried: do not try again)
+    u32* pre_stage; KPreBlk* pre_blk; u32* pre_nblk; u32 pre_seq_cap, pre_blk_cap; int pre_tried;
+    u8* pre_lits; KPreLit* pre_lit; u32* pre_nlit; u32 pre_lit_cap;
     u32* len_ok; u32* d_status;                // sanitised slice lengths of the running batch; status word (KMP_STATUS_*)
     // one batch at a time per context: a batch queued on another stream waits for the previous one's last kernel
     hipEvent_t ev_done; int have_done;
     // experiment switches, read from the environment once, when the context is created
     struct { u32 chunks, match_flags, entropy_pad, first_permille, entropy_flags, decode_flags, decode_pad, big_rounds, big_spw,
-                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags; } knob;
+                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre; } knob;
 };
 
 static u32 env_u32(const char* name, u32 dflt)
@@ -233,6 +241,9 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     c->knob.big_rounds = env_u32("KMP_BIG_ROUNDS", 0); c->knob.big_spw = env_u32("KMP_BIG_SLICES_PER_WAVE", 0);
     c->knob.dfl_chunk = env_u32("KMP_DEFLATE_CHUNK", 16384u); c->knob.dfl_chain_waves = env_u32("KMP_DEFLATE_CHAIN_WAVES", 4);
     c->knob.dfl_serial = env_u32("KMP_DEFLATE_SERIAL", 0); c->knob.dfl_flags = env_u32("KMP_DEFLATE_FLAGS", 0);
+    // experiment, off by default (measured slower): bit 0 = sequences decoded ahead of k_zstd_decode
+    // (k_zstd_seq_predecode, one lane per frame), bit 1 = literals (k_zstd_lit_predecode, one lane per stream)
+    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 0);
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return KMP_OK;
@@ -252,6 +263,8 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     if (c->ev_last_match) (void)hipEventDestroy(c->ev_last_match);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     (void)hipFree(c->len_ok); (void)hipFree(c->d_status);
+    (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk);
+    (void)hipFree(c->pre_lits); (void)hipFree(c->pre_lit); (void)hipFree(c->pre_nlit);
     if (c->st2) (void)hipStreamDestroy(c->st2);
     (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta); (void)hipFree(c->dfl_blocks);
     if (c->dfl_events) for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->dfl_searched[i]); (void)hipEventDestroy(c->dfl_done[i]); }
@@ -641,7 +654,44 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
     d.lits = c->lits; d.lit_cap = c->lit_cap; d.flags = c->knob.decode_flags;
     KMP_TRY(batch_begin(c, st, nullptr, n, 0));            // the decoder checks every length itself; lits is shared with the compressors
     d.dict = (const u8*)d_dict; d.dict_size = d_dict ? dict_size : 0u;
+    // staging for the sequences decoded ahead (12 bytes per sequence, a frame of S bytes holds at most S / 3): allocated on
+    // first use; a context whose slices would need more than 64 GiB of it decodes everything in k_zstd_decode, as before
+    if (!c->pre_tried && c->knob.decode_pre) {
+        c->pre_tried = 1;
+        u32 const seq_cap = c->max_slice_bytes / 3u + 64u, blk_cap = c->max_slice_bytes / 8192u + 16u, lit_cap = c->max_slice_bytes + 64u;
+        c->pre_blk_cap = blk_cap;
+        if ((c->knob.decode_pre & 1u) && (u64)c->max_slices * seq_cap * 12ull <= (64ull << 30)) {
+            if (hipMalloc((void**)&c->pre_stage, (size_t)c->max_slices * seq_cap * 12u) == hipSuccess &&
+                hipMalloc((void**)&c->pre_blk, (size_t)c->max_slices * blk_cap * sizeof(KPreBlk)) == hipSuccess &&
+                hipMalloc((void**)&c->pre_nblk, (size_t)c->max_slices * 4u) == hipSuccess) c->pre_seq_cap = seq_cap;
+            else { (void)hipGetLastError(); (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); c->pre_stage = nullptr; c->pre_blk = nullptr; c->pre_nblk = nullptr; }
+        }
+        if ((c->knob.decode_pre & 2u) && (u64)c->max_slices * lit_cap <= (64ull << 30)) {
+            if (hipMalloc((void**)&c->pre_lits, (size_t)c->max_slices * lit_cap) == hipSuccess &&
+                hipMalloc((void**)&c->pre_lit, (size_t)c->max_slices * blk_cap * sizeof(KPreLit)) == hipSuccess &&
+                hipMalloc((void**)&c->pre_nlit, (size_t)c->max_slices * 4u) == hipSuccess) c->pre_lit_cap = lit_cap;
+            else { (void)hipGetLastError(); (void)hipFree(c->pre_lits); (void)hipFree(c->pre_lit); (void)hipFree(c->pre_nlit); c->pre_lits = nullptr; c->pre_lit = nullptr; c->pre_nlit = nullptr; }
+        }
+    }
+    d.pre_stage = nullptr; d.pre_seq_cap = 0; d.pre_blk = nullptr; d.pre_blk_cap = c->pre_blk_cap; d.pre_nblk = nullptr;
+    d.pre_lits = nullptr; d.pre_lit_cap = 0; d.pre_lit = nullptr; d.pre_nlit = nullptr;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[4], st));
+    if (c->pre_lits) {
+        KLitArgs p;
+        p.src = d.src; p.in_off = d_in_off; p.in_len = d_in_len; p.n_slices = n;
+        p.lits = c->pre_lits; p.lit_cap = c->pre_lit_cap; p.rec = c->pre_lit; p.blk_cap = c->pre_blk_cap; p.nrec = c->pre_nlit;
+        hipLaunchKernelGGL(k_zstd_lit_predecode, dim3((n + KXL_FRAMES - 1) / KXL_FRAMES), dim3(128), 0, st, p);
+        HIP_TRY(hipGetLastError());
+        d.pre_lits = c->pre_lits; d.pre_lit_cap = c->pre_lit_cap; d.pre_lit = c->pre_lit; d.pre_nlit = c->pre_nlit;
+    }
+    if (c->pre_stage) {
+        KPreArgs p;
+        p.src = d.src; p.in_off = d_in_off; p.in_len = d_in_len; p.n_slices = n;
+        p.stage = c->pre_stage; p.seq_cap = c->pre_seq_cap; p.blk = c->pre_blk; p.blk_cap = c->pre_blk_cap; p.nblk = c->pre_nblk;
+        hipLaunchKernelGGL(k_zstd_seq_predecode, dim3((n + KXP_FRAMES - 1) / KXP_FRAMES), dim3(64 * KXP_WAVES), 0, st, p);
+        HIP_TRY(hipGetLastError());
+        d.pre_stage = c->pre_stage; d.pre_seq_cap = c->pre_seq_cap; d.pre_blk = c->pre_blk; d.pre_blk_cap = c->pre_blk_cap; d.pre_nblk = c->pre_nblk;
+    }
     hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), c->knob.decode_pad, st, d);   // padding = occupancy experiment only
     HIP_TRY(hipGetLastError());
     if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[5], st)); c->ev_valid[2] = 1; }

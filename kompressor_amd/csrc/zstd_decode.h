@@ -16,7 +16,17 @@
 #pragma once
 #include "zstd_common.h"
 
+// What k_zstd_seq_predecode (zstd_predecode.h: one lane per frame) leaves for a compressed block of an entry's first
+// frame: where its decoded sequences (litLength, matchLength, offset) start in the entry's staging area, how many, whether
+// they are there at all, and the repeat offsets after the block.
+struct KPreBlk { u32 seq_off; u32 nbSeq; u32 ok; u32 rep[3]; u32 pad[2]; };
+// ... and k_zstd_lit_predecode (one lane per Huffman stream): where the block's decoded literals start in the entry's
+// literal staging area, how many, whether they are there
+struct KPreLit { u32 off; u32 regen; u32 ok; u32 pad; };
+
 struct KDecodeArgs {
+    const u32* pre_stage; u32 pre_seq_cap; const KPreBlk* pre_blk; u32 pre_blk_cap; const u32* pre_nblk;   // null / 0: nothing pre-decoded
+    const u8* pre_lits; u32 pre_lit_cap; const KPreLit* pre_lit; const u32* pre_nlit;                      // (records: pre_blk_cap per entry)
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
     u8* dst; const u64* out_off; const u32* out_cap; u32* out_len; u32* status;
     u8* lits; u32 lit_cap;                 // per frame: decoded literals of one block
@@ -155,7 +165,8 @@ KX_DEV u32 kbb_peek(const KBackBits& b, u32 n)
 
 // ---- Huffman table description -> LDS decoding table; returns bytes consumed, 0 on error
 // weights[0..nw) -> decoding table (lane 0). false on an invalid weight set
-KX_DEV bool khuf_fill_dtable(KDecodeLds& lds, u32 nw, u32 tableLog)
+template <class LDS>
+KX_DEV bool khuf_fill_dtable(LDS& lds, u32 nw, u32 tableLog)
 {
     for (u32 i = 0; i < 16; i++) lds.rank[i] = 0;
     for (u32 i = 0; i < nw; i++) lds.rank[lds.weights[i]]++;
@@ -172,7 +183,8 @@ KX_DEV bool khuf_fill_dtable(KDecodeLds& lds, u32 nw, u32 tableLog)
     return true;
 }
 
-KX_DEV u32 khuf_read_dtable(KDecodeLds& lds, const u8* p, u32 size, u32* tableLogOut, u32* nwOut)
+template <class LDS>
+KX_DEV u32 khuf_read_dtable(LDS& lds, const u8* p, u32 size, u32* tableLogOut, u32* nwOut)
 {
     if (size < 1) return 0;
     u32 const hb = p[0]; u32 nw = 0, used;
@@ -222,7 +234,8 @@ KX_DEV u32 khuf_read_dtable(KDecodeLds& lds, const u8* p, u32 size, u32* tableLo
 }
 
 // one lane decodes one Huffman stream of `count` symbols; returns false on corruption
-KX_DEV bool khuf_decode_stream(const KDecodeLds& lds, u32 tableLog, const u8* p, u32 size, u8* out, u32 count)
+template <class LDS>
+KX_DEV bool khuf_decode_stream(const LDS& lds, u32 tableLog, const u8* p, u32 size, u8* out, u32 count)
 {
     KBackBits b;
     if (!kbb_init(b, p, size)) return false;
@@ -361,6 +374,9 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
     u32 pos = 0;                      // bytes of the entry consumed
     u32 op = 0;                       // bytes produced
     u32 nframes = 0;
+    u32 cblk = 0;                     // compressed blocks of the entry's first frame so far (index into the pre-decoded records)
+    u32 const npre = a.pre_nblk ? a.pre_nblk[f] : 0u;
+    u32 const nlitpre = a.pre_nlit ? a.pre_nlit[f] : 0u;
     for (;;) {
     // ---- frame header (every lane computes the same thing) ---------------
     u32 hasContent = 0, checksum = 0; u64 contentSize = 0; u64 windowSize = 0;
@@ -438,6 +454,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             continue;
         }
         // ---- compressed block --------------------------------------------
+        u32 const ord = (nframes == 0) ? cblk++ : 0xFFFFFFFFu;          // index into what the pre-decode kernels left for the entry's first frame
         if (pos + bsize > srcSize || bsize > 128u * 1024u) { err = KZE_SRCSIZE; break; }     // libzstd: "Src size is incorrect" for both
         if (bsize < 2) { err = KZE_CORRUPT; break; }
         const u8* const bp = src + pos; u32 const bend = bsize;
@@ -485,6 +502,14 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             }
             const u8* const sp = bp + lpos + hused; u32 const ssize = comp - hused;
             bool ok = true;
+            // the block's literals may lie decoded in HBM already (k_zstd_lit_predecode); the table above is still kept up
+            // for a later tree-less block that this kernel has to decode itself
+            bool preLit = false;
+            if (ord < nlitpre) {
+                KPreLit const pl = a.pre_lit[(size_t)f * a.pre_blk_cap + ord];
+                if (pl.ok && pl.regen == regen) { litPtr = a.pre_lits + (size_t)f * a.pre_lit_cap + pl.off; preLit = true; }
+            }
+            if (preLit) { /* nothing to decode */ } else
             if (nstreams == 1) {
                 if (lane == 0 && !(a.flags & 1u)) ok = khuf_decode_stream(lds, hufLog, sp, ssize, lits, regen);
             } else {
@@ -525,6 +550,12 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
         kx_sync();
         if (lds.bc[0]) { err = lds.bc[0]; break; }
         u32 const nbSeq = lds.bc[1]; u32 spos = lds.bc[2]; u32 const modes = lds.bc[3];
+        // this block's sequences may lie decoded in HBM already (k_zstd_seq_predecode)
+        const u32* preSeq = nullptr; u32 preRep1 = 0, preRep2 = 0, preRep3 = 0;
+        if (ord < npre) {
+            KPreBlk const pb = a.pre_blk[(size_t)f * a.pre_blk_cap + ord];
+            if (pb.ok && pb.nbSeq == nbSeq && nbSeq) { preSeq = a.pre_stage + ((size_t)f * a.pre_seq_cap + pb.seq_off) * 3u; preRep1 = pb.rep[0]; preRep2 = pb.rep[1]; preRep3 = pb.rep[2]; }
+        }
         if (nbSeq) {
             for (int t = 0; t < 3 && !err; t++) {
                 u32 const mode = (modes >> (6 - 2 * t)) & 3u;
@@ -571,7 +602,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                 u32 const cnt = (nbSeq - done) < 64 ? (nbSeq - done) : 64;
                 // keep >= 176 words (64 sequences x <= 88 bits) of stream below the read position in LDS (254 staged)
                 int const curWord = (int)kx_bcast((u32)bitPos, 0) >> 5;
-                if (sbLo < 0 || (sbLo > 0 && curWord - sbLo < 176)) {
+                if (!preSeq && (sbLo < 0 || (sbLo > 0 && curWord - sbLo < 176))) {
                     int newLo = curWord + 2 - 254; if (newLo < 0) newLo = 0;
                     int hiW = curWord + 2; if (hiW > totalWords) hiW = totalWords;
                     kx_sync();
@@ -586,7 +617,11 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                     sbLo = newLo;
                     kx_sync();
                 }
-                {
+                if (preSeq) {
+                    // decoded ahead of this kernel: 64 sequences are one coalesced load
+                    for (u32 i = (u32)lane; i < 3u * cnt; i += 64) lds.u.q.stage[i] = preSeq[3u * done + i];
+                    if (lane == 0) lds.u.q.stage[192] = 0u;
+                } else {
                     // Every lane runs the loop (the cost of an instruction does not depend on how many lanes are active);
                     // lanes 0, 1, 2 decode the OF, ML and LL field of a sequence at once: one table look-up, one extra-bits
                     // field and one state update per lane instead of three in a row on one lane.  Lanes >= 3 shadow lane 2.
@@ -736,6 +771,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
 #undef KXD_CONTAINER
 #undef KXD_WORD
             if (err) break;
+            if (preSeq) { rep1 = preRep1; rep2 = preRep2; rep3 = preRep3; }      // the repeat offsets after the block, for a later block decoded here
         }
         // remaining literals
         if (a.flags & 2u) litUsed = 0;

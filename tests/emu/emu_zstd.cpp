@@ -252,6 +252,7 @@ int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_le
 }
 
 #include "zstd_decode.h"
+#include "zstd_predecode.h"
 extern "C" __attribute__((visibility("default")))
 int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len, u32 n, u32 nblocks,
                              u8* dst, const u64* out_off, const u32* out_cap, u32* out_len, u32* status, u32 lit_cap,
@@ -270,7 +271,32 @@ int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len
     d.src = src; d.in_off = in_off; d.in_len = in_len; d.n_slices = n;
     d.dst = dst; d.out_off = out_off; d.out_cap = out_cap; d.out_len = out_len; d.status = status;
     d.lits = lits.data(); d.lit_cap = lit_cap; d.flags = 0; d.dict = dict; d.dict_size = dict ? dict_size : 0;
+    // sequences decoded ahead, one lane per frame (what the product does); KXEMU_NO_PRE=1: everything in the decode body
+    u32 const seq_cap = lit_cap / 3u + 64u, blk_cap = lit_cap / 8192u + 16u;
+    std::vector<u32> stage; std::vector<KPreBlk> pblk; std::vector<u32> nblk;
+    d.pre_stage = nullptr; d.pre_seq_cap = 0; d.pre_blk = nullptr; d.pre_blk_cap = 0; d.pre_nblk = nullptr;
     kxemu::failed = 0;
+    if (!getenv("KXEMU_NO_PRE")) {
+        stage.assign((size_t)n * seq_cap * 3u, 0xCDCDCDCDu); pblk.resize((size_t)n * blk_cap); nblk.assign(n, 0u);
+        KPreArgs p;
+        p.src = src; p.in_off = in_off; p.in_len = in_len; p.n_slices = n;
+        p.stage = stage.data(); p.seq_cap = seq_cap; p.blk = pblk.data(); p.blk_cap = blk_cap; p.nblk = nblk.data();
+        kxemu::launch_block((n + KXP_FRAMES - 1) / KXP_FRAMES, KXP_WAVES, [&]() { zstd_seq_predecode_body(p); });
+        if (kxemu::failed) return -2;
+        d.pre_stage = stage.data(); d.pre_seq_cap = seq_cap; d.pre_blk = pblk.data(); d.pre_blk_cap = blk_cap; d.pre_nblk = nblk.data();
+    }
+    std::vector<u8> plits; std::vector<KPreLit> plrec; std::vector<u32> nlit;
+    d.pre_lits = nullptr; d.pre_lit_cap = 0; d.pre_lit = nullptr; d.pre_nlit = nullptr; d.pre_blk_cap = blk_cap;
+    if (!getenv("KXEMU_NO_PRE")) {
+        u32 const plcap = lit_cap + 64u;
+        plits.assign((size_t)n * plcap, 0xABu); plrec.resize((size_t)n * blk_cap); nlit.assign(n, 0u);
+        KLitArgs p;
+        p.src = src; p.in_off = in_off; p.in_len = in_len; p.n_slices = n;
+        p.lits = plits.data(); p.lit_cap = plcap; p.rec = plrec.data(); p.blk_cap = blk_cap; p.nrec = nlit.data();
+        kxemu::launch_block((n + KXL_FRAMES - 1) / KXL_FRAMES, 2, [&]() { zstd_lit_predecode_body(p); });
+        if (kxemu::failed) return -3;
+        d.pre_lits = plits.data(); d.pre_lit_cap = plcap; d.pre_lit = plrec.data(); d.pre_nlit = nlit.data();
+    }
     kxemu::launch(nblocks, [&]() { zstd_decode_body(d); });
     return kxemu::failed ? -1 : 0;
 }

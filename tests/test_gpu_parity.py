@@ -908,3 +908,37 @@ def test_large_stream_like_the_reference_largeSample():
     if z is not None:
         assert f == z.compress_streaming(d, [0, n // 2, n], out_chunk=8192)
     assert hashlib.sha256(ZstdDecompressor().transform_bytes(f)).digest() == hashlib.sha256(d).digest()
+
+
+def test_predecode_kernels_give_the_same_frames(monkeypatch):
+    """The two pre-decode kernels (sequences one lane per frame, literals one lane per Huffman stream; an experiment that is
+    off by default because it measured slower) must not change a byte: the golden frames, foreign-level and
+    multi-block frames, damaged frames and a multi-block batch decode identically with them switched on."""
+    from kompressor_amd.batch import ZstdBatch
+    G = helpers.golden()
+    S = 65536
+    rows = G["config1"][:512]
+    buf = corpus.make(0, len(rows), S)
+    datas = [buf[i * S:(i + 1) * S].tobytes() for i in range(len(rows))]
+    big = [d for _, d in helpers.multiblock_inputs()[20:30]]
+    ref = ZstdBatch(max_slices=600, max_slice_bytes=2 << 20)
+    monkeypatch.setenv("KMP_DECODE_PRE", "3")
+    pre = ZstdBatch(max_slices=600, max_slice_bytes=2 << 20)
+    monkeypatch.delenv("KMP_DECODE_PRE")
+    try:
+        frames = gpu_compress(ref, datas) + gpu_compress_kw(ref, big, reference=True)
+        frames += [base64.b64decode(r["frame"]) for r in G["decode_only"]]
+        rng = np.random.default_rng(5)
+        for k in range(200):                      # damaged frames: same status, same bytes when accepted
+            f = bytearray(frames[k % 512])
+            for _ in range(int(rng.integers(1, 4))):
+                f[int(rng.integers(0, len(f)))] ^= 1 << int(rng.integers(0, 8))
+            frames.append(bytes(f[: int(rng.integers(len(f) // 2, len(f) + 1))]) if k % 3 == 0 else bytes(f))
+        caps = [2 << 20] * len(frames)
+        a, sa = gpu_decompress(ref, frames, caps)
+        b, sb = gpu_decompress(pre, frames, caps)
+        assert sa == sb and a == b
+        assert a[: len(datas)] == datas and a[len(datas): len(datas) + len(big)] == big
+    finally:
+        ref.close()
+        pre.close()
