@@ -56,9 +56,11 @@ struct KdArgs {
 // ---------------------------------------------------------------------------
 // k_deflate_chains: 256 threads per workgroup, head[32768] in LDS
 // ---------------------------------------------------------------------------
+// HEAD: u16 while every slice fits 64 KiB (64 KiB of LDS: two workgroups per CU), u32 for longer ones (128 KiB)
+template <class HEAD>
 KX_DEV void deflate_chains_body(const KdArgs& a)
 {
-    KX_SHARED u32 head[32768];                                   // position + 1 of the last string with that hash, 0 = none
+    KX_SHARED HEAD head[32768];                                  // position + 1 of the last string with that hash, 0 = none
     int const lane = kx_lane(); int const wv = kx_wave(); int const nw = kx_nwaves(); int const tid = wv * 64 + lane; int const nthreads = nw * 64;
     for (u32 slice = kx_block(); slice < a.n_slices; slice += kx_nblocks()) {
         const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
@@ -95,9 +97,9 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
                     if (wv == w) {
                         u32 const old = valid ? head[h] : 0u;
                         kx_lockstep();
-                        if (valid) head[h] = p + 1u;
+                        if (valid) head[h] = (HEAD)(p + 1u);
                         kx_lockstep();
-                        u32 const chk = valid ? head[h] : p + 1u;
+                        u32 const chk = valid ? (u32)head[h] : p + 1u;
                         lk = old;
                         // lanes of this wave that share a bucket: one bucket per round; inside a bucket the nearest
                         // lower lane is the predecessor and the highest lane is the one left in the table
@@ -108,7 +110,7 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
                             if (valid && h == hL) {
                                 u64 const below = grp & ((1ull << lane) - 1ull);
                                 if (below) lk = p + 1u - (u32)(lane - (63 - (int)__builtin_clzll(below)));
-                                if ((grp >> lane) == 1ull) head[h] = p + 1u;          // highest lane of the bucket
+                                if ((grp >> lane) == 1ull) head[h] = (HEAD)(p + 1u);  // highest lane of the bucket
                             }
                             losers &= ~grp;
                         }
@@ -281,12 +283,12 @@ KX_DEV void deflate_parse_body(const KdArgs& a)
 #define KD_TALLY(dist_, lc_) { syms[nsym++] = (u32)(dist_) | ((u32)(lc_) << 16); blockSyms++; }
     for (;;) {
         if (dataEnd - strstart < KD_MIN_LOOKAHEAD) {
-            do {                                                                       // fill_window
-                int more = 2 * KD_WSIZE - (dataEnd - base);
-                if (strstart - base >= KD_WSIZE + KD_MAX_DIST) { base += KD_WSIZE; more += KD_WSIZE; }
-                if (dataEnd == n) break;
-                dataEnd += (n - dataEnd < more) ? n - dataEnd : more;
-            } while (dataEnd - strstart < KD_MIN_LOOKAHEAD && dataEnd != n);
+            // fill_window: one pass is enough (it brings at least 65 536 - strstart bytes, or all that is left)
+            int const rel = strstart - base;
+            int const slide = (rel >= KD_WSIZE + KD_MAX_DIST) ? KD_WSIZE : 0;
+            base += slide;
+            int const more = 2 * KD_WSIZE - (dataEnd - base);
+            dataEnd += (n - dataEnd < more) ? n - dataEnd : more;
             if (dataEnd == strstart) break;
         }
         int const lookahead = n - strstart;          // (what lies ahead in the buffer is this, or at least MIN_LOOKAHEAD > MAX_MATCH)
@@ -313,6 +315,7 @@ KX_DEV void deflate_parse_body(const KdArgs& a)
             if (blockSyms == KD_LIT_BUFSIZE - 1) KD_FLUSH(0)
             strstart++;
         } else { match_available = true; strstart++; }
+        KX_OPAQUE(match_length); KX_OPAQUE(strstart);          // one flat loop: see kx_wave.h
     }
     if (match_available) KD_TALLY(0, src[strstart - 1])
     KD_FLUSH(1)

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(64 * KXP_WAVES) void k_zstd_seq_predecode(KPreArgs 
 // ... and the Huffman-coded literals, one lane per stream (32 frames per workgroup of 128 threads)
 __global__ __launch_bounds__(128) void k_zstd_lit_predecode(KLitArgs a) { zstd_lit_predecode_body(a); }
 
-__global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chains_body(a); }
+__global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chains_body<u16>(a); }          // slices <= 64 KiB
+__global__ __launch_bounds__(256) void k_deflate_chains_long(KdArgs a) { deflate_chains_body<u32>(a); }
 __global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_parse(KdArgs a) { deflate_parse_body(a); }
 __global__ __launch_bounds__(64, 4) void k_deflate_encode(KdArgs a) { deflate_encode_body(a); }
@@ -792,7 +793,8 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
         hipStream_t const s2 = serial ? st : c->st2;
         if (!serial && piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[h], 0));      // this half's previous piece has been encoded
         if (prof) HIP_TRY(hipEventRecord(c->ev[8], st));
-        hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(64u * chain_waves), 0, st, a);
+        if (c->dfl_pos_cap <= 65536u) hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(64u * chain_waves), 0, st, a);
+        else hipLaunchKernelGGL(k_deflate_chains_long, dim3(m), dim3(64u * chain_waves), 0, st, a);
         if (prof) HIP_TRY(hipEventRecord(c->ev[9], st));
         hipLaunchKernelGGL(k_deflate_best, dim3(m), dim3(1024), 0, st, a);
         if (prof) HIP_TRY(hipEventRecord(c->ev[10], st));

@@ -63,6 +63,10 @@ KX_DEV void kx_lds_inc(u32* p) { atomicAdd(p, 1u); }
 KX_DEV u32 kx_lds_add(u32* p, u32 v) { return atomicAdd(p, v); }   // returns the value before
 KX_DEV void kx_lds_or(u32* p, u32 v) { atomicOr(p, v); }
 
+// The optimiser must not look through this value (keeps a lane-serial loop ONE loop: when it threads the paths of an
+// iteration into separate nested loops, the lanes of a wave wait for one another at every inner loop's exit).
+#define KX_OPAQUE(x) __asm__ volatile("" : "+v"(x))
+
 // ---- bit tricks -------------------------------------------------------
 KX_DEV u32 kx_alignbyte(u32 hi, u32 lo, u32 bytes) { return __builtin_amdgcn_alignbyte(hi, lo, bytes); }   // ({hi,lo} >> 8*bytes) & 0xffffffff
 KX_DEV u32 kx_umulhi(u32 a, u32 b) { return __umulhi(a, b); }

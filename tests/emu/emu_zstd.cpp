@@ -322,7 +322,8 @@ int emu_deflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* 
     a.link = link.data(); a.best = best.data(); a.syms = syms.data(); a.meta = meta.data();
     a.dst = dst; a.out_off = out_off; a.out_len = out_len; a.flags = 0; a.format = format;
     kxemu::failed = 0;
-    kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_chains_body(a); });
+    if (pos_cap <= 65536u) kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_chains_body<u16>(a); });
+    else kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_chains_body<u32>(a); });
     if (kxemu::failed) return -1;
     kxemu::launch_block(n < 2 ? n : 2, 16, [&]() { deflate_best_body(a); });
     if (kxemu::failed) return -2;

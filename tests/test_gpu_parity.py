@@ -921,9 +921,9 @@ def test_predecode_kernels_give_the_same_frames(monkeypatch):
     buf = corpus.make(0, len(rows), S)
     datas = [buf[i * S:(i + 1) * S].tobytes() for i in range(len(rows))]
     big = [d for _, d in helpers.multiblock_inputs()[20:30]]
-    ref = ZstdBatch(max_slices=600, max_slice_bytes=2 << 20)
+    ref = ZstdBatch(max_slices=800, max_slice_bytes=2 << 20)
     monkeypatch.setenv("KMP_DECODE_PRE", "3")
-    pre = ZstdBatch(max_slices=600, max_slice_bytes=2 << 20)
+    pre = ZstdBatch(max_slices=800, max_slice_bytes=2 << 20)
     monkeypatch.delenv("KMP_DECODE_PRE")
     try:
         frames = gpu_compress(ref, datas) + gpu_compress_kw(ref, big, reference=True)
