@@ -1942,6 +1942,10 @@ KREF_API size_t kref_zstd_l3_compress_stream(u8* dst, size_t cap, const u8* src,
 /* so the room at a wrap is outChunk - produced % outChunk); tailDirect =   */
 /* for a stream, the bytes the closing call brought when that applied to    */
 /* it (they must start on a lap boundary), else 0.                          */
+/* knownSize = 2: no staging at all -- ZSTD_compress2 into a buffer of      */
+/* ZSTD_compressBound bytes compresses the caller's array in place, as one  */
+/* chunk (kref_zstd_l3_compress's frames, here for any length: beyond 2 MiB */
+/* only the window's low limit moves).                                      */
 /* ================================================================== */
 typedef struct { u32 lowLimit, dictLimit; } kref_window;
 
@@ -1974,10 +1978,10 @@ KREF_API size_t kref_zstd_l3_compress_buffered(u8* dst, size_t cap, const u8* sr
                 if (room >= r + (r >> 8) + (r < blockSizeMax ? (blockSizeMax - r) >> 11 : 0)) tail = 1;
             } else if (!knownSize && tailDirect && ipos + tailDirect == srcSize) tail = 1;
         }
-        chunkEnd = (!tail && ipos + blockSizeMax < srcSize) ? ipos + blockSizeMax : srcSize;     /* chunks start at multiples of 128 KiB */
+        chunkEnd = (!tail && knownSize != 2 && ipos + blockSizeMax < srcSize) ? ipos + blockSizeMax : srcSize;     /* chunks start at multiples of 128 KiB */
         chunkLen = chunkEnd - ipos;
         lastChunk = (chunkEnd == srcSize) && !emptyEnd;
-        if (ipos == blockSizeMax) savings -= (int64_t)hdr;                /* the frame header counts as produced from the second chunk on */
+        if (ipos == blockSizeMax && knownSize != 2) savings -= (int64_t)hdr;                /* the frame header counts as produced from the second chunk on */
         /* ZSTD_window_update for the chunk at inBuff + bufPos */
         if (ipos != 0 && bufPos == 0) {                                     /* the chunk is not contiguous with the previous one: new segment */
             win.lowLimit = win.dictLimit;

@@ -40,6 +40,9 @@ def main():
         row = {"name": name, "size": n, "input_sha256": hashlib.sha256(d).hexdigest(),
                "oneshot_len": len(one), "oneshot_sha256": hashlib.sha256(one).hexdigest(),
                "stream_len": len(stream), "stream_sha256": hashlib.sha256(stream).hexdigest()}
+        if n > (2 << 20):                # ZSTD_compress2 into a bound-sized buffer beyond the window (below it: zstd_l3_multiblock_golden.json)
+            c2 = z.compress(d)
+            row["compress2_len"], row["compress2_sha256"] = len(c2), hashlib.sha256(c2).hexdigest()
         if n <= (512 << 10):             # level 1 (the Ktor encoder's level) through the same one-shot driver, up to its window
             l1 = z.compress_streaming(d, [0, n], out_chunk=max(8192, n // 10), level=1)
             row["l1_oneshot_len"], row["l1_oneshot_sha256"] = len(l1), hashlib.sha256(l1).hexdigest()

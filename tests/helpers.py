@@ -273,7 +273,8 @@ class Oracle:
     def compress_buffered(self, d: bytes, known_size: bool = True, empty_end: bool = False, out_chunk=None, tail_direct: int = 0) -> bytes:
         """The frame ZstdCompressor(3) really produces above 128 KiB (libzstd stages the input in chunks of 128 KiB because
         the reference's output slices are smaller than ZSTD_compressBound): known_size = finish = true from the first
-        call, out_chunk = the driver's output slice size; False = a stream fed with finish = false first (tail_direct: the
+        call, out_chunk = the driver's output slice size (known_size = 2: no staging, ZSTD_compress2 into a bound-sized buffer,
+        any length); False = a stream fed with finish = false first (tail_direct: the
         bytes its closing call brought, when they arrived on an empty staging buffer with room for their bound).
         Any length (the window slides)."""
         k = self.lib
@@ -284,7 +285,7 @@ class Oracle:
         o = ctypes.create_string_buffer(cap)
         if out_chunk is None:
             out_chunk = max(8192, len(d) // 10)              # SliceTransform.kt:47-56 getOutput
-        n = k.kref_zstd_l3_compress_buffered(o, cap, d, len(d), 1 if known_size else 0, 1 if empty_end else 0, out_chunk, tail_direct)
+        n = k.kref_zstd_l3_compress_buffered(o, cap, d, len(d), int(known_size), 1 if empty_end else 0, out_chunk, tail_direct)
         if n == 2 ** 64 - 1:
             raise RuntimeError("oracle: input outside the restatement's scope")
         return o.raw[:n]

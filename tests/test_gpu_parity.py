@@ -822,6 +822,10 @@ def test_reference_driver_frames_above_128k_and_beyond_the_window():
                 if key == "oneshot":
                     back, st = gpu_decompress(b, frames, [len(d) for d in datas])
                     assert st == [0] * n and back == datas
+            # ZSTD_compress2's frames (the caller's array compressed in place) beyond the window
+            for (nm, d), f in zip(group, gpu_compress(b, datas)):
+                if "compress2_len" in rows[nm]:
+                    assert len(f) == rows[nm]["compress2_len"] and helpers.sha256(f) == rows[nm]["compress2_sha256"], (cap, "compress2", nm)
         finally:
             b.close()
     # level 1 (the Ktor encoder's level) through the same driver, up to its 512 KiB window

@@ -186,6 +186,9 @@ def test_oracle_matches_the_reference_call_pattern_above_128k_and_beyond_the_win
         assert len(f) == row["oneshot_len"] and helpers.sha256(f) == row["oneshot_sha256"], ("oneshot", row["name"])
         f = o.compress_buffered(d, known_size=False)
         assert len(f) == row["stream_len"] and helpers.sha256(f) == row["stream_sha256"], ("stream", row["name"])
+        if "compress2_len" in row:
+            f = o.compress_buffered(d, known_size=2)
+            assert len(f) == row["compress2_len"] and helpers.sha256(f) == row["compress2_sha256"], ("compress2", row["name"])
         if "l1_oneshot_len" in row:
             f = o.compress_level_big(d, 1, stream=3)
             assert len(f) == row["l1_oneshot_len"] and helpers.sha256(f) == row["l1_oneshot_sha256"], ("level 1", row["name"])
