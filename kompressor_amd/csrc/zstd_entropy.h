@@ -1058,7 +1058,7 @@ struct KFrameArgs {
 
 // The block before fs.ipos is out: libzstd's staging buffer and window move on to the block that starts there
 // (ZSTD_compressStream_generic's buffered path, ZSTD_window_update per chunk, ZSTD_window_enforceMaxDist per block;
-// restated on the CPU in oracle/zstd_l3_ref.c, kref_zstd_l3_compress_buffered).  Returns what is left of the chunk: the
+// the tests hold a CPU restatement of the same rules, pinned on the binary library).  Returns what is left of the chunk: the
 // input the pre-splitter may look at.  fs.ipos < n.
 KX_DEV u32 kx_frame_window_step(KFrameState& fs, u32 n, u32 mode, u32 windowLog, u32 tailDirect, u32 outChunkArg)
 {
