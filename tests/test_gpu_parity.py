@@ -946,3 +946,45 @@ def test_predecode_kernels_give_the_same_frames(monkeypatch):
     finally:
         ref.close()
         pre.close()
+
+
+@pytest.mark.timeout(600)
+def test_fuzz_long_slices_all_framings_against_oracle():
+    """96 slices of arbitrary sizes 128 KiB + 1 .. 5.5 MiB (every class, byte runs, copies of earlier pieces at any distance)
+    in the three framings libzstd has for them -- the reference's one-shot driver, a stream, ZSTD_compress2 in place --
+    each compared with the oracle's frame (which is pinned on the binary library, tests/test_oracle_golden.py)."""
+    import random
+    from kompressor_amd.batch import ZstdBatch
+    rng = random.Random(4711)
+    o = helpers.oracle()
+    lap = 17 * 131072
+
+    def build(n):
+        out = bytearray()
+        while len(out) < n:
+            r = rng.random()
+            if r < 0.3 and len(out) > 1000:
+                a = rng.randrange(0, len(out))
+                out += out[a:a + rng.randrange(10, 300000)]
+            elif r < 0.36:
+                out += bytes([rng.randrange(256)]) * rng.randrange(1, 200000)
+            else:
+                out += corpus.make(rng.randrange(1 << 30), 1, rng.randrange(1000, 300000), mix=ord(rng.choice("TXSBDIZR"))).tobytes()
+        return bytes(out[:n])
+
+    sizes = [rng.choice([rng.randrange(131073, 600000), rng.randrange(600000, 2 << 20), (2 << 20) + rng.randrange(-5, 140000),
+                         lap + rng.randrange(-3, 300000), 131072 * rng.randrange(2, 40) + rng.randrange(-2, 3),
+                         rng.randrange(2 << 20, 5500000)]) for _ in range(96)]
+    datas = [build(n) for n in sizes]
+    for cap, sel in ((2 << 20, [d for d in datas if len(d) <= (2 << 20)]), (6 << 20, datas)):
+        b = ZstdBatch(max_slices=len(sel), max_slice_bytes=cap)
+        try:
+            for kw, ref in (({"reference": True}, lambda d: o.compress_buffered(d, True)),
+                            ({"streaming": "data"}, lambda d: o.compress_buffered(d, False)),
+                            ({}, lambda d: o.compress_buffered(d, 2))):
+                frames = gpu_compress_kw(b, sel, **kw)
+                assert b.status() == (0, 0)
+                for d, f in zip(sel, frames):
+                    assert f == ref(d), (cap, kw, len(d))
+        finally:
+            b.close()
