@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 
     else atomicAdd(remaining, 1u);
 }
 __global__ __launch_bounds__(64, 6) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
-// the sequence bitstreams decoded ahead of it, one lane per frame (32 frames per workgroup: their FSE tables fill the LDS)
-__global__ __launch_bounds__(64 * KXP_WAVES) void k_zstd_seq_predecode(KPreArgs a) { zstd_seq_predecode_body(a); }
+// the sequence bitstreams decoded ahead of it, one lane per frame (FSE tables in HBM)
+__global__ __launch_bounds__(64) void k_zstd_seq_predecode(KPreArgs a) { zstd_seq_predecode_body(a); }
 // ... and the Huffman-coded literals, one lane per stream (32 frames per workgroup of 128 threads)
 __global__ __launch_bounds__(128) void k_zstd_lit_predecode(KLitArgs a) { zstd_lit_predecode_body(a); }
 
@@ -156,6 +156,7 @@ struct kmp_batch_ctx {
     int profiling; hipEvent_t ev[14]; int ev_valid[7];
     // zstd compress pipeline: entropy coding of chunk i (second stream) runs beside the match kernel of chunk i+1
     hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join, ev_last_match; int have_last_match; u32 last_chunks;
+    hipEvent_t ev_pre[KMP_MAX_CHUNKS + 1];      // decoder: [0] where the caller's stream stands, [1 + i] piece i pre-decoded
     // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
     u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta;      // two halves of dfl_chunk slices each
     u32 dfl_pos_cap, dfl_blk_cap; KdBlockInfo* dfl_blocks;                                      // positions / blocks per slice in them
@@ -166,7 +167,7 @@ struct kmp_batch_ctx {
     int big; int big_G; KFrameState* fstate; u32* hufct; u32* big_tables; u32* remaining; u32* big_counters; u32 last_rounds;
     u32 cus;                                   // compute units of the device
     // decoder: sequences decoded ahead of k_zstd_decode (allocated on first use; pre_tried: do not try again)
-    u32* pre_stage; KPreBlk* pre_blk; u32* pre_nblk; u32 pre_seq_cap, pre_blk_cap; int pre_tried;
+    u32* pre_stage; KPreBlk* pre_blk; u32* pre_nblk; u32* pre_tables; u32 pre_seq_cap, pre_blk_cap; int pre_tried;
     u8* pre_lits; KPreLit* pre_lit; u32* pre_nlit; u32 pre_lit_cap;
     u32* len_ok; u32* d_status;                // sanitised slice lengths of the running batch; status word (KMP_STATUS_*)
     // one batch at a time per context: a batch queued on another stream waits for the previous one's last kernel
@@ -232,6 +233,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_last_match, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    for (int i = 0; i <= KMP_MAX_CHUNKS; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_pre[i], hipEventDisableTiming));
     c->cus = (u32)prop.multiProcessorCount;
     HIP_TRY(hipMalloc((void**)&c->len_ok, ns * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->d_status, 64));
@@ -263,8 +265,9 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_last_match) (void)hipEventDestroy(c->ev_last_match);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    for (int i = 0; i <= KMP_MAX_CHUNKS; i++) if (c->ev_pre[i]) (void)hipEventDestroy(c->ev_pre[i]);
     (void)hipFree(c->len_ok); (void)hipFree(c->d_status);
-    (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk);
+    (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); (void)hipFree(c->pre_tables);
     (void)hipFree(c->pre_lits); (void)hipFree(c->pre_lit); (void)hipFree(c->pre_nlit);
     if (c->st2) (void)hipStreamDestroy(c->st2);
     (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta); (void)hipFree(c->dfl_blocks);
@@ -664,8 +667,9 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
         if ((c->knob.decode_pre & 1u) && (u64)c->max_slices * seq_cap * 12ull <= (64ull << 30)) {
             if (hipMalloc((void**)&c->pre_stage, (size_t)c->max_slices * seq_cap * 12u) == hipSuccess &&
                 hipMalloc((void**)&c->pre_blk, (size_t)c->max_slices * blk_cap * sizeof(KPreBlk)) == hipSuccess &&
-                hipMalloc((void**)&c->pre_nblk, (size_t)c->max_slices * 4u) == hipSuccess) c->pre_seq_cap = seq_cap;
-            else { (void)hipGetLastError(); (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); c->pre_stage = nullptr; c->pre_blk = nullptr; c->pre_nblk = nullptr; }
+                hipMalloc((void**)&c->pre_nblk, (size_t)c->max_slices * 4u) == hipSuccess &&
+                hipMalloc((void**)&c->pre_tables, (size_t)c->max_slices * KXP_TBL_WORDS * 4u) == hipSuccess) c->pre_seq_cap = seq_cap;
+            else { (void)hipGetLastError(); (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); (void)hipFree(c->pre_tables); c->pre_stage = nullptr; c->pre_blk = nullptr; c->pre_nblk = nullptr; c->pre_tables = nullptr; }
         }
         if ((c->knob.decode_pre & 2u) && (u64)c->max_slices * lit_cap <= (64ull << 30)) {
             if (hipMalloc((void**)&c->pre_lits, (size_t)c->max_slices * lit_cap) == hipSuccess &&
@@ -686,15 +690,39 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
         d.pre_lits = c->pre_lits; d.pre_lit_cap = c->pre_lit_cap; d.pre_lit = c->pre_lit; d.pre_nlit = c->pre_nlit;
     }
     if (c->pre_stage) {
-        KPreArgs p;
-        p.src = d.src; p.in_off = d_in_off; p.in_len = d_in_len; p.n_slices = n;
-        p.stage = c->pre_stage; p.seq_cap = c->pre_seq_cap; p.blk = c->pre_blk; p.blk_cap = c->pre_blk_cap; p.nblk = c->pre_nblk;
-        hipLaunchKernelGGL(k_zstd_seq_predecode, dim3((n + KXP_FRAMES - 1) / KXP_FRAMES), dim3(64 * KXP_WAVES), 0, st, p);
+        // The sequence pre-decoder is bound by memory transactions, the decoder by instruction issue: the batch goes through
+        // in pieces, the pre-decoder (second stream) working on the pieces ahead of the one the decoder has.
+        u32 const pieces = (n >= 8192u) ? (u32)KMP_MAX_CHUNKS : 1u;
+        u32 const per = ((n + pieces - 1) / pieces + 63u) & ~63u;
+        HIP_TRY(hipEventRecord(c->ev_pre[0], st)); HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_pre[0], 0));     // st2 starts where st stands
+        for (u32 first = 0, pi = 0; first < n; first += per, pi++) {
+            u32 const m = (n - first < per) ? n - first : per;
+            KPreArgs p;
+            p.src = d.src; p.in_off = d_in_off + first; p.in_len = d_in_len + first; p.n_slices = m;
+            p.stage = c->pre_stage + (size_t)first * c->pre_seq_cap * 3u; p.seq_cap = c->pre_seq_cap;
+            p.blk = c->pre_blk + (size_t)first * c->pre_blk_cap; p.blk_cap = c->pre_blk_cap; p.nblk = c->pre_nblk + first;
+            p.tables = c->pre_tables + (size_t)first * KXP_TBL_WORDS;
+            hipLaunchKernelGGL(k_zstd_seq_predecode, dim3((m + 63) / 64), dim3(64), 0, c->st2, p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev_pre[1 + pi], c->st2));
+        }
+        for (u32 first = 0, pi = 0; first < n; first += per, pi++) {
+            u32 const m = (n - first < per) ? n - first : per;
+            KDecodeArgs q = d;
+            q.in_off = d_in_off + first; q.in_len = d_in_len + first; q.n_slices = m;
+            q.out_off = d_out_off + first; q.out_cap = d_out_cap + first; q.out_len = d_out_len + first; q.status = d_status + first;
+            q.lits = c->lits + (size_t)first * c->lit_cap;
+            q.pre_stage = c->pre_stage + (size_t)first * c->pre_seq_cap * 3u; q.pre_seq_cap = c->pre_seq_cap;
+            q.pre_blk = c->pre_blk + (size_t)first * c->pre_blk_cap; q.pre_blk_cap = c->pre_blk_cap; q.pre_nblk = c->pre_nblk + first;
+            if (d.pre_lits) { q.pre_lits = d.pre_lits + (size_t)first * d.pre_lit_cap; q.pre_lit = d.pre_lit + (size_t)first * c->pre_blk_cap; q.pre_nlit = d.pre_nlit + first; }
+            HIP_TRY(hipStreamWaitEvent(st, c->ev_pre[1 + pi], 0));
+            hipLaunchKernelGGL(k_zstd_decode, dim3(m), dim3(64), c->knob.decode_pad, st, q);
+            HIP_TRY(hipGetLastError());
+        }
+    } else {
+        hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), c->knob.decode_pad, st, d);   // padding = occupancy experiment only
         HIP_TRY(hipGetLastError());
-        d.pre_stage = c->pre_stage; d.pre_seq_cap = c->pre_seq_cap; d.pre_blk = c->pre_blk; d.pre_blk_cap = c->pre_blk_cap; d.pre_nblk = c->pre_nblk;
     }
-    hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), c->knob.decode_pad, st, d);   // padding = occupancy experiment only
-    HIP_TRY(hipGetLastError());
     if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[5], st)); c->ev_valid[2] = 1; }
     return batch_end(c, st, nullptr, n, 0, nullptr, nullptr);
 }

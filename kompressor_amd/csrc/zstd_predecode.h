@@ -4,8 +4,11 @@
 // work: 86 % of that kernel's instructions served three lanes of a wave, and instruction issue
 // was what bound it.  A sequence costs the same instructions whether one lane or sixty-four execute them, so this
 // kernel turns the work sideways: a lane owns a whole frame, walks its blocks, builds the three FSE decoding tables of
-// each compressed block in its own slice of the LDS and decodes the block's sequences -- literal length, match length
-// and the offset with the repeat-offset rules already applied -- into a staging area in HBM.  k_zstd_decode then loads
+// each compressed block (in HBM: 5 KiB per frame, so that nothing limits how many frames are in flight; the first
+// version kept them in LDS, 32 frames per CU, and ran at one wave per SIMD with every latency exposed) and decodes the
+// block's sequences -- literal length, match length and the offset with the repeat-offset rules already applied --
+// into a staging area in HBM.  What it costs is three random table words per sequence: it is bound by memory
+// transactions where k_zstd_decode is bound by instruction issue, so the two run side by side on the same CUs.  k_zstd_decode then loads
 // 64 finished sequences per step instead of decoding them and keeps everything else (headers, literals, execution,
 // every check and error code).
 //
@@ -20,27 +23,53 @@
 #pragma once
 #include "zstd_decode.h"
 
+// n (<= 32) bits of the 128-bit window (hi : lo) starting t bits above lo's bit 0 (0 <= t, t + n <= 128); n = 0 gives 0
+KX_DEV u32 kxp_bits(u64 hi, u64 lo, int t, u32 n)
+{
+    u64 const x = (t >= 64) ? (hi >> (t - 64)) : ((lo >> t) | ((hi << 1) << (63 - t)));
+    return (u32)x & (u32)((1ull << n) - 1ull);
+}
+
 struct KPreArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
     u32* stage; u32 seq_cap;            // per entry: seq_cap x (litLength, matchLength, offset)
     KPreBlk* blk; u32 blk_cap;          // per entry: blk_cap records (compressed blocks in frame order)
     u32* nblk;                          // per entry: records written
+    u32* tables;                        // per entry: KXP_TBL_WORDS words: the three FSE decoding tables + their construction scratch
 };
 
-#define KXP_FRAMES 32                   /* frames per workgroup: what the LDS holds */
-#define KXP_WAVES 4                     /* ... spread over 4 waves (8 lanes each busy), one per SIMD */
-#define KXP_WIN 64                      /* words of a lane's bitstream window in LDS */
+// per entry in HBM: one word per FSE state (newStateBase | nbBits << 16 | symbol << 24), LL [0,512) ML [512,1024) OF [1024,1280),
+// then the normalised counts and the per-symbol cursor of the table under construction (56 x i16 + 56 x u16)
+#define KXP_TBL_WORDS (1280 + 56)
 
-struct KPreLaneLds {
-    u16 fb[1280]; u8 fc[1280];          // FSE decoding tables LL [0,512) ML [512,1024) OF [1024,1280), as in KDecodeLds
-    short keepNorm[3][56]; u16 symnext[56];
-    u32 win[KXP_WIN];                   // the sequence bitstream around the read position: word i of the stream at win[i & 63]
-};
-struct KPreLds { KPreLaneLds f[KXP_FRAMES]; u32 llx[36]; u32 mlx[53]; };
+// FSE table description -> the entry's table in HBM (same construction as kfse_build_dtable)
+KX_DEV void kxp_build_dtable(u32* tb, const short* norm, u32 maxSymbolValue, u32 tableLog, u16* symnext)
+{
+    u32 const tableSize = 1u << tableLog, mask = tableSize - 1;
+    u32 const step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    u32 high = tableSize - 1;
+    for (u32 s = 0; s <= maxSymbolValue; s++) {
+        if (norm[s] == -1) { tb[high--] = s << 24; symnext[s] = 1; }
+        else symnext[s] = (u16)norm[s];
+    }
+    u32 pos = 0;
+    for (u32 s = 0; s <= maxSymbolValue; s++) {
+        for (int i = 0; i < norm[s]; i++) {
+            tb[pos] = s << 24;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    }
+    for (u32 u = 0; u < tableSize; u++) {
+        u32 const s = tb[u] >> 24; u32 const next = symnext[s]++;
+        u32 const nb = tableLog - kx_hb32(next);
+        tb[u] = (((next << nb) - tableSize) & 0xFFFFu) | (nb << 16) | (s << 24);
+    }
+}
 
-// One symbol type's table for the block, into the lane's LDS; keep* remember what a later "repeat" mode rebuilds from.
+// One symbol type's table for the block (a "repeat" mode keeps what is there).  kind[t]: 0 none yet, 1 RLE, 2 FSE.
 // Returns bytes consumed or KXD_FAIL.
-KX_DEV u32 kxp_seq_table(KPreLaneLds& L, int t, u32 mode, const u8* p, u32 size, u32* tableLog, u32* keepKind, u32* keepLog, u32* keepMax)
+KX_DEV u32 kxp_seq_table(u32* tables, int t, u32 mode, const u8* p, u32 size, u32* tableLog, u32* kind, u32* klog)
 {
     static const short LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2, 2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
     static const short ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,
@@ -48,216 +77,190 @@ KX_DEV u32 kxp_seq_table(KPreLaneLds& L, int t, u32 mode, const u8* p, u32 size,
     static const short OF_defaultNorm[29] = { 1,1,1,1,1,1,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, -1,-1,-1,-1,-1 };
     u32 const maxSym = (t == 0) ? 35 : (t == 1) ? 31 : 52;
     u32 const maxLog = (t == 0) ? 9 : (t == 1) ? 8 : 9;
-    u16* const db = L.fb + kxd_seq_base(t); u8* const dc = L.fc + kxd_seq_base(t);
+    u32* const tb = tables + kxd_seq_base(t);
+    short* const norm = (short*)(tables + 1280); u16* const symnext = (u16*)(tables + 1280 + 28);
     u32 used = 0;
     if (mode == 0) {
         const short* dn = (t == 0) ? LL_defaultNorm : (t == 1) ? OF_defaultNorm : ML_defaultNorm;
         u32 const dmax = (t == 0) ? 35 : (t == 1) ? 28 : 52; u32 const dlog = (t == 1) ? 5 : 6;
-        for (u32 s = 0; s <= dmax; s++) L.keepNorm[t][s] = dn[s];
-        keepKind[t] = 2; keepLog[t] = dlog; keepMax[t] = dmax;
+        for (u32 s = 0; s <= dmax; s++) norm[s] = dn[s];
+        kxp_build_dtable(tb, norm, dmax, dlog, symnext);
+        kind[t] = 2; klog[t] = dlog;
     } else if (mode == 1) {
         if (size < 1 || p[0] > maxSym) return KXD_FAIL;
-        keepKind[t] = 1; keepLog[t] = 0; keepMax[t] = p[0];
+        tb[0] = (u32)p[0] << 24;                             // nbBits 0, next state 0
+        kind[t] = 1; klog[t] = 0;
         used = 1;
     } else if (mode == 2) {
         u32 maxSV = maxSym, tl = 0;
-        u32 const h = kfse_read_ncount(L.keepNorm[t], &maxSV, &tl, p, size, maxLog);
-        if (h == 0) { keepKind[t] = 0; return KXD_FAIL; }
-        keepKind[t] = 2; keepLog[t] = tl; keepMax[t] = maxSV;
+        u32 const h = kfse_read_ncount(norm, &maxSV, &tl, p, size, maxLog);
+        if (h == 0) { kind[t] = 0; return KXD_FAIL; }
+        kxp_build_dtable(tb, norm, maxSV, tl, symnext);
+        kind[t] = 2; klog[t] = tl;
         used = h;
-    } else if (keepKind[t] == 0) return KXD_FAIL;        // repeat without a previous table
-    if (keepKind[t] == 1) { db[0] = 0; dc[0] = (u8)keepMax[t]; }
-    else kfse_build_dtable(db, dc, L.keepNorm[t], keepMax[t], keepLog[t], L.symnext, dc);     // the spread IS the symbol table
-    *tableLog = keepLog[t];
+    } else if (kind[t] == 0) return KXD_FAIL;            // repeat without a previous table
+    *tableLog = klog[t];
     return used;
+}
+
+// 64 bits of a sequence bitstream at word index j (bytes [8 j, 8 j + 8)); words below the stream read as zero, the
+// last one may be short
+KX_DEV u64 kxp_word(const u8* sq, u32 ssz, int j)
+{
+    if (j < 0) return 0;
+    u32 const o = 8u * (u32)j;
+    if (o + 8u <= ssz) return kx_ld64(sq + o);
+    u64 v = 0;
+    for (u32 k = 0; o + k < ssz; k++) v |= (u64)sq[o + k] << (8 * k);
+    return v;
 }
 
 KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
 {
-    KX_SHARED KPreLds lds;
-    int const lane = kx_lane(), wv = kx_wave();
+    KX_SHARED u32 llx[36]; KX_SHARED u32 mlx[53];          // per code: baseValue | extraBits << 24
     {
-        int const t = wv * 64 + lane;
-        if (t < 36) lds.llx[t] = kx_ll_base((u32)t) | (kxd_ll_bits((u32)t) << 24);
-        if (t >= 64 && t < 64 + 53) lds.mlx[t - 64] = kx_ml_base((u32)(t - 64)) | (kxd_ml_bits((u32)(t - 64)) << 24);
+        int const lane = kx_lane();
+        if (lane < 36) llx[lane] = kx_ll_base((u32)lane) | (kxd_ll_bits((u32)lane) << 24);
+        if (lane < 53) mlx[lane] = kx_ml_base((u32)lane) | (kxd_ml_bits((u32)lane) << 24);
     }
-    kx_block_sync();
-    constexpr int PER = KXP_FRAMES / KXP_WAVES;
-    if (lane >= PER) return;
-    KPreLaneLds& L = lds.f[wv * PER + lane];
-    for (u32 f = (kx_block() * KXP_WAVES + (u32)wv) * PER + (u32)lane; f < a.n_slices; f += kx_nblocks() * KXP_FRAMES) {
-        const u8* const src = a.src + a.in_off[f];
-        u32 const srcSize = a.in_len[f];
-        u32* const stage = a.stage + (size_t)f * a.seq_cap * 3u;
-        KPreBlk* const blk = a.blk + (size_t)f * a.blk_cap;
-        u32 nb = 0, nstaged = 0;              // compressed blocks seen / sequences staged so far
-        u32 pos = 0;
-        // ---- frame header (first frame of the entry only) ----
-        bool ok = srcSize >= 5 && kx_ld32(src) == 0xFD2FB528u;
-        if (ok) {
-            u32 const fhd = src[4]; u32 const dictId = fhd & 3, single = (fhd >> 5) & 1, fcsId = fhd >> 6;
-            if (fhd & 0x08) ok = false;
-            u32 const didSize = dictId == 3 ? 4 : dictId;
-            u32 const fcsSize = fcsId == 0 ? single : (fcsId == 1 ? 2 : fcsId == 2 ? 4 : 8);
-            pos = 5 + (single ? 0u : 1u) + didSize + fcsSize;
-            if (pos > srcSize) ok = false;
-        }
-        u32 rep1 = 1, rep2 = 4, rep3 = 8;
-        u32 keepKind[3] = { 0, 0, 0 }, keepLog[3] = { 0, 0, 0 }, keepMax[3] = { 0, 0, 0 };
-        bool last = false;
-        while (ok && !last && nb < a.blk_cap) {
-            if (pos + 3 > srcSize) break;
-            u32 const bh = (u32)src[pos] | ((u32)src[pos + 1] << 8) | ((u32)src[pos + 2] << 16);
-            last = bh & 1; u32 const btype = (bh >> 1) & 3; u32 const bsize = bh >> 3;
-            pos += 3;
-            if (btype == 3) break;
-            if (btype == 0) { if (pos + bsize > srcSize) break; pos += bsize; continue; }
-            if (btype == 1) { if (pos + 1 > srcSize) break; pos += 1; continue; }
-            if (pos + bsize > srcSize || bsize > 128u * 1024u || bsize < 2) break;
-            const u8* const bp = src + pos; u32 const bend = bsize;
-            // literals section: only its size matters here
-            u32 const lh0 = bp[0]; u32 const ltype = lh0 & 3, sf = (lh0 >> 2) & 3;
-            u32 lpos;
-            if (ltype < 2) {
-                u32 lhSize, regen;
-                if (sf == 0 || sf == 2) { lhSize = 1; regen = lh0 >> 3; }
-                else if (sf == 1) { lhSize = 2; regen = kx_ld16(bp) >> 4; }
-                else { if (bend < 3) break; lhSize = 3; regen = ((u32)bp[0] | ((u32)bp[1] << 8) | ((u32)bp[2] << 16)) >> 4; }
-                lpos = lhSize + (ltype == 0 ? regen : 1u);
-            } else {
-                if (bend < 5) break;
-                u32 const w = kx_ld32(bp); u32 lhSize, comp;
-                if (sf < 2) { lhSize = 3; comp = (w >> 14) & 0x3FF; }
-                else if (sf == 2) { lhSize = 4; comp = w >> 18; }
-                else { lhSize = 5; comp = (w >> 22) + ((u32)bp[4] << 10); }
-                lpos = lhSize + comp;
-            }
-            if (lpos >= bend) break;
-            // sequences header
-            u32 nbSeq, p2 = lpos;
-            {
-                u32 const b0 = bp[p2++];
-                if (b0 < 128) nbSeq = b0;
-                else if (b0 < 255) { if (p2 >= bend) break; nbSeq = ((b0 - 128) << 8) + bp[p2++]; }
-                else { if (p2 + 2 > bend) break; nbSeq = kx_ld16(bp + p2) + 0x7F00; p2 += 2; }
-            }
-            KPreBlk rec; rec.seq_off = nstaged; rec.nbSeq = nbSeq; rec.ok = 0; rec.rep[0] = rep1; rec.rep[1] = rep2; rec.rep[2] = rep3; rec.pad[0] = 0; rec.pad[1] = 0;
-            if (nbSeq == 0) { rec.ok = 1; blk[nb++] = rec; pos += bsize; continue; }
-            if (p2 >= bend) break;
-            u32 const modes = bp[p2++];
-            if (modes & 3) break;
-            if (nstaged + nbSeq > a.seq_cap) break;
-            u32 tlLL = 0, tlOF = 0, tlML = 0; bool tok = true;
-            for (int t = 0; t < 3 && tok; t++) {
-                u32 const mode = (modes >> (6 - 2 * t)) & 3u;
-                u32 const r = kxp_seq_table(L, t, mode, bp + p2, bend - p2, t == 0 ? &tlLL : t == 1 ? &tlOF : &tlML, keepKind, keepLog, keepMax);
-                if (r == KXD_FAIL) tok = false; else p2 += r;
-            }
-            if (!tok || p2 >= bend) break;
-            // ---- the bitstream, read backwards from its last set bit ----
-            const u8* const sq = bp + p2; u32 const ssz = bend - p2;
-            u32 const lastByte = sq[ssz - 1];
-            if (lastByte == 0) break;
-            int const totalWords = (int)((ssz + 3) >> 2);
-            int bitPos = (int)(8 * (ssz - 1) + kx_hb32(lastByte));     // unread bits
-            bool bad = false;
-            // The window holds the words [lo, lo + 64) of the stream (words below 0 read as zero: the container of an
-            // exhausted stream reaches word -3), circularly.  The stream is read downwards, a sequence takes at most 89
-            // bits = words [top - 4, top]; the next eight words below the window wait in registers, loaded one refill
-            // ahead, so no sequence waits for memory.
-            int lo;
-            {
-                int const curWord = bitPos >> 5;
-                int hiW = curWord + 2; if (hiW > totalWords) hiW = totalWords;
-                lo = hiW - KXP_WIN;
-                for (int w0 = lo; w0 < hiW; w0 += 8) {
-                    u32 t[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        int const w = w0 + j; int const o = 4 * w; u32 v = 0;
-                        if (w >= 0 && w < hiW) {
-                            if (o + 4 <= (int)ssz) v = kx_ld32(sq + o);
-                            else for (int k = 0; o + k < (int)ssz; k++) v |= (u32)sq[o + k] << (8 * k);
-                        }
-                        t[j] = v;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; j++) L.win[(w0 + j) & (KXP_WIN - 1)] = t[j];
-                }
-            }
-            u32 pf[8];
-#define KXP_PREFETCH() { _Pragma("unroll") for (int j = 0; j < 8; j++) { int const w = lo - 8 + j; pf[j] = (w >= 0) ? kx_ld32(sq + 4 * w) : 0u; } }
-            KXP_PREFETCH()
-#define KXP_WORD(i) L.win[(i) & (KXP_WIN - 1)]
-#define KXP_CONTAINER(C_) u64 C_; { int const topw_ = (bitPos - 1) >> 5; \
-                u32 const hi_ = KXP_WORD(topw_), mid_ = KXP_WORD(topw_ - 1), lo_ = KXP_WORD(topw_ - 2); \
-                u32 const used_ = (u32)(32 * (topw_ + 1) - bitPos); \
-                C_ = ((((u64)hi_ << 32) | mid_) << used_) | ((u64)lo_ >> (32u - used_)); }
-#define KXP_AT(C_, c_, n_) ((u32)((((C_) << (c_)) >> 1) >> (63u - (n_))))
-            u32 sLL = 0, sOF = 0, sML = 0; bool primed = false;
-            u32* const out = stage + (size_t)nstaged * 3u;
-            for (u32 i = 0; i < nbSeq; i++) {
-                if ((bitPos >> 5) - lo < 8 && lo > -8) {
-                    // the registers move into the window (over words that lie above the read position by now) ...
-#pragma unroll
-                    for (int j = 0; j < 8; j++) L.win[(lo - 8 + j) & (KXP_WIN - 1)] = pf[j];
-                    lo -= 8;
-                    KXP_PREFETCH()               // ... and the next eight are requested
-                }
-                if (!primed) {
-                    u32 const need0 = tlLL + tlOF + tlML;
-                    bad |= bitPos < (int)need0;
-                    KXP_CONTAINER(C0)
-                    sLL = KXP_AT(C0, 0u, tlLL); sOF = KXP_AT(C0, tlLL, tlOF); sML = KXP_AT(C0, tlLL + tlOF, tlML);    // stream order LL, OF, ML
-                    if (tlLL == 0) sLL = 0; if (tlOF == 0) sOF = 0; if (tlML == 0) sML = 0;
-                    bitPos -= (int)need0; bitPos = bitPos < 0 ? 0 : bitPos;
-                    primed = true;
-                }
-                KXP_CONTAINER(C)
-                u32 const eL = L.fb[KXD_LL0 + sLL], cL = L.fc[KXD_LL0 + sLL];
-                u32 const eO = L.fb[KXD_OF0 + sOF], cO = L.fc[KXD_OF0 + sOF];
-                u32 const eM = L.fb[KXD_ML0 + sML], cM = L.fc[KXD_ML0 + sML];
-                if (cL > 35 || cM > 52 || cO > 31) { bad = true; break; }
-                u32 const xL = lds.llx[cL], xM = lds.mlx[cM];
-                u32 const aO = cO, aM = xM >> 24, aL = xL >> 24;
-                bool const upd = i + 1 < nbSeq;                        // the block's final sequence updates no state
-                u32 const nL = upd ? eL >> 12 : 0u, nM = upd ? eM >> 12 : 0u, nO = upd ? eO >> 12 : 0u;
-                u32 const needA = aO + aM + aL, needB = nL + nM + nO;
-                bad |= bitPos < (int)(needA + needB);
-                // bit order inside a sequence: OF extra, ML extra, LL extra, then LL state, ML state, OF state
-                u32 const xo = aO ? KXP_AT(C, 0u, aO) : 0u;
-                u32 const xm = aM ? KXP_AT(C, aO, aM) : 0u;
-                u32 const xl = aL ? KXP_AT(C, aO + aM, aL) : 0u;
-                u64 Cs = C; u32 offB = needA;
-                if (needA + needB > 64) { bitPos -= (int)needA; bitPos = bitPos < 0 ? 0 : bitPos; KXP_CONTAINER(C2) bitPos += (int)needA; Cs = C2; offB = 0; }
-                u32 const yL = nL ? KXP_AT(Cs, offB, nL) : 0u;
-                u32 const yM = nM ? KXP_AT(Cs, offB + nL, nM) : 0u;
-                u32 const yO = nO ? KXP_AT(Cs, offB + nL + nM, nO) : 0u;
-                bitPos -= (int)(needA + needB); bitPos = bitPos < 0 ? 0 : bitPos;
-                u32 const ofv = (1u << cO) + xo, ml = (xM & 0xFFFFFFu) + xm, ll = (xL & 0xFFFFFFu) + xl;
-                // repeat-offset rules
-                bool const isRep = ofv <= 3;
-                u32 const idx = ofv - 1 + (ll == 0);
-                u32 const rm1 = (rep1 - 1) ? rep1 - 1 : 1u;
-                u32 const roff = idx == 0 ? rep1 : idx == 1 ? rep2 : idx == 2 ? rep3 : rm1;
-                u32 const off = isRep ? roff : ofv - 3;
-                bool const sh2 = !isRep || idx >= 2, sh1 = !isRep || idx >= 1;
-                rep3 = sh2 ? rep2 : rep3; rep2 = sh1 ? rep1 : rep2; rep1 = off;
-                out[3 * i] = ll; out[3 * i + 1] = ml; out[3 * i + 2] = off;
-                sLL = ((eL & 0xFFFu) + yL) & 511u; sML = ((eM & 0xFFFu) + yM) & 511u; sOF = ((eO & 0xFFFu) + yO) & 255u;
-            }
-#undef KXP_AT
-#undef KXP_CONTAINER
-#undef KXP_WORD
-#undef KXP_PREFETCH
-            if (bad || bitPos != 0) break;          // irregular: this block and the rest are left to k_zstd_decode
-            rec.ok = 1; rec.rep[0] = rep1; rec.rep[1] = rep2; rec.rep[2] = rep3;
-            blk[nb++] = rec;
-            nstaged += nbSeq;
-            pos += bsize;
-        }
-        a.nblk[f] = nb;
+    kx_sync();
+    u32 const f = kx_block() * 64u + (u32)kx_lane();
+    if (f >= a.n_slices) return;
+    const u8* const src = a.src + a.in_off[f];
+    u32 const srcSize = a.in_len[f];
+    u32* const stage = a.stage + (size_t)f * a.seq_cap * 3u;
+    KPreBlk* const blk = a.blk + (size_t)f * a.blk_cap;
+    u32* const tables = a.tables + (size_t)f * KXP_TBL_WORDS;
+    u32 nb = 0, nstaged = 0;              // compressed blocks seen / sequences staged so far
+    u32 pos = 0;
+    // ---- frame header (first frame of the entry only) ----
+    bool ok = srcSize >= 5 && kx_ld32(src) == 0xFD2FB528u;
+    if (ok) {
+        u32 const fhd = src[4]; u32 const dictId = fhd & 3, single = (fhd >> 5) & 1, fcsId = fhd >> 6;
+        if (fhd & 0x08) ok = false;
+        u32 const didSize = dictId == 3 ? 4 : dictId;
+        u32 const fcsSize = fcsId == 0 ? single : (fcsId == 1 ? 2 : fcsId == 2 ? 4 : 8);
+        pos = 5 + (single ? 0u : 1u) + didSize + fcsSize;
+        if (pos > srcSize) ok = false;
     }
+    u32 rep1 = 1, rep2 = 4, rep3 = 8;
+    u32 kind[3] = { 0, 0, 0 }, klog[3] = { 0, 0, 0 };
+    bool last = false;
+    while (ok && !last && nb < a.blk_cap) {
+        if (pos + 3 > srcSize) break;
+        u32 const bh = (u32)src[pos] | ((u32)src[pos + 1] << 8) | ((u32)src[pos + 2] << 16);
+        last = bh & 1; u32 const btype = (bh >> 1) & 3; u32 const bsize = bh >> 3;
+        pos += 3;
+        if (btype == 3) break;
+        if (btype == 0) { if (pos + bsize > srcSize) break; pos += bsize; continue; }
+        if (btype == 1) { if (pos + 1 > srcSize) break; pos += 1; continue; }
+        if (pos + bsize > srcSize || bsize > 128u * 1024u || bsize < 2) break;
+        const u8* const bp = src + pos; u32 const bend = bsize;
+        // literals section: only its size matters here
+        u32 const lh0 = bp[0]; u32 const ltype = lh0 & 3, sf = (lh0 >> 2) & 3;
+        u32 lpos;
+        if (ltype < 2) {
+            u32 lhSize, regen;
+            if (sf == 0 || sf == 2) { lhSize = 1; regen = lh0 >> 3; }
+            else if (sf == 1) { lhSize = 2; regen = kx_ld16(bp) >> 4; }
+            else { if (bend < 3) break; lhSize = 3; regen = ((u32)bp[0] | ((u32)bp[1] << 8) | ((u32)bp[2] << 16)) >> 4; }
+            lpos = lhSize + (ltype == 0 ? regen : 1u);
+        } else {
+            if (bend < 5) break;
+            u32 const w = kx_ld32(bp); u32 lhSize, comp;
+            if (sf < 2) { lhSize = 3; comp = (w >> 14) & 0x3FF; }
+            else if (sf == 2) { lhSize = 4; comp = w >> 18; }
+            else { lhSize = 5; comp = (w >> 22) + ((u32)bp[4] << 10); }
+            lpos = lhSize + comp;
+        }
+        if (lpos >= bend) break;
+        // sequences header
+        u32 nbSeq, p2 = lpos;
+        {
+            u32 const b0 = bp[p2++];
+            if (b0 < 128) nbSeq = b0;
+            else if (b0 < 255) { if (p2 >= bend) break; nbSeq = ((b0 - 128) << 8) + bp[p2++]; }
+            else { if (p2 + 2 > bend) break; nbSeq = kx_ld16(bp + p2) + 0x7F00; p2 += 2; }
+        }
+        KPreBlk rec; rec.seq_off = nstaged; rec.nbSeq = nbSeq; rec.ok = 0; rec.rep[0] = rep1; rec.rep[1] = rep2; rec.rep[2] = rep3; rec.pad[0] = 0; rec.pad[1] = 0;
+        if (nbSeq == 0) { rec.ok = 1; blk[nb++] = rec; pos += bsize; continue; }
+        if (p2 >= bend) break;
+        u32 const modes = bp[p2++];
+        if (modes & 3) break;
+        if (nstaged + nbSeq > a.seq_cap) break;
+        u32 tlLL = 0, tlOF = 0, tlML = 0; bool tok = true;
+        for (int t = 0; t < 3 && tok; t++) {
+            u32 const mode = (modes >> (6 - 2 * t)) & 3u;
+            u32 const r = kxp_seq_table(tables, t, mode, bp + p2, bend - p2, t == 0 ? &tlLL : t == 1 ? &tlOF : &tlML, kind, klog);
+            if (r == KXD_FAIL) tok = false; else p2 += r;
+        }
+        if (!tok || p2 >= bend) break;
+        // ---- the bitstream, read backwards from its last set bit ----
+        const u8* const sq = bp + p2; u32 const ssz = bend - p2;
+        u32 const lastByte = sq[ssz - 1];
+        if (lastByte == 0) break;
+        int bitPos = (int)(8 * (ssz - 1) + kx_hb32(lastByte));     // unread bits
+        bool bad = false;
+        // The reader keeps 128 bits of the stream in registers: lo = word k (bits [64 k, 64 k + 64)), hi = word k + 1, and the
+        // two words below them already requested (q0, q1), so a field never waits for the stream.  Fields come in two
+        // groups per sequence, each at most 64 bits: ENSURE moves the window down until the group lies inside it.
+        int k = ((bitPos - 1) >> 6) - 1;
+        u64 hi = kxp_word(sq, ssz, k + 1), lo = kxp_word(sq, ssz, k), q0 = kxp_word(sq, ssz, k - 1), q1 = kxp_word(sq, ssz, k - 2);
+#define KXP_DOWN() { hi = lo; lo = q0; q0 = q1; k--; q1 = kxp_word(sq, ssz, k - 2); }
+#define KXP_ENSURE(m_) { if (bitPos - (int)(m_) < 64 * k) KXP_DOWN() if (bitPos - (int)(m_) < 64 * k) KXP_DOWN() }
+// the n (<= 32) bits below bit position P_ (P_ - n >= 64 k, P_ <= 64 k + 128); n = 0 gives 0
+#define KXP_BITS(P_, n_) kxp_bits(hi, lo, (int)(P_) - (int)(n_) - 64 * k, (n_))
+        u32 sLL, sOF, sML;
+        {
+            u32 const need0 = tlLL + tlOF + tlML;                  // initial states, stream order LL, OF, ML
+            if (bitPos < (int)need0) break;
+            KXP_ENSURE(need0)
+            sLL = KXP_BITS(bitPos, tlLL); sOF = KXP_BITS(bitPos - (int)tlLL, tlOF); sML = KXP_BITS(bitPos - (int)(tlLL + tlOF), tlML);
+            bitPos -= (int)need0;
+        }
+        u32* const out = stage + (size_t)nstaged * 3u;
+        u32 eL = tables[KXD_LL0 + sLL], eO = tables[KXD_OF0 + sOF], eM = tables[KXD_ML0 + sML];
+        for (u32 i = 0; i < nbSeq; i++) {
+            u32 const cL = eL >> 24, cO = eO >> 24, cM = eM >> 24;
+            if (cL > 35 || cM > 52 || cO > 31) { bad = true; break; }
+            u32 const xL = llx[cL], xM = mlx[cM];
+            u32 const aL = xL >> 24, aM = xM >> 24, aO = cO;
+            bool const upd = i + 1 < nbSeq;                        // the block's final sequence updates no state
+            u32 const nL = upd ? (eL >> 16) & 0xFFu : 0u, nM = upd ? (eM >> 16) & 0xFFu : 0u, nO = upd ? (eO >> 16) & 0xFFu : 0u;
+            u32 const needA = aO + aM + aL, needB = nL + nM + nO;
+            if (bitPos < (int)(needA + needB)) { bad = true; break; }
+            // bit order inside a sequence: OF extra, ML extra, LL extra, then LL state, ML state, OF state
+            KXP_ENSURE(needA)
+            u32 const xo = KXP_BITS(bitPos, aO), xm = KXP_BITS(bitPos - (int)aO, aM), xl = KXP_BITS(bitPos - (int)(aO + aM), aL);
+            bitPos -= (int)needA;
+            KXP_ENSURE(needB)
+            u32 const yL = KXP_BITS(bitPos, nL), yM = KXP_BITS(bitPos - (int)nL, nM), yO = KXP_BITS(bitPos - (int)(nL + nM), nO);
+            bitPos -= (int)needB;
+            // the next states' table words are requested before this sequence is finished
+            sLL = ((eL & 0xFFFFu) + yL) & 511u; sML = ((eM & 0xFFFFu) + yM) & 511u; sOF = ((eO & 0xFFFFu) + yO) & 255u;
+            u32 const nLe = tables[KXD_LL0 + sLL], nOe = tables[KXD_OF0 + sOF], nMe = tables[KXD_ML0 + sML];
+            u32 const ofv = (1u << cO) + xo, ml = (xM & 0xFFFFFFu) + xm, ll = (xL & 0xFFFFFFu) + xl;
+            // repeat-offset rules
+            bool const isRep = ofv <= 3;
+            u32 const idx = ofv - 1 + (ll == 0);
+            u32 const rm1 = (rep1 - 1) ? rep1 - 1 : 1u;
+            u32 const roff = idx == 0 ? rep1 : idx == 1 ? rep2 : idx == 2 ? rep3 : rm1;
+            u32 const off = isRep ? roff : ofv - 3;
+            bool const sh2 = !isRep || idx >= 2, sh1 = !isRep || idx >= 1;
+            rep3 = sh2 ? rep2 : rep3; rep2 = sh1 ? rep1 : rep2; rep1 = off;
+            out[3 * i] = ll; out[3 * i + 1] = ml; out[3 * i + 2] = off;
+            eL = nLe; eO = nOe; eM = nMe;
+        }
+#undef KXP_BITS
+#undef KXP_ENSURE
+#undef KXP_DOWN
+        if (bad || bitPos != 0) break;          // irregular: this block and the rest are left to k_zstd_decode
+        rec.ok = 1; rec.rep[0] = rep1; rec.rep[1] = rep2; rec.rep[2] = rep3;
+        blk[nb++] = rec;
+        nstaged += nbSeq;
+        pos += bsize;
+    }
+    a.nblk[f] = nb;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -280,8 +280,9 @@ int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len
         stage.assign((size_t)n * seq_cap * 3u, 0xCDCDCDCDu); pblk.resize((size_t)n * blk_cap); nblk.assign(n, 0u);
         KPreArgs p;
         p.src = src; p.in_off = in_off; p.in_len = in_len; p.n_slices = n;
-        p.stage = stage.data(); p.seq_cap = seq_cap; p.blk = pblk.data(); p.blk_cap = blk_cap; p.nblk = nblk.data();
-        kxemu::launch_block((n + KXP_FRAMES - 1) / KXP_FRAMES, KXP_WAVES, [&]() { zstd_seq_predecode_body(p); });
+        std::vector<u32> ptables((size_t)n * KXP_TBL_WORDS, 0xEFEFEFEFu);
+        p.stage = stage.data(); p.seq_cap = seq_cap; p.blk = pblk.data(); p.blk_cap = blk_cap; p.nblk = nblk.data(); p.tables = ptables.data();
+        kxemu::launch((n + 63) / 64, [&]() { zstd_seq_predecode_body(p); });
         if (kxemu::failed) return -2;
         d.pre_stage = stage.data(); d.pre_seq_cap = seq_cap; d.pre_blk = pblk.data(); d.pre_blk_cap = blk_cap; d.pre_nblk = nblk.data();
     }
