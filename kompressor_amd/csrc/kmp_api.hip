@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 
     if (len == 0) { u8* d = dst + out_off[i]; kx_st32(d, 0xFD2FB528u); d[4] = wd ? 0x00 : 0x20; d[5] = (u8)wd; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
     else atomicAdd(remaining, 1u);
 }
-__global__ __launch_bounds__(64, 6) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
+__global__ __launch_bounds__(64, 5) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
 // the sequence bitstreams decoded ahead of it, one lane per frame (FSE tables in HBM)
 __global__ __launch_bounds__(64) void k_zstd_seq_predecode(KPreArgs a) { zstd_seq_predecode_body(a); }
 // ... and the Huffman-coded literals, one lane per stream (32 frames per workgroup of 128 threads)

@@ -30,13 +30,15 @@ struct KDecodeArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
     u8* dst; const u64* out_off; const u32* out_cap; u32* out_len; u32* status;
     u8* lits; u32 lit_cap;                 // per frame: decoded literals of one block
-    u32 flags;                             // timing-only ablations (results wrong): 1 skip Huffman walk, 2 skip sequences, 4 skip copies
+    u32 flags;                             // timing-only ablations (results wrong): 1 skip Huffman walk, 2 skip sequences, 4 skip copies;
+                                           //   window executor: 8 skip the flush, 16 short literals, 32 short matches from HBM, 64 all matches
     const u8* dict; u32 dict_size;         // raw-content dictionary shared by the batch (history before every frame), or null / 0
 };
 
 enum { KZE_GENERIC = 1, KZE_PREFIX = 10, KZE_FRAMEPARAM = 14, KZE_WINDOW = 16, KZE_CORRUPT = 20, KZE_CHECKSUM = 22,
        KZE_LITHDR = 24, KZE_DICT = 32, KZE_WORKSPACE = 66, KZE_DSTSMALL = 70, KZE_SRCSIZE = 72 };
 
+#define KXD_WIN 5120u
 struct KDecodeLds {
     union {                     // phase-shared region: the phases of a block never overlap in time
         u16 huf[2048];          // literal phase: Huffman decoding table (depth <= 11, RFC 8878): symbol | nbBits << 8
@@ -50,6 +52,9 @@ struct KDecodeLds {
                                 //   + 1 spare); also the spread scratch
             u32 stage[194];     // 64 x (litLength, matchLength, offset) + error flag
         } q;
+        struct {                // sequence phase of a block whose sequences were decoded ahead (no tables, no bitstream):
+            u8 win[KXD_WIN];    // the newest output, [winBase, op + the chunk in the making): matches are resolved here
+        } w;
     } u;
     u32 llx[36];                // per code: baseValue | extraBits << 24
     u32 mlx[53];
@@ -61,6 +66,8 @@ struct KDecodeLds {
     u32 rank[16];
     u32 bc[16];                 // lane 0 -> wave broadcast slots
 };
+KX_SHARED KDecodeLds g_kxd_lds;        // k_zstd_decode's workgroup (one wave) state; file scope so that a function called from the kernel can name it
+
 enum { KXD_LL0 = 0, KXD_ML0 = 512, KXD_OF0 = 1024 };
 
 // ---- forward (LSB-first) bit reader over bytes, for table descriptions ----
@@ -319,7 +326,7 @@ KX_DEV int kxd_seq_base(int t) { return t == 0 ? KXD_LL0 : t == 1 ? KXD_OF0 : KX
 // with the Huffman table, so every block builds its tables; "repeat" rebuilds from what the last table was made of).
 // Returns bytes consumed, KXD_FAIL on error.
 #define KXD_FAIL 0xFFFFFFFFu
-KX_DEV u32 kxd_seq_table(KDecodeLds& lds, int t, u32 mode, const u8* p, u32 size, u32* tableLog)
+KX_DEV u32 kxd_seq_table(KDecodeLds& lds, int t, u32 mode, const u8* p, u32 size, u32* tableLog, bool build)
 {
     static const short LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2, 2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
     static const short ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,
@@ -346,7 +353,8 @@ KX_DEV u32 kxd_seq_table(KDecodeLds& lds, int t, u32 mode, const u8* p, u32 size
         lds.keepKind[t] = 2; lds.keepLog[t] = tl; lds.keepMax[t] = maxSV;
         used = h;
     } else if (lds.keepKind[t] == 0) return KXD_FAIL;    // repeat without a previous table
-    if (lds.keepKind[t] == 1) { db[0] = 0; dc[0] = (u8)lds.keepMax[t]; }          // nbBits 0, next state 0
+    if (!build) { }                                     // the block's sequences are decoded already: the description is kept for a later "repeat"
+    else if (lds.keepKind[t] == 1) { db[0] = 0; dc[0] = (u8)lds.keepMax[t]; }          // nbBits 0, next state 0
     else kfse_build_dtable(db, dc, lds.keepNorm[t], lds.keepMax[t], lds.keepLog[t], lds.symnext, spread);
     *tableLog = lds.keepLog[t];
     return used;
@@ -358,6 +366,243 @@ KX_DEV void kxd_wave_copy(u8* dst, const u8* src, u32 n, int lane)
     for (; i + 8 <= n; i += 512u) kx_st64(dst + i, kx_ld64(src + i));
     u32 const tail = n & ~7u;
     if (lane < (int)(n - tail)) dst[tail + lane] = src[tail + lane];
+}
+
+// Exactly n (<= 32) bytes from s to d, the two ranges disjoint.  Every load is issued before the first store, so the
+// copy costs one memory latency whatever n is (a byte loop costs one per step: the compiler must assume s and d alias).
+// The pieces overlap instead of shrinking: [0,8) [8,16) [16,24) and the last eight bytes; two words below eight bytes;
+// first, middle and last byte below four.
+KX_DEV void kxd_copy32(u8* d, const u8* s, u32 n)
+{
+    if (n >= 8) {
+        u32 const o1 = n > 16 ? 8u : 0u, o2 = n > 24 ? 16u : 0u;
+        u64 const v0 = kx_ld64(s), v1 = kx_ld64(s + o1), v2 = kx_ld64(s + o2), vt = kx_ld64(s + n - 8);
+        kx_st64(d, v0);
+        if (n > 16) kx_st64(d + 8, v1);
+        if (n > 24) kx_st64(d + 16, v2);
+        kx_st64(d + n - 8, vt);
+    } else if (n >= 4) {
+        u32 const v0 = kx_ld32(s), vt = kx_ld32(s + n - 4);
+        kx_st32(d, v0); kx_st32(d + n - 4, vt);
+    } else if (n) {
+        u8 const b0 = s[0], b1 = s[n >> 1], b2 = s[n - 1];
+        d[0] = b0; d[n >> 1] = b1; d[n - 1] = b2;
+    }
+}
+
+// kxd_copy32 in two halves, so that several copies' loads are in flight before the first store waits for one of them
+struct KxdRun32 { u64 v0, v1, v2, vt; };
+KX_DEV void kxd_load32(KxdRun32& r, const u8* s, u32 n)
+{
+    r.v0 = 0; r.v1 = 0; r.v2 = 0; r.vt = 0;
+    if (n >= 8) {
+        u32 const o1 = n > 16 ? 8u : 0u, o2 = n > 24 ? 16u : 0u;
+        r.v0 = kx_ld64(s); r.v1 = kx_ld64(s + o1); r.v2 = kx_ld64(s + o2); r.vt = kx_ld64(s + n - 8);
+    } else if (n >= 4) { r.v0 = kx_ld32(s); r.vt = kx_ld32(s + n - 4); }
+    else if (n) { r.v0 = s[0]; r.v1 = s[n >> 1]; r.vt = s[n - 1]; }
+}
+KX_DEV void kxd_store32(u8* d, const KxdRun32& r, u32 n)
+{
+    if (n >= 8) {
+        kx_st64(d, r.v0);
+        if (n > 16) kx_st64(d + 8, r.v1);
+        if (n > 24) kx_st64(d + 16, r.v2);
+        kx_st64(d + n - 8, r.vt);
+    } else if (n >= 4) { kx_st32(d, (u32)r.v0); kx_st32(d + n - 4, (u32)r.vt); }
+    else if (n) { d[0] = (u8)r.v0; d[n >> 1] = (u8)r.v1; d[n - 1] = (u8)r.vt; }
+}
+
+// One byte of the frame's output (or of the dictionary before it) while a chunk is being put together: absolute
+// position q below the write front.  What lies at or above winBase is in the LDS window, everything below the chunk's
+// first byte has been flushed to dst; q < fbase is dictionary content.
+KX_DEV u8 kxd_hist_byte(const u8* dict, u32 dict_size, const u8* win, u32 winBase, const u8* dst, u32 q, bool inDictRange, u32 dictBack)
+{
+    if (inDictRange) return dict[dict_size - dictBack];
+    return q >= winBase ? win[q - winBase] : dst[q];
+}
+
+// ---- the sequences of one block, decoded ahead of this kernel, executed through an LDS window ----------------------
+// Executing sequences against dst in HBM costs the texture addresser one slot per lane and instruction (every lane
+// copies a few bytes somewhere else) and a trip to L2 per dependency round.  Here a chunk of up to 64 sequences is put
+// together in LDS -- literals and far matches come in from HBM, near matches (source inside the window) are LDS to LDS
+// copies, and the rounds that order dependent matches cost LDS latency -- and goes out to dst as one contiguous run.
+// The window keeps the chunks already written as history while they fit; a chunk that does not fit behind them
+// starts the window over, and a single sequence larger than the window is copied HBM to HBM by the whole wave.
+// Same checks and error codes as the loop in zstd_decode_frame.
+// Everything that is the same in every lane is taken with kx_bcast (v_readlane: the result lives in a scalar
+// register), never kx_shfl: positions, sizes and with them every address stay scalar base + 32-bit lane offset.
+struct KxdExecResult { u32 err, op, litUsed; };
+#define KXD_EXEC_FAIL(e_) { KxdExecResult r_; r_.err = (e_); r_.op = op; r_.litUsed = litUsed; return r_; }
+KX_DEV KxdExecResult kxd_exec_window(const u8* dict, u32 dict_size, u32 flags, const u32* preSeq, u32 nbSeq,
+                                              u8* dst, u32 fbase, u32 cap, const u8* litPtr, u32 regen, u32 op)
+{
+    int const lane = kx_lane();
+    u8* const win = g_kxd_lds.u.w.win;
+    u32 litUsed = 0, winBase = op;
+    u32 heldAt = 0xFFFFFFFFu, hLL = 0, hML = 0, hOF = 1;            // lane i holds sequence heldAt + i
+    for (u32 done = 0; done < nbSeq; ) {
+        u32 cnt = (nbSeq - done) < 64 ? (nbSeq - done) : 64;
+        if (heldAt != done) {
+            u32 const ix = done + (u32)lane;
+            if (ix < nbSeq) { hLL = preSeq[3 * ix]; hML = preSeq[3 * ix + 1]; hOF = preSeq[3 * ix + 2]; }
+            heldAt = done;
+        }
+        u32 pLL = 0, pML = 0, pOF = 1;                                // the next chunk's, requested now
+        { u32 const nx = done + 64u + (u32)lane; if (nx < nbSeq) { pLL = preSeq[3 * nx]; pML = preSeq[3 * nx + 1]; pOF = preSeq[3 * nx + 2]; } }
+        bool own = (u32)lane < cnt;
+        u32 ll = own ? hLL : 0u, ml = own ? hML : 0u, off = own ? hOF : 1u;
+        u32 sl = ll, st = ll + ml;                    // inclusive scans over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            u32 const a1 = kx_shfl(sl, lane - o), a2 = kx_shfl(st, lane - o);
+            if (lane >= o) { sl += a1; st += a2; }
+        }
+        u32 const fit = kx_popc64(kx_ballot(own && st <= KXD_WIN));
+        if (fit == 0) {
+            // the chunk's first sequence alone is larger than the window: HBM to HBM, by the whole wave
+            u32 const llE = kx_bcast(ll, 0), mlE = kx_bcast(ml, 0), offE = kx_bcast(off, 0);
+            if (litUsed + llE > regen) KXD_EXEC_FAIL(KZE_CORRUPT)
+            if ((u64)op + llE + mlE > cap) KXD_EXEC_FAIL(KZE_DSTSMALL)
+            u32 const dE = op + llE;
+            if (offE > dE - fbase + dict_size) KXD_EXEC_FAIL(KZE_CORRUPT)
+            if (!(flags & 4u)) {
+                kxd_wave_copy(dst + op, litPtr + litUsed, llE, lane);
+                kx_lockstep();
+                u32 const inDict = offE > dE - fbase ? offE - (dE - fbase) : 0u;
+                const u8* const dsrc = dict + (dict_size - inDict);
+                if (offE >= 64) {
+                    for (u32 base = 0; base < mlE; base += 64) {
+                        u32 const k = base + (u32)lane;
+                        if (k < mlE) dst[dE + k] = (k < inDict) ? dsrc[k] : dst[dE + k - offE];
+                        kx_lockstep();
+                    }
+                } else if (inDict) {
+                    if (lane == 0) for (u32 k = 0; k < mlE; k++) dst[dE + k] = (k < inDict) ? dsrc[k] : dst[dE + k - offE];
+                } else {
+                    u32 const chunk = (64 / offE) * offE; u32 const m = (u32)lane % offE;
+                    u8 v = 0;
+                    if ((u32)lane < chunk) v = dst[dE - offE + m];
+                    for (u32 base = 0; base < mlE; base += chunk) {
+                        u32 const k = base + (u32)lane;
+                        if ((u32)lane < chunk && k < mlE) dst[dE + k] = v;
+                    }
+                }
+                kx_lockstep();
+            }
+            op += llE + mlE; litUsed += llE; winBase = op;
+            done += 1;
+            continue;
+        }
+        if (fit < cnt) { cnt = fit; own = (u32)lane < cnt; if (!own) { ll = 0; ml = 0; off = 1; } }
+        u32 const totLit = kx_bcast(sl, (int)cnt - 1), totOut = kx_bcast(st, (int)cnt - 1);
+        if (litUsed + totLit > regen) KXD_EXEC_FAIL(KZE_CORRUPT)
+        if ((u64)op + totOut > cap) KXD_EXEC_FAIL(KZE_DSTSMALL)
+        u32 const lp = litUsed + (sl - ll);           // my literals in the literal buffer
+        u32 const dlit = op + (st - ll - ml);         // where they go
+        u32 const dmat = dlit + ll;                   // where my match goes
+        // a match may start inside the dictionary (the history before the frame's first byte)
+        if (kx_any(own && off > dmat - fbase + dict_size)) KXD_EXEC_FAIL(KZE_CORRUPT)
+        if (!(flags & 4u)) {
+            if ((op - winBase) + totOut > KXD_WIN) winBase = op;      // no room behind the history: start over
+            // ---- everything that depends on nothing in this chunk, with every HBM load in flight at once ----
+            // literals (from the literal buffer) and "early" matches, whose whole source lies in earlier chunks' output
+            // (below op): in the window if it reaches back that far, else in dst.
+            u32 const srcPos = dmat - off;                                // meaningful when the match starts inside the frame
+            bool const inDictL = off > dmat - fbase;
+            bool const inWin = !inDictL && srcPos >= winBase;             // the source lies in the window
+            bool const early = own && !inDictL && srcPos + ml <= op;
+            u8* const dl_ = win + (dlit - winBase); u8* const dm_ = win + (dmat - winBase);
+            u64 const longFar = kx_ballot(early && ml > 32 && !inWin);
+            // (the first long match from dst: its first 512 bytes travel with the rest)
+            int const lf = longFar ? (int)kx_ctz64(longFar) : 0;
+            u32 const lfN = longFar ? kx_bcast(ml, lf) : 0u, lfS = kx_bcast(srcPos, lf), lfD = kx_bcast(dmat, lf) - winBase;
+            u64 lfV = 0; u8 lfB = 0;
+            if ((u32)lane * 8u + 8u <= lfN) lfV = kx_ld64(dst + lfS + (u32)lane * 8u);
+            if ((lfN & ~7u) < 512u && (u32)lane < (lfN & 7u)) lfB = dst[lfS + (lfN & ~7u) + (u32)lane];
+            KxdRun32 rl, rm;
+            u32 const nl = (own && ll <= 32 && !(flags & 16u)) ? ll : 0u;
+            u32 const nm = (early && ml <= 32 && !inWin && !(flags & 32u)) ? ml : 0u;
+            kxd_load32(rl, litPtr + lp, nl);
+            kxd_load32(rm, dst + srcPos, nm);
+            if (early && ml <= 32 && inWin) kxd_copy32(dm_, win + (srcPos - winBase), ml);       // (LDS to LDS: disjoint, srcPos + ml <= op <= dmat)
+            kxd_store32(dl_, rl, nl);
+            kxd_store32(dm_, rm, nm);
+            if ((u32)lane * 8u + 8u <= lfN) kx_st64(win + lfD + (u32)lane * 8u, lfV);
+            if ((lfN & ~7u) < 512u && (u32)lane < (lfN & 7u)) win[lfD + (lfN & ~7u) + (u32)lane] = lfB;
+            if (lfN > 512u) kxd_wave_copy(win + lfD + 512u, dst + lfS + 512u, lfN - 512u, lane);
+            // the other long ones, one at a time: literals, further matches from dst, matches from the window
+            for (u64 longs = kx_ballot(own && ll > 32); longs; longs &= longs - 1) {
+                int const e = (int)kx_ctz64(longs);
+                kxd_wave_copy(win + (kx_bcast(dlit, e) - winBase), litPtr + kx_bcast(lp, e), kx_bcast(ll, e), lane);
+            }
+            for (u64 m = longFar & (longFar - 1); m; m &= m - 1) {
+                int const e = (int)kx_ctz64(m);
+                kxd_wave_copy(win + (kx_bcast(dmat, e) - winBase), dst + kx_bcast(srcPos, e), kx_bcast(ml, e), lane);
+            }
+            for (u64 m = kx_ballot(early && ml > 32 && inWin); m; m &= m - 1) {
+                int const e = (int)kx_ctz64(m);
+                kxd_wave_copy(win + (kx_bcast(dmat, e) - winBase), win + (kx_bcast(srcPos, e) - winBase), kx_bcast(ml, e), lane);
+            }
+            kx_lockstep();
+            // ---- the matches that read this chunk, in dependency rounds (as in zstd_decode_frame): LDS to LDS ----
+            // a match copied by its own lane has its whole source in the window; anything else goes by the whole wave
+            bool const byWave = ml > 32 || off < 8 || inDictL || !inWin;
+            u64 const W = kx_ballot(own && byWave);
+            for (u64 P = (flags & 64u) ? 0ull : kx_ballot(own && !early); P; ) {
+                int const e = (int)kx_ctz64(P);
+                u32 const dE = kx_bcast(dmat, e);
+                if ((W >> e) & 1ull) {
+                    u32 const mlE = kx_bcast(ml, e), offE = kx_bcast(off, e);
+                    u32 const inDict = offE > dE - fbase ? offE - (dE - fbase) : 0u;      // leading bytes that come from the dictionary
+                    u32 const sE = dE - offE;
+                    u8* const dw = win + (dE - winBase);
+                    if (!inDict && offE >= mlE && sE >= winBase) kxd_wave_copy(dw, win + (sE - winBase), mlE, lane);
+                    else if (offE >= 64) {
+                        for (u32 base = 0; base < mlE; base += 64) {
+                            u32 const k = base + (u32)lane;
+                            if (k < mlE) dw[k] = kxd_hist_byte(dict, dict_size, win, winBase, dst, sE + k, k < inDict, inDict - k);
+                            kx_lockstep();
+                        }
+                    } else if (inDict) {
+                        if (lane == 0) for (u32 k = 0; k < mlE; k++) dw[k] = kxd_hist_byte(dict, dict_size, win, winBase, dst, sE + k, k < inDict, inDict - k);
+                    } else {
+                        u32 const chunk = (64 / offE) * offE; u32 const m = (u32)lane % offE;
+                        u8 v = 0;
+                        if ((u32)lane < chunk) v = kxd_hist_byte(dict, dict_size, win, winBase, dst, sE + m, false, 0);
+                        for (u32 base = 0; base < mlE; base += chunk) {
+                            u32 const k = base + (u32)lane;
+                            if ((u32)lane < chunk && k < mlE) dw[k] = v;
+                        }
+                    }
+                    kx_lockstep();
+                    P &= P - 1;
+                    continue;
+                }
+                bool const safe = ((P >> lane) & 1ull) && !byWave && (lane == e || srcPos + ml <= dE);
+                if (safe) {
+                    // only the earliest pending match can overlap its own source (the others' sources end below its destination)
+                    const u8* const s_ = win + (srcPos - winBase);
+                    if (off >= ml) kxd_copy32(dm_, s_, ml);
+                    else { u32 k = 0; for (; k + 8 <= ml; k += 8) kx_st64(dm_ + k, kx_ld64(s_ + k)); for (; k < ml; k++) dm_[k] = s_[k]; }
+                }
+                P &= ~kx_ballot(safe);
+                kx_lockstep();
+            }
+            // ---- the chunk goes out ----
+            if (!(flags & 8u)) {
+                const u8* const w0 = win + (op - winBase); u8* const d0 = dst + op;
+                u32 i = (u32)lane * 8u;
+                for (; i + 8 <= totOut; i += 512u) kx_st64(d0 + i, kx_ld64(w0 + i));
+                u32 const tail = totOut & ~7u;
+                if ((u32)lane < totOut - tail) d0[tail + lane] = w0[tail + lane];
+            }
+            kx_lockstep();
+        }
+        op += totOut; litUsed += totLit;
+        if (cnt == 64) { hLL = pLL; hML = pML; hOF = pOF; heldAt = done + 64; }
+        done += cnt;
+    }
+    KXD_EXEC_FAIL(0u)
 }
 
 KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int lane)
@@ -561,9 +806,9 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                 u32 const mode = (modes >> (6 - 2 * t)) & 3u;
                 if (lane == 0) {
                     u32 r;
-                    if (t == 0) r = kxd_seq_table(lds, 0, mode, bp + spos, bend - spos, &tlLL);
-                    else if (t == 1) r = kxd_seq_table(lds, 1, mode, bp + spos, bend - spos, &tlOF);
-                    else r = kxd_seq_table(lds, 2, mode, bp + spos, bend - spos, &tlML);
+                    if (t == 0) r = kxd_seq_table(lds, 0, mode, bp + spos, bend - spos, &tlLL, !preSeq);
+                    else if (t == 1) r = kxd_seq_table(lds, 1, mode, bp + spos, bend - spos, &tlOF, !preSeq);
+                    else r = kxd_seq_table(lds, 2, mode, bp + spos, bend - spos, &tlML, !preSeq);
                     lds.bc[4] = r; lds.bc[5] = (t == 0) ? tlLL : (t == 1) ? tlOF : tlML;
                 }
                 kx_sync();
@@ -578,7 +823,13 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
         // lane 0 keeps the table logs / validity for later blocks; share them
         tlLL = kx_bcast(tlLL, 0); tlOF = kx_bcast(tlOF, 0); tlML = kx_bcast(tlML, 0);
         u32 litUsed = 0;
-        if (nbSeq && !(a.flags & 2u)) {
+        if (nbSeq && preSeq && !(a.flags & 2u)) {
+            KxdExecResult const xr = kxd_exec_window(a.dict, a.dict_size, a.flags, preSeq, nbSeq, dst, fbase, cap, litPtr, regen, op);
+            err = xr.err; op = xr.op; litUsed = xr.litUsed;
+            if (err) break;
+            rep1 = preRep1; rep2 = preRep2; rep3 = preRep3;      // the repeat offsets after the block, for a later block decoded here
+            kx_sync();
+        } else if (nbSeq && !(a.flags & 2u)) {
             const u8* const sq = bp + spos; u32 const ssz = bend - spos;
             u32 const lastByte = sq[ssz - 1];
             if (lastByte == 0) { err = KZE_CORRUPT; break; }
@@ -600,9 +851,11 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
 #define KXD_AT(C_, c_, n_) ((u32)((((C_) << (c_)) >> 1) >> (63u - (n_))))
             for (u32 done = 0; done < nbSeq && !err; ) {
                 u32 const cnt = (nbSeq - done) < 64 ? (nbSeq - done) : 64;
+                bool const own = (u32)lane < cnt;
+                u32 ll, ml, off;
                 // keep >= 176 words (64 sequences x <= 88 bits) of stream below the read position in LDS (254 staged)
                 int const curWord = (int)kx_bcast((u32)bitPos, 0) >> 5;
-                if (!preSeq && (sbLo < 0 || (sbLo > 0 && curWord - sbLo < 176))) {
+                if (sbLo < 0 || (sbLo > 0 && curWord - sbLo < 176)) {
                     int newLo = curWord + 2 - 254; if (newLo < 0) newLo = 0;
                     int hiW = curWord + 2; if (hiW > totalWords) hiW = totalWords;
                     kx_sync();
@@ -617,11 +870,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                     sbLo = newLo;
                     kx_sync();
                 }
-                if (preSeq) {
-                    // decoded ahead of this kernel: 64 sequences are one coalesced load
-                    for (u32 i = (u32)lane; i < 3u * cnt; i += 64) lds.u.q.stage[i] = preSeq[3u * done + i];
-                    if (lane == 0) lds.u.q.stage[192] = 0u;
-                } else {
+                {
                     // Every lane runs the loop (the cost of an instruction does not depend on how many lanes are active);
                     // lanes 0, 1, 2 decode the OF, ML and LL field of a sequence at once: one table look-up, one extra-bits
                     // field and one state update per lane instead of three in a row on one lane.  Lanes >= 3 shadow lane 2.
@@ -677,12 +926,11 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                     }
                     if (lastChunk && !bad && bitPos != 0) bad = true;
                     if (lane == 0) lds.u.q.stage[192] = bad ? 1u : 0u;
+                    kx_sync();
+                    if (lds.u.q.stage[192]) { err = KZE_CORRUPT; break; }
+                    ll = own ? lds.u.q.stage[3 * lane] : 0u; ml = own ? lds.u.q.stage[3 * lane + 1] : 0u; off = own ? lds.u.q.stage[3 * lane + 2] : 1u;
                 }
-                kx_sync();
-                if (lds.u.q.stage[192]) { err = KZE_CORRUPT; break; }
                 // ---- execute the chunk: lane i owns sequence i -----------------
-                bool const own = (u32)lane < cnt;
-                u32 const ll = own ? lds.u.q.stage[3 * lane] : 0u, ml = own ? lds.u.q.stage[3 * lane + 1] : 0u, off = own ? lds.u.q.stage[3 * lane + 2] : 1u;
                 u32 sl = ll, st = ll + ml;                    // inclusive scans over the lanes
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
@@ -699,11 +947,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                 if (kx_any(own && off > dmat - fbase + a.dict_size)) { err = KZE_CORRUPT; break; }
                 // literals: short runs lane-serially (exact length), long runs by the whole wave
                 if (a.flags & 4u) { op += totOut; litUsed += totLit; kx_sync(); done += cnt; continue; }
-                if (own && ll <= 32) {
-                    const u8* const s_ = litPtr + lp; u8* const d_ = dst + dlit; u32 k = 0;
-                    for (; k + 8 <= ll; k += 8) kx_st64(d_ + k, kx_ld64(s_ + k));
-                    for (; k < ll; k++) d_[k] = s_[k];
-                }
+                if (own && ll <= 32) kxd_copy32(dst + dlit, litPtr + lp, ll);
                 for (u64 longs = kx_ballot(own && ll > 32); longs; longs &= longs - 1) {
                     int const e = (int)kx_ctz64(longs);
                     kxd_wave_copy(dst + kx_bcast(dlit, e), litPtr + kx_bcast(lp, e), kx_bcast(ll, e), lane);      // e is uniform: v_readlane, no LDS permute
@@ -755,9 +999,10 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
                     }
                     bool const safe = ((P >> lane) & 1ull) && ml <= 32 && off >= 8 && off <= dmat - fbase && (lane == e || dmat - off + ml <= dE);
                     if (safe) {
-                        const u8* const s_ = dst + dmat - off; u8* const d_ = dst + dmat; u32 k = 0;
-                        for (; k + 8 <= ml; k += 8) kx_st64(d_ + k, kx_ld64(s_ + k));
-                        for (; k < ml; k++) d_[k] = s_[k];
+                        // only the earliest pending match can overlap its own source (the others' sources end below its destination)
+                        const u8* const s_ = dst + dmat - off; u8* const d_ = dst + dmat;
+                        if (off >= ml) kxd_copy32(d_, s_, ml);
+                        else { u32 k = 0; for (; k + 8 <= ml; k += 8) kx_st64(d_ + k, kx_ld64(s_ + k)); for (; k < ml; k++) d_[k] = s_[k]; }
                     }
                     P &= ~kx_ballot(safe);
                     kx_lockstep();
@@ -771,7 +1016,6 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
 #undef KXD_CONTAINER
 #undef KXD_WORD
             if (err) break;
-            if (preSeq) { rep1 = preRep1; rep2 = preRep2; rep3 = preRep3; }      // the repeat offsets after the block, for a later block decoded here
         }
         // remaining literals
         if (a.flags & 2u) litUsed = 0;
@@ -801,7 +1045,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
 
 KX_DEV void zstd_decode_body(const KDecodeArgs& a)
 {
-    KX_SHARED KDecodeLds lds;
+    KDecodeLds& lds = g_kxd_lds;
     int const lane = kx_lane();
     if (lane < 36) lds.llx[lane] = kx_ll_base((u32)lane) | (kxd_ll_bits((u32)lane) << 24);
     if (lane < 53) lds.mlx[lane] = kx_ml_base((u32)lane) | (kxd_ml_bits((u32)lane) << 24);
