@@ -68,6 +68,7 @@ KX_DEV void kx_lds_or(u32* p, u32 v) { atomicOr(p, v); }
 #define KX_OPAQUE(x) __asm__ volatile("" : "+v"(x))
 
 // ---- bit tricks -------------------------------------------------------
+KX_DEV u32 kx_alignbit(u32 hi, u32 lo, u32 s) { return __builtin_amdgcn_alignbit(hi, lo, s); }      // low 32 bits of (hi : lo) >> (s & 31)
 KX_DEV u32 kx_alignbyte(u32 hi, u32 lo, u32 bytes) { return __builtin_amdgcn_alignbyte(hi, lo, bytes); }   // ({hi,lo} >> 8*bytes) & 0xffffffff
 KX_DEV u32 kx_umulhi(u32 a, u32 b) { return __umulhi(a, b); }
 KX_DEV u32 kx_ctz32(u32 v) { return (u32)__builtin_ctz(v); }

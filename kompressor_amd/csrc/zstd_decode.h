@@ -240,33 +240,61 @@ KX_DEV u32 khuf_read_dtable(LDS& lds, const u8* p, u32 size, u32* tableLogOut, u
     return used;
 }
 
-// one lane decodes one Huffman stream of `count` symbols; returns false on corruption
+// n (<= 32) bits of the 128-bit window (hi : lo) starting t bits above lo's bit 0 (0 <= t, t + n <= 128); n = 0 gives 0
+KX_DEV u32 kxp_bits(u64 hi, u64 lo, int t, u32 n)
+{
+    u64 const x = (t >= 64) ? (hi >> (t - 64)) : ((lo >> t) | ((hi << 1) << (63 - t)));
+    return (u32)x & (u32)((1ull << n) - 1ull);
+}
+
+// 64 bits of a backward bitstream at word index j (bytes [8 j, 8 j + 8)); words below the stream read as zero, the
+// last one may be short
+KX_DEV u64 kxp_word(const u8* sq, u32 ssz, int j)
+{
+    if (j < 0) return 0;
+    u32 const o = 8u * (u32)j;
+    if (o + 8u <= ssz) return kx_ld64(sq + o);
+    u64 v = 0;
+    for (u32 k = 0; o + k < ssz; k++) v |= (u64)sq[o + k] << (8 * k);
+    return v;
+}
+
+// One lane decodes one Huffman stream of `count` symbols; returns false on corruption.
+// The unread bits sit at the top of a 64-bit container (hi : lo) held as two 32-bit halves -- a symbol is one shift of
+// hi, one LDS look-up and a funnel shift -- and 32 more come in whenever 32 or fewer are left, from a word that was
+// requested two refills earlier (the stream is cut into 32-bit words counted from its first byte; below it: zeros).
+// Four symbols and two refill points per trip, the symbols leave as one word.  Reading past the stream's first bit
+// is harmless (the trip count is the symbol count, table indices are tableLog bits) and shows in the final test:
+// the stream must have been consumed to exactly its first bit.
 template <class LDS>
 KX_DEV bool khuf_decode_stream(const LDS& lds, u32 tableLog, const u8* p, u32 size, u8* out, u32 count)
 {
-    KBackBits b;
-    if (!kbb_init(b, p, size)) return false;
+    if (size == 0) return false;
+    u32 const lastByte = p[size - 1];
+    if (lastByte == 0) return false;
+    u32 const totalBits = 8 * (size - 1) + kx_hb32(lastByte);
+    int j = (int)((size - 1) >> 2);                                // the top word (1 to 4 bytes of it exist)
+    u32 wt = 0;
+    for (u32 k = 4u * (u32)j; k < size; k++) wt |= (u32)p[k] << (8u * (k - 4u * (u32)j));
+    u32 const vb = totalBits - 32u * (u32)j;                       // its bits below the end mark: 0..31
+    u32 hi = vb ? wt << (32u - vb) : 0u, lo = 0, avail = vb;
+    u32 w1 = j >= 1 ? kx_ld32(p + 4 * (j - 1)) : 0u, w2 = j >= 2 ? kx_ld32(p + 4 * (j - 2)) : 0u;
+    j -= 2;                                                        // the word w2 holds
+    u32 consumed = 0; u32 const sh = 32u - tableLog;
+#define KHUF_REFILL if (avail <= 32u) { u64 const c_ = (((u64)hi << 32) | lo) | ((u64)w1 << (32u - avail)); hi = (u32)(c_ >> 32); lo = (u32)c_; \
+                                        avail += 32u; w1 = w2; j--; w2 = j >= 0 ? kx_ld32(p + 4 * j) : 0u; }
+#define KHUF_SYM(k_) { u32 const e_ = lds.u.huf[hi >> sh]; u32 const nb_ = e_ >> 8; hi = kx_alignbit(hi, lo, 32u - nb_); lo <<= nb_; \
+                       avail -= nb_; consumed += nb_; acc |= (e_ & 0xFFu) << (8 * (k_)); }
     u32 i = 0;
-    while (i < count) {
-        if (b.bits <= 0) return false;
-        // 64-bit window whose top bit is the next unread bit of the stream
-        int const end = (b.bits + 7) >> 3;
-        int const slack = 8 * end - b.bits;                 // already-consumed bits of the top byte
-        u64 w = kx_ld64(b.base + end - 8) << slack;
-        int avail = 64 - slack; if (avail > b.bits) avail = b.bits;
-        bool const tail = (avail == b.bits);                 // window reaches the stream start
-        if (avail < 64) w &= ~0ull << (64 - avail);          // bits before the stream start read as zero
-        int used = 0;
-        while (i < count) {
-            if (used + (int)tableLog > avail && !tail) break;                // refill
-            u32 const e = lds.u.huf[(u32)(w >> (64 - tableLog))];
-            int const nb = (int)(e >> 8);
-            if (used + nb > avail) return false;
-            out[i++] = (u8)e; w <<= nb; used += nb;
-        }
-        b.bits -= used;
+    for (; i + 4 <= count; i += 4) {
+        u32 acc = 0;
+        KHUF_REFILL KHUF_SYM(0) KHUF_SYM(1) KHUF_REFILL KHUF_SYM(2) KHUF_SYM(3)
+        kx_st32(out + i, acc);
     }
-    return b.bits == 0;
+    for (; i < count; i++) { u32 acc = 0; KHUF_REFILL KHUF_SYM(0) out[i] = (u8)acc; }
+#undef KHUF_SYM
+#undef KHUF_REFILL
+    return consumed == totalBits;
 }
 
 KX_DEV u64 kxxh_round(u64 acc, u64 in)

@@ -23,13 +23,6 @@
 #pragma once
 #include "zstd_decode.h"
 
-// n (<= 32) bits of the 128-bit window (hi : lo) starting t bits above lo's bit 0 (0 <= t, t + n <= 128); n = 0 gives 0
-KX_DEV u32 kxp_bits(u64 hi, u64 lo, int t, u32 n)
-{
-    u64 const x = (t >= 64) ? (hi >> (t - 64)) : ((lo >> t) | ((hi << 1) << (63 - t)));
-    return (u32)x & (u32)((1ull << n) - 1ull);
-}
-
 struct KPreArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
     u32* stage; u32 seq_cap;            // per entry: seq_cap x (litLength, matchLength, offset)
@@ -101,18 +94,6 @@ KX_DEV u32 kxp_seq_table(u32* tables, int t, u32 mode, const u8* p, u32 size, u3
     } else if (kind[t] == 0) return KXD_FAIL;            // repeat without a previous table
     *tableLog = klog[t];
     return used;
-}
-
-// 64 bits of a sequence bitstream at word index j (bytes [8 j, 8 j + 8)); words below the stream read as zero, the
-// last one may be short
-KX_DEV u64 kxp_word(const u8* sq, u32 ssz, int j)
-{
-    if (j < 0) return 0;
-    u32 const o = 8u * (u32)j;
-    if (o + 8u <= ssz) return kx_ld64(sq + o);
-    u64 v = 0;
-    for (u32 k = 0; o + k < ssz; k++) v |= (u64)sq[o + k] << (8 * k);
-    return v;
 }
 
 KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)

@@ -55,6 +55,7 @@ KX_DEV void kx_lds_or(u32* p, u32 v) { *p |= v; }
 
 #define KX_OPAQUE(x) __asm__ volatile("" : "+r"(x))
 
+KX_DEV u32 kx_alignbit(u32 hi, u32 lo, u32 s) { return (u32)((((u64)hi << 32) | lo) >> (s & 31)); }
 KX_DEV u32 kx_alignbyte(u32 hi, u32 lo, u32 bytes) { return (u32)((((u64)hi << 32) | lo) >> (8 * (bytes & 3))); }
 KX_DEV u32 kx_umulhi(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
 KX_DEV u32 kx_ctz32(u32 v) { return (u32)__builtin_ctz(v); }
