@@ -68,6 +68,9 @@ __global__ __launch_bounds__(64, 5) void k_zstd_decode(KDecodeArgs a) { zstd_dec
 __global__ __launch_bounds__(64) void k_zstd_seq_predecode(KPreArgs a) { zstd_seq_predecode_body(a); }
 // ... and the Huffman-coded literals, one lane per stream (32 frames per workgroup of 128 threads)
 __global__ __launch_bounds__(128) void k_zstd_lit_predecode(KLitArgs a) { zstd_lit_predecode_body(a); }
+__global__ __launch_bounds__(256) void k_zstd_seq_count(KSeqSortArgs a) { zstd_seq_count_body(a); }
+__global__ __launch_bounds__(256) void k_zstd_seq_rank(KSeqSortArgs a) { zstd_seq_rank_body(a); }
+__global__ __launch_bounds__(256) void k_zstd_seq_perm(KSeqSortArgs a) { zstd_seq_perm_body(a); }
 
 __global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chains_body<u16>(a); }          // slices <= 64 KiB
 __global__ __launch_bounds__(256) void k_deflate_chains_long(KdArgs a) { deflate_chains_body<u32>(a); }
@@ -167,14 +170,15 @@ struct kmp_batch_ctx {
     int big; int big_G; KFrameState* fstate; u32* hufct; u32* big_tables; u32* remaining; u32* big_counters; u32 last_rounds;
     u32 cus;                                   // compute units of the device
     // decoder: sequences decoded ahead of k_zstd_decode (allocated on first use; pre_tried: do not try again)
-    u32* pre_stage; KPreBlk* pre_blk; u32* pre_nblk; u32* pre_tables; u32 pre_seq_cap, pre_blk_cap; int pre_tried;
+    u64* pre_stage; KPreBlk* pre_blk; u32* pre_nblk; u32 pre_seq_cap, pre_blk_cap; int pre_tried;
+    u32* pre_sort;                              // per entry key and slot -> entry map, then KMP_MAX_CHUNKS x 256 bucket counters
     u8* pre_lits; KPreLit* pre_lit; u32* pre_nlit; u32 pre_lit_cap;
     u32* len_ok; u32* d_status;                // sanitised slice lengths of the running batch; status word (KMP_STATUS_*)
     // one batch at a time per context: a batch queued on another stream waits for the previous one's last kernel
     hipEvent_t ev_done; int have_done;
     // experiment switches, read from the environment once, when the context is created
     struct { u32 chunks, match_flags, entropy_pad, first_permille, entropy_flags, decode_flags, decode_pad, big_rounds, big_spw,
-                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre; } knob;
+                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre, decode_sort, decode_pieces; } knob;
 };
 
 static u32 env_u32(const char* name, u32 dflt)
@@ -246,7 +250,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     c->knob.dfl_serial = env_u32("KMP_DEFLATE_SERIAL", 0); c->knob.dfl_flags = env_u32("KMP_DEFLATE_FLAGS", 0);
     // experiment, off by default (measured slower): bit 0 = sequences decoded ahead of k_zstd_decode
     // (k_zstd_seq_predecode, one lane per frame), bit 1 = literals (k_zstd_lit_predecode, one lane per stream)
-    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 0);
+    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 1); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1);
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return KMP_OK;
@@ -267,7 +271,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     for (int i = 0; i <= KMP_MAX_CHUNKS; i++) if (c->ev_pre[i]) (void)hipEventDestroy(c->ev_pre[i]);
     (void)hipFree(c->len_ok); (void)hipFree(c->d_status);
-    (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); (void)hipFree(c->pre_tables);
+    (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); (void)hipFree(c->pre_sort);
     (void)hipFree(c->pre_lits); (void)hipFree(c->pre_lit); (void)hipFree(c->pre_nlit);
     if (c->st2) (void)hipStreamDestroy(c->st2);
     (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta); (void)hipFree(c->dfl_blocks);
@@ -658,18 +662,18 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
     d.lits = c->lits; d.lit_cap = c->lit_cap; d.flags = c->knob.decode_flags;
     KMP_TRY(batch_begin(c, st, nullptr, n, 0));            // the decoder checks every length itself; lits is shared with the compressors
     d.dict = (const u8*)d_dict; d.dict_size = d_dict ? dict_size : 0u;
-    // staging for the sequences decoded ahead (12 bytes per sequence, a frame of S bytes holds at most S / 3): allocated on
+    // staging for the sequences decoded ahead (8 bytes per sequence, a frame of S bytes holds at most S / 3): allocated on
     // first use; a context whose slices would need more than 64 GiB of it decodes everything in k_zstd_decode, as before
     if (!c->pre_tried && c->knob.decode_pre) {
         c->pre_tried = 1;
         u32 const seq_cap = c->max_slice_bytes / 3u + 64u, blk_cap = c->max_slice_bytes / 8192u + 16u, lit_cap = c->max_slice_bytes + 64u;
         c->pre_blk_cap = blk_cap;
-        if ((c->knob.decode_pre & 1u) && (u64)c->max_slices * seq_cap * 12ull <= (64ull << 30)) {
-            if (hipMalloc((void**)&c->pre_stage, (size_t)c->max_slices * seq_cap * 12u) == hipSuccess &&
+        if ((c->knob.decode_pre & 1u) && (u64)c->max_slices * seq_cap * 8ull <= (64ull << 30)) {
+            if (hipMalloc((void**)&c->pre_stage, (size_t)c->max_slices * seq_cap * 8u) == hipSuccess &&
                 hipMalloc((void**)&c->pre_blk, (size_t)c->max_slices * blk_cap * sizeof(KPreBlk)) == hipSuccess &&
                 hipMalloc((void**)&c->pre_nblk, (size_t)c->max_slices * 4u) == hipSuccess &&
-                hipMalloc((void**)&c->pre_tables, (size_t)c->max_slices * KXP_TBL_WORDS * 4u) == hipSuccess) c->pre_seq_cap = seq_cap;
-            else { (void)hipGetLastError(); (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); (void)hipFree(c->pre_tables); c->pre_stage = nullptr; c->pre_blk = nullptr; c->pre_nblk = nullptr; c->pre_tables = nullptr; }
+                hipMalloc((void**)&c->pre_sort, ((size_t)c->max_slices * 2u + (size_t)KMP_MAX_CHUNKS * KXP_SORT_BUCKETS) * 4u) == hipSuccess) c->pre_seq_cap = seq_cap;
+            else { (void)hipGetLastError(); (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); (void)hipFree(c->pre_sort); c->pre_stage = nullptr; c->pre_blk = nullptr; c->pre_nblk = nullptr; c->pre_sort = nullptr; }
         }
         if ((c->knob.decode_pre & 2u) && (u64)c->max_slices * lit_cap <= (64ull << 30)) {
             if (hipMalloc((void**)&c->pre_lits, (size_t)c->max_slices * lit_cap) == hipSuccess &&
@@ -692,17 +696,30 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
     if (c->pre_stage) {
         // The sequence pre-decoder is bound by memory transactions, the decoder by instruction issue: the batch goes through
         // in pieces, the pre-decoder (second stream) working on the pieces ahead of the one the decoder has.
-        u32 const pieces = (n >= 8192u) ? (u32)KMP_MAX_CHUNKS : 1u;
+        u32 pieces = (n >= 8192u) ? c->knob.decode_pieces : 1u;
+        if (pieces < 1u || pieces > (u32)KMP_MAX_CHUNKS) pieces = (u32)KMP_MAX_CHUNKS;
         u32 const per = ((n + pieces - 1) / pieces + 63u) & ~63u;
         HIP_TRY(hipEventRecord(c->ev_pre[0], st)); HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_pre[0], 0));     // st2 starts where st stands
+        u32* const sort_key = c->pre_sort; u32* const sort_perm = c->pre_sort + c->max_slices; u32* const sort_hist = c->pre_sort + 2u * (size_t)c->max_slices;
+        bool const sorted = c->knob.decode_sort != 0 && n >= 1024u;
+        if (sorted) HIP_TRY(hipMemsetAsync(sort_hist, 0, (size_t)KMP_MAX_CHUNKS * KXP_SORT_BUCKETS * 4u, c->st2));
         for (u32 first = 0, pi = 0; first < n; first += per, pi++) {
             u32 const m = (n - first < per) ? n - first : per;
+            if (sorted) {
+                KSeqSortArgs sa;
+                sa.src = d.src; sa.in_off = d_in_off + first; sa.in_len = d_in_len + first; sa.n_slices = m;
+                sa.key = sort_key + first; sa.hist = sort_hist + (size_t)pi * KXP_SORT_BUCKETS; sa.perm = sort_perm + first;
+                hipLaunchKernelGGL(k_zstd_seq_count, dim3((m + 255) / 256), dim3(256), 0, c->st2, sa);
+                hipLaunchKernelGGL(k_zstd_seq_rank, dim3(1), dim3(256), 0, c->st2, sa);
+                hipLaunchKernelGGL(k_zstd_seq_perm, dim3((m + 255) / 256), dim3(256), 0, c->st2, sa);
+                HIP_TRY(hipGetLastError());
+            }
             KPreArgs p;
+            p.perm = sorted ? sort_perm + first : nullptr;
             p.src = d.src; p.in_off = d_in_off + first; p.in_len = d_in_len + first; p.n_slices = m;
-            p.stage = c->pre_stage + (size_t)first * c->pre_seq_cap * 3u; p.seq_cap = c->pre_seq_cap;
+            p.stage = c->pre_stage + (size_t)first * c->pre_seq_cap; p.seq_cap = c->pre_seq_cap;
             p.blk = c->pre_blk + (size_t)first * c->pre_blk_cap; p.blk_cap = c->pre_blk_cap; p.nblk = c->pre_nblk + first;
-            p.tables = c->pre_tables + (size_t)first * KXP_TBL_WORDS;
-            hipLaunchKernelGGL(k_zstd_seq_predecode, dim3((m + 63) / 64), dim3(64), 0, c->st2, p);
+            hipLaunchKernelGGL(k_zstd_seq_predecode, dim3((m + KXP_FRAMES - 1) / KXP_FRAMES), dim3(64), 0, c->st2, p);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev_pre[1 + pi], c->st2));
         }
@@ -712,7 +729,7 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
             q.in_off = d_in_off + first; q.in_len = d_in_len + first; q.n_slices = m;
             q.out_off = d_out_off + first; q.out_cap = d_out_cap + first; q.out_len = d_out_len + first; q.status = d_status + first;
             q.lits = c->lits + (size_t)first * c->lit_cap;
-            q.pre_stage = c->pre_stage + (size_t)first * c->pre_seq_cap * 3u; q.pre_seq_cap = c->pre_seq_cap;
+            q.pre_stage = c->pre_stage + (size_t)first * c->pre_seq_cap; q.pre_seq_cap = c->pre_seq_cap;
             q.pre_blk = c->pre_blk + (size_t)first * c->pre_blk_cap; q.pre_blk_cap = c->pre_blk_cap; q.pre_nblk = c->pre_nblk + first;
             if (d.pre_lits) { q.pre_lits = d.pre_lits + (size_t)first * d.pre_lit_cap; q.pre_lit = d.pre_lit + (size_t)first * c->pre_blk_cap; q.pre_nlit = d.pre_nlit + first; }
             HIP_TRY(hipStreamWaitEvent(st, c->ev_pre[1 + pi], 0));

@@ -55,6 +55,11 @@ KX_DEV void kx_st16(u8* p, u32 v) { u16 x = (u16)v; __builtin_memcpy(p, &x, 2); 
 struct alignas(16) KxU128 { u64 a, b; };
 KX_DEV void kx_st128(void* p, u64 a, u64 b) { KxU128 v; v.a = a; v.b = b; *(KxU128*)p = v; }
 
+// sixteen bytes as four words: the global side may be unaligned (one global_load/store_dwordx4), the LDS side is 16-byte aligned
+struct alignas(16) KxQuad { u32 x, y, z, w; };
+KX_DEV KxQuad kx_ld128u(const u8* p) { KxQuad q; __builtin_memcpy(&q, p, 16); return q; }
+KX_DEV void kx_st128u(u8* p, const KxQuad& q) { __builtin_memcpy(p, &q, 16); }
+
 KX_DEV u32 kx_ld_nt(const u32* p) { return __builtin_nontemporal_load(p); }
 KX_DEV void kx_st_nt(u32* p, u32 v) { __builtin_nontemporal_store(v, p); }
 KX_DEV u32 kx_atomic_add(u32* p, u32 v) { return atomicAdd(p, v); }

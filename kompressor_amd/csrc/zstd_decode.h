@@ -25,7 +25,7 @@ struct KPreBlk { u32 seq_off; u32 nbSeq; u32 ok; u32 rep[3]; u32 pad[2]; };
 struct KPreLit { u32 off; u32 regen; u32 ok; u32 pad; };
 
 struct KDecodeArgs {
-    const u32* pre_stage; u32 pre_seq_cap; const KPreBlk* pre_blk; u32 pre_blk_cap; const u32* pre_nblk;   // null / 0: nothing pre-decoded
+    const u64* pre_stage; u32 pre_seq_cap; const KPreBlk* pre_blk; u32 pre_blk_cap; const u32* pre_nblk;   // null / 0: nothing pre-decoded
     const u8* pre_lits; u32 pre_lit_cap; const KPreLit* pre_lit; const u32* pre_nlit;                      // (records: pre_blk_cap per entry)
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
     u8* dst; const u64* out_off; const u32* out_cap; u32* out_len; u32* status;
@@ -461,7 +461,7 @@ KX_DEV u8 kxd_hist_byte(const u8* dict, u32 dict_size, const u8* win, u32 winBas
 // register), never kx_shfl: positions, sizes and with them every address stay scalar base + 32-bit lane offset.
 struct KxdExecResult { u32 err, op, litUsed; };
 #define KXD_EXEC_FAIL(e_) { KxdExecResult r_; r_.err = (e_); r_.op = op; r_.litUsed = litUsed; return r_; }
-KX_DEV KxdExecResult kxd_exec_window(const u8* dict, u32 dict_size, u32 flags, const u32* preSeq, u32 nbSeq,
+KX_DEV KxdExecResult kxd_exec_window(const u8* dict, u32 dict_size, u32 flags, const u64* preSeq, u32 nbSeq,
                                               u8* dst, u32 fbase, u32 cap, const u8* litPtr, u32 regen, u32 op)
 {
     int const lane = kx_lane();
@@ -472,11 +472,11 @@ KX_DEV KxdExecResult kxd_exec_window(const u8* dict, u32 dict_size, u32 flags, c
         u32 cnt = (nbSeq - done) < 64 ? (nbSeq - done) : 64;
         if (heldAt != done) {
             u32 const ix = done + (u32)lane;
-            if (ix < nbSeq) { hLL = preSeq[3 * ix]; hML = preSeq[3 * ix + 1]; hOF = preSeq[3 * ix + 2]; }
+            if (ix < nbSeq) { u64 const v = preSeq[ix]; hLL = (u32)v & 0xFFFFu; hML = (((u32)v >> 16) & 0xFFFFu) + 3u; hOF = (u32)(v >> 32); }
             heldAt = done;
         }
         u32 pLL = 0, pML = 0, pOF = 1;                                // the next chunk's, requested now
-        { u32 const nx = done + 64u + (u32)lane; if (nx < nbSeq) { pLL = preSeq[3 * nx]; pML = preSeq[3 * nx + 1]; pOF = preSeq[3 * nx + 2]; } }
+        { u32 const nx = done + 64u + (u32)lane; if (nx < nbSeq) { u64 const v = preSeq[nx]; pLL = (u32)v & 0xFFFFu; pML = (((u32)v >> 16) & 0xFFFFu) + 3u; pOF = (u32)(v >> 32); } }
         bool own = (u32)lane < cnt;
         u32 ll = own ? hLL : 0u, ml = own ? hML : 0u, off = own ? hOF : 1u;
         u32 sl = ll, st = ll + ml;                    // inclusive scans over the lanes
@@ -824,10 +824,10 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
         if (lds.bc[0]) { err = lds.bc[0]; break; }
         u32 const nbSeq = lds.bc[1]; u32 spos = lds.bc[2]; u32 const modes = lds.bc[3];
         // this block's sequences may lie decoded in HBM already (k_zstd_seq_predecode)
-        const u32* preSeq = nullptr; u32 preRep1 = 0, preRep2 = 0, preRep3 = 0;
+        const u64* preSeq = nullptr; u32 preRep1 = 0, preRep2 = 0, preRep3 = 0;
         if (ord < npre) {
             KPreBlk const pb = a.pre_blk[(size_t)f * a.pre_blk_cap + ord];
-            if (pb.ok && pb.nbSeq == nbSeq && nbSeq) { preSeq = a.pre_stage + ((size_t)f * a.pre_seq_cap + pb.seq_off) * 3u; preRep1 = pb.rep[0]; preRep2 = pb.rep[1]; preRep3 = pb.rep[2]; }
+            if (pb.ok && pb.nbSeq == nbSeq && nbSeq) { preSeq = a.pre_stage + ((size_t)f * a.pre_seq_cap + pb.seq_off); preRep1 = pb.rep[0]; preRep2 = pb.rep[1]; preRep3 = pb.rep[2]; }
         }
         if (nbSeq) {
             for (int t = 0; t < 3 && !err; t++) {

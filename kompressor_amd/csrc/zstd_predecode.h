@@ -4,13 +4,12 @@
 // work: 86 % of that kernel's instructions served three lanes of a wave, and instruction issue
 // was what bound it.  A sequence costs the same instructions whether one lane or sixty-four execute them, so this
 // kernel turns the work sideways: a lane owns a whole frame, walks its blocks, builds the three FSE decoding tables of
-// each compressed block (in HBM: 5 KiB per frame, so that nothing limits how many frames are in flight; the first
-// version kept them in LDS, 32 frames per CU, and ran at one wave per SIMD with every latency exposed) and decodes the
-// block's sequences -- literal length, match length and the offset with the repeat-offset rules already applied --
-// into a staging area in HBM.  What it costs is three random table words per sequence: it is bound by memory
-// transactions where k_zstd_decode is bound by instruction issue, so the two run side by side on the same CUs.  k_zstd_decode then loads
-// 64 finished sequences per step instead of decoding them and keeps everything else (headers, literals, execution,
-// every check and error code).
+// each compressed block in its share of the LDS (2.5 KiB: one 16-bit word per state) and decodes the block's sequences
+// -- literal length, match length and the offset with the repeat-offset rules already applied -- into a staging area
+// in HBM, 8 bytes per sequence.  Sixteen frames share a wave (LDS capacity sets how many frames a CU has in flight;
+// tables in HBM instead -- tried, profiles/ -- lift that limit and put 1 to 2 us of memory latency into every state
+// transition).  k_zstd_decode then loads 64 finished sequences per step instead of decoding them and keeps everything
+// else (headers, literals, execution, every check and error code).
 //
 // This kernel is an accelerator, not an authority: it records a block as staged only if everything about it was
 // regular (the bitstream consumed to the last bit included); at the first doubt it stops, the remaining blocks of the
@@ -25,44 +24,50 @@
 
 struct KPreArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
-    u32* stage; u32 seq_cap;            // per entry: seq_cap x (litLength, matchLength, offset)
+    u64* stage; u32 seq_cap;            // per entry: seq_cap sequences: litLength | (matchLength - 3) << 16 | offset << 32
     KPreBlk* blk; u32 blk_cap;          // per entry: blk_cap records (compressed blocks in frame order)
     u32* nblk;                          // per entry: records written
-    u32* tables;                        // per entry: KXP_TBL_WORDS words: the three FSE decoding tables + their construction scratch
+    const u32* perm;                    // which entry each lane slot takes (k_zstd_seq_perm), or null: slot i takes entry i
 };
 
-// per entry in HBM: one word per FSE state (newStateBase | nbBits << 16 | symbol << 24), LL [0,512) ML [512,1024) OF [1024,1280),
-// then the normalised counts and the per-symbol cursor of the table under construction (56 x i16 + 56 x u16)
-#define KXP_TBL_WORDS (1280 + 56)
+// Per frame in LDS: one 16-bit word per FSE state -- the state's rank among its symbol's states, as "next" = count +
+// rank (10 bits; FSE_buildDTable's symbolNext), and the symbol (6 bits): nbBits = tableLog - highbit(next) and
+// newStateBase = (next << nbBits) - tableSize follow from it -- LL [0,512) ML [512,1024) OF [1024,1280), then the
+// normalised counts and the per-symbol cursor of the table under construction.
+#define KXP_FRAMES 16
+// ... and the two queues that keep HBM out of the sequence loop (see zstd_seq_predecode_body): 64 words of the
+// bitstream, eight finished sequences.
+#define KXP_RING 64
+struct KPreFrameLds { u16 tb[1280]; short norm[56]; u16 symnext[56]; alignas(16) u32 ring[KXP_RING + 4]; alignas(16) u64 outq[8]; };      // (ring[64], ring[65] repeat ring[0], ring[1]: three words in a row never wrap)
+struct KPreLds { KPreFrameLds f[KXP_FRAMES]; u32 llx[36]; u32 mlx[53]; };       // (llx, mlx: per code baseValue | extraBits << 24)
 
-// FSE table description -> the entry's table in HBM (same construction as kfse_build_dtable)
-KX_DEV void kxp_build_dtable(u32* tb, const short* norm, u32 maxSymbolValue, u32 tableLog, u16* symnext)
+// FSE table description -> the frame's table (same construction as kfse_build_dtable)
+KX_DEV void kxp_build_dtable(u16* tb, const short* norm, u32 maxSymbolValue, u32 tableLog, u16* symnext)
 {
     u32 const tableSize = 1u << tableLog, mask = tableSize - 1;
     u32 const step = (tableSize >> 1) + (tableSize >> 3) + 3;
     u32 high = tableSize - 1;
     for (u32 s = 0; s <= maxSymbolValue; s++) {
-        if (norm[s] == -1) { tb[high--] = s << 24; symnext[s] = 1; }
+        if (norm[s] == -1) { tb[high--] = (u16)s; symnext[s] = 1; }
         else symnext[s] = (u16)norm[s];
     }
     u32 pos = 0;
     for (u32 s = 0; s <= maxSymbolValue; s++) {
         for (int i = 0; i < norm[s]; i++) {
-            tb[pos] = s << 24;
+            tb[pos] = (u16)s;
             pos = (pos + step) & mask;
             while (pos > high) pos = (pos + step) & mask;
         }
     }
     for (u32 u = 0; u < tableSize; u++) {
-        u32 const s = tb[u] >> 24; u32 const next = symnext[s]++;
-        u32 const nb = tableLog - kx_hb32(next);
-        tb[u] = (((next << nb) - tableSize) & 0xFFFFu) | (nb << 16) | (s << 24);
+        u32 const s = tb[u]; u32 const next = symnext[s]++;
+        tb[u] = (u16)(next | (s << 10));
     }
 }
 
 // One symbol type's table for the block (a "repeat" mode keeps what is there).  kind[t]: 0 none yet, 1 RLE, 2 FSE.
 // Returns bytes consumed or KXD_FAIL.
-KX_DEV u32 kxp_seq_table(u32* tables, int t, u32 mode, const u8* p, u32 size, u32* tableLog, u32* kind, u32* klog)
+KX_DEV u32 kxp_seq_table(KPreFrameLds& fl, int t, u32 mode, const u8* p, u32 size, u32* tableLog, u32* kind, u32* klog)
 {
     static const short LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2, 2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
     static const short ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,
@@ -70,25 +75,24 @@ KX_DEV u32 kxp_seq_table(u32* tables, int t, u32 mode, const u8* p, u32 size, u3
     static const short OF_defaultNorm[29] = { 1,1,1,1,1,1,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, -1,-1,-1,-1,-1 };
     u32 const maxSym = (t == 0) ? 35 : (t == 1) ? 31 : 52;
     u32 const maxLog = (t == 0) ? 9 : (t == 1) ? 8 : 9;
-    u32* const tb = tables + kxd_seq_base(t);
-    short* const norm = (short*)(tables + 1280); u16* const symnext = (u16*)(tables + 1280 + 28);
+    u16* const tb = fl.tb + kxd_seq_base(t);
     u32 used = 0;
     if (mode == 0) {
         const short* dn = (t == 0) ? LL_defaultNorm : (t == 1) ? OF_defaultNorm : ML_defaultNorm;
         u32 const dmax = (t == 0) ? 35 : (t == 1) ? 28 : 52; u32 const dlog = (t == 1) ? 5 : 6;
-        for (u32 s = 0; s <= dmax; s++) norm[s] = dn[s];
-        kxp_build_dtable(tb, norm, dmax, dlog, symnext);
+        for (u32 s = 0; s <= dmax; s++) fl.norm[s] = dn[s];
+        kxp_build_dtable(tb, fl.norm, dmax, dlog, fl.symnext);
         kind[t] = 2; klog[t] = dlog;
     } else if (mode == 1) {
         if (size < 1 || p[0] > maxSym) return KXD_FAIL;
-        tb[0] = (u32)p[0] << 24;                             // nbBits 0, next state 0
+        tb[0] = (u16)(1u | ((u32)p[0] << 10));               // tableLog 0: nbBits 0, next state 0
         kind[t] = 1; klog[t] = 0;
         used = 1;
     } else if (mode == 2) {
         u32 maxSV = maxSym, tl = 0;
-        u32 const h = kfse_read_ncount(norm, &maxSV, &tl, p, size, maxLog);
+        u32 const h = kfse_read_ncount(fl.norm, &maxSV, &tl, p, size, maxLog);
         if (h == 0) { kind[t] = 0; return KXD_FAIL; }
-        kxp_build_dtable(tb, norm, maxSV, tl, symnext);
+        kxp_build_dtable(tb, fl.norm, maxSV, tl, fl.symnext);
         kind[t] = 2; klog[t] = tl;
         used = h;
     } else if (kind[t] == 0) return KXD_FAIL;            // repeat without a previous table
@@ -96,22 +100,102 @@ KX_DEV u32 kxp_seq_table(u32* tables, int t, u32 mode, const u8* p, u32 size, u3
     return used;
 }
 
+// ---- which frames share a wave ----------------------------------------------------------------------------------
+// The sixteen lanes of a wave run until the longest of their frames is done: with frames taken in batch order a wave's
+// longest frame has 1.7 times the average number of sequences (the bench corpus), and that factor is the kernel's
+// time.  Three small kernels order the lane slots by sequence count (a counting sort over count / 64, most first, so
+// the waves that start last are the short ones): count (a thread per entry reads the first compressed block's sequence
+// count), rank (bucket sizes to bucket starts), perm (an entry takes the next slot of its bucket; the order inside a
+// bucket is whatever the atomics give, which changes nothing but who shares a wave).
+#define KXP_SORT_BUCKETS 256
+struct KSeqSortArgs { const u8* src; const u64* in_off; const u32* in_len; u32 n_slices; u32* key; u32* hist; u32* perm; };
+
+// sequences of the entry's first compressed block; 0 when there is none or anything is irregular (the pre-decoder will see that itself)
+KX_DEV u32 kxp_first_nbseq(const u8* src, u32 srcSize)
+{
+    if (srcSize < 9 || kx_ld32(src) != 0xFD2FB528u) return 0;
+    u32 const fhd = src[4]; u32 const dictId = fhd & 3, single = (fhd >> 5) & 1, fcsId = fhd >> 6;
+    u32 const didSize = dictId == 3 ? 4 : dictId;
+    u32 const fcsSize = fcsId == 0 ? single : (fcsId == 1 ? 2 : fcsId == 2 ? 4 : 8);
+    u32 pos = 5 + (single ? 0u : 1u) + didSize + fcsSize;
+    for (int guard = 0; guard < 4; guard++) {                   // raw / RLE blocks in front of it: a few at most are followed
+        if (pos + 3 > srcSize) return 0;
+        u32 const bh = (u32)src[pos] | ((u32)src[pos + 1] << 8) | ((u32)src[pos + 2] << 16);
+        u32 const btype = (bh >> 1) & 3, bsize = bh >> 3;
+        pos += 3;
+        if (btype == 2) {
+            if (pos + bsize > srcSize || bsize < 5) return 0;
+            const u8* const bp = src + pos;
+            u32 const lh0 = bp[0]; u32 const ltype = lh0 & 3, sf = (lh0 >> 2) & 3; u32 lpos;
+            if (ltype < 2) {
+                u32 lhSize, regen;
+                if (sf == 0 || sf == 2) { lhSize = 1; regen = lh0 >> 3; }
+                else if (sf == 1) { lhSize = 2; regen = kx_ld16(bp) >> 4; }
+                else { lhSize = 3; regen = ((u32)bp[0] | ((u32)bp[1] << 8) | ((u32)bp[2] << 16)) >> 4; }
+                lpos = lhSize + (ltype == 0 ? regen : 1u);
+            } else {
+                u32 const w = kx_ld32(bp); u32 lhSize, comp;
+                if (sf < 2) { lhSize = 3; comp = (w >> 14) & 0x3FF; }
+                else if (sf == 2) { lhSize = 4; comp = w >> 18; }
+                else { lhSize = 5; comp = (w >> 22) + ((u32)bp[4] << 10); }
+                lpos = lhSize + comp;
+            }
+            if (lpos + 3 > bsize) return 0;
+            u32 const b0 = bp[lpos];
+            if (b0 < 128) return b0;
+            if (b0 < 255) return ((b0 - 128) << 8) + bp[lpos + 1];
+            return kx_ld16(bp + lpos + 1) + 0x7F00;
+        }
+        if (btype == 3 || (bh & 1)) return 0;
+        pos += btype == 0 ? bsize : 1u;
+    }
+    return 0;
+}
+
+KX_DEV void zstd_seq_count_body(const KSeqSortArgs& a)          // 256 threads per workgroup, a thread per entry
+{
+    u32 const f = kx_block() * 256u + (u32)kx_wave() * 64u + (u32)kx_lane();
+    if (f >= a.n_slices) return;
+    u32 k = kxp_first_nbseq(a.src + a.in_off[f], a.in_len[f]) >> 6;
+    if (k >= KXP_SORT_BUCKETS) k = KXP_SORT_BUCKETS - 1;
+    a.key[f] = k;
+    kx_atomic_add(a.hist + k, 1u);
+}
+
+KX_DEV void zstd_seq_rank_body(const KSeqSortArgs& a)           // one workgroup of 256 threads: thread k owns bucket k
+{
+    u32 const k = (u32)kx_wave() * 64u + (u32)kx_lane();
+    u32 before = 0;                                             // entries in the buckets that come first (the larger counts)
+    for (u32 i = k + 1; i < KXP_SORT_BUCKETS; i++) before += a.hist[i];
+    kx_block_sync();
+    a.hist[k] = before;
+}
+
+KX_DEV void zstd_seq_perm_body(const KSeqSortArgs& a)
+{
+    u32 const f = kx_block() * 256u + (u32)kx_wave() * 64u + (u32)kx_lane();
+    if (f >= a.n_slices) return;
+    a.perm[kx_atomic_add(a.hist + a.key[f], 1u)] = f;
+}
+
 KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
 {
-    KX_SHARED u32 llx[36]; KX_SHARED u32 mlx[53];          // per code: baseValue | extraBits << 24
+    KX_SHARED KPreLds lds;
     {
         int const lane = kx_lane();
-        if (lane < 36) llx[lane] = kx_ll_base((u32)lane) | (kxd_ll_bits((u32)lane) << 24);
-        if (lane < 53) mlx[lane] = kx_ml_base((u32)lane) | (kxd_ml_bits((u32)lane) << 24);
+        if (lane < 36) lds.llx[lane] = kx_ll_base((u32)lane) | (kxd_ll_bits((u32)lane) << 24);
+        if (lane < 53) lds.mlx[lane] = kx_ml_base((u32)lane) | (kxd_ml_bits((u32)lane) << 24);
     }
     kx_sync();
-    u32 const f = kx_block() * 64u + (u32)kx_lane();
-    if (f >= a.n_slices) return;
+    if (kx_lane() >= KXP_FRAMES) return;
+    u32 const slot = kx_block() * (u32)KXP_FRAMES + (u32)kx_lane();
+    if (slot >= a.n_slices) return;
+    u32 const f = a.perm ? a.perm[slot] : slot;
+    KPreFrameLds& fl = lds.f[kx_lane()];
     const u8* const src = a.src + a.in_off[f];
     u32 const srcSize = a.in_len[f];
-    u32* const stage = a.stage + (size_t)f * a.seq_cap * 3u;
+    u64* const stage = a.stage + (size_t)f * a.seq_cap;
     KPreBlk* const blk = a.blk + (size_t)f * a.blk_cap;
-    u32* const tables = a.tables + (size_t)f * KXP_TBL_WORDS;
     u32 nb = 0, nstaged = 0;              // compressed blocks seen / sequences staged so far
     u32 pos = 0;
     // ---- frame header (first frame of the entry only) ----
@@ -172,54 +256,116 @@ KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
         u32 tlLL = 0, tlOF = 0, tlML = 0; bool tok = true;
         for (int t = 0; t < 3 && tok; t++) {
             u32 const mode = (modes >> (6 - 2 * t)) & 3u;
-            u32 const r = kxp_seq_table(tables, t, mode, bp + p2, bend - p2, t == 0 ? &tlLL : t == 1 ? &tlOF : &tlML, kind, klog);
+            u32 const r = kxp_seq_table(fl, t, mode, bp + p2, bend - p2, t == 0 ? &tlLL : t == 1 ? &tlOF : &tlML, kind, klog);
             if (r == KXD_FAIL) tok = false; else p2 += r;
         }
         if (!tok || p2 >= bend) break;
         // ---- the bitstream, read backwards from its last set bit ----
+        // The reader has no state but `remaining`, the number of unread bits: every sequence builds a 64-bit container
+        // (hi : lo, top bit = next unread bit) from the three 32-bit words of the stream that hold it -- one address,
+        // three LDS reads, two funnel shifts -- takes the three extra-bits fields from hi, moves the container up by
+        // their total, and takes the three state fields.  (More than 32 bits of extra bits in one sequence -- offsets
+        // beyond 64 KiB with long lengths -- takes a second container.)
+        //
+        // No HBM access inside the loop waits for memory.  On gfx9 loads and stores share one counter, and a wait in a
+        // loop with conditional accesses is a wait for all of them: with the stream read straight from HBM and the
+        // sequence stored straight to it, every refill waited a full round trip (measured: 2 250 cycles a sequence).
+        // So the stream comes through a ring in LDS, filled sixteen words (64 bytes, aligned to the stream's 16-word
+        // grid) at a time, and sequences leave through a queue of eight: every eighth sequence the batch requested
+        // eight sequences earlier is written to the ring, the next one is requested, and the eight sequences go out as
+        // one 64-byte run.  The one wait there finds everything long done.  A stream that outruns the ring (more than
+        // 64 bits a sequence for a while) fills it on the spot.
         const u8* const sq = bp + p2; u32 const ssz = bend - p2;
         u32 const lastByte = sq[ssz - 1];
         if (lastByte == 0) break;
-        int bitPos = (int)(8 * (ssz - 1) + kx_hb32(lastByte));     // unread bits
+        int remaining = (int)(8 * (ssz - 1) + kx_hb32(lastByte));      // unread bits; the stream must end at exactly 0
+        int lowFetched;                                                 // words [lowFetched, top] of the stream are in the ring
+        int reqM = -1;                                                  // batch (16 words from word 16 reqM) on its way, -1: none
+        KxQuad b0, b1, b2, b3;
+        b0.x = b0.y = b0.z = b0.w = 0; b1 = b0; b2 = b0; b3 = b0;
+#define KXP_RING_PUT(m_, q0_, q1_, q2_, q3_) { u32* const r_ = fl.ring + ((16 * (m_)) & (KXP_RING - 1)); \
+            *(KxQuad*)r_ = q0_; *(KxQuad*)(r_ + 4) = q1_; *(KxQuad*)(r_ + 8) = q2_; *(KxQuad*)(r_ + 12) = q3_; \
+            if (r_ == fl.ring) { fl.ring[KXP_RING] = (q0_).x; fl.ring[KXP_RING + 1] = (q0_).y; } }
+        {
+            // the top batch holds the stream's last word (1 to 4 bytes of it exist): its words come in one by one (a
+            // 64-byte load could leave the entry); the batch below it, whole, with them; the one below that is requested
+            int const jt = (int)((ssz - 1) >> 2), mt = jt >> 4;
+            u32 wt = 0;
+            for (u32 k = 4u * (u32)jt; k < ssz; k++) wt |= (u32)sq[k] << (8u * (k - 4u * (u32)jt));
+            KxQuad t0, t1, t2, t3; u32* const t = &t0.x;
+            u32 tw[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) { int const wi = 16 * mt + k; tw[k] = wi < jt ? kx_ld32(sq + 4 * wi) : (wi == jt ? wt : 0u); }
+            (void)t;
+            t0.x = tw[0]; t0.y = tw[1]; t0.z = tw[2]; t0.w = tw[3]; t1.x = tw[4]; t1.y = tw[5]; t1.z = tw[6]; t1.w = tw[7];
+            t2.x = tw[8]; t2.y = tw[9]; t2.z = tw[10]; t2.w = tw[11]; t3.x = tw[12]; t3.y = tw[13]; t3.z = tw[14]; t3.w = tw[15];
+            if (mt >= 1) { const u8* const q = sq + 64 * (mt - 1); b0 = kx_ld128u(q); b1 = kx_ld128u(q + 16); b2 = kx_ld128u(q + 32); b3 = kx_ld128u(q + 48); }
+            KXP_RING_PUT(mt, t0, t1, t2, t3)
+            lowFetched = 16 * mt;
+            if (mt >= 1) { KXP_RING_PUT(mt - 1, b0, b1, b2, b3) lowFetched = 16 * (mt - 1); }
+            if (mt >= 2) { const u8* const q = sq + 64 * (mt - 2); b0 = kx_ld128u(q); b1 = kx_ld128u(q + 16); b2 = kx_ld128u(q + 32); b3 = kx_ld128u(q + 48); reqM = mt - 2; }
+        }
         bool bad = false;
-        // The reader keeps 128 bits of the stream in registers: lo = word k (bits [64 k, 64 k + 64)), hi = word k + 1, and the
-        // two words below them already requested (q0, q1), so a field never waits for the stream.  Fields come in two
-        // groups per sequence, each at most 64 bits: ENSURE moves the window down until the group lies inside it.
-        int k = ((bitPos - 1) >> 6) - 1;
-        u64 hi = kxp_word(sq, ssz, k + 1), lo = kxp_word(sq, ssz, k), q0 = kxp_word(sq, ssz, k - 1), q1 = kxp_word(sq, ssz, k - 2);
-#define KXP_DOWN() { hi = lo; lo = q0; q0 = q1; k--; q1 = kxp_word(sq, ssz, k - 2); }
-#define KXP_ENSURE(m_) { if (bitPos - (int)(m_) < 64 * k) KXP_DOWN() if (bitPos - (int)(m_) < 64 * k) KXP_DOWN() }
-// the n (<= 32) bits below bit position P_ (P_ - n >= 64 k, P_ <= 64 k + 128); n = 0 gives 0
-#define KXP_BITS(P_, n_) kxp_bits(hi, lo, (int)(P_) - (int)(n_) - 64 * k, (n_))
+// the 64 bits below the read position; words below the stream's first read as zero (only its last sequences get there)
+#define KXP_CONTAINER(hi_, lo_) u32 hi_, lo_; { \
+            int const w_ = remaining >> 5; u32 const s_ = (u32)remaining & 31u; \
+            if (w_ - 2 < lowFetched && lowFetched > 0) { \
+                /* the ring ran dry: the batch on its way is taken now, further ones are loaded on the spot -- the only waits for HBM the loop has */ \
+                if (reqM >= 0) { KXP_RING_PUT(reqM, b0, b1, b2, b3) lowFetched = 16 * reqM; reqM = -1; } \
+                while (w_ - 2 < lowFetched && lowFetched > 0) { int const m_ = (lowFetched >> 4) - 1; const u8* const q_ = sq + 64 * m_; \
+                    KxQuad const c0_ = kx_ld128u(q_), c1_ = kx_ld128u(q_ + 16), c2_ = kx_ld128u(q_ + 32), c3_ = kx_ld128u(q_ + 48); \
+                    KXP_RING_PUT(m_, c0_, c1_, c2_, c3_) lowFetched = 16 * m_; } } \
+            u32 x2_, x1_, x0_; \
+            if (w_ >= 2) { const u32* const r_ = fl.ring + ((w_ - 2) & (KXP_RING - 1)); x0_ = r_[0]; x1_ = r_[1]; x2_ = r_[2]; } \
+            else { x2_ = fl.ring[w_ & (KXP_RING - 1)]; x1_ = w_ >= 1 ? fl.ring[(w_ - 1) & (KXP_RING - 1)] : 0u; x0_ = 0u; } \
+            hi_ = kx_alignbit(x2_, x1_, s_); lo_ = kx_alignbit(x1_, x0_, s_); }
+// the top n (<= 31) bits of t_, which then moves up by n
+#define KXP_TAKE(dst_, t_, n_) { u32 const n__ = (n_); dst_ = ((t_) >> 1) >> (31u - n__); (t_) <<= n__; }
         u32 sLL, sOF, sML;
         {
-            u32 const need0 = tlLL + tlOF + tlML;                  // initial states, stream order LL, OF, ML
-            if (bitPos < (int)need0) break;
-            KXP_ENSURE(need0)
-            sLL = KXP_BITS(bitPos, tlLL); sOF = KXP_BITS(bitPos - (int)tlLL, tlOF); sML = KXP_BITS(bitPos - (int)(tlLL + tlOF), tlML);
-            bitPos -= (int)need0;
+            KXP_CONTAINER(hi, lo)
+            (void)lo;
+            u32 t = hi;                                             // initial states, stream order LL, OF, ML
+            KXP_TAKE(sLL, t, tlLL) KXP_TAKE(sOF, t, tlOF) KXP_TAKE(sML, t, tlML)
+            remaining -= (int)(tlLL + tlOF + tlML);
         }
-        u32* const out = stage + (size_t)nstaged * 3u;
-        u32 eL = tables[KXD_LL0 + sLL], eO = tables[KXD_OF0 + sOF], eM = tables[KXD_ML0 + sML];
+        if (remaining < 0) break;
+        u64* const out = stage + nstaged;
+        u32 const szLL = 1u << tlLL, szOF = 1u << tlOF, szML = 1u << tlML;
+        u32 eL = fl.tb[KXD_LL0 + sLL], eO = fl.tb[KXD_OF0 + sOF], eM = fl.tb[KXD_ML0 + sML];
         for (u32 i = 0; i < nbSeq; i++) {
-            u32 const cL = eL >> 24, cO = eO >> 24, cM = eM >> 24;
-            if (cL > 35 || cM > 52 || cO > 31) { bad = true; break; }
-            u32 const xL = llx[cL], xM = mlx[cM];
+            u32 const cL = eL >> 10, cO = eO >> 10, cM = eM >> 10;
+            if (cL > 35 || cM > 52 || cO > 31 || remaining < 0) { bad = true; break; }
+            u32 const xL = lds.llx[cL], xM = lds.mlx[cM];
             u32 const aL = xL >> 24, aM = xM >> 24, aO = cO;
             bool const upd = i + 1 < nbSeq;                        // the block's final sequence updates no state
-            u32 const nL = upd ? (eL >> 16) & 0xFFu : 0u, nM = upd ? (eM >> 16) & 0xFFu : 0u, nO = upd ? (eO >> 16) & 0xFFu : 0u;
-            u32 const needA = aO + aM + aL, needB = nL + nM + nO;
-            if (bitPos < (int)(needA + needB)) { bad = true; break; }
+            u32 const kL = eL & 1023u, kM = eM & 1023u, kO = eO & 1023u;
+            u32 const nL = upd ? tlLL - kx_hb32(kL) : 0u, nM = upd ? tlML - kx_hb32(kM) : 0u, nO = upd ? tlOF - kx_hb32(kO) : 0u;
             // bit order inside a sequence: OF extra, ML extra, LL extra, then LL state, ML state, OF state
-            KXP_ENSURE(needA)
-            u32 const xo = KXP_BITS(bitPos, aO), xm = KXP_BITS(bitPos - (int)aO, aM), xl = KXP_BITS(bitPos - (int)(aO + aM), aL);
-            bitPos -= (int)needA;
-            KXP_ENSURE(needB)
-            u32 const yL = KXP_BITS(bitPos, nL), yM = KXP_BITS(bitPos - (int)nL, nM), yO = KXP_BITS(bitPos - (int)(nL + nM), nO);
-            bitPos -= (int)needB;
+            u32 xo, xm, xl, yL, yM, yO;
+            u32 const needA = aO + aM + aL;
+            KXP_CONTAINER(hi, lo)
+            if (needA <= 32u) {
+                u32 t = hi;
+                KXP_TAKE(xo, t, aO) KXP_TAKE(xm, t, aM) KXP_TAKE(xl, t, aL)
+                t = (u32)(((((u64)hi << 32) | lo) << needA) >> 32);
+                KXP_TAKE(yL, t, nL) KXP_TAKE(yM, t, nM) KXP_TAKE(yO, t, nO)
+                remaining -= (int)(needA + nL + nM + nO);
+            } else {
+                u32 t = hi;
+                KXP_TAKE(xo, t, aO)
+                remaining -= (int)aO;
+                if (remaining < 0) { bad = true; break; }
+                KXP_CONTAINER(hi2, lo2)
+                t = hi2;
+                KXP_TAKE(xm, t, aM) KXP_TAKE(xl, t, aL)
+                t = (u32)(((((u64)hi2 << 32) | lo2) << (aM + aL)) >> 32);
+                KXP_TAKE(yL, t, nL) KXP_TAKE(yM, t, nM) KXP_TAKE(yO, t, nO)
+                remaining -= (int)(aM + aL + nL + nM + nO);
+            }
             // the next states' table words are requested before this sequence is finished
-            sLL = ((eL & 0xFFFFu) + yL) & 511u; sML = ((eM & 0xFFFFu) + yM) & 511u; sOF = ((eO & 0xFFFFu) + yO) & 255u;
-            u32 const nLe = tables[KXD_LL0 + sLL], nOe = tables[KXD_OF0 + sOF], nMe = tables[KXD_ML0 + sML];
+            sLL = (((kL << nL) - szLL) + yL) & 511u; sML = (((kM << nM) - szML) + yM) & 511u; sOF = (((kO << nO) - szOF) + yO) & 255u;
+            u32 const nLe = fl.tb[KXD_LL0 + sLL], nOe = fl.tb[KXD_OF0 + sOF], nMe = fl.tb[KXD_ML0 + sML];
             u32 const ofv = (1u << cO) + xo, ml = (xM & 0xFFFFFFu) + xm, ll = (xL & 0xFFFFFFu) + xl;
             // repeat-offset rules
             bool const isRep = ofv <= 3;
@@ -229,13 +375,29 @@ KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
             u32 const off = isRep ? roff : ofv - 3;
             bool const sh2 = !isRep || idx >= 2, sh1 = !isRep || idx >= 1;
             rep3 = sh2 ? rep2 : rep3; rep2 = sh1 ? rep1 : rep2; rep1 = off;
-            out[3 * i] = ll; out[3 * i + 1] = ml; out[3 * i + 2] = off;
+            if (ll > 0xFFFFu || ml - 3u > 0xFFFFu) { bad = true; break; }       // does not fit the staging word: left to k_zstd_decode
+            fl.outq[i & 7u] = (u64)(ll | ((ml - 3u) << 16)) | ((u64)off << 32);
             eL = nLe; eO = nOe; eM = nMe;
+            if ((i & 7u) == 7u) {
+                // the batch requested eight sequences ago goes into the ring (its slots held words long taken)
+                if (reqM >= 0) { KXP_RING_PUT(reqM, b0, b1, b2, b3) lowFetched = 16 * reqM; reqM = -1; }
+                // the next one, if its slots are free: the ring holds words [lowFetched, lowFetched + 64), the batch takes the
+                // slots of the top sixteen
+                if (lowFetched >= 16 && (remaining >> 5) < lowFetched + (KXP_RING - 16)) {
+                    reqM = (lowFetched >> 4) - 1;
+                    const u8* const q = sq + 64 * reqM; b0 = kx_ld128u(q); b1 = kx_ld128u(q + 16); b2 = kx_ld128u(q + 32); b3 = kx_ld128u(q + 48);
+                }
+                // eight sequences leave
+                u8* const o = (u8*)(out + (i - 7u)); const KxQuad* const oq = (const KxQuad*)fl.outq;
+                KxQuad const q0 = oq[0], q1 = oq[1], q2 = oq[2], q3 = oq[3];
+                kx_st128u(o, q0); kx_st128u(o + 16, q1); kx_st128u(o + 32, q2); kx_st128u(o + 48, q3);
+            }
         }
-#undef KXP_BITS
-#undef KXP_ENSURE
-#undef KXP_DOWN
-        if (bad || bitPos != 0) break;          // irregular: this block and the rest are left to k_zstd_decode
+#undef KXP_TAKE
+#undef KXP_CONTAINER
+#undef KXP_RING_PUT
+        if (!bad) for (u32 k = nbSeq & ~7u; k < nbSeq; k++) out[k] = fl.outq[k & 7u];
+        if (bad || remaining != 0) break;          // irregular: this block and the rest are left to k_zstd_decode
         rec.ok = 1; rec.rep[0] = rep1; rec.rep[1] = rep2; rec.rep[2] = rep3;
         blk[nb++] = rec;
         nstaged += nbSeq;

@@ -273,16 +273,15 @@ int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len
     d.lits = lits.data(); d.lit_cap = lit_cap; d.flags = 0; d.dict = dict; d.dict_size = dict ? dict_size : 0;
     // sequences decoded ahead, one lane per frame (what the product does); KXEMU_NO_PRE=1: everything in the decode body
     u32 const seq_cap = lit_cap / 3u + 64u, blk_cap = lit_cap / 8192u + 16u;
-    std::vector<u32> stage; std::vector<KPreBlk> pblk; std::vector<u32> nblk;
+    std::vector<u64> stage; std::vector<KPreBlk> pblk; std::vector<u32> nblk;
     d.pre_stage = nullptr; d.pre_seq_cap = 0; d.pre_blk = nullptr; d.pre_blk_cap = 0; d.pre_nblk = nullptr;
     kxemu::failed = 0;
     if (!getenv("KXEMU_NO_PRE")) {
-        stage.assign((size_t)n * seq_cap * 3u, 0xCDCDCDCDu); pblk.resize((size_t)n * blk_cap); nblk.assign(n, 0u);
+        stage.assign((size_t)n * seq_cap, 0xCDCDCDCDCDCDCDCDull); pblk.resize((size_t)n * blk_cap); nblk.assign(n, 0u);
         KPreArgs p;
         p.src = src; p.in_off = in_off; p.in_len = in_len; p.n_slices = n;
-        std::vector<u32> ptables((size_t)n * KXP_TBL_WORDS, 0xEFEFEFEFu);
-        p.stage = stage.data(); p.seq_cap = seq_cap; p.blk = pblk.data(); p.blk_cap = blk_cap; p.nblk = nblk.data(); p.tables = ptables.data();
-        kxemu::launch((n + 63) / 64, [&]() { zstd_seq_predecode_body(p); });
+        p.stage = stage.data(); p.seq_cap = seq_cap; p.blk = pblk.data(); p.blk_cap = blk_cap; p.nblk = nblk.data(); p.perm = nullptr;
+        kxemu::launch((n + KXP_FRAMES - 1) / KXP_FRAMES, [&]() { zstd_seq_predecode_body(p); });
         if (kxemu::failed) return -2;
         d.pre_stage = stage.data(); d.pre_seq_cap = seq_cap; d.pre_blk = pblk.data(); d.pre_blk_cap = blk_cap; d.pre_nblk = nblk.data();
     }

@@ -45,6 +45,10 @@ KX_DEV void kx_st32(u8* p, u32 v) { memcpy(p, &v, 4); }
 KX_DEV void kx_st16(u8* p, u32 v) { u16 x = (u16)v; memcpy(p, &x, 2); }
 KX_DEV void kx_st128(void* p, u64 a, u64 b) { memcpy(p, &a, 8); memcpy((u8*)p + 8, &b, 8); }
 
+struct alignas(16) KxQuad { u32 x, y, z, w; };
+KX_DEV KxQuad kx_ld128u(const u8* p) { KxQuad q; memcpy(&q, p, 16); return q; }
+KX_DEV void kx_st128u(u8* p, const KxQuad& q) { memcpy(p, &q, 16); }
+
 KX_DEV u32 kx_ld_nt(const u32* p) { return *p; }
 KX_DEV void kx_st_nt(u32* p, u32 v) { *p = v; }
 KX_DEV u32 kx_atomic_add(u32* p, u32 v) { u32 o = *p; *p = o + v; return o; }
