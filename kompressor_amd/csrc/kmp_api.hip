@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64, 5) void k_zstd_decode(KDecodeArgs a) { zstd_dec
 // the sequence bitstreams decoded ahead of it, one lane per frame (FSE tables in HBM)
 __global__ __launch_bounds__(64) void k_zstd_seq_predecode(KPreArgs a) { zstd_seq_predecode_body(a); }
 // ... and the Huffman-coded literals, one lane per stream (32 frames per workgroup of 128 threads)
-__global__ __launch_bounds__(128) void k_zstd_lit_predecode(KLitArgs a) { zstd_lit_predecode_body(a); }
+__global__ __launch_bounds__(64) void k_zstd_lit_predecode(KLitArgs a) { zstd_lit_predecode_body(a); }
 __global__ __launch_bounds__(256) void k_zstd_seq_count(KSeqSortArgs a) { zstd_seq_count_body(a); }
 __global__ __launch_bounds__(256) void k_zstd_seq_rank(KSeqSortArgs a) { zstd_seq_rank_body(a); }
 __global__ __launch_bounds__(256) void k_zstd_seq_perm(KSeqSortArgs a) { zstd_seq_perm_body(a); }
@@ -250,7 +250,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     c->knob.dfl_serial = env_u32("KMP_DEFLATE_SERIAL", 0); c->knob.dfl_flags = env_u32("KMP_DEFLATE_FLAGS", 0);
     // experiment, off by default (measured slower): bit 0 = sequences decoded ahead of k_zstd_decode
     // (k_zstd_seq_predecode, one lane per frame), bit 1 = literals (k_zstd_lit_predecode, one lane per stream)
-    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 1); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1);
+    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1);
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return KMP_OK;
@@ -685,11 +685,12 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
     d.pre_stage = nullptr; d.pre_seq_cap = 0; d.pre_blk = nullptr; d.pre_blk_cap = c->pre_blk_cap; d.pre_nblk = nullptr;
     d.pre_lits = nullptr; d.pre_lit_cap = 0; d.pre_lit = nullptr; d.pre_nlit = nullptr;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[4], st));
+    if (c->pre_stage) { HIP_TRY(hipEventRecord(c->ev_pre[0], st)); HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_pre[0], 0)); }     // st2 starts where st stands: the two pre-decoders run side by side
     if (c->pre_lits) {
         KLitArgs p;
         p.src = d.src; p.in_off = d_in_off; p.in_len = d_in_len; p.n_slices = n;
         p.lits = c->pre_lits; p.lit_cap = c->pre_lit_cap; p.rec = c->pre_lit; p.blk_cap = c->pre_blk_cap; p.nrec = c->pre_nlit;
-        hipLaunchKernelGGL(k_zstd_lit_predecode, dim3((n + KXL_FRAMES - 1) / KXL_FRAMES), dim3(128), 0, st, p);
+        hipLaunchKernelGGL(k_zstd_lit_predecode, dim3((n + KXL_FRAMES - 1) / KXL_FRAMES), dim3(64), 0, st, p);
         HIP_TRY(hipGetLastError());
         d.pre_lits = c->pre_lits; d.pre_lit_cap = c->pre_lit_cap; d.pre_lit = c->pre_lit; d.pre_nlit = c->pre_nlit;
     }
@@ -699,7 +700,6 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
         u32 pieces = (n >= 8192u) ? c->knob.decode_pieces : 1u;
         if (pieces < 1u || pieces > (u32)KMP_MAX_CHUNKS) pieces = (u32)KMP_MAX_CHUNKS;
         u32 const per = ((n + pieces - 1) / pieces + 63u) & ~63u;
-        HIP_TRY(hipEventRecord(c->ev_pre[0], st)); HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_pre[0], 0));     // st2 starts where st stands
         u32* const sort_key = c->pre_sort; u32* const sort_perm = c->pre_sort + c->max_slices; u32* const sort_hist = c->pre_sort + 2u * (size_t)c->max_slices;
         bool const sorted = c->knob.decode_sort != 0 && n >= 1024u;
         if (sorted) HIP_TRY(hipMemsetAsync(sort_hist, 0, (size_t)KMP_MAX_CHUNKS * KXP_SORT_BUCKETS * 4u, c->st2));

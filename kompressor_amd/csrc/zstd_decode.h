@@ -190,7 +190,8 @@ KX_DEV bool khuf_fill_dtable(LDS& lds, u32 nw, u32 tableLog)
     return true;
 }
 
-template <class LDS>
+// (FILL = false: the weights and the table log only; the caller has its own table layout)
+template <class LDS, bool FILL = true>
 KX_DEV u32 khuf_read_dtable(LDS& lds, const u8* p, u32 size, u32* tableLogOut, u32* nwOut)
 {
     if (size < 1) return 0;
@@ -235,28 +236,9 @@ KX_DEV u32 khuf_read_dtable(LDS& lds, const u8* p, u32 size, u32* tableLogOut, u
     u32 const rest = (1u << tableLog) - total;
     if (rest & (rest - 1)) return 0;              // must be a power of two
     lds.weights[nw] = (u8)(kx_hb32(rest) + 1); nw++;
-    if (!khuf_fill_dtable(lds, nw, tableLog)) return 0;
+    if constexpr (FILL) { if (!khuf_fill_dtable(lds, nw, tableLog)) return 0; }
     *tableLogOut = tableLog; *nwOut = nw;
     return used;
-}
-
-// n (<= 32) bits of the 128-bit window (hi : lo) starting t bits above lo's bit 0 (0 <= t, t + n <= 128); n = 0 gives 0
-KX_DEV u32 kxp_bits(u64 hi, u64 lo, int t, u32 n)
-{
-    u64 const x = (t >= 64) ? (hi >> (t - 64)) : ((lo >> t) | ((hi << 1) << (63 - t)));
-    return (u32)x & (u32)((1ull << n) - 1ull);
-}
-
-// 64 bits of a backward bitstream at word index j (bytes [8 j, 8 j + 8)); words below the stream read as zero, the
-// last one may be short
-KX_DEV u64 kxp_word(const u8* sq, u32 ssz, int j)
-{
-    if (j < 0) return 0;
-    u32 const o = 8u * (u32)j;
-    if (o + 8u <= ssz) return kx_ld64(sq + o);
-    u64 v = 0;
-    for (u32 k = 0; o + k < ssz; k++) v |= (u64)sq[o + k] << (8 * k);
-    return v;
 }
 
 // One lane decodes one Huffman stream of `count` symbols; returns false on corruption.
@@ -648,8 +630,12 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
     u32 op = 0;                       // bytes produced
     u32 nframes = 0;
     u32 cblk = 0;                     // compressed blocks of the entry's first frame so far (index into the pre-decoded records)
-    u32 const npre = a.pre_nblk ? a.pre_nblk[f] : 0u;
-    u32 const nlitpre = a.pre_nlit ? a.pre_nlit[f] : 0u;
+    // what the pre-decode kernels left for the entry's first frame: records, and (top bit) whether they cover the frame to
+    // its last block.  Then nothing a later block could need from an earlier one (a tree-less block's table, a "repeat"
+    // mode's counts) has to be kept up here, and the descriptions of pre-decoded blocks are not even read.
+    u32 const npreW = a.pre_nblk ? a.pre_nblk[f] : 0u, nlitW = a.pre_nlit ? a.pre_nlit[f] : 0u;
+    u32 const npre = npreW & 0x7FFFFFFFu, nlitpre = nlitW & 0x7FFFFFFFu;
+    bool const seqAll = (npreW >> 31) != 0, litAll = (nlitW >> 31) != 0;
     for (;;) {
     // ---- frame header (every lane computes the same thing) ---------------
     u32 hasContent = 0, checksum = 0; u64 contentSize = 0; u64 windowSize = 0;
@@ -760,6 +746,13 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
         } else {
             if (lpos + comp > bend || comp == 0) { err = KZE_CORRUPT; break; }
             u32 hused = 0;
+            // the block's literals may lie decoded in HBM already (k_zstd_lit_predecode)
+            bool preLit = false;
+            if (ord < nlitpre) {
+                KPreLit const pl = a.pre_lit[(size_t)f * a.pre_blk_cap + ord];
+                if (pl.ok && pl.regen == regen) { litPtr = a.pre_lits + (size_t)f * a.pre_lit_cap + pl.off; preLit = true; }
+            }
+            if (preLit && litAll) { /* neither the tree nor the streams are looked at */ } else
             if (ltype == 2) {
                 u32 r = 0;
                 if (lane == 0) { u32 tl = 0, nw = 0; r = khuf_read_dtable(lds, bp + lpos, comp, &tl, &nw); lds.bc[0] = r; lds.bc[1] = tl; lds.bc[2] = nw; }
@@ -775,13 +768,8 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             }
             const u8* const sp = bp + lpos + hused; u32 const ssize = comp - hused;
             bool ok = true;
-            // the block's literals may lie decoded in HBM already (k_zstd_lit_predecode); the table above is still kept up
-            // for a later tree-less block that this kernel has to decode itself
-            bool preLit = false;
-            if (ord < nlitpre) {
-                KPreLit const pl = a.pre_lit[(size_t)f * a.pre_blk_cap + ord];
-                if (pl.ok && pl.regen == regen) { litPtr = a.pre_lits + (size_t)f * a.pre_lit_cap + pl.off; preLit = true; }
-            }
+            // (literals decoded ahead in a frame not covered to its end: the table above is still kept up for a later
+            // tree-less block that this kernel has to decode itself)
             if (preLit) { /* nothing to decode */ } else
             if (nstreams == 1) {
                 if (lane == 0 && !(a.flags & 1u)) ok = khuf_decode_stream(lds, hufLog, sp, ssize, lits, regen);
@@ -804,32 +792,30 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             kx_sync();
         }
         kx_sync();
-        // sequences header, then the three tables (lane 0)
-        if (lane == 0) {
-            u32 e = 0, nbSeq = 0, p2 = lpos, modes = 0;
-            if (p2 >= bend) e = KZE_CORRUPT;
+        // sequences header (every lane computes the same thing), then the three tables (lane 0)
+        u32 nbSeq = 0, spos = lpos, modes = 0;
+        {
+            u32 e = 0;
+            if (spos >= bend) e = KZE_CORRUPT;
             if (!e) {
-                u32 const b0 = bp[p2++];
+                u32 const b0 = bp[spos++];
                 if (b0 < 128) nbSeq = b0;
-                else if (b0 < 255) { if (p2 >= bend) e = KZE_CORRUPT; else nbSeq = ((b0 - 128) << 8) + bp[p2++]; }
-                else { if (p2 + 2 > bend) e = KZE_CORRUPT; else { nbSeq = kx_ld16(bp + p2) + 0x7F00; p2 += 2; } }
+                else if (b0 < 255) { if (spos >= bend) e = KZE_CORRUPT; else nbSeq = ((b0 - 128) << 8) + bp[spos++]; }
+                else { if (spos + 2 > bend) e = KZE_CORRUPT; else { nbSeq = kx_ld16(bp + spos) + 0x7F00; spos += 2; } }
             }
             if (!e && nbSeq) {
-                if (p2 >= bend) e = KZE_CORRUPT;
-                else { modes = bp[p2++]; if (modes & 3) e = KZE_CORRUPT; }
+                if (spos >= bend) e = KZE_CORRUPT;
+                else { modes = bp[spos++]; if (modes & 3) e = KZE_CORRUPT; }
             }
-            lds.bc[0] = e; lds.bc[1] = nbSeq; lds.bc[2] = p2; lds.bc[3] = modes;
+            if (e) { err = e; break; }
         }
-        kx_sync();
-        if (lds.bc[0]) { err = lds.bc[0]; break; }
-        u32 const nbSeq = lds.bc[1]; u32 spos = lds.bc[2]; u32 const modes = lds.bc[3];
         // this block's sequences may lie decoded in HBM already (k_zstd_seq_predecode)
         const u64* preSeq = nullptr; u32 preRep1 = 0, preRep2 = 0, preRep3 = 0;
         if (ord < npre) {
             KPreBlk const pb = a.pre_blk[(size_t)f * a.pre_blk_cap + ord];
             if (pb.ok && pb.nbSeq == nbSeq && nbSeq) { preSeq = a.pre_stage + ((size_t)f * a.pre_seq_cap + pb.seq_off); preRep1 = pb.rep[0]; preRep2 = pb.rep[1]; preRep3 = pb.rep[2]; }
         }
-        if (nbSeq) {
+        if (nbSeq && !(preSeq && seqAll)) {
             for (int t = 0; t < 3 && !err; t++) {
                 u32 const mode = (modes >> (6 - 2 * t)) & 3u;
                 if (lane == 0) {

@@ -211,14 +211,15 @@ KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
     u32 rep1 = 1, rep2 = 4, rep3 = 8;
     u32 kind[3] = { 0, 0, 0 }, klog[3] = { 0, 0, 0 };
     bool last = false;
+    u32 covered = 0;                      // set when the frame's last block has been taken: every compressed block has a record
     while (ok && !last && nb < a.blk_cap) {
         if (pos + 3 > srcSize) break;
         u32 const bh = (u32)src[pos] | ((u32)src[pos + 1] << 8) | ((u32)src[pos + 2] << 16);
         last = bh & 1; u32 const btype = (bh >> 1) & 3; u32 const bsize = bh >> 3;
         pos += 3;
         if (btype == 3) break;
-        if (btype == 0) { if (pos + bsize > srcSize) break; pos += bsize; continue; }
-        if (btype == 1) { if (pos + 1 > srcSize) break; pos += 1; continue; }
+        if (btype == 0) { if (pos + bsize > srcSize) break; pos += bsize; if (last) covered = 0x80000000u; continue; }
+        if (btype == 1) { if (pos + 1 > srcSize) break; pos += 1; if (last) covered = 0x80000000u; continue; }
         if (pos + bsize > srcSize || bsize > 128u * 1024u || bsize < 2) break;
         const u8* const bp = src + pos; u32 const bend = bsize;
         // literals section: only its size matters here
@@ -248,7 +249,7 @@ KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
             else { if (p2 + 2 > bend) break; nbSeq = kx_ld16(bp + p2) + 0x7F00; p2 += 2; }
         }
         KPreBlk rec; rec.seq_off = nstaged; rec.nbSeq = nbSeq; rec.ok = 0; rec.rep[0] = rep1; rec.rep[1] = rep2; rec.rep[2] = rep3; rec.pad[0] = 0; rec.pad[1] = 0;
-        if (nbSeq == 0) { rec.ok = 1; blk[nb++] = rec; pos += bsize; continue; }
+        if (nbSeq == 0) { rec.ok = 1; blk[nb++] = rec; pos += bsize; if (last) covered = 0x80000000u; continue; }
         if (p2 >= bend) break;
         u32 const modes = bp[p2++];
         if (modes & 3) break;
@@ -402,20 +403,32 @@ KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
         blk[nb++] = rec;
         nstaged += nbSeq;
         pos += bsize;
+        if (last) covered = 0x80000000u;
     }
-    a.nblk[f] = nb;
+    a.nblk[f] = nb | covered;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_zstd_lit_predecode -- the Huffman-coded literals of a batch of frames, one LANE per stream.
 //
-// In k_zstd_decode four lanes of a wave walk the four Huffman streams of a block while sixty sit idle.  Here a
-// workgroup takes 32 frames: in phase A thread j parses frame j up to its next Huffman-coded literals section and
-// builds that block's decoding table in the frame's slice of the LDS; after a workgroup barrier, in phase B thread
-// 4 j + s decodes stream s of frame j into the entry's literal staging area in HBM; another barrier, and phase A moves on
-// to the frame's next block.  k_zstd_decode then reads the literals instead of decoding them.  Like the sequence
-// pre-decoder above this is an accelerator: a block is recorded only if its streams decoded to the last bit; anything
-// irregular ends the frame's pre-decoding and k_zstd_decode handles (and reports) the rest as before.
+// In k_zstd_decode four lanes of a wave walk the four Huffman streams of a block while sixty sit idle.  Here a wave
+// takes 16 frames, a round per block: lanes 0..15 parse their frame up to its next Huffman-coded literals section;
+// four lanes per frame bring the tree description into LDS; lanes 0..15 turn it into the frame's decoding table; then
+// lane 4 j + s decodes stream s of frame j into the entry's literal staging area in HBM, and lanes 0..15 record the
+// block.  k_zstd_decode then reads the literals instead of decoding them.
+//
+// The table is two-level so that sixteen of them and the stream rings fit three times into a CU's LDS: codes of up to
+// 9 bits (all of them when the table log is 9 or less) are looked up by the top 9 bits of the window; the longer codes
+// are the symbols of the one or two smallest weights, and zstd's table puts those first: a window below T (where the
+// 9-bit codes start) indexes that prefix of the full table directly, at most 256 symbols x 2 entries.  Exact for every
+// valid tree.
+//
+// As in the sequence pre-decoder no HBM access inside the symbol loop waits for memory: a lane's stream comes through
+// a ring of 32 words in LDS, sixteen words per batch, requested 32 symbols before they are written to the ring; the
+// 32 symbols leave as two 16-byte stores at the same point.
+//
+// Like the sequence pre-decoder this is an accelerator: a block is recorded only if its streams decoded to the last
+// bit; anything irregular ends the frame's pre-decoding and k_zstd_decode handles (and reports) the rest as before.
 struct KLitArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
     u8* lits; u32 lit_cap;              // per entry: lit_cap bytes of literal staging (the literals of all blocks, back to back)
@@ -423,25 +436,123 @@ struct KLitArgs {
     u32* nrec;                          // per entry: records written
 };
 
-#define KXL_FRAMES 32
+#define KXL_FRAMES 16
+#define KXL_RING 32
+#define KXL_TREE 144                    // a tree description is at most 1 + 127 bytes; eight bytes in front for the reader's 8-byte loads
 struct KLitFrameLds {
-    union { u16 huf[2048]; struct { u16 wb[64]; u8 wc[64]; u8 tsym[64]; } b; } u;     // as KDecodeLds: the weights' FSE table lives where the decoding table goes
+    union { struct { u16 l1[512]; u16 lg[512]; } t; struct { u16 wb[64]; u8 wc[64]; u8 tsym[64]; } b; } u;     // the weights' FSE table lives where the decoding table goes
+    union { alignas(16) u32 ring[4][KXL_RING]; u8 tree[8 + KXL_TREE]; } r;
     u8 weights[256]; short norm[64]; u16 symnext[64]; u32 rank[16];
     // this round's job for the four stream lanes
-    u32 valid, tableLog, soff[4], ssz[4], cnt[4], dst, bad;
+    u32 valid, tableLog, T, soff[4], ssz[4], cnt[4], dst, bad, treeOff, treeLen;
 };
 struct KLitLds { KLitFrameLds f[KXL_FRAMES]; u32 more; };
+
+// weights[0..nw) -> the two-level table; false on an invalid weight set
+KX_DEV bool khuf_fill_compact(KLitFrameLds& L, u32 nw, u32 tableLog)
+{
+    for (u32 i = 0; i < 16; i++) L.rank[i] = 0;
+    for (u32 i = 0; i < nw; i++) L.rank[L.weights[i]]++;
+    if (L.rank[1] < 2 || (L.rank[1] & 1)) return false;
+    u32 const sh = tableLog > 9 ? tableLog - 9 : 0u;
+    u32 next = 0, T = 0;
+    for (u32 w = 1; w <= tableLog; w++) { u32 const cur = next; next += L.rank[w] << (w - 1); L.rank[w] = cur; if (w == sh) T = next; }
+    for (u32 s = 0; s < nw; s++) {
+        u32 const w = L.weights[s];
+        if (!w) continue;
+        u32 const len = 1u << (w - 1); u32 const start = L.rank[w]; u32 const e = s | ((tableLog + 1 - w) << 8);
+        if (w <= sh) { for (u32 i = 0; i < len; i++) L.u.t.lg[start + i] = (u16)e; }
+        else { u32 const n = len >> sh, o = start >> sh; for (u32 i = 0; i < n; i++) L.u.t.l1[o + i] = (u16)e; }
+        L.rank[w] += len;
+    }
+    L.T = T;
+    return true;
+}
+
+// one lane, one stream, through the lane's ring (see the kernel's header); returns false on corruption
+KX_DEV bool khuf_decode_stream_ring(const KLitFrameLds& L, u32* ring, const u8* p, u32 size, u8* out, u32 count)
+{
+    if (size == 0) return false;
+    u32 const lastByte = p[size - 1];
+    if (lastByte == 0) return false;
+    u32 const tableLog = L.tableLog, T = L.T;
+    u32 const sh = 32u - tableLog, sh1 = tableLog > 9 ? tableLog - 9 : 0u;
+    u32 const totalBits = 8 * (size - 1) + kx_hb32(lastByte);
+    const u16* const tbl = L.u.t.l1;                                // (lg follows l1: one array of 1024)
+    int low;                                                        // words [low, low + 32) of the stream are in the ring
+    int reqM = -1;                                                  // batch (16 words from word 16 reqM = low - 16) on its way, -1: none
+    KxQuad b0, b1, b2, b3;
+    b0.x = b0.y = b0.z = b0.w = 0; b1 = b0; b2 = b0; b3 = b0;
+#define KHR_PUT(m_, q0_, q1_, q2_, q3_) { u32* const r_ = ring + ((16 * (m_)) & (KXL_RING - 1)); \
+        *(KxQuad*)r_ = q0_; *(KxQuad*)(r_ + 4) = q1_; *(KxQuad*)(r_ + 8) = q2_; *(KxQuad*)(r_ + 12) = q3_; }
+#define KHR_LOAD(m_, q0_, q1_, q2_, q3_) { const u8* const g_ = p + 64 * (m_); q0_ = kx_ld128u(g_); q1_ = kx_ld128u(g_ + 16); q2_ = kx_ld128u(g_ + 32); q3_ = kx_ld128u(g_ + 48); }
+    int j = (int)((size - 1) >> 2);                                // the top word (1 to 4 bytes of it exist)
+    u32 wt = 0;
+    for (u32 k = 4u * (u32)j; k < size; k++) wt |= (u32)p[k] << (8u * (k - 4u * (u32)j));
+    u32 const vb = totalBits - 32u * (u32)j;                       // its bits below the end mark: 0..31
+    u32 hi = vb ? wt << (32u - vb) : 0u, lo = 0, avail = vb;
+    {
+        // the top batch's words below the top word come in one by one (a 64-byte load could leave the entry); the batch
+        // below it, whole, with them; the one below that is requested
+        int const mt = j >> 4;
+        u32 tw[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { int const wi = 16 * mt + k; tw[k] = wi < j ? kx_ld32(p + 4 * wi) : 0u; }
+        KxQuad t0, t1, t2, t3;
+        t0.x = tw[0]; t0.y = tw[1]; t0.z = tw[2]; t0.w = tw[3]; t1.x = tw[4]; t1.y = tw[5]; t1.z = tw[6]; t1.w = tw[7];
+        t2.x = tw[8]; t2.y = tw[9]; t2.z = tw[10]; t2.w = tw[11]; t3.x = tw[12]; t3.y = tw[13]; t3.z = tw[14]; t3.w = tw[15];
+        if (mt >= 1) KHR_LOAD(mt - 1, b0, b1, b2, b3)
+        KHR_PUT(mt, t0, t1, t2, t3)
+        low = 16 * mt;
+        if (mt >= 1) { KHR_PUT(mt - 1, b0, b1, b2, b3) low = 16 * (mt - 1); }
+        if (mt >= 2) { KHR_LOAD(mt - 2, b0, b1, b2, b3) reqM = mt - 2; }
+    }
+    j--;                                                            // the next word to take ...
+    u32 w1;                                                         // ... read ahead of its use
+// (the ring ran dry -- it cannot at 11 bits a symbol, the code is there for the reader's sake: the batch on its way is
+// taken now, further ones are loaded on the spot)
+#define KHR_FETCH { if (j >= 0 && j < low) { \
+                        if (reqM >= 0) { KHR_PUT(reqM, b0, b1, b2, b3) low = 16 * reqM; reqM = -1; } \
+                        while (j < low) { int const m_ = (low >> 4) - 1; KxQuad c0_, c1_, c2_, c3_; KHR_LOAD(m_, c0_, c1_, c2_, c3_) KHR_PUT(m_, c0_, c1_, c2_, c3_) low = 16 * m_; } } \
+                    w1 = j < 0 ? 0u : ring[j & (KXL_RING - 1)]; }
+    KHR_FETCH
+    u32 consumed = 0;
+#define KHR_REFILL if (avail <= 32u) { u64 const c_ = (((u64)hi << 32) | lo) | ((u64)w1 << (32u - avail)); hi = (u32)(c_ >> 32); lo = (u32)c_; \
+                                       avail += 32u; j--; KHR_FETCH }
+#define KHR_SYM(acc_, k_) { u32 const ix_ = hi >> sh; u32 const e_ = tbl[ix_ < T ? 512u + ix_ : ix_ >> sh1]; u32 const nb_ = e_ >> 8; \
+                            hi = kx_alignbit(hi, lo, 32u - nb_); lo <<= nb_; avail -= nb_; consumed += nb_; acc_ |= (e_ & 0xFFu) << (8 * (k_)); }
+#define KHR_FOUR(acc_) { acc_ = 0; KHR_REFILL KHR_SYM(acc_, 0) KHR_SYM(acc_, 1) KHR_REFILL KHR_SYM(acc_, 2) KHR_SYM(acc_, 3) }
+    u32 i = 0;
+    for (; i + 32 <= count; i += 32) {
+        KxQuad qa, qb;
+        KHR_FOUR(qa.x) KHR_FOUR(qa.y) KHR_FOUR(qa.z) KHR_FOUR(qa.w) KHR_FOUR(qb.x) KHR_FOUR(qb.y) KHR_FOUR(qb.z) KHR_FOUR(qb.w)
+        // the batch requested 32 symbols ago goes into the ring once the words in its slots (the ring's top half) are taken;
+        // then the next one is requested; the 32 symbols leave
+        if (reqM >= 0 && j < low + 16) { KHR_PUT(reqM, b0, b1, b2, b3) low = 16 * reqM; reqM = -1; }
+        if (reqM < 0 && low >= 16) { reqM = (low >> 4) - 1; KHR_LOAD(reqM, b0, b1, b2, b3) }
+        kx_st128u(out + i, qa); kx_st128u(out + i + 16, qb);
+    }
+    for (; i < count; i++) { u32 acc = 0; KHR_REFILL KHR_SYM(acc, 0) out[i] = (u8)acc; }
+#undef KHR_FOUR
+#undef KHR_SYM
+#undef KHR_REFILL
+#undef KHR_FETCH
+#undef KHR_LOAD
+#undef KHR_PUT
+    return consumed == totalBits;
+}
 
 KX_DEV void zstd_lit_predecode_body(const KLitArgs& a)
 {
     KX_SHARED KLitLds lds;
-    int const tid = kx_wave() * 64 + kx_lane();                 // 128 threads
+    int const tid = kx_lane();                                  // 64 threads
     for (u32 base = kx_block() * KXL_FRAMES; base < a.n_slices; base += kx_nblocks() * KXL_FRAMES) {
-        // ---- phase A state of thread tid < 32: frame base + tid ----
+        // ---- the parsing state of lane tid < 16: frame base + tid ----
         u32 const fa = base + (u32)tid;
         bool const owner = tid < KXL_FRAMES && fa < a.n_slices;
         const u8* srcA = a.src; u32 srcSize = 0, pos = 0, nb = 0, litUsed = 0; bool go = false, last = false;
         u32 hufLog = 0; bool hufValid = false;
+        u32 covered = 0;                  // set when the frame's last block has been taken: every compressed block has a record
         if (owner) {
             srcA = a.src + a.in_off[fa]; srcSize = a.in_len[fa];
             go = srcSize >= 5 && kx_ld32(srcA) == 0xFD2FB528u;
@@ -454,90 +565,113 @@ KX_DEV void zstd_lit_predecode_body(const KLitArgs& a)
                 if (pos > srcSize) go = false;
             }
         }
-        // ---- phase B identity of every thread: stream sB of frame base + jB ----
+        // ---- the decoding identity of every lane: stream sB of frame base + jB ----
         int const jB = tid >> 2, sB = tid & 3;
         u32 const fb = base + (u32)jB;
+        const u8* const srcB = fb < a.n_slices ? a.src + a.in_off[fb] : a.src;
+        u32 const srcSizeB = fb < a.n_slices ? a.in_len[fb] : 0u;
         for (;;) {
             if (tid == 0) lds.more = 0;
-            if (tid < KXL_FRAMES) { lds.f[tid].valid = 0; lds.f[tid].bad = 0; }
-            kx_block_sync();
-            // ---- phase A: up to the frame's next Huffman-coded literals section ----
-            u32 regenA = 0;
+            if (tid < KXL_FRAMES) { lds.f[tid].valid = 0; lds.f[tid].bad = 0; lds.f[tid].treeLen = 0; }
+            kx_sync();
+            // ---- the owner: up to the frame's next Huffman-coded literals section ----
+            u32 regenA = 0, lhSizeA = 0, compA = 0, nstreamsA = 0, ltypeA = 0, bposA = 0; bool found = false;
             if (owner && go) {
                 KLitFrameLds& L = lds.f[tid];
-                bool found = false;
                 while (go && !last && !found) {
                     if (nb >= a.blk_cap || pos + 3 > srcSize) { go = false; break; }
                     u32 const bh = (u32)srcA[pos] | ((u32)srcA[pos + 1] << 8) | ((u32)srcA[pos + 2] << 16);
                     last = bh & 1; u32 const btype = (bh >> 1) & 3; u32 const bsize = bh >> 3;
                     pos += 3;
                     if (btype == 3) { go = false; break; }
-                    if (btype == 0) { if (pos + bsize > srcSize) { go = false; break; } pos += bsize; continue; }
-                    if (btype == 1) { if (pos + 1 > srcSize) { go = false; break; } pos += 1; continue; }
+                    if (btype == 0) { if (pos + bsize > srcSize) { go = false; break; } pos += bsize; if (last) covered = 0x80000000u; continue; }
+                    if (btype == 1) { if (pos + 1 > srcSize) { go = false; break; } pos += 1; if (last) covered = 0x80000000u; continue; }
                     if (pos + bsize > srcSize || bsize > 128u * 1024u || bsize < 2) { go = false; break; }
                     const u8* const bp = srcA + pos; u32 const bend = bsize;
                     u32 const lh0 = bp[0]; u32 const ltype = lh0 & 3, sf = (lh0 >> 2) & 3;
                     KPreLit r; r.off = litUsed; r.regen = 0; r.ok = 0; r.pad = 0;
-                    if (ltype < 2) { a.rec[(size_t)fa * a.blk_cap + nb++] = r; pos += bsize; continue; }      // raw / RLE literals: nothing to decode
+                    if (ltype < 2) { a.rec[(size_t)fa * a.blk_cap + nb++] = r; pos += bsize; if (last) covered = 0x80000000u; continue; }      // raw / RLE literals: nothing to decode
                     if (bend < 5) { go = false; break; }
                     u32 const w = kx_ld32(bp); u32 lhSize, regen, comp, nstreams;
                     if (sf < 2) { lhSize = 3; regen = (w >> 4) & 0x3FF; comp = (w >> 14) & 0x3FF; nstreams = sf ? 4 : 1; }
                     else if (sf == 2) { lhSize = 4; regen = (w >> 4) & 0x3FFF; comp = w >> 18; nstreams = 4; }
                     else { lhSize = 5; regen = (w >> 4) & 0x3FFFF; comp = (w >> 22) + ((u32)bp[4] << 10); nstreams = 4; }
                     if (regen > 128u * 1024u || lhSize + comp > bend || comp == 0 || litUsed + regen > a.lit_cap) { go = false; break; }
-                    u32 hused = 0;
-                    if (ltype == 2) {
-                        u32 tl = 0, nw = 0;
-                        hused = khuf_read_dtable(L, bp + lhSize, comp, &tl, &nw);
-                        if (hused == 0) { go = false; break; }
-                        hufLog = tl; (void)nw; hufValid = true;
-                    } else {
-                        if (!hufValid) { go = false; break; }
-                        // (the table of the previous Huffman block is still in this frame's slice of the LDS)
-                    }
-                    u32 const so = (u32)(bp - srcA) + lhSize + hused, ssize = comp - hused;
-                    if (nstreams == 1) {
-                        L.soff[0] = so; L.ssz[0] = ssize; L.cnt[0] = regen;
-                        for (int k = 1; k < 4; k++) { L.soff[k] = 0; L.ssz[k] = 0; L.cnt[k] = 0xFFFFFFFFu; }       // no such stream
-                    } else {
-                        if (ssize < 10) { go = false; break; }
-                        u32 const c0 = kx_ld16(srcA + so), c1 = kx_ld16(srcA + so + 2), c2 = kx_ld16(srcA + so + 4);
-                        if (6 + c0 + c1 + c2 > ssize) { go = false; break; }
-                        u32 const seg = (regen + 3) / 4;
-                        if (3 * seg > regen) { go = false; break; }
-                        L.soff[0] = so + 6; L.soff[1] = so + 6 + c0; L.soff[2] = so + 6 + c0 + c1; L.soff[3] = so + 6 + c0 + c1 + c2;
-                        L.ssz[0] = c0; L.ssz[1] = c1; L.ssz[2] = c2; L.ssz[3] = ssize - 6 - c0 - c1 - c2;
-                        L.cnt[0] = seg; L.cnt[1] = seg; L.cnt[2] = seg; L.cnt[3] = regen - 3 * seg;
-                    }
-                    L.tableLog = hufLog; L.dst = litUsed; L.valid = 1;
-                    regenA = regen; found = true;
+                    if (ltype == 3 && !hufValid) { go = false; break; }
+                    // (a tree-less block: the table of the previous Huffman block is still in this frame's slice of the LDS)
+                    if (ltype == 2) { L.treeOff = pos + lhSize; L.treeLen = comp < (u32)KXL_TREE ? comp : (u32)KXL_TREE; }
+                    regenA = regen; lhSizeA = lhSize; compA = comp; nstreamsA = nstreams; ltypeA = ltype; bposA = pos;
+                    found = true;
                     pos += bsize;
                 }
                 if (found) lds.more = 1;
             }
-            kx_block_sync();
+            kx_sync();
             if (lds.more == 0) break;
-            // ---- phase B: one lane per stream ----
+            // ---- four lanes per frame: the tree description into LDS ----
+            {
+                KLitFrameLds& L = lds.f[jB];
+                u32 const tl_ = L.treeLen, to_ = L.treeOff;
+                for (u32 k = (u32)sB * 4u; k < tl_; k += 16u) {
+                    if (k + 4 <= tl_) { u32 const v = kx_ld32(srcB + to_ + k); __builtin_memcpy(L.r.tree + 8 + k, &v, 4); }
+                    else for (u32 q = k; q < tl_; q++) L.r.tree[8 + q] = srcB[to_ + q];
+                }
+            }
+            kx_sync();
+            // ---- the owner: the table, the streams ----
+            if (owner && found) {
+                KLitFrameLds& L = lds.f[tid];
+                u32 hused = 0; bool okA = true;
+                if (ltypeA == 2) {
+                    u32 tl = 0, nw = 0;
+                    hused = khuf_read_dtable<KLitFrameLds, false>(L, L.r.tree + 8, L.treeLen, &tl, &nw);
+                    if (hused == 0 || !khuf_fill_compact(L, nw, tl)) okA = false;
+                    else { hufLog = tl; hufValid = true; }
+                }
+                u32 const so = bposA + lhSizeA + hused, ssize = compA - hused;
+                if (okA && hused >= compA) okA = false;
+                if (okA) {
+                    if (nstreamsA == 1) {
+                        L.soff[0] = so; L.ssz[0] = ssize; L.cnt[0] = regenA;
+                        for (int k = 1; k < 4; k++) { L.soff[k] = 0; L.ssz[k] = 0; L.cnt[k] = 0xFFFFFFFFu; }       // no such stream
+                    } else if (ssize < 10) okA = false;
+                    else {
+                        u32 const c0 = kx_ld16(srcA + so), c1 = kx_ld16(srcA + so + 2), c2 = kx_ld16(srcA + so + 4);
+                        u32 const seg = (regenA + 3) / 4;
+                        if (6 + c0 + c1 + c2 > ssize || 3 * seg > regenA) okA = false;
+                        else {
+                            L.soff[0] = so + 6; L.soff[1] = so + 6 + c0; L.soff[2] = so + 6 + c0 + c1; L.soff[3] = so + 6 + c0 + c1 + c2;
+                            L.ssz[0] = c0; L.ssz[1] = c1; L.ssz[2] = c2; L.ssz[3] = ssize - 6 - c0 - c1 - c2;
+                            L.cnt[0] = seg; L.cnt[1] = seg; L.cnt[2] = seg; L.cnt[3] = regenA - 3 * seg;
+                        }
+                    }
+                }
+                if (okA) { L.tableLog = hufLog; L.dst = litUsed; L.valid = 1; }
+                else { go = false; found = false; }
+            }
+            kx_sync();
+            // ---- one lane per stream ----
             if (fb < a.n_slices && lds.f[jB].valid) {
-                KLitFrameLds const& L = lds.f[jB];
+                KLitFrameLds& L = lds.f[jB];
                 u32 const cnt = L.cnt[sB];
                 if (cnt != 0xFFFFFFFFu) {
                     u32 const seg = L.cnt[0];                                   // stream s writes behind s full segments
                     u8* const out = a.lits + (size_t)fb * a.lit_cap + L.dst + (L.cnt[1] == 0xFFFFFFFFu ? 0u : (u32)sB * seg);
-                    bool const ok = khuf_decode_stream(L, L.tableLog, a.src + a.in_off[fb] + L.soff[sB], L.ssz[sB], out, cnt);
-                    if (!ok) lds.f[jB].bad = 1;
+                    bool const ok = khuf_decode_stream_ring(L, L.r.ring[sB], srcB + L.soff[sB], L.ssz[sB], out, cnt);
+                    if (!ok) L.bad = 1;
                 }
             }
-            kx_block_sync();
+            (void)srcSizeB;
+            kx_sync();
             // ---- the owner records the block ----
-            if (owner && lds.f[tid].valid) {
+            if (owner && found) {
                 KPreLit r; r.off = litUsed; r.regen = regenA; r.ok = lds.f[tid].bad ? 0u : 1u; r.pad = 0;
                 a.rec[(size_t)fa * a.blk_cap + nb++] = r;
-                if (lds.f[tid].bad) go = false; else litUsed += regenA;
+                if (lds.f[tid].bad) go = false; else { litUsed += regenA; if (last) covered = 0x80000000u; }
             }
-            kx_block_sync();
+            kx_sync();
         }
-        if (owner) a.nrec[fa] = nb;
-        kx_block_sync();
+        if (owner) a.nrec[fa] = nb | covered;
+        kx_sync();
     }
 }
