@@ -406,8 +406,8 @@ KX_DEV void kxd_load32(KxdRun32& r, const u8* s, u32 n)
 {
     r.v0 = 0; r.v1 = 0; r.v2 = 0; r.vt = 0;
     if (n >= 8) {
-        u32 const o1 = n > 16 ? 8u : 0u, o2 = n > 24 ? 16u : 0u;
-        r.v0 = kx_ld64(s); r.v1 = kx_ld64(s + o1); r.v2 = kx_ld64(s + o2); r.vt = kx_ld64(s + n - 8);
+        r.v0 = kx_ld64(s); r.vt = kx_ld64(s + n - 8);
+        if (n > 16) { r.v1 = kx_ld64(s + 8); if (n > 24) r.v2 = kx_ld64(s + 16); }
     } else if (n >= 4) { r.v0 = kx_ld32(s); r.vt = kx_ld32(s + n - 4); }
     else if (n) { r.v0 = s[0]; r.v1 = s[n >> 1]; r.vt = s[n - 1]; }
 }
