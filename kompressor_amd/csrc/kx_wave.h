@@ -35,6 +35,11 @@ KX_DEV u32 kx_shfl(u32 v, int src) { return (u32)__builtin_amdgcn_ds_bpermute((s
 // orders LDS/global traffic between the lanes of the (single-wave) workgroup
 // value held by lane k (a compile-time constant): v_readlane_b32, the result is wave-uniform
 KX_DEV u32 kx_bcast(u32 v, int k) { return (u32)__builtin_amdgcn_readlane((int)v, k); }
+// value held by lane K of the caller's quad (lanes 4 q .. 4 q + 3): one DPP move, no LDS
+template <int K> KX_DEV u32 kx_quad_bcast(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55, 0xF, 0xF, true); }
+// orders LDS traffic between the four lanes of a quad: on the GPU they are lanes of one wave (program order is enough, this only
+// stops the compiler); the emulator's lanes are fibers and meet here
+KX_DEV void kx_quad_sync() { __builtin_amdgcn_wave_barrier(); }
 KX_DEV void kx_sync() { __syncthreads(); }
 // The lanes of a wave execute in lock step and the vector-memory pipeline keeps
 // one wave's accesses to an address in program order, so memory written by some

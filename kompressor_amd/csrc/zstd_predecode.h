@@ -187,11 +187,15 @@ KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
         if (lane < 53) lds.mlx[lane] = kx_ml_base((u32)lane) | (kxd_ml_bits((u32)lane) << 24);
     }
     kx_sync();
-    if (kx_lane() >= KXP_FRAMES) return;
-    u32 const slot = kx_block() * (u32)KXP_FRAMES + (u32)kx_lane();
+    // Four lanes per frame.  All four walk the frame's blocks (same loads, same decisions); lane 0 of the quad builds the
+    // tables and writes the records; in the sequence loop lane 0 is the offset's tANS chain, lane 1 the match length's,
+    // lane 2 the literal length's (lane 3 shadows lane 2): a table look-up, an extra-bits field and a state update each,
+    // the bit counts and values exchanged inside the quad (DPP), the bitstream container the same three LDS words for all.
+    u32 const role = (u32)kx_lane() & 3u;
+    u32 const slot = kx_block() * (u32)KXP_FRAMES + ((u32)kx_lane() >> 2);
     if (slot >= a.n_slices) return;
     u32 const f = a.perm ? a.perm[slot] : slot;
-    KPreFrameLds& fl = lds.f[kx_lane()];
+    KPreFrameLds& fl = lds.f[kx_lane() >> 2];
     const u8* const src = a.src + a.in_off[f];
     u32 const srcSize = a.in_len[f];
     u64* const stage = a.stage + (size_t)f * a.seq_cap;
@@ -209,7 +213,7 @@ KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
         if (pos > srcSize) ok = false;
     }
     u32 rep1 = 1, rep2 = 4, rep3 = 8;
-    u32 kind[3] = { 0, 0, 0 }, klog[3] = { 0, 0, 0 };
+    u32 kind[3] = { 0, 0, 0 }, klog[3] = { 0, 0, 0 };        // (lane 0 of the quad)
     bool last = false;
     u32 covered = 0;                      // set when the frame's last block has been taken: every compressed block has a record
     while (ok && !last && nb < a.blk_cap) {
@@ -249,7 +253,7 @@ KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
             else { if (p2 + 2 > bend) break; nbSeq = kx_ld16(bp + p2) + 0x7F00; p2 += 2; }
         }
         KPreBlk rec; rec.seq_off = nstaged; rec.nbSeq = nbSeq; rec.ok = 0; rec.rep[0] = rep1; rec.rep[1] = rep2; rec.rep[2] = rep3; rec.pad[0] = 0; rec.pad[1] = 0;
-        if (nbSeq == 0) { rec.ok = 1; blk[nb++] = rec; pos += bsize; if (last) covered = 0x80000000u; continue; }
+        if (nbSeq == 0) { rec.ok = 1; if (role == 0) blk[nb] = rec; nb++; pos += bsize; if (last) covered = 0x80000000u; continue; }
         if (p2 >= bend) break;
         u32 const modes = bp[p2++];
         if (modes & 3) break;
@@ -257,117 +261,110 @@ KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
         u32 tlLL = 0, tlOF = 0, tlML = 0; bool tok = true;
         for (int t = 0; t < 3 && tok; t++) {
             u32 const mode = (modes >> (6 - 2 * t)) & 3u;
-            u32 const r = kxp_seq_table(fl, t, mode, bp + p2, bend - p2, t == 0 ? &tlLL : t == 1 ? &tlOF : &tlML, kind, klog);
+            u32 r = 0, tl = 0;
+            if (role == 0) r = kxp_seq_table(fl, t, mode, bp + p2, bend - p2, &tl, kind, klog);
+            r = kx_quad_bcast<0>(r); tl = kx_quad_bcast<0>(tl);
+            if (t == 0) tlLL = tl; else if (t == 1) tlOF = tl; else tlML = tl;
             if (r == KXD_FAIL) tok = false; else p2 += r;
         }
         if (!tok || p2 >= bend) break;
         // ---- the bitstream, read backwards from its last set bit ----
         // The reader has no state but `remaining`, the number of unread bits: every sequence builds a 64-bit container
-        // (hi : lo, top bit = next unread bit) from the three 32-bit words of the stream that hold it -- one address,
-        // three LDS reads, two funnel shifts -- takes the three extra-bits fields from hi, moves the container up by
-        // their total, and takes the three state fields.  (More than 32 bits of extra bits in one sequence -- offsets
-        // beyond 64 KiB with long lengths -- takes a second container.)
+        // (top bit = next unread bit) from the three 32-bit words of the stream that hold it -- one address, three LDS
+        // reads, two funnel shifts -- and each role lane takes its extra-bits field and its state field out of it.
+        // (More than 64 bits in one sequence -- offsets beyond 64 KiB with long lengths -- takes a second container.)
         //
         // No HBM access inside the loop waits for memory.  On gfx9 loads and stores share one counter, and a wait in a
         // loop with conditional accesses is a wait for all of them: with the stream read straight from HBM and the
         // sequence stored straight to it, every refill waited a full round trip (measured: 2 250 cycles a sequence).
         // So the stream comes through a ring in LDS, filled sixteen words (64 bytes, aligned to the stream's 16-word
-        // grid) at a time, and sequences leave through a queue of eight: every eighth sequence the batch requested
-        // eight sequences earlier is written to the ring, the next one is requested, and the eight sequences go out as
-        // one 64-byte run.  The one wait there finds everything long done.  A stream that outruns the ring (more than
-        // 64 bits a sequence for a while) fills it on the spot.
+        // grid; a quarter per lane) at a time, and sequences leave through a queue of eight: every eighth sequence the
+        // batch requested eight sequences earlier is written to the ring, the next one is requested, and the eight
+        // sequences go out as one 64-byte run.  The one wait there finds everything long done.  A stream that outruns
+        // the ring (more than 64 bits a sequence for a while) fills it on the spot.
         const u8* const sq = bp + p2; u32 const ssz = bend - p2;
         u32 const lastByte = sq[ssz - 1];
         if (lastByte == 0) break;
         int remaining = (int)(8 * (ssz - 1) + kx_hb32(lastByte));      // unread bits; the stream must end at exactly 0
         int lowFetched;                                                 // words [lowFetched, top] of the stream are in the ring
         int reqM = -1;                                                  // batch (16 words from word 16 reqM) on its way, -1: none
-        KxQuad b0, b1, b2, b3;
-        b0.x = b0.y = b0.z = b0.w = 0; b1 = b0; b2 = b0; b3 = b0;
-#define KXP_RING_PUT(m_, q0_, q1_, q2_, q3_) { u32* const r_ = fl.ring + ((16 * (m_)) & (KXP_RING - 1)); \
-            *(KxQuad*)r_ = q0_; *(KxQuad*)(r_ + 4) = q1_; *(KxQuad*)(r_ + 8) = q2_; *(KxQuad*)(r_ + 12) = q3_; \
-            if (r_ == fl.ring) { fl.ring[KXP_RING] = (q0_).x; fl.ring[KXP_RING + 1] = (q0_).y; } }
+        KxQuad bq; bq.x = bq.y = bq.z = bq.w = 0;                       // this lane's quarter of it
+#define KXP_RING_PUT(m_, q_) { u32 const o_ = (u32)(16 * (m_)) & (KXP_RING - 1); *(KxQuad*)(fl.ring + o_ + 4u * role) = q_; \
+            if (o_ == 0 && role == 0) { fl.ring[KXP_RING] = (q_).x; fl.ring[KXP_RING + 1] = (q_).y; } }
         {
             // the top batch holds the stream's last word (1 to 4 bytes of it exist): its words come in one by one (a
             // 64-byte load could leave the entry); the batch below it, whole, with them; the one below that is requested
             int const jt = (int)((ssz - 1) >> 2), mt = jt >> 4;
             u32 wt = 0;
             for (u32 k = 4u * (u32)jt; k < ssz; k++) wt |= (u32)sq[k] << (8u * (k - 4u * (u32)jt));
-            KxQuad t0, t1, t2, t3; u32* const t = &t0.x;
-            u32 tw[16];
+            u32 tw[4];
 #pragma unroll
-            for (int k = 0; k < 16; k++) { int const wi = 16 * mt + k; tw[k] = wi < jt ? kx_ld32(sq + 4 * wi) : (wi == jt ? wt : 0u); }
-            (void)t;
-            t0.x = tw[0]; t0.y = tw[1]; t0.z = tw[2]; t0.w = tw[3]; t1.x = tw[4]; t1.y = tw[5]; t1.z = tw[6]; t1.w = tw[7];
-            t2.x = tw[8]; t2.y = tw[9]; t2.z = tw[10]; t2.w = tw[11]; t3.x = tw[12]; t3.y = tw[13]; t3.z = tw[14]; t3.w = tw[15];
-            if (mt >= 1) { const u8* const q = sq + 64 * (mt - 1); b0 = kx_ld128u(q); b1 = kx_ld128u(q + 16); b2 = kx_ld128u(q + 32); b3 = kx_ld128u(q + 48); }
-            KXP_RING_PUT(mt, t0, t1, t2, t3)
+            for (int k = 0; k < 4; k++) { int const wi = 16 * mt + 4 * (int)role + k; tw[k] = wi < jt ? kx_ld32(sq + 4 * wi) : (wi == jt ? wt : 0u); }
+            KxQuad t0; t0.x = tw[0]; t0.y = tw[1]; t0.z = tw[2]; t0.w = tw[3];
+            if (mt >= 1) bq = kx_ld128u(sq + 64 * (mt - 1) + 16 * (int)role);
+            KXP_RING_PUT(mt, t0)
             lowFetched = 16 * mt;
-            if (mt >= 1) { KXP_RING_PUT(mt - 1, b0, b1, b2, b3) lowFetched = 16 * (mt - 1); }
-            if (mt >= 2) { const u8* const q = sq + 64 * (mt - 2); b0 = kx_ld128u(q); b1 = kx_ld128u(q + 16); b2 = kx_ld128u(q + 32); b3 = kx_ld128u(q + 48); reqM = mt - 2; }
+            if (mt >= 1) { KXP_RING_PUT(mt - 1, bq) lowFetched = 16 * (mt - 1); }
+            if (mt >= 2) { bq = kx_ld128u(sq + 64 * (mt - 2) + 16 * (int)role); reqM = mt - 2; }
+            kx_quad_sync();
         }
-        bool bad = false;
-// the 64 bits below the read position; words below the stream's first read as zero (only its last sequences get there)
-#define KXP_CONTAINER(hi_, lo_) u32 hi_, lo_; { \
-            int const w_ = remaining >> 5; u32 const s_ = (u32)remaining & 31u; \
+        u32 bad = 0;
+// the 64 bits below bit position pos_ of the stream; words below the stream's first read as zero (only its last sequences get there)
+#define KXP_CONTAINER(C_, pos_) u64 C_; { \
+            int const w_ = (pos_) >> 5; u32 const s_ = (u32)(pos_) & 31u; \
             if (w_ - 2 < lowFetched && lowFetched > 0) { \
                 /* the ring ran dry: the batch on its way is taken now, further ones are loaded on the spot -- the only waits for HBM the loop has */ \
-                if (reqM >= 0) { KXP_RING_PUT(reqM, b0, b1, b2, b3) lowFetched = 16 * reqM; reqM = -1; } \
-                while (w_ - 2 < lowFetched && lowFetched > 0) { int const m_ = (lowFetched >> 4) - 1; const u8* const q_ = sq + 64 * m_; \
-                    KxQuad const c0_ = kx_ld128u(q_), c1_ = kx_ld128u(q_ + 16), c2_ = kx_ld128u(q_ + 32), c3_ = kx_ld128u(q_ + 48); \
-                    KXP_RING_PUT(m_, c0_, c1_, c2_, c3_) lowFetched = 16 * m_; } } \
+                if (reqM >= 0) { KXP_RING_PUT(reqM, bq) lowFetched = 16 * reqM; reqM = -1; } \
+                while (w_ - 2 < lowFetched && lowFetched > 0) { int const m_ = (lowFetched >> 4) - 1; \
+                    KxQuad const c_ = kx_ld128u(sq + 64 * m_ + 16 * (int)role); KXP_RING_PUT(m_, c_) lowFetched = 16 * m_; } \
+                kx_quad_sync(); } \
             u32 x2_, x1_, x0_; \
             if (w_ >= 2) { const u32* const r_ = fl.ring + ((w_ - 2) & (KXP_RING - 1)); x0_ = r_[0]; x1_ = r_[1]; x2_ = r_[2]; } \
-            else { x2_ = fl.ring[w_ & (KXP_RING - 1)]; x1_ = w_ >= 1 ? fl.ring[(w_ - 1) & (KXP_RING - 1)] : 0u; x0_ = 0u; } \
-            hi_ = kx_alignbit(x2_, x1_, s_); lo_ = kx_alignbit(x1_, x0_, s_); }
-// the top n (<= 31) bits of t_, which then moves up by n
-#define KXP_TAKE(dst_, t_, n_) { u32 const n__ = (n_); dst_ = ((t_) >> 1) >> (31u - n__); (t_) <<= n__; }
-        u32 sLL, sOF, sML;
+            else { x2_ = w_ >= 0 ? fl.ring[w_ & (KXP_RING - 1)] : 0u; x1_ = w_ >= 1 ? fl.ring[(w_ - 1) & (KXP_RING - 1)] : 0u; x0_ = 0u; } \
+            C_ = ((u64)kx_alignbit(x2_, x1_, s_) << 32) | kx_alignbit(x1_, x0_, s_); }
+// n (<= 31) bits of container C_ that start o_ (<= 63) bits below its top
+#define KXP_FIELD(C_, o_, n_) ((((u32)(((C_) << (o_)) >> 32)) >> 1) >> (31u - (n_)))
+        // this lane's chain: 0 offset, 1 match length, 2 (and 3) literal length
+        u32 const tbase = role == 0 ? (u32)KXD_OF0 : role == 1 ? (u32)KXD_ML0 : (u32)KXD_LL0;
+        u32 const tl = role == 0 ? tlOF : role == 1 ? tlML : tlLL;
+        u32 const sz = 1u << tl, smask = role == 0 ? 255u : 511u, maxSym = role == 0 ? 31u : role == 1 ? 52u : 35u;
+        const u32* const xt = role == 1 ? lds.mlx : lds.llx;
+        u32 st;
         {
-            KXP_CONTAINER(hi, lo)
-            (void)lo;
-            u32 t = hi;                                             // initial states, stream order LL, OF, ML
-            KXP_TAKE(sLL, t, tlLL) KXP_TAKE(sOF, t, tlOF) KXP_TAKE(sML, t, tlML)
+            KXP_CONTAINER(C0, remaining)                            // initial states, stream order LL, OF, ML
+            u32 const o0 = role == 0 ? tlLL : role == 1 ? tlLL + tlOF : 0u;
+            st = KXP_FIELD(C0, o0, tl);
             remaining -= (int)(tlLL + tlOF + tlML);
         }
         if (remaining < 0) break;
         u64* const out = stage + nstaged;
-        u32 const szLL = 1u << tlLL, szOF = 1u << tlOF, szML = 1u << tlML;
-        u32 eL = fl.tb[KXD_LL0 + sLL], eO = fl.tb[KXD_OF0 + sOF], eM = fl.tb[KXD_ML0 + sML];
+        u32 e = fl.tb[tbase + st];
         for (u32 i = 0; i < nbSeq; i++) {
-            u32 const cL = eL >> 10, cO = eO >> 10, cM = eM >> 10;
-            if (cL > 35 || cM > 52 || cO > 31 || remaining < 0) { bad = true; break; }
-            u32 const xL = lds.llx[cL], xM = lds.mlx[cM];
-            u32 const aL = xL >> 24, aM = xM >> 24, aO = cO;
+            u32 const sym = e >> 10, k = e & 1023u;
             bool const upd = i + 1 < nbSeq;                        // the block's final sequence updates no state
-            u32 const kL = eL & 1023u, kM = eM & 1023u, kO = eO & 1023u;
-            u32 const nL = upd ? tlLL - kx_hb32(kL) : 0u, nM = upd ? tlML - kx_hb32(kM) : 0u, nO = upd ? tlOF - kx_hb32(kO) : 0u;
+            u32 const n = upd ? tl - kx_hb32(k) : 0u;
+            u32 const symc = sym > maxSym ? maxSym : sym;
+            bad |= (sym > maxSym) | (remaining < 0);
+            u32 const x = xt[symc];
+            u32 const ax = role == 0 ? symc : x >> 24, base = role == 0 ? (1u << symc) : (x & 0xFFFFFFu);
+            u32 const aO = kx_quad_bcast<0>(ax), aM = kx_quad_bcast<1>(ax), aL = kx_quad_bcast<2>(ax);
+            u32 const nO = kx_quad_bcast<0>(n), nM = kx_quad_bcast<1>(n), nL = kx_quad_bcast<2>(n);
             // bit order inside a sequence: OF extra, ML extra, LL extra, then LL state, ML state, OF state
-            u32 xo, xm, xl, yL, yM, yO;
-            u32 const needA = aO + aM + aL;
-            KXP_CONTAINER(hi, lo)
-            if (needA <= 32u) {
-                u32 t = hi;
-                KXP_TAKE(xo, t, aO) KXP_TAKE(xm, t, aM) KXP_TAKE(xl, t, aL)
-                t = (u32)(((((u64)hi << 32) | lo) << needA) >> 32);
-                KXP_TAKE(yL, t, nL) KXP_TAKE(yM, t, nM) KXP_TAKE(yO, t, nO)
-                remaining -= (int)(needA + nL + nM + nO);
-            } else {
-                u32 t = hi;
-                KXP_TAKE(xo, t, aO)
-                remaining -= (int)aO;
-                if (remaining < 0) { bad = true; break; }
-                KXP_CONTAINER(hi2, lo2)
-                t = hi2;
-                KXP_TAKE(xm, t, aM) KXP_TAKE(xl, t, aL)
-                t = (u32)(((((u64)hi2 << 32) | lo2) << (aM + aL)) >> 32);
-                KXP_TAKE(yL, t, nL) KXP_TAKE(yM, t, nM) KXP_TAKE(yO, t, nO)
-                remaining -= (int)(aM + aL + nL + nM + nO);
-            }
-            // the next states' table words are requested before this sequence is finished
-            sLL = (((kL << nL) - szLL) + yL) & 511u; sML = (((kM << nM) - szML) + yM) & 511u; sOF = (((kO << nO) - szOF) + yO) & 255u;
-            u32 const nLe = fl.tb[KXD_LL0 + sLL], nOe = fl.tb[KXD_OF0 + sOF], nMe = fl.tb[KXD_ML0 + sML];
-            u32 const ofv = (1u << cO) + xo, ml = (xM & 0xFFFFFFu) + xm, ll = (xL & 0xFFFFFFu) + xl;
+            u32 const needA = aO + aM + aL, needB = nL + nM + nO;
+            u32 const offA = role == 0 ? 0u : role == 1 ? aO : aO + aM;
+            u32 const offB = role == 0 ? nL + nM : role == 1 ? nL : 0u;
+            int const rem0 = remaining < 0 ? 0 : remaining;
+            KXP_CONTAINER(C, rem0)
+            u32 const xv = KXP_FIELD(C, offA, ax);
+            u32 yv;
+            if (needA + needB <= 64u) { u32 const o = needA + offB; yv = KXP_FIELD(C, o > 63u ? 63u : o, n); }
+            else { int const rem2 = rem0 - (int)needA < 0 ? 0 : rem0 - (int)needA; KXP_CONTAINER(C2, rem2) yv = KXP_FIELD(C2, offB, n); }
+            remaining -= (int)(needA + needB);
+            // the next state's table word is requested before this sequence is finished
+            st = (((k << n) - sz) + yv) & smask;
+            u32 const en = fl.tb[tbase + st];
+            u32 const val = base + xv;
+            u32 const ofv = kx_quad_bcast<0>(val), ml = kx_quad_bcast<1>(val), ll = kx_quad_bcast<2>(val);
             // repeat-offset rules
             bool const isRep = ofv <= 3;
             u32 const idx = ofv - 1 + (ll == 0);
@@ -376,36 +373,38 @@ KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
             u32 const off = isRep ? roff : ofv - 3;
             bool const sh2 = !isRep || idx >= 2, sh1 = !isRep || idx >= 1;
             rep3 = sh2 ? rep2 : rep3; rep2 = sh1 ? rep1 : rep2; rep1 = off;
-            if (ll > 0xFFFFu || ml - 3u > 0xFFFFu) { bad = true; break; }       // does not fit the staging word: left to k_zstd_decode
-            fl.outq[i & 7u] = (u64)(ll | ((ml - 3u) << 16)) | ((u64)off << 32);
-            eL = nLe; eO = nOe; eM = nMe;
+            bad |= (ll > 0xFFFFu) | (ml - 3u > 0xFFFFu);              // does not fit the staging word: the block is left to k_zstd_decode
+            if (role == 0) fl.outq[i & 7u] = (u64)((ll & 0xFFFFu) | ((ml - 3u) << 16)) | ((u64)off << 32);
+            e = en;
             if ((i & 7u) == 7u) {
                 // the batch requested eight sequences ago goes into the ring (its slots held words long taken)
-                if (reqM >= 0) { KXP_RING_PUT(reqM, b0, b1, b2, b3) lowFetched = 16 * reqM; reqM = -1; }
+                if (reqM >= 0) { KXP_RING_PUT(reqM, bq) lowFetched = 16 * reqM; reqM = -1; }
                 // the next one, if its slots are free: the ring holds words [lowFetched, lowFetched + 64), the batch takes the
                 // slots of the top sixteen
                 if (lowFetched >= 16 && (remaining >> 5) < lowFetched + (KXP_RING - 16)) {
                     reqM = (lowFetched >> 4) - 1;
-                    const u8* const q = sq + 64 * reqM; b0 = kx_ld128u(q); b1 = kx_ld128u(q + 16); b2 = kx_ld128u(q + 32); b3 = kx_ld128u(q + 48);
+                    bq = kx_ld128u(sq + 64 * reqM + 16 * (int)role);
                 }
-                // eight sequences leave
-                u8* const o = (u8*)(out + (i - 7u)); const KxQuad* const oq = (const KxQuad*)fl.outq;
-                KxQuad const q0 = oq[0], q1 = oq[1], q2 = oq[2], q3 = oq[3];
-                kx_st128u(o, q0); kx_st128u(o + 16, q1); kx_st128u(o + 32, q2); kx_st128u(o + 48, q3);
+                // eight sequences leave, a quarter per lane
+                kx_quad_sync();
+                KxQuad const q = ((const KxQuad*)fl.outq)[role];
+                kx_st128u((u8*)(out + (i - 7u)) + 16u * role, q);
             }
         }
-#undef KXP_TAKE
+#undef KXP_FIELD
 #undef KXP_CONTAINER
 #undef KXP_RING_PUT
-        if (!bad) for (u32 k = nbSeq & ~7u; k < nbSeq; k++) out[k] = fl.outq[k & 7u];
+        bad = kx_quad_bcast<0>(bad) | kx_quad_bcast<1>(bad) | kx_quad_bcast<2>(bad);
+        if (!bad && role == 0) for (u32 k = nbSeq & ~7u; k < nbSeq; k++) out[k] = fl.outq[k & 7u];
         if (bad || remaining != 0) break;          // irregular: this block and the rest are left to k_zstd_decode
         rec.ok = 1; rec.rep[0] = rep1; rec.rep[1] = rep2; rec.rep[2] = rep3;
-        blk[nb++] = rec;
+        if (role == 0) blk[nb] = rec;
+        nb++;
         nstaged += nbSeq;
         pos += bsize;
         if (last) covered = 0x80000000u;
     }
-    a.nblk[f] = nb | covered;
+    if (role == 0) a.nblk[f] = nb | covered;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

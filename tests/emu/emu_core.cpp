@@ -77,6 +77,16 @@ static void run_block(int W)
         int alive = 0, at_block_sync = 0; bool resolved = false;
         for (int i = 0; i < N; i++) if (fib[i].state != F_DEAD) { alive++; if (fib[i].state == F_WAIT && fib[i].op == OP_BLOCK_SYNC) at_block_sync++; }
         if (!alive) break;
+        // quad-scoped exchanges (DPP on the GPU: no rendezvous beyond the four lanes) resolve as soon as the quad's live lanes are there
+        for (int q = 0; q < N / 4 && !resolved; q++) {
+            int n = 0, waiting = 0;
+            for (int l = 0; l < 4; l++) { Fiber& f = fib[q * 4 + l]; if (f.state == F_DEAD) continue; n++; if (f.state == F_WAIT && f.op == OP_QUAD) waiting++; }
+            if (!n || waiting != n) continue;
+            for (int l = 0; l < 4; l++) { Fiber& f = fib[q * 4 + l]; if (f.state != F_WAIT) continue; Fiber& s2 = fib[q * 4 + (int)(f.b & 3)]; f.res = (s2.state == F_WAIT) ? s2.a : 0; }
+            for (int l = 0; l < 4; l++) if (fib[q * 4 + l].state == F_WAIT) fib[q * 4 + l].state = F_READY;
+            resolved = true;
+        }
+        if (resolved) continue;
         if (at_block_sync == alive) { for (int i = 0; i < N; i++) if (fib[i].state == F_WAIT) { fib[i].res = 0; fib[i].state = F_READY; } resolved = true; }
         else for (int w = 0; w < W; w++) {
             int o = 0, n = 0, waiting = 0; u64 mask = 0; bool mixed = false;

@@ -17,7 +17,7 @@ typedef uint64_t u64;
 #define KX_SHARED static
 
 namespace kxemu {
-enum { OP_BALLOT = 1, OP_SHFL = 2, OP_SYNC = 3, OP_BLOCK_SYNC = 4 };
+enum { OP_BALLOT = 1, OP_SHFL = 2, OP_SYNC = 3, OP_BLOCK_SYNC = 4, OP_QUAD = 5 };
 extern int cur_lane, cur_wave, waves_per_block; extern u32 cur_block, num_blocks;
 u64 arrive(int op, u64 a, u64 b);
 }
@@ -34,6 +34,8 @@ KX_DEV bool kx_any(bool p) { return kx_ballot(p) != 0; }
 KX_DEV bool kx_all(bool p) { return kx_ballot(!p) == 0; }
 KX_DEV u32 kx_shfl(u32 v, int src) { return (u32)kxemu::arrive(kxemu::OP_SHFL, v, (u64)(src & 63)); }
 KX_DEV u32 kx_bcast(u32 v, int k) { return kx_shfl(v, k); }
+template <int K> KX_DEV u32 kx_quad_bcast(u32 v) { return (u32)kxemu::arrive(kxemu::OP_QUAD, v, (u64)K); }
+KX_DEV void kx_quad_sync() { kxemu::arrive(kxemu::OP_QUAD, 0, 0); }
 KX_DEV void kx_sync() { kxemu::arrive(kxemu::OP_SYNC, 0, 0); }
 KX_DEV void kx_lockstep() { kxemu::arrive(kxemu::OP_SYNC, 1, 0); }
 
