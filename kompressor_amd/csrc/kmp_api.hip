@@ -685,9 +685,24 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
     d.pre_stage = nullptr; d.pre_seq_cap = 0; d.pre_blk = nullptr; d.pre_blk_cap = c->pre_blk_cap; d.pre_nblk = nullptr;
     d.pre_lits = nullptr; d.pre_lit_cap = 0; d.pre_lit = nullptr; d.pre_nlit = nullptr;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[4], st));
+    // one piece: both pre-decoders take their frames in order of sequence count (neighbours in size share a wave)
+    u32 decode_pieces = (n >= 8192u) ? c->knob.decode_pieces : 1u;
+    if (decode_pieces < 1u || decode_pieces > (u32)KMP_MAX_CHUNKS) decode_pieces = (u32)KMP_MAX_CHUNKS;
+    bool const sort_all = c->pre_stage && c->knob.decode_sort != 0 && n >= 1024u && decode_pieces == 1u;
+    if (sort_all) {
+        u32* const sort_key = c->pre_sort; u32* const sort_perm = c->pre_sort + c->max_slices; u32* const sort_hist = c->pre_sort + 2u * (size_t)c->max_slices;
+        HIP_TRY(hipMemsetAsync(sort_hist, 0, (size_t)KXP_SORT_BUCKETS * 4u, st));
+        KSeqSortArgs sa;
+        sa.src = d.src; sa.in_off = d_in_off; sa.in_len = d_in_len; sa.n_slices = n; sa.key = sort_key; sa.hist = sort_hist; sa.perm = sort_perm;
+        hipLaunchKernelGGL(k_zstd_seq_count, dim3((n + 255) / 256), dim3(256), 0, st, sa);
+        hipLaunchKernelGGL(k_zstd_seq_rank, dim3(1), dim3(256), 0, st, sa);
+        hipLaunchKernelGGL(k_zstd_seq_perm, dim3((n + 255) / 256), dim3(256), 0, st, sa);
+        HIP_TRY(hipGetLastError());
+    }
     if (c->pre_stage) { HIP_TRY(hipEventRecord(c->ev_pre[0], st)); HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_pre[0], 0)); }     // st2 starts where st stands: the two pre-decoders run side by side
     if (c->pre_lits) {
         KLitArgs p;
+        p.perm = sort_all ? c->pre_sort + c->max_slices : nullptr;
         p.src = d.src; p.in_off = d_in_off; p.in_len = d_in_len; p.n_slices = n;
         p.lits = c->pre_lits; p.lit_cap = c->pre_lit_cap; p.rec = c->pre_lit; p.blk_cap = c->pre_blk_cap; p.nrec = c->pre_nlit;
         hipLaunchKernelGGL(k_zstd_lit_predecode, dim3((n + KXL_FRAMES - 1) / KXL_FRAMES), dim3(64), 0, st, p);
@@ -697,11 +712,10 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
     if (c->pre_stage) {
         // The sequence pre-decoder is bound by memory transactions, the decoder by instruction issue: the batch goes through
         // in pieces, the pre-decoder (second stream) working on the pieces ahead of the one the decoder has.
-        u32 pieces = (n >= 8192u) ? c->knob.decode_pieces : 1u;
-        if (pieces < 1u || pieces > (u32)KMP_MAX_CHUNKS) pieces = (u32)KMP_MAX_CHUNKS;
+        u32 const pieces = decode_pieces;
         u32 const per = ((n + pieces - 1) / pieces + 63u) & ~63u;
         u32* const sort_key = c->pre_sort; u32* const sort_perm = c->pre_sort + c->max_slices; u32* const sort_hist = c->pre_sort + 2u * (size_t)c->max_slices;
-        bool const sorted = c->knob.decode_sort != 0 && n >= 1024u;
+        bool const sorted = c->knob.decode_sort != 0 && n >= 1024u && !sort_all;
         if (sorted) HIP_TRY(hipMemsetAsync(sort_hist, 0, (size_t)KMP_MAX_CHUNKS * KXP_SORT_BUCKETS * 4u, c->st2));
         for (u32 first = 0, pi = 0; first < n; first += per, pi++) {
             u32 const m = (n - first < per) ? n - first : per;
@@ -715,7 +729,7 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
                 HIP_TRY(hipGetLastError());
             }
             KPreArgs p;
-            p.perm = sorted ? sort_perm + first : nullptr;
+            p.perm = (sorted || sort_all) ? sort_perm + first : nullptr;
             p.src = d.src; p.in_off = d_in_off + first; p.in_len = d_in_len + first; p.n_slices = m;
             p.stage = c->pre_stage + (size_t)first * c->pre_seq_cap; p.seq_cap = c->pre_seq_cap;
             p.blk = c->pre_blk + (size_t)first * c->pre_blk_cap; p.blk_cap = c->pre_blk_cap; p.nblk = c->pre_nblk + first;

@@ -433,6 +433,7 @@ struct KLitArgs {
     u8* lits; u32 lit_cap;              // per entry: lit_cap bytes of literal staging (the literals of all blocks, back to back)
     KPreLit* rec; u32 blk_cap;          // per entry: blk_cap records (compressed blocks of the first frame, in order)
     u32* nrec;                          // per entry: records written
+    const u32* perm;                    // which entry each frame slot takes (k_zstd_seq_perm: neighbours in size share a wave), or null
 };
 
 #define KXL_FRAMES 16
@@ -547,8 +548,8 @@ KX_DEV void zstd_lit_predecode_body(const KLitArgs& a)
     int const tid = kx_lane();                                  // 64 threads
     for (u32 base = kx_block() * KXL_FRAMES; base < a.n_slices; base += kx_nblocks() * KXL_FRAMES) {
         // ---- the parsing state of lane tid < 16: frame base + tid ----
-        u32 const fa = base + (u32)tid;
-        bool const owner = tid < KXL_FRAMES && fa < a.n_slices;
+        bool const owner = tid < KXL_FRAMES && base + (u32)tid < a.n_slices;
+        u32 const fa = !owner ? 0u : a.perm ? a.perm[base + (u32)tid] : base + (u32)tid;
         const u8* srcA = a.src; u32 srcSize = 0, pos = 0, nb = 0, litUsed = 0; bool go = false, last = false;
         u32 hufLog = 0; bool hufValid = false;
         u32 covered = 0;                  // set when the frame's last block has been taken: every compressed block has a record
@@ -566,9 +567,10 @@ KX_DEV void zstd_lit_predecode_body(const KLitArgs& a)
         }
         // ---- the decoding identity of every lane: stream sB of frame base + jB ----
         int const jB = tid >> 2, sB = tid & 3;
-        u32 const fb = base + (u32)jB;
-        const u8* const srcB = fb < a.n_slices ? a.src + a.in_off[fb] : a.src;
-        u32 const srcSizeB = fb < a.n_slices ? a.in_len[fb] : 0u;
+        bool const haveB = base + (u32)jB < a.n_slices;
+        u32 const fb = !haveB ? 0u : a.perm ? a.perm[base + (u32)jB] : base + (u32)jB;
+        const u8* const srcB = haveB ? a.src + a.in_off[fb] : a.src;
+        u32 const srcSizeB = haveB ? a.in_len[fb] : 0u;
         for (;;) {
             if (tid == 0) lds.more = 0;
             if (tid < KXL_FRAMES) { lds.f[tid].valid = 0; lds.f[tid].bad = 0; lds.f[tid].treeLen = 0; }
@@ -650,7 +652,7 @@ KX_DEV void zstd_lit_predecode_body(const KLitArgs& a)
             }
             kx_sync();
             // ---- one lane per stream ----
-            if (fb < a.n_slices && lds.f[jB].valid) {
+            if (haveB && lds.f[jB].valid) {
                 KLitFrameLds& L = lds.f[jB];
                 u32 const cnt = L.cnt[sB];
                 if (cnt != 0xFFFFFFFFu) {

@@ -292,7 +292,7 @@ int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len
         plits.assign((size_t)n * plcap, 0xABu); plrec.resize((size_t)n * blk_cap); nlit.assign(n, 0u);
         KLitArgs p;
         p.src = src; p.in_off = in_off; p.in_len = in_len; p.n_slices = n;
-        p.lits = plits.data(); p.lit_cap = plcap; p.rec = plrec.data(); p.blk_cap = blk_cap; p.nrec = nlit.data();
+        p.lits = plits.data(); p.lit_cap = plcap; p.rec = plrec.data(); p.blk_cap = blk_cap; p.nrec = nlit.data(); p.perm = nullptr;
         kxemu::launch((n + KXL_FRAMES - 1) / KXL_FRAMES, [&]() { zstd_lit_predecode_body(p); });
         if (kxemu::failed) return -3;
         d.pre_lits = plits.data(); d.pre_lit_cap = plcap; d.pre_lit = plrec.data(); d.pre_nlit = nlit.data();
