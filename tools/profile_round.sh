@@ -27,6 +27,12 @@ for mode in decompress deflate; do
     timeout -k 10 300 rocprofv3 --pmc $ctr -d $d -o run -- python3 $R/bench.py --mode $mode --steps 1 --warmup 0 --no-cpu $extra > $d.out 2>> $O/log.txt || echo "pmc pass $mode $ctr failed" >> $O/log.txt
   done
 done
+# instruction mix of the decode pipeline (VERDICT r1 item 3 asks for SQ_INSTS_VALU per slice)
+for ctr in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES"; do
+  d=$O/pmc2_decompress_$(echo $ctr | tr ' ' '_' | cut -c1-30)
+  echo "== pmc decompress $ctr" >> $O/log.txt
+  timeout -k 10 300 rocprofv3 --pmc $ctr -d $d -o run -- python3 $R/bench.py --mode decompress --steps 1 --warmup 0 --no-cpu > $d.out 2>> $O/log.txt || echo "pmc pass decompress $ctr failed" >> $O/log.txt
+done
 # ... and of the other parsers: levels 1 / 2 ("fast"), the dictionary parser, the block-chain kernel (frames of several blocks)
 pmc3() { tag=$1; shift; for ctr in FETCH_SIZE WRITE_SIZE; do
     d=$O/pmc3_${tag}_$ctr; echo "== pmc $tag $ctr" >> $O/log.txt

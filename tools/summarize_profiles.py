@@ -67,7 +67,7 @@ def main():
         db = os.path.join(P, d, "run_results.db")
         if d.startswith("pmc2_") and os.path.exists(db):
             for k, c, v, n in counters(db):
-                if "k_zstd_decode" in k or "k_deflate" in k or "k_inflate" in k:
+                if "k_zstd_decode" in k or "predecode" in k or "k_deflate" in k or "k_inflate" in k:
                     other[(k.split("(")[0], c)] = (v, n)
                     lines.append(f"{k:40s} {c:24s} {v:.6g}   ({n} launches)")
     lines.append("")
@@ -97,7 +97,7 @@ def main():
               "zstd_match_write_requests_per_launch": int(allc.get((k, "TCC_EA0_WRREQ_sum"), (0, 1))[0] / nl),
               "note": "(FETCH_SIZE+WRITE_SIZE)*1024 / launches; the guide's x2 correction for wide coalesced reads is not applied: "
                       "this kernel's reads are scattered 4- and 8-byte probes (TCC_EA0_RDREQ_32B = 0, RDREQ*64 = FETCH_SIZE)"}
-        for kern in ("k_zstd_decode", "k_deflate_chains", "k_deflate_best", "k_deflate_parse", "k_deflate_encode", "k_inflate"):
+        for kern in ("k_zstd_decode", "k_zstd_seq_predecode", "k_zstd_lit_predecode", "k_deflate_chains", "k_deflate_best", "k_deflate_parse", "k_deflate_encode", "k_inflate"):
             if (kern, "FETCH_SIZE") in other and (kern, "WRITE_SIZE") in other:
                 f, nl2 = other[(kern, "FETCH_SIZE")]
                 w, _ = other[(kern, "WRITE_SIZE")]
@@ -107,7 +107,7 @@ def main():
                 f, nl3 = third[(tag, kern, "FETCH_SIZE")]
                 w, _ = third[(tag, kern, "WRITE_SIZE")]
                 pj[f"{tag}:{kern}_hbm_bytes_per_launch"] = int((f + w) * 1024 / nl3)
-        pj["note_other_kernels"] = "k_zstd_decode: 65536 frames per launch; k_deflate_* / k_inflate: 16384 slices per launch; (FETCH_SIZE+WRITE_SIZE)*1024 / launches"
+        pj["note_other_kernels"] = "k_zstd_decode / k_zstd_seq_predecode / k_zstd_lit_predecode: 65536 frames per launch; k_deflate_* / k_inflate: 16384 slices per launch; (FETCH_SIZE+WRITE_SIZE)*1024 / launches"
         json.dump(pj, open(os.path.join(outdir, "pmc_latest.json"), "w"), indent=1)
     print("\n".join(lines[:60]))
 
