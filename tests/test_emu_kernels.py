@@ -67,6 +67,22 @@ def test_emulated_decoder(G):
         assert s == 0 and helpers.sha256(o) == r["plain_sha256"], r["index"]
 
 
+def test_emulated_decoder_without_the_predecoders(G, monkeypatch):
+    """k_zstd_decode's own sequence and literal decoding (what runs for blocks the pre-decode kernels did not stage): the
+    emulator's switch KXEMU_NO_PRE leaves everything to it."""
+    monkeypatch.setenv("KXEMU_NO_PRE", "1")
+    d = G["decode_only"]
+    outs, st = helpers.emu_decompress([base64.b64decode(r["frame"]) for r in d], [r["size"] for r in d])
+    for r, o, s in zip(d, outs, st):
+        assert s == 0 and helpers.sha256(o) == r["plain_sha256"], r["index"]
+    S = 40000
+    buf = corpus.make(7100, 6, S)
+    datas = [buf[k * S:(k + 1) * S].tobytes() for k in range(6)]
+    frames = helpers.emu_compress(datas, G=8)
+    outs, st = helpers.emu_decompress(frames, [S] * 6)
+    assert st == [0] * 6 and outs == datas
+
+
 def test_emulated_decoder_rejects_bad_frames(G):
     good = base64.b64decode(next(r["frame"] for r in G["special"] if r["name"] == "ramp_64k"))
     bad_magic = b"\x00" + good[1:]

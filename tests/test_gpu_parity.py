@@ -915,9 +915,11 @@ def test_large_stream_like_the_reference_largeSample():
 
 
 def test_predecode_kernels_give_the_same_frames(monkeypatch):
-    """The two pre-decode kernels (sequences one lane per frame, literals one lane per Huffman stream; an experiment that is
-    off by default because it measured slower) must not change a byte: the golden frames, foreign-level and
-    multi-block frames, damaged frames and a multi-block batch decode identically with them switched on."""
+    """The decoder is three kernels: the two pre-decoders (sequences: four lanes per frame; literals:
+    one lane per Huffman stream) stage what k_zstd_decode then executes, and whatever they do not stage k_zstd_decode decodes
+    itself.  Every combination (KMP_DECODE_PRE = 0: everything in k_zstd_decode, 1: sequences ahead, 2: literals ahead,
+    default 3: both) must give the same bytes and the same status words: the golden frames, foreign-level and multi-block
+    frames, damaged frames and a multi-block batch."""
     from kompressor_amd.batch import ZstdBatch
     G = helpers.golden()
     S = 65536
@@ -926,8 +928,10 @@ def test_predecode_kernels_give_the_same_frames(monkeypatch):
     datas = [buf[i * S:(i + 1) * S].tobytes() for i in range(len(rows))]
     big = [d for _, d in helpers.multiblock_inputs()[20:30]]
     ref = ZstdBatch(max_slices=800, max_slice_bytes=2 << 20)
-    monkeypatch.setenv("KMP_DECODE_PRE", "3")
-    pre = ZstdBatch(max_slices=800, max_slice_bytes=2 << 20)
+    others = []
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("KMP_DECODE_PRE", mode)
+        others.append(ZstdBatch(max_slices=800, max_slice_bytes=2 << 20))
     monkeypatch.delenv("KMP_DECODE_PRE")
     try:
         frames = gpu_compress(ref, datas) + gpu_compress_kw(ref, big, reference=True)
@@ -940,12 +944,14 @@ def test_predecode_kernels_give_the_same_frames(monkeypatch):
             frames.append(bytes(f[: int(rng.integers(len(f) // 2, len(f) + 1))]) if k % 3 == 0 else bytes(f))
         caps = [2 << 20] * len(frames)
         a, sa = gpu_decompress(ref, frames, caps)
-        b, sb = gpu_decompress(pre, frames, caps)
-        assert sa == sb and a == b
         assert a[: len(datas)] == datas and a[len(datas): len(datas) + len(big)] == big
+        for mode, ctx in zip("012", others):
+            b, sb = gpu_decompress(ctx, frames, caps)
+            assert sa == sb and a == b, f"KMP_DECODE_PRE={mode}"
     finally:
         ref.close()
-        pre.close()
+        for ctx in others:
+            ctx.close()
 
 
 @pytest.mark.timeout(600)
