@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 K=$1; shift
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_k; rm -rf $O; mkdir -p $O
-for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM"; do
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU"; do
   d=$O/$(echo $grp | tr ' ' '_' | cut -c1-30)
   timeout -k 10 300 rocprofv3 --pmc $grp -d $d -o run -- python3 $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu > $d.out 2>$d.err || echo "pass $grp failed"
 done
