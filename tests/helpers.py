@@ -354,6 +354,23 @@ def deflate_golden():
         return json.load(fh)
 
 
+def foreign_frames():
+    """Frames of other zstd settings than the product's own (tests/golden/make_foreign_frames.py): [(row, frame, plain)]."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_foreign_frames import plain_of
+    g = os.path.join(ROOT, "tests", "golden")
+    meta = json.load(open(os.path.join(g, "foreign_frames.json")))
+    blob = open(os.path.join(g, "foreign_frames.bin"), "rb").read()
+    assert sha256(blob) == meta["blob_sha256"]
+    out = []
+    for r in meta["rows"]:
+        plain = plain_of(r)
+        assert sha256(plain) == r["plain_sha256"], r          # the corpus generator still makes the bytes the frame was made of
+        out.append((r, blob[r["off"]: r["off"] + r["len"]], plain))
+    return out
+
+
 def live_libzstd():
     """A libzstd 1.5.7 found on this machine, or None (never required)."""
     import sys

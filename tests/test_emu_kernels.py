@@ -83,6 +83,21 @@ def test_emulated_decoder_without_the_predecoders(G, monkeypatch):
     assert st == [0] * 6 and outs == datas
 
 
+def test_emulated_decoder_takes_frames_of_other_settings(monkeypatch):
+    """A third of tests/golden/foreign_frames.* (levels 1 .. 22, checksum, large window, runs and periods) through the three
+    decode kernels on the emulator, and a few of them through k_zstd_decode alone."""
+    rows = helpers.foreign_frames()
+    pick = [x for i, x in enumerate(rows) if i % 3 == 0 or x[0]["kind"] != "corpus"]
+    outs, st = helpers.emu_decompress([f for _, f, _ in pick], [len(p) for _, _, p in pick])
+    for (r, _, plain), o, s_ in zip(pick, outs, st):
+        assert s_ == 0 and o == plain, (r["level"], r.get("cls"), r["size"])
+    monkeypatch.setenv("KXEMU_NO_PRE", "1")
+    few = pick[::6]
+    outs, st = helpers.emu_decompress([f for _, f, _ in few], [len(p) for _, _, p in few])
+    for (r, _, plain), o, s_ in zip(few, outs, st):
+        assert s_ == 0 and o == plain, (r["level"], r.get("cls"), r["size"])
+
+
 def test_emulated_decoder_rejects_bad_frames(G):
     good = base64.b64decode(next(r["frame"] for r in G["special"] if r["name"] == "ramp_64k"))
     bad_magic = b"\x00" + good[1:]

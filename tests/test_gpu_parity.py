@@ -914,6 +914,19 @@ def test_large_stream_like_the_reference_largeSample():
     assert hashlib.sha256(ZstdDecompressor().transform_bytes(f)).digest() == hashlib.sha256(d).digest()
 
 
+def test_frames_of_other_encoder_settings_decode(batch):
+    """ZstdDecompressor takes what any zstd encoder made: 104 frames libzstd 1.5.7 produced at levels 1 .. 22, with a content
+    checksum, with a window larger than the content, of long runs and of short periods (tests/golden/foreign_frames.*:
+    Huffman trees of every depth, single-stream literals, RLE / predefined / repeat sequence tables, offsets the
+    pre-decoder takes in two containers).  Decoded in one batch, twice: with exact capacities and with room to spare."""
+    rows = helpers.foreign_frames()
+    frames = [f for _, f, _ in rows]
+    for slack in (0, 777):
+        outs, st = gpu_decompress(batch, frames, [len(p) + slack for _, _, p in rows])
+        for (r, _, plain), o, s_ in zip(rows, outs, st):
+            assert s_ == 0 and o == plain, (r["level"], r.get("cls"), r["size"], r["extra"])
+
+
 def test_predecode_kernels_give_the_same_frames(monkeypatch):
     """The decoder is three kernels: the two pre-decoders (sequences: four lanes per frame; literals:
     one lane per Huffman stream) stage what k_zstd_decode then executes, and whatever they do not stage k_zstd_decode decodes
