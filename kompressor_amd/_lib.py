@@ -72,6 +72,14 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m kompressor_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch ships its own ROCm runtime (torch/lib/libamdhip64.so).  Two HIP runtimes in one process do not share devices:
+    # if this library pulled in /opt/rocm's copy first, torch would come up later with its own and kmp_batch_create
+    # would find "no ROCm-capable device".  So when torch is importable it is loaded first and this library binds to
+    # the runtime already in the process (same soname); without torch (a C caller's process) /opt/rocm's is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, res, args in SIGNATURES:
         fn = getattr(lib, name)          # AttributeError if the export is missing
