@@ -67,7 +67,7 @@ KMP_API size_t kmp_zstd_cctx_load_dictionary(kmp_zstd_cctx* cctx, const void* di
  * the caller's memory is compressed in place (ZSTD_compress2's frame); otherwise -- the reference's driver, whose output
  * slices hold max(8192, n / 10) bytes -- the input is staged in chunks of 128 KiB (kmp_zstd_compress_batch_reference),
  * and data that arrived with e_continue makes it a streaming frame (no content size).  Input is collected until e_end;
- * streams up to 1 GiB (level 1: 512 KiB, level 2: 128 KiB one-shot). */
+ * streams up to 1 GiB (levels 1 and 2: their windows, 512 KiB and 1 MiB). */
 KMP_API size_t kmp_zstd_compress_stream(kmp_zstd_cctx* cctx,
                                         void* dst, size_t dst_size, size_t* dst_pos,
                                         const void* src, size_t src_size, size_t* src_pos,

@@ -71,13 +71,13 @@ class ZstdBatch:
     def compress(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, dictionary=None, level=3, streaming=None, reference=False):
         """src: uint8 device tensor; in_off int64, in_len int32 device tensors (n each).  dictionary: bytes of a
         raw-content dictionary shared by all slices (host memory; its tables are built once per dictionary).
-        level: 3 (default), or 1 / 2 for slices of at most 128 KiB without a dictionary; level 1 also for slices up to
-        512 KiB (context created for slice sizes in (128 KiB, 512 KiB]).
+        level: 3 (default), or 1 / 2 without a dictionary: slices up to the level's window (512 KiB / 1 MiB; above 128 KiB
+        the context must have been created for slice sizes in (128 KiB, 512 KiB] / (128 KiB, 1 MiB]).
         streaming: None = one-shot frames; "data" / "empty" = the frames of slices that arrived through finish = false
-        calls, closed by a call with / without data (context created for slices above 128 KiB; levels 3 and 1).
+        calls, closed by a call with / without data (context created for slices above 128 KiB; levels 1 to 3).
         reference: the frames ZstdCompressor(level).transform(bytes) returns -- above 128 KiB the reference's output slices
         make libzstd stage the input in 128 KiB chunks, so they differ from ZSTD_compress2's (the default here) wherever
-        the block pre-splitter cuts (levels 3 and 1, no dictionary); up to 128 KiB both are the same.
+        the block pre-splitter cuts (no dictionary); up to 128 KiB both are the same.
         Returns (dst, out_off, out_len): frame i = dst[out_off[i] : out_off[i] + out_len[i]]."""
         n = in_len.numel()
         if dst is None:

@@ -359,9 +359,9 @@ extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
     if (c->big) {
-        // frames of several blocks: level 1 only, slices up to its 512 KiB window
-        if (level != 1 || c->max_slice_bytes > (512u << 10)) { g_last_error = "kmp_zstd_compress_batch_level: above 128 KiB level 1 is served for slices up to 512 KiB (context max_slice_bytes <= 512 KiB)"; return KMP_ERR_CAPACITY; }
-        return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st, 0, 1);
+        // frames of several blocks: slices up to the level's window (512 KiB at level 1, 1 MiB at level 2)
+        if (c->max_slice_bytes > ((level == 1 ? 512u : 1024u) << 10)) { g_last_error = "kmp_zstd_compress_batch_level: above 128 KiB levels 1 and 2 are served for slices up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
+        return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st, 0, (u32)level);
     }
     KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
     HIP_TRY(hipMemsetAsync(c->counter, 0, 4, st));
@@ -464,7 +464,9 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     d_in_len = c->len_ok;
     HIP_TRY(hipMemsetAsync(c->big_tables, 0, (size_t)n * KX_BIG_TBL_ENTRIES * sizeof(u32), st));
     HIP_TRY(hipMemsetAsync(c->remaining, 0, 4, st));
-    hipLaunchKernelGGL(k_zstd_frame_init, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, c->fstate, (u8*)d_dst, d_out_off, d_out_len, c->remaining, streaming ? (strategy ? 0x48u : 0x58u) : 0u, stream != 0 ? 1u : 0u);
+    // strategy: 0 level 3 (double-fast), 1 level 1 (fast), 2 level 2 (fast, but double-fast for 128 KiB < size <= 256 KiB when the size is known)
+    u32 const level2 = strategy == 2u ? 1u : 0u;
+    hipLaunchKernelGGL(k_zstd_frame_init, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, c->fstate, (u8*)d_dst, d_out_off, d_out_len, c->remaining, streaming ? (strategy == 1u ? 0x48u : strategy == 2u ? 0x50u : 0x58u) : 0u, stream != 0 ? 1u : 0u);
     HIP_TRY(hipGetLastError());
     KMatchArgs m;
     m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
@@ -477,7 +479,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
     e.scratch = c->scratch; e.scratch_words = c->scratch_words;
     e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
-    e.fstate = c->fstate; e.hufct = c->hufct; e.remaining = c->remaining; e.stream = stream; e.strategy = strategy;
+    e.fstate = c->fstate; e.hufct = c->hufct; e.remaining = c->remaining; e.stream = stream; e.strategy = strategy ? 1u : 0u; e.level2 = level2; e.cls = 0;
     e.tail_direct = stream == 3 ? 0u : tail_direct; e.out_chunk = stream == 3 ? tail_direct : 0u;      // (one parameter: the mode says which it is)
     if (strategy || c->knob.big_rounds == 0) {
         // one wave per slice walks its chain of blocks
@@ -492,6 +494,21 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
         g.spw = spw;
         u32 const grid = (n + spw - 1) / spw;
         HIP_TRY(hipMemsetAsync(c->big_counters, 0, (size_t)n * 4, st));
+        if (level2 && !streaming) {
+            // level 2, sizes known: the slices of its double-fast row first (class 1), the others (class 2) through the fast parser below
+            g.e.strategy = 0; g.e.cls = 1; g.m.flags = m.flags | 32u | (1u << 6);
+            switch (bigG) {
+            case 2:  hipLaunchKernelGGL(k_zstd_big<2>, dim3(grid), dim3(64), 0, st, g); break;
+            case 4:  hipLaunchKernelGGL(k_zstd_big<4>, dim3(grid), dim3(64), 0, st, g); break;
+            case 8:  hipLaunchKernelGGL(k_zstd_big<8>, dim3(grid), dim3(64), 0, st, g); break;
+            case 16: hipLaunchKernelGGL(k_zstd_big<16>, dim3(grid), dim3(64), 0, st, g); break;
+            case 32: hipLaunchKernelGGL(k_zstd_big<32>, dim3(grid), dim3(64), 0, st, g); break;
+            default: hipLaunchKernelGGL(k_zstd_big<64>, dim3(grid), dim3(64), 0, st, g); break;
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemsetAsync(c->big_counters, 0, (size_t)n * 4, st));
+            g.e.strategy = 1; g.e.cls = 2; g.m.flags = m.flags | (2u << 6);
+        }
         if (strategy) switch (bigG) {
         case 2:  hipLaunchKernelGGL(k_zstd_big_fast<2>, dim3(grid), dim3(64), 0, st, g); break;
         case 4:  hipLaunchKernelGGL(k_zstd_big_fast<4>, dim3(grid), dim3(64), 0, st, g); break;
@@ -547,19 +564,19 @@ extern "C" int kmp_zstd_compress_batch_stream_level(kmp_batch_ctx* c, const void
 extern "C" int kmp_zstd_compress_batch_stream(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                               uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int empty_end, void* hip_stream)
 { return kmp_zstd_compress_batch_stream_level(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, empty_end, 3, hip_stream); }
-/* level 3 (streams <= 2 MiB) or level 1 (the Ktor encoder's: streams <= 512 KiB, its window) */
+/* level 3, or level 1 (the Ktor encoder's: streams <= 512 KiB, its window) or level 2 (<= 1 MiB) */
 extern "C" int kmp_zstd_compress_batch_stream_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                                     uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int empty_end, int level, void* hip_stream)
 {
     if (level == 0) level = 3;
-    if (level != 1 && level != 3) { g_last_error = "kmp_zstd_compress_batch_stream_level: levels 1 and 3 are served"; return KMP_ERR_ARG; }
-    if (c && level == 1 && c->max_slice_bytes > (512u << 10)) { g_last_error = "kmp_zstd_compress_batch_stream_level: level 1 streams up to 512 KiB (context max_slice_bytes <= 512 KiB)"; return KMP_ERR_CAPACITY; }
+    if (level < 1 || level > 3) { g_last_error = "kmp_zstd_compress_batch_stream_level: levels 1, 2 and 3 are served"; return KMP_ERR_ARG; }
+    if (c && level != 3 && c->max_slice_bytes > ((level == 1 ? 512u : 1024u) << 10)) { g_last_error = "kmp_zstd_compress_batch_stream_level: level 1 / 2 streams up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_stream: null argument"; return KMP_ERR_ARG; }
     if (!c->big) { g_last_error = "kmp_zstd_compress_batch_stream: the context must be created with max_slice_bytes above 128 KiB"; return KMP_ERR_CAPACITY; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_stream: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, empty_end ? 2u : 1u, level == 1 ? 1u : 0u);
+    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, empty_end ? 2u : 1u, level == 3 ? 0u : (u32)level);
 }
 /* What ZstdCompressor(level).transform(ByteArray) returns: above 128 KiB libzstd stages the input in chunks of 128 KiB
  * because the reference's output slices are smaller than ZSTD_compressBound (include/kompressor_hip.h). */
@@ -569,13 +586,13 @@ extern "C" int kmp_zstd_compress_batch_reference(kmp_batch_ctx* c, const void* d
     if (level == 0) level = 3;
     if (!c) { g_last_error = "kmp_zstd_compress_batch_reference: null argument"; return KMP_ERR_ARG; }
     if (!c->big) return kmp_zstd_compress_batch_level(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, level, hip_stream);   // one block: one chunk
-    if (level != 1 && level != 3) { g_last_error = "kmp_zstd_compress_batch_reference: above 128 KiB levels 1 and 3 are served"; return KMP_ERR_ARG; }
-    if (level == 1 && c->max_slice_bytes > (512u << 10)) { g_last_error = "kmp_zstd_compress_batch_reference: level 1 up to 512 KiB (context max_slice_bytes <= 512 KiB)"; return KMP_ERR_CAPACITY; }
+    if (level < 1 || level > 3) { g_last_error = "kmp_zstd_compress_batch_reference: levels 1, 2 and 3 are served"; return KMP_ERR_ARG; }
+    if (level != 3 && c->max_slice_bytes > ((level == 1 ? 512u : 1024u) << 10)) { g_last_error = "kmp_zstd_compress_batch_reference: levels 1 / 2 up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
     if (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len)) { g_last_error = "kmp_zstd_compress_batch_reference: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_reference: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, 3u, level == 1 ? 1u : 0u, out_chunk);
+    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, 3u, level == 3 ? 0u : (u32)level, out_chunk);
 }
 /* block rounds of the last batch of a context for slices above 128 KiB */
 extern "C" int kmp_batch_last_rounds(kmp_batch_ctx* c) { return c ? (int)c->last_rounds : 0; }
@@ -1037,11 +1054,12 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
         size_t const lap = 17u * (size_t)KX_BLOCK_MAX;                  // level-3 stream: window 2 MiB + one block
         if (c->level == 3 && (n - end_avail) % lap == 0) tail_direct = (u32)end_avail;
     }
-    if (streaming && (c->level == 2 || !c->dict.empty())) return KERRC(ZE_parameter_unsupported);
-    bool const l1big = c->level == 1 && (streaming || n > KMP_MAX_SLICE_BYTES);      // level 1, frame of several blocks / stream
-    if (l1big && n > (512u << 10)) return KERRC(ZE_parameter_unsupported);             // beyond its window: CPU library
+    if (streaming && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
+    bool const l1big = c->level != 3 && (streaming || n > KMP_MAX_SLICE_BYTES);      // level 1 / 2, frame of several blocks / stream
+    u32 const lwin = (c->level == 1 ? 512u : 1024u) << 10;                             // their windows
+    if (l1big && n > lwin) return KERRC(ZE_parameter_unsupported);                     // beyond the window: CPU library
     if (!stream_dev_select(c->dev)) return KERRC(ZE_GENERIC);
-    { size_t const e = stream_dev_init(c->dev, streaming && n <= KMP_MAX_SLICE_BYTES ? KMP_MAX_SLICE_BYTES + 1 : n, l1big ? (512u << 10) : 0u); if (e) return e; }
+    { size_t const e = stream_dev_init(c->dev, streaming && n <= KMP_MAX_SLICE_BYTES ? KMP_MAX_SLICE_BYTES + 1 : n, l1big ? lwin : 0u); if (e) return e; }
     stream_dev& s = c->dev;
     u64 offs[2] = { 0, 0 }; u32 len = (u32)n, olen = 0;
     if (n && hipMemcpy(s.d_in, c->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
@@ -1058,7 +1076,7 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
         if (kmp_zstd_compress_batch_reference(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->level, (u32)first_room, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
     } else
     if (c->level != 3) {
-        if ((n > KMP_MAX_SLICE_BYTES && !l1big) || !c->dict.empty()) return KERRC(ZE_parameter_unsupported);   // level 2: one block; no dictionary
+        if (!c->dict.empty()) return KERRC(ZE_parameter_unsupported);   // levels 1 / 2: no dictionary
         if (kmp_zstd_compress_batch_level(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->level, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
     } else
     if (!c->dict.empty()) {

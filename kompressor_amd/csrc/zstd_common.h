@@ -104,6 +104,12 @@ KX_DEV KParams kx_params_l3(u32 n)
     return p;
 }
 
+// Level 2 has one double-fast row: sizes above 128 KiB up to 256 KiB (window 18, chain 14, hash 14, minMatch 5); its other
+// rows are "fast" ones (zstd_match_fast.h).  A batch at level 2 therefore goes through both block-chain kernels, each
+// taking the slices of its class (KFrameArgs.cls: 0 every slice, 1 only that size class, 2 only the others).
+KX_DEV KParams kx_params_l2_dfast() { KParams p; p.windowLog = 18; p.chainLog = 14; p.hashLog = 14; p.minMatch = 5; return p; }
+KX_DEV bool kx_in_class(u32 cls, u32 n) { return cls == 0u || ((n > 131072u && n <= 262144u) == (cls == 1u)); }
+
 KX_DEV u32 kx_frame_header_size(u32 n)
 {
     // magic(4) + FHD(1) + FCS; single segment while the window (2 MiB at most, level 3) covers the content, else a window

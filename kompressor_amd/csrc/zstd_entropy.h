@@ -1044,7 +1044,9 @@ struct KFrameArgs {
     u8* dst; const u64* out_off; u32* out_len;
     KFrameState* fstate; u32* hufct;         // per slice: state, two Huffman table slots of 256 words
     u32* remaining;                          // frames not finished yet (decremented here)
-    u32 strategy;                            // 0: level 3 (double-fast); 1: level 1 (fast): other pre-splitter, other encoding-type constant, window 2^19
+    u32 strategy;                            // 0: double-fast (level 3; level 2's 128 .. 256 KiB row); 1: fast (levels 1, 2): other pre-splitter, other encoding-type constant
+    u32 level2;                              // 1: level 2's parameters (window 2^20 / 2^18 instead of 2^19 / level 3's)
+    u32 cls;                                 // which slices this launch takes (kx_in_class): a level-2 batch goes through both kernels
     u32 stream;                              // 0: one-shot frames as ZSTD_compress2 writes them into a bound-sized buffer (size known, the
                                              // caller's array compressed in place); 1: streaming frames (finish = false ... finish = true:
                                              // no content size, window 2^21, input taken in chunks of 128 KiB); 2: same, and the
@@ -1176,7 +1178,7 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
     bool const emptyEnd = a.stream == 2 && (n % KX_BLOCK_MAX) == 0;
     if (fs.ipos == 0 && streaming) {
         // streaming frame header: no content size, window descriptor for 2^21
-        if (lane == 0) { kx_st32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)(((a.strategy ? 19 : 21) - 10) << 3); }
+        if (lane == 0) { kx_st32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)(((a.strategy ? (a.level2 ? 20 : 19) : 21) - 10) << 3); }
         fs.opos = 6;
     } else if (fs.ipos == 0) {
         // frame header: content size; single segment while the window covers the slice
@@ -1237,7 +1239,7 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
     if (a.stream && fs.ipos == KX_BLOCK_MAX) fs.savings -= streaming ? 6 : (int)kx_frame_header_size(n);
     if (fs.ipos < n) {
         // (level 1 is served up to its window: nothing slides there)
-        u32 const windowLog = a.strategy ? 30u : (streaming ? 21u : kx_params_l3(n).windowLog);
+        u32 const windowLog = a.strategy ? 30u : (streaming ? 21u : a.level2 ? 18u : kx_params_l3(n).windowLog);
         u32 const remaining = kx_frame_window_step(fs, n, a.stream, windowLog, a.tail_direct, a.out_chunk);
         if (remaining < KX_BLOCK_MAX) next = remaining;
         else if (fs.savings < 3) next = KX_BLOCK_MAX;
@@ -1287,11 +1289,11 @@ KX_DEV void zstd_big_body(const KBigArgs& a)
         m.counter = a.counters + kx_block();
         for (u32 guard = 0; guard < KX_MAX_BIG_SLICE / 64u; guard++) {         // (a block is at least 8 KiB unless it ends a chunk)
             bool open = false;
-            for (u32 t = 0; t < cnt; t++) open |= a.e.fstate[base + t].blockSize != 0;
+            for (u32 t = 0; t < cnt; t++) open |= a.e.fstate[base + t].blockSize != 0 && kx_in_class(a.e.cls, a.e.in_len[base + t]);
             if (!open) break;
             if (lane == 0) *m.counter = 0;
             kx_sync();
-            if (FAST) { KFastArgs fa; fa.m = m; fa.level = 1; zstd_match_fast_body<G, true>(fa); }
+            if (FAST) { KFastArgs fa; fa.m = m; fa.level = a.e.level2 ? 2u : 1u; zstd_match_fast_body<G, true>(fa); }
             else {
                 zstd_match_body<G, true>(m);
                 // blocks behind a wrap of libzstd's staging buffer: the extDict variant of the parse
@@ -1308,7 +1310,7 @@ KX_DEV void zstd_big_body(const KBigArgs& a)
                 }
             }
             kx_sync();
-            for (u32 t = 0; t < cnt; t++) { zstd_frame_block(a.e, lds, base + t, lane); kx_sync(); }
+            for (u32 t = 0; t < cnt; t++) { if (kx_in_class(a.e.cls, a.e.in_len[base + t])) zstd_frame_block(a.e, lds, base + t, lane); kx_sync(); }
         }
     }
 }

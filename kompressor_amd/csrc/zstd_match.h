@@ -166,11 +166,11 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 if (s >= a.n_slices) state = KST_DONE;
                 else if (BLK) {
                     KFrameState const fs = a.fstate[s];
-                    KParams P0 = kx_params_l3(a.in_len[s]);
+                    KParams P0 = (a.flags & 32u) ? kx_params_l2_dfast() : kx_params_l3(a.in_len[s]);          // (flags bit 5: level 2's double-fast row)
                     if (a.flags & 8u) { P0.windowLog = 21; P0.chainLog = 16; P0.hashLog = 17; P0.minMatch = 5; }   // streaming frame: size unknown when it starts
                     KBlockWin const bw = kx_block_window(fs.lowLimit, fs.dictLimit, fs.ipos, fs.blockSize, P0.windowLog);
                     // (a block that libzstd parses with the extDict variant is left to zstd_match_ext_body)
-                    if (fs.blockSize != 0 && !bw.ext) {           // else: frame finished, fetch the next slice
+                    if (fs.blockSize != 0 && !bw.ext && kx_in_class((a.flags >> 6) & 3u, a.in_len[s])) {           // else: frame finished (or not this launch's), fetch the next slice
                         slice = s;
                         src = a.src + a.in_off[s];
                         seqs = a.seqs + (size_t)s * a.seq_cap; lits = a.lits + (size_t)s * a.lit_cap;

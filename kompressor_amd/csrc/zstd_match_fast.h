@@ -18,7 +18,8 @@ KX_DEV void kx_params_fast(u32 level, u32 n, u32& hashLog, u32& mml)
         if (n <= 16384) { W = 14; hashLog = 15; mml = 5; } else if (n <= 131072) { W = 17; hashLog = 13; mml = 6; }
         else if (n <= 262144) { W = 18; hashLog = 14; mml = 6; } else { W = 19; hashLog = 14; mml = 7; }
     } else {
-        if (n <= 16384) { W = 14; hashLog = 15; mml = 4; } else { W = 17; hashLog = 15; mml = 5; }
+        if (n <= 16384) { W = 14; hashLog = 15; mml = 4; } else if (n <= 131072) { W = 17; hashLog = 15; mml = 5; }
+        else { W = 20; hashLog = 16; mml = 6; }         // (128 KiB < n <= 256 KiB is a double-fast row: kx_params_l2_dfast)
     }
     u32 const srcLog = (n < 64) ? 6 : kx_hb32(n - 1) + 1;
     if (W > srcLog) W = srcLog;
@@ -70,13 +71,13 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                 if (s >= a.n_slices) state = KFS_DONE;
                 else if (BLK) {
                     KFrameState const fs = a.fstate[s];
-                    if (fs.blockSize != 0) {
+                    if (fs.blockSize != 0 && kx_in_class((a.flags >> 6) & 3u, a.in_len[s])) {
                         slice = s;
                         src = a.src + a.in_off[s];
                         seqs = a.seqs + (size_t)s * a.seq_cap;
                         H = a.big_tables + (size_t)s * KX_BIG_TBL_ENTRIES;
                         kx_params_fast(f.level, a.in_len[s], hlog, mls);
-                        if (a.flags & 8u) { hlog = 14; mls = 7; }              // level 1, size unknown: window 19, hash 14, minMatch 7
+                        if (a.flags & 8u) { hlog = f.level == 2 ? 16 : 14; mls = f.level == 2 ? 6 : 7; }      // size unknown: level 1 window 19, hash 14, minMatch 7; level 2 window 20, hash 16, minMatch 6
                         nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = 0; tag = 0;
                         bstart = (int)fs.ipos; n = bstart + (int)fs.blockSize;   // n = end of the block
                         anchor = bstart; ilimit = n - 8;

@@ -1949,8 +1949,16 @@ KREF_API size_t kref_zstd_l3_compress_stream(u8* dst, size_t cap, const u8* src,
 /* ================================================================== */
 typedef struct { u32 lowLimit, dictLimit; } kref_window;
 
+static size_t dfast_compress_buffered(u8* dst, size_t cap, const u8* src, size_t srcSize, int knownSize, int emptyEnd,
+                                      size_t outChunk, size_t tailDirect, const u32* Pknown);
 KREF_API size_t kref_zstd_l3_compress_buffered(u8* dst, size_t cap, const u8* src, size_t srcSize, int knownSize, int emptyEnd,
                                                size_t outChunk, size_t tailDirect)
+{ return dfast_compress_buffered(dst, cap, src, srcSize, knownSize, emptyEnd, outChunk, tailDirect, NULL); }
+
+/* Pknown: the parameters of a frame whose size is known, when they are not level 3's (level 2 has a double-fast row for
+ * 128 KiB < size <= 256 KiB: kref_zstd_fast_compress_big) */
+static size_t dfast_compress_buffered(u8* dst, size_t cap, const u8* src, size_t srcSize, int knownSize, int emptyEnd,
+                                      size_t outChunk, size_t tailDirect, const u32* Pknown)
 {
     int tail = 0;
     u32 P[4]; kref_wksp w; kref_frame_state fs; size_t pos, ipos = 0, hdr; int64_t savings = 0;
@@ -1958,7 +1966,7 @@ KREF_API size_t kref_zstd_l3_compress_buffered(u8* dst, size_t cap, const u8* sr
     kref_window win; size_t windowSize, inBuffSize, bufPos = 0, extBase = 0; u32 maxDist; int haveExt = 0;
     if (srcSize >= 0xF0000000u) return KERR;
     if (cap < kref_compress_bound(srcSize) + 16) return KERR;
-    if (knownSize) { kref_params_l3(srcSize, P); pos = write_frame_header(dst, srcSize, P[0]); emptyEnd = 0; }
+    if (knownSize) { if (Pknown) memcpy(P, Pknown, sizeof(P)); else kref_params_l3(srcSize, P); pos = write_frame_header(dst, srcSize, P[0]); emptyEnd = 0; }
     else { P[0] = 21; P[1] = 16; P[2] = 17; P[3] = 5; wr32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)((P[0] - 10) << 3); pos = 6; }
     hdr = pos;
     if (knownSize && srcSize == 0) { wr24(dst + pos, 1); return pos + 3; }
@@ -2079,9 +2087,9 @@ KREF_API size_t kref_zstd_fast_compress_big(u8* dst, size_t cap, const u8* src, 
     int const chunked = stream != 0, unknown = stream == 1 || stream == 2;
     if (level != 1 && level != 2) return KERR;
     if (level == 2 && !unknown && srcSize > 131072 && srcSize <= 262144) {
-        if (stream == 3) return KERR;
         /* level 2's row for this size class is a double-fast one: window 18, chain 14, hash 14, minMatch 5 */
         u32 const Pd[4] = { 18, 14, 14, 5 };
+        if (stream == 3) return dfast_compress_buffered(dst, cap, src, srcSize, 1, 0, srcSize / 10 > 8192 ? srcSize / 10 : 8192, 0, Pd);
         return compress_blocks_dfast(dst, cap, src, srcSize, NULL, NULL, Pd);
     }
     if (unknown) { P[0] = (level == 1) ? 19 : 20; P[2] = (level == 1) ? 14 : 16; P[3] = (level == 1) ? 7 : 6; }

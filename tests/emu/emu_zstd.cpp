@@ -159,7 +159,8 @@ extern "C" __attribute__((visibility("default")))
 int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
                               u8* dst, const u64* out_off, u32* out_len, u32* rounds_out, u32 stream_and_strategy, u32 tail_or_chunk, u32 wide)
 {
-    u32 const stream = stream_and_strategy & 0xFFu, strategy = stream_and_strategy >> 8;     // strategy 1: level 1 (fast)
+    u32 const stream = stream_and_strategy & 0xFFu, strategy = stream_and_strategy >> 8;     // strategy 1: level 1 (fast); 2: level 2 (as zstd_compress_big in kmp_api.hip)
+    u32 const level2 = strategy == 2u ? 1u : 0u;
     bool const streaming = stream == 1 || stream == 2;
     u32 const block_cap = 128u * 1024u;
     u32 const seq_cap = (block_cap / 4 + 8 + 15) & ~15u, lit_cap = block_cap + 64, scratch_words = block_cap / 4 + 64;
@@ -176,7 +177,7 @@ int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_le
         s.blockSize = in_len[i] < KX_BLOCK_MAX ? in_len[i] : KX_BLOCK_MAX; s.first = 1; s.rep[0] = 1; s.rep[1] = 4; s.rep[2] = 8;
         s.lowLimit = 2; s.dictLimit = 2; s.chunkEnd = (stream != 0 && in_len[i] > KX_BLOCK_MAX) ? KX_BLOCK_MAX : in_len[i];
         fstate[i] = s;
-        if (in_len[i] == 0) { u8* d = dst + out_off[i]; u32 const magic = 0xFD2FB528u; memcpy(d, &magic, 4); d[4] = streaming ? 0x00 : 0x20; d[5] = streaming ? (strategy ? 0x48 : 0x58) : 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
+        if (in_len[i] == 0) { u8* d = dst + out_off[i]; u32 const magic = 0xFD2FB528u; memcpy(d, &magic, 4); d[4] = streaming ? 0x00 : 0x20; d[5] = streaming ? (strategy == 1u ? 0x48 : strategy == 2u ? 0x50 : 0x58) : 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
         else remaining++;
     }
     KMatchArgs m;
@@ -189,7 +190,7 @@ int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_le
     e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
     e.scratch = scratch.data(); e.scratch_words = scratch_words;
     e.dst = dst; e.out_off = out_off; e.out_len = out_len;
-    e.fstate = fstate.data(); e.hufct = hufct.data(); e.remaining = &remaining; e.stream = stream; e.strategy = strategy;
+    e.fstate = fstate.data(); e.hufct = hufct.data(); e.remaining = &remaining; e.stream = stream; e.strategy = strategy ? 1u : 0u; e.level2 = level2; e.cls = 0;
     e.tail_direct = stream == 3 ? 0u : tail_or_chunk; e.out_chunk = stream == 3 ? tail_or_chunk : 0u;
     if (strategy && rounds_out) return -6;
     if (!rounds_out) {
@@ -197,6 +198,22 @@ int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_le
         std::vector<u32> counters(nblocks, 0u);
         KBigArgs g; g.m = m; g.e = e; g.counters = counters.data(); g.spw = (n > 2 && 64 / G >= 2) ? 2 : 1;
         kxemu::failed = 0;
+        if (level2 && !streaming) {
+            // level 2, sizes known: the slices of its double-fast row first (class 1), the others (class 2) through the fast parser below
+            g.e.strategy = 0; g.e.cls = 1; g.m.flags = m.flags | 32u | (1u << 6);
+            switch (G) {
+            case 2:  kxemu::launch(nblocks, [&]() { zstd_big_body<2>(g); }); break;
+            case 4:  kxemu::launch(nblocks, [&]() { zstd_big_body<4>(g); }); break;
+            case 8:  kxemu::launch(nblocks, [&]() { zstd_big_body<8>(g); }); break;
+            case 16: kxemu::launch(nblocks, [&]() { zstd_big_body<16>(g); }); break;
+            case 32: kxemu::launch(nblocks, [&]() { zstd_big_body<32>(g); }); break;
+            case 64: kxemu::launch(nblocks, [&]() { zstd_big_body<64>(g); }); break;
+            default: return -2;
+            }
+            if (kxemu::failed) return -1;
+            for (auto& x : counters) x = 0;
+            g.e.strategy = 1; g.e.cls = 2; g.m.flags = m.flags | (2u << 6);
+        }
         if (strategy) switch (G) {
         case 2:  kxemu::launch(nblocks, [&]() { zstd_big_body<2, true>(g); }); break;
         case 4:  kxemu::launch(nblocks, [&]() { zstd_big_body<4, true>(g); }); break;
@@ -216,7 +233,8 @@ int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_le
         default: return -2;
         }
         if (kxemu::failed) return -1;
-        return remaining == 0 ? 0 : -5;
+        for (u32 i = 0; i < n; i++) if (fstate[i].blockSize != 0) return -5;
+        return 0;
     }
     u32 rounds = 0;
     while (remaining != 0) {

@@ -231,6 +231,31 @@ def test_emulated_level1_multiblock_and_streams():
     assert n >= 6
 
 
+def test_emulated_level2_multiblock_and_streams():
+    """Level 2 above 128 KiB: a batch goes through both block-chain kernels (the double-fast one takes the slices of 128 KiB <
+    size <= 256 KiB, the fast one the others); both framings and streams against libzstd 1.5.7 (the smaller vectors; the GPU
+    suite runs all)."""
+    G = helpers.level2_big_golden()
+    ins = dict(helpers.multiblock_inputs())
+    rows = [r for r in G["multiblock"] if r[1] <= 300000][:8] + [r for r in G["multiblock"] if 300000 < r[1] <= 600000][:2]
+    assert any(131072 < r[1] <= 262144 for r in rows) and any(r[1] > 262144 for r in rows)
+    datas = [ins[r[0]] for r in rows]
+    f0 = helpers.emu_compress_big(datas, G=8, nblocks=2, level=2)[0]
+    f3 = helpers.emu_compress_big(datas, G=16, nblocks=2, level=2, stream=3)[0]
+    for (name, n, l0, s0, l3, s3), a, b in zip(rows, f0, f3):
+        assert (len(a), helpers.sha256(a)) == (l0, s0) and (len(b), helpers.sha256(b)) == (l3, s3), name
+    cases = [(d, cuts) for d, cuts in helpers.stream_cases() if len(d) <= 1024 * 1024]
+    n = 0
+    for (d, cuts), (size, fed, flen, sha) in zip(cases, G["stream"]):
+        if len(d) > 300000 or n >= 6:
+            continue
+        empty = cuts[-1] == cuts[-2]
+        f = helpers.emu_compress_big([d], G=(4, 16)[n % 2], stream=2 if empty else 1, level=2)[0][0]
+        assert len(f) == flen and helpers.sha256(f) == sha, (size, cuts)
+        n += 1
+    assert n >= 5
+
+
 def test_decoder_concatenated_and_skippable_frames():
     """One entry with several frames back to back, skippable frames between them, an empty entry and garbage after a frame:
     the semantics of ZSTD_decompress / ZSTD_decompressStream (ZSTD_decompressMultiFrame), which the reference's

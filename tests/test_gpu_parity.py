@@ -562,11 +562,17 @@ def test_level1_multiblock_and_streaming_frames():
             torch.cuda.synchronize()
             f = dst[: int(olen[0])].cpu().numpy().tobytes()
             assert len(f) == flen and helpers.sha256(f) == sha, (size, cuts)
-        # level 2 above 128 KiB and level 1 on a 2 MiB context are refused, not served differently
-        with pytest.raises(RuntimeError):
-            b.compress(src, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.tensor([len(d)], dtype=torch.int32, device="cuda"), level=2)
     finally:
         b.close()
+    # level 1 beyond its 512 KiB window (a context for larger slices) is refused, not served differently
+    b2 = ZstdBatch(max_slices=2, max_slice_bytes=2 << 20)
+    try:
+        with pytest.raises(RuntimeError):
+            b2.compress(src, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.tensor([len(d)], dtype=torch.int32, device="cuda"), level=1)
+        with pytest.raises(RuntimeError):
+            b2.compress(src, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.tensor([len(d)], dtype=torch.int32, device="cuda"), level=2)
+    finally:
+        b2.close()
     lib = _lib.load()
     for (d, cuts), (size, fed, flen, sha) in list(zip(cases, G["l1_stream"]))[:10]:
         cctx = lib.kmp_zstd_create_cctx()
@@ -592,6 +598,38 @@ def test_level1_multiblock_and_streaming_frames():
     name, n, flen, sha = rows[3]
     f = ZstdCompressor(compression_level=1).transform_bytes(ins[name])
     assert len(f) == flen and helpers.sha256(f) == sha
+
+
+def test_level2_multiblock_and_streaming_frames():
+    """Level 2 above 128 KiB (up to its 1 MiB window).  Its row for 128 KiB < size <= 256 KiB is a double-fast one, the others
+    are fast ones: one batch goes through both block-chain kernels.  ZSTD_compress2's frames, the frames the reference's
+    one-shot driver gets (ZstdCompressor(2).transform(bytes)), streamed frames and the kmp_zstd_compress_stream call pattern,
+    against libzstd 1.5.7 (tests/golden/zstd_level2_big_golden.json), decoded back on the GPU."""
+    from kompressor_amd import ZstdCompressor
+    from kompressor_amd.batch import ZstdBatch
+    G = helpers.level2_big_golden()
+    ins = dict(helpers.multiblock_inputs())
+    rows = G["multiblock"]
+    assert any(131072 < r[1] <= 262144 for r in rows) and any(r[1] > 262144 for r in rows)
+    datas = [ins[r[0]] for r in rows]
+    b = ZstdBatch(max_slices=len(datas), max_slice_bytes=1 << 20)
+    try:
+        f0 = gpu_compress_kw(b, datas, level=2)
+        f3 = gpu_compress_kw(b, datas, level=2, reference=True)
+        for (name, n, l0, s0, l3, s3), x, y in zip(rows, f0, f3):
+            assert (len(x), helpers.sha256(x)) == (l0, s0) and (len(y), helpers.sha256(y)) == (l3, s3), name
+        back, st = gpu_decompress(b, f3, [len(d) for d in datas])
+        assert st == [0] * len(f3) and back == datas
+        cases = [(d, cuts) for d, cuts in helpers.stream_cases() if len(d) <= 1024 * 1024]
+        for (d, cuts), (size, fed, flen, sha) in zip(cases, G["stream"]):
+            f = gpu_compress_kw(b, [d], level=2, streaming="empty" if cuts[-1] == cuts[-2] else "data")[0]
+            assert len(f) == flen and helpers.sha256(f) == sha, (size, cuts)
+    finally:
+        b.close()
+    # through the streaming ABI: one-shot (finish = true from the first call), a small and a large one of each row kind
+    for name, n, l0, s0, l3, s3 in (rows[0], next(r for r in rows if 131072 < r[1] <= 262144), next(r for r in rows if r[1] > 300000)):
+        f = ZstdCompressor(compression_level=2).transform_bytes(ins[name])
+        assert (len(f), helpers.sha256(f)) == (l3, s3), name
 
 
 def test_concatenated_and_skippable_frames(batch):

@@ -128,6 +128,25 @@ def test_oracle_streaming_frames_match_golden():
         assert len(f) == flen and helpers.sha256(f) == sha, (n, cuts)
 
 
+def test_oracle_level2_multiblock_and_streams_match_golden():
+    """Level 2 above 128 KiB (up to its 1 MiB window): the row for 128 KiB < size <= 256 KiB is a double-fast one, the others
+    are fast ones; ZSTD_compress2's frames, the frames the reference's one-shot driver gets, and streamed frames, against
+    libzstd 1.5.7 (tests/golden/make_golden_level2_big.py)."""
+    G = helpers.level2_big_golden()
+    o = helpers.oracle()
+    ins = dict(helpers.multiblock_inputs())
+    assert len(G["multiblock"]) >= 30
+    for name, n, l0, s0, l3, s3 in G["multiblock"]:
+        d = ins[name]
+        f0, f3 = o.compress_level_big(d, 2, 0), o.compress_level_big(d, 2, 3)
+        assert (len(f0), helpers.sha256(f0)) == (l0, s0) and (len(f3), helpers.sha256(f3)) == (l3, s3), name
+    cases = [(d, cuts) for d, cuts in helpers.stream_cases() if len(d) <= 1024 * 1024]
+    assert len(cases) == len(G["stream"]) >= 20
+    for (d, cuts), (n, fed, flen, sha) in zip(cases, G["stream"]):
+        f = o.compress_level_big(d, 2, 1, cuts[-1] == cuts[-2])
+        assert (len(f), helpers.sha256(f)) == (flen, sha), (n, cuts)
+
+
 def test_oracle_level1_multiblock_and_streams_match_golden():
     """Level 1 above 128 KiB: the "fromBorders" pre-splitter, the table and repcodes carried from block to block, and the
     level-1 streaming frames (window 2^19) the reference's Ktor encoder produces (ZstdContentEncoder.kt:11)."""
