@@ -171,14 +171,15 @@ struct kmp_batch_ctx {
     u32 cus;                                   // compute units of the device
     // decoder: sequences decoded ahead of k_zstd_decode (allocated on first use; pre_tried: do not try again)
     u64* pre_stage; KPreBlk* pre_blk; u32* pre_nblk; u32 pre_seq_cap, pre_blk_cap; int pre_tried;
-    u32* pre_sort;                              // per entry key and slot -> entry map, then KMP_MAX_CHUNKS x 256 bucket counters
+    u32 pre_slices;                             // entries the staging areas hold (a larger batch is decoded in pieces)
+    u32* pre_sort;                              // per staged entry: key, slot -> entry map; then 256 bucket counters
     u8* pre_lits; KPreLit* pre_lit; u32* pre_nlit; u32 pre_lit_cap;
     u32* len_ok; u32* d_status;                // sanitised slice lengths of the running batch; status word (KMP_STATUS_*)
     // one batch at a time per context: a batch queued on another stream waits for the previous one's last kernel
     hipEvent_t ev_done; int have_done;
     // experiment switches, read from the environment once, when the context is created
     struct { u32 chunks, match_flags, entropy_pad, first_permille, entropy_flags, decode_flags, decode_pad, big_rounds, big_spw,
-                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre, decode_sort, decode_pieces; } knob;
+                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre, decode_sort, decode_pieces, decode_stage_slices; } knob;
 };
 
 static u32 env_u32(const char* name, u32 dflt)
@@ -250,7 +251,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     c->knob.dfl_serial = env_u32("KMP_DEFLATE_SERIAL", 0); c->knob.dfl_flags = env_u32("KMP_DEFLATE_FLAGS", 0);
     // experiment, off by default (measured slower): bit 0 = sequences decoded ahead of k_zstd_decode
     // (k_zstd_seq_predecode, one lane per frame), bit 1 = literals (k_zstd_lit_predecode, one lane per stream)
-    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1);
+    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1); c->knob.decode_stage_slices = env_u32("KMP_DECODE_STAGE_SLICES", 0);
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return KMP_OK;
@@ -679,97 +680,88 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
     d.lits = c->lits; d.lit_cap = c->lit_cap; d.flags = c->knob.decode_flags;
     KMP_TRY(batch_begin(c, st, nullptr, n, 0));            // the decoder checks every length itself; lits is shared with the compressors
     d.dict = (const u8*)d_dict; d.dict_size = d_dict ? dict_size : 0u;
-    // staging for the sequences decoded ahead (8 bytes per sequence, a frame of S bytes holds at most S / 3): allocated on
-    // first use; a context whose slices would need more than 64 GiB of it decodes everything in k_zstd_decode, as before
+    // Staging for what the pre-decode kernels leave (8 bytes per sequence -- a frame of S bytes holds at most S / 3 -- and
+    // the literals): allocated on the first call, for as many entries as 48 GiB hold (all of them for the bench's batches;
+    // a larger batch goes through in pieces, one after the other, that reuse the staging).
     if (!c->pre_tried && c->knob.decode_pre) {
         c->pre_tried = 1;
         u32 const seq_cap = c->max_slice_bytes / 3u + 64u, blk_cap = c->max_slice_bytes / 8192u + 16u, lit_cap = c->max_slice_bytes + 64u;
+        u64 const per_entry = (u64)seq_cap * 8u + (u64)lit_cap + (u64)blk_cap * (sizeof(KPreBlk) + sizeof(KPreLit)) + 64u;
+        u64 fit = c->knob.decode_stage_slices ? c->knob.decode_stage_slices : (48ull << 30) / per_entry;
+        if (fit > c->max_slices) fit = c->max_slices;
+        if (fit >= 1024u) fit &= ~1023ull;                           // (whole workgroups of every kernel)
+        u32 const ps = (u32)fit;
         c->pre_blk_cap = blk_cap;
-        if ((c->knob.decode_pre & 1u) && (u64)c->max_slices * seq_cap * 8ull <= (64ull << 30)) {
-            if (hipMalloc((void**)&c->pre_stage, (size_t)c->max_slices * seq_cap * 8u) == hipSuccess &&
-                hipMalloc((void**)&c->pre_blk, (size_t)c->max_slices * blk_cap * sizeof(KPreBlk)) == hipSuccess &&
-                hipMalloc((void**)&c->pre_nblk, (size_t)c->max_slices * 4u) == hipSuccess &&
-                hipMalloc((void**)&c->pre_sort, ((size_t)c->max_slices * 2u + (size_t)KMP_MAX_CHUNKS * KXP_SORT_BUCKETS) * 4u) == hipSuccess) c->pre_seq_cap = seq_cap;
+        if (ps && (c->knob.decode_pre & 1u)) {
+            if (hipMalloc((void**)&c->pre_stage, (size_t)ps * seq_cap * 8u) == hipSuccess &&
+                hipMalloc((void**)&c->pre_blk, (size_t)ps * blk_cap * sizeof(KPreBlk)) == hipSuccess &&
+                hipMalloc((void**)&c->pre_nblk, (size_t)ps * 4u) == hipSuccess &&
+                hipMalloc((void**)&c->pre_sort, ((size_t)ps * 2u + KXP_SORT_BUCKETS) * 4u) == hipSuccess) { c->pre_seq_cap = seq_cap; c->pre_slices = ps; }
             else { (void)hipGetLastError(); (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); (void)hipFree(c->pre_sort); c->pre_stage = nullptr; c->pre_blk = nullptr; c->pre_nblk = nullptr; c->pre_sort = nullptr; }
         }
-        if ((c->knob.decode_pre & 2u) && (u64)c->max_slices * lit_cap <= (64ull << 30)) {
-            if (hipMalloc((void**)&c->pre_lits, (size_t)c->max_slices * lit_cap) == hipSuccess &&
-                hipMalloc((void**)&c->pre_lit, (size_t)c->max_slices * blk_cap * sizeof(KPreLit)) == hipSuccess &&
-                hipMalloc((void**)&c->pre_nlit, (size_t)c->max_slices * 4u) == hipSuccess) c->pre_lit_cap = lit_cap;
+        if (ps && (c->knob.decode_pre & 2u)) {
+            if (hipMalloc((void**)&c->pre_lits, (size_t)ps * lit_cap) == hipSuccess &&
+                hipMalloc((void**)&c->pre_lit, (size_t)ps * blk_cap * sizeof(KPreLit)) == hipSuccess &&
+                hipMalloc((void**)&c->pre_nlit, (size_t)ps * 4u) == hipSuccess) { c->pre_lit_cap = lit_cap; c->pre_slices = ps; }
             else { (void)hipGetLastError(); (void)hipFree(c->pre_lits); (void)hipFree(c->pre_lit); (void)hipFree(c->pre_nlit); c->pre_lits = nullptr; c->pre_lit = nullptr; c->pre_nlit = nullptr; }
         }
     }
     d.pre_stage = nullptr; d.pre_seq_cap = 0; d.pre_blk = nullptr; d.pre_blk_cap = c->pre_blk_cap; d.pre_nblk = nullptr;
     d.pre_lits = nullptr; d.pre_lit_cap = 0; d.pre_lit = nullptr; d.pre_nlit = nullptr;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[4], st));
-    // one piece: both pre-decoders take their frames in order of sequence count (neighbours in size share a wave)
-    u32 decode_pieces = (n >= 8192u) ? c->knob.decode_pieces : 1u;
-    if (decode_pieces < 1u || decode_pieces > (u32)KMP_MAX_CHUNKS) decode_pieces = (u32)KMP_MAX_CHUNKS;
-    bool const sort_all = c->pre_stage && c->knob.decode_sort != 0 && n >= 1024u && decode_pieces == 1u;
-    if (sort_all) {
-        u32* const sort_key = c->pre_sort; u32* const sort_perm = c->pre_sort + c->max_slices; u32* const sort_hist = c->pre_sort + 2u * (size_t)c->max_slices;
-        HIP_TRY(hipMemsetAsync(sort_hist, 0, (size_t)KXP_SORT_BUCKETS * 4u, st));
-        KSeqSortArgs sa;
-        sa.src = d.src; sa.in_off = d_in_off; sa.in_len = d_in_len; sa.n_slices = n; sa.key = sort_key; sa.hist = sort_hist; sa.perm = sort_perm;
-        hipLaunchKernelGGL(k_zstd_seq_count, dim3((n + 255) / 256), dim3(256), 0, st, sa);
-        hipLaunchKernelGGL(k_zstd_seq_rank, dim3(1), dim3(256), 0, st, sa);
-        hipLaunchKernelGGL(k_zstd_seq_perm, dim3((n + 255) / 256), dim3(256), 0, st, sa);
+    if (!c->pre_stage && !c->pre_lits) {
+        hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), c->knob.decode_pad, st, d);   // padding = occupancy experiment only
         HIP_TRY(hipGetLastError());
-    }
-    if (c->pre_stage) { HIP_TRY(hipEventRecord(c->ev_pre[0], st)); HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_pre[0], 0)); }     // st2 starts where st stands: the two pre-decoders run side by side
-    if (c->pre_lits) {
-        KLitArgs p;
-        p.perm = sort_all ? c->pre_sort + c->max_slices : nullptr;
-        p.src = d.src; p.in_off = d_in_off; p.in_len = d_in_len; p.n_slices = n;
-        p.lits = c->pre_lits; p.lit_cap = c->pre_lit_cap; p.rec = c->pre_lit; p.blk_cap = c->pre_blk_cap; p.nrec = c->pre_nlit;
-        hipLaunchKernelGGL(k_zstd_lit_predecode, dim3((n + KXL_FRAMES - 1) / KXL_FRAMES), dim3(64), 0, st, p);
-        HIP_TRY(hipGetLastError());
-        d.pre_lits = c->pre_lits; d.pre_lit_cap = c->pre_lit_cap; d.pre_lit = c->pre_lit; d.pre_nlit = c->pre_nlit;
-    }
-    if (c->pre_stage) {
-        // The sequence pre-decoder is bound by memory transactions, the decoder by instruction issue: the batch goes through
-        // in pieces, the pre-decoder (second stream) working on the pieces ahead of the one the decoder has.
-        u32 const pieces = decode_pieces;
-        u32 const per = ((n + pieces - 1) / pieces + 63u) & ~63u;
-        u32* const sort_key = c->pre_sort; u32* const sort_perm = c->pre_sort + c->max_slices; u32* const sort_hist = c->pre_sort + 2u * (size_t)c->max_slices;
-        bool const sorted = c->knob.decode_sort != 0 && n >= 1024u && !sort_all;
-        if (sorted) HIP_TRY(hipMemsetAsync(sort_hist, 0, (size_t)KMP_MAX_CHUNKS * KXP_SORT_BUCKETS * 4u, c->st2));
-        for (u32 first = 0, pi = 0; first < n; first += per, pi++) {
+    } else {
+        // piece by piece (one piece unless the batch is larger than the staging; KMP_DECODE_PIECES asks for more): the two
+        // pre-decoders side by side -- literals on the caller's stream, sequences on the context's second one, their lane
+        // slots in order of sequence count (neighbours in size share a wave) -- then k_zstd_decode
+        u32 pieces = (n + c->pre_slices - 1) / c->pre_slices;
+        if (c->knob.decode_pieces > pieces && n >= 8192u) pieces = c->knob.decode_pieces;
+        u32 per = ((n + pieces - 1) / pieces + 63u) & ~63u;
+        if (per > c->pre_slices) per = c->pre_slices;
+        u32* const sort_key = c->pre_sort; u32* const sort_perm = c->pre_sort ? c->pre_sort + c->pre_slices : nullptr; u32* const sort_hist = c->pre_sort ? c->pre_sort + 2u * (size_t)c->pre_slices : nullptr;
+        for (u32 first = 0; first < n; first += per) {
             u32 const m = (n - first < per) ? n - first : per;
+            bool const sorted = c->pre_stage && c->knob.decode_sort != 0 && m >= 1024u;
             if (sorted) {
+                HIP_TRY(hipMemsetAsync(sort_hist, 0, (size_t)KXP_SORT_BUCKETS * 4u, st));
                 KSeqSortArgs sa;
-                sa.src = d.src; sa.in_off = d_in_off + first; sa.in_len = d_in_len + first; sa.n_slices = m;
-                sa.key = sort_key + first; sa.hist = sort_hist + (size_t)pi * KXP_SORT_BUCKETS; sa.perm = sort_perm + first;
-                hipLaunchKernelGGL(k_zstd_seq_count, dim3((m + 255) / 256), dim3(256), 0, c->st2, sa);
-                hipLaunchKernelGGL(k_zstd_seq_rank, dim3(1), dim3(256), 0, c->st2, sa);
-                hipLaunchKernelGGL(k_zstd_seq_perm, dim3((m + 255) / 256), dim3(256), 0, c->st2, sa);
+                sa.src = d.src; sa.in_off = d_in_off + first; sa.in_len = d_in_len + first; sa.n_slices = m; sa.key = sort_key; sa.hist = sort_hist; sa.perm = sort_perm;
+                hipLaunchKernelGGL(k_zstd_seq_count, dim3((m + 255) / 256), dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(k_zstd_seq_rank, dim3(1), dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(k_zstd_seq_perm, dim3((m + 255) / 256), dim3(256), 0, st, sa);
                 HIP_TRY(hipGetLastError());
             }
-            KPreArgs p;
-            p.perm = (sorted || sort_all) ? sort_perm + first : nullptr;
-            p.src = d.src; p.in_off = d_in_off + first; p.in_len = d_in_len + first; p.n_slices = m;
-            p.stage = c->pre_stage + (size_t)first * c->pre_seq_cap; p.seq_cap = c->pre_seq_cap;
-            p.blk = c->pre_blk + (size_t)first * c->pre_blk_cap; p.blk_cap = c->pre_blk_cap; p.nblk = c->pre_nblk + first;
-            hipLaunchKernelGGL(k_zstd_seq_predecode, dim3((m + KXP_FRAMES - 1) / KXP_FRAMES), dim3(64), 0, c->st2, p);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(c->ev_pre[1 + pi], c->st2));
-        }
-        for (u32 first = 0, pi = 0; first < n; first += per, pi++) {
-            u32 const m = (n - first < per) ? n - first : per;
             KDecodeArgs q = d;
             q.in_off = d_in_off + first; q.in_len = d_in_len + first; q.n_slices = m;
             q.out_off = d_out_off + first; q.out_cap = d_out_cap + first; q.out_len = d_out_len + first; q.status = d_status + first;
             q.lits = c->lits + (size_t)first * c->lit_cap;
-            q.pre_stage = c->pre_stage + (size_t)first * c->pre_seq_cap; q.pre_seq_cap = c->pre_seq_cap;
-            q.pre_blk = c->pre_blk + (size_t)first * c->pre_blk_cap; q.pre_blk_cap = c->pre_blk_cap; q.pre_nblk = c->pre_nblk + first;
-            if (d.pre_lits) { q.pre_lits = d.pre_lits + (size_t)first * d.pre_lit_cap; q.pre_lit = d.pre_lit + (size_t)first * c->pre_blk_cap; q.pre_nlit = d.pre_nlit + first; }
-            HIP_TRY(hipStreamWaitEvent(st, c->ev_pre[1 + pi], 0));
+            if (c->pre_stage) {
+                // (st2 starts where st stands: behind the previous piece's k_zstd_decode, which read the staging)
+                HIP_TRY(hipEventRecord(c->ev_pre[0], st)); HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_pre[0], 0));
+                KPreArgs p;
+                p.perm = sorted ? sort_perm : nullptr;
+                p.src = d.src; p.in_off = q.in_off; p.in_len = q.in_len; p.n_slices = m;
+                p.stage = c->pre_stage; p.seq_cap = c->pre_seq_cap; p.blk = c->pre_blk; p.blk_cap = c->pre_blk_cap; p.nblk = c->pre_nblk;
+                hipLaunchKernelGGL(k_zstd_seq_predecode, dim3((m + KXP_FRAMES - 1) / KXP_FRAMES), dim3(64), 0, c->st2, p);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(c->ev_pre[1], c->st2));
+                q.pre_stage = c->pre_stage; q.pre_seq_cap = c->pre_seq_cap; q.pre_blk = c->pre_blk; q.pre_nblk = c->pre_nblk;
+            }
+            if (c->pre_lits) {
+                KLitArgs p;
+                p.perm = sorted ? sort_perm : nullptr;
+                p.src = d.src; p.in_off = q.in_off; p.in_len = q.in_len; p.n_slices = m;
+                p.lits = c->pre_lits; p.lit_cap = c->pre_lit_cap; p.rec = c->pre_lit; p.blk_cap = c->pre_blk_cap; p.nrec = c->pre_nlit;
+                hipLaunchKernelGGL(k_zstd_lit_predecode, dim3((m + KXL_FRAMES - 1) / KXL_FRAMES), dim3(64), 0, st, p);
+                HIP_TRY(hipGetLastError());
+                q.pre_lits = c->pre_lits; q.pre_lit_cap = c->pre_lit_cap; q.pre_lit = c->pre_lit; q.pre_nlit = c->pre_nlit;
+            }
+            if (c->pre_stage) HIP_TRY(hipStreamWaitEvent(st, c->ev_pre[1], 0));
             hipLaunchKernelGGL(k_zstd_decode, dim3(m), dim3(64), c->knob.decode_pad, st, q);
             HIP_TRY(hipGetLastError());
         }
-    } else {
-        hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), c->knob.decode_pad, st, d);   // padding = occupancy experiment only
-        HIP_TRY(hipGetLastError());
     }
     if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[5], st)); c->ev_valid[2] = 1; }
     return batch_end(c, st, nullptr, n, 0, nullptr, nullptr);

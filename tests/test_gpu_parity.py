@@ -984,6 +984,9 @@ def test_predecode_kernels_give_the_same_frames(monkeypatch):
         monkeypatch.setenv("KMP_DECODE_PRE", mode)
         others.append(ZstdBatch(max_slices=800, max_slice_bytes=2 << 20))
     monkeypatch.delenv("KMP_DECODE_PRE")
+    monkeypatch.setenv("KMP_DECODE_STAGE_SLICES", "256")         # staging for 256 entries: the batch goes through in pieces that reuse it
+    others.append(ZstdBatch(max_slices=800, max_slice_bytes=2 << 20))
+    monkeypatch.delenv("KMP_DECODE_STAGE_SLICES")
     try:
         frames = gpu_compress(ref, datas) + gpu_compress_kw(ref, big, reference=True)
         frames += [base64.b64decode(r["frame"]) for r in G["decode_only"]]
@@ -996,9 +999,9 @@ def test_predecode_kernels_give_the_same_frames(monkeypatch):
         caps = [2 << 20] * len(frames)
         a, sa = gpu_decompress(ref, frames, caps)
         assert a[: len(datas)] == datas and a[len(datas): len(datas) + len(big)] == big
-        for mode, ctx in zip("012", others):
+        for mode, ctx in zip(("KMP_DECODE_PRE=0", "KMP_DECODE_PRE=1", "KMP_DECODE_PRE=2", "KMP_DECODE_STAGE_SLICES=256"), others):
             b, sb = gpu_decompress(ctx, frames, caps)
-            assert sa == sb and a == b, f"KMP_DECODE_PRE={mode}"
+            assert sa == sb and a == b, mode
     finally:
         ref.close()
         for ctx in others:
