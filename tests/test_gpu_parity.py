@@ -269,7 +269,7 @@ def test_streaming_abi_one_shot_like_the_reference(G):
     with pytest.raises(RuntimeError, match="Bad zstd result code -40: Unsupported parameter"):
         ZstdCompressor(compression_level=19)
     with pytest.raises(RuntimeError, match="Bad zstd result code -40: Unsupported parameter"):
-        ZstdCompressor(compression_level=2).transform_bytes(bytes(131073))      # level 2: one block
+        ZstdCompressor(compression_level=2).transform_bytes(bytes((1 << 20) + 1))        # level 2: up to its 1 MiB window
     with pytest.raises(RuntimeError, match="Bad zstd result code -40: Unsupported parameter"):
         ZstdCompressor(compression_level=1).transform_bytes(bytes((512 << 10) + 1))      # level 1: up to its 512 KiB window
     with pytest.raises(RuntimeError, match="Unknown frame descriptor"):
