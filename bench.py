@@ -260,13 +260,14 @@ def main():
     b.set_profiling(True)
 
     if args.mode == "deflate":
-        # configs[4]: ZlibCompressor(ZlibFormat.Raw, 6) over the same slices
+        # configs[4]: ZlibCompressor(ZlibFormat.Raw, 6) over the same slices (--level 4 .. 9: zlib's other lazy-matching levels)
+        dlevel = args.level if 4 <= args.level <= 9 else 6
         for _ in range(args.warmup):
-            b.deflate(src, in_off, in_len, dst, out_off, out_len)
+            b.deflate(src, in_off, in_len, dst, out_off, out_len, level=dlevel)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            b.deflate(src, in_off, in_len, dst, out_off, out_len)
+            b.deflate(src, in_off, in_len, dst, out_off, out_len, level=dlevel)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         kms = b.deflate_kernel_ms()
@@ -295,7 +296,7 @@ def main():
 
         def _zrun(t):
             for i in range(t * per_t, min(sample, (t + 1) * per_t)):
-                c = _z.compressobj(6, _z.DEFLATED, -15, 8, 0)
+                c = _z.compressobj(dlevel, _z.DEFLATED, -15, 8, 0)
                 c.compress(host[i * SLICE:(i + 1) * SLICE].tobytes()); c.flush()
 
         t1 = time.perf_counter()
@@ -317,11 +318,12 @@ def main():
                         "frac": round(algo_piece / (ms_best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic_best,
                         "slices_per_launch": piece, "avg_launch_ms": round(ms_best, 3)}
         print(json.dumps({
-            "metric": "raw DEFLATE level-6 compression throughput, 64 KiB-slice batch (uncompressed input bytes per second)",
+            "metric": f"raw DEFLATE level-{dlevel} compression throughput, 64 KiB-slice batch (uncompressed input bytes per second)",
             "value": round(n * SLICE / (dt / args.steps) / 1e9, 3), "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[4]: {n} x 64 KiB slices, raw DEFLATE level 6 (windowBits 15, memLevel 8)",
+            "config": {"workload": (f"BASELINE configs[4]: {n} x 64 KiB slices, raw DEFLATE level 6 (windowBits 15, memLevel 8)" if dlevel == 6 else
+                                    f"{n} x 64 KiB slices, raw DEFLATE level {dlevel} (windowBits 15, memLevel 8)"),
                        "ratio": round(n * SLICE / float(lens.sum()), 4), "inflate_spot_check_ok": ok,
                        "gpu_inflate_GBps": round(n * SLICE / inflate_s / 1e9, 3), "gpu_inflate_roundtrip_ok": inflate_ok},
             "kernels_ms_first_workspace_chunk": {k: round(v, 3) for k, v in kms.items()},

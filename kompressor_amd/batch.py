@@ -151,9 +151,9 @@ class ZstdBatch:
             raise RuntimeError(f"kmp_inflate_batch failed ({rc}): {_lib.last_error()}")
         return dst, out_off, out_len, status
 
-    def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, zlib_wrapper=False, format=None):   # noqa: A002
-        """DEFLATE streams (zlib level 6, windowBits 15, memLevel 8), format "raw" / "zlib" / "gzip", for slices up to the
-        context's max_slice_bytes (64 KiB at least)."""
+    def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, zlib_wrapper=False, format=None, level=6):   # noqa: A002
+        """DEFLATE streams (zlib level 6 -- or any other of its lazy-matching levels, 4 .. 9 --, windowBits 15, memLevel 8),
+        format "raw" / "zlib" / "gzip", for slices up to the context's max_slice_bytes (64 KiB at least)."""
         fmt = self._FORMATS[format] if format is not None else (1 if zlib_wrapper else 0)
         if fmt == 3:
             raise ValueError("Compression can't be used with auto-detection")       # ZlibFormat.kt:28
@@ -165,8 +165,12 @@ class ZstdBatch:
             out_off = torch.arange(n, dtype=torch.int64, device=self.device) * stride
         if out_len is None:
             out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
-        fn = (self.lib.kmp_deflate_compress_batch, self.lib.kmp_zlib_compress_batch, self.lib.kmp_gzip_compress_batch)[fmt]
-        rc = fn(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n, _ptr(dst), _ptr(out_off), _ptr(out_len), self._stream())
+        if level in (-1, 6):
+            fn = (self.lib.kmp_deflate_compress_batch, self.lib.kmp_zlib_compress_batch, self.lib.kmp_gzip_compress_batch)[fmt]
+            rc = fn(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n, _ptr(dst), _ptr(out_off), _ptr(out_len), self._stream())
+        else:
+            rc = self.lib.kmp_deflate_compress_batch_level(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n, _ptr(dst), _ptr(out_off), _ptr(out_len),
+                                                           fmt, level, self._stream())
         if rc != 0:
             raise RuntimeError(f"kmp_deflate_compress_batch failed ({rc}): {_lib.last_error()}")
         return dst, out_off, out_len

@@ -51,7 +51,19 @@ struct KdArgs {
     u8* dst; const u64* out_off; u32* out_len;
     u32 flags;          // timing-only ablations (results wrong): 1 = no match extension, 2 = at most 16 chain steps; 4 = chunks of 8192 positions (results right); bits 8.. = refill threshold
     u32 format;         // 0 = raw deflate, 1 = zlib wrapper (78 9C header, Adler-32 trailer)
+    u32 good, lazy, nice, chain;     // zlib's configuration_table row of the level (deflate_slow: levels 4 .. 9; level 6 = 8, 16, 128, 128)
+    u32 zflg, gxfl;                  // what the wrappers say about the level: the zlib header's FLG byte (5E / 9C / DA), gzip's XFL (2 at level 9)
 };
+// (KdBest's fields are named after level 6: len128 / dist128 = the result of a full chain, len32 / dist32 = of a quarter of it,
+// what longest_match walks when the previous match was at least `good` long)
+static inline void kd_level_config(KdArgs& a, int level)        // (host side: fills the kernel arguments)
+{
+    static const u32 cfg[10][4] = { {8,16,128,128}, {8,16,128,128}, {8,16,128,128}, {8,16,128,128},
+        { 4, 4, 16, 16 }, { 8, 16, 32, 32 }, { 8, 16, 128, 128 }, { 8, 32, 128, 256 }, { 32, 128, 258, 1024 }, { 32, 258, 258, 4096 } };
+    int const l = (level < 4 || level > 9) ? 6 : level;
+    a.good = cfg[l][0]; a.lazy = cfg[l][1]; a.nice = cfg[l][2]; a.chain = cfg[l][3];
+    a.zflg = l < 6 ? 0x5Eu : l == 6 ? 0x9Cu : 0xDAu; a.gxfl = l == 9 ? 2u : 0u;
+}
 
 // ---------------------------------------------------------------------------
 // k_deflate_chains: 256 threads per workgroup, head[32768] in LDS
@@ -175,7 +187,8 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                 int p = 0, c = 0, steps = 0, bestLen = 2, bestPos = 0, so = 0, maxlen = 0, nice = 0, limit = 0;
                 u32 scan01 = 0, scanEnd = 0; KdBest r; r.len128 = 0; r.dist128 = 0; r.len32 = 0; r.dist32 = 0;
                 int const lane = kx_lane();
-                int const maxSteps = (a.flags & 2u) ? 16 : 128;
+                int const maxSteps = (a.flags & 2u) ? 16 : (int)a.chain;
+                int const quarter = maxSteps >> 2, niceMax = (int)a.nice;
                 int const refillAt = (a.flags >> 8) ? (int)(a.flags >> 8) : 16;      // idle lanes that trigger a refill (tuning switch)
                 int const reps = ((a.flags >> 4) & 15u) ? (int)((a.flags >> 4) & 15u) : 8;   // flags bits 4..7: candidate steps per refill check (1: 349 ms, 2: 332, 4: 325, 8: 320 per 16 384 slices)
                 for (;;) {
@@ -198,7 +211,7 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                                     int const d0 = lds.lnk[p - lo];
                                     c = p - d0;
                                     if (d0 != 0) {
-                                        nice = lookahead < 128 ? lookahead : 128;
+                                        nice = lookahead < niceMax ? lookahead : niceMax;
                                         maxlen = lookahead < KD_MAX_MATCH ? lookahead : KD_MAX_MATCH;
                                         so = p - lo;                              // scan offset in the staged window
                                         scan01 = kd_ld16(lds.sw, so);
@@ -241,10 +254,10 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                                     else scanEnd = kd_ld16(lds.sw, so + bestLen - 1);
                                 }
                             }
-                            if (steps == 32 || (done && steps < 32)) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.dist32 = (u16)(p - bestPos); }
+                            if (steps == quarter || (done && steps < quarter)) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.dist32 = (u16)(p - bestPos); }
                             c = cnext;
                             if (done || !(c > limit && steps < maxSteps)) {
-                                if (steps < 32 && !done) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.dist32 = (u16)(p - bestPos); }
+                                if (steps < quarter && !done) { r.len32 = (u16)(bestLen > 2 ? bestLen : 0); r.dist32 = (u16)(p - bestPos); }
                                 r.len128 = (u16)(bestLen > 2 ? bestLen : 0); r.dist128 = (u16)(p - bestPos);
                                 best[p] = r;
                                 active = false;
@@ -294,11 +307,11 @@ KX_DEV void deflate_parse_body(const KdArgs& a)
         int const lookahead = n - strstart;          // (what lies ahead in the buffer is this, or at least MIN_LOOKAHEAD > MAX_MATCH)
         prev_length = match_length; prev_dist = match_dist;
         match_length = KD_MIN_MATCH - 1;
-        if (lookahead >= KD_MIN_MATCH && prev_length < 16) {
+        if (lookahead >= KD_MIN_MATCH && prev_length < (int)a.lazy) {
             // longest_match starts from best_len = prev_length, so only a longer match changes anything;
             // a previous match >= good_match (8) shortens the chain walk to 32 steps
             KdBest const r = best[strstart];
-            int const len = prev_length >= 8 ? r.len32 : r.len128, dist = prev_length >= 8 ? r.dist32 : r.dist128;
+            int const len = prev_length >= (int)a.good ? r.len32 : r.len128, dist = prev_length >= (int)a.good ? r.dist32 : r.dist128;
             if (len > prev_length) {
                 match_length = len; match_dist = dist;
                 if (match_length == KD_MIN_MATCH && match_dist > KD_TOO_FAR) match_length = KD_MIN_MATCH - 1;

@@ -781,7 +781,15 @@ extern "C" int kmp_zstd_decompress_batch_dict(kmp_batch_ctx* c, const void* d_sr
 extern "C" size_t kmp_deflate_bound(size_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 7 + 18; }
 
 static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream);
+                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream, int level = 6);
+/* any of zlib's deflate_slow levels (4 .. 9; -1 = 6): the same kernels with the level's good / lazy / nice / chain numbers */
+extern "C" int kmp_deflate_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                                uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int format, int level, void* hip_stream)
+{
+    if (level == -1) level = 6;
+    if (format < 0 || format > 2 || level < 4 || level > 9) { g_last_error = "kmp_deflate_compress_batch_level: format 0 (raw), 1 (zlib) or 2 (gzip), level 4 .. 9 (zlib's lazy-matching levels)"; return KMP_ERR_ARG; }
+    return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (u32)format, hip_stream, level);
+}
 extern "C" int kmp_deflate_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                           uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
 { return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, 0, hip_stream); }
@@ -811,7 +819,7 @@ extern "C" int kmp_inflate_batch(kmp_batch_ctx* c, const void* d_src, const uint
 }
 
 static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream)
+                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream, int level)
 {
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_deflate_compress_batch: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_deflate_compress_batch: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
@@ -857,6 +865,7 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
         a.link = c->dfl_link + half * c->dfl_pos_cap; a.best = c->dfl_best + half * c->dfl_pos_cap;
         a.syms = c->dfl_syms + half * c->dfl_pos_cap; a.meta = c->dfl_meta + half; a.blocks = c->dfl_blocks + half * c->dfl_blk_cap;
         a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
+        kd_level_config(a, level);
         bool const prof = c->profiling && first == 0;      // per-kernel events for the first piece
         hipStream_t const s2 = serial ? st : c->st2;
         if (!serial && piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[h], 0));      // this half's previous piece has been encoded
@@ -1120,10 +1129,10 @@ struct kmp_zlib_cstream { int level, window_bits, mem_level, strategy; std::vect
 
 extern "C" kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bits, int mem_level, int strategy)
 {
-    // what deflateInit2 would accept; the GPU path implements raw deflate (-15), level 6 (-1 = default = 6), memLevel 8, strategy 0
+    // what deflateInit2 would accept; the GPU path implements levels 4 .. 9 (zlib's lazy-matching levels; -1 = default = 6), memLevel 8, strategy 0
     if (level == -1) level = 6;
     // windowBits: -15 raw, 15 zlib wrapper, 31 (15 + 16) gzip wrapper
-    if (level != 6 || (window_bits != -15 && window_bits != 15 && window_bits != 31) || mem_level != 8 || strategy != 0) return nullptr;
+    if (level < 4 || level > 9 || (window_bits != -15 && window_bits != 15 && window_bits != 31) || mem_level != 8 || strategy != 0) return nullptr;
     kmp_zlib_cstream* z = new (std::nothrow) kmp_zlib_cstream();
     if (!z) return nullptr;
     z->level = level; z->window_bits = window_bits; z->mem_level = mem_level; z->strategy = strategy; z->out_pos = 0; z->stage = 0;
@@ -1148,7 +1157,7 @@ extern "C" int kmp_zlib_compress_stream(kmp_zlib_cstream* z, void* dst, size_t d
         if (len && hipMemcpy(s.d_in, z->in.data(), len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
         if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
         if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
-        if (deflate_batch_impl(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, z->window_bits == 31 ? 2u : (z->window_bits > 0 ? 1u : 0u), nullptr) != KMP_OK) return Z_MEM_ERROR_;
+        if (deflate_batch_impl(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, z->window_bits == 31 ? 2u : (z->window_bits > 0 ? 1u : 0u), nullptr, z->level) != KMP_OK) return Z_MEM_ERROR_;
         if (hipMemcpy(&olen, s.d_len + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR_;
         if (olen == 0 || olen > s.out_cap) return Z_DATA_ERROR_;
         z->out.resize(olen);

@@ -77,6 +77,7 @@ typedef struct {
     const u8* in; size_t in_len, in_pos;
     u8 window[2 * W_SIZE]; u16 prev[W_SIZE]; u16 head[HASH_SIZE];
     u32 strstart, lookahead, match_start, match_length, prev_length, prev_match, ins_h, insert; long block_start; int match_available;
+    u32 good_match, max_lazy, nice_match, max_chain;      /* zlib's configuration_table row of the level (deflate_slow levels 4 .. 9) */
     /* symbols */
     u16 d_buf[LIT_BUFSIZE]; u8 l_buf[LIT_BUFSIZE]; u32 last_lit;
     ct dyn_ltree[HEAP_SIZE], dyn_dtree[2 * D_CODES + 1], bl_tree[2 * BL_CODES + 1];
@@ -358,12 +359,12 @@ static void fill_window(dstate* s)
 
 static u32 longest_match(dstate* s, u32 cur_match)
 {
-    unsigned chain_length = 128; const u8* scan = s->window + s->strstart; const u8* match; int len;
-    int best_len = (int)s->prev_length; int nice_match = 128;
+    unsigned chain_length = s->max_chain; const u8* scan = s->window + s->strstart; const u8* match; int len;
+    int best_len = (int)s->prev_length; int nice_match = (int)s->nice_match;
     u32 limit = s->strstart > MAX_DIST ? s->strstart - MAX_DIST : NIL;
     const u8* strend = s->window + s->strstart + MAX_MATCH;
     u8 scan_end1 = scan[best_len - 1], scan_end = scan[best_len];
-    if (s->prev_length >= 8) chain_length >>= 2;
+    if (s->prev_length >= s->good_match) chain_length >>= 2;
     if ((u32)nice_match > s->lookahead) nice_match = (int)s->lookahead;
     do {
         match = s->window + cur_match;
@@ -394,7 +395,7 @@ static void deflate_slow_finish(dstate* s)
         if (s->lookahead >= MIN_MATCH) { INSERT_STRING(s, s->strstart, hash_head); }
         s->prev_length = s->match_length; s->prev_match = s->match_start;
         s->match_length = MIN_MATCH - 1;
-        if (hash_head != NIL && s->prev_length < 16 && s->strstart - hash_head <= MAX_DIST) {
+        if (hash_head != NIL && s->prev_length < s->max_lazy && s->strstart - hash_head <= MAX_DIST) {
             s->match_length = longest_match(s, hash_head);
             if (s->match_length <= 5 && (s->match_length == MIN_MATCH && s->strstart - s->match_start > TOO_FAR)) s->match_length = MIN_MATCH - 1;
         }
@@ -418,11 +419,19 @@ static void deflate_slow_finish(dstate* s)
 
 DREF_API size_t dref_deflate_bound(size_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 13 + 64; }
 
-/* raw deflate level 6, windowBits 15, memLevel 8, strategy 0, one shot. returns size or (size_t)-1 */
-DREF_API size_t dref_deflate_l6_raw(u8* dst, size_t cap, const u8* src, size_t n)
+/* raw deflate at a deflate_slow level (4 .. 9; zlib's configuration_table: good_length, max_lazy, nice_length, max_chain),
+ * windowBits 15, memLevel 8, strategy 0, one shot. returns size or (size_t)-1 */
+DREF_API size_t dref_deflate_raw_level(u8* dst, size_t cap, const u8* src, size_t n, int level);
+DREF_API size_t dref_deflate_l6_raw(u8* dst, size_t cap, const u8* src, size_t n) { return dref_deflate_raw_level(dst, cap, src, n, 6); }
+DREF_API size_t dref_deflate_raw_level(u8* dst, size_t cap, const u8* src, size_t n, int level)
 {
-    dstate* s = (dstate*)calloc(1, sizeof(dstate)); size_t r;
+    static const u32 cfg[10][4] = { {0,0,0,0}, {0,0,0,0}, {0,0,0,0}, {0,0,0,0},
+        { 4, 4, 16, 16 }, { 8, 16, 32, 32 }, { 8, 16, 128, 128 }, { 8, 32, 128, 256 }, { 32, 128, 258, 1024 }, { 32, 258, 258, 4096 } };
+    dstate* s; size_t r;
+    if (level < 4 || level > 9) return (size_t)-1;
+    s = (dstate*)calloc(1, sizeof(dstate));
     if (!s) return (size_t)-1;
+    s->good_match = cfg[level][0]; s->max_lazy = cfg[level][1]; s->nice_match = cfg[level][2]; s->max_chain = cfg[level][3];
     tr_static_init();
     s->in = src; s->in_len = n; s->out = dst; s->out_cap = cap;
     s->l_desc.tree = s->dyn_ltree; s->l_desc.sd.stree = static_ltree; s->l_desc.sd.extra = extra_lbits; s->l_desc.sd.base = LITERALS + 1; s->l_desc.sd.elems = L_CODES; s->l_desc.sd.max_length = MAX_BITS;

@@ -323,8 +323,15 @@ int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len
 #include "deflate_encode.h"
 // raw DEFLATE level 6 pipeline (chains -> best -> parse -> encode) on the emulator
 extern "C" __attribute__((visibility("default")))
+int emu_deflate_level(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* dst, const u64* out_off, u32* out_len,
+                      u16* link_out, KdBest* best_out, u32 format, int level);
+extern "C" __attribute__((visibility("default")))
 int emu_deflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* dst, const u64* out_off, u32* out_len,
                 u16* link_out, KdBest* best_out, u32 format)
+{ return emu_deflate_level(src, in_off, in_len, n, dst, out_off, out_len, link_out, best_out, format, 6); }
+extern "C" __attribute__((visibility("default")))
+int emu_deflate_level(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* dst, const u64* out_off, u32* out_len,
+                      u16* link_out, KdBest* best_out, u32 format, int level)
 {
     u32 maxlen = 65536u;
     for (u32 i = 0; i < n; i++) if (in_len[i] > maxlen) maxlen = in_len[i];
@@ -339,6 +346,7 @@ int emu_deflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* 
     a.pos_cap = pos_cap; a.blk_cap = blk_cap; a.blocks = blocks.data();
     a.link = link.data(); a.best = best.data(); a.syms = syms.data(); a.meta = meta.data();
     a.dst = dst; a.out_off = out_off; a.out_len = out_len; a.flags = 0; a.format = format;
+    kd_level_config(a, level);
     kxemu::failed = 0;
     if (pos_cap <= 65536u) kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_chains_body<u16>(a); });
     else kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_chains_body<u32>(a); });

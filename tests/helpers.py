@@ -334,11 +334,14 @@ class DeflateOracle:
         d = self.lib = ctypes.CDLL(lib)
         d.dref_deflate_l6_raw.restype = ctypes.c_size_t
         d.dref_deflate_l6_raw.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+        d.dref_deflate_raw_level.restype = ctypes.c_size_t
+        d.dref_deflate_raw_level.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
 
-    def compress(self, d: bytes) -> bytes:
+    def compress(self, d: bytes, level: int = 6) -> bytes:
+        """raw DEFLATE at a deflate_slow level (4 .. 9), windowBits 15, memLevel 8"""
         cap = len(d) + len(d) // 100 + 256
         o = ctypes.create_string_buffer(cap)
-        n = self.lib.dref_deflate_l6_raw(o, cap, d, len(d))
+        n = self.lib.dref_deflate_raw_level(o, cap, d, len(d), level)
         if n == 2 ** 64 - 1:
             raise RuntimeError("deflate oracle: output did not fit")
         return o.raw[:n]
@@ -514,7 +517,7 @@ def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False, stream=0, level=3,
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)], rounds.value
 
 
-def emu_deflate(datas, zlib_wrapper=False, fmt=None):
+def emu_deflate(datas, zlib_wrapper=False, fmt=None, level=6):
     """chains -> best -> parse -> encode kernel bodies on the CPU wave emulator."""
     n = len(datas)
     lens = np.array([len(d) for d in datas], dtype=np.uint32)
@@ -531,7 +534,7 @@ def emu_deflate(datas, zlib_wrapper=False, fmt=None):
     out = np.zeros(n * stride, dtype=np.uint8)
     ooff = np.arange(n, dtype=np.uint64) * stride
     olen = np.zeros(n, dtype=np.uint32)
-    r = emu().emu_deflate(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(olen), None, None, fmt if fmt is not None else (1 if zlib_wrapper else 0))
+    r = emu().emu_deflate_level(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(olen), None, None, fmt if fmt is not None else (1 if zlib_wrapper else 0), level)
     assert r == 0, f"emulator reported {r}"
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
 

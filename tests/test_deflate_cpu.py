@@ -74,6 +74,23 @@ def test_emulated_deflate_kernels_match_golden():
         assert zlib.decompress(f, -15) == sp[r["name"]]
 
 
+def test_deflate_levels_4_to_9_oracle_and_emulator_against_zlib():
+    """zlib's other lazy-matching levels (deflate.c configuration_table: 4: 4 4 16 16 ... 9: 32 258 258 4096): the oracle and the
+    kernel bodies against this Python's zlib, raw streams and the level-dependent wrapper bytes (78 5E / 78 DA, gzip XFL)."""
+    import zlib
+    o = helpers.deflate_oracle()
+    for lvl in (4, 5, 7, 8, 9):
+        datas = [corpus.make(6100 + n + lvl, 1, n, mix=ord(c)).tobytes() for n, c in ((1, "T"), (300, "X"), (5000, "B"), (40000, "T"), (65536, "S"), (100000, "D"))]
+        outs = helpers.emu_deflate(datas, level=lvl)
+        for d, f in zip(datas, outs):
+            co = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, 0)
+            ref = co.compress(d) + co.flush()
+            assert f == ref and o.compress(d, lvl) == ref, (lvl, len(d))
+        assert helpers.emu_deflate(datas[:2], zlib_wrapper=True, level=lvl) == [zlib.compress(d, lvl) for d in datas[:2]]
+        co = zlib.compressobj(lvl, zlib.DEFLATED, 31, 8, 0)
+        assert helpers.emu_deflate(datas[1:2], fmt=2, level=lvl)[0] == co.compress(datas[1]) + co.flush()
+
+
 def test_emulated_zlib_wrapper_and_inflate():
     G = helpers.deflate_golden()
     kat = G["reference_kat"]

@@ -14,7 +14,25 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def gpu_deflate(batch, datas):
+def gpu_inflate(batch, streams, caps):
+    n = len(streams)
+    slen = np.array([len(x) for x in streams], dtype=np.int32)
+    soff = np.zeros(n, dtype=np.int64)
+    pos = 0
+    for i, x in enumerate(streams):
+        soff[i] = pos
+        pos += (len(x) + 15) & ~15
+    host = np.zeros(pos + 64, dtype=np.uint8)
+    for i, x in enumerate(streams):
+        host[soff[i]:soff[i] + len(x)] = np.frombuffer(x, dtype=np.uint8)
+    cap = torch.tensor(caps, dtype=torch.int32).cuda()
+    out, o2, l2, st = batch.inflate(torch.from_numpy(host).cuda(), torch.from_numpy(soff).cuda(), torch.from_numpy(slen).cuda(), cap)
+    torch.cuda.synchronize()
+    out, o2, l2, st = out.cpu().numpy(), o2.cpu().numpy(), l2.cpu().numpy(), st.cpu().numpy()
+    return [out[o2[i]:o2[i] + l2[i]].tobytes() for i in range(n)], [int(x) for x in st]
+
+
+def gpu_deflate(batch, datas, level=6):
     n = len(datas)
     lens = np.array([len(d) for d in datas], dtype=np.int32)
     offs = np.zeros(n, dtype=np.int64)
@@ -25,7 +43,7 @@ def gpu_deflate(batch, datas):
     host = np.zeros(pos + 64, dtype=np.uint8)
     for i, d in enumerate(datas):
         host[offs[i]:offs[i] + len(d)] = np.frombuffer(d, dtype=np.uint8)
-    dst, ooff, olen = batch.deflate(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda())
+    dst, ooff, olen = batch.deflate(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), level=level)
     torch.cuda.synchronize()
     dst, ooff, olen = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
     return [dst[ooff[i]:ooff[i] + olen[i]].tobytes() for i in range(n)]
@@ -71,6 +89,26 @@ def test_deflate_against_oracle_and_inflate(batch):
         assert zlib.decompress(f, -15) == d
 
 
+def test_deflate_levels_4_to_9_against_zlib(batch):
+    """ZlibCompressor(level = 4 .. 9): zlib's deflate_slow with the level's good_length / max_lazy / nice_length / max_chain
+    (deflate.c configuration_table); raw streams of a ragged batch against the oracle (pinned on zlib, test_deflate_cpu.py)
+    and against the zlib of this Python, then inflated on the GPU."""
+    o = helpers.deflate_oracle()
+    S = 65536
+    buf = corpus.make(41000, 48, S)
+    datas = [buf[i * S:(i + 1) * S].tobytes() for i in range(48)]
+    datas += [buf[i * S:i * S + 1 + (i * 1777) % 65000].tobytes() for i in range(48)] + [b"", b"a", bytes(65536)]
+    for lvl in (4, 5, 7, 8, 9):
+        outs = gpu_deflate(batch, datas, level=lvl)
+        for i, (d, f) in enumerate(zip(datas, outs)):
+            co = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, 0)
+            assert f == co.compress(d) + co.flush(), (lvl, i)
+            if i % 16 == 0:
+                assert f == o.compress(d, lvl), (lvl, i)
+        back, st = gpu_inflate(batch, outs, [max(len(d), 1) for d in datas])
+        assert st == [0] * len(datas) and back == datas, lvl
+
+
 def test_zlib_streaming_abi_like_the_reference():
     from kompressor_amd.zlib import ZlibCompressor, ZlibFormat
     G = helpers.deflate_golden()
@@ -94,7 +132,12 @@ def test_zlib_streaming_abi_like_the_reference():
     with pytest.raises(RuntimeError, match="Bad zlib result code -3: Z_DATA_ERROR"):
         ZlibDecompressor(ZlibFormat.Zlib).transform_bytes(zd[:-1] + bytes([zd[-1] ^ 1]))
     with pytest.raises(RuntimeError, match="Failed allocating zlib stream"):
-        ZlibCompressor(ZlibFormat.Zlib, 9)                 # other levels stay on the CPU library
+        ZlibCompressor(ZlibFormat.Zlib, 1)                 # deflate_fast (levels 1 .. 3) and stored (0) stay on the CPU library
+    # the other lazy-matching levels, each wrapper saying its level as zlib's does (78 5E / 78 DA, gzip XFL 2 at level 9)
+    for lvl in (4, 5, 7, 8, 9):
+        assert ZlibCompressor(ZlibFormat.Zlib, lvl).transform_bytes(d) == zlib.compress(d, lvl), lvl
+        co = zlib.compressobj(lvl, zlib.DEFLATED, 31, 8, 0)
+        assert ZlibCompressor(ZlibFormat.Gzip, lvl).transform_bytes(d) == co.compress(d) + co.flush(), lvl
     # above 64 KiB zlib's window slides; the reference's own round trip is 1 MiB + 3 random bytes (ZlibTest.kt:16,28-33)
     rnd = np.random.default_rng(1).integers(0, 256, (1 << 20) + 3, dtype=np.uint8).tobytes()
     zr = ZlibCompressor(ZlibFormat.Zlib, 6).transform_bytes(rnd)
