@@ -319,6 +319,22 @@ int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len
     return kxemu::failed ? -1 : 0;
 }
 
+// the counting sort that orders the pre-decoders' lane slots by sequence count (zstd_predecode.h): count, rank, perm
+extern "C" __attribute__((visibility("default")))
+int emu_seq_sort(const u8* src, const u64* in_off, const u32* in_len, u32 n, u32* key, u32* perm)
+{
+    std::vector<u32> hist(KXP_SORT_BUCKETS, 0u);
+    KSeqSortArgs sa;
+    sa.src = src; sa.in_off = in_off; sa.in_len = in_len; sa.n_slices = n; sa.key = key; sa.hist = hist.data(); sa.perm = perm;
+    kxemu::failed = 0;
+    kxemu::launch_block((n + 255) / 256, 4, [&]() { zstd_seq_count_body(sa); });
+    if (kxemu::failed) return -1;
+    kxemu::launch_block(1, 4, [&]() { zstd_seq_rank_body(sa); });
+    if (kxemu::failed) return -2;
+    kxemu::launch_block((n + 255) / 256, 4, [&]() { zstd_seq_perm_body(sa); });
+    return kxemu::failed ? -3 : 0;
+}
+
 #include "deflate_match.h"
 #include "deflate_encode.h"
 // raw DEFLATE level 6 pipeline (chains -> best -> parse -> encode) on the emulator

@@ -4,6 +4,8 @@ against the golden vectors.  This is host-side coverage of the device
 algorithm; the -m gpu tests are the parity tests proper."""
 import base64
 
+import numpy as np
+
 import pytest
 
 import helpers
@@ -96,6 +98,35 @@ def test_emulated_decoder_takes_frames_of_other_settings(monkeypatch):
     outs, st = helpers.emu_decompress([f for _, f, _ in few], [len(p) for _, _, p in few])
     for (r, _, plain), o, s_ in zip(few, outs, st):
         assert s_ == 0 and o == plain, (r["level"], r.get("cls"), r["size"])
+
+
+def test_emulated_sequence_count_sort():
+    """The three small kernels that order the pre-decoders' lane slots (count, rank, perm): the slot -> entry map is a
+    permutation, most sequences first, and the key is the first compressed block's sequence count / 64 (0 for raw frames,
+    empty entries and garbage)."""
+    import ctypes
+    o = helpers.oracle()
+    datas = [corpus.make(8800 + i, 1, n, mix=ord(c)).tobytes() for i, (n, c) in enumerate(
+        [(65536, "T"), (65536, "R"), (3000, "X"), (40000, "B"), (65536, "Z"), (100, "T"), (20000, "S"), (65536, "D"), (50000, "I")] * 35)]
+    frames = [o.compress(d) for d in datas[:9]] * 35 + [b"", b"garbage!" * 4]
+    n = len(frames)
+    lens = np.array([len(f) for f in frames], dtype=np.uint32)
+    offs = np.zeros(n, dtype=np.uint64)
+    pos = 16
+    for i, f in enumerate(frames):
+        offs[i] = pos
+        pos += (len(f) + 31) & ~15
+    buf = np.zeros(pos + 64, dtype=np.uint8)
+    for i, f in enumerate(frames):
+        buf[int(offs[i]):int(offs[i]) + len(f)] = np.frombuffer(f, dtype=np.uint8)
+    key = np.zeros(n, dtype=np.uint32)
+    perm = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)                      # noqa: E731
+    assert helpers.emu().emu_seq_sort(vp(buf), vp(offs), vp(lens), n, vp(key), vp(perm)) == 0
+    assert sorted(perm.tolist()) == list(range(n))
+    ks = key[perm]
+    assert all(int(ks[i]) >= int(ks[i + 1]) for i in range(n - 1))
+    assert key[1] == 0 and key[n - 1] == 0 and key[n - 2] == 0 and key[0] > 40         # random slice: raw block; empty; garbage; text
 
 
 def test_emulated_decoder_rejects_bad_frames(G):
