@@ -294,11 +294,23 @@ int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len
     std::vector<u64> stage; std::vector<KPreBlk> pblk; std::vector<u32> nblk;
     d.pre_stage = nullptr; d.pre_seq_cap = 0; d.pre_blk = nullptr; d.pre_blk_cap = 0; d.pre_nblk = nullptr;
     kxemu::failed = 0;
+    // as the product: the pre-decoders take their entries in order of sequence count (the product sorts batches of 1024 and more;
+    // here every batch of 4 and more, so that the CPU suite covers the mapping)
+    std::vector<u32> skey(n, 0u), sperm(n, 0u), shist(KXP_SORT_BUCKETS, 0u);
+    bool const sorted = n >= 4 && !getenv("KXEMU_NO_PRE");
+    if (sorted) {
+        KSeqSortArgs sa;
+        sa.src = src; sa.in_off = in_off; sa.in_len = in_len; sa.n_slices = n; sa.key = skey.data(); sa.hist = shist.data(); sa.perm = sperm.data();
+        kxemu::launch_block((n + 255) / 256, 4, [&]() { zstd_seq_count_body(sa); });
+        kxemu::launch_block(1, 4, [&]() { zstd_seq_rank_body(sa); });
+        kxemu::launch_block((n + 255) / 256, 4, [&]() { zstd_seq_perm_body(sa); });
+        if (kxemu::failed) return -5;
+    }
     if (!getenv("KXEMU_NO_PRE")) {
         stage.assign((size_t)n * seq_cap, 0xCDCDCDCDCDCDCDCDull); pblk.resize((size_t)n * blk_cap); nblk.assign(n, 0u);
         KPreArgs p;
         p.src = src; p.in_off = in_off; p.in_len = in_len; p.n_slices = n;
-        p.stage = stage.data(); p.seq_cap = seq_cap; p.blk = pblk.data(); p.blk_cap = blk_cap; p.nblk = nblk.data(); p.perm = nullptr;
+        p.stage = stage.data(); p.seq_cap = seq_cap; p.blk = pblk.data(); p.blk_cap = blk_cap; p.nblk = nblk.data(); p.perm = sorted ? sperm.data() : nullptr;
         kxemu::launch((n + KXP_FRAMES - 1) / KXP_FRAMES, [&]() { zstd_seq_predecode_body(p); });
         if (kxemu::failed) return -2;
         d.pre_stage = stage.data(); d.pre_seq_cap = seq_cap; d.pre_blk = pblk.data(); d.pre_blk_cap = blk_cap; d.pre_nblk = nblk.data();
@@ -310,7 +322,7 @@ int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len
         plits.assign((size_t)n * plcap, 0xABu); plrec.resize((size_t)n * blk_cap); nlit.assign(n, 0u);
         KLitArgs p;
         p.src = src; p.in_off = in_off; p.in_len = in_len; p.n_slices = n;
-        p.lits = plits.data(); p.lit_cap = plcap; p.rec = plrec.data(); p.blk_cap = blk_cap; p.nrec = nlit.data(); p.perm = nullptr;
+        p.lits = plits.data(); p.lit_cap = plcap; p.rec = plrec.data(); p.blk_cap = blk_cap; p.nrec = nlit.data(); p.perm = sorted ? sperm.data() : nullptr;
         kxemu::launch((n + KXL_FRAMES - 1) / KXL_FRAMES, [&]() { zstd_lit_predecode_body(p); });
         if (kxemu::failed) return -3;
         d.pre_lits = plits.data(); d.pre_lit_cap = plcap; d.pre_lit = plrec.data(); d.pre_nlit = nlit.data();
