@@ -260,8 +260,9 @@ def main():
     b.set_profiling(True)
 
     if args.mode == "deflate":
-        # configs[4]: ZlibCompressor(ZlibFormat.Raw, 6) over the same slices (--level 4 .. 9: zlib's other lazy-matching levels)
-        dlevel = args.level if 4 <= args.level <= 9 else 6
+        # configs[4]: ZlibCompressor(ZlibFormat.Raw, 6) over the same slices (--level 1 .. 9: zlib's other levels; 103 = level 3, as 3 is the flag's default)
+        dlevel = args.level if (1 <= args.level <= 9 and args.level != 3) else 6      # (--level 3 is the argument's default = zstd's; DEFLATE level 3: --level 103)
+        if args.level == 103: dlevel = 3
         for _ in range(args.warmup):
             b.deflate(src, in_off, in_len, dst, out_off, out_len, level=dlevel)
         torch.cuda.synchronize()

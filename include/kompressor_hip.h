@@ -267,11 +267,12 @@ KMP_API int kmp_gzip_compress_batch(kmp_batch_ctx* ctx,
                                     uint32_t n,
                                     void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                     void* hip_stream);
-/* The three above at another of zlib's lazy-matching levels (deflate_slow: 4 .. 9, -1 = 6; ZlibCompressor(level = ...),
- * ZlibCompressor.jvm.kt:19-30 -> deflateInit2, Wrapper.cpp:20): the level's good_length / max_lazy / nice_length / max_chain
- * (4: 4 4 16 16, 5: 8 16 32 32, 6: 8 16 128 128, 7: 8 32 128 256, 8: 32 128 258 1024, 9: 32 258 258 4096) drive the same
- * kernels; the zlib header's level flags (78 5E / 78 9C / 78 DA) and gzip's XFL (2 at level 9) follow.  format: 0 raw,
- * 1 zlib, 2 gzip.  Levels 0 .. 3 (stored, deflate_fast) are not served: KMP_ERR_ARG. */
+/* The three above at another of zlib's levels (1 .. 9, -1 = 6; ZlibCompressor(level = ...),
+ * ZlibCompressor.jvm.kt:19-30 -> deflateInit2, Wrapper.cpp:20).  4 .. 9 (deflate_slow): the level's good_length / max_lazy /
+ * nice_length / max_chain (4: 4 4 16 16, 5: 8 16 32 32, 6: 8 16 128 128, 7: 8 32 128 256, 8: 32 128 258 1024,
+ * 9: 32 258 258 4096) drive the same kernels.  1 .. 3 (deflate_fast; 1: 4 4 8 4, 2: 4 5 16 8, 3: 4 6 32 32): one kernel that
+ * parses and keeps its hash chains a lane per slice.  The zlib header's level flags (78 01 / 78 5E / 78 9C / 78 DA) and gzip's
+ * XFL (4 at level 1, 2 at level 9) follow.  format: 0 raw, 1 zlib, 2 gzip.  Level 0 (stored) is not served: KMP_ERR_ARG. */
 KMP_API int kmp_deflate_compress_batch_level(kmp_batch_ctx* ctx,
                                              const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                              uint32_t n,

@@ -152,7 +152,7 @@ class ZstdBatch:
         return dst, out_off, out_len, status
 
     def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, zlib_wrapper=False, format=None, level=6):   # noqa: A002
-        """DEFLATE streams (zlib level 6 -- or any other of its lazy-matching levels, 4 .. 9 --, windowBits 15, memLevel 8),
+        """DEFLATE streams (zlib level 6 -- or any other level 1 .. 9: deflate_fast 1 .. 3, deflate_slow 4 .. 9 --, windowBits 15, memLevel 8),
         format "raw" / "zlib" / "gzip", for slices up to the context's max_slice_bytes (64 KiB at least)."""
         fmt = self._FORMATS[format] if format is not None else (1 if zlib_wrapper else 0)
         if fmt == 3:

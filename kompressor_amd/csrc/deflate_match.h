@@ -58,11 +58,11 @@ struct KdArgs {
 // what longest_match walks when the previous match was at least `good` long)
 static inline void kd_level_config(KdArgs& a, int level)        // (host side: fills the kernel arguments)
 {
-    static const u32 cfg[10][4] = { {8,16,128,128}, {8,16,128,128}, {8,16,128,128}, {8,16,128,128},
+    static const u32 cfg[10][4] = { {8,16,128,128}, { 4, 4, 8, 4 }, { 4, 5, 16, 8 }, { 4, 6, 32, 32 },     // (1 .. 3: deflate_fast, lazy = max_insert_length)
         { 4, 4, 16, 16 }, { 8, 16, 32, 32 }, { 8, 16, 128, 128 }, { 8, 32, 128, 256 }, { 32, 128, 258, 1024 }, { 32, 258, 258, 4096 } };
-    int const l = (level < 4 || level > 9) ? 6 : level;
+    int const l = (level < 1 || level > 9) ? 6 : level;
     a.good = cfg[l][0]; a.lazy = cfg[l][1]; a.nice = cfg[l][2]; a.chain = cfg[l][3];
-    a.zflg = l < 6 ? 0x5Eu : l == 6 ? 0x9Cu : 0xDAu; a.gxfl = l == 9 ? 2u : 0u;
+    a.zflg = l < 2 ? 0x01u : l < 6 ? 0x5Eu : l == 6 ? 0x9Cu : 0xDAu; a.gxfl = l == 9 ? 2u : l == 1 ? 4u : 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -336,4 +336,128 @@ KX_DEV void deflate_parse_body(const KdArgs& a)
     a.meta[slice] = mm;
 #undef KD_TALLY
 #undef KD_FLUSH
+}
+
+// ---------------------------------------------------------------------------
+// k_deflate_fast: zlib's deflate_fast (levels 1 .. 3), one lane per slice
+// ---------------------------------------------------------------------------
+// deflate_fast takes the first acceptable match at a position and, when that match is longer than max_insert_length (the
+// max_lazy column: 4 / 5 / 6), does NOT enter the strings inside it into the hash chains: the chains depend on the parse, so
+// the split into a chain kernel and a parse kernel of the lazy levels does not apply.  The chains are short instead (4 / 8 / 32
+// steps), so one lane per slice walks them straight in HBM (head and prev tables of position + 1, 32 768 words each per
+// slice, in the workspace that holds KdBest at the lazy levels); tens of thousands of slices in flight hide the latency.
+// Positions are absolute; zlib's window-relative ones are position - base, where base follows fill_window's slides:
+// an entry is NIL when it is 0 or not above base (slide_hash would have zeroed it).
+// One loop iteration handles one SYMBOL: the <= 5 insert-only positions a short match left behind and the next search
+// position.  Their head-table loads are issued together (one memory latency instead of up to six) and strings of equal hash
+// among them are put in order in registers, as the stores then are in memory.
+KX_DEV void deflate_fast_body(const KdArgs& a)
+{
+    u32 const slice = kx_block() * 64u + (u32)kx_lane();
+    if (slice >= a.n_slices) return;
+    const u8* const src = a.src + a.in_off[slice]; int const n = (int)a.in_len[slice];
+    u32* const head = (u32*)a.best + (size_t)slice * 32768u;                    // cleared by the host before the launch
+    u32* const prev = (u32*)a.best + ((size_t)a.n_slices + slice) * 32768u;     // read only where written
+    u32* const syms = a.syms + (size_t)slice * a.pos_cap;
+    KdBlockInfo* const blocks = a.blocks + (size_t)slice * a.blk_cap;
+    KdSliceMeta mm; mm.nblocks = 0; mm.nsym = 0; mm.pad[0] = 0; mm.pad[1] = 0;
+    int strstart = 0, run_n = 0;                                                // run_n: insert-only positions right before strstart
+    u32 nsym = 0, blockSyms = 0; int block_start = 0;
+    int base = 0, dataEnd = n < 2 * KD_WSIZE ? n : 2 * KD_WSIZE;               // zlib's window buffer holds [base, dataEnd), see k_deflate_parse
+    int const maxChain = (int)a.chain, niceMax = (int)a.nice, maxInsert = (int)a.lazy;
+#define KDF_FLUSH(last_, end_) { KdBlockInfo b_; \
+        b_.nsym_end = nsym; b_.end_pos = (u32)(end_); b_.start_pos = (u32)block_start; b_.stored_ok = (block_start - base >= 0) ? 1u : 0u; \
+        if (mm.nblocks < a.blk_cap) blocks[mm.nblocks] = b_; \
+        mm.nblocks++; block_start = (end_); blockSyms = 0; }
+    for (;;) {
+        if (dataEnd - strstart < KD_MIN_LOOKAHEAD) {           // (fill_window runs after the inserts of the previous round; they do not depend on it)
+            int const rel = strstart - base;
+            int const slide = (rel >= KD_WSIZE + KD_MAX_DIST) ? KD_WSIZE : 0;
+            base += slide;
+            int const more = 2 * KD_WSIZE - (dataEnd - base);
+            dataEnd += (n - dataEnd < more) ? n - dataEnd : more;
+            if (dataEnd == strstart) break;
+        }
+        int const lookahead = dataEnd - strstart;
+        u32 w = 0;                                              // the bytes at strstart
+        if (strstart + 4 <= n) w = kx_ld32(src + strstart);
+        else for (int k = 0; strstart + k < n; k++) w |= (u32)src[strstart + k] << (8 * k);
+        // the strings of the run: positions strstart - run_n .. strstart - 1 (a run is only left when 3 bytes follow the match,
+        // so the bytes up to strstart + 2 exist; the match before it started at position 1 or later, so strstart >= 4)
+        u64 x = 0;                                              // bytes strstart - 5 .. strstart + 2
+        if (run_n > 0) {
+            if (strstart >= 5) x = kx_ld64(src + strstart - 5);
+            else x = (u64)kx_ld32(src) << 8 | (u64)kx_ld16(src + 4) << 40 | (u64)src[6] << 56;     // strstart == 4: bytes -1 .. 6
+        }
+        u32 rh[5], rv[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {                           // slot k holds position strstart - 5 + k; the run is the last run_n slots
+            u32 const b = (u32)(x >> (8 * k));
+            rh[k] = kd_hash3(b & 0xFFu, (b >> 8) & 0xFFu, (b >> 16) & 0xFFu);
+            rv[k] = 0;
+            if (k >= 5 - run_n) rv[k] = head[rh[k]];
+        }
+        u32 const h = kd_hash3(w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu);
+        u32 hh = 0;                                             // INSERT_STRING: position + 1 of the previous string with this hash
+        if (lookahead >= KD_MIN_MATCH) hh = head[h];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if (k >= 5 - run_n) {
+                u32 v = rv[k];
+#pragma unroll
+                for (int j = 0; j < k; j++) if (j >= 5 - run_n && rh[j] == rh[k]) v = (u32)(strstart - 5 + j) + 1u;
+                prev[(strstart - 5 + k) & (KD_WSIZE - 1)] = v; head[rh[k]] = (u32)(strstart - 5 + k) + 1u;
+                if (rh[k] == h) hh = (u32)(strstart - 5 + k) + 1u;
+            }
+        }
+        run_n = 0;
+        if (lookahead >= KD_MIN_MATCH) { prev[strstart & (KD_WSIZE - 1)] = hh; head[h] = (u32)strstart + 1u; }
+        int match_length = KD_MIN_MATCH - 1, match_start = 0;
+        if (hh != 0 && (int)(hh - 1u) > base && strstart - (int)(hh - 1u) <= KD_MAX_DIST) {
+            // longest_match with prev_length = 2 (deflate_fast never changes it, so good_match never shortens the chain)
+            int const maxlen = lookahead < KD_MAX_MATCH ? lookahead : KD_MAX_MATCH;
+            int const nice = lookahead < niceMax ? lookahead : niceMax;
+            int const limit = (strstart - KD_MAX_DIST > base) ? strstart - KD_MAX_DIST : base;
+            int best_len = 2, chain = maxChain; int cur = (int)(hh - 1u);
+            u32 scanEnd = (w >> 8) & 0xFFFFu;                   // scan[best_len - 1], scan[best_len]
+            for (;;) {
+                const u8* const m = src + cur;
+                u32 const nx = prev[cur & (KD_WSIZE - 1)];      // (the next link is fetched beside the candidate's bytes)
+                if (kx_ld16(m + best_len - 1) == scanEnd && kx_ld16(m) == (w & 0xFFFFu)) {
+                    int len = 2;                                // (byte 2 is equal when bytes 0, 1 and the hash are)
+                    while (len < maxlen) {
+                        if (strstart + len + 8 <= n) {
+                            u64 const d = kx_ld64(m + len) ^ kx_ld64(src + strstart + len);
+                            if (d) { len += (int)(kx_ctz64(d) >> 3); break; }
+                            len += 8;
+                        } else { if (m[len] != src[strstart + len]) break; len++; }
+                    }
+                    if (len > maxlen) len = maxlen;
+                    if (len > best_len) {
+                        match_start = cur; best_len = len;
+                        if (len >= nice) break;
+                        scanEnd = kx_ld16(src + strstart + best_len - 1);
+                    }
+                }
+                if (nx == 0 || (int)(nx - 1u) <= limit || --chain == 0) break;
+                cur = (int)(nx - 1u);
+            }
+            match_length = best_len;                            // (best_len <= maxlen <= lookahead)
+        }
+        if (match_length >= KD_MIN_MATCH) {
+            syms[nsym++] = (u32)(strstart - match_start) | ((u32)(match_length - KD_MIN_MATCH) << 16); blockSyms++;
+            int const after = strstart + match_length;
+            if (match_length <= maxInsert && dataEnd - after >= KD_MIN_MATCH) run_n = match_length - 1;
+            strstart = after;
+            if (blockSyms == KD_LIT_BUFSIZE - 1) KDF_FLUSH(0, after)
+        } else {
+            syms[nsym++] = (w & 0xFFu) << 16; blockSyms++;
+            strstart++;
+            if (blockSyms == KD_LIT_BUFSIZE - 1) KDF_FLUSH(0, strstart)
+        }
+    }
+    KDF_FLUSH(1, strstart)
+    mm.nsym = nsym;
+    a.meta[slice] = mm;
+#undef KDF_FLUSH
 }

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chai
 __global__ __launch_bounds__(256) void k_deflate_chains_long(KdArgs a) { deflate_chains_body<u32>(a); }
 __global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_parse(KdArgs a) { deflate_parse_body(a); }
+__global__ __launch_bounds__(64) void k_deflate_fast(KdArgs a) { deflate_fast_body(a); }
 __global__ __launch_bounds__(64, 4) void k_deflate_encode(KdArgs a) { deflate_encode_body(a); }
 __global__ __launch_bounds__(64, 5) void k_inflate(KiArgs a) { inflate_body(a); }
 
@@ -162,6 +163,7 @@ struct kmp_batch_ctx {
     hipEvent_t ev_pre[KMP_MAX_CHUNKS + 1];      // decoder: [0] where the caller's stream stands, [1 + i] piece i pre-decoded
     // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
     u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta;      // two halves of dfl_chunk slices each
+    u32* dfl_fsyms; KdSliceMeta* dfl_fmeta; KdBlockInfo* dfl_fblocks; int dfl_ftried;          // levels 1 .. 3: symbols / blocks of 4 * dfl_chunk slices (one piece)
     u32 dfl_pos_cap, dfl_blk_cap; KdBlockInfo* dfl_blocks;                                      // positions / blocks per slice in them
     hipEvent_t dfl_searched[2], dfl_done[2]; int dfl_events;
     // frames of several blocks (max_slice_bytes above 128 KiB): per-slice state carried between the block rounds
@@ -276,6 +278,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     (void)hipFree(c->pre_lits); (void)hipFree(c->pre_lit); (void)hipFree(c->pre_nlit);
     if (c->st2) (void)hipStreamDestroy(c->st2);
     (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta); (void)hipFree(c->dfl_blocks);
+    (void)hipFree(c->dfl_fsyms); (void)hipFree(c->dfl_fmeta); (void)hipFree(c->dfl_fblocks);
     if (c->dfl_events) for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->dfl_searched[i]); (void)hipEventDestroy(c->dfl_done[i]); }
     delete c;
 }
@@ -782,12 +785,13 @@ extern "C" size_t kmp_deflate_bound(size_t n) { return n + (n >> 12) + (n >> 14)
 
 static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                               uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream, int level = 6);
-/* any of zlib's deflate_slow levels (4 .. 9; -1 = 6): the same kernels with the level's good / lazy / nice / chain numbers */
+/* any of zlib's levels 1 .. 9 (-1 = 6): 4 .. 9 (deflate_slow) are the same kernels with the level's good / lazy / nice / chain
+ * numbers, 1 .. 3 (deflate_fast) one kernel that parses and keeps its hash chains a lane per slice */
 extern "C" int kmp_deflate_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                                 uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int format, int level, void* hip_stream)
 {
     if (level == -1) level = 6;
-    if (format < 0 || format > 2 || level < 4 || level > 9) { g_last_error = "kmp_deflate_compress_batch_level: format 0 (raw), 1 (zlib) or 2 (gzip), level 4 .. 9 (zlib's lazy-matching levels)"; return KMP_ERR_ARG; }
+    if (format < 0 || format > 2 || level < 1 || level > 9) { g_last_error = "kmp_deflate_compress_batch_level: format 0 (raw), 1 (zlib) or 2 (gzip), level 1 .. 9"; return KMP_ERR_ARG; }
     return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (u32)format, hip_stream, level);
 }
 extern "C" int kmp_deflate_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
@@ -855,6 +859,48 @@ static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_
     u32 chain_waves = c->knob.dfl_chain_waves; if (chain_waves < 1 || chain_waves > 4) chain_waves = 4;
     bool const serial = c->knob.dfl_serial != 0;          // experiment switch: everything on the caller's stream
     u32 piece = 0;
+    if (level >= 1 && level <= 3) {
+        // deflate_fast needs no link / best arrays: the head / prev tables of a slice (256 KiB) live where the KdBest entries of
+        // the lazy levels do, which has room for 4 * dfl_chunk slices.  The kernel is a lane per slice and bound by memory
+        // latency, so the more slices are in flight the better: symbols and block lists for that many slices are allocated
+        // on the first call at these levels (16 GiB with the default sizes; if that fails, pieces of 2 * dfl_chunk slices use
+        // the arrays of the lazy levels).  Everything runs on the caller's stream.
+        if (!c->dfl_ftried) {
+            c->dfl_ftried = 1;
+            size_t const cap4 = (size_t)4 * c->dfl_chunk;
+            if (c->max_slices > 2u * c->dfl_chunk && !c->knob.dfl_serial) {
+                if (hipMalloc((void**)&c->dfl_fsyms, cap4 * c->dfl_pos_cap * sizeof(u32)) != hipSuccess ||
+                    hipMalloc((void**)&c->dfl_fmeta, cap4 * sizeof(KdSliceMeta)) != hipSuccess ||
+                    hipMalloc((void**)&c->dfl_fblocks, cap4 * c->dfl_blk_cap * sizeof(KdBlockInfo)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    (void)hipFree(c->dfl_fsyms); (void)hipFree(c->dfl_fmeta); (void)hipFree(c->dfl_fblocks);
+                    c->dfl_fsyms = nullptr; c->dfl_fmeta = nullptr; c->dfl_fblocks = nullptr;
+                }
+            }
+        }
+        bool const wide = c->dfl_fsyms && c->dfl_fmeta && c->dfl_fblocks;
+        u32 const span = (wide ? 4u : 2u) * c->dfl_chunk;
+        for (u32 first = 0; first < n; first += span) {
+            u32 const m = (n - first < span) ? n - first : span;
+            KdArgs a;
+            a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = c->len_ok + first; a.n_slices = m;
+            a.pos_cap = c->dfl_pos_cap; a.blk_cap = c->dfl_blk_cap;
+            a.link = c->dfl_link; a.best = c->dfl_best;
+            a.syms = wide ? c->dfl_fsyms : c->dfl_syms; a.meta = wide ? c->dfl_fmeta : c->dfl_meta; a.blocks = wide ? c->dfl_fblocks : c->dfl_blocks;
+            a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
+            kd_level_config(a, level);
+            bool const prof = c->profiling && first == 0;
+            if (prof) { HIP_TRY(hipEventRecord(c->ev[8], st)); HIP_TRY(hipEventRecord(c->ev[9], st)); HIP_TRY(hipEventRecord(c->ev[10], st)); HIP_TRY(hipEventRecord(c->ev[13], st)); }
+            HIP_TRY(hipMemsetAsync(c->dfl_best, 0, (size_t)m * 32768u * sizeof(u32), st));          // the head tables
+            hipLaunchKernelGGL(k_deflate_fast, dim3((m + 63) / 64), dim3(64), 0, st, a);
+            if (prof) HIP_TRY(hipEventRecord(c->ev[11], st));
+            hipLaunchKernelGGL(k_deflate_encode, dim3(m), dim3(64), 0, st, a);
+            if (prof) HIP_TRY(hipEventRecord(c->ev[12], st));
+            HIP_TRY(hipGetLastError());
+        }
+        if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[7], st)); c->ev_valid[3] = 1; }
+        return batch_end(c, st, d_in_len, n, dfl_cap, d_out_len, nullptr);
+    }
     for (u32 first = 0; first < n; first += c->dfl_chunk, piece++) {
         u32 const m = (n - first < c->dfl_chunk) ? n - first : c->dfl_chunk;
         u32 const h = piece & 1u;                                        // workspace half
@@ -1129,10 +1175,10 @@ struct kmp_zlib_cstream { int level, window_bits, mem_level, strategy; std::vect
 
 extern "C" kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bits, int mem_level, int strategy)
 {
-    // what deflateInit2 would accept; the GPU path implements levels 4 .. 9 (zlib's lazy-matching levels; -1 = default = 6), memLevel 8, strategy 0
+    // what deflateInit2 would accept; the GPU path implements levels 1 .. 9 (-1 = default = 6), memLevel 8, strategy 0
     if (level == -1) level = 6;
     // windowBits: -15 raw, 15 zlib wrapper, 31 (15 + 16) gzip wrapper
-    if (level < 4 || level > 9 || (window_bits != -15 && window_bits != 15 && window_bits != 31) || mem_level != 8 || strategy != 0) return nullptr;
+    if (level < 1 || level > 9 || (window_bits != -15 && window_bits != 15 && window_bits != 31) || mem_level != 8 || strategy != 0) return nullptr;
     kmp_zlib_cstream* z = new (std::nothrow) kmp_zlib_cstream();
     if (!z) return nullptr;
     z->level = level; z->window_bits = window_bits; z->mem_level = mem_level; z->strategy = strategy; z->out_pos = 0; z->stage = 0;

@@ -4,7 +4,7 @@
   ZlibFormat          .../commonMain/.../ZlibFormat.kt:32-57 (Raw negates windowBits)
   ZlibWrapper externs .../zlib/ZlibWrapper.kt:24-54 (-> jni/Wrapper.cpp)
 
-The GPU path covers ZlibFormat.Raw, Zlib and Gzip at zlib's lazy-matching levels 4 .. 9 (6, the default, is BASELINE
+The GPU path covers ZlibFormat.Raw, Zlib and Gzip at zlib's levels 1 .. 9 (6, the default, is BASELINE
 configs[4] and the reference's deflate KAT) and inflate for all of them plus AutoDetectZlibGzip."""
 import ctypes
 import weakref

@@ -417,18 +417,50 @@ static void deflate_slow_finish(dstate* s)
     FLUSH_BLOCK(s, 1);
 }
 
+/* zlib deflate.c deflate_fast (levels 1 .. 3): no lazy evaluation; the strings inside a match enter the hash chains
+ * only when the match is at most max_insert_length long (the max_lazy column of the table), so the chains depend on the parse */
+static void deflate_fast_finish(dstate* s)
+{
+    u32 hash_head; int bflush;
+    for (;;) {
+        if (s->lookahead < MIN_LOOKAHEAD) { fill_window(s); if (s->lookahead == 0) break; }
+        hash_head = NIL;
+        if (s->lookahead >= MIN_MATCH) { INSERT_STRING(s, s->strstart, hash_head); }
+        if (hash_head != NIL && s->strstart - hash_head <= MAX_DIST) s->match_length = longest_match(s, hash_head);
+        if (s->match_length >= MIN_MATCH) {
+            bflush = tally(s, s->strstart - s->match_start, s->match_length - MIN_MATCH);
+            s->lookahead -= s->match_length;
+            if (s->match_length <= s->max_lazy && s->lookahead >= MIN_MATCH) {
+                s->match_length--;
+                do { s->strstart++; INSERT_STRING(s, s->strstart, hash_head); } while (--s->match_length != 0);
+                s->strstart++;
+            } else {
+                s->strstart += s->match_length; s->match_length = 0;
+                s->ins_h = s->window[s->strstart];
+                UPDATE_HASH(s, s->ins_h, s->window[s->strstart + 1]);
+            }
+        } else {
+            bflush = tally(s, 0, s->window[s->strstart]);
+            s->lookahead--; s->strstart++;
+        }
+        if (bflush) FLUSH_BLOCK(s, 0);
+    }
+    s->insert = s->strstart < MIN_MATCH - 1 ? s->strstart : MIN_MATCH - 1;
+    FLUSH_BLOCK(s, 1);
+}
+
 DREF_API size_t dref_deflate_bound(size_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 13 + 64; }
 
-/* raw deflate at a deflate_slow level (4 .. 9; zlib's configuration_table: good_length, max_lazy, nice_length, max_chain),
+/* raw deflate at level 1 .. 9 (1 .. 3 deflate_fast, 4 .. 9 deflate_slow; zlib's configuration_table: good_length, max_lazy, nice_length, max_chain),
  * windowBits 15, memLevel 8, strategy 0, one shot. returns size or (size_t)-1 */
 DREF_API size_t dref_deflate_raw_level(u8* dst, size_t cap, const u8* src, size_t n, int level);
 DREF_API size_t dref_deflate_l6_raw(u8* dst, size_t cap, const u8* src, size_t n) { return dref_deflate_raw_level(dst, cap, src, n, 6); }
 DREF_API size_t dref_deflate_raw_level(u8* dst, size_t cap, const u8* src, size_t n, int level)
 {
-    static const u32 cfg[10][4] = { {0,0,0,0}, {0,0,0,0}, {0,0,0,0}, {0,0,0,0},
+    static const u32 cfg[10][4] = { {0,0,0,0}, { 4, 4, 8, 4 }, { 4, 5, 16, 8 }, { 4, 6, 32, 32 },
         { 4, 4, 16, 16 }, { 8, 16, 32, 32 }, { 8, 16, 128, 128 }, { 8, 32, 128, 256 }, { 32, 128, 258, 1024 }, { 32, 258, 258, 4096 } };
     dstate* s; size_t r;
-    if (level < 4 || level > 9) return (size_t)-1;
+    if (level < 1 || level > 9) return (size_t)-1;
     s = (dstate*)calloc(1, sizeof(dstate));
     if (!s) return (size_t)-1;
     s->good_match = cfg[level][0]; s->max_lazy = cfg[level][1]; s->nice_match = cfg[level][2]; s->max_chain = cfg[level][3];
@@ -439,7 +471,7 @@ DREF_API size_t dref_deflate_raw_level(u8* dst, size_t cap, const u8* src, size_
     s->bl_desc.tree = s->bl_tree; s->bl_desc.sd.stree = NULL; s->bl_desc.sd.extra = extra_blbits; s->bl_desc.sd.base = 0; s->bl_desc.sd.elems = BL_CODES; s->bl_desc.sd.max_length = 7;
     init_block(s);
     s->match_length = s->prev_length = MIN_MATCH - 1;
-    deflate_slow_finish(s);
+    if (level < 4) deflate_fast_finish(s); else deflate_slow_finish(s);
     r = s->overflow ? (size_t)-1 : s->out_pos;
     free(s);
     return r;

@@ -376,6 +376,13 @@ int emu_deflate_level(const u8* src, const u64* in_off, const u32* in_len, u32 n
     a.dst = dst; a.out_off = out_off; a.out_len = out_len; a.flags = 0; a.format = format;
     kd_level_config(a, level);
     kxemu::failed = 0;
+    if (level >= 1 && level <= 3) {
+        memset((void*)best.data(), 0, (size_t)n * 32768u * 4u);
+        kxemu::launch((n + 63) / 64, [&]() { deflate_fast_body(a); });
+        if (kxemu::failed) return -3;
+        kxemu::launch(n < 3 ? n : 3, [&]() { deflate_encode_body(a); });
+        return kxemu::failed ? -4 : 0;
+    }
     if (pos_cap <= 65536u) kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_chains_body<u16>(a); });
     else kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_chains_body<u32>(a); });
     if (kxemu::failed) return -1;

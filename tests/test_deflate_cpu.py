@@ -91,6 +91,27 @@ def test_deflate_levels_4_to_9_oracle_and_emulator_against_zlib():
         assert helpers.emu_deflate(datas[1:2], fmt=2, level=lvl)[0] == co.compress(datas[1]) + co.flush()
 
 
+def test_deflate_levels_1_to_3_oracle_and_emulator_against_zlib():
+    """zlib's deflate_fast levels (configuration_table 1: 4 4 8 4, 2: 4 5 16 8, 3: 4 6 32 32; the strings inside a match longer
+    than max_insert_length stay out of the hash chains): the oracle and k_deflate_fast's body against this Python's zlib --
+    every content class, the empty and tiny inputs, sizes around the window slide, and the wrapper bytes (78 01 / 78 5E, XFL 4)."""
+    import zlib
+    o = helpers.deflate_oracle()
+    sizes = ((0, "T"), (1, "T"), (2, "X"), (3, "X"), (4, "B"), (300, "X"), (5000, "B"), (40000, "T"), (65536, "S"), (65536, "I"),
+             (65536, "R"), (65536, "L"), (65274, "T"), (65275, "D"), (100000, "D"), (140000, "T"))
+    for lvl in (1, 2, 3):
+        datas = [corpus.make(7100 + n + lvl, 1, n, mix=ord(c)).tobytes() for n, c in sizes]
+        outs = helpers.emu_deflate(datas, level=lvl)
+        for d, f in zip(datas, outs):
+            co = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, 0)
+            ref = co.compress(d) + co.flush()
+            assert o.compress(d, lvl) == ref, (lvl, len(d))
+            assert f == ref, (lvl, len(d))
+        assert helpers.emu_deflate(datas[5:7], zlib_wrapper=True, level=lvl) == [zlib.compress(d, lvl) for d in datas[5:7]]
+        co = zlib.compressobj(lvl, zlib.DEFLATED, 31, 8, 0)
+        assert helpers.emu_deflate(datas[5:6], fmt=2, level=lvl)[0] == co.compress(datas[5]) + co.flush()
+
+
 def test_emulated_zlib_wrapper_and_inflate():
     G = helpers.deflate_golden()
     kat = G["reference_kat"]

@@ -32,7 +32,7 @@ def gpu_inflate(batch, streams, caps):
     return [out[o2[i]:o2[i] + l2[i]].tobytes() for i in range(n)], [int(x) for x in st]
 
 
-def gpu_deflate(batch, datas, level=6):
+def gpu_deflate(batch, datas, level=6, fmt=None):
     n = len(datas)
     lens = np.array([len(d) for d in datas], dtype=np.int32)
     offs = np.zeros(n, dtype=np.int64)
@@ -43,7 +43,7 @@ def gpu_deflate(batch, datas, level=6):
     host = np.zeros(pos + 64, dtype=np.uint8)
     for i, d in enumerate(datas):
         host[offs[i]:offs[i] + len(d)] = np.frombuffer(d, dtype=np.uint8)
-    dst, ooff, olen = batch.deflate(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), level=level)
+    dst, ooff, olen = batch.deflate(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), level=level, format=fmt)
     torch.cuda.synchronize()
     dst, ooff, olen = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
     return [dst[ooff[i]:ooff[i] + olen[i]].tobytes() for i in range(n)]
@@ -109,6 +109,30 @@ def test_deflate_levels_4_to_9_against_zlib(batch):
         assert st == [0] * len(datas) and back == datas, lvl
 
 
+def test_deflate_levels_1_to_3_against_zlib(batch):
+    """ZlibCompressor(level = 1 .. 3): zlib's deflate_fast (k_deflate_fast keeps the hash chains itself: strings inside a match
+    longer than max_insert_length never enter them); a ragged batch of every content class against the zlib of this Python and
+    the oracle, the wrapper bytes of the Zlib / Gzip formats, then inflated on the GPU."""
+    o = helpers.deflate_oracle()
+    S = 65536
+    buf = corpus.make(43000, 64, S)
+    datas = [buf[i * S:(i + 1) * S].tobytes() for i in range(64)]
+    datas += [buf[i * S:i * S + 1 + (i * 1777) % 65000].tobytes() for i in range(64)] + [b"", b"a", b"ab", b"abc", bytes(65536)]
+    datas += [corpus.make(43100 + k, 1, 65536, mix=ord(c)).tobytes() for k, c in enumerate("TXBSDRLI")]
+    for lvl in (1, 2, 3):
+        outs = gpu_deflate(batch, datas, level=lvl)
+        for i, (d, f) in enumerate(zip(datas, outs)):
+            co = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, 0)
+            assert f == co.compress(d) + co.flush(), (lvl, i)
+            if i % 16 == 0:
+                assert f == o.compress(d, lvl), (lvl, i)
+        back, st = gpu_inflate(batch, outs, [max(len(d), 1) for d in datas])
+        assert st == [0] * len(datas) and back == datas, lvl
+        assert gpu_deflate(batch, datas[64:68], level=lvl, fmt="zlib") == [zlib.compress(d, lvl) for d in datas[64:68]]
+        co = zlib.compressobj(lvl, zlib.DEFLATED, 31, 8, 0)
+        assert gpu_deflate(batch, datas[70:71], level=lvl, fmt="gzip")[0] == co.compress(datas[70]) + co.flush()
+
+
 def test_zlib_streaming_abi_like_the_reference():
     from kompressor_amd.zlib import ZlibCompressor, ZlibFormat
     G = helpers.deflate_golden()
@@ -132,9 +156,9 @@ def test_zlib_streaming_abi_like_the_reference():
     with pytest.raises(RuntimeError, match="Bad zlib result code -3: Z_DATA_ERROR"):
         ZlibDecompressor(ZlibFormat.Zlib).transform_bytes(zd[:-1] + bytes([zd[-1] ^ 1]))
     with pytest.raises(RuntimeError, match="Failed allocating zlib stream"):
-        ZlibCompressor(ZlibFormat.Zlib, 1)                 # deflate_fast (levels 1 .. 3) and stored (0) stay on the CPU library
-    # the other lazy-matching levels, each wrapper saying its level as zlib's does (78 5E / 78 DA, gzip XFL 2 at level 9)
-    for lvl in (4, 5, 7, 8, 9):
+        ZlibCompressor(ZlibFormat.Zlib, 0)                 # stored blocks only (level 0) stay on the CPU library
+    # the other levels, each wrapper saying its level as zlib's does (78 01 / 78 5E / 78 DA, gzip XFL 4 at level 1 and 2 at level 9)
+    for lvl in (1, 2, 3, 4, 5, 7, 8, 9):
         assert ZlibCompressor(ZlibFormat.Zlib, lvl).transform_bytes(d) == zlib.compress(d, lvl), lvl
         co = zlib.compressobj(lvl, zlib.DEFLATED, 31, 8, 0)
         assert ZlibCompressor(ZlibFormat.Gzip, lvl).transform_bytes(d) == co.compress(d) + co.flush(), lvl
