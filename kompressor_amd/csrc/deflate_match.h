@@ -369,6 +369,12 @@ KX_DEV void deflate_fast_body(const KdArgs& a)
         b_.nsym_end = nsym; b_.end_pos = (u32)(end_); b_.start_pos = (u32)block_start; b_.stored_ok = (block_start - base >= 0) ? 1u : 0u; \
         if (mm.nblocks < a.blk_cap) blocks[mm.nblocks] = b_; \
         mm.nblocks++; block_start = (end_); blockSyms = 0; }
+    // symbols leave in groups of four (one 16-byte store: the kernel is bound by the number of memory requests)
+    u32 sq0 = 0, sq1 = 0, sq2 = 0;
+#define KDF_SYM(v_) { u32 const v__ = (v_); u32 const k__ = nsym & 3u; \
+        if (k__ == 0) sq0 = v__; else if (k__ == 1) sq1 = v__; else if (k__ == 2) sq2 = v__; \
+        else kx_st128(syms + (nsym - 3u), (u64)sq0 | (u64)sq1 << 32, (u64)sq2 | (u64)v__ << 32); \
+        nsym++; blockSyms++; }
     for (;;) {
         if (dataEnd - strstart < KD_MIN_LOOKAHEAD) {           // (fill_window runs after the inserts of the previous round; they do not depend on it)
             int const rel = strstart - base;
@@ -422,7 +428,8 @@ KX_DEV void deflate_fast_body(const KdArgs& a)
             u32 scanEnd = (w >> 8) & 0xFFFFu;                   // scan[best_len - 1], scan[best_len]
             for (;;) {
                 const u8* const m = src + cur;
-                u32 const nx = prev[cur & (KD_WSIZE - 1)];      // (the next link is fetched beside the candidate's bytes)
+                u32 nx = 0;                                     // the next link, fetched beside the candidate's bytes (not behind the last step)
+                if (chain > 1) nx = prev[cur & (KD_WSIZE - 1)];
                 if (kx_ld16(m + best_len - 1) == scanEnd && kx_ld16(m) == (w & 0xFFFFu)) {
                     int len = 2;                                // (byte 2 is equal when bytes 0, 1 and the hash are)
                     while (len < maxlen) {
@@ -445,19 +452,22 @@ KX_DEV void deflate_fast_body(const KdArgs& a)
             match_length = best_len;                            // (best_len <= maxlen <= lookahead)
         }
         if (match_length >= KD_MIN_MATCH) {
-            syms[nsym++] = (u32)(strstart - match_start) | ((u32)(match_length - KD_MIN_MATCH) << 16); blockSyms++;
+            KDF_SYM((u32)(strstart - match_start) | ((u32)(match_length - KD_MIN_MATCH) << 16))
             int const after = strstart + match_length;
             if (match_length <= maxInsert && dataEnd - after >= KD_MIN_MATCH) run_n = match_length - 1;
             strstart = after;
             if (blockSyms == KD_LIT_BUFSIZE - 1) KDF_FLUSH(0, after)
         } else {
-            syms[nsym++] = (w & 0xFFu) << 16; blockSyms++;
+            KDF_SYM((w & 0xFFu) << 16)
             strstart++;
             if (blockSyms == KD_LIT_BUFSIZE - 1) KDF_FLUSH(0, strstart)
         }
     }
+    { u32 const k = nsym & 3u; u32* const q = syms + (nsym - k);                // the open group
+      if (k > 0) q[0] = sq0; if (k > 1) q[1] = sq1; if (k > 2) q[2] = sq2; }
     KDF_FLUSH(1, strstart)
     mm.nsym = nsym;
     a.meta[slice] = mm;
 #undef KDF_FLUSH
+#undef KDF_SYM
 }

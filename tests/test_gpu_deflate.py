@@ -294,6 +294,12 @@ def test_batches_larger_than_the_workspace_go_through_in_pieces(monkeypatch):
             for i, (d, f) in enumerate(zip(datas, outs)):
                 c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, 0)
                 assert f == c.compress(d) + c.flush(), (i, len(d))
+        # levels 1 .. 3 take pieces of four times that many slices, through symbol arrays of their own (first call allocates)
+        for lvl in (1, 3, 1):
+            outs = gpu_deflate(b, datas, level=lvl)
+            for i, (d, f) in enumerate(zip(datas, outs)):
+                c = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, 0)
+                assert f == c.compress(d) + c.flush(), (lvl, i, len(d))
     finally:
         b.close()
 
@@ -423,6 +429,11 @@ def test_long_slices_match_zlib_on_the_gpu():
         for d, f in zip(ragged, outs[len(inputs):]):
             c = zlib.compressobj(6, zlib.DEFLATED, -15, 8, 0)
             assert f == c.compress(d) + c.flush(), len(d)
+        for lvl in (1, 2, 3):                             # deflate_fast across the window slides (absolute positions, NIL = not above the base)
+            longs = [d for _, d in inputs] + ragged
+            for d, f in zip(longs, gpu_deflate(b, longs, level=lvl)):
+                c = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, 0)
+                assert f == c.compress(d) + c.flush(), (lvl, len(d))
         # back through the GPU inflate
         n = len(outs)
         lens = np.array([len(f) for f in outs], dtype=np.int32)
