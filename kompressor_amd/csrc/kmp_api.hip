@@ -423,6 +423,9 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_dict: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (c->big) { g_last_error = "kmp_zstd_compress_batch_dict: slices above 128 KiB are not served with a dictionary"; return KMP_ERR_CAPACITY; }
     if (dict_size < 8 || dict_size > KX_MAX_DICT) { g_last_error = "kmp_zstd_compress_batch_dict: dictionary of 8 .. 130560 bytes expected"; return KMP_ERR_CAPACITY; }
+    // a dictionary in zstd's own format (magic EC30A437: entropy tables, repeat offsets, then content) would be loaded with
+    // its tables by libzstd: taking it as raw content would give frames libzstd does not read back.  Refused.
+    if (memcmp(h_dict, "\x37\xA4\x30\xEC", 4) == 0) { g_last_error = "kmp_zstd_compress_batch_dict: formatted zstd dictionaries (magic EC30A437) are not served, raw-content dictionaries only"; return KMP_ERR_ARG; }
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));

@@ -669,6 +669,8 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
             u32 did = 0;
             for (u32 i = 0; i < didSize; i++) did |= (u32)src[pos + i] << (8 * i);
             if (did) err = KZE_DICT;
+            // (the batch's dictionary is raw content; one in zstd's own format -- magic EC30A437 -- would bring tables: refused)
+            if (a.dict_size >= 8 && kx_ld32(a.dict) == 0xEC30A437u) err = KZE_DICT;
             pos += didSize;
             if (fcsSize) {
                 hasContent = 1;

@@ -400,6 +400,14 @@ def test_decoder_with_raw_dictionary(batch):
         except RuntimeError:
             wrong = None
         assert wrong != plain, name
+    # a dictionary in zstd's own format (magic EC30A437 + tables) is refused on both sides, not taken as raw content
+    fd = b"\x37\xa4\x30\xec" + bytes(range(200)) * 4
+    dd = torch.from_numpy(np.frombuffer(fd, dtype=np.uint8).copy()).cuda()
+    out, ooff, olen, st = batch.decompress(torch.from_numpy(host).cuda(), offs, lens, cap, dictionary=dd)
+    torch.cuda.synchronize()
+    assert all(int(x) == 32 for x in st.cpu().numpy())                    # ZSTD_error_dictionary_corrupted's neighbourhood: KZE_DICT
+    with pytest.raises(RuntimeError, match="formatted zstd dictionaries"):
+        batch.compress(torch.from_numpy(host).cuda(), offs, torch.tensor([100] * 3, dtype=torch.int32).cuda(), dictionary=fd)
 
 
 def test_compress_with_raw_dictionary(batch):
