@@ -232,7 +232,7 @@ def test_emulated_streaming_frames():
     rows = helpers.levels_golden()["stream"]
     n = 0
     for (d, cuts), (size, fed, flen, sha) in zip(helpers.stream_cases(), rows):
-        if len(d) > 300000:
+        if len(d) > 300000 or n >= 12:
             continue
         empty = cuts[-1] == cuts[-2]
         f = helpers.emu_compress_big([d], G=8, stream=2 if empty else 1)[0][0]
@@ -268,7 +268,7 @@ def test_emulated_level2_multiblock_and_streams():
     suite runs all)."""
     G = helpers.level2_big_golden()
     ins = dict(helpers.multiblock_inputs())
-    rows = [r for r in G["multiblock"] if r[1] <= 300000][:8] + [r for r in G["multiblock"] if 300000 < r[1] <= 600000][:2]
+    rows = [r for r in G["multiblock"] if r[1] <= 300000][:6] + [r for r in G["multiblock"] if 300000 < r[1] <= 600000][:1]
     assert any(131072 < r[1] <= 262144 for r in rows) and any(r[1] > 262144 for r in rows)
     datas = [ins[r[0]] for r in rows]
     f0 = helpers.emu_compress_big(datas, G=8, nblocks=2, level=2)[0]
@@ -278,7 +278,7 @@ def test_emulated_level2_multiblock_and_streams():
     cases = [(d, cuts) for d, cuts in helpers.stream_cases() if len(d) <= 1024 * 1024]
     n = 0
     for (d, cuts), (size, fed, flen, sha) in zip(cases, G["stream"]):
-        if len(d) > 300000 or n >= 6:
+        if len(d) > 300000 or n >= 5:
             continue
         empty = cuts[-1] == cuts[-2]
         f = helpers.emu_compress_big([d], G=(4, 16)[n % 2], stream=2 if empty else 1, level=2)[0][0]
