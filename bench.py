@@ -318,6 +318,17 @@ def main():
                         "achieved": round(algo_piece / (ms_best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(algo_piece / (ms_best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic_best,
                         "slices_per_launch": piece, "avg_launch_ms": round(ms_best, 3)}
+        if dlevel <= 3:
+            # levels 1 .. 3: one k_deflate_fast launch over the whole batch (its time is reported in the parse slot of the events)
+            piece = n if n <= 65536 else 65536
+            algo_piece = (n * SLICE + int(lens.sum()) + 16 * n) * piece // n
+            ms_fast = float(kms.get("k_deflate_parse", 0.0)) or 1.0
+            kms = {"k_deflate_fast (with the clearing of its head tables)": ms_fast, "k_deflate_encode": float(kms.get("k_deflate_encode", 0.0))}
+            dfl_roofline = {"bound": "hbm", "kernel": "k_deflate_fast (a lane per slice; chains of dependent HBM reads, DESIGN.md section 4.4)",
+                            "achieved": round(algo_piece / (ms_fast * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(algo_piece / (ms_fast * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                            "traffic": 520_000_000_000 if (dlevel == 1 and n == 65536 and SLICE == 65536) else None,      # tools/pmc_dfl_fast.sh, DESIGN.md
+                            "slices_per_launch": piece, "avg_launch_ms": round(ms_fast, 3)}
         print(json.dumps({
             "metric": f"raw DEFLATE level-{dlevel} compression throughput, 64 KiB-slice batch (uncompressed input bytes per second)",
             "value": round(n * SLICE / (dt / args.steps) / 1e9, 3), "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -327,7 +338,7 @@ def main():
                                     f"{n} x 64 KiB slices, raw DEFLATE level {dlevel} (windowBits 15, memLevel 8)"),
                        "ratio": round(n * SLICE / float(lens.sum()), 4), "inflate_spot_check_ok": ok,
                        "gpu_inflate_GBps": round(n * SLICE / inflate_s / 1e9, 3), "gpu_inflate_roundtrip_ok": inflate_ok},
-            "kernels_ms_first_workspace_chunk": {k: round(v, 3) for k, v in kms.items()},
+            ("kernels_ms" if dlevel <= 3 else "kernels_ms_first_workspace_chunk"): {k: round(v, 3) for k, v in kms.items()},
             "roofline": dfl_roofline,
             "cpu_baseline": None if args.no_cpu else {"value": round(cpu, 4), "unit": "GB/s", "cores": cpu_cores, "kind": "reference",
                              "sample": f"first {sample} slices, zlib {_z.ZLIB_RUNTIME_VERSION} via Python, {cpu_cores} threads"}}), flush=True)
