@@ -12,6 +12,7 @@
 #include "deflate_match.h"
 #include "deflate_encode.h"
 #include "deflate_decode.h"
+#include "deflate_predecode.h"
 #include "../../include/kompressor_hip.h"
 
 #include <mutex>
@@ -77,6 +78,8 @@ __global__ __launch_bounds__(256) void k_deflate_chains_long(KdArgs a) { deflate
 __global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_parse(KdArgs a) { deflate_parse_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_fast(KdArgs a) { deflate_fast_body(a); }
+__global__ __launch_bounds__(64) void k_inflate_predecode(KipArgs a) { inflate_predecode_body(a); }
+__global__ __launch_bounds__(64) void k_inflate_exec(KieArgs a) { inflate_exec_body(a); }
 __global__ __launch_bounds__(64, 4) void k_deflate_encode(KdArgs a) { deflate_encode_body(a); }
 __global__ __launch_bounds__(64, 5) void k_inflate(KiArgs a) { inflate_body(a); }
 
@@ -181,7 +184,7 @@ struct kmp_batch_ctx {
     hipEvent_t ev_done; int have_done;
     // experiment switches, read from the environment once, when the context is created
     struct { u32 chunks, match_flags, entropy_pad, first_permille, fast_first_permille, entropy_flags, decode_flags, decode_pad, big_rounds, big_spw,
-                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre, decode_sort, decode_pieces, decode_stage_slices; } knob;
+                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre, decode_sort, decode_pieces, decode_stage_slices, inflate_pre; } knob;
 };
 
 static u32 env_u32(const char* name, u32 dflt)
@@ -253,7 +256,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     c->knob.dfl_serial = env_u32("KMP_DEFLATE_SERIAL", 0); c->knob.dfl_flags = env_u32("KMP_DEFLATE_FLAGS", 0);
     // experiment, off by default (measured slower): bit 0 = sequences decoded ahead of k_zstd_decode
     // (k_zstd_seq_predecode, one lane per frame), bit 1 = literals (k_zstd_lit_predecode, one lane per stream)
-    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1); c->knob.decode_stage_slices = env_u32("KMP_DECODE_STAGE_SLICES", 0);
+    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1); c->knob.decode_stage_slices = env_u32("KMP_DECODE_STAGE_SLICES", 0); c->knob.inflate_pre = env_u32("KMP_INFLATE_PRE", 1);
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return KMP_OK;
@@ -687,6 +690,36 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     return batch_end(c, st, d_in_len, n, c->max_slice_bytes, d_out_len, c->meta);
 }
 
+// Staging for what the pre-decode kernels leave (8 bytes per sequence -- a frame of S bytes holds at most S / 3 -- and
+// the literals): allocated on the first call that wants it, for as many entries as 48 GiB hold (all of them for the bench's
+// batches; a larger batch goes through in pieces, one after the other, that reuse the staging).  Shared by the zstd decoder
+// and inflate.
+static void ensure_pre_staging(kmp_batch_ctx* c)
+{
+    if (c->pre_tried || !c->knob.decode_pre) return;
+    c->pre_tried = 1;
+    u32 const seq_cap = c->max_slice_bytes / 3u + 64u, blk_cap = c->max_slice_bytes / 8192u + 16u, lit_cap = c->max_slice_bytes + 64u;
+    u64 const per_entry = (u64)seq_cap * 8u + (u64)lit_cap + (u64)blk_cap * (sizeof(KPreBlk) + sizeof(KPreLit)) + 64u;
+    u64 fit = c->knob.decode_stage_slices ? c->knob.decode_stage_slices : (48ull << 30) / per_entry;
+    if (fit > c->max_slices) fit = c->max_slices;
+    if (fit >= 1024u) fit &= ~1023ull;                           // (whole workgroups of every kernel)
+    u32 const ps = (u32)fit;
+    c->pre_blk_cap = blk_cap;
+    if (ps && (c->knob.decode_pre & 1u)) {
+        if (hipMalloc((void**)&c->pre_stage, (size_t)ps * seq_cap * 8u) == hipSuccess &&
+            hipMalloc((void**)&c->pre_blk, (size_t)ps * blk_cap * sizeof(KPreBlk)) == hipSuccess &&
+            hipMalloc((void**)&c->pre_nblk, (size_t)ps * 4u) == hipSuccess &&
+            hipMalloc((void**)&c->pre_sort, ((size_t)ps * 2u + KXP_SORT_BUCKETS) * 4u) == hipSuccess) { c->pre_seq_cap = seq_cap; c->pre_slices = ps; }
+        else { (void)hipGetLastError(); (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); (void)hipFree(c->pre_sort); c->pre_stage = nullptr; c->pre_blk = nullptr; c->pre_nblk = nullptr; c->pre_sort = nullptr; }
+    }
+    if (ps && (c->knob.decode_pre & 2u)) {
+        if (hipMalloc((void**)&c->pre_lits, (size_t)ps * lit_cap) == hipSuccess &&
+            hipMalloc((void**)&c->pre_lit, (size_t)ps * blk_cap * sizeof(KPreLit)) == hipSuccess &&
+            hipMalloc((void**)&c->pre_nlit, (size_t)ps * 4u) == hipSuccess) { c->pre_lit_cap = lit_cap; c->pre_slices = ps; }
+        else { (void)hipGetLastError(); (void)hipFree(c->pre_lits); (void)hipFree(c->pre_lit); (void)hipFree(c->pre_nlit); c->pre_lits = nullptr; c->pre_lit = nullptr; c->pre_nlit = nullptr; }
+    }
+}
+
 static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                 uint32_t n, void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                 uint32_t* d_out_len, uint32_t* d_status, const void* d_dict, uint32_t dict_size, void* hip_stream)
@@ -705,29 +738,7 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
     // Staging for what the pre-decode kernels leave (8 bytes per sequence -- a frame of S bytes holds at most S / 3 -- and
     // the literals): allocated on the first call, for as many entries as 48 GiB hold (all of them for the bench's batches;
     // a larger batch goes through in pieces, one after the other, that reuse the staging).
-    if (!c->pre_tried && c->knob.decode_pre) {
-        c->pre_tried = 1;
-        u32 const seq_cap = c->max_slice_bytes / 3u + 64u, blk_cap = c->max_slice_bytes / 8192u + 16u, lit_cap = c->max_slice_bytes + 64u;
-        u64 const per_entry = (u64)seq_cap * 8u + (u64)lit_cap + (u64)blk_cap * (sizeof(KPreBlk) + sizeof(KPreLit)) + 64u;
-        u64 fit = c->knob.decode_stage_slices ? c->knob.decode_stage_slices : (48ull << 30) / per_entry;
-        if (fit > c->max_slices) fit = c->max_slices;
-        if (fit >= 1024u) fit &= ~1023ull;                           // (whole workgroups of every kernel)
-        u32 const ps = (u32)fit;
-        c->pre_blk_cap = blk_cap;
-        if (ps && (c->knob.decode_pre & 1u)) {
-            if (hipMalloc((void**)&c->pre_stage, (size_t)ps * seq_cap * 8u) == hipSuccess &&
-                hipMalloc((void**)&c->pre_blk, (size_t)ps * blk_cap * sizeof(KPreBlk)) == hipSuccess &&
-                hipMalloc((void**)&c->pre_nblk, (size_t)ps * 4u) == hipSuccess &&
-                hipMalloc((void**)&c->pre_sort, ((size_t)ps * 2u + KXP_SORT_BUCKETS) * 4u) == hipSuccess) { c->pre_seq_cap = seq_cap; c->pre_slices = ps; }
-            else { (void)hipGetLastError(); (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); (void)hipFree(c->pre_sort); c->pre_stage = nullptr; c->pre_blk = nullptr; c->pre_nblk = nullptr; c->pre_sort = nullptr; }
-        }
-        if (ps && (c->knob.decode_pre & 2u)) {
-            if (hipMalloc((void**)&c->pre_lits, (size_t)ps * lit_cap) == hipSuccess &&
-                hipMalloc((void**)&c->pre_lit, (size_t)ps * blk_cap * sizeof(KPreLit)) == hipSuccess &&
-                hipMalloc((void**)&c->pre_nlit, (size_t)ps * 4u) == hipSuccess) { c->pre_lit_cap = lit_cap; c->pre_slices = ps; }
-            else { (void)hipGetLastError(); (void)hipFree(c->pre_lits); (void)hipFree(c->pre_lit); (void)hipFree(c->pre_nlit); c->pre_lits = nullptr; c->pre_lit = nullptr; c->pre_nlit = nullptr; }
-        }
-    }
+    ensure_pre_staging(c);
     d.pre_stage = nullptr; d.pre_seq_cap = 0; d.pre_blk = nullptr; d.pre_blk_cap = c->pre_blk_cap; d.pre_nblk = nullptr;
     d.pre_lits = nullptr; d.pre_lit_cap = 0; d.pre_lit = nullptr; d.pre_nlit = nullptr;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[4], st));
@@ -749,7 +760,7 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
             if (sorted) {
                 HIP_TRY(hipMemsetAsync(sort_hist, 0, (size_t)KXP_SORT_BUCKETS * 4u, st));
                 KSeqSortArgs sa;
-                sa.src = d.src; sa.in_off = d_in_off + first; sa.in_len = d_in_len + first; sa.n_slices = m; sa.key = sort_key; sa.hist = sort_hist; sa.perm = sort_perm;
+                sa.src = d.src; sa.in_off = d_in_off + first; sa.in_len = d_in_len + first; sa.n_slices = m; sa.key = sort_key; sa.hist = sort_hist; sa.perm = sort_perm; sa.len_shift = 0;
                 hipLaunchKernelGGL(k_zstd_seq_count, dim3((m + 255) / 256), dim3(256), 0, st, sa);
                 hipLaunchKernelGGL(k_zstd_seq_rank, dim3(1), dim3(256), 0, st, sa);
                 hipLaunchKernelGGL(k_zstd_seq_perm, dim3((m + 255) / 256), dim3(256), 0, st, sa);
@@ -836,6 +847,39 @@ extern "C" int kmp_inflate_batch(kmp_batch_ctx* c, const void* d_src, const uint
     a.src = (const u8*)d_src; a.in_off = d_in_off; a.in_len = d_in_len; a.n_slices = n;
     a.dst = (u8*)d_dst; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_len = d_out_len; a.status = d_status; a.format = (u32)format;
     KMP_TRY(batch_begin(c, st, nullptr, n, 0));
+    if (c->knob.inflate_pre) ensure_pre_staging(c);
+    if (c->knob.inflate_pre && c->pre_stage && c->pre_lits && c->pre_nblk && c->pre_nlit && c->pre_slices) {
+        // two kernels: a lane per stream decodes the Huffman codes into staged literals and match records (the staging of
+        // the zstd decoder), a wave per stream executes them -- and decodes the streams the first kernel did not cover
+        for (u32 first = 0; first < n; first += c->pre_slices) {
+            u32 const m = (n - first < c->pre_slices) ? n - first : c->pre_slices;
+            // streams of similar compressed size (about as many symbols) share a wave: a wave lasts as long as its longest lane
+            u32* const sort_key = c->pre_sort; u32* const sort_perm = c->pre_sort ? c->pre_sort + c->pre_slices : nullptr; u32* const sort_hist = c->pre_sort ? c->pre_sort + 2u * (size_t)c->pre_slices : nullptr;
+            bool const sorted = c->pre_sort && c->knob.decode_sort != 0 && m >= 1024u;
+            if (sorted) {
+                u32 sh = 1; while ((c->max_slice_bytes >> sh) >= KXP_SORT_BUCKETS) sh++;
+                HIP_TRY(hipMemsetAsync(sort_hist, 0, (size_t)KXP_SORT_BUCKETS * 4u, st));
+                KSeqSortArgs sa;
+                sa.src = a.src; sa.in_off = a.in_off + first; sa.in_len = a.in_len + first; sa.n_slices = m; sa.key = sort_key; sa.hist = sort_hist; sa.perm = sort_perm; sa.len_shift = sh;
+                hipLaunchKernelGGL(k_zstd_seq_count, dim3((m + 255) / 256), dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(k_zstd_seq_rank, dim3(1), dim3(256), 0, st, sa);
+                hipLaunchKernelGGL(k_zstd_seq_perm, dim3((m + 255) / 256), dim3(256), 0, st, sa);
+                HIP_TRY(hipGetLastError());
+            }
+            KipArgs p;
+            p.perm = sorted ? sort_perm : nullptr;
+            p.src = a.src; p.in_off = a.in_off + first; p.in_len = a.in_len + first; p.n_slices = m; p.out_cap = a.out_cap + first; p.format = a.format;
+            p.stage = c->pre_stage; p.seq_cap = c->pre_seq_cap; p.lits = c->pre_lits; p.lit_cap = c->pre_lit_cap; p.nseq = c->pre_nblk; p.nlit = c->pre_nlit;
+            hipLaunchKernelGGL(k_inflate_predecode, dim3((m + KIP_STREAMS - 1) / KIP_STREAMS), dim3(64), 0, st, p);
+            HIP_TRY(hipGetLastError());
+            KieArgs e;
+            e.i = a; e.i.in_off += first; e.i.in_len += first; e.i.n_slices = m; e.i.out_off += first; e.i.out_cap += first; e.i.out_len += first; e.i.status += first;
+            e.stage = c->pre_stage; e.seq_cap = c->pre_seq_cap; e.lits = c->pre_lits; e.lit_cap = c->pre_lit_cap; e.nseq = c->pre_nblk; e.nlit = c->pre_nlit;
+            hipLaunchKernelGGL(k_inflate_exec, dim3(m), dim3(64), 0, st, e);
+            HIP_TRY(hipGetLastError());
+        }
+        return batch_end(c, st, nullptr, n, 0, nullptr, nullptr);
+    }
     hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return batch_end(c, st, nullptr, n, 0, nullptr, nullptr);

@@ -83,6 +83,7 @@ KX_DEV u32 kx_alignbyte(u32 hi, u32 lo, u32 bytes) { return __builtin_amdgcn_ali
 KX_DEV u32 kx_umulhi(u32 a, u32 b) { return __umulhi(a, b); }
 KX_DEV u32 kx_ctz32(u32 v) { return (u32)__builtin_ctz(v); }
 KX_DEV u32 kx_ctz64(u64 v) { return (u32)__builtin_ctzll(v); }
+KX_DEV u32 kx_brev32(u32 v) { return __builtin_bitreverse32(v); }      // v_bfrev_b32
 KX_DEV u32 kx_clz32(u32 v) { return (u32)__builtin_clz(v); }
 KX_DEV u32 kx_hb32(u32 v) { return 31u - (u32)__builtin_clz(v); }
 KX_DEV u32 kx_popc64(u64 v) { return (u32)__builtin_popcountll(v); }

@@ -108,7 +108,8 @@ KX_DEV u32 kxp_seq_table(KPreFrameLds& fl, int t, u32 mode, const u8* p, u32 siz
 // count), rank (bucket sizes to bucket starts), perm (an entry takes the next slot of its bucket; the order inside a
 // bucket is whatever the atomics give, which changes nothing but who shares a wave).
 #define KXP_SORT_BUCKETS 256
-struct KSeqSortArgs { const u8* src; const u64* in_off; const u32* in_len; u32 n_slices; u32* key; u32* hist; u32* perm; };
+struct KSeqSortArgs { const u8* src; const u64* in_off; const u32* in_len; u32 n_slices; u32* key; u32* hist; u32* perm;
+                      u32 len_shift; };   // 0: key = sequences of the first block / 64; else key = entry bytes >> len_shift (inflate: symbols go with the compressed size)
 
 // sequences of the entry's first compressed block; 0 when there is none or anything is irregular (the pre-decoder will see that itself)
 KX_DEV u32 kxp_first_nbseq(const u8* src, u32 srcSize)
@@ -156,7 +157,7 @@ KX_DEV void zstd_seq_count_body(const KSeqSortArgs& a)          // 256 threads p
 {
     u32 const f = kx_block() * 256u + (u32)kx_wave() * 64u + (u32)kx_lane();
     if (f >= a.n_slices) return;
-    u32 k = kxp_first_nbseq(a.src + a.in_off[f], a.in_len[f]) >> 6;
+    u32 k = a.len_shift ? (a.in_len[f] >> a.len_shift) : (kxp_first_nbseq(a.src + a.in_off[f], a.in_len[f]) >> 6);
     if (k >= KXP_SORT_BUCKETS) k = KXP_SORT_BUCKETS - 1;
     a.key[f] = k;
     kx_atomic_add(a.hist + k, 1u);

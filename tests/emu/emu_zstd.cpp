@@ -300,7 +300,7 @@ int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len
     bool const sorted = n >= 4 && !getenv("KXEMU_NO_PRE");
     if (sorted) {
         KSeqSortArgs sa;
-        sa.src = src; sa.in_off = in_off; sa.in_len = in_len; sa.n_slices = n; sa.key = skey.data(); sa.hist = shist.data(); sa.perm = sperm.data();
+        sa.src = src; sa.in_off = in_off; sa.in_len = in_len; sa.n_slices = n; sa.key = skey.data(); sa.hist = shist.data(); sa.perm = sperm.data(); sa.len_shift = 0;
         kxemu::launch_block((n + 255) / 256, 4, [&]() { zstd_seq_count_body(sa); });
         kxemu::launch_block(1, 4, [&]() { zstd_seq_rank_body(sa); });
         kxemu::launch_block((n + 255) / 256, 4, [&]() { zstd_seq_perm_body(sa); });
@@ -333,11 +333,16 @@ int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len
 
 // the counting sort that orders the pre-decoders' lane slots by sequence count (zstd_predecode.h): count, rank, perm
 extern "C" __attribute__((visibility("default")))
-int emu_seq_sort(const u8* src, const u64* in_off, const u32* in_len, u32 n, u32* key, u32* perm)
+int emu_seq_sort_by(const u8* src, const u64* in_off, const u32* in_len, u32 n, u32* key, u32* perm, u32 len_shift);
+extern "C" __attribute__((visibility("default")))
+int emu_seq_sort(const u8* src, const u64* in_off, const u32* in_len, u32 n, u32* key, u32* perm) { return emu_seq_sort_by(src, in_off, in_len, n, key, perm, 0); }
+// len_shift != 0: keyed by the entry's size (what inflate's pre-decoder is given)
+extern "C" __attribute__((visibility("default")))
+int emu_seq_sort_by(const u8* src, const u64* in_off, const u32* in_len, u32 n, u32* key, u32* perm, u32 len_shift)
 {
     std::vector<u32> hist(KXP_SORT_BUCKETS, 0u);
     KSeqSortArgs sa;
-    sa.src = src; sa.in_off = in_off; sa.in_len = in_len; sa.n_slices = n; sa.key = key; sa.hist = hist.data(); sa.perm = perm;
+    sa.src = src; sa.in_off = in_off; sa.in_len = in_len; sa.n_slices = n; sa.key = key; sa.hist = hist.data(); sa.perm = perm; sa.len_shift = len_shift;
     kxemu::failed = 0;
     kxemu::launch_block((n + 255) / 256, 4, [&]() { zstd_seq_count_body(sa); });
     if (kxemu::failed) return -1;
@@ -397,7 +402,36 @@ int emu_deflate_level(const u8* src, const u64* in_off, const u32* in_len, u32 n
     return 0;
 }
 
-#include "deflate_decode.h"
+#include "deflate_predecode.h"
+// the two-kernel inflate (lane-per-stream pre-decoder, then the executor / inflate_stream for what it did not cover);
+// covered_out[i] = 1 where the pre-decoder's staging was executed.  stage_bytes: the size the staging is made for
+// (max_slice_bytes of a context)
+extern "C" __attribute__((visibility("default")))
+int emu_inflate_pre(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* dst, const u64* out_off, const u32* out_cap,
+                    u32* out_len, int* status, u32 format, u32 stage_bytes, u32* covered_out)
+{
+    u32 const seq_cap = stage_bytes / 3u + 64u, lit_cap = stage_bytes + 64u;
+    std::vector<u64> stage((size_t)n * seq_cap, 0xDDDDDDDDDDDDDDDDull);
+    std::vector<u8> lits((size_t)n * lit_cap, 0xEE);
+    std::vector<u32> nseq(n, 0x12345678u), nlit(n, 0x12345678u);
+    KipArgs p;
+    p.src = src; p.in_off = in_off; p.in_len = in_len; p.n_slices = n; p.out_cap = out_cap; p.format = format;
+    p.stage = stage.data(); p.seq_cap = seq_cap; p.lits = lits.data(); p.lit_cap = lit_cap; p.nseq = nseq.data(); p.nlit = nlit.data();
+    std::vector<u32> perm(n), skey(n);                      // the host's order: by compressed size, largest first
+    { u32 sh = 1; while ((stage_bytes >> sh) >= KXP_SORT_BUCKETS) sh++; if (emu_seq_sort_by(src, in_off, in_len, n, skey.data(), perm.data(), sh) != 0) return -3; }
+    p.perm = perm.data();
+    kxemu::failed = 0;
+    kxemu::launch((n + KIP_STREAMS - 1) / KIP_STREAMS, [&]() { inflate_predecode_body(p); });
+    if (kxemu::failed) return -1;
+    for (u32 i = 0; i < n; i++) if (covered_out) covered_out[i] = nseq[i] >> 31;
+    KieArgs e;
+    e.i.src = src; e.i.in_off = in_off; e.i.in_len = in_len; e.i.n_slices = n;
+    e.i.dst = dst; e.i.out_off = out_off; e.i.out_cap = out_cap; e.i.out_len = out_len; e.i.status = status; e.i.format = format;
+    e.stage = stage.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.nseq = nseq.data(); e.nlit = nlit.data();
+    kxemu::launch(n < 3 ? n : 3, [&]() { inflate_exec_body(e); });
+    return kxemu::failed ? -2 : 0;
+}
+
 extern "C" __attribute__((visibility("default")))
 int emu_inflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* dst, const u64* out_off, const u32* out_cap,
                 u32* out_len, int* status, u32 format)

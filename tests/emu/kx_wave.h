@@ -66,6 +66,7 @@ KX_DEV u32 kx_alignbyte(u32 hi, u32 lo, u32 bytes) { return (u32)((((u64)hi << 3
 KX_DEV u32 kx_umulhi(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
 KX_DEV u32 kx_ctz32(u32 v) { return (u32)__builtin_ctz(v); }
 KX_DEV u32 kx_ctz64(u64 v) { return (u32)__builtin_ctzll(v); }
+KX_DEV u32 kx_brev32(u32 v) { u32 r = 0; for (int i = 0; i < 32; i++) { r = (r << 1) | (v & 1u); v >>= 1; } return r; }
 KX_DEV u32 kx_clz32(u32 v) { return (u32)__builtin_clz(v); }
 KX_DEV u32 kx_hb32(u32 v) { return 31u - (u32)__builtin_clz(v); }
 KX_DEV u32 kx_popc64(u64 v) { return (u32)__builtin_popcountll(v); }

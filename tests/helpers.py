@@ -539,7 +539,7 @@ def emu_deflate(datas, zlib_wrapper=False, fmt=None, level=6):
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
 
 
-def emu_inflate(streams, caps, zlib_wrapper=False, fmt=None):
+def emu_inflate(streams, caps, zlib_wrapper=False, fmt=None, pre=True, stage_bytes=65536):
     n = len(streams)
     lens = np.array([len(f) for f in streams], dtype=np.uint32)
     offs = np.zeros(n, dtype=np.uint64)
@@ -559,9 +559,22 @@ def emu_inflate(streams, caps, zlib_wrapper=False, fmt=None):
     out = np.zeros(t + 64, dtype=np.uint8)
     olen = np.zeros(n, dtype=np.uint32)
     st = np.zeros(n, dtype=np.int32)
-    r = emu().emu_inflate(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(caps), _vp(olen), _vp(st), fmt if fmt is not None else (1 if zlib_wrapper else 0))
+    f_ = fmt if fmt is not None else (1 if zlib_wrapper else 0)
+    r = emu().emu_inflate(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(caps), _vp(olen), _vp(st), f_)
     assert r == 0, f"emulator reported {r}"
-    return [out[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)], [int(x) for x in st]
+    res = [out[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)], [int(x) for x in st]
+    if pre:
+        # the same streams through the two-kernel path (lane-per-stream pre-decoder + executor): same bytes, same status
+        out2 = np.zeros(t + 64, dtype=np.uint8)
+        olen2 = np.zeros(n, dtype=np.uint32)
+        st2 = np.zeros(n, dtype=np.int32)
+        cov = np.zeros(n, dtype=np.uint32)
+        r = emu().emu_inflate_pre(_vp(buf), _vp(offs), _vp(lens), n, _vp(out2), _vp(ooff), _vp(caps), _vp(olen2), _vp(st2), f_, int(stage_bytes), _vp(cov))
+        assert r == 0, f"emulator reported {r} (two-kernel inflate)"
+        res2 = [out2[int(ooff[i]):int(ooff[i]) + int(olen2[i])].tobytes() for i in range(n)], [int(x) for x in st2]
+        assert res2 == res, "two-kernel inflate differs from k_inflate"
+        emu_inflate.last_covered = [int(x) for x in cov]
+    return res
 
 
 def dict_cases():
