@@ -19,7 +19,7 @@
 #pragma once
 #include "deflate_decode.h"
 
-#define KIP_STREAMS 32          /* streams (active lanes) per wave */
+#define KIP_STREAMS 16          /* streams (active lanes) per wave */
 #define KIP_RING 64             /* input words per stream */
 #define KIP_SYMS 64             /* symbols per phase */
 
@@ -93,23 +93,42 @@ KX_DEV bool kip_walk(u64 buf, const u16* count, u32& index, u32& clen)
     return false;
 }
 
-// The same walk for the codes the first-level tables do not hold, without touching LDS: the counts of the lengths above
-// the table's index width are packed into one 64-bit register when the tables are built (W bits per length), together
-// with where the walk stands after the shorter lengths (first code, symbols so far).  A wave takes this path whenever one
-// of its lanes meets a long code, which is most rounds, so it must not cost fifteen LDS round trips.
+// The codes the first-level tables do not hold, without touching LDS.  A wave takes this path whenever one of its lanes
+// meets a long code -- most rounds -- so it must be short.  In a canonical code the codes of one length are a contiguous
+// range of the 15-bit left-aligned code space, and the ranges follow each other by length: with the range ends of the
+// lengths above the table width in registers (16 bits each), the length of a code is one comparison per length, and its
+// place in the canonical order is (code - start of its range) >> (15 - length) + the symbols of the shorter lengths.
+// TB: index width of the first-level table; W: bits per "symbols before this length" field.
+struct KipLong { u32 e[4]; u32 lo0; u64 ib; };
 template <int TB, int W>
-KX_DEV bool kip_walk_packed(u64 buf, u64 pack, u32 first, u32 idx, u32& index, u32& clen)
+KX_DEV void kip_long_build(const u16* count, KipLong& K)
 {
-    u32 code = (kx_brev32((u32)buf & ((1u << TB) - 1u)) >> (32 - TB)) << 1;
-    bool found = false; index = 0; clen = 0;
-#pragma unroll
+    u32 first = 0, idx = 0;
+    for (int l = 1; l <= TB; l++) { u32 const cnt = count[l]; idx += cnt; first = (first + cnt) << 1; }
+    K.lo0 = first << (15 - (TB + 1));
+    K.ib = 0; K.e[0] = 0; K.e[1] = 0; K.e[2] = 0; K.e[3] = 0;
     for (int l = TB + 1; l <= 15; l++) {
-        code |= (u32)(buf >> (l - 1)) & 1u;
-        u32 const cnt = (u32)(pack >> (W * (l - TB - 1))) & ((1u << W) - 1u);
-        if (!found && code < first + cnt) { index = idx + (code - first); clen = (u32)l; found = true; }
-        idx += cnt; first = (first + cnt) << 1; code <<= 1;
+        int const j = l - TB - 1; u32 const cnt = count[l];
+        K.ib |= (u64)idx << (W * j);
+        u32 const end = (first + cnt) << (15 - l);
+        if (j < 8) K.e[j >> 1] |= end << (16 * (j & 1));
+        idx += cnt; first = (first + cnt) << 1;
     }
-    return found;
+}
+template <int TB, int W>
+KX_DEV void kip_long(u64 buf, const KipLong& K, u32& index, u32& clen)
+{
+    u32 const c15 = kx_brev32((u32)buf) >> 17;
+    u32 k = 0, lo = K.lo0;
+#pragma unroll
+    for (int j = 0; j < 14 - TB; j++) {
+        u32 const ej = (K.e[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        bool const ge = c15 >= ej;
+        k += ge ? 1u : 0u; lo = ge ? ej : lo;
+    }
+    u32 const l = (u32)TB + 1u + k;
+    index = ((u32)(K.ib >> ((u32)W * k)) & ((1u << W) - 1u)) + ((c15 - lo) >> (15u - l));
+    clen = l;
 }
 
 KX_DEV void inflate_predecode_body(const KipArgs& a)
@@ -151,7 +170,8 @@ KX_DEV void inflate_predecode_body(const KipArgs& a)
     bool inBlock = false, last = false;
     u32 op = 0, nseq = 0, nlit = 0, ll = 0;                  // output position, records, literal bytes, literals since the last match
     u64 lq = 0;                                              // literal bytes not yet stored (nlit & 7 of them)
-    u64 lpack = 0, dpack = 0; u32 lfirst = 0, lidx = 0, dfirst = 0, didx = 0;     // the long codes of the block (kip_walk_packed)
+    KipLong LL, DL;                                          // the long codes of the block
+    LL.e[0] = LL.e[1] = LL.e[2] = LL.e[3] = 0; LL.lo0 = 0; LL.ib = 0; DL = LL;
     while (kx_any(!fin)) {
         // ---- top the ring up: every free group of four words, up to eight groups ----------------------------------------
         {
@@ -236,9 +256,7 @@ KX_DEV void inflate_predecode_body(const KipArgs& a)
                                 }
                                 code <<= 1;
                             }
-                            dpack = 0; dfirst = 0; didx = 0;
-                            for (u32 l = 1; l <= 6; l++) { u32 const cnt = S.dcount[l]; didx += cnt; dfirst = (dfirst + cnt) << 1; }
-                            for (u32 l = 7; l <= 15; l++) dpack |= (u64)S.dcount[l] << (5u * (l - 7u));
+                            kip_long_build<6, 5>(S.dcount, DL);
                             good = kip_counts(S.lcount, S.t.lens, (int)(btype == 1 ? 288u : hlit));
                         }
                         if (good) {
@@ -261,9 +279,7 @@ KX_DEV void inflate_predecode_body(const KipArgs& a)
                                 else { k += cnt; code += cnt; }
                                 code <<= 1;
                             }
-                            lpack = 0; lfirst = 0; lidx = 0;
-                            for (u32 l = 1; l <= 8; l++) { u32 const cnt = S.lcount[l]; lidx += cnt; lfirst = (lfirst + cnt) << 1; }
-                            for (u32 l = 9; l <= 15; l++) lpack |= (u64)S.lcount[l] << (9u * (l - 9u));
+                            kip_long_build<8, 9>(S.lcount, LL);
                             inBlock = true;
                         } else { ok = false; fin = true; }
                     }
@@ -280,7 +296,8 @@ KX_DEV void inflate_predecode_body(const KipArgs& a)
                 if (clen) sym = e & 511u;
                 else {
                     u32 index = 0;
-                    if (kip_walk_packed<8, 9>(br.buf, lpack, lfirst, lidx, index, clen)) sym = kip_lsym(S, index); else { sym = 999; clen = 0; }
+                    kip_long<8, 9>(br.buf, LL, index, clen);
+                    sym = index < 288u ? kip_lsym(S, index) : 999u;
                 }
                 br.buf >>= clen; br.cnt -= (int)clen;
                 if (sym < 256) {
@@ -298,7 +315,8 @@ KX_DEV void inflate_predecode_body(const KipArgs& a)
                     if (dlen) dsym = de & 511u;
                     else {
                         u32 index = 0;
-                        if (kip_walk_packed<6, 5>(br.buf, dpack, dfirst, didx, index, dlen)) dsym = S.dsort[index]; else { dsym = 99; dlen = 0; }
+                        kip_long<6, 5>(br.buf, DL, index, dlen);
+                        dsym = index < 32u ? S.dsort[index] : 99u;
                     }
                     br.buf >>= dlen; br.cnt -= (int)dlen;
                     if (dsym > 29) { ok = false; fin = true; }

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_deflate_chains_long(KdArgs a) { deflate
 __global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_parse(KdArgs a) { deflate_parse_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_fast(KdArgs a) { deflate_fast_body(a); }
-__global__ __launch_bounds__(64) void k_inflate_predecode(KipArgs a) { inflate_predecode_body(a); }
+__global__ __launch_bounds__(64, 2) void k_inflate_predecode(KipArgs a) { inflate_predecode_body(a); }
 __global__ __launch_bounds__(64) void k_inflate_exec(KieArgs a) { inflate_exec_body(a); }
 __global__ __launch_bounds__(64, 4) void k_deflate_encode(KdArgs a) { deflate_encode_body(a); }
 __global__ __launch_bounds__(64, 5) void k_inflate(KiArgs a) { inflate_body(a); }

@@ -190,6 +190,12 @@ def run_inflate(args):
     emu = helpers.emu()
     fn = emu.emu_inflate
     fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint32] + [ctypes.c_void_p] * 5 + [ctypes.c_uint32]
+    if args.pre:
+        # the two-kernel path: k_inflate_predecode (a lane per stream) + k_inflate_exec, staging made for 64 KiB slices
+        pre = emu.emu_inflate_pre
+        pre.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint32] + [ctypes.c_void_p] * 5 + [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+        cov = np.zeros(1, dtype=np.uint32)
+        fn = lambda *a: (pre(*a, 65536, helpers._vp(cov)), stats.__setitem__("covered", stats.get("covered", 0) + int(cov[0])))[0]    # noqa: E731
     stats = {"cases": 0, "accepted": 0, "rejected": 0}
     only = [s for s, _, _ in streams]
     for it in range(args.iters):
@@ -244,6 +250,7 @@ def run_inflate(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", choices=("zstd", "inflate"), default="zstd")
+    ap.add_argument("--pre", action="store_true", help="inflate: through the pre-decoder + executor kernels instead of k_inflate alone")
     ap.add_argument("--iters", type=int, default=500)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--verbose", action="store_true")

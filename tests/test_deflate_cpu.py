@@ -112,6 +112,33 @@ def test_deflate_levels_1_to_3_oracle_and_emulator_against_zlib():
         assert helpers.emu_deflate(datas[5:6], fmt=2, level=lvl)[0] == co.compress(datas[5]) + co.flush()
 
 
+def test_emulated_inflate_predecoder_covers_huffman_streams():
+    """k_inflate_predecode (a lane per stream, staging in the zstd decoder's format) + k_inflate_exec: every helpers.emu_inflate
+    call runs them beside k_inflate and compares bytes and status; here also WHICH streams the pre-decoder takes: dynamic and
+    fixed Huffman blocks of any level and strategy in all three wrappers, not stored blocks, not streams whose output is larger
+    than the staging, not damaged ones -- those fall to inflate_stream inside k_inflate_exec."""
+    import zlib
+    datas = [corpus.make(8800 + k, 1, s, mix=ord(c)).tobytes() for k, (s, c) in enumerate(
+        [(65536, "T"), (65536, "X"), (65536, "B"), (65536, "S"), (65536, "D"), (65536, "I"), (65536, "Z"), (40000, "T"), (300, "X"), (1, "T"), (0, "T")])]
+    for lvl, strat, wb, fmt in [(6, 0, -15, 0), (1, 0, -15, 0), (9, 0, 15, 1), (6, zlib.Z_FIXED, 31, 2), (6, zlib.Z_HUFFMAN_ONLY, 15, 3), (4, zlib.Z_RLE, -15, 0)]:
+        streams = []
+        for x in datas:
+            c = zlib.compressobj(lvl, zlib.DEFLATED, wb, 8, strat)
+            streams.append(c.compress(x) + c.flush())
+        outs, st = helpers.emu_inflate(streams, [max(len(x), 1) for x in datas], fmt=fmt)
+        assert st == [0] * len(datas) and outs == datas, (lvl, strat)
+        assert helpers.emu_inflate.last_covered == [1] * len(datas), (lvl, strat, helpers.emu_inflate.last_covered)
+    rnd = corpus.make(8900, 1, 65536, mix=ord("R")).tobytes()
+    big = corpus.make(8901, 1, 200000, mix=ord("T")).tobytes()
+    good = zlib.compress(datas[0], 6)
+    bad = good[:1000] + bytes([good[1000] ^ 0x40]) + good[1001:]
+    streams = [zlib.compress(rnd, 6), zlib.compress(big, 6), bad, zlib.compress(datas[1], 0), good]
+    outs, st = helpers.emu_inflate(streams, [65536, 200000, 65536, 65536, 65536], fmt=1)
+    assert st[0] == 0 and st[1] == 0 and st[2] != 0 and st[3] == 0 and st[4] == 0
+    assert outs[0] == rnd and outs[1] == big and outs[3] == datas[1] and outs[4] == datas[0]
+    assert helpers.emu_inflate.last_covered[:2] == [0, 0] and helpers.emu_inflate.last_covered[3:] == [0, 1]     # stored; above the 64 KiB staging; level 0; and a good one
+
+
 def test_emulated_zlib_wrapper_and_inflate():
     G = helpers.deflate_golden()
     kat = G["reference_kat"]

@@ -207,6 +207,48 @@ def test_inflate_batch_roundtrip_and_foreign_streams(batch):
         assert st[i] == 0 and out[o2[i]:o2[i] + l2[i]].tobytes() == plains[i], i
 
 
+def test_inflate_paths_agree_on_the_gpu(monkeypatch):
+    """The two-kernel inflate (k_inflate_predecode + k_inflate_exec, the default) and k_inflate alone (KMP_INFLATE_PRE=0) give
+    the same bytes and the same status words: streams of every level and strategy, stored blocks, damaged and truncated
+    streams, an output above the staging's slice size (those the pre-decoder leaves to inflate_stream)."""
+    from kompressor_amd.batch import ZstdBatch
+    rng = np.random.default_rng(5)
+    datas = [corpus.make(9400 + i, 1, int(rng.integers(1, 65537)), mix=ord("TXSBDIZR"[i % 8])).tobytes() for i in range(96)]
+    streams = []
+    for i, d in enumerate(datas):
+        lvl, strat = [(6, 0), (1, 0), (9, 0), (0, 0), (6, zlib.Z_FIXED), (4, zlib.Z_RLE)][i % 6]
+        c = zlib.compressobj(lvl, zlib.DEFLATED, 15, 8, strat)
+        streams.append(c.compress(d) + c.flush())
+    caps = [len(d) for d in datas]
+    for k in range(0, 96, 7):                              # damage some
+        s_ = bytearray(streams[k]); s_[len(s_) // 2] ^= 0x10; streams[k] = bytes(s_)
+    streams[3] = streams[3][:-5]
+    caps[5] = max(caps[5] - 1, 0)
+    big = corpus.make(9500, 1, 300000, mix=ord("T")).tobytes()
+    streams.append(zlib.compress(big, 6)); caps.append(len(big)); datas.append(big)
+    res = []
+    for pre in ("1", "0"):
+        monkeypatch.setenv("KMP_INFLATE_PRE", pre)
+        b = ZstdBatch(max_slices=2048, max_slice_bytes=65536)
+        try:
+            n = len(streams)
+            lens = np.array([len(f) for f in streams], dtype=np.int32)
+            offs = np.concatenate([[0], np.cumsum(lens[:-1].astype(np.int64))]).astype(np.int64)
+            host = np.frombuffer(b"".join(streams) + bytes(64), dtype=np.uint8).copy()
+            dst, ooff, olen, st = b.inflate(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(),
+                                            torch.tensor(caps, dtype=torch.int32).cuda(), format="zlib")
+            torch.cuda.synchronize()
+            dd, oo, ol, ss = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy(), st.cpu().numpy()
+            res.append(([dd[oo[i]:oo[i] + ol[i]].tobytes() for i in range(n)], [int(x) for x in ss]))
+        finally:
+            b.close()
+    assert res[0] == res[1]
+    outs, st = res[0]
+    assert st[-1] == 0 and outs[-1] == big and st[3] != 0 and st[0] != 0
+    ok = [i for i in range(96) if st[i] == 0]
+    assert len(ok) > 60 and all(outs[i] == datas[i] for i in ok)
+
+
 def test_gzip_format_and_autodetect(batch):
     """ZlibFormat.Gzip / AutoDetectZlibGzip (ZlibFormat.kt:39-55) through the batch and the streaming entry points."""
     import gzip
