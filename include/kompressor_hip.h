@@ -281,7 +281,10 @@ KMP_API int kmp_deflate_compress_batch_level(kmp_batch_ctx* ctx,
 /* inflate: n streams -> d_dst + d_out_off[i] (capacity d_out_cap[i]); format 0 = raw deflate, 1 = zlib,
  * 2 = gzip, 3 = zlib or gzip decided per stream by its first bytes (ZlibFormat.AutoDetectZlibGzip,
  * ZlibFormat.kt:52-55); checksums are verified;
- * d_status[i] = 0, -3 (Z_DATA_ERROR) or -5 (Z_BUF_ERROR: capacity too small or input truncated) */
+ * d_status[i] = 0, -3 (Z_DATA_ERROR) or -5 (Z_BUF_ERROR: capacity too small or input truncated).
+ * Runs as two kernels when the context's staging is there (allocated on the first call, shared with the zstd decoder:
+ * streams whose output fits the context's max_slice_bytes are decoded a lane per stream and executed a wave per stream;
+ * the others -- and every stream with stored blocks or an error -- by one wave per stream); any n. */
 KMP_API int kmp_inflate_batch(kmp_batch_ctx* ctx,
                               const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
                               void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
