@@ -145,6 +145,7 @@ KX_DEV void inflate_predecode_body(const KipArgs& a)
     if (live) {
         const u8* const src = a.src + a.in_off[f]; u32 const srcSize = a.in_len[f];
         cap = a.out_cap[f];
+        if (cap > a.lit_cap) cap = a.lit_cap & ~7u;              // (a stream that decodes to more than the staging holds is not covered)
         u32 spos = 0, send = srcSize, fmt = a.format;
         if (fmt == 3) fmt = (srcSize >= 2 && src[0] == 0x1F && src[1] == 0x8B) ? 2u : 1u;
         if (fmt == 2) {
@@ -302,8 +303,8 @@ KX_DEV void inflate_predecode_body(const KipArgs& a)
                 br.buf >>= clen; br.cnt -= (int)clen;
                 if (sym < 256) {
                     lq |= (u64)sym << (8u * (nlit & 7u)); nlit++; ll++; op++;
-                    if ((nlit & 7u) == 0) { if (nlit <= a.lit_cap) kx_st64(lits + (nlit - 8u), lq); lq = 0; }
-                    if (nlit > a.lit_cap || op > cap) { ok = false; fin = true; }
+                    if (op > cap) { ok = false; fin = true; }                          // (cap here is at most lit_cap: nlit <= op)
+                    else if ((nlit & 7u) == 0) { kx_st64(lits + (nlit - 8u), lq); lq = 0; }
                 } else if (sym == 256) inBlock = false;
                 else if (sym > 285) { ok = false; fin = true; }
                 else {
