@@ -197,8 +197,8 @@ def main():
                     help="compress with a raw-content dictionary of this many KiB shared by all slices (ZstdCompressor(3, dictionary))")
     ap.add_argument("--slice-kib", type=int, default=64,
                     help="slice size in KiB (64 = BASELINE configs[1]; above 128 the frames have several blocks, up to 2048)")
-    ap.add_argument("--mode", choices=["compress", "decompress", "deflate"], default="compress",
-                    help="compress = BASELINE configs[1] (the headline); decompress = configs[2] over the same frames; deflate = configs[4] (raw DEFLATE level 6)")
+    ap.add_argument("--mode", choices=["compress", "decompress", "deflate", "inflate"], default="compress",
+                    help="compress = BASELINE configs[1] (the headline); decompress = configs[2] over the same frames; deflate = configs[4] (raw DEFLATE level 6); inflate = ZlibDecompressor over configs[4]'s streams")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
@@ -259,10 +259,46 @@ def main():
     out_len = torch.zeros(n, dtype=torch.int32, device=dev)
     b.set_profiling(True)
 
-    if args.mode == "deflate":
+    if args.mode in ("deflate", "inflate"):
         # configs[4]: ZlibCompressor(ZlibFormat.Raw, 6) over the same slices (--level 1 .. 9: zlib's other levels; 103 = level 3, as 3 is the flag's default)
         dlevel = args.level if (1 <= args.level <= 9 and args.level != 3) else 6      # (--level 3 is the argument's default = zstd's; DEFLATE level 3: --level 103)
         if args.level == 103: dlevel = 3
+        if args.mode == "inflate":
+            # ZlibDecompressor(ZlibFormat.Raw) over the streams of configs[4] (made here, once): k_inflate_predecode + k_inflate_exec
+            b.deflate(src, in_off, in_len, dst, out_off, out_len, level=dlevel)
+            torch.cuda.synchronize()
+            lens = out_len.cpu().numpy().astype(np.int64)
+            cap = torch.full((n,), SLICE, dtype=torch.int32, device=dev)
+            back = torch.empty(n * SLICE + 64, dtype=torch.uint8, device=dev)
+            for _ in range(max(args.warmup, 1)):
+                b.inflate(dst, out_off, out_len, cap, dst=back, out_off=in_off)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter(); e0.record()
+            for _ in range(args.steps):
+                _, _, l2, st_ = b.inflate(dst, out_off, out_len, cap, dst=back, out_off=in_off)
+            e1.record(); torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            ok = bool(int(st_.abs().sum().item()) == 0 and torch.equal(back[: n * SLICE], src))
+            ms_pipe = e0.elapsed_time(e1) / args.steps
+            algo = n * SLICE + int(lens.sum())
+            traffic = None
+            try:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("inflate_pipeline_hbm_bytes_per_step") if (n == 65536 and dlevel == 6) else None
+            except Exception:
+                traffic = None
+            print(json.dumps({
+                "metric": f"raw DEFLATE decompression throughput, level-{dlevel} streams of 64 KiB slices (decoded bytes per second)",
+                "value": round(n * SLICE / (dt / args.steps) / 1e9, 3), "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
+                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u8", "data": "synthetic",
+                "config": {"workload": f"ZlibDecompressor(ZlibFormat.Raw) over the {n} raw DEFLATE level-{dlevel} streams of BASELINE configs[4]'s slices", "roundtrip_ok": ok},
+                "roofline": {"bound": "hbm", "kernel": "the inflate pipeline: k_inflate_predecode (a lane per stream; bound by instruction issue) then k_inflate_exec; one event bracket per step on the caller's stream",
+                             "achieved": round(algo / (ms_pipe * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(algo / (ms_pipe * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic},
+                "kernels_ms": {"inflate_pipeline": round(ms_pipe, 3)}, "cpu_baseline": None}), flush=True)
+            b.close()
+            return
         for _ in range(args.warmup):
             b.deflate(src, in_off, in_len, dst, out_off, out_len, level=dlevel)
         torch.cuda.synchronize()

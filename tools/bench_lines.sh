@@ -7,6 +7,7 @@ run() { echo "## python bench.py $*" >> $O; timeout -k 10 400 python $R/bench.py
 run --steps 5 --warmup 2
 run --mode decompress --steps 5 --warmup 2 --no-cpu
 run --mode deflate --steps 2 --warmup 1
+run --mode inflate --steps 3 --warmup 1 --no-cpu
 run --level 1 --steps 3 --warmup 1 --no-cpu
 run --level 2 --steps 3 --warmup 1 --no-cpu
 run --dict-kib 16 --steps 3 --warmup 1 --no-cpu

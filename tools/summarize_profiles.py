@@ -43,7 +43,8 @@ def main():
             ("big1m", "python3 bench.py --slice-kib 1024 --slices 8192 --steps 2 --warmup 1   (north_star slice-size sweep: 1 MiB slices, frames of several blocks)"),
             ("big256k", "python3 bench.py --slice-kib 256 --slices 32768 --steps 2 --warmup 1 --no-cpu   (slice-size sweep: 256 KiB slices)"),
             ("level1", "python3 bench.py --level 1 --steps 3 --warmup 1 --no-cpu   (65 536 x 64 KiB at level 1, the Ktor encoder's level)"),
-            ("deflate1", "python3 bench.py --mode deflate --level 1 --steps 1 --warmup 0 --no-cpu   (raw DEFLATE level 1 = deflate_fast: one k_deflate_fast launch over the batch, then the shared encoder)")]
+            ("deflate1", "python3 bench.py --mode deflate --level 1 --steps 1 --warmup 0 --no-cpu   (raw DEFLATE level 1 = deflate_fast: one k_deflate_fast launch over the batch, then the shared encoder)"),
+            ("inflate", "python3 bench.py --mode inflate --steps 3 --warmup 1 --no-cpu   (ZlibDecompressor over the 65 536 level-6 streams of configs[4]; the streams are made first)")]
     for key, cmd in runs:
         db = os.path.join(P, key, "run_results.db")
         if not os.path.exists(db):
@@ -98,7 +99,7 @@ def main():
               "zstd_match_write_requests_per_launch": int(allc.get((k, "TCC_EA0_WRREQ_sum"), (0, 1))[0] / nl),
               "note": "(FETCH_SIZE+WRITE_SIZE)*1024 / launches; the guide's x2 correction for wide coalesced reads is not applied: "
                       "this kernel's reads are scattered 4- and 8-byte probes (TCC_EA0_RDREQ_32B = 0, RDREQ*64 = FETCH_SIZE)"}
-        for kern in ("k_zstd_decode", "k_zstd_seq_predecode", "k_zstd_lit_predecode", "k_deflate_chains", "k_deflate_best", "k_deflate_parse", "k_deflate_encode", "k_inflate"):
+        for kern in ("k_zstd_decode", "k_zstd_seq_predecode", "k_zstd_lit_predecode", "k_deflate_chains", "k_deflate_best", "k_deflate_parse", "k_deflate_encode", "k_inflate", "k_inflate_predecode", "k_inflate_exec"):
             if (kern, "FETCH_SIZE") in other and (kern, "WRITE_SIZE") in other:
                 f, nl2 = other[(kern, "FETCH_SIZE")]
                 w, _ = other[(kern, "WRITE_SIZE")]
@@ -108,7 +109,9 @@ def main():
                 f, nl3 = third[(tag, kern, "FETCH_SIZE")]
                 w, _ = third[(tag, kern, "WRITE_SIZE")]
                 pj[f"{tag}:{kern}_hbm_bytes_per_launch"] = int((f + w) * 1024 / nl3)
-        pj["note_other_kernels"] = "k_zstd_decode / k_zstd_seq_predecode / k_zstd_lit_predecode: 65536 frames per launch; k_deflate_* / k_inflate: 16384 slices per launch; (FETCH_SIZE+WRITE_SIZE)*1024 / launches"
+        if "k_inflate_predecode_hbm_bytes_per_launch" in pj and "k_inflate_exec_hbm_bytes_per_launch" in pj:
+            pj["inflate_pipeline_hbm_bytes_per_step"] = pj["k_inflate_predecode_hbm_bytes_per_launch"] + pj["k_inflate_exec_hbm_bytes_per_launch"]      # (the bench.py --mode inflate pass: 65 536 streams per launch)
+        pj["note_other_kernels"] = "k_zstd_decode / k_zstd_seq_predecode / k_zstd_lit_predecode: 65536 frames per launch; k_deflate_*: 16384 slices per launch; k_inflate_predecode / k_inflate_exec: 65536 streams per launch (the --mode inflate pass); (FETCH_SIZE+WRITE_SIZE)*1024 / launches"
         json.dump(pj, open(os.path.join(outdir, "pmc_latest.json"), "w"), indent=1)
     print("\n".join(lines[:60]))
 
