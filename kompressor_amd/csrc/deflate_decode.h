@@ -304,7 +304,8 @@ KX_DEV void inflate_body(const KiArgs& a)
 {
     KX_SHARED KiLds lds;
     int const lane = kx_lane();
-    for (u32 f = kx_block(); f < a.n_slices; f += kx_nblocks()) {
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
+        u32 const f = kx_xcd_chunk(it, a.n_slices);
         inflate_stream(a, lds, f, lane);
         kx_sync();
     }

@@ -393,7 +393,8 @@ KX_DEV void deflate_encode_body(const KdArgs& a)
 {
     KX_SHARED KdEncLds lds;
     int const lane = kx_lane();
-    for (u32 slice = kx_block(); slice < a.n_slices; slice += kx_nblocks()) {
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
+        u32 const slice = kx_xcd_chunk(it, a.n_slices);
         deflate_encode_slice(a, lds, slice, lane);
         kx_sync();
     }

@@ -74,7 +74,8 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
 {
     KX_SHARED HEAD head[32768];                                  // position + 1 of the last string with that hash, 0 = none
     int const lane = kx_lane(); int const wv = kx_wave(); int const nw = kx_nwaves(); int const tid = wv * 64 + lane; int const nthreads = nw * 64;
-    for (u32 slice = kx_block(); slice < a.n_slices; slice += kx_nblocks()) {
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
+        u32 const slice = kx_xcd_chunk(it, a.n_slices);
         const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
         u16* const link = a.link + (size_t)slice * a.pos_cap;
         for (int i = tid; i < 32768; i += nthreads) head[i] = 0;
@@ -157,7 +158,8 @@ KX_DEV void deflate_best_body(const KdArgs& a)
 {
     KX_SHARED KdBestLds lds;
     int const tid = kx_wave() * 64 + kx_lane(); int const nthreads = kx_nwaves() * 64;
-    for (u32 slice = kx_block(); slice < a.n_slices; slice += kx_nblocks()) {
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
+        u32 const slice = kx_xcd_chunk(it, a.n_slices);
         const u8* const src = a.src + a.in_off[slice]; int const n = (int)a.in_len[slice];
         const u16* const link = a.link + (size_t)slice * a.pos_cap;
         KdBest* const best = a.best + (size_t)slice * a.pos_cap;

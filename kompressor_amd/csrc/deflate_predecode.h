@@ -353,7 +353,8 @@ KX_DEV void inflate_exec_body(const KieArgs& a)
 {
     KX_SHARED KiLds lds;
     int const lane = kx_lane();
-    for (u32 f = kx_block(); f < a.i.n_slices; f += kx_nblocks()) {
+    for (u32 it = kx_block(); it < a.i.n_slices; it += kx_nblocks()) {
+        u32 const f = kx_xcd_chunk(it, a.i.n_slices);
         u32 const ns = a.nseq[f];
         bool done = false;
         if (ns >> 31) {

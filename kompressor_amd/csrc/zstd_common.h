@@ -175,3 +175,13 @@ KX_DEV u64 kx_ld64_clamped(const u8* src, int p, int n)
     if (p + 8 <= n) return kx_ld64(src + p);
     return kx_ld64(src + n - 8) >> (8 * (p + 8 - n));
 }
+
+// Workgroups go to the eight XCDs round robin by their index, so with "workgroup b takes slice b" a batch whose content
+// has a period of 8 or 16 slices (the bench's class mix does: ...B at 7, R at 15 -> one XCD gets every incompressible slice)
+// leaves one XCD with the expensive slices and seven waiting for it.  Here the workgroups of one XCD take a contiguous
+// eighth of the batch instead: it (= workgroup index + k * grid size) is a virtual workgroup index out of n.
+KX_DEV u32 kx_xcd_chunk(u32 it, u32 n)
+{
+    u32 const x = it & 7u, j = it >> 3, q = n >> 3, r = n & 7u;
+    return x * q + (x < r ? x : r) + j;
+}

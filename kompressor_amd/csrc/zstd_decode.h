@@ -1066,7 +1066,8 @@ KX_DEV void zstd_decode_body(const KDecodeArgs& a)
     if (lane < 36) lds.llx[lane] = kx_ll_base((u32)lane) | (kxd_ll_bits((u32)lane) << 24);
     if (lane < 53) lds.mlx[lane] = kx_ml_base((u32)lane) | (kxd_ml_bits((u32)lane) << 24);
     kx_sync();
-    for (u32 f = kx_block(); f < a.n_slices; f += kx_nblocks()) {
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
+        u32 const f = kx_xcd_chunk(it, a.n_slices);
         zstd_decode_frame(a, lds, f, lane);
         kx_sync();
     }

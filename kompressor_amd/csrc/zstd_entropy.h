@@ -1257,7 +1257,8 @@ KX_DEV void zstd_frame_body(const KFrameArgs& a)
 {
     KX_SHARED KEntropyLds lds;
     int const lane = kx_lane();
-    for (u32 slice = kx_block(); slice < a.n_slices; slice += kx_nblocks()) {
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
+        u32 const slice = kx_xcd_chunk(it, a.n_slices);
         zstd_frame_block(a, lds, slice, lane);
         kx_sync();
     }
@@ -1278,7 +1279,8 @@ KX_DEV void zstd_big_body(const KBigArgs& a)
     int const lane = kx_lane();
     u32 const spw = a.spw;
     u32 const ngroups = (a.e.n_slices + spw - 1) / spw;
-    for (u32 grp = kx_block(); grp < ngroups; grp += kx_nblocks()) {
+    for (u32 it = kx_block(); it < ngroups; it += kx_nblocks()) {
+        u32 const grp = kx_xcd_chunk(it, ngroups);
         // this wave's slices: their blocks are parsed side by side (one team each), then coded one after the other
         u32 const base = grp * spw;
         u32 const cnt = (a.e.n_slices - base < spw) ? a.e.n_slices - base : spw;
@@ -1319,7 +1321,8 @@ KX_DEV void zstd_entropy_body(const KEntropyArgs& a)
 {
     KX_SHARED KEntropyLds lds;
     int const lane = kx_lane();
-    for (u32 slice = kx_block(); slice < a.n_slices; slice += kx_nblocks()) {
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
+        u32 const slice = kx_xcd_chunk(it, a.n_slices);
         zstd_entropy_slice(a, lds, slice, lane);
         kx_sync();
     }
