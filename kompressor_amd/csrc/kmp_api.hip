@@ -108,7 +108,8 @@ __global__ __launch_bounds__(1024) void k_scan_lengths(const u32* len, u32 n, u6
 __global__ __launch_bounds__(64) void k_compact(const u8* src, const u64* in_off, const u32* len, u32 n, u8* dst, const u64* out_off)
 {
     int const lane = threadIdx.x;
-    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+    for (u32 it = blockIdx.x; it < n; it += gridDim.x) {
+        u32 const i = kx_xcd_chunk(it, n);                  // (frame sizes follow the content's period too: zstd_common.h)
         const u8* s = src + in_off[i]; u8* d = dst + out_off[i]; u32 const L = len[i];
         u32 k = (u32)lane * 8u;
         for (; k + 8 <= L; k += 512u) kx_st64(d + k, kx_ld64(s + k));
