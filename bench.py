@@ -197,6 +197,7 @@ def main():
                     help="compress with a raw-content dictionary of this many KiB shared by all slices (ZstdCompressor(3, dictionary))")
     ap.add_argument("--slice-kib", type=int, default=64,
                     help="slice size in KiB (64 = BASELINE configs[1]; above 128 the frames have several blocks, up to 2048)")
+    ap.add_argument("--deflate-level", type=int, default=None, help="zlib level of --mode deflate / inflate (1 .. 9, default 6 = BASELINE configs[4])")
     ap.add_argument("--mode", choices=["compress", "decompress", "deflate", "inflate"], default="compress",
                     help="compress = BASELINE configs[1] (the headline); decompress = configs[2] over the same frames; deflate = configs[4] (raw DEFLATE level 6); inflate = ZlibDecompressor over configs[4]'s streams")
     args = ap.parse_args()
@@ -260,9 +261,10 @@ def main():
     b.set_profiling(True)
 
     if args.mode in ("deflate", "inflate"):
-        # configs[4]: ZlibCompressor(ZlibFormat.Raw, 6) over the same slices (--level 1 .. 9: zlib's other levels; 103 = level 3, as 3 is the flag's default)
-        dlevel = args.level if (1 <= args.level <= 9 and args.level != 3) else 6      # (--level 3 is the argument's default = zstd's; DEFLATE level 3: --level 103)
-        if args.level == 103: dlevel = 3
+        # configs[4]: ZlibCompressor(ZlibFormat.Raw, 6) over the same slices (--deflate-level 1 .. 9: zlib's other levels)
+        dlevel = args.deflate_level if args.deflate_level is not None else (args.level if (1 <= args.level <= 9 and args.level != 3) else 6)   # (--level is zstd's, default 3: it only counts here when it is not 3)
+        if not 1 <= dlevel <= 9:
+            raise SystemExit("--deflate-level 1 .. 9")
         if args.mode == "inflate":
             # ZlibDecompressor(ZlibFormat.Raw) over the streams of configs[4] (made here, once): k_inflate_predecode + k_inflate_exec
             b.deflate(src, in_off, in_len, dst, out_off, out_len, level=dlevel)

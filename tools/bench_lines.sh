@@ -19,7 +19,7 @@ run --slice-kib 1024 --slices 16384 --steps 2 --warmup 1 --no-cpu
 run --slice-kib 256 --slices 32768 --level 1 --steps 2 --warmup 1 --no-cpu
 run --slice-kib 256 --slices 32768 --level 2 --steps 2 --warmup 1 --no-cpu
 run --slice-kib 1024 --slices 8192 --level 2 --steps 2 --warmup 1 --no-cpu
-run --mode deflate --level 4 --steps 2 --warmup 1 --no-cpu
-run --mode deflate --level 1 --steps 2 --warmup 1 --no-cpu
+run --mode deflate --deflate-level 4 --steps 2 --warmup 1 --no-cpu
+run --mode deflate --deflate-level 1 --steps 2 --warmup 1 --no-cpu
 run --mode decompress --slice-kib 256 --slices 16384 --steps 3 --warmup 1 --no-cpu
 echo done

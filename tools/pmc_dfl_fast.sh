@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_f; rm -rf $O; mkdir -p $O
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   d=$O/$(echo $grp | tr ' ' '_' | cut -c1-30)
-  timeout -k 10 300 rocprofv3 --pmc $grp -d $d -o run -- python3 $R/bench.py --mode deflate --level ${LEVEL:-1} --steps 1 --warmup 0 --no-cpu > $d.out 2>$d.err || echo "pass $grp failed"
+  timeout -k 10 300 rocprofv3 --pmc $grp -d $d -o run -- python3 $R/bench.py --mode deflate --deflate-level ${LEVEL:-1} --steps 1 --warmup 0 --no-cpu > $d.out 2>$d.err || echo "pass $grp failed"
 done
 cd $R && python3 - <<'PY'
 import sqlite3,glob

@@ -43,7 +43,7 @@ def main():
             ("big1m", "python3 bench.py --slice-kib 1024 --slices 8192 --steps 2 --warmup 1   (north_star slice-size sweep: 1 MiB slices, frames of several blocks)"),
             ("big256k", "python3 bench.py --slice-kib 256 --slices 32768 --steps 2 --warmup 1 --no-cpu   (slice-size sweep: 256 KiB slices)"),
             ("level1", "python3 bench.py --level 1 --steps 3 --warmup 1 --no-cpu   (65 536 x 64 KiB at level 1, the Ktor encoder's level)"),
-            ("deflate1", "python3 bench.py --mode deflate --level 1 --steps 1 --warmup 0 --no-cpu   (raw DEFLATE level 1 = deflate_fast: one k_deflate_fast launch over the batch, then the shared encoder)"),
+            ("deflate1", "python3 bench.py --mode deflate --deflate-level 1 --steps 1 --warmup 0 --no-cpu   (raw DEFLATE level 1 = deflate_fast: one k_deflate_fast launch over the batch, then the shared encoder)"),
             ("inflate", "python3 bench.py --mode inflate --steps 3 --warmup 1 --no-cpu   (ZlibDecompressor over the 65 536 level-6 streams of configs[4]; the streams are made first)")]
     for key, cmd in runs:
         db = os.path.join(P, key, "run_results.db")
