@@ -145,7 +145,9 @@ KX_DEV void inflate_predecode_body(const KipArgs& a)
     if (live) {
         const u8* const src = a.src + a.in_off[f]; u32 const srcSize = a.in_len[f];
         cap = a.out_cap[f];
-        if (cap > a.lit_cap) cap = a.lit_cap & ~7u;              // (a stream that decodes to more than the staging holds is not covered)
+        // (a stream that decodes to more than the staging holds is not covered; the literals of one phase may run past cap
+        //  before the check at its end, so cap keeps KIP_SYMS bytes of the staging free)
+        if (cap > a.lit_cap - KIP_SYMS) cap = (a.lit_cap - KIP_SYMS) & ~7u;
         u32 spos = 0, send = srcSize, fmt = a.format;
         if (fmt == 3) fmt = (srcSize >= 2 && src[0] == 0x1F && src[1] == 0x8B) ? 2u : 1u;
         if (fmt == 2) {
@@ -303,10 +305,10 @@ KX_DEV void inflate_predecode_body(const KipArgs& a)
                 br.buf >>= clen; br.cnt -= (int)clen;
                 if (sym < 256) {
                     lq |= (u64)sym << (8u * (nlit & 7u)); nlit++; ll++; op++;
-                    if (op > cap) { ok = false; fin = true; }                          // (cap here is at most lit_cap: nlit <= op)
-                    else if ((nlit & 7u) == 0) { kx_st64(lits + (nlit - 8u), lq); lq = 0; }
+                    if ((nlit & 7u) == 0) { kx_st64(lits + (nlit - 8u), lq); lq = 0; }  // (nlit <= op <= cap + KIP_SYMS <= lit_cap: checked per phase)
                 } else if (sym == 256) inBlock = false;
                 else if (sym > 285) { ok = false; fin = true; }
+                else if (op > cap) { ok = false; fin = true; }                           // (literals ran past the capacity earlier in this phase)
                 else {
                     u32 const lc = sym - 257; u32 len, x;
                     if (lc < 8) len = 3 + lc; else if (lc == 28) len = 258;
@@ -328,9 +330,9 @@ KX_DEV void inflate_predecode_body(const KipArgs& a)
                         else { stage[nseq++] = (u64)ll | ((u64)(len - 3u) << 16) | ((u64)dist << 32); ll = 0; op += len; }
                     }
                 }
-                if (br.cnt < 0) { ok = false; fin = true; }                               // ran past the input
             }
         }
+        if (!fin && op > cap) { ok = false; fin = true; }                                 // more output than the caller's capacity (or the staging's)
     }
     if (live) {
         if (ok) { u32 const k = nlit & 7u; for (u32 i = 0; i < k; i++) lits[(nlit - k) + i] = (u8)(lq >> (8u * i)); }
