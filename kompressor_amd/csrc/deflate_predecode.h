@@ -20,8 +20,8 @@
 #include "deflate_decode.h"
 
 #define KIP_STREAMS 16          /* streams (active lanes) per wave */
-#define KIP_RING 64             /* input words per stream */
-#define KIP_SYMS 64             /* symbols per phase */
+#define KIP_RING 32             /* input words per stream */
+#define KIP_SYMS 48             /* symbols per phase */
 
 struct KipArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices; const u32* out_cap; u32 format;
