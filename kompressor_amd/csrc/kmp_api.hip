@@ -212,9 +212,11 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     u32 const need = (max_slices + teams_per_wave - 1) / teams_per_wave;
     if (blocks > need) blocks = need;
     c->match_blocks = blocks; c->nteams = blocks * teams_per_wave;
-    // the level-3 parser is transaction bound and a little faster with 12 waves per CU; the one-position-per-step parsers
-    // (levels 1 / 2, dictionary) are latency bound and want every slice in flight
-    { u32 const l3 = (u32)prop.multiProcessorCount * env_u32("KMP_MATCH_WAVES_PER_CU_L3", 12); c->match_blocks_l3 = l3 < blocks ? l3 : blocks; c->l3_team_slots = l3 * teams_per_wave; }
+    // Every parser wants every slice in flight: 16 waves per CU.  (The level-3 parser ran with 12 for most of two rounds --
+    // 49 152 team slots, a 65 536-slice batch in two launches with the entropy kernel of the first beside the second: 251 ms.
+    // That optimum belonged to an entropy kernel that was a third slower than it had to be (zstd_common.h kx_xcd_chunk);
+    // with it fixed, one launch of each kernel at 16 waves per CU takes 191 + 27 ms.)
+    { u32 const l3 = (u32)prop.multiProcessorCount * env_u32("KMP_MATCH_WAVES_PER_CU_L3", 16); c->match_blocks_l3 = l3 < blocks ? l3 : blocks; c->l3_team_slots = l3 * teams_per_wave; }
     c->big = c->max_slice_bytes > KMP_MAX_SLICE_BYTES;
     u32 const block_cap = c->big ? KMP_MAX_SLICE_BYTES : c->max_slice_bytes;     // the sequence / literal workspaces hold one block
     c->seq_cap = (block_cap / 4 + 8 + 15) & ~15u; c->lit_cap = block_cap + 64; c->scratch_words = block_cap / 4 + 64;
