@@ -163,6 +163,10 @@ struct kmp_batch_ctx {
     KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* team_epoch; u32* counter;
     int profiling; hipEvent_t ev[14]; int ev_valid[7];
     // zstd compress pipeline: entropy coding of chunk i (second stream) runs beside the match kernel of chunk i+1
+    // level 3, batches of more than half the team slots: one launch of each kernel or two chunks?  Tried once each on the
+    // context's first two such batches (whole-step HIP events), then the faster stays -- the parse kernel's time differs
+    // by 17 % between runs of the same box, and which setting wins depends on it.
+    int tune_state; int tune_pending; u32 tune_pick; float tune_ms[2]; hipEvent_t tune_ev[2];
     hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join, ev_last_match; int have_last_match; u32 last_chunks;
     hipEvent_t ev_pre[KMP_MAX_CHUNKS + 1];      // decoder: [0] where the caller's stream stands, [1 + i] piece i pre-decoded
     // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
@@ -185,7 +189,7 @@ struct kmp_batch_ctx {
     hipEvent_t ev_done; int have_done;
     // experiment switches, read from the environment once, when the context is created
     struct { u32 chunks, match_flags, entropy_pad, first_permille, fast_first_permille, entropy_flags, decode_flags, decode_pad, big_rounds, big_spw,
-                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre, decode_sort, decode_pieces, decode_stage_slices, inflate_pre, inflate_pieces; } knob;
+                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre, decode_sort, decode_pieces, decode_stage_slices, inflate_pre, inflate_pieces, autotune; } knob;
 };
 
 static u32 env_u32(const char* name, u32 dflt)
@@ -244,6 +248,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     HIP_TRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { HIP_TRY(hipEventCreate(&c->evm[i][j])); HIP_TRY(hipEventCreate(&c->eve[i][j])); }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&c->tune_ev[0])); HIP_TRY(hipEventCreate(&c->tune_ev[1]));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_last_match, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     for (int i = 0; i <= KMP_MAX_CHUNKS; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_pre[i], hipEventDisableTiming));
@@ -259,7 +264,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     c->knob.dfl_serial = env_u32("KMP_DEFLATE_SERIAL", 0); c->knob.dfl_flags = env_u32("KMP_DEFLATE_FLAGS", 0);
     // experiment, off by default (measured slower): bit 0 = sequences decoded ahead of k_zstd_decode
     // (k_zstd_seq_predecode, one lane per frame), bit 1 = literals (k_zstd_lit_predecode, one lane per stream)
-    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1); c->knob.decode_stage_slices = env_u32("KMP_DECODE_STAGE_SLICES", 0); c->knob.inflate_pre = env_u32("KMP_INFLATE_PRE", 1); c->knob.inflate_pieces = env_u32("KMP_INFLATE_PIECES", 1);
+    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1); c->knob.decode_stage_slices = env_u32("KMP_DECODE_STAGE_SLICES", 0); c->knob.inflate_pre = env_u32("KMP_INFLATE_PRE", 1); c->knob.inflate_pieces = env_u32("KMP_INFLATE_PIECES", 1); c->knob.autotune = env_u32("KMP_ZSTD_AUTOTUNE", 1);
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return KMP_OK;
@@ -276,6 +281,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { if (c->evm[i][j]) (void)hipEventDestroy(c->evm[i][j]); if (c->eve[i][j]) (void)hipEventDestroy(c->eve[i][j]); }
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (int i = 0; i < 2; i++) if (c->tune_ev[i]) (void)hipEventDestroy(c->tune_ev[i]);
     if (c->ev_last_match) (void)hipEventDestroy(c->ev_last_match);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     for (int i = 0; i <= KMP_MAX_CHUNKS; i++) if (c->ev_pre[i]) (void)hipEventDestroy(c->ev_pre[i]);
@@ -641,11 +647,23 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     // 32 768 x 128 KiB -> 1: 17.7 GB/s against 13.1 with two half-empty launches)
     u32 const team_slots = c->l3_team_slots;                 // what the device holds, whatever this context's max_slices
     u32 chunks = c->knob.chunks ? c->knob.chunks : (n > team_slots ? 2u : 1u);       // measured: 49 152 slices (= the slots) 16.4 GB/s in one launch, 15.5 in two; 57 344: 15.2 / 16.2
+    bool const tunable = !c->knob.chunks && c->knob.autotune && n <= team_slots && 2u * n > team_slots;
+    if (tunable) {
+        if (c->tune_pending) {                       // the previous such batch was a trial: its whole-step time
+            c->tune_pending = 0;
+            float ms = 0;
+            if (hipEventSynchronize(c->tune_ev[1]) == hipSuccess && hipEventElapsedTime(&ms, c->tune_ev[0], c->tune_ev[1]) == hipSuccess) c->tune_ms[c->tune_state++] = ms;
+            else { (void)hipGetLastError(); c->tune_state = 2; c->tune_pick = 0; }
+            if (c->tune_state == 2 && c->tune_ms[1] > 0) c->tune_pick = c->tune_ms[1] < c->tune_ms[0] ? 1u : 0u;
+        }
+        chunks = (c->tune_state < 2 ? (u32)c->tune_state : c->tune_pick) ? 2u : 1u;
+    }
     if (chunks < 1) chunks = 1; if (chunks > KMP_MAX_CHUNKS) chunks = KMP_MAX_CHUNKS; if (chunks > n) chunks = 1;
     // One batch at a time per context (the sequence / literal / scratch workspaces and the team tables are shared): a
     // batch queued on another stream waits for the last kernel of the previous one.  (Letting the next batch's match
     // kernel start beside this batch's last entropy launch was measured and gave nothing: DESIGN.md section 8.)
     KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
+    if (tunable && c->tune_state < 2) HIP_TRY(hipEventRecord(c->tune_ev[0], st));
     HIP_TRY(hipMemsetAsync(c->counter, 0, 4 * KMP_MAX_CHUNKS, st));
     u32 const tpw = 64 / (u32)c->G;
     u32 const match_flags = c->knob.match_flags, entropy_pad = c->knob.entropy_pad;   // experiments only
@@ -690,6 +708,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     if (forked) { HIP_TRY(hipEventRecord(c->ev_join, c->st2)); HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0)); }
     c->last_chunks = chunks;
     if (c->profiling) { c->ev_valid[0] = 1; c->ev_valid[1] = 1; }
+    if (tunable && c->tune_state < 2) { HIP_TRY(hipEventRecord(c->tune_ev[1], st)); c->tune_pending = 1; }
     return batch_end(c, st, d_in_len, n, c->max_slice_bytes, d_out_len, c->meta);
 }
 
