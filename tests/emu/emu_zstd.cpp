@@ -443,3 +443,8 @@ int emu_inflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* 
     kxemu::launch(n < 3 ? n : 3, [&]() { inflate_body(a); });
     return kxemu::failed ? -1 : 0;
 }
+
+// kx_xcd_chunk (zstd_common.h): the slice a virtual workgroup index takes
+extern "C" __attribute__((visibility("default")))
+unsigned emu_xcd_chunk(unsigned it, unsigned n) { return kx_xcd_chunk(it, n); }
+

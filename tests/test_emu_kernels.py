@@ -373,3 +373,21 @@ def test_reference_driver_frames_and_a_wrapped_staging_buffer_on_the_emulator():
         for mode, key in modes:
             f, _ = helpers.emu_compress_big([d], G=16, nblocks=1, stream=mode)
             assert len(f[0]) == rows[name][key + "_len"] and helpers.sha256(f[0]) == rows[name][key + "_sha256"], (name, key)
+
+
+def test_xcd_aware_slice_mapping_is_a_bijection_with_contiguous_chunks():
+    """kx_xcd_chunk: workgroup b (on XCD b % 8) takes a slice out of a contiguous eighth of the batch; every slice is taken
+    exactly once for any batch size, and the workgroups of one XCD walk their chunk in order."""
+    import ctypes
+    f = helpers.emu().emu_xcd_chunk
+    f.restype = ctypes.c_uint32
+    f.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    for n in (1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 100, 1000, 4099, 65536):
+        got = [f(i, n) for i in range(n)]
+        assert sorted(got) == list(range(n)), n
+        for x in range(min(8, n)):
+            mine = got[x::8]
+            assert mine == list(range(mine[0], mine[0] + len(mine))), (n, x)       # contiguous, ascending
+        starts = [got[x] for x in range(min(8, n))]
+        assert starts == sorted(starts)
+
