@@ -196,6 +196,19 @@ def test_full_batch_roundtrip_and_checksum_of_checksums():
     assert torch.equal(out[: n * S], src)
     ratio = n * S / float(lens.astype(np.int64).sum())
     assert 2.3 < ratio < 2.7, ratio
+    # a context tries "one launch of each kernel" on its first batch of this size and "two chunks" on its second, then keeps
+    # the faster (kmp_api.hip): all of them give the same frames
+    first_lens = olen.clone(); probe = [int(ooff[i]) for i in (0, 1, 40000, n - 1)]
+    first_bytes = [dst[o:o + int(first_lens[i])].clone() for o, i in zip(probe, (0, 1, 40000, n - 1))]
+    seen = {b.last_chunks()}
+    for _ in range(2):
+        dst2, ooff2, olen2 = b.compress(src, in_off, in_len, dst, ooff, olen)
+        torch.cuda.synchronize()
+        seen.add(b.last_chunks())
+        assert torch.equal(olen2, first_lens)
+        for o, i, fb in zip(probe, (0, 1, 40000, n - 1), first_bytes):
+            assert torch.equal(dst2[o:o + int(first_lens[i])], fb)
+    assert seen == {1, 2}
     # dense packing helper: offsets are the exclusive scan, bytes unchanged
     packed, offs = b.compact(dst, ooff, olen)
     torch.cuda.synchronize()
