@@ -311,6 +311,10 @@ KMP_API int kmp_batch_last_chunks(kmp_batch_ctx* ctx);
 /* A context for slices above 128 KiB compresses block by block (libzstd decides each block's size from the bytes
  * produced so far): block rounds of the last batch. */
 KMP_API int kmp_batch_last_rounds(kmp_batch_ctx* ctx);
+/* diagnostic (no reference counterpart): milliseconds of blocks x 256 threads x iters random 4-byte read + write pairs over the
+ * device region [d_region, d_region + bytes) -- the access pattern of the level-3 parser's tables.  The rate differs between
+ * regions of one device's HBM (tools/region_probe.py). */
+KMP_API int kmp_debug_probe_region(void* d_region, size_t bytes, uint32_t blocks, uint32_t iters, float* ms, void* hip_stream);
 
 KMP_API const char* kmp_last_error(void);
 KMP_API const char* kmp_version(void);

@@ -151,6 +151,37 @@ static int hip_fail(hipError_t e, const char* what)
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
 
 extern "C" const char* kmp_last_error(void) { return g_last_error.c_str(); }
+
+// Random 4-byte read-modify-writes over a region, the way the level-3 parser touches its tables: how fast is THIS piece
+// of HBM?  (The rate differs by a sixth between regions of one device: DESIGN.md section 5a; tools/region_probe.py.)
+__global__ __launch_bounds__(256) void k_region_probe(u32* p, u64 words, u32 iters, u32 salt)
+{
+    u64 x = ((u64)blockIdx.x * 256u + threadIdx.x) * 0x9E3779B97F4A7C15ull + salt;
+    u32 acc = 0;
+    for (u32 i = 0; i < iters; i++) {
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        u64 const w = x % words;
+        u32 const v = kx_ld_nt(p + w);
+        acc += v;
+        kx_st_nt(p + ((w * 2654435761ull + 12345u) % words), v + i);
+    }
+    if (acc == 0x12345678u) p[0] = acc;
+}
+// milliseconds for blocks x 256 threads x iters random read + write pairs over [p, p + bytes)
+extern "C" int kmp_debug_probe_region(void* p, size_t bytes, uint32_t blocks, uint32_t iters, float* ms, void* hip_stream)
+{
+    if (!p || bytes < 4096 || !ms) { g_last_error = "kmp_debug_probe_region: bad argument"; return KMP_ERR_ARG; }
+    hipStream_t const st = (hipStream_t)hip_stream;
+    hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_region_probe, dim3(blocks), dim3(256), 0, st, (u32*)p, (u64)(bytes / 4), 8u, 1u);       // warm
+    HIP_TRY(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_region_probe, dim3(blocks), dim3(256), 0, st, (u32*)p, (u64)(bytes / 4), iters, 7u);
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return KMP_OK;
+}
 extern "C" const char* kmp_version(void) { return "kompressor_hip 0.2 (gfx950; zstd level 3 frames up to 2 MiB, deflate level 6)"; }
 
 // --------------------------------------------------------------------------
@@ -166,6 +197,7 @@ struct kmp_batch_ctx {
     // level 3, batches of more than half the team slots: one launch of each kernel or two chunks?  Tried once each on the
     // context's first two such batches (whole-step HIP events), then the faster stays -- the parse kernel's time differs
     // by 17 % between runs of the same box, and which setting wins depends on it.
+    float place_ms; u32 place_tried;            // the team tables' placement: probe time of the region kept, candidates tried
     int tune_state; int tune_pending; u32 tune_pick; float tune_ms[2]; hipEvent_t tune_ev[2];
     hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join, ev_last_match; int have_last_match; u32 last_chunks;
     hipEvent_t ev_pre[KMP_MAX_CHUNKS + 1];      // decoder: [0] where the caller's stream stands, [1 + i] piece i pre-decoded
@@ -238,7 +270,29 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     HIP_TRY(hipMalloc((void**)&c->lits, ns * c->lit_cap));
     HIP_TRY(hipMalloc((void**)&c->meta, ns * sizeof(KSliceMeta)));
     HIP_TRY(hipMalloc((void**)&c->scratch, ns * c->scratch_words * sizeof(u32)));
-    HIP_TRY(hipMalloc((void**)&c->tables, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
+    {
+        // Where the team tables land matters: the random-access rate of this device's HBM differs by a sixth between
+        // regions (tools/region_probe.py: two of ten 24 GiB regions give 27.5 G accesses/s, the others 34 - 37), and the
+        // parsers live off that rate.  Large tables are therefore placed by trial: up to KMP_PLACE_TRIES (default 3)
+        // allocations are probed with the tables' access pattern (k_region_probe, ~30 ms each), the fastest stays, the
+        // others are freed.  (The candidates are held until the choice is made so that each lands somewhere else; an
+        // allocation that fails ends the search.)
+        size_t const tbytes = (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32);
+        u32 tries = env_u32("KMP_PLACE_TRIES", 3); if (tries < 1) tries = 1; if (tries > 6) tries = 6;
+        if (tbytes < ((size_t)4 << 30)) tries = 1;
+        u32* cand[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; float ms[6] = { 0, 0, 0, 0, 0, 0 };
+        u32 got = 0, best = 0;
+        for (u32 t = 0; t < tries; t++) {
+            if (hipMalloc((void**)&cand[t], tbytes) != hipSuccess) { (void)hipGetLastError(); cand[t] = nullptr; break; }
+            got = t + 1;
+            if (tries > 1 && kmp_debug_probe_region(cand[t], tbytes, 4096u, 384u, &ms[t], nullptr) != KMP_OK) { ms[t] = 1e30f; }
+            if (ms[t] < ms[best]) best = t;
+        }
+        if (got == 0) return hip_fail(hipErrorOutOfMemory, "hipMalloc(team tables)");
+        for (u32 t = 0; t < got; t++) if (t != best) (void)hipFree(cand[t]);
+        c->tables = cand[best];
+        c->place_ms = ms[best]; c->place_tried = got;
+    }
     HIP_TRY(hipMalloc((void**)&c->team_epoch, (size_t)c->nteams * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->counter, 64));
     HIP_TRY(hipMemset(c->tables, 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
