@@ -230,6 +230,35 @@ static u32 env_u32(const char* name, u32 dflt)
     return (v && *v) ? (u32)strtoul(v, nullptr, 10) : dflt;
 }
 
+// Where a randomly accessed table lands matters: the random-access rate of this device's HBM differs by a sixth between
+// regions (tools/region_probe.py: two of ten 24 GiB regions give 27.5 G accesses/s, the others 34 - 37), and the parsers
+// live off that rate.  Large tables are therefore placed by trial: up to KMP_PLACE_TRIES (default 6) allocations are
+// probed with the tables' access pattern (k_region_probe, ~30 ms each) until one is of the fast kind; the fastest stays, the
+// others are freed.  (The
+// candidates are held until the choice is made so that each lands somewhere else; an allocation that fails ends the search.)
+static int place_alloc(u32** out, size_t bytes, float* kept_ms, u32* tried_out)
+{
+    u32 tries = env_u32("KMP_PLACE_TRIES", 6); if (tries < 1) tries = 1; if (tries > 6) tries = 6;
+    if (bytes < ((size_t)4 << 30)) tries = 1;
+    u32* cand[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; float ms[6] = { 0, 0, 0, 0, 0, 0 };
+    u32 got = 0, best = 0;
+    for (u32 t = 0; t < tries; t++) {
+        if (hipMalloc((void**)&cand[t], bytes) != hipSuccess) { (void)hipGetLastError(); cand[t] = nullptr; break; }
+        got = t + 1;
+        if (tries > 1 && kmp_debug_probe_region(cand[t], bytes, 4096u, 384u, &ms[t], nullptr) != KMP_OK) ms[t] = 1e30f;
+        if (ms[t] < ms[best]) best = t;
+        // 805 M accesses: the fast kind of region takes 23.5 ms (34 G/s), the slow kind 29.2 (27.6 G/s) on an MI355X
+        if (ms[t] <= 26.0f) break;
+    }
+    if (got == 0) return hip_fail(hipErrorOutOfMemory, "hipMalloc(parser tables)");
+    if (env_u32("KMP_PLACE_VERBOSE", 0)) { fprintf(stderr, "place_alloc %zu MiB:", bytes >> 20); for (u32 t = 0; t < got; t++) fprintf(stderr, " %.1f ms%s", ms[t], t == best ? "*" : ""); fprintf(stderr, "\n"); }
+    for (u32 t = 0; t < got; t++) if (t != best) (void)hipFree(cand[t]);
+    *out = cand[best];
+    if (kept_ms) *kept_ms = ms[best];
+    if (tried_out) *tried_out = got;
+    return KMP_OK;
+}
+
 extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes)
 {
     if (!out || max_slices == 0) { g_last_error = "kmp_batch_create: bad argument"; return KMP_ERR_ARG; }
@@ -262,7 +291,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
         if (c->big_G != 0 && c->big_G != 2 && c->big_G != 4 && c->big_G != 8 && c->big_G != 16 && c->big_G != 32 && c->big_G != 64) c->big_G = 0;
         HIP_TRY(hipMalloc((void**)&c->fstate, ns * sizeof(KFrameState)));
         HIP_TRY(hipMalloc((void**)&c->hufct, ns * 512 * sizeof(u32)));
-        HIP_TRY(hipMalloc((void**)&c->big_tables, ns * KX_BIG_TBL_ENTRIES * sizeof(u32)));
+        { int const rc = place_alloc(&c->big_tables, ns * KX_BIG_TBL_ENTRIES * sizeof(u32), nullptr, nullptr); if (rc != KMP_OK) return rc; }     // (the block-chain parser's tables: the same access pattern)
         HIP_TRY(hipMalloc((void**)&c->remaining, 64));
         HIP_TRY(hipMalloc((void**)&c->big_counters, ns * 4));
     }
@@ -270,29 +299,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     HIP_TRY(hipMalloc((void**)&c->lits, ns * c->lit_cap));
     HIP_TRY(hipMalloc((void**)&c->meta, ns * sizeof(KSliceMeta)));
     HIP_TRY(hipMalloc((void**)&c->scratch, ns * c->scratch_words * sizeof(u32)));
-    {
-        // Where the team tables land matters: the random-access rate of this device's HBM differs by a sixth between
-        // regions (tools/region_probe.py: two of ten 24 GiB regions give 27.5 G accesses/s, the others 34 - 37), and the
-        // parsers live off that rate.  Large tables are therefore placed by trial: up to KMP_PLACE_TRIES (default 3)
-        // allocations are probed with the tables' access pattern (k_region_probe, ~30 ms each), the fastest stays, the
-        // others are freed.  (The candidates are held until the choice is made so that each lands somewhere else; an
-        // allocation that fails ends the search.)
-        size_t const tbytes = (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32);
-        u32 tries = env_u32("KMP_PLACE_TRIES", 3); if (tries < 1) tries = 1; if (tries > 6) tries = 6;
-        if (tbytes < ((size_t)4 << 30)) tries = 1;
-        u32* cand[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; float ms[6] = { 0, 0, 0, 0, 0, 0 };
-        u32 got = 0, best = 0;
-        for (u32 t = 0; t < tries; t++) {
-            if (hipMalloc((void**)&cand[t], tbytes) != hipSuccess) { (void)hipGetLastError(); cand[t] = nullptr; break; }
-            got = t + 1;
-            if (tries > 1 && kmp_debug_probe_region(cand[t], tbytes, 4096u, 384u, &ms[t], nullptr) != KMP_OK) { ms[t] = 1e30f; }
-            if (ms[t] < ms[best]) best = t;
-        }
-        if (got == 0) return hip_fail(hipErrorOutOfMemory, "hipMalloc(team tables)");
-        for (u32 t = 0; t < got; t++) if (t != best) (void)hipFree(cand[t]);
-        c->tables = cand[best];
-        c->place_ms = ms[best]; c->place_tried = got;
-    }
+    { int const rc = place_alloc(&c->tables, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32), &c->place_ms, &c->place_tried); if (rc != KMP_OK) return rc; }
     HIP_TRY(hipMalloc((void**)&c->team_epoch, (size_t)c->nteams * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->counter, 64));
     HIP_TRY(hipMemset(c->tables, 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
