@@ -232,15 +232,15 @@ static u32 env_u32(const char* name, u32 dflt)
 
 // Where a randomly accessed table lands matters: the random-access rate of this device's HBM differs by a sixth between
 // regions (tools/region_probe.py: two of ten 24 GiB regions give 27.5 G accesses/s, the others 34 - 37), and the parsers
-// live off that rate.  Large tables are therefore placed by trial: up to KMP_PLACE_TRIES (default 6) allocations are
+// live off that rate.  Large tables are therefore placed by trial: up to KMP_PLACE_TRIES (default 8) allocations are
 // probed with the tables' access pattern (k_region_probe, ~30 ms each) until one is of the fast kind; the fastest stays, the
 // others are freed.  (The
 // candidates are held until the choice is made so that each lands somewhere else; an allocation that fails ends the search.)
 static int place_alloc(u32** out, size_t bytes, float* kept_ms, u32* tried_out)
 {
-    u32 tries = env_u32("KMP_PLACE_TRIES", 6); if (tries < 1) tries = 1; if (tries > 6) tries = 6;
+    u32 tries = env_u32("KMP_PLACE_TRIES", 8); if (tries < 1) tries = 1; if (tries > 8) tries = 8;
     if (bytes < ((size_t)4 << 30)) tries = 1;
-    u32* cand[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; float ms[6] = { 0, 0, 0, 0, 0, 0 };
+    u32* cand[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; float ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     u32 got = 0, best = 0;
     for (u32 t = 0; t < tries; t++) {
         if (hipMalloc((void**)&cand[t], bytes) != hipSuccess) { (void)hipGetLastError(); cand[t] = nullptr; break; }
