@@ -197,6 +197,8 @@ struct kmp_batch_ctx {
     // level 3, batches of more than half the team slots: one launch of each kernel or two chunks?  Tried once each on the
     // context's first two such batches (whole-step HIP events), then the faster stays -- the parse kernel's time differs
     // by 17 % between runs of the same box, and which setting wins depends on it.
+    u32* tables_flat; u32* team_epoch_flat;     // levels 1 / 2 and the dictionary parser: one piece (they wait for latency and are slower over spread tables), allocated on first use when the level-3 tables are spread
+    u32* tseg[4]; u32 tseg_n;                   // the team tables in four pieces spread over the HBM (or tseg_n == 1: tables alone)
     float place_ms; u32 place_tried;            // the team tables' placement: probe time of the region kept, candidates tried
     int tune_state; int tune_pending; u32 tune_pick; float tune_ms[2]; hipEvent_t tune_ev[2];
     hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join, ev_last_match; int have_last_match; u32 last_chunks;
@@ -299,10 +301,30 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     HIP_TRY(hipMalloc((void**)&c->lits, ns * c->lit_cap));
     HIP_TRY(hipMalloc((void**)&c->meta, ns * sizeof(KSliceMeta)));
     HIP_TRY(hipMalloc((void**)&c->scratch, ns * c->scratch_words * sizeof(u32)));
-    { int const rc = place_alloc(&c->tables, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32), &c->place_ms, &c->place_tried); if (rc != KMP_OK) return rc; }
+    {
+        // Large team tables go into four pieces far apart: random accesses confined to a few dozen GiB of this device's HBM
+        // reach 27.5 G/s, spread over 144 GiB or more 37 (tools/region_probe3.py) -- the memory is interleaved over its
+        // stacks in coarse blocks.  The pieces are kept apart by paddings that are freed again before this function returns
+        // (KMP_TABLE_SPREAD=0, little free memory or a failed allocation: one allocation, placed by trial as below).
+        size_t const tbytes = (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32);
+        c->tseg_n = 1;
+        size_t fr = 0, tot = 0;
+        if (env_u32("KMP_TABLE_SPREAD", 1) && tbytes >= ((size_t)4 << 30) && (c->nteams & 3u) == 0 && hipMemGetInfo(&fr, &tot) == hipSuccess && fr > tbytes + ((size_t)40 << 30)) {
+            size_t pad = (fr - tbytes - ((size_t)16 << 30)) / 3; if (pad > ((size_t)56 << 30)) pad = (size_t)56 << 30;
+            void* pads[3] = { nullptr, nullptr, nullptr }; bool ok = true;
+            for (int i = 0; i < 4 && ok; i++) {
+                if (hipMalloc((void**)&c->tseg[i], tbytes / 4) != hipSuccess) { ok = false; break; }
+                if (i < 3 && hipMalloc(&pads[i], pad) != hipSuccess) ok = false;
+            }
+            for (int i = 0; i < 3; i++) if (pads[i]) (void)hipFree(pads[i]);
+            if (ok) { c->tseg_n = 4; c->tables = c->tseg[0]; }
+            else { (void)hipGetLastError(); for (int i = 0; i < 4; i++) { if (c->tseg[i]) (void)hipFree(c->tseg[i]); c->tseg[i] = nullptr; } }
+        }
+        if (c->tseg_n == 1) { int const rc = place_alloc(&c->tables, tbytes, &c->place_ms, &c->place_tried); if (rc != KMP_OK) return rc; c->tseg[0] = c->tables; }
+    }
     HIP_TRY(hipMalloc((void**)&c->team_epoch, (size_t)c->nteams * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->counter, 64));
-    HIP_TRY(hipMemset(c->tables, 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32)));
+    for (u32 i = 0; i < c->tseg_n; i++) HIP_TRY(hipMemset(c->tseg[i], 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32) / c->tseg_n));
     HIP_TRY(hipMemset(c->team_epoch, 0, (size_t)c->nteams * sizeof(u32)));
     HIP_TRY(hipMemset(c->meta, 0, ns * sizeof(KSliceMeta)));
     for (int i = 0; i < 14; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
@@ -336,7 +358,9 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch);
-    (void)hipFree(c->tables); (void)hipFree(c->team_epoch);
+    for (u32 i = 0; i < 4; i++) if (c->tseg[i]) (void)hipFree(c->tseg[i]);      // (tseg[0] == tables)
+    (void)hipFree(c->tables_flat); (void)hipFree(c->team_epoch_flat);
+    (void)hipFree(c->team_epoch);
     (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS);
     (void)hipFree(c->fstate); (void)hipFree(c->hufct); (void)hipFree(c->big_tables); (void)hipFree(c->remaining); (void)hipFree(c->big_counters); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -422,6 +446,22 @@ extern "C" size_t kmp_zstd_compress_bound(size_t n)
     return n + (n >> 8) + ((n < (128u << 10)) ? (((128u << 10) - n) >> 11) : 0);
 }
 
+// the tables of the one-position-per-step parsers (levels 1 / 2, dictionary): the level-3 tables when those are one piece,
+// else a piece of their own with its own epochs (measured over the spread tables: level 1 19.8 GB/s against 23.9)
+static int flat_tables(kmp_batch_ctx* c, u32** tables, u32** epochs)
+{
+    if (c->tseg_n == 1) { *tables = c->tables; *epochs = c->team_epoch; return KMP_OK; }
+    if (!c->tables_flat) {
+        size_t const tbytes = (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32);
+        int const rc = place_alloc(&c->tables_flat, tbytes, nullptr, nullptr); if (rc != KMP_OK) return rc;
+        HIP_TRY(hipMalloc((void**)&c->team_epoch_flat, (size_t)c->nteams * sizeof(u32)));
+        HIP_TRY(hipMemset(c->tables_flat, 0, tbytes));
+        HIP_TRY(hipMemset(c->team_epoch_flat, 0, (size_t)c->nteams * sizeof(u32)));
+    }
+    *tables = c->tables_flat; *epochs = c->team_epoch_flat;
+    return KMP_OK;
+}
+
 // ---- levels 1 and 2 -------------------------------------------------------------------------------------
 static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct = 0);
@@ -457,7 +497,7 @@ extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src
         KFastArgs g;
         g.m.src = (const u8*)d_src; g.m.in_off = d_in_off + first; g.m.in_len = c->len_ok + first; g.m.n_slices = m_n;
         g.m.seqs = c->seqs + (size_t)first * c->seq_cap; g.m.seq_cap = c->seq_cap; g.m.lits = c->lits + (size_t)first * c->lit_cap; g.m.lit_cap = c->lit_cap; g.m.meta = c->meta + first;
-        g.m.tables = c->tables; g.m.team_epoch = c->team_epoch; g.m.counter = c->counter + ci; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
+        { u32* ft_ = nullptr; u32* fe_ = nullptr; KMP_TRY(flat_tables(c, &ft_, &fe_)); g.m.tables = ft_; g.m.tseg_n = 1; g.m.team_epoch = fe_; } g.m.counter = c->counter + ci; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
         g.level = (u32)level;
         u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
         switch (c->G) {
@@ -522,7 +562,7 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
     KDictArgs g;
     g.m.src = (const u8*)d_src; g.m.in_off = d_in_off; g.m.in_len = c->len_ok; g.m.n_slices = n;
     g.m.seqs = c->seqs; g.m.seq_cap = c->seq_cap; g.m.lits = c->lits; g.m.lit_cap = c->lit_cap; g.m.meta = c->meta;
-    g.m.tables = c->tables; g.m.team_epoch = c->team_epoch; g.m.counter = c->counter; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
+    { u32* ft_ = nullptr; u32* fe_ = nullptr; KMP_TRY(flat_tables(c, &ft_, &fe_)); g.m.tables = ft_; g.m.tseg_n = 1; g.m.team_epoch = fe_; } g.m.counter = c->counter; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
     g.dict = c->d_dict; g.dict_size = dict_size; g.dictL = c->d_dictL; g.dictS = c->d_dictS;
     g.dWindowLog = c->cdW; g.dHashLog = c->cdH; g.dChainLog = c->cdC; g.dMinMatch = c->cdM;
     u32 const tpw = 64 / (u32)c->G;
@@ -567,7 +607,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     KMatchArgs m;
     m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
     m.seqs = c->seqs; m.seq_cap = c->seq_cap; m.meta = c->meta; m.lits = c->lits; m.lit_cap = c->lit_cap;
-    m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter;
+    m.tables = c->tables; for (int ts_ = 0; ts_ < 4; ts_++) m.tseg[ts_] = c->tseg[ts_]; m.tseg_n = c->tseg_n; m.team_epoch = c->team_epoch; m.counter = c->counter;
     m.flags = 2u | (streaming ? 8u : 0u) | (c->max_slice_bytes >= KX_BLK_WIDE_FROM ? 16u : 0u);
     m.fstate = c->fstate; m.big_tables = c->big_tables;
     KFrameArgs e;
@@ -741,7 +781,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         m.src = (const u8*)d_src; m.in_off = d_in_off + first; m.in_len = c->len_ok + first; m.n_slices = m_n;
         m.seqs = c->seqs + (size_t)first * c->seq_cap; m.seq_cap = c->seq_cap; m.meta = c->meta + first;
         m.lits = c->lits + (size_t)first * c->lit_cap; m.lit_cap = c->lit_cap;
-        m.tables = c->tables; m.team_epoch = c->team_epoch; m.counter = c->counter + ci; m.flags = match_flags;
+        m.tables = c->tables; for (int ts_ = 0; ts_ < 4; ts_++) m.tseg[ts_] = c->tseg[ts_]; m.tseg_n = c->tseg_n; m.team_epoch = c->team_epoch; m.counter = c->counter + ci; m.flags = match_flags;
         u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > c->match_blocks_l3) blocks = c->match_blocks_l3;
         if (c->profiling) HIP_TRY(hipEventRecord(c->evm[ci][0], st));
         switch (c->G) {

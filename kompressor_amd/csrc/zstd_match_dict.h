@@ -102,7 +102,7 @@ KX_DEV void zstd_match_dict_body(const KDictArgs& d)
     int const k = lane & (G - 1);
     int const tbase = lane - k;
     u32 const team = kx_block() * NT + (u32)(lane / G);
-    u32* const L = a.tables + (size_t)team * KX_TBL_ENTRIES;
+    u32* const L = kx_team_tables(a, team);
     u32* const S = L + KX_TBL_LONG;
     u64 const tmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
     int const D = (int)d.dict_size;

@@ -43,7 +43,7 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
     int const k = lane & (G - 1);
     int const tbase = lane - k;
     u32 const team = kx_block() * NT + (u32)(lane / G);
-    u32* H = BLK ? a.big_tables : a.tables + (size_t)team * KX_TBL_ENTRIES;
+    u32* H = BLK ? a.big_tables : kx_team_tables(a, team);
     int bstart = 0; u32 saved1 = 0, saved2 = 0;
     u64 const tmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
 
