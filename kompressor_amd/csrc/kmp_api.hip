@@ -3,6 +3,7 @@
 // single-slice API declared in include/kompressor_hip.h.
 #include "kx_wave.h"
 #include "zstd_match.h"
+#include "zstd_match2.h"
 #include "zstd_entropy.h"
 #include "zstd_match_dict.h"
 #include "zstd_match_fast.h"
@@ -28,6 +29,9 @@
 // --------------------------------------------------------------------------
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match(KMatchArgs a) { zstd_match_body<G>(a); }
+// the same parse as a split-phase stage machine (zstd_match2.h): one memory round trip per outer iteration
+template <int G, int R>
+__global__ __launch_bounds__(64, 4) void k_zstd_match2(KMatchArgs a) { zstd_match2_body<G, R>(a); }
 __global__ __launch_bounds__(64, 4) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
 // levels 1 and 2 (strategy "fast")
 template <int G>
@@ -223,7 +227,7 @@ struct kmp_batch_ctx {
     hipEvent_t ev_done; int have_done;
     // experiment switches, read from the environment once, when the context is created
     struct { u32 chunks, match_flags, entropy_pad, first_permille, fast_first_permille, entropy_flags, decode_flags, decode_pad, big_rounds, big_spw,
-                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre, decode_sort, decode_pieces, decode_stage_slices, inflate_pre, inflate_pieces, autotune; } knob;
+                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre, decode_sort, decode_pieces, decode_stage_slices, inflate_pre, inflate_pieces, autotune, match_v2; } knob;
 };
 
 static u32 env_u32(const char* name, u32 dflt)
@@ -348,6 +352,7 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     // experiment, off by default (measured slower): bit 0 = sequences decoded ahead of k_zstd_decode
     // (k_zstd_seq_predecode, one lane per frame), bit 1 = literals (k_zstd_lit_predecode, one lane per stream)
     c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1); c->knob.decode_stage_slices = env_u32("KMP_DECODE_STAGE_SLICES", 0); c->knob.inflate_pre = env_u32("KMP_INFLATE_PRE", 1); c->knob.inflate_pieces = env_u32("KMP_INFLATE_PIECES", 1); c->knob.autotune = env_u32("KMP_ZSTD_AUTOTUNE", 1);
+    c->knob.match_v2 = env_u32("KMP_MATCH_V2", 1);                     // 0: zstd_match.h; 1: zstd_match2.h (2: with a 512-byte window at team width 4)
     HIP_TRY(hipDeviceSynchronize());
     *out = c;
     return KMP_OK;
@@ -784,6 +789,15 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         m.tables = c->tables; for (int ts_ = 0; ts_ < 4; ts_++) m.tseg[ts_] = c->tseg[ts_]; m.tseg_n = c->tseg_n; m.team_epoch = c->team_epoch; m.counter = c->counter + ci; m.flags = match_flags;
         u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > c->match_blocks_l3) blocks = c->match_blocks_l3;
         if (c->profiling) HIP_TRY(hipEventRecord(c->evm[ci][0], st));
+        if (c->knob.match_v2 && (c->G == 2 || c->G == 4 || c->G == 8)) {
+            m.flags |= 4u;                                                // this parser never copies literals: the entropy kernel gathers them
+            bool const r512 = c->knob.match_v2 == 2;
+            switch (c->G) {
+            case 2:  hipLaunchKernelGGL((k_zstd_match2<2, 256>), dim3(blocks), dim3(64), 0, st, m); break;
+            case 4:  if (r512) hipLaunchKernelGGL((k_zstd_match2<4, 512>), dim3(blocks), dim3(64), 0, st, m); else hipLaunchKernelGGL((k_zstd_match2<4, 256>), dim3(blocks), dim3(64), 0, st, m); break;
+            default: hipLaunchKernelGGL((k_zstd_match2<8, 512>), dim3(blocks), dim3(64), 0, st, m); break;
+            }
+        } else
         switch (c->G) {
         case 2:  hipLaunchKernelGGL(k_zstd_match<2>, dim3(blocks), dim3(64), 0, st, m); break;
         case 4:  hipLaunchKernelGGL(k_zstd_match<4>, dim3(blocks), dim3(64), 0, st, m); break;
@@ -798,7 +812,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         e.src = (const u8*)d_src; e.in_off = d_in_off + first; e.in_len = c->len_ok + first; e.n_slices = m_n;
         e.seqs = m.seqs; e.seq_cap = c->seq_cap; e.lits = c->lits + (size_t)first * c->lit_cap; e.lit_cap = c->lit_cap; e.meta = m.meta;
         e.scratch = c->scratch + (size_t)first * c->scratch_words; e.scratch_words = c->scratch_words;
-        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = c->knob.entropy_flags | ((match_flags & 4u) ? 8u : 0u);
+        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = c->knob.entropy_flags | ((m.flags & 4u) ? 8u : 0u);
         hipStream_t es = st;
         if (ci + 1 < chunks) { es = c->st2; HIP_TRY(hipStreamWaitEvent(es, c->evm[ci][1], 0)); forked = true; }
         if (c->profiling) HIP_TRY(hipEventRecord(c->eve[ci][0], es));

@@ -77,6 +77,9 @@ KX_DEV void kx_lds_or(u32* p, u32 v) { atomicOr(p, v); }
 // iteration into separate nested loops, the lanes of a wave wait for one another at every inner loop's exit).
 #define KX_OPAQUE(x) __asm__ volatile("" : "+v"(x))
 
+// statistics hook of the CPU emulator (tests/emu shadows this header); nothing on the GPU
+#define KX_STAT(slot, v) ((void)0)
+
 // ---- bit tricks -------------------------------------------------------
 KX_DEV u32 kx_alignbit(u32 hi, u32 lo, u32 s) { return __builtin_amdgcn_alignbit(hi, lo, s); }      // low 32 bits of (hi : lo) >> (s & 31)
 KX_DEV u32 kx_alignbyte(u32 hi, u32 lo, u32 bytes) { return __builtin_amdgcn_alignbyte(hi, lo, bytes); }   // ({hi,lo} >> 8*bytes) & 0xffffffff
@@ -85,5 +88,6 @@ KX_DEV u32 kx_ctz32(u32 v) { return (u32)__builtin_ctz(v); }
 KX_DEV u32 kx_ctz64(u64 v) { return (u32)__builtin_ctzll(v); }
 KX_DEV u32 kx_brev32(u32 v) { return __builtin_bitreverse32(v); }      // v_bfrev_b32
 KX_DEV u32 kx_clz32(u32 v) { return (u32)__builtin_clz(v); }
+KX_DEV u32 kx_clz64(u64 v) { return (u32)__builtin_clzll(v); }
 KX_DEV u32 kx_hb32(u32 v) { return 31u - (u32)__builtin_clz(v); }
 KX_DEV u32 kx_popc64(u64 v) { return (u32)__builtin_popcountll(v); }

@@ -74,6 +74,7 @@ KX_DEV u32 kx_team_extend(bool act, const u8* src, int n, int s, int m, u32 len,
 {
     bool running = act;
     while (kx_any(running)) {
+        if (kx_lane() == 0) KX_STAT(4, 1);                      // extension rounds of the wave
         u32 eq = 8;
         if (running) {
             int const p = s + (int)len + 8 * k;
@@ -106,6 +107,7 @@ KX_DEV u32 kx_team_backward(bool act, const u8* src, int s, int m, int maxback, 
     u32 back = 0;
     bool running = act && maxback > 0;
     while (kx_any(running)) {
+        if (kx_lane() == 0) KX_STAT(7, 1);                      // backward rounds of the wave
         bool ne = true;
         if (running) {
             int const o = (int)back + k;
@@ -222,9 +224,11 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             }
         }
         if (kx_all(state == KST_DONE)) break;
+        if (lane == 0) KX_STAT(0, 1);                           // outer iterations of the wave
 
         // ================= immediate repcode check ====================
         if (kx_any(state == KST_REPCHECK)) {
+            if (lane == 0) KX_STAT(1, 1);
             bool const inrep = state == KST_REPCHECK;
             bool hit = false;
             if (inrep && ip <= ilimit && off2 > 0) hit = kx_ld32(src + ip) == kx_ld32(src + ip - (int)off2);
@@ -247,6 +251,8 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
 
         // ================= speculative search step ====================
         if (kx_any(state == KST_SEARCH)) {
+            if (lane == 0) KX_STAT(2, 1);
+            if (k == 0 && state == KST_SEARCH) KX_STAT(5, 1);   // team search steps
             bool const srch = state == KST_SEARCH;
             int const pos = ip + k * step;
             bool const cand = srch && (k < G - 1) && (k == 0 || pos < nextStep) && (pos + step <= ilimit);
@@ -365,6 +371,8 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
 
         // ================= take the match =============================
         if (kx_any(state == KST_MATCH)) {
+            if (lane == 0) KX_STAT(3, 1);
+            if (k == 0 && state == KST_MATCH) KX_STAT(6, 1);    // team sequences
             bool const mt = state == KST_MATCH;
             bool l1ok = false; int s1 = 0, m1 = 0;
             if (mt && m_type == KMT_SHORT && m_idxl1 > lowIdx) {

@@ -41,6 +41,7 @@ static void* sched_sp; static int cur_fiber;
 static u8* stacks = nullptr; static size_t stacks_n = 0;
 static const std::function<void()>* cur_fn;
 int failed = 0;
+u64 stat[64];
 
 u64 arrive(int o, u64 a, u64 b)
 {
@@ -111,4 +112,9 @@ void launch_block(u32 nblocks, int waves, const std::function<void()>& fn)
     cur_fn = &fn; num_blocks = nblocks; waves_per_block = waves;
     for (u32 b = 0; b < nblocks && !failed; b++) { cur_block = b; run_block(waves); }
 }
+}
+
+extern "C" __attribute__((visibility("default"))) void emu_stats(unsigned long long* out, int clear)
+{
+    for (int i = 0; i < 64; i++) { out[i] = kxemu::stat[i]; if (clear) kxemu::stat[i] = 0; }
 }

@@ -30,6 +30,32 @@ int emu_zstd_match(const u8* src, const u64* in_off, const u32* in_len, u32 n, i
     return kxemu::failed ? -1 : 0;
 }
 
+#include "zstd_match2.h"
+// The split-phase parser (zstd_match2.h): same interface, same results.  ring = bytes of a team's window in LDS.
+extern "C" __attribute__((visibility("default")))
+int emu_zstd_match2(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
+                    KSeq* seqs, u32 seq_cap, u8* lits, u32 lit_cap, KSliceMeta* meta, u32 start_epoch)
+{
+    int const ring = getenv("KXEMU_RING") ? atoi(getenv("KXEMU_RING")) : 256;
+    u32 const nteams = nblocks * (64 / G);
+    std::vector<u32> tables((size_t)nteams * KX_TBL_ENTRIES, 0xDEADBEEFu & 0x0003FFFFu);   // stale junk with epoch 0
+    std::vector<u32> epoch(nteams, start_epoch);
+    u32 counter = 0;
+    KMatchArgs a;
+    a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
+    a.seqs = seqs; a.seq_cap = seq_cap; a.lits = lits; a.lit_cap = lit_cap; a.meta = meta;
+    a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter; a.flags = 0; a.fstate = nullptr; a.big_tables = nullptr;
+    kxemu::failed = 0;
+    switch (G * 1000 + ring) {
+    case 2256:  kxemu::launch(nblocks, [&]() { zstd_match2_body<2, 256>(a); }); break;
+    case 4256:  kxemu::launch(nblocks, [&]() { zstd_match2_body<4, 256>(a); }); break;
+    case 4512:  kxemu::launch(nblocks, [&]() { zstd_match2_body<4, 512>(a); }); break;
+    case 8512:  kxemu::launch(nblocks, [&]() { zstd_match2_body<8, 512>(a); }); break;
+    default: return -2;
+    }
+    return kxemu::failed ? -1 : 0;
+}
+
 #include "zstd_entropy.h"
 
 // Full compress pipeline (match kernel + entropy kernel) on the emulator.

@@ -59,6 +59,9 @@ KX_DEV void kx_lds_inc(u32* p) { *p += 1; }
 KX_DEV u32 kx_lds_add(u32* p, u32 v) { u32 const o = *p; *p = o + v; return o; }
 KX_DEV void kx_lds_or(u32* p, u32 v) { *p |= v; }
 
+namespace kxemu { extern u64 stat[64]; }
+#define KX_STAT(slot, v) (kxemu::stat[slot] += (u64)(v))
+
 #define KX_OPAQUE(x) __asm__ volatile("" : "+r"(x))
 
 KX_DEV u32 kx_alignbit(u32 hi, u32 lo, u32 s) { return (u32)((((u64)hi << 32) | lo) >> (s & 31)); }
@@ -68,5 +71,6 @@ KX_DEV u32 kx_ctz32(u32 v) { return (u32)__builtin_ctz(v); }
 KX_DEV u32 kx_ctz64(u64 v) { return (u32)__builtin_ctzll(v); }
 KX_DEV u32 kx_brev32(u32 v) { u32 r = 0; for (int i = 0; i < 32; i++) { r = (r << 1) | (v & 1u); v >>= 1; } return r; }
 KX_DEV u32 kx_clz32(u32 v) { return (u32)__builtin_clz(v); }
+KX_DEV u32 kx_clz64(u64 v) { return (u32)__builtin_clzll(v); }
 KX_DEV u32 kx_hb32(u32 v) { return 31u - (u32)__builtin_clz(v); }
 KX_DEV u32 kx_popc64(u64 v) { return (u32)__builtin_popcountll(v); }
