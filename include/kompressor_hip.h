@@ -91,9 +91,11 @@ KMP_API size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* dctx,
  * createCompressor :10-26 (deflateInit2), freeCompressor :28-38 (deflateEnd), compressStream :40-82
  * (deflate, call at :73).  Same cursor semantics; the return value is zlib's: Z_OK 0, Z_STREAM_END 1,
  * Z_BUF_ERROR -5 are benign for the Kotlin side (ZlibCompressor.jvm.kt:49-56).  The GPU path implements
- * level 6 (or -1), windowBits -15 (ZlibFormat.Raw), 15 (ZlibFormat.Zlib: 78 9C header + Adler-32) or
+ * levels 1 .. 9 (-1 = 6: zlib's deflate_fast for 1 .. 3, deflate_slow for 4 .. 9, each byte-identical to zlib's output),
+ * windowBits -15 (ZlibFormat.Raw), 15 (ZlibFormat.Zlib: 78 01 / 5E / 9C / DA header by level + Adler-32) or
  * 31 (ZlibFormat.Gzip: 10-byte header, CRC-32 + ISIZE), memLevel 8, strategy 0, streams up to 1 GiB (the stream is
- * compressed when the caller finishes it); other settings (other levels, smaller windows) make create return NULL. */
+ * compressed when the caller finishes it); other settings (level 0, smaller windows, other memLevels or strategies) make
+ * create return NULL. */
 typedef struct kmp_zlib_cstream kmp_zlib_cstream;
 typedef struct kmp_zlib_dstream kmp_zlib_dstream;
 KMP_API kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bits, int mem_level, int strategy);

@@ -68,7 +68,14 @@ class ZstdBatch:
         """Launches of each zstd compress kernel in the last batch."""
         return int(self.lib.kmp_batch_last_chunks(self._h))
 
-    def compress(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, dictionary=None, level=3, streaming=None, reference=False):
+    def _check(self, what):
+        """check=True of compress / deflate: wait for the batch and raise on a status bit (a slice longer than the context
+        holds, a parser guard) instead of handing back frames of length 0."""
+        rc, bits = self.status()
+        if rc != 0:
+            raise RuntimeError(f"{what}: status bits {bits:#x} ({rc}): {_lib.last_error()}")
+
+    def compress(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, dictionary=None, level=3, streaming=None, reference=False, check=False):
         """src: uint8 device tensor; in_off int64, in_len int32 device tensors (n each).  dictionary: bytes of a
         raw-content dictionary shared by all slices (host memory; its tables are built once per dictionary).
         level: 3 (default), or 1 / 2 without a dictionary: slices up to the level's window (512 KiB / 1 MiB; above 128 KiB
@@ -107,6 +114,8 @@ class ZstdBatch:
                                                   _ptr(dst), _ptr(out_off), _ptr(out_len), self._stream())
         if rc != 0:
             raise RuntimeError(f"kmp_zstd_compress_batch failed ({rc}): {_lib.last_error()}")
+        if check:
+            self._check("kmp_zstd_compress_batch")
         return dst, out_off, out_len
 
     def decompress(self, src, in_off, in_len, out_cap, dst=None, out_off=None, dictionary=None):
@@ -151,7 +160,7 @@ class ZstdBatch:
             raise RuntimeError(f"kmp_inflate_batch failed ({rc}): {_lib.last_error()}")
         return dst, out_off, out_len, status
 
-    def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, zlib_wrapper=False, format=None, level=6):   # noqa: A002
+    def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, zlib_wrapper=False, format=None, level=6, check=False):   # noqa: A002
         """DEFLATE streams (zlib level 6 -- or any other level 1 .. 9: deflate_fast 1 .. 3, deflate_slow 4 .. 9 --, windowBits 15, memLevel 8),
         format "raw" / "zlib" / "gzip", for slices up to the context's max_slice_bytes (64 KiB at least)."""
         fmt = self._FORMATS[format] if format is not None else (1 if zlib_wrapper else 0)
@@ -173,6 +182,8 @@ class ZstdBatch:
                                                            fmt, level, self._stream())
         if rc != 0:
             raise RuntimeError(f"kmp_deflate_compress_batch failed ({rc}): {_lib.last_error()}")
+        if check:
+            self._check("kmp_deflate_compress_batch")
         return dst, out_off, out_len
 
     def deflate_kernel_ms(self):

@@ -186,7 +186,7 @@ extern "C" int kmp_debug_probe_region(void* p, size_t bytes, uint32_t blocks, ui
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return KMP_OK;
 }
-extern "C" const char* kmp_version(void) { return "kompressor_hip 0.2 (gfx950; zstd level 3 frames up to 2 MiB, deflate level 6)"; }
+extern "C" const char* kmp_version(void) { return "kompressor_hip 0.3 (gfx950; zstd levels 1-3: frames and streams up to 1 GiB, raw-content dictionaries; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
 
 // --------------------------------------------------------------------------
 // batch context
@@ -202,7 +202,8 @@ struct kmp_batch_ctx {
     // context's first two such batches (whole-step HIP events), then the faster stays -- the parse kernel's time differs
     // by 17 % between runs of the same box, and which setting wins depends on it.
     u32* tables_flat; u32* team_epoch_flat;     // levels 1 / 2 and the dictionary parser: one piece (they wait for latency and are slower over spread tables), allocated on first use when the level-3 tables are spread
-    u32* tseg[4]; u32 tseg_n;                   // the team tables in four pieces spread over the HBM (or tseg_n == 1: tables alone)
+    u32* tseg[4]; u32 tseg_n;                   // the team tables in four pieces spread over the context's arena (or tseg_n == 1: tables alone)
+    u8* arena; size_t arena_bytes;              // one allocation that holds seqs / lits / meta / scratch and the table pieces (else null: separate allocations)
     float place_ms; u32 place_tried;            // the team tables' placement: probe time of the region kept, candidates tried
     int tune_state; int tune_pending; u32 tune_pick; float tune_ms[2]; hipEvent_t tune_ev[2];
     hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join, ev_last_match; int have_last_match; u32 last_chunks;
@@ -236,15 +237,16 @@ static u32 env_u32(const char* name, u32 dflt)
     return (v && *v) ? (u32)strtoul(v, nullptr, 10) : dflt;
 }
 
-// Where a randomly accessed table lands matters: the random-access rate of this device's HBM differs by a sixth between
-// regions (tools/region_probe.py: two of ten 24 GiB regions give 27.5 G accesses/s, the others 34 - 37), and the parsers
-// live off that rate.  Large tables are therefore placed by trial: up to KMP_PLACE_TRIES (default 8) allocations are
-// probed with the tables' access pattern (k_region_probe, ~30 ms each) until one is of the fast kind; the fastest stays, the
-// others are freed.  (The
-// candidates are held until the choice is made so that each lands somewhere else; an allocation that fails ends the search.)
+// Where a randomly accessed table lands matters a little: read + insert pairs confined to a few dozen GiB of this device's HBM
+// run at 20 G/s, over a span of 72 GiB or more at 26 (tools/spanprobe, profiles/r03_match_floor.txt).  The level-3 team tables
+// get their span from the context's arena (kmp_batch_create); for the other large tables a placement by trial is available
+// as an option: with KMP_PLACE_TRIES = 2 .. 8 that many allocations are probed with the tables' access pattern
+// (k_region_probe, ~30 ms each) until one is of the fast kind, the fastest stays, the others are freed.  The default is one
+// plain allocation: the candidates of a trial are held until the choice is made, and a library must not take that much
+// memory behind its caller's back.
 static int place_alloc(u32** out, size_t bytes, float* kept_ms, u32* tried_out)
 {
-    u32 tries = env_u32("KMP_PLACE_TRIES", 8); if (tries < 1) tries = 1; if (tries > 8) tries = 8;
+    u32 tries = env_u32("KMP_PLACE_TRIES", 1); if (tries < 1) tries = 1; if (tries > 8) tries = 8;
     if (bytes < ((size_t)4 << 30)) tries = 1;
     u32* cand[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; float ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     u32 got = 0, best = 0;
@@ -265,6 +267,8 @@ static int place_alloc(u32** out, size_t bytes, float* kept_ms, u32* tried_out)
     return KMP_OK;
 }
 
+static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes);
+extern "C" void kmp_batch_destroy(kmp_batch_ctx* c);
 extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes)
 {
     if (!out || max_slices == 0) { g_last_error = "kmp_batch_create: bad argument"; return KMP_ERR_ARG; }
@@ -275,6 +279,13 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     kmp_batch_ctx* c = new (std::nothrow) kmp_batch_ctx();
     if (!c) { g_last_error = "out of host memory"; return KMP_ERR_ARG; }
     memset(c, 0, sizeof(*c));
+    int const rc = batch_create_body(c, device, max_slices, max_slice_bytes, team_lanes);
+    if (rc != KMP_OK) { std::string const keep = g_last_error; kmp_batch_destroy(c); g_last_error = keep; return rc; }      // nothing half-built is left behind
+    *out = c;
+    return KMP_OK;
+}
+static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes)
+{
     c->device = device; c->max_slices = max_slices; c->max_slice_bytes = max_slice_bytes < 64 ? 64 : max_slice_bytes; c->G = team_lanes;
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
     u32 const waves_per_cu = env_u32("KMP_MATCH_WAVES_PER_CU", 16);     // 16 x 16 teams x 256 CUs = 65 536 slices in flight at team width 4
@@ -301,30 +312,46 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
         HIP_TRY(hipMalloc((void**)&c->remaining, 64));
         HIP_TRY(hipMalloc((void**)&c->big_counters, ns * 4));
     }
-    HIP_TRY(hipMalloc((void**)&c->seqs, ns * c->seq_cap * sizeof(KSeq)));
-    HIP_TRY(hipMalloc((void**)&c->lits, ns * c->lit_cap));
-    HIP_TRY(hipMalloc((void**)&c->meta, ns * sizeof(KSliceMeta)));
-    HIP_TRY(hipMalloc((void**)&c->scratch, ns * c->scratch_words * sizeof(u32)));
     {
-        // Large team tables go into four pieces far apart: random accesses confined to a few dozen GiB of this device's HBM
-        // reach 27.5 G/s, spread over 144 GiB or more 37 (tools/region_probe3.py) -- the memory is interleaved over its
-        // stacks in coarse blocks.  The pieces are kept apart by paddings that are freed again before this function returns
-        // (KMP_TABLE_SPREAD=0, little free memory or a failed allocation: one allocation, placed by trial as below).
+        // The workspace of a context with large team tables is ONE allocation (an arena): the tables in four pieces (team t:
+        // piece t & 3) with the sequence, literal and staging buffers between them.  Read + insert pairs run a quarter faster
+        // when they span two of the coarse blocks this device's HBM is laid out in (20 -> 26 G pairs/s from 36 to 72 GiB of
+        // span, tools/spanprobe), and the arena gives the tables the span the context has anyway -- nothing is allocated
+        // transiently, the peak at creation is the workspace.  KMP_TABLE_SPAN_GIB = n asks for an arena of at least n GiB with
+        // the pieces spread evenly over it (an operator who owns the device trading memory for ~4 % of parser time).
+        // KMP_TABLE_ARENA=0, small tables: separate allocations, tables in one piece.
         size_t const tbytes = (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32);
+        size_t const A = (size_t)2 << 20;                                // every part starts on a 2 MiB boundary
+        auto up = [&](size_t v) { return (v + A - 1) & ~(A - 1); };
+        size_t const seqs_b = up(ns * c->seq_cap * sizeof(KSeq)), lits_b = up(ns * c->lit_cap), meta_b = up(ns * sizeof(KSliceMeta)), scr_b = up(ns * c->scratch_words * sizeof(u32));
         c->tseg_n = 1;
-        size_t fr = 0, tot = 0;
-        if (env_u32("KMP_TABLE_SPREAD", 1) && tbytes >= ((size_t)4 << 30) && (c->nteams & 3u) == 0 && hipMemGetInfo(&fr, &tot) == hipSuccess && fr > tbytes + ((size_t)40 << 30)) {
-            size_t pad = (fr - tbytes - ((size_t)16 << 30)) / 3; if (pad > ((size_t)56 << 30)) pad = (size_t)56 << 30;
-            void* pads[3] = { nullptr, nullptr, nullptr }; bool ok = true;
-            for (int i = 0; i < 4 && ok; i++) {
-                if (hipMalloc((void**)&c->tseg[i], tbytes / 4) != hipSuccess) { ok = false; break; }
-                if (i < 3 && hipMalloc(&pads[i], pad) != hipSuccess) ok = false;
-            }
-            for (int i = 0; i < 3; i++) if (pads[i]) (void)hipFree(pads[i]);
-            if (ok) { c->tseg_n = 4; c->tables = c->tseg[0]; }
-            else { (void)hipGetLastError(); for (int i = 0; i < 4; i++) { if (c->tseg[i]) (void)hipFree(c->tseg[i]); c->tseg[i] = nullptr; } }
+        if (env_u32("KMP_TABLE_ARENA", 1) && tbytes >= ((size_t)4 << 30) && (c->nteams & 3u) == 0) {
+            size_t const piece = up(tbytes / 4);
+            size_t const need = 4 * piece + seqs_b + lits_b + meta_b + scr_b;
+            size_t const want = (size_t)env_u32("KMP_TABLE_SPAN_GIB", 0) << 30;
+            size_t const gap = want > need ? up((want - need) / 3) : 0;     // unused bytes behind each of the three buffers between the pieces
+            size_t fr = 0, tot = 0;
+            size_t const total = need + 3 * gap;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > total + ((size_t)1 << 30) && hipMalloc((void**)&c->arena, total) == hipSuccess) {
+                u8* q = c->arena; c->arena_bytes = total;
+                c->tseg[0] = (u32*)q; q += piece;
+                c->seqs = (KSeq*)q; q += seqs_b + gap;
+                c->tseg[1] = (u32*)q; q += piece;
+                c->lits = q; q += lits_b; c->meta = (KSliceMeta*)q; q += meta_b + gap;
+                c->tseg[2] = (u32*)q; q += piece;
+                c->scratch = (u32*)q; q += scr_b + gap;
+                c->tseg[3] = (u32*)q;
+                c->tseg_n = 4; c->tables = c->tseg[0];
+            } else { (void)hipGetLastError(); c->arena = nullptr; }
         }
-        if (c->tseg_n == 1) { int const rc = place_alloc(&c->tables, tbytes, &c->place_ms, &c->place_tried); if (rc != KMP_OK) return rc; c->tseg[0] = c->tables; }
+        if (!c->arena) {
+            HIP_TRY(hipMalloc((void**)&c->seqs, ns * c->seq_cap * sizeof(KSeq)));
+            HIP_TRY(hipMalloc((void**)&c->lits, ns * c->lit_cap));
+            HIP_TRY(hipMalloc((void**)&c->meta, ns * sizeof(KSliceMeta)));
+            HIP_TRY(hipMalloc((void**)&c->scratch, ns * c->scratch_words * sizeof(u32)));
+            int const rc = place_alloc(&c->tables, tbytes, &c->place_ms, &c->place_tried); if (rc != KMP_OK) return rc;
+            c->tseg[0] = c->tables;
+        }
     }
     HIP_TRY(hipMalloc((void**)&c->team_epoch, (size_t)c->nteams * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->counter, 64));
@@ -349,12 +376,12 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     c->knob.big_rounds = env_u32("KMP_BIG_ROUNDS", 0); c->knob.big_spw = env_u32("KMP_BIG_SLICES_PER_WAVE", 0);
     c->knob.dfl_chunk = env_u32("KMP_DEFLATE_CHUNK", 16384u); c->knob.dfl_chain_waves = env_u32("KMP_DEFLATE_CHAIN_WAVES", 4);
     c->knob.dfl_serial = env_u32("KMP_DEFLATE_SERIAL", 0); c->knob.dfl_flags = env_u32("KMP_DEFLATE_FLAGS", 0);
-    // experiment, off by default (measured slower): bit 0 = sequences decoded ahead of k_zstd_decode
-    // (k_zstd_seq_predecode, one lane per frame), bit 1 = literals (k_zstd_lit_predecode, one lane per stream)
-    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1); c->knob.decode_stage_slices = env_u32("KMP_DECODE_STAGE_SLICES", 0); c->knob.inflate_pre = env_u32("KMP_INFLATE_PRE", 1); c->knob.inflate_pieces = env_u32("KMP_INFLATE_PIECES", 1); c->knob.autotune = env_u32("KMP_ZSTD_AUTOTUNE", 1);
+    // the decoder's pre-decode kernels (on by default for batches of KMP_PRE_MIN_BATCH = 256 entries or more, DESIGN.md section
+    // 4.3): bit 0 = sequences decoded ahead of k_zstd_decode (k_zstd_seq_predecode, one lane per frame), bit 1 = literals
+    // (k_zstd_lit_predecode, one lane per stream)
+    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1); c->knob.decode_stage_slices = env_u32("KMP_DECODE_STAGE_SLICES", 0); c->knob.inflate_pre = env_u32("KMP_INFLATE_PRE", 1); c->knob.inflate_pieces = env_u32("KMP_INFLATE_PIECES", 1); c->knob.autotune = env_u32("KMP_ZSTD_AUTOTUNE", 0);      // opt-in: one launch or two chunks, tried once each (two blocking event reads on the 2nd / 3rd batch)
     c->knob.match_v2 = env_u32("KMP_MATCH_V2", 1);                     // 0: zstd_match.h; 1: zstd_match2.h (2: with a 512-byte window at team width 4)
     HIP_TRY(hipDeviceSynchronize());
-    *out = c;
     return KMP_OK;
 }
 
@@ -362,8 +389,8 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch);
-    for (u32 i = 0; i < 4; i++) if (c->tseg[i]) (void)hipFree(c->tseg[i]);      // (tseg[0] == tables)
+    if (c->arena) (void)hipFree(c->arena);                                        // (holds seqs, lits, meta, scratch and the table pieces)
+    else { (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch); (void)hipFree(c->tables); }
     (void)hipFree(c->tables_flat); (void)hipFree(c->team_epoch_flat);
     (void)hipFree(c->team_epoch);
     (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS);
@@ -831,6 +858,7 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
 // the literals): allocated on the first call that wants it, for as many entries as 48 GiB hold (all of them for the bench's
 // batches; a larger batch goes through in pieces, one after the other, that reuse the staging).  Shared by the zstd decoder
 // and inflate.
+static u32 env_pre_min_batch() { static u32 const v = env_u32("KMP_PRE_MIN_BATCH", 256); return v; }
 static void ensure_pre_staging(kmp_batch_ctx* c)
 {
     if (c->pre_tried || !c->knob.decode_pre) return;
@@ -875,11 +903,14 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
     // Staging for what the pre-decode kernels leave (8 bytes per sequence -- a frame of S bytes holds at most S / 3 -- and
     // the literals): allocated on the first call, for as many entries as 48 GiB hold (all of them for the bench's batches;
     // a larger batch goes through in pieces, one after the other, that reuse the staging).
-    ensure_pre_staging(c);
+    // (a small batch -- the one-frame contexts of the streaming entry points above all -- goes straight to k_zstd_decode: a quad
+    // or a lane doing a whole frame's serial decode first is the old serial cost plus a second pass, and the staging is memory)
+    bool const use_pre = n >= env_pre_min_batch();
+    if (use_pre) ensure_pre_staging(c);
     d.pre_stage = nullptr; d.pre_seq_cap = 0; d.pre_blk = nullptr; d.pre_blk_cap = c->pre_blk_cap; d.pre_nblk = nullptr;
     d.pre_lits = nullptr; d.pre_lit_cap = 0; d.pre_lit = nullptr; d.pre_nlit = nullptr;
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[4], st));
-    if (!c->pre_stage && !c->pre_lits) {
+    if (!use_pre || (!c->pre_stage && !c->pre_lits)) {
         hipLaunchKernelGGL(k_zstd_decode, dim3(n), dim3(64), c->knob.decode_pad, st, d);   // padding = occupancy experiment only
         HIP_TRY(hipGetLastError());
     } else {
@@ -984,8 +1015,9 @@ extern "C" int kmp_inflate_batch(kmp_batch_ctx* c, const void* d_src, const uint
     a.src = (const u8*)d_src; a.in_off = d_in_off; a.in_len = d_in_len; a.n_slices = n;
     a.dst = (u8*)d_dst; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_len = d_out_len; a.status = d_status; a.format = (u32)format;
     KMP_TRY(batch_begin(c, st, nullptr, n, 0));
-    if (c->knob.inflate_pre) ensure_pre_staging(c);
-    if (c->knob.inflate_pre && c->pre_stage && c->pre_lits && c->pre_nblk && c->pre_nlit && c->pre_slices) {
+    bool const use_pre = c->knob.inflate_pre && n >= env_pre_min_batch();
+    if (use_pre) ensure_pre_staging(c);
+    if (use_pre && c->pre_stage && c->pre_lits && c->pre_nblk && c->pre_nlit && c->pre_slices) {
         // two kernels: a lane per stream decodes the Huffman codes into staged literals and match records (the staging of
         // the zstd decoder), a wave per stream executes them -- and decodes the streams the first kernel did not cover
         // One piece when the batch fits the staging; a larger batch goes through in pieces of the staging's size, one after the

@@ -1,6 +1,9 @@
 import os
 import sys
 
+# the decoders' pre-decode kernels are for batches (KMP_PRE_MIN_BATCH, default 256 entries); the suite's small cases run them too
+os.environ.setdefault("KMP_PRE_MIN_BATCH", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -68,14 +68,17 @@ int emu_zstd_compress(const u8* src, const u64* in_off, const u32* in_len, u32 n
     std::vector<u8> lits((size_t)n * lit_cap, 0xEE);
     std::vector<KSliceMeta> meta(n);
     std::vector<u32> scratch((size_t)n * scratch_words, 0xA5A5A5A5u);
-    int r = emu_zstd_match(src, in_off, in_len, n, G, nblocks, seqs.data(), seq_cap, lits.data(), lit_cap, meta.data(), 7);
+    // KXEMU_MATCH_V2=1: the split-phase parser (zstd_match2.h; it copies no literals, the entropy kernel gathers them)
+    bool const v2 = getenv("KXEMU_MATCH_V2") && atoi(getenv("KXEMU_MATCH_V2")) != 0;
+    int r = v2 ? emu_zstd_match2(src, in_off, in_len, n, G, nblocks, seqs.data(), seq_cap, lits.data(), lit_cap, meta.data(), 7)
+               : emu_zstd_match(src, in_off, in_len, n, G, nblocks, seqs.data(), seq_cap, lits.data(), lit_cap, meta.data(), 7);
     if (r) return r;
     for (u32 i = 0; i < n; i++) if (meta[i].status) return -3;
     KEntropyArgs e;
     e.src = src; e.in_off = in_off; e.in_len = in_len; e.n_slices = n;
     e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
     e.scratch = scratch.data(); e.scratch_words = scratch_words;
-    e.dst = dst; e.out_off = out_off; e.out_len = out_len; e.flags = 0;
+    e.dst = dst; e.out_off = out_off; e.out_len = out_len; e.flags = v2 ? 8u : 0u;
     kxemu::failed = 0;
     kxemu::launch(nblocks, [&]() { zstd_entropy_body(e); });
     return kxemu::failed ? -1 : 0;

@@ -28,6 +28,50 @@ def test_emulated_compress_matches_golden_64k(G, team):
         assert len(f) == flen and helpers.sha256(f) == sha, f"slice {i} class {cls} team {team}"
 
 
+@pytest.mark.parametrize("team,ring", [(4, 256), (2, 256), (8, 512), (4, 512)])
+def test_emulated_split_phase_parser_matches_golden(G, monkeypatch, team, ring):
+    """zstd_match2.h (the level-3 parse as a split-phase stage machine with an LDS source window): the same frames as libzstd
+    1.5.7 on 64 KiB slices of every class, on the ragged ladder (empty, tiny, maximum), and on the hand-made edge inputs."""
+    monkeypatch.setenv("KXEMU_MATCH_V2", "1")
+    monkeypatch.setenv("KXEMU_RING", str(ring))
+    rows = G["config1"][40:56] if team == 4 and ring == 256 else G["config1"][56:64]
+    S = 65536
+    buf = corpus.make(rows[0][0], len(rows), S)
+    frames = helpers.emu_compress([buf[k * S:(k + 1) * S].tobytes() for k in range(len(rows))], G=team, nblocks=max(1, len(rows) * team // 128))
+    for (i, cls, flen, sha), f in zip(rows, frames):
+        assert len(f) == flen and helpers.sha256(f) == sha, f"slice {i} class {cls} team {team}"
+    lad = [r for r in G["ladder"] if r["index"] in (1001, 1005)]
+    datas = []
+    for r in lad:
+        S2, k = r["size"], r["index"] - 1000
+        datas.append(corpus.make(1000, 8, S2)[k * S2:(k + 1) * S2].tobytes() if S2 else b"")
+    frames = helpers.emu_compress(datas, G=team, nblocks=3)
+    for r, f in zip(lad, frames):
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r
+    sp = helpers.special_inputs()
+    frames = helpers.emu_compress([sp[r["name"]] for r in G["special"]], G=team)
+    for r, f in zip(G["special"], frames):
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r["name"]
+
+
+def test_emulated_split_phase_parser_at_the_end_of_a_slice(monkeypatch):
+    """Matches that run into the last bytes of a slice (the window's 16-byte looks must not count bytes they do not hold): every
+    distance of a repeat's start from the end, several periods, against the oracle."""
+    monkeypatch.setenv("KXEMU_MATCH_V2", "1")
+    o = helpers.oracle()
+    rng = np.random.default_rng(11)
+    ds = []
+    for per in (1, 2, 3, 5, 8, 15, 16, 17, 33):
+        pat = rng.integers(0, 256, per, dtype=np.uint8).tobytes()
+        for tail in range(0, 40, 3):
+            pre = rng.integers(0, 256, 64 + per, dtype=np.uint8).tobytes()
+            body = (pat * 80)[:per + 9 + tail]
+            ds += [pre + body, pre + body + b"\x07", pre + body[:-1] + bytes([body[-1] ^ 1])]
+    frames = helpers.emu_compress(ds, G=4, nblocks=4)
+    for d, f in zip(ds, frames):
+        assert f == o.compress(d), len(d)
+
+
 def test_emulated_compress_ladder_ragged_batch(G):
     # one batch with every ladder size at once: ragged lengths, empty input, 128 KiB maximum
     rows = [r for r in G["ladder"] if r["index"] in (1000, 1003)]

@@ -164,16 +164,25 @@ def test_decoder_error_codes(G, batch):
     assert outs[4] == bytes(range(256)) * 256
 
 
-@pytest.mark.timeout(600)
-def test_full_batch_roundtrip_and_checksum_of_checksums():
+@pytest.mark.timeout(900)
+def test_full_batch_roundtrip_and_checksum_of_checksums(monkeypatch):
     """BASELINE.json configs[1] size: 65 536 x 64 KiB.  decode(encode(x)) == x for every slice; the 2 048 slices the
     golden manifest covers hash to the manifest's values inside the big batch (batch position does not change a frame);
-    and every one of the 65 536 frames -- and of configs[4]'s 65 536 DEFLATE streams, and of 16 384 slices of
-    configs[3]'s mix -- equals the reference library's, checked through one sha256 per 4 096-slice group."""
+    and every one of the 65 536 frames -- from both level-3 parsers --, of configs[4]'s 65 536 DEFLATE streams, and of the
+    131 072 slices of rank 0's block of configs[3] (as the 8-GPU run shards it) equals the reference library's, checked
+    through one sha256 per 4 096-slice group.  The context's workspace is one arena: creating it takes what it holds."""
     from kompressor_amd.batch import ZstdBatch
     G = helpers.golden()
     n, S = 65536, 65536
+    monkeypatch.setenv("KMP_ZSTD_AUTOTUNE", "1")           # (opt-in: one launch of each kernel or two chunks, tried once each)
+    monkeypatch.setenv("KMP_MATCH_V2", "0")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
     b = ZstdBatch(max_slices=n, max_slice_bytes=S)
+    torch.cuda.synchronize()
+    taken = free0 - torch.cuda.mem_get_info()[0]
+    # team tables 24 GiB + sequences 8.6 + literals 4.3 + staging words 4.3 GB + small change: nothing transient, nothing spare
+    assert 38 << 30 < taken < 43 << 30, taken / 2 ** 30
     src = torch.empty(n * S, dtype=torch.uint8, device="cuda")
     chunk = 4096
     for c in range(0, n, chunk):
@@ -227,6 +236,19 @@ def test_full_batch_roundtrip_and_checksum_of_checksums():
         lo, hi = int(offs[g * F["group"]]), int(offs[(g + 1) * F["group"]])
         assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"group {g} differs from libzstd 1.5.7"
     del host, packed
+    # the split-phase parser (zstd_match2.h, KMP_MATCH_V2): the same 65 536 frames
+    monkeypatch.setenv("KMP_MATCH_V2", "2")
+    monkeypatch.setenv("KMP_ZSTD_AUTOTUNE", "0")
+    b2 = ZstdBatch(max_slices=n, max_slice_bytes=S)
+    dst2, ooff2, olen2 = b2.compress(src, in_off, in_len, check=True)
+    packed2, offs2 = b2.compact(dst2, ooff2, olen2)
+    torch.cuda.synchronize()
+    offs2 = offs2.cpu().numpy(); host = packed2.cpu().numpy()
+    for g, total, sha in F["config1_zstd3"]:
+        lo, hi = int(offs2[g * F["group"]]), int(offs2[(g + 1) * F["group"]])
+        assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"split-phase parser: group {g} differs from libzstd 1.5.7"
+    b2.close()
+    del host, packed2, dst2
     # ... and all 65 536 raw DEFLATE level-6 streams of configs[4] against zlib, the same way
     ddst, doff, dlen = b.deflate(src, in_off, in_len)
     dpacked, doffs = b.compact(ddst, doff, dlen)
@@ -238,18 +260,20 @@ def test_full_batch_roundtrip_and_checksum_of_checksums():
         lo, hi = int(doffs[g * F["group"]]), int(doffs[(g + 1) * F["group"]])
         assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"group {g} differs from zlib {F['zlib']}"
     del host, dpacked, ddst
-    # configs[3]: the first 16 384 slices of rank 0's block (text / binary alternating), reusing the context
-    n3 = 16384
-    for c in range(0, n3, chunk):
-        src[c * S:(c + chunk) * S] = torch.from_numpy(corpus.make(c, chunk, S, corpus.MIX_TEXT_BINARY)).cuda()
-    dst, ooff, olen = b.compress(src, in_off[:n3], in_len[:n3])
-    packed, offs = b.compact(dst, ooff, olen)
-    torch.cuda.synchronize()
-    offs = offs.cpu().numpy()
-    host = packed.cpu().numpy()
-    for g, total, sha in F["config3_zstd3_first_16384"]:
-        lo, hi = int(offs[g * F["group"]]), int(offs[(g + 1) * F["group"]])
-        assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"configs[3] group {g} differs from libzstd 1.5.7"
+    # configs[3]: rank 0's block of the 8-GPU run (131 072 text / binary slices) in two batches of 65 536, reusing the context
+    for half in range(2):
+        for c in range(0, n, chunk):
+            src[c * S:(c + chunk) * S] = torch.from_numpy(corpus.make(half * n + c, chunk, S, corpus.MIX_TEXT_BINARY)).cuda()
+        dst, ooff, olen = b.compress(src, in_off, in_len, dst, ooff, olen, check=True)
+        packed, offs = b.compact(dst, ooff, olen)
+        torch.cuda.synchronize()
+        offs = offs.cpu().numpy()
+        host = packed.cpu().numpy()
+        for g, total, sha in F["config3_zstd3_rank0"][half * 16:(half + 1) * 16]:
+            gl = g - half * 16
+            lo, hi = int(offs[gl * F["group"]]), int(offs[(gl + 1) * F["group"]])
+            assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"configs[3] group {g} differs from libzstd 1.5.7"
+        del host, packed
     b.close()
 
 
@@ -823,6 +847,25 @@ def test_slices_longer_than_the_context_are_refused_not_overrun():
         frames = gpu_compress(b, datas)
         assert b.status() == (-3, 1)
         assert frames[1] == b"" and frames[0] == o.compress(datas[0]) and frames[2] == o.compress(datas[2])
+    finally:
+        b.close()
+
+
+def test_python_wrapper_check_raises_on_a_refused_slice():
+    """ZstdBatch.compress(check=True) reads the status word: a slice longer than the context holds is an exception, not an
+    empty frame that compact() would drop silently."""
+    from kompressor_amd.batch import ZstdBatch
+    b = ZstdBatch(max_slices=4, max_slice_bytes=16384)
+    try:
+        host = corpus.make(5, 1, 40000)
+        src = torch.from_numpy(host).cuda()
+        off = torch.tensor([0, 16384], dtype=torch.int64, device="cuda")
+        ln = torch.tensor([16384, 20000], dtype=torch.int32, device="cuda")
+        with pytest.raises(RuntimeError, match="status bits 0x1"):
+            b.compress(src, off, ln, check=True)
+        ln[1] = 16000
+        _, _, olen = b.compress(src, off, ln, check=True)
+        assert int(olen.min()) > 0
     finally:
         b.close()
 
