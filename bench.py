@@ -33,98 +33,103 @@ SLICE = 65536
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def host_cores():
+    """What this process may use of the host: logical CPUs, the scheduler affinity, the cgroup's CPU quota (a GPU box hands
+    one GPU's share of the host to a job), and the thread count the CPU legs use = the smallest of them."""
+    nproc = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = nproc
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    use = min(nproc, aff)
+    if quota:
+        use = max(1, min(use, int(quota + 0.5)))
+    return {"nproc": nproc, "affinity": aff, "cgroup_quota": None if quota is None else round(quota, 2), "threads_used": use}
+
+
+def build_cpu_bench():
+    """oracle/cpu_bench.c -> oracle/_build/libcpubench.so (the GPU box has gcc; __graft_entry__.build() builds it too)."""
+    src = os.path.join(ROOT, "oracle", "cpu_bench.c")
+    out = os.path.join(ROOT, "oracle", "_build", "libcpubench.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-fvisibility=hidden", "-o", out, src, "-ldl", "-lpthread"], check=True)
+    return out
+
+
 def cpu_baseline(host, n_slices, frames_expected, sample=None):
-    """Times the reference's arithmetic on the host cores: a binary libzstd 1.5.7
-    if this machine has one (kind "reference"), else the oracle's C restatement
-    (kind "port").  Bounded sample of the same workload."""
-    from concurrent.futures import ThreadPoolExecutor
+    """Times the reference's arithmetic on the host cores (oracle/cpu_bench.c: plain pthreads, one context per thread): a
+    binary libzstd 1.5.7 if this machine has one (kind "reference"), else the oracle's C restatement (kind "port").  All the
+    cores this job may use: 1 warm-up + 5 passes over the first `sample` slices of the batch, the median pass; and one thread
+    the same way on an eighth of the sample.  Bounded: a few tens of seconds."""
+    import statistics
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    cores = min(os.cpu_count() or 1, 64)
-    sample = min(n_slices, 8192) if sample is None else sample
-    kind, label, workers = None, None, []
-    label_holder = []
+    hc = host_cores()
+    cores = hc["threads_used"]
+    if sample is None:
+        sample = min(n_slices, max(64, (1 << 30) // SLICE))          # 1 GiB: 16 384 slices of 64 KiB
+    sample = min(sample, host.size // SLICE)
+    lib = ctypes.CDLL(build_cpu_bench())
+    lib.cpubench_zstd_l3.restype = ctypes.c_int
+    lib.cpubench_zstd_l3.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    zpath = None
     try:
         from libzstd_ref import find_libzstd_157
-        lib = find_libzstd_157()
+        z = find_libzstd_157()
+        zpath = z._path if z is not None else None
     except Exception:
-        lib = None
-    if lib is not None:
+        zpath = None
+    if zpath:
         kind = "reference"
-        label = f"libzstd 1.5.7 ({os.path.basename(lib._path)}) ZSTD_compress2 level 3"
-        lib.ZSTD_createCCtx.restype = ctypes.c_void_p
-        lib.ZSTD_CCtx_setParameter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-        lib.ZSTD_compress2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
-        lib.ZSTD_compress2.restype = ctypes.c_size_t
-
-        class _Buf(ctypes.Structure):
-            _fields_ = [("p", ctypes.c_void_p), ("size", ctypes.c_size_t), ("pos", ctypes.c_size_t)]
-        lib.ZSTD_compressStream2.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Buf), ctypes.POINTER(_Buf), ctypes.c_int]
-        lib.ZSTD_compressStream2.restype = ctypes.c_size_t
-
-        def make_worker():
-            cctx = lib.ZSTD_createCCtx()
-            lib.ZSTD_CCtx_setParameter(cctx, 100, 3)
-            if SLICE <= 131072:
-                cap = SLICE + SLICE // 128 + 1024
-                out = ctypes.create_string_buffer(cap)
-                return lambda ptr: lib.ZSTD_compress2(cctx, out, cap, ptr, SLICE)
-            # above 128 KiB: driven as the reference drives it (SliceTransform.kt:33-56): finish = true from the first call,
-            # output slices of max(8192, n / 10) bytes
-            chunk = max(8192, SLICE // 10)
-            out = ctypes.create_string_buffer(chunk)
-            op = ctypes.cast(out, ctypes.c_void_p).value
-            label_holder.append(f"ZSTD_compressStream2(e_end), {chunk}-byte output slices")
-
-            def one(ptr, _keep=out):                 # (the closure keeps the output buffer alive)
-                ib = _Buf(ptr, SLICE, 0)
-                total = 0
-                while True:
-                    ob = _Buf(op, chunk, 0)
-                    r = lib.ZSTD_compressStream2(cctx, ctypes.byref(ob), ctypes.byref(ib), 2)
-                    total += ob.pos
-                    if r == 0 or r > (1 << 40):
-                        return total if r == 0 else r
-            return one
+        label = f"libzstd 1.5.7 ({os.path.basename(zpath)}) " + ("ZSTD_compress2" if SLICE <= 131072 else f"ZSTD_compressStream2(e_end), {max(8192, SLICE // 10)}-byte output slices") + " level 3"
+        kpath = None
     else:
         import helpers
-        k = helpers.oracle().lib
         kind = "port"
         label = "oracle/zstd_l3_ref.c (C restatement)"
+        kpath = helpers.build_oracle()
 
-        def make_worker():
-            cap = SLICE + SLICE // 128 + 1024
-            out = ctypes.create_string_buffer(cap)
-            return lambda ptr: k.kref_zstd_l3_compress(out, cap, ctypes.c_char_p(ptr), SLICE)
-    base = host.ctypes.data
-    per = (sample + cores - 1) // cores
-    totals = [0] * cores
+    def run(threads, cnt, passes):
+        secs = (ctypes.c_double * passes)()
+        fb, err = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        rc = lib.cpubench_zstd_l3(zpath.encode() if zpath else None, kpath.encode() if kpath else None, host.ctypes.data, cnt, SLICE, threads, passes,
+                                  secs, ctypes.byref(fb), ctypes.byref(err))
+        if rc != 0:
+            raise RuntimeError(f"cpubench_zstd_l3 failed ({rc})")
+        return list(secs), fb.value, err.value
 
-    errors = [0] * cores
-
-    def run(t):
-        w = make_worker()
-        s = 0
-        for i in range(t * per, min(sample, (t + 1) * per)):
-            r = w(base + i * SLICE)
-            if r == 0 or r > (1 << 40):          # libzstd error codes are (size_t)-code
-                errors[t] += 1
-            else:
-                s += r
-        totals[t] = s
-
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(run, range(cores)))
-    dt = time.perf_counter() - t0
-    ok = (frames_expected is None) or (sum(totals) == frames_expected)
-    if label_holder:
-        label = label.replace("ZSTD_compress2", label_holder[0])
-    if sum(errors):
-        label += f" [{sum(errors)} of {sample} CPU calls returned an error]"
-    return {"value": round(sample * SLICE / dt / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": kind,
-            "sample": f"first {sample} slices of the same batch, {label}, {cores} threads, one context per thread, "
-                      f"{dt:.2f} s wall; total frame bytes {'match' if ok else 'DIFFER from'} the GPU's"}
+    passes = 6
+    secs, fb, err = run(cores, sample, passes)
+    med = statistics.median(secs[1:])
+    one_n = max(16, sample // 8)
+    secs1, _, err1 = run(1, one_n, passes)
+    med1 = statistics.median(secs1[1:])
+    ok = (frames_expected is None) or (fb == frames_expected)
+    all_gbs, one_gbs = sample * SLICE / med / 1e9, one_n * SLICE / med1 / 1e9
+    note = f" [{err + err1} CPU calls returned an error]" if (err + err1) else ""
+    return {"value": round(all_gbs, 4), "unit": "GB/s", "cores": cores, "kind": kind,
+            "single_thread": {"value": round(one_gbs, 4), "unit": "GB/s", "sample_slices": one_n},
+            "per_thread_MBps_at_full_load": round(all_gbs * 1e3 / cores, 1),
+            "host": hc,
+            "passes_s": [round(x, 3) for x in secs],
+            "sample": f"first {sample} slices of the same batch, {label}, {cores} pthreads (oracle/cpu_bench.c), one context per thread, "
+                      f"1 warm-up + {passes - 1} passes, median {med:.2f} s; total frame bytes {'match' if ok else 'DIFFER from'} the GPU's{note}"}
 
 
 def cpu_decode_baseline(frames_host, offs, lens, n_slices, sample=32768):
@@ -138,7 +143,7 @@ def cpu_decode_baseline(frames_host, offs, lens, n_slices, sample=32768):
         lib = None
     if lib is None:
         return None
-    cores = min(os.cpu_count() or 1, 64)
+    cores = host_cores()["threads_used"]
     sample = min(n_slices, sample)
     lib.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
     lib.ZSTD_decompress.restype = ctypes.c_size_t
@@ -161,12 +166,33 @@ def cpu_decode_baseline(frames_host, offs, lens, n_slices, sample=32768):
                       + (f" [{sum(bad)} calls failed]" if sum(bad) else "")}
 
 
+def count_gpus_without_hip():
+    """GPUs this process would see, counted without initialising the HIP runtime (the parent of the ranks must not hold one):
+    the KFD topology's nodes with SIMDs, cut down to HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set."""
+    have = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for d in os.listdir(base):
+            try:
+                props = dict(l.split()[:2] for l in open(os.path.join(base, d, "properties")).read().splitlines() if len(l.split()) >= 2)
+                if int(props.get("simd_count", "0")) > 0:
+                    have += 1
+            except Exception:
+                continue
+    except Exception:
+        have = -1                                            # unknown: let the ranks find out
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and have >= 0:
+            have = min(have, len([x for x in v.split(",") if x.strip() != ""]))
+    return have
+
+
 def launch_ranks(n):
-    """--gpus N > 1 without a launcher: start the N ranks as children of this process (which has not touched a GPU:
-    torch.cuda.device_count() does not initialise HIP) and hand back their exit code."""
-    import torch
-    have = torch.cuda.device_count()
-    if have < n and not os.environ.get("KMP_BENCH_REHEARSAL"):
+    """--gpus N > 1 without a launcher: start the N ranks as children of this process -- which never touches a GPU: the
+    devices are counted from the KFD topology, not through HIP -- and hand back their exit code."""
+    have = count_gpus_without_hip()
+    if 0 <= have < n and not os.environ.get("KMP_BENCH_REHEARSAL"):
         print(f"bench.py: --gpus {n} but this machine shows {have} GPU(s)", file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -329,7 +355,7 @@ def main():
         inflate_ok = bool(int(st.abs().sum().item()) == 0 and torch.equal(back[: n * SLICE], src))
         # CPU baseline: the host zlib through Python (its compress calls release the GIL) on the host threads
         from concurrent.futures import ThreadPoolExecutor
-        cpu_cores = min(os.cpu_count() or 1, 64)
+        cpu_cores = host_cores()["threads_used"]
         sample = min(n, 16384)
         per_t = (sample + cpu_cores - 1) // cpu_cores
 
@@ -414,7 +440,7 @@ def main():
     # context setup: a level-3 context picks its launch setting on its first two batches of this size (kmp_api.hip,
     # KMP_ZSTD_AUTOTUNE); they run here, next to the workspace allocation, so that the W warmup steps and the K timed
     # steps all run the setting it kept
-    setup_batches = 2 if (args.level == 3 and dictionary is None and not ref_pattern and os.environ.get("KMP_ZSTD_AUTOTUNE", "1") != "0") else 0
+    setup_batches = 2 if (args.level == 3 and dictionary is None and not ref_pattern and os.environ.get("KMP_ZSTD_AUTOTUNE", "0") != "0") else 0
     for _ in range(setup_batches):
         step()
     for _ in range(args.warmup):
@@ -616,13 +642,19 @@ def main():
                 if pj.get("slices") == n and pj.get("launches", 1) == launches and (args.team or 4) == pj.get("team", 4):
                     traffic = pj.get("zstd_match_hbm_bytes_per_launch")
                     rd, wr = pj.get("zstd_match_read_requests_per_launch"), pj.get("zstd_match_write_requests_per_launch")
-                    if rd and wr:
-                        # the bound that does apply: random 64-byte transactions, priced with tools/randgather.hip on this
-                        # GPU (profiles/r01_random_access.txt): a probe + insert into one line 20 G/s, further reads 54 G/s
-                        floor_ms = (wr / 20e9 + max(0, rd - wr) / 54e9) * 1e3
+                    reads_ps, pairs_ps = b.table_rates()
+                    if rd and wr and reads_ps > 0 and pairs_ps > 0:
+                        # The bound that does apply: every table insert brings a 64-byte line in and sends a
+                        # 32-byte sector back -- a read + write PAIR -- and the remaining read requests bring lines in only.
+                        # Both rates were measured on this context's own tables when it was created (k_table_probe: random
+                        # load + store-into-the-same-word pairs, random loads); the request counts are the PMC pass's.
+                        pairs, pure = wr, max(0, rd - wr)
+                        model_ms = (pairs / pairs_ps + pure / reads_ps) * 1e3
                         random_access = {"read_requests_per_launch": rd, "write_requests_per_launch": wr,
-                                         "floor_ms": round(floor_ms, 1), "frac": round(floor_ms / ms_match, 3),
-                                         "source": "TCC_EA0_RDREQ / WRREQ from profiles/pmc_latest.json; rates from profiles/r01_random_access.txt"}
+                                         "pairs_per_s_on_these_tables": round(pairs_ps / 1e9, 2), "reads_per_s_on_these_tables": round(reads_ps / 1e9, 2),
+                                         "unit_of_rates": "G/s", "floor_ms": round(model_ms, 1), "frac": round(min(1.0, model_ms / ms_match), 3),
+                                         "measured_over_model": round(ms_match / model_ms, 3),
+                                         "source": "TCC_EA0_RDREQ / WRREQ per launch from profiles/pmc_latest.json; rates measured at context creation (kmp_batch_table_rates)"}
             except Exception:
                 traffic = None
         res = {
@@ -637,7 +669,8 @@ def main():
                                    + "ZstdCompressor(level=3) one-shot frames, bit-identical to libzstd 1.5.7",
                        "slices_per_gpu": n, "slice_bytes": SLICE, "ratio": round(in_bytes / frame_bytes, 4),
                        "team_lanes": b.lib and (args.team or int(os.environ.get("KMP_TEAM_LANES", "4"))), "parallelism": f"slice-sharded x{world}",
-                       "context_setup": f"{setup_batches} batches before the warmup: the context tries one launch of each kernel and two chunks, keeps the faster ({launches} kept)"},
+                       "parser": {"0": "zstd_match.h", "1": "zstd_match2.h (split-phase, 256-byte window)", "2": "zstd_match2.h (split-phase, 512-byte window)"}.get(os.environ.get("KMP_MATCH_V2", "0"), "?"),
+                       "table_span_gib": int(os.environ.get("KMP_TABLE_SPAN_GIB", "0")) or "the arena's own"},
             "roofline": {"bound": "hbm", "kernel": "k_zstd_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms_match, 3), "launches_per_step": launches},
@@ -650,8 +683,8 @@ def main():
         if pcie:
             res["end_to_end_pcie"] = pcie
         if not args.no_cpu and world == 1:          # the CPU baseline is a rank-0, N = 1 figure
-            sample = min(n, 8192)
-            res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()))
+            sample = min(n, 16384)
+            res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()), sample)
         print(json.dumps(res), flush=True)
     b.close()
     if dist is not None:

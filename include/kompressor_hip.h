@@ -318,6 +318,11 @@ KMP_API int kmp_batch_last_rounds(kmp_batch_ctx* ctx);
  * regions of one device's HBM (tools/region_probe.py). */
 KMP_API int kmp_debug_probe_region(void* d_region, size_t bytes, uint32_t blocks, uint32_t iters, float* ms, void* hip_stream);
 
+/* diagnostic (no reference counterpart): random 4-byte loads per second, and load + store-into-the-same-word pairs per second,
+ * over the context's level-3 team tables where they lie, measured once when the context was created (both 0 for a context
+ * whose tables are below 4 GiB).  bench.py prices the parser's measured memory requests with them. */
+KMP_API int kmp_batch_table_rates(kmp_batch_ctx* ctx, float* reads_per_s, float* pairs_per_s);
+
 KMP_API const char* kmp_last_error(void);
 KMP_API const char* kmp_version(void);
 

@@ -54,6 +54,13 @@ class ZstdBatch:
         rc = self.lib.kmp_batch_status(self._h, ctypes.byref(bits), self._stream())
         return rc, bits.value
 
+    def table_rates(self):
+        """(random loads per second, load + store pairs per second) over this context's level-3 team tables, measured at creation."""
+        r, q = ctypes.c_float(), ctypes.c_float()
+        if self.lib.kmp_batch_table_rates(self._h, ctypes.byref(r), ctypes.byref(q)) != 0:
+            raise RuntimeError(_lib.last_error())
+        return r.value, q.value
+
     def set_profiling(self, on=True):
         self.lib.kmp_batch_set_profiling(self._h, 1 if on else 0)
 

@@ -186,6 +186,31 @@ extern "C" int kmp_debug_probe_region(void* p, size_t bytes, uint32_t blocks, ui
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return KMP_OK;
 }
+// What the memory system gives the level-3 parser's tables WHERE THEY LIE: random accesses over the context's table pieces,
+// four independent chains per lane, 16 waves per CU.  mode 0: 4-byte loads (a probe that inserts nothing); mode 1: a load
+// and a store into the same word (a probe + insert: the line comes in and goes back).  Run once when a context with large
+// tables is created, before the tables are zeroed; bench.py prices the parser's measured memory requests with the two rates
+// (DESIGN.md section 4.1).
+__global__ __launch_bounds__(64) void k_table_probe(u32* p0, u32* p1, u32* p2, u32* p3, u32 pieces, u64 words, u32 iters, u32 mode, u32* sink)
+{
+    u64 s[4]; u32 acc = 0;
+    u64 const gid = (u64)blockIdx.x * 64 + threadIdx.x;
+    for (int j = 0; j < 4; j++) s[j] = (gid * 4 + j) * 0x9E3779B97F4A7C15ull + 12345;
+    for (u32 i = 0; i < iters; i++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            s[j] = s[j] * 6364136223846793005ull + 1442695040888963407ull;
+            u64 const r = s[j] >> 11;
+            u32 const pc = pieces == 4 ? (u32)(r & 3) : 0u;
+            u32* const base = pc == 0 ? p0 : pc == 1 ? p1 : pc == 2 ? p2 : p3;
+            u32* const q = base + __umul64hi(r << 11, words);
+            u32 v = *q;
+            if (mode) kx_st_nt(q, v + 1);
+            acc += v; s[j] += v & 1;
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
 extern "C" const char* kmp_version(void) { return "kompressor_hip 0.3 (gfx950; zstd levels 1-3: frames and streams up to 1 GiB, raw-content dictionaries; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
 
 // --------------------------------------------------------------------------
@@ -205,6 +230,7 @@ struct kmp_batch_ctx {
     u32* tseg[4]; u32 tseg_n;                   // the team tables in four pieces spread over the context's arena (or tseg_n == 1: tables alone)
     u8* arena; size_t arena_bytes;              // one allocation that holds seqs / lits / meta / scratch and the table pieces (else null: separate allocations)
     float place_ms; u32 place_tried;            // the team tables' placement: probe time of the region kept, candidates tried
+    float table_reads_per_s, table_pairs_per_s; // random loads / load + store pairs per second over this context's team tables (k_table_probe at creation; 0 = not measured)
     int tune_state; int tune_pending; u32 tune_pick; float tune_ms[2]; hipEvent_t tune_ev[2];
     hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join, ev_last_match; int have_last_match; u32 last_chunks;
     hipEvent_t ev_pre[KMP_MAX_CHUNKS + 1];      // decoder: [0] where the caller's stream stands, [1 + i] piece i pre-decoded
@@ -314,11 +340,14 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
     }
     {
         // The workspace of a context with large team tables is ONE allocation (an arena): the tables in four pieces (team t:
-        // piece t & 3) with the sequence, literal and staging buffers between them.  Read + insert pairs run a quarter faster
-        // when they span two of the coarse blocks this device's HBM is laid out in (20 -> 26 G pairs/s from 36 to 72 GiB of
-        // span, tools/spanprobe), and the arena gives the tables the span the context has anyway -- nothing is allocated
-        // transiently, the peak at creation is the workspace.  KMP_TABLE_SPAN_GIB = n asks for an arena of at least n GiB with
-        // the pieces spread evenly over it (an operator who owns the device trading memory for ~4 % of parser time).
+        // piece t & 3) with the sequence, literal and staging buffers between them, laid out over a span of
+        // KMP_TABLE_SPAN_GIB (default 80) GiB.  Why a span: read + insert pairs run a quarter faster when they straddle
+        // the coarse blocks this device's HBM is laid out in -- 20 G pairs/s inside any 24 .. 36 GiB, 25 - 26 from 72 GiB of
+        // span on (tools/spanprobe, profiles/r03_match_floor.txt) -- and the parser lives on that rate: the same context
+        // takes 205 ms per batch with its 41 GiB packed, 194 with separate allocations wherever they land, 182 over 80 GiB.
+        // Nothing is allocated transiently and nothing is probed: what creation takes is what the context holds, the
+        // gaps between the parts included (39 GiB of a 65 536-slice context's 80).  KMP_TABLE_SPAN_GIB=0 packs the arena
+        // (memory over ~12 % of parser time); a device without that much free memory gets the packed form by itself.
         // KMP_TABLE_ARENA=0, small tables: separate allocations, tables in one piece.
         size_t const tbytes = (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32);
         size_t const A = (size_t)2 << 20;                                // every part starts on a 2 MiB boundary
@@ -328,11 +357,13 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
         if (env_u32("KMP_TABLE_ARENA", 1) && tbytes >= ((size_t)4 << 30) && (c->nteams & 3u) == 0) {
             size_t const piece = up(tbytes / 4);
             size_t const need = 4 * piece + seqs_b + lits_b + meta_b + scr_b;
-            size_t const want = (size_t)env_u32("KMP_TABLE_SPAN_GIB", 0) << 30;
-            size_t const gap = want > need ? up((want - need) / 3) : 0;     // unused bytes behind each of the three buffers between the pieces
+            size_t want = (size_t)env_u32("KMP_TABLE_SPAN_GIB", 80) << 30;
             size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
+            if (want > need && fr < want + ((size_t)16 << 30)) want = 0;    // not that much room: pack
+            size_t const gap = want > need ? up((want - need) / 3) : 0;     // unused bytes behind each of the three buffers between the pieces
             size_t const total = need + 3 * gap;
-            if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > total + ((size_t)1 << 30) && hipMalloc((void**)&c->arena, total) == hipSuccess) {
+            if (fr > total + ((size_t)1 << 30) && hipMalloc((void**)&c->arena, total) == hipSuccess) {
                 u8* q = c->arena; c->arena_bytes = total;
                 c->tseg[0] = (u32*)q; q += piece;
                 c->seqs = (KSeq*)q; q += seqs_b + gap;
@@ -355,6 +386,24 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
     }
     HIP_TRY(hipMalloc((void**)&c->team_epoch, (size_t)c->nteams * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->counter, 64));
+    if ((size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32) >= ((size_t)4 << 30) && env_u32("KMP_TABLE_PROBE", 1)) {
+        // ~40 ms: the two rates the parser lives on, measured on these very tables (they are zeroed right below)
+        hipEvent_t e[3]; for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&e[i]));
+        u64 const words = (u64)c->nteams * KX_TBL_ENTRIES / c->tseg_n; u32 const blocks = (u32)prop.multiProcessorCount * 16u, iters = 96u;
+        u32* const t1 = c->tseg_n == 4 ? c->tseg[1] : c->tseg[0]; u32* const t2 = c->tseg_n == 4 ? c->tseg[2] : c->tseg[0]; u32* const t3 = c->tseg_n == 4 ? c->tseg[3] : c->tseg[0];
+        hipLaunchKernelGGL(k_table_probe, dim3(blocks), dim3(64), 0, 0, c->tseg[0], t1, t2, t3, c->tseg_n, words, 8u, 1u, c->counter);     // warm (TLB)
+        HIP_TRY(hipEventRecord(e[0], 0));
+        hipLaunchKernelGGL(k_table_probe, dim3(blocks), dim3(64), 0, 0, c->tseg[0], t1, t2, t3, c->tseg_n, words, iters, 0u, c->counter);
+        HIP_TRY(hipEventRecord(e[1], 0));
+        hipLaunchKernelGGL(k_table_probe, dim3(blocks), dim3(64), 0, 0, c->tseg[0], t1, t2, t3, c->tseg_n, words, iters, 1u, c->counter);
+        HIP_TRY(hipEventRecord(e[2], 0));
+        HIP_TRY(hipEventSynchronize(e[2]));
+        float ms0 = 0, ms1 = 0; HIP_TRY(hipEventElapsedTime(&ms0, e[0], e[1])); HIP_TRY(hipEventElapsedTime(&ms1, e[1], e[2]));
+        double const ops = (double)blocks * 64.0 * iters * 4.0;
+        if (ms0 > 0) c->table_reads_per_s = (float)(ops / (ms0 * 1e-3));
+        if (ms1 > 0) c->table_pairs_per_s = (float)(ops / (ms1 * 1e-3));
+        for (int i = 0; i < 3; i++) (void)hipEventDestroy(e[i]);
+    }
     for (u32 i = 0; i < c->tseg_n; i++) HIP_TRY(hipMemset(c->tseg[i], 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32) / c->tseg_n));
     HIP_TRY(hipMemset(c->team_epoch, 0, (size_t)c->nteams * sizeof(u32)));
     HIP_TRY(hipMemset(c->meta, 0, ns * sizeof(KSliceMeta)));
@@ -380,7 +429,7 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
     // 4.3): bit 0 = sequences decoded ahead of k_zstd_decode (k_zstd_seq_predecode, one lane per frame), bit 1 = literals
     // (k_zstd_lit_predecode, one lane per stream)
     c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1); c->knob.decode_stage_slices = env_u32("KMP_DECODE_STAGE_SLICES", 0); c->knob.inflate_pre = env_u32("KMP_INFLATE_PRE", 1); c->knob.inflate_pieces = env_u32("KMP_INFLATE_PIECES", 1); c->knob.autotune = env_u32("KMP_ZSTD_AUTOTUNE", 0);      // opt-in: one launch or two chunks, tried once each (two blocking event reads on the 2nd / 3rd batch)
-    c->knob.match_v2 = env_u32("KMP_MATCH_V2", 1);                     // 0: zstd_match.h; 1: zstd_match2.h (2: with a 512-byte window at team width 4)
+    c->knob.match_v2 = env_u32("KMP_MATCH_V2", 0);                     // 0: zstd_match.h (the default: 4 % faster, both sit on the same memory floor); 1: zstd_match2.h; 2: with a 512-byte window at team width 4
     HIP_TRY(hipDeviceSynchronize());
     return KMP_OK;
 }
@@ -430,6 +479,14 @@ extern "C" int kmp_batch_last_kernel_ms(kmp_batch_ctx* c, int which, float* ms)
     }
     HIP_TRY(hipEventSynchronize(c->ev[2 * which + 1]));
     HIP_TRY(hipEventElapsedTime(ms, c->ev[2 * which], c->ev[2 * which + 1]));
+    return KMP_OK;
+}
+/* random 4-byte loads per second and load + store pairs per second over this context's level-3 team tables, measured when
+ * the context was created (0 when its tables are small: nothing to price) */
+extern "C" int kmp_batch_table_rates(kmp_batch_ctx* c, float* reads_per_s, float* pairs_per_s)
+{
+    if (!c || !reads_per_s || !pairs_per_s) { g_last_error = "kmp_batch_table_rates: null argument"; return KMP_ERR_ARG; }
+    *reads_per_s = c->table_reads_per_s; *pairs_per_s = c->table_pairs_per_s;
     return KMP_OK;
 }
 /* launches of each zstd compress kernel in the last batch (the batch is cut into that many chunks) */

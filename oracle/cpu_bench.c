@@ -1,0 +1,119 @@
+/* cpu_bench.c -- TEST / BENCH INFRASTRUCTURE (never on the product path).
+ *
+ * bench.py's cpu_baseline leg: times the reference's arithmetic on the GPU box's host cores from plain pthreads, so that
+ * the figure does not carry a Python thread pool (all cores stated, a single-thread figure, a warm-up
+ * and several passes).  What is timed is either the binary libzstd 1.5.7 the reference binds (gradle/libs.versions.toml:9,46;
+ * the call behind kompressor-zstd--nativelib/src/jvmCommonMain/jni/Wrapper.cpp:112), looked up on the machine and passed in
+ * by path -- driven with ZSTD_compress2 up to 128 KiB (what the reference's one-shot driver amounts to there) and with
+ * ZSTD_compressStream2(e_end) into output slices of max(8192, n / 10) bytes above (SliceTransform.kt:33-56) --, or, when the
+ * machine has none, the oracle's C restatement (oracle/zstd_l3_ref.c: kref_zstd_l3_compress).
+ *
+ *   gcc -O2 -shared -fPIC -o oracle/_build/libcpubench.so oracle/cpu_bench.c -ldl -lpthread
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+typedef struct { void* p; size_t size, pos; } zbuf;
+typedef void* (*create_t)(void);
+typedef size_t (*setparam_t)(void*, int, int);
+typedef size_t (*compress2_t)(void*, void*, size_t, const void*, size_t);
+typedef size_t (*stream2_t)(void*, zbuf*, zbuf*, int);
+typedef size_t (*free_t)(void*);
+typedef size_t (*kref_t)(void*, size_t, const char*, size_t);
+
+typedef struct {
+    int id, threads, passes; uint32_t n, slice; const unsigned char* base;
+    create_t create; setparam_t setp; compress2_t c2; stream2_t s2; free_t freec; kref_t kref;
+    pthread_barrier_t* bar; double* secs; uint64_t* bytes; uint64_t* errors;
+} job;
+
+static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
+
+static void* worker(void* arg)
+{
+    job* j = (job*)arg;
+    size_t const cap = j->slice + j->slice / 128 + 1024;
+    size_t const chunk = j->slice / 10 > 8192 ? j->slice / 10 : 8192;
+    unsigned char* out = (unsigned char*)malloc(cap);
+    void* cctx = j->create ? j->create() : NULL;
+    if (cctx) j->setp(cctx, 100, 3);                                 /* ZSTD_c_compressionLevel = 100 (ZstdCompressor.jvm.kt:41) */
+    uint32_t const per = (j->n + j->threads - 1) / j->threads;
+    uint32_t const lo = (uint32_t)j->id * per, hi = lo + per < j->n ? lo + per : j->n;
+    for (int p = 0; p < j->passes; p++) {
+        pthread_barrier_wait(j->bar);
+        double const t0 = now();
+        uint64_t total = 0, bad = 0;
+        for (uint32_t i = lo; i < hi; i++) {
+            const unsigned char* src = j->base + (size_t)i * j->slice;
+            size_t r;
+            if (j->kref) r = j->kref(out, cap, (const char*)src, j->slice);
+            else if (j->slice <= 131072) r = j->c2(cctx, out, cap, src, j->slice);
+            else {
+                zbuf ib = { (void*)src, j->slice, 0 };
+                r = 0;
+                for (;;) {
+                    zbuf ob = { out, chunk, 0 };
+                    size_t const q = j->s2(cctx, &ob, &ib, 2);          /* ZSTD_e_end from the first call, as the reference's driver */
+                    r += ob.pos;
+                    if (q == 0) break;
+                    if (q > ((size_t)1 << 40)) { r = q; break; }
+                }
+            }
+            if (r == 0 || r > ((size_t)1 << 40)) bad++; else total += r;
+        }
+        pthread_barrier_wait(j->bar);
+        if (j->id == 0) j->secs[p] = now() - t0;
+        j->bytes[(size_t)p * j->threads + j->id] = total;
+        j->errors[j->id] += bad;
+    }
+    if (cctx && j->freec) j->freec(cctx);
+    free(out);
+    return NULL;
+}
+
+/* Compresses slices base[i * slice .. ), i < n, on `threads` host threads, `passes` times (the caller treats the first as a
+ * warm-up).  libpath: a libzstd 1.5.7 (kind "reference"), or NULL with krefpath = the oracle's library (kind "port").
+ * secs[p] = wall time of pass p, frame_bytes = the frames' total size (one pass).  0 on success. */
+__attribute__((visibility("default")))
+int cpubench_zstd_l3(const char* libpath, const char* krefpath, const unsigned char* base, uint32_t n, uint32_t slice,
+                     int threads, int passes, double* secs, uint64_t* frame_bytes, uint64_t* errors)
+{
+    if (threads < 1 || passes < 1 || n == 0) return -1;
+    job proto; memset(&proto, 0, sizeof proto);
+    if (libpath) {
+        void* h = dlopen(libpath, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+        if (!h) return -2;
+        proto.create = (create_t)dlsym(h, "ZSTD_createCCtx"); proto.setp = (setparam_t)dlsym(h, "ZSTD_CCtx_setParameter");
+        proto.c2 = (compress2_t)dlsym(h, "ZSTD_compress2"); proto.s2 = (stream2_t)dlsym(h, "ZSTD_compressStream2");
+        proto.freec = (free_t)dlsym(h, "ZSTD_freeCCtx");
+        unsigned (*ver)(void) = (unsigned (*)(void))dlsym(h, "ZSTD_versionNumber");
+        if (!proto.create || !proto.setp || !proto.c2 || !proto.s2 || !ver || ver() != 10507) return -3;
+    } else {
+        void* h = dlopen(krefpath, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return -2;
+        proto.kref = (kref_t)dlsym(h, "kref_zstd_l3_compress");
+        if (!proto.kref) return -3;
+    }
+    pthread_barrier_t bar; pthread_barrier_init(&bar, NULL, (unsigned)threads);
+    uint64_t* bytes = (uint64_t*)calloc((size_t)passes * threads, sizeof(uint64_t));
+    uint64_t* errs = (uint64_t*)calloc((size_t)threads, sizeof(uint64_t));
+    job* jobs = (job*)calloc((size_t)threads, sizeof(job));
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    for (int t = 0; t < threads; t++) {
+        jobs[t] = proto; jobs[t].id = t; jobs[t].threads = threads; jobs[t].passes = passes; jobs[t].n = n; jobs[t].slice = slice; jobs[t].base = base;
+        jobs[t].bar = &bar; jobs[t].secs = secs; jobs[t].bytes = bytes; jobs[t].errors = errs;
+        pthread_create(&th[t], NULL, worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    uint64_t tot = 0, bad = 0;
+    for (int t = 0; t < threads; t++) { tot += bytes[(size_t)(passes - 1) * threads + t]; bad += errs[t]; }
+    *frame_bytes = tot; *errors = bad;
+    pthread_barrier_destroy(&bar);
+    free(bytes); free(errs); free(jobs); free(th);
+    return 0;
+}

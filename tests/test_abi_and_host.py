@@ -148,3 +148,26 @@ def test_jni_shims_export_what_the_kotlin_side_binds():
     from kompressor_amd import build
     if build.find_jni_include() is None:
         assert build.build_jni() == []
+
+
+def test_cpu_bench_harness_times_the_oracle_port(tmp_path):
+    """oracle/cpu_bench.c (bench.py's cpu_baseline leg): pthreads over a few slices with the oracle's restatement as the
+    compressor -- frame bytes equal the oracle's own, every pass is timed, and the host-core accounting is sane."""
+    import ctypes
+    import numpy as np
+    import bench
+    from kompressor_amd import corpus
+    hc = bench.host_cores()
+    assert 1 <= hc["threads_used"] <= hc["nproc"] and hc["affinity"] >= 1
+    lib = ctypes.CDLL(bench.build_cpu_bench())
+    lib.cpubench_zstd_l3.restype = ctypes.c_int
+    lib.cpubench_zstd_l3.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    n, S = 12, 65536
+    buf = corpus.make(300, n, S)
+    secs = (ctypes.c_double * 2)(); fb, err = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    rc = lib.cpubench_zstd_l3(None, helpers.build_oracle().encode(), buf.ctypes.data, n, S, 3, 2, secs, ctypes.byref(fb), ctypes.byref(err))
+    assert rc == 0 and err.value == 0 and secs[0] > 0 and secs[1] > 0
+    o = helpers.oracle()
+    assert fb.value == sum(len(o.compress(buf[i * S:(i + 1) * S].tobytes())) for i in range(n))
+    assert bench.count_gpus_without_hip() in (-1, 0) or bench.count_gpus_without_hip() > 0
