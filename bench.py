@@ -132,6 +132,52 @@ def cpu_baseline(host, n_slices, frames_expected, sample=None):
                       f"1 warm-up + {passes - 1} passes, median {med:.2f} s; total frame bytes {'match' if ok else 'DIFFER from'} the GPU's{note}"}
 
 
+def streaming_abi_figure(host, n_slices):
+    """What a Kotlin caller can bind today: ZstdCompressor(3).transform(bytes) per slice through kmp_zstd_compress_stream (host
+    memory in, host memory out, the reference's one-shot driver loop).  One context taking slices in turn, then 64 contexts on
+    64 threads (AsyncSliceTransform.kt:56-65 runs transforms like that): the library coalesces closing calls that arrive
+    together into one batch.  And the same slices through kmp_zstd_compress_host_batch, the call jni/zstd/BatchWrapper.cpp adds."""
+    import threading
+    from kompressor_amd import ZstdCompressor
+    from kompressor_amd.batch import compress_host_batch
+    slices = [host[i * SLICE:(i + 1) * SLICE].tobytes() for i in range(min(n_slices, 1024))]
+    c = ZstdCompressor(3)
+    c.transform_bytes(slices[0])                                   # (creates the engine)
+    one_n = 64
+    t0 = time.perf_counter()
+    for i in range(one_n):
+        c.transform_bytes(slices[i])
+    one_dt = time.perf_counter() - t0
+    T, per = 64, 16
+    ctxs = [ZstdCompressor(3) for _ in range(T)]
+    sizes = [0] * T
+
+    def work(t):
+        for k in range(per):
+            sizes[t] += len(ctxs[t].transform_bytes(slices[(t * per + k) % len(slices)]))
+
+    for warm in (True, False):
+        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        many_dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    frames = compress_host_batch(slices)
+    hb_dt = time.perf_counter() - t0
+    one_us, many_us = one_dt / one_n * 1e6, many_dt / (T * per) * 1e6
+    return {"one_context": {"us_per_slice": round(one_us, 1), "GBps": round(SLICE / one_us / 1e3, 4), "slices": one_n},
+            "contexts_64": {"us_per_slice": round(many_us, 1), "GBps": round(SLICE / many_us / 1e3, 4), "slices": T * per, "threads": T,
+                            "speedup_over_one_context": round(one_us / many_us, 1)},
+            "host_batch_call": {"us_per_slice": round(hb_dt / len(slices) * 1e6, 1), "GBps": round(len(slices) * SLICE / hb_dt / 1e9, 3), "slices": len(slices)},
+            "what": f"{SLICE // 1024} KiB slices in host memory, frames back in host memory, Python threads over ctypes (the C calls run without the GIL); "
+                    "one_context / contexts_64: ZstdCompressor(3).transform_bytes per slice = kmp_zstd_compress_stream under the reference's driver loop "
+                    "(closing calls of concurrent contexts are coalesced into one device batch); host_batch_call: kmp_zstd_compress_host_batch "
+                    "(includes joining the slices into one buffer in Python)"}
+
+
 def cpu_decode_baseline(frames_host, offs, lens, n_slices, sample=32768):
     """libzstd 1.5.7 ZSTD_decompress over the first `sample` frames the GPU produced, on the host threads."""
     from concurrent.futures import ThreadPoolExecutor
@@ -218,6 +264,7 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="N = 1: skip the end-to-end figure that includes the host copies over PCIe")
     ap.add_argument("--team", type=int, default=0, help="lanes per slice in the match kernel (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="N = 1: skip the figures of the streaming entry point (what a Kotlin caller binds)")
     ap.add_argument("--level", type=int, default=3, help="zstd level: 3 (BASELINE configs), or 1 / 2 (strategy fast)")
     ap.add_argument("--dict-kib", type=int, default=0,
                     help="compress with a raw-content dictionary of this many KiB shared by all slices (ZstdCompressor(3, dictionary))")
@@ -682,6 +729,8 @@ def main():
             res["with_scatter_gather"] = exchange
         if pcie:
             res["end_to_end_pcie"] = pcie
+        if not args.no_stream and world == 1 and SLICE <= 131072:
+            res["streaming_abi"] = streaming_abi_figure(host, n)
         if not args.no_cpu and world == 1:          # the CPU baseline is a rank-0, N = 1 figure
             sample = min(n, 16384)
             res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()), sample)

@@ -318,6 +318,20 @@ KMP_API int kmp_batch_last_rounds(kmp_batch_ctx* ctx);
  * regions of one device's HBM (tools/region_probe.py). */
 KMP_API int kmp_debug_probe_region(void* d_region, size_t bytes, uint32_t blocks, uint32_t iters, float* ms, void* hip_stream);
 
+/* The batch for callers that hold HOST memory (the JVM): slices h_src[in_off[i] .. + in_len[i]) of at most 128 KiB in, frames at
+ * h_dst[out_off[i] ..) out (out_cap[i] bytes of room: kmp_zstd_compress_bound(in_len[i]) always suffices), out_len[i] = frame
+ * size (0 with KMP_ERR_CAPACITY when the room was too small).  Levels 1 .. 3; the frames are what ZstdCompressor(level) returns
+ * for each slice on its own.  Pinned staging, one copy in, the device batch, one copy out; batches larger than the staging go
+ * through in pieces.  jni/zstd/BatchWrapper.cpp binds the two for direct ByteBuffers.  Reference counterpart: none -- the
+ * reference compresses one slice per call (ZstdWrapper.kt:35-46); this is the call a maintainer adds to hand the GPU a batch.
+ * kmp_zstd_compress_stream itself coalesces the closing calls of concurrent contexts into such batches (KMP_COALESCE=0: off;
+ * KMP_COALESCE_US: the gather window, default 150 microseconds; KMP_COALESCE_MAX: slices per batch, default 256). */
+KMP_API int kmp_zstd_compress_host_batch(int device, int level, const void* h_src, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+                                         void* h_dst, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len);
+/* frames in, content out (out_cap[i] = room, at most 128 KiB); status[i] = libzstd's error number for entry i, 0 = fine */
+KMP_API int kmp_zstd_decompress_host_batch(int device, const void* h_src, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+                                           void* h_dst, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, uint32_t* status);
+
 /* diagnostic (no reference counterpart): random 4-byte loads per second, and load + store-into-the-same-word pairs per second,
  * over the context's level-3 team tables where they lie, measured once when the context was created (both 0 for a context
  * whose tables are below 4 GiB).  bench.py prices the parser's measured memory requests with them. */

@@ -15,6 +15,54 @@ def compress_bound(n: int) -> int:
     return _lib.load().kmp_zstd_compress_bound(n)
 
 
+def compress_host_batch(slices, level=3, device=0):
+    """kmp_zstd_compress_host_batch: slices held in HOST memory (a list of bytes-like objects of at most 128 KiB) -> their
+    frames, through pinned staging and the device batch (the call jni/zstd/BatchWrapper.cpp binds for the JVM)."""
+    import numpy as np
+    lib = _lib.load()
+    n = len(slices)
+    lens = np.array([len(s) for s in slices], dtype=np.uint32)
+    offs = np.zeros(n, dtype=np.uint64)
+    if n > 1:
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+    src = np.frombuffer(b"".join(bytes(s) for s in slices) + b"\0", dtype=np.uint8)
+    caps = np.array([compress_bound(int(l)) for l in lens], dtype=np.uint32)
+    ooff = np.zeros(n, dtype=np.uint64)
+    if n > 1:
+        ooff[1:] = np.cumsum(caps[:-1], dtype=np.uint64)
+    dst = np.empty(int(caps.sum()) + 1, dtype=np.uint8)
+    olen = np.zeros(n, dtype=np.uint32)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)          # noqa: E731
+    rc = lib.kmp_zstd_compress_host_batch(device, level, p(src), p(offs), p(lens), n, p(dst), p(ooff), p(caps), p(olen))
+    if rc != 0:
+        raise RuntimeError(f"kmp_zstd_compress_host_batch failed ({rc}): {_lib.last_error()}")
+    return [dst[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)]
+
+
+def decompress_host_batch(frames, caps, device=0):
+    """kmp_zstd_decompress_host_batch: frames in host memory -> (contents, statuses); caps[i] = room for entry i (<= 128 KiB)."""
+    import numpy as np
+    lib = _lib.load()
+    n = len(frames)
+    lens = np.array([len(f) for f in frames], dtype=np.uint32)
+    offs = np.zeros(n, dtype=np.uint64)
+    if n > 1:
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+    src = np.frombuffer(b"".join(bytes(f) for f in frames) + b"\0", dtype=np.uint8)
+    caps = np.array(caps, dtype=np.uint32)
+    ooff = np.zeros(n, dtype=np.uint64)
+    if n > 1:
+        ooff[1:] = np.cumsum(caps[:-1], dtype=np.uint64)
+    dst = np.empty(int(caps.sum()) + 1, dtype=np.uint8)
+    olen = np.zeros(n, dtype=np.uint32)
+    st = np.zeros(n, dtype=np.uint32)
+    p = lambda a: ctypes.c_void_p(a.ctypes.data)          # noqa: E731
+    rc = lib.kmp_zstd_decompress_host_batch(device, p(src), p(offs), p(lens), n, p(dst), p(ooff), p(caps), p(olen), p(st))
+    if rc != 0:
+        raise RuntimeError(f"kmp_zstd_decompress_host_batch failed ({rc}): {_lib.last_error()}")
+    return [dst[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)], [int(x) for x in st]
+
+
 class ZstdBatch:
     """Owns the device workspace for batches of up to `max_slices` slices of up to
     `max_slice_bytes` bytes (<= 128 KiB) on one GPU."""

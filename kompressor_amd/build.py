@@ -63,8 +63,9 @@ def find_jni_include():
     return None
 
 
-JNI_SHIMS = {"libzstd-jni.so": os.path.join(ROOT, "jni", "zstd", "Wrapper.cpp"),       # the names ZstdWrapper.kt:10-17 /
-             "libz-jni.so": os.path.join(ROOT, "jni", "zlib", "Wrapper.cpp")}          # ZlibWrapper.kt load
+JNI_SHIMS = {"libzstd-jni.so": [os.path.join(ROOT, "jni", "zstd", "Wrapper.cpp"),      # the names ZstdWrapper.kt:10-17 /
+                                os.path.join(ROOT, "jni", "zstd", "BatchWrapper.cpp")],  # (+ the batch exports)
+             "libz-jni.so": [os.path.join(ROOT, "jni", "zlib", "Wrapper.cpp")]}         # ZlibWrapper.kt load
 
 
 def build_jni(force=False):
@@ -74,12 +75,12 @@ def build_jni(force=False):
     if inc is None:
         return []
     out = []
-    for name, src in JNI_SHIMS.items():
+    for name, srcs in JNI_SHIMS.items():
         target = os.path.join(HERE, name)
-        deps = [src, os.path.join(ROOT, "jni", "common", "kmp_jni.h"), os.path.join(ROOT, "include", "kompressor_hip.h")]
+        deps = srcs + [os.path.join(ROOT, "jni", "common", "kmp_jni.h"), os.path.join(ROOT, "include", "kompressor_hip.h")]
         if force or _newer(target, deps):
             cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden"] + [f"-I{d}" for d in inc] + \
-                  ["-o", target, src, f"-L{HERE}", "-lkompressor_hip", "-Wl,-rpath,$ORIGIN"]
+                  ["-o", target] + srcs + [f"-L{HERE}", "-lkompressor_hip", "-Wl,-rpath,$ORIGIN"]
             subprocess.run(cmd, check=True)
         out.append(target)
     return out

@@ -1267,6 +1267,8 @@ extern "C" int kmp_compact_batch(kmp_batch_ctx* c, const void* d_src, const uint
     return KMP_OK;
 }
 
+#include "kmp_coalesce.h"
+
 // --------------------------------------------------------------------------
 // streaming-compatible single-slice API (mirrors libzstd's calling convention)
 // --------------------------------------------------------------------------
@@ -1405,6 +1407,15 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
         if (c->level == 3 && (n - end_avail) % lap == 0) tail_direct = (u32)end_avail;
     }
     if (streaming && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
+    // the plain case -- level 3, no dictionary, the whole slice at once, one block -- joins whatever other contexts are
+    // closing right now: one batch for all of them (kmp_coalesce.h); the frame is the one this context would get alone
+    if (!streaming && c->level == 3 && c->dict.empty() && n <= KMP_MAX_SLICE_BYTES && coalesce_enabled()) {
+        int dev = 0;
+        if (c->dev.batch) dev = c->dev.batch->device; else if (hipGetDevice(&dev) != hipSuccess) return KERRC(ZE_GENERIC);
+        int const rc = coalesced_compress(dev, c->in.data(), (u32)n, &c->out);
+        if (rc == KMP_OK) return 0;
+        (void)hipGetLastError();                    // fall through: compress alone
+    }
     bool const l1big = c->level != 3 && (streaming || n > KMP_MAX_SLICE_BYTES);      // level 1 / 2, frame of several blocks / stream
     u32 const lwin = (c->level == 1 ? 512u : 1024u) << 10;                             // their windows
     if (l1big && n > lwin) return KERRC(ZE_parameter_unsupported);                     // beyond the window: CPU library

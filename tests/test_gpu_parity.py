@@ -857,6 +857,49 @@ def test_slices_longer_than_the_context_are_refused_not_overrun():
         b.close()
 
 
+def test_host_batch_and_the_coalescer_of_the_streaming_entry_point(G):
+    """The batch a JVM can reach.  kmp_zstd_compress_host_batch / kmp_zstd_decompress_host_batch (what jni/zstd/BatchWrapper.cpp
+    binds): host slices in, frames out, equal to the oracle's; more slices than the staging holds go through in pieces.  And
+    kmp_zstd_compress_stream's coalescer: 48 contexts closing their slices at once from 48 threads get, each, the frame it would
+    have got alone (AsyncSliceTransform.kt:56-65 runs transforms like this)."""
+    import threading
+    from kompressor_amd import ZstdCompressor, ZstdDecompressor
+    from kompressor_amd.batch import compress_host_batch, decompress_host_batch
+    o = helpers.oracle()
+    rng = np.random.default_rng(3)
+    datas = []
+    for i in range(1100):                                   # > KMP_HOST_BATCH_SLICES (1024): two pieces
+        n = int(rng.integers(0, 131073)) if i % 7 else (0, 1, 131072, 65536, 7, 8, 9)[(i // 7) % 7]
+        datas.append(corpus.make(70000 + i, 1, max(n, 1), mix=ord("TXSBDIZR"[i % 8])).tobytes()[:n])
+    frames = compress_host_batch(datas)
+    for k in range(0, len(datas), 37):
+        assert frames[k] == o.compress(datas[k]), (k, len(datas[k]))
+    for lvl in (1, 2):
+        fl = compress_host_batch(datas[:40], level=lvl)
+        for d, f in zip(datas[:40], fl):
+            assert f == o.compress_level(d, lvl), (lvl, len(d))
+    outs, st = decompress_host_batch(frames, [max(len(d), 1) for d in datas])
+    assert st == [0] * len(datas) and outs == datas
+    outs, st = decompress_host_batch([frames[3][:-2], b"junk" * 8, frames[5]], [131072, 131072, 4])
+    assert st[0] != 0 and st[1] != 0 and (st[2] == 70 or len(datas[5]) <= 4)
+    # the coalescer
+    picks = [datas[i] for i in range(0, 48 * 3, 3)]
+    results = [None] * len(picks)
+
+    def work(t):
+        c = ZstdCompressor(3)
+        results[t] = (c.transform_bytes(picks[t]), c.transform_bytes(picks[(t + 1) % len(picks)]))      # (a context is reused)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(len(picks))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for t, (a, b2) in enumerate(results):
+        assert a == o.compress(picks[t]) and b2 == o.compress(picks[(t + 1) % len(picks)]), t
+    assert ZstdDecompressor().transform_bytes(results[0][0]) == picks[0]
+
+
 def test_python_wrapper_check_raises_on_a_refused_slice():
     """ZstdBatch.compress(check=True) reads the status word: a slice longer than the context holds is an exception, not an
     empty frame that compact() would drop silently."""
