@@ -357,9 +357,14 @@ static void fill_window(dstate* s)
      * zero-allocated); this window starts zeroed and bytes once written keep their value, as there */
 }
 
+/* hooks of tools/deflate_predict_model.c (a model of a predicted-parse scheme); nothing by default */
+#ifndef DREF_TRACE_REQ
+#define DREF_TRACE_REQ(pos) ((void)0)
+#define DREF_CHAIN(c) (c)
+#endif
 static u32 longest_match(dstate* s, u32 cur_match)
 {
-    unsigned chain_length = s->max_chain; const u8* scan = s->window + s->strstart; const u8* match; int len;
+    unsigned chain_length = DREF_CHAIN(s->max_chain); const u8* scan = s->window + s->strstart; const u8* match; int len;
     int best_len = (int)s->prev_length; int nice_match = (int)s->nice_match;
     u32 limit = s->strstart > MAX_DIST ? s->strstart - MAX_DIST : NIL;
     const u8* strend = s->window + s->strstart + MAX_MATCH;
@@ -396,6 +401,7 @@ static void deflate_slow_finish(dstate* s)
         s->prev_length = s->match_length; s->prev_match = s->match_start;
         s->match_length = MIN_MATCH - 1;
         if (hash_head != NIL && s->prev_length < s->max_lazy && s->strstart - hash_head <= MAX_DIST) {
+            DREF_TRACE_REQ(s->strstart);
             s->match_length = longest_match(s, hash_head);
             if (s->match_length <= 5 && (s->match_length == MIN_MATCH && s->strstart - s->match_start > TOO_FAR)) s->match_length = MIN_MATCH - 1;
         }
