@@ -717,7 +717,7 @@ def main():
                        "slices_per_gpu": n, "slice_bytes": SLICE, "ratio": round(in_bytes / frame_bytes, 4),
                        "team_lanes": b.lib and (args.team or int(os.environ.get("KMP_TEAM_LANES", "4"))), "parallelism": f"slice-sharded x{world}",
                        "parser": {"0": "zstd_match.h", "1": "zstd_match2.h (split-phase, 256-byte window)", "2": "zstd_match2.h (split-phase, 512-byte window)"}.get(os.environ.get("KMP_MATCH_V2", "0"), "?"),
-                       "table_span_gib": int(os.environ.get("KMP_TABLE_SPAN_GIB", "0")) or "the arena's own"},
+                       "table_span_gib": int(os.environ.get("KMP_TABLE_SPAN_GIB", "100")) or "packed"},
             "roofline": {"bound": "hbm", "kernel": "k_zstd_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms_match, 3), "launches_per_step": launches},

@@ -341,13 +341,15 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
     {
         // The workspace of a context with large team tables is ONE allocation (an arena): the tables in four pieces (team t:
         // piece t & 3) with the sequence, literal and staging buffers between them, laid out over a span of
-        // KMP_TABLE_SPAN_GIB (default 80) GiB.  Why a span: read + insert pairs run a quarter faster when they straddle
+        // KMP_TABLE_SPAN_GIB (default 100) GiB.  Why a span: read + insert pairs run a quarter faster when they straddle
         // the coarse blocks this device's HBM is laid out in -- 20 G pairs/s inside any 24 .. 36 GiB, 25 - 26 from 72 GiB of
         // span on (tools/spanprobe, profiles/r03_match_floor.txt) -- and the parser lives on that rate: the same context
-        // takes 205 ms per batch with its 41 GiB packed, 194 with separate allocations wherever they land, 182 over 80 GiB.
-        // Nothing is allocated transiently and nothing is probed: what creation takes is what the context holds, the
-        // gaps between the parts included (39 GiB of a 65 536-slice context's 80).  KMP_TABLE_SPAN_GIB=0 packs the arena
-        // (memory over ~12 % of parser time); a device without that much free memory gets the packed form by itself.
+        // takes 205 ms per batch with its 41 GiB packed (232 over 60 GiB on one box: all four pieces inside one block),
+        // 194 with separate allocations wherever they land, 183 - 185 over 100 - 140 GiB on every box tried; 80 GiB gave
+        // 182 on one box and 206 on another (where the blocks' boundaries fall differs), so the default is 100.
+        // Nothing is allocated transiently: what creation takes is what the context holds, the gaps between the parts
+        // included (59 GiB of a 65 536-slice context's 100).  KMP_TABLE_SPAN_GIB=0 packs the arena (memory over ~11 % of
+        // parser time); a device without that much free memory gets the packed form by itself.
         // KMP_TABLE_ARENA=0, small tables: separate allocations, tables in one piece.
         size_t const tbytes = (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32);
         size_t const A = (size_t)2 << 20;                                // every part starts on a 2 MiB boundary
@@ -357,7 +359,7 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
         if (env_u32("KMP_TABLE_ARENA", 1) && tbytes >= ((size_t)4 << 30) && (c->nteams & 3u) == 0) {
             size_t const piece = up(tbytes / 4);
             size_t const need = 4 * piece + seqs_b + lits_b + meta_b + scr_b;
-            size_t want = (size_t)env_u32("KMP_TABLE_SPAN_GIB", 80) << 30;
+            size_t want = (size_t)env_u32("KMP_TABLE_SPAN_GIB", 100) << 30;
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
             if (want > need && fr < want + ((size_t)16 << 30)) want = 0;    // not that much room: pack

@@ -159,6 +159,9 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
     u64 sq0 = 0, sq1 = 0;
     // long-table lookup of the first position of the next step, when the last step's extra lane already made it
     bool carry = false; u32 carry_idxl = 0;
+    // flags bit 7 (experiment): the speculation width follows the last hit -- after a hit at lane w the next step looks at
+    // w + 1 positions, after a step without a hit at all G - 1 again: the probes of lanes behind a winner are reads that buy nothing
+    int kmax = G - 1; bool const adaptive = !BLK && (a.flags & 128u) != 0;
 
     for (;;) {
         // ================= fetch the next slice =======================
@@ -255,8 +258,8 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             if (k == 0 && state == KST_SEARCH) KX_STAT(5, 1);   // team search steps
             bool const srch = state == KST_SEARCH;
             int const pos = ip + k * step;
-            bool const cand = srch && (k < G - 1) && (k == 0 || pos < nextStep) && (pos + step <= ilimit);
-            bool const prov = srch && (k == 0 || ((k == 1 || pos - step < nextStep) && pos <= ilimit));
+            bool const cand = srch && (k < kmax) && (k == 0 || pos < nextStep) && (pos + step <= ilimit);
+            bool const prov = srch && (k == 0 || ((k == 1 || pos - step < nextStep) && pos <= ilimit && k <= kmax));
             u64 w = 0; u32 hl = 0, hs = 0, el = 0, es = 0;
             if (prov) {
                 w = kx_ld64(src + pos);
@@ -347,6 +350,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
 
             if (srch) {
                 guard++;
+                if (adaptive) { kmax = th ? wl + 1 : G - 1; if (kmax > G - 1) kmax = G - 1; }
                 if (!th) {
                     ip += K * step;
                     carry = p_prov && K > 0; carry_idxl = p_idxl;

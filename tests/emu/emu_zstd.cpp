@@ -17,6 +17,7 @@ int emu_zstd_match(const u8* src, const u64* in_off, const u32* in_len, u32 n, i
     a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
     a.seqs = seqs; a.seq_cap = seq_cap; a.lits = lits; a.lit_cap = lit_cap; a.meta = meta;
     a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter; a.flags = 0; a.fstate = nullptr; a.big_tables = nullptr;
+    if (getenv("KXEMU_MATCH_FLAGS")) a.flags |= (u32)atoi(getenv("KXEMU_MATCH_FLAGS")) & 128u;       // (bit 7: adaptive speculation width)
     kxemu::failed = 0;
     switch (G) {
     case 2:  kxemu::launch(nblocks, [&]() { zstd_match_body<2>(a); }); break;

@@ -182,8 +182,8 @@ def test_full_batch_roundtrip_and_checksum_of_checksums(monkeypatch):
     torch.cuda.synchronize()
     taken = free0 - torch.cuda.mem_get_info()[0]
     # team tables 24 GiB + sequences 8.6 + literals 4.3 + staging words 4.3 GB + small change = 41 GiB of parts, laid out over
-    # the arena's default span of 80 GiB (KMP_TABLE_SPAN_GIB): nothing transient, what creation takes is what the context holds
-    assert 79 << 30 < taken < 83 << 30, taken / 2 ** 30
+    # the arena's default span of 100 GiB (KMP_TABLE_SPAN_GIB): nothing transient, what creation takes is what the context holds
+    assert 99 << 30 < taken < 103 << 30, taken / 2 ** 30
     src = torch.empty(n * S, dtype=torch.uint8, device="cuda")
     chunk = 4096
     for c in range(0, n, chunk):
