@@ -312,6 +312,26 @@ def main():
     n = args.slices
     first = rank * n                                   # this rank's block of the global slice index space
     mix = corpus.MIX_TEXT_BINARY if args.config == 3 else corpus.MIX_CONFIG1
+    # this rank's HBM plan, checked against what the device has free before anything is allocated (configs[3]'s share is
+    # 131 072 slices per GPU: the 8-GPU run must fail with a sentence, not with an allocator error half way through)
+    if args.mode == "compress" and not big:
+        GiB = float(1 << 30)
+        stride = ((SLICE + (SLICE >> 8) + (((128 << 10) - SLICE) >> 11 if SLICE < (128 << 10) else 0)) + 8 + 63) & ~63
+        slots = min(n, 65536)
+        parts = {"slices": n * SLICE, "frames_strided": n * stride, "frames_dense": n * stride,
+                 "context_parts": n * ((SLICE // 4 + 24) * 8 + 2 * (SLICE + 64) + 256 + 32) + slots * 393216,
+                 "exchange_on_root": (n * world * SLICE + int(n * world * SLICE / 2.3)) if (world > 1 and not args.no_exchange and rank == 0) else 0,
+                 "exchange_per_rank": n * SLICE if (world > 1 and not args.no_exchange) else 0}
+        span = int(os.environ.get("KMP_TABLE_SPAN_GIB", "100")) << 30
+        parts["context_arena"] = max(parts.pop("context_parts"), span if slots * 393216 >= (4 << 30) else 0)
+        need = sum(parts.values())
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        plan = {"rank": rank, "need_GiB": round(need / GiB, 1), "free_GiB": round(free_b / GiB, 1), **{k: round(v / GiB, 1) for k, v in parts.items()}}
+        print("bench.py HBM plan: " + json.dumps(plan), file=sys.stderr, flush=True)
+        if need + (2 << 30) > free_b:
+            print(f"bench.py: rank {rank} needs {need / GiB:.1f} GiB of HBM and {free_b / GiB:.1f} GiB are free: "
+                  "fewer --slices, --no-exchange, or KMP_TABLE_SPAN_GIB=0 (a packed context arena)", file=sys.stderr)
+            sys.exit(3)
     # rank-local generation from seeds, in pieces of 1 GiB; the host keeps the whole block only up to 4 GiB
     # (the CPU baseline and the spot checks read the first slices)
     src = torch.empty(n * SLICE, dtype=torch.uint8, device=dev)

@@ -218,7 +218,7 @@ extern "C" const char* kmp_version(void) { return "kompressor_hip 0.3 (gfx950; z
 // --------------------------------------------------------------------------
 enum { KMP_MAX_CHUNKS = 4 };
 struct kmp_batch_ctx {
-    int device; u32 max_slices, max_slice_bytes; int G; u32 match_blocks, match_blocks_l3, nteams, l3_team_slots;
+    int device; u32 max_slices, max_slice_bytes; int G; int team_fixed; u32 match_blocks, match_blocks_l3, nteams, l3_team_slots;
     u32 seq_cap, lit_cap, scratch_words;
     KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* team_epoch; u32* counter;
     int profiling; hipEvent_t ev[14]; int ev_valid[7];
@@ -299,12 +299,14 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
 {
     if (!out || max_slices == 0) { g_last_error = "kmp_batch_create: bad argument"; return KMP_ERR_ARG; }
     if (max_slice_bytes > KMP_MAX_BIG_SLICE_BYTES) { g_last_error = "kmp_batch_create: slices above 1 GiB are not supported"; return KMP_ERR_CAPACITY; }
+    int const team_fixed = (team_lanes != 0 || getenv("KMP_TEAM_LANES")) ? 1 : 0;
     if (team_lanes == 0) team_lanes = (int)env_u32("KMP_TEAM_LANES", 4);
     if (team_lanes != 2 && team_lanes != 4 && team_lanes != 8 && team_lanes != 16 && team_lanes != 32 && team_lanes != 64) { g_last_error = "team_lanes must be 2, 4, 8, 16, 32 or 64"; return KMP_ERR_ARG; }
     HIP_TRY(hipSetDevice(device));
     kmp_batch_ctx* c = new (std::nothrow) kmp_batch_ctx();
     if (!c) { g_last_error = "out of host memory"; return KMP_ERR_ARG; }
     memset(c, 0, sizeof(*c));
+    c->team_fixed = team_fixed;
     int const rc = batch_create_body(c, device, max_slices, max_slice_bytes, team_lanes);
     if (rc != KMP_OK) { std::string const keep = g_last_error; kmp_batch_destroy(c); g_last_error = keep; return rc; }      // nothing half-built is left behind
     *out = c;
@@ -857,7 +859,12 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
     if (tunable && c->tune_state < 2) HIP_TRY(hipEventRecord(c->tune_ev[0], st));
     HIP_TRY(hipMemsetAsync(c->counter, 0, 4 * KMP_MAX_CHUNKS, st));
-    u32 const tpw = 64 / (u32)c->G;
+    // Team width per batch: a small batch is bound by each slice's own chain, not by the memory system, and 8 lanes per slice
+    // (7 positions per step) run it a quarter faster than 4 (64 slices: 29 ms against 39; 4 096: 43 against 49; 16 384 and up: 4
+    // wins).  The tables belong to team slots, not to a width, so the choice is free per batch (KMP_TEAM_LANES or an explicit
+    // team_lanes fixes it).
+    int const G = (c->G == 4 && !c->team_fixed && n <= 8192u) ? 8 : c->G;
+    u32 const tpw = 64 / (u32)G;
     u32 const match_flags = c->knob.match_flags, entropy_pad = c->knob.entropy_pad;   // experiments only
     u32 const per = (n + chunks - 1) / chunks;
     u32 starts[KMP_MAX_CHUNKS + 1];
@@ -873,18 +880,19 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         m.seqs = c->seqs + (size_t)first * c->seq_cap; m.seq_cap = c->seq_cap; m.meta = c->meta + first;
         m.lits = c->lits + (size_t)first * c->lit_cap; m.lit_cap = c->lit_cap;
         m.tables = c->tables; for (int ts_ = 0; ts_ < 4; ts_++) m.tseg[ts_] = c->tseg[ts_]; m.tseg_n = c->tseg_n; m.team_epoch = c->team_epoch; m.counter = c->counter + ci; m.flags = match_flags;
-        u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > c->match_blocks_l3) blocks = c->match_blocks_l3;
+        u32 const max_blocks = (u32)((u64)c->match_blocks_l3 * (64u / (u32)c->G) / tpw);      // the context's team slots at this batch's width
+        u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > max_blocks) blocks = max_blocks;
         if (c->profiling) HIP_TRY(hipEventRecord(c->evm[ci][0], st));
-        if (c->knob.match_v2 && (c->G == 2 || c->G == 4 || c->G == 8)) {
+        if (c->knob.match_v2 && (G == 2 || G == 4 || G == 8)) {
             m.flags |= 4u;                                                // this parser never copies literals: the entropy kernel gathers them
             bool const r512 = c->knob.match_v2 == 2;
-            switch (c->G) {
+            switch (G) {
             case 2:  hipLaunchKernelGGL((k_zstd_match2<2, 256>), dim3(blocks), dim3(64), 0, st, m); break;
             case 4:  if (r512) hipLaunchKernelGGL((k_zstd_match2<4, 512>), dim3(blocks), dim3(64), 0, st, m); else hipLaunchKernelGGL((k_zstd_match2<4, 256>), dim3(blocks), dim3(64), 0, st, m); break;
             default: hipLaunchKernelGGL((k_zstd_match2<8, 512>), dim3(blocks), dim3(64), 0, st, m); break;
             }
         } else
-        switch (c->G) {
+        switch (G) {
         case 2:  hipLaunchKernelGGL(k_zstd_match<2>, dim3(blocks), dim3(64), 0, st, m); break;
         case 4:  hipLaunchKernelGGL(k_zstd_match<4>, dim3(blocks), dim3(64), 0, st, m); break;
         case 8:  hipLaunchKernelGGL(k_zstd_match<8>, dim3(blocks), dim3(64), 0, st, m); break;
