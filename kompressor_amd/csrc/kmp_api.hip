@@ -720,6 +720,11 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
         u32 const resident = 12u * c->cus;
         u32 spw = c->knob.big_spw ? c->knob.big_spw : (n + resident - 1) / resident;
         if (spw < 1) spw = 1; if (spw > 64u / (u32)bigG) spw = 64u / (u32)bigG;
+        if (!c->knob.big_spw) {
+            // ... and a grid that is a whole number of waves per CU when a few more slices per wave give one: the launch lasts as
+            // long as its fullest CU (8 192 x 1 MiB: 3 slices per wave = 2 731 waves 6.5 GB/s, 4 = 2 048 waves 7.3)
+            for (u32 t = spw; t <= 64u / (u32)bigG && t <= spw + 2u; t++) if (((n + t - 1) / t) % c->cus == 0) { spw = t; break; }
+        }
         g.spw = spw;
         u32 const grid = (n + spw - 1) / spw;
         HIP_TRY(hipMemsetAsync(c->big_counters, 0, (size_t)n * 4, st));
