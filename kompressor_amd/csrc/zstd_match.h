@@ -101,18 +101,21 @@ KX_DEV u32 kx_team_extend(bool act, const u8* src, int n, int s, int m, u32 len,
 }
 
 // Number of equal bytes walking backwards from src[s-1] / src[m-1], at most maxback.
+// have0: the bytes of the first round (offset k) were requested earlier (s0 / m0), together with other loads of the match
 template <int G>
-KX_DEV u32 kx_team_backward(bool act, const u8* src, int s, int m, int maxback, int k, int tbase, u64 tmask)
+KX_DEV u32 kx_team_backward(bool act, const u8* src, int s, int m, int maxback, int k, int tbase, u64 tmask, bool have0 = false, u32 s0 = 0, u32 m0 = 0)
 {
     u32 back = 0;
     bool running = act && maxback > 0;
+    bool first = true;
     while (kx_any(running)) {
         if (kx_lane() == 0) KX_STAT(7, 1);                      // backward rounds of the wave
         bool ne = true;
         if (running) {
             int const o = (int)back + k;
-            if (o < maxback) ne = src[s - 1 - o] != src[m - 1 - o];
+            if (o < maxback) ne = (first && have0) ? (s0 != m0) : (src[s - 1 - o] != src[m - 1 - o]);
         }
+        first = false;
         u64 const b = kx_ballot(running && ne);
         u64 const tb = (b >> tbase) & tmask;
         if (running) {
@@ -162,6 +165,12 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
     // flags bit 7 (experiment): the speculation width follows the last hit -- after a hit at lane w the next step looks at
     // w + 1 positions, after a step without a hit at all G - 1 again: the probes of lanes behind a winner are reads that buy nothing
     int kmax = G - 1; bool const adaptive = !BLK && (a.flags & 128u) != 0;
+    // Loads that depend on the new position only are requested together, in the repcode-check block: the bytes of the immediate
+    // repcode test, the bytes of the complementary inserts of the match that just ended (compl_due; wa = the bytes at its
+    // search position + 2, requested when the match was taken) and the words of the first search step (pw: lane k's
+    // position ip + k) -- one round trip instead of three in the chain of every sequence.
+    bool compl_due = false; u64 wa = 0; int c_pos = 0;
+    u64 pw = 0; bool have_pw = false;
 
     for (;;) {
         // ================= fetch the next slice =======================
@@ -203,7 +212,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                         u32 const maxRep = ((u32)ip + 2u) - kx_lowest_prefix((u32)ip + 2u, bw.dictLimit, bw.maxDist);
                         if (off2 > maxRep) { saved2 = off2; off2 = 0; }
                         if (off1 > maxRep) { saved1 = off1; off1 = 0; }
-                        step = 1; nextStep = ip + 256; carry = false;
+                        step = 1; nextStep = ip + 256; carry = false; compl_due = false; have_pw = false;
                         state = (fs.blockSize < 8 || ip + 1 > ilimit) ? KST_CLEANUP : KST_SEARCH;
                     }
                 } else {
@@ -221,7 +230,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     tag = ep << KX_TAG_SHIFT;
                     anchor = 0; ilimit = n - 8;
                     ip = 1; off1 = 1; off2 = 0;     // rep {1,4,8}: 4 exceeds the 1 byte of history at ip=1
-                    step = 1; nextStep = ip + 256; carry = false;
+                    step = 1; nextStep = ip + 256; carry = false; compl_due = false; have_pw = false;
                     state = (n < 8 || ip + 1 > ilimit) ? KST_CLEANUP : KST_SEARCH;
                 }
             }
@@ -233,23 +242,40 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
         if (kx_any(state == KST_REPCHECK)) {
             if (lane == 0) KX_STAT(1, 1);
             bool const inrep = state == KST_REPCHECK;
-            bool hit = false;
-            if (inrep && ip <= ilimit && off2 > 0) hit = kx_ld32(src + ip) == kx_ld32(src + ip - (int)off2);
+            bool const chk = inrep && ip <= ilimit && off2 > 0;
+            bool const docompl = inrep && compl_due && k == 0;            // (compl_due implies ip <= ilimit)
+            u32 a4 = 0, b4 = 0; u64 wb = 0, wc = 0; bool pwv = false;
+            if (chk) { a4 = kx_ld32(src + ip); b4 = kx_ld32(src + ip - (int)off2); }
+            if (inrep && ip + k <= ilimit) { pw = kx_ld64(src + ip + k); pwv = true; }
+            if (docompl) { wb = kx_ld64(src + ip - 2); wc = kx_ld64(src + ip - 1); }
+            if (docompl) {
+                // complementary insertion: curr+2 into both tables, then ip-2 (long) and ip-1 (short)
+                u32 const va = tag | (u32)(c_pos + 2 + 2);
+                L[kx_hash_long(wa, hbL)] = va | (wide ? 0u : kx_chk_long(wa, hbL) << CHKS);
+                L[kx_hash_long(wb, hbL)] = (tag | (u32)(ip - 2 + 2)) | (wide ? 0u : kx_chk_long(wb, hbL) << CHKS);
+                S[kx_hash_short(wa, hbS, mls)] = va | (wide ? 0u : kx_chk_short(wa) << CHKS);
+                S[kx_hash_short(wc, hbS, mls)] = (tag | (u32)(ip - 1 + 2)) | (wide ? 0u : kx_chk_short(wc) << CHKS);
+            }
+            bool const hit = chk && a4 == b4;
             if (inrep) {
+                compl_due = false;
                 if (hit) {
                     if (k == 0) {
-                        u64 const w = kx_ld64(src + ip);
+                        u64 const w = pw;                                  // (lane 0's word is the one at ip, and ip <= ilimit)
                         u32 const v = tag | (u32)(ip + 2);
                         S[kx_hash_short(w, hbS, mls)] = v | (wide ? 0u : kx_chk_short(w) << CHKS);
                         L[kx_hash_long(w, hbL)] = v | (wide ? 0u : kx_chk_long(w, hbL) << CHKS);
                     }
                     m_type = KMT_REP0; m_pos = ip; m_start = ip; m_mpos = ip - (int)off2; m_len0 = 4;
+                    have_pw = false;
                     state = KST_MATCH;
                 } else {
                     step = 1; nextStep = ip + 256; carry = false;
+                    have_pw = true;                                        // (every lane the first step asks has its word: its position is <= ilimit)
                     state = (ip + 1 > ilimit) ? KST_CLEANUP : KST_SEARCH;
                 }
             }
+            (void)pwv;
         }
 
         // ================= speculative search step ====================
@@ -262,7 +288,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             bool const prov = srch && (k == 0 || ((k == 1 || pos - step < nextStep) && pos <= ilimit && k <= kmax));
             u64 w = 0; u32 hl = 0, hs = 0, el = 0, es = 0;
             if (prov) {
-                w = kx_ld64(src + pos);
+                w = have_pw ? pw : kx_ld64(src + pos);
                 hl = kx_hash_long(w, hbL); hs = kx_hash_short(w, hbS, mls);
                 // the lane after the last candidate only provides the long-table lookup of "ip1"
                 bool const haveL = carry && k == 0;
@@ -350,6 +376,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
 
             if (srch) {
                 guard++;
+                have_pw = false;
                 if (adaptive) { kmax = th ? wl + 1 : G - 1; if (kmax > G - 1) kmax = G - 1; }
                 if (!th) {
                     ip += K * step;
@@ -378,20 +405,31 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
             if (lane == 0) KX_STAT(3, 1);
             if (k == 0 && state == KST_MATCH) KX_STAT(6, 1);    // team sequences
             bool const mt = state == KST_MATCH;
-            bool l1ok = false; int s1 = 0, m1 = 0;
+            // requested up front, beside the first round of the extension: the long candidate at ip + 1, the bytes of the
+            // complementary inserts at the search position + 2, and the first round of the backward growth of this candidate
+            bool l1cand = false; int s1 = 0, m1 = 0; u64 l1v = 0;
             if (mt && m_type == KMT_SHORT && m_idxl1 > lowIdx) {
                 m1 = (int)m_idxl1 - 2; s1 = m_pos + step;
-                l1ok = kx_ld64(src + m1) == m_w1;
+                l1v = kx_ld64(src + m1); l1cand = true;
             }
+            u64 wa_new = 0;
+            if (mt && m_type != KMT_REP0 && k == 0 && m_pos + 10 <= n) wa_new = kx_ld64(src + m_pos + 2);     // (only then can the new position lie at or below ilimit)
+            bool const bw0 = mt && (m_type == KMT_LONG || m_type == KMT_SHORT);
+            int const mlow0 = m_mpos - ((int)lowIdx - 2);
+            int const mb0 = (m_start - anchor < mlow0) ? m_start - anchor : mlow0;
+            u32 bs0 = 0, bm0 = 0;
+            if (bw0 && k < mb0) { bs0 = src[m_start - 1 - k]; bm0 = src[m_mpos - 1 - k]; }
             u32 lenA = kx_team_extend<G>(mt, src, n, m_start, m_mpos, m_len0, k, tbase, tmask);
+            bool const l1ok = l1cand && l1v == m_w1;
+            bool tookB = false;
             if (kx_any(l1ok)) {
                 u32 const lenB = kx_team_extend<G>(l1ok, src, n, s1, m1, 8u, k, tbase, tmask);
-                if (l1ok && lenB > lenA) { m_start = s1; m_mpos = m1; lenA = lenB; m_off = (u32)(s1 - m1); }
+                if (l1ok && lenB > lenA) { m_start = s1; m_mpos = m1; lenA = lenB; m_off = (u32)(s1 - m1); tookB = true; }
             }
             bool const bw = mt && (m_type == KMT_LONG || m_type == KMT_SHORT);
             int const mlow = m_mpos - ((int)lowIdx - 2);               // the match may grow backwards down to the lowest valid position
             int const mb = (m_start - anchor < mlow) ? m_start - anchor : mlow;
-            u32 const back = kx_team_backward<G>(bw, src, m_start, m_mpos, mb, k, tbase, tmask);
+            u32 const back = kx_team_backward<G>(bw, src, m_start, m_mpos, mb, k, tbase, tmask, !tookB, bs0, bm0);
             if (mt) {
                 u32 offBase = 1;
                 if (bw) { m_start -= (int)back; m_mpos -= (int)back; lenA += back; off2 = off1; off1 = m_off; offBase = m_off + 3; }
@@ -408,17 +446,9 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 if (lenA - 3 > 0xFFFF) { longType = 2; longPos = nseq; }
                 nseq++; nlit += (u32)ll;
                 ip = m_start + (int)lenA; anchor = ip;
-                if (m_type != KMT_REP0 && ip <= ilimit && k == 0) {
-                    // complementary insertion: curr+2 into both tables, then ip-2 (long) and ip-1 (short)
-                    u64 const wa = kx_ld64(src + m_pos + 2);
-                    u64 const wb = kx_ld64(src + ip - 2);
-                    u64 const wc = kx_ld64(src + ip - 1);
-                    u32 const va = tag | (u32)(m_pos + 2 + 2);
-                    L[kx_hash_long(wa, hbL)] = va | (wide ? 0u : kx_chk_long(wa, hbL) << CHKS);
-                    L[kx_hash_long(wb, hbL)] = (tag | (u32)(ip - 2 + 2)) | (wide ? 0u : kx_chk_long(wb, hbL) << CHKS);
-                    S[kx_hash_short(wa, hbS, mls)] = va | (wide ? 0u : kx_chk_short(wa) << CHKS);
-                    S[kx_hash_short(wc, hbS, mls)] = (tag | (u32)(ip - 1 + 2)) | (wide ? 0u : kx_chk_short(wc) << CHKS);
-                }
+                // the complementary inserts of this match wait for the bytes at the new position: the repcode-check block asks for them
+                compl_due = m_type != KMT_REP0 && ip <= ilimit;
+                if (compl_due) { wa = wa_new; c_pos = m_pos; }
                 if (++guard > 2u * (u32)n + 64u) { status = 2; state = KST_CLEANUP; }
                 else state = KST_REPCHECK;
             }
