@@ -5,6 +5,8 @@ O=$R/gpurun_out/bench_lines.txt
 : > $O
 run() { echo "## python bench.py $*" >> $O; timeout -k 10 400 python $R/bench.py "$@" 2>/dev/null | tail -n 1 >> $O; echo >> $O; }
 run --steps 5 --warmup 2
+run --config 3 --steps 3 --warmup 1 --no-cpu --no-stream
+KMP_MATCH_V2=2 run --steps 5 --warmup 2 --no-cpu --no-pcie --no-stream
 run --mode decompress --steps 5 --warmup 2 --no-cpu
 run --mode deflate --steps 2 --warmup 1
 run --mode inflate --steps 3 --warmup 1 --no-cpu

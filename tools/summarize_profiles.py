@@ -38,6 +38,7 @@ def main():
     lines = [f"# {name}: MI355X, 1 GPU; collected on the GPU box by tools/profile_round.sh, summarised by tools/summarize_profiles.py.",
              "# Durations in microseconds (rocprofv3 --kernel-trace --stats, result database view top_kernels).", ""]
     runs = [("compress", "python3 bench.py --steps 5 --warmup 1      (compress, BASELINE configs[1])"),
+            ("config3", "python3 bench.py --config 3 --steps 3 --warmup 1 --no-cpu --no-stream   (BASELINE configs[3]'s share of one GPU: 131 072 text / binary slices, two launches of each kernel per step)"),
             ("decompress", "python3 bench.py --mode decompress --steps 3 --warmup 1 --no-cpu   (configs[2]; the frames are compressed first)"),
             ("deflate", "python3 bench.py --mode deflate --steps 1 --warmup 0   (configs[4]: four pieces of 16 384 slices, search of one beside parse + encode of the previous)"),
             ("big1m", "python3 bench.py --slice-kib 1024 --slices 8192 --steps 2 --warmup 1   (north_star slice-size sweep: 1 MiB slices, frames of several blocks)"),
@@ -54,7 +55,7 @@ def main():
         lines.append("bench line of the same run:")
         lines.append(open(os.path.join(P, key + ".json")).read().strip())
         lines.append("")
-    lines.append("## PMC passes (each its own run: rocprofv3 --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu); sums over the launches of a kernel")
+    lines.append("## PMC passes (each its own run: rocprofv3 --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-pcie --no-stream: every launch of a kernel in such a pass is one full batch); sums over the launches of a kernel")
     allc = {}
     for d in sorted(os.listdir(P)):
         db = os.path.join(P, d, "run_results.db")
@@ -90,7 +91,7 @@ def main():
         fetch, nl = allc[(k, "FETCH_SIZE")]
         write, _ = allc[(k, "WRITE_SIZE")]
         line = json.loads(open(os.path.join(P, "compress.json")).read())
-        pj = {"source": f"profiles/{name}.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, bench.py --steps 1)",
+        pj = {"source": f"profiles/{name}.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, bench.py --steps 1 --warmup 0 --no-pcie --no-stream: every counted launch is a full batch)",
               "slices": line["config"]["slices_per_gpu"], "team": line["config"]["team_lanes"],
               "launches": line["roofline"].get("launches_per_step", 2), "launches_in_the_counter_pass": nl,
               "zstd_match_fetch_kib": fetch, "zstd_match_write_kib": write,
