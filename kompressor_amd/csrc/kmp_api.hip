@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void k_len_guard(const u32* in_len, u32 n, u32
     len_ok[i] = len > cap ? 0u : len;
     if (len > cap) atomicOr(status, (u32)KMP_STATUS_SLICE_TOO_LARGE);
 }
+__global__ void k_status_take(u32* status, u32* out) { *out = atomicExch(status, 0u); }
 // meta: the one-block zstd parsers' per-slice record (a tripped loop guard there also voids the frame), or null
 __global__ __launch_bounds__(256) void k_len_guard_finish(const u32* in_len, u32 n, u32 cap, u32* out_len, const KSliceMeta* meta, u32* status)
 {
@@ -502,9 +503,11 @@ extern "C" int kmp_batch_status(kmp_batch_ctx* c, uint32_t* bits, void* hip_stre
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
     if (c->have_done) HIP_TRY(hipStreamWaitEvent(st, c->ev_done, 0));
+    // read and clear in ONE atomic exchange: a bit raised by a batch on another stream between a copy and a memset would be lost
     u32 v = 0;
-    HIP_TRY(hipMemcpyAsync(&v, c->d_status, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemsetAsync(c->d_status, 0, 4, st));
+    hipLaunchKernelGGL(k_status_take, dim3(1), dim3(1), 0, st, c->d_status, c->d_status + 1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&v, c->d_status + 1, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (bits) *bits = v;
     if (v & KMP_STATUS_SLICE_TOO_LARGE) { g_last_error = "a slice is larger than the context was created for: its out_len is 0"; return KMP_ERR_CAPACITY; }
@@ -710,6 +713,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
     e.fstate = c->fstate; e.hufct = c->hufct; e.remaining = c->remaining; e.stream = stream; e.strategy = strategy ? 1u : 0u; e.level2 = level2; e.cls = 0;
     e.tail_direct = stream == 3 ? 0u : tail_direct; e.out_chunk = stream == 3 ? tail_direct : 0u;      // (one parameter: the mode says which it is)
+    e.status_word = c->d_status;
     if (strategy || c->knob.big_rounds == 0) {
         // one wave per slice walks its chain of blocks
         // few slices: one per wave (most waves); many: up to 64 / G per wave so that all of them are in flight

@@ -1056,6 +1056,7 @@ struct KFrameArgs {
     u32 tail_direct;                         // streams: bytes the closing call brought onto an empty staging buffer with room for
                                              // their bound in its output slice (compressed in place as one chunk); else 0
     u32 out_chunk;                           // stream == 3: size of the driver's output slices; 0 = the reference's max(8192, n / 10)
+    u32* status_word = nullptr;              // the context's status word: bit 1 (KMP_STATUS_KERNEL_GUARD) when a block's parser tripped its loop guard
 };
 
 // The block before fs.ipos is out: libzstd's staging buffer and window move on to the block that starts there
@@ -1194,6 +1195,7 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
     KHufPrev hp; hp.ct = hufct + 256u * fs.hufSel; hp.valid = fs.hufValid != 0; hp.newCt = hufct + 256u * (fs.hufSel ^ 1u); hp.outcome = 0;
     if (bs >= 7) {                                       // MIN_CBLOCK_SIZE + block header + 1 + 1
         mm = a.meta[slice];
+        if (mm.status != 0 && lane == 0 && a.status_word) kx_atomic_or(a.status_word, 2u);          // (never expected; the frame cannot be trusted)
         const KSeq* const seqs = a.seqs + (size_t)slice * a.seq_cap;
         u8* const lits = a.lits + (size_t)slice * a.lit_cap;
         u32 const litSize = mm.litSize + mm.lastLL;

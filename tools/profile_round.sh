@@ -7,7 +7,7 @@ O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 run() { name=$1; shift; echo "== $name: $*" >> $O/log.txt; timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/$name -o run -- python3 $R/bench.py "$@" > $O/$name.out 2>> $O/log.txt; tail -1 $O/$name.out > $O/$name.json; }
-run compress --steps 5 --warmup 1 &&
+run compress --steps 5 --warmup 1 --no-stream &&
 run config3 --config 3 --steps 3 --warmup 1 --no-cpu --no-stream &&
 run decompress --mode decompress --steps 3 --warmup 1 --no-cpu &&
 run deflate --mode deflate --steps 1 --warmup 0 &&

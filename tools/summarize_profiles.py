@@ -37,7 +37,7 @@ def main():
     os.makedirs(outdir, exist_ok=True)
     lines = [f"# {name}: MI355X, 1 GPU; collected on the GPU box by tools/profile_round.sh, summarised by tools/summarize_profiles.py.",
              "# Durations in microseconds (rocprofv3 --kernel-trace --stats, result database view top_kernels).", ""]
-    runs = [("compress", "python3 bench.py --steps 5 --warmup 1      (compress, BASELINE configs[1])"),
+    runs = [("compress", "python3 bench.py --steps 5 --warmup 1 --no-stream     (compress, BASELINE configs[1]; the figures of the streaming entry point are in the bench lines)"),
             ("config3", "python3 bench.py --config 3 --steps 3 --warmup 1 --no-cpu --no-stream   (BASELINE configs[3]'s share of one GPU: 131 072 text / binary slices, two launches of each kernel per step)"),
             ("decompress", "python3 bench.py --mode decompress --steps 3 --warmup 1 --no-cpu   (configs[2]; the frames are compressed first)"),
             ("deflate", "python3 bench.py --mode deflate --steps 1 --warmup 0   (configs[4]: four pieces of 16 384 slices, search of one beside parse + encode of the previous)"),
