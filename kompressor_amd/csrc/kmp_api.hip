@@ -348,8 +348,9 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
         // the coarse blocks this device's HBM is laid out in -- 20 G pairs/s inside any 24 .. 36 GiB, 25 - 26 from 72 GiB of
         // span on (tools/spanprobe, profiles/r03_match_floor.txt) -- and the parser lives on that rate: the same context
         // takes 205 ms per batch with its 41 GiB packed (232 over 60 GiB on one box: all four pieces inside one block),
-        // 194 with separate allocations wherever they land, 183 - 185 over 100 - 140 GiB on every box tried; 80 GiB gave
-        // 182 on one box and 206 on another (where the blocks' boundaries fall differs), so the default is 100.
+        // 194 with separate allocations wherever they land, 183 - 190 over 100 - 140 GiB on every box tried; 80 GiB gave
+        // 182 on one box and 206 on another (where the blocks' boundaries fall differs), so the default is 100, with two
+        // pieces at either end of the arena.
         // Nothing is allocated transiently: what creation takes is what the context holds, the gaps between the parts
         // included (59 GiB of a 65 536-slice context's 100).  KMP_TABLE_SPAN_GIB=0 packs the arena (memory over ~11 % of
         // parser time); a device without that much free memory gets the packed form by itself.
@@ -370,13 +371,23 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
             size_t const total = need + 3 * gap;
             if (fr > total + ((size_t)1 << 30) && hipMalloc((void**)&c->arena, total) == hipSuccess) {
                 u8* q = c->arena; c->arena_bytes = total;
-                c->tseg[0] = (u32*)q; q += piece;
-                c->seqs = (KSeq*)q; q += seqs_b + gap;
-                c->tseg[1] = (u32*)q; q += piece;
-                c->lits = q; q += lits_b; c->meta = (KSliceMeta*)q; q += meta_b + gap;
-                c->tseg[2] = (u32*)q; q += piece;
-                c->scratch = (u32*)q; q += scr_b + gap;
-                c->tseg[3] = (u32*)q;
+                if (env_u32("KMP_TABLE_LAYOUT", 1) == 1) {
+                    // two pieces at the bottom of the arena, two at its top, everything else and the gap between: a boundary of
+                    // the HBM's blocks anywhere in the 76 GiB between them splits the table traffic evenly (measured on one box,
+                    // parser ms at spans 80 / 100 / 140: this layout 187 / 190 / 188, pieces evenly spread (KMP_TABLE_LAYOUT=0)
+                    // 205 / 189 / 183; packed 231 on that box, 205 on others)
+                    c->tseg[0] = (u32*)q; q += piece; c->tseg[1] = (u32*)q; q += piece;
+                    c->seqs = (KSeq*)q; q += seqs_b; c->lits = q; q += lits_b; c->meta = (KSliceMeta*)q; q += meta_b; c->scratch = (u32*)q; q += scr_b + 3 * gap;
+                    c->tseg[2] = (u32*)q; q += piece; c->tseg[3] = (u32*)q;
+                } else {
+                    c->tseg[0] = (u32*)q; q += piece;
+                    c->seqs = (KSeq*)q; q += seqs_b + gap;
+                    c->tseg[1] = (u32*)q; q += piece;
+                    c->lits = q; q += lits_b; c->meta = (KSliceMeta*)q; q += meta_b + gap;
+                    c->tseg[2] = (u32*)q; q += piece;
+                    c->scratch = (u32*)q; q += scr_b + gap;
+                    c->tseg[3] = (u32*)q;
+                }
                 c->tseg_n = 4; c->tables = c->tseg[0];
             } else { (void)hipGetLastError(); c->arena = nullptr; }
         }
