@@ -1713,6 +1713,22 @@ extern "C" size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* d, void* dst, size_t
         if (content != (size_t)-1 && content > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_frameParameter_unsupported);
         if (total && total < d->in.size()) { *src_pos -= d->in.size() - total; d->in.resize(total); }
         if (total == 0) return d->in.size() >= frame_max ? KERRC(ZE_frameParameter_unsupported) : 3;      // hint: more input expected
+        // the plain case -- no dictionary, content size in the header, at most 128 KiB either way -- joins whatever other contexts
+        // are decoding right now: one batch for all of them (kmp_coalesce.h)
+        if (d->dict.empty() && content != (size_t)-1 && content <= KMP_MAX_SLICE_BYTES && total <= KMP_MAX_SLICE_BYTES && coalesce_enabled()) {
+            int dev = 0;
+            if (d->dev.batch) dev = d->dev.batch->device; else if (hipGetDevice(&dev) != hipSuccess) return KERRC(ZE_GENERIC);
+            d->out.resize(content ? content : 1);
+            u32 olen = 0, st = 0;
+            int const rc = coalesced_decompress(dev, d->in.data(), (u32)total, d->out.data(), (u32)content, &olen, &st);
+            if (rc == KMP_OK) {
+                if (st) { d->out.clear(); return KERRC(st); }
+                d->out.resize(olen);
+                d->in.clear(); d->stage = 1; d->out_pos = 0;
+                goto flush_output;
+            }
+            (void)hipGetLastError(); d->out.clear();                 // fall through: decode alone
+        }
         if (!d->d_status && hipMalloc((void**)&d->d_status, 64) != hipSuccess) return KERRC(ZE_memory_allocation);
         u32 res[2] = { 0, 0 };
         // content size in the header: staged for exactly that; none (streaming frames): for 4 x the frame (2 MiB at least),
@@ -1741,6 +1757,7 @@ extern "C" size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* d, void* dst, size_t
         if (res[0] && hipMemcpy(d->out.data(), s.d_out, res[0], hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
         d->in.clear(); d->stage = 1; d->out_pos = 0;
     }
+flush_output:
     {
         size_t const room = dst_size - *dst_pos, left = d->out.size() - d->out_pos;
         size_t const k = room < left ? room : left;

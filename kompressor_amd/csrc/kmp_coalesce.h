@@ -207,37 +207,39 @@ extern "C" int kmp_zstd_decompress_host_batch(int device, const void* h_src, con
 // window once; 64 concurrent contexts share one launch of each kernel instead of queueing 64 batches of one.
 struct coalescer {
     std::mutex m; std::condition_variable cv;
-    std::vector<host_job*> queue; bool leading; int device; u32 window_us, max_batch;
+    std::vector<host_job*> queue; bool leading; int device; u32 window_us, max_batch; int decode;
 };
-static coalescer* coalescer_get(int device)
+// one per device and direction (decode = 1: the decoder's, over host_engine_decompress)
+static coalescer* coalescer_get(int device, int decode = 0)
 {
-    static std::mutex m; static coalescer* cs[16] = { nullptr };
+    static std::mutex m; static coalescer* cs[2][16] = { { nullptr }, { nullptr } };
     if (device < 0 || device >= 16) return nullptr;
     std::lock_guard<std::mutex> g(m);
-    if (!cs[device]) {
+    if (!cs[decode][device]) {
         coalescer* c = new (std::nothrow) coalescer();
         if (!c) return nullptr;
-        c->leading = false; c->device = device; c->window_us = env_u32("KMP_COALESCE_US", 150); c->max_batch = env_u32("KMP_COALESCE_MAX", 256);
+        c->leading = false; c->device = device; c->decode = decode; c->window_us = env_u32("KMP_COALESCE_US", 150); c->max_batch = env_u32("KMP_COALESCE_MAX", 256);
         if (c->max_batch < 1) c->max_batch = 1;
-        cs[device] = c;
+        cs[decode][device] = c;
     }
-    return cs[device];
+    return cs[decode][device];
 }
 // 0 = off: every context compresses alone as before
 static bool coalesce_enabled() { static u32 const v = env_u32("KMP_COALESCE", 1); return v != 0; }
 
-// the frame of `in` (len <= 128 KiB, level 3, no dictionary) into *out; returns a KMP_* code
-static int coalesced_compress(int device, const u8* in, u32 len, std::vector<u8>* out)
+// One job through its direction's coalescer: queued, run in whatever batch forms, handed back.  Returns a KMP_* code for the
+// batch; job.status / job.out_len say what became of this entry.
+static int coalesced_run(int device, int decode, host_job& job)
 {
-    coalescer* c = coalescer_get(device);
+    coalescer* c = coalescer_get(device, decode);
     host_engine* e = host_engine_get(device);
     if (!c || !e) return KMP_ERR_ARG;
-    host_job job; job.in = in; job.len = len; job.out = nullptr; job.out_cap = 0; job.out_len = 0; job.status = 0; job.out_vec = out; job.done = false;
+    job.out_len = 0; job.status = 0; job.done = false;
     std::unique_lock<std::mutex> lk(c->m);
     c->queue.push_back(&job);
     c->cv.notify_all();                                                   // (a leader in its window counts the queue)
     for (;;) {
-        if (job.done) return job.status ? KMP_ERR_KERNEL : KMP_OK;
+        if (job.done) return (job.status && !decode) ? KMP_ERR_KERNEL : KMP_OK;
         if (!c->leading) {
             c->leading = true;
             u32 const cap = c->max_batch < e->cap_slices ? c->max_batch : e->cap_slices;
@@ -249,13 +251,31 @@ static int coalesced_compress(int device, const u8* in, u32 len, std::vector<u8>
             lk.unlock();
             std::vector<host_job> batch(take);
             for (u32 i = 0; i < take; i++) batch[i] = *mine[i];
-            int const rc = host_engine_compress(e, batch.data(), take, 3);
+            int const rc = decode ? host_engine_decompress(e, batch.data(), take) : host_engine_compress(e, batch.data(), take, 3);
             lk.lock();
-            for (u32 i = 0; i < take; i++) { mine[i]->out_len = batch[i].out_len; mine[i]->status = (rc != KMP_OK && batch[i].out_len == 0) ? 1u : batch[i].status; mine[i]->done = true; }
+            for (u32 i = 0; i < take; i++) {
+                mine[i]->out_len = batch[i].out_len;
+                mine[i]->status = (rc != KMP_OK && batch[i].out_len == 0 && batch[i].status == 0) ? 1u : batch[i].status;
+                mine[i]->done = true;
+            }
             c->leading = false;
             c->cv.notify_all();
             continue;                                                      // (my own job was in that batch unless the queue was longer than a batch)
         }
         c->cv.wait(lk);
     }
+}
+// the frame of `in` (len <= 128 KiB, level 3, no dictionary) into *out; returns a KMP_* code
+static int coalesced_compress(int device, const u8* in, u32 len, std::vector<u8>* out)
+{
+    host_job job; job.in = in; job.len = len; job.out = nullptr; job.out_cap = 0; job.out_vec = out;
+    return coalesced_run(device, 0, job);
+}
+// the content of the frame `in` (no dictionary; content size known and <= 128 KiB) into out[0 .. cap); *status = libzstd's error number
+static int coalesced_decompress(int device, const u8* in, u32 len, u8* out, u32 cap, u32* out_len, u32* status)
+{
+    host_job job; job.in = in; job.len = len; job.out = out; job.out_cap = cap; job.out_vec = nullptr;
+    int const rc = coalesced_run(device, 1, job);
+    *out_len = job.out_len; *status = job.status;
+    return rc;
 }

@@ -898,6 +898,30 @@ def test_host_batch_and_the_coalescer_of_the_streaming_entry_point(G):
     for t, (a, b2) in enumerate(results):
         assert a == o.compress(picks[t]) and b2 == o.compress(picks[(t + 1) % len(picks)]), t
     assert ZstdDecompressor().transform_bytes(results[0][0]) == picks[0]
+    # ... and the decoder's: 48 ZstdDecompressor contexts at once, one of them fed a damaged frame
+    back = [None] * len(picks)
+
+    def unwork(t):
+        d = ZstdDecompressor()
+        if t == 7:
+            bad = bytearray(results[t][0]); bad[len(bad) // 2] ^= 0x55
+            try:
+                back[t] = ("ok", d.transform_bytes(bytes(bad)))
+            except RuntimeError as e_:
+                back[t] = ("err", str(e_))
+        else:
+            back[t] = ("ok", d.transform_bytes(results[t][0]) + d.transform_bytes(results[t][1]))
+
+    th = [threading.Thread(target=unwork, args=(t,)) for t in range(len(picks))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for t, (kind, val) in enumerate(back):
+        if t == 7:
+            assert kind == "err" or val != picks[t]
+        else:
+            assert kind == "ok" and val == picks[t] + picks[(t + 1) % len(picks)], t
 
 
 def test_python_wrapper_check_raises_on_a_refused_slice():
