@@ -42,6 +42,8 @@ struct KEntropyLds {
             KHNode node[516]; // ([0] is the sentinel before huffNode[0])
             u32 rank[192];    // bucket sort positions: curr | base << 16
             u32 qstack[40];   // explicit quicksort stack
+            u8 weight[256];   // Huffman weights (behind everything their FSE coding uses of the sequence phase's arrays below: the
+                              // state table, dnb[0], dfs[0] and the spread scratch end at byte 4 608 of the union, this starts at 5 056)
         } huf;
         struct {              // sequence phase (stateLL/dnb[0]/dfs[0] also serve the Huffman-weight FSE)
             u16 stateLL[512];    // FSE next-state tables
@@ -60,8 +62,7 @@ struct KEntropyLds {
     u16 cumul[3][66];
     u8 ncbuf[3][80];          // table descriptions of the three symbol types, before concatenation
     u32 cnt[16];
-    u8 weight[256];
-};
+};      // 10 196 bytes: sixteen waves per CU (160 KiB of LDS)
 
 KX_DEV u16* kxe_state(KEntropyLds& lds, int t) { return t == 0 ? lds.u.seq.stateLL : t == 1 ? lds.u.seq.stateOF : lds.u.seq.stateML; }
 // FSE spread scratch (LL / weights 512 B, ML 512 B, OF 256 B): the staging area of the bitstream loop (stage, sbits,
@@ -455,7 +456,7 @@ KX_DEV u32 khuf_build_ctable(KEntropyLds& lds, u32 maxSymbolValue, u32 maxNbBits
 KX_DEV u32 khuf_compress_weights(u8* dst, KEntropyLds& lds, u32 wtSize)
 {
     u8* op = dst; u32 maxSymbolValue = 12; u32 tableLog = 6;
-    const u8* const weightTable = lds.weight;
+    const u8* const weightTable = lds.u.huf.weight;
     if (wtSize <= 1) return 0;
     {
         u32 maxCount = 0;
@@ -487,7 +488,7 @@ KX_DEV u32 khuf_compress_weights(u8* dst, KEntropyLds& lds, u32 wtSize)
 // Huffman tree description; returns its size or KXE_ERR
 KX_DEV u32 khuf_write_ctable(u8* dst, KEntropyLds& lds, u32 maxSymbolValue, u32 huffLog)
 {
-    for (u32 n = 0; n < maxSymbolValue; n++) { u32 const nb = lds.ct[n] >> 16; lds.weight[n] = (u8)(nb ? huffLog + 1 - nb : 0); }
+    for (u32 n = 0; n < maxSymbolValue; n++) { u32 const nb = lds.ct[n] >> 16; lds.u.huf.weight[n] = (u8)(nb ? huffLog + 1 - nb : 0); }
     {
         u32 const hSize = khuf_compress_weights(dst + 1, lds, maxSymbolValue);
         if (hSize == KXE_ERR) return KXE_ERR;
@@ -495,8 +496,8 @@ KX_DEV u32 khuf_write_ctable(u8* dst, KEntropyLds& lds, u32 maxSymbolValue, u32 
     }
     if (maxSymbolValue > (256 - 128)) return KXE_ERR;
     dst[0] = (u8)(128 + (maxSymbolValue - 1));
-    lds.weight[maxSymbolValue] = 0;
-    for (u32 n = 0; n < maxSymbolValue; n += 2) dst[(n / 2) + 1] = (u8)((lds.weight[n] << 4) + lds.weight[n + 1]);
+    lds.u.huf.weight[maxSymbolValue] = 0;
+    for (u32 n = 0; n < maxSymbolValue; n += 2) dst[(n / 2) + 1] = (u8)((lds.u.huf.weight[n] << 4) + lds.u.huf.weight[n + 1]);
     return ((maxSymbolValue + 1) / 2) + 1;
 }
 

@@ -294,6 +294,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 bool const haveL = carry && k == 0;
                 if (a.flags & 1u) { if (!haveL) el = kx_ld_nt(&L[hl]); if (cand) es = kx_ld_nt(&S[hs]); }
                 else { if (!haveL) el = L[hl]; if (cand) es = S[hs]; }
+                KX_STAT(8, haveL ? 0 : 1); KX_STAT(9, cand ? 1 : 0);      // table probes issued (long, short)
             }
             u32 idxl = ((el & TAGM) == tag) ? (el & IDXM) : 0u;
             u32 idxs = ((es & TAGM) == tag) ? (es & IDXM) : 0u;
@@ -355,6 +356,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                 supL = (rl >> k) & 1ull; supS = (rs >> k) & 1ull;
             }
             if (ins) {
+                KX_STAT(10, (supL ? 0 : 1) + (supS ? 0 : 1));             // inserts of searched positions
                 u32 const v = tag | (u32)(pos + 2);
                 if (a.flags & 2u) { if (!supL) kx_st_nt(&L[hl], v | ckl); if (!supS) kx_st_nt(&S[hs], v | cks); }
                 else { if (!supL) L[hl] = v | ckl; if (!supS) S[hs] = v | cks; }
