@@ -337,6 +337,11 @@ KMP_API int kmp_zstd_decompress_host_batch(int device, const void* h_src, const 
  * whose tables are below 4 GiB).  bench.py prices the parser's measured memory requests with them. */
 KMP_API int kmp_batch_table_rates(kmp_batch_ctx* ctx, float* reads_per_s, float* pairs_per_s);
 
+/* diagnostic: the per-slice parser records (32 bytes each: sequences, literal bytes, trailing literals, long-length info, status and
+ * two spare words -- with KMP_MATCH_FLAGS bit 8 the device's 100 MHz clock when the slice was finished) of the last one-block
+ * zstd batch, copied to host memory after the device has gone idle */
+KMP_API int kmp_debug_copy_meta(kmp_batch_ctx* ctx, void* h_dst, uint32_t n);
+
 KMP_API const char* kmp_last_error(void);
 KMP_API const char* kmp_version(void);
 

@@ -505,6 +505,15 @@ extern "C" int kmp_batch_table_rates(kmp_batch_ctx* c, float* reads_per_s, float
     *reads_per_s = c->table_reads_per_s; *pairs_per_s = c->table_pairs_per_s;
     return KMP_OK;
 }
+// diagnostics: the per-slice records of the last one-block zstd batch (KSliceMeta, 32 bytes each) copied to host memory
+extern "C" int kmp_debug_copy_meta(kmp_batch_ctx* c, void* h_dst, uint32_t n)
+{
+    if (!c || !h_dst || n > c->max_slices) { g_last_error = "kmp_debug_copy_meta: bad argument"; return KMP_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_dst, c->meta, (size_t)n * sizeof(KSliceMeta), hipMemcpyDeviceToHost));
+    return KMP_OK;
+}
 /* launches of each zstd compress kernel in the last batch (the batch is cut into that many chunks) */
 extern "C" int kmp_batch_last_chunks(kmp_batch_ctx* c) { return c ? (int)c->last_chunks : 0; }
 

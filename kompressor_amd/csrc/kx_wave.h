@@ -77,6 +77,8 @@ KX_DEV void kx_lds_or(u32* p, u32 v) { atomicOr(p, v); }
 // iteration into separate nested loops, the lanes of a wave wait for one another at every inner loop's exit).
 #define KX_OPAQUE(x) __asm__ volatile("" : "+v"(x))
 
+// 100 MHz wall clock of the device (diagnostics only)
+KX_DEV u64 kx_realtime() { return __builtin_amdgcn_s_memrealtime(); }
 // statistics hook of the CPU emulator (tests/emu shadows this header); nothing on the GPU
 #define KX_STAT(slot, v) ((void)0)
 

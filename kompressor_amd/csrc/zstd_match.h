@@ -469,6 +469,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     KSliceMeta mm;
                     mm.nbSeq = nseq; mm.litSize = nlit; mm.lastLL = (u32)(n - anchor);
                     mm.longType = longType; mm.longPos = longPos; mm.status = status; mm.pad[0] = 0; mm.pad[1] = 0;
+                    if (!BLK && (a.flags & 256u)) { u64 const t = kx_realtime(); mm.pad[0] = (u32)t; mm.pad[1] = (u32)(t >> 32); }   // diagnostics: when the slice was done (100 MHz ticks)
                     if (BLK) {
                         // repcodes this block leaves behind (taken over by the frame only if the block is emitted compressed)
                         u32 const s2 = (saved1 != 0 && off1 != 0) ? saved1 : saved2;

@@ -59,6 +59,7 @@ KX_DEV void kx_lds_inc(u32* p) { *p += 1; }
 KX_DEV u32 kx_lds_add(u32* p, u32 v) { u32 const o = *p; *p = o + v; return o; }
 KX_DEV void kx_lds_or(u32* p, u32 v) { *p |= v; }
 
+KX_DEV u64 kx_realtime() { return 0; }
 namespace kxemu { extern u64 stat[64]; }
 #define KX_STAT(slot, v) (kxemu::stat[slot] += (u64)(v))
 

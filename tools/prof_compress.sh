@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel times of the compress step (rocprofv3 --kernel-trace --stats), printed; extra bench.py arguments pass through
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_cmp -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-pcie "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_cmp.json 2>/dev/null
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_cmp -o run -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-pcie --no-stream "$@" > $GRAFT_REPO_ROOT/gpurun_out/prof_cmp.json 2>/dev/null
 cd $GRAFT_REPO_ROOT && python3 -c "
 import sqlite3,glob
 db=glob.glob('gpurun_out/prof_cmp/**/run_results.db',recursive=True)[0]
