@@ -296,6 +296,7 @@ static int place_alloc(u32** out, size_t bytes, float* kept_ms, u32* tried_out)
 
 static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes);
 extern "C" void kmp_batch_destroy(kmp_batch_ctx* c);
+static thread_local int g_create_packed = 0;        // batch_create_packed: this creation packs its arena whatever KMP_TABLE_SPAN_GIB says
 extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes)
 {
     if (!out || max_slices == 0) { g_last_error = "kmp_batch_create: bad argument"; return KMP_ERR_ARG; }
@@ -312,6 +313,14 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     if (rc != KMP_OK) { std::string const keep = g_last_error; kmp_batch_destroy(c); g_last_error = keep; return rc; }      // nothing half-built is left behind
     *out = c;
     return KMP_OK;
+}
+// a context whose arena is packed (the engines of the host-memory batch: kmp_coalesce.h)
+static int batch_create_packed(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes)
+{
+    g_create_packed = 1;
+    int const rc = kmp_batch_create(out, device, max_slices, max_slice_bytes, 0);
+    g_create_packed = 0;
+    return rc;
 }
 static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes)
 {
@@ -363,7 +372,7 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
         if (env_u32("KMP_TABLE_ARENA", 1) && tbytes >= ((size_t)4 << 30) && (c->nteams & 3u) == 0) {
             size_t const piece = up(tbytes / 4);
             size_t const need = 4 * piece + seqs_b + lits_b + meta_b + scr_b;
-            size_t want = (size_t)env_u32("KMP_TABLE_SPAN_GIB", 100) << 30;
+            size_t want = g_create_packed ? 0 : ((size_t)env_u32("KMP_TABLE_SPAN_GIB", 100) << 30);
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
             if (want > need && fr < want + ((size_t)16 << 30)) want = 0;    // not that much room: pack

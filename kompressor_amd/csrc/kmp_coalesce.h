@@ -12,9 +12,11 @@
 //     batch; each caller gets its own frame back, bit-identical to what it would have got alone (frames do not depend
 //     on batch position: tests/test_gpu_parity.py).
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <thread>
 
 struct host_job { const u8* in; u32 len; u8* out; u32 out_cap; u32 out_len; u32 status; std::vector<u8>* out_vec; bool done; };
 
@@ -39,25 +41,29 @@ static void host_engine_free(host_engine* e)
     delete e;
 }
 
-// one engine per device and process, made on first use: batches of up to KMP_HOST_BATCH_SLICES (default 1024) slices of up to 128 KiB
-static host_engine* host_engine_get(int device)
+// Engines per device and process, made on first use.  Slot 0: batches of up to KMP_HOST_BATCH_SLICES (default 1024) slices of up to
+// 128 KiB -- the coalescer's and the small calls'.  Slots 1 ..: the bulk engines of large host batches (KMP_HOST_BULK_SLICES,
+// default 16 384 slices each), one per worker thread of such a call.
+enum { KMP_HOST_ENGINES = 5 };
+static host_engine* host_engine_get(int device, int slot = 0)
 {
-    static std::mutex m; static host_engine* engines[16] = { nullptr };
-    if (device < 0 || device >= 16) return nullptr;
+    static std::mutex m; static host_engine* engines[16][KMP_HOST_ENGINES] = { { nullptr } };
+    if (device < 0 || device >= 16 || slot < 0 || slot >= KMP_HOST_ENGINES) return nullptr;
     std::lock_guard<std::mutex> g(m);
-    if (engines[device]) return engines[device];
+    if (engines[device][slot]) return engines[device][slot];
     if (hipSetDevice(device) != hipSuccess) return nullptr;
     host_engine* e = new (std::nothrow) host_engine();
     if (!e) return nullptr;
     e->device = device; e->batch = nullptr; e->st = nullptr;
     e->h_in = e->h_out = nullptr; e->h_off = e->h_doff = nullptr; e->h_len = e->h_cap = e->h_st = nullptr;
     e->d_in = e->d_out = e->d_dense = nullptr; e->d_off = e->d_ooff = e->d_doff = nullptr; e->d_len = e->d_olen = e->d_cap = e->d_st = nullptr;
-    e->cap_slices = env_u32("KMP_HOST_BATCH_SLICES", 1024); if (e->cap_slices < 16) e->cap_slices = 16; if (e->cap_slices > 65536) e->cap_slices = 65536;
+    e->cap_slices = slot == 0 ? env_u32("KMP_HOST_BATCH_SLICES", 1024) : env_u32("KMP_HOST_BULK_SLICES", 16384);
+    if (e->cap_slices < 16) e->cap_slices = 16; if (e->cap_slices > 65536) e->cap_slices = 65536;
     e->slice_cap = KMP_MAX_SLICE_BYTES;
     e->stride = (kmp_zstd_compress_bound(e->slice_cap) + 8 + 63) & ~(size_t)63;
     size_t const n = e->cap_slices;
     e->in_bytes = n * ((size_t)e->slice_cap + 64); e->out_bytes = n * e->stride;
-    bool ok = kmp_batch_create(&e->batch, device, e->cap_slices, e->slice_cap, 0) == KMP_OK;
+    bool ok = batch_create_packed(&e->batch, device, e->cap_slices, e->slice_cap) == KMP_OK;       // (its arena packed: an engine is not the place to spend a span on)
     ok = ok && hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&e->h_in, e->in_bytes) == hipSuccess && hipHostMalloc((void**)&e->h_out, e->out_bytes) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&e->h_off, (n + 1) * 8) == hipSuccess && hipHostMalloc((void**)&e->h_doff, (n + 1) * 8) == hipSuccess;
@@ -71,7 +77,7 @@ static host_engine* host_engine_get(int device)
         ok = hipMemcpy(e->d_ooff, e->h_doff, (n + 1) * 8, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) { (void)hipGetLastError(); host_engine_free(e); g_last_error = "host batch engine: allocation failed"; return nullptr; }
-    engines[device] = e;
+    engines[device][slot] = e;
     return e;
 }
 
@@ -154,23 +160,50 @@ extern "C" int kmp_zstd_compress_host_batch(int device, int level, const void* h
     if (n && (!h_src || !in_off || !in_len || !h_dst || !out_off || !out_cap || !out_len)) { g_last_error = "kmp_zstd_compress_host_batch: null argument"; return KMP_ERR_ARG; }
     if (level == 0) level = 3;
     if (level < 1 || level > 3) { g_last_error = "kmp_zstd_compress_host_batch: levels 1, 2 and 3 are served"; return KMP_ERR_ARG; }
-    host_engine* e = host_engine_get(device);
-    if (!e) return KMP_ERR_ARG;
-    std::vector<host_job> jobs(e->cap_slices);
-    int rc = KMP_OK;
-    for (u32 first = 0; first < n; first += e->cap_slices) {
-        u32 const m = n - first < e->cap_slices ? n - first : e->cap_slices;
-        for (u32 i = 0; i < m; i++) {
-            host_job& j = jobs[i];
-            j.in = (const u8*)h_src + in_off[first + i]; j.len = in_len[first + i]; j.out = (u8*)h_dst + out_off[first + i]; j.out_cap = out_cap[first + i];
-            j.out_len = 0; j.status = 0; j.out_vec = nullptr; j.done = false;
-        }
-        int const r = host_engine_compress(e, jobs.data(), m, level);
-        if (r != KMP_OK && r != KMP_ERR_CAPACITY) return r;
-        if (r != KMP_OK) rc = r;
-        for (u32 i = 0; i < m; i++) out_len[first + i] = jobs[i].out_len;
+    host_engine* e0 = host_engine_get(device);
+    if (!e0) return KMP_ERR_ARG;
+    // A large batch goes through the bulk engines: pieces of KMP_HOST_BULK_SLICES slices handed to KMP_HOST_BULK_WORKERS
+    // (default 2, at most 4) threads, each with an engine of its own -- while one piece is on the device the next is being
+    // packed into pinned memory and the last one's frames are being handed out, and the device has two pieces in flight.
+    // (measured, 65 536 x 64 KiB from pageable host memory to frames in host memory: 1.5 GB/s through the 1 024-slice engine piece
+    // by piece, 5.7 with one bulk worker, 9.5 with two, 11.6 with three: tools/r03_hostbatch.py.  An engine that cannot be made --
+    // its pinned staging is 4.3 GiB -- is done without.)
+    u32 const workers_wanted = env_u32("KMP_HOST_BULK_WORKERS", 3);
+    bool bulk = n > 2u * e0->cap_slices && workers_wanted >= 1;
+    u32 workers = !bulk ? 1u : (workers_wanted > (u32)KMP_HOST_ENGINES - 1u ? (u32)KMP_HOST_ENGINES - 1u : workers_wanted);
+    std::vector<host_engine*> eng(workers, e0);
+    if (bulk) {
+        u32 got = 0;
+        for (u32 w = 0; w < workers; w++) { host_engine* const x = host_engine_get(device, 1 + (int)w); if (!x) { (void)hipGetLastError(); break; } eng[got++] = x; }
+        if (got == 0) { bulk = false; workers = 1; eng.assign(1, e0); } else { workers = got; eng.resize(got); }
     }
-    return rc;
+    u32 const piece = eng[0]->cap_slices;
+    std::atomic<u32> next(0); std::atomic<int> rc(KMP_OK);
+    auto work = [&](u32 w) {
+        std::vector<host_job> jobs(piece);
+        for (;;) {
+            u32 const first = next.fetch_add(piece);
+            if (first >= n || (rc.load() != KMP_OK && rc.load() != KMP_ERR_CAPACITY)) return;
+            u32 const m = n - first < piece ? n - first : piece;
+            for (u32 i = 0; i < m; i++) {
+                host_job& j = jobs[i];
+                j.in = (const u8*)h_src + in_off[first + i]; j.len = in_len[first + i]; j.out = (u8*)h_dst + out_off[first + i]; j.out_cap = out_cap[first + i];
+                j.out_len = 0; j.status = 0; j.out_vec = nullptr; j.done = false;
+            }
+            int const r = host_engine_compress(eng[w], jobs.data(), m, level);
+            if (r != KMP_OK) rc.store(r);
+            if (r == KMP_OK || r == KMP_ERR_CAPACITY) for (u32 i = 0; i < m; i++) out_len[first + i] = jobs[i].out_len;
+        }
+    };
+    if (workers == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (u32 w = 0; w < workers; w++) th.emplace_back(work, w);
+        for (auto& t : th) t.join();
+    }
+    if (rc.load() != KMP_OK && rc.load() != KMP_ERR_CAPACITY) g_last_error = "kmp_zstd_compress_host_batch: a piece failed on a worker thread";
+    else if (rc.load() == KMP_ERR_CAPACITY) g_last_error = "host batch: an output region is smaller than its frame (kmp_zstd_compress_bound)";
+    return rc.load();
 }
 
 extern "C" int kmp_zstd_decompress_host_batch(int device, const void* h_src, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,

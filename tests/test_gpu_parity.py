@@ -880,6 +880,10 @@ def test_host_batch_and_the_coalescer_of_the_streaming_entry_point(G):
             assert f == o.compress_level(d, lvl), (lvl, len(d))
     outs, st = decompress_host_batch(frames, [max(len(d), 1) for d in datas])
     assert st == [0] * len(datas) and outs == datas
+    # a large batch: more than twice the small engine's 1 024 slices -> the bulk engines, pieces on worker threads
+    many = [datas[i % len(datas)] for i in range(5000)]
+    fr2 = compress_host_batch(many)
+    assert all(fr2[i] == frames[i % len(datas)] for i in range(0, 5000, 13))
     outs, st = decompress_host_batch([frames[3][:-2], b"junk" * 8, frames[5]], [131072, 131072, 4])
     assert st[0] != 0 and st[1] != 0 and (st[2] == 70 or len(datas[5]) <= 4)
     # the coalescer
