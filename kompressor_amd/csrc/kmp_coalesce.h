@@ -210,27 +210,55 @@ extern "C" int kmp_zstd_decompress_host_batch(int device, const void* h_src, con
                                               void* h_dst, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, uint32_t* status)
 {
     if (n && (!h_src || !in_off || !in_len || !h_dst || !out_off || !out_cap || !out_len || !status)) { g_last_error = "kmp_zstd_decompress_host_batch: null argument"; return KMP_ERR_ARG; }
-    host_engine* e = host_engine_get(device);
-    if (!e) return KMP_ERR_ARG;
-    std::vector<host_job> jobs(e->cap_slices);
+    host_engine* e0 = host_engine_get(device);
+    if (!e0) return KMP_ERR_ARG;
+    // (large batches: the bulk engines on worker threads, as on the compress side)
+    u32 const workers_wanted = env_u32("KMP_HOST_BULK_WORKERS", 3);
+    bool bulk = n > 2u * e0->cap_slices && workers_wanted >= 1;
+    u32 workers = !bulk ? 1u : (workers_wanted > (u32)KMP_HOST_ENGINES - 1u ? (u32)KMP_HOST_ENGINES - 1u : workers_wanted);
+    std::vector<host_engine*> eng(workers, e0);
+    if (bulk) {
+        u32 got = 0;
+        for (u32 w = 0; w < workers; w++) { host_engine* const x = host_engine_get(device, 1 + (int)w); if (!x) { (void)hipGetLastError(); break; } eng[got++] = x; }
+        if (got == 0) { bulk = false; workers = 1; eng.assign(1, e0); } else { workers = got; eng.resize(got); }
+    }
+    host_engine* const e = eng[0];
+    // pieces: as many entries as an engine's staging holds
+    std::vector<u32> starts; starts.push_back(0);
     for (u32 first = 0; first < n; ) {
-        // as many entries as the staging holds
         u32 m = 0; size_t ib = 0, ob = 0;
         while (first + m < n && m < e->cap_slices) {
-            size_t const a = ((size_t)in_len[first + m] + 63) & ~(size_t)63, b = ((size_t)out_cap[first + m] + 63) & ~(size_t)63;
-            if (m && (ib + a > e->in_bytes || ob + b > e->out_bytes)) break;
-            ib += a; ob += b; m++;
+            size_t const a_ = ((size_t)in_len[first + m] + 63) & ~(size_t)63, b_ = ((size_t)out_cap[first + m] + 63) & ~(size_t)63;
+            if (m && (ib + a_ > e->in_bytes || ob + b_ > e->out_bytes)) break;
+            ib += a_; ob += b_; m++;
         }
-        for (u32 i = 0; i < m; i++) {
-            host_job& j = jobs[i];
-            j.in = (const u8*)h_src + in_off[first + i]; j.len = in_len[first + i]; j.out = (u8*)h_dst + out_off[first + i]; j.out_cap = out_cap[first + i];
-            j.out_len = 0; j.status = 0; j.out_vec = nullptr; j.done = false;
-        }
-        KMP_TRY(host_engine_decompress(e, jobs.data(), m));
-        for (u32 i = 0; i < m; i++) { out_len[first + i] = jobs[i].out_len; status[first + i] = jobs[i].status; }
-        first += m;
+        first += m; starts.push_back(first);
     }
-    return KMP_OK;
+    std::atomic<u32> next(0); std::atomic<int> rc(KMP_OK);
+    auto work = [&](u32 w) {
+        std::vector<host_job> jobs(e->cap_slices);
+        for (;;) {
+            u32 const pi = next.fetch_add(1);
+            if (pi + 1 >= starts.size() || rc.load() != KMP_OK) return;
+            u32 const first = starts[pi], m = starts[pi + 1] - first;
+            for (u32 i = 0; i < m; i++) {
+                host_job& j = jobs[i];
+                j.in = (const u8*)h_src + in_off[first + i]; j.len = in_len[first + i]; j.out = (u8*)h_dst + out_off[first + i]; j.out_cap = out_cap[first + i];
+                j.out_len = 0; j.status = 0; j.out_vec = nullptr; j.done = false;
+            }
+            int const r = host_engine_decompress(eng[w], jobs.data(), m);
+            if (r != KMP_OK) { rc.store(r); return; }
+            for (u32 i = 0; i < m; i++) { out_len[first + i] = jobs[i].out_len; status[first + i] = jobs[i].status; }
+        }
+    };
+    if (workers == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (u32 w = 0; w < workers; w++) th.emplace_back(work, w);
+        for (auto& t : th) t.join();
+    }
+    if (rc.load() != KMP_OK) g_last_error = "kmp_zstd_decompress_host_batch: a piece failed";
+    return rc.load();
 }
 
 // ---- the coalescer of kmp_zstd_compress_stream ---------------------------------------------------------------------

@@ -884,6 +884,8 @@ def test_host_batch_and_the_coalescer_of_the_streaming_entry_point(G):
     many = [datas[i % len(datas)] for i in range(5000)]
     fr2 = compress_host_batch(many)
     assert all(fr2[i] == frames[i % len(datas)] for i in range(0, 5000, 13))
+    outs2, st2 = decompress_host_batch(fr2, [max(len(d), 1) for d in many])
+    assert st2 == [0] * len(many) and all(outs2[i] == many[i] for i in range(0, 5000, 7))
     outs, st = decompress_host_batch([frames[3][:-2], b"junk" * 8, frames[5]], [131072, 131072, 4])
     assert st[0] != 0 and st[1] != 0 and (st[2] == 70 or len(datas[5]) <= 4)
     # the coalescer
