@@ -761,7 +761,7 @@ def main():
                                     + " seeded mixed slices per GPU (T/X/S/B/D/I/Z/R classes), ")
                                    + "ZstdCompressor(level=3) one-shot frames, bit-identical to libzstd 1.5.7",
                        "slices_per_gpu": n, "slice_bytes": SLICE, "ratio": round(in_bytes / frame_bytes, 4),
-                       "team_lanes": b.lib and (args.team or int(os.environ.get("KMP_TEAM_LANES", "4"))), "parallelism": f"slice-sharded x{world}",
+                       "team_lanes": b.lib and (args.team or int(os.environ.get("KMP_TEAM_LANES", "8" if n <= 8192 else "4"))), "parallelism": f"slice-sharded x{world}",
                        "parser": {"0": "zstd_match.h", "1": "zstd_match2.h (split-phase, 256-byte window)", "2": "zstd_match2.h (split-phase, 512-byte window)"}.get(os.environ.get("KMP_MATCH_V2", "0"), "?"),
                        "table_span_gib": int(os.environ.get("KMP_TABLE_SPAN_GIB", "100")) or "packed"},
             "roofline": {"bound": "hbm", "kernel": "k_zstd_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
