@@ -18,6 +18,13 @@
 #include <mutex>
 #include <thread>
 
+// the engines run on their own device whatever the calling thread's current one is, and leave that as they found it
+struct device_guard {
+    int prev; bool ok;
+    explicit device_guard(int dev) : prev(0), ok(false) { if (hipGetDevice(&prev) == hipSuccess) ok = true; (void)hipSetDevice(dev); }
+    ~device_guard() { if (ok) (void)hipSetDevice(prev); }
+};
+
 struct host_job { const u8* in; u32 len; u8* out; u32 out_cap; u32 out_len; u32 status; std::vector<u8>* out_vec; bool done; };
 
 struct host_engine {
@@ -51,7 +58,7 @@ static host_engine* host_engine_get(int device, int slot = 0)
     if (device < 0 || device >= 16 || slot < 0 || slot >= KMP_HOST_ENGINES) return nullptr;
     std::lock_guard<std::mutex> g(m);
     if (engines[device][slot]) return engines[device][slot];
-    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    device_guard const on(device);
     host_engine* e = new (std::nothrow) host_engine();
     if (!e) return nullptr;
     e->device = device; e->batch = nullptr; e->st = nullptr;
@@ -86,7 +93,7 @@ static host_engine* host_engine_get(int device, int slot = 0)
 static int host_engine_compress(host_engine* e, host_job* jobs, u32 n, int level)
 {
     std::lock_guard<std::mutex> g(e->run_mutex);
-    HIP_TRY(hipSetDevice(e->device));
+    device_guard const on(e->device);
     size_t pos = 0;
     for (u32 i = 0; i < n; i++) {
         if (jobs[i].len > e->slice_cap) { g_last_error = "host batch: a slice is larger than 128 KiB"; return KMP_ERR_CAPACITY; }
@@ -124,7 +131,7 @@ static int host_engine_compress(host_engine* e, host_job* jobs, u32 n, int level
 static int host_engine_decompress(host_engine* e, host_job* jobs, u32 n)
 {
     std::lock_guard<std::mutex> g(e->run_mutex);
-    HIP_TRY(hipSetDevice(e->device));
+    device_guard const on(e->device);
     size_t pos = 0, opos = 0;
     for (u32 i = 0; i < n; i++) {
         if (jobs[i].len > e->stride || jobs[i].out_cap > e->slice_cap) { g_last_error = "host batch: a frame or its content is larger than 128 KiB"; return KMP_ERR_CAPACITY; }
