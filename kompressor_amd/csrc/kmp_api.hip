@@ -229,6 +229,7 @@ struct kmp_batch_ctx {
     // by 17 % between runs of the same box, and which setting wins depends on it.
     u32* tables_flat; u32* team_epoch_flat;     // levels 1 / 2 and the dictionary parser: one piece (they wait for latency and are slower over spread tables), allocated on first use when the level-3 tables are spread
     u32* tseg[4]; u32 tseg_n;                   // the team tables in four pieces spread over the context's arena (or tseg_n == 1: tables alone)
+    u32 table_layout;                           // which of the arena's layouts holds the table pieces (1 .. 4; 0: no arena)
     u8* arena; size_t arena_bytes;              // one allocation that holds seqs / lits / meta / scratch and the table pieces (else null: separate allocations)
     float place_ms; u32 place_tried;            // the team tables' placement: probe time of the region kept, candidates tried
     float table_reads_per_s, table_pairs_per_s; // random loads / load + store pairs per second over this context's team tables (k_table_probe at creation; 0 = not measured)
@@ -379,24 +380,63 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
             size_t const gap = want > need ? up((want - need) / 3) : 0;     // unused bytes behind each of the three buffers between the pieces
             size_t const total = need + 3 * gap;
             if (fr > total + ((size_t)1 << 30) && hipMalloc((void**)&c->arena, total) == hipSuccess) {
-                u8* q = c->arena; c->arena_bytes = total;
-                if (env_u32("KMP_TABLE_LAYOUT", 1) == 1) {
-                    // two pieces at the bottom of the arena, two at its top, everything else and the gap between: a boundary of
-                    // the HBM's blocks anywhere in the 76 GiB between them splits the table traffic evenly (measured on one box,
-                    // parser ms at spans 80 / 100 / 140: this layout 187 / 190 / 188, pieces evenly spread (KMP_TABLE_LAYOUT=0)
-                    // 205 / 189 / 183; packed 231 on that box, 205 on others)
-                    c->tseg[0] = (u32*)q; q += piece; c->tseg[1] = (u32*)q; q += piece;
-                    c->seqs = (KSeq*)q; q += seqs_b; c->lits = q; q += lits_b; c->meta = (KSliceMeta*)q; q += meta_b; c->scratch = (u32*)q; q += scr_b + 3 * gap;
-                    c->tseg[2] = (u32*)q; q += piece; c->tseg[3] = (u32*)q;
-                } else {
-                    c->tseg[0] = (u32*)q; q += piece;
-                    c->seqs = (KSeq*)q; q += seqs_b + gap;
-                    c->tseg[1] = (u32*)q; q += piece;
-                    c->lits = q; q += lits_b; c->meta = (KSliceMeta*)q; q += meta_b + gap;
-                    c->tseg[2] = (u32*)q; q += piece;
-                    c->scratch = (u32*)q; q += scr_b + gap;
-                    c->tseg[3] = (u32*)q;
+                c->arena_bytes = total;
+                // Where in the arena the four pieces go is chosen by measurement, inside the arena (nothing else is allocated):
+                // up to four layouts are probed with the tables' own traffic (k_table_probe, read + insert pairs, ~12 ms each) and
+                // the fastest stays.  Which physical blocks of the HBM an offset of the arena falls into differs from process to
+                // process: with one fixed layout the same box gave 21.6 and 24.9 G pairs/s (parser 213 and 196 ms) in two runs
+                // a minute apart.  KMP_TABLE_LAYOUT = 1 .. 4 fixes a layout (1: two pieces at either end; 2: evenly spread;
+                // 3: the ends moved inwards by an eighth; 4: the second and third quarter).  The other buffers fill the space
+                // the pieces leave.
+                size_t const slackT = total - 4 * piece;                                   // bytes that are not table
+                size_t lay[4][4]; u32 nlay = 0;
+                // (a layout counts only if its pieces do not overlap and the other buffers fit into what it leaves free)
+                auto fits = [&](const size_t* o, KSeq** ps, u8** pl, KSliceMeta** pm, u32** pc) -> bool {
+                    size_t fs_[5], fe_[5]; u32 nf = 0; size_t cur = 0;
+                    for (int i = 0; i < 4; i++) { if (o[i] < cur || o[i] + piece > total) return false; if (o[i] > cur) { fs_[nf] = cur; fe_[nf] = o[i]; nf++; } cur = o[i] + piece; }
+                    if (cur < total) { fs_[nf] = cur; fe_[nf] = total; nf++; }
+                    auto take = [&](size_t bytes) -> u8* { for (u32 f = 0; f < nf; f++) if (fe_[f] - fs_[f] >= bytes) { u8* const r = c->arena + fs_[f]; fs_[f] += bytes; return r; } return nullptr; };
+                    u8* const a0 = take(seqs_b); u8* const a1 = take(lits_b); u8* const a2 = take(meta_b); u8* const a3 = take(scr_b);
+                    if (!a0 || !a1 || !a2 || !a3) return false;
+                    if (ps) { *ps = (KSeq*)a0; *pl = a1; *pm = (KSliceMeta*)a2; *pc = (u32*)a3; }
+                    return true;
+                };
+                auto add = [&](size_t o0, size_t o1, size_t o2, size_t o3) {
+                    size_t const o[4] = { o0 & ~(A - 1), o1 & ~(A - 1), o2 & ~(A - 1), o3 & ~(A - 1) };
+                    if (!fits(o, nullptr, nullptr, nullptr, nullptr)) return;
+                    for (int i = 0; i < 4; i++) lay[nlay][i] = o[i];
+                    nlay++;
+                };
+                add(0, piece, total - 2 * piece, total - piece);
+                if (gap) {
+                    add(0, up(slackT / 3) + piece, 2 * up(slackT / 3) + 2 * piece, total - piece);
+                    add(up(total / 8), up(total / 8) + piece, total - 2 * piece - up(total / 8), total - piece - up(total / 8));
+                    add(up(total / 4), up(total / 4) + piece, total - 2 * piece - up(total / 4), total - piece - up(total / 4));
                 }
+                u32 pick = 0;
+                u32 const fixed = env_u32("KMP_TABLE_LAYOUT", 0);
+                if (fixed >= 1 && fixed <= nlay) pick = fixed - 1;
+                else if (nlay > 1) {
+                    hipEvent_t e0, e1; HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+                    float best = 1e30f;
+                    u64 const words = (u64)(piece / 4); u32 const pb = (u32)prop.multiProcessorCount * 16u;
+                    for (u32 l = 0; l < nlay; l++) {
+                        u32* t[4]; for (int i = 0; i < 4; i++) t[i] = (u32*)(c->arena + lay[l][i]);
+                        hipLaunchKernelGGL(k_table_probe, dim3(pb), dim3(64), 0, 0, t[0], t[1], t[2], t[3], 4u, words, 4u, 1u, t[0]);       // warm (TLB)
+                        HIP_TRY(hipEventRecord(e0, 0));
+                        hipLaunchKernelGGL(k_table_probe, dim3(pb), dim3(64), 0, 0, t[0], t[1], t[2], t[3], 4u, words, 32u, 1u, t[0]);
+                        HIP_TRY(hipEventRecord(e1, 0));
+                        HIP_TRY(hipEventSynchronize(e1));
+                        float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+                        if (env_u32("KMP_PLACE_VERBOSE", 0)) fprintf(stderr, "arena layout %u: %.2f ms (%.1f G pairs/s)\n", l + 1, ms, (double)pb * 64.0 * 32.0 * 4.0 / (ms * 1e-3) / 1e9);
+                        if (ms < best) { best = ms; pick = l; }
+                    }
+                    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+                }
+                c->table_layout = pick + 1;
+                for (int i = 0; i < 4; i++) c->tseg[i] = (u32*)(c->arena + lay[pick][i]);
+                // the other buffers: first fit into what the pieces leave free
+                if (nlay == 0 || !fits(lay[pick], &c->seqs, &c->lits, &c->meta, &c->scratch)) { g_last_error = "kmp_batch_create: arena layout failed"; return KMP_ERR_ARG; }
                 c->tseg_n = 4; c->tables = c->tseg[0];
             } else { (void)hipGetLastError(); c->arena = nullptr; }
         }
