@@ -290,6 +290,7 @@ def main():
     ap.add_argument("--no-pcie", action="store_true", help="N = 1: skip the end-to-end figure that includes the host copies over PCIe")
     ap.add_argument("--team", type=int, default=0, help="lanes per slice in the match kernel (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--slice-class", default="", help="experiments: every slice of one corpus class (T X S B D I Z R) instead of the configuration's mix")
     ap.add_argument("--no-stream", action="store_true", help="N = 1: skip the figures of the streaming entry point (what a Kotlin caller binds)")
     ap.add_argument("--level", type=int, default=3, help="zstd level: 3 (BASELINE configs), or 1 / 2 (strategy fast)")
     ap.add_argument("--dict-kib", type=int, default=0,
@@ -338,6 +339,8 @@ def main():
     n = args.slices
     first = rank * n                                   # this rank's block of the global slice index space
     mix = corpus.MIX_TEXT_BINARY if args.config == 3 else corpus.MIX_CONFIG1
+    if args.slice_class:
+        mix = ord(args.slice_class[0])
     # this rank's HBM plan, checked against what the device has free before anything is allocated (configs[3]'s share is
     # 131 072 slices per GPU: the 8-GPU run must fail with a sentence, not with an allocator error half way through)
     if args.mode == "compress" and not big:
@@ -759,7 +762,8 @@ def main():
                                     f"(1 048 576 slices on 8), text and binary classes alternating, " if args.config == 3 else
                                     (f"BASELINE configs[1]: {n} x 64 KiB" if args.slice_kib == 64 else f"configs[1]'s mix at another slice size: {n} x {args.slice_kib} KiB")
                                     + " seeded mixed slices per GPU (T/X/S/B/D/I/Z/R classes), ")
-                                   + "ZstdCompressor(level=3) one-shot frames, bit-identical to libzstd 1.5.7",
+                                   + "ZstdCompressor(level=3) one-shot frames, bit-identical to libzstd 1.5.7"
+                                   + (f" [EXPERIMENT: every slice of class {args.slice_class[0]}]" if args.slice_class else ""),
                        "slices_per_gpu": n, "slice_bytes": SLICE, "ratio": round(in_bytes / frame_bytes, 4),
                        "team_lanes": b.lib and (args.team or int(os.environ.get("KMP_TEAM_LANES", "8" if n <= 8192 else "4"))), "parallelism": f"slice-sharded x{world}",
                        "parser": {"0": "zstd_match.h", "1": "zstd_match2.h (split-phase, 256-byte window)", "2": "zstd_match2.h (split-phase, 512-byte window)"}.get(os.environ.get("KMP_MATCH_V2", "0"), "?"),

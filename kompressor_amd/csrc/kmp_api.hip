@@ -33,6 +33,9 @@ __global__ __launch_bounds__(64) void k_zstd_match(KMatchArgs a) { zstd_match_bo
 template <int G, int R>
 __global__ __launch_bounds__(64, 4) void k_zstd_match2(KMatchArgs a) { zstd_match2_body<G, R>(a); }
 __global__ __launch_bounds__(64, 4) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
+// parse and entropy stage in one launch (zstd_entropy.h: zstd_l3_fused_body)
+template <int G>
+__global__ __launch_bounds__(64, 4) void k_zstd_l3_fused(KMatchArgs a, KEntropyArgs e) { zstd_l3_fused_body<G>(a, e); }
 // levels 1 and 2 (strategy "fast")
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match_fast(KFastArgs a) { zstd_match_fast_body<G>(a); }
@@ -256,7 +259,7 @@ struct kmp_batch_ctx {
     hipEvent_t ev_done; int have_done;
     // experiment switches, read from the environment once, when the context is created
     struct { u32 chunks, match_flags, entropy_pad, first_permille, fast_first_permille, entropy_flags, decode_flags, decode_pad, big_rounds, big_spw,
-                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre, decode_sort, decode_pieces, decode_stage_slices, inflate_pre, inflate_pieces, autotune, match_v2; } knob;
+                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre, decode_sort, decode_pieces, decode_stage_slices, inflate_pre, inflate_pieces, autotune, match_v2, fuse; } knob;
 };
 
 static u32 env_u32(const char* name, u32 dflt)
@@ -494,6 +497,7 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
     // 4.3): bit 0 = sequences decoded ahead of k_zstd_decode (k_zstd_seq_predecode, one lane per frame), bit 1 = literals
     // (k_zstd_lit_predecode, one lane per stream)
     c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1); c->knob.decode_stage_slices = env_u32("KMP_DECODE_STAGE_SLICES", 0); c->knob.inflate_pre = env_u32("KMP_INFLATE_PRE", 1); c->knob.inflate_pieces = env_u32("KMP_INFLATE_PIECES", 1); c->knob.autotune = env_u32("KMP_ZSTD_AUTOTUNE", 0);      // opt-in: one launch or two chunks, tried once each (two blocking event reads on the 2nd / 3rd batch)
+    c->knob.fuse = env_u32("KMP_FUSE", 0);                             // 1: k_zstd_l3_fused (the entropy stage inside the parse kernel's waves)
     c->knob.match_v2 = env_u32("KMP_MATCH_V2", 0);                     // 0: zstd_match.h (the default: 4 % faster, both sit on the same memory floor); 1: zstd_match2.h; 2: with a 512-byte window at team width 4
     HIP_TRY(hipDeviceSynchronize());
     return KMP_OK;
@@ -961,6 +965,16 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         u32 const max_blocks = (u32)((u64)c->match_blocks_l3 * (64u / (u32)c->G) / tpw);      // the context's team slots at this batch's width
         u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > max_blocks) blocks = max_blocks;
         if (c->profiling) HIP_TRY(hipEventRecord(c->evm[ci][0], st));
+        KEntropyArgs e;
+        e.src = (const u8*)d_src; e.in_off = d_in_off + first; e.in_len = c->len_ok + first; e.n_slices = m_n;
+        e.seqs = m.seqs; e.seq_cap = c->seq_cap; e.lits = c->lits + (size_t)first * c->lit_cap; e.lit_cap = c->lit_cap; e.meta = m.meta;
+        e.scratch = c->scratch + (size_t)first * c->scratch_words; e.scratch_words = c->scratch_words;
+        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = c->knob.entropy_flags | ((m.flags & 4u) ? 8u : 0u);
+        bool const fuse = c->knob.fuse && !c->knob.match_v2 && (G == 4 || G == 8);
+        if (fuse) {
+            if (G == 4) hipLaunchKernelGGL(k_zstd_l3_fused<4>, dim3(blocks), dim3(64), 0, st, m, e);
+            else hipLaunchKernelGGL(k_zstd_l3_fused<8>, dim3(blocks), dim3(64), 0, st, m, e);
+        } else
         if (c->knob.match_v2 && (G == 2 || G == 4 || G == 8)) {
             m.flags |= 4u;                                                // this parser never copies literals: the entropy kernel gathers them
             bool const r512 = c->knob.match_v2 == 2;
@@ -980,15 +994,11 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->evm[ci][1], st));
-        KEntropyArgs e;
-        e.src = (const u8*)d_src; e.in_off = d_in_off + first; e.in_len = c->len_ok + first; e.n_slices = m_n;
-        e.seqs = m.seqs; e.seq_cap = c->seq_cap; e.lits = c->lits + (size_t)first * c->lit_cap; e.lit_cap = c->lit_cap; e.meta = m.meta;
-        e.scratch = c->scratch + (size_t)first * c->scratch_words; e.scratch_words = c->scratch_words;
-        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = c->knob.entropy_flags | ((m.flags & 4u) ? 8u : 0u);
+        e.flags = c->knob.entropy_flags | ((m.flags & 4u) ? 8u : 0u);
         hipStream_t es = st;
         if (ci + 1 < chunks) { es = c->st2; HIP_TRY(hipStreamWaitEvent(es, c->evm[ci][1], 0)); forked = true; }
         if (c->profiling) HIP_TRY(hipEventRecord(c->eve[ci][0], es));
-        hipLaunchKernelGGL(k_zstd_entropy, dim3(m_n), dim3(64), entropy_pad, es, e);
+        if (!fuse) hipLaunchKernelGGL(k_zstd_entropy, dim3(m_n), dim3(64), entropy_pad, es, e);
         HIP_TRY(hipGetLastError());
         if (c->profiling) HIP_TRY(hipEventRecord(c->eve[ci][1], es));
     }

@@ -16,6 +16,7 @@ typedef uint64_t u64;
 
 #define KX_DEV __device__ __forceinline__
 #define KX_DEV_NOINLINE __device__ __noinline__
+#define KX_MEMBER __device__ __forceinline__       // member functions (the emulator's KX_DEV says "static")
 #define KX_SHARED __shared__
 
 // ---- identity ---------------------------------------------------------
@@ -76,6 +77,8 @@ KX_DEV void kx_lds_or(u32* p, u32 v) { atomicOr(p, v); }
 // The optimiser must not look through this value (keeps a lane-serial loop ONE loop: when it threads the paths of an
 // iteration into separate nested loops, the lanes of a wave wait for one another at every inner loop's exit).
 #define KX_OPAQUE(x) __asm__ volatile("" : "+v"(x))
+// The memory behind p is read and written here as far as the optimiser knows (a private array stays an array in memory).
+#define KX_ESCAPE(p) __asm__ volatile("" : : "v"(p) : "memory")
 
 // 100 MHz wall clock of the device (diagnostics only)
 KX_DEV u64 kx_realtime() { return __builtin_amdgcn_s_memrealtime(); }

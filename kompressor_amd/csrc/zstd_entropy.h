@@ -52,10 +52,10 @@ struct KEntropyLds {
             u32 dnb[3][64];      // FSE deltaNbBits
             int dfs[3][64];      // FSE deltaFindState
             u32 stage[64];       // codes of 64 staged sequences: ll | of << 8 | ml << 16
-            u16 sbits[3][64];    // per staged sequence and stream: state bits value | count << 12
+            u16 sbits[3][64];    // per staged sequence and stream: the chain's state before the sequence
             u32 cbuf[192];       // bit assembly buffer of one 64-sequence chunk
             u32 pnb[3][65];      // per staged sequence and stream: deltaNbBits / deltaFindState of its code, looked up by
-            int pfs[3][65];      //   all lanes at once so that the state chains only wait for the state table
+            int pfs[3][65];      //   (times two: a byte offset) of its code, looked up by all lanes at once so that the state chains only wait for the state table
         } seq;
     } u;
     short norm[3][64];
@@ -861,39 +861,60 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
     u8* const streamStart = op;
     u32* const cbuf = lds.u.seq.cbuf;
     for (int i = lane; i < 192; i += 64) cbuf[i] = 0;
-    u32 state = 0; bool started = false; u32 bitpos = 0;
+    u32 state = 0; u32 bitpos = 0;
     for (u32 hi = nbSeq; hi > 0; ) {
         u32 const cnt = hi > 64 ? 64u : hi;
         bool const valid = (u32)lane < cnt;
         KSeq q; q.offBase = 1; q.litLength = 0; q.mlBase = 0; KSeqCodes c; c.ll = 0; c.of = 0; c.ml = 0;
+        u32 dLL = 0, dOF = 0, dML = 0;
+        bool const first = (hi == nbSeq);
         if (valid) {
             u32 const idx = hi - 1 - (u32)lane;            // lane order == stream order
             q = seqs[idx]; c = kx_seq_codes(q, idx, longType, longPos);
             lds.u.seq.stage[lane] = c.ll | (c.of << 8) | (c.ml << 16);
-            lds.u.seq.pnb[0][lane] = lds.u.seq.dnb[0][c.ll]; lds.u.seq.pfs[0][lane] = lds.u.seq.dfs[0][c.ll];
-            lds.u.seq.pnb[1][lane] = lds.u.seq.dnb[1][c.of]; lds.u.seq.pfs[1][lane] = lds.u.seq.dfs[1][c.of];
-            lds.u.seq.pnb[2][lane] = lds.u.seq.dnb[2][c.ml]; lds.u.seq.pfs[2][lane] = lds.u.seq.dfs[2][c.ml];
+            dLL = lds.u.seq.dnb[0][c.ll]; dOF = lds.u.seq.dnb[1][c.of]; dML = lds.u.seq.dnb[2][c.ml];
+            lds.u.seq.pnb[0][lane] = dLL; lds.u.seq.pfs[0][lane] = 2 * lds.u.seq.dfs[0][c.ll];      // (byte offsets into the state table)
+            lds.u.seq.pnb[1][lane] = dOF; lds.u.seq.pfs[1][lane] = 2 * lds.u.seq.dfs[1][c.of];
+            lds.u.seq.pnb[2][lane] = dML; lds.u.seq.pfs[2][lane] = 2 * lds.u.seq.dfs[2][c.ml];
         }
         kx_sync();
+        // The chains are what the kernel's time goes into once everything else is wave-parallel (three lanes, one LDS read
+        // after the other, and the other waves of the SIMD doing the same): a step is kept to add, shift, shift-add and the
+        // state table's load -- the state itself is stored, and the lane that owns the sequence derives the bit count and the
+        // bits from it afterwards -- and a whole chunk runs without loop control.
         if (lane < 3) {
-            u32 s = 0;
-            if (!started) {
-                state = kfse_init_state(ct, (lds.u.seq.stage[0] >> (8u * (u32)lane)) & 0xFFu);
-                lds.u.seq.sbits[lane][0] = 0; started = true; s = 1;
-            }
-            // the only load a step waits for is the state table's: the next step's deltas are requested before it
-            u32 dn = lds.u.seq.pnb[lane][s]; int df = lds.u.seq.pfs[lane][s];
-            for (; s < cnt; s++) {
-                u32 const dn1 = lds.u.seq.pnb[lane][s + 1]; int const df1 = lds.u.seq.pfs[lane][s + 1];
-                u32 const nb = (state + dn) >> 16;
-                lds.u.seq.sbits[lane][s] = (u16)((state & ((1u << nb) - 1u)) | (nb << 12));
-                state = ct.state[(state >> nb) + df];
-                dn = dn1; df = df1;
+            const u8* const stb = (const u8*)ct.state;
+            if (!first && cnt == 64u) {
+                u32 dn = lds.u.seq.pnb[lane][0]; int df = lds.u.seq.pfs[lane][0];
+#pragma unroll
+                for (u32 s = 0; s < 64u; s++) {
+                    u32 const dn1 = lds.u.seq.pnb[lane][s + 1]; int const df1 = lds.u.seq.pfs[lane][s + 1];
+                    lds.u.seq.sbits[lane][s] = (u16)state;
+                    u32 const nb = (state + dn) >> 16;
+                    state = *(const u16*)(stb + df + (int)((state >> nb) << 1));
+                    dn = dn1; df = df1;
+                }
+            } else {
+                u32 s = 0;
+                if (first) {
+                    state = kfse_init_state(ct, (lds.u.seq.stage[0] >> (8u * (u32)lane)) & 0xFFu);
+                    lds.u.seq.sbits[lane][0] = 0; s = 1;
+                }
+                u32 dn = lds.u.seq.pnb[lane][s]; int df = lds.u.seq.pfs[lane][s];
+                for (; s < cnt; s++) {
+                    u32 const dn1 = lds.u.seq.pnb[lane][s + 1]; int const df1 = lds.u.seq.pfs[lane][s + 1];
+                    lds.u.seq.sbits[lane][s] = (u16)state;
+                    u32 const nb = (state + dn) >> 16;
+                    state = *(const u16*)(stb + df + (int)((state >> nb) << 1));
+                    dn = dn1; df = df1;
+                }
             }
         }
         kx_sync();
-        u32 const sLL = valid ? lds.u.seq.sbits[0][lane] : 0u, sOF = valid ? lds.u.seq.sbits[1][lane] : 0u, sML = valid ? lds.u.seq.sbits[2][lane] : 0u;
-        u32 const nLL = sLL >> 12, nOF = sOF >> 12, nML = sML >> 12;
+        u32 const rLL = valid ? lds.u.seq.sbits[0][lane] : 0u, rOF = valid ? lds.u.seq.sbits[1][lane] : 0u, rML = valid ? lds.u.seq.sbits[2][lane] : 0u;
+        bool const coded = valid && !(first && lane == 0);              // the first sequence only sets the states
+        u32 const nLL = coded ? (rLL + dLL) >> 16 : 0u, nOF = coded ? (rOF + dOF) >> 16 : 0u, nML = coded ? (rML + dML) >> 16 : 0u;
+        u32 const sLL = rLL & ((1u << nLL) - 1u), sOF = rOF & ((1u << nOF) - 1u), sML = rML & ((1u << nML) - 1u);
         u32 const llb = valid ? kx_ll_bits(c.ll) : 0u, mlb = valid ? kx_ml_bits(c.ml) : 0u, ofb = valid ? c.of : 0u;
         u32 const mybits = nLL + nOF + nML + llb + mlb + ofb;
         u32 v = mybits;                                           // inclusive prefix sum over lanes
@@ -1318,6 +1339,29 @@ KX_DEV void zstd_big_body(const KBigArgs& a)
             for (u32 t = 0; t < cnt; t++) { if (kx_in_class(a.e.cls, a.e.in_len[base + t])) zstd_frame_block(a.e, lds, base + t, lane); kx_sync(); }
         }
     }
+}
+
+// ---- parse and entropy stage in one launch -------------------------------------------------
+// The parse kernel's waves wait for their table loads three quarters of the time; a wave entropy-codes each slice the
+// moment one of its teams has parsed it (zstd_match_body's DONE hook), in the issue slots the SIMD's other waves leave idle.
+// (a real call: the entropy stage's registers are its own, the parse loop keeps its allocation and only what lives across the call
+// is saved around it)
+KX_DEV_NOINLINE void zstd_entropy_call(const KEntropyArgs* e, u32 slice)
+{
+    KX_SHARED KEntropyLds lds;
+    zstd_entropy_slice(*e, lds, slice, kx_lane());
+    kx_sync();
+}
+struct KFuseDone {
+    static constexpr bool on = true;
+    const KEntropyArgs* e;
+    KX_MEMBER void operator()(u32 slice) const { zstd_entropy_call(e, slice); }
+};
+template <int G>
+KX_DEV void zstd_l3_fused_body(const KMatchArgs& a, const KEntropyArgs& e)
+{
+    KFuseDone done; done.e = &e;
+    zstd_match_body<G, false, KFuseDone>(a, done);
 }
 
 KX_DEV void zstd_entropy_body(const KEntropyArgs& a)

@@ -129,8 +129,13 @@ KX_DEV u32 kx_team_backward(bool act, const u8* src, int s, int m, int maxback, 
 // BLK = false: every slice is one block (<= 128 KiB); tables per team, epoch-tagged.
 // BLK = true:  the block [ipos, ipos + blockSize) of every slice whose frame is unfinished; tables per slice
 //              (they persist from block to block), repcodes come from and go back to the frame state.
-template <int G, bool BLK = false>
-KX_DEV void zstd_match_body(const KMatchArgs& a)
+// DONE: what the wave does with a slice the moment one of its teams has finished it (k_zstd_l3_fused: entropy-code it, all 64
+// lanes, while the other waves of the SIMD keep waiting for their table loads); called from wave-uniform control flow, after
+// the team's stores have been waited for.
+struct KNoDone { static constexpr bool on = false; KX_MEMBER void operator()(u32) const {} };
+
+template <int G, bool BLK = false, class DONE = KNoDone>
+KX_DEV void zstd_match_body(const KMatchArgs& a, DONE const& done = DONE())
 {
     constexpr int NT = 64 / G;
     bool const wide = BLK && (a.flags & 16u);               // entries without check bits (indices need all 32 bits)
@@ -458,7 +463,8 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
 
         // ================= finish the slice ===========================
         if (kx_any(state == KST_CLEANUP)) {
-            if (state == KST_CLEANUP) {
+            bool const fin = state == KST_CLEANUP;
+            if (fin) {
                 {
                     u32 const cnt = nseq & (2u * G - 1u);       // sequences still in registers
                     u64* const sp = (u64*)(seqs + (nseq - cnt));
@@ -478,6 +484,46 @@ KX_DEV void zstd_match_body(const KMatchArgs& a)
                     a.meta[slice] = mm;
                 }
                 state = KST_IDLE;
+            }
+            if (DONE::on) {
+                u64 fm = kx_ballot(fin && k == 0);
+                kx_sync();                                      // the team's sequences, literals and meta are in memory
+                // `done` is a real call into code that wants every register: the parse state goes to private memory by hand and
+                // comes back afterwards, so that nothing of it lives across the call (left to the register allocator, the spills
+                // land inside the search loop).
+                u32 sv[64];
+#define KX_MS32(X) X(state) X(n) X(ilimit) X(slice) X(ip) X(anchor) X(off1) X(off2) X(step) X(nextStep) X(nseq) X(nlit) X(tag) X(hbL) X(hbS) X(mls) \
+                   X(longType) X(longPos) X(guard) X(status) X(m_type) X(m_pos) X(m_start) X(m_mpos) X(m_len0) X(m_off) X(m_idxl1) X(carry_idxl) X(kmax) \
+                   X(c_pos) X(lowIdx) X(bstart) X(saved1) X(saved2)
+#define KX_MS64(X) X(m_w1) X(sq0) X(sq1) X(wa) X(pw)
+#define KX_MSP(X) X(src) X(seqs) X(lits) X(L) X(S)
+                {
+                    int q = 0;
+#define KX_SAVE32(x) sv[q++] = (u32)(x);
+#define KX_SAVE64(x) sv[q++] = (u32)(u64)(x); sv[q++] = (u32)((u64)(x) >> 32);
+#define KX_SAVEP(x) sv[q++] = (u32)(uintptr_t)(x); sv[q++] = (u32)((u64)(uintptr_t)(x) >> 32);
+                    KX_MS32(KX_SAVE32) KX_MS64(KX_SAVE64) KX_MSP(KX_SAVEP)
+                    sv[q++] = (carry ? 1u : 0u) | (compl_due ? 2u : 0u) | (have_pw ? 4u : 0u);
+                }
+                KX_ESCAPE(sv);
+                while (fm) { int const j = (int)kx_ctz64(fm); fm &= fm - 1ull; done(kx_bcast(sv[3], j)); KX_ESCAPE(sv); }
+                {
+                    int q = 0;
+#define KX_LOAD32(x) x = (decltype(x))sv[q++];
+#define KX_LOAD64(x) { u32 const lo_ = sv[q++]; u32 const hi_ = sv[q++]; x = (u64)lo_ | ((u64)hi_ << 32); }
+#define KX_LOADP(x) { u32 const lo_ = sv[q++]; u32 const hi_ = sv[q++]; x = (decltype(x))(uintptr_t)((u64)lo_ | ((u64)hi_ << 32)); }
+                    KX_MS32(KX_LOAD32) KX_MS64(KX_LOAD64) KX_MSP(KX_LOADP)
+                    u32 const fl = sv[q++]; carry = fl & 1u; compl_due = (fl & 2u) != 0; have_pw = (fl & 4u) != 0;
+                }
+#undef KX_MS32
+#undef KX_MS64
+#undef KX_MSP
+#undef KX_SAVE32
+#undef KX_SAVE64
+#undef KX_SAVEP
+#undef KX_LOAD32
+#undef KX_LOAD64
+#undef KX_LOADP
             }
         }
     }

@@ -71,6 +71,28 @@ int emu_zstd_compress(const u8* src, const u64* in_off, const u32* in_len, u32 n
     std::vector<u32> scratch((size_t)n * scratch_words, 0xA5A5A5A5u);
     // KXEMU_MATCH_V2=1: the split-phase parser (zstd_match2.h; it copies no literals, the entropy kernel gathers them)
     bool const v2 = getenv("KXEMU_MATCH_V2") && atoi(getenv("KXEMU_MATCH_V2")) != 0;
+    // KXEMU_FUSE=1: k_zstd_l3_fused's body (the entropy stage inside the parse kernel's waves)
+    if (getenv("KXEMU_FUSE") && atoi(getenv("KXEMU_FUSE")) != 0 && (G == 4 || G == 8)) {
+        u32 const nteams = nblocks * (64 / G);
+        std::vector<u32> tables((size_t)nteams * KX_TBL_ENTRIES, 0xDEADBEEFu & 0x0003FFFFu);
+        std::vector<u32> epoch(nteams, 7);
+        u32 counter = 0;
+        KMatchArgs a;
+        a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
+        a.seqs = seqs.data(); a.seq_cap = seq_cap; a.lits = lits.data(); a.lit_cap = lit_cap; a.meta = meta.data();
+        a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter; a.flags = 0; a.fstate = nullptr; a.big_tables = nullptr;
+        KEntropyArgs e;
+        e.src = src; e.in_off = in_off; e.in_len = in_len; e.n_slices = n;
+        e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
+        e.scratch = scratch.data(); e.scratch_words = scratch_words;
+        e.dst = dst; e.out_off = out_off; e.out_len = out_len; e.flags = 0u;
+        kxemu::failed = 0;
+        if (G == 4) kxemu::launch(nblocks, [&]() { zstd_l3_fused_body<4>(a, e); });
+        else kxemu::launch(nblocks, [&]() { zstd_l3_fused_body<8>(a, e); });
+        if (kxemu::failed) return -1;
+        for (u32 i = 0; i < n; i++) if (meta[i].status) return -3;
+        return 0;
+    }
     int r = v2 ? emu_zstd_match2(src, in_off, in_len, n, G, nblocks, seqs.data(), seq_cap, lits.data(), lit_cap, meta.data(), 7)
                : emu_zstd_match(src, in_off, in_len, n, G, nblocks, seqs.data(), seq_cap, lits.data(), lit_cap, meta.data(), 7);
     if (r) return r;

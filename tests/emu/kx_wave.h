@@ -14,6 +14,7 @@ typedef uint64_t u64;
 
 #define KX_DEV static inline
 #define KX_DEV_NOINLINE static
+#define KX_MEMBER inline
 #define KX_SHARED static
 
 namespace kxemu {
@@ -64,6 +65,7 @@ namespace kxemu { extern u64 stat[64]; }
 #define KX_STAT(slot, v) (kxemu::stat[slot] += (u64)(v))
 
 #define KX_OPAQUE(x) __asm__ volatile("" : "+r"(x))
+#define KX_ESCAPE(p) __asm__ volatile("" : : "r"(p) : "memory")
 
 KX_DEV u32 kx_alignbit(u32 hi, u32 lo, u32 s) { return (u32)((((u64)hi << 32) | lo) >> (s & 31)); }
 KX_DEV u32 kx_alignbyte(u32 hi, u32 lo, u32 bytes) { return (u32)((((u64)hi << 32) | lo) >> (8 * (bytes & 3))); }

@@ -54,6 +54,32 @@ def test_emulated_split_phase_parser_matches_golden(G, monkeypatch, team, ring):
         assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r["name"]
 
 
+@pytest.mark.parametrize("team", [4, 8])
+def test_emulated_fused_kernel_matches_golden(G, monkeypatch, team):
+    """k_zstd_l3_fused's body (zstd_entropy.h: a wave entropy-codes each slice the moment one of its teams has parsed it, the parse
+    state set aside in private memory around the call): the frames of libzstd 1.5.7 on 64 KiB slices of every class (several
+    slices per team, so that teams fetch new slices after such a call), the ragged ladder and the hand-made edge inputs."""
+    monkeypatch.setenv("KXEMU_FUSE", "1")
+    rows = G["config1"][64:80] if team == 4 else G["config1"][80:88]
+    S = 65536
+    buf = corpus.make(rows[0][0], len(rows), S)
+    frames = helpers.emu_compress([buf[k * S:(k + 1) * S].tobytes() for k in range(len(rows))], G=team, nblocks=1 if team == 8 else 2)
+    for (i, cls, flen, sha), f in zip(rows, frames):
+        assert len(f) == flen and helpers.sha256(f) == sha, f"slice {i} class {cls} team {team}"
+    lad = G["ladder"]
+    datas = []
+    for r in lad:
+        S2, k = r["size"], r["index"] - 1000
+        datas.append(corpus.make(1000, 8, S2)[k * S2:(k + 1) * S2].tobytes() if S2 else b"")
+    frames = helpers.emu_compress(datas, G=team, nblocks=1)
+    for r, f in zip(lad, frames):
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r
+    sp = helpers.special_inputs()
+    frames = helpers.emu_compress([sp[r["name"]] for r in G["special"]], G=team, nblocks=1)
+    for r, f in zip(G["special"], frames):
+        assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r["name"]
+
+
 def test_emulated_split_phase_parser_at_the_end_of_a_slice(monkeypatch):
     """Matches that run into the last bytes of a slice (the window's 16-byte looks must not count bytes they do not hold): every
     distance of a repeat's start from the end, several periods, against the oracle."""

@@ -255,6 +255,22 @@ def test_full_batch_roundtrip_and_checksum_of_checksums(monkeypatch):
         assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"split-phase parser: group {g} differs from libzstd 1.5.7"
     b2.close()
     del host, packed2, dst2
+    # k_zstd_l3_fused (KMP_FUSE: the entropy stage inside the parse kernel's waves): the same 65 536 frames
+    monkeypatch.setenv("KMP_MATCH_V2", "0")
+    monkeypatch.setenv("KMP_FUSE", "1")
+    monkeypatch.setenv("KMP_TABLE_SPAN_GIB", "0")
+    b3 = ZstdBatch(max_slices=n, max_slice_bytes=S)
+    monkeypatch.delenv("KMP_TABLE_SPAN_GIB")
+    monkeypatch.delenv("KMP_FUSE")
+    dst3, ooff3, olen3 = b3.compress(src, in_off, in_len, check=True)
+    packed3, offs3 = b3.compact(dst3, ooff3, olen3)
+    torch.cuda.synchronize()
+    offs3 = offs3.cpu().numpy(); host = packed3.cpu().numpy()
+    for g, total, sha in F["config1_zstd3"]:
+        lo, hi = int(offs3[g * F["group"]]), int(offs3[(g + 1) * F["group"]])
+        assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"fused kernel: group {g} differs from libzstd 1.5.7"
+    b3.close()
+    del host, packed3, dst3
     # ... and all 65 536 raw DEFLATE level-6 streams of configs[4] against zlib, the same way
     ddst, doff, dlen = b.deflate(src, in_off, in_len)
     dpacked, doffs = b.compact(ddst, doff, dlen)
