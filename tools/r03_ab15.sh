@@ -1,0 +1,5 @@
+#!/bin/bash
+# the arena's layout chosen by measurement among eight candidates: six fresh processes
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+run() { env "$@" KMP_PLACE_VERBOSE=1 timeout -k 10 300 python $R/bench.py --steps 2 --warmup 1 --no-cpu --no-pcie --no-stream 2>gpurun_out/ab15.err | tail -n 1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('random_access_roofline') or {}; print('$*', d['kernels_ms']['k_zstd_match'], r.get('pairs_per_s_on_these_tables'))"; grep "arena layout" gpurun_out/ab15.err | sed "s/arena layout //" | tr '\n' ';'; echo; }
+for i in 1 2 3 4 5 6; do run KMP_TABLE_LAYOUT=0; done
