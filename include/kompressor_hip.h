@@ -137,6 +137,7 @@ typedef struct kmp_batch_ctx kmp_batch_ctx;
  * slice gets d_out_len[i] = 0 (a frame or stream is never empty) and the context's status word collects these bits. */
 #define KMP_STATUS_SLICE_TOO_LARGE 1u   /* a d_in_len[i] above the context's max_slice_bytes (DEFLATE: above 64 KiB) */
 #define KMP_STATUS_KERNEL_GUARD    2u   /* a parser's loop guard tripped (never expected) */
+#define KMP_STATUS_LEVEL_SIZE      4u   /* zstd level 4: a slice of 16 KiB or less (that size class of level 4 is strategy "greedy", not served): out_len 0 */
 
 #define KMP_MAX_SLICE_BYTES (128u * 1024u)        /* one block per frame: the batched fast path */
 #define KMP_MAX_BIG_SLICE_BYTES (1u << 30)       /* frames of several blocks (context created with max_slice_bytes above
@@ -201,7 +202,11 @@ KMP_API int kmp_zstd_compress_batch_reference(kmp_batch_ctx* ctx,
                                               int level, uint32_t out_chunk, void* hip_stream);
 /* One-shot frames at another compression level: 1 and 2 (libzstd's one-table "fast" strategy) for slices <= 128 KiB;
  * level 1 also as frames of several blocks for slices <= 512 KiB (context created with max_slice_bytes in
- * (128 KiB, 512 KiB]); 3 (or 0) = kmp_zstd_compress_batch.  Frames are the ones libzstd 1.5.7 writes at that level. */
+ * (128 KiB, 512 KiB]); 3 (or 0) = kmp_zstd_compress_batch.  Frames are the ones libzstd 1.5.7 writes at that level.
+ * Level 4 is served where libzstd runs it as "double-fast" with one block: slices above 16 KiB up to 128 KiB (window <= 17,
+ * chain 17, hash 17, minimum match 4; ZSTD_getCParams(4, n, 0)).  Its tables (1 MiB per team, at most 16 GiB) are allocated by
+ * the first level-4 batch of a context.  A slice of 16 KiB or less in a level-4 batch is refused like an oversized one
+ * (out_len 0, KMP_STATUS_LEVEL_SIZE): that size class of level 4 is strategy "greedy", as are levels 5 and up -- not served. */
 KMP_API int kmp_zstd_compress_batch_level(kmp_batch_ctx* ctx,
                                           const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                           uint32_t n,

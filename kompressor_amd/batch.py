@@ -97,7 +97,8 @@ class ZstdBatch:
 
     def status(self):
         """Waits for the batches queued so far and returns (rc, bits): KMP_STATUS_* bits raised on the device since the
-        last call (1 = a slice longer than the context holds, 2 = a parser guard tripped); such slices have out_len 0."""
+        last call (1 = a slice longer than the context holds, 2 = a parser guard tripped, 4 = a slice of 16 KiB or less in a
+        level-4 batch); such slices have out_len 0."""
         bits = ctypes.c_uint32()
         rc = self.lib.kmp_batch_status(self._h, ctypes.byref(bits), self._stream())
         return rc, bits.value
@@ -134,7 +135,8 @@ class ZstdBatch:
         """src: uint8 device tensor; in_off int64, in_len int32 device tensors (n each).  dictionary: bytes of a
         raw-content dictionary shared by all slices (host memory; its tables are built once per dictionary).
         level: 3 (default), or 1 / 2 without a dictionary: slices up to the level's window (512 KiB / 1 MiB; above 128 KiB
-        the context must have been created for slice sizes in (128 KiB, 512 KiB] / (128 KiB, 1 MiB]).
+        the context must have been created for slice sizes in (128 KiB, 512 KiB] / (128 KiB, 1 MiB]); or 4 for slices above
+        16 KiB up to 128 KiB (where libzstd runs level 4 as the double-fast parse; smaller slices are refused: out_len 0).
         streaming: None = one-shot frames; "data" / "empty" = the frames of slices that arrived through finish = false
         calls, closed by a call with / without data (context created for slices above 128 KiB; levels 1 to 3).
         reference: the frames ZstdCompressor(level).transform(bytes) returns -- above 128 KiB the reference's output slices

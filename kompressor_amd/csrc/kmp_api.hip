@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void k_len_guard_finish(const u32* in_len, u32
     u32 const i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     if (in_len[i] > cap) out_len[i] = 0;
+    else if (meta && meta[i].status == 3u) { out_len[i] = 0; atomicOr(status, (u32)KMP_STATUS_LEVEL_SIZE); }
     else if (meta && in_len[i] >= 8 && meta[i].status != 0) { out_len[i] = 0; atomicOr(status, (u32)KMP_STATUS_KERNEL_GUARD); }
 }
 
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(64) void k_table_probe(u32* p0, u32* p1, u32* p2, u
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
-extern "C" const char* kmp_version(void) { return "kompressor_hip 0.3 (gfx950; zstd levels 1-3: frames and streams up to 1 GiB, raw-content dictionaries; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
+extern "C" const char* kmp_version(void) { return "kompressor_hip 0.3 (gfx950; zstd levels 1-3: frames and streams up to 1 GiB, raw-content dictionaries; level 4 for slices of 16 KiB - 128 KiB; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
 
 // --------------------------------------------------------------------------
 // batch context
@@ -232,6 +233,7 @@ struct kmp_batch_ctx {
     // by 17 % between runs of the same box, and which setting wins depends on it.
     u32* tables_flat; u32* team_epoch_flat;     // levels 1 / 2 and the dictionary parser: one piece (they wait for latency and are slower over spread tables), allocated on first use when the level-3 tables are spread
     u32* tseg[4]; u32 tseg_n;                   // the team tables in four pieces spread over the context's arena (or tseg_n == 1: tables alone)
+    u32* tables4 = nullptr; u32* epoch4 = nullptr; u32 teams4 = 0;      // level 4's table set (1 MiB per team), allocated by the first level-4 batch
     u32 table_layout;                           // which of the arena's layouts holds the table pieces (1 .. 8; 0: no arena)
     u8* arena; size_t arena_bytes;              // one allocation that holds seqs / lits / meta / scratch and the table pieces (else null: separate allocations)
     float place_ms; u32 place_tried;            // the team tables' placement: probe time of the region kept, candidates tried
@@ -544,7 +546,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     if (c->arena) (void)hipFree(c->arena);                                        // (holds seqs, lits, meta, scratch and the table pieces)
     else { (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch); (void)hipFree(c->tables); }
     (void)hipFree(c->tables_flat); (void)hipFree(c->team_epoch_flat);
-    (void)hipFree(c->team_epoch);
+    (void)hipFree(c->team_epoch); (void)hipFree(c->tables4); (void)hipFree(c->epoch4);
     (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS);
     (void)hipFree(c->fstate); (void)hipFree(c->hufct); (void)hipFree(c->big_tables); (void)hipFree(c->remaining); (void)hipFree(c->big_counters); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -619,6 +621,7 @@ extern "C" int kmp_batch_status(kmp_batch_ctx* c, uint32_t* bits, void* hip_stre
     if (bits) *bits = v;
     if (v & KMP_STATUS_SLICE_TOO_LARGE) { g_last_error = "a slice is larger than the context was created for: its out_len is 0"; return KMP_ERR_CAPACITY; }
     if (v & KMP_STATUS_KERNEL_GUARD) { g_last_error = "a parser's loop guard tripped: the slice's out_len is 0"; return KMP_ERR_KERNEL; }
+    if (v & KMP_STATUS_LEVEL_SIZE) { g_last_error = "zstd level 4 is served for slices above 16 KiB: a smaller slice's out_len is 0"; return KMP_ERR_CAPACITY; }
     return KMP_OK;
 }
 
@@ -668,11 +671,14 @@ static int flat_tables(kmp_batch_ctx* c, u32** tables, u32** epochs)
 // ---- levels 1 and 2 -------------------------------------------------------------------------------------
 static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct = 0);
+static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                               uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream, int level);
 extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int level, void* hip_stream)
 {
     if (level == 3 || level == 0) return kmp_zstd_compress_batch(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, hip_stream);
-    if (level != 1 && level != 2) { g_last_error = "kmp_zstd_compress_batch_level: levels 1, 2 and 3 are served"; return KMP_ERR_ARG; }
+    if (level == 4) return zstd_compress_dfast(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, hip_stream, 4);
+    if (level != 1 && level != 2) { g_last_error = "kmp_zstd_compress_batch_level: levels 1, 2, 3 and (slices above 16 KiB up to 128 KiB) 4 are served"; return KMP_ERR_ARG; }
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_level: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_level: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;
@@ -942,22 +948,45 @@ extern "C" int kmp_zstd_compress_batch_reference(kmp_batch_ctx* c, const void* d
 /* block rounds of the last batch of a context for slices above 128 KiB */
 extern "C" int kmp_batch_last_rounds(kmp_batch_ctx* c) { return c ? (int)c->last_rounds : 0; }
 
-extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
+// Level 4 where it is the double-fast parse (slices above 16 KiB up to 128 KiB: zstd_common.h kx_params_l4): its tables are
+// 1 MiB per team, a set of their own allocated by the first such batch (at most 16 384 teams = 16 GiB; the batch's slices
+// go through them by the work counter).
+static int ensure_tables4(kmp_batch_ctx* c)
+{
+    if (c->tables4) return KMP_OK;
+    u32 const cap4 = env_u32("KMP_L4_TEAMS", 16384);                  // (the tests run many slices through few teams)
+    u32 teams = c->nteams < cap4 ? c->nteams : cap4;
+    teams &= ~63u; if (teams == 0) teams = 64;
+    size_t const bytes = (size_t)teams * KX_TBL4_ENTRIES * sizeof(u32);
+    u32* t = nullptr; u32* e = nullptr;
+    if (hipMalloc((void**)&t, bytes) != hipSuccess || hipMalloc((void**)&e, (size_t)teams * sizeof(u32)) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipFree(t); (void)hipFree(e);
+        g_last_error = "kmp_zstd_compress_batch_level: no memory for level 4's tables"; return KMP_ERR_HIP;
+    }
+    if (hipMemset(t, 0, bytes) != hipSuccess || hipMemset(e, 0, (size_t)teams * sizeof(u32)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(t); (void)hipFree(e); g_last_error = "kmp_zstd_compress_batch_level: hipMemset failed"; return KMP_ERR_HIP; }
+    c->tables4 = t; c->epoch4 = e; c->teams4 = teams;
+    return KMP_OK;
+}
+
+static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                               uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream, int level)
 {
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
+    bool const l4 = level == 4;
+    if (l4 && c->big) { g_last_error = "kmp_zstd_compress_batch_level: level 4 is served for one-block slices (context max_slice_bytes <= 128 KiB)"; return KMP_ERR_CAPACITY; }
+    if (l4) KMP_TRY(ensure_tables4(c));
     if (c->big) return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st, 0, 0);
     // Chunks: the match kernel of chunk i+1 (memory-transaction bound) runs beside the entropy kernel of
     // chunk i (latency bound) on a second stream; the caller's stream sees everything finished.
     // (two chunks only when each still fills at least half of the match kernel's team slots: 65 536 x 64 KiB -> 2,
     // 32 768 x 128 KiB -> 1: 17.7 GB/s against 13.1 with two half-empty launches)
     u32 const team_slots = c->l3_team_slots;                 // what the device holds, whatever this context's max_slices
-    u32 chunks = c->knob.chunks ? c->knob.chunks : (n > team_slots ? 2u : 1u);       // measured: 49 152 slices (= the slots) 16.4 GB/s in one launch, 15.5 in two; 57 344: 15.2 / 16.2
-    bool const tunable = !c->knob.chunks && c->knob.autotune && n <= team_slots && 2u * n > team_slots;
+    u32 chunks = l4 ? 1u : c->knob.chunks ? c->knob.chunks : (n > team_slots ? 2u : 1u);       // measured: 49 152 slices (= the slots) 16.4 GB/s in one launch, 15.5 in two; 57 344: 15.2 / 16.2
+    bool const tunable = !l4 && !c->knob.chunks && c->knob.autotune && n <= team_slots && 2u * n > team_slots;
     if (tunable) {
         if (c->tune_pending) {                       // the previous such batch was a trial: its whole-step time
             c->tune_pending = 0;
@@ -996,7 +1025,11 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         m.seqs = c->seqs + (size_t)first * c->seq_cap; m.seq_cap = c->seq_cap; m.meta = c->meta + first;
         m.lits = c->lits + (size_t)first * c->lit_cap; m.lit_cap = c->lit_cap;
         m.tables = c->tables; for (int ts_ = 0; ts_ < 4; ts_++) m.tseg[ts_] = c->tseg[ts_]; m.tseg_n = c->tseg_n; m.team_epoch = c->team_epoch; m.counter = c->counter + ci; m.flags = match_flags;
-        u32 const max_blocks = (u32)((u64)c->match_blocks_l3 * (64u / (u32)c->G) / tpw);      // the context's team slots at this batch's width
+        u32 max_blocks = (u32)((u64)c->match_blocks_l3 * (64u / (u32)c->G) / tpw);      // the context's team slots at this batch's width
+        if (l4) {
+            m.tables = c->tables4; m.tseg_n = 1; m.team_epoch = c->epoch4; m.tbl_stride = KX_TBL4_ENTRIES; m.tbl_long = KX_TBL4_LONG; m.level = 4;
+            if (max_blocks > c->teams4 / tpw) max_blocks = c->teams4 / tpw;
+        }
         u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > max_blocks) blocks = max_blocks;
         if (c->profiling) HIP_TRY(hipEventRecord(c->evm[ci][0], st));
         KEntropyArgs e;
@@ -1004,12 +1037,12 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
         e.seqs = m.seqs; e.seq_cap = c->seq_cap; e.lits = c->lits + (size_t)first * c->lit_cap; e.lit_cap = c->lit_cap; e.meta = m.meta;
         e.scratch = c->scratch + (size_t)first * c->scratch_words; e.scratch_words = c->scratch_words;
         e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = c->knob.entropy_flags | ((m.flags & 4u) ? 8u : 0u);
-        bool const fuse = c->knob.fuse && !c->knob.match_v2 && (G == 4 || G == 8);
+        bool const fuse = c->knob.fuse && !c->knob.match_v2 && !l4 && (G == 4 || G == 8);
         if (fuse) {
             if (G == 4) hipLaunchKernelGGL(k_zstd_l3_fused<4>, dim3(blocks), dim3(64), 0, st, m, e);
             else hipLaunchKernelGGL(k_zstd_l3_fused<8>, dim3(blocks), dim3(64), 0, st, m, e);
         } else
-        if (c->knob.match_v2 && (G == 2 || G == 4 || G == 8)) {
+        if (c->knob.match_v2 && !l4 && (G == 2 || G == 4 || G == 8)) {
             m.flags |= 4u;                                                // this parser never copies literals: the entropy kernel gathers them
             bool const r512 = c->knob.match_v2 == 2;
             switch (G) {
@@ -1041,6 +1074,11 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
     if (c->profiling) { c->ev_valid[0] = 1; c->ev_valid[1] = 1; }
     if (tunable && c->tune_state < 2) { HIP_TRY(hipEventRecord(c->tune_ev[1], st)); c->tune_pending = 1; }
     return batch_end(c, st, d_in_len, n, c->max_slice_bytes, d_out_len, c->meta);
+}
+extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
+{
+    return zstd_compress_dfast(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, hip_stream, 3);
 }
 
 // Staging for what the pre-decode kernels leave (8 bytes per sequence -- a frame of S bytes holds at most S / 3 -- and
@@ -1508,7 +1546,7 @@ extern "C" size_t kmp_zstd_cctx_set_parameter(kmp_zstd_cctx* c, int param, int v
     if (param != KMP_ZSTD_c_compressionLevel) return KERRC(ZE_parameter_unsupported);
     if (c->stage != 0 || !c->in.empty()) return KERRC(ZE_stage_wrong);
     if (value == 0) value = 3;
-    if (value < 1 || value > 3) return KERRC(ZE_parameter_unsupported);
+    if (value < 1 || value > 4) return KERRC(ZE_parameter_unsupported);       // (4: its double-fast size class only, decided when the stream closes)
     c->level = value;
     return 0;
 }
@@ -1539,6 +1577,8 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
         if (c->level == 3 && (n - end_avail) % lap == 0) tail_direct = (u32)end_avail;
     }
     if (streaming && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
+    // level 4: what arrives in one closing call, above 16 KiB up to 128 KiB (libzstd's double-fast row of that level); the rest: CPU library
+    if (c->level == 4 && (streaming || !c->dict.empty() || n <= 16384u || n > KMP_MAX_SLICE_BYTES)) return KERRC(ZE_parameter_unsupported);
     // the plain case -- level 3, no dictionary, the whole slice at once, one block -- joins whatever other contexts are
     // closing right now: one batch for all of them (kmp_coalesce.h); the frame is the one this context would get alone
     if (!streaming && c->level == 3 && c->dict.empty() && n <= KMP_MAX_SLICE_BYTES && coalesce_enabled()) {

@@ -104,6 +104,23 @@ KX_DEV KParams kx_params_l3(u32 n)
     return p;
 }
 
+// Level 4 is double-fast in two of its four size classes (ZSTD_getCParams(4, n, 0): above 16 KiB up to 128 KiB {17,17,17, minMatch 4},
+// above 256 KiB {21,18,18, minMatch 5}; the other two are strategy "greedy", another parser).  One-block slices of the first
+// class are served: long table up to 2^17 entries, short table up to 2^17 (KX_TBL4_*: 1 MiB per team, from a table set of
+// its own).  ok = false: not such a slice.
+#define KX_TBL4_LONG (1u << 17)
+#define KX_TBL4_ENTRIES (1u << 18)
+KX_DEV KParams kx_params_l4(u32 n, bool& ok)
+{
+    KParams p; p.windowLog = 17; p.chainLog = 17; p.hashLog = 17; p.minMatch = 4;
+    ok = n > 16384u && n <= 131072u;
+    u32 const srcLog = (n < 64) ? 6 : kx_hb32(n - 1) + 1;
+    if (p.windowLog > srcLog) p.windowLog = srcLog;
+    if (p.hashLog > p.windowLog + 1) p.hashLog = p.windowLog + 1;
+    if (p.chainLog > p.windowLog) p.chainLog = p.windowLog;
+    return p;
+}
+
 // Level 2 has one double-fast row: sizes above 128 KiB up to 256 KiB (window 18, chain 14, hash 14, minMatch 5); its other
 // rows are "fast" ones (zstd_match_fast.h).  A batch at level 2 therefore goes through both block-chain kernels, each
 // taking the slices of its class (KFrameArgs.cls: 0 every slice, 1 only that size class, 2 only the others).

@@ -40,12 +40,14 @@ struct KMatchArgs {
     // the team tables in four pieces far apart in the HBM (team t: tseg[t & 3] + (t >> 2) tables), or tseg_n == 1: `tables` alone.
     // Random accesses confined to a few dozen GiB of this device's HBM reach 27.5 G/s, spread over most of it 37.
     u32* tseg[4] = { nullptr, nullptr, nullptr, nullptr }; u32 tseg_n = 1;
+    // geometry of a team's tables (entries): the level-3 one unless the batch runs level 4's double-fast row (level = 4)
+    u32 tbl_stride = KX_TBL_ENTRIES, tbl_long = KX_TBL_LONG, level = 3;
 };
 
 KX_DEV u32* kx_team_tables(const KMatchArgs& a, u32 team)
 {
-    if (a.tseg_n == 4) return a.tseg[team & 3u] + (size_t)(team >> 2) * KX_TBL_ENTRIES;
-    return a.tables + (size_t)team * KX_TBL_ENTRIES;
+    if (a.tseg_n == 4) return a.tseg[team & 3u] + (size_t)(team >> 2) * a.tbl_stride;
+    return a.tables + (size_t)team * a.tbl_stride;
 }
 
 enum { KST_IDLE = 0, KST_SEARCH = 1, KST_REPCHECK = 2, KST_MATCH = 3, KST_CLEANUP = 4, KST_DONE = 5 };
@@ -150,7 +152,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a, DONE const& done = DONE())
     int const tbase = lane - k;
     u32 const team = kx_block() * NT + (u32)(lane / G);
     u32* L = BLK ? a.big_tables : kx_team_tables(a, team);
-    u32* S = L + (BLK ? KX_BIG_TBL_LONG : KX_TBL_LONG);
+    u32* S = L + (BLK ? KX_BIG_TBL_LONG : a.tbl_long);
     int bstart = 0; u32 saved1 = 0, saved2 = 0;          // block mode: block start, repcodes set aside at block start
     u64 const tmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
 
@@ -225,18 +227,19 @@ KX_DEV void zstd_match_body(const KMatchArgs& a, DONE const& done = DONE())
                     src = a.src + a.in_off[s];
                     n = (int)a.in_len[s];
                     seqs = a.seqs + (size_t)s * a.seq_cap; lits = a.lits + (size_t)s * a.lit_cap;
-                    KParams const P = kx_params_l3((u32)n);
+                    bool lvl_ok = true;
+                    KParams const P = (a.level == 4u) ? kx_params_l4((u32)n, lvl_ok) : kx_params_l3((u32)n);
                     hbL = P.hashLog; hbS = P.chainLog; mls = P.minMatch;
-                    nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = 0;
+                    nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = lvl_ok ? 0u : 3u;      // 3: no double-fast row for this size at this level
                     if (ep == 0) {
-                        for (u32 i = (u32)k; i < KX_TBL_ENTRIES; i += G) L[i] = 0;
+                        for (u32 i = (u32)k; i < a.tbl_stride; i += G) L[i] = 0;
                         ep = 1;
                     }
                     tag = ep << KX_TAG_SHIFT;
                     anchor = 0; ilimit = n - 8;
                     ip = 1; off1 = 1; off2 = 0;     // rep {1,4,8}: 4 exceeds the 1 byte of history at ip=1
                     step = 1; nextStep = ip + 256; carry = false; compl_due = false; have_pw = false;
-                    state = (n < 8 || ip + 1 > ilimit) ? KST_CLEANUP : KST_SEARCH;
+                    state = (n < 8 || ip + 1 > ilimit || !lvl_ok) ? KST_CLEANUP : KST_SEARCH;
                 }
             }
         }
@@ -312,16 +315,20 @@ KX_DEV void zstd_match_body(const KMatchArgs& a, DONE const& done = DONE())
             }
             if (srch && carry && k == 0) idxl = carry_idxl;
             // what lanes < k of this team would have inserted before lane k looks up
-            u32 const hpack = hl | (hs << 16);       // hashLog <= 16 and chainLog <= 15 without BLK
             int predL = -1, predS = -1;
+            if (BLK || a.level == 4u) {              // hashLog 17 / chainLog 16 or 17: two shuffles
 #pragma unroll
-            for (int d = 1; d < G; d++) {
-                bool const ok = prov && k >= d;
-                if (BLK) {                           // hashLog 17 / chainLog 16: two shuffles
+                for (int d = 1; d < G; d++) {
+                    bool const ok = prov && k >= d;
                     u32 const pl = kx_shfl(hl, lane - d), ps = kx_shfl(hs, lane - d);
                     if (ok && predL < 0 && pl == hl) predL = k - d;
                     if (ok && predS < 0 && ps == hs) predS = k - d;
-                } else {
+                }
+            } else {
+                u32 const hpack = hl | (hs << 16);   // level 3, one block: hashLog <= 16 and chainLog <= 15
+#pragma unroll
+                for (int d = 1; d < G; d++) {
+                    bool const ok = prov && k >= d;
                     u32 const hp = kx_shfl(hpack, lane - d);
                     if (ok && predL < 0 && (hp & 0xFFFFu) == hl) predL = k - d;
                     if (ok && predS < 0 && (hp >> 16) == hs) predS = k - d;

@@ -70,6 +70,25 @@ KREF_API void kref_params_l3(size_t srcSize, u32* out4)
     out4[0] = W; out4[1] = C; out4[2] = H; out4[3] = mml;
 }
 
+/* Level 4's double-fast rows (libzstd: ZSTD_getCParams(4, srcSize, 0)): above 16 KiB up to 128 KiB {17,17,17,mml 4},
+ * above 256 KiB {21,18,18, mml 5}.  Its other rows are strategy "greedy" (up to 16 KiB and 128 - 256 KiB): returns 0 there. */
+KREF_API int kref_params_l4(size_t srcSize, u32* out4)
+{
+    u32 W, C, H, mml;
+    if (srcSize <= 16384) return 0;
+    else if (srcSize <= 131072) { W = 17; C = 17; H = 17; mml = 4; }
+    else if (srcSize <= 262144) return 0;
+    else                        { W = 21; C = 18; H = 18; mml = 5; }
+    {
+        u32 const srcLog = hb32((u32)(srcSize - 1)) + 1;
+        if (W > srcLog) W = srcLog;
+        if (H > W + 1) H = W + 1;
+        if (C > W) C = W;
+    }
+    out4[0] = W; out4[1] = C; out4[2] = H; out4[3] = mml;
+    return 1;
+}
+
 /* ------------------------------------------------------------------ */
 /* sequence store                                                      */
 /* ------------------------------------------------------------------ */
@@ -1009,7 +1028,7 @@ static size_t compress_sequences(u8* dst, size_t cap, const seqstore* ss)
     size_t const nbSeq = ss->nbSeq;
     u8* op = dst; u8* const oend = dst + cap;
     u8 *llCode, *ofCode, *mlCode; size_t i; size_t lastCountSize = 0;
-    static fse_ctable ctLL, ctOF, ctML;   /* oracle is single-threaded per process */
+    static __thread fse_ctable ctLL, ctOF, ctML;   /* (per thread: oracle/cpu_bench.c runs the restatement from several pthreads) */
     u32 count[64];
 
     if ((size_t)(oend - op) < 3 + 1) return KERR;
@@ -1276,6 +1295,14 @@ KREF_API size_t kref_zstd_l3_compress_blocks(u8* dst, size_t cap, const u8* src,
 KREF_API size_t kref_zstd_l3_compress(u8* dst, size_t cap, const u8* src, size_t srcSize)
 {
     return compress_blocks_dfast(dst, cap, src, srcSize, NULL, NULL, NULL);
+}
+/* Level 4 where it is double-fast (kref_params_l4): the same parse and entropy stage with that level's table sizes and
+ * minimum match.  (size_t)-1 outside those size classes. */
+KREF_API size_t kref_zstd_l4_compress(u8* dst, size_t cap, const u8* src, size_t srcSize)
+{
+    u32 P[4];
+    if (srcSize == 0 || !kref_params_l4(srcSize, P)) return KERR;
+    return compress_blocks_dfast(dst, cap, src, srcSize, NULL, NULL, P);
 }
 
 /* Stage taps for kernel-by-kernel diffing: the seqStore of the single block of a slice <= 128 KiB.

@@ -10,13 +10,15 @@ int emu_zstd_match(const u8* src, const u64* in_off, const u32* in_len, u32 n, i
                    KSeq* seqs, u32 seq_cap, u8* lits, u32 lit_cap, KSliceMeta* meta, u32 start_epoch)
 {
     u32 const nteams = nblocks * (64 / G);
-    std::vector<u32> tables((size_t)nteams * KX_TBL_ENTRIES, 0xDEADBEEFu & 0x0003FFFFu);   // stale junk with epoch 0
+    bool const l4 = getenv("KXEMU_LEVEL") && atoi(getenv("KXEMU_LEVEL")) == 4;          // level 4's double-fast row: larger tables
+    std::vector<u32> tables((size_t)nteams * (l4 ? KX_TBL4_ENTRIES : KX_TBL_ENTRIES), 0xDEADBEEFu & 0x0003FFFFu);   // stale junk with epoch 0
     std::vector<u32> epoch(nteams, start_epoch);
     u32 counter = 0;
     KMatchArgs a;
     a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
     a.seqs = seqs; a.seq_cap = seq_cap; a.lits = lits; a.lit_cap = lit_cap; a.meta = meta;
     a.tables = tables.data(); a.team_epoch = epoch.data(); a.counter = &counter; a.flags = 0; a.fstate = nullptr; a.big_tables = nullptr;
+    if (l4) { a.tbl_stride = KX_TBL4_ENTRIES; a.tbl_long = KX_TBL4_LONG; a.level = 4; }
     if (getenv("KXEMU_MATCH_FLAGS")) a.flags |= (u32)atoi(getenv("KXEMU_MATCH_FLAGS")) & 128u;       // (bit 7: adaptive speculation width)
     kxemu::failed = 0;
     switch (G) {

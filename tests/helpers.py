@@ -166,6 +166,12 @@ def stream_cases():
     return out
 
 
+def level4_golden():
+    """libzstd 1.5.7 at level 4 where it is the double-fast parse with one block (tests/golden/make_golden_level4.py)."""
+    with open(os.path.join(os.path.dirname(GOLDEN_PATH), "zstd_level4_golden.json")) as fh:
+        return json.load(fh)
+
+
 def levels_golden():
     with open(os.path.join(os.path.dirname(GOLDEN_PATH), "zstd_levels_golden.json")) as fh:
         return json.load(fh)
@@ -251,8 +257,18 @@ class Oracle:
         return o.raw[:n], bool(mode.value)
 
     def compress_level(self, d: bytes, level: int) -> bytes:
-        """Frame at level 1 or 2 (strategy "fast")."""
+        """Frame at level 1 or 2 (strategy "fast"), or 4 where it is the double-fast parse (16 KiB < size <= 128 KiB, and above
+        256 KiB ZSTD_compress2's frame)."""
         k = self.lib
+        if level == 4:
+            k.kref_zstd_l4_compress.restype = ctypes.c_size_t
+            k.kref_zstd_l4_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+            cap = k.kref_compress_bound(len(d)) + 64
+            o = ctypes.create_string_buffer(cap)
+            n = k.kref_zstd_l4_compress(o, cap, d, len(d))
+            if n == 2 ** 64 - 1:
+                raise RuntimeError("oracle: level 4 has no double-fast row for this size")
+            return o.raw[:n]
         k.kref_zstd_fast_compress.restype = ctypes.c_size_t
         k.kref_zstd_fast_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
         cap = k.kref_compress_bound(len(d)) + 64

@@ -80,6 +80,24 @@ def test_emulated_fused_kernel_matches_golden(G, monkeypatch, team):
         assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], r["name"]
 
 
+@pytest.mark.parametrize("team", [4, 8])
+def test_emulated_level_4_matches_golden(monkeypatch, team):
+    """zstd_match.h with level 4's double-fast row (hash 17, chain up to 17, minimum match 4; a team's tables 1 MiB): the
+    frames of libzstd 1.5.7 at level 4 on 64 KiB slices of every class and on the ragged sizes above 16 KiB."""
+    monkeypatch.setenv("KXEMU_LEVEL", "4")
+    G = helpers.level4_golden()
+    S = 65536
+    lo = 0 if team == 4 else 16
+    buf = corpus.make(lo, 16, S)
+    frames = helpers.emu_compress([buf[k * S:(k + 1) * S].tobytes() for k in range(16)], G=team, nblocks=1)
+    for (i, flen, sha), f in zip(G["config1"][lo:lo + 16], frames):
+        assert len(f) == flen and helpers.sha256(f) == sha, (i, team)
+    lad = [r for r in G["ladder"] if r[1] in ((0, 2, 5) if team == 4 else (1, 6))]
+    frames = helpers.emu_compress([corpus.make(1000, 8, S2)[k * S2:(k + 1) * S2].tobytes() for S2, k, _l, _s in lad], G=team, nblocks=1)
+    for (S2, k, flen, sha), f in zip(lad, frames):
+        assert len(f) == flen and helpers.sha256(f) == sha, (S2, k, team)
+
+
 def test_emulated_split_phase_parser_at_the_end_of_a_slice(monkeypatch):
     """Matches that run into the last bytes of a slice (the window's 16-byte looks must not count bytes they do not hold): every
     distance of a repeat's start from the end, several periods, against the oracle."""

@@ -554,6 +554,75 @@ def test_levels_1_and_2(batch):
     assert f1 == o.compress_level(mix[3], 1) and ZstdDecompressor().transform_bytes(f1) == mix[3]
 
 
+def test_level_4_where_it_is_double_fast(batch, monkeypatch):
+    """ZstdCompressor(level = 4) for slices above 16 KiB up to 128 KiB (libzstd runs that size class of level 4 as the double-fast
+    parse with hash 17 / chain 17 / minimum match 4): the ragged sizes in one batch and 256 slices of the 64 KiB mix against
+    libzstd 1.5.7, decoded back on the GPU; a slice of 16 KiB or less in such a batch (strategy "greedy": no parser here) is
+    refused -- out_len 0 and KMP_STATUS_LEVEL_SIZE -- while its neighbours come out right; level 3 still works on the same context
+    afterwards (its tables are another set); and the host-batch call takes the level."""
+    from kompressor_amd.batch import compress_host_batch
+    G = helpers.level4_golden()
+
+    def run(datas, level, check=True):
+        n = len(datas)
+        lens = np.array([len(d) for d in datas], dtype=np.int32)
+        offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64) if n > 1 else np.zeros(1, dtype=np.int64)
+        host = np.frombuffer(b"".join(datas) + bytes(64), dtype=np.uint8).copy()
+        dst, ooff, olen = batch.compress(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), level=level, check=check)
+        torch.cuda.synchronize()
+        hd, ho, hl = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+        return [hd[ho[i]:ho[i] + hl[i]].tobytes() for i in range(n)]
+
+    ladder = [corpus.make(1000, 8, S)[k * S:(k + 1) * S].tobytes() for S, k, *_ in G["ladder"]]
+    frames = run(ladder, 4)
+    for (S, k, flen, sha), f in zip(G["ladder"], frames):
+        assert len(f) == flen and helpers.sha256(f) == sha, (S, k)
+    back, st = gpu_decompress(batch, frames, [len(d) for d in ladder])
+    assert st == [0] * len(frames) and back == ladder
+    S = 65536
+    buf = corpus.make(0, 256, S)
+    mix = [buf[i * S:(i + 1) * S].tobytes() for i in range(256)]
+    frames4 = run(mix, 4)
+    for (i, flen, sha), f in zip(G["config1"], frames4):
+        assert len(f) == flen and helpers.sha256(f) == sha, i
+    # a batch with slices of the "greedy" size class among the others
+    batch.status()
+    mixed = [mix[0], mix[1][:16384], mix[2], b"", mix[3][:20000]]
+    frames = run(mixed, 4, check=False)
+    assert batch.status()[1] & 4                     # KMP_STATUS_LEVEL_SIZE
+    o = helpers.oracle()
+    assert frames[0] == frames4[0] and frames[1] == b"" and frames[2] == frames4[2] and frames[3] == b"" and frames[4] == o.compress_level(mixed[4], 4)
+    with pytest.raises(RuntimeError):
+        run(mixed, 4)                                # (check=True raises on the refused slices)
+    # level 3 on the same context afterwards
+    G3 = helpers.golden()
+    frames3 = run(mix[:16], 3)
+    for (i, cls, flen, sha), f in zip(G3["config1"][:16], frames3):
+        assert len(f) == flen and helpers.sha256(f) == sha, i
+    assert compress_host_batch(mix[:8], level=4) == frames4[:8]
+    # the streaming entry point (what ZstdCompressor(4).transform(bytes) binds): served for that size class, refused below it
+    from kompressor_amd import ZstdCompressor
+    assert ZstdCompressor(compression_level=4).transform_bytes(mix[5]) == frames4[5]
+    with pytest.raises(Exception):
+        ZstdCompressor(compression_level=4).transform_bytes(mix[5][:9000])
+    # many slices through few teams: every team parses four slices per batch on tables it never clears (epoch tags), three batches
+    from kompressor_amd.batch import ZstdBatch
+    monkeypatch.setenv("KMP_L4_TEAMS", "64")
+    small = ZstdBatch(max_slices=4096, max_slice_bytes=131072)
+    monkeypatch.delenv("KMP_L4_TEAMS")
+    try:
+        lens = torch.full((256,), S, dtype=torch.int32, device="cuda")
+        offs = torch.arange(256, dtype=torch.int64, device="cuda") * S
+        dev = torch.from_numpy(buf).cuda()
+        for _ in range(3):
+            dst, ooff, olen = small.compress(dev, offs, lens, level=4, check=True)
+            torch.cuda.synchronize()
+            hd, ho, hl = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+            assert [hd[ho[i]:ho[i] + hl[i]].tobytes() for i in range(256)] == frames4
+    finally:
+        small.close()
+
+
 def test_streaming_frames_finish_false_then_true():
     """The reference's streaming callers (SliceTransformRawSource.kt:32-55): input in several finish = false calls, then
     finish = true.  libzstd does not know the size then: the frames (no content size, window 2^21, 128 KiB input chunks)

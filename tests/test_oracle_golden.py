@@ -117,6 +117,28 @@ def test_oracle_levels_1_and_2_match_golden():
             assert len(f) == flen and helpers.sha256(f) == sha, (i, lvl)
 
 
+def test_oracle_level_4_double_fast_rows_match_golden():
+    """Level 4 where libzstd runs it as the double-fast parse (ZSTD_getCParams(4, n, 0): above 16 KiB up to 128 KiB window <= 17,
+    chain 17, hash 17, minimum match 4): the same restatement as level 3 with those parameters, against libzstd 1.5.7
+    (tests/golden/make_golden_level4.py).  The golden file also records libzstd's parameters per size class and level:
+    the other classes of level 4, and every class of levels 5 and up, are strategies this backend has no parser for."""
+    o = helpers.oracle()
+    G = helpers.level4_golden()
+    for S, k, flen, sha in G["ladder"]:
+        f = o.compress_level(corpus.make(1000, 8, S)[k * S:(k + 1) * S].tobytes(), 4)
+        assert len(f) == flen and helpers.sha256(f) == sha, (S, k)
+    S = 65536
+    buf = corpus.make(0, 256, S)
+    for i, flen, sha in G["config1"]:
+        f = o.compress_level(buf[i * S:(i + 1) * S].tobytes(), 4)
+        assert len(f) == flen and helpers.sha256(f) == sha, i
+    with pytest.raises(RuntimeError):
+        o.compress_level(b"x" * 16384, 4)
+    strategy = {(size, lvl): st for size, lvl, *_r, st in G["cparams"]}
+    assert strategy[(65536, 4)] == 2 and strategy[(131072, 4)] == 2 and strategy[(16384, 4)] == 3 and strategy[(262144, 4)] == 3
+    assert all(strategy[(size, 5)] >= 3 for size in (4096, 65536, 1 << 20))
+
+
 def test_oracle_streaming_frames_match_golden():
     """finish = false ... finish = true (SliceTransformRawSource.kt:32-55): frames without content size, window 2^21,
     the input cut at multiples of 128 KiB before the pre-splitter sees it."""

@@ -12,12 +12,14 @@ run --mode deflate --steps 2 --warmup 1
 run --mode inflate --steps 3 --warmup 1 --no-cpu
 run --level 1 --steps 3 --warmup 1 --no-cpu
 run --level 2 --steps 3 --warmup 1 --no-cpu
+run --level 4 --steps 3 --warmup 1 --no-cpu
 run --dict-kib 16 --steps 3 --warmup 1 --no-cpu
 run --dict-kib 64 --slice-kib 8 --slices 262144 --steps 3 --warmup 1 --no-cpu
 run --slice-kib 128 --slices 32768 --steps 3 --warmup 1 --no-cpu
 run --slice-kib 256 --slices 32768 --steps 2 --warmup 1 --no-cpu
 run --slice-kib 1024 --slices 8192 --steps 2 --warmup 1
 run --slice-kib 1024 --slices 16384 --steps 2 --warmup 1 --no-cpu
+run --slice-kib 1024 --slices 32768 --steps 2 --warmup 1 --no-cpu --no-stream
 run --slice-kib 256 --slices 32768 --level 1 --steps 2 --warmup 1 --no-cpu
 run --slice-kib 256 --slices 32768 --level 2 --steps 2 --warmup 1 --no-cpu
 run --slice-kib 1024 --slices 8192 --level 2 --steps 2 --warmup 1 --no-cpu
