@@ -709,7 +709,7 @@ def main():
             res["roofline"]["kernel"] = "k_zstd_match_dict + k_zstd_entropy (one launch each per step)"
         if args.level != 3:
             res["roofline"]["kernel"] = ("k_zstd_big_fast (one launch per step: every wave walks the block chains of its slices)" if SLICE > 128 * 1024
-                                         else "k_zstd_match + k_zstd_entropy with level 4's double-fast row (tables of 1 MiB per team, 16 384 teams)" if args.level == 4
+                                         else "k_zstd_match + k_zstd_entropy with level 4's double-fast row (tables of 1 MiB per team)" if args.level == 4
                                          else "k_zstd_match_fast + k_zstd_entropy (one launch each per step)")
             res["config"]["workload"] = f"{n} x {args.slice_kib} KiB seeded mixed slices per GPU, ZstdCompressor(level={args.level}), bit-identical to libzstd 1.5.7"
             res["metric"] = f"zstd level-{args.level} compression throughput (uncompressed input bytes per second)"

@@ -204,7 +204,7 @@ KMP_API int kmp_zstd_compress_batch_reference(kmp_batch_ctx* ctx,
  * level 1 also as frames of several blocks for slices <= 512 KiB (context created with max_slice_bytes in
  * (128 KiB, 512 KiB]); 3 (or 0) = kmp_zstd_compress_batch.  Frames are the ones libzstd 1.5.7 writes at that level.
  * Level 4 is served where libzstd runs it as "double-fast" with one block: slices above 16 KiB up to 128 KiB (window <= 17,
- * chain 17, hash 17, minimum match 4; ZSTD_getCParams(4, n, 0)).  Its tables (1 MiB per team, at most 16 GiB) are allocated by
+ * chain 17, hash 17, minimum match 4; ZSTD_getCParams(4, n, 0)).  Its tables (1 MiB per team: 64 GiB beside a 65 536-slice context, less when the device has less room; KMP_L4_TEAMS caps it) are allocated by
  * the first level-4 batch of a context.  A slice of 16 KiB or less in a level-4 batch is refused like an oversized one
  * (out_len 0, KMP_STATUS_LEVEL_SIZE): that size class of level 4 is strategy "greedy", as are levels 5 and up -- not served. */
 KMP_API int kmp_zstd_compress_batch_level(kmp_batch_ctx* ctx,

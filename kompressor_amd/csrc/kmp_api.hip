@@ -949,13 +949,17 @@ extern "C" int kmp_zstd_compress_batch_reference(kmp_batch_ctx* c, const void* d
 extern "C" int kmp_batch_last_rounds(kmp_batch_ctx* c) { return c ? (int)c->last_rounds : 0; }
 
 // Level 4 where it is the double-fast parse (slices above 16 KiB up to 128 KiB: zstd_common.h kx_params_l4): its tables are
-// 1 MiB per team, a set of their own allocated by the first such batch (at most 16 384 teams = 16 GiB; the batch's slices
-// go through them by the work counter).
+// 1 MiB per team, a set of their own allocated by the first such batch (as many teams as level 3 has, memory permitting; the
+// batch's slices go through them by the work counter).
 static int ensure_tables4(kmp_batch_ctx* c)
 {
     if (c->tables4) return KMP_OK;
-    u32 const cap4 = env_u32("KMP_L4_TEAMS", 16384);                  // (the tests run many slices through few teams)
+    // as many teams as level 3 has (65 536 x 64 KiB: 19.4 GB/s with 65 536 teams = 64 GiB of tables, 15.9 with 32 768, 14.6 with 16 384:
+    // tools/r03_l4.sh), fewer when the device has less room (16 GiB stay free); KMP_L4_TEAMS caps it (the tests run many slices
+    // through few teams)
+    u32 const cap4 = env_u32("KMP_L4_TEAMS", 65536);
     u32 teams = c->nteams < cap4 ? c->nteams : cap4;
+    { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess) { size_t const room = fr > ((size_t)16 << 30) ? (fr - ((size_t)16 << 30)) / ((size_t)KX_TBL4_ENTRIES * sizeof(u32)) : 0; if (teams > room) teams = (u32)room; } else (void)hipGetLastError(); }
     teams &= ~63u; if (teams == 0) teams = 64;
     size_t const bytes = (size_t)teams * KX_TBL4_ENTRIES * sizeof(u32);
     u32* t = nullptr; u32* e = nullptr;
