@@ -774,6 +774,9 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms_match, 3), "launches_per_step": launches},
             "kernels_ms": {"k_zstd_match": round(ms_match, 3), "k_zstd_entropy": round(ms_entropy, 3)},
         }
+        if launches > 1:
+            res["kernels_ms_note"] = ("mean duration per launch; with several launches per step an entropy launch runs beside the next piece's parse and is "
+                                      "stretched over it (its own cost is the last launch's, about a tenth of a parse launch): the step is the parse launches plus one entropy launch")
         if random_access:
             res["random_access_roofline"] = random_access
         if exchange:
