@@ -36,6 +36,10 @@ def find_libzstd_157():
     return None
 
 
+class _ZBuf(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_void_p), ("size", ctypes.c_size_t), ("pos", ctypes.c_size_t)]
+
+
 class LibZstd:
     """Mirror of what Kompressor's JNI layer does with libzstd (level param id 100)."""
 
@@ -52,6 +56,8 @@ class LibZstd:
         lib.ZSTD_compress2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                        ctypes.c_void_p, ctypes.c_size_t]
         lib.ZSTD_compress2.restype = ctypes.c_size_t
+        lib.ZSTD_compressStream2.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ZBuf), ctypes.POINTER(_ZBuf), ctypes.c_int]
+        lib.ZSTD_compressStream2.restype = ctypes.c_size_t
         lib.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
         lib.ZSTD_compressBound.restype = ctypes.c_size_t
         lib.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
@@ -99,11 +105,7 @@ class LibZstd:
         """What the reference's streaming callers do (SliceTransformRawSource.kt:32-55): data[cuts[i]:cuts[i+1]] is fed with
         ZSTD_e_continue (finish = false), the last piece with ZSTD_e_end; output drained through out_chunk-byte buffers."""
         lib = self.lib
-
-        class Buf(ctypes.Structure):
-            _fields_ = [("p", ctypes.c_void_p), ("size", ctypes.c_size_t), ("pos", ctypes.c_size_t)]
-        lib.ZSTD_compressStream2.argtypes = [ctypes.c_void_p, ctypes.POINTER(Buf), ctypes.POINTER(Buf), ctypes.c_int]
-        lib.ZSTD_compressStream2.restype = ctypes.c_size_t
+        Buf = _ZBuf                      # (one type and one prototype for all callers: several threads may be in here)
         cctx = lib.ZSTD_createCCtx()
         lib.ZSTD_CCtx_setParameter(cctx, 100, level)
         src = ctypes.create_string_buffer(data, len(data) + 1)

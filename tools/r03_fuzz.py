@@ -1,0 +1,134 @@
+"""Differential fuzz on the GPU box: ragged slices of stress inputs (tools/fuzzgen.c: short-distance matches, repeated offsets,
+small alphabets, periodic data, abrupt regime changes) and of the corpus classes through every level-3 path (team width 4, the
+per-batch width 8, the split-phase parser, the fused kernel), levels 1, 2 and 4, and raw DEFLATE at levels 1, 6 and 9 -- EVERY frame compared with the binary
+libzstd 1.5.7 (DEFLATE: with this machine's zlib) on the host cores (Pillow's copy: test infrastructure, looked up by oracle/libzstd_ref.py), and decoded back on
+the GPU.  usage: python tools/r03_fuzz.py [seed] [n_slices]"""
+import os, sys, ctypes, subprocess, time
+from concurrent.futures import ThreadPoolExecutor
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np, torch
+from kompressor_amd import corpus
+from kompressor_amd.batch import ZstdBatch
+from libzstd_ref import find_libzstd_157
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 24000
+out_dir = os.path.join(ROOT, "gpurun_out"); os.makedirs(out_dir, exist_ok=True)
+so = os.path.join(out_dir, "libfuzzgen.so")
+subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools", "fuzzgen.c")], check=True)
+FG = ctypes.CDLL(so); FG.fuzz_fill.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint64]
+rng = np.random.default_rng(seed)
+lens = np.where(rng.random(N) < 0.10, rng.integers(0, 300, N), np.where(rng.random(N) < 0.5, rng.integers(0, 131073, N), rng.integers(16385, 131073, N))).astype(np.int64)
+lens[:10] = [0, 1, 7, 8, 9, 131072, 131071, 65536, 16384, 16385]
+offs = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.int64)
+total = int(lens.sum())
+host = np.empty(total + 64, dtype=np.uint8)
+# three quarters stress inputs (one generator stream per slice), one quarter corpus classes cut raggedly
+for i in range(N):
+    if i % 4 != 3 and lens[i]:
+        FG.fuzz_fill(host[offs[i]:].ctypes.data, int(lens[i]), seed * 1000003 + i)
+for i in range(3, N, 4):
+    if lens[i]:
+        host[offs[i]:offs[i] + lens[i]] = corpus.make(700000 + seed * N + i, 1, int(lens[i]), mix=ord("TXSBDIZR"[(i // 4) % 8]))
+print(f"seed {seed}: {N} slices, {total / 1e9:.2f} GB", flush=True)
+
+lib = find_libzstd_157(); assert lib is not None, "no libzstd 1.5.7 on this machine"
+lib.ZSTD_compress.restype = ctypes.c_size_t
+lib.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+def ref_frames(level, idx):
+    def work(chunk):
+        out = []; buf = ctypes.create_string_buffer(140000)
+        for i in chunk:
+            r = lib.ZSTD_compress(buf, 140000, host[offs[i]:].ctypes.data, int(lens[i]), level)
+            out.append(buf.raw[:r])
+        return out
+    chunks = [idx[k::16] for k in range(16)]
+    with ThreadPoolExecutor(16) as ex: parts = list(ex.map(work, chunks))
+    res = {}
+    for ch, pa in zip(chunks, parts):
+        for i, f in zip(ch, pa): res[int(i)] = f
+    return res
+
+src = torch.from_numpy(host).cuda()
+d_off = torch.from_numpy(offs).cuda(); d_len = torch.from_numpy(lens.astype(np.int32)).cuda()
+def gpu_frames(env, level, n_ctx, piece, idx):
+    for k in ("KMP_MATCH_V2", "KMP_FUSE"): os.environ.pop(k, None)
+    os.environ.update(env)
+    b = ZstdBatch(max_slices=n_ctx, max_slice_bytes=131072)
+    sel = torch.from_numpy(np.asarray(idx, dtype=np.int64)).cuda()
+    o_all, l_all = d_off[sel], d_len[sel]
+    frames = {}
+    for lo in range(0, len(idx), piece):
+        hi = min(len(idx), lo + piece)
+        dst, ooff, olen = b.compress(src, o_all[lo:hi], l_all[lo:hi], level=level, check=True)
+        torch.cuda.synchronize()
+        d, oo, ol = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+        for k in range(hi - lo): frames[int(idx[lo + k])] = d[int(oo[k]):int(oo[k]) + int(ol[k])].tobytes()
+        cap = torch.clamp(l_all[lo:hi], min=1)
+        out, o2, l2, st = b.decompress(dst, ooff, olen, cap)
+        torch.cuda.synchronize()
+        assert int(st.abs().sum().item()) == 0 and bool((l2 == l_all[lo:hi]).all()), "decode status"
+        oh, o2h = out.cpu().numpy(), o2.cpu().numpy()
+        for k in range(0, hi - lo, 97):                        # every 97th slice byte for byte (the lengths and statuses of all)
+            i = int(idx[lo + k]); assert oh[int(o2h[k]):int(o2h[k]) + int(lens[i])].tobytes() == host[offs[i]:offs[i] + lens[i]].tobytes(), ("round trip", i)
+    b.close()
+    return frames
+
+all_idx = np.arange(N)
+big_idx = np.nonzero(lens > 16384)[0]
+bad_total = 0
+for name, env, level, n_ctx, piece, idx in (
+        ("level 3, team width 4, one batch", {}, 3, N, N, all_idx),
+        ("level 3, batches of 6 000 (team width 8)", {}, 3, 6000, 6000, all_idx),
+        ("level 3, split-phase parser", {"KMP_MATCH_V2": "2"}, 3, N, N, all_idx),
+        ("level 3, fused kernel", {"KMP_FUSE": "1"}, 3, N, N, all_idx),
+        ("level 1", {}, 1, N, N, all_idx),
+        ("level 2", {}, 2, N, N, all_idx),
+        ("level 4 (slices above 16 KiB)", {}, 4, N, N, big_idx),
+        ("level 4, batches of 4 000 (team width 8)", {}, 4, 4000, 4000, big_idx)):
+    t0 = time.time()
+    g = gpu_frames(env, level, n_ctx, piece, idx)
+    r = ref_frames(level, idx)
+    bad = [i for i in idx if g[int(i)] != r[int(i)]]
+    bad_total += len(bad)
+    print(f"{name}: {len(idx)} frames against libzstd 1.5.7, different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:8]]}  ({time.time() - t0:.0f} s)", flush=True)
+# raw DEFLATE (zlib's levels 1, 6 and 9) against this machine's zlib, and inflate of what came out
+import zlib
+dfl_idx = np.arange(0, N, 3)                                     # a third of the slices (the level-9 search is slow on both sides)
+def zlib_frames(level, idx):
+    def work(chunk):
+        out = []
+        for i in chunk:
+            c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, zlib.Z_DEFAULT_STRATEGY)
+            out.append(c.compress(host[offs[i]:offs[i] + lens[i]].tobytes()) + c.flush())
+        return out
+    chunks = [idx[k::16] for k in range(16)]
+    with ThreadPoolExecutor(16) as ex: parts = list(ex.map(work, chunks))
+    res = {}
+    for ch, pa in zip(chunks, parts):
+        for i, f in zip(ch, pa): res[int(i)] = f
+    return res
+for k in ("KMP_MATCH_V2", "KMP_FUSE"): os.environ.pop(k, None)
+bd = ZstdBatch(max_slices=len(dfl_idx), max_slice_bytes=131072)
+sel = torch.from_numpy(dfl_idx.astype(np.int64)).cuda()
+for level in (1, 6, 9):
+    t0 = time.time()
+    dst, ooff, olen = bd.deflate(src, d_off[sel], d_len[sel], level=level, check=True)
+    torch.cuda.synchronize()
+    d, oo, ol = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+    g = {int(dfl_idx[k]): d[int(oo[k]):int(oo[k]) + int(ol[k])].tobytes() for k in range(len(dfl_idx))}
+    r = zlib_frames(level, dfl_idx)
+    bad = [i for i in dfl_idx if g[int(i)] != r[int(i)]]
+    bad_total += len(bad)
+    cap = torch.clamp(d_len[sel], min=1)
+    out, o2, l2, st = bd.inflate(dst, ooff, olen, cap)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum().item()) == 0 and bool((l2 == d_len[sel]).all()), "inflate status"
+    oh, o2h = out.cpu().numpy(), o2.cpu().numpy()
+    for k in range(0, len(dfl_idx), 53):
+        i = int(dfl_idx[k]); assert oh[int(o2h[k]):int(o2h[k]) + int(lens[i])].tobytes() == host[offs[i]:offs[i] + lens[i]].tobytes(), ("inflate round trip", i)
+    print(f"raw DEFLATE level {level}: {len(dfl_idx)} streams against zlib {zlib.ZLIB_RUNTIME_VERSION}, different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:8]]}  ({time.time() - t0:.0f} s)", flush=True)
+bd.close()
+print("FUZZ OK" if bad_total == 0 else f"FUZZ FOUND {bad_total} DIFFERENCES")
+sys.exit(0 if bad_total == 0 else 1)
