@@ -98,7 +98,11 @@ static void gen_codes(ct* tree, int max_code, u16* bl_count)
 static void tr_static_init(void)
 {
     int n, bits, length, code, dist; u16 bl_count[MAX_BITS + 1];
-    if (tables_ready) return;
+    /* (once, whatever the number of threads that arrive here together: the tests' helpers may call from a pool) */
+    static int lock = 0;
+    if (__atomic_load_n(&tables_ready, __ATOMIC_ACQUIRE)) return;
+    while (__atomic_exchange_n(&lock, 1, __ATOMIC_ACQUIRE)) { }
+    if (tables_ready) { __atomic_store_n(&lock, 0, __ATOMIC_RELEASE); return; }
     length = 0;
     for (code = 0; code < 28; code++) { base_length[code] = length; for (n = 0; n < (1 << extra_lbits[code]); n++) length_code[length++] = (u8)code; }
     length_code[length - 1] = (u8)code;
@@ -114,7 +118,8 @@ static void tr_static_init(void)
     while (n <= 287) static_ltree[n++].len = 8, bl_count[8]++;
     gen_codes(static_ltree, L_CODES + 1, bl_count);
     for (n = 0; n < D_CODES; n++) { static_dtree[n].len = 5; static_dtree[n].code = (u16)bi_reverse((unsigned)n, 5); }
-    tables_ready = 1;
+    __atomic_store_n(&tables_ready, 1, __ATOMIC_RELEASE);
+    __atomic_store_n(&lock, 0, __ATOMIC_RELEASE);
 }
 #define d_code(dist) ((dist) < 256 ? dist_code[dist] : dist_code[256 + ((dist) >> 7)])
 
