@@ -93,6 +93,39 @@ for name, env, level, n_ctx, piece, idx in (
     bad = [i for i in idx if g[int(i)] != r[int(i)]]
     bad_total += len(bad)
     print(f"{name}: {len(idx)} frames against libzstd 1.5.7, different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:8]]}  ({time.time() - t0:.0f} s)", flush=True)
+# ZstdCompressor(3, dictionary): a raw-content dictionary shared by the batch (text + JSON of the corpus + stress bytes), two sizes
+from libzstd_ref import LibZstd
+import threading
+_tl = threading.local()
+def with_dict(d, dic):
+    if not hasattr(_tl, "z"): _tl.z = LibZstd()
+    return _tl.z.compress_with_dict(d, dic, 3)
+for k in ("KMP_MATCH_V2", "KMP_FUSE"): os.environ.pop(k, None)
+dict_idx = np.arange(0, N, 2)
+for dsize in (16384, 65536):
+    t0 = time.time()
+    dic = (corpus.make(4242 + seed, 1, dsize // 2, mix=ord("T")).tobytes() + corpus.make(4343 + seed, 1, dsize // 4, mix=ord("X")).tobytes()
+           + host[offs[5]:offs[5] + dsize // 4].tobytes()).ljust(dsize, b"\0")[:dsize]
+    bdic = ZstdBatch(max_slices=len(dict_idx), max_slice_bytes=131072)
+    sel = torch.from_numpy(dict_idx.astype(np.int64)).cuda()
+    dst, ooff, olen = bdic.compress(src, d_off[sel], d_len[sel], dictionary=dic, check=True)
+    torch.cuda.synchronize()
+    d, oo, ol = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+    g = {int(dict_idx[k]): d[int(oo[k]):int(oo[k]) + int(ol[k])].tobytes() for k in range(len(dict_idx))}
+    chunks = [dict_idx[k::16] for k in range(16)]
+    with ThreadPoolExecutor(16) as ex: parts = list(ex.map(lambda ch: [with_dict(host[offs[i]:offs[i] + lens[i]].tobytes(), dic) for i in ch], chunks))
+    r = {}
+    for ch, pa in zip(chunks, parts):
+        for i, f in zip(ch, pa): r[int(i)] = f
+    bad = [i for i in dict_idx if g[int(i)] != r[int(i)]]
+    bad_total += len(bad)
+    cap = torch.clamp(d_len[sel], min=1)
+    out, o2, l2, st = bdic.decompress(dst, ooff, olen, cap, dictionary=torch.from_numpy(np.frombuffer(dic, dtype=np.uint8).copy()).cuda())
+    torch.cuda.synchronize()
+    assert int(st.abs().sum().item()) == 0 and bool((l2 == d_len[sel]).all()), "decode with dictionary: status"
+    bdic.close()
+    print(f"level 3 with a raw-content dictionary of {dsize} bytes: {len(dict_idx)} frames against libzstd 1.5.7, different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:8]]}  ({time.time() - t0:.0f} s)", flush=True)
+
 # raw DEFLATE (zlib's levels 1, 6 and 9) against this machine's zlib, and inflate of what came out
 import zlib
 dfl_idx = np.arange(0, N, 3)                                     # a third of the slices (the level-9 search is slow on both sides)

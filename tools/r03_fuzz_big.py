@@ -20,6 +20,7 @@ FG = ctypes.CDLL(so); FG.fuzz_fill.argtypes = [ctypes.c_void_p, ctypes.c_size_t,
 rng = np.random.default_rng(seed)
 MAXL = 1536 * 1024
 lens = np.where(rng.random(N) < 0.5, rng.integers(131073, 524289, N), rng.integers(131073, MAXL + 1, N)).astype(np.int64)
+lens = np.where(rng.random(N) < 0.1, rng.integers(1, 131073, N), lens).astype(np.int64)        # a tenth of them one-block slices in the same batches
 lens[:6] = [131073, 131072 * 2, 131072 * 2 + 1, 262144 + 131072, MAXL, 524288]
 offs = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.int64)
 total = int(lens.sum())
@@ -43,10 +44,10 @@ def ref_frames(fn, idx):
     return res
 src = torch.from_numpy(host).cuda()
 d_off = torch.from_numpy(offs).cuda(); d_len = torch.from_numpy(lens.astype(np.int32)).cuda()
-def gpu_frames(level, reference, idx, max_bytes):
+def gpu_frames(level, reference, idx, max_bytes, streaming=None):
     b = ZstdBatch(max_slices=len(idx), max_slice_bytes=max_bytes)
     sel = torch.from_numpy(np.asarray(idx, dtype=np.int64)).cuda()
-    dst, ooff, olen = b.compress(src, d_off[sel], d_len[sel], level=level, reference=reference, check=True)
+    dst, ooff, olen = b.compress(src, d_off[sel], d_len[sel], level=level, reference=reference, streaming=streaming, check=True)
     torch.cuda.synchronize()
     d, oo, ol = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
     frames = {int(idx[k]): d[int(oo[k]):int(oo[k]) + int(ol[k])].tobytes() for k in range(len(idx))}
@@ -60,13 +61,22 @@ def gpu_frames(level, reference, idx, max_bytes):
     return frames
 all_idx = np.arange(N); l1_idx = np.nonzero(lens <= 524288)[0]
 bad_total = 0
-for name, level, reference, idx, fn in (
-        ("level 3, the reference driver's frames (input staged in 128 KiB chunks)", 3, True, all_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), 3)),
-        ("level 3, ZSTD_compress2's frames", 3, False, all_idx, lambda d: one_shot(d, 3)),
-        ("level 1 up to 512 KiB, the reference driver's frames", 1, True, l1_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), 1)),
-        ("level 1 up to 512 KiB, ZSTD_compress2's frames", 1, False, l1_idx, lambda d: one_shot(d, 1))):
+cutr = np.random.default_rng(seed + 99)
+def streamed(d, level, empty):                   # finish = false calls, then finish = true with / without data; 8 KiB output slices
+    n = len(d)
+    if empty or n < 2: return z.compress_streaming(d, [0, n, n], 8192, level)
+    k = 1 + (hash(d[:64]) % (n - 1))
+    return z.compress_streaming(d, [0, k, n], 8192, level)
+for name, level, reference, idx, fn, streaming in (
+        ("level 3, streamed, the closing call brings data", 3, False, all_idx, lambda d: streamed(d, 3, False), "data"),
+        ("level 3, streamed, the closing call is empty", 3, False, all_idx, lambda d: streamed(d, 3, True), "empty"),
+        ("level 1 up to 512 KiB, streamed, the closing call brings data", 1, False, l1_idx, lambda d: streamed(d, 1, False), "data"),
+        ("level 3, the reference driver's frames (input staged in 128 KiB chunks)", 3, True, all_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), 3), None),
+        ("level 3, ZSTD_compress2's frames", 3, False, all_idx, lambda d: one_shot(d, 3), None),
+        ("level 1 up to 512 KiB, the reference driver's frames", 1, True, l1_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), 1), None),
+        ("level 1 up to 512 KiB, ZSTD_compress2's frames", 1, False, l1_idx, lambda d: one_shot(d, 1), None)):
     t0 = time.time()
-    g = gpu_frames(level, reference, idx, MAXL if level == 3 else 524288)
+    g = gpu_frames(level, reference, idx, MAXL if level == 3 else 524288, streaming)
     r = ref_frames(fn, idx)
     bad = [i for i in idx if g[int(i)] != r[int(i)]]
     bad_total += len(bad)
