@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64) void k_table_probe(u32* p0, u32* p1, u32* p2, u
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
-extern "C" const char* kmp_version(void) { return "kompressor_hip 0.3 (gfx950; zstd levels 1-3: frames and streams up to 1 GiB, raw-content dictionaries; level 4 for slices of 16 KiB - 128 KiB; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
+extern "C" const char* kmp_version(void) { return "kompressor_hip 0.3 (gfx950; zstd levels 1-3: frames and streams up to 1 GiB, raw-content dictionaries; level 4 for slices of 16 KiB - 128 KiB, negative levels for slices up to 128 KiB; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
 
 // --------------------------------------------------------------------------
 // batch context
@@ -678,12 +678,14 @@ extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src
 {
     if (level == 3 || level == 0) return kmp_zstd_compress_batch(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, hip_stream);
     if (level == 4) return zstd_compress_dfast(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, hip_stream, 4);
-    if (level != 1 && level != 2) { g_last_error = "kmp_zstd_compress_batch_level: levels 1, 2, 3 and (slices above 16 KiB up to 128 KiB) 4 are served"; return KMP_ERR_ARG; }
+    bool const neg = level < 0;                // negative levels: strategy "fast" with a step of 1 - level, literals left uncompressed
+    if ((level != 1 && level != 2 && !neg) || level < -131072) { g_last_error = "kmp_zstd_compress_batch_level: levels -131072 .. -1, 1, 2, 3 and (slices above 16 KiB up to 128 KiB) 4 are served"; return KMP_ERR_ARG; }
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_level: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_level: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->big && neg) { g_last_error = "kmp_zstd_compress_batch_level: negative levels are served for one-block slices (context max_slice_bytes <= 128 KiB)"; return KMP_ERR_CAPACITY; }
     if (c->big) {
         // frames of several blocks: slices up to the level's window (512 KiB at level 1, 1 MiB at level 2)
         if (c->max_slice_bytes > ((level == 1 ? 512u : 1024u) << 10)) { g_last_error = "kmp_zstd_compress_batch_level: above 128 KiB levels 1 and 2 are served for slices up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
@@ -707,7 +709,7 @@ extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src
         g.m.src = (const u8*)d_src; g.m.in_off = d_in_off + first; g.m.in_len = c->len_ok + first; g.m.n_slices = m_n;
         g.m.seqs = c->seqs + (size_t)first * c->seq_cap; g.m.seq_cap = c->seq_cap; g.m.lits = c->lits + (size_t)first * c->lit_cap; g.m.lit_cap = c->lit_cap; g.m.meta = c->meta + first;
         { u32* ft_ = nullptr; u32* fe_ = nullptr; KMP_TRY(flat_tables(c, &ft_, &fe_)); g.m.tables = ft_; g.m.tseg_n = 1; g.m.team_epoch = fe_; } g.m.counter = c->counter + ci; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
-        g.level = (u32)level;
+        g.level = neg ? 0u : (u32)level; g.step0 = neg ? (u32)(1 - level) : 2u;
         u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
         switch (c->G) {
         case 2:  hipLaunchKernelGGL(k_zstd_match_fast<2>, dim3(blocks), dim3(64), 0, st, g); break;
@@ -723,7 +725,7 @@ extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src
         e.src = (const u8*)d_src; e.in_off = d_in_off + first; e.in_len = c->len_ok + first; e.n_slices = m_n;
         e.seqs = g.m.seqs; e.seq_cap = c->seq_cap; e.lits = g.m.lits; e.lit_cap = c->lit_cap; e.meta = g.m.meta;
         e.scratch = c->scratch + (size_t)first * c->scratch_words; e.scratch_words = c->scratch_words;
-        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = 8u | 32u;   // gather literals; strategy "fast"
+        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = 8u | 32u | (neg ? 64u : 0u);   // gather literals; strategy "fast"; negative levels: literals stay raw
         hipStream_t es = st;
         if (ci + 1 < chunks) { es = c->st2; HIP_TRY(hipStreamWaitEvent(es, c->evm[ci][1], 0)); forked = true; }
         hipLaunchKernelGGL(k_zstd_entropy, dim3(m_n), dim3(64), 0, es, e);
@@ -1550,7 +1552,7 @@ extern "C" size_t kmp_zstd_cctx_set_parameter(kmp_zstd_cctx* c, int param, int v
     if (param != KMP_ZSTD_c_compressionLevel) return KERRC(ZE_parameter_unsupported);
     if (c->stage != 0 || !c->in.empty()) return KERRC(ZE_stage_wrong);
     if (value == 0) value = 3;
-    if (value < 1 || value > 4) return KERRC(ZE_parameter_unsupported);       // (4: its double-fast size class only, decided when the stream closes)
+    if (value < -131072 || value > 4) return KERRC(ZE_parameter_unsupported);       // (4 and the negative levels: what arrives in one closing call of their size class, decided when the stream closes)
     c->level = value;
     return 0;
 }
@@ -1583,6 +1585,7 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
     if (streaming && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
     // level 4: what arrives in one closing call, above 16 KiB up to 128 KiB (libzstd's double-fast row of that level); the rest: CPU library
     if (c->level == 4 && (streaming || !c->dict.empty() || n <= 16384u || n > KMP_MAX_SLICE_BYTES)) return KERRC(ZE_parameter_unsupported);
+    if (c->level < 0 && (streaming || !c->dict.empty() || n > KMP_MAX_SLICE_BYTES)) return KERRC(ZE_parameter_unsupported);
     // the plain case -- level 3, no dictionary, the whole slice at once, one block -- joins whatever other contexts are
     // closing right now: one batch for all of them (kmp_coalesce.h); the frame is the one this context would get alone
     if (!streaming && c->level == 3 && c->dict.empty() && n <= KMP_MAX_SLICE_BYTES && coalesce_enabled()) {

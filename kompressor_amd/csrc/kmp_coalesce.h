@@ -166,7 +166,7 @@ extern "C" int kmp_zstd_compress_host_batch(int device, int level, const void* h
 {
     if (n && (!h_src || !in_off || !in_len || !h_dst || !out_off || !out_cap || !out_len)) { g_last_error = "kmp_zstd_compress_host_batch: null argument"; return KMP_ERR_ARG; }
     if (level == 0) level = 3;
-    if (level < 1 || level > 4) { g_last_error = "kmp_zstd_compress_host_batch: levels 1 to 3 are served, and 4 for slices above 16 KiB"; return KMP_ERR_ARG; }
+    if (level < -131072 || level > 4) { g_last_error = "kmp_zstd_compress_host_batch: levels -131072 .. 3 are served, and 4 for slices above 16 KiB"; return KMP_ERR_ARG; }
     host_engine* e0 = host_engine_get(device);
     if (!e0) return KMP_ERR_ARG;
     // A large batch goes through the bulk engines: pieces of KMP_HOST_BULK_SLICES slices handed to KMP_HOST_BULK_WORKERS

@@ -26,7 +26,8 @@ struct KEntropyArgs {
     u32* scratch; u32 scratch_words;         // per slice: Huffman stream staging (u32 aligned)
     u8* dst; const u64* out_off; u32* out_len;
     u32 flags;                               // timing experiments only (results become wrong): 1 no literal coding, 2 no sequence coding (timing experiments, results become wrong);
-                                             // 8: the match kernel copied no literals, gather them here; 32: strategy "fast" (levels 1, 2)
+                                             // 8: the match kernel copied no literals, gather them here; 32: strategy "fast" (levels 1, 2);
+                                             // 64: literals are left uncompressed (negative levels: ZSTD_literalsCompressionIsDisabled)
 };
 
 #define KXE_ERR 0xFFFFFFFFu
@@ -629,13 +630,13 @@ struct KHufPrev { const u32* ct; bool valid; u32* newCt; u32 outcome; };    // o
 
 // literals section at `dst`; returns its size (uniform across the wave)
 KX_DEV u32 kzstd_literals(KEntropyLds& lds, u8* dst, const u8* lits, u32 litSize, bool suspect, u32* scratch, int lane,
-                          KHufPrev* prev = nullptr)
+                          KHufPrev* prev = nullptr, bool disabled = false)
 {
     u32 const lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
     bool const single = litSize < 256;
     u32 hType = 2;
     u32 cLit = 0;      // 0 => raw, 1 => rle
-    if (litSize >= 64) {
+    if (litSize >= 64 && !disabled) {
         bool go = true;
         if (suspect && litSize >= 40960) {
             u32 const lb = kx_wave_hist(lds, lits, 4096, lane);
@@ -1036,7 +1037,7 @@ KX_DEV void zstd_entropy_slice(const KEntropyArgs& a, KEntropyLds& lds, u32 slic
         kx_wave_copy(lits + mm.litSize, src + (n - mm.lastLL), mm.lastLL, lane);
         kx_sync();
         bool const suspect = (mm.nbSeq == 0) || (litSize / mm.nbSeq >= 20);
-        u32 const litSec = (a.flags & 1u) ? 3u : kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane);
+        u32 const litSec = (a.flags & 1u) ? 3u : kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane, nullptr, (a.flags & 64u) != 0);
         kx_sync();
         u32 const seqSec = (a.flags & 2u) ? 0u : kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < n ? n - litSec : 0u, a.flags);
         if (seqSec != 0) {

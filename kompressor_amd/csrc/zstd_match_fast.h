@@ -8,12 +8,17 @@
 #pragma once
 #include "zstd_match.h"
 
-struct KFastArgs { KMatchArgs m; u32 level; };     // level 1 or 2 (block mode: level 1; m.flags bit 8 = stream of unknown size)
+struct KFastArgs { KMatchArgs m; u32 level; u32 step0 = 2; };     // level 1 or 2 (block mode: level 1; m.flags bit 8 = stream of unknown size), or 0 = a negative
+                                                                  // level (row 0 of libzstd's tables) with step0 = 1 - level (ZSTD_compressBlock_fast: targetLength + 1)
 
 // ZSTD_getCParams(level, n, 0) for the fast rows: hashLog, minMatch
 KX_DEV void kx_params_fast(u32 level, u32 n, u32& hashLog, u32& mml)
 {
     u32 W;
+    if (level == 0) {            // negative levels
+        if (n <= 16384) { W = 14; hashLog = 13; mml = 5; } else if (n <= 131072) { W = 17; hashLog = 12; mml = 5; }
+        else if (n <= 262144) { W = 18; hashLog = 13; mml = 5; } else { W = 19; hashLog = 13; mml = 6; }
+    } else
     if (level == 1) {
         if (n <= 16384) { W = 14; hashLog = 15; mml = 5; } else if (n <= 131072) { W = 17; hashLog = 13; mml = 6; }
         else if (n <= 262144) { W = 18; hashLog = 14; mml = 6; } else { W = 19; hashLog = 14; mml = 7; }
@@ -109,8 +114,8 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
         // ================= "_start": a new run of pairs =====================
         if (kx_any(state == KFS_START)) {
             if (state == KFS_START) {
-                step = 2; gap = 2; nextStep = ip0 + 128;
-                if (ip0 + 3 >= ilimit) state = KFS_CLEANUP;
+                step = (int)f.step0; gap = (int)f.step0; nextStep = ip0 + 128;
+                if (ip0 + step + 1 >= ilimit) state = KFS_CLEANUP;             // (ip3 = ip0 + step + 1)
                 else {
                     u32 e = 0, h0 = 0, h1 = 0, ck0 = 0;
                     if (k == 0) {

@@ -1739,6 +1739,12 @@ KREF_API size_t kref_zstd_l3_compress_dict(u8* dst, size_t cap, const u8* src, s
 KREF_API void kref_params_fast(int level, size_t srcSize, u32* out4)   /* windowLog, (unused), hashLog, minMatch */
 {
     u32 W, H, mml;
+    if (level < 0) {                       /* row 0 of libzstd's tables ("fast" with targetLength = -level: kref_fast_step) */
+        if (srcSize <= 16384)        { W = 14; H = 13; mml = 5; }
+        else if (srcSize <= 131072)  { W = 17; H = 12; mml = 5; }
+        else if (srcSize <= 262144)  { W = 18; H = 13; mml = 5; }
+        else                         { W = 19; H = 13; mml = 6; }
+    } else
     if (level == 1) {
         if (srcSize <= 16384)        { W = 14; H = 15; mml = 5; }
         else if (srcSize <= 131072)  { W = 17; H = 13; mml = 6; }
@@ -1759,7 +1765,10 @@ KREF_API void kref_params_fast(int level, size_t srcSize, u32* out4)   /* window
     out4[0] = W; out4[1] = 0; out4[2] = H; out4[3] = mml;
 }
 
-static size_t fast_block(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize, u32* hashTable, u32 hlog, u32 mls)
+/* stepSize of ZSTD_compressBlock_fast: targetLength + !targetLength + 1, targetLength = -level for negative levels, else 0 */
+static size_t kref_fast_step(int level) { return level < 0 ? (size_t)(-(long)level) + 1 : 2; }
+
+static size_t fast_block_step(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize, u32* hashTable, u32 hlog, u32 mls, size_t stepSize)
 {
     const u8* const base = src - IDX0;
     const u8* const istart = src;
@@ -1771,7 +1780,7 @@ static size_t fast_block(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize
     u32 current0 = 0;
     u32 rep_offset1 = rep[0], rep_offset2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0;
     size_t hash0, hash1; u32 matchIdx; u32 offcode; const u8* match0; size_t mLength;
-    size_t const stepSize = 2; size_t step; const u8* nextStep; size_t const kStepIncr = 1 << 7;
+    size_t step; const u8* nextStep; size_t const kStepIncr = 1 << 7;
 
     if (srcSize < 8) return srcSize;
     ip0 += (ip0 == prefixStart);
@@ -1859,12 +1868,13 @@ _match:
     goto _start;
 }
 
-/* One-shot frame at level 1 or 2 (strategy fast), srcSize <= 128 KiB (one block). */
+/* One-shot frame at level 1 or 2 (strategy fast) or at a negative level ("fast" with a larger step and literals left
+ * uncompressed: ZSTD_literalsCompressionIsDisabled), srcSize <= 128 KiB (one block). */
 KREF_API size_t kref_zstd_fast_compress(u8* dst, size_t cap, const u8* src, size_t srcSize, int level)
 {
     u32 P[4]; kref_wksp w; seqstore ss; u32 rep[3] = { 1, 4, 8 }; kref_hufstate h0, h1;
     size_t pos, lastLL, litC, seqC, cSize = 0; u8* body;
-    if (srcSize > 131072 || (level != 1 && level != 2)) return KERR;
+    if (srcSize > 131072 || (level != 1 && level != 2 && level >= 0) || level < -131072) return KERR;
     if (cap < kref_compress_bound(srcSize)) return KERR;
     kref_params_fast(level, srcSize, P);
     pos = write_frame_header(dst, srcSize, P[0]);
@@ -1874,12 +1884,12 @@ KREF_API size_t kref_zstd_fast_compress(u8* dst, size_t cap, const u8* src, size
     w.seqs = (kref_seq*)malloc(sizeof(kref_seq) * ((128 << 10) / 3 + 8)); w.lits = (u8*)malloc((128 << 10) + 32);
     memset(&ss, 0, sizeof(ss)); ss.seqs = w.seqs; ss.lits = w.lits; ss.strategy = 1;
     if (srcSize >= 7) {
-        lastLL = fast_block(&ss, rep, src, srcSize, w.hashLong, P[2], P[3]);
+        lastLL = fast_block_step(&ss, rep, src, srcSize, w.hashLong, P[2], P[3], kref_fast_step(level));
         memcpy(ss.lits + ss.litSize, src + srcSize - lastLL, lastLL); ss.litSize += lastLL;
         h0.valid = 0; memset(&h0.ct, 0, sizeof(h0.ct));
         {
             int const suspect = (ss.nbSeq == 0) || (ss.litSize / ss.nbSeq >= 20);
-            litC = compress_literals(body, cap - pos - 3, ss.lits, ss.litSize, suspect, &h0, &h1);
+            litC = (level < 0) ? lit_raw(body, cap - pos - 3, ss.lits, ss.litSize) : compress_literals(body, cap - pos - 3, ss.lits, ss.litSize, suspect, &h0, &h1);
             if (litC != KERR) {
                 seqC = compress_sequences(body + litC, cap - pos - 3 - litC, &ss);
                 if (seqC != KERR && seqC != 0) { cSize = litC + seqC; if (cSize >= srcSize - min_gain(srcSize)) cSize = 0; }

@@ -128,7 +128,7 @@ int emu_zstd_compress_level(const u8* src, const u64* in_off, const u32* in_len,
     g.m.src = src; g.m.in_off = in_off; g.m.in_len = in_len; g.m.n_slices = n;
     g.m.seqs = seqs.data(); g.m.seq_cap = seq_cap; g.m.lits = lits.data(); g.m.lit_cap = lit_cap; g.m.meta = meta.data();
     g.m.tables = tables.data(); g.m.team_epoch = epoch.data(); g.m.counter = &counter; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
-    g.level = (u32)level;
+    g.level = level < 0 ? 0u : (u32)level; g.step0 = level < 0 ? (u32)(1 - level) : 2u;     // negative levels: row 0, a step of 1 - level
     kxemu::failed = 0;
     switch (G) {
     case 2:  kxemu::launch(nblocks, [&]() { zstd_match_fast_body<2>(g); }); break;
@@ -143,7 +143,7 @@ int emu_zstd_compress_level(const u8* src, const u64* in_off, const u32* in_len,
     e.src = src; e.in_off = in_off; e.in_len = in_len; e.n_slices = n;
     e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
     e.scratch = scratch.data(); e.scratch_words = scratch_words;
-    e.dst = dst; e.out_off = out_off; e.out_len = out_len; e.flags = 8u | 32u;
+    e.dst = dst; e.out_off = out_off; e.out_len = out_len; e.flags = 8u | 32u | (level < 0 ? 64u : 0u);
     kxemu::launch(nblocks, [&]() { zstd_entropy_body(e); });
     return kxemu::failed ? -1 : 0;
 }

@@ -172,6 +172,12 @@ def level4_golden():
         return json.load(fh)
 
 
+def neg_levels_golden():
+    """libzstd 1.5.7 at negative levels (tests/golden/make_golden_neg_levels.py); sha256 cut to 32 hex digits."""
+    with open(os.path.join(os.path.dirname(GOLDEN_PATH), "zstd_neg_levels_golden.json")) as fh:
+        return json.load(fh)
+
+
 def levels_golden():
     with open(os.path.join(os.path.dirname(GOLDEN_PATH), "zstd_levels_golden.json")) as fh:
         return json.load(fh)
@@ -257,8 +263,8 @@ class Oracle:
         return o.raw[:n], bool(mode.value)
 
     def compress_level(self, d: bytes, level: int) -> bytes:
-        """Frame at level 1 or 2 (strategy "fast"), or 4 where it is the double-fast parse (16 KiB < size <= 128 KiB, and above
-        256 KiB ZSTD_compress2's frame)."""
+        """Frame at level 1 or 2 or at a negative level (strategy "fast"), or 4 where it is the double-fast parse (16 KiB < size <=
+        128 KiB, and above 256 KiB ZSTD_compress2's frame)."""
         k = self.lib
         if level == 4:
             k.kref_zstd_l4_compress.restype = ctypes.c_size_t

@@ -98,6 +98,24 @@ def test_emulated_level_4_matches_golden(monkeypatch, team):
         assert len(f) == flen and helpers.sha256(f) == sha, (S2, k, team)
 
 
+@pytest.mark.parametrize("level,team", [(-1, 4), (-3, 8), (-20, 4), (-1000, 16)])
+def test_emulated_negative_levels_match_golden(level, team):
+    """zstd_match_fast.h with a step of 1 - level on row 0 of libzstd's tables, the entropy stage with literals left raw: the frames
+    of libzstd 1.5.7 at negative levels on a part of the size ladder and on 64 KiB slices of every class."""
+    G = helpers.neg_levels_golden()
+    j = G["levels"].index(level)
+    rows = [r for r in G["ladder"] if r[1] in (0, 3, 6) and r[0] in (0, 1, 7, 8, 9, 64, 300, 1024, 4096, 16384, 16385, 40960, 65537, 131072)]
+    datas = [corpus.make(1000, 8, r[0])[r[1] * r[0]:(r[1] + 1) * r[0]].tobytes() if r[0] else b"" for r in rows]
+    frames = helpers.emu_compress_level(datas, level, G=team, nblocks=1)
+    for r, f in zip(rows, frames):
+        assert len(f) == r[2 + 2 * j] and helpers.sha256(f)[:32] == r[3 + 2 * j], (r[0], r[1], level)
+    S = 65536
+    buf = corpus.make(0, 16, S)
+    frames = helpers.emu_compress_level([buf[i * S:(i + 1) * S].tobytes() for i in range(16)], level, G=team, nblocks=1)
+    for r, f in zip(G["config1"][:16], frames):
+        assert len(f) == r[1 + 2 * j] and helpers.sha256(f)[:32] == r[2 + 2 * j], (r[0], level)
+
+
 def test_emulated_split_phase_parser_at_the_end_of_a_slice(monkeypatch):
     """Matches that run into the last bytes of a slice (the window's 16-byte looks must not count bytes they do not hold): every
     distance of a repeat's start from the end, several periods, against the oracle."""

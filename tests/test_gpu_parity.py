@@ -554,6 +554,43 @@ def test_levels_1_and_2(batch):
     assert f1 == o.compress_level(mix[3], 1) and ZstdDecompressor().transform_bytes(f1) == mix[3]
 
 
+def test_negative_levels(batch):
+    """ZstdCompressor(level < 0) (libzstd's "fast" strategy with a step of 1 - level and literals left uncompressed): the whole size
+    ladder in one ragged batch and 64 slices of the 64 KiB mix per level against libzstd 1.5.7, decoded back on the GPU; the host-batch
+    call and the streaming entry point take the level."""
+    from kompressor_amd import ZstdCompressor, ZstdDecompressor
+    from kompressor_amd.batch import compress_host_batch
+    G = helpers.neg_levels_golden()
+
+    def run(datas, level):
+        n = len(datas)
+        lens = np.array([len(d) for d in datas], dtype=np.int32)
+        offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.int64)]).astype(np.int64) if n > 1 else np.zeros(1, dtype=np.int64)
+        host = np.frombuffer(b"".join(datas) + bytes(64), dtype=np.uint8).copy()
+        dst, ooff, olen = batch.compress(torch.from_numpy(host).cuda(), torch.from_numpy(offs).cuda(), torch.from_numpy(lens).cuda(), level=level, check=True)
+        torch.cuda.synchronize()
+        hd, ho, hl = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+        return [hd[ho[i]:ho[i] + hl[i]].tobytes() for i in range(n)]
+
+    ladder = [corpus.make(1000, 8, r[0])[r[1] * r[0]:(r[1] + 1) * r[0]].tobytes() if r[0] else b"" for r in G["ladder"]]
+    S = 65536
+    buf = corpus.make(0, 64, S)
+    mix = [buf[i * S:(i + 1) * S].tobytes() for i in range(64)]
+    for j, lvl in enumerate(G["levels"]):
+        frames = run(ladder, lvl)
+        for row, f in zip(G["ladder"], frames):
+            assert len(f) == row[2 + 2 * j] and helpers.sha256(f)[:32] == row[3 + 2 * j], (row[0], row[1], lvl)
+        back, st = gpu_decompress(batch, frames, [max(len(d), 1) for d in ladder])
+        assert st == [0] * len(frames) and back == ladder
+        frames = run(mix, lvl)
+        for row, f in zip(G["config1"], frames):
+            assert len(f) == row[1 + 2 * j] and helpers.sha256(f)[:32] == row[2 + 2 * j], (row[0], lvl)
+    o = helpers.oracle()
+    assert compress_host_batch(mix[:8], level=-5) == [o.compress_level(d, -5) for d in mix[:8]]
+    f1 = ZstdCompressor(compression_level=-2).transform_bytes(mix[3])
+    assert f1 == o.compress_level(mix[3], -2) and ZstdDecompressor().transform_bytes(f1) == mix[3]
+
+
 def test_level_4_where_it_is_double_fast(batch, monkeypatch):
     """ZstdCompressor(level = 4) for slices above 16 KiB up to 128 KiB (libzstd runs that size class of level 4 as the double-fast
     parse with hash 17 / chain 17 / minimum match 4): the ragged sizes in one batch and 256 slices of the 64 KiB mix against

@@ -139,6 +139,26 @@ def test_oracle_level_4_double_fast_rows_match_golden():
     assert all(strategy[(size, 5)] >= 3 for size in (4096, 65536, 1 << 20))
 
 
+def test_oracle_negative_levels_match_golden():
+    """Negative levels: strategy "fast" on row 0 of libzstd's tables, a step of 1 - level, literals left uncompressed."""
+    o = helpers.oracle()
+    G = helpers.neg_levels_golden()
+    levels = G["levels"]
+    for row in G["ladder"]:
+        S, k = row[0], row[1]
+        d = corpus.make(1000, 8, S)[k * S:(k + 1) * S].tobytes() if S else b""
+        for j, lvl in enumerate(levels):
+            f = o.compress_level(d, lvl)
+            assert len(f) == row[2 + 2 * j] and helpers.sha256(f)[:32] == row[3 + 2 * j], (S, k, lvl)
+    S = 65536
+    buf = corpus.make(0, 64, S)
+    for row in G["config1"]:
+        d = buf[row[0] * S:(row[0] + 1) * S].tobytes()
+        for j, lvl in enumerate(levels):
+            f = o.compress_level(d, lvl)
+            assert len(f) == row[1 + 2 * j] and helpers.sha256(f)[:32] == row[2 + 2 * j], (row[0], lvl)
+
+
 def test_oracle_streaming_frames_match_golden():
     """finish = false ... finish = true (SliceTransformRawSource.kt:32-55): frames without content size, window 2^21,
     the input cut at multiples of 128 KiB before the pre-splitter sees it."""

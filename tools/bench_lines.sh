@@ -13,6 +13,8 @@ run --mode inflate --steps 3 --warmup 1 --no-cpu
 run --level 1 --steps 3 --warmup 1 --no-cpu
 run --level 2 --steps 3 --warmup 1 --no-cpu
 run --level 4 --steps 3 --warmup 1 --no-cpu
+run --level -1 --steps 3 --warmup 1 --no-cpu
+run --level -5 --steps 3 --warmup 1 --no-cpu
 run --dict-kib 16 --steps 3 --warmup 1 --no-cpu
 run --dict-kib 64 --slice-kib 8 --slices 262144 --steps 3 --warmup 1 --no-cpu
 run --slice-kib 128 --slices 32768 --steps 3 --warmup 1 --no-cpu

@@ -1,6 +1,6 @@
 """Differential fuzz on the GPU box: ragged slices of stress inputs (tools/fuzzgen.c: short-distance matches, repeated offsets,
 small alphabets, periodic data, abrupt regime changes) and of the corpus classes through every level-3 path (team width 4, the
-per-batch width 8, the split-phase parser, the fused kernel), levels 1, 2 and 4, and raw DEFLATE at levels 1, 6 and 9 -- EVERY frame compared with the binary
+per-batch width 8, the split-phase parser, the fused kernel), levels 1, 2, 4 and three negative ones, and raw DEFLATE at levels 1, 6 and 9 -- EVERY frame compared with the binary
 libzstd 1.5.7 (DEFLATE: with this machine's zlib) on the host cores (Pillow's copy: test infrastructure, looked up by oracle/libzstd_ref.py), and decoded back on
 the GPU.  usage: python tools/r03_fuzz.py [seed] [n_slices]"""
 import os, sys, ctypes, subprocess, time
@@ -85,6 +85,9 @@ for name, env, level, n_ctx, piece, idx in (
         ("level 3, fused kernel", {"KMP_FUSE": "1"}, 3, N, N, all_idx),
         ("level 1", {}, 1, N, N, all_idx),
         ("level 2", {}, 2, N, N, all_idx),
+        ("level -1", {}, -1, N, N, all_idx),
+        ("level -7", {}, -7, N, N, all_idx),
+        ("level -200", {}, -200, 8000, 8000, all_idx),
         ("level 4 (slices above 16 KiB)", {}, 4, N, N, big_idx),
         ("level 4, batches of 4 000 (team width 8)", {}, 4, 4000, 4000, big_idx)):
     t0 = time.time()
