@@ -292,7 +292,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--slice-class", default="", help="experiments: every slice of one corpus class (T X S B D I Z R) instead of the configuration's mix")
     ap.add_argument("--no-stream", action="store_true", help="N = 1: skip the figures of the streaming entry point (what a Kotlin caller binds)")
-    ap.add_argument("--level", type=int, default=3, help="zstd level: 3 (BASELINE configs), 1 / 2 (strategy fast), or 4 (its double-fast row: slices above 16 KiB up to 128 KiB)")
+    ap.add_argument("--level", type=int, default=3, help="zstd level: 3 (BASELINE configs), 1 / 2 (strategy fast), 4 (its double-fast row: slices above 16 KiB up to 128 KiB), or a negative level (slices up to 128 KiB)")
     ap.add_argument("--dict-kib", type=int, default=0,
                     help="compress with a raw-content dictionary of this many KiB shared by all slices (ZstdCompressor(3, dictionary))")
     ap.add_argument("--slice-kib", type=int, default=64,
@@ -710,9 +710,10 @@ def main():
         if args.level != 3:
             res["roofline"]["kernel"] = ("k_zstd_big_fast (one launch per step: every wave walks the block chains of its slices)" if SLICE > 128 * 1024
                                          else "k_zstd_match + k_zstd_entropy with level 4's double-fast row (tables of 1 MiB per team)" if args.level == 4
+                                         else "k_zstd_match_fast (a step of 1 - level) + k_zstd_entropy with the literals left raw" if args.level < 0
                                          else "k_zstd_match_fast + k_zstd_entropy (one launch each per step)")
             res["config"]["workload"] = f"{n} x {args.slice_kib} KiB seeded mixed slices per GPU, ZstdCompressor(level={args.level}), bit-identical to libzstd 1.5.7"
-            res["metric"] = f"zstd level-{args.level} compression throughput (uncompressed input bytes per second)"
+            res["metric"] = f"zstd level {args.level} compression throughput (uncompressed input bytes per second)"
         if not args.no_cpu and not dictionary and args.level == 3:
             sample = min(n, max(64, (1 << 29) // SLICE))
             res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()), sample)
