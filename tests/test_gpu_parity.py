@@ -554,6 +554,23 @@ def test_levels_1_and_2(batch):
     assert f1 == o.compress_level(mix[3], 1) and ZstdDecompressor().transform_bytes(f1) == mix[3]
 
 
+@pytest.mark.timeout(900)
+def test_differential_fuzz_against_the_live_library():
+    """tools/r03_fuzz.py / r03_fuzz_big.py at a small size (their long runs are in profiles/r03_fuzz.txt): ragged stress inputs and
+    corpus slices through every level-3 path, levels 1, 2, 4 and three negative ones, two dictionary sizes and three DEFLATE levels,
+    and frames of several blocks in seven forms -- every frame against the binary libzstd 1.5.7 / zlib of THIS machine.  Skipped
+    where no libzstd 1.5.7 is installed (the library is only ever the checker)."""
+    import os
+    import subprocess
+    import sys
+    if helpers.live_libzstd() is None:
+        pytest.skip("no libzstd 1.5.7 on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tool, args in (("r03_fuzz.py", ["7", "6000"]), ("r03_fuzz_big.py", ["7", "300"])):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", tool)] + args, capture_output=True, text=True, timeout=420)
+        assert r.returncode == 0 and "FUZZ OK" in r.stdout, (tool, r.stdout[-1500:], r.stderr[-1500:])
+
+
 def test_negative_levels(batch):
     """ZstdCompressor(level < 0) (libzstd's "fast" strategy with a step of 1 - level and literals left uncompressed): the whole size
     ladder in one ragged batch and 64 slices of the 64 KiB mix per level against libzstd 1.5.7, decoded back on the GPU; the host-batch
