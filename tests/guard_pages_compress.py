@@ -4,7 +4,8 @@ page (and starts right after one), the output buffer likewise with kmp_zstd_comp
 match / entropy (zstd levels 3, 1, 2) and DEFLATE kernel bodies run on the CPU wave emulator: a read past the end of a slice
 or a write past the output bound kills the process.  The frames are compared with the oracle / zlib on the way.
 
-    python tests/guard_pages_compress.py zstd | l1 | l2 | deflate [--quick]
+    python tests/guard_pages_compress.py zstd | l1 | l2 | neg | l4 | deflate [--quick]      (neg: level -3; l4: level 4, slices above 16 KiB;
+    KXEMU_FUSE=1 / KXEMU_MATCH_V2=1 in the environment: the fused kernel / the split-phase parser for `zstd`)
 """
 import ctypes
 import os
@@ -22,6 +23,8 @@ which = sys.argv[1]
 sizes = [1,2,3,5,7,8,9,15,16,17,31,33,63,64,65,100,255,256,1000,4095,4096,4097,9000,20000,65535,65536] + ([131071,131072] if which!='deflate' else [])
 if '--quick' in sys.argv:
     sizes = [1, 7, 8, 9, 17, 64, 255, 4097, 20000] + ([65536] if which == 'deflate' else [131072])
+if which == 'l4':
+    os.environ['KXEMU_LEVEL'] = '4'; sizes = [S for S in sizes if S > 16384] + [16385, 40000]
 for S in sizes:
     for mix in "TZRB":
         d = corpus.make(4000+S, 1, S, mix=ord(mix)).tobytes()
@@ -30,16 +33,16 @@ for S in sizes:
         stride = helpers.compress_bound(len(d)) + 1024
         gout = F.Guarded(stride, 0)
         ooff = np.array([gout.off], dtype=np.uint64); olen = np.zeros(1, dtype=np.uint32)
-        if which == 'zstd':
+        if which in ('zstd', 'l4'):
             fn = emu.emu_zstd_compress
             fn.argtypes = [ctypes.c_void_p]*3 + [ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32] + [ctypes.c_void_p]*3 + [ctypes.c_uint32]
             r = fn(g.base, helpers._vp(in_off), helpers._vp(in_len), 1, 8, 1, gout.base, helpers._vp(ooff), helpers._vp(olen), 131072)
             assert r == 0
-            f = gout.read(int(olen[0])); assert f == o.compress(d), (S, mix)
-        elif which in ('l1','l2'):
+            f = gout.read(int(olen[0])); assert f == (o.compress_level(d, 4) if which == 'l4' else o.compress(d)), (S, mix)
+        elif which in ('l1','l2','neg'):
             fn = emu.emu_zstd_compress_level
             fn.argtypes = [ctypes.c_void_p]*3 + [ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32] + [ctypes.c_void_p]*3 + [ctypes.c_uint32, ctypes.c_int]
-            lvl = 1 if which=='l1' else 2
+            lvl = 1 if which=='l1' else 2 if which=='l2' else -3
             r = fn(g.base, helpers._vp(in_off), helpers._vp(in_len), 1, 4, 1, gout.base, helpers._vp(ooff), helpers._vp(olen), 131072, lvl)
             assert r == 0
             f = gout.read(int(olen[0])); assert f == o.compress_level(d, lvl), (S, mix)

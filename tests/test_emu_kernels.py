@@ -443,17 +443,19 @@ def test_decoders_survive_mutated_input(which):
     assert r.returncode == 0 and ("FUZZ OK" in r.stdout or "FUZZ SKIP" in r.stdout), r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("which", ["zstd", "zstd-split-phase", "l1", "deflate"])
+@pytest.mark.parametrize("which", ["zstd", "zstd-split-phase", "zstd-fused", "l1", "neg", "l4", "deflate"])
 def test_compressors_stay_inside_their_buffers(which):
     """tests/guard_pages_compress.py --quick: slices that end exactly at an unmapped page, outputs bounded by
     kmp_zstd_compress_bound + 1024: the compressor kernel bodies read and write nothing outside (the split-phase parser
-    with its 16-byte looks at candidates and its window refills included)."""
+    with its 16-byte looks at candidates and its window refills included; the fused kernel; level -3; level 4)."""
     import os
     import subprocess
     import sys
     env = dict(os.environ)
     if which == "zstd-split-phase":
         which = "zstd"; env["KXEMU_MATCH_V2"] = "1"; env["KXEMU_RING"] = "512"
+    if which == "zstd-fused":
+        which = "zstd"; env["KXEMU_FUSE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "guard_pages_compress.py"), which, "--quick"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "GUARD OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
