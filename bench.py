@@ -201,7 +201,7 @@ def streaming_abi_figure(host, n_slices):
                     "one_context / contexts_64: ZstdCompressor(3).transform_bytes per slice = kmp_zstd_compress_stream under the reference's driver loop "
                     "(closing calls of concurrent contexts are coalesced into one device batch); host_batch_call: kmp_zstd_compress_host_batch "
                     "(includes joining the slices into one buffer in Python); host_batch_bulk: the same call over the whole batch in pageable host memory "
-                    "(pieces of 16 384 slices on three worker threads, each with its own pinned staging and device batch)"}
+                    "(pieces of 8 192 slices on four worker threads, each with its own pinned staging and device batch)"}
 
 
 def cpu_decode_baseline(frames_host, offs, lens, n_slices, sample=32768):

@@ -64,7 +64,7 @@ static host_engine* host_engine_get(int device, int slot = 0)
     e->device = device; e->batch = nullptr; e->st = nullptr;
     e->h_in = e->h_out = nullptr; e->h_off = e->h_doff = nullptr; e->h_len = e->h_cap = e->h_st = nullptr;
     e->d_in = e->d_out = e->d_dense = nullptr; e->d_off = e->d_ooff = e->d_doff = nullptr; e->d_len = e->d_olen = e->d_cap = e->d_st = nullptr;
-    e->cap_slices = slot == 0 ? env_u32("KMP_HOST_BATCH_SLICES", 1024) : env_u32("KMP_HOST_BULK_SLICES", 16384);
+    e->cap_slices = slot == 0 ? env_u32("KMP_HOST_BATCH_SLICES", 1024) : env_u32("KMP_HOST_BULK_SLICES", 8192);
     if (e->cap_slices < 16) e->cap_slices = 16; if (e->cap_slices > 65536) e->cap_slices = 65536;
     e->slice_cap = KMP_MAX_SLICE_BYTES;
     e->stride = (kmp_zstd_compress_bound(e->slice_cap) + 8 + 63) & ~(size_t)63;
@@ -170,12 +170,13 @@ extern "C" int kmp_zstd_compress_host_batch(int device, int level, const void* h
     host_engine* e0 = host_engine_get(device);
     if (!e0) return KMP_ERR_ARG;
     // A large batch goes through the bulk engines: pieces of KMP_HOST_BULK_SLICES slices handed to KMP_HOST_BULK_WORKERS
-    // (default 2, at most 4) threads, each with an engine of its own -- while one piece is on the device the next is being
+    // (default 4) threads, each with an engine of its own -- while one piece is on the device the next is being
     // packed into pinned memory and the last one's frames are being handed out, and the device has two pieces in flight.
     // (measured, 65 536 x 64 KiB from pageable host memory to frames in host memory: 1.5 GB/s through the 1 024-slice engine piece
-    // by piece, 5.7 with one bulk worker, 9.5 with two, 11.6 with three: tools/r03_hostbatch.py.  An engine that cannot be made --
-    // its pinned staging is 4.3 GiB -- is done without.)
-    u32 const workers_wanted = env_u32("KMP_HOST_BULK_WORKERS", 3);
+    // by piece, 5.7 with one bulk worker, 9.5 with two, 11.6 with three: tools/r03_hostbatch.py; pieces of 8 192 on four workers: 13.0
+    // against 10.8 for 16 384 on three, 12.6 for 8 192 on six, 9.4 for 4 096 on eight: tools/r03_bulk.sh -- the default.  An engine that
+    // cannot be made -- its pinned staging is 2.2 GiB -- is done without.)
+    u32 const workers_wanted = env_u32("KMP_HOST_BULK_WORKERS", 4);
     bool bulk = n > 2u * e0->cap_slices && workers_wanted >= 1;
     u32 workers = !bulk ? 1u : (workers_wanted > (u32)KMP_HOST_ENGINES - 1u ? (u32)KMP_HOST_ENGINES - 1u : workers_wanted);
     std::vector<host_engine*> eng(workers, e0);
@@ -220,7 +221,7 @@ extern "C" int kmp_zstd_decompress_host_batch(int device, const void* h_src, con
     host_engine* e0 = host_engine_get(device);
     if (!e0) return KMP_ERR_ARG;
     // (large batches: the bulk engines on worker threads, as on the compress side)
-    u32 const workers_wanted = env_u32("KMP_HOST_BULK_WORKERS", 3);
+    u32 const workers_wanted = env_u32("KMP_HOST_BULK_WORKERS", 4);
     bool bulk = n > 2u * e0->cap_slices && workers_wanted >= 1;
     u32 workers = !bulk ? 1u : (workers_wanted > (u32)KMP_HOST_ENGINES - 1u ? (u32)KMP_HOST_ENGINES - 1u : workers_wanted);
     std::vector<host_engine*> eng(workers, e0);
