@@ -204,7 +204,7 @@ KMP_API int kmp_zstd_compress_batch_reference(kmp_batch_ctx* ctx,
  * level 1 also as frames of several blocks for slices <= 512 KiB (context created with max_slice_bytes in
  * (128 KiB, 512 KiB]); 3 (or 0) = kmp_zstd_compress_batch.  Frames are the ones libzstd 1.5.7 writes at that level.
  * Negative levels (-131072 .. -1: libzstd's "fast" strategy on row 0 of its parameter tables, a step of 1 - level, literals
- * left uncompressed) are served for slices <= 128 KiB.
+ * left uncompressed) are served like level 1: one-block slices, and frames of several blocks / streams up to their 512 KiB window.
  * Level 4 is served where libzstd runs it as "double-fast" with one block: slices above 16 KiB up to 128 KiB (window <= 17,
  * chain 17, hash 17, minimum match 4; ZSTD_getCParams(4, n, 0)).  Its tables (1 MiB per team: 64 GiB beside a 65 536-slice context, less when the device has less room; KMP_L4_TEAMS caps it) are allocated by
  * the first level-4 batch of a context.  A slice of 16 KiB or less in a level-4 batch is refused like an oversized one

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64) void k_table_probe(u32* p0, u32* p1, u32* p2, u
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
-extern "C" const char* kmp_version(void) { return "kompressor_hip 0.3 (gfx950; zstd levels 1-3: frames and streams up to 1 GiB, raw-content dictionaries; level 4 for slices of 16 KiB - 128 KiB, negative levels for slices up to 128 KiB; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
+extern "C" const char* kmp_version(void) { return "kompressor_hip 0.3 (gfx950; zstd levels 1-3: frames and streams up to 1 GiB, raw-content dictionaries; level 4 for slices of 16 KiB - 128 KiB, negative levels up to 512 KiB; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
 
 // --------------------------------------------------------------------------
 // batch context
@@ -670,7 +670,7 @@ static int flat_tables(kmp_batch_ctx* c, u32** tables, u32** epochs)
 
 // ---- levels 1 and 2 -------------------------------------------------------------------------------------
 static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct = 0);
+                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct = 0, u32 fast_step0 = 0);
 static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream, int level);
 extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
@@ -685,11 +685,10 @@ extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
-    if (c->big && neg) { g_last_error = "kmp_zstd_compress_batch_level: negative levels are served for one-block slices (context max_slice_bytes <= 128 KiB)"; return KMP_ERR_CAPACITY; }
     if (c->big) {
-        // frames of several blocks: slices up to the level's window (512 KiB at level 1, 1 MiB at level 2)
-        if (c->max_slice_bytes > ((level == 1 ? 512u : 1024u) << 10)) { g_last_error = "kmp_zstd_compress_batch_level: above 128 KiB levels 1 and 2 are served for slices up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
-        return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st, 0, (u32)level);
+        // frames of several blocks: slices up to the level's window (512 KiB at level 1 and at the negative levels, 1 MiB at level 2)
+        if (c->max_slice_bytes > ((level == 2 ? 1024u : 512u) << 10)) { g_last_error = "kmp_zstd_compress_batch_level: above 128 KiB levels 1 and 2 are served for slices up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
+        return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st, 0, neg ? 1u : (u32)level, 0, neg ? (u32)(1 - level) : 0u);
     }
     KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
     HIP_TRY(hipMemsetAsync(c->counter, 0, 4 * KMP_MAX_CHUNKS, st));
@@ -803,7 +802,7 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
 // so the rounds are sequential and the host only reads back how many frames are still open.
 // stream: KFrameArgs.stream (0 ZSTD_compress2's frames, 1 / 2 streaming frames, 3 the reference's one-shot driver)
 static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct)
+                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct, u32 fast_step0)
 {
     bool const streaming = stream == 1 || stream == 2;
     const uint32_t* const d_in_len_caller = d_in_len;
@@ -827,6 +826,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     e.scratch = c->scratch; e.scratch_words = c->scratch_words;
     e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
     e.fstate = c->fstate; e.hufct = c->hufct; e.remaining = c->remaining; e.stream = stream; e.strategy = strategy ? 1u : 0u; e.level2 = level2; e.cls = 0;
+    e.fast_step0 = strategy == 1u ? fast_step0 : 0u;         // a negative level: the level-1 machinery (window 2^19) on row 0 of the tables, a step of 1 - level, raw literals
     e.tail_direct = stream == 3 ? 0u : tail_direct; e.out_chunk = stream == 3 ? tail_direct : 0u;      // (one parameter: the mode says which it is)
     e.status_word = c->d_status;
     if (strategy || c->knob.big_rounds == 0) {
@@ -922,14 +922,15 @@ extern "C" int kmp_zstd_compress_batch_stream_level(kmp_batch_ctx* c, const void
                                                     uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int empty_end, int level, void* hip_stream)
 {
     if (level == 0) level = 3;
-    if (level < 1 || level > 3) { g_last_error = "kmp_zstd_compress_batch_stream_level: levels 1, 2 and 3 are served"; return KMP_ERR_ARG; }
-    if (c && level != 3 && c->max_slice_bytes > ((level == 1 ? 512u : 1024u) << 10)) { g_last_error = "kmp_zstd_compress_batch_stream_level: level 1 / 2 streams up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
+    bool const neg = level < 0;
+    if ((level < 1 && !neg) || level > 3 || level < -131072) { g_last_error = "kmp_zstd_compress_batch_stream_level: levels -131072 .. -1, 1, 2 and 3 are served"; return KMP_ERR_ARG; }
+    if (c && level != 3 && c->max_slice_bytes > ((level == 2 ? 1024u : 512u) << 10)) { g_last_error = "kmp_zstd_compress_batch_stream_level: level 1 / 2 streams up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_stream: null argument"; return KMP_ERR_ARG; }
     if (!c->big) { g_last_error = "kmp_zstd_compress_batch_stream: the context must be created with max_slice_bytes above 128 KiB"; return KMP_ERR_CAPACITY; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_stream: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, empty_end ? 2u : 1u, level == 3 ? 0u : (u32)level);
+    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, empty_end ? 2u : 1u, level == 3 ? 0u : neg ? 1u : (u32)level, 0, neg ? (u32)(1 - level) : 0u);
 }
 /* What ZstdCompressor(level).transform(ByteArray) returns: above 128 KiB libzstd stages the input in chunks of 128 KiB
  * because the reference's output slices are smaller than ZSTD_compressBound (include/kompressor_hip.h). */
@@ -939,13 +940,14 @@ extern "C" int kmp_zstd_compress_batch_reference(kmp_batch_ctx* c, const void* d
     if (level == 0) level = 3;
     if (!c) { g_last_error = "kmp_zstd_compress_batch_reference: null argument"; return KMP_ERR_ARG; }
     if (!c->big) return kmp_zstd_compress_batch_level(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, level, hip_stream);   // one block: one chunk
-    if (level < 1 || level > 3) { g_last_error = "kmp_zstd_compress_batch_reference: levels 1, 2 and 3 are served"; return KMP_ERR_ARG; }
-    if (level != 3 && c->max_slice_bytes > ((level == 1 ? 512u : 1024u) << 10)) { g_last_error = "kmp_zstd_compress_batch_reference: levels 1 / 2 up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
+    bool const neg = level < 0;
+    if ((level < 1 && !neg) || level > 3 || level < -131072) { g_last_error = "kmp_zstd_compress_batch_reference: levels -131072 .. -1, 1, 2 and 3 are served"; return KMP_ERR_ARG; }
+    if (level != 3 && c->max_slice_bytes > ((level == 2 ? 1024u : 512u) << 10)) { g_last_error = "kmp_zstd_compress_batch_reference: levels 1 / 2 up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
     if (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len)) { g_last_error = "kmp_zstd_compress_batch_reference: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_reference: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, 3u, level == 3 ? 0u : (u32)level, out_chunk);
+    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, 3u, level == 3 ? 0u : neg ? 1u : (u32)level, out_chunk, neg ? (u32)(1 - level) : 0u);
 }
 /* block rounds of the last batch of a context for slices above 128 KiB */
 extern "C" int kmp_batch_last_rounds(kmp_batch_ctx* c) { return c ? (int)c->last_rounds : 0; }
@@ -1585,7 +1587,7 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
     if (streaming && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
     // level 4: what arrives in one closing call, above 16 KiB up to 128 KiB (libzstd's double-fast row of that level); the rest: CPU library
     if (c->level == 4 && (streaming || !c->dict.empty() || n <= 16384u || n > KMP_MAX_SLICE_BYTES)) return KERRC(ZE_parameter_unsupported);
-    if (c->level < 0 && (streaming || !c->dict.empty() || n > KMP_MAX_SLICE_BYTES)) return KERRC(ZE_parameter_unsupported);
+    if (c->level < 0 && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
     // the plain case -- level 3, no dictionary, the whole slice at once, one block -- joins whatever other contexts are
     // closing right now: one batch for all of them (kmp_coalesce.h); the frame is the one this context would get alone
     if (!streaming && c->level == 3 && c->dict.empty() && n <= KMP_MAX_SLICE_BYTES && coalesce_enabled()) {
@@ -1595,8 +1597,8 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
         if (rc == KMP_OK) return 0;
         (void)hipGetLastError();                    // fall through: compress alone
     }
-    bool const l1big = c->level != 3 && (streaming || n > KMP_MAX_SLICE_BYTES);      // level 1 / 2, frame of several blocks / stream
-    u32 const lwin = (c->level == 1 ? 512u : 1024u) << 10;                             // their windows
+    bool const l1big = c->level != 3 && c->level != 4 && (streaming || n > KMP_MAX_SLICE_BYTES);      // level 1 / 2 / negative, frame of several blocks / stream
+    u32 const lwin = (c->level == 2 ? 1024u : 512u) << 10;                             // their windows (the negative levels: level 1's)
     if (l1big && n > lwin) return KERRC(ZE_parameter_unsupported);                     // beyond the window: CPU library
     if (!stream_dev_select(c->dev)) return KERRC(ZE_GENERIC);
     { size_t const e = stream_dev_init(c->dev, streaming && n <= KMP_MAX_SLICE_BYTES ? KMP_MAX_SLICE_BYTES + 1 : n, l1big ? lwin : 0u); if (e) return e; }

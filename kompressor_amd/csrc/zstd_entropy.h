@@ -1069,6 +1069,7 @@ struct KFrameArgs {
     u32* remaining;                          // frames not finished yet (decremented here)
     u32 strategy;                            // 0: double-fast (level 3; level 2's 128 .. 256 KiB row); 1: fast (levels 1, 2): other pre-splitter, other encoding-type constant
     u32 level2;                              // 1: level 2's parameters (window 2^20 / 2^18 instead of 2^19 / level 3's)
+    u32 fast_step0 = 0;                      // strategy 1 only: 0 = level 1 / 2; else a negative level: row 0 of libzstd's tables, a step of 1 - level, literals left raw
     u32 cls;                                 // which slices this launch takes (kx_in_class): a level-2 batch goes through both kernels
     u32 stream;                              // 0: one-shot frames as ZSTD_compress2 writes them into a bound-sized buffer (size known, the
                                              // caller's array compressed in place); 1: streaming frames (finish = false ... finish = true:
@@ -1226,7 +1227,7 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
         kx_wave_copy(lits + mm.litSize, bsrc + (bs - mm.lastLL), mm.lastLL, lane);
         kx_sync();
         bool const suspect = (mm.nbSeq == 0) || (litSize / mm.nbSeq >= 20);
-        u32 const litSec = kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane, &hp);
+        u32 const litSec = kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane, &hp, a.fast_step0 != 0);
         kx_sync();
         u32 const seqSec = kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < bs ? bs - litSec : 0u, a.strategy ? 32u : 0u);
         if (seqSec != 0) {
@@ -1320,7 +1321,7 @@ KX_DEV void zstd_big_body(const KBigArgs& a)
             if (!open) break;
             if (lane == 0) *m.counter = 0;
             kx_sync();
-            if (FAST) { KFastArgs fa; fa.m = m; fa.level = a.e.level2 ? 2u : 1u; zstd_match_fast_body<G, true>(fa); }
+            if (FAST) { KFastArgs fa; fa.m = m; fa.level = a.e.fast_step0 ? 0u : a.e.level2 ? 2u : 1u; if (a.e.fast_step0) fa.step0 = a.e.fast_step0; zstd_match_fast_body<G, true>(fa); }
             else {
                 zstd_match_body<G, true>(m);
                 // blocks behind a wrap of libzstd's staging buffer: the extDict variant of the parse

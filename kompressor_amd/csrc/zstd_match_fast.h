@@ -82,7 +82,7 @@ KX_DEV void zstd_match_fast_body(const KFastArgs& f)
                         seqs = a.seqs + (size_t)s * a.seq_cap;
                         H = a.big_tables + (size_t)s * KX_BIG_TBL_ENTRIES;
                         kx_params_fast(f.level, a.in_len[s], hlog, mls);
-                        if (a.flags & 8u) { hlog = f.level == 2 ? 16 : 14; mls = f.level == 2 ? 6 : 7; }      // size unknown: level 1 window 19, hash 14, minMatch 7; level 2 window 20, hash 16, minMatch 6
+                        if (a.flags & 8u) { hlog = f.level == 2 ? 16 : f.level == 0 ? 13 : 14; mls = f.level == 1 ? 7 : 6; }      // size unknown: level 1 window 19, hash 14, minMatch 7; level 2 window 20, hash 16, minMatch 6; negative levels window 19, hash 13, minMatch 6
                         nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = 0; tag = 0;
                         bstart = (int)fs.ipos; n = bstart + (int)fs.blockSize;   // n = end of the block
                         anchor = bstart; ilimit = n - 8;

@@ -2112,7 +2112,7 @@ static size_t split_block_from_borders(const u8* p)          /* block of exactly
 }
 
 /* fast_block for a block inside a larger input (tables and repcodes carried) */
-static size_t fast_block_at(seqstore* ss, u32 rep[3], const u8* input, size_t blockStart, size_t srcSize, u32* hashTable, u32 hlog, u32 mls);
+static size_t fast_block_at(seqstore* ss, u32 rep[3], const u8* input, size_t blockStart, size_t srcSize, u32* hashTable, u32 hlog, u32 mls, size_t stepSize);
 
 KREF_API size_t kref_zstd_fast_compress_big(u8* dst, size_t cap, const u8* src, size_t srcSize, int level, int stream, int emptyEnd)
 {
@@ -2122,14 +2122,14 @@ KREF_API size_t kref_zstd_fast_compress_big(u8* dst, size_t cap, const u8* src, 
     u32 P[4]; kref_wksp w; seqstore ss; kref_frame_state fs; kref_hufstate nextHuf;
     size_t pos, ipos = 0, hdr; int64_t savings = 0; size_t const blockSizeMax = 128 << 10;
     int const chunked = stream != 0, unknown = stream == 1 || stream == 2;
-    if (level != 1 && level != 2) return KERR;
+    if ((level != 1 && level != 2 && level >= 0) || level < -131072) return KERR;      /* negative levels: row 0 of the tables, a step of 1 - level, raw literals */
     if (level == 2 && !unknown && srcSize > 131072 && srcSize <= 262144) {
         /* level 2's row for this size class is a double-fast one: window 18, chain 14, hash 14, minMatch 5 */
         u32 const Pd[4] = { 18, 14, 14, 5 };
         if (stream == 3) return dfast_compress_buffered(dst, cap, src, srcSize, 1, 0, srcSize / 10 > 8192 ? srcSize / 10 : 8192, 0, Pd);
         return compress_blocks_dfast(dst, cap, src, srcSize, NULL, NULL, Pd);
     }
-    if (unknown) { P[0] = (level == 1) ? 19 : 20; P[2] = (level == 1) ? 14 : 16; P[3] = (level == 1) ? 7 : 6; }
+    if (unknown) { P[0] = (level == 2) ? 20 : 19; P[2] = (level == 1) ? 14 : (level == 2) ? 16 : 13; P[3] = (level == 1) ? 7 : 6; }
     else kref_params_fast(level, srcSize, P);
     if (srcSize > ((size_t)1 << P[0])) return KERR;                  /* the window would slide */
     if (cap < kref_compress_bound(srcSize) + 16) return KERR;
@@ -2154,11 +2154,12 @@ KREF_API size_t kref_zstd_fast_compress_big(u8* dst, size_t cap, const u8* src, 
             memset(&ss, 0, sizeof(ss)); ss.seqs = w.seqs; ss.lits = w.lits; ss.strategy = 1;
             if (blockSize >= 7) {
                 memcpy(rep, fs.rep, sizeof(rep));
-                lastLL = fast_block_at(&ss, rep, src, ipos, blockSize, w.hashLong, P[2], P[3]);
+                lastLL = fast_block_at(&ss, rep, src, ipos, blockSize, w.hashLong, P[2], P[3], kref_fast_step(level));
                 memcpy(ss.lits + ss.litSize, bsrc + blockSize - lastLL, lastLL); ss.litSize += lastLL;
                 {
                     int const suspect = (ss.nbSeq == 0) || (ss.litSize / ss.nbSeq >= 20);
-                    litC = compress_literals(body, cap - pos - 3, ss.lits, ss.litSize, suspect, &fs.huf, &nextHuf);
+                    if (level < 0) { nextHuf = fs.huf; litC = lit_raw(body, cap - pos - 3, ss.lits, ss.litSize); }
+                    else litC = compress_literals(body, cap - pos - 3, ss.lits, ss.litSize, suspect, &fs.huf, &nextHuf);
                     if (litC != KERR) {
                         seqC = compress_sequences(body + litC, cap - pos - 3 - litC, &ss);
                         if (seqC != KERR && seqC != 0) { cSize = litC + seqC; if (cSize >= blockSize - min_gain(blockSize)) cSize = 0; }
@@ -2182,7 +2183,7 @@ KREF_API size_t kref_zstd_fast_compress_big(u8* dst, size_t cap, const u8* src, 
     if (emptyEnd) { wr24(dst + pos, 1); pos += 3; }
     return pos;
 }
-static size_t fast_block_at(seqstore* ss, u32 rep[3], const u8* input, size_t blockStart, size_t srcSize, u32* hashTable, u32 hlog, u32 mls)
+static size_t fast_block_at(seqstore* ss, u32 rep[3], const u8* input, size_t blockStart, size_t srcSize, u32* hashTable, u32 hlog, u32 mls, size_t stepSize)
 {
     const u8* const base = input - IDX0;
     const u8* const src = input + blockStart;
@@ -2195,7 +2196,7 @@ static size_t fast_block_at(seqstore* ss, u32 rep[3], const u8* input, size_t bl
     u32 current0 = 0;
     u32 rep_offset1 = rep[0], rep_offset2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0;
     size_t hash0, hash1; u32 matchIdx; u32 offcode; const u8* match0; size_t mLength;
-    size_t const stepSize = 2; size_t step; const u8* nextStep; size_t const kStepIncr = 1 << 7;
+    size_t step; const u8* nextStep; size_t const kStepIncr = 1 << 7;
 
     if (srcSize < 8) return srcSize;   /* (libzstd runs into _cleanup at once: repcodes unchanged) */
     ip0 += (ip0 == prefixStart);

@@ -213,7 +213,8 @@ extern "C" __attribute__((visibility("default")))
 int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
                               u8* dst, const u64* out_off, u32* out_len, u32* rounds_out, u32 stream_and_strategy, u32 tail_or_chunk, u32 wide)
 {
-    u32 const stream = stream_and_strategy & 0xFFu, strategy = stream_and_strategy >> 8;     // strategy 1: level 1 (fast); 2: level 2 (as zstd_compress_big in kmp_api.hip)
+    u32 const stream = stream_and_strategy & 0xFFu, strategy = (stream_and_strategy >> 8) & 0xFFu;     // strategy 1: level 1 (fast); 2: level 2 (as zstd_compress_big in kmp_api.hip)
+    u32 const fast_step0 = strategy == 1u ? stream_and_strategy >> 16 : 0u;                               // bits 16 ..: a negative level's step (1 - level), with strategy 1
     u32 const level2 = strategy == 2u ? 1u : 0u;
     bool const streaming = stream == 1 || stream == 2;
     u32 const block_cap = 128u * 1024u;
@@ -244,7 +245,7 @@ int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_le
     e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
     e.scratch = scratch.data(); e.scratch_words = scratch_words;
     e.dst = dst; e.out_off = out_off; e.out_len = out_len;
-    e.fstate = fstate.data(); e.hufct = hufct.data(); e.remaining = &remaining; e.stream = stream; e.strategy = strategy ? 1u : 0u; e.level2 = level2; e.cls = 0;
+    e.fstate = fstate.data(); e.hufct = hufct.data(); e.remaining = &remaining; e.stream = stream; e.strategy = strategy ? 1u : 0u; e.level2 = level2; e.cls = 0; e.fast_step0 = fast_step0;
     e.tail_direct = stream == 3 ? 0u : tail_or_chunk; e.out_chunk = stream == 3 ? tail_or_chunk : 0u;
     if (strategy && rounds_out) return -6;
     if (!rounds_out) {

@@ -533,7 +533,7 @@ def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False, stream=0, level=3,
     olen = np.zeros(n, dtype=np.uint32)
     rounds = ctypes.c_uint32(0)
     r = emu().emu_zstd_compress_big_ex2(_vp(buf), _vp(offs), _vp(lens), n, G, nblocks, _vp(out), _vp(ooff), _vp(olen),
-                                        ctypes.byref(rounds) if by_rounds else None, stream | ((level if level in (1, 2) else 0) << 8),
+                                        ctypes.byref(rounds) if by_rounds else None, stream | ((level if level in (1, 2) else 1 if level < 0 else 0) << 8) | (((1 - level) << 16) if level < 0 else 0),
                                         tail_or_chunk, 1 if wide else 0)
     assert r == 0, f"emulator reported {r}"
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)], rounds.value

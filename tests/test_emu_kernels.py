@@ -98,6 +98,21 @@ def test_emulated_level_4_matches_golden(monkeypatch, team):
         assert len(f) == flen and helpers.sha256(f) == sha, (S2, k, team)
 
 
+def test_emulated_negative_levels_above_128_kib():
+    """Negative levels on the block-chain path (the level-1 machinery with row 0 of libzstd's tables, a step of 1 - level, literals
+    left raw): ZSTD_compress2's frames, the frames the reference's driver gets and streamed ones, against the oracle (pinned on
+    libzstd 1.5.7 for these: 324 frames of three levels while developing, and the fuzz legs on the GPU box)."""
+    o = helpers.oracle()
+    datas = []
+    for S in (131073, 262145, 400000):
+        buf = corpus.make(60, 2, S)
+        datas += [buf[k * S:(k + 1) * S].tobytes() for k in range(2)]
+    for lvl, mode in ((-1, 0), (-6, 3), (-2, 1)):
+        frames, _ = helpers.emu_compress_big(datas, G=8, nblocks=2, stream=mode, level=lvl)
+        for d, f in zip(datas, frames):
+            assert f == o.compress_level_big(d, lvl, stream=mode), (lvl, len(d), mode)
+
+
 @pytest.mark.parametrize("level,team", [(-1, 4), (-3, 8), (-20, 4), (-1000, 16)])
 def test_emulated_negative_levels_match_golden(level, team):
     """zstd_match_fast.h with a step of 1 - level on row 0 of libzstd's tables, the entropy stage with literals left raw: the frames

@@ -606,6 +606,10 @@ def test_negative_levels(batch):
     assert compress_host_batch(mix[:8], level=-5) == [o.compress_level(d, -5) for d in mix[:8]]
     f1 = ZstdCompressor(compression_level=-2).transform_bytes(mix[3])
     assert f1 == o.compress_level(mix[3], -2) and ZstdDecompressor().transform_bytes(f1) == mix[3]
+    # above 128 KiB (up to the 512 KiB window of these levels): the frame the reference's driver gets, through the streaming entry point
+    big = corpus.make(77, 1, 300000).tobytes()
+    f2 = ZstdCompressor(compression_level=-3).transform_bytes(big)
+    assert f2 == o.compress_level_big(big, -3, stream=3) and ZstdDecompressor().transform_bytes(f2) == big
 
 
 def test_level_4_where_it_is_double_fast(batch, monkeypatch):

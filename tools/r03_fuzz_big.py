@@ -1,6 +1,6 @@
 """Differential fuzz of the block-chain path (frames of several blocks, slices of 128 KiB + 1 .. 1.5 MiB): stress inputs
 (tools/fuzzgen.c) and corpus classes; the frames the reference's one-shot driver gets (output slices of max(8192, n / 10) bytes:
-libzstd stages the input in 128 KiB chunks), ZSTD_compress2's frames, and level 1 (up to its 512 KiB window) -- every frame against
+libzstd stages the input in 128 KiB chunks), ZSTD_compress2's frames, level 1 and three negative levels (up to their 512 KiB window) -- every frame against
 the binary libzstd 1.5.7 on the host cores, every frame decoded back on the GPU.  usage: python tools/r03_fuzz_big.py [seed] [n]"""
 import os, sys, ctypes, subprocess, time
 from concurrent.futures import ThreadPoolExecutor
@@ -74,7 +74,10 @@ for name, level, reference, idx, fn, streaming in (
         ("level 3, the reference driver's frames (input staged in 128 KiB chunks)", 3, True, all_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), 3), None),
         ("level 3, ZSTD_compress2's frames", 3, False, all_idx, lambda d: one_shot(d, 3), None),
         ("level 1 up to 512 KiB, the reference driver's frames", 1, True, l1_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), 1), None),
-        ("level 1 up to 512 KiB, ZSTD_compress2's frames", 1, False, l1_idx, lambda d: one_shot(d, 1), None)):
+        ("level 1 up to 512 KiB, ZSTD_compress2's frames", 1, False, l1_idx, lambda d: one_shot(d, 1), None),
+        ("level -1 up to 512 KiB, the reference driver's frames", -1, True, l1_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), -1), None),
+        ("level -5 up to 512 KiB, ZSTD_compress2's frames", -5, False, l1_idx, lambda d: one_shot(d, -5), None),
+        ("level -3 up to 512 KiB, streamed, the closing call brings data", -3, False, l1_idx, lambda d: streamed(d, -3, False), "data")):
     t0 = time.time()
     g = gpu_frames(level, reference, idx, MAXL if level == 3 else 524288, streaming)
     r = ref_frames(fn, idx)
