@@ -137,7 +137,7 @@ typedef struct kmp_batch_ctx kmp_batch_ctx;
  * slice gets d_out_len[i] = 0 (a frame or stream is never empty) and the context's status word collects these bits. */
 #define KMP_STATUS_SLICE_TOO_LARGE 1u   /* a d_in_len[i] above the context's max_slice_bytes (DEFLATE: above 64 KiB) */
 #define KMP_STATUS_KERNEL_GUARD    2u   /* a parser's loop guard tripped (never expected) */
-#define KMP_STATUS_LEVEL_SIZE      4u   /* zstd level 4: a slice of 16 KiB or less (that size class of level 4 is strategy "greedy", not served): out_len 0 */
+#define KMP_STATUS_LEVEL_SIZE      4u   /* zstd level 4: a slice of 16 KiB or less or of 128 - 256 KiB (those size classes of level 4 are strategy "greedy", not served): out_len 0 */
 
 #define KMP_MAX_SLICE_BYTES (128u * 1024u)        /* one block per frame: the batched fast path */
 #define KMP_MAX_BIG_SLICE_BYTES (1u << 30)       /* frames of several blocks (context created with max_slice_bytes above
@@ -205,10 +205,11 @@ KMP_API int kmp_zstd_compress_batch_reference(kmp_batch_ctx* ctx,
  * (128 KiB, 512 KiB]); 3 (or 0) = kmp_zstd_compress_batch.  Frames are the ones libzstd 1.5.7 writes at that level.
  * Negative levels (-131072 .. -1: libzstd's "fast" strategy on row 0 of its parameter tables, a step of 1 - level, literals
  * left uncompressed) are served like level 1: one-block slices, and frames of several blocks / streams up to their 512 KiB window.
- * Level 4 is served where libzstd runs it as "double-fast" with one block: slices above 16 KiB up to 128 KiB (window <= 17,
- * chain 17, hash 17, minimum match 4; ZSTD_getCParams(4, n, 0)).  Its tables (1 MiB per team: 64 GiB beside a 65 536-slice context, less when the device has less room; KMP_L4_TEAMS caps it) are allocated by
- * the first level-4 batch of a context.  A slice of 16 KiB or less in a level-4 batch is refused like an oversized one
- * (out_len 0, KMP_STATUS_LEVEL_SIZE): that size class of level 4 is strategy "greedy", as are levels 5 and up -- not served. */
+ * Level 4 is served where libzstd runs it as "double-fast": slices above 16 KiB up to 128 KiB (window <= 17, chain 17, hash 17,
+ * minimum match 4; ZSTD_getCParams(4, n, 0)), slices above 256 KiB (window <= 21, chain 18, hash 18, minimum match 5: contexts created
+ * for slices above 128 KiB, per-slice tables of 2 MiB allocated by the first such batch) and streams of any size (kmp_zstd_compress_batch_stream_level).  Its tables (1 MiB per team: 64 GiB beside a 65 536-slice context, less when the device has less room; KMP_L4_TEAMS caps it) are allocated by
+ * the first level-4 batch of a context.  A slice of 16 KiB or less, or of more than 128 KiB up to 256 KiB, in a level-4 batch is refused
+ * like an oversized one (out_len 0, KMP_STATUS_LEVEL_SIZE): those size classes of level 4 are strategy "greedy", as are levels 5 and up -- not served. */
 KMP_API int kmp_zstd_compress_batch_level(kmp_batch_ctx* ctx,
                                           const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                           uint32_t n,

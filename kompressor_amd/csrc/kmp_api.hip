@@ -58,11 +58,18 @@ template <int G>
 __global__ __launch_bounds__(64, 3) void k_zstd_big_fast(KBigArgs a) { zstd_big_body<G, true>(a); }
 // first block size, repcodes {1,4,8}, no Huffman table, a fresh window; an empty slice is a header and an empty raw block
 // chunked: the input is taken in chunks of 128 KiB (KFrameArgs.stream != 0); wd: window descriptor byte of a streaming frame, 0 = one-shot
-__global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 n, KFrameState* fs, u8* dst, const u64* out_off, u32* out_len, u32* remaining, u32 wd, u32 chunked)
+// level4: slices of the size classes level 4 runs as "greedy" (up to 16 KiB, 128 - 256 KiB; sizes known) are refused: out_len 0, status bit
+__global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 n, KFrameState* fs, u8* dst, const u64* out_off, u32* out_len, u32* remaining, u32 wd, u32 chunked, u32 level4 = 0, u32* status = nullptr)
 {
     u32 const i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     KFrameState s; u32 const len = in_len[i];
+    if (level4 && !wd && !kx_l4_served(len)) {
+        s.ipos = 0; s.opos = 0; s.blockSize = 0; s.first = 1; s.rep[0] = 1; s.rep[1] = 4; s.rep[2] = 8; s.hufValid = 0; s.hufSel = 0; s.savings = 0;
+        s.lowLimit = 2; s.dictLimit = 2; s.bufPos = 0; s.extBase = 0; s.wflags = 0; s.chunkEnd = 0;
+        fs[i] = s; out_len[i] = 0; if (status) atomicOr(status, (u32)KMP_STATUS_LEVEL_SIZE);
+        return;
+    }
     s.ipos = 0; s.opos = 0; s.blockSize = len < KX_BLOCK_MAX ? len : KX_BLOCK_MAX; s.first = 1;
     s.rep[0] = 1; s.rep[1] = 4; s.rep[2] = 8; s.hufValid = 0; s.hufSel = 0; s.savings = 0;
     s.lowLimit = 2; s.dictLimit = 2; s.bufPos = 0; s.extBase = 0; s.wflags = 0;
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(64) void k_table_probe(u32* p0, u32* p1, u32* p2, u
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
-extern "C" const char* kmp_version(void) { return "kompressor_hip 0.3 (gfx950; zstd levels 1-3: frames and streams up to 1 GiB, raw-content dictionaries; level 4 for slices of 16 KiB - 128 KiB, negative levels up to 512 KiB; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
+extern "C" const char* kmp_version(void) { return "kompressor_hip 0.3 (gfx950; zstd levels 1-3: frames and streams up to 1 GiB, raw-content dictionaries; level 4 in its double-fast size classes, negative levels up to 512 KiB; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
 
 // --------------------------------------------------------------------------
 // batch context
@@ -234,6 +241,7 @@ struct kmp_batch_ctx {
     u32* tables_flat; u32* team_epoch_flat;     // levels 1 / 2 and the dictionary parser: one piece (they wait for latency and are slower over spread tables), allocated on first use when the level-3 tables are spread
     u32* tseg[4]; u32 tseg_n;                   // the team tables in four pieces spread over the context's arena (or tseg_n == 1: tables alone)
     u32* tables4 = nullptr; u32* epoch4 = nullptr; u32 teams4 = 0;      // level 4's table set (1 MiB per team), allocated by the first level-4 batch
+    u32* big_tables4 = nullptr;                 // ... and on the block-chain path: 2 MiB per slice (2^18 + 2^18 entries)
     u32 table_layout;                           // which of the arena's layouts holds the table pieces (1 .. 8; 0: no arena)
     u8* arena; size_t arena_bytes;              // one allocation that holds seqs / lits / meta / scratch and the table pieces (else null: separate allocations)
     float place_ms; u32 place_tried;            // the team tables' placement: probe time of the region kept, candidates tried
@@ -546,7 +554,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     if (c->arena) (void)hipFree(c->arena);                                        // (holds seqs, lits, meta, scratch and the table pieces)
     else { (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch); (void)hipFree(c->tables); }
     (void)hipFree(c->tables_flat); (void)hipFree(c->team_epoch_flat);
-    (void)hipFree(c->team_epoch); (void)hipFree(c->tables4); (void)hipFree(c->epoch4);
+    (void)hipFree(c->team_epoch); (void)hipFree(c->tables4); (void)hipFree(c->epoch4); (void)hipFree(c->big_tables4);
     (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS);
     (void)hipFree(c->fstate); (void)hipFree(c->hufct); (void)hipFree(c->big_tables); (void)hipFree(c->remaining); (void)hipFree(c->big_counters); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -670,7 +678,7 @@ static int flat_tables(kmp_batch_ctx* c, u32** tables, u32** epochs)
 
 // ---- levels 1 and 2 -------------------------------------------------------------------------------------
 static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct = 0, u32 fast_step0 = 0);
+                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct = 0, u32 fast_step0 = 0, bool level4 = false);
 static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream, int level);
 extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
@@ -802,17 +810,25 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
 // so the rounds are sequential and the host only reads back how many frames are still open.
 // stream: KFrameArgs.stream (0 ZSTD_compress2's frames, 1 / 2 streaming frames, 3 the reference's one-shot driver)
 static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct, u32 fast_step0)
+                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct, u32 fast_step0, bool level4)
 {
     bool const streaming = stream == 1 || stream == 2;
     const uint32_t* const d_in_len_caller = d_in_len;
     KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
     d_in_len = c->len_ok;
+    if (level4) {
+        // level 4's double-fast rows on this path (16 - 128 KiB: hash 17 / chain 17; above 256 KiB and streams: 18 / 18): per-slice tables of
+        // 2 MiB, allocated by the first such batch of the context
+        if (!c->big_tables4 && hipMalloc((void**)&c->big_tables4, (size_t)c->max_slices * KX_BIG4_ENTRIES * sizeof(u32)) != hipSuccess) {
+            (void)hipGetLastError(); c->big_tables4 = nullptr; g_last_error = "kmp_zstd_compress_batch_level: no memory for level 4's tables"; return KMP_ERR_HIP;
+        }
+        HIP_TRY(hipMemsetAsync(c->big_tables4, 0, (size_t)n * KX_BIG4_ENTRIES * sizeof(u32), st));
+    } else
     HIP_TRY(hipMemsetAsync(c->big_tables, 0, (size_t)n * KX_BIG_TBL_ENTRIES * sizeof(u32), st));
     HIP_TRY(hipMemsetAsync(c->remaining, 0, 4, st));
     // strategy: 0 level 3 (double-fast), 1 level 1 (fast), 2 level 2 (fast, but double-fast for 128 KiB < size <= 256 KiB when the size is known)
     u32 const level2 = strategy == 2u ? 1u : 0u;
-    hipLaunchKernelGGL(k_zstd_frame_init, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, c->fstate, (u8*)d_dst, d_out_off, d_out_len, c->remaining, streaming ? (strategy == 1u ? 0x48u : strategy == 2u ? 0x50u : 0x58u) : 0u, stream != 0 ? 1u : 0u);
+    hipLaunchKernelGGL(k_zstd_frame_init, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, c->fstate, (u8*)d_dst, d_out_off, d_out_len, c->remaining, streaming ? (strategy == 1u ? 0x48u : strategy == 2u ? 0x50u : 0x58u) : 0u, stream != 0 ? 1u : 0u, level4 ? 1u : 0u, c->d_status);
     HIP_TRY(hipGetLastError());
     KMatchArgs m;
     m.src = (const u8*)d_src; m.in_off = d_in_off; m.in_len = d_in_len; m.n_slices = n;
@@ -820,6 +836,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     m.tables = c->tables; for (int ts_ = 0; ts_ < 4; ts_++) m.tseg[ts_] = c->tseg[ts_]; m.tseg_n = c->tseg_n; m.team_epoch = c->team_epoch; m.counter = c->counter;
     m.flags = 2u | (streaming ? 8u : 0u) | (c->max_slice_bytes >= KX_BLK_WIDE_FROM ? 16u : 0u);
     m.fstate = c->fstate; m.big_tables = c->big_tables;
+    if (level4) { m.level = 4; m.big_tables = c->big_tables4; m.big_stride = KX_BIG4_ENTRIES; m.big_long = KX_BIG4_LONG; }
     KFrameArgs e;
     e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = d_in_len; e.n_slices = n;
     e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
@@ -923,14 +940,14 @@ extern "C" int kmp_zstd_compress_batch_stream_level(kmp_batch_ctx* c, const void
 {
     if (level == 0) level = 3;
     bool const neg = level < 0;
-    if ((level < 1 && !neg) || level > 3 || level < -131072) { g_last_error = "kmp_zstd_compress_batch_stream_level: levels -131072 .. -1, 1, 2 and 3 are served"; return KMP_ERR_ARG; }
-    if (c && level != 3 && c->max_slice_bytes > ((level == 2 ? 1024u : 512u) << 10)) { g_last_error = "kmp_zstd_compress_batch_stream_level: level 1 / 2 streams up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
+    if ((level < 1 && !neg) || level > 4 || level < -131072) { g_last_error = "kmp_zstd_compress_batch_stream_level: levels -131072 .. -1 and 1 .. 4 are served"; return KMP_ERR_ARG; }
+    if (c && level != 3 && level != 4 && c->max_slice_bytes > ((level == 2 ? 1024u : 512u) << 10)) { g_last_error = "kmp_zstd_compress_batch_stream_level: level 1 / 2 streams up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_stream: null argument"; return KMP_ERR_ARG; }
     if (!c->big) { g_last_error = "kmp_zstd_compress_batch_stream: the context must be created with max_slice_bytes above 128 KiB"; return KMP_ERR_CAPACITY; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_stream: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, empty_end ? 2u : 1u, level == 3 ? 0u : neg ? 1u : (u32)level, 0, neg ? (u32)(1 - level) : 0u);
+    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, empty_end ? 2u : 1u, (level == 3 || level == 4) ? 0u : neg ? 1u : (u32)level, 0, neg ? (u32)(1 - level) : 0u, level == 4);
 }
 /* What ZstdCompressor(level).transform(ByteArray) returns: above 128 KiB libzstd stages the input in chunks of 128 KiB
  * because the reference's output slices are smaller than ZSTD_compressBound (include/kompressor_hip.h). */
@@ -941,13 +958,13 @@ extern "C" int kmp_zstd_compress_batch_reference(kmp_batch_ctx* c, const void* d
     if (!c) { g_last_error = "kmp_zstd_compress_batch_reference: null argument"; return KMP_ERR_ARG; }
     if (!c->big) return kmp_zstd_compress_batch_level(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, level, hip_stream);   // one block: one chunk
     bool const neg = level < 0;
-    if ((level < 1 && !neg) || level > 3 || level < -131072) { g_last_error = "kmp_zstd_compress_batch_reference: levels -131072 .. -1, 1, 2 and 3 are served"; return KMP_ERR_ARG; }
-    if (level != 3 && c->max_slice_bytes > ((level == 2 ? 1024u : 512u) << 10)) { g_last_error = "kmp_zstd_compress_batch_reference: levels 1 / 2 up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
+    if ((level < 1 && !neg) || level > 4 || level < -131072) { g_last_error = "kmp_zstd_compress_batch_reference: levels -131072 .. -1 and 1 .. 4 are served"; return KMP_ERR_ARG; }
+    if (level != 3 && level != 4 && c->max_slice_bytes > ((level == 2 ? 1024u : 512u) << 10)) { g_last_error = "kmp_zstd_compress_batch_reference: levels 1 / 2 up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
     if (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len)) { g_last_error = "kmp_zstd_compress_batch_reference: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_reference: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, 3u, level == 3 ? 0u : neg ? 1u : (u32)level, out_chunk, neg ? (u32)(1 - level) : 0u);
+    return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_stream, 3u, (level == 3 || level == 4) ? 0u : neg ? 1u : (u32)level, out_chunk, neg ? (u32)(1 - level) : 0u, level == 4);
 }
 /* block rounds of the last batch of a context for slices above 128 KiB */
 extern "C" int kmp_batch_last_rounds(kmp_batch_ctx* c) { return c ? (int)c->last_rounds : 0; }
@@ -985,9 +1002,8 @@ static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
     bool const l4 = level == 4;
-    if (l4 && c->big) { g_last_error = "kmp_zstd_compress_batch_level: level 4 is served for one-block slices (context max_slice_bytes <= 128 KiB)"; return KMP_ERR_CAPACITY; }
-    if (l4) KMP_TRY(ensure_tables4(c));
-    if (c->big) return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st, 0, 0);
+    if (l4 && !c->big) KMP_TRY(ensure_tables4(c));
+    if (c->big) return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st, 0, 0, 0, 0, l4);
     // Chunks: the match kernel of chunk i+1 (memory-transaction bound) runs beside the entropy kernel of
     // chunk i (latency bound) on a second stream; the caller's stream sees everything finished.
     // (two chunks only when each still fills at least half of the match kernel's team slots: 65 536 x 64 KiB -> 2,
@@ -1582,11 +1598,11 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
     u32 tail_direct = 0;
     if (streaming && in_place && end_avail != 0) {
         size_t const lap = 17u * (size_t)KX_BLOCK_MAX;                  // level-3 stream: window 2 MiB + one block
-        if (c->level == 3 && (n - end_avail) % lap == 0) tail_direct = (u32)end_avail;
+        if ((c->level == 3 || c->level == 4) && (n - end_avail) % lap == 0) tail_direct = (u32)end_avail;      // (level 4's streams: the same window)
     }
     if (streaming && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
     // level 4: what arrives in one closing call, above 16 KiB up to 128 KiB (libzstd's double-fast row of that level); the rest: CPU library
-    if (c->level == 4 && (streaming || !c->dict.empty() || n <= 16384u || n > KMP_MAX_SLICE_BYTES)) return KERRC(ZE_parameter_unsupported);
+    if (c->level == 4 && (!c->dict.empty() || (!streaming && !((n > 16384u && n <= 131072u) || n > 262144u)))) return KERRC(ZE_parameter_unsupported);
     if (c->level < 0 && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
     // the plain case -- level 3, no dictionary, the whole slice at once, one block -- joins whatever other contexts are
     // closing right now: one batch for all of them (kmp_coalesce.h); the frame is the one this context would get alone
@@ -1609,11 +1625,11 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
     if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (streaming) {
         if (tail_direct) {
-            if (zstd_compress_big(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, nullptr, 1u, 0u, tail_direct) != KMP_OK) return KERRC(ZE_GENERIC);
+            if (zstd_compress_big(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, nullptr, 1u, 0u, tail_direct, 0u, c->level == 4) != KMP_OK) return KERRC(ZE_GENERIC);
         } else
         if (kmp_zstd_compress_batch_stream_level(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->end_was_empty, c->level, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
     } else
-    if (n > KMP_MAX_SLICE_BYTES && !in_place && c->dict.empty() && (c->level == 3 || l1big)) {
+    if (n > KMP_MAX_SLICE_BYTES && !in_place && c->dict.empty() && (c->level == 3 || c->level == 4 || l1big)) {
         // the reference's one-shot driver above 128 KiB: staged input
         if (kmp_zstd_compress_batch_reference(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->level, (u32)first_room, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
     } else

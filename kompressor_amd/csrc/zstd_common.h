@@ -110,10 +110,15 @@ KX_DEV KParams kx_params_l3(u32 n)
 // its own).  ok = false: not such a slice.
 #define KX_TBL4_LONG (1u << 17)
 #define KX_TBL4_ENTRIES (1u << 18)
+// ... and, on the block-chain path, of the second (frames of several blocks: per-slice tables of 2^18 + 2^18 entries)
+#define KX_BIG4_LONG (1u << 18)
+#define KX_BIG4_ENTRIES (1u << 19)
+KX_DEV bool kx_l4_served(u32 n) { return (n > 16384u && n <= 131072u) || n > 262144u; }
 KX_DEV KParams kx_params_l4(u32 n, bool& ok)
 {
     KParams p; p.windowLog = 17; p.chainLog = 17; p.hashLog = 17; p.minMatch = 4;
-    ok = n > 16384u && n <= 131072u;
+    if (n > 262144u) { p.windowLog = 21; p.chainLog = 18; p.hashLog = 18; p.minMatch = 5; }
+    ok = kx_l4_served(n);
     u32 const srcLog = (n < 64) ? 6 : kx_hb32(n - 1) + 1;
     if (p.windowLog > srcLog) p.windowLog = srcLog;
     if (p.hashLog > p.windowLog + 1) p.hashLog = p.windowLog + 1;

@@ -1313,7 +1313,7 @@ KX_DEV void zstd_big_body(const KBigArgs& a)
         KMatchArgs m = a.m;
         m.in_off += base; m.in_len += base; m.n_slices = cnt;
         m.seqs += (size_t)base * m.seq_cap; m.lits += (size_t)base * m.lit_cap; m.meta += base; m.fstate += base;
-        m.big_tables += (size_t)base * KX_BIG_TBL_ENTRIES;
+        m.big_tables += (size_t)base * (FAST ? (size_t)KX_BIG_TBL_ENTRIES : (size_t)m.big_stride);
         m.counter = a.counters + kx_block();
         for (u32 guard = 0; guard < KX_MAX_BIG_SLICE / 64u; guard++) {         // (a block is at least 8 KiB unless it ends a chunk)
             bool open = false;

@@ -42,6 +42,7 @@ struct KMatchArgs {
     u32* tseg[4] = { nullptr, nullptr, nullptr, nullptr }; u32 tseg_n = 1;
     // geometry of a team's tables (entries): the level-3 one unless the batch runs level 4's double-fast row (level = 4)
     u32 tbl_stride = KX_TBL_ENTRIES, tbl_long = KX_TBL_LONG, level = 3;
+    u32 big_stride = KX_BIG_TBL_ENTRIES, big_long = KX_BIG_TBL_LONG;      // block mode: a slice's tables (level 4: KX_BIG4_*)
 };
 
 KX_DEV u32* kx_team_tables(const KMatchArgs& a, u32 team)
@@ -152,7 +153,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a, DONE const& done = DONE())
     int const tbase = lane - k;
     u32 const team = kx_block() * NT + (u32)(lane / G);
     u32* L = BLK ? a.big_tables : kx_team_tables(a, team);
-    u32* S = L + (BLK ? KX_BIG_TBL_LONG : a.tbl_long);
+    u32* S = L + (BLK ? a.big_long : a.tbl_long);
     int bstart = 0; u32 saved1 = 0, saved2 = 0;          // block mode: block start, repcodes set aside at block start
     u64 const tmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
 
@@ -196,15 +197,16 @@ KX_DEV void zstd_match_body(const KMatchArgs& a, DONE const& done = DONE())
                 if (s >= a.n_slices) state = KST_DONE;
                 else if (BLK) {
                     KFrameState const fs = a.fstate[s];
-                    KParams P0 = (a.flags & 32u) ? kx_params_l2_dfast() : kx_params_l3(a.in_len[s]);          // (flags bit 5: level 2's double-fast row)
-                    if (a.flags & 8u) { P0.windowLog = 21; P0.chainLog = 16; P0.hashLog = 17; P0.minMatch = 5; }   // streaming frame: size unknown when it starts
+                    bool ok4 = true;
+                    KParams P0 = (a.flags & 32u) ? kx_params_l2_dfast() : (a.level == 4u) ? kx_params_l4(a.in_len[s], ok4) : kx_params_l3(a.in_len[s]);          // (flags bit 5: level 2's double-fast row)
+                    if (a.flags & 8u) { P0.windowLog = 21; P0.chainLog = a.level == 4u ? 18 : 16; P0.hashLog = a.level == 4u ? 18 : 17; P0.minMatch = 5; }   // streaming frame: size unknown when it starts
                     KBlockWin const bw = kx_block_window(fs.lowLimit, fs.dictLimit, fs.ipos, fs.blockSize, P0.windowLog);
                     // (a block that libzstd parses with the extDict variant is left to zstd_match_ext_body)
                     if (fs.blockSize != 0 && !bw.ext && kx_in_class((a.flags >> 6) & 3u, a.in_len[s])) {           // else: frame finished (or not this launch's), fetch the next slice
                         slice = s;
                         src = a.src + a.in_off[s];
                         seqs = a.seqs + (size_t)s * a.seq_cap; lits = a.lits + (size_t)s * a.lit_cap;
-                        L = a.big_tables + (size_t)s * KX_BIG_TBL_ENTRIES; S = L + KX_BIG_TBL_LONG;
+                        L = a.big_tables + (size_t)s * a.big_stride; S = L + a.big_long;
                         KParams const P = P0;
                         hbL = P.hashLog; hbS = P.chainLog; mls = P.minMatch;
                         nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = 0; tag = 0;

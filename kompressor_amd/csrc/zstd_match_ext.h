@@ -47,14 +47,15 @@ KX_DEV void zstd_match_ext_body(const KMatchArgs& a)
                 if (s >= a.n_slices) state = KXS_DONE;
                 else {
                     KFrameState const fs = a.fstate[s];
-                    KParams P = kx_params_l3(a.in_len[s]);
-                    if (a.flags & 8u) { P.windowLog = 21; P.chainLog = 16; P.hashLog = 17; P.minMatch = 5; }
+                    bool ok4 = true;
+                    KParams P = (a.level == 4u) ? kx_params_l4(a.in_len[s], ok4) : kx_params_l3(a.in_len[s]);
+                    if (a.flags & 8u) { P.windowLog = 21; P.chainLog = a.level == 4u ? 18 : 16; P.hashLog = a.level == 4u ? 18 : 17; P.minMatch = 5; }
                     KBlockWin const bw = kx_block_window(fs.lowLimit, fs.dictLimit, fs.ipos, fs.blockSize, P.windowLog);
                     if (fs.blockSize != 0 && bw.ext) {
                         slice = s;
                         src = a.src + a.in_off[s];
                         seqs = a.seqs + (size_t)s * a.seq_cap; lits = a.lits + (size_t)s * a.lit_cap;
-                        L = a.big_tables + (size_t)s * KX_BIG_TBL_ENTRIES; S = L + KX_BIG_TBL_LONG;
+                        L = a.big_tables + (size_t)s * a.big_stride; S = L + a.big_long;
                         hbL = P.hashLog; hbS = P.chainLog; mls = P.minMatch;
                         dsi = bw.dictStartIndex; psi = bw.prefixStartIndex;
                         nseq = 0; nlit = 0; longType = 0; longPos = 0; guard = 0; status = 0;

@@ -1991,6 +1991,14 @@ static size_t dfast_compress_buffered(u8* dst, size_t cap, const u8* src, size_t
 KREF_API size_t kref_zstd_l3_compress_buffered(u8* dst, size_t cap, const u8* src, size_t srcSize, int knownSize, int emptyEnd,
                                                size_t outChunk, size_t tailDirect)
 { return dfast_compress_buffered(dst, cap, src, srcSize, knownSize, emptyEnd, outChunk, tailDirect, NULL); }
+/* The same at level 4, where its rows are double-fast ones (kref_params_l4; a stream of unknown size: window 21, chain 18, hash 18). */
+KREF_API size_t kref_zstd_l4_compress_buffered(u8* dst, size_t cap, const u8* src, size_t srcSize, int knownSize, int emptyEnd,
+                                               size_t outChunk, size_t tailDirect)
+{
+    u32 P[4] = { 21, 18, 18, 5 };
+    if (knownSize && (srcSize == 0 || !kref_params_l4(srcSize, P))) return KERR;
+    return dfast_compress_buffered(dst, cap, src, srcSize, knownSize, emptyEnd, outChunk, tailDirect, P);
+}
 
 /* Pknown: the parameters of a frame whose size is known, when they are not level 3's (level 2 has a double-fast row for
  * 128 KiB < size <= 256 KiB: kref_zstd_fast_compress_big) */
@@ -2004,7 +2012,7 @@ static size_t dfast_compress_buffered(u8* dst, size_t cap, const u8* src, size_t
     if (srcSize >= 0xF0000000u) return KERR;
     if (cap < kref_compress_bound(srcSize) + 16) return KERR;
     if (knownSize) { if (Pknown) memcpy(P, Pknown, sizeof(P)); else kref_params_l3(srcSize, P); pos = write_frame_header(dst, srcSize, P[0]); emptyEnd = 0; }
-    else { P[0] = 21; P[1] = 16; P[2] = 17; P[3] = 5; wr32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)((P[0] - 10) << 3); pos = 6; }
+    else { if (Pknown) memcpy(P, Pknown, sizeof(P)); else { P[0] = 21; P[1] = 16; P[2] = 17; P[3] = 5; } wr32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)((P[0] - 10) << 3); pos = 6; }
     hdr = pos;
     if (knownSize && srcSize == 0) { wr24(dst + pos, 1); return pos + 3; }
     if (!wksp_alloc(&w, P)) { wksp_free(&w); return KERR; }

@@ -213,7 +213,8 @@ extern "C" __attribute__((visibility("default")))
 int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,
                               u8* dst, const u64* out_off, u32* out_len, u32* rounds_out, u32 stream_and_strategy, u32 tail_or_chunk, u32 wide)
 {
-    u32 const stream = stream_and_strategy & 0xFFu, strategy = (stream_and_strategy >> 8) & 0xFFu;     // strategy 1: level 1 (fast); 2: level 2 (as zstd_compress_big in kmp_api.hip)
+    u32 const stream = stream_and_strategy & 0xFFu; u32 strategy = (stream_and_strategy >> 8) & 0xFFu;     // strategy 1: level 1 (fast); 2: level 2 (as zstd_compress_big in kmp_api.hip)
+    bool const level4 = strategy == 4u; if (level4) strategy = 0;                                           // 4: level 4's double-fast rows (the level-3 kernels, larger tables)
     u32 const fast_step0 = strategy == 1u ? stream_and_strategy >> 16 : 0u;                               // bits 16 ..: a negative level's step (1 - level), with strategy 1
     u32 const level2 = strategy == 2u ? 1u : 0u;
     bool const streaming = stream == 1 || stream == 2;
@@ -225,12 +226,13 @@ int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_le
     std::vector<u32> scratch((size_t)n * scratch_words, 0xA5A5A5A5u);
     std::vector<KFrameState> fstate(n);
     std::vector<u32> hufct((size_t)n * 512, 0xDEADBEEFu);
-    std::vector<u32> big_tables((size_t)n * KX_BIG_TBL_ENTRIES, 0u);
+    std::vector<u32> big_tables((size_t)n * (level4 ? KX_BIG4_ENTRIES : KX_BIG_TBL_ENTRIES), 0u);
     u32 remaining = 0, counter = 0;
     for (u32 i = 0; i < n; i++) {
         KFrameState s; memset(&s, 0, sizeof(s));
         s.blockSize = in_len[i] < KX_BLOCK_MAX ? in_len[i] : KX_BLOCK_MAX; s.first = 1; s.rep[0] = 1; s.rep[1] = 4; s.rep[2] = 8;
         s.lowLimit = 2; s.dictLimit = 2; s.chunkEnd = (stream != 0 && in_len[i] > KX_BLOCK_MAX) ? KX_BLOCK_MAX : in_len[i];
+        if (level4 && !streaming && !kx_l4_served(in_len[i])) { s.blockSize = 0; s.chunkEnd = 0; fstate[i] = s; out_len[i] = 0; continue; }      // (k_zstd_frame_init: refused size class)
         fstate[i] = s;
         if (in_len[i] == 0) { u8* d = dst + out_off[i]; u32 const magic = 0xFD2FB528u; memcpy(d, &magic, 4); d[4] = streaming ? 0x00 : 0x20; d[5] = streaming ? (strategy == 1u ? 0x48 : strategy == 2u ? 0x50 : 0x58) : 0; d[6] = 1; d[7] = 0; d[8] = 0; out_len[i] = 9; }
         else remaining++;
@@ -240,6 +242,7 @@ int emu_zstd_compress_big_ex2(const u8* src, const u64* in_off, const u32* in_le
     m.seqs = seqs.data(); m.seq_cap = seq_cap; m.lits = lits.data(); m.lit_cap = lit_cap; m.meta = meta.data();
     m.tables = nullptr; m.team_epoch = nullptr; m.counter = &counter; m.flags = (streaming ? 8u : 0u) | (wide ? 16u : 0u);
     m.fstate = fstate.data(); m.big_tables = big_tables.data();
+    if (level4) { m.level = 4; m.big_stride = KX_BIG4_ENTRIES; m.big_long = KX_BIG4_LONG; }
     KFrameArgs e;
     e.src = src; e.in_off = in_off; e.in_len = in_len; e.n_slices = n;
     e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();

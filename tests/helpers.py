@@ -297,7 +297,7 @@ class Oracle:
             raise RuntimeError("oracle: input outside the restatement's scope")
         return o.raw[:n]
 
-    def compress_buffered(self, d: bytes, known_size: bool = True, empty_end: bool = False, out_chunk=None, tail_direct: int = 0) -> bytes:
+    def compress_buffered(self, d: bytes, known_size: bool = True, empty_end: bool = False, out_chunk=None, tail_direct: int = 0, level: int = 3) -> bytes:
         """The frame ZstdCompressor(3) really produces above 128 KiB (libzstd stages the input in chunks of 128 KiB because
         the reference's output slices are smaller than ZSTD_compressBound): known_size = finish = true from the first
         call, out_chunk = the driver's output slice size (known_size = 2: no staging, ZSTD_compress2 into a bound-sized buffer,
@@ -305,14 +305,14 @@ class Oracle:
         bytes its closing call brought, when they arrived on an empty staging buffer with room for their bound).
         Any length (the window slides)."""
         k = self.lib
-        k.kref_zstd_l3_compress_buffered.restype = ctypes.c_size_t
-        k.kref_zstd_l3_compress_buffered.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
-                                                     ctypes.c_size_t, ctypes.c_size_t]
+        fn = k.kref_zstd_l4_compress_buffered if level == 4 else k.kref_zstd_l3_compress_buffered      # (level 4: its double-fast rows)
+        fn.restype = ctypes.c_size_t
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t]
         cap = k.kref_compress_bound(len(d)) + 64
         o = ctypes.create_string_buffer(cap)
         if out_chunk is None:
             out_chunk = max(8192, len(d) // 10)              # SliceTransform.kt:47-56 getOutput
-        n = k.kref_zstd_l3_compress_buffered(o, cap, d, len(d), int(known_size), 1 if empty_end else 0, out_chunk, tail_direct)
+        n = fn(o, cap, d, len(d), int(known_size), 1 if empty_end else 0, out_chunk, tail_direct)
         if n == 2 ** 64 - 1:
             raise RuntimeError("oracle: input outside the restatement's scope")
         return o.raw[:n]
@@ -533,7 +533,7 @@ def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False, stream=0, level=3,
     olen = np.zeros(n, dtype=np.uint32)
     rounds = ctypes.c_uint32(0)
     r = emu().emu_zstd_compress_big_ex2(_vp(buf), _vp(offs), _vp(lens), n, G, nblocks, _vp(out), _vp(ooff), _vp(olen),
-                                        ctypes.byref(rounds) if by_rounds else None, stream | ((level if level in (1, 2) else 1 if level < 0 else 0) << 8) | (((1 - level) << 16) if level < 0 else 0),
+                                        ctypes.byref(rounds) if by_rounds else None, stream | ((level if level in (1, 2, 4) else 1 if level < 0 else 0) << 8) | (((1 - level) << 16) if level < 0 else 0),
                                         tail_or_chunk, 1 if wide else 0)
     assert r == 0, f"emulator reported {r}"
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)], rounds.value

@@ -663,6 +663,13 @@ def test_level_4_where_it_is_double_fast(batch, monkeypatch):
     assert ZstdCompressor(compression_level=4).transform_bytes(mix[5]) == frames4[5]
     with pytest.raises(Exception):
         ZstdCompressor(compression_level=4).transform_bytes(mix[5][:9000])
+    # frames of several blocks (above 256 KiB level 4 is double-fast again: window 21, chain 18, hash 18) and streams, through the
+    # streaming entry point as the reference's driver calls it; 128 - 256 KiB is a "greedy" class: refused
+    o = helpers.oracle()
+    big = corpus.make(78, 1, 700000).tobytes()
+    assert ZstdCompressor(compression_level=4).transform_bytes(big) == o.compress_buffered(big, True, level=4)
+    with pytest.raises(Exception):
+        ZstdCompressor(compression_level=4).transform_bytes(big[:200000])
     # many slices through few teams: every team parses four slices per batch on tables it never clears (epoch tags), three batches
     from kompressor_amd.batch import ZstdBatch
     monkeypatch.setenv("KMP_L4_TEAMS", "64")

@@ -60,6 +60,7 @@ def gpu_frames(level, reference, idx, max_bytes, streaming=None):
     b.close()
     return frames
 all_idx = np.arange(N); l1_idx = np.nonzero(lens <= 524288)[0]
+l4_idx = np.nonzero(((lens > 16384) & (lens <= 131072)) | (lens > 262144))[0]          # the size classes level 4 runs as double-fast
 bad_total = 0
 cutr = np.random.default_rng(seed + 99)
 def streamed(d, level, empty):                   # finish = false calls, then finish = true with / without data; 8 KiB output slices
@@ -77,9 +78,13 @@ for name, level, reference, idx, fn, streaming in (
         ("level 1 up to 512 KiB, ZSTD_compress2's frames", 1, False, l1_idx, lambda d: one_shot(d, 1), None),
         ("level -1 up to 512 KiB, the reference driver's frames", -1, True, l1_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), -1), None),
         ("level -5 up to 512 KiB, ZSTD_compress2's frames", -5, False, l1_idx, lambda d: one_shot(d, -5), None),
-        ("level -3 up to 512 KiB, streamed, the closing call brings data", -3, False, l1_idx, lambda d: streamed(d, -3, False), "data")):
+        ("level -3 up to 512 KiB, streamed, the closing call brings data", -3, False, l1_idx, lambda d: streamed(d, -3, False), "data"),
+        ("level 4 (its double-fast size classes), the reference driver's frames", 4, True, l4_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), 4), None),
+        ("level 4 (its double-fast size classes), ZSTD_compress2's frames", 4, False, l4_idx, lambda d: one_shot(d, 4), None),
+        ("level 4, streamed, the closing call brings data", 4, False, all_idx, lambda d: streamed(d, 4, False), "data"),
+        ("level 4, streamed, the closing call is empty", 4, False, all_idx, lambda d: streamed(d, 4, True), "empty")):
     t0 = time.time()
-    g = gpu_frames(level, reference, idx, MAXL if level == 3 else 524288, streaming)
+    g = gpu_frames(level, reference, idx, MAXL if level in (3, 4) else 524288, streaming)
     r = ref_frames(fn, idx)
     bad = [i for i in idx if g[int(i)] != r[int(i)]]
     bad_total += len(bad)
