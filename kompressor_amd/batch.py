@@ -136,8 +136,8 @@ class ZstdBatch:
         raw-content dictionary shared by all slices (host memory; its tables are built once per dictionary).
         level: 3 (default), or 1 / 2 without a dictionary: slices up to the level's window (512 KiB / 1 MiB; above 128 KiB
         the context must have been created for slice sizes in (128 KiB, 512 KiB] / (128 KiB, 1 MiB]); a negative level (slices up
-        to 128 KiB); or 4 for slices above
-        16 KiB up to 128 KiB (where libzstd runs level 4 as the double-fast parse; smaller slices are refused: out_len 0).
+        to 128 KiB, and up to 512 KiB in a context created for such slices); or 4 for slices above 16 KiB up to 128 KiB and above 256 KiB
+        (where libzstd runs level 4 as the double-fast parse; the other sizes are refused: out_len 0).
         streaming: None = one-shot frames; "data" / "empty" = the frames of slices that arrived through finish = false
         calls, closed by a call with / without data (context created for slices above 128 KiB; levels 1 to 3).
         reference: the frames ZstdCompressor(level).transform(bytes) returns -- above 128 KiB the reference's output slices
