@@ -25,6 +25,8 @@ run --slice-kib 1024 --slices 32768 --steps 2 --warmup 1 --no-cpu --no-stream
 run --slice-kib 256 --slices 32768 --level 1 --steps 2 --warmup 1 --no-cpu
 run --slice-kib 256 --slices 32768 --level 2 --steps 2 --warmup 1 --no-cpu
 run --slice-kib 1024 --slices 8192 --level 2 --steps 2 --warmup 1 --no-cpu
+run --slice-kib 1024 --slices 8192 --level 4 --steps 2 --warmup 1 --no-cpu --no-stream
+run --slice-kib 512 --slices 16384 --level -1 --steps 2 --warmup 1 --no-cpu --no-stream
 run --mode deflate --deflate-level 4 --steps 2 --warmup 1 --no-cpu
 run --mode deflate --deflate-level 1 --steps 2 --warmup 1 --no-cpu
 run --mode decompress --slice-kib 256 --slices 16384 --steps 3 --warmup 1 --no-cpu
