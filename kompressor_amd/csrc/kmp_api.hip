@@ -468,7 +468,7 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
                     // allocated and probed, the faster of the two stays and the other is freed before creation returns
                     // (KMP_TABLE_RETRY=0: never; 2: always, for the tests).
                     size_t fr2 = 0, tot2 = 0;
-                    if ((pr1 < 23.5e9f || env_u32("KMP_TABLE_RETRY", 1) == 2) && env_u32("KMP_TABLE_RETRY", 1) && hipMemGetInfo(&fr2, &tot2) == hipSuccess && fr2 > total + ((size_t)16 << 30)) {
+                    if ((pr1 < (float)env_u32("KMP_TABLE_RETRY_BELOW", 235) * 1e8f || env_u32("KMP_TABLE_RETRY", 1) == 2) && env_u32("KMP_TABLE_RETRY", 1) && hipMemGetInfo(&fr2, &tot2) == hipSuccess && fr2 > total + ((size_t)16 << 30)) {
                         u8* second = nullptr;
                         if (hipMalloc((void**)&second, total) == hipSuccess) {
                             u32 pick2 = 0; float ms2 = 0, pr2 = 0;
