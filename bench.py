@@ -238,6 +238,177 @@ def cpu_decode_baseline(frames_host, offs, lens, n_slices, sample=32768):
                       + (f" [{sum(bad)} calls failed]" if sum(bad) else "")}
 
 
+def _pmc_file():
+    """profiles/pmc_latest.json (HBM bytes per launch from the round's rocprofv3 --pmc passes) and whether the kernels have
+    changed since it was collected: the file records a hash of kompressor_amd/csrc at collection time (tools/summarize_profiles.py)."""
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+    except Exception:
+        return None, None
+    want = pj.get("csrc_sha256")
+    if not want:
+        return pj, "unknown (the file records no source hash)"
+    return pj, (None if csrc_sha256() == want else "STALE: kompressor_amd/csrc changed since the counters were collected")
+
+
+def csrc_sha256():
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "kompressor_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_codec_baseline(kind, base, offs, lens, n, cap, what, out_bytes_per_entry=None, level=6):
+    """oracle/cpu_bench.c cpubench_codec on the host threads this job may use: kind 1 = libzstd 1.5.7 ZSTD_decompressStream driven
+    like the reference's one-shot driver (+ the one-buffer ZSTD_decompressDCtx figure), 2 = zlib deflate(level, raw), 3 = zlib
+    inflate(raw).  1 warm-up + 3 passes over the first n entries, the median; throughput in uncompressed bytes."""
+    import statistics
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    hc = host_cores()
+    cores = hc["threads_used"]
+    lib = ctypes.CDLL(build_cpu_bench())
+    lib.cpubench_codec.restype = ctypes.c_int
+    lib.cpubench_codec.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                   ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_int]
+    zpath = None
+    if kind == 1:
+        try:
+            from libzstd_ref import find_libzstd_157
+            z = find_libzstd_157()
+            zpath = z._path if z is not None else None
+        except Exception:
+            zpath = None
+        if not zpath:
+            return None
+    offs = np.ascontiguousarray(offs[:n], dtype=np.uint64); lens = np.ascontiguousarray(lens[:n], dtype=np.uint32)
+    passes = 4
+
+    def run(stream_api):
+        secs = (ctypes.c_double * passes)()
+        ob, er = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        ver = ctypes.create_string_buffer(32)
+        rc = lib.cpubench_codec(kind, zpath.encode() if zpath else None, level, stream_api, base.ctypes.data, offs.ctypes.data, lens.ctypes.data, n, cap,
+                                cores, passes, secs, ctypes.byref(ob), ctypes.byref(er), ver, 32)
+        if rc != 0:
+            raise RuntimeError(f"cpubench_codec({kind}) failed ({rc})")
+        return list(secs), ob.value, er.value, ver.value.decode()
+
+    secs, ob, er, ver = run(1)
+    med = statistics.median(secs[1:])
+    unc = (ob if kind != 2 else int(lens.astype(np.int64).sum()))          # uncompressed bytes of one pass
+    res = {"value": round(unc / med / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "reference", "passes_s": [round(x, 3) for x in secs],
+           "sample": f"first {n} {what}, {cores} pthreads (oracle/cpu_bench.c), 1 warm-up + {passes - 1} passes, median {med:.3f} s"
+                     + (f", zlib {ver}" if kind != 1 else f", {os.path.basename(zpath)}") + (f" [{er} calls failed]" if er else "")}
+    if kind == 1:
+        secs0, ob0, er0, _ = run(0)
+        res["one_buffer_api"] = {"value": round(ob0 / statistics.median(secs0[1:]) / 1e9, 4), "unit": "GB/s", "what": "ZSTD_decompressDCtx into one 64 KiB buffer (no output slices)"}
+        res["sample"] += "; ZSTD_decompressStream with the whole frame as input and output slices of max(8192, frame / 10) bytes, as SliceTransform.kt:33-45 drives Wrapper.cpp:178"
+    if kind == 2:
+        res["frame_bytes"] = ob
+    return res
+
+
+def extra_legs(b, torch, np, src, in_off, in_len, dst, out_off, out_len, host, n, dev, no_cpu, steps=3):
+    """The other single-GPU BASELINE configs on the same batch, after the headline's timed region: configs[2] (ZstdDecompressor
+    over the frames just written), configs[4] (raw DEFLATE level 6) and inflate of its streams.  Each: `steps` timed passes after
+    one warm-up (inputs resident in HBM), the pipeline's HIP-event time for the roofline figure, a CPU figure from the same
+    run (oracle/cpu_bench.c)."""
+    S = SLICE
+    in_bytes = n * S
+    pj, stale = _pmc_file()
+    pj = pj if (pj and pj.get("slices") == n and S == 65536) else None
+    out = {}
+    cap = torch.full((n,), S, dtype=torch.int32, device=dev)
+    back = torch.empty(n * S + 64, dtype=torch.uint8, device=dev)
+
+    def timed(fn):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); e0.record()
+        for _ in range(steps):
+            r = fn()
+        e1.record(); torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, e0.elapsed_time(e1) / steps, r
+
+    # ---- configs[2]: decode --------------------------------------------------------------------------------------------
+    lens = out_len.cpu().numpy().astype(np.int64)
+    frame_bytes = int(lens.sum())
+    dt, ms_ev, r = timed(lambda: b.decompress(dst, out_off, out_len, cap, dst=back, out_off=in_off))
+    ok = bool(int(r[3].abs().sum().item()) == 0 and torch.equal(back[: n * S], src))
+    ms_dec = b.last_kernel_ms(2)
+    algo = in_bytes + frame_bytes + 16 * n
+    traffic = None
+    if pj:
+        parts = [pj.get(k + "_hbm_bytes_per_launch") for k in ("k_zstd_decode", "k_zstd_seq_predecode", "k_zstd_lit_predecode")]
+        traffic = sum(parts) if all(v is not None for v in parts) else None
+    cpu = None
+    if not no_cpu:
+        ns = min(n, 16384)
+        end = int(out_off[ns - 1].item()) + int(out_len[ns - 1].item())
+        cpu = cpu_codec_baseline(1, dst[:end].cpu().numpy(), out_off[:ns].cpu().numpy(), out_len[:ns].cpu().numpy(), ns, S, "frames of the same batch")
+    out["decode"] = {"metric": "zstd decompression throughput (decoded bytes per second), BASELINE configs[2]: ZstdDecompressor over the level-3 frames of configs[1]",
+                     "value": round(in_bytes / dt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "roundtrip_ok": ok,
+                     "roofline": {"bound": "hbm", "kernel": "decode pipeline (k_zstd_lit_predecode + k_zstd_seq_predecode side by side, then k_zstd_decode), one HIP-event bracket",
+                                  "achieved": round(algo / (ms_dec * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(algo / (ms_dec * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(ms_dec, 3)},
+                     "cpu_baseline": cpu}
+    # ---- configs[4]: raw DEFLATE level 6 ---------------------------------------------------------------------------------
+    d_dst = torch.empty(n * b.out_stride + 64, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    dt, ms_ev, _ = timed(lambda: b.deflate(src, in_off, in_len, d_dst, out_off, d_len, level=6))
+    kms = b.deflate_kernel_ms()
+    dlens = d_len.cpu().numpy().astype(np.int64)
+    import zlib as _z
+    ok = True
+    for i in (0, 1, 5, 777 % n, n - 1):
+        f = d_dst[int(out_off[i]):int(out_off[i]) + int(dlens[i])].cpu().numpy().tobytes()
+        ok = ok and _z.decompress(f, -15) == host[i * S:(i + 1) * S].tobytes()
+    piece = min(n, 16384)
+    algo_piece = (in_bytes + int(dlens.sum()) + 16 * n) * piece // n
+    ms_best = float(kms.get("k_deflate_best", 0.0)) or 1.0
+    cpu = None
+    if not no_cpu:
+        ns = min(n, 8192)
+        cpu = cpu_codec_baseline(2, host, np.arange(ns, dtype=np.uint64) * S, np.full(ns, S, dtype=np.uint32), ns, S + S // 8, "slices of the same batch, deflateInit2(6, -15, 8, 0) + deflate(Z_FINISH)")
+        if cpu is not None:
+            cpu["stream_bytes_match_gpu"] = bool(cpu.pop("frame_bytes") == int(dlens[:ns].sum()))
+    out["deflate6"] = {"metric": "raw DEFLATE level-6 compression throughput (uncompressed input bytes per second), BASELINE configs[4]",
+                       "value": round(in_bytes / dt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+                       "ratio": round(in_bytes / float(dlens.sum()), 4), "zlib_inflate_spot_check_ok": ok,
+                       "kernels_ms_first_piece": {k: round(v, 3) for k, v in kms.items()},
+                       "roofline": {"bound": "hbm", "kernel": "k_deflate_best (LDS- and issue-bound chain walk over every position; HBM is not what limits it), one launch per piece of 16 384 slices",
+                                    "achieved": round(algo_piece / (ms_best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(algo_piece / (ms_best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                    "traffic": (pj.get("k_deflate_best_hbm_bytes_per_launch") if (pj and piece == 16384) else None),
+                                    "slices_per_launch": piece, "avg_launch_ms": round(ms_best, 3)},
+                       "cpu_baseline": cpu}
+    # ---- inflate of those streams ------------------------------------------------------------------------------------------
+    dt, ms_ev, r = timed(lambda: b.inflate(d_dst, out_off, d_len, cap, dst=back, out_off=in_off))
+    ok = bool(int(r[3].abs().sum().item()) == 0 and torch.equal(back[: n * S], src))
+    algo = in_bytes + int(dlens.sum()) + 16 * n
+    cpu = None
+    if not no_cpu:
+        ns = min(n, 16384)
+        end = int(out_off[ns - 1].item()) + int(d_len[ns - 1].item())
+        cpu = cpu_codec_baseline(3, d_dst[:end].cpu().numpy(), out_off[:ns].cpu().numpy(), d_len[:ns].cpu().numpy(), ns, S, "streams of the same batch, inflateInit2(-15) + inflate(Z_FINISH)")
+    out["inflate"] = {"metric": "raw DEFLATE decompression throughput (decoded bytes per second): ZlibDecompressor(ZlibFormat.Raw) over configs[4]'s streams",
+                      "value": round(in_bytes / dt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "roundtrip_ok": ok,
+                      "roofline": {"bound": "hbm", "kernel": "inflate pipeline (k_inflate_predecode, a lane per stream, then k_inflate_exec), one event bracket on the launch stream",
+                                   "achieved": round(algo / (ms_ev * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(algo / (ms_ev * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                   "traffic": (pj.get("inflate_pipeline_hbm_bytes_per_step") if pj else None), "avg_launch_ms": round(ms_ev, 3)},
+                      "cpu_baseline": cpu}
+    if stale:
+        for k in out:
+            out[k]["roofline"]["traffic_note"] = stale
+    del d_dst, back
+    return out
+
+
 def count_gpus_without_hip():
     """GPUs this process would see, counted without initialising the HIP runtime (the parent of the ranks must not hold one):
     the KFD topology's nodes with SIMDs, cut down to HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set."""
@@ -291,6 +462,7 @@ def main():
     ap.add_argument("--team", type=int, default=0, help="lanes per slice in the match kernel (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--slice-class", default="", help="experiments: every slice of one corpus class (T X S B D I Z R) instead of the configuration's mix")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the legs for BASELINE configs[2] / [4] (decode, DEFLATE level 6, inflate) that follow the headline")
     ap.add_argument("--no-stream", action="store_true", help="N = 1: skip the figures of the streaming entry point (what a Kotlin caller binds)")
     ap.add_argument("--level", type=int, default=3, help="zstd level: 3 (BASELINE configs), 1 / 2 (strategy fast), 4 (its double-fast row: slices above 16 KiB up to 128 KiB), or a negative level (slices up to 128 KiB)")
     ap.add_argument("--dict-kib", type=int, default=0,
@@ -784,6 +956,13 @@ def main():
             res["with_scatter_gather"] = exchange
         if pcie:
             res["end_to_end_pcie"] = pcie
+        if traffic is not None:
+            stale = _pmc_file()[1]
+            if stale:
+                res["roofline"]["traffic_note"] = stale
+        if not args.no_extra and dist is None and args.config == 1 and SLICE == 65536 and not args.slice_class:
+            # BASELINE configs[2] and [4] on the same batch, after (and outside) the headline's timed region
+            res.update(extra_legs(b, torch, np, src, in_off, in_len, dst, out_off, out_len, host, n, dev, args.no_cpu))
         if not args.no_stream and world == 1 and SLICE <= 131072:
             res["streaming_abi"] = streaming_abi_figure(host, n)
         if not args.no_cpu and world == 1:          # the CPU baseline is a rank-0, N = 1 figure

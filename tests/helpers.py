@@ -412,6 +412,21 @@ def live_libzstd():
         return None
 
 
+def require_live_libzstd(report=True):
+    """For the -m gpu tests that check against the binary library of the machine they run on: the image of the GPU boxes
+    carries libzstd 1.5.7 (the Pillow wheel's), so its absence there is a broken box or a changed image, not a reason to
+    skip -- the test FAILS with a sentence, and the library's path goes into the test's output (pytest -rA / the junit
+    record show that the differential leg ran, and against what)."""
+    import pytest
+    z = live_libzstd()
+    if z is None:
+        pytest.fail("no binary libzstd 1.5.7 on this GPU box: the differential tests against the live library cannot run "
+                    "(oracle/libzstd_ref.py looks in the Pillow wheel's pillow.libs/); they are not skipped silently")
+    if report:
+        print(f"[live library] libzstd 1.5.7 at {z.path}")
+    return z
+
+
 # -------------------------------------------------------------- emulator ----
 _EMU = None
 

@@ -558,13 +558,12 @@ def test_levels_1_and_2(batch):
 def test_differential_fuzz_against_the_live_library():
     """tools/r03_fuzz.py / r03_fuzz_big.py at a small size (their long runs are in profiles/r03_fuzz.txt): ragged stress inputs and
     corpus slices through every level-3 path, levels 1, 2, 4 and three negative ones, two dictionary sizes and three DEFLATE levels,
-    and frames of several blocks in seven forms -- every frame against the binary libzstd 1.5.7 / zlib of THIS machine.  Skipped
-    where no libzstd 1.5.7 is installed (the library is only ever the checker)."""
+    and frames of several blocks in seven forms -- every frame against the binary libzstd 1.5.7 / zlib of THIS machine.  The
+    GPU boxes carry that library: where it is missing the test fails (helpers.require_live_libzstd), it does not skip."""
     import os
     import subprocess
     import sys
-    if helpers.live_libzstd() is None:
-        pytest.skip("no libzstd 1.5.7 on this machine")
+    helpers.require_live_libzstd()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for tool, args in (("r03_fuzz.py", ["7", "6000"]), ("r03_fuzz_big.py", ["7", "300"])):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", tool)] + args, capture_output=True, text=True, timeout=420)
@@ -866,9 +865,7 @@ def test_mutated_frames_on_the_gpu(batch):
     loop does not check that the literal streams end where they should, this decoder does)."""
     import random
     import fuzz_decoders as F
-    z = helpers.live_libzstd()
-    if z is None:
-        pytest.skip("no libzstd 1.5.7 on this machine")
+    z = helpers.require_live_libzstd()
     rng = random.Random(2025)
     srcs = F.sources(rng, 16)
     frames = [(z.compress(d, lvl), d) for d in srcs for lvl in ((1, 3, 19) if len(d) < 100000 else (3,))]

@@ -113,6 +113,10 @@ def main():
         if "k_inflate_predecode_hbm_bytes_per_launch" in pj and "k_inflate_exec_hbm_bytes_per_launch" in pj:
             pj["inflate_pipeline_hbm_bytes_per_step"] = pj["k_inflate_predecode_hbm_bytes_per_launch"] + pj["k_inflate_exec_hbm_bytes_per_launch"]      # (the bench.py --mode inflate pass: 65 536 streams per launch)
         pj["note_other_kernels"] = "k_zstd_decode / k_zstd_seq_predecode / k_zstd_lit_predecode: 65536 frames per launch; k_deflate_*: 16384 slices per launch; k_inflate_predecode / k_inflate_exec: 65536 streams per launch (the --mode inflate pass); (FETCH_SIZE+WRITE_SIZE)*1024 / launches"
+        # bench.py compares this with the tree it runs from: counters collected on other kernel sources are flagged, not passed on silently
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        pj["csrc_sha256"] = bench.csrc_sha256()
         json.dump(pj, open(os.path.join(outdir, "pmc_latest.json"), "w"), indent=1)
     print("\n".join(lines[:60]))
 
