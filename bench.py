@@ -478,6 +478,11 @@ def main():
     if args.slices <= 0:
         args.slices = 131072 if args.config == 3 else 65536
 
+    # The ROCm runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a
+    # queue run in order: the end-to-end leg below uses a stream per piece plus two copy streams, each of which wants a queue of its
+    # own (measured: with 4 queues a piece's parse waited behind another piece's whole parse; INTEGRATION.md "Streams").  Read when the
+    # runtime initialises, so set before anything touches HIP.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import numpy as np
     import torch
     from kompressor_amd import corpus, sharding
@@ -523,10 +528,16 @@ def main():
                  "context_parts": n * ((SLICE // 4 + 24) * 8 + 2 * (SLICE + 64) + 256 + 32) + slots * 393216,
                  "exchange_on_root": (n * world * SLICE + int(n * world * SLICE / 2.3)) if (world > 1 and not args.no_exchange and rank == 0) else 0,
                  "exchange_per_rank": n * SLICE if (world > 1 and not args.no_exchange) else 0}
-        span = int(os.environ.get("KMP_TABLE_SPAN_GIB", "100")) << 30
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        # the arena's span: what is asked for, bounded by half of the free memory (the library's rule); on a rank whose other buffers
+        # leave less than that, packed (the root of configs[3]'s exchange: 124 GiB of its own + the whole batch and its frames)
+        span = min(int(os.environ.get("KMP_TABLE_SPAN_GIB", "100")) << 30, free_b // 2)
+        others = sum(v for k, v in parts.items() if k != "context_parts")
+        if others + span + (24 << 30) > free_b:
+            span = 0
+            os.environ["KMP_TABLE_SPAN_GIB"] = "0"
         parts["context_arena"] = max(parts.pop("context_parts"), span if slots * 393216 >= (4 << 30) else 0)
         need = sum(parts.values())
-        free_b, total_b = torch.cuda.mem_get_info(dev)
         plan = {"rank": rank, "need_GiB": round(need / GiB, 1), "free_GiB": round(free_b / GiB, 1), **{k: round(v / GiB, 1) for k, v in parts.items()}}
         print("bench.py HBM plan: " + json.dumps(plan), file=sys.stderr, flush=True)
         if need + (2 << 30) > free_b:
@@ -548,7 +559,11 @@ def main():
     del tmp
     in_off = torch.arange(n, dtype=torch.int64, device=dev) * SLICE
     in_len = torch.full((n,), SLICE, dtype=torch.int32, device=dev)
-    b = ZstdBatch(max_slices=n, max_slice_bytes=SLICE, device=local_rank, team_lanes=args.team)
+    # the bench asks for the arena's span and for the second-arena retry explicitly (kmp_batch_options; the library's default is no retry)
+    span_gib = int(os.environ.get("KMP_TABLE_SPAN_GIB", "100"))
+    retry = int(os.environ.get("KMP_TABLE_RETRY", "1"))
+    b = ZstdBatch(max_slices=n, max_slice_bytes=SLICE, device=local_rank, team_lanes=args.team, table_span_gib=span_gib, table_retry=retry)
+    print("bench.py context memory: " + json.dumps({k: round(v / 2**30, 2) for k, v in b.memory().items()}) + " GiB", file=sys.stderr, flush=True)
     dst = torch.empty(n * b.out_stride + 64, dtype=torch.uint8, device=dev)
     out_off = torch.arange(n, dtype=torch.int64, device=dev) * b.out_stride
     out_len = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -705,12 +720,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # context setup: a level-3 context picks its launch setting on its first two batches of this size (kmp_api.hip,
-    # KMP_ZSTD_AUTOTUNE); they run here, next to the workspace allocation, so that the W warmup steps and the K timed
-    # steps all run the setting it kept
-    setup_batches = 2 if (args.level == 3 and dictionary is None and not ref_pattern and os.environ.get("KMP_ZSTD_AUTOTUNE", "0") != "0") else 0
-    for _ in range(setup_batches):
-        step()
     for _ in range(args.warmup):
         step()
     fence()
@@ -779,27 +788,67 @@ def main():
         del everything, src2, stream_buf
 
     # ---- second line of SURVEY 8d, N = 1: the same step with the host copies over PCIe included (never `value`) --------
+    # The batch goes through in PIECES that run side by side (kmp_zstd_compress_batch_pieces): piece p's slices come in on stream p,
+    # its kernels follow on that stream while the later pieces are still arriving, its dense frames leave while the others are still
+    # being coded -- H2D, kernels and D2H overlap and the device still has every slice in flight once all have arrived.
     pcie = None
     if dist is None and args.mode == "compress" and not args.no_pcie and not big:
         pin_in = torch.from_numpy(host[: n * SLICE]).pin_memory() if host.size >= n * SLICE else None
         if pin_in is not None:
+            P = max(1, min(8, int(os.environ.get("KMP_BENCH_PCIE_PIECES", "8"))))
             pin_out = torch.empty(frame_bytes + 64, dtype=torch.uint8).pin_memory()
+            pin_tot = torch.zeros(P, dtype=torch.int64).pin_memory()
             src2 = torch.empty(n * SLICE, dtype=torch.uint8, device=dev)
+            streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
+            s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)      # the copies: one after the other, in piece order
+            ranges = [b.piece_range(n, P, p) for p in range(P)]
+            poffs = [torch.zeros(cnt + 1, dtype=torch.int64, device=dev) for _, cnt in ranges]
+            arrived = [torch.cuda.Event() for _ in range(P)]
+            pdone = [torch.cuda.Event() for _ in range(P)]
 
             def pstep():
-                src2.copy_(pin_in, non_blocking=True)
-                step(src2)
-                pin_out[:frame_bytes].copy_(dense[:frame_bytes], non_blocking=True)
+                for p, (first, cnt) in enumerate(ranges):
+                    # (copies of different pieces queued on different streams would share the link and all arrive at the end)
+                    with torch.cuda.stream(s_in):
+                        src2[first * SLICE:(first + cnt) * SLICE].copy_(pin_in[first * SLICE:(first + cnt) * SLICE], non_blocking=True)
+                        arrived[p].record(s_in)
+                    streams[p].wait_event(arrived[p])
+                b.compress_pieces(src2, in_off, in_len, dst, out_off, out_len, streams)
+                for p, (first, cnt) in enumerate(ranges):
+                    with torch.cuda.stream(streams[p]):
+                        # the piece's frames, densely packed, into its own part of `dense` (worst-case placement: first * stride)
+                        b.compact_piece(dst, out_off, out_len, first, cnt, dense[first * b.out_stride:], poffs[p], streams[p])
+                        pin_tot[p:p + 1].copy_(poffs[p][cnt:cnt + 1], non_blocking=True)
+                        pdone[p].record(streams[p])
+                base = 0
+                for p, (first, cnt) in enumerate(ranges):
+                    pdone[p].synchronize()                        # (the host needs the piece's size to place it in the caller's buffer)
+                    tot = int(pin_tot[p])
+                    with torch.cuda.stream(s_out):
+                        pin_out[base:base + tot].copy_(dense[first * b.out_stride:first * b.out_stride + tot], non_blocking=True)
+                    base += tot
+                s_out.synchronize()
+                return base
 
-            pstep()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
             pstep()
-            torch.cuda.synchronize()
-            pdt = time.perf_counter() - t0
-            pcie = {"value": round(in_bytes / pdt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(pdt * 1e3, 3),
-                    "what": "pinned host slices -> HBM, the step, dense frames -> pinned host memory, one pass, copies not overlapped with the kernels"}
-            del src2, pin_in, pin_out
+            pt = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                got = pstep()
+                pt.append(time.perf_counter() - t0)
+            pdt = min(pt)
+            # what arrived is the frames of the timed steps, back to back in slice order
+            same = bool(got == frame_bytes)
+            if same:
+                b.compact_into(dst, out_off, out_len, dense, dense_off)
+                torch.cuda.synchronize()
+                same = bool(torch.equal(pin_out[:frame_bytes], dense[:frame_bytes].cpu()))
+            pcie = {"value": round(in_bytes / pdt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(pdt * 1e3, 3), "pieces": P, "passes_ms": [round(x * 1e3, 1) for x in pt],
+                    "frames_equal_the_one_launch_batch": same,
+                    "what": f"pinned host slices -> HBM, the level-3 step, dense frames -> pinned host memory, in {P} pieces that run side by side "
+                            "(kmp_zstd_compress_batch_pieces: the copies in on one stream in piece order, piece p's kernels and packing on stream p behind its copy, the copies out on one stream); best of 3 passes"}
+            del src2, pin_in, pin_out, poffs
 
     if args.mode == "decompress":
         # configs[2]: ZstdDecompressor over the level-3 frames just produced (strided layout), decoded in place of a fresh buffer
@@ -940,8 +989,8 @@ def main():
                                    + (f" [EXPERIMENT: every slice of class {args.slice_class[0]}]" if args.slice_class else ""),
                        "slices_per_gpu": n, "slice_bytes": SLICE, "ratio": round(in_bytes / frame_bytes, 4),
                        "team_lanes": b.lib and (args.team or int(os.environ.get("KMP_TEAM_LANES", "8" if n <= 8192 else "4"))), "parallelism": f"slice-sharded x{world}",
-                       "parser": {"0": "zstd_match.h", "1": "zstd_match2.h (split-phase, 256-byte window)", "2": "zstd_match2.h (split-phase, 512-byte window)"}.get(os.environ.get("KMP_MATCH_V2", "0"), "?"),
-                       "table_span_gib": int(os.environ.get("KMP_TABLE_SPAN_GIB", "100")) or "packed"},
+                       "parser": "zstd_match.h",
+                       "table_span_gib": round(b.memory()["arena"] / 2**30, 1) or "no arena", "table_retry": retry},
             "roofline": {"bound": "hbm", "kernel": "k_zstd_match", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(ms_match, 3), "launches_per_step": launches},

@@ -148,6 +148,24 @@ typedef struct kmp_batch_ctx kmp_batch_ctx;
  * the match kernel (4, 8, 16, 32 or 64; 0 = default). */
 KMP_API int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_slices,
                              uint32_t max_slice_bytes, int team_lanes);
+/* ... with options.  struct_bytes = sizeof(kmp_batch_options) (versioning).  team_lanes: as above.
+ * table_span_gib: the address span, in GiB, over which a context with 4 GiB or more of level-3 team tables lays out its
+ * workspace arena (-1 = the environment's KMP_TABLE_SPAN_GIB, else 100; 0 = packed).  The parser's table traffic runs 11 % faster
+ * over 72 GiB or more of span than inside a few dozen (DESIGN.md section 5a'); the gaps are memory the context holds and does not
+ * use, so the span is bounded by half of the device's free memory at creation, and kmp_batch_memory says what was taken.
+ * table_retry: 1 = when the arena measures slow whatever the layout and the device has room for a second one, try one more and
+ * keep the faster (the other is freed before the call returns: the one transient allocation creation can make); 0 = never
+ * (-1 = KMP_TABLE_RETRY, else 0). */
+typedef struct kmp_batch_options { uint32_t struct_bytes; int team_lanes; int table_span_gib; int table_retry; } kmp_batch_options;
+KMP_API int kmp_batch_create_ex(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes,
+                                const kmp_batch_options* opts);
+/* Device memory the context holds right now, by part, in bytes (sets allocated on a first use count once they exist): arena =
+ * the one allocation of a large context (arena_used = its parts without the span's gaps), workspace = the separate allocations of
+ * a small one plus the per-team / per-slice words, other_tables = the flat tables of levels 1 / 2 / the dictionary parser, level
+ * 4's sets and a dictionary's tables, block_chain = the per-slice state of contexts for slices above 128 KiB, decode_staging =
+ * what the pre-decoders leave (shared by the zstd decoder and inflate), deflate_workspace = link / match / symbol arrays. */
+typedef struct kmp_batch_memory_info { uint32_t struct_bytes; uint32_t reserved; size_t arena, arena_used, workspace, other_tables, block_chain, decode_staging, deflate_workspace, total; } kmp_batch_memory_info;
+KMP_API int kmp_batch_memory(kmp_batch_ctx* ctx, kmp_batch_memory_info* info);
 KMP_API void kmp_batch_destroy(kmp_batch_ctx* ctx);
 /* Status bits (KMP_STATUS_*) raised by the batches run on this context since the last call; waits for `hip_stream`,
  * then clears them.  Returns KMP_OK, KMP_ERR_CAPACITY (a slice was too large) or KMP_ERR_KERNEL; *bits may be NULL.
@@ -166,6 +184,21 @@ KMP_API int kmp_zstd_compress_batch(kmp_batch_ctx* ctx,
                                     uint32_t n,
                                     void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                     void* hip_stream);
+
+/* The same batch in `pieces` (1 .. 8) parts that run side by side, part p on hip_streams[p]: what a caller whose slices arrive over
+ * PCIe (or from another rank) uses to overlap the copies with the kernels.  Part p covers the slices kmp_batch_piece_range(n, pieces, p)
+ * names; its kernels are queued behind whatever the caller has queued on hip_streams[p] (the copy that brings those slices in) and the
+ * caller queues what takes the part's frames away behind them (kmp_compact_batch on the part's range, the copy out).  The parts own
+ * disjoint parts of the context's team slots and workspace, so a later part joins the earlier ones on the device instead of waiting for
+ * them: the device fills up as the batch arrives.  d_in_off / d_in_len / d_out_off must be complete when the call is made (they are
+ * small); frames are bit for bit kmp_zstd_compress_batch's.  Level 3, slices up to 128 KiB.  The next batch on the context, on whatever
+ * stream, waits for all parts. */
+KMP_API void kmp_batch_piece_range(uint32_t n, uint32_t pieces, uint32_t piece, uint32_t* first, uint32_t* count);
+KMP_API int kmp_zstd_compress_batch_pieces(kmp_batch_ctx* ctx,
+                                           const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                           uint32_t n,
+                                           void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
+                                           uint32_t pieces, void* const* hip_streams);
 
 /* Streaming frames: what libzstd writes when a slice arrives through ZSTD_e_continue calls (finish = false:
  * SliceTransformRawSource.kt:32-55, BaseSliceTransformContentEncoder.kt:23-54) and is closed with ZSTD_e_end -- the size

@@ -27,9 +27,13 @@ SIGNATURES = [
     ("kmp_zstd_get_error_name", _c.c_char_p, [_c.c_size_t]),
     ("kmp_zstd_compress_bound", _c.c_size_t, [_c.c_size_t]),
     ("kmp_batch_create", _c.c_int, [_c.POINTER(_P), _c.c_int, _c.c_uint32, _c.c_uint32, _c.c_int]),
+    ("kmp_batch_create_ex", _c.c_int, [_c.POINTER(_P), _c.c_int, _c.c_uint32, _c.c_uint32, _P]),
+    ("kmp_batch_memory", _c.c_int, [_P, _P]),
     ("kmp_batch_destroy", None, [_P]),
     ("kmp_batch_status", _c.c_int, [_P, _c.POINTER(_c.c_uint32), _P]),
     ("kmp_zstd_compress_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P]),
+    ("kmp_batch_piece_range", None, [_c.c_uint32, _c.c_uint32, _c.c_uint32, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_uint32)]),
+    ("kmp_zstd_compress_batch_pieces", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_uint32, _P]),
     ("kmp_zstd_compress_batch_stream", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_int, _P]),
     ("kmp_zstd_compress_batch_stream_level", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_int, _c.c_int, _P]),
     ("kmp_zstd_compress_batch_level", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_int, _P]),
@@ -66,17 +70,45 @@ SIGNATURES = [
     ("kmp_version", _c.c_char_p, []),
 ]
 
+ABL_LIB_PATH = os.path.join(HERE, "libkompressor_hip_abl.so")    # the same sources built with -DKMP_ABLATIONS (kompressor_amd/build.py)
+
+
+
+class BatchOptions(_c.Structure):          # kmp_batch_options
+    _fields_ = [("struct_bytes", _c.c_uint32), ("team_lanes", _c.c_int), ("table_span_gib", _c.c_int), ("table_retry", _c.c_int)]
+
+
+class BatchMemoryInfo(_c.Structure):       # kmp_batch_memory_info
+    _fields_ = [("struct_bytes", _c.c_uint32), ("reserved", _c.c_uint32)] + [(k, _c.c_size_t) for k in
+                ("arena", "arena_used", "workspace", "other_tables", "block_chain", "decode_staging", "deflate_workspace", "total")]
+
+
 _lib = None
+_abl = None
+
+
+def load_ablations():
+    """The ablation build of the same library (the second level-3 parser, the fused kernel, every experiment knob as an
+    environment variable) as a second handle in this process: what the tests of those paths and the A/B tools use
+    (ZstdBatch(..., ablations=True)).  Never what the package's codecs run on."""
+    global _abl
+    if _abl is None:
+        _abl = _open(ABL_LIB_PATH)
+    return _abl
 
 
 def load():
     """Load (once) and return the HIP backend. Raises if it is not built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+def _open(path):
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m kompressor_amd.build` "
+            f"{path} is missing: build it with `python -m kompressor_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     # PyTorch ships its own ROCm runtime (torch/lib/libamdhip64.so).  Two HIP runtimes in one process do not share devices:
     # if this library pulled in /opt/rocm's copy first, torch would come up later with its own and kmp_batch_create
@@ -86,12 +118,11 @@ def load():
         import torch  # noqa: F401
     except Exception:
         pass
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, res, args in SIGNATURES:
         fn = getattr(lib, name)          # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
 
 

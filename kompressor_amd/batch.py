@@ -67,19 +67,27 @@ class ZstdBatch:
     """Owns the device workspace for batches of up to `max_slices` slices of up to
     `max_slice_bytes` bytes (<= 128 KiB) on one GPU."""
 
-    def __init__(self, max_slices, max_slice_bytes=65536, device=None, team_lanes=0):
-        self.lib = _lib.load()
+    def __init__(self, max_slices, max_slice_bytes=65536, device=None, team_lanes=0, ablations=False, table_span_gib=None, table_retry=None):
+        """table_span_gib / table_retry: kmp_batch_options (None = the environment's KMP_TABLE_SPAN_GIB / KMP_TABLE_RETRY, else the
+        library's defaults: a span of 100 GiB bounded by half of the free memory, no second arena)."""
+        # ablations=True: the library's ablation build (tests and A/B tools only: kompressor_amd/_lib.py load_ablations)
+        self.lib = _lib.load_ablations() if ablations else _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("kompressor_amd needs a ROCm GPU (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.max_slices = max_slices
         self.max_slice_bytes = max_slice_bytes
         h = ctypes.c_void_p()
-        rc = self.lib.kmp_batch_create(ctypes.byref(h), self.device.index, max_slices, max_slice_bytes, team_lanes)
+        opts = _lib.BatchOptions(ctypes.sizeof(_lib.BatchOptions), team_lanes, -1 if table_span_gib is None else int(table_span_gib),
+                                 -1 if table_retry is None else int(table_retry))
+        rc = self.lib.kmp_batch_create_ex(ctypes.byref(h), self.device.index, max_slices, max_slice_bytes, ctypes.byref(opts))
         if rc != 0:
-            raise RuntimeError(f"kmp_batch_create failed ({rc}): {_lib.last_error()}")
+            raise RuntimeError(f"kmp_batch_create failed ({rc}): {self._err()}")
         self._h = h
         self.out_stride = (compress_bound(max_slice_bytes) + 8 + 63) & ~63
+
+    def _err(self):
+        return self.lib.kmp_last_error().decode()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -103,11 +111,18 @@ class ZstdBatch:
         rc = self.lib.kmp_batch_status(self._h, ctypes.byref(bits), self._stream())
         return rc, bits.value
 
+    def memory(self):
+        """kmp_batch_memory: device bytes the context holds right now, by part (a dict)."""
+        m = _lib.BatchMemoryInfo(); m.struct_bytes = ctypes.sizeof(m)
+        if self.lib.kmp_batch_memory(self._h, ctypes.byref(m)) != 0:
+            raise RuntimeError(self._err())
+        return {k: int(getattr(m, k)) for k, _ in m._fields_[2:]}
+
     def table_rates(self):
         """(random loads per second, load + store pairs per second) over this context's level-3 team tables, measured at creation."""
         r, q = ctypes.c_float(), ctypes.c_float()
         if self.lib.kmp_batch_table_rates(self._h, ctypes.byref(r), ctypes.byref(q)) != 0:
-            raise RuntimeError(_lib.last_error())
+            raise RuntimeError(self._err())
         return r.value, q.value
 
     def set_profiling(self, on=True):
@@ -117,7 +132,7 @@ class ZstdBatch:
         ms = ctypes.c_float()
         rc = self.lib.kmp_batch_last_kernel_ms(self._h, which, ctypes.byref(ms))
         if rc != 0:
-            raise RuntimeError(_lib.last_error())
+            raise RuntimeError(self._err())
         return ms.value
 
     def last_chunks(self):
@@ -129,7 +144,7 @@ class ZstdBatch:
         holds, a parser guard) instead of handing back frames of length 0."""
         rc, bits = self.status()
         if rc != 0:
-            raise RuntimeError(f"{what}: status bits {bits:#x} ({rc}): {_lib.last_error()}")
+            raise RuntimeError(f"{what}: status bits {bits:#x} ({rc}): {self._err()}")
 
     def compress(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, dictionary=None, level=3, streaming=None, reference=False, check=False):
         """src: uint8 device tensor; in_off int64, in_len int32 device tensors (n each).  dictionary: bytes of a
@@ -171,10 +186,34 @@ class ZstdBatch:
             rc = self.lib.kmp_zstd_compress_batch(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n,
                                                   _ptr(dst), _ptr(out_off), _ptr(out_len), self._stream())
         if rc != 0:
-            raise RuntimeError(f"kmp_zstd_compress_batch failed ({rc}): {_lib.last_error()}")
+            raise RuntimeError(f"kmp_zstd_compress_batch failed ({rc}): {self._err()}")
         if check:
             self._check("kmp_zstd_compress_batch")
         return dst, out_off, out_len
+
+    def piece_range(self, n, pieces, piece):
+        """(first, count) of part `piece` of an n-slice batch cut into `pieces` (kmp_batch_piece_range)."""
+        a, b = ctypes.c_uint32(), ctypes.c_uint32()
+        self.lib.kmp_batch_piece_range(n, pieces, piece, ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    def compress_pieces(self, src, in_off, in_len, dst, out_off, out_len, streams):
+        """kmp_zstd_compress_batch_pieces: the level-3 batch in len(streams) parts that run side by side, part p queued on the torch
+        stream streams[p] behind whatever the caller queued there (the copy that brings the part's slices in)."""
+        n = in_len.numel()
+        arr = (ctypes.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
+        rc = self.lib.kmp_zstd_compress_batch_pieces(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n, _ptr(dst), _ptr(out_off), _ptr(out_len), len(streams), arr)
+        if rc != 0:
+            raise RuntimeError(f"kmp_zstd_compress_batch_pieces failed ({rc}): {self._err()}")
+        return dst, out_off, out_len
+
+    def compact_piece(self, src, in_off, lens, first, count, dst, offs, stream):
+        """Dense packing of one part on `stream`: frames first .. first + count of the strided layout go to dst (a buffer of the part's
+        own) back to back; offs (int64, count + 1 entries) receives the exclusive scan, offs[count] the part's bytes."""
+        rc = self.lib.kmp_compact_batch(self._h, _ptr(src), ctypes.c_void_p(in_off.data_ptr() + 8 * first), ctypes.c_void_p(lens.data_ptr() + 4 * first), count,
+                                        _ptr(dst), _ptr(offs), ctypes.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"kmp_compact_batch failed ({rc}): {self._err()}")
 
     def decompress(self, src, in_off, in_len, out_cap, dst=None, out_off=None, dictionary=None):
         """Frames -> slices.  out_cap: int32 device tensor of per-frame capacities.  dictionary: uint8 device tensor
@@ -196,7 +235,7 @@ class ZstdBatch:
                                                     _ptr(dst), _ptr(out_off), _ptr(out_cap), _ptr(out_len), _ptr(status),
                                                     self._stream())
         if rc != 0:
-            raise RuntimeError(f"kmp_zstd_decompress_batch failed ({rc}): {_lib.last_error()}")
+            raise RuntimeError(f"kmp_zstd_decompress_batch failed ({rc}): {self._err()}")
         return dst, out_off, out_len, status
 
     _FORMATS = {"raw": 0, "zlib": 1, "gzip": 2, "auto": 3}
@@ -215,7 +254,7 @@ class ZstdBatch:
         rc = self.lib.kmp_inflate_batch(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n, _ptr(dst), _ptr(out_off), _ptr(out_cap),
                                         _ptr(out_len), _ptr(status), fmt, self._stream())
         if rc != 0:
-            raise RuntimeError(f"kmp_inflate_batch failed ({rc}): {_lib.last_error()}")
+            raise RuntimeError(f"kmp_inflate_batch failed ({rc}): {self._err()}")
         return dst, out_off, out_len, status
 
     def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, zlib_wrapper=False, format=None, level=6, check=False):   # noqa: A002
@@ -239,7 +278,7 @@ class ZstdBatch:
             rc = self.lib.kmp_deflate_compress_batch_level(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n, _ptr(dst), _ptr(out_off), _ptr(out_len),
                                                            fmt, level, self._stream())
         if rc != 0:
-            raise RuntimeError(f"kmp_deflate_compress_batch failed ({rc}): {_lib.last_error()}")
+            raise RuntimeError(f"kmp_deflate_compress_batch failed ({rc}): {self._err()}")
         if check:
             self._check("kmp_deflate_compress_batch")
         return dst, out_off, out_len
@@ -247,7 +286,7 @@ class ZstdBatch:
     def deflate_kernel_ms(self):
         ms = (ctypes.c_float * 4)()
         if self.lib.kmp_deflate_last_kernel_ms(self._h, ms) != 0:
-            raise RuntimeError(_lib.last_error())
+            raise RuntimeError(self._err())
         return dict(zip(("k_deflate_chains", "k_deflate_best", "k_deflate_parse", "k_deflate_encode"), (float(x) for x in ms)))
 
     def compact_into(self, src, in_off, lens, dst, offs):
@@ -258,7 +297,7 @@ class ZstdBatch:
             raise ValueError("offs needs n + 1 entries")
         rc = self.lib.kmp_compact_batch(self._h, _ptr(src), _ptr(in_off), _ptr(lens), n, _ptr(dst), _ptr(offs), self._stream())
         if rc != 0:
-            raise RuntimeError(f"kmp_compact_batch failed ({rc}): {_lib.last_error()}")
+            raise RuntimeError(f"kmp_compact_batch failed ({rc}): {self._err()}")
         return dst, offs
 
     def compact(self, src, in_off, lens):
@@ -269,5 +308,5 @@ class ZstdBatch:
         dst = torch.empty(total_cap + 64, dtype=torch.uint8, device=self.device)
         rc = self.lib.kmp_compact_batch(self._h, _ptr(src), _ptr(in_off), _ptr(lens), n, _ptr(dst), _ptr(offs), self._stream())
         if rc != 0:
-            raise RuntimeError(f"kmp_compact_batch failed ({rc}): {_lib.last_error()}")
+            raise RuntimeError(f"kmp_compact_batch failed ({rc}): {self._err()}")
         return dst, offs

@@ -1,8 +1,10 @@
 """Builds the in-tree native libraries (no torch extension machinery needed:
 the product boundary is a plain C ABI).
 
-  libkompressor_hip.so  hipcc, gfx950 only   -- the product
-  libkmpcorpus.so       gcc                   -- seeded synthetic corpus (bench + tests)
+  libkompressor_hip.so      hipcc, gfx950 only   -- the product: csrc/kmp_batch.hip + kmp_deflate.hip + kmp_stream.hip
+  libkompressor_hip_abl.so  the same sources with -DKMP_ABLATIONS: the second level-3 parser, the fused kernel and the
+                            experiment knobs as environment variables (what the tests of those paths and the A/B tools load)
+  libkmpcorpus.so           gcc                   -- seeded synthetic corpus (bench + tests)
 """
 import os
 import shutil
@@ -13,6 +15,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 
 HIP_LIB = os.path.join(HERE, "libkompressor_hip.so")
+HIP_LIB_ABL = os.path.join(HERE, "libkompressor_hip_abl.so")
+HIP_UNITS = ("kmp_batch.hip", "kmp_deflate.hip", "kmp_stream.hip")
+OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 CORPUS_LIB = os.path.join(HERE, "libkmpcorpus.so")
 
 
@@ -30,17 +35,27 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the kompressor_amd backend needs ROCm to build")
 
 
-def build_hip(force=False, verbose=False):
+def build_hip(force=False, verbose=False, ablations=False):
+    """The translation units are compiled side by side (one hipcc each) and linked into one shared object."""
+    target = HIP_LIB_ABL if ablations else HIP_LIB
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(ROOT, "include", "kompressor_hip.h"))
-    if not force and not _newer(HIP_LIB, srcs):
-        return HIP_LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
-           "-o", HIP_LIB, os.path.join(CSRC, "kmp_api.hip")]
+    if not force and not _newer(target, srcs):
+        return target
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + (["-DKMP_ABLATIONS"] if ablations else [])
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.run(cmd, check=True)
-    return HIP_LIB
+        flags.append("-Rpass-analysis=kernel-resource-usage")
+    objs, procs = [], []
+    for unit in HIP_UNITS:
+        obj = os.path.join(OBJ_DIR, unit.replace(".hip", "_abl.o" if ablations else ".o"))
+        objs.append(obj)
+        procs.append((unit, subprocess.Popen([_hipcc()] + flags + ["-c", "-o", obj, os.path.join(CSRC, unit)])))
+    for unit, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, f"hipcc -c {unit}")
+    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", target] + objs, check=True)
+    return target
 
 
 def build_corpus(force=False):
@@ -88,6 +103,7 @@ def build_jni(force=False):
 
 def build_all(force=False, verbose=False):
     libs = build_hip(force, verbose), build_corpus(force)
+    build_hip(force, verbose, ablations=True)
     build_jni(force)
     return libs
 

@@ -1,47 +1,47 @@
-// kmp_api.hip -- host side of libkompressor_hip.so: kernel entry points for
-// gfx950, workspace management, the batched API and the streaming-compatible
-// single-slice API declared in include/kompressor_hip.h.
+// kmp_batch.hip -- the zstd half of libkompressor_hip.so's batched device API (include/kompressor_hip.h part 2): kernel entry
+// points for gfx950, the batch context and its workspace, kmp_zstd_compress_batch* / kmp_zstd_decompress_batch*,
+// kmp_compact_batch.  The DEFLATE half is kmp_deflate.hip, the streaming-compatible API kmp_stream.hip.
 #include "kx_wave.h"
 #include "zstd_match.h"
+#ifdef KMP_ABLATIONS
 #include "zstd_match2.h"
+#endif
 #include "zstd_entropy.h"
 #include "zstd_match_dict.h"
 #include "zstd_match_fast.h"
 #include "zstd_cdict_host.h"
 #include "zstd_decode.h"
 #include "zstd_predecode.h"
-#include "deflate_match.h"
-#include "deflate_encode.h"
-#include "deflate_decode.h"
-#include "deflate_predecode.h"
-#include "../../include/kompressor_hip.h"
+#include "deflate_match.h"          // (KdBest & co.: the context frees the DEFLATE workspace)
+#include "kmp_internal.h"
 
 #include <mutex>
 #include <new>
-#include <string>
 #include <vector>
-#include <string.h>
-#include <stdio.h>
-#include <stdlib.h>
 
 // --------------------------------------------------------------------------
 // kernels (one 64-lane wave per workgroup everywhere)
 // --------------------------------------------------------------------------
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match(KMatchArgs a) { zstd_match_body<G>(a); }
+#ifdef KMP_ABLATIONS
 // the same parse as a split-phase stage machine (zstd_match2.h): one memory round trip per outer iteration
 template <int G, int R>
 __global__ __launch_bounds__(64, 4) void k_zstd_match2(KMatchArgs a) { zstd_match2_body<G, R>(a); }
+#endif
 __global__ __launch_bounds__(64, 4) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
+#ifdef KMP_ABLATIONS
 // parse and entropy stage in one launch (zstd_entropy.h: zstd_l3_fused_body)
 template <int G>
 __global__ __launch_bounds__(64, 4) void k_zstd_l3_fused(KMatchArgs a, KEntropyArgs e) { zstd_l3_fused_body<G>(a, e); }
+#endif
 // levels 1 and 2 (strategy "fast")
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match_fast(KFastArgs a) { zstd_match_fast_body<G>(a); }
 // the parse when the context holds a raw-content dictionary
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match_dict(KDictArgs a) { zstd_match_dict_body<G>(a); }
+#ifdef KMP_ABLATIONS
 // frames of several blocks (slices above 128 KiB): one block of every unfinished slice per launch
 template <int G>
 __global__ __launch_bounds__(64) void k_zstd_match_blk(KMatchArgs a)
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(64) void k_zstd_match_blk(KMatchArgs a)
     zstd_match_ext_body<G>(a);
 }
 __global__ __launch_bounds__(64, 4) void k_zstd_frame(KFrameArgs a) { zstd_frame_body(a); }
+#endif
 // ... or the whole chain of blocks of a slice by one wave (no host rounds)
 template <int G>
 __global__ __launch_bounds__(64, 3) void k_zstd_big(KBigArgs a) { zstd_big_body<G>(a); }
@@ -86,17 +87,6 @@ __global__ __launch_bounds__(64) void k_zstd_lit_predecode(KLitArgs a) { zstd_li
 __global__ __launch_bounds__(256) void k_zstd_seq_count(KSeqSortArgs a) { zstd_seq_count_body(a); }
 __global__ __launch_bounds__(256) void k_zstd_seq_rank(KSeqSortArgs a) { zstd_seq_rank_body(a); }
 __global__ __launch_bounds__(256) void k_zstd_seq_perm(KSeqSortArgs a) { zstd_seq_perm_body(a); }
-
-__global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chains_body<u16>(a); }          // slices <= 64 KiB
-__global__ __launch_bounds__(256) void k_deflate_chains_long(KdArgs a) { deflate_chains_body<u32>(a); }
-__global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_body(a); }
-__global__ __launch_bounds__(64) void k_deflate_parse(KdArgs a) { deflate_parse_body(a); }
-__global__ __launch_bounds__(64) void k_deflate_fast(KdArgs a) { deflate_fast_body(a); }
-__global__ __launch_bounds__(64, 2) void k_inflate_predecode(KipArgs a) { inflate_predecode_body(a); }
-__global__ __launch_bounds__(64) void k_inflate_exec(KieArgs a) { inflate_exec_body(a); }
-__global__ __launch_bounds__(64, 4) void k_deflate_encode(KdArgs a) { deflate_encode_body(a); }
-__global__ __launch_bounds__(64, 5) void k_inflate(KiArgs a) { inflate_body(a); }
-
 // exclusive prefix sum of u32 lengths into u64 offsets, single workgroup
 __global__ __launch_bounds__(1024) void k_scan_lengths(const u32* len, u32 n, u64* off)
 {
@@ -158,13 +148,12 @@ __global__ __launch_bounds__(256) void k_len_guard_finish(const u32* in_len, u32
 // --------------------------------------------------------------------------
 // errors
 // --------------------------------------------------------------------------
-static thread_local std::string g_last_error;
-static int hip_fail(hipError_t e, const char* what)
+thread_local std::string g_last_error;
+int hip_fail(hipError_t e, const char* what)
 {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);
     return KMP_ERR_HIP;
 }
-#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
 
 extern "C" const char* kmp_last_error(void) { return g_last_error.c_str(); }
 
@@ -225,54 +214,7 @@ __global__ __launch_bounds__(64) void k_table_probe(u32* p0, u32* p1, u32* p2, u
 }
 extern "C" const char* kmp_version(void) { return "kompressor_hip 0.3 (gfx950; zstd levels 1-3: frames and streams up to 1 GiB, raw-content dictionaries; level 4 in its double-fast size classes, negative levels up to 512 KiB; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
 
-// --------------------------------------------------------------------------
-// batch context
-// --------------------------------------------------------------------------
-enum { KMP_MAX_CHUNKS = 4 };
-struct kmp_batch_ctx {
-    int device; u32 max_slices, max_slice_bytes; int G; int team_fixed; int table_retry = 0; u32 match_blocks, match_blocks_l3, nteams, l3_team_slots;
-    u32 seq_cap, lit_cap, scratch_words;
-    KSeq* seqs; u8* lits; KSliceMeta* meta; u32* scratch; u32* tables; u32* team_epoch; u32* counter;
-    int profiling; hipEvent_t ev[14]; int ev_valid[7];
-    // zstd compress pipeline: entropy coding of chunk i (second stream) runs beside the match kernel of chunk i+1
-    // level 3, batches of more than half the team slots: one launch of each kernel or two chunks?  Tried once each on the
-    // context's first two such batches (whole-step HIP events), then the faster stays -- the parse kernel's time differs
-    // by 17 % between runs of the same box, and which setting wins depends on it.
-    u32* tables_flat; u32* team_epoch_flat;     // levels 1 / 2 and the dictionary parser: one piece (they wait for latency and are slower over spread tables), allocated on first use when the level-3 tables are spread
-    u32* tseg[4]; u32 tseg_n;                   // the team tables in four pieces spread over the context's arena (or tseg_n == 1: tables alone)
-    u32* tables4 = nullptr; u32* epoch4 = nullptr; u32 teams4 = 0;      // level 4's table set (1 MiB per team), allocated by the first level-4 batch
-    u32* big_tables4 = nullptr;                 // ... and on the block-chain path: 2 MiB per slice (2^18 + 2^18 entries)
-    u32 table_layout;                           // which of the arena's layouts holds the table pieces (1 .. 8; 0: no arena)
-    u8* arena; size_t arena_bytes;              // one allocation that holds seqs / lits / meta / scratch and the table pieces (else null: separate allocations)
-    float place_ms; u32 place_tried;            // the team tables' placement: probe time of the region kept, candidates tried
-    float table_reads_per_s, table_pairs_per_s; // random loads / load + store pairs per second over this context's team tables (k_table_probe at creation; 0 = not measured)
-    int tune_state; int tune_pending; u32 tune_pick; float tune_ms[2]; hipEvent_t tune_ev[2];
-    hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join, ev_last_match; int have_last_match; u32 last_chunks;
-    hipEvent_t ev_pre[KMP_MAX_CHUNKS + 1];      // decoder: [0] where the caller's stream stands, [1 + i] piece i pre-decoded
-    // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
-    u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta;      // two halves of dfl_chunk slices each
-    u32* dfl_fsyms; KdSliceMeta* dfl_fmeta; KdBlockInfo* dfl_fblocks; int dfl_ftried;          // levels 1 .. 3: symbols / blocks of 4 * dfl_chunk slices (one piece)
-    u32 dfl_pos_cap, dfl_blk_cap; KdBlockInfo* dfl_blocks;                                      // positions / blocks per slice in them
-    hipEvent_t dfl_searched[2], dfl_done[2]; int dfl_events;
-    // frames of several blocks (max_slice_bytes above 128 KiB): per-slice state carried between the block rounds
-    // raw-content dictionary of the last kmp_zstd_compress_batch_dict call: device copy + CDict tables (built on the host)
-    u8* d_dict; u32* d_dictL; u32* d_dictS; u32 dict_size; u64 dict_hash; u32 cdW, cdH, cdC, cdM;
-    int big; int big_G; KFrameState* fstate; u32* hufct; u32* big_tables; u32* remaining; u32* big_counters; u32 last_rounds;
-    u32 cus;                                   // compute units of the device
-    // decoder: sequences decoded ahead of k_zstd_decode (allocated on first use; pre_tried: do not try again)
-    u64* pre_stage; KPreBlk* pre_blk; u32* pre_nblk; u32 pre_seq_cap, pre_blk_cap; int pre_tried;
-    u32 pre_slices;                             // entries the staging areas hold (a larger batch is decoded in pieces)
-    u32* pre_sort;                              // per staged entry: key, slot -> entry map; then 256 bucket counters
-    u8* pre_lits; KPreLit* pre_lit; u32* pre_nlit; u32 pre_lit_cap;
-    u32* len_ok; u32* d_status;                // sanitised slice lengths of the running batch; status word (KMP_STATUS_*)
-    // one batch at a time per context: a batch queued on another stream waits for the previous one's last kernel
-    hipEvent_t ev_done; int have_done;
-    // experiment switches, read from the environment once, when the context is created
-    struct { u32 chunks, match_flags, entropy_pad, first_permille, fast_first_permille, entropy_flags, decode_flags, decode_pad, big_rounds, big_spw,
-                 dfl_chunk, dfl_chain_waves, dfl_serial, dfl_flags, decode_pre, decode_sort, decode_pieces, decode_stage_slices, inflate_pre, inflate_pieces, autotune, match_v2, fuse; } knob;
-};
-
-static u32 env_u32(const char* name, u32 dflt)
+u32 env_u32(const char* name, u32 dflt)
 {
     const char* v = getenv(name);
     return (v && *v) ? (u32)strtoul(v, nullptr, 10) : dflt;
@@ -287,7 +229,7 @@ static u32 env_u32(const char* name, u32 dflt)
 // memory behind its caller's back.
 static int place_alloc(u32** out, size_t bytes, float* kept_ms, u32* tried_out)
 {
-    u32 tries = env_u32("KMP_PLACE_TRIES", 1); if (tries < 1) tries = 1; if (tries > 8) tries = 8;
+    u32 tries = KMP_KNOB("KMP_PLACE_TRIES", 1); if (tries < 1) tries = 1; if (tries > 8) tries = 8;
     if (bytes < ((size_t)4 << 30)) tries = 1;
     u32* cand[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; float ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     u32 got = 0, best = 0;
@@ -300,7 +242,7 @@ static int place_alloc(u32** out, size_t bytes, float* kept_ms, u32* tried_out)
         if (ms[t] <= 26.0f) break;
     }
     if (got == 0) return hip_fail(hipErrorOutOfMemory, "hipMalloc(parser tables)");
-    if (env_u32("KMP_PLACE_VERBOSE", 0)) { fprintf(stderr, "place_alloc %zu MiB:", bytes >> 20); for (u32 t = 0; t < got; t++) fprintf(stderr, " %.1f ms%s", ms[t], t == best ? "*" : ""); fprintf(stderr, "\n"); }
+    if (env_u32("KMP_VERBOSE", 0)) { fprintf(stderr, "place_alloc %zu MiB:", bytes >> 20); for (u32 t = 0; t < got; t++) fprintf(stderr, " %.1f ms%s", ms[t], t == best ? "*" : ""); fprintf(stderr, "\n"); }
     for (u32 t = 0; t < got; t++) if (t != best) (void)hipFree(cand[t]);
     *out = cand[best];
     if (kept_ms) *kept_ms = ms[best];
@@ -308,10 +250,10 @@ static int place_alloc(u32** out, size_t bytes, float* kept_ms, u32* tried_out)
     return KMP_OK;
 }
 
-static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes);
+struct create_opts { int span_gib; int retry; };          // -1 = the environment's / the default
+static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes, create_opts const& o);
 extern "C" void kmp_batch_destroy(kmp_batch_ctx* c);
-static thread_local int g_create_packed = 0;        // batch_create_packed: this creation packs its arena whatever KMP_TABLE_SPAN_GIB says
-extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes)
+static int batch_create_with(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes, create_opts const& o)
 {
     if (!out || max_slices == 0) { g_last_error = "kmp_batch_create: bad argument"; return KMP_ERR_ARG; }
     if (max_slice_bytes > KMP_MAX_BIG_SLICE_BYTES) { g_last_error = "kmp_batch_create: slices above 1 GiB are not supported"; return KMP_ERR_CAPACITY; }
@@ -323,24 +265,36 @@ extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_sl
     if (!c) { g_last_error = "out of host memory"; return KMP_ERR_ARG; }
     memset(c, 0, sizeof(*c));
     c->team_fixed = team_fixed;
-    int const rc = batch_create_body(c, device, max_slices, max_slice_bytes, team_lanes);
+    int const rc = batch_create_body(c, device, max_slices, max_slice_bytes, team_lanes, o);
     if (rc != KMP_OK) { std::string const keep = g_last_error; kmp_batch_destroy(c); g_last_error = keep; return rc; }      // nothing half-built is left behind
     *out = c;
     return KMP_OK;
 }
-// a context whose arena is packed (the engines of the host-memory batch: kmp_coalesce.h)
-static int batch_create_packed(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes)
+extern "C" int kmp_batch_create(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes)
 {
-    g_create_packed = 1;
-    int const rc = kmp_batch_create(out, device, max_slices, max_slice_bytes, 0);
-    g_create_packed = 0;
-    return rc;
+    create_opts const o = { -1, -1 };
+    return batch_create_with(out, device, max_slices, max_slice_bytes, team_lanes, o);
 }
-static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes)
+extern "C" int kmp_batch_create_ex(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes, const kmp_batch_options* opts)
+{
+    if (!opts || opts->struct_bytes < sizeof(kmp_batch_options)) { g_last_error = "kmp_batch_create_ex: options missing or of another version"; return KMP_ERR_ARG; }
+    create_opts const o = { opts->table_span_gib, opts->table_retry };
+    return batch_create_with(out, device, max_slices, max_slice_bytes, opts->team_lanes, o);
+}
+// a context whose arena is packed (the engines of the host-memory batch: kmp_coalesce.h)
+int batch_create_packed(kmp_batch_ctx** out, int device, uint32_t max_slices, uint32_t max_slice_bytes)
+{
+    create_opts const o = { 0, 0 };
+    return batch_create_with(out, device, max_slices, max_slice_bytes, 0, o);
+}
+static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, uint32_t max_slice_bytes, int team_lanes, create_opts const& o)
 {
     c->device = device; c->max_slices = max_slices; c->max_slice_bytes = max_slice_bytes < 64 ? 64 : max_slice_bytes; c->G = team_lanes;
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
-    u32 const waves_per_cu = env_u32("KMP_MATCH_WAVES_PER_CU", 16);     // 16 x 16 teams x 256 CUs = 65 536 slices in flight at team width 4
+    // the context's own stream: the second stream of its pipelines, and where creation's probes and clears run (non-blocking:
+    // nothing here serialises with the caller's streams, the NULL stream included)
+    HIP_TRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+    u32 const waves_per_cu = KMP_KNOB("KMP_MATCH_WAVES_PER_CU", 16);     // 16 x 16 teams x 256 CUs = 65 536 slices in flight at team width 4
     u32 const teams_per_wave = 64 / (u32)team_lanes;
     u32 blocks = (u32)prop.multiProcessorCount * waves_per_cu;
     u32 const need = (max_slices + teams_per_wave - 1) / teams_per_wave;
@@ -350,13 +304,13 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
     // 49 152 team slots, a 65 536-slice batch in two launches with the entropy kernel of the first beside the second: 251 ms.
     // That optimum belonged to an entropy kernel that was a third slower than it had to be (zstd_common.h kx_xcd_chunk);
     // with it fixed, one launch of each kernel at 16 waves per CU takes 191 + 27 ms.)
-    { u32 const l3 = (u32)prop.multiProcessorCount * env_u32("KMP_MATCH_WAVES_PER_CU_L3", 16); c->match_blocks_l3 = l3 < blocks ? l3 : blocks; c->l3_team_slots = l3 * teams_per_wave; }
+    { u32 const l3 = (u32)prop.multiProcessorCount * KMP_KNOB("KMP_MATCH_WAVES_PER_CU_L3", 16); c->match_blocks_l3 = l3 < blocks ? l3 : blocks; c->l3_team_slots = l3 * teams_per_wave; }
     c->big = c->max_slice_bytes > KMP_MAX_SLICE_BYTES;
     u32 const block_cap = c->big ? KMP_MAX_SLICE_BYTES : c->max_slice_bytes;     // the sequence / literal workspaces hold one block
     c->seq_cap = (block_cap / 4 + 8 + 15) & ~15u; c->lit_cap = block_cap + 64; c->scratch_words = block_cap / 4 + 64;
     size_t const ns = max_slices;
     if (c->big) {
-        c->big_G = (int)env_u32("KMP_BIG_TEAM_LANES", 0);      // 0 = by batch size (zstd_compress_big)
+        c->big_G = (int)KMP_KNOB("KMP_BIG_TEAM_LANES", 0);      // 0 = by batch size (zstd_compress_big)
         if (c->big_G != 0 && c->big_G != 2 && c->big_G != 4 && c->big_G != 8 && c->big_G != 16 && c->big_G != 32 && c->big_G != 64) c->big_G = 0;
         HIP_TRY(hipMalloc((void**)&c->fstate, ns * sizeof(KFrameState)));
         HIP_TRY(hipMalloc((void**)&c->hufct, ns * 512 * sizeof(u32)));
@@ -367,30 +321,32 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
     {
         // The workspace of a context with large team tables is ONE allocation (an arena): the tables in four pieces (team t:
         // piece t & 3) with the sequence, literal and staging buffers between them, laid out over a span of
-        // KMP_TABLE_SPAN_GIB (default 100) GiB.  Why a span: read + insert pairs run a quarter faster when they straddle
-        // the coarse blocks this device's HBM is laid out in -- 20 G pairs/s inside any 24 .. 36 GiB, 25 - 26 from 72 GiB of
-        // span on (tools/spanprobe, profiles/r03_match_floor.txt) -- and the parser lives on that rate: the same context
-        // takes 205 ms per batch with its 41 GiB packed (232 over 60 GiB on one box: all four pieces inside one block),
-        // 194 with separate allocations wherever they land, 183 - 190 over 100 - 140 GiB on every box tried; 80 GiB gave
-        // 182 on one box and 206 on another (where the blocks' boundaries fall differs), so the default is 100, with two
-        // pieces at either end of the arena.
-        // Nothing is allocated transiently: what creation takes is what the context holds, the gaps between the parts
-        // included (59 GiB of a 65 536-slice context's 100).  KMP_TABLE_SPAN_GIB=0 packs the arena (memory over ~11 % of
-        // parser time); a device without that much free memory gets the packed form by itself.
-        // KMP_TABLE_ARENA=0, small tables: separate allocations, tables in one piece.
+        // KMP_TABLE_SPAN_GIB / kmp_batch_options.table_span_gib (default 100) GiB.  Why a span: read + insert pairs run a quarter
+        // faster when they straddle the coarse blocks this device's HBM is laid out in -- 20 G pairs/s inside any 24 .. 36 GiB,
+        // 25 - 26 from 72 GiB of span on (tools/spanprobe, profiles/r03_match_floor.txt) -- and the parser lives on that rate:
+        // the same context takes 205 ms per batch with its 41 GiB packed, 183 - 190 over 100 - 140 GiB on every box tried.
+        // The gaps between the parts are memory the context holds and does not use (59 GiB of a 65 536-slice context's 100), so
+        // the span is BOUNDED: never more than half of what the device has free when the context is created (a second context,
+        // the caller's own buffers and the host engines must still fit: ADVICE r3); below the parts' own size the arena is
+        // packed.  Span 0 packs it (memory over ~11 % of parser time).  kmp_batch_memory reports what the context holds.
+        // A second arena is tried only on request (KMP_TABLE_RETRY=1 / table_retry: when the first measures slow whatever the
+        // layout -- some allocations land on slower memory, 212 ms instead of 189 -- and the device has room for both; one of
+        // the two is freed before creation returns).  That is the one transient allocation creation can make, hence opt-in;
+        // bench.py asks for it and says so in its line.
         size_t const tbytes = (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32);
         size_t const A = (size_t)2 << 20;                                // every part starts on a 2 MiB boundary
         auto up = [&](size_t v) { return (v + A - 1) & ~(A - 1); };
         size_t const seqs_b = up(ns * c->seq_cap * sizeof(KSeq)), lits_b = up(ns * c->lit_cap), meta_b = up(ns * sizeof(KSliceMeta)), scr_b = up(ns * c->scratch_words * sizeof(u32));
         c->tseg_n = 1;
-        if (env_u32("KMP_TABLE_ARENA", 1) && tbytes >= ((size_t)4 << 30) && (c->nteams & 3u) == 0) {
+        if (KMP_KNOB("KMP_TABLE_ARENA", 1) && tbytes >= ((size_t)4 << 30) && (c->nteams & 3u) == 0) {
             size_t const piece = up(tbytes / 4);
             size_t const need = 4 * piece + seqs_b + lits_b + meta_b + scr_b;
-            size_t want = g_create_packed ? 0 : ((size_t)env_u32("KMP_TABLE_SPAN_GIB", 100) << 30);
+            size_t want = (size_t)(o.span_gib >= 0 ? (u32)o.span_gib : env_u32("KMP_TABLE_SPAN_GIB", 100)) << 30;
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
+            if (want > fr / 2) want = fr / 2;                               // bounded: at most half of the free memory
             if (want > need && fr < want + ((size_t)16 << 30)) want = 0;    // not that much room: pack
-            size_t const gap = want > need ? up((want - need) / 3) : 0;     // unused bytes behind each of the three buffers between the pieces
+            size_t const gap = want > need ? ((want - need) / 3) & ~(A - 1) : 0;     // unused bytes behind each of the three buffers between the pieces (rounded down: the span is a bound)
             size_t const total = need + 3 * gap;
             if (fr > total + ((size_t)1 << 30) && hipMalloc((void**)&c->arena, total) == hipSuccess) {
                 c->arena_bytes = total;
@@ -431,7 +387,7 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
                     add(up(total / 16), up(total / 16 * 5), up(total / 16 * 9), up(total / 16 * 13));               // 8: one piece in every quarter
                 }
                 u32 pick = 0;
-                u32 const fixed = env_u32("KMP_TABLE_LAYOUT", 0);
+                u32 const fixed = KMP_KNOB("KMP_TABLE_LAYOUT", 0);
                 // probes every layout on the arena at `base`: the fastest one (priced with the parser's own mix) and its pair rate
                 auto probe_arena = [&](u8* base, u32* best_l, float* best_ms, float* best_pairs) -> int {
                     hipEvent_t e[3] = { nullptr, nullptr, nullptr };
@@ -440,19 +396,19 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
                     int rc = KMP_OK; *best_ms = 1e30f; *best_l = 0; *best_pairs = 0;
                     for (u32 l = 0; l < nlay && rc == KMP_OK; l++) {
                         u32* t[4]; for (int i = 0; i < 4; i++) t[i] = (u32*)(base + lay[l][i]);
-                        hipLaunchKernelGGL(k_table_probe, dim3(pb), dim3(64), 0, 0, t[0], t[1], t[2], t[3], 4u, words, 4u, 1u, t[0]);       // warm (TLB)
-                        bool ok = hipEventRecord(e[0], 0) == hipSuccess;
-                        hipLaunchKernelGGL(k_table_probe, dim3(pb), dim3(64), 0, 0, t[0], t[1], t[2], t[3], 4u, words, 96u, 1u, t[0]);
-                        ok = ok && hipEventRecord(e[1], 0) == hipSuccess;
-                        hipLaunchKernelGGL(k_table_probe, dim3(pb), dim3(64), 0, 0, t[0], t[1], t[2], t[3], 4u, words, 96u, 0u, t[0]);
-                        ok = ok && hipEventRecord(e[2], 0) == hipSuccess && hipEventSynchronize(e[2]) == hipSuccess;
+                        hipLaunchKernelGGL(k_table_probe, dim3(pb), dim3(64), 0, c->st2, t[0], t[1], t[2], t[3], 4u, words, 4u, 1u, t[0]);       // warm (TLB)
+                        bool ok = hipEventRecord(e[0], c->st2) == hipSuccess;
+                        hipLaunchKernelGGL(k_table_probe, dim3(pb), dim3(64), 0, c->st2, t[0], t[1], t[2], t[3], 4u, words, 96u, 1u, t[0]);
+                        ok = ok && hipEventRecord(e[1], c->st2) == hipSuccess;
+                        hipLaunchKernelGGL(k_table_probe, dim3(pb), dim3(64), 0, c->st2, t[0], t[1], t[2], t[3], 4u, words, 96u, 0u, t[0]);
+                        ok = ok && hipEventRecord(e[2], c->st2) == hipSuccess && hipEventSynchronize(e[2]) == hipSuccess;
                         float msp = 0, msr = 0;
                         ok = ok && hipEventElapsedTime(&msp, e[0], e[1]) == hipSuccess && hipEventElapsedTime(&msr, e[1], e[2]) == hipSuccess;
                         if (!ok) { g_last_error = "kmp_batch_create: probing the arena failed"; rc = KMP_ERR_HIP; break; }
                         // the parser's own mix: per batch 3.97 G probe + insert pairs and 1.80 G reads that insert nothing (profiles/pmc_latest.json)
                         float const ms = 3.97f * msp + 1.80f * msr;
                         float const pairs = (float)((double)pb * 64.0 * 96.0 * 4.0 / (msp * 1e-3));
-                        if (env_u32("KMP_PLACE_VERBOSE", 0)) fprintf(stderr, "arena %p layout %u: %.1f G pairs/s, %.1f G reads/s\n", (void*)base, l + 1, pairs / 1e9, (double)pb * 64.0 * 96.0 * 4.0 / (msr * 1e-3) / 1e9);
+                        if (env_u32("KMP_VERBOSE", 0)) fprintf(stderr, "arena %p layout %u: %.1f G pairs/s, %.1f G reads/s\n", (void*)base, l + 1, pairs / 1e9, (double)pb * 64.0 * 96.0 * 4.0 / (msr * 1e-3) / 1e9);
                         if (ms < *best_ms) { *best_ms = ms; *best_l = l; *best_pairs = pairs; }
                     }
                     for (int i = 0; i < 3; i++) (void)hipEventDestroy(e[i]);
@@ -464,17 +420,18 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
                     { int const rc = probe_arena(c->arena, &pick, &ms1, &pr1); if (rc != KMP_OK) return rc; }
                     // Some allocations are slow whatever the layout (one box: every second process, 21.7 G pairs/s at best against
                     // 25; the parser then takes 212 ms instead of 189 -- which physical memory the allocator hands out is not ours to
-                    // choose).  When that happens and the device has room for a second arena beside the first, ONE more is
-                    // allocated and probed, the faster of the two stays and the other is freed before creation returns
-                    // (KMP_TABLE_RETRY=0: never; 2: always, for the tests).
+                    // choose).  On request (table_retry / KMP_TABLE_RETRY = 1), when that happens and the device has room for a second
+                    // arena beside the first, ONE more is allocated and probed, the faster of the two stays and the other is freed
+                    // before creation returns (0: never, the default; 2: always, for the tests).
                     size_t fr2 = 0, tot2 = 0;
-                    if ((pr1 < (float)env_u32("KMP_TABLE_RETRY_BELOW", 235) * 1e8f || env_u32("KMP_TABLE_RETRY", 1) == 2) && env_u32("KMP_TABLE_RETRY", 1) && hipMemGetInfo(&fr2, &tot2) == hipSuccess && fr2 > total + ((size_t)16 << 30)) {
+                    u32 const retry = o.retry >= 0 ? (u32)o.retry : env_u32("KMP_TABLE_RETRY", 0);     // 0 never (the default), 1 when slow, 2 always (tests)
+                    if ((pr1 < (float)KMP_KNOB("KMP_TABLE_RETRY_BELOW", 235) * 1e8f || retry == 2) && retry && hipMemGetInfo(&fr2, &tot2) == hipSuccess && fr2 > total + ((size_t)16 << 30)) {
                         u8* second = nullptr;
                         if (hipMalloc((void**)&second, total) == hipSuccess) {
                             u32 pick2 = 0; float ms2 = 0, pr2 = 0;
                             int const rc = probe_arena(second, &pick2, &ms2, &pr2);
                             if (rc != KMP_OK) { (void)hipFree(second); return rc; }
-                            if (env_u32("KMP_PLACE_VERBOSE", 0)) fprintf(stderr, "arena retry: %.1f -> %.1f G pairs/s\n", pr1 / 1e9, pr2 / 1e9);
+                            if (env_u32("KMP_VERBOSE", 0)) fprintf(stderr, "arena retry: %.1f -> %.1f G pairs/s\n", pr1 / 1e9, pr2 / 1e9);
                             if (ms2 < ms1 * 0.98f) { (void)hipFree(c->arena); c->arena = second; pick = pick2; c->table_retry = 2; }
                             else { (void)hipFree(second); c->table_retry = 1; }
                         } else (void)hipGetLastError();
@@ -498,17 +455,17 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
     }
     HIP_TRY(hipMalloc((void**)&c->team_epoch, (size_t)c->nteams * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->counter, 64));
-    if ((size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32) >= ((size_t)4 << 30) && env_u32("KMP_TABLE_PROBE", 1)) {
+    if ((size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32) >= ((size_t)4 << 30) && KMP_KNOB("KMP_TABLE_PROBE", 1)) {
         // ~40 ms: the two rates the parser lives on, measured on these very tables (they are zeroed right below)
         hipEvent_t e[3]; for (int i = 0; i < 3; i++) HIP_TRY(hipEventCreate(&e[i]));
         u64 const words = (u64)c->nteams * KX_TBL_ENTRIES / c->tseg_n; u32 const blocks = (u32)prop.multiProcessorCount * 16u, iters = 96u;
         u32* const t1 = c->tseg_n == 4 ? c->tseg[1] : c->tseg[0]; u32* const t2 = c->tseg_n == 4 ? c->tseg[2] : c->tseg[0]; u32* const t3 = c->tseg_n == 4 ? c->tseg[3] : c->tseg[0];
-        hipLaunchKernelGGL(k_table_probe, dim3(blocks), dim3(64), 0, 0, c->tseg[0], t1, t2, t3, c->tseg_n, words, 8u, 1u, c->counter);     // warm (TLB)
-        HIP_TRY(hipEventRecord(e[0], 0));
-        hipLaunchKernelGGL(k_table_probe, dim3(blocks), dim3(64), 0, 0, c->tseg[0], t1, t2, t3, c->tseg_n, words, iters, 0u, c->counter);
-        HIP_TRY(hipEventRecord(e[1], 0));
-        hipLaunchKernelGGL(k_table_probe, dim3(blocks), dim3(64), 0, 0, c->tseg[0], t1, t2, t3, c->tseg_n, words, iters, 1u, c->counter);
-        HIP_TRY(hipEventRecord(e[2], 0));
+        hipLaunchKernelGGL(k_table_probe, dim3(blocks), dim3(64), 0, c->st2, c->tseg[0], t1, t2, t3, c->tseg_n, words, 8u, 1u, c->counter);     // warm (TLB)
+        HIP_TRY(hipEventRecord(e[0], c->st2));
+        hipLaunchKernelGGL(k_table_probe, dim3(blocks), dim3(64), 0, c->st2, c->tseg[0], t1, t2, t3, c->tseg_n, words, iters, 0u, c->counter);
+        HIP_TRY(hipEventRecord(e[1], c->st2));
+        hipLaunchKernelGGL(k_table_probe, dim3(blocks), dim3(64), 0, c->st2, c->tseg[0], t1, t2, t3, c->tseg_n, words, iters, 1u, c->counter);
+        HIP_TRY(hipEventRecord(e[2], c->st2));
         HIP_TRY(hipEventSynchronize(e[2]));
         float ms0 = 0, ms1 = 0; HIP_TRY(hipEventElapsedTime(&ms0, e[0], e[1])); HIP_TRY(hipEventElapsedTime(&ms1, e[1], e[2]));
         double const ops = (double)blocks * 64.0 * iters * 4.0;
@@ -516,34 +473,34 @@ static int batch_create_body(kmp_batch_ctx* c, int device, uint32_t max_slices, 
         if (ms1 > 0) c->table_pairs_per_s = (float)(ops / (ms1 * 1e-3));
         for (int i = 0; i < 3; i++) (void)hipEventDestroy(e[i]);
     }
-    for (u32 i = 0; i < c->tseg_n; i++) HIP_TRY(hipMemset(c->tseg[i], 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32) / c->tseg_n));
-    HIP_TRY(hipMemset(c->team_epoch, 0, (size_t)c->nteams * sizeof(u32)));
-    HIP_TRY(hipMemset(c->meta, 0, ns * sizeof(KSliceMeta)));
+    for (u32 i = 0; i < c->tseg_n; i++) HIP_TRY(hipMemsetAsync(c->tseg[i], 0, (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32) / c->tseg_n, c->st2));
+    HIP_TRY(hipMemsetAsync(c->team_epoch, 0, (size_t)c->nteams * sizeof(u32), c->st2));
+    HIP_TRY(hipMemsetAsync(c->meta, 0, ns * sizeof(KSliceMeta), c->st2));
     for (int i = 0; i < 14; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
-    HIP_TRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { HIP_TRY(hipEventCreate(&c->evm[i][j])); HIP_TRY(hipEventCreate(&c->eve[i][j])); }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&c->tune_ev[0])); HIP_TRY(hipEventCreate(&c->tune_ev[1]));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_last_match, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    for (int i = 0; i < KMP_MAX_PIECES; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_piece[i], hipEventDisableTiming));
     for (int i = 0; i <= KMP_MAX_CHUNKS; i++) HIP_TRY(hipEventCreateWithFlags(&c->ev_pre[i], hipEventDisableTiming));
     c->cus = (u32)prop.multiProcessorCount;
     HIP_TRY(hipMalloc((void**)&c->len_ok, ns * sizeof(u32)));
     HIP_TRY(hipMalloc((void**)&c->d_status, 64));
-    HIP_TRY(hipMemset(c->d_status, 0, 64));
-    c->knob.chunks = env_u32("KMP_ZSTD_CHUNKS", 0); c->knob.match_flags = env_u32("KMP_MATCH_FLAGS", 6); c->knob.entropy_pad = env_u32("KMP_ENTROPY_PAD_LDS", 0);
-    c->knob.first_permille = env_u32("KMP_ZSTD_FIRST_PERMILLE", 500); c->knob.fast_first_permille = env_u32("KMP_ZSTD_FAST_FIRST_PERMILLE", 550); c->knob.entropy_flags = env_u32("KMP_ENTROPY_FLAGS", 0);
-    c->knob.decode_flags = env_u32("KMP_DECODE_FLAGS", 0); c->knob.decode_pad = env_u32("KMP_DECODE_PAD_LDS", 0);
-    c->knob.big_rounds = env_u32("KMP_BIG_ROUNDS", 0); c->knob.big_spw = env_u32("KMP_BIG_SLICES_PER_WAVE", 0);
-    c->knob.dfl_chunk = env_u32("KMP_DEFLATE_CHUNK", 16384u); c->knob.dfl_chain_waves = env_u32("KMP_DEFLATE_CHAIN_WAVES", 4);
-    c->knob.dfl_serial = env_u32("KMP_DEFLATE_SERIAL", 0); c->knob.dfl_flags = env_u32("KMP_DEFLATE_FLAGS", 0);
+    HIP_TRY(hipMemsetAsync(c->d_status, 0, 64, c->st2));
+    c->knob.chunks = KMP_KNOB("KMP_ZSTD_CHUNKS", 0); c->knob.match_flags = KMP_KNOB("KMP_MATCH_FLAGS", 6); c->knob.entropy_pad = KMP_KNOB("KMP_ENTROPY_PAD_LDS", 0);
+    c->knob.first_permille = KMP_KNOB("KMP_ZSTD_FIRST_PERMILLE", 500); c->knob.fast_first_permille = KMP_KNOB("KMP_ZSTD_FAST_FIRST_PERMILLE", 550); c->knob.entropy_flags = KMP_KNOB("KMP_ENTROPY_FLAGS", 0);
+    c->knob.decode_flags = KMP_KNOB("KMP_DECODE_FLAGS", 0); c->knob.decode_pad = KMP_KNOB("KMP_DECODE_PAD_LDS", 0);
+    c->knob.big_rounds = KMP_KNOB("KMP_BIG_ROUNDS", 0); c->knob.big_spw = KMP_KNOB("KMP_BIG_SLICES_PER_WAVE", 0);
+    c->knob.dfl_chunk = env_u32("KMP_DEFLATE_CHUNK", 16384u); c->knob.dfl_chain_waves = KMP_KNOB("KMP_DEFLATE_CHAIN_WAVES", 4);
+    c->knob.dfl_serial = KMP_KNOB("KMP_DEFLATE_SERIAL", 0); c->knob.dfl_flags = KMP_KNOB("KMP_DEFLATE_FLAGS", 0);
     // the decoder's pre-decode kernels (on by default for batches of KMP_PRE_MIN_BATCH = 256 entries or more, DESIGN.md section
     // 4.3): bit 0 = sequences decoded ahead of k_zstd_decode (k_zstd_seq_predecode, one lane per frame), bit 1 = literals
     // (k_zstd_lit_predecode, one lane per stream)
-    c->knob.decode_pre = env_u32("KMP_DECODE_PRE", 3); c->knob.decode_sort = env_u32("KMP_DECODE_SORT", 1); c->knob.decode_pieces = env_u32("KMP_DECODE_PIECES", 1); c->knob.decode_stage_slices = env_u32("KMP_DECODE_STAGE_SLICES", 0); c->knob.inflate_pre = env_u32("KMP_INFLATE_PRE", 1); c->knob.inflate_pieces = env_u32("KMP_INFLATE_PIECES", 1); c->knob.autotune = env_u32("KMP_ZSTD_AUTOTUNE", 0);      // opt-in: one launch or two chunks, tried once each (two blocking event reads on the 2nd / 3rd batch)
-    c->knob.fuse = env_u32("KMP_FUSE", 0);                             // 1: k_zstd_l3_fused (the entropy stage inside the parse kernel's waves)
-    c->knob.match_v2 = env_u32("KMP_MATCH_V2", 0);                     // 0: zstd_match.h (the default: 4 % faster, both sit on the same memory floor); 1: zstd_match2.h; 2: with a 512-byte window at team width 4
-    HIP_TRY(hipDeviceSynchronize());
+    c->knob.decode_pre = KMP_KNOB("KMP_DECODE_PRE", 3); c->knob.decode_sort = KMP_KNOB("KMP_DECODE_SORT", 1); c->knob.decode_pieces = KMP_KNOB("KMP_DECODE_PIECES", 1); c->knob.decode_stage_slices = env_u32("KMP_DECODE_STAGE_SLICES", 0); c->knob.inflate_pre = KMP_KNOB("KMP_INFLATE_PRE", 1); c->knob.inflate_pieces = KMP_KNOB("KMP_INFLATE_PIECES", 1); c->knob.autotune = KMP_KNOB("KMP_ZSTD_AUTOTUNE", 0);      // opt-in: one launch or two chunks, tried once each (two blocking event reads on the 2nd / 3rd batch)
+    c->knob.fuse = KMP_KNOB("KMP_FUSE", 0);                             // 1: k_zstd_l3_fused (the entropy stage inside the parse kernel's waves)
+    c->knob.match_v2 = KMP_KNOB("KMP_MATCH_V2", 0);                     // 0: zstd_match.h (the default: 4 % faster, both sit on the same memory floor); 1: zstd_match2.h; 2: with a 512-byte window at team width 4
+    HIP_TRY(hipStreamSynchronize(c->st2));
     return KMP_OK;
 }
 
@@ -563,6 +520,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     for (int i = 0; i < 2; i++) if (c->tune_ev[i]) (void)hipEventDestroy(c->tune_ev[i]);
     if (c->ev_last_match) (void)hipEventDestroy(c->ev_last_match);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    for (int i = 0; i < KMP_MAX_PIECES; i++) if (c->ev_piece[i]) (void)hipEventDestroy(c->ev_piece[i]);
     for (int i = 0; i <= KMP_MAX_CHUNKS; i++) if (c->ev_pre[i]) (void)hipEventDestroy(c->ev_pre[i]);
     (void)hipFree(c->len_ok); (void)hipFree(c->d_status);
     (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); (void)hipFree(c->pre_sort);
@@ -572,6 +530,31 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     (void)hipFree(c->dfl_fsyms); (void)hipFree(c->dfl_fmeta); (void)hipFree(c->dfl_fblocks);
     if (c->dfl_events) for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->dfl_searched[i]); (void)hipEventDestroy(c->dfl_done[i]); }
     delete c;
+}
+
+/* What the context holds on the device right now, by part (bytes): the arena (or the separate workspace allocations), the other
+ * table sets, the decoders' staging, the DEFLATE workspace, the block-chain state.  Sets allocated on first use count once they exist. */
+extern "C" int kmp_batch_memory(kmp_batch_ctx* c, kmp_batch_memory_info* info)
+{
+    if (!c || !info || info->struct_bytes < sizeof(kmp_batch_memory_info)) { g_last_error = "kmp_batch_memory: bad argument"; return KMP_ERR_ARG; }
+    size_t const ns = c->max_slices;
+    kmp_batch_memory_info m; memset(&m, 0, sizeof m); m.struct_bytes = sizeof m;
+    size_t const tbytes = (size_t)c->nteams * KX_TBL_ENTRIES * sizeof(u32);
+    if (c->arena) { m.arena = c->arena_bytes; m.arena_used = tbytes + ns * c->seq_cap * sizeof(KSeq) + ns * c->lit_cap + ns * sizeof(KSliceMeta) + ns * c->scratch_words * sizeof(u32); }
+    else { m.arena = 0; m.arena_used = 0; m.workspace = tbytes + ns * c->seq_cap * sizeof(KSeq) + ns * c->lit_cap + ns * sizeof(KSliceMeta) + ns * c->scratch_words * sizeof(u32); }
+    m.workspace += (size_t)c->nteams * sizeof(u32) + ns * sizeof(u32) + 192;
+    if (c->tables_flat) m.other_tables += tbytes + (size_t)c->nteams * sizeof(u32);
+    if (c->tables4) m.other_tables += (size_t)c->teams4 * KX_TBL4_ENTRIES * sizeof(u32) + (size_t)c->teams4 * sizeof(u32);
+    if (c->big_tables4) m.other_tables += ns * KX_BIG4_ENTRIES * sizeof(u32);
+    if (c->d_dict) m.other_tables += c->dict_size + 64 + ((size_t)4 << c->cdH) + ((size_t)4 << c->cdC);
+    if (c->big) m.block_chain = ns * sizeof(KFrameState) + ns * 512 * sizeof(u32) + ns * KX_BIG_TBL_ENTRIES * sizeof(u32) + ns * 4 + 64;
+    if (c->pre_stage) m.decode_staging += (size_t)c->pre_slices * c->pre_seq_cap * 8u + (size_t)c->pre_slices * c->pre_blk_cap * sizeof(KPreBlk) + (size_t)c->pre_slices * 4u + ((size_t)c->pre_slices * 2u + KXP_SORT_BUCKETS) * 4u;
+    if (c->pre_lits) m.decode_staging += (size_t)c->pre_slices * c->pre_lit_cap + (size_t)c->pre_slices * c->pre_blk_cap * sizeof(KPreLit) + (size_t)c->pre_slices * 4u;
+    if (c->dfl_link) m.deflate_workspace += (size_t)2 * c->dfl_chunk * c->dfl_pos_cap * (sizeof(u16) + sizeof(KdBest) + sizeof(u32)) + (size_t)2 * c->dfl_chunk * (sizeof(KdSliceMeta) + (size_t)c->dfl_blk_cap * sizeof(KdBlockInfo));
+    if (c->dfl_fsyms) m.deflate_workspace += (size_t)4 * c->dfl_chunk * ((size_t)c->dfl_pos_cap * sizeof(u32) + sizeof(KdSliceMeta) + (size_t)c->dfl_blk_cap * sizeof(KdBlockInfo));
+    m.total = m.arena + m.workspace + m.other_tables + m.block_chain + m.decode_staging + m.deflate_workspace;
+    *info = m;
+    return KMP_OK;
 }
 
 extern "C" int kmp_batch_set_profiling(kmp_batch_ctx* c, int on) { if (!c) return KMP_ERR_ARG; c->profiling = on; return KMP_OK; }
@@ -619,7 +602,7 @@ extern "C" int kmp_batch_status(kmp_batch_ctx* c, uint32_t* bits, void* hip_stre
     if (!c) { g_last_error = "kmp_batch_status: null context"; return KMP_ERR_ARG; }
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
-    if (c->have_done) HIP_TRY(hipStreamWaitEvent(st, c->ev_done, 0));
+    KMP_TRY(batch_wait_previous(c, st));
     // read and clear in ONE atomic exchange: a bit raised by a batch on another stream between a copy and a memset would be lost
     u32 v = 0;
     hipLaunchKernelGGL(k_status_take, dim3(1), dim3(1), 0, st, c->d_status, c->d_status + 1);
@@ -635,31 +618,35 @@ extern "C" int kmp_batch_status(kmp_batch_ctx* c, uint32_t* bits, void* hip_stre
 
 // A batch begins: it waits for the previous batch of this context (whatever stream that ran on), and its kernels get
 // the sanitised lengths (k_len_guard).  A batch ends: oversized slices lose their frames, the event is recorded.
-static int batch_begin(kmp_batch_ctx* c, hipStream_t st, const u32* d_in_len, u32 n, u32 cap)
+int batch_wait_previous(kmp_batch_ctx* c, hipStream_t st)
 {
     if (c->have_done) HIP_TRY(hipStreamWaitEvent(st, c->ev_done, 0));
+    for (u32 p = 0; p < c->pieces_pending; p++) HIP_TRY(hipStreamWaitEvent(st, c->ev_piece[p], 0));
+    return KMP_OK;
+}
+int batch_begin(kmp_batch_ctx* c, hipStream_t st, const u32* d_in_len, u32 n, u32 cap)
+{
+    KMP_TRY(batch_wait_previous(c, st));
     if (d_in_len) {
         hipLaunchKernelGGL(k_len_guard, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, cap, c->len_ok, c->d_status);
         HIP_TRY(hipGetLastError());
     }
     return KMP_OK;
 }
-static int batch_end(kmp_batch_ctx* c, hipStream_t st, const u32* d_in_len, u32 n, u32 cap, u32* d_out_len, const KSliceMeta* meta)
+int batch_end(kmp_batch_ctx* c, hipStream_t st, const u32* d_in_len, u32 n, u32 cap, u32* d_out_len, const KSliceMeta* meta)
 {
     if (d_in_len) {
         hipLaunchKernelGGL(k_len_guard_finish, dim3((n + 255) / 256), dim3(256), 0, st, d_in_len, n, cap, d_out_len, meta, c->d_status);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(c->ev_done, st)); c->have_done = 1;
+    HIP_TRY(hipEventRecord(c->ev_done, st)); c->have_done = 1; c->pieces_pending = 0;      // (this batch waited for the pieces before it)
     return KMP_OK;
 }
-#define KMP_TRY(x) do { int r_ = (x); if (r_ != KMP_OK) return r_; } while (0)
 
 extern "C" size_t kmp_zstd_compress_bound(size_t n)
 {
     return n + (n >> 8) + ((n < (128u << 10)) ? (((128u << 10) - n) >> 11) : 0);
 }
-
 // the tables of the one-position-per-step parsers (levels 1 / 2, dictionary): the level-3 tables when those are one piece,
 // else a piece of their own with its own epochs (measured over the spread tables: level 1 19.8 GB/s against 23.9)
 static int flat_tables(kmp_batch_ctx* c, u32** tables, u32** epochs)
@@ -677,8 +664,6 @@ static int flat_tables(kmp_batch_ctx* c, u32** tables, u32** epochs)
 }
 
 // ---- levels 1 and 2 -------------------------------------------------------------------------------------
-static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct = 0, u32 fast_step0 = 0, bool level4 = false);
 static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream, int level);
 extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
@@ -809,8 +794,8 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
 // one block of every unfinished slice; block sizes depend on the bytes already produced (ZSTD_optimalBlockSize),
 // so the rounds are sequential and the host only reads back how many frames are still open.
 // stream: KFrameArgs.stream (0 ZSTD_compress2's frames, 1 / 2 streaming frames, 3 the reference's one-shot driver)
-static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct, u32 fast_step0, bool level4)
+int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                      uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct, u32 fast_step0, bool level4)
 {
     bool const streaming = stream == 1 || stream == 2;
     const uint32_t* const d_in_len_caller = d_in_len;
@@ -846,7 +831,10 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     e.fast_step0 = strategy == 1u ? fast_step0 : 0u;         // a negative level: the level-1 machinery (window 2^19) on row 0 of the tables, a step of 1 - level, raw literals
     e.tail_direct = stream == 3 ? 0u : tail_direct; e.out_chunk = stream == 3 ? tail_direct : 0u;      // (one parameter: the mode says which it is)
     e.status_word = c->d_status;
-    if (strategy || c->knob.big_rounds == 0) {
+#ifdef KMP_ABLATIONS
+    if (strategy || c->knob.big_rounds == 0)
+#endif
+    {
         // one wave per slice walks its chain of blocks
         // few slices: one per wave (most waves); many: up to 64 / G per wave so that all of them are in flight
         KBigArgs g; g.m = m; g.e = e; g.counters = c->big_counters;
@@ -899,6 +887,7 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
         c->last_rounds = 0; c->last_chunks = 1;
         return batch_end(c, st, d_in_len_caller, n, c->max_slice_bytes, d_out_len, nullptr);
     }
+#ifdef KMP_ABLATIONS
     // (experiment switch KMP_BIG_ROUNDS=1) the same steps as separate launches per round of blocks
     int const bigR = c->big_G ? c->big_G : 8;
     u32 const tpw = 64 / (u32)bigR;
@@ -925,6 +914,9 @@ static int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t
     }
     c->last_rounds = rounds; c->last_chunks = 1;
     return batch_end(c, st, d_in_len_caller, n, c->max_slice_bytes, d_out_len, nullptr);
+#else
+    g_last_error = "zstd_compress_big: unreachable"; return KMP_ERR_ARG;
+#endif
 }
 /* Streaming frames: what libzstd writes when a slice arrives through finish = false calls and is closed with
  * finish = true (size unknown when the frame starts).  empty_end: the closing calls brought no data.  The context must
@@ -1061,6 +1053,8 @@ static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64
         e.seqs = m.seqs; e.seq_cap = c->seq_cap; e.lits = c->lits + (size_t)first * c->lit_cap; e.lit_cap = c->lit_cap; e.meta = m.meta;
         e.scratch = c->scratch + (size_t)first * c->scratch_words; e.scratch_words = c->scratch_words;
         e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = c->knob.entropy_flags | ((m.flags & 4u) ? 8u : 0u);
+#ifdef KMP_ABLATIONS
+        // the ablation build's other two forms of the level-3 step: the split-phase parser, the fused kernel
         bool const fuse = c->knob.fuse && !c->knob.match_v2 && !l4 && (G == 4 || G == 8);
         if (fuse) {
             if (G == 4) hipLaunchKernelGGL(k_zstd_l3_fused<4>, dim3(blocks), dim3(64), 0, st, m, e);
@@ -1075,6 +1069,9 @@ static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64
             default: hipLaunchKernelGGL((k_zstd_match2<8, 512>), dim3(blocks), dim3(64), 0, st, m); break;
             }
         } else
+#else
+        bool const fuse = false;
+#endif
         switch (G) {
         case 2:  hipLaunchKernelGGL(k_zstd_match<2>, dim3(blocks), dim3(64), 0, st, m); break;
         case 4:  hipLaunchKernelGGL(k_zstd_match<4>, dim3(blocks), dim3(64), 0, st, m); break;
@@ -1099,6 +1096,73 @@ static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64
     if (tunable && c->tune_state < 2) { HIP_TRY(hipEventRecord(c->tune_ev[1], st)); c->tune_pending = 1; }
     return batch_end(c, st, d_in_len, n, c->max_slice_bytes, d_out_len, c->meta);
 }
+// ---- a batch in pieces, each on a stream of its own ---------------------------------------------------------------------
+// What a caller with HOST memory needs (every caller of the reference's boundary starts and ends there): the slices arrive over
+// PCIe while earlier ones are being compressed, the frames leave while later ones still are.  One launch over the whole batch
+// cannot start before its last slice is in; pieces run one after the other lose what makes this parser fast -- every slice in
+// flight (16 384 slices alone take 73 ms, 65 536 together 187).  So the pieces of one batch run SIDE BY SIDE: piece p's kernels
+// go to hip_streams[p] (behind whatever the caller queued there: its copy in), own the p-th part of the context's team slots
+// (KMatchArgs.block_base) and of its workspace, and the device fills up as the pieces arrive.
+extern "C" void kmp_batch_piece_range(uint32_t n, uint32_t pieces, uint32_t piece, uint32_t* first, uint32_t* count)
+{
+    if (pieces == 0) pieces = 1;
+    auto cut = [&](u32 p) -> u32 { return p >= pieces ? n : (u32)(((u64)n * p / pieces) & ~63ull); };
+    u32 const a = cut(piece), b = cut(piece + 1);
+    if (first) *first = a;
+    if (count) *count = b > a ? b - a : 0u;
+}
+extern "C" int kmp_zstd_compress_batch_pieces(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
+                                              void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, uint32_t pieces, void* const* hip_streams)
+{
+    if (!c || !hip_streams || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_pieces: null argument"; return KMP_ERR_ARG; }
+    if (pieces < 1 || pieces > KMP_MAX_PIECES) { g_last_error = "kmp_zstd_compress_batch_pieces: 1 .. 8 pieces"; return KMP_ERR_ARG; }
+    if (c->big) { g_last_error = "kmp_zstd_compress_batch_pieces: contexts for slices up to 128 KiB only"; return KMP_ERR_CAPACITY; }
+    if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_pieces: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
+    if (n == 0) return KMP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    u32 const tpw = 64 / (u32)c->G;
+    u32 const blocks_per_piece = c->match_blocks_l3 / pieces;
+    if (blocks_per_piece == 0) { g_last_error = "kmp_zstd_compress_batch_pieces: more pieces than the context has workgroups"; return KMP_ERR_ARG; }
+    // every stream first waits for whatever ran on this context before (a batch, or the pieces of one) ...
+    for (u32 p = 0; p < pieces; p++) KMP_TRY(batch_wait_previous(c, (hipStream_t)hip_streams[p]));
+    // ... then gets its piece
+    for (u32 p = 0; p < pieces; p++) {
+        hipStream_t const st = (hipStream_t)hip_streams[p];
+        u32 first = 0, m_n = 0; kmp_batch_piece_range(n, pieces, p, &first, &m_n);
+        if (m_n == 0) { HIP_TRY(hipEventRecord(c->ev_piece[p], st)); continue; }
+        hipLaunchKernelGGL(k_len_guard, dim3((m_n + 255) / 256), dim3(256), 0, st, d_in_len + first, m_n, c->max_slice_bytes, c->len_ok + first, c->d_status);
+        HIP_TRY(hipMemsetAsync(c->counter + p, 0, 4, st));
+        KMatchArgs m;
+        m.src = (const u8*)d_src; m.in_off = d_in_off + first; m.in_len = c->len_ok + first; m.n_slices = m_n;
+        m.seqs = c->seqs + (size_t)first * c->seq_cap; m.seq_cap = c->seq_cap; m.meta = c->meta + first;
+        m.lits = c->lits + (size_t)first * c->lit_cap; m.lit_cap = c->lit_cap;
+        m.tables = c->tables; for (int ts_ = 0; ts_ < 4; ts_++) m.tseg[ts_] = c->tseg[ts_]; m.tseg_n = c->tseg_n; m.team_epoch = c->team_epoch;
+        m.counter = c->counter + p; m.flags = c->knob.match_flags; m.block_base = p * blocks_per_piece;
+        u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > blocks_per_piece) blocks = blocks_per_piece;
+        switch (c->G) {
+        case 2:  hipLaunchKernelGGL(k_zstd_match<2>, dim3(blocks), dim3(64), 0, st, m); break;
+        case 4:  hipLaunchKernelGGL(k_zstd_match<4>, dim3(blocks), dim3(64), 0, st, m); break;
+        case 8:  hipLaunchKernelGGL(k_zstd_match<8>, dim3(blocks), dim3(64), 0, st, m); break;
+        case 16: hipLaunchKernelGGL(k_zstd_match<16>, dim3(blocks), dim3(64), 0, st, m); break;
+        case 32: hipLaunchKernelGGL(k_zstd_match<32>, dim3(blocks), dim3(64), 0, st, m); break;
+        default: hipLaunchKernelGGL(k_zstd_match<64>, dim3(blocks), dim3(64), 0, st, m); break;
+        }
+        HIP_TRY(hipGetLastError());
+        KEntropyArgs e;
+        e.src = (const u8*)d_src; e.in_off = d_in_off + first; e.in_len = c->len_ok + first; e.n_slices = m_n;
+        e.seqs = m.seqs; e.seq_cap = c->seq_cap; e.lits = m.lits; e.lit_cap = c->lit_cap; e.meta = m.meta;
+        e.scratch = c->scratch + (size_t)first * c->scratch_words; e.scratch_words = c->scratch_words;
+        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = c->knob.entropy_flags | ((m.flags & 4u) ? 8u : 0u);
+        hipLaunchKernelGGL(k_zstd_entropy, dim3(m_n), dim3(64), 0, st, e);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_len_guard_finish, dim3((m_n + 255) / 256), dim3(256), 0, st, d_in_len + first, m_n, c->max_slice_bytes, d_out_len + first, c->meta + first, c->d_status);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_piece[p], st));
+    }
+    c->have_done = 0; c->pieces_pending = pieces; c->last_chunks = pieces;
+    return KMP_OK;
+}
+
 extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                        uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
 {
@@ -1109,8 +1173,8 @@ extern "C" int kmp_zstd_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
 // the literals): allocated on the first call that wants it, for as many entries as 48 GiB hold (all of them for the bench's
 // batches; a larger batch goes through in pieces, one after the other, that reuse the staging).  Shared by the zstd decoder
 // and inflate.
-static u32 env_pre_min_batch() { static u32 const v = env_u32("KMP_PRE_MIN_BATCH", 256); return v; }
-static void ensure_pre_staging(kmp_batch_ctx* c)
+u32 env_pre_min_batch() { static u32 const v = env_u32("KMP_PRE_MIN_BATCH", 256); return v; }
+void ensure_pre_staging(kmp_batch_ctx* c)
 {
     if (c->pre_tried || !c->knob.decode_pre) return;
     c->pre_tried = 1;
@@ -1134,6 +1198,20 @@ static void ensure_pre_staging(kmp_batch_ctx* c)
             hipMalloc((void**)&c->pre_nlit, (size_t)ps * 4u) == hipSuccess) { c->pre_lit_cap = lit_cap; c->pre_slices = ps; }
         else { (void)hipGetLastError(); (void)hipFree(c->pre_lits); (void)hipFree(c->pre_lit); (void)hipFree(c->pre_nlit); c->pre_lits = nullptr; c->pre_lit = nullptr; c->pre_nlit = nullptr; }
     }
+}
+
+// the counting sort behind the lane-per-entry kernels' slot order (key, rank, permutation: three small launches)
+int size_sort(kmp_batch_ctx* c, hipStream_t st, const u8* src, const u64* in_off, const u32* in_len, u32 m, u32* key, u32* hist, u32* perm, u32 len_shift)
+{
+    (void)c;
+    HIP_TRY(hipMemsetAsync(hist, 0, (size_t)KXP_SORT_BUCKETS * 4u, st));
+    KSeqSortArgs sa;
+    sa.src = src; sa.in_off = in_off; sa.in_len = in_len; sa.n_slices = m; sa.key = key; sa.hist = hist; sa.perm = perm; sa.len_shift = len_shift;
+    hipLaunchKernelGGL(k_zstd_seq_count, dim3((m + 255) / 256), dim3(256), 0, st, sa);
+    hipLaunchKernelGGL(k_zstd_seq_rank, dim3(1), dim3(256), 0, st, sa);
+    hipLaunchKernelGGL(k_zstd_seq_perm, dim3((m + 255) / 256), dim3(256), 0, st, sa);
+    HIP_TRY(hipGetLastError());
+    return KMP_OK;
 }
 
 static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
@@ -1176,15 +1254,7 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
         for (u32 first = 0; first < n; first += per) {
             u32 const m = (n - first < per) ? n - first : per;
             bool const sorted = c->pre_stage && c->knob.decode_sort != 0 && m >= 1024u;
-            if (sorted) {
-                HIP_TRY(hipMemsetAsync(sort_hist, 0, (size_t)KXP_SORT_BUCKETS * 4u, st));
-                KSeqSortArgs sa;
-                sa.src = d.src; sa.in_off = d_in_off + first; sa.in_len = d_in_len + first; sa.n_slices = m; sa.key = sort_key; sa.hist = sort_hist; sa.perm = sort_perm; sa.len_shift = 0;
-                hipLaunchKernelGGL(k_zstd_seq_count, dim3((m + 255) / 256), dim3(256), 0, st, sa);
-                hipLaunchKernelGGL(k_zstd_seq_rank, dim3(1), dim3(256), 0, st, sa);
-                hipLaunchKernelGGL(k_zstd_seq_perm, dim3((m + 255) / 256), dim3(256), 0, st, sa);
-                HIP_TRY(hipGetLastError());
-            }
+            if (sorted) KMP_TRY(size_sort(c, st, d.src, d_in_off + first, d_in_len + first, m, sort_key, sort_hist, sort_perm, 0));
             KDecodeArgs q = d;
             q.in_off = d_in_off + first; q.in_len = d_in_len + first; q.n_slices = m;
             q.out_off = d_out_off + first; q.out_cap = d_out_cap + first; q.out_len = d_out_len + first; q.status = d_status + first;
@@ -1227,224 +1297,6 @@ extern "C" int kmp_zstd_decompress_batch_dict(kmp_batch_ctx* c, const void* d_sr
                                               uint32_t n, void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                               uint32_t* d_out_len, uint32_t* d_status, const void* d_dict, uint32_t dict_size, void* hip_stream)
 { return zstd_decompress_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_cap, d_out_len, d_status, d_dict, dict_size, hip_stream); }
-
-// zlib's deflateBound for the default parameters plus the largest wrapper: stored blocks (5 bytes each per 16 383-symbol
-// block at worst) + 7 for the end of the stream + 18 for a gzip header and trailer (zlib wrapper: 6, raw: 0)
-extern "C" size_t kmp_deflate_bound(size_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 7 + 18; }
-
-static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream, int level = 6);
-/* any of zlib's levels 1 .. 9 (-1 = 6): 4 .. 9 (deflate_slow) are the same kernels with the level's good / lazy / nice / chain
- * numbers, 1 .. 3 (deflate_fast) one kernel that parses and keeps its hash chains a lane per slice */
-extern "C" int kmp_deflate_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                                                uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int format, int level, void* hip_stream)
-{
-    if (level == -1) level = 6;
-    if (format < 0 || format > 2 || level < 1 || level > 9) { g_last_error = "kmp_deflate_compress_batch_level: format 0 (raw), 1 (zlib) or 2 (gzip), level 1 .. 9"; return KMP_ERR_ARG; }
-    return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (u32)format, hip_stream, level);
-}
-extern "C" int kmp_deflate_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                                          uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
-{ return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, 0, hip_stream); }
-extern "C" int kmp_zlib_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
-{ return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, 1, hip_stream); }
-extern "C" int kmp_gzip_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
-{ return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, 2, hip_stream); }
-
-extern "C" int kmp_inflate_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
-                                 void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap, uint32_t* d_out_len, int32_t* d_status,
-                                 int format, void* hip_stream)
-{
-    if (format < 0 || format > 3) { g_last_error = "kmp_inflate_batch: format must be 0 (raw), 1 (zlib), 2 (gzip) or 3 (zlib or gzip)"; return KMP_ERR_ARG; }
-    if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_cap || !d_out_len || !d_status))) { g_last_error = "kmp_inflate_batch: null argument"; return KMP_ERR_ARG; }
-    if (n == 0) return KMP_OK;
-    hipStream_t const st = (hipStream_t)hip_stream;
-    HIP_TRY(hipSetDevice(c->device));
-    KiArgs a;
-    a.src = (const u8*)d_src; a.in_off = d_in_off; a.in_len = d_in_len; a.n_slices = n;
-    a.dst = (u8*)d_dst; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_len = d_out_len; a.status = d_status; a.format = (u32)format;
-    KMP_TRY(batch_begin(c, st, nullptr, n, 0));
-    bool const use_pre = c->knob.inflate_pre && n >= env_pre_min_batch();
-    if (use_pre) ensure_pre_staging(c);
-    if (use_pre && c->pre_stage && c->pre_lits && c->pre_nblk && c->pre_nlit && c->pre_slices) {
-        // two kernels: a lane per stream decodes the Huffman codes into staged literals and match records (the staging of
-        // the zstd decoder), a wave per stream executes them -- and decodes the streams the first kernel did not cover
-        // One piece when the batch fits the staging; a larger batch goes through in pieces of the staging's size, one after the
-        // other.  (KMP_INFLATE_PIECES=2..4 splits a batch that fits, each piece with its own part of the staging and its executor
-        // on the context's second stream beside the next piece's pre-decoder: measured 55 / 44 / 36 GB/s against 64 in one
-        // piece -- the launches get short and their tails long, as in the zstd decoder.)
-        u32 pieces = (n <= c->pre_slices && n >= 16384u && c->knob.inflate_pieces > 1) ? c->knob.inflate_pieces : 1u;
-        if (pieces > KMP_MAX_CHUNKS) pieces = KMP_MAX_CHUNKS;
-        bool const overlap = pieces > 1;
-        u32 const per = overlap ? (((n + pieces - 1) / pieces + 1023u) & ~1023u) : c->pre_slices;
-        if (overlap) { HIP_TRY(hipEventRecord(c->ev_pre[0], st)); HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_pre[0], 0)); }
-        u32 pi = 0;
-        for (u32 first = 0; first < n; first += per, pi++) {
-            u32 const m = (n - first < per) ? n - first : per;
-            size_t const so = overlap ? first : 0;                      // this piece's place in the staging
-            // streams of similar compressed size (about as many symbols) share a wave: a wave lasts as long as its longest lane
-            u32* const sort_key = c->pre_sort ? c->pre_sort + so : nullptr; u32* const sort_perm = c->pre_sort ? c->pre_sort + c->pre_slices + so : nullptr; u32* const sort_hist = c->pre_sort ? c->pre_sort + 2u * (size_t)c->pre_slices : nullptr;
-            bool const sorted = c->pre_sort && c->knob.decode_sort != 0 && m >= 1024u;
-            if (sorted) {
-                u32 sh = 1; while ((c->max_slice_bytes >> sh) >= KXP_SORT_BUCKETS) sh++;
-                HIP_TRY(hipMemsetAsync(sort_hist, 0, (size_t)KXP_SORT_BUCKETS * 4u, st));
-                KSeqSortArgs sa;
-                sa.src = a.src; sa.in_off = a.in_off + first; sa.in_len = a.in_len + first; sa.n_slices = m; sa.key = sort_key; sa.hist = sort_hist; sa.perm = sort_perm; sa.len_shift = sh;
-                hipLaunchKernelGGL(k_zstd_seq_count, dim3((m + 255) / 256), dim3(256), 0, st, sa);
-                hipLaunchKernelGGL(k_zstd_seq_rank, dim3(1), dim3(256), 0, st, sa);
-                hipLaunchKernelGGL(k_zstd_seq_perm, dim3((m + 255) / 256), dim3(256), 0, st, sa);
-                HIP_TRY(hipGetLastError());
-            }
-            KipArgs p;
-            p.perm = sorted ? sort_perm : nullptr;
-            p.src = a.src; p.in_off = a.in_off + first; p.in_len = a.in_len + first; p.n_slices = m; p.out_cap = a.out_cap + first; p.format = a.format;
-            p.stage = c->pre_stage + so * c->pre_seq_cap; p.seq_cap = c->pre_seq_cap; p.lits = c->pre_lits + so * c->pre_lit_cap; p.lit_cap = c->pre_lit_cap; p.nseq = c->pre_nblk + so; p.nlit = c->pre_nlit + so;
-            hipLaunchKernelGGL(k_inflate_predecode, dim3((m + KIP_STREAMS - 1) / KIP_STREAMS), dim3(64), 0, st, p);
-            HIP_TRY(hipGetLastError());
-            hipStream_t es = st;
-            if (overlap) { es = c->st2; HIP_TRY(hipEventRecord(c->ev_pre[1 + pi], st)); HIP_TRY(hipStreamWaitEvent(es, c->ev_pre[1 + pi], 0)); }
-            KieArgs e;
-            e.i = a; e.i.in_off += first; e.i.in_len += first; e.i.n_slices = m; e.i.out_off += first; e.i.out_cap += first; e.i.out_len += first; e.i.status += first;
-            e.stage = p.stage; e.seq_cap = c->pre_seq_cap; e.lits = p.lits; e.lit_cap = c->pre_lit_cap; e.nseq = p.nseq; e.nlit = p.nlit;
-            hipLaunchKernelGGL(k_inflate_exec, dim3(m), dim3(64), 0, es, e);
-            HIP_TRY(hipGetLastError());
-        }
-        if (overlap) { HIP_TRY(hipEventRecord(c->ev_join, c->st2)); HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0)); }
-        return batch_end(c, st, nullptr, n, 0, nullptr, nullptr);
-    }
-    hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, st, a);
-    HIP_TRY(hipGetLastError());
-    return batch_end(c, st, nullptr, n, 0, nullptr, nullptr);
-}
-
-static int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream, int level)
-{
-    if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_deflate_compress_batch: null argument"; return KMP_ERR_ARG; }
-    if (n > c->max_slices) { g_last_error = "kmp_deflate_compress_batch: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
-    if (n == 0) return KMP_OK;
-    hipStream_t const st = (hipStream_t)hip_stream;
-    HIP_TRY(hipSetDevice(c->device));
-    if (!c->dfl_link) {
-        // Two workspace halves of up to 16 384 slices each (28 GiB of the 288 GB for both): while the search kernels
-        // (chains, best: LDS-bound) work on one piece of the batch, the parse (one lane per slice, pure latency, no LDS)
-        // and the encoder of the previous piece run beside them on the context's second stream.
-        // (14 bytes of workspace per position: link, best, symbol; the pieces hold 2^30 positions each at most)
-        u32 const pos_cap = ((c->max_slice_bytes < 65536u ? 65536u : c->max_slice_bytes) + 63u) & ~63u;
-        u32 cap = c->knob.dfl_chunk ? c->knob.dfl_chunk : 16384u;
-        if ((u64)cap * pos_cap > (1ull << 30)) cap = (u32)((1ull << 30) / pos_cap);
-        if (cap < 1) cap = 1;
-        u32 const chunk = c->max_slices < cap ? c->max_slices : cap;
-        c->dfl_pos_cap = pos_cap; c->dfl_blk_cap = pos_cap / (KD_LIT_BUFSIZE - 1) + 2u;
-        HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)2 * chunk * pos_cap * sizeof(u16)));
-        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * chunk * pos_cap * sizeof(KdBest)));
-        HIP_TRY(hipMalloc((void**)&c->dfl_syms, (size_t)2 * chunk * pos_cap * sizeof(u32)));
-        HIP_TRY(hipMalloc((void**)&c->dfl_meta, (size_t)2 * chunk * sizeof(KdSliceMeta)));
-        HIP_TRY(hipMalloc((void**)&c->dfl_blocks, (size_t)2 * chunk * c->dfl_blk_cap * sizeof(KdBlockInfo)));
-        for (int i = 0; i < 2; i++) {
-            HIP_TRY(hipEventCreateWithFlags(&c->dfl_searched[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&c->dfl_done[i], hipEventDisableTiming));
-        }
-        c->dfl_events = 1;
-        c->dfl_chunk = chunk;
-    }
-    u32 const dfl_cap = c->max_slice_bytes < 65536u ? 65536u : c->max_slice_bytes;       // a context for smaller slices still takes 64 KiB ones
-    KMP_TRY(batch_begin(c, st, d_in_len, n, dfl_cap));
-    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[6], st));
-    u32 chain_waves = c->knob.dfl_chain_waves; if (chain_waves < 1 || chain_waves > 4) chain_waves = 4;
-    bool const serial = c->knob.dfl_serial != 0;          // experiment switch: everything on the caller's stream
-    u32 piece = 0;
-    if (level >= 1 && level <= 3) {
-        // deflate_fast needs no link / best arrays: the head / prev tables of a slice (256 KiB) live where the KdBest entries of
-        // the lazy levels do, which has room for 4 * dfl_chunk slices.  The kernel is a lane per slice and bound by memory
-        // latency, so the more slices are in flight the better: symbols and block lists for that many slices are allocated
-        // on the first call at these levels (16 GiB with the default sizes; if that fails, pieces of 2 * dfl_chunk slices use
-        // the arrays of the lazy levels).  Everything runs on the caller's stream.
-        if (!c->dfl_ftried) {
-            c->dfl_ftried = 1;
-            size_t const cap4 = (size_t)4 * c->dfl_chunk;
-            if (c->max_slices > 2u * c->dfl_chunk && !c->knob.dfl_serial) {
-                if (hipMalloc((void**)&c->dfl_fsyms, cap4 * c->dfl_pos_cap * sizeof(u32)) != hipSuccess ||
-                    hipMalloc((void**)&c->dfl_fmeta, cap4 * sizeof(KdSliceMeta)) != hipSuccess ||
-                    hipMalloc((void**)&c->dfl_fblocks, cap4 * c->dfl_blk_cap * sizeof(KdBlockInfo)) != hipSuccess) {
-                    (void)hipGetLastError();
-                    (void)hipFree(c->dfl_fsyms); (void)hipFree(c->dfl_fmeta); (void)hipFree(c->dfl_fblocks);
-                    c->dfl_fsyms = nullptr; c->dfl_fmeta = nullptr; c->dfl_fblocks = nullptr;
-                }
-            }
-        }
-        bool const wide = c->dfl_fsyms && c->dfl_fmeta && c->dfl_fblocks;
-        u32 const span = (wide ? 4u : 2u) * c->dfl_chunk;
-        for (u32 first = 0; first < n; first += span) {
-            u32 const m = (n - first < span) ? n - first : span;
-            KdArgs a;
-            a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = c->len_ok + first; a.n_slices = m;
-            a.pos_cap = c->dfl_pos_cap; a.blk_cap = c->dfl_blk_cap;
-            a.link = c->dfl_link; a.best = c->dfl_best;
-            a.syms = wide ? c->dfl_fsyms : c->dfl_syms; a.meta = wide ? c->dfl_fmeta : c->dfl_meta; a.blocks = wide ? c->dfl_fblocks : c->dfl_blocks;
-            a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
-            kd_level_config(a, level);
-            bool const prof = c->profiling && first == 0;
-            if (prof) { HIP_TRY(hipEventRecord(c->ev[8], st)); HIP_TRY(hipEventRecord(c->ev[9], st)); HIP_TRY(hipEventRecord(c->ev[10], st)); HIP_TRY(hipEventRecord(c->ev[13], st)); }
-            HIP_TRY(hipMemsetAsync(c->dfl_best, 0, (size_t)m * 32768u * sizeof(u32), st));          // the head tables
-            hipLaunchKernelGGL(k_deflate_fast, dim3((m + 63) / 64), dim3(64), 0, st, a);
-            if (prof) HIP_TRY(hipEventRecord(c->ev[11], st));
-            hipLaunchKernelGGL(k_deflate_encode, dim3(m), dim3(64), 0, st, a);
-            if (prof) HIP_TRY(hipEventRecord(c->ev[12], st));
-            HIP_TRY(hipGetLastError());
-        }
-        if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[7], st)); c->ev_valid[3] = 1; }
-        return batch_end(c, st, d_in_len, n, dfl_cap, d_out_len, nullptr);
-    }
-    for (u32 first = 0; first < n; first += c->dfl_chunk, piece++) {
-        u32 const m = (n - first < c->dfl_chunk) ? n - first : c->dfl_chunk;
-        u32 const h = piece & 1u;                                        // workspace half
-        KdArgs a;
-        a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = c->len_ok + first; a.n_slices = m;
-        size_t const half = (size_t)h * c->dfl_chunk;
-        a.pos_cap = c->dfl_pos_cap; a.blk_cap = c->dfl_blk_cap;
-        a.link = c->dfl_link + half * c->dfl_pos_cap; a.best = c->dfl_best + half * c->dfl_pos_cap;
-        a.syms = c->dfl_syms + half * c->dfl_pos_cap; a.meta = c->dfl_meta + half; a.blocks = c->dfl_blocks + half * c->dfl_blk_cap;
-        a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
-        kd_level_config(a, level);
-        bool const prof = c->profiling && first == 0;      // per-kernel events for the first piece
-        hipStream_t const s2 = serial ? st : c->st2;
-        if (!serial && piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[h], 0));      // this half's previous piece has been encoded
-        if (prof) HIP_TRY(hipEventRecord(c->ev[8], st));
-        if (c->dfl_pos_cap <= 65536u) hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(64u * chain_waves), 0, st, a);
-        else hipLaunchKernelGGL(k_deflate_chains_long, dim3(m), dim3(64u * chain_waves), 0, st, a);
-        if (prof) HIP_TRY(hipEventRecord(c->ev[9], st));
-        hipLaunchKernelGGL(k_deflate_best, dim3(m), dim3(1024), 0, st, a);
-        if (prof) HIP_TRY(hipEventRecord(c->ev[10], st));
-        if (!serial) { HIP_TRY(hipEventRecord(c->dfl_searched[h], st)); HIP_TRY(hipStreamWaitEvent(s2, c->dfl_searched[h], 0)); }
-        if (prof) HIP_TRY(hipEventRecord(c->ev[13], s2));
-        hipLaunchKernelGGL(k_deflate_parse, dim3((m + 63) / 64), dim3(64), 0, s2, a);
-        if (prof) HIP_TRY(hipEventRecord(c->ev[11], s2));
-        hipLaunchKernelGGL(k_deflate_encode, dim3(m), dim3(64), 0, s2, a);
-        if (prof) HIP_TRY(hipEventRecord(c->ev[12], s2));
-        HIP_TRY(hipGetLastError());
-        if (!serial) HIP_TRY(hipEventRecord(c->dfl_done[h], s2));
-    }
-    if (!serial) {                                                        // the caller's stream continues when every piece is out
-        HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[0], 0));
-        if (piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[1], 0));
-    }
-    if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[7], st)); c->ev_valid[3] = 1; }
-    return batch_end(c, st, d_in_len, n, dfl_cap, d_out_len, nullptr);
-}
-
-// per-kernel milliseconds of the first workspace chunk of the last deflate batch: chains, best, parse, encode
-extern "C" int kmp_deflate_last_kernel_ms(kmp_batch_ctx* c, float* ms4)
-{
-    if (!c || !ms4 || !c->ev_valid[3]) { g_last_error = "no deflate timing recorded"; return KMP_ERR_ARG; }
-    HIP_TRY(hipEventSynchronize(c->ev[12]));
-    static const int from[4] = { 8, 9, 13, 11 }, to[4] = { 9, 10, 11, 12 };
-    for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&ms4[i], c->ev[from[i]], c->ev[to[i]]));
-    return KMP_OK;
-}
-
 extern "C" int kmp_compact_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_len, uint32_t n,
                                  void* d_dst, uint64_t* d_out_off, void* hip_stream)
 {
@@ -1459,478 +1311,4 @@ extern "C" int kmp_compact_batch(kmp_batch_ctx* c, const void* d_src, const uint
         HIP_TRY(hipGetLastError());
     }
     return KMP_OK;
-}
-
-#include "kmp_coalesce.h"
-
-// --------------------------------------------------------------------------
-// streaming-compatible single-slice API (mirrors libzstd's calling convention)
-// --------------------------------------------------------------------------
-#define KERRC(code) ((size_t)0 - (size_t)(code))
-enum { ZE_GENERIC = 1, ZE_prefix_unknown = 10, ZE_frameParameter_unsupported = 14, ZE_corruption_detected = 20,
-       ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 42, ZE_stage_wrong = 60, ZE_memory_allocation = 64,
-       ZE_dstSize_tooSmall = 70, ZE_srcSize_wrong = 72, ZE_maxCode = 120 };
-
-extern "C" unsigned kmp_zstd_is_error(size_t code) { return code > KERRC(ZE_maxCode); }
-extern "C" const char* kmp_zstd_get_error_name(size_t code)
-{
-    if (!kmp_zstd_is_error(code)) return "No error detected";
-    switch ((int)(0 - code)) {
-    case 1: return "Error (generic)";
-    case 10: return "Unknown frame descriptor";
-    case 12: return "Version not supported";
-    case 14: return "Unsupported frame parameter";
-    case 16: return "Frame requires too much memory for decoding";
-    case 20: return "Data corruption detected";
-    case 22: return "Restored data doesn't match checksum";
-    case 24: return "Header of Literals' block doesn't respect format specification";
-    case 30: return "Dictionary is corrupted";
-    case 32: return "Dictionary mismatch";
-    case 34: return "Cannot create Dictionary from provided samples";
-    case 40: return "Unsupported parameter";
-    case 41: return "Unsupported combination of parameters";
-    case 42: return "Parameter is out of bound";
-    case 44: return "tableLog requires too much memory : unsupported";
-    case 46: return "Unsupported max Symbol Value : too large";
-    case 48: return "Specified maxSymbolValue is too small";
-    case 49: return "This mode cannot generate an uncompressed block";
-    case 50: return "pledged buffer stability condition is not respected";
-    case 60: return "Operation not authorized at current processing stage";
-    case 62: return "Context should be init first";
-    case 64: return "Allocation error : not enough memory";
-    case 66: return "workSpace buffer is not large enough";
-    case 70: return "Destination buffer is too small";
-    case 72: return "Src size is incorrect";
-    case 74: return "Operation on NULL destination buffer";
-    case 80: return "Operation made no progress over multiple calls, due to output buffer being full";
-    case 82: return "Operation made no progress over multiple calls, due to input being empty";
-    case 100: return "Frame index is too large";
-    case 102: return "An I/O error occurred when reading/seeking";
-    case 104: return "Destination buffer is wrong";
-    case 105: return "Source buffer is wrong";
-    case 106: return "Block-level external sequence producer returned an error code";
-    case 107: return "External sequences are not valid";
-    default: return "Unspecified error code";
-    }
-}
-
-// device staging shared by the two stream contexts
-struct stream_dev {
-    kmp_batch_ctx* batch; u8* d_in; u8* d_out; u64* d_off; u32* d_len; size_t in_cap, out_cap; u32 tier;
-};
-// the staging buffers live on the device the context was first used on: later calls may come from a thread whose
-// current device is another one (the reference frees contexts on a cleaner thread, Cleaner.jvm.kt:23-36)
-static bool stream_dev_select(const stream_dev& s) { return !s.batch || hipSetDevice(s.batch->device) == hipSuccess; }
-static void stream_dev_free(stream_dev& s);
-// staging for one slice / frame of at most `bytes` on either side: the 128 KiB tier first, the 2 MiB tier
-// (frames of several blocks) when a larger one shows up
-// (level 1 above 128 KiB wants a context of exactly its 512 KiB window: `exact` = that tier)
-static size_t stream_dev_init(stream_dev& s, size_t bytes = 0, u32 exact = 0)
-{
-    if (s.batch && exact && s.tier == exact) return 0;
-    if (s.batch && !exact && bytes + 1024 <= s.in_cap) return 0;
-    if (s.batch) stream_dev_free(s);
-    // 128 KiB, 2 MiB, then the next power of two that holds the slice
-    u32 tier = exact ? exact : (bytes <= KMP_MAX_SLICE_BYTES) ? KMP_MAX_SLICE_BYTES : (2u << 20);
-    while (!exact && (size_t)tier < bytes && tier < KMP_MAX_BIG_SLICE_BYTES) tier <<= 1;
-    s.tier = tier;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return KERRC(ZE_GENERIC);          // the caller's current device, as a libzstd context lives where its caller runs
-    if (kmp_batch_create(&s.batch, dev, 1, tier, 8) != KMP_OK) return KERRC(ZE_memory_allocation);
-    s.in_cap = tier + (tier >> 7) + 1024; s.out_cap = tier + (tier >> 7) + 1024;
-    if (hipMalloc((void**)&s.d_in, s.in_cap) != hipSuccess || hipMalloc((void**)&s.d_out, s.out_cap) != hipSuccess ||
-        hipMalloc((void**)&s.d_off, 64) != hipSuccess || hipMalloc((void**)&s.d_len, 64) != hipSuccess) return KERRC(ZE_memory_allocation);
-    return 0;
-}
-static void stream_dev_free(stream_dev& s)
-{
-    if (s.batch) { (void)hipSetDevice(s.batch->device); kmp_batch_destroy(s.batch); (void)hipFree(s.d_in); (void)hipFree(s.d_out); (void)hipFree(s.d_off); (void)hipFree(s.d_len); }
-    memset(&s, 0, sizeof(s));
-}
-
-struct kmp_zstd_cctx {
-    int level; std::vector<u8> in; std::vector<u8> out; size_t out_pos; int stage;   // 0 = collecting, 1 = flushing
-    stream_dev dev;
-    std::vector<u8> dict;                       // raw-content dictionary (ZSTD_CCtx_loadDictionary keeps a copy too)
-    size_t fed_continue;                        // bytes that arrived with ZSTD_e_continue: > 0 makes it a streaming frame
-    int end_was_empty;                          // the closing calls brought no data
-};
-
-extern "C" kmp_zstd_cctx* kmp_zstd_create_cctx(void)
-{
-    kmp_zstd_cctx* c = new (std::nothrow) kmp_zstd_cctx();
-    if (!c) return nullptr;
-    c->level = 3; c->out_pos = 0; c->stage = 0; memset(&c->dev, 0, sizeof(c->dev)); c->fed_continue = 0; c->end_was_empty = 0;
-    return c;
-}
-extern "C" size_t kmp_zstd_free_cctx(kmp_zstd_cctx* c) { if (c) { stream_dev_free(c->dev); delete c; } return 0; }
-extern "C" size_t kmp_zstd_cctx_set_parameter(kmp_zstd_cctx* c, int param, int value)
-{
-    if (!c) return KERRC(ZE_GENERIC);
-    if (param != KMP_ZSTD_c_compressionLevel) return KERRC(ZE_parameter_unsupported);
-    if (c->stage != 0 || !c->in.empty()) return KERRC(ZE_stage_wrong);
-    if (value == 0) value = 3;
-    if (value < -131072 || value > 4) return KERRC(ZE_parameter_unsupported);       // (4 and the negative levels: what arrives in one closing call of their size class, decided when the stream closes)
-    c->level = value;
-    return 0;
-}
-extern "C" size_t kmp_zstd_cctx_load_dictionary(kmp_zstd_cctx* c, const void* dict, size_t dict_size)
-{
-    if (!c) return KERRC(ZE_GENERIC);
-    if (c->stage != 0 || !c->in.empty()) return KERRC(ZE_stage_wrong);
-    c->dict.clear();
-    if (dict == nullptr || dict_size == 0) return 0;
-    if (dict_size >= 8 && memcmp(dict, "\x37\xA4\x30\xEC", 4) == 0) return KERRC(ZE_parameter_unsupported);   // formatted zstd dictionary: CPU library
-    if (dict_size < 8 || dict_size > KX_MAX_DICT) return KERRC(ZE_parameter_unsupported);
-    c->dict.assign((const u8*)dict, (const u8*)dict + dict_size);
-    return 0;
-}
-
-// first_room: room in the output slice of the call that closed the stream; end_avail: the bytes that call brought
-static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t end_avail)
-{
-    size_t const n = c->in.size();
-    if (n > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
-    bool const streaming = c->fed_continue > 0;          // data arrived with finish = false: libzstd did not know the size
-    // libzstd compresses the caller's memory in place when its staging buffer is empty and the output slice has room for
-    // ZSTD_compressBound of what the call brought; otherwise it stages the input in chunks of 128 KiB (kmp_zstd_compress_batch_reference)
-    bool const in_place = first_room >= kmp_zstd_compress_bound(end_avail);
-    u32 tail_direct = 0;
-    if (streaming && in_place && end_avail != 0) {
-        size_t const lap = 17u * (size_t)KX_BLOCK_MAX;                  // level-3 stream: window 2 MiB + one block
-        if ((c->level == 3 || c->level == 4) && (n - end_avail) % lap == 0) tail_direct = (u32)end_avail;      // (level 4's streams: the same window)
-    }
-    if (streaming && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
-    // level 4: what arrives in one closing call, above 16 KiB up to 128 KiB (libzstd's double-fast row of that level); the rest: CPU library
-    if (c->level == 4 && (!c->dict.empty() || (!streaming && !((n > 16384u && n <= 131072u) || n > 262144u)))) return KERRC(ZE_parameter_unsupported);
-    if (c->level < 0 && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
-    // the plain case -- level 3, no dictionary, the whole slice at once, one block -- joins whatever other contexts are
-    // closing right now: one batch for all of them (kmp_coalesce.h); the frame is the one this context would get alone
-    if (!streaming && c->level == 3 && c->dict.empty() && n <= KMP_MAX_SLICE_BYTES && coalesce_enabled()) {
-        int dev = 0;
-        if (c->dev.batch) dev = c->dev.batch->device; else if (hipGetDevice(&dev) != hipSuccess) return KERRC(ZE_GENERIC);
-        int const rc = coalesced_compress(dev, c->in.data(), (u32)n, &c->out);
-        if (rc == KMP_OK) return 0;
-        (void)hipGetLastError();                    // fall through: compress alone
-    }
-    bool const l1big = c->level != 3 && c->level != 4 && (streaming || n > KMP_MAX_SLICE_BYTES);      // level 1 / 2 / negative, frame of several blocks / stream
-    u32 const lwin = (c->level == 2 ? 1024u : 512u) << 10;                             // their windows (the negative levels: level 1's)
-    if (l1big && n > lwin) return KERRC(ZE_parameter_unsupported);                     // beyond the window: CPU library
-    if (!stream_dev_select(c->dev)) return KERRC(ZE_GENERIC);
-    { size_t const e = stream_dev_init(c->dev, streaming && n <= KMP_MAX_SLICE_BYTES ? KMP_MAX_SLICE_BYTES + 1 : n, l1big ? lwin : 0u); if (e) return e; }
-    stream_dev& s = c->dev;
-    u64 offs[2] = { 0, 0 }; u32 len = (u32)n, olen = 0;
-    if (n && hipMemcpy(s.d_in, c->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
-    if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
-    if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
-    if (streaming) {
-        if (tail_direct) {
-            if (zstd_compress_big(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, nullptr, 1u, 0u, tail_direct, 0u, c->level == 4) != KMP_OK) return KERRC(ZE_GENERIC);
-        } else
-        if (kmp_zstd_compress_batch_stream_level(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->end_was_empty, c->level, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
-    } else
-    if (n > KMP_MAX_SLICE_BYTES && !in_place && c->dict.empty() && (c->level == 3 || c->level == 4 || l1big)) {
-        // the reference's one-shot driver above 128 KiB: staged input
-        if (kmp_zstd_compress_batch_reference(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->level, (u32)first_room, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
-    } else
-    if (c->level != 3) {
-        if (!c->dict.empty()) return KERRC(ZE_parameter_unsupported);   // levels 1 / 2: no dictionary
-        if (kmp_zstd_compress_batch_level(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->level, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
-    } else
-    if (!c->dict.empty()) {
-        if (n > KMP_MAX_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);          // frames of several blocks with a dictionary: CPU library
-        if (kmp_zstd_compress_batch_dict(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1,
-                                         c->dict.data(), (u32)c->dict.size(), nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
-    } else
-    if (kmp_zstd_compress_batch(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
-    if (hipMemcpy(&olen, s.d_len + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
-    if (olen == 0 || olen > s.out_cap) return KERRC(ZE_GENERIC);
-    c->out.resize(olen);
-    if (hipMemcpy(c->out.data(), s.d_out, olen, hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
-    return 0;
-}
-
-extern "C" size_t kmp_zstd_compress_stream(kmp_zstd_cctx* c, void* dst, size_t dst_size, size_t* dst_pos,
-                                           const void* src, size_t src_size, size_t* src_pos, int end_op)
-{
-    if (!c || !dst_pos || !src_pos) return KERRC(ZE_GENERIC);
-    if (*dst_pos > dst_size) return KERRC(ZE_dstSize_tooSmall);
-    if (*src_pos > src_size) return KERRC(ZE_srcSize_wrong);
-    if ((unsigned)end_op > 2u) return KERRC(ZE_parameter_outOfBound);
-    if (c->stage == 0) {
-        // one-shot semantics (finish=true from the first call, SliceTransform.kt:33-45): the whole
-        // slice arrives before the frame can be produced, so input is collected until e_end
-        size_t const avail = src_size - *src_pos;
-        if (avail) { const u8* p = (const u8*)src + *src_pos; c->in.insert(c->in.end(), p, p + avail); *src_pos = src_size; }
-        if (c->in.size() > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);
-        if (end_op != KMP_ZSTD_e_end) { c->fed_continue += avail; return 0; }
-        c->end_was_empty = avail == 0;
-        size_t const e = run_single_compress(c, dst_size - *dst_pos, avail);
-        if (e) return e;
-        c->stage = 1; c->out_pos = 0;
-    } else if (*src_pos != src_size) {
-        return KERRC(ZE_stage_wrong);      // new input while a finished frame is still being flushed
-    }
-    {
-        size_t const room = dst_size - *dst_pos, left = c->out.size() - c->out_pos;
-        size_t const k = room < left ? room : left;
-        if (k) { memcpy((u8*)dst + *dst_pos, c->out.data() + c->out_pos, k); *dst_pos += k; c->out_pos += k; }
-        size_t const remaining = c->out.size() - c->out_pos;
-        if (remaining == 0) { c->stage = 0; c->in.clear(); c->out.clear(); c->out_pos = 0; c->fed_continue = 0; c->end_was_empty = 0; }
-        return remaining;
-    }
-}
-
-// ---- zlib-compatible one-shot compressor (raw deflate, level 6) ---------------------------------
-struct kmp_zlib_cstream { int level, window_bits, mem_level, strategy; std::vector<u8> in; std::vector<u8> out; size_t out_pos; int stage; stream_dev dev; };
-
-extern "C" kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bits, int mem_level, int strategy)
-{
-    // what deflateInit2 would accept; the GPU path implements levels 1 .. 9 (-1 = default = 6), memLevel 8, strategy 0
-    if (level == -1) level = 6;
-    // windowBits: -15 raw, 15 zlib wrapper, 31 (15 + 16) gzip wrapper
-    if (level < 1 || level > 9 || (window_bits != -15 && window_bits != 15 && window_bits != 31) || mem_level != 8 || strategy != 0) return nullptr;
-    kmp_zlib_cstream* z = new (std::nothrow) kmp_zlib_cstream();
-    if (!z) return nullptr;
-    z->level = level; z->window_bits = window_bits; z->mem_level = mem_level; z->strategy = strategy; z->out_pos = 0; z->stage = 0;
-    memset(&z->dev, 0, sizeof(z->dev));
-    return z;
-}
-extern "C" int kmp_zlib_free_compressor(kmp_zlib_cstream* z) { if (z) { stream_dev_free(z->dev); delete z; } return 0; }
-
-extern "C" int kmp_zlib_compress_stream(kmp_zlib_cstream* z, void* dst, size_t dst_size, size_t* dst_pos,
-                                        const void* src, size_t src_size, size_t* src_pos, int finish)
-{
-    enum { Z_OK_ = 0, Z_STREAM_END_ = 1, Z_STREAM_ERROR_ = -2, Z_DATA_ERROR_ = -3, Z_MEM_ERROR_ = -4, Z_BUF_ERROR_ = -5 };
-    if (!z || !dst_pos || !src_pos || *dst_pos > dst_size || *src_pos > src_size) return Z_STREAM_ERROR_;
-    if (z->stage == 0) {
-        size_t const avail = src_size - *src_pos;
-        if (avail) { const u8* p = (const u8*)src + *src_pos; z->in.insert(z->in.end(), p, p + avail); *src_pos = src_size; }
-        if (z->in.size() > KD_MAX_SLICE) return Z_MEM_ERROR_;          // streams above 1 GiB are not served
-        if (!finish) return avail ? Z_OK_ : Z_BUF_ERROR_;
-        if (!stream_dev_select(z->dev) || stream_dev_init(z->dev, z->in.size())) return Z_MEM_ERROR_;
-        stream_dev& s = z->dev;
-        u64 offs[2] = { 0, 0 }; u32 len = (u32)z->in.size(), olen = 0;
-        if (len && hipMemcpy(s.d_in, z->in.data(), len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
-        if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
-        if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
-        if (deflate_batch_impl(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, z->window_bits == 31 ? 2u : (z->window_bits > 0 ? 1u : 0u), nullptr, z->level) != KMP_OK) return Z_MEM_ERROR_;
-        if (hipMemcpy(&olen, s.d_len + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR_;
-        if (olen == 0 || olen > s.out_cap) return Z_DATA_ERROR_;
-        z->out.resize(olen);
-        if (hipMemcpy(z->out.data(), s.d_out, olen, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR_;
-        z->stage = 1; z->out_pos = 0;
-    }
-    size_t const room = dst_size - *dst_pos, left = z->out.size() - z->out_pos;
-    size_t const k = room < left ? room : left;
-    if (k) { memcpy((u8*)dst + *dst_pos, z->out.data() + z->out_pos, k); *dst_pos += k; z->out_pos += k; }
-    if (z->out_pos == z->out.size()) { z->stage = 2; return Z_STREAM_END_; }
-    return k ? Z_OK_ : Z_BUF_ERROR_;
-}
-
-struct kmp_zlib_dstream { int window_bits; std::vector<u8> in; std::vector<u8> out; size_t out_pos; int stage; kmp_batch_ctx* batch; };
-
-extern "C" kmp_zlib_dstream* kmp_zlib_create_decompressor(int window_bits)
-{
-    // inflateInit2 semantics: -15..-8 raw, 8..15 zlib wrapper, 24..31 gzip, 40..47 zlib or gzip by the header
-    bool const raw = window_bits <= -8 && window_bits >= -15, zl = window_bits >= 8 && window_bits <= 15;
-    bool const gz = window_bits >= 24 && window_bits <= 31, any = window_bits >= 40 && window_bits <= 47;
-    if (!raw && !zl && !gz && !any) return nullptr;
-    kmp_zlib_dstream* z = new (std::nothrow) kmp_zlib_dstream();
-    if (!z) return nullptr;
-    z->window_bits = window_bits; z->out_pos = 0; z->stage = 0; z->batch = nullptr;
-    return z;
-}
-extern "C" int kmp_zlib_free_decompressor(kmp_zlib_dstream* z) { if (z) { if (z->batch) kmp_batch_destroy(z->batch); delete z; } return 0; }
-
-extern "C" int kmp_zlib_decompress_stream(kmp_zlib_dstream* z, void* dst, size_t dst_size, size_t* dst_pos,
-                                          const void* src, size_t src_size, size_t* src_pos, int finish)
-{
-    enum { Z_OK_ = 0, Z_STREAM_END_ = 1, Z_STREAM_ERROR_ = -2, Z_DATA_ERROR_ = -3, Z_MEM_ERROR_ = -4, Z_BUF_ERROR_ = -5 };
-    if (!z || !dst_pos || !src_pos || *dst_pos > dst_size || *src_pos > src_size) return Z_STREAM_ERROR_;
-    if (z->stage == 0) {
-        size_t const avail = src_size - *src_pos;
-        if (avail) { const u8* p = (const u8*)src + *src_pos; z->in.insert(z->in.end(), p, p + avail); *src_pos = src_size; }
-        if (!finish) return avail ? Z_OK_ : Z_BUF_ERROR_;           // the stream is decoded when the caller finishes it
-        if (!z->batch) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || kmp_batch_create(&z->batch, dev, 1, 65536, 8) != KMP_OK) return Z_MEM_ERROR_;
-        }
-        size_t const n = z->in.size();
-        u8* d_in = nullptr; u8* d_out = nullptr; u64* d_off = nullptr; u32* d_len = nullptr; int rc = Z_MEM_ERROR_;
-        if (hipMalloc((void**)&d_in, n + 64) == hipSuccess && hipMalloc((void**)&d_off, 64) == hipSuccess && hipMalloc((void**)&d_len, 64) == hipSuccess) {
-            // the decoded size is not known in advance: grow the capacity until the stream fits
-            for (size_t cap = 256u << 10; cap <= (256u << 20); cap <<= 2) {
-                if (d_out) { (void)hipFree(d_out); d_out = nullptr; }
-                if (hipMalloc((void**)&d_out, cap + 64) != hipSuccess) break;
-                u64 offs[2] = { 0, 0 }; u32 lens[4] = { (u32)n, (u32)cap, 0, 0 };
-                if ((n && hipMemcpy(d_in, z->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) ||
-                    hipMemcpy(d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess ||
-                    hipMemcpy(d_len, lens, sizeof(lens), hipMemcpyHostToDevice) != hipSuccess) break;
-                if (kmp_inflate_batch(z->batch, d_in, d_off, d_len, 1, d_out, d_off + 1, d_len + 1, d_len + 2, (int32_t*)(d_len + 3),
-                                      z->window_bits < 0 ? 0 : (z->window_bits <= 15 ? 1 : (z->window_bits <= 31 ? 2 : 3)), nullptr) != KMP_OK) break;
-                if (hipMemcpy(lens, d_len, sizeof(lens), hipMemcpyDeviceToHost) != hipSuccess) break;
-                int const st = (int)lens[3];
-                if (st == Z_BUF_ERROR_) continue;                    // output did not fit: next capacity
-                if (st != 0) { rc = st; break; }
-                z->out.resize(lens[2]);
-                if (lens[2] && hipMemcpy(z->out.data(), d_out, lens[2], hipMemcpyDeviceToHost) != hipSuccess) break;
-                rc = Z_OK_;
-                break;
-            }
-        }
-        (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_off); (void)hipFree(d_len);
-        if (rc != Z_OK_) return rc == Z_MEM_ERROR_ ? Z_MEM_ERROR_ : Z_DATA_ERROR_;
-        z->stage = 1; z->out_pos = 0;
-    }
-    size_t const room = dst_size - *dst_pos, left = z->out.size() - z->out_pos;
-    size_t const k = room < left ? room : left;
-    if (k) { memcpy((u8*)dst + *dst_pos, z->out.data() + z->out_pos, k); *dst_pos += k; z->out_pos += k; }
-    if (z->out_pos == z->out.size()) { z->stage = 2; return Z_STREAM_END_; }
-    return k ? Z_OK_ : Z_BUF_ERROR_;
-}
-
-struct kmp_zstd_dctx {
-    std::vector<u8> in; std::vector<u8> out; size_t out_pos; int stage;   // 0 = collecting a frame, 1 = flushing
-    stream_dev dev; u32* d_status;
-    std::vector<u8> dict; u8* d_dict;                  // raw-content dictionary (ZSTD_DCtx_loadDictionary), host copy + device copy
-};
-
-extern "C" kmp_zstd_dctx* kmp_zstd_create_dctx(void)
-{
-    kmp_zstd_dctx* d = new (std::nothrow) kmp_zstd_dctx();
-    if (!d) return nullptr;
-    d->out_pos = 0; d->stage = 0; memset(&d->dev, 0, sizeof(d->dev)); d->d_status = nullptr; d->d_dict = nullptr;
-    return d;
-}
-extern "C" size_t kmp_zstd_free_dctx(kmp_zstd_dctx* d) { if (d) { stream_dev_free(d->dev); if (d->d_dict) (void)hipFree(d->d_dict); if (d->d_status) (void)hipFree(d->d_status); delete d; } return 0; }
-extern "C" size_t kmp_zstd_dctx_load_dictionary(kmp_zstd_dctx* d, const void* dict, size_t dict_size)
-{
-    if (!d) return KERRC(ZE_GENERIC);
-    // raw-content dictionary: its bytes are the history before every frame decoded by this context (Wrapper.cpp:58-73)
-    if (d->stage != 0 || !d->in.empty()) return KERRC(ZE_stage_wrong);
-    if (d->d_dict) { (void)hipFree(d->d_dict); d->d_dict = nullptr; }
-    d->dict.clear();
-    if (dict == nullptr || dict_size == 0) return 0;
-    if (dict_size >= 8 && memcmp(dict, "\x37\xA4\x30\xEC", 4) == 0) return KERRC(ZE_parameter_unsupported);   // formatted zstd dictionary: CPU library
-    if (dict_size > (8u << 20)) return KERRC(ZE_memory_allocation);
-    d->dict.assign((const u8*)dict, (const u8*)dict + dict_size);
-    if (hipMalloc((void**)&d->d_dict, dict_size + 64) != hipSuccess) { d->d_dict = nullptr; d->dict.clear(); return KERRC(ZE_memory_allocation); }
-    if (hipMemcpy(d->d_dict, d->dict.data(), dict_size, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
-    return 0;
-}
-
-// Size of the complete frame at p (n bytes available): 0 = need more input, KERRC(..) = malformed
-static size_t frame_total_size(const u8* p, size_t n, size_t* contentSize)
-{
-    if (n < 5) return 0;
-    if ((p[0] & 0xF0) == 0x50 && p[1] == 0x2A && p[2] == 0x4D && p[3] == 0x18) {       // skippable frame: magic, size, payload
-        if (n < 8) return 0;
-        u32 sz; memcpy(&sz, p + 4, 4);
-        *contentSize = 0;
-        return n < 8 + (size_t)sz ? 0 : 8 + (size_t)sz;
-    }
-    if (p[0] != 0x28 || p[1] != 0xB5 || p[2] != 0x2F || p[3] != 0xFD) return KERRC(ZE_prefix_unknown);
-    u32 const fhd = p[4]; u32 const dictID = fhd & 3, checksum = (fhd >> 2) & 1, single = (fhd >> 5) & 1, fcsId = fhd >> 6;
-    if (fhd & 0x08) return KERRC(ZE_frameParameter_unsupported);
-    size_t pos = 5 + (single ? 0 : 1);
-    static const u32 didSize[4] = { 0, 1, 2, 4 };
-    pos += didSize[dictID];
-    u32 const fcsSize = fcsId == 0 ? single : (fcsId == 1 ? 2 : fcsId == 2 ? 4 : 8);
-    if (n < pos + fcsSize) return 0;
-    u64 cs = (u64)-1;
-    if (fcsSize == 1) cs = p[pos]; else if (fcsSize == 2) cs = (u64)(p[pos] | (p[pos + 1] << 8)) + 256;
-    else if (fcsSize == 4) { u32 v; memcpy(&v, p + pos, 4); cs = v; } else if (fcsSize == 8) memcpy(&cs, p + pos, 8);
-    *contentSize = (size_t)cs;
-    pos += fcsSize;
-    for (;;) {
-        if (n < pos + 3) return 0;
-        u32 const bh = p[pos] | (p[pos + 1] << 8) | (p[pos + 2] << 16);
-        u32 const last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
-        if (type == 3) return KERRC(ZE_corruption_detected);
-        pos += 3 + (type == 1 ? 1 : bsz);
-        if (last) break;
-    }
-    pos += checksum ? 4 : 0;
-    if (n < pos) return 0;
-    return pos;
-}
-
-extern "C" size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* d, void* dst, size_t dst_size, size_t* dst_pos,
-                                             const void* src, size_t src_size, size_t* src_pos)
-{
-    if (!d || !dst_pos || !src_pos) return KERRC(ZE_GENERIC);
-    if (*dst_pos > dst_size) return KERRC(ZE_dstSize_tooSmall);
-    if (*src_pos > src_size) return KERRC(ZE_srcSize_wrong);
-    if (d->stage == 0) {
-        // take input until one whole frame is buffered
-        size_t content = (size_t)-1;
-        // the largest frame this path stages: 1 GiB of content, whose frame is at most that + 1/128 + block headers
-        size_t const frame_max = (size_t)KMP_MAX_BIG_SLICE_BYTES + (KMP_MAX_BIG_SLICE_BYTES >> 7) + 1024;
-        {   // take what is offered (never more than one largest frame beyond what is buffered), then hand back what lies beyond the frame's end
-            size_t avail = src_size - *src_pos;
-            if (d->in.size() >= frame_max) return KERRC(ZE_frameParameter_unsupported);      // still no complete frame: larger than served here
-            if (avail > frame_max - d->in.size()) avail = frame_max - d->in.size();
-            const u8* p = (const u8*)src + *src_pos;
-            d->in.insert(d->in.end(), p, p + avail); *src_pos += avail;
-        }
-        size_t const total = frame_total_size(d->in.data(), d->in.size(), &content);
-        if (kmp_zstd_is_error(total)) return total;
-        // a declared content size beyond what is served is refused as soon as the header is in
-        if (content != (size_t)-1 && content > KMP_MAX_BIG_SLICE_BYTES) return KERRC(ZE_frameParameter_unsupported);
-        if (total && total < d->in.size()) { *src_pos -= d->in.size() - total; d->in.resize(total); }
-        if (total == 0) return d->in.size() >= frame_max ? KERRC(ZE_frameParameter_unsupported) : 3;      // hint: more input expected
-        // the plain case -- no dictionary, content size in the header, at most 128 KiB either way -- joins whatever other contexts
-        // are decoding right now: one batch for all of them (kmp_coalesce.h)
-        if (d->dict.empty() && content != (size_t)-1 && content <= KMP_MAX_SLICE_BYTES && total <= KMP_MAX_SLICE_BYTES && coalesce_enabled()) {
-            int dev = 0;
-            if (d->dev.batch) dev = d->dev.batch->device; else if (hipGetDevice(&dev) != hipSuccess) return KERRC(ZE_GENERIC);
-            d->out.resize(content ? content : 1);
-            u32 olen = 0, st = 0;
-            int const rc = coalesced_decompress(dev, d->in.data(), (u32)total, d->out.data(), (u32)content, &olen, &st);
-            if (rc == KMP_OK) {
-                if (st) { d->out.clear(); return KERRC(st); }
-                d->out.resize(olen);
-                d->in.clear(); d->stage = 1; d->out_pos = 0;
-                goto flush_output;
-            }
-            (void)hipGetLastError(); d->out.clear();                 // fall through: decode alone
-        }
-        if (!d->d_status && hipMalloc((void**)&d->d_status, 64) != hipSuccess) return KERRC(ZE_memory_allocation);
-        u32 res[2] = { 0, 0 };
-        // content size in the header: staged for exactly that; none (streaming frames): for 4 x the frame (2 MiB at least),
-        // and again for 4 x as much while the decoder answers "destination too small", up to the 1 GiB served here
-        size_t want = content != (size_t)-1 ? (content > d->in.size() ? content : d->in.size())
-                                            : (4 * total > (size_t)(2u << 20) ? 4 * total : (size_t)(2u << 20));
-        for (;;) {
-            if (want > KMP_MAX_BIG_SLICE_BYTES) want = KMP_MAX_BIG_SLICE_BYTES;
-            if (!stream_dev_select(d->dev)) return KERRC(ZE_GENERIC);
-            { size_t const e = stream_dev_init(d->dev, want > total ? want : total); if (e) return e; }
-            stream_dev& s = d->dev;
-            if (total > s.in_cap) return KERRC(ZE_frameParameter_unsupported);
-            u64 offs[2] = { 0, 0 }; u32 lens[2] = { (u32)total, (u32)s.out_cap };
-            if (hipMemcpy(s.d_in, d->in.data(), total, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
-            if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
-            if (hipMemcpy(s.d_len, lens, sizeof(lens), hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
-            if (kmp_zstd_decompress_batch_dict(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1,
-                                               d->d_status, d->d_status + 1, d->d_dict, (u32)d->dict.size(), nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
-            if (hipMemcpy(res, d->d_status, 8, hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
-            if (res[1] == (u32)ZE_dstSize_tooSmall && content == (size_t)-1 && want < KMP_MAX_BIG_SLICE_BYTES) { want *= 4; continue; }
-            break;
-        }
-        stream_dev& s = d->dev;
-        if (res[1]) return KERRC(res[1]);
-        d->out.resize(res[0]);
-        if (res[0] && hipMemcpy(d->out.data(), s.d_out, res[0], hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
-        d->in.clear(); d->stage = 1; d->out_pos = 0;
-    }
-flush_output:
-    {
-        size_t const room = dst_size - *dst_pos, left = d->out.size() - d->out_pos;
-        size_t const k = room < left ? room : left;
-        if (k) { memcpy((u8*)dst + *dst_pos, d->out.data() + d->out_pos, k); *dst_pos += k; d->out_pos += k; }
-        size_t const remaining = d->out.size() - d->out_pos;
-        if (remaining == 0) { d->stage = 0; d->out.clear(); d->out_pos = 0; }
-        return remaining;
-    }
 }

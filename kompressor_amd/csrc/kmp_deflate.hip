@@ -1,0 +1,229 @@
+// kmp_deflate.hip -- the zlib twin (BASELINE configs[4]): DEFLATE / inflate kernel entry points and the batched calls
+// kmp_deflate_compress_batch* / kmp_zlib_compress_batch / kmp_gzip_compress_batch / kmp_inflate_batch over the batch
+// context of kmp_batch.hip (reference: kompressor-zlib--nativelib/src/jvmCommonMain/jni/Wrapper.cpp:20,73,91,144).
+#include "kx_wave.h"
+#include "zstd_common.h"
+#include "deflate_match.h"
+#include "deflate_encode.h"
+#include "deflate_decode.h"
+#include "deflate_predecode.h"
+#include "kmp_internal.h"
+
+__global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chains_body<u16>(a); }          // slices <= 64 KiB
+__global__ __launch_bounds__(256) void k_deflate_chains_long(KdArgs a) { deflate_chains_body<u32>(a); }
+__global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_body(a); }
+__global__ __launch_bounds__(64) void k_deflate_parse(KdArgs a) { deflate_parse_body(a); }
+__global__ __launch_bounds__(64) void k_deflate_fast(KdArgs a) { deflate_fast_body(a); }
+__global__ __launch_bounds__(64, 2) void k_inflate_predecode(KipArgs a) { inflate_predecode_body(a); }
+__global__ __launch_bounds__(64) void k_inflate_exec(KieArgs a) { inflate_exec_body(a); }
+__global__ __launch_bounds__(64, 4) void k_deflate_encode(KdArgs a) { deflate_encode_body(a); }
+__global__ __launch_bounds__(64, 5) void k_inflate(KiArgs a) { inflate_body(a); }
+
+// zlib's deflateBound for the default parameters plus the largest wrapper: stored blocks (5 bytes each per 16 383-symbol
+// block at worst) + 7 for the end of the stream + 18 for a gzip header and trailer (zlib wrapper: 6, raw: 0)
+extern "C" size_t kmp_deflate_bound(size_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 7 + 18; }
+
+/* any of zlib's levels 1 .. 9 (-1 = 6): 4 .. 9 (deflate_slow) are the same kernels with the level's good / lazy / nice / chain
+ * numbers, 1 .. 3 (deflate_fast) one kernel that parses and keeps its hash chains a lane per slice */
+extern "C" int kmp_deflate_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                                uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int format, int level, void* hip_stream)
+{
+    if (level == -1) level = 6;
+    if (format < 0 || format > 2 || level < 1 || level > 9) { g_last_error = "kmp_deflate_compress_batch_level: format 0 (raw), 1 (zlib) or 2 (gzip), level 1 .. 9"; return KMP_ERR_ARG; }
+    return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (u32)format, hip_stream, level);
+}
+extern "C" int kmp_deflate_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                          uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
+{ return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, 0, hip_stream); }
+extern "C" int kmp_zlib_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
+{ return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, 1, hip_stream); }
+extern "C" int kmp_gzip_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
+{ return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, 2, hip_stream); }
+
+extern "C" int kmp_inflate_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
+                                 void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap, uint32_t* d_out_len, int32_t* d_status,
+                                 int format, void* hip_stream)
+{
+    if (format < 0 || format > 3) { g_last_error = "kmp_inflate_batch: format must be 0 (raw), 1 (zlib), 2 (gzip) or 3 (zlib or gzip)"; return KMP_ERR_ARG; }
+    if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_cap || !d_out_len || !d_status))) { g_last_error = "kmp_inflate_batch: null argument"; return KMP_ERR_ARG; }
+    if (n == 0) return KMP_OK;
+    hipStream_t const st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(c->device));
+    KiArgs a;
+    a.src = (const u8*)d_src; a.in_off = d_in_off; a.in_len = d_in_len; a.n_slices = n;
+    a.dst = (u8*)d_dst; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_len = d_out_len; a.status = d_status; a.format = (u32)format;
+    KMP_TRY(batch_begin(c, st, nullptr, n, 0));
+    bool const use_pre = c->knob.inflate_pre && n >= env_pre_min_batch();
+    if (use_pre) ensure_pre_staging(c);
+    if (use_pre && c->pre_stage && c->pre_lits && c->pre_nblk && c->pre_nlit && c->pre_slices) {
+        // two kernels: a lane per stream decodes the Huffman codes into staged literals and match records (the staging of
+        // the zstd decoder), a wave per stream executes them -- and decodes the streams the first kernel did not cover
+        // One piece when the batch fits the staging; a larger batch goes through in pieces of the staging's size, one after the
+        // other.  (KMP_INFLATE_PIECES=2..4 splits a batch that fits, each piece with its own part of the staging and its executor
+        // on the context's second stream beside the next piece's pre-decoder: measured 55 / 44 / 36 GB/s against 64 in one
+        // piece -- the launches get short and their tails long, as in the zstd decoder.)
+        u32 pieces = (n <= c->pre_slices && n >= 16384u && c->knob.inflate_pieces > 1) ? c->knob.inflate_pieces : 1u;
+        if (pieces > KMP_MAX_CHUNKS) pieces = KMP_MAX_CHUNKS;
+        bool const overlap = pieces > 1;
+        u32 const per = overlap ? (((n + pieces - 1) / pieces + 1023u) & ~1023u) : c->pre_slices;
+        if (overlap) { HIP_TRY(hipEventRecord(c->ev_pre[0], st)); HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_pre[0], 0)); }
+        u32 pi = 0;
+        for (u32 first = 0; first < n; first += per, pi++) {
+            u32 const m = (n - first < per) ? n - first : per;
+            size_t const so = overlap ? first : 0;                      // this piece's place in the staging
+            // streams of similar compressed size (about as many symbols) share a wave: a wave lasts as long as its longest lane
+            u32* const sort_key = c->pre_sort ? c->pre_sort + so : nullptr; u32* const sort_perm = c->pre_sort ? c->pre_sort + c->pre_slices + so : nullptr; u32* const sort_hist = c->pre_sort ? c->pre_sort + 2u * (size_t)c->pre_slices : nullptr;
+            bool const sorted = c->pre_sort && c->knob.decode_sort != 0 && m >= 1024u;
+            if (sorted) {
+                u32 sh = 1; while ((c->max_slice_bytes >> sh) >= 256u) sh++;          // (256 = the sort's buckets)
+                KMP_TRY(size_sort(c, st, a.src, a.in_off + first, a.in_len + first, m, sort_key, sort_hist, sort_perm, sh));
+            }
+            KipArgs p;
+            p.perm = sorted ? sort_perm : nullptr;
+            p.src = a.src; p.in_off = a.in_off + first; p.in_len = a.in_len + first; p.n_slices = m; p.out_cap = a.out_cap + first; p.format = a.format;
+            p.stage = c->pre_stage + so * c->pre_seq_cap; p.seq_cap = c->pre_seq_cap; p.lits = c->pre_lits + so * c->pre_lit_cap; p.lit_cap = c->pre_lit_cap; p.nseq = c->pre_nblk + so; p.nlit = c->pre_nlit + so;
+            hipLaunchKernelGGL(k_inflate_predecode, dim3((m + KIP_STREAMS - 1) / KIP_STREAMS), dim3(64), 0, st, p);
+            HIP_TRY(hipGetLastError());
+            hipStream_t es = st;
+            if (overlap) { es = c->st2; HIP_TRY(hipEventRecord(c->ev_pre[1 + pi], st)); HIP_TRY(hipStreamWaitEvent(es, c->ev_pre[1 + pi], 0)); }
+            KieArgs e;
+            e.i = a; e.i.in_off += first; e.i.in_len += first; e.i.n_slices = m; e.i.out_off += first; e.i.out_cap += first; e.i.out_len += first; e.i.status += first;
+            e.stage = p.stage; e.seq_cap = c->pre_seq_cap; e.lits = p.lits; e.lit_cap = c->pre_lit_cap; e.nseq = p.nseq; e.nlit = p.nlit;
+            hipLaunchKernelGGL(k_inflate_exec, dim3(m), dim3(64), 0, es, e);
+            HIP_TRY(hipGetLastError());
+        }
+        if (overlap) { HIP_TRY(hipEventRecord(c->ev_join, c->st2)); HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0)); }
+        return batch_end(c, st, nullptr, n, 0, nullptr, nullptr);
+    }
+    hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return batch_end(c, st, nullptr, n, 0, nullptr, nullptr);
+}
+
+int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream, int level)
+{
+    if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_deflate_compress_batch: null argument"; return KMP_ERR_ARG; }
+    if (n > c->max_slices) { g_last_error = "kmp_deflate_compress_batch: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
+    if (n == 0) return KMP_OK;
+    hipStream_t const st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->dfl_link) {
+        // Two workspace halves of up to 16 384 slices each (28 GiB of the 288 GB for both): while the search kernels
+        // (chains, best: LDS-bound) work on one piece of the batch, the parse (one lane per slice, pure latency, no LDS)
+        // and the encoder of the previous piece run beside them on the context's second stream.
+        // (14 bytes of workspace per position: link, best, symbol; the pieces hold 2^30 positions each at most)
+        u32 const pos_cap = ((c->max_slice_bytes < 65536u ? 65536u : c->max_slice_bytes) + 63u) & ~63u;
+        u32 cap = c->knob.dfl_chunk ? c->knob.dfl_chunk : 16384u;
+        if ((u64)cap * pos_cap > (1ull << 30)) cap = (u32)((1ull << 30) / pos_cap);
+        if (cap < 1) cap = 1;
+        u32 const chunk = c->max_slices < cap ? c->max_slices : cap;
+        c->dfl_pos_cap = pos_cap; c->dfl_blk_cap = pos_cap / (KD_LIT_BUFSIZE - 1) + 2u;
+        HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)2 * chunk * pos_cap * sizeof(u16)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * chunk * pos_cap * sizeof(KdBest)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_syms, (size_t)2 * chunk * pos_cap * sizeof(u32)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_meta, (size_t)2 * chunk * sizeof(KdSliceMeta)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_blocks, (size_t)2 * chunk * c->dfl_blk_cap * sizeof(KdBlockInfo)));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipEventCreateWithFlags(&c->dfl_searched[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&c->dfl_done[i], hipEventDisableTiming));
+        }
+        c->dfl_events = 1;
+        c->dfl_chunk = chunk;
+    }
+    u32 const dfl_cap = c->max_slice_bytes < 65536u ? 65536u : c->max_slice_bytes;       // a context for smaller slices still takes 64 KiB ones
+    KMP_TRY(batch_begin(c, st, d_in_len, n, dfl_cap));
+    if (c->profiling) HIP_TRY(hipEventRecord(c->ev[6], st));
+    u32 chain_waves = c->knob.dfl_chain_waves; if (chain_waves < 1 || chain_waves > 4) chain_waves = 4;
+    bool const serial = c->knob.dfl_serial != 0;          // experiment switch: everything on the caller's stream
+    u32 piece = 0;
+    if (level >= 1 && level <= 3) {
+        // deflate_fast needs no link / best arrays: the head / prev tables of a slice (256 KiB) live where the KdBest entries of
+        // the lazy levels do, which has room for 4 * dfl_chunk slices.  The kernel is a lane per slice and bound by memory
+        // latency, so the more slices are in flight the better: symbols and block lists for that many slices are allocated
+        // on the first call at these levels (16 GiB with the default sizes; if that fails, pieces of 2 * dfl_chunk slices use
+        // the arrays of the lazy levels).  Everything runs on the caller's stream.
+        if (!c->dfl_ftried) {
+            c->dfl_ftried = 1;
+            size_t const cap4 = (size_t)4 * c->dfl_chunk;
+            if (c->max_slices > 2u * c->dfl_chunk && !c->knob.dfl_serial) {
+                if (hipMalloc((void**)&c->dfl_fsyms, cap4 * c->dfl_pos_cap * sizeof(u32)) != hipSuccess ||
+                    hipMalloc((void**)&c->dfl_fmeta, cap4 * sizeof(KdSliceMeta)) != hipSuccess ||
+                    hipMalloc((void**)&c->dfl_fblocks, cap4 * c->dfl_blk_cap * sizeof(KdBlockInfo)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    (void)hipFree(c->dfl_fsyms); (void)hipFree(c->dfl_fmeta); (void)hipFree(c->dfl_fblocks);
+                    c->dfl_fsyms = nullptr; c->dfl_fmeta = nullptr; c->dfl_fblocks = nullptr;
+                }
+            }
+        }
+        bool const wide = c->dfl_fsyms && c->dfl_fmeta && c->dfl_fblocks;
+        u32 const span = (wide ? 4u : 2u) * c->dfl_chunk;
+        for (u32 first = 0; first < n; first += span) {
+            u32 const m = (n - first < span) ? n - first : span;
+            KdArgs a;
+            a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = c->len_ok + first; a.n_slices = m;
+            a.pos_cap = c->dfl_pos_cap; a.blk_cap = c->dfl_blk_cap;
+            a.link = c->dfl_link; a.best = c->dfl_best;
+            a.syms = wide ? c->dfl_fsyms : c->dfl_syms; a.meta = wide ? c->dfl_fmeta : c->dfl_meta; a.blocks = wide ? c->dfl_fblocks : c->dfl_blocks;
+            a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
+            kd_level_config(a, level);
+            bool const prof = c->profiling && first == 0;
+            if (prof) { HIP_TRY(hipEventRecord(c->ev[8], st)); HIP_TRY(hipEventRecord(c->ev[9], st)); HIP_TRY(hipEventRecord(c->ev[10], st)); HIP_TRY(hipEventRecord(c->ev[13], st)); }
+            HIP_TRY(hipMemsetAsync(c->dfl_best, 0, (size_t)m * 32768u * sizeof(u32), st));          // the head tables
+            hipLaunchKernelGGL(k_deflate_fast, dim3((m + 63) / 64), dim3(64), 0, st, a);
+            if (prof) HIP_TRY(hipEventRecord(c->ev[11], st));
+            hipLaunchKernelGGL(k_deflate_encode, dim3(m), dim3(64), 0, st, a);
+            if (prof) HIP_TRY(hipEventRecord(c->ev[12], st));
+            HIP_TRY(hipGetLastError());
+        }
+        if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[7], st)); c->ev_valid[3] = 1; }
+        return batch_end(c, st, d_in_len, n, dfl_cap, d_out_len, nullptr);
+    }
+    for (u32 first = 0; first < n; first += c->dfl_chunk, piece++) {
+        u32 const m = (n - first < c->dfl_chunk) ? n - first : c->dfl_chunk;
+        u32 const h = piece & 1u;                                        // workspace half
+        KdArgs a;
+        a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = c->len_ok + first; a.n_slices = m;
+        size_t const half = (size_t)h * c->dfl_chunk;
+        a.pos_cap = c->dfl_pos_cap; a.blk_cap = c->dfl_blk_cap;
+        a.link = c->dfl_link + half * c->dfl_pos_cap; a.best = c->dfl_best + half * c->dfl_pos_cap;
+        a.syms = c->dfl_syms + half * c->dfl_pos_cap; a.meta = c->dfl_meta + half; a.blocks = c->dfl_blocks + half * c->dfl_blk_cap;
+        a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
+        kd_level_config(a, level);
+        bool const prof = c->profiling && first == 0;      // per-kernel events for the first piece
+        hipStream_t const s2 = serial ? st : c->st2;
+        if (!serial && piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[h], 0));      // this half's previous piece has been encoded
+        if (prof) HIP_TRY(hipEventRecord(c->ev[8], st));
+        if (c->dfl_pos_cap <= 65536u) hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(64u * chain_waves), 0, st, a);
+        else hipLaunchKernelGGL(k_deflate_chains_long, dim3(m), dim3(64u * chain_waves), 0, st, a);
+        if (prof) HIP_TRY(hipEventRecord(c->ev[9], st));
+        hipLaunchKernelGGL(k_deflate_best, dim3(m), dim3(1024), 0, st, a);
+        if (prof) HIP_TRY(hipEventRecord(c->ev[10], st));
+        if (!serial) { HIP_TRY(hipEventRecord(c->dfl_searched[h], st)); HIP_TRY(hipStreamWaitEvent(s2, c->dfl_searched[h], 0)); }
+        if (prof) HIP_TRY(hipEventRecord(c->ev[13], s2));
+        hipLaunchKernelGGL(k_deflate_parse, dim3((m + 63) / 64), dim3(64), 0, s2, a);
+        if (prof) HIP_TRY(hipEventRecord(c->ev[11], s2));
+        hipLaunchKernelGGL(k_deflate_encode, dim3(m), dim3(64), 0, s2, a);
+        if (prof) HIP_TRY(hipEventRecord(c->ev[12], s2));
+        HIP_TRY(hipGetLastError());
+        if (!serial) HIP_TRY(hipEventRecord(c->dfl_done[h], s2));
+    }
+    if (!serial) {                                                        // the caller's stream continues when every piece is out
+        HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[0], 0));
+        if (piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[1], 0));
+    }
+    if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[7], st)); c->ev_valid[3] = 1; }
+    return batch_end(c, st, d_in_len, n, dfl_cap, d_out_len, nullptr);
+}
+
+// per-kernel milliseconds of the first workspace chunk of the last deflate batch: chains, best, parse, encode
+extern "C" int kmp_deflate_last_kernel_ms(kmp_batch_ctx* c, float* ms4)
+{
+    if (!c || !ms4 || !c->ev_valid[3]) { g_last_error = "no deflate timing recorded"; return KMP_ERR_ARG; }
+    HIP_TRY(hipEventSynchronize(c->ev[12]));
+    static const int from[4] = { 8, 9, 13, 11 }, to[4] = { 9, 10, 11, 12 };
+    for (int i = 0; i < 4; i++) HIP_TRY(hipEventElapsedTime(&ms4[i], c->ev[from[i]], c->ev[to[i]]));
+    return KMP_OK;
+}

@@ -43,6 +43,9 @@ struct KMatchArgs {
     // geometry of a team's tables (entries): the level-3 one unless the batch runs level 4's double-fast row (level = 4)
     u32 tbl_stride = KX_TBL_ENTRIES, tbl_long = KX_TBL_LONG, level = 3;
     u32 big_stride = KX_BIG_TBL_ENTRIES, big_long = KX_BIG_TBL_LONG;      // block mode: a slice's tables (level 4: KX_BIG4_*)
+    // a piece of a batch on a stream of its own (kmp_zstd_compress_batch_pieces): this launch's workgroups own the teams from
+    // block_base * (64 / G) on, so that the pieces of one batch run side by side over disjoint team tables
+    u32 block_base = 0;
 };
 
 KX_DEV u32* kx_team_tables(const KMatchArgs& a, u32 team)
@@ -151,7 +154,7 @@ KX_DEV void zstd_match_body(const KMatchArgs& a, DONE const& done = DONE())
     int const lane = kx_lane();
     int const k = lane & (G - 1);
     int const tbase = lane - k;
-    u32 const team = kx_block() * NT + (u32)(lane / G);
+    u32 const team = (kx_block() + a.block_base) * NT + (u32)(lane / G);
     u32* L = BLK ? a.big_tables : kx_team_tables(a, team);
     u32* S = L + (BLK ? a.big_long : a.tbl_long);
     int bstart = 0; u32 saved1 = 0, saved2 = 0;          // block mode: block start, repcodes set aside at block start

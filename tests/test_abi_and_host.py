@@ -178,3 +178,29 @@ def test_cpu_bench_harness_times_the_oracle_port(tmp_path):
     o = helpers.oracle()
     assert fb.value == sum(len(o.compress(buf[i * S:(i + 1) * S].tobytes())) for i in range(n))
     assert bench.count_gpus_without_hip() in (-1, 0) or bench.count_gpus_without_hip() > 0
+
+
+def test_product_build_has_one_level3_parser_and_a_short_environment_surface():
+    """The product library carries one level-3 parser and reads a short, documented list of environment variables; the second
+    parser, the fused kernel and the experiment switches exist only in the ablation build (libkompressor_hip_abl.so, -DKMP_ABLATIONS),
+    which exports the same C ABI."""
+    import re
+    import subprocess
+    from kompressor_amd import _lib, build
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    build.build_all()
+    prod = open(build.HIP_LIB, "rb").read()
+    abl = open(build.HIP_LIB_ABL, "rb").read()
+    names = lambda blob: set(m.decode() for m in re.findall(rb"KMP_[A-Z][A-Z0-9_]+(?=\x00)", blob)) - {"KMP_MAX_CHUNKS"}      # noqa: E731
+    env_prod, env_abl = names(prod), names(abl)
+    assert len(env_prod) <= 20, sorted(env_prod)
+    assert env_prod < env_abl and {"KMP_MATCH_V2", "KMP_FUSE", "KMP_ZSTD_AUTOTUNE"} <= env_abl - env_prod
+    # every variable the product reads is in INTEGRATION.md's table
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert all(v in doc for v in env_prod), sorted(v for v in env_prod if v not in doc)
+    assert b"k_zstd_match2" not in prod and b"k_zstd_l3_fused" not in prod
+    assert b"k_zstd_match2" in abl and b"k_zstd_l3_fused" in abl
+    # same exports
+    for lib in (_lib.load(), _lib.load_ablations()):
+        for name, _, _ in _lib.SIGNATURES:
+            assert hasattr(lib, name)

@@ -228,8 +228,8 @@ def test_inflate_paths_agree_on_the_gpu(monkeypatch):
     streams.append(zlib.compress(big, 6)); caps.append(len(big)); datas.append(big)
     res = []
     for pre in ("1", "0"):
-        monkeypatch.setenv("KMP_INFLATE_PRE", pre)
-        b = ZstdBatch(max_slices=2048, max_slice_bytes=65536)
+        monkeypatch.setenv("KMP_INFLATE_PRE", pre)           # (a switch of the ablation build; the product always pre-decodes batches)
+        b = ZstdBatch(max_slices=2048, max_slice_bytes=65536, ablations=(pre == "0"))
         try:
             n = len(streams)
             lens = np.array([len(f) for f in streams], dtype=np.int32)

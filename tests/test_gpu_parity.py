@@ -174,19 +174,17 @@ def test_full_batch_roundtrip_and_checksum_of_checksums(monkeypatch):
     from kompressor_amd.batch import ZstdBatch
     G = helpers.golden()
     n, S = 65536, 65536
-    monkeypatch.setenv("KMP_ZSTD_AUTOTUNE", "1")           # (opt-in: one launch of each kernel or two chunks, tried once each)
-    monkeypatch.setenv("KMP_MATCH_V2", "0")
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
-    monkeypatch.setenv("KMP_TABLE_RETRY", "2")             # (always take the path that tries a second arena when the first is slow)
-    b = ZstdBatch(max_slices=n, max_slice_bytes=S)
-    monkeypatch.delenv("KMP_TABLE_RETRY")
+    b = ZstdBatch(max_slices=n, max_slice_bytes=S, table_retry=2)     # (2: always take the path that tries a second arena)
     torch.cuda.synchronize()
     taken = free0 - torch.cuda.mem_get_info()[0]
     # team tables 24 GiB + sequences 8.6 + literals 4.3 + staging words 4.3 GB + small change = 41 GiB of parts, laid out over
-    # the arena's default span of 100 GiB (KMP_TABLE_SPAN_GIB): what creation holds when it returns is the one arena (a second
-    # one, tried when the first is on slow memory, has been freed again -- or the first, when the second won)
+    # the arena's default span of 100 GiB (bounded by half of the free memory): what creation holds when it returns is the one
+    # arena (the second one, tried on request, has been freed again -- or the first, when the second won); kmp_batch_memory says so
     assert 99 << 30 < taken < 103 << 30, taken / 2 ** 30
+    mem = b.memory()
+    assert (100 << 30) - (8 << 20) <= mem["arena"] <= 100 << 30 and 40 << 30 < mem["arena_used"] < 43 << 30 and mem["total"] < taken + (1 << 28), mem
     src = torch.empty(n * S, dtype=torch.uint8, device="cuda")
     chunk = 4096
     for c in range(0, n, chunk):
@@ -209,19 +207,6 @@ def test_full_batch_roundtrip_and_checksum_of_checksums(monkeypatch):
     assert torch.equal(out[: n * S], src)
     ratio = n * S / float(lens.astype(np.int64).sum())
     assert 2.3 < ratio < 2.7, ratio
-    # a context tries "one launch of each kernel" on its first batch of this size and "two chunks" on its second, then keeps
-    # the faster (kmp_api.hip): all of them give the same frames
-    first_lens = olen.clone(); probe = [int(ooff[i]) for i in (0, 1, 40000, n - 1)]
-    first_bytes = [dst[o:o + int(first_lens[i])].clone() for o, i in zip(probe, (0, 1, 40000, n - 1))]
-    seen = {b.last_chunks()}
-    for _ in range(2):
-        dst2, ooff2, olen2 = b.compress(src, in_off, in_len, dst, ooff, olen)
-        torch.cuda.synchronize()
-        seen.add(b.last_chunks())
-        assert torch.equal(olen2, first_lens)
-        for o, i, fb in zip(probe, (0, 1, 40000, n - 1), first_bytes):
-            assert torch.equal(dst2[o:o + int(first_lens[i])], fb)
-    assert seen == {1, 2}
     # dense packing helper: offsets are the exclusive scan, bytes unchanged
     packed, offs = b.compact(dst, ooff, olen)
     torch.cuda.synchronize()
@@ -240,40 +225,17 @@ def test_full_batch_roundtrip_and_checksum_of_checksums(monkeypatch):
         lo, hi = int(offs[g * F["group"]]), int(offs[(g + 1) * F["group"]])
         assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"group {g} differs from libzstd 1.5.7"
     del host, packed
-    # the split-phase parser (zstd_match2.h, KMP_MATCH_V2): the same 65 536 frames
-    monkeypatch.setenv("KMP_MATCH_V2", "2")
-    monkeypatch.setenv("KMP_ZSTD_AUTOTUNE", "0")
-    monkeypatch.setenv("KMP_TABLE_SPAN_GIB", "0")          # (the packed arena)
+    # a second context beside the first gets a bounded arena by itself: half of what is free now, or packed -- never another 100 GiB
     free1 = torch.cuda.mem_get_info()[0]
     b2 = ZstdBatch(max_slices=n, max_slice_bytes=S)
     torch.cuda.synchronize()
-    assert 38 << 30 < free1 - torch.cuda.mem_get_info()[0] < 43 << 30
-    monkeypatch.delenv("KMP_TABLE_SPAN_GIB")
+    took2 = free1 - torch.cuda.mem_get_info()[0]
+    assert took2 <= free1 // 2 + (1 << 30) and b2.memory()["arena"] <= free1 // 2, (took2, free1)
     dst2, ooff2, olen2 = b2.compress(src, in_off, in_len, check=True)
-    packed2, offs2 = b2.compact(dst2, ooff2, olen2)
     torch.cuda.synchronize()
-    offs2 = offs2.cpu().numpy(); host = packed2.cpu().numpy()
-    for g, total, sha in F["config1_zstd3"]:
-        lo, hi = int(offs2[g * F["group"]]), int(offs2[(g + 1) * F["group"]])
-        assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"split-phase parser: group {g} differs from libzstd 1.5.7"
+    assert torch.equal(olen2, olen)
     b2.close()
-    del host, packed2, dst2
-    # k_zstd_l3_fused (KMP_FUSE: the entropy stage inside the parse kernel's waves): the same 65 536 frames
-    monkeypatch.setenv("KMP_MATCH_V2", "0")
-    monkeypatch.setenv("KMP_FUSE", "1")
-    monkeypatch.setenv("KMP_TABLE_SPAN_GIB", "0")
-    b3 = ZstdBatch(max_slices=n, max_slice_bytes=S)
-    monkeypatch.delenv("KMP_TABLE_SPAN_GIB")
-    monkeypatch.delenv("KMP_FUSE")
-    dst3, ooff3, olen3 = b3.compress(src, in_off, in_len, check=True)
-    packed3, offs3 = b3.compact(dst3, ooff3, olen3)
-    torch.cuda.synchronize()
-    offs3 = offs3.cpu().numpy(); host = packed3.cpu().numpy()
-    for g, total, sha in F["config1_zstd3"]:
-        lo, hi = int(offs3[g * F["group"]]), int(offs3[(g + 1) * F["group"]])
-        assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"fused kernel: group {g} differs from libzstd 1.5.7"
-    b3.close()
-    del host, packed3, dst3
+    del dst2
     # ... and all 65 536 raw DEFLATE level-6 streams of configs[4] against zlib, the same way
     ddst, doff, dlen = b.deflate(src, in_off, in_len)
     dpacked, doffs = b.compact(ddst, doff, dlen)
@@ -300,6 +262,58 @@ def test_full_batch_roundtrip_and_checksum_of_checksums(monkeypatch):
             assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"configs[3] group {g} differs from libzstd 1.5.7"
         del host, packed
     b.close()
+
+
+@pytest.mark.timeout(900)
+def test_ablation_build_gives_the_same_frames(monkeypatch):
+    """The ablation build of the library (-DKMP_ABLATIONS: libkompressor_hip_abl.so, a second handle in this process) carries what
+    the product build compiles out: the split-phase parser (zstd_match2.h, KMP_MATCH_V2), the fused kernel (KMP_FUSE), the trial of
+    launch settings (KMP_ZSTD_AUTOTUNE).  All 65 536 configs[1] frames from each equal libzstd 1.5.7's (one sha256 per 4 096-slice
+    group, tests/golden/fullsize_golden.json)."""
+    from kompressor_amd.batch import ZstdBatch
+    n, S = 65536, 65536
+    F = helpers.fullsize_golden()
+    src = torch.empty(n * S, dtype=torch.uint8, device="cuda")
+    chunk = 4096
+    for c in range(0, n, chunk):
+        src[c * S:(c + chunk) * S] = torch.from_numpy(corpus.make(c, chunk, S)).cuda()
+    in_off = torch.arange(n, dtype=torch.int64, device="cuda") * S
+    in_len = torch.full((n,), S, dtype=torch.int32, device="cuda")
+
+    def check(b, what, dst=None, ooff=None, olen=None):
+        dst, ooff, olen = b.compress(src, in_off, in_len, dst, ooff, olen, check=True)
+        packed, offs = b.compact(dst, ooff, olen)
+        torch.cuda.synchronize()
+        offs = offs.cpu().numpy(); host = packed.cpu().numpy()
+        for g, total, sha in F["config1_zstd3"]:
+            lo, hi = int(offs[g * F["group"]]), int(offs[(g + 1) * F["group"]])
+            assert hi - lo == total and hashlib.sha256(host[lo:hi]).hexdigest() == sha, f"{what}: group {g} differs from libzstd 1.5.7"
+        return dst, ooff, olen
+
+    for what, env in (("split-phase parser", {"KMP_MATCH_V2": "2"}), ("fused kernel", {"KMP_FUSE": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        b = ZstdBatch(max_slices=n, max_slice_bytes=S, ablations=True, table_span_gib=0)      # (the packed arena)
+        for k in env:
+            monkeypatch.delenv(k)
+        try:
+            check(b, what)
+        finally:
+            b.close()
+    # the trial of launch settings: "one launch of each kernel" on the first batch of this size, "two chunks" on the second, then the
+    # faster -- all of them give the same frames
+    monkeypatch.setenv("KMP_ZSTD_AUTOTUNE", "1")
+    b = ZstdBatch(max_slices=n, max_slice_bytes=S, ablations=True, table_span_gib=0)
+    monkeypatch.delenv("KMP_ZSTD_AUTOTUNE")
+    try:
+        seen = set()
+        bufs = (None, None, None)
+        for r in range(3):
+            bufs = check(b, f"autotune batch {r}", *bufs)
+            seen.add(b.last_chunks())
+        assert seen == {1, 2}
+    finally:
+        b.close()
 
 
 def test_streaming_abi_one_shot_like_the_reference(G):
@@ -370,13 +384,13 @@ def test_multiblock_frames_match_libzstd():
             assert len(f) == row["len"] and helpers.sha256(f) == row["sha256"], name
         for d, f in zip(small, frames[len(datas):]):
             assert f == o.compress(d), len(d)
-        # several slices per wave, and the same steps as separate launches per round of blocks (experiment switches)
+        # several slices per wave, and the same steps as separate launches per round of blocks (experiment switches of the ablation build)
         import os
         # (the switches are read when a context is created)
         for key, val in (("KMP_BIG_SLICES_PER_WAVE", "4"), ("KMP_BIG_ROUNDS", "1")):
             os.environ[key] = val
             try:
-                b2 = ZstdBatch(max_slices=len(datas) + len(small), max_slice_bytes=2 << 20)
+                b2 = ZstdBatch(max_slices=len(datas) + len(small), max_slice_bytes=2 << 20, ablations=True)
             finally:
                 del os.environ[key]
             try:
@@ -556,7 +570,7 @@ def test_levels_1_and_2(batch):
 
 @pytest.mark.timeout(900)
 def test_differential_fuzz_against_the_live_library():
-    """tools/r03_fuzz.py / r03_fuzz_big.py at a small size (their long runs are in profiles/r03_fuzz.txt): ragged stress inputs and
+    """tools/fuzz_gpu.py / fuzz_gpu_big.py at a small size (their long runs are in profiles/r03_fuzz.txt): ragged stress inputs and
     corpus slices through every level-3 path, levels 1, 2, 4 and three negative ones, two dictionary sizes and three DEFLATE levels,
     and frames of several blocks in seven forms -- every frame against the binary libzstd 1.5.7 / zlib of THIS machine.  The
     GPU boxes carry that library: where it is missing the test fails (helpers.require_live_libzstd), it does not skip."""
@@ -565,7 +579,7 @@ def test_differential_fuzz_against_the_live_library():
     import sys
     helpers.require_live_libzstd()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for tool, args in (("r03_fuzz.py", ["7", "6000"]), ("r03_fuzz_big.py", ["7", "300"])):
+    for tool, args in (("fuzz_gpu.py", ["7", "6000"]), ("fuzz_gpu_big.py", ["7", "300"])):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", tool)] + args, capture_output=True, text=True, timeout=420)
         assert r.returncode == 0 and "FUZZ OK" in r.stdout, (tool, r.stdout[-1500:], r.stderr[-1500:])
 
@@ -1274,8 +1288,8 @@ def test_predecode_kernels_give_the_same_frames(monkeypatch):
     ref = ZstdBatch(max_slices=800, max_slice_bytes=2 << 20)
     others = []
     for mode in ("0", "1", "2"):
-        monkeypatch.setenv("KMP_DECODE_PRE", mode)
-        others.append(ZstdBatch(max_slices=800, max_slice_bytes=2 << 20))
+        monkeypatch.setenv("KMP_DECODE_PRE", mode)           # (a switch of the ablation build)
+        others.append(ZstdBatch(max_slices=800, max_slice_bytes=2 << 20, ablations=True))
     monkeypatch.delenv("KMP_DECODE_PRE")
     monkeypatch.setenv("KMP_DECODE_STAGE_SLICES", "256")         # staging for 256 entries: the batch goes through in pieces that reuse it
     others.append(ZstdBatch(max_slices=800, max_slice_bytes=2 << 20))
@@ -1341,3 +1355,70 @@ def test_fuzz_long_slices_all_framings_against_oracle():
                     assert f == ref(d), (cap, kw, len(d))
         finally:
             b.close()
+
+
+def test_batch_in_pieces_side_by_side(G):
+    """kmp_zstd_compress_batch_pieces: the level-3 batch cut into 1 .. 8 parts, part p queued on a stream of its own behind the copy that
+    brings its slices in, the parts sharing the context (disjoint team slots and workspace).  Frames are bit for bit the one-launch
+    batch's (the 2 048 golden slices of configs[1] among them), for equal and for ragged slices, and a plain batch on the same context
+    afterwards waits for the parts."""
+    from kompressor_amd.batch import ZstdBatch
+    n, S = 8192, 65536
+    host = corpus.make(0, n, S)
+    pin = torch.from_numpy(host).pin_memory()
+    b = ZstdBatch(max_slices=n, max_slice_bytes=131072, team_lanes=4)
+    try:
+        src = torch.from_numpy(host).cuda()
+        in_off = torch.arange(n, dtype=torch.int64, device="cuda") * S
+        in_len = torch.full((n,), S, dtype=torch.int32, device="cuda")
+        ref, ooff, rlen = b.compress(src, in_off, in_len, check=True)
+        torch.cuda.synchronize()
+        ref = ref.clone(); rlen = rlen.clone()
+        lens = rlen.cpu().numpy()
+        for i, cls, flen, sha in G["config1"]:
+            assert lens[i] == flen
+        for P in (1, 3, 4, 8):
+            streams = [torch.cuda.Stream() for _ in range(P)]
+            src2 = torch.zeros(n * S, dtype=torch.uint8, device="cuda")
+            dst = torch.zeros_like(ref); olen = torch.zeros_like(rlen)
+            torch.cuda.synchronize()
+            covered = 0
+            for p in range(P):
+                first, cnt = b.piece_range(n, P, p)
+                assert first == covered
+                covered += cnt
+                with torch.cuda.stream(streams[p]):
+                    src2[first * S:(first + cnt) * S].copy_(pin[first * S:(first + cnt) * S], non_blocking=True)
+            assert covered == n
+            b.compress_pieces(src2, in_off, in_len, dst, ooff, olen, streams)
+            # a plain batch right behind the pieces, on the default stream: it must wait for them (shared workspace)
+            d3, o3, l3 = b.compress(src, in_off, in_len)
+            torch.cuda.synchronize()
+            assert b.status() == (0, 0)
+            assert torch.equal(olen, rlen) and torch.equal(l3, rlen), P
+            hd, hr, ho = dst.cpu().numpy(), ref.cpu().numpy(), ooff.cpu().numpy()
+            for i in range(n):
+                assert hd[ho[i]:ho[i] + lens[i]].tobytes() == hr[ho[i]:ho[i] + lens[i]].tobytes(), (P, i)
+            for i, cls, flen, sha in G["config1"][::16]:
+                assert helpers.sha256(hd[ho[i]:ho[i] + lens[i]].tobytes()) == sha, (P, i)
+        # ragged slices (0 .. 128 KiB), five pieces, against the oracle
+        rng = np.random.default_rng(11)
+        sizes = [int(x) for x in rng.integers(0, 131073, 700)] + [0, 1, 7, 8, 131072]
+        datas = [corpus.make(5000 + k, 1, max(s, 1), mix=ord("TXSBDIZR"[k % 8])).tobytes()[:s] for k, s in enumerate(sizes)]
+        m = len(datas)
+        rl = np.array(sizes, dtype=np.int32); ro = np.concatenate([[0], np.cumsum(rl[:-1].astype(np.int64))]).astype(np.int64)
+        rh = torch.from_numpy(np.frombuffer(b"".join(datas) + bytes(64), dtype=np.uint8).copy()).cuda()
+        streams = [torch.cuda.Stream() for _ in range(5)]
+        dst = torch.zeros(m * b.out_stride + 64, dtype=torch.uint8, device="cuda")
+        ooff2 = torch.arange(m, dtype=torch.int64, device="cuda") * b.out_stride
+        olen2 = torch.zeros(m, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        b.compress_pieces(rh, torch.from_numpy(ro).cuda(), torch.from_numpy(rl).cuda(), dst, ooff2, olen2, streams)
+        torch.cuda.synchronize()
+        assert b.status() == (0, 0)
+        o = helpers.oracle()
+        hd, hl = dst.cpu().numpy(), olen2.cpu().numpy()
+        for i, d in enumerate(datas):
+            assert hd[i * b.out_stride:i * b.out_stride + hl[i]].tobytes() == o.compress(d), (i, len(d))
+    finally:
+        b.close()

@@ -2,7 +2,7 @@
 small alphabets, periodic data, abrupt regime changes) and of the corpus classes through every level-3 path (team width 4, the
 per-batch width 8, the split-phase parser, the fused kernel), levels 1, 2, 4 and three negative ones, and raw DEFLATE at levels 1, 6 and 9 -- EVERY frame compared with the binary
 libzstd 1.5.7 (DEFLATE: with this machine's zlib) on the host cores (Pillow's copy: test infrastructure, looked up by oracle/libzstd_ref.py), and decoded back on
-the GPU.  usage: python tools/r03_fuzz.py [seed] [n_slices]"""
+the GPU.  usage: python tools/fuzz_gpu.py [seed] [n_slices]"""
 import os, sys, ctypes, subprocess, time
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -55,7 +55,7 @@ d_off = torch.from_numpy(offs).cuda(); d_len = torch.from_numpy(lens.astype(np.i
 def gpu_frames(env, level, n_ctx, piece, idx):
     for k in ("KMP_MATCH_V2", "KMP_FUSE"): os.environ.pop(k, None)
     os.environ.update(env)
-    b = ZstdBatch(max_slices=n_ctx, max_slice_bytes=131072)
+    b = ZstdBatch(max_slices=n_ctx, max_slice_bytes=131072, ablations=bool(env))      # (the split-phase parser and the fused kernel live in the ablation build)
     sel = torch.from_numpy(np.asarray(idx, dtype=np.int64)).cuda()
     o_all, l_all = d_off[sel], d_len[sel]
     frames = {}

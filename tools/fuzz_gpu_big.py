@@ -1,7 +1,7 @@
 """Differential fuzz of the block-chain path (frames of several blocks, slices of 128 KiB + 1 .. 1.5 MiB): stress inputs
 (tools/fuzzgen.c) and corpus classes; the frames the reference's one-shot driver gets (output slices of max(8192, n / 10) bytes:
 libzstd stages the input in 128 KiB chunks), ZSTD_compress2's frames, level 1 and three negative levels (up to their 512 KiB window) -- every frame against
-the binary libzstd 1.5.7 on the host cores, every frame decoded back on the GPU.  usage: python tools/r03_fuzz_big.py [seed] [n]"""
+the binary libzstd 1.5.7 on the host cores, every frame decoded back on the GPU.  usage: python tools/fuzz_gpu_big.py [seed] [n]"""
 import os, sys, ctypes, subprocess, time
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
