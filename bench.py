@@ -179,17 +179,36 @@ def streaming_abi_figure(host, n_slices):
         caps = np.full(n_slices, cap, dtype=np.uint32); ooff = np.arange(n_slices, dtype=np.uint64) * cap
         out = np.empty(n_slices * cap + 64, dtype=np.uint8); olen = np.zeros(n_slices, dtype=np.uint32)
         vp = lambda a: ctypes.c_void_p(a.ctypes.data)          # noqa: E731
-        times = []
-        for _ in range(3):                                      # (the first pass makes the engines)
-            t0 = time.perf_counter()
-            rc = lib.kmp_zstd_compress_host_batch(0, 3, vp(host), vp(offs), vp(lens), n_slices, vp(out), vp(ooff), vp(caps), vp(olen))
-            times.append(time.perf_counter() - t0)
-            if rc != 0:
-                times = None
-                break
+        def passes(k):
+            ts = []
+            for _ in range(k):
+                t0 = time.perf_counter()
+                rc = lib.kmp_zstd_compress_host_batch(0, 3, vp(host), vp(offs), vp(lens), n_slices, vp(out), vp(ooff), vp(caps), vp(olen))
+                ts.append(time.perf_counter() - t0)
+                if rc != 0:
+                    return None
+            return ts
+        times = passes(3)                                       # (the first pass makes the bulk compressor)
         if times:
-            bulk = {"GBps": round(n_slices * SLICE / min(times[1:]) / 1e9, 3), "ms": round(min(times[1:]) * 1e3, 1), "slices": n_slices,
-                    "frame_bytes": int(olen.astype(np.int64).sum()), "first_pass_ms_with_engine_setup": round(times[0] * 1e3, 1)}
+            pageable = {"GBps": round(n_slices * SLICE / min(times[1:]) / 1e9, 3), "ms": round(min(times[1:]) * 1e3, 1),
+                        "first_pass_ms_with_setup": round(times[0] * 1e3, 1)}
+            fb = int(olen.astype(np.int64).sum())
+            # the same buffers made page-stable (kmp_host_register: what a Kotlin caller does once for a direct ByteBuffer it reuses)
+            from kompressor_amd.batch import host_register, host_unregister
+            t0 = time.perf_counter()
+            host_register(host); host_register(out)
+            reg_ms = (time.perf_counter() - t0) * 1e3
+            try:
+                rt = passes(3)
+            finally:
+                host_unregister(host); host_unregister(out)
+            if rt:
+                bulk = {"GBps": round(n_slices * SLICE / min(rt[1:]) / 1e9, 3), "ms": round(min(rt[1:]) * 1e3, 1), "slices": n_slices,
+                        "frame_bytes": int(olen.astype(np.int64).sum()), "frame_bytes_equal_pageable_run": bool(int(olen.astype(np.int64).sum()) == fb),
+                        "memory": "registered (kmp_host_register: the device reads the slices and writes the frames itself)",
+                        "register_ms_both_buffers_once": round(reg_ms, 1), "pageable": pageable}
+            else:
+                bulk = dict(pageable, slices=n_slices, frame_bytes=fb, memory="pageable (registered run failed)")
         del out
     one_us, many_us = one_dt / one_n * 1e6, many_dt / (T * per) * 1e6
     return {"one_context": {"us_per_slice": round(one_us, 1), "GBps": round(SLICE / one_us / 1e3, 4), "slices": one_n},

@@ -361,10 +361,16 @@ KMP_API int kmp_debug_probe_region(void* d_region, size_t bytes, uint32_t blocks
 
 /* The batch for callers that hold HOST memory (the JVM): slices h_src[in_off[i] .. + in_len[i]) of at most 128 KiB in, frames at
  * h_dst[out_off[i] ..) out (out_cap[i] bytes of room: kmp_zstd_compress_bound(in_len[i]) always suffices), out_len[i] = frame
- * size (0 with KMP_ERR_CAPACITY when the room was too small).  Levels 1 .. 3; the frames are what ZstdCompressor(level) returns
- * for each slice on its own.  Pinned staging, one copy in, the device batch, one copy out; batches larger than the staging go
- * through in pieces.  jni/zstd/BatchWrapper.cpp binds the two for direct ByteBuffers.  Reference counterpart: none -- the
- * reference compresses one slice per call (ZstdWrapper.kt:35-46); this is the call a maintainer adds to hand the GPU a batch.
+ * size (0 with KMP_ERR_CAPACITY when the room was too small).  Levels -131072 .. 4 (0 = 3): what kmp_zstd_compress_batch_level serves
+ * for one-block slices -- the frames are what ZstdCompressor(level) returns for each slice on its own; a level-4 batch's slices of
+ * 16 KiB or less (that level's "greedy" size class) come back with out_len 0 and the call returns KMP_ERR_CAPACITY after every other
+ * slice has been compressed.  out_len is written for every slice whatever the return value.
+ * A small batch goes through pinned staging and one device batch.  A large level-3 batch (more than 2 * KMP_HOST_BATCH_SLICES slices)
+ * goes through the pipelined bulk compressor: eight pieces that run side by side on the device (kmp_zstd_compress_batch_pieces), each
+ * piece's copy in, kernels and copy out overlapping the others'.  Memory the caller has made page-stable -- kmp_host_register, or its
+ * own pinned allocation -- is read and written by the device directly; pageable memory goes through pinned staging filled and emptied
+ * by KMP_HOST_BULK_WORKERS host threads.  jni/zstd/BatchWrapper.cpp binds the calls for direct ByteBuffers.  Reference counterpart:
+ * none -- the reference compresses one slice per call (ZstdWrapper.kt:35-46); this is the call a maintainer adds to hand the GPU a batch.
  * kmp_zstd_compress_stream itself coalesces the closing calls of concurrent contexts into such batches (KMP_COALESCE=0: off;
  * KMP_COALESCE_US: the gather window, default 150 microseconds; KMP_COALESCE_MAX: slices per batch, default 256). */
 KMP_API int kmp_zstd_compress_host_batch(int device, int level, const void* h_src, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
@@ -372,6 +378,15 @@ KMP_API int kmp_zstd_compress_host_batch(int device, int level, const void* h_sr
 /* frames in, content out (out_cap[i] = room, at most 128 KiB); status[i] = libzstd's error number for entry i, 0 = fine */
 KMP_API int kmp_zstd_decompress_host_batch(int device, const void* h_src, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
                                            void* h_dst, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len, uint32_t* status);
+/* Page-stable caller memory: pins [ptr, ptr + bytes) and maps it for the device (hipHostRegister), so that the host-batch calls read
+ * slices from it and write frames into it over PCIe without a staging copy -- what the reference's JNI layer borrows and releases
+ * around every call (GetByteArrayElements / ReleaseByteArrayElements, Wrapper.cpp:92-118), borrowed once for a buffer that outlives
+ * many calls: a direct ByteBuffer a Kotlin caller reuses.  Unregister before the memory is freed. */
+KMP_API int kmp_host_register(void* ptr, size_t bytes);
+KMP_API int kmp_host_unregister(void* ptr);
+/* Gives back what the host-batch calls and the coalescer of the streaming entry points hold on `device` (-1: every device): pinned
+ * staging, device buffers, batch contexts.  The next call that needs them makes them again.  Not while such a call is running. */
+KMP_API int kmp_host_engines_release(int device);
 
 /* diagnostic (no reference counterpart): random 4-byte loads per second, and load + store-into-the-same-word pairs per second,
  * over the context's level-3 team tables where they lie, measured once when the context was created (both 0 for a context

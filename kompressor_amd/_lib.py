@@ -63,6 +63,9 @@ SIGNATURES = [
     ("kmp_batch_last_rounds", _c.c_int, [_P]),
     ("kmp_zstd_compress_host_batch", _c.c_int, [_c.c_int, _c.c_int, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P]),
     ("kmp_zstd_decompress_host_batch", _c.c_int, [_c.c_int, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P, _P]),
+    ("kmp_host_register", _c.c_int, [_P, _c.c_size_t]),
+    ("kmp_host_unregister", _c.c_int, [_P]),
+    ("kmp_host_engines_release", _c.c_int, [_c.c_int]),
     ("kmp_batch_table_rates", _c.c_int, [_P, _c.POINTER(_c.c_float), _c.POINTER(_c.c_float)]),
     ("kmp_debug_copy_meta", _c.c_int, [_P, _P, _c.c_uint32]),
     ("kmp_debug_probe_region", _c.c_int, [_P, _c.c_size_t, _c.c_uint32, _c.c_uint32, _c.POINTER(_c.c_float), _P]),

@@ -63,6 +63,27 @@ def decompress_host_batch(frames, caps, device=0):
     return [dst[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)], [int(x) for x in st]
 
 
+def host_register(array):
+    """kmp_host_register over a numpy array's memory (pins it and maps it for the device); unregister with host_unregister before
+    the array goes away."""
+    rc = _lib.load().kmp_host_register(ctypes.c_void_p(array.ctypes.data), array.nbytes)
+    if rc != 0:
+        raise RuntimeError(f"kmp_host_register failed ({rc}): {_lib.last_error()}")
+
+
+def host_unregister(array):
+    rc = _lib.load().kmp_host_unregister(ctypes.c_void_p(array.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"kmp_host_unregister failed ({rc}): {_lib.last_error()}")
+
+
+def host_engines_release(device=-1):
+    """kmp_host_engines_release: the pinned staging, device buffers and contexts behind the host-batch calls and the coalescer."""
+    rc = _lib.load().kmp_host_engines_release(device)
+    if rc != 0:
+        raise RuntimeError(f"kmp_host_engines_release failed ({rc}): {_lib.last_error()}")
+
+
 class ZstdBatch:
     """Owns the device workspace for batches of up to `max_slices` slices of up to
     `max_slice_bytes` bytes (<= 128 KiB) on one GPU."""

@@ -1111,55 +1111,95 @@ extern "C" void kmp_batch_piece_range(uint32_t n, uint32_t pieces, uint32_t piec
     if (first) *first = a;
     if (count) *count = b > a ? b - a : 0u;
 }
+// the three steps of a batch in pieces (kmp_coalesce.h queues a piece as soon as its copy in is queued)
+int pieces_begin(kmp_batch_ctx* c, u32 pieces, void* const* hip_streams)
+{
+    if (!c || !hip_streams) { g_last_error = "kmp_zstd_compress_batch_pieces: null argument"; return KMP_ERR_ARG; }
+    if (pieces < 1 || pieces > KMP_MAX_PIECES) { g_last_error = "kmp_zstd_compress_batch_pieces: 1 .. 8 pieces"; return KMP_ERR_ARG; }
+    if (c->big) { g_last_error = "kmp_zstd_compress_batch_pieces: contexts for slices up to 128 KiB only"; return KMP_ERR_CAPACITY; }
+    if (c->match_blocks_l3 / pieces == 0) { g_last_error = "kmp_zstd_compress_batch_pieces: more pieces than the context has workgroups"; return KMP_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    // every stream first waits for whatever ran on this context before (a batch, or the pieces of one)
+    for (u32 p = 0; p < pieces; p++) KMP_TRY(batch_wait_previous(c, (hipStream_t)hip_streams[p]));
+    return KMP_OK;
+}
+int piece_enqueue(kmp_batch_ctx* c, u32 p, u32 pieces, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
+                  void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st)
+{
+    u32 const tpw = 64 / (u32)c->G;
+    u32 const blocks_per_piece = c->match_blocks_l3 / pieces;
+    u32 first = 0, m_n = 0; kmp_batch_piece_range(n, pieces, p, &first, &m_n);
+    if (m_n == 0) { HIP_TRY(hipEventRecord(c->ev_piece[p], st)); return KMP_OK; }
+    hipLaunchKernelGGL(k_len_guard, dim3((m_n + 255) / 256), dim3(256), 0, st, d_in_len + first, m_n, c->max_slice_bytes, c->len_ok + first, c->d_status);
+    HIP_TRY(hipMemsetAsync(c->counter + p, 0, 4, st));
+    KMatchArgs m;
+    m.src = (const u8*)d_src; m.in_off = d_in_off + first; m.in_len = c->len_ok + first; m.n_slices = m_n;
+    m.seqs = c->seqs + (size_t)first * c->seq_cap; m.seq_cap = c->seq_cap; m.meta = c->meta + first;
+    m.lits = c->lits + (size_t)first * c->lit_cap; m.lit_cap = c->lit_cap;
+    m.tables = c->tables; for (int ts_ = 0; ts_ < 4; ts_++) m.tseg[ts_] = c->tseg[ts_]; m.tseg_n = c->tseg_n; m.team_epoch = c->team_epoch;
+    m.counter = c->counter + p; m.flags = c->knob.match_flags; m.block_base = p * blocks_per_piece;
+    u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > blocks_per_piece) blocks = blocks_per_piece;
+    switch (c->G) {
+    case 2:  hipLaunchKernelGGL(k_zstd_match<2>, dim3(blocks), dim3(64), 0, st, m); break;
+    case 4:  hipLaunchKernelGGL(k_zstd_match<4>, dim3(blocks), dim3(64), 0, st, m); break;
+    case 8:  hipLaunchKernelGGL(k_zstd_match<8>, dim3(blocks), dim3(64), 0, st, m); break;
+    case 16: hipLaunchKernelGGL(k_zstd_match<16>, dim3(blocks), dim3(64), 0, st, m); break;
+    case 32: hipLaunchKernelGGL(k_zstd_match<32>, dim3(blocks), dim3(64), 0, st, m); break;
+    default: hipLaunchKernelGGL(k_zstd_match<64>, dim3(blocks), dim3(64), 0, st, m); break;
+    }
+    HIP_TRY(hipGetLastError());
+    KEntropyArgs e;
+    e.src = (const u8*)d_src; e.in_off = d_in_off + first; e.in_len = c->len_ok + first; e.n_slices = m_n;
+    e.seqs = m.seqs; e.seq_cap = c->seq_cap; e.lits = m.lits; e.lit_cap = c->lit_cap; e.meta = m.meta;
+    e.scratch = c->scratch + (size_t)first * c->scratch_words; e.scratch_words = c->scratch_words;
+    e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = c->knob.entropy_flags | ((m.flags & 4u) ? 8u : 0u);
+    hipLaunchKernelGGL(k_zstd_entropy, dim3(m_n), dim3(64), 0, st, e);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_len_guard_finish, dim3((m_n + 255) / 256), dim3(256), 0, st, d_in_len + first, m_n, c->max_slice_bytes, d_out_len + first, c->meta + first, c->d_status);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev_piece[p], st));
+    return KMP_OK;
+}
+void pieces_end(kmp_batch_ctx* c, u32 pieces) { c->have_done = 0; c->pieces_pending = pieces; c->last_chunks = pieces; }
+
 extern "C" int kmp_zstd_compress_batch_pieces(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
                                               void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, uint32_t pieces, void* const* hip_streams)
 {
     if (!c || !hip_streams || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_pieces: null argument"; return KMP_ERR_ARG; }
-    if (pieces < 1 || pieces > KMP_MAX_PIECES) { g_last_error = "kmp_zstd_compress_batch_pieces: 1 .. 8 pieces"; return KMP_ERR_ARG; }
-    if (c->big) { g_last_error = "kmp_zstd_compress_batch_pieces: contexts for slices up to 128 KiB only"; return KMP_ERR_CAPACITY; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_pieces: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
+    KMP_TRY(pieces_begin(c, pieces, hip_streams));
     if (n == 0) return KMP_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    u32 const tpw = 64 / (u32)c->G;
-    u32 const blocks_per_piece = c->match_blocks_l3 / pieces;
-    if (blocks_per_piece == 0) { g_last_error = "kmp_zstd_compress_batch_pieces: more pieces than the context has workgroups"; return KMP_ERR_ARG; }
-    // every stream first waits for whatever ran on this context before (a batch, or the pieces of one) ...
-    for (u32 p = 0; p < pieces; p++) KMP_TRY(batch_wait_previous(c, (hipStream_t)hip_streams[p]));
-    // ... then gets its piece
-    for (u32 p = 0; p < pieces; p++) {
-        hipStream_t const st = (hipStream_t)hip_streams[p];
-        u32 first = 0, m_n = 0; kmp_batch_piece_range(n, pieces, p, &first, &m_n);
-        if (m_n == 0) { HIP_TRY(hipEventRecord(c->ev_piece[p], st)); continue; }
-        hipLaunchKernelGGL(k_len_guard, dim3((m_n + 255) / 256), dim3(256), 0, st, d_in_len + first, m_n, c->max_slice_bytes, c->len_ok + first, c->d_status);
-        HIP_TRY(hipMemsetAsync(c->counter + p, 0, 4, st));
-        KMatchArgs m;
-        m.src = (const u8*)d_src; m.in_off = d_in_off + first; m.in_len = c->len_ok + first; m.n_slices = m_n;
-        m.seqs = c->seqs + (size_t)first * c->seq_cap; m.seq_cap = c->seq_cap; m.meta = c->meta + first;
-        m.lits = c->lits + (size_t)first * c->lit_cap; m.lit_cap = c->lit_cap;
-        m.tables = c->tables; for (int ts_ = 0; ts_ < 4; ts_++) m.tseg[ts_] = c->tseg[ts_]; m.tseg_n = c->tseg_n; m.team_epoch = c->team_epoch;
-        m.counter = c->counter + p; m.flags = c->knob.match_flags; m.block_base = p * blocks_per_piece;
-        u32 blocks = (m_n + tpw - 1) / tpw; if (blocks > blocks_per_piece) blocks = blocks_per_piece;
-        switch (c->G) {
-        case 2:  hipLaunchKernelGGL(k_zstd_match<2>, dim3(blocks), dim3(64), 0, st, m); break;
-        case 4:  hipLaunchKernelGGL(k_zstd_match<4>, dim3(blocks), dim3(64), 0, st, m); break;
-        case 8:  hipLaunchKernelGGL(k_zstd_match<8>, dim3(blocks), dim3(64), 0, st, m); break;
-        case 16: hipLaunchKernelGGL(k_zstd_match<16>, dim3(blocks), dim3(64), 0, st, m); break;
-        case 32: hipLaunchKernelGGL(k_zstd_match<32>, dim3(blocks), dim3(64), 0, st, m); break;
-        default: hipLaunchKernelGGL(k_zstd_match<64>, dim3(blocks), dim3(64), 0, st, m); break;
-        }
-        HIP_TRY(hipGetLastError());
-        KEntropyArgs e;
-        e.src = (const u8*)d_src; e.in_off = d_in_off + first; e.in_len = c->len_ok + first; e.n_slices = m_n;
-        e.seqs = m.seqs; e.seq_cap = c->seq_cap; e.lits = m.lits; e.lit_cap = c->lit_cap; e.meta = m.meta;
-        e.scratch = c->scratch + (size_t)first * c->scratch_words; e.scratch_words = c->scratch_words;
-        e.dst = (u8*)d_dst; e.out_off = d_out_off + first; e.out_len = d_out_len + first; e.flags = c->knob.entropy_flags | ((m.flags & 4u) ? 8u : 0u);
-        hipLaunchKernelGGL(k_zstd_entropy, dim3(m_n), dim3(64), 0, st, e);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(k_len_guard_finish, dim3((m_n + 255) / 256), dim3(256), 0, st, d_in_len + first, m_n, c->max_slice_bytes, d_out_len + first, c->meta + first, c->d_status);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev_piece[p], st));
+    for (u32 p = 0; p < pieces; p++) KMP_TRY(piece_enqueue(c, p, pieces, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (hipStream_t)hip_streams[p]));
+    pieces_end(c, pieces);
+    return KMP_OK;
+}
+// frame i of a piece straight into the caller's HOST memory (registered / pinned: h_dst is its device-visible address): what the
+// dense packing + copy out + host-side memcpy do for pageable memory, in one kernel over PCIe.  A frame larger than its room is
+// not written: out_len 0, status 70 (libzstd's "Destination buffer is too small").
+__global__ __launch_bounds__(64) void k_scatter_frames(const u8* src, const u64* in_off, u32* len, u32 n, u8* h_dst, const u64* h_off, const u32* h_cap, u32* status)
+{
+    int const lane = threadIdx.x;
+    for (u32 it = blockIdx.x; it < n; it += gridDim.x) {
+        u32 const i = kx_xcd_chunk(it, n);
+        u32 const L = len[i];
+        bool const fits = L <= h_cap[i];
+        if (lane == 0) status[i] = (L == 0) ? 1u : fits ? 0u : 70u;
+        if (!fits) { if (lane == 0) len[i] = 0; continue; }
+        const u8* s = src + in_off[i]; u8* d = h_dst + h_off[i];
+        // 16 bytes per lane where both sides allow it (the strided frames start on 64-byte boundaries; the caller's offsets may not)
+        u32 k = (u32)lane * 8u;
+        for (; k + 8 <= L; k += 512u) kx_st64(d + k, kx_ld64(s + k));
+        u32 const tail = L & ~7u;
+        if (lane < (int)(L - tail)) d[tail + lane] = s[tail + lane];
     }
-    c->have_done = 0; c->pieces_pending = pieces; c->last_chunks = pieces;
+}
+int scatter_frames(kmp_batch_ctx* c, hipStream_t st, const u8* d_src, const u64* d_in_off, u32* d_len, u32 n, u8* h_dst_dev, const u64* d_h_off, const u32* d_h_cap, u32* d_status)
+{
+    (void)c;
+    if (!n) return KMP_OK;
+    u32 const blocks = n < 16384u ? n : 16384u;
+    hipLaunchKernelGGL(k_scatter_frames, dim3(blocks), dim3(64), 0, st, d_src, d_in_off, d_len, n, h_dst_dev, d_h_off, d_h_cap, d_status);
+    HIP_TRY(hipGetLastError());
     return KMP_OK;
 }
 

@@ -109,6 +109,13 @@ void ensure_pre_staging(kmp_batch_ctx* c);
 // lane slots of the lane-per-entry kernels in order of size: key / rank / permutation (the zstd pre-decoders' counting sort;
 // len_shift = 0: keyed by the frames' sequence counts, else by entry bytes >> len_shift)
 int size_sort(kmp_batch_ctx* c, hipStream_t st, const u8* src, const u64* in_off, const u32* in_len, u32 m, u32* key, u32* hist, u32* perm, u32 len_shift);
+// a level-3 batch in pieces, each on a stream of its own (kmp_zstd_compress_batch_pieces = begin + every piece + end)
+int pieces_begin(kmp_batch_ctx* c, u32 pieces, void* const* hip_streams);
+int piece_enqueue(kmp_batch_ctx* c, u32 p, u32 pieces, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
+                  void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st);
+void pieces_end(kmp_batch_ctx* c, u32 pieces);
+// frames out of the strided device layout straight into registered host memory (device-visible address h_dst_dev)
+int scatter_frames(kmp_batch_ctx* c, hipStream_t st, const u8* d_src, const u64* d_in_off, u32* d_len, u32 n, u8* h_dst_dev, const u64* d_h_off, const u32* d_h_cap, u32* d_status);
 // frames of several blocks (kmp_batch.hip); stream: KFrameArgs.stream
 int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct = 0, u32 fast_step0 = 0, bool level4 = false);

@@ -18,6 +18,7 @@ struct JNIEnv {
     jlong* GetLongArrayElements(jlongArray, jboolean*); void ReleaseLongArrayElements(jlongArray, jlong*, jint);
     jint* GetIntArrayElements(jintArray, jboolean*); void ReleaseIntArrayElements(jintArray, jint*, jint);
     void* GetDirectBufferAddress(jobject);
+    jlong GetDirectBufferCapacity(jobject);
     jsize GetArrayLength(jarray); void SetIntField(jobject, jfieldID, jint); jstring NewStringUTF(const char*);
 };
 struct JavaVM { jint GetEnv(void**, jint); };

@@ -148,7 +148,7 @@ def test_jni_shims_export_what_the_kotlin_side_binds():
     # the batch for the JVM (no reference counterpart): two more exports of libzstd-jni.so over the host-batch calls
     path = os.path.join(root, "jni", "zstd", "BatchWrapper.cpp")
     src = open(path).read()
-    assert set(re.findall(r"Java_com_ensody_kompressor_zstd_ZstdBatchWrapper_(\w+)\s*\(", src)) == {"compressBatch", "decompressBatch"}
+    assert set(re.findall(r"Java_com_ensody_kompressor_zstd_ZstdBatchWrapper_(\w+)\s*\(", src)) == {"compressBatch", "decompressBatch", "registerBuffer", "unregisterBuffer", "releaseEngines"}
     called = set(re.findall(r"\b(kmp_zstd_\w+)\s*\(", src))
     assert called == {"kmp_zstd_compress_host_batch", "kmp_zstd_decompress_host_batch"} and called <= declared
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I" + os.path.join(root, "tests", "jni_stub"), path], check=True)

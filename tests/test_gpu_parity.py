@@ -1422,3 +1422,103 @@ def test_batch_in_pieces_side_by_side(G):
             assert hd[i * b.out_stride:i * b.out_stride + hl[i]].tobytes() == o.compress(d), (i, len(d))
     finally:
         b.close()
+
+
+@pytest.mark.timeout(600)
+def test_host_batch_pipelined_registered_memory_and_release():
+    """The pipelined bulk compressor behind kmp_zstd_compress_host_batch (kmp_coalesce.h): a large level-3 batch from pageable
+    memory (pinned staging, worker threads), from memory registered with kmp_host_register (the device reads the slices and writes
+    the frames itself: no staging copy), from registered memory whose slices do not lie one behind the other (the staged copy in,
+    frames still written directly), with output regions that are too small (those slices: out_len 0, KMP_ERR_CAPACITY, the rest
+    fine) -- every frame equal to the device batch's, a sample equal to the oracle's.  Then kmp_host_engines_release: the pinned
+    staging and the device memory are given back, and the next call makes them again."""
+    import ctypes
+    from kompressor_amd import _lib
+    from kompressor_amd.batch import ZstdBatch, compress_bound, host_engines_release, host_register, host_unregister
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    n = 6000
+    sizes = rng.integers(1, 65537, n).astype(np.uint32); sizes[::97] = 65536; sizes[5] = 0
+    offs = np.concatenate([[0], np.cumsum(sizes[:-1].astype(np.uint64))]).astype(np.uint64)
+    total = int(sizes.astype(np.int64).sum())
+    src = np.empty(total + 64, dtype=np.uint8)
+    pos = 0
+    for k in range(0, n, 500):
+        blk = corpus.make(31000 + k, 500, 65536)
+        for j in range(500):
+            i = k + j
+            src[pos:pos + sizes[i]] = blk[j * 65536:j * 65536 + sizes[i]]; pos += int(sizes[i])
+    caps = np.array([compress_bound(int(s)) for s in sizes], dtype=np.uint32)
+    ooff = np.concatenate([[0], np.cumsum(caps[:-1].astype(np.uint64))]).astype(np.uint64)
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)          # noqa: E731
+
+    def run(s, so, sl, cap=caps, oo=ooff):
+        dst = np.zeros(int(cap.astype(np.int64).sum()) + 64, dtype=np.uint8)
+        olen = np.full(n, 7, dtype=np.uint32)
+        rc = lib.kmp_zstd_compress_host_batch(0, 3, vp(s), vp(so), vp(sl), n, vp(dst), vp(oo), vp(cap), vp(olen))
+        return rc, dst, olen
+
+    # the reference: the device batch over the same slices
+    b = ZstdBatch(max_slices=n, max_slice_bytes=65536)
+    d_dst, d_ooff, d_olen = b.compress(torch.from_numpy(src).cuda(), torch.from_numpy(offs.astype(np.int64)).cuda(), torch.from_numpy(sizes.astype(np.int32)).cuda(), check=True)
+    torch.cuda.synchronize()
+    hd, ho, hl = d_dst.cpu().numpy(), d_ooff.cpu().numpy(), d_olen.cpu().numpy()
+    want = [hd[ho[i]:ho[i] + hl[i]].tobytes() for i in range(n)]
+    b.close()
+    o = helpers.oracle()
+    for i in range(0, n, 211):
+        assert want[i] == o.compress(src[int(offs[i]):int(offs[i]) + int(sizes[i])].tobytes()), i
+
+    def same(dst, olen, oo=ooff):
+        assert np.array_equal(olen, hl.astype(np.uint32))
+        for i in range(n):
+            assert dst[int(oo[i]):int(oo[i]) + int(olen[i])].tobytes() == want[i], i
+
+    host_engines_release()                                     # (whatever earlier tests of this process left)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    rc, dst, olen = run(src, offs, sizes)                      # pageable in, pageable out
+    assert rc == 0, lib.kmp_last_error()
+    same(dst, olen)
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held > (1 << 30)                                    # the bulk compressor is there now
+    # registered memory both ways
+    dst2 = np.zeros(int(caps.astype(np.int64).sum()) + 64, dtype=np.uint8)
+    host_register(src); host_register(dst2)
+    try:
+        olen2 = np.full(n, 7, dtype=np.uint32)
+        rc = lib.kmp_zstd_compress_host_batch(0, 3, vp(src), vp(offs), vp(sizes), n, vp(dst2), vp(ooff), vp(caps), vp(olen2))
+        assert rc == 0, lib.kmp_last_error()
+        same(dst2, olen2)
+        # slices that do not lie one behind the other (every second pair swapped): the copy in falls back to staging
+        perm = np.arange(n); perm[0:n - 1:2], perm[1:n:2] = np.arange(1, n, 2), np.arange(0, n - 1, 2)
+        dst2[:] = 0; olen3 = np.zeros(n, dtype=np.uint32)
+        po, pl = np.ascontiguousarray(offs[perm]), np.ascontiguousarray(sizes[perm])
+        pc = np.ascontiguousarray(caps[perm]); poo = np.concatenate([[0], np.cumsum(pc[:-1].astype(np.uint64))]).astype(np.uint64)
+        rc = lib.kmp_zstd_compress_host_batch(0, 3, vp(src), vp(po), vp(pl), n, vp(dst2), vp(poo), vp(pc), vp(olen3))
+        assert rc == 0, lib.kmp_last_error()
+        for i in range(n):
+            assert dst2[int(poo[i]):int(poo[i]) + int(olen3[i])].tobytes() == want[int(perm[i])], i
+        # output regions that are too small, registered (the scatter kernel refuses them) and pageable (the hand-out does)
+        small = caps.copy(); small[10] = 8; small[4001] = max(int(hl[4001]) - 1, 1)
+        for registered in (True, False):
+            d4 = dst2 if registered else np.zeros_like(dst2)
+            d4[:] = 0; olen4 = np.full(n, 7, dtype=np.uint32)
+            rc = lib.kmp_zstd_compress_host_batch(0, 3, vp(src), vp(offs), vp(sizes), n, vp(d4), vp(ooff), vp(small), vp(olen4))
+            assert rc == -3, (registered, rc)
+            assert olen4[10] == 0 and olen4[4001] == 0
+            ok = np.ones(n, dtype=bool); ok[[10, 4001]] = False
+            assert np.array_equal(olen4[ok], hl.astype(np.uint32)[ok])
+            for i in (9, 11, 4000, 4002, n - 1):
+                assert d4[int(ooff[i]):int(ooff[i]) + int(olen4[i])].tobytes() == want[i], (registered, i)
+            assert not d4[int(ooff[10]) + 8:int(ooff[11])].any()           # nothing written past a small region
+    finally:
+        host_unregister(src); host_unregister(dst2)
+    # release: what the calls held comes back; the next call makes it again
+    host_engines_release(0)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+    rc, dst, olen = run(src, offs, sizes)
+    assert rc == 0, lib.kmp_last_error()
+    same(dst, olen)
+    host_engines_release()
