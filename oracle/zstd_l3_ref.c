@@ -2292,3 +2292,362 @@ _match:
     goto _start;
 }
 
+
+/* ================================================================== */
+/* Strategy "fast" (levels 1, 2, negative) beyond its window (round 4) */
+/* The staging logic of dfast_compress_buffered is not about the       */
+/* strategy: ZSTD_compressStream_generic stages the input in chunks of */
+/* 128 KiB into a buffer of window + 128 KiB bytes whatever the level; */
+/* once that buffer has wrapped the lap before is an older segment and */
+/* libzstd 1.5.7 parses the blocks with                                 */
+/* ZSTD_compressBlock_fast_extDict_generic, restated below, until      */
+/* ZSTD_window_enforceMaxDist has pushed the segment out of the        */
+/* window.  The Ktor encoder streams at level 1                         */
+/* (kompressor-zstd-ktor ZstdContentEncoder.kt:11): window 2^19, so    */
+/* every response above 640 KiB goes through here.                      */
+/* ================================================================== */
+
+/* ZSTD_compressBlock_fast_noDict_generic for a block inside a longer input whose window may have slid: matches are valid from
+ * ZSTD_getLowestPrefixIndex at the block's END on, repcodes are checked against the one at the first searched position. */
+static size_t fast_block_low(seqstore* ss, u32 rep[3], const u8* input, size_t blockStart, size_t srcSize, u32* hashTable, u32 hlog, u32 mls,
+                             size_t stepSize, u32 dictLimit, u32 maxDist)
+{
+    const u8* const base = input - IDX0;
+    const u8* const src = input + blockStart;
+    const u8* const istart = src;
+    u32 const endIndex = (u32)(blockStart + srcSize) + IDX0;
+    u32 const prefixStartIndex = (endIndex - dictLimit > maxDist) ? endIndex - maxDist : dictLimit;
+    const u8* const prefixStart = base + prefixStartIndex;
+    const u8* const iend = istart + srcSize;
+    const u8* const ilimit = iend - 8;
+    const u8* anchor = istart; const u8* ip0 = istart; const u8 *ip1, *ip2, *ip3;
+    u32 current0 = 0;
+    u32 rep_offset1 = rep[0], rep_offset2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0;
+    size_t hash0, hash1; u32 matchIdx; u32 offcode; const u8* match0; size_t mLength;
+    size_t step; const u8* nextStep; size_t const kStepIncr = 1 << 7;
+
+    if (srcSize < 8) return srcSize;
+    ip0 += (ip0 == prefixStart);
+    {
+        u32 const curr = (u32)(ip0 - base);
+        u32 const windowLow = (curr - dictLimit > maxDist) ? curr - maxDist : dictLimit;
+        u32 const maxRep = curr - windowLow;
+        if (rep_offset2 > maxRep) { offsetSaved2 = rep_offset2; rep_offset2 = 0; }
+        if (rep_offset1 > maxRep) { offsetSaved1 = rep_offset1; rep_offset1 = 0; }
+    }
+_start:
+    step = stepSize;
+    nextStep = ip0 + kStepIncr;
+    ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
+    if (ip3 >= ilimit) goto _cleanup;
+    hash0 = hash_short(ip0, hlog, mls);
+    hash1 = hash_short(ip1, hlog, mls);
+    matchIdx = hashTable[hash0];
+    do {
+        u32 const rval = rd32(ip2 - rep_offset1);
+        current0 = (u32)(ip0 - base);
+        hashTable[hash0] = current0;
+        if ((rd32(ip2) == rval) & (rep_offset1 > 0)) {
+            ip0 = ip2;
+            match0 = ip0 - rep_offset1;
+            mLength = ip0[-1] == match0[-1];
+            ip0 -= mLength; match0 -= mLength;
+            offcode = 1;
+            mLength += 4;
+            hashTable[hash1] = (u32)(ip1 - base);
+            goto _match;
+        }
+        if (matchIdx >= prefixStartIndex && rd32(base + matchIdx) == rd32(ip0)) {
+            hashTable[hash1] = (u32)(ip1 - base);
+            goto _offset;
+        }
+        matchIdx = hashTable[hash1];
+        hash0 = hash1;
+        hash1 = hash_short(ip2, hlog, mls);
+        ip0 = ip1; ip1 = ip2; ip2 = ip3;
+        current0 = (u32)(ip0 - base);
+        hashTable[hash0] = current0;
+        if (matchIdx >= prefixStartIndex && rd32(base + matchIdx) == rd32(ip0)) {
+            if (step <= 4) hashTable[hash1] = (u32)(ip1 - base);
+            goto _offset;
+        }
+        matchIdx = hashTable[hash1];
+        hash0 = hash1;
+        hash1 = hash_short(ip2, hlog, mls);
+        ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+        if (ip2 >= nextStep) { step++; nextStep += kStepIncr; }
+    } while (ip3 < ilimit);
+
+_cleanup:
+    offsetSaved2 = ((offsetSaved1 != 0) && (rep_offset1 != 0)) ? offsetSaved1 : offsetSaved2;
+    rep[0] = rep_offset1 ? rep_offset1 : offsetSaved1;
+    rep[1] = rep_offset2 ? rep_offset2 : offsetSaved2;
+    return (size_t)(iend - anchor);
+
+_offset:
+    match0 = base + matchIdx;
+    rep_offset2 = rep_offset1;
+    rep_offset1 = (u32)(ip0 - match0);
+    offcode = rep_offset1 + 3;
+    mLength = 4;
+    while (((ip0 > anchor) & (match0 > prefixStart)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
+
+_match:
+    mLength += count_eq(ip0 + mLength, match0 + mLength, iend);
+    store_seq(ss, (size_t)(ip0 - anchor), anchor, offcode, mLength);
+    ip0 += mLength;
+    anchor = ip0;
+    if (ip0 <= ilimit) {
+        hashTable[hash_short(base + current0 + 2, hlog, mls)] = current0 + 2;
+        hashTable[hash_short(ip0 - 2, hlog, mls)] = (u32)(ip0 - 2 - base);
+        if (rep_offset2 > 0) {
+            while ((ip0 <= ilimit) && (rd32(ip0) == rd32(ip0 - rep_offset2))) {
+                size_t const rLength = count_eq(ip0 + 4, ip0 + 4 - rep_offset2, iend) + 4;
+                { u32 const tmpOff = rep_offset2; rep_offset2 = rep_offset1; rep_offset1 = tmpOff; }
+                hashTable[hash_short(ip0, hlog, mls)] = (u32)(ip0 - base);
+                ip0 += rLength;
+                store_seq(ss, 0, anchor, 1, rLength);
+                anchor = ip0;
+            }
+        }
+    }
+    goto _start;
+}
+
+/* ZSTD_compressBlock_fast_extDict_generic over the block [istart, istart + srcSize): indices below prefixStartIndex are the older
+ * segment (valid from dictStartIndex on).  The whole stream is contiguous here, so both segments sit behind the same base and
+ * ZSTD_count_2segments is an ordinary count; what stays of the two segments are the index rules: a match that starts in the older
+ * segment does not grow backwards past its start, a repcode that would straddle the boundary is refused. */
+static size_t fast_extdict_block(seqstore* ss, u32 rep[3], const u8* input, size_t blockStart, size_t srcSize, u32* hashTable, u32 hlog, u32 mls,
+                                 size_t stepSize, u32 dictStartIndex, u32 prefixStartIndex)
+{
+    const u8* const base = input - IDX0;
+    const u8* const istart = input + blockStart;
+    const u8* anchor = istart;
+    const u8* const dictStart = base + dictStartIndex;
+    const u8* const prefixStart = base + prefixStartIndex;
+    const u8* const iend = istart + srcSize;
+    const u8* const ilimit = iend - 8;
+    u32 offset_1 = rep[0], offset_2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0;
+    const u8* ip0 = istart; const u8 *ip1, *ip2, *ip3;
+    u32 current0 = 0;
+    size_t hash0, hash1; u32 idx; u32 offcode; const u8* match0; size_t mLength;
+    size_t step; const u8* nextStep; size_t const kStepIncr = 1 << 7;
+
+    if (srcSize < 8) return srcSize;
+    {
+        u32 const curr = (u32)(ip0 - base);
+        u32 const maxRep = curr - dictStartIndex;
+        if (offset_2 >= maxRep) { offsetSaved2 = offset_2; offset_2 = 0; }
+        if (offset_1 >= maxRep) { offsetSaved1 = offset_1; offset_1 = 0; }
+    }
+_start:
+    step = stepSize;
+    nextStep = ip0 + kStepIncr;
+    ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
+    if (ip3 >= ilimit) goto _cleanup;
+    hash0 = hash_short(ip0, hlog, mls);
+    hash1 = hash_short(ip1, hlog, mls);
+    idx = hashTable[hash0];
+    do {
+        {   /* repcode at ip2 */
+            u32 const current2 = (u32)(ip2 - base);
+            u32 const repIndex = current2 - offset_1;
+            u32 rval;
+            if (((u32)(prefixStartIndex - repIndex) >= 4) & (offset_1 > 0)) rval = rd32(base + repIndex);
+            else rval = rd32(ip2) ^ 1;
+            current0 = (u32)(ip0 - base);
+            hashTable[hash0] = current0;
+            if (rd32(ip2) == rval) {
+                ip0 = ip2;
+                match0 = base + repIndex;
+                mLength = ip0[-1] == match0[-1];
+                ip0 -= mLength; match0 -= mLength;
+                offcode = 1;
+                mLength += 4;
+                goto _match;
+            }
+        }
+        {
+            u32 const mval = idx >= dictStartIndex ? rd32(base + idx) : rd32(ip0) ^ 1;
+            if (rd32(ip0) == mval) goto _offset;
+        }
+        idx = hashTable[hash1];
+        hash0 = hash1;
+        hash1 = hash_short(ip2, hlog, mls);
+        ip0 = ip1; ip1 = ip2; ip2 = ip3;
+        current0 = (u32)(ip0 - base);
+        hashTable[hash0] = current0;
+        {
+            u32 const mval = idx >= dictStartIndex ? rd32(base + idx) : rd32(ip0) ^ 1;
+            if (rd32(ip0) == mval) goto _offset;
+        }
+        idx = hashTable[hash1];
+        hash0 = hash1;
+        hash1 = hash_short(ip2, hlog, mls);
+        ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+        if (ip2 >= nextStep) { step++; nextStep += kStepIncr; }
+    } while (ip3 < ilimit);
+
+_cleanup:
+    offsetSaved2 = ((offsetSaved1 != 0) && (offset_1 != 0)) ? offsetSaved1 : offsetSaved2;
+    rep[0] = offset_1 ? offset_1 : offsetSaved1;
+    rep[1] = offset_2 ? offset_2 : offsetSaved2;
+    return (size_t)(iend - anchor);
+
+_offset:
+    {
+        u32 const offset = current0 - idx;
+        const u8* const lowMatchPtr = idx < prefixStartIndex ? dictStart : prefixStart;
+        match0 = base + idx;
+        offset_2 = offset_1;
+        offset_1 = offset;
+        offcode = offset + 3;
+        mLength = 4;
+        while (((ip0 > anchor) & (match0 > lowMatchPtr)) && (ip0[-1] == match0[-1])) { ip0--; match0--; mLength++; }
+    }
+_match:
+    mLength += count_eq(ip0 + mLength, match0 + mLength, iend);
+    store_seq(ss, (size_t)(ip0 - anchor), anchor, offcode, mLength);
+    ip0 += mLength;
+    anchor = ip0;
+    if (ip1 < ip0) hashTable[hash1] = (u32)(ip1 - base);
+    if (ip0 <= ilimit) {
+        hashTable[hash_short(base + current0 + 2, hlog, mls)] = current0 + 2;
+        hashTable[hash_short(ip0 - 2, hlog, mls)] = (u32)(ip0 - 2 - base);
+        while (ip0 <= ilimit) {
+            u32 const repIndex2 = (u32)(ip0 - base) - offset_2;
+            if ((index_overlap_check(prefixStartIndex, repIndex2) & (offset_2 > 0)) && rd32(base + repIndex2) == rd32(ip0)) {
+                size_t const repLength2 = count_eq(ip0 + 4, base + repIndex2 + 4, iend) + 4;
+                { u32 const tmpOffset = offset_2; offset_2 = offset_1; offset_1 = tmpOffset; }
+                store_seq(ss, 0, anchor, 1, repLength2);
+                hashTable[hash_short(ip0, hlog, mls)] = (u32)(ip0 - base);
+                ip0 += repLength2;
+                anchor = ip0;
+                continue;
+            }
+            break;
+        }
+    }
+    goto _start;
+}
+
+/* how many blocks the last buffered "fast" frame of this thread parsed with the extDict variant (the tests make sure their inputs
+ * reach it) */
+static __thread unsigned kref_fast_ext_blocks_tl = 0;
+KREF_API unsigned kref_fast_ext_blocks(void) { return kref_fast_ext_blocks_tl; }
+
+/* The buffered frame at a "fast" level (1, 2, negative), any length below 4 GiB: dfast_compress_buffered's window bookkeeping with
+ * this strategy's pre-splitter ("fromBorders"), parser pair and literal rule.  knownSize / emptyEnd / outChunk / tailDirect as there. */
+static size_t fast_compress_buffered(u8* dst, size_t cap, const u8* src, size_t srcSize, int level, int knownSize, int emptyEnd, size_t outChunk, size_t tailDirect)
+{
+    int tail = 0;
+    u32 P[4]; kref_wksp w; kref_frame_state fs; seqstore ss; kref_hufstate nextHuf; size_t pos, ipos = 0, hdr; int64_t savings = 0;
+    size_t const blockSizeMax = 128 << 10;
+    kref_window win; size_t windowSize, inBuffSize, bufPos = 0, extBase = 0; u32 maxDist; int haveExt = 0;
+    kref_fast_ext_blocks_tl = 0;
+    if ((level != 1 && level != 2 && level >= 0) || level < -131072) return KERR;
+    if (srcSize >= 0xF0000000u) return KERR;
+    if (cap < kref_compress_bound(srcSize) + 16) return KERR;
+    if (knownSize) { kref_params_fast(level, srcSize, P); pos = write_frame_header(dst, srcSize, P[0]); emptyEnd = 0; }
+    else { P[0] = (level == 2) ? 20 : 19; P[1] = 0; P[2] = (level == 1) ? 14 : (level == 2) ? 16 : 13; P[3] = (level == 1) ? 7 : 6; wr32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)((P[0] - 10) << 3); pos = 6; }
+    hdr = pos;
+    if (knownSize && srcSize == 0) { wr24(dst + pos, 1); return pos + 3; }
+    w.hashLong = (u32*)calloc((size_t)1 << P[2], sizeof(u32)); w.hashSmall = NULL;
+    w.seqs = (kref_seq*)malloc(sizeof(kref_seq) * ((128 << 10) / 3 + 8)); w.lits = (u8*)malloc((128 << 10) + 32);
+    if (!w.hashLong || !w.seqs || !w.lits) { free(w.hashLong); free(w.seqs); free(w.lits); return KERR; }
+    fs.rep[0] = 1; fs.rep[1] = 4; fs.rep[2] = 8; fs.huf.valid = 0; memset(&fs.huf.ct, 0, sizeof(fs.huf.ct)); fs.isFirstBlock = 1;
+    if (srcSize % blockSizeMax != 0 || srcSize == 0) emptyEnd = (!knownSize && srcSize == 0);
+    maxDist = 1u << P[0];
+    windowSize = (knownSize && srcSize < ((size_t)1 << P[0])) ? (srcSize ? srcSize : 1) : ((size_t)1 << P[0]);
+    inBuffSize = windowSize + (blockSizeMax < windowSize ? blockSizeMax : windowSize);
+    win.lowLimit = IDX0; win.dictLimit = IDX0;
+    while (ipos < srcSize) {
+        size_t chunkEnd, chunkLen; int lastChunk;
+        if (ipos != 0 && bufPos == 0 && !tail) {
+            if (knownSize && outChunk) {
+                size_t const room = outChunk - pos % outChunk, r = srcSize - ipos;
+                if (room >= r + (r >> 8) + (r < blockSizeMax ? (blockSizeMax - r) >> 11 : 0)) tail = 1;
+            } else if (!knownSize && tailDirect && ipos + tailDirect == srcSize) tail = 1;
+        }
+        chunkEnd = (!tail && knownSize != 2 && ipos + blockSizeMax < srcSize) ? ipos + blockSizeMax : srcSize;
+        chunkLen = chunkEnd - ipos;
+        lastChunk = (chunkEnd == srcSize) && !emptyEnd;
+        if (ipos == blockSizeMax && knownSize != 2) savings -= (int64_t)hdr;
+        if (ipos != 0 && bufPos == 0) {
+            win.lowLimit = win.dictLimit;
+            win.dictLimit = (u32)ipos + IDX0;
+            if (win.dictLimit - win.lowLimit < 8) win.lowLimit = win.dictLimit;
+            haveExt = 1;
+        }
+        if (haveExt && !tail) {
+            size_t const extLoPhys = (size_t)(win.lowLimit - IDX0) - extBase, extHiPhys = (size_t)(win.dictLimit - IDX0) - extBase;
+            if (bufPos + chunkLen > extLoPhys && bufPos < extHiPhys) {
+                size_t const high = extBase + bufPos + chunkLen + IDX0;
+                win.lowLimit = high > win.dictLimit ? win.dictLimit : (u32)high;
+            }
+        }
+        while (ipos < chunkEnd) {
+            size_t const remaining = chunkEnd - ipos;
+            size_t const blockSize = (remaining < blockSizeMax) ? remaining : (savings < 3) ? blockSizeMax : split_block_from_borders(src + ipos);
+            u32 const lastBlock = lastChunk && (blockSize == remaining);
+            u8* const body = dst + pos + 3; const u8* const bsrc = src + ipos;
+            size_t cSize = 0, lastLL, litC, seqC; u32 rep[3];
+            u32 const startIdx = (u32)ipos + IDX0, endIdx = (u32)(ipos + blockSize) + IDX0;
+            int ext = 0; u32 dsi = 0, psi = 0;
+            if (startIdx > maxDist) {                                          /* ZSTD_window_enforceMaxDist */
+                u32 const newLow = startIdx - maxDist;
+                if (win.lowLimit < newLow) win.lowLimit = newLow;
+                if (win.dictLimit < win.lowLimit) win.dictLimit = win.lowLimit;
+            }
+            if (win.lowLimit < win.dictLimit) {                               /* ZSTD_window_hasExtDict */
+                u32 const low = (endIdx - win.lowLimit > maxDist) ? endIdx - maxDist : win.lowLimit;
+                u32 const prefixStart = win.dictLimit > low ? win.dictLimit : low;
+                if (prefixStart != low) { ext = 1; dsi = low; psi = prefixStart; }
+            }
+            memset(&ss, 0, sizeof(ss)); ss.seqs = w.seqs; ss.lits = w.lits; ss.strategy = 1;
+            if (blockSize >= 7) {
+                memcpy(rep, fs.rep, sizeof(rep));
+                if (ext) kref_fast_ext_blocks_tl++;
+                if (ext) lastLL = fast_extdict_block(&ss, rep, src, ipos, blockSize, w.hashLong, P[2], P[3], kref_fast_step(level), dsi, psi);
+                else lastLL = fast_block_low(&ss, rep, src, ipos, blockSize, w.hashLong, P[2], P[3], kref_fast_step(level), win.dictLimit, maxDist);
+                memcpy(ss.lits + ss.litSize, bsrc + blockSize - lastLL, lastLL); ss.litSize += lastLL;
+                {
+                    int const suspect = (ss.nbSeq == 0) || (ss.litSize / ss.nbSeq >= 20);
+                    if (level < 0) { nextHuf = fs.huf; litC = lit_raw(body, cap - pos - 3, ss.lits, ss.litSize); }
+                    else litC = compress_literals(body, cap - pos - 3, ss.lits, ss.litSize, suspect, &fs.huf, &nextHuf);
+                    if (litC != KERR) {
+                        seqC = compress_sequences(body + litC, cap - pos - 3 - litC, &ss);
+                        if (seqC != KERR && seqC != 0) { cSize = litC + seqC; if (cSize >= blockSize - min_gain(blockSize)) cSize = 0; }
+                    }
+                }
+                if (!fs.isFirstBlock && ss.nbSeq < 4 && ss.litSize < 10) {
+                    size_t i; int same = 1;
+                    for (i = 1; i < blockSize; i++) if (bsrc[i] != bsrc[0]) { same = 0; break; }
+                    if (same) { body[0] = bsrc[0]; cSize = 1; }
+                }
+                if (cSize > 1) { memcpy(fs.rep, rep, sizeof(rep)); fs.huf = nextHuf; }
+            }
+            if (cSize == 0) { wr24(dst + pos, lastBlock + (0 << 1) + (u32)(blockSize << 3)); memcpy(body, bsrc, blockSize); cSize = 3 + blockSize; }
+            else if (cSize == 1) { wr24(dst + pos, lastBlock + (1 << 1) + (u32)(blockSize << 3)); cSize = 3 + 1; }
+            else { wr24(dst + pos, lastBlock + (2 << 1) + (u32)(cSize << 3)); cSize += 3; }
+            savings += (int64_t)blockSize - (int64_t)cSize;
+            ipos += blockSize; pos += cSize; fs.isFirstBlock = 0;
+        }
+        bufPos += chunkLen;
+        if (bufPos + blockSizeMax > inBuffSize) { extBase = ipos - bufPos; bufPos = 0; }
+    }
+    free(w.hashLong); free(w.seqs); free(w.lits);
+    if (emptyEnd) { wr24(dst + pos, 1); pos += 3; }
+    return pos;
+}
+/* stream as in kref_zstd_fast_compress_big (0 in place, 1 / 2 streaming frame closed with / without data, 3 the reference's one-shot
+ * driver); outChunk = 0: max(8192, n / 10) in mode 3; tailDirect: dfast_compress_buffered's.  Any length: beyond the level's window
+ * (512 KiB at level 1 and the negative levels, 1 MiB at level 2) the window slides as libzstd's does. */
+KREF_API size_t kref_zstd_fast_compress_buffered(u8* dst, size_t cap, const u8* src, size_t srcSize, int level, int stream, int emptyEnd, size_t outChunk, size_t tailDirect)
+{
+    int const unknown = stream == 1 || stream == 2;
+    if (level == 2 && !unknown && srcSize > 131072 && srcSize <= 262144) return kref_zstd_fast_compress_big(dst, cap, src, srcSize, level, stream, emptyEnd);   /* (its double-fast row) */
+    if (stream == 3 && !outChunk) outChunk = srcSize / 10 > 8192 ? srcSize / 10 : 8192;
+    return fast_compress_buffered(dst, cap, src, srcSize, level, unknown ? 0 : stream == 0 ? 2 : 1, stream == 2 ? 1 : emptyEnd, stream == 3 ? outChunk : 0, unknown ? tailDirect : 0);
+}

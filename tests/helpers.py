@@ -93,6 +93,42 @@ def beyond_window_inputs():
     return [(f"beyond_{n}", build(n)) for n in sizes]
 
 
+def fast_window_inputs():
+    """Seeded inputs longer than the windows of the "fast" levels (512 KiB at level 1 and the negative levels, 1 MiB at level 2)
+    and than libzstd's staging buffers for them (window + 128 KiB: 5 and 9 chunks): sizes around the windows, the wrap points and
+    chunk boundaries; pieces of every class, byte runs and copies of earlier pieces at any distance.  (name, level, bytes); the
+    list tests/golden/make_golden_fast_window.py used."""
+    import random
+    from kompressor_amd import corpus
+    rng = random.Random(20261006)
+
+    def build(n):
+        out = bytearray()
+        while len(out) < n:
+            r = rng.random()
+            if r < 0.3 and len(out) > 1000:
+                a = rng.randrange(0, len(out))
+                out += out[a:a + rng.randrange(10, 300000)]
+            elif r < 0.35:
+                out += bytes([rng.randrange(256)]) * rng.randrange(1, 200000)
+            else:
+                out += corpus.make(rng.randrange(1 << 30), 1, rng.randrange(1000, 300000), mix=ord(rng.choice("TXSBDIZR"))).tobytes()
+        return bytes(out[:n])
+
+    rows = []
+    for level in (1, -1, -5, 2):
+        win = (1 << 20) if level == 2 else (1 << 19)
+        lap = win + 131072
+        sizes = [win + 1, lap - 1, lap, lap + 1, lap + 131072 + 7, 2 * lap - 3, 2 * lap + 50000, 3 * lap + 4097] if level in (1, 2) else [win + 9, lap, lap + 70001, 2 * lap + 50000]
+        rows += [(f"l{level}_{n}", level, build(n)) for n in sizes]
+    return rows
+
+
+def fast_window_golden():
+    with open(os.path.join(ROOT, "tests", "golden", "zstd_fast_window_golden.json")) as f:
+        return json.load(f)
+
+
 def deflate_long_inputs():
     """Seeded DEFLATE inputs above 64 KiB (zlib's window slides many times): sizes around the slide points
     (k x 32 KiB + 32 506), the reference's own round-trip size (1 MiB + 3 random bytes, ZlibTest.kt:16,28-33), runs, far
@@ -326,6 +362,20 @@ class Oracle:
         cap = k.kref_compress_bound(len(d)) + 64
         o = ctypes.create_string_buffer(cap)
         n = k.kref_zstd_fast_compress_big(o, cap, d, len(d), level, int(stream), 1 if empty_end else 0)
+        if n == 2 ** 64 - 1:
+            raise RuntimeError("oracle: input outside the restatement's scope")
+        return o.raw[:n]
+
+    def compress_fast_buffered(self, d: bytes, level: int, stream=0, empty_end: bool = False, out_chunk: int = 0, tail_direct: int = 0) -> bytes:
+        """Levels 1, 2 and the negative ones at ANY length (round 4: beyond the level's window libzstd's staging buffer wraps and
+        the blocks are parsed by ZSTD_compressBlock_fast_extDict): stream 0 = ZSTD_compress2's frame, 1 / 2 = a stream's (closed with /
+        without data), 3 = the one-shot frame the reference's driver gets (out_chunk 0 = max(8192, n / 10))."""
+        k = self.lib
+        k.kref_zstd_fast_compress_buffered.restype = ctypes.c_size_t
+        k.kref_zstd_fast_compress_buffered.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t]
+        cap = k.kref_compress_bound(len(d)) + 64
+        o = ctypes.create_string_buffer(cap)
+        n = k.kref_zstd_fast_compress_buffered(o, cap, d, len(d), level, int(stream), 1 if empty_end else 0, out_chunk, tail_direct)
         if n == 2 ** 64 - 1:
             raise RuntimeError("oracle: input outside the restatement's scope")
         return o.raw[:n]

@@ -207,6 +207,39 @@ def test_oracle_level1_multiblock_and_streams_match_golden():
         assert len(f) == flen and helpers.sha256(f) == sha, (n, cuts)
 
 
+def test_oracle_fast_levels_beyond_their_window_match_golden():
+    """Levels 1, 2, -1, -5 on inputs longer than the level's window (512 KiB / 1 MiB) -- the Ktor encoder streams at level 1
+    (ZstdContentEncoder.kt:11), so every response above 640 KiB is such a frame: libzstd's staging buffer wraps, the lap before
+    becomes an older segment and the blocks go through ZSTD_compressBlock_fast_extDict until the window has slid past it.  The
+    restatement against libzstd 1.5.7 under the reference's one-shot driver, as a stream closed with and without data, and in
+    place (tests/golden/make_golden_fast_window.py); the rows reach the extDict variant, and below the window the new driver agrees
+    with round 2's (kref_zstd_fast_compress_big)."""
+    import ctypes
+    o = helpers.oracle()
+    G = helpers.fast_window_golden()
+    ins = helpers.fast_window_inputs()
+    assert len(ins) == len(G["rows"]) >= 24
+    o.lib.kref_fast_ext_blocks.restype = ctypes.c_uint
+    ext_rows = 0
+    for (name, level, d), row in zip(ins, G["rows"]):
+        assert row["name"] == name and row["level"] == level and row["size"] == len(d) and helpers.sha256(d) == row["input_sha256"], name
+        f = o.compress_fast_buffered(d, level, stream=3)
+        ext_rows += o.lib.kref_fast_ext_blocks() > 0
+        assert (len(f), helpers.sha256(f)) == (row["oneshot_len"], row["oneshot_sha256"]), (name, "oneshot")
+        f = o.compress_fast_buffered(d, level, stream=1)
+        assert (len(f), helpers.sha256(f)) == (row["stream_len"], row["stream_sha256"]), (name, "stream")
+        f = o.compress_fast_buffered(d, level, stream=2)
+        assert (len(f), helpers.sha256(f)) == (row["stream_empty_end_len"], row["stream_empty_end_sha256"]), (name, "stream, empty end")
+        f = o.compress_fast_buffered(d, level, stream=0)
+        assert (len(f), helpers.sha256(f)) == (row["compress2_len"], row["compress2_sha256"]), (name, "compress2")
+    assert ext_rows >= 10                          # (the inputs longer than window + 128 KiB)
+    for name, d in helpers.multiblock_inputs()[:12]:
+        for level in (1, 2, -3):
+            if len(d) <= ((1 << 20) if level == 2 else (1 << 19)):
+                for stream in (0, 1, 3):
+                    assert o.compress_fast_buffered(d, level, stream=stream) == o.compress_level_big(d, level, stream), (name, level, stream)
+
+
 def test_params_above_128k():
     o = helpers.oracle()
     expect = {131073: (18, 16, 16, 4), 262144: (18, 16, 16, 4), 262145: (19, 16, 17, 5), 524288: (19, 16, 17, 5),
@@ -259,6 +292,24 @@ def test_oracle_matches_the_reference_call_pattern_above_128k_and_beyond_the_win
         d = base[: row["laps"] * lap + row["tail"]]
         f = o.compress_buffered(d, known_size=False, tail_direct=row["tail"])
         assert len(f) == row["len"] and helpers.sha256(f) == row["sha256"], row["name"]
+
+
+def test_fast_buffered_oracle_against_live_libzstd_random_cuts():
+    """The same restatement against the live library on fresh seeded inputs, fed in random pieces (skipped without libzstd 1.5.7)."""
+    import random
+    z = helpers.live_libzstd()
+    if z is None:
+        pytest.skip("no binary libzstd 1.5.7 on this machine")
+    o = helpers.oracle()
+    rng = random.Random(99)
+    ins = helpers.fast_window_inputs()
+    for name, level, d in ins[::3]:
+        n = rng.randrange(len(d) // 2, len(d) + 1)
+        d = d[len(d) - n:]
+        cuts = sorted({0, n, rng.randrange(1, n), rng.randrange(1, n), rng.randrange(1, n)})
+        assert o.compress_fast_buffered(d, level, stream=1) == z.compress_streaming(d, cuts, out_chunk=8192, level=level), (name, cuts)
+        assert o.compress_fast_buffered(d, level, stream=3) == z.compress_streaming(d, [0, n], out_chunk=max(8192, n // 10), level=level), name
+        assert o.compress_fast_buffered(d, level, stream=0) == z.compress(d, level), name
 
 
 def test_buffered_oracle_against_live_libzstd_random_cuts():
