@@ -679,8 +679,8 @@ extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
     if (c->big) {
-        // frames of several blocks: slices up to the level's window (512 KiB at level 1 and at the negative levels, 1 MiB at level 2)
-        if (c->max_slice_bytes > ((level == 2 ? 1024u : 512u) << 10)) { g_last_error = "kmp_zstd_compress_batch_level: above 128 KiB levels 1 and 2 are served for slices up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
+        // frames of several blocks, any size the context holds: beyond the level's window (512 KiB at level 1 and at the negative levels,
+        // 1 MiB at level 2) libzstd's staging buffer wraps and the window slides (zstd_match_fast_ext_body)
         return zstd_compress_big(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, st, 0, neg ? 1u : (u32)level, 0, neg ? (u32)(1 - level) : 0u);
     }
     KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
@@ -933,7 +933,6 @@ extern "C" int kmp_zstd_compress_batch_stream_level(kmp_batch_ctx* c, const void
     if (level == 0) level = 3;
     bool const neg = level < 0;
     if ((level < 1 && !neg) || level > 4 || level < -131072) { g_last_error = "kmp_zstd_compress_batch_stream_level: levels -131072 .. -1 and 1 .. 4 are served"; return KMP_ERR_ARG; }
-    if (c && level != 3 && level != 4 && c->max_slice_bytes > ((level == 2 ? 1024u : 512u) << 10)) { g_last_error = "kmp_zstd_compress_batch_stream_level: level 1 / 2 streams up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_stream: null argument"; return KMP_ERR_ARG; }
     if (!c->big) { g_last_error = "kmp_zstd_compress_batch_stream: the context must be created with max_slice_bytes above 128 KiB"; return KMP_ERR_CAPACITY; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_stream: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
@@ -951,7 +950,6 @@ extern "C" int kmp_zstd_compress_batch_reference(kmp_batch_ctx* c, const void* d
     if (!c->big) return kmp_zstd_compress_batch_level(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, level, hip_stream);   // one block: one chunk
     bool const neg = level < 0;
     if ((level < 1 && !neg) || level > 4 || level < -131072) { g_last_error = "kmp_zstd_compress_batch_reference: levels -131072 .. -1 and 1 .. 4 are served"; return KMP_ERR_ARG; }
-    if (level != 3 && level != 4 && c->max_slice_bytes > ((level == 2 ? 1024u : 512u) << 10)) { g_last_error = "kmp_zstd_compress_batch_reference: levels 1 / 2 up to their window (context max_slice_bytes <= 512 KiB / 1 MiB)"; return KMP_ERR_CAPACITY; }
     if (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len)) { g_last_error = "kmp_zstd_compress_batch_reference: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_reference: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;

@@ -148,8 +148,10 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
     bool const in_place = first_room >= kmp_zstd_compress_bound(end_avail);
     u32 tail_direct = 0;
     if (streaming && in_place && end_avail != 0) {
-        size_t const lap = 17u * (size_t)KX_BLOCK_MAX;                  // level-3 stream: window 2 MiB + one block
-        if ((c->level == 3 || c->level == 4) && (n - end_avail) % lap == 0) tail_direct = (u32)end_avail;      // (level 4's streams: the same window)
+        // libzstd's staging buffer: the window of a stream of unknown size + one block (level 3 / 4: 2 MiB, level 2: 1 MiB, level 1 and
+        // the negative levels: 512 KiB)
+        size_t const lap = ((c->level == 3 || c->level == 4) ? 17u : c->level == 2 ? 9u : 5u) * (size_t)KX_BLOCK_MAX;
+        if ((n - end_avail) % lap == 0) tail_direct = (u32)end_avail;
     }
     if (streaming && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
     // level 4: what arrives in one closing call, above 16 KiB up to 128 KiB (libzstd's double-fast row of that level); the rest: CPU library
@@ -164,11 +166,9 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
         if (rc == KMP_OK) return 0;
         (void)hipGetLastError();                    // fall through: compress alone
     }
-    bool const l1big = c->level != 3 && c->level != 4 && (streaming || n > KMP_MAX_SLICE_BYTES);      // level 1 / 2 / negative, frame of several blocks / stream
-    u32 const lwin = (c->level == 2 ? 1024u : 512u) << 10;                             // their windows (the negative levels: level 1's)
-    if (l1big && n > lwin) return KERRC(ZE_parameter_unsupported);                     // beyond the window: CPU library
+    bool const l1big = c->level != 3 && c->level != 4 && (streaming || n > KMP_MAX_SLICE_BYTES);      // level 1 / 2 / negative, frame of several blocks / stream (any length: beyond the level's window it slides as libzstd's does)
     if (!stream_dev_select(c->dev)) return KERRC(ZE_GENERIC);
-    { size_t const e = stream_dev_init(c->dev, streaming && n <= KMP_MAX_SLICE_BYTES ? KMP_MAX_SLICE_BYTES + 1 : n, l1big ? lwin : 0u); if (e) return e; }
+    { size_t const e = stream_dev_init(c->dev, streaming && n <= KMP_MAX_SLICE_BYTES ? KMP_MAX_SLICE_BYTES + 1 : n); if (e) return e; }
     stream_dev& s = c->dev;
     u64 offs[2] = { 0, 0 }; u32 len = (u32)n, olen = 0;
     if (n && hipMemcpy(s.d_in, c->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
@@ -176,7 +176,9 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
     if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);
     if (streaming) {
         if (tail_direct) {
-            if (zstd_compress_big(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, nullptr, 1u, 0u, tail_direct, 0u, c->level == 4) != KMP_OK) return KERRC(ZE_GENERIC);
+            bool const neg = c->level < 0;
+            u32 const strategy = (c->level == 3 || c->level == 4) ? 0u : neg ? 1u : (u32)c->level;
+            if (zstd_compress_big(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, nullptr, 1u, strategy, tail_direct, neg ? (u32)(1 - c->level) : 0u, c->level == 4) != KMP_OK) return KERRC(ZE_GENERIC);
         } else
         if (kmp_zstd_compress_batch_stream_level(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, c->end_was_empty, c->level, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
     } else

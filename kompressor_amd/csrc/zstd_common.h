@@ -132,21 +132,21 @@ KX_DEV KParams kx_params_l4(u32 n, bool& ok)
 KX_DEV KParams kx_params_l2_dfast() { KParams p; p.windowLog = 18; p.chainLog = 14; p.hashLog = 14; p.minMatch = 5; return p; }
 KX_DEV bool kx_in_class(u32 cls, u32 n) { return cls == 0u || ((n > 131072u && n <= 262144u) == (cls == 1u)); }
 
-KX_DEV u32 kx_frame_header_size(u32 n)
+KX_DEV u32 kx_frame_header_size(u32 n, u32 windowLog = 21)
 {
-    // magic(4) + FHD(1) + FCS; single segment while the window (2 MiB at most, level 3) covers the content, else a window
-    // descriptor byte as well
-    return 5 + ((n < 256) ? 1 : (n < 65536 + 256) ? 2 : 4) + (n > (2u << 20) ? 1u : 0u);
+    // magic(4) + FHD(1) + FCS; single segment while the window (2 MiB at level 3; 512 KiB / 1 MiB at the "fast" levels) covers the
+    // content, else a window descriptor byte as well
+    return 5 + ((n < 256) ? 1 : (n < 65536 + 256) ? 2 : 4) + (n > (1u << windowLog) ? 1u : 0u);
 }
-// frame header of a one-shot level-3 frame (content size known): returns its size
-KX_DEV u32 kx_write_frame_header(u8* dst, u32 n)
+// frame header of a one-shot frame (content size known): returns its size
+KX_DEV u32 kx_write_frame_header(u8* dst, u32 n, u32 windowLog = 21)
 {
     u32 const fcsCode = (n >= 256) + (n >= 65536 + 256);
-    bool const single = n <= (2u << 20);
+    bool const single = n <= (1u << windowLog);
     kx_st32(dst, 0xFD2FB528u);
     dst[4] = (u8)((single ? 1u << 5 : 0u) + (fcsCode << 6));
     u32 p = 5;
-    if (!single) dst[p++] = (u8)((21 - 10) << 3);
+    if (!single) dst[p++] = (u8)((windowLog - 10) << 3);
     if (fcsCode == 0) dst[p++] = (u8)n;
     else if (fcsCode == 1) { kx_st16(dst + p, n - 256); p += 2; }
     else { kx_st32(dst + p, n); p += 4; }

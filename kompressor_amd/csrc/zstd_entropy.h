@@ -1201,14 +1201,18 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
     u32* const hufct = a.hufct + (size_t)slice * 512u;
     bool const streaming = a.stream == 1 || a.stream == 2;       // size unknown when the frame starts
     bool const emptyEnd = a.stream == 2 && (n % KX_BLOCK_MAX) == 0;
+    // the window a frame of known size is written with: level 3's 2^21 at most, or the "fast" level's own (2^19 / 2^20), past which the
+    // header carries a window descriptor instead of the single-segment flag
+    u32 const fastLevel = a.fast_step0 ? 0u : a.level2 ? 2u : 1u;
+    u32 const wlogKnown = a.strategy ? kx_window_log_fast(fastLevel, n, false) : 21u;
     if (fs.ipos == 0 && streaming) {
         // streaming frame header: no content size, window descriptor for 2^21
         if (lane == 0) { kx_st32(dst, 0xFD2FB528u); dst[4] = 0; dst[5] = (u8)(((a.strategy ? (a.level2 ? 20 : 19) : 21) - 10) << 3); }
         fs.opos = 6;
     } else if (fs.ipos == 0) {
         // frame header: content size; single segment while the window covers the slice
-        if (lane == 0) kx_write_frame_header(dst, n);
-        fs.opos = kx_frame_header_size(n);
+        if (lane == 0) kx_write_frame_header(dst, n, wlogKnown);
+        fs.opos = kx_frame_header_size(n, wlogKnown);
     }
     u32 const bs = fs.blockSize;
     const u8* const bsrc = src + fs.ipos;
@@ -1262,10 +1266,10 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
     // ZSTD_optimalBlockSize for the next block (staged input is compressed in chunks of 128 KiB; the frame header counts
     // as produced from the second chunk on)
     u32 next = 0;
-    if (a.stream && fs.ipos == KX_BLOCK_MAX) fs.savings -= streaming ? 6 : (int)kx_frame_header_size(n);
+    if (a.stream && fs.ipos == KX_BLOCK_MAX) fs.savings -= streaming ? 6 : (int)kx_frame_header_size(n, wlogKnown);
     if (fs.ipos < n) {
-        // (level 1 is served up to its window: nothing slides there)
-        u32 const windowLog = a.strategy ? 30u : (streaming ? 21u : a.level2 ? 18u : kx_params_l3(n).windowLog);
+        // the window of the level: beyond it libzstd's staging buffer wraps and the window slides (the "fast" levels too, since round 4)
+        u32 const windowLog = a.strategy ? kx_window_log_fast(fastLevel, n, streaming) : (streaming ? 21u : a.level2 ? 18u : kx_params_l3(n).windowLog);
         u32 const remaining = kx_frame_window_step(fs, n, a.stream, windowLog, a.tail_direct, a.out_chunk);
         if (remaining < KX_BLOCK_MAX) next = remaining;
         else if (fs.savings < 3) next = KX_BLOCK_MAX;
@@ -1321,15 +1325,23 @@ KX_DEV void zstd_big_body(const KBigArgs& a)
             if (!open) break;
             if (lane == 0) *m.counter = 0;
             kx_sync();
-            if (FAST) { KFastArgs fa; fa.m = m; fa.level = a.e.fast_step0 ? 0u : a.e.level2 ? 2u : 1u; if (a.e.fast_step0) fa.step0 = a.e.fast_step0; zstd_match_fast_body<G, true>(fa); }
-            else {
-                zstd_match_body<G, true>(m);
-                // blocks behind a wrap of libzstd's staging buffer: the extDict variant of the parse
-                bool ext = false;
-                for (u32 t = 0; t < cnt; t++) {
-                    KFrameState const& f = a.e.fstate[base + t];
-                    if (f.blockSize != 0 && f.lowLimit < f.dictLimit) ext = true;
+            // blocks behind a wrap of libzstd's staging buffer go through the extDict variant of the parse (each body skips the other's blocks)
+            bool ext = false;
+            for (u32 t = 0; t < cnt; t++) {
+                KFrameState const& f = a.e.fstate[base + t];
+                if (f.blockSize != 0 && f.lowLimit < f.dictLimit) ext = true;
+            }
+            if (FAST) {
+                KFastArgs fa; fa.m = m; fa.level = a.e.fast_step0 ? 0u : a.e.level2 ? 2u : 1u; if (a.e.fast_step0) fa.step0 = a.e.fast_step0;
+                zstd_match_fast_body<G, true>(fa);
+                if (ext) {
+                    kx_sync();
+                    if (lane == 0) *m.counter = 0;
+                    kx_sync();
+                    zstd_match_fast_ext_body<G>(fa);
                 }
+            } else {
+                zstd_match_body<G, true>(m);
                 if (ext) {
                     kx_sync();
                     if (lane == 0) *m.counter = 0;

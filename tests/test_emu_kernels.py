@@ -520,6 +520,24 @@ def test_reference_driver_frames_and_a_wrapped_staging_buffer_on_the_emulator():
             assert len(f[0]) == rows[name][key + "_len"] and helpers.sha256(f[0]) == rows[name][key + "_sha256"], (name, key)
 
 
+def test_fast_levels_beyond_their_window_on_the_emulator():
+    """Levels 1, -1 and 2 on slices longer than the level's window and than libzstd's staging buffer for it (window + 128 KiB): the
+    block-chain kernel body with the window-aware "fast" parser and its extDict variant (zstd_match_fast.h:
+    zstd_match_fast_ext_body), against tests/golden/zstd_fast_window_golden.json (libzstd 1.5.7) -- the reference's one-shot
+    driver, a stream closed with and without data, ZSTD_compress2 in place; two slices side by side in one wave, narrow and wide
+    (no check bits) table entries."""
+    G = {r["name"]: r for r in helpers.fast_window_golden()["rows"]}
+    ins = {name: (level, d) for name, level, d in helpers.fast_window_inputs()}
+    lap1 = (1 << 19) + 131072
+    for names in (("l1_%d" % (lap1 + 1), "l1_%d" % (lap1 + 131072 + 7)), ("l-1_%d" % (lap1 + 70001),), ("l2_%d" % ((1 << 20) + 131072 + 1),)):
+        level = ins[names[0]][0]
+        datas = [ins[nm][1] for nm in names]
+        for mode, key in ((3, "oneshot"), (1, "stream"), (2, "stream_empty_end"), (0, "compress2")) if level == 1 else ((3, "oneshot"), (1, "stream")):
+            frames, _ = helpers.emu_compress_big(datas, G=(8, 4)[mode & 1], nblocks=1, stream=mode, level=level, wide=(mode == 2))
+            for nm, f in zip(names, frames):
+                assert (len(f), helpers.sha256(f)) == (G[nm][key + "_len"], G[nm][key + "_sha256"]), (nm, key)
+
+
 def test_xcd_aware_slice_mapping_is_a_bijection_with_contiguous_chunks():
     """kx_xcd_chunk: workgroup b (on XCD b % 8) takes a slice out of a contiguous eighth of the batch; every slice is taken
     exactly once for any batch size, and the workgroups of one XCD walk their chunk in order."""

@@ -781,13 +781,14 @@ def test_level1_multiblock_and_streaming_frames():
             assert len(f) == flen and helpers.sha256(f) == sha, (size, cuts)
     finally:
         b.close()
-    # level 1 beyond its 512 KiB window (a context for larger slices) is refused, not served differently
+    # a context made for larger slices serves the same slices with the same frames (round 4: beyond the window it slides, it no longer refuses)
     b2 = ZstdBatch(max_slices=2, max_slice_bytes=2 << 20)
     try:
-        with pytest.raises(RuntimeError):
-            b2.compress(src, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.tensor([len(d)], dtype=torch.int32, device="cuda"), level=1)
-        with pytest.raises(RuntimeError):
-            b2.compress(src, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.tensor([len(d)], dtype=torch.int32, device="cuda"), level=2)
+        o = helpers.oracle()
+        for lvl in (1, 2):
+            dst2, _, olen2 = b2.compress(src, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.tensor([len(d)], dtype=torch.int32, device="cuda"), level=lvl, check=True)
+            torch.cuda.synchronize()
+            assert dst2[: int(olen2[0])].cpu().numpy().tobytes() == o.compress_level_big(d, lvl), lvl
     finally:
         b2.close()
     lib = _lib.load()
@@ -1522,3 +1523,85 @@ def test_host_batch_pipelined_registered_memory_and_release():
     assert rc == 0, lib.kmp_last_error()
     same(dst, olen)
     host_engines_release()
+
+
+def _stream_through_abi(lib, d, level, cuts, out_chunk=8192):
+    """kmp_zstd_compress_stream the way the reference's streaming callers drive ZSTD_compressStream2 (SliceTransformRawSource.kt:32-55):
+    d[cuts[i]:cuts[i+1]] fed with finish = false, the last piece with finish = true; output drained through out_chunk-byte slices."""
+    import ctypes
+    cctx = lib.kmp_zstd_create_cctx()
+    assert lib.kmp_zstd_cctx_set_parameter(cctx, 100, level) == 0
+    out = bytearray(); obuf = ctypes.create_string_buffer(out_chunk)
+    pieces = list(zip(cuts[:-1], cuts[1:]))
+    try:
+        for j, (a0, a1) in enumerate(pieces):
+            end = j == len(pieces) - 1
+            sp = ctypes.c_size_t(a0)
+            while True:
+                dp = ctypes.c_size_t(0)
+                r = lib.kmp_zstd_compress_stream(cctx, obuf, out_chunk, ctypes.byref(dp), d, a1, ctypes.byref(sp), 2 if end else 0)
+                assert not lib.kmp_zstd_is_error(r), lib.kmp_zstd_get_error_name(r)
+                out += obuf.raw[:dp.value]
+                if (end and r == 0) or (not end and sp.value == a1 and dp.value < out_chunk):
+                    break
+    finally:
+        lib.kmp_zstd_free_cctx(cctx)
+    return bytes(out)
+
+
+@pytest.mark.timeout(900)
+def test_fast_levels_beyond_their_window():
+    """Levels 1, 2 and the negative ones on slices and streams LONGER than the level's window (512 KiB / 1 MiB): libzstd's staging
+    buffer wraps, the blocks behind the wrap go through ZSTD_compressBlock_fast_extDict (zstd_match_fast_ext_body) until the window
+    has slid past the older segment.  The reference's Ktor encoder streams at level 1 (ZstdContentEncoder.kt:11 through
+    BaseSliceTransformContentEncoder.kt:23-54), so every response above 640 KiB is such a frame.  All 24 committed inputs in the four
+    framings against libzstd 1.5.7 (tests/golden/zstd_fast_window_golden.json) through the batch calls, a wide-index context, the
+    streaming entry point on a 2 MiB and a 24 MiB level-1 stream fed in pieces (against the oracle and, where present, the live
+    library), and everything decoded back on the GPU."""
+    from kompressor_amd import _lib, ZstdCompressor, ZstdDecompressor
+    from kompressor_amd.batch import ZstdBatch
+    G = helpers.fast_window_golden()["rows"]
+    ins = helpers.fast_window_inputs()
+    o = helpers.oracle()
+    for level in (1, -1, -5, 2):
+        rows = [(r, d) for (nm, lv, d), r in zip(ins, G) if lv == level]
+        datas = [d for _, d in rows]
+        b = ZstdBatch(max_slices=len(datas), max_slice_bytes=max(len(d) for d in datas) + 1)
+        try:
+            for kw, key in ((dict(reference=True), "oneshot"), (dict(streaming="data"), "stream"), (dict(streaming="empty"), "stream_empty_end"), (dict(), "compress2")):
+                frames = gpu_compress_kw(b, datas, level=level, check=True, **kw)
+                for (r, d), f in zip(rows, frames):
+                    assert (len(f), helpers.sha256(f)) == (r[key + "_len"], r[key + "_sha256"]), (r["name"], key)
+            back, st = gpu_decompress(b, frames, [len(d) for d in datas])
+            assert st == [0] * len(frames) and back == datas
+        finally:
+            b.close()
+    # a context for slices of 4 MiB and more keeps plain 32-bit indices in its tables (no check bits): the same frames
+    rows = [(r, d) for (nm, lv, d), r in zip(ins, G) if lv == 1][3:6]
+    b = ZstdBatch(max_slices=len(rows), max_slice_bytes=5 << 20)
+    try:
+        frames = gpu_compress_kw(b, [d for _, d in rows], level=1, reference=True, check=True)
+        for (r, d), f in zip(rows, frames):
+            assert (len(f), helpers.sha256(f)) == (r["oneshot_len"], r["oneshot_sha256"]), r["name"]
+    finally:
+        b.close()
+    # the streaming entry point: what a Ktor response of 2 MiB and of 24 MiB + 3 bytes becomes at level 1 (finish = false pieces, then finish = true)
+    lib = _lib.load()
+    z = helpers.live_libzstd()
+    rng = np.random.default_rng(7)
+    two = b"".join(d for _, _, d in ins[:3])[: 2 << 20]
+    big = bytearray()
+    while len(big) < (24 << 20) + 3:
+        k = int(rng.integers(0, len(ins)))
+        big += ins[k][2][: int(rng.integers(1000, 900000))]
+    big = bytes(big[: (24 << 20) + 3])
+    for d, cuts in ((two, [0, 300000, 1 << 20, len(two)]), (big, [0, 5 << 20, (17 << 20) + 11, len(big)])):
+        f = _stream_through_abi(lib, d, 1, cuts)
+        assert f == o.compress_fast_buffered(d, 1, stream=1), len(d)
+        if z is not None:
+            assert f == z.compress_streaming(d, cuts, out_chunk=8192, level=1), len(d)
+        assert hashlib.sha256(ZstdDecompressor().transform_bytes(f)).digest() == hashlib.sha256(d).digest()
+    # ... and one-shot through the reference's driver (finish = true from the first call), levels 1 and -3
+    for level in (1, -3):
+        f = ZstdCompressor(compression_level=level).transform_bytes(two)
+        assert f == o.compress_fast_buffered(two, level, stream=3), level

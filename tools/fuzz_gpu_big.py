@@ -1,6 +1,6 @@
 """Differential fuzz of the block-chain path (frames of several blocks, slices of 128 KiB + 1 .. 1.5 MiB): stress inputs
 (tools/fuzzgen.c) and corpus classes; the frames the reference's one-shot driver gets (output slices of max(8192, n / 10) bytes:
-libzstd stages the input in 128 KiB chunks), ZSTD_compress2's frames, level 1 and three negative levels (up to their 512 KiB window) -- every frame against
+libzstd stages the input in 128 KiB chunks), ZSTD_compress2's frames, levels 1, 2 and three negative levels (beyond their windows of 512 KiB / 1 MiB the fast extDict parse) -- every frame against
 the binary libzstd 1.5.7 on the host cores, every frame decoded back on the GPU.  usage: python tools/fuzz_gpu_big.py [seed] [n]"""
 import os, sys, ctypes, subprocess, time
 from concurrent.futures import ThreadPoolExecutor
@@ -71,20 +71,23 @@ def streamed(d, level, empty):                   # finish = false calls, then fi
 for name, level, reference, idx, fn, streaming in (
         ("level 3, streamed, the closing call brings data", 3, False, all_idx, lambda d: streamed(d, 3, False), "data"),
         ("level 3, streamed, the closing call is empty", 3, False, all_idx, lambda d: streamed(d, 3, True), "empty"),
-        ("level 1 up to 512 KiB, streamed, the closing call brings data", 1, False, l1_idx, lambda d: streamed(d, 1, False), "data"),
+        ("level 1, streamed, the closing call brings data", 1, False, all_idx, lambda d: streamed(d, 1, False), "data"),
         ("level 3, the reference driver's frames (input staged in 128 KiB chunks)", 3, True, all_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), 3), None),
         ("level 3, ZSTD_compress2's frames", 3, False, all_idx, lambda d: one_shot(d, 3), None),
-        ("level 1 up to 512 KiB, the reference driver's frames", 1, True, l1_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), 1), None),
-        ("level 1 up to 512 KiB, ZSTD_compress2's frames", 1, False, l1_idx, lambda d: one_shot(d, 1), None),
-        ("level -1 up to 512 KiB, the reference driver's frames", -1, True, l1_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), -1), None),
-        ("level -5 up to 512 KiB, ZSTD_compress2's frames", -5, False, l1_idx, lambda d: one_shot(d, -5), None),
-        ("level -3 up to 512 KiB, streamed, the closing call brings data", -3, False, l1_idx, lambda d: streamed(d, -3, False), "data"),
+        ("level 1, the reference driver's frames", 1, True, all_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), 1), None),
+        ("level 1, ZSTD_compress2's frames", 1, False, all_idx, lambda d: one_shot(d, 1), None),
+        ("level -1, the reference driver's frames", -1, True, all_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), -1), None),
+        ("level -5, ZSTD_compress2's frames", -5, False, all_idx, lambda d: one_shot(d, -5), None),
+        ("level -3, streamed, the closing call brings data", -3, False, all_idx, lambda d: streamed(d, -3, False), "data"),
+        ("level 2, streamed, the closing call brings data (beyond its 1 MiB window: the fast extDict parse)", 2, False, all_idx, lambda d: streamed(d, 2, False), "data"),
+        ("level 2, the reference driver's frames", 2, True, all_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), 2), None),
+        ("level 2, ZSTD_compress2's frames", 2, False, all_idx, lambda d: one_shot(d, 2), None),
         ("level 4 (its double-fast size classes), the reference driver's frames", 4, True, l4_idx, lambda d: z.compress_streaming(d, [0, len(d)], max(8192, len(d) // 10), 4), None),
         ("level 4 (its double-fast size classes), ZSTD_compress2's frames", 4, False, l4_idx, lambda d: one_shot(d, 4), None),
         ("level 4, streamed, the closing call brings data", 4, False, all_idx, lambda d: streamed(d, 4, False), "data"),
         ("level 4, streamed, the closing call is empty", 4, False, all_idx, lambda d: streamed(d, 4, True), "empty")):
     t0 = time.time()
-    g = gpu_frames(level, reference, idx, MAXL if level in (3, 4) else 524288, streaming)
+    g = gpu_frames(level, reference, idx, MAXL, streaming)
     r = ref_frames(fn, idx)
     bad = [i for i in idx if g[int(i)] != r[int(i)]]
     bad_total += len(bad)
