@@ -1,0 +1,306 @@
+// deflate_lazy.h -- zlib's lazy levels (4 .. 9: "deflate_slow") for slices up to 64 KiB as TWO kernels that only do the work
+// zlib does (round 4).  Replaces k_deflate_chains + k_deflate_best + k_deflate_parse of deflate_match.h for such slices.
+//
+// Why.  k_deflate_best walked the whole hash chain of EVERY position (a lane per position, 25 - 85 dependent LDS steps
+// each); zlib's lazy parse asks longest_match for one position in 5.6 -- the positions inside an accepted match are
+// inserted into the chains but never searched.  Which positions are searched is the parse's serial decision chain, so the
+// search has to be driven BY the parse; what makes that affordable on a GPU is that a search need not be serial:
+//   * zlib inserts every position into its chains, so the candidates of a position do not depend on the parse: they are the
+//     earlier positions with the same 3-byte hash, nearest first.  k_deflate_sort lays the positions of a slice out SORTED
+//     BY HASH (a stable counting sort: srt[]), and records for every position where it sits (where) and how many same-hash
+//     positions precede it (rank): the candidates of p are srt[where - 1], srt[where - 2], ... -- contiguous in memory.
+//   * longest_match's result does not depend on the order effects of its walk: it is the first candidate (nearest first)
+//     that reaches nice_length if there is one within max_chain steps, else the longest candidate, the nearest among equals
+//     (best_len only ever grows; a candidate is skipped when it cannot beat it).  So k_deflate_lazy, one WAVE per slice,
+//     measures 64 candidates of the position at once -- a coalesced load of their positions, one 8-byte compare per lane,
+//     more only for the lanes that still match -- and picks the winner with two ballots.  A search is two dependent memory
+//     round trips instead of a chain of up to 128, and only the positions the parse really asks about are searched.
+// The parse itself (fill_window and its slides, lazy evaluation, TOO_FAR, the 16 383-symbol blocks, stored-block
+// eligibility) is deflate_parse_body's, run wave-uniformly; the symbols leave 64 at a time.  Output: the symbol list, block
+// list and slice record k_deflate_encode takes, as before.  Reference: the call at kompressor-zlib--nativelib/src/
+// jvmCommonMain/jni/Wrapper.cpp:73 (deflate) under deflateInit2(level, 8, -15, 8, 0) (:20).
+#pragma once
+#include "deflate_match.h"
+
+// The per-slice arrays of the two kernels: srt (the positions in hash order, 2 bytes each) where the chain links lived; sb (the
+// first 16 bytes of every position, in the same order: a search reads its candidates' bytes as ONE contiguous run, and most
+// candidates are measured without a second trip to memory -- a kernel that waits for memory three quarters of its cycles lives on
+// the number of dependent round trips per search, not on bytes) where KdBest lived (twice its size); wr (where | rank << 16,
+// 4 bytes per position) in an array of its own; the ranks of the first pass sit in the symbol array until the parse fills it.
+struct alignas(16) KdlBytes { u64 lo, hi; };
+KX_DEV u32* kdl_wr(const KdArgs& a, u32 slice) { return a.wr + (size_t)slice * a.pos_cap; }
+KX_DEV u16* kdl_srt(const KdArgs& a, u32 slice) { return a.link + (size_t)slice * a.pos_cap; }
+KX_DEV KdlBytes* kdl_sb(const KdArgs& a, u32 slice) { return (KdlBytes*)(a.best + (size_t)slice * a.pos_cap * 2u); }
+KX_DEV u16* kdl_rank(const KdArgs& a, u32 slice) { return (u16*)(a.syms + (size_t)slice * a.pos_cap); }
+
+// 8 bytes at position q of a slice of n bytes, bytes past the end read as zero (q < n)
+KX_DEV u64 kdl_ld64(const u8* src, int q, int n)
+{
+    if (q + 8 <= n) return kx_ld64(src + q);
+    u64 v = 0;
+    for (int k = 0; q + k < n; k++) v |= (u64)src[q + k] << (8 * k);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// k_deflate_sort: 256 threads per workgroup, one slice at a time, cnt[32768] in LDS
+// ---------------------------------------------------------------------------
+// Pass 1, in position order (the waves of the workgroup take turns on the table, as in k_deflate_chains): rank[p] = how many
+// earlier positions share p's hash.  Pass 2: exclusive scan of the bucket sizes.  Pass 3, any order: where[p] = start of the
+// bucket + rank[p]; srt[where[p]] = p.
+KX_DEV void deflate_sort_body(const KdArgs& a)
+{
+    KX_SHARED u16 cnt[32768];                     // bucket sizes, then bucket starts (a slice has at most 65 534 chained positions)
+    KX_SHARED u32 part[256];
+    int const lane = kx_lane(); int const wv = kx_wave(); int const nw = kx_nwaves(); int const tid = wv * 64 + lane; int const nthreads = nw * 64;
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
+        u32 const slice = kx_xcd_chunk(it, a.n_slices);
+        const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
+        u16* const rank = kdl_rank(a, slice);
+        u32* const wr = kdl_wr(a, slice); u16* const srt = kdl_srt(a, slice); KdlBytes* const sb = kdl_sb(a, slice);
+        for (int i = tid; i < 32768; i += nthreads) cnt[i] = 0;
+        kx_block_sync();
+        u32 const nIns = n >= 3 ? n - 2 : 0;                // positions 0 .. n-3 enter the chains, in order
+        // ---- pass 1 (the source bytes of a group of four rounds are fetched a group ahead, as in k_deflate_chains)
+        u32 hq[4]; bool vq[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 const p0 = (u32)k * (u32)nthreads + (u32)wv * 64u + (u32)lane;
+            vq[k] = p0 < nIns; hq[k] = 0;
+            if (vq[k]) hq[k] = (p0 + 4 <= n) ? kx_ld32(src + p0) : ((u32)src[p0] | ((u32)src[p0 + 1] << 8) | ((u32)src[p0 + 2] << 16));
+        }
+        for (u32 gbase = 0; gbase < nIns; gbase += 4u * (u32)nthreads) {
+            u32 hn[4]; bool vn[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u32 const pn = gbase + (4u + (u32)k) * (u32)nthreads + (u32)wv * 64u + (u32)lane;
+                vn[k] = pn < nIns; hn[k] = 0;
+                if (vn[k]) hn[k] = (pn + 4 <= n) ? kx_ld32(src + pn) : ((u32)src[pn] | ((u32)src[pn + 1] << 8) | ((u32)src[pn + 2] << 16));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u32 const base = gbase + (u32)k * (u32)nthreads;
+                if (base >= nIns) break;                    // uniform over the workgroup
+                u32 const p = base + (u32)wv * 64u + (u32)lane; bool const valid = vq[k];
+                u32 const h = valid ? kd_hash3(hq[k] & 0xFFu, (hq[k] >> 8) & 0xFFu, (hq[k] >> 16) & 0xFFu) : 0x8000u + (u32)lane;
+                u32 rk = 0;
+                for (int w = 0; w < nw; w++) {
+                    if (wv == w) {
+                        u32 const old = valid ? (u32)cnt[h] : 0u;
+                        // lanes of this wave that share a bucket: a lane's rank counts the lower ones, the highest one leaves the total
+                        u32 below = 0, group = 1;
+                        {
+                            // (one bucket per round, for the lanes that are not alone in theirs)
+                            kx_lockstep();
+                            if (valid) cnt[h] = (u16)lane;           // a mark: who is alone reads its own lane back
+                            kx_lockstep();
+                            bool const shared = valid && (u32)cnt[h] != (u32)lane;
+                            for (u64 todo = kx_ballot(shared); todo; ) {
+                                int const L = (int)kx_ctz64(todo);
+                                u32 const hL = kx_bcast(h, L);
+                                u64 const grp = kx_ballot(valid && h == hL);
+                                if (valid && h == hL) { below = kx_popc64(grp & ((1ull << lane) - 1ull)); group = kx_popc64(grp); }
+                                todo &= ~grp;
+                            }
+                            // (a lane that read its own mark can still share its bucket with LOWER lanes whose marks it overwrote: they were
+                            // `shared`, so their round set this lane's below / group too -- the ballot is over all valid lanes of the bucket)
+                        }
+                        rk = old + below;
+                        kx_lockstep();
+                        if (valid && below + 1u == group) cnt[h] = (u16)(old + group);      // the highest lane of the bucket
+                        kx_lockstep();
+                    }
+                    if (nw > 1) kx_block_sync();
+                }
+                if (valid) rank[p] = (u16)rk;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { hq[k] = hn[k]; vq[k] = vn[k]; }
+        }
+        kx_block_sync();
+        // ---- pass 2: bucket starts (each thread scans 32768 / nthreads consecutive buckets; the threads' sums through LDS)
+        {
+            int const per = 32768 / nthreads;
+            u32 s = 0;
+            for (int i = 0; i < per; i++) s += cnt[tid * per + i];
+            part[tid] = s;
+            kx_block_sync();
+            if (tid == 0) { u32 run = 0; for (int t = 0; t < nthreads; t++) { u32 const v = part[t]; part[t] = run; run += v; } }
+            kx_block_sync();
+            u32 run = part[tid];
+            for (int i = 0; i < per; i++) { u32 const v = cnt[tid * per + i]; cnt[tid * per + i] = (u16)run; run += v; }
+        }
+        kx_block_sync();
+        // ---- pass 3
+        for (u32 p = (u32)tid; p < nIns; p += (u32)nthreads) {
+            u64 const w8 = kdl_ld64(src, (int)p, (int)n);
+            u32 const w = (u32)w8;
+            u32 const h = kd_hash3(w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu);
+            u32 const rk = rank[p];
+            u32 const where = (u32)cnt[h] + rk;
+            wr[p] = where | (rk << 16);
+            srt[where] = (u16)p;
+            KdlBytes e; e.lo = w8; e.hi = ((int)p + 8 < (int)n) ? kdl_ld64(src, (int)p + 8, (int)n) : 0ull;
+            sb[where] = e;
+        }
+        kx_block_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_deflate_lazy: one wave per slice
+// ---------------------------------------------------------------------------
+KX_DEV void deflate_lazy_body(const KdArgs& a)
+{
+    int const lane = kx_lane();
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
+        u32 const slice = kx_xcd_chunk(it, a.n_slices);
+        const u8* const src = a.src + a.in_off[slice]; int const n = (int)a.in_len[slice];
+        const u32* const wr = kdl_wr(a, slice); const u16* const srt = kdl_srt(a, slice); const KdlBytes* const sb = kdl_sb(a, slice);
+        u32* const syms = a.syms + (size_t)slice * a.pos_cap;
+        KdBlockInfo* const blocks = a.blocks + (size_t)slice * a.blk_cap;
+        KdSliceMeta mm; mm.nblocks = 0; mm.nsym = 0; mm.pad[0] = 0; mm.pad[1] = 0;
+        int strstart = 0; int match_length = 2, prev_length = 2; int match_dist = 0, prev_dist = 0; bool match_available = false;
+        u32 nsym = 0, blockSyms = 0; int block_start = 0;
+        u32 symq = 0;                                      // lane (nsym & 63) holds symbol nsym until 64 are there
+        // zlib's 64 KiB window buffer (see deflate_parse_body): only the stored-block eligibility of a block depends on it
+        int base = 0, dataEnd = n < 2 * KD_WSIZE ? n : 2 * KD_WSIZE;
+        int const maxChain = (int)a.chain, niceMax = (int)a.nice;
+        int const nIns = n >= 3 ? n - 2 : 0;
+        // What the parse reads at its own position -- where / rank, the bytes ahead (the string to match, the literal behind it) -- comes
+        // out of two register windows, refilled with one coalesced load each when the position leaves them: lane i holds wr[wbase + i]
+        // and the 8 bytes at sbase + 8 i.  A search then waits for memory once (its candidates), not three times.
+        int wbase = -(1 << 20); u32 wrv = 0;
+        int sbase = -(1 << 20); u64 sv = 0;
+        // ... and with the where / rank window comes a verdict for each of its 64 positions, worked out by all lanes at once: can a
+        // search there find anything?  A position with no candidate, or whose one or two candidates differ from it within the first
+        // three bytes, cannot (longest_match would return what it started with), and the parse passes it without touching memory:
+        // in incompressible data that is nearly every position -- 65 536 of them per slice, each a round trip to HBM before this.
+        u64 maybe = 0;
+#define KDL_BYTES8(p_, out_) { int const o_ = (p_) - sbase; int const q_ = o_ >> 3; u32 const sh_ = (u32)(o_ & 7) * 8u; \
+        u64 const lo_ = (u64)kx_bcast((u32)sv, q_) | ((u64)kx_bcast((u32)(sv >> 32), q_) << 32); \
+        u64 const hi_ = (u64)kx_bcast((u32)sv, q_ + 1) | ((u64)kx_bcast((u32)(sv >> 32), q_ + 1) << 32); \
+        out_ = sh_ ? (lo_ >> sh_) | (hi_ << (64u - sh_)) : lo_; }
+#define KDL_FLUSH() { KdBlockInfo b_; \
+        b_.nsym_end = nsym; b_.end_pos = (u32)strstart; b_.start_pos = (u32)block_start; b_.stored_ok = (block_start - base >= 0) ? 1u : 0u; \
+        if (lane == 0 && mm.nblocks < a.blk_cap) blocks[mm.nblocks] = b_; \
+        mm.nblocks++; block_start = strstart; blockSyms = 0; }
+#define KDL_TALLY(dist_, lc_) { u32 const v__ = (u32)(dist_) | ((u32)(lc_) << 16); \
+        if ((u32)lane == (nsym & 63u)) symq = v__; \
+        nsym++; blockSyms++; \
+        if ((nsym & 63u) == 0) syms[nsym - 64u + (u32)lane] = symq; }
+        for (;;) {
+            if (dataEnd - strstart < KD_MIN_LOOKAHEAD) {
+                // fill_window: one pass is enough (it brings at least 65 536 - strstart bytes, or all that is left)
+                int const rel = strstart - base;
+                int const slide = (rel >= KD_WSIZE + KD_MAX_DIST) ? KD_WSIZE : 0;
+                base += slide;
+                int const more = 2 * KD_WSIZE - (dataEnd - base);
+                dataEnd += (n - dataEnd < more) ? n - dataEnd : more;
+                if (dataEnd == strstart) break;
+            }
+            int const lookahead = n - strstart;
+            // the byte window covers [strstart - 1, strstart + 288): the literal behind the position, the string ahead of it (MAX_MATCH
+            // + the 16 bytes a compare step reads); 63 lanes of 8 bytes are addressable with their upper neighbour
+            if (strstart - 1 < sbase || strstart + 296 > sbase + 504) {
+                sbase = strstart > 0 ? (strstart - 1) & ~7 : 0;
+                int const q = sbase + 8 * lane;
+                sv = q < n ? kdl_ld64(src, q, n) : 0ull;
+            }
+            prev_length = match_length; prev_dist = match_dist;
+            match_length = KD_MIN_MATCH - 1;
+            if (lookahead >= KD_MIN_MATCH && prev_length < (int)a.lazy) {
+                // ---- longest_match(strstart), starting from best_len = prev_length: only a longer match changes anything; a previous
+                // match >= good_match shortens the walk to a quarter of max_chain
+                if (strstart < wbase || strstart >= wbase + 64) {
+                    wbase = strstart; wrv = (strstart + lane < nIns) ? wr[strstart + lane] : 0u;
+                    u32 const wh = wrv & 0xFFFFu, rk_ = wrv >> 16;
+                    bool m = rk_ > 2u;                                         // more candidates than are looked at here: ask the search
+                    if (strstart + lane < nIns && rk_ >= 1u && rk_ <= 2u) {
+                        // the position's own entry and its nearest candidates are neighbours in the sorted array
+                        u32 const own = (u32)sb[wh].lo & 0xFFFFFFu;
+                        m = (((u32)sb[wh - 1u].lo & 0xFFFFFFu) == own) || (rk_ == 2u && ((u32)sb[wh - 2u].lo & 0xFFFFFFu) == own);
+                    }
+                    maybe = kx_ballot(m);
+                }
+                if (!((maybe >> (strstart - wbase)) & 1ull)) goto kdl_no_search;      // (wave-uniform)
+                {
+                u32 const w0 = kx_bcast(wrv, strstart - wbase);
+                int const where = (int)(w0 & 0xFFFFu), rk = (int)(w0 >> 16);
+                int const chain = prev_length >= (int)a.good ? (maxChain >> 2) : maxChain;
+                int const ncand = rk < chain ? rk : chain;
+                int const maxlen = lookahead < KD_MAX_MATCH ? lookahead : KD_MAX_MATCH;
+                int const nice = lookahead < niceMax ? lookahead : niceMax;
+                int bestLen = prev_length, bestPos = -1;
+                u64 scan0, scan1;
+                KDL_BYTES8(strstart, scan0) KDL_BYTES8(strstart + 8, scan1)
+                for (int cb = 0; cb < ncand; cb += 64) {
+                    int const j = cb + lane;
+                    bool valid = j < ncand;
+                    int const c = valid ? (int)srt[where - 1 - j] : 0;
+                    KdlBytes cbytes; cbytes.lo = 0; cbytes.hi = 0;
+                    if (valid) cbytes = sb[where - 1 - j];                   // (the candidates' first bytes lie next to each other, like their positions)
+                    // position 0 is zlib's NIL; beyond MAX_DIST the chain ends (and with it every later candidate: they lie further back).
+                    // The head of the chain may lie exactly MAX_DIST back (deflate_slow's test), the others must be nearer (longest_match's limit).
+                    bool const inWin = valid && c != 0 && (j == 0 ? strstart - c <= KD_MAX_DIST : strstart - c < KD_MAX_DIST);
+                    u64 const ended = kx_ballot(valid && !inWin);
+                    valid = inWin;
+                    int len = 0;
+                    if (valid) {
+                        u64 const d0 = cbytes.lo ^ scan0, d1 = cbytes.hi ^ scan1;
+                        len = d0 ? (int)(kx_ctz64(d0) >> 3) : d1 ? 8 + (int)(kx_ctz64(d1) >> 3) : 16;
+                    }
+                    // the lanes whose first sixteen bytes agree go on, sixteen bytes at a time
+                    bool more = valid && len == 16 && len < maxlen;
+                    for (int done16 = 16; kx_any(more); done16 += 16) {
+                        u64 s0, s1;
+                        KDL_BYTES8(strstart + done16, s0) KDL_BYTES8(strstart + done16 + 8, s1)
+                        if (more) {
+                            int const q = c + done16;
+                            u64 const d0 = (q < n ? kdl_ld64(src, q, n) : 0ull) ^ s0, d1 = (q + 8 < n ? kdl_ld64(src, q + 8, n) : 0ull) ^ s1;
+                            if (d0) { len = done16 + (int)(kx_ctz64(d0) >> 3); more = false; }
+                            else if (d1) { len = done16 + 8 + (int)(kx_ctz64(d1) >> 3); more = false; }
+                            else { len = done16 + 16; if (len >= maxlen) more = false; }
+                        }
+                    }
+                    if (len > maxlen) len = maxlen;
+                    // the walk stops at the first candidate that reaches nice_length
+                    u64 const niceM = kx_ballot(valid && len >= nice);
+                    bool const take = valid && (niceM == 0 || lane <= (int)kx_ctz64(niceM));
+                    // ... and keeps the longest it has seen, the earlier one among equals: successive improvements in lane order
+                    for (u64 up = kx_ballot(take && len > bestLen); up; up = kx_ballot(take && len > bestLen)) {
+                        int const L = (int)kx_ctz64(up);
+                        bestLen = (int)kx_bcast((u32)len, L); bestPos = (int)kx_bcast((u32)c, L);
+                    }
+                    if (niceM != 0 || ended != 0) break;
+                }
+                if (bestPos >= 0) {
+                    match_length = bestLen; match_dist = strstart - bestPos;
+                    if (match_length == KD_MIN_MATCH && match_dist > KD_TOO_FAR) match_length = KD_MIN_MATCH - 1;
+                }
+                }
+            }
+kdl_no_search:
+            if (prev_length >= KD_MIN_MATCH && match_length <= prev_length) {
+                KDL_TALLY(prev_dist, prev_length - KD_MIN_MATCH)
+                bool const bflush = blockSyms == KD_LIT_BUFSIZE - 1;
+                strstart += prev_length - 1;
+                match_available = false; match_length = KD_MIN_MATCH - 1;
+                if (bflush) KDL_FLUSH()
+            } else if (match_available) {
+                u64 lit; KDL_BYTES8(strstart - 1, lit)
+                KDL_TALLY(0, (u32)lit & 0xFFu)
+                if (blockSyms == KD_LIT_BUFSIZE - 1) KDL_FLUSH()
+                strstart++;
+            } else { match_available = true; strstart++; }
+        }
+        if (match_available) KDL_TALLY(0, kx_bcast((u32)src[strstart - 1], 0))
+        KDL_FLUSH()
+        if ((nsym & 63u) != 0 && (u32)lane < (nsym & 63u)) syms[(nsym & ~63u) + (u32)lane] = symq;
+        mm.nsym = nsym;
+        if (lane == 0) a.meta[slice] = mm;
+#undef KDL_TALLY
+#undef KDL_FLUSH
+#undef KDL_BYTES8
+    }
+}

@@ -45,6 +45,7 @@ struct KdArgs {
     u32 pos_cap;        // positions of the per-slice arrays below (the context's max_slice_bytes, rounded up to 64)
     u16* link;          // per slice: pos_cap entries: distance to the previous position with the same hash, 0 = none
     KdBest* best;       // per slice: pos_cap entries
+    u32* wr = nullptr;  // per slice: pos_cap entries (deflate_lazy.h: where | rank << 16)
     u32* syms;          // per slice: pos_cap entries: dist | lc << 16
     KdSliceMeta* meta;
     KdBlockInfo* blocks; u32 blk_cap;    // per slice: blk_cap entries

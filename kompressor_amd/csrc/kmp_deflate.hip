@@ -4,6 +4,7 @@
 #include "kx_wave.h"
 #include "zstd_common.h"
 #include "deflate_match.h"
+#include "deflate_lazy.h"
 #include "deflate_encode.h"
 #include "deflate_decode.h"
 #include "deflate_predecode.h"
@@ -14,6 +15,9 @@ __global__ __launch_bounds__(256) void k_deflate_chains_long(KdArgs a) { deflate
 __global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_parse(KdArgs a) { deflate_parse_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_fast(KdArgs a) { deflate_fast_body(a); }
+// the lazy levels for slices up to 64 KiB: positions sorted by hash, then the parse with a wave-wide longest_match (deflate_lazy.h)
+__global__ __launch_bounds__(256) void k_deflate_sort(KdArgs a) { deflate_sort_body(a); }
+__global__ __launch_bounds__(64, 8) void k_deflate_lazy(KdArgs a) { deflate_lazy_body(a); }
 __global__ __launch_bounds__(64, 2) void k_inflate_predecode(KipArgs a) { inflate_predecode_body(a); }
 __global__ __launch_bounds__(64) void k_inflate_exec(KieArgs a) { inflate_exec_body(a); }
 __global__ __launch_bounds__(64, 4) void k_deflate_encode(KdArgs a) { deflate_encode_body(a); }
@@ -122,8 +126,10 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
         u32 const chunk = c->max_slices < cap ? c->max_slices : cap;
         c->dfl_pos_cap = pos_cap; c->dfl_blk_cap = pos_cap / (KD_LIT_BUFSIZE - 1) + 2u;
         HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)2 * chunk * pos_cap * sizeof(u16)));
-        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * chunk * pos_cap * sizeof(KdBest)));
+        // (slices up to 64 KiB: deflate_lazy.h keeps 16 bytes per position where the older kernels keep a KdBest of 8)
+        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * chunk * pos_cap * sizeof(KdBest) * (pos_cap <= 65536u ? 2u : 1u)));
         HIP_TRY(hipMalloc((void**)&c->dfl_syms, (size_t)2 * chunk * pos_cap * sizeof(u32)));
+        if (pos_cap <= 65536u) HIP_TRY(hipMalloc((void**)&c->dfl_wr, (size_t)2 * chunk * pos_cap * sizeof(u32)));       // (deflate_lazy.h: where / rank of every position)
         HIP_TRY(hipMalloc((void**)&c->dfl_meta, (size_t)2 * chunk * sizeof(KdSliceMeta)));
         HIP_TRY(hipMalloc((void**)&c->dfl_blocks, (size_t)2 * chunk * c->dfl_blk_cap * sizeof(KdBlockInfo)));
         for (int i = 0; i < 2; i++) {
@@ -188,22 +194,28 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
         a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = c->len_ok + first; a.n_slices = m;
         size_t const half = (size_t)h * c->dfl_chunk;
         a.pos_cap = c->dfl_pos_cap; a.blk_cap = c->dfl_blk_cap;
-        a.link = c->dfl_link + half * c->dfl_pos_cap; a.best = c->dfl_best + half * c->dfl_pos_cap;
+        a.link = c->dfl_link + half * c->dfl_pos_cap; a.best = c->dfl_best + half * c->dfl_pos_cap * (c->dfl_wr ? 2u : 1u);
         a.syms = c->dfl_syms + half * c->dfl_pos_cap; a.meta = c->dfl_meta + half; a.blocks = c->dfl_blocks + half * c->dfl_blk_cap;
+        a.wr = c->dfl_wr ? c->dfl_wr + half * c->dfl_pos_cap : nullptr;
         a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
         kd_level_config(a, level);
         bool const prof = c->profiling && first == 0;      // per-kernel events for the first piece
         hipStream_t const s2 = serial ? st : c->st2;
         if (!serial && piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[h], 0));      // this half's previous piece has been encoded
+        // slices up to 64 KiB: k_deflate_sort + k_deflate_lazy (only the positions zlib's parse asks about are searched, each by a
+        // whole wave: deflate_lazy.h); longer ones: the chain / all-positions search / lane-per-slice parse of deflate_match.h
+        bool const lazy2 = c->dfl_wr != nullptr && !KMP_KNOB("KMP_DEFLATE_OLD", 0);
         if (prof) HIP_TRY(hipEventRecord(c->ev[8], st));
-        if (c->dfl_pos_cap <= 65536u) hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(64u * chain_waves), 0, st, a);
+        if (lazy2) hipLaunchKernelGGL(k_deflate_sort, dim3(m), dim3(256), 0, st, a);
+        else if (c->dfl_pos_cap <= 65536u) hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(64u * chain_waves), 0, st, a);
         else hipLaunchKernelGGL(k_deflate_chains_long, dim3(m), dim3(64u * chain_waves), 0, st, a);
         if (prof) HIP_TRY(hipEventRecord(c->ev[9], st));
-        hipLaunchKernelGGL(k_deflate_best, dim3(m), dim3(1024), 0, st, a);
+        if (!lazy2) hipLaunchKernelGGL(k_deflate_best, dim3(m), dim3(1024), 0, st, a);
         if (prof) HIP_TRY(hipEventRecord(c->ev[10], st));
         if (!serial) { HIP_TRY(hipEventRecord(c->dfl_searched[h], st)); HIP_TRY(hipStreamWaitEvent(s2, c->dfl_searched[h], 0)); }
         if (prof) HIP_TRY(hipEventRecord(c->ev[13], s2));
-        hipLaunchKernelGGL(k_deflate_parse, dim3((m + 63) / 64), dim3(64), 0, s2, a);
+        if (lazy2) hipLaunchKernelGGL(k_deflate_lazy, dim3(m), dim3(64), 0, s2, a);
+        else hipLaunchKernelGGL(k_deflate_parse, dim3((m + 63) / 64), dim3(64), 0, s2, a);
         if (prof) HIP_TRY(hipEventRecord(c->ev[11], s2));
         hipLaunchKernelGGL(k_deflate_encode, dim3(m), dim3(64), 0, s2, a);
         if (prof) HIP_TRY(hipEventRecord(c->ev[12], s2));

@@ -411,6 +411,7 @@ int emu_seq_sort_by(const u8* src, const u64* in_off, const u32* in_len, u32 n, 
 }
 
 #include "deflate_match.h"
+#include "deflate_lazy.h"
 #include "deflate_encode.h"
 // raw DEFLATE level 6 pipeline (chains -> best -> parse -> encode) on the emulator
 extern "C" __attribute__((visibility("default")))
@@ -428,11 +429,13 @@ int emu_deflate_level(const u8* src, const u64* in_off, const u32* in_len, u32 n
     for (u32 i = 0; i < n; i++) if (in_len[i] > maxlen) maxlen = in_len[i];
     u32 const pos_cap = (maxlen + 63u) & ~63u, blk_cap = pos_cap / (KD_LIT_BUFSIZE - 1) + 2u;
     std::vector<u16> link((size_t)n * pos_cap, 0xEEEE);
-    std::vector<KdBest> best((size_t)n * pos_cap);
+    std::vector<KdBest> best((size_t)n * pos_cap * 2);
     std::vector<u32> syms((size_t)n * pos_cap, 0xDDDDDDDDu);
+    std::vector<u32> wrv((size_t)n * pos_cap, 0xCCCCCCCCu);
     std::vector<KdSliceMeta> meta(n);
     std::vector<KdBlockInfo> blocks((size_t)n * blk_cap);
     KdArgs a;
+    a.wr = wrv.data();
     a.src = src; a.in_off = in_off; a.in_len = in_len; a.n_slices = n;
     a.pos_cap = pos_cap; a.blk_cap = blk_cap; a.blocks = blocks.data();
     a.link = link.data(); a.best = best.data(); a.syms = syms.data(); a.meta = meta.data();
@@ -442,6 +445,16 @@ int emu_deflate_level(const u8* src, const u64* in_off, const u32* in_len, u32 n
     if (level >= 1 && level <= 3) {
         memset((void*)best.data(), 0, (size_t)n * 32768u * 4u);
         kxemu::launch((n + 63) / 64, [&]() { deflate_fast_body(a); });
+        if (kxemu::failed) return -3;
+        kxemu::launch(n < 3 ? n : 3, [&]() { deflate_encode_body(a); });
+        return kxemu::failed ? -4 : 0;
+    }
+    // slices up to 64 KiB: the sort + wave-wide lazy parse of deflate_lazy.h (what the product runs there), unless the caller wants the
+    // chain links / per-position records of the older kernels back (link_out / best_out) -- the tests keep both pipelines honest
+    if (pos_cap <= 65536u && !link_out && !best_out) {
+        kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_sort_body(a); });
+        if (kxemu::failed) return -1;
+        kxemu::launch(n < 3 ? n : 3, [&]() { deflate_lazy_body(a); });
         if (kxemu::failed) return -3;
         kxemu::launch(n < 3 ? n : 3, [&]() { deflate_encode_body(a); });
         return kxemu::failed ? -4 : 0;
@@ -456,7 +469,7 @@ int emu_deflate_level(const u8* src, const u64* in_off, const u32* in_len, u32 n
     kxemu::launch(n < 3 ? n : 3, [&]() { deflate_encode_body(a); });
     if (kxemu::failed) return -4;
     if (link_out) memcpy(link_out, link.data(), link.size() * 2);
-    if (best_out) memcpy(best_out, best.data(), best.size() * sizeof(KdBest));
+    if (best_out) memcpy(best_out, best.data(), (size_t)n * pos_cap * sizeof(KdBest));
     return 0;
 }
 
