@@ -41,6 +41,16 @@ KX_DEV u64 kdl_ld64(const u8* src, int q, int n)
     for (int k = 0; q + k < n; k++) v |= (u64)src[q + k] << (8 * k);
     return v;
 }
+// the same for a slice of at least 16 bytes, any q >= 0, without a branch: one load that ends at the slice's last byte at the latest
+// (the parse runs on the scalar unit, and a branch per lane is a handful of scalar instructions for the whole wave)
+KX_DEV u64 kdl_ld64_fast(const u8* src, int q, int n)
+{
+    int const aq = q + 8 <= n ? q : n - 8;
+    u32 const sh = (u32)(q - aq);
+    u64 const v = kx_ld64(src + aq);
+    return sh >= 8u ? 0ull : v >> (8u * sh);
+}
+template <bool TINY> KX_DEV u64 kdl_get64(const u8* src, int q, int n) { return TINY ? (q < n ? kdl_ld64(src, q, n) : 0ull) : kdl_ld64_fast(src, q, n); }
 
 // ---------------------------------------------------------------------------
 // k_deflate_sort: 256 threads per workgroup, one slice at a time, cnt[32768] in LDS
@@ -150,11 +160,11 @@ KX_DEV void deflate_sort_body(const KdArgs& a)
 // ---------------------------------------------------------------------------
 // k_deflate_lazy: one wave per slice
 // ---------------------------------------------------------------------------
-KX_DEV void deflate_lazy_body(const KdArgs& a)
+// TINY: a slice of fewer than 16 bytes (its loads are assembled byte by byte; every other slice takes the branch-free loader)
+template <bool TINY>
+KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
 {
-    int const lane = kx_lane();
-    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
-        u32 const slice = kx_xcd_chunk(it, a.n_slices);
+    {
         const u8* const src = a.src + a.in_off[slice]; int const n = (int)a.in_len[slice];
         const u32* const wr = kdl_wr(a, slice); const u16* const srt = kdl_srt(a, slice); const KdlBytes* const sb = kdl_sb(a, slice);
         u32* const syms = a.syms + (size_t)slice * a.pos_cap;
@@ -167,26 +177,25 @@ KX_DEV void deflate_lazy_body(const KdArgs& a)
         int base = 0, dataEnd = n < 2 * KD_WSIZE ? n : 2 * KD_WSIZE;
         int const maxChain = (int)a.chain, niceMax = (int)a.nice;
         int const nIns = n >= 3 ? n - 2 : 0;
-        // What the parse reads at its own position -- where / rank, the bytes ahead (the string to match, the literal behind it) -- comes
-        // out of two register windows, refilled with one coalesced load each when the position leaves them: lane i holds wr[wbase + i]
-        // and the 8 bytes at sbase + 8 i.  A search then waits for memory once (its candidates), not three times.
-        int wbase = -(1 << 20); u32 wrv = 0;
-        int sbase = -(1 << 20); u64 sv = 0;
-        // ... and with the where / rank window comes a verdict for each of its 64 positions, worked out by all lanes at once: can a
-        // search there find anything?  A position with no candidate, or whose one or two candidates differ from it within the first
-        // three bytes, cannot (longest_match would return what it started with), and the parse passes it without touching memory:
-        // in incompressible data that is nearly every position -- 65 536 of them per slice, each a round trip to HBM before this.
-        u64 maybe = 0;
-#define KDL_BYTES8(p_, out_) { int const o_ = (p_) - sbase; int const q_ = o_ >> 3; u32 const sh_ = (u32)(o_ & 7) * 8u; \
-        u64 const lo_ = (u64)kx_bcast((u32)sv, q_) | ((u64)kx_bcast((u32)(sv >> 32), q_) << 32); \
-        u64 const hi_ = (u64)kx_bcast((u32)sv, q_ + 1) | ((u64)kx_bcast((u32)(sv >> 32), q_ + 1) << 32); \
-        out_ = sh_ ? (lo_ >> sh_) | (hi_ << (64u - sh_)) : lo_; }
+        // The parse is one decision chain per slice and runs on the scalar unit, of which a compute unit has ONE: with 32 slices per CU
+        // in flight the kernel is bound by scalar instructions per position (counters: profiles/r04_deflate_lazy.txt), so the parse
+        // touches as few positions as it can and does as little as it can at each.
+        // where / rank of the 64 positions from wbase on sit in a register window (lane i: wr[wbase + i]), and with them a verdict for
+        // each, worked out by all lanes at once when the window is loaded: can a search there find anything?  A position with no
+        // candidate, or whose one or two candidates differ from it within the first three bytes, cannot (longest_match would return
+        // what it started with): the parse passes it without a search, and a RUN of such positions -- incompressible data is nothing
+        // else -- in one step that emits their literals 64 lanes wide.
+        int wbase = -(1 << 20); u32 wrv = 0; u64 maybe = 0;
 #define KDL_FLUSH() { KdBlockInfo b_; \
         b_.nsym_end = nsym; b_.end_pos = (u32)strstart; b_.start_pos = (u32)block_start; b_.stored_ok = (block_start - base >= 0) ? 1u : 0u; \
         if (lane == 0 && mm.nblocks < a.blk_cap) blocks[mm.nblocks] = b_; \
         mm.nblocks++; block_start = strstart; blockSyms = 0; }
-#define KDL_TALLY(dist_, lc_) { u32 const v__ = (u32)(dist_) | ((u32)(lc_) << 16); \
+        // (a symbol whose value a single lane fetches -- a literal -- is loaded by that lane only, and nobody waits for it before the 64 are stored)
+#define KDL_TALLY_MATCH(dist_, lc_) { u32 const v__ = (u32)(dist_) | ((u32)(lc_) << 16); \
         if ((u32)lane == (nsym & 63u)) symq = v__; \
+        nsym++; blockSyms++; \
+        if ((nsym & 63u) == 0) syms[nsym - 64u + (u32)lane] = symq; }
+#define KDL_TALLY_LIT(pos_) { if ((u32)lane == (nsym & 63u)) symq = (u32)src[pos_] << 16; \
         nsym++; blockSyms++; \
         if ((nsym & 63u) == 0) syms[nsym - 64u + (u32)lane] = symq; }
         for (;;) {
@@ -200,40 +209,53 @@ KX_DEV void deflate_lazy_body(const KdArgs& a)
                 if (dataEnd == strstart) break;
             }
             int const lookahead = n - strstart;
-            // the byte window covers [strstart - 1, strstart + 288): the literal behind the position, the string ahead of it (MAX_MATCH
-            // + the 16 bytes a compare step reads); 63 lanes of 8 bytes are addressable with their upper neighbour
-            if (strstart - 1 < sbase || strstart + 296 > sbase + 504) {
-                sbase = strstart > 0 ? (strstart - 1) & ~7 : 0;
-                int const q = sbase + 8 * lane;
-                sv = q < n ? kdl_ld64(src, q, n) : 0ull;
+            bool const search_here = lookahead >= KD_MIN_MATCH && match_length < (int)a.lazy;       // (match_length: what becomes prev_length below)
+            if (search_here && (strstart < wbase || strstart >= wbase + 64)) {
+                wbase = strstart; wrv = (strstart + lane < nIns) ? wr[strstart + lane] : 0u;
+                u32 const wh = wrv & 0xFFFFu, rk_ = wrv >> 16;
+                // the position's own entry and its nearest candidates are neighbours in the sorted array (three loads, no branch between them)
+                u32 const own = (u32)sb[wh].lo & 0xFFFFFFu;
+                u32 const c1 = (u32)sb[wh - (rk_ >= 1u ? 1u : 0u)].lo & 0xFFFFFFu, c2 = (u32)sb[wh - (rk_ >= 2u ? 2u : 0u)].lo & 0xFFFFFFu;
+                bool const m = rk_ > 2u || (rk_ >= 1u && c1 == own) || (rk_ == 2u && c2 == own);      // more than two candidates: ask the search
+                maybe = kx_ballot(m && strstart + lane < nIns);
+            }
+            int const off = strstart - wbase;
+            if (search_here && match_length == KD_MIN_MATCH - 1 && !((maybe >> off) & 1ull)) {
+                // ---- a run of positions at which nothing can be found, after a position at which nothing was: literals, all at once.
+                // Bounded by the window, by fill_window's next turn, by the symbol buffer's 64 and by the block's 16 383 symbols (the
+                // step that fills a block is left to the ordinary path below).
+                u64 const rest = maybe >> off;
+                int K = rest ? (int)kx_ctz64(rest) : 64; if (K > 64 - off) K = 64 - off;
+                int const room_w = dataEnd - KD_MIN_LOOKAHEAD - strstart + 1; if (K > room_w) K = room_w;
+                int const first_lit = match_available ? strstart - 1 : strstart;          // the first position passed emits the byte behind it, if that is still owed
+                int L = match_available ? K : K - 1;
+                int const room_q = 64 - (int)(nsym & 63u), room_b = (int)(KD_LIT_BUFSIZE - 2) - (int)blockSyms;
+                int const Lmax = room_q < room_b ? room_q : room_b;
+                if (L > Lmax) { K -= L - Lmax; L = Lmax; }
+                if (K >= 2 && L >= 1) {
+                    int const i = lane - (int)(nsym & 63u);
+                    if (i >= 0 && i < L) symq = (u32)src[first_lit + i] << 16;
+                    nsym += (u32)L; blockSyms += (u32)L;
+                    if ((nsym & 63u) == 0) syms[nsym - 64u + (u32)lane] = symq;
+                    strstart += K; match_available = true;
+                    prev_length = KD_MIN_MATCH - 1;                               // (match_length stays MIN_MATCH - 1: nothing was found at the last of them either)
+                    continue;
+                }
             }
             prev_length = match_length; prev_dist = match_dist;
             match_length = KD_MIN_MATCH - 1;
-            if (lookahead >= KD_MIN_MATCH && prev_length < (int)a.lazy) {
+            if (search_here && ((maybe >> off) & 1ull)) {
                 // ---- longest_match(strstart), starting from best_len = prev_length: only a longer match changes anything; a previous
                 // match >= good_match shortens the walk to a quarter of max_chain
-                if (strstart < wbase || strstart >= wbase + 64) {
-                    wbase = strstart; wrv = (strstart + lane < nIns) ? wr[strstart + lane] : 0u;
-                    u32 const wh = wrv & 0xFFFFu, rk_ = wrv >> 16;
-                    bool m = rk_ > 2u;                                         // more candidates than are looked at here: ask the search
-                    if (strstart + lane < nIns && rk_ >= 1u && rk_ <= 2u) {
-                        // the position's own entry and its nearest candidates are neighbours in the sorted array
-                        u32 const own = (u32)sb[wh].lo & 0xFFFFFFu;
-                        m = (((u32)sb[wh - 1u].lo & 0xFFFFFFu) == own) || (rk_ == 2u && ((u32)sb[wh - 2u].lo & 0xFFFFFFu) == own);
-                    }
-                    maybe = kx_ballot(m);
-                }
-                if (!((maybe >> (strstart - wbase)) & 1ull)) goto kdl_no_search;      // (wave-uniform)
-                {
-                u32 const w0 = kx_bcast(wrv, strstart - wbase);
+                u32 const w0 = kx_bcast(wrv, off);
                 int const where = (int)(w0 & 0xFFFFu), rk = (int)(w0 >> 16);
                 int const chain = prev_length >= (int)a.good ? (maxChain >> 2) : maxChain;
                 int const ncand = rk < chain ? rk : chain;
                 int const maxlen = lookahead < KD_MAX_MATCH ? lookahead : KD_MAX_MATCH;
                 int const nice = lookahead < niceMax ? lookahead : niceMax;
                 int bestLen = prev_length, bestPos = -1;
-                u64 scan0, scan1;
-                KDL_BYTES8(strstart, scan0) KDL_BYTES8(strstart + 8, scan1)
+                // the string at the position: every lane reads the same sixteen bytes (one request), beside the candidates' loads
+                u64 const scan0 = kdl_get64<TINY>(src, strstart, n), scan1 = kdl_get64<TINY>(src, strstart + 8, n);
                 for (int cb = 0; cb < ncand; cb += 64) {
                     int const j = cb + lane;
                     bool valid = j < ncand;
@@ -253,11 +275,10 @@ KX_DEV void deflate_lazy_body(const KdArgs& a)
                     // the lanes whose first sixteen bytes agree go on, sixteen bytes at a time
                     bool more = valid && len == 16 && len < maxlen;
                     for (int done16 = 16; kx_any(more); done16 += 16) {
-                        u64 s0, s1;
-                        KDL_BYTES8(strstart + done16, s0) KDL_BYTES8(strstart + done16 + 8, s1)
                         if (more) {
-                            int const q = c + done16;
-                            u64 const d0 = (q < n ? kdl_ld64(src, q, n) : 0ull) ^ s0, d1 = (q + 8 < n ? kdl_ld64(src, q + 8, n) : 0ull) ^ s1;
+                            int const q = c + done16, r = strstart + done16;
+                            u64 const d0 = kdl_get64<TINY>(src, q, n) ^ kdl_get64<TINY>(src, r, n);
+                            u64 const d1 = kdl_get64<TINY>(src, q + 8, n) ^ kdl_get64<TINY>(src, r + 8, n);
                             if (d0) { len = done16 + (int)(kx_ctz64(d0) >> 3); more = false; }
                             else if (d1) { len = done16 + 8 + (int)(kx_ctz64(d1) >> 3); more = false; }
                             else { len = done16 + 16; if (len >= maxlen) more = false; }
@@ -278,29 +299,36 @@ KX_DEV void deflate_lazy_body(const KdArgs& a)
                     match_length = bestLen; match_dist = strstart - bestPos;
                     if (match_length == KD_MIN_MATCH && match_dist > KD_TOO_FAR) match_length = KD_MIN_MATCH - 1;
                 }
-                }
             }
-kdl_no_search:
             if (prev_length >= KD_MIN_MATCH && match_length <= prev_length) {
-                KDL_TALLY(prev_dist, prev_length - KD_MIN_MATCH)
+                KDL_TALLY_MATCH(prev_dist, prev_length - KD_MIN_MATCH)
                 bool const bflush = blockSyms == KD_LIT_BUFSIZE - 1;
                 strstart += prev_length - 1;
                 match_available = false; match_length = KD_MIN_MATCH - 1;
                 if (bflush) KDL_FLUSH()
             } else if (match_available) {
-                u64 lit; KDL_BYTES8(strstart - 1, lit)
-                KDL_TALLY(0, (u32)lit & 0xFFu)
+                KDL_TALLY_LIT(strstart - 1)
                 if (blockSyms == KD_LIT_BUFSIZE - 1) KDL_FLUSH()
                 strstart++;
             } else { match_available = true; strstart++; }
         }
-        if (match_available) KDL_TALLY(0, kx_bcast((u32)src[strstart - 1], 0))
+        if (match_available) KDL_TALLY_LIT(strstart - 1)
         KDL_FLUSH()
         if ((nsym & 63u) != 0 && (u32)lane < (nsym & 63u)) syms[(nsym & ~63u) + (u32)lane] = symq;
         mm.nsym = nsym;
         if (lane == 0) a.meta[slice] = mm;
-#undef KDL_TALLY
+#undef KDL_TALLY_MATCH
+#undef KDL_TALLY_LIT
 #undef KDL_FLUSH
-#undef KDL_BYTES8
+    }
+}
+
+KX_DEV void deflate_lazy_body(const KdArgs& a)
+{
+    int const lane = kx_lane();
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
+        u32 const slice = kx_xcd_chunk(it, a.n_slices);
+        if (a.in_len[slice] < 16u) deflate_lazy_slice<true>(a, slice, lane);
+        else deflate_lazy_slice<false>(a, slice, lane);
     }
 }
