@@ -46,6 +46,7 @@ struct KdArgs {
     u16* link;          // per slice: pos_cap entries: distance to the previous position with the same hash, 0 = none
     KdBest* best;       // per slice: pos_cap entries
     u32* wr = nullptr;  // per slice: pos_cap entries (deflate_lazy.h: where | rank << 16)
+    u32* order_key = nullptr; u32* order_hist = nullptr; const u32* order = nullptr;      // deflate_lazy.h: per slice a cost class (0 .. 255) and their histogram, written by k_deflate_sort; the slices ordered by it, largest first
     u32* syms;          // per slice: pos_cap entries: dist | lc << 16
     KdSliceMeta* meta;
     KdBlockInfo* blocks; u32 blk_cap;    // per slice: blk_cap entries

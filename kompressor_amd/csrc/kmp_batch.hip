@@ -526,7 +526,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     (void)hipFree(c->pre_stage); (void)hipFree(c->pre_blk); (void)hipFree(c->pre_nblk); (void)hipFree(c->pre_sort);
     (void)hipFree(c->pre_lits); (void)hipFree(c->pre_lit); (void)hipFree(c->pre_nlit);
     if (c->st2) (void)hipStreamDestroy(c->st2);
-    (void)hipFree(c->dfl_wr); (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta); (void)hipFree(c->dfl_blocks);
+    (void)hipFree(c->dfl_wr); (void)hipFree(c->dfl_order); (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta); (void)hipFree(c->dfl_blocks);
     (void)hipFree(c->dfl_fsyms); (void)hipFree(c->dfl_fmeta); (void)hipFree(c->dfl_fblocks);
     if (c->dfl_events) for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->dfl_searched[i]); (void)hipEventDestroy(c->dfl_done[i]); }
     delete c;
@@ -1246,6 +1246,17 @@ int size_sort(kmp_batch_ctx* c, hipStream_t st, const u8* src, const u64* in_off
     KSeqSortArgs sa;
     sa.src = src; sa.in_off = in_off; sa.in_len = in_len; sa.n_slices = m; sa.key = key; sa.hist = hist; sa.perm = perm; sa.len_shift = len_shift;
     hipLaunchKernelGGL(k_zstd_seq_count, dim3((m + 255) / 256), dim3(256), 0, st, sa);
+    hipLaunchKernelGGL(k_zstd_seq_rank, dim3(1), dim3(256), 0, st, sa);
+    hipLaunchKernelGGL(k_zstd_seq_perm, dim3((m + 255) / 256), dim3(256), 0, st, sa);
+    HIP_TRY(hipGetLastError());
+    return KMP_OK;
+}
+
+int size_sort_keys(kmp_batch_ctx* c, hipStream_t st, u32 m, u32* key, u32* hist, u32* perm)
+{
+    (void)c;
+    KSeqSortArgs sa;
+    sa.src = nullptr; sa.in_off = nullptr; sa.in_len = nullptr; sa.n_slices = m; sa.key = key; sa.hist = hist; sa.perm = perm; sa.len_shift = 0;
     hipLaunchKernelGGL(k_zstd_seq_rank, dim3(1), dim3(256), 0, st, sa);
     hipLaunchKernelGGL(k_zstd_seq_perm, dim3((m + 255) / 256), dim3(256), 0, st, sa);
     HIP_TRY(hipGetLastError());

@@ -130,6 +130,7 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
         HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * chunk * pos_cap * sizeof(KdBest) * (pos_cap <= 65536u ? 2u : 1u)));
         HIP_TRY(hipMalloc((void**)&c->dfl_syms, (size_t)2 * chunk * pos_cap * sizeof(u32)));
         if (pos_cap <= 65536u) HIP_TRY(hipMalloc((void**)&c->dfl_wr, (size_t)2 * chunk * pos_cap * sizeof(u32)));       // (deflate_lazy.h: where / rank of every position)
+        if (pos_cap <= 65536u) HIP_TRY(hipMalloc((void**)&c->dfl_order, ((size_t)2 * (2 * chunk + 256)) * sizeof(u32)));  // (per half: cost classes, their histogram, the slices in order)
         HIP_TRY(hipMalloc((void**)&c->dfl_meta, (size_t)2 * chunk * sizeof(KdSliceMeta)));
         HIP_TRY(hipMalloc((void**)&c->dfl_blocks, (size_t)2 * chunk * c->dfl_blk_cap * sizeof(KdBlockInfo)));
         for (int i = 0; i < 2; i++) {
@@ -206,7 +207,13 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
         // whole wave: deflate_lazy.h); longer ones: the chain / all-positions search / lane-per-slice parse of deflate_match.h
         bool const lazy2 = c->dfl_wr != nullptr && !KMP_KNOB("KMP_DEFLATE_OLD", 0);
         if (prof) HIP_TRY(hipEventRecord(c->ev[8], st));
-        if (lazy2) hipLaunchKernelGGL(k_deflate_sort, dim3(m), dim3(256), 0, st, a);
+        if (lazy2) {
+            u32* const ord = c->dfl_order + (size_t)h * (2 * c->dfl_chunk + 256);
+            a.order_key = ord; a.order_hist = ord + c->dfl_chunk; a.order = ord + c->dfl_chunk + 256;
+            HIP_TRY(hipMemsetAsync(a.order_hist, 0, 256 * sizeof(u32), st));
+            hipLaunchKernelGGL(k_deflate_sort, dim3(m), dim3(256), 0, st, a);
+            KMP_TRY(size_sort_keys(c, st, m, a.order_key, a.order_hist, (u32*)a.order));
+        }
         else if (c->dfl_pos_cap <= 65536u) hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(64u * chain_waves), 0, st, a);
         else hipLaunchKernelGGL(k_deflate_chains_long, dim3(m), dim3(64u * chain_waves), 0, st, a);
         if (prof) HIP_TRY(hipEventRecord(c->ev[9], st));

@@ -69,7 +69,7 @@ struct kmp_batch_ctx {
     hipStream_t st2; hipEvent_t evm[KMP_MAX_CHUNKS][2], eve[KMP_MAX_CHUNKS][2], ev_join, ev_last_match; int have_last_match; u32 last_chunks;
     hipEvent_t ev_pre[KMP_MAX_CHUNKS + 1];      // decoder: [0] where the caller's stream stands, [1 + i] piece i pre-decoded
     // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
-    u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta; u32* dfl_wr;      // two halves of dfl_chunk slices each
+    u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta; u32* dfl_wr; u32* dfl_order;      // two halves of dfl_chunk slices each
     u32* dfl_fsyms; KdSliceMeta* dfl_fmeta; KdBlockInfo* dfl_fblocks; int dfl_ftried;          // levels 1 .. 3: symbols / blocks of 4 * dfl_chunk slices (one piece)
     u32 dfl_pos_cap, dfl_blk_cap; KdBlockInfo* dfl_blocks;                                      // positions / blocks per slice in them
     hipEvent_t dfl_searched[2], dfl_done[2]; int dfl_events;
@@ -108,6 +108,8 @@ u32 env_pre_min_batch();
 void ensure_pre_staging(kmp_batch_ctx* c);
 // lane slots of the lane-per-entry kernels in order of size: key / rank / permutation (the zstd pre-decoders' counting sort;
 // len_shift = 0: keyed by the frames' sequence counts, else by entry bytes >> len_shift)
+// ... with the keys (0 .. 255) and their histogram already there: bucket starts + permutation, largest keys first
+int size_sort_keys(kmp_batch_ctx* c, hipStream_t st, u32 m, u32* key, u32* hist, u32* perm);
 int size_sort(kmp_batch_ctx* c, hipStream_t st, const u8* src, const u64* in_off, const u32* in_len, u32 m, u32* key, u32* hist, u32* perm, u32 len_shift);
 // a level-3 batch in pieces, each on a stream of its own (kmp_zstd_compress_batch_pieces = begin + every piece + end)
 int pieces_begin(kmp_batch_ctx* c, u32 pieces, void* const* hip_streams);
