@@ -388,7 +388,8 @@ def extra_legs(b, torch, np, src, in_off, in_len, dst, out_off, out_len, host, n
         ok = ok and _z.decompress(f, -15) == host[i * S:(i + 1) * S].tobytes()
     piece = min(n, 16384)
     algo_piece = (in_bytes + int(dlens.sum()) + 16 * n) * piece // n
-    ms_best = float(kms.get("k_deflate_best", 0.0)) or 1.0
+    ms_lazy = float(kms.get("parse", 0.0)) or 1.0
+    kms = {"k_deflate_sort (+ heaviest-first order)": kms["prepare"], "k_deflate_lazy": kms["parse"], "k_deflate_encode": kms["encode"]}
     cpu = None
     if not no_cpu:
         ns = min(n, 8192)
@@ -399,11 +400,12 @@ def extra_legs(b, torch, np, src, in_off, in_len, dst, out_off, out_len, host, n
                        "value": round(in_bytes / dt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
                        "ratio": round(in_bytes / float(dlens.sum()), 4), "zlib_inflate_spot_check_ok": ok,
                        "kernels_ms_first_piece": {k: round(v, 3) for k, v in kms.items()},
-                       "roofline": {"bound": "hbm", "kernel": "k_deflate_best (LDS- and issue-bound chain walk over every position; HBM is not what limits it), one launch per piece of 16 384 slices",
-                                    "achieved": round(algo_piece / (ms_best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(algo_piece / (ms_best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                    "traffic": (pj.get("k_deflate_best_hbm_bytes_per_launch") if (pj and piece == 16384) else None),
-                                    "slices_per_launch": piece, "avg_launch_ms": round(ms_best, 3)},
+                       "roofline": {"bound": "hbm", "kernel": "k_deflate_lazy (a wave per slice walks zlib's lazy parse; bound by scalar issue and LDS round trips, not by HBM: DESIGN.md section 4.4), "
+                                                              "one launch per piece of 16 384 slices, timed for the first piece while the next piece's k_deflate_sort runs beside it",
+                                    "achieved": round(algo_piece / (ms_lazy * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(algo_piece / (ms_lazy * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                    "traffic": (pj.get("k_deflate_lazy_hbm_bytes_per_launch") if (pj and piece == 16384) else None),
+                                    "slices_per_launch": piece, "avg_launch_ms": round(ms_lazy, 3)},
                        "cpu_baseline": cpu}
     # ---- inflate of those streams ------------------------------------------------------------------------------------------
     dt, ms_ev, r = timed(lambda: b.inflate(d_dst, out_off, d_len, cap, dst=back, out_off=in_off))
@@ -671,25 +673,27 @@ def main():
             with ThreadPoolExecutor(cpu_cores) as ex:
                 list(ex.map(_zrun, range(cpu_cores)))
         cpu = sample * SLICE / max(time.perf_counter() - t1, 1e-9) / 1e9 if not args.no_cpu else 0.0
-        # dominant kernel: k_deflate_best, one launch per piece of <= 16384 slices; algorithmic bytes per slice as in SURVEY 8d
+        # dominant kernel: k_deflate_lazy, one launch per piece of <= 16384 slices; algorithmic bytes per slice as in SURVEY 8d
         piece = min(n, 16384)
         algo_piece = (n * SLICE + int(lens.sum()) + 16 * n) * piece // n
         traffic_best = None
         try:
-            traffic_best = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("k_deflate_best_hbm_bytes_per_launch") if piece == 16384 else None
+            traffic_best = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("k_deflate_lazy_hbm_bytes_per_launch") if piece == 16384 else None
         except Exception:
             traffic_best = None
-        ms_best = float(kms.get("k_deflate_best", 0.0)) or 1.0
-        dfl_roofline = {"bound": "hbm", "kernel": "k_deflate_best (LDS- and issue-bound chain walk; HBM is not what limits it)",
+        ms_best = float(kms.get("parse", 0.0)) or 1.0
+        dfl_roofline = {"bound": "hbm", "kernel": "k_deflate_lazy (a wave per slice walks zlib's lazy parse; scalar-issue and LDS bound, HBM is not what limits it), first piece, beside the next piece's k_deflate_sort",
                         "achieved": round(algo_piece / (ms_best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(algo_piece / (ms_best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic_best,
                         "slices_per_launch": piece, "avg_launch_ms": round(ms_best, 3)}
+        if dlevel > 3:
+            kms = {"k_deflate_sort (+ heaviest-first order)": kms["prepare"], "k_deflate_lazy": kms["parse"], "k_deflate_encode": kms["encode"]}
         if dlevel <= 3:
             # levels 1 .. 3: one k_deflate_fast launch over the whole batch (its time is reported in the parse slot of the events)
             piece = n if n <= 65536 else 65536
             algo_piece = (n * SLICE + int(lens.sum()) + 16 * n) * piece // n
-            ms_fast = float(kms.get("k_deflate_parse", 0.0)) or 1.0
-            kms = {"k_deflate_fast (with the clearing of its head tables)": ms_fast, "k_deflate_encode": float(kms.get("k_deflate_encode", 0.0))}
+            ms_fast = float(kms.get("parse", 0.0)) or 1.0
+            kms = {"k_deflate_fast (with the clearing of its head tables)": ms_fast, "k_deflate_encode": float(kms.get("encode", 0.0))}
             dfl_roofline = {"bound": "hbm", "kernel": "k_deflate_fast (a lane per slice; chains of dependent HBM reads, DESIGN.md section 4.4)",
                             "achieved": round(algo_piece / (ms_fast * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(algo_piece / (ms_fast * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

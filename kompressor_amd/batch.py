@@ -308,7 +308,12 @@ class ZstdBatch:
         ms = (ctypes.c_float * 4)()
         if self.lib.kmp_deflate_last_kernel_ms(self._h, ms) != 0:
             raise RuntimeError(self._err())
-        return dict(zip(("k_deflate_chains", "k_deflate_best", "k_deflate_parse", "k_deflate_encode"), (float(x) for x in ms)))
+        # the four stages of the first workspace piece; which kernels they are depends on the level and the slice size:
+        #   prepare: k_deflate_sort + the heaviest-first order (slices <= 64 KiB, levels >= 4) | k_deflate_chains (longer slices)
+        #   search : nothing                                                                  | k_deflate_best
+        #   parse  : k_deflate_lazy                                                           | k_deflate_parse;  levels 1 .. 3: k_deflate_fast
+        #   encode : k_deflate_encode
+        return dict(zip(("prepare", "search", "parse", "encode"), (float(x) for x in ms)))
 
     def compact_into(self, src, in_off, lens, dst, offs):
         """Dense packing into caller-owned buffers, no host round trip: frame i goes to dst[offs[i] : offs[i] + lens[i]],

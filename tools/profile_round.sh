@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round profile on the GPU box: rocprofv3 kernel stats for each bench mode + separate PMC passes for the compress step.
 # Usage (through gpurun): bash tools/profile_round.sh [name]   -> gpurun_out/prof/, summary gpurun_out/prof_summary/<name>.txt
-NAME=${1:-r03_final}
+NAME=${1:-r04_final}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 run() { name=$1; shift; echo "== $name: $*" >> $O/log.txt; timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/$name -o run -- python3 $R/bench.py "$@" > $O/$name.out 2>> $O/log.txt; tail -1 $O/$name.out > $O/$name.json; }
-run compress --steps 5 --warmup 1 --no-stream &&
+run compress --steps 5 --warmup 1 --no-stream --no-extra &&
 run config3 --config 3 --steps 3 --warmup 1 --no-cpu --no-stream &&
 run decompress --mode decompress --steps 3 --warmup 1 --no-cpu &&
 run deflate --mode deflate --steps 1 --warmup 0 &&
@@ -20,7 +20,7 @@ for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY 
   d=$O/pmc_$(echo $ctr | tr ' ' '_' | cut -c1-40)
   echo "== pmc $ctr" >> $O/log.txt
   # (every launch of such a pass is one full batch: no PCIe pass, no streaming figures, no trial of launch settings)
-  timeout -k 10 300 rocprofv3 --pmc $ctr -d $d -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-pcie --no-stream > $d.out 2>> $O/log.txt || echo "pmc pass $ctr failed" >> $O/log.txt
+  timeout -k 10 300 rocprofv3 --pmc $ctr -d $d -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-pcie --no-stream --no-extra > $d.out 2>> $O/log.txt || echo "pmc pass $ctr failed" >> $O/log.txt
 done
 # HBM bytes of the decoder and of the DEFLATE kernels (same counters, their own runs)
 for mode in decompress deflate inflate; do
@@ -40,7 +40,7 @@ done
 # ... and of the other parsers: levels 1 / 2 ("fast"), the dictionary parser, the block-chain kernel (frames of several blocks)
 pmc3() { tag=$1; shift; for ctr in FETCH_SIZE WRITE_SIZE; do
     d=$O/pmc3_${tag}_$ctr; echo "== pmc $tag $ctr" >> $O/log.txt
-    timeout -k 10 300 rocprofv3 --pmc $ctr -d $d -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-stream "$@" > $d.out 2>> $O/log.txt || echo "pmc pass $tag $ctr failed" >> $O/log.txt
+    timeout -k 10 300 rocprofv3 --pmc $ctr -d $d -o run -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu --no-stream --no-extra "$@" > $d.out 2>> $O/log.txt || echo "pmc pass $tag $ctr failed" >> $O/log.txt
   done; }
 pmc3 level1 --level 1
 pmc3 dict16 --dict-kib 16

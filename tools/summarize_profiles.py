@@ -100,7 +100,7 @@ def main():
               "zstd_match_write_requests_per_launch": int(allc.get((k, "TCC_EA0_WRREQ_sum"), (0, 1))[0] / nl),
               "note": "(FETCH_SIZE+WRITE_SIZE)*1024 / launches; the guide's x2 correction for wide coalesced reads is not applied: "
                       "this kernel's reads are scattered 4- and 8-byte probes (TCC_EA0_RDREQ_32B = 0, RDREQ*64 = FETCH_SIZE)"}
-        for kern in ("k_zstd_decode", "k_zstd_seq_predecode", "k_zstd_lit_predecode", "k_deflate_chains", "k_deflate_best", "k_deflate_parse", "k_deflate_encode", "k_inflate", "k_inflate_predecode", "k_inflate_exec"):
+        for kern in ("k_zstd_decode", "k_zstd_seq_predecode", "k_zstd_lit_predecode", "k_deflate_sort", "k_deflate_lazy", "k_deflate_chains", "k_deflate_best", "k_deflate_parse", "k_deflate_encode", "k_inflate", "k_inflate_predecode", "k_inflate_exec"):
             if (kern, "FETCH_SIZE") in other and (kern, "WRITE_SIZE") in other:
                 f, nl2 = other[(kern, "FETCH_SIZE")]
                 w, _ = other[(kern, "WRITE_SIZE")]
