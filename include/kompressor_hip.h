@@ -67,7 +67,8 @@ KMP_API size_t kmp_zstd_cctx_load_dictionary(kmp_zstd_cctx* cctx, const void* di
  * the caller's memory is compressed in place (ZSTD_compress2's frame); otherwise -- the reference's driver, whose output
  * slices hold max(8192, n / 10) bytes -- the input is staged in chunks of 128 KiB (kmp_zstd_compress_batch_reference),
  * and data that arrived with e_continue makes it a streaming frame (no content size).  Input is collected until e_end;
- * streams up to 1 GiB (levels 1 and 2: their windows, 512 KiB and 1 MiB). */
+ * streams up to 1 GiB at every served level (beyond a level's window -- 512 KiB at level 1 and the negative levels, 1 MiB
+ * at level 2, 2 MiB at levels 3 and 4 -- the window slides as libzstd's does). */
 KMP_API size_t kmp_zstd_compress_stream(kmp_zstd_cctx* cctx,
                                         void* dst, size_t dst_size, size_t* dst_pos,
                                         const void* src, size_t src_size, size_t* src_pos,
@@ -213,9 +214,11 @@ KMP_API int kmp_zstd_compress_batch_stream(kmp_batch_ctx* ctx,
                                            uint32_t n,
                                            void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                            int empty_end, void* hip_stream);
-/* ... at level 3 (or 0: the call above) or level 1 -- the reference's Ktor ZstdContentEncoder streams at level 1
- * (kompressor-zstd-ktor ZstdContentEncoder.kt:11): window 2^19, so streams <= 512 KiB and a context created with
- * max_slice_bytes in (128 KiB, 512 KiB]. */
+/* ... at level 3 (or 0: the call above), 4, 2, 1 or a negative level -- the reference's Ktor ZstdContentEncoder streams at
+ * level 1 (kompressor-zstd-ktor ZstdContentEncoder.kt:11).  Levels 1 and below have a window of 2^19, level 2 of 2^20:
+ * a longer stream is parsed as libzstd parses it once its staging buffer (window + 128 KiB) has wrapped -- blocks that
+ * still reach into the lap before by its extDict variant of the "fast" parser (ZSTD_compressBlock_fast_extDict_generic),
+ * restated in zstd_match_fast.h.  Any length the context holds. */
 KMP_API int kmp_zstd_compress_batch_stream_level(kmp_batch_ctx* ctx,
                                                  const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                                  uint32_t n,
@@ -226,18 +229,19 @@ KMP_API int kmp_zstd_compress_batch_stream_level(kmp_batch_ctx* ctx,
  * bytes: from 128 KiB + 1 on that is less than ZSTD_compressBound(n), so libzstd does not compress the array in place
  * but stages it in chunks of 128 KiB -- the block pre-splitter sees one chunk at a time, and beyond the window + 128 KiB
  * the staging buffer wraps and the window slides.  Frames differ from kmp_zstd_compress_batch's
- * wherever the pre-splitter cuts; up to 128 KiB they are the same.  level 3 (or 0), or 1 with a context created for
- * slices <= 512 KiB.  out_chunk: size of the caller's output slices if it is not the reference's (0 = max(8192, n / 10)). */
+ * wherever the pre-splitter cuts; up to 128 KiB they are the same.  Levels -131072 .. -1 and 1 .. 4 (0 = 3), any size the
+ * context holds.  out_chunk: size of the caller's output slices if it is not the reference's (0 = max(8192, n / 10)). */
 KMP_API int kmp_zstd_compress_batch_reference(kmp_batch_ctx* ctx,
                                               const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                               uint32_t n,
                                               void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                               int level, uint32_t out_chunk, void* hip_stream);
-/* One-shot frames at another compression level: 1 and 2 (libzstd's one-table "fast" strategy) for slices <= 128 KiB;
- * level 1 also as frames of several blocks for slices <= 512 KiB (context created with max_slice_bytes in
- * (128 KiB, 512 KiB]); 3 (or 0) = kmp_zstd_compress_batch.  Frames are the ones libzstd 1.5.7 writes at that level.
+/* One-shot frames at another compression level: 1 and 2 (libzstd's one-table "fast" strategy) for slices of any size the
+ * context holds (one block up to 128 KiB, frames of several blocks above; the window follows the slice size as
+ * ZSTD_getCParams(level, n, 0) sets it, and a slice beyond the level's largest window is parsed with the window sliding);
+ * 3 (or 0) = kmp_zstd_compress_batch.  Frames are the ones libzstd 1.5.7 writes at that level.
  * Negative levels (-131072 .. -1: libzstd's "fast" strategy on row 0 of its parameter tables, a step of 1 - level, literals
- * left uncompressed) are served like level 1: one-block slices, and frames of several blocks / streams up to their 512 KiB window.
+ * left uncompressed) are served like level 1.
  * Level 4 is served where libzstd runs it as "double-fast": slices above 16 KiB up to 128 KiB (window <= 17, chain 17, hash 17,
  * minimum match 4; ZSTD_getCParams(4, n, 0)), slices above 256 KiB (window <= 21, chain 18, hash 18, minimum match 5: contexts created
  * for slices above 128 KiB, per-slice tables of 2 MiB allocated by the first such batch) and streams of any size (kmp_zstd_compress_batch_stream_level).  Its tables (1 MiB per team: 64 GiB beside a 65 536-slice context, less when the device has less room; KMP_L4_TEAMS caps it) are allocated by

@@ -6,7 +6,6 @@ O=$R/gpurun_out/bench_lines.txt
 run() { echo "## python bench.py $*" >> $O; timeout -k 10 400 python $R/bench.py "$@" 2>/dev/null | tail -n 1 >> $O; echo >> $O; }
 run --steps 5 --warmup 2
 run --config 3 --steps 3 --warmup 1 --no-cpu --no-stream
-KMP_MATCH_V2=2 run --steps 5 --warmup 2 --no-cpu --no-pcie --no-stream
 run --mode decompress --steps 5 --warmup 2 --no-cpu
 run --mode deflate --steps 2 --warmup 1
 run --mode inflate --steps 3 --warmup 1 --no-cpu
@@ -27,7 +26,9 @@ run --slice-kib 256 --slices 32768 --level 2 --steps 2 --warmup 1 --no-cpu
 run --slice-kib 1024 --slices 8192 --level 2 --steps 2 --warmup 1 --no-cpu
 run --slice-kib 1024 --slices 8192 --level 4 --steps 2 --warmup 1 --no-cpu --no-stream
 run --slice-kib 512 --slices 16384 --level -1 --steps 2 --warmup 1 --no-cpu --no-stream
+run --slice-kib 1024 --slices 8192 --level 1 --steps 2 --warmup 1 --no-cpu --no-stream
 run --mode deflate --deflate-level 4 --steps 2 --warmup 1 --no-cpu
 run --mode deflate --deflate-level 1 --steps 2 --warmup 1 --no-cpu
+run --mode deflate --deflate-level 9 --steps 1 --warmup 1 --no-cpu
 run --mode decompress --slice-kib 256 --slices 16384 --steps 3 --warmup 1 --no-cpu
 echo done
