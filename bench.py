@@ -520,6 +520,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:          # KMP_BENCH_FORCE_DIST without a launcher: a process group of one
+            os.environ.setdefault("MASTER_PORT", "29531"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
         if os.environ.get("KMP_BENCH_REHEARSAL"):
             # rehearsal of the N > 1 control flow on a box with ONE GPU: every rank on cuda:0, gloo instead of RCCL
             # (RCCL refuses two ranks on one device).  Never a measurement.

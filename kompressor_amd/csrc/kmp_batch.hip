@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_zstd_frame_init(const u32* in_len, u32 
 }
 __global__ __launch_bounds__(64, 5) void k_zstd_decode(KDecodeArgs a) { zstd_decode_body(a); }
 // the sequence bitstreams decoded ahead of it, one lane per frame (FSE tables in HBM)
-__global__ __launch_bounds__(64) void k_zstd_seq_predecode(KPreArgs a) { zstd_seq_predecode_body(a); }
+__global__ __launch_bounds__(4 * KXP_FRAMES) void k_zstd_seq_predecode(KPreArgs a) { zstd_seq_predecode_body(a); }
 // ... and the Huffman-coded literals, one lane per stream (32 frames per workgroup of 128 threads)
 __global__ __launch_bounds__(64) void k_zstd_lit_predecode(KLitArgs a) { zstd_lit_predecode_body(a); }
 __global__ __launch_bounds__(256) void k_zstd_seq_count(KSeqSortArgs a) { zstd_seq_count_body(a); }
@@ -1315,7 +1315,7 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
                 p.perm = sorted ? sort_perm : nullptr;
                 p.src = d.src; p.in_off = q.in_off; p.in_len = q.in_len; p.n_slices = m;
                 p.stage = c->pre_stage; p.seq_cap = c->pre_seq_cap; p.blk = c->pre_blk; p.blk_cap = c->pre_blk_cap; p.nblk = c->pre_nblk;
-                hipLaunchKernelGGL(k_zstd_seq_predecode, dim3((m + KXP_FRAMES - 1) / KXP_FRAMES), dim3(64), 0, c->st2, p);
+                hipLaunchKernelGGL(k_zstd_seq_predecode, dim3((m + KXP_FRAMES - 1) / KXP_FRAMES), dim3(4 * KXP_FRAMES), 0, c->st2, p);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(c->ev_pre[1], c->st2));
                 q.pre_stage = c->pre_stage; q.pre_seq_cap = c->pre_seq_cap; q.pre_blk = c->pre_blk; q.pre_nblk = c->pre_nblk;

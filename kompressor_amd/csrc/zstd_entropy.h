@@ -33,6 +33,7 @@ struct KEntropyArgs {
 #define KXE_ERR 0xFFFFFFFFu
 
 struct KHNode { u32 count; u16 parent; u8 byte; u8 nbBits; };
+struct alignas(8) KSeqDelta { u32 nb; int fs; };
 
 // ---- LDS of one entropy wave ------------------------------------------
 struct KEntropyLds {
@@ -55,8 +56,8 @@ struct KEntropyLds {
             u32 stage[64];       // codes of 64 staged sequences: ll | of << 8 | ml << 16
             u16 sbits[3][64];    // per staged sequence and stream: the chain's state before the sequence
             u32 cbuf[192];       // bit assembly buffer of one 64-sequence chunk
-            u32 pnb[3][65];      // per staged sequence and stream: deltaNbBits / deltaFindState of its code, looked up by
-            int pfs[3][65];      //   (times two: a byte offset) of its code, looked up by all lanes at once so that the state chains only wait for the state table
+            KSeqDelta pp[3][65]; // per staged sequence and stream: deltaNbBits / deltaFindState (times two: a byte offset) of its code, looked up by
+                                 //   all lanes at once so that the state chains only wait for the state table; one 8-byte read a step
         } seq;
     } u;
     short norm[3][64];
@@ -874,9 +875,9 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
             q = seqs[idx]; c = kx_seq_codes(q, idx, longType, longPos);
             lds.u.seq.stage[lane] = c.ll | (c.of << 8) | (c.ml << 16);
             dLL = lds.u.seq.dnb[0][c.ll]; dOF = lds.u.seq.dnb[1][c.of]; dML = lds.u.seq.dnb[2][c.ml];
-            lds.u.seq.pnb[0][lane] = dLL; lds.u.seq.pfs[0][lane] = 2 * lds.u.seq.dfs[0][c.ll];      // (byte offsets into the state table)
-            lds.u.seq.pnb[1][lane] = dOF; lds.u.seq.pfs[1][lane] = 2 * lds.u.seq.dfs[1][c.of];
-            lds.u.seq.pnb[2][lane] = dML; lds.u.seq.pfs[2][lane] = 2 * lds.u.seq.dfs[2][c.ml];
+            KSeqDelta d0, d1, d2;                                                                    // (fs: byte offsets into the state table)
+            d0.nb = dLL; d0.fs = 2 * lds.u.seq.dfs[0][c.ll]; d1.nb = dOF; d1.fs = 2 * lds.u.seq.dfs[1][c.of]; d2.nb = dML; d2.fs = 2 * lds.u.seq.dfs[2][c.ml];
+            lds.u.seq.pp[0][lane] = d0; lds.u.seq.pp[1][lane] = d1; lds.u.seq.pp[2][lane] = d2;
         }
         kx_sync();
         // The chains are what the kernel's time goes into once everything else is wave-parallel (three lanes, one LDS read
@@ -886,14 +887,17 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
         if (lane < 3) {
             const u8* const stb = (const u8*)ct.state;
             if (!first && cnt == 64u) {
-                u32 dn = lds.u.seq.pnb[lane][0]; int df = lds.u.seq.pfs[lane][0];
+                // (LDS instructions with three live lanes hold the pipe like full ones, and with every wave of the CU in its chains the
+                // pipe is what they queue for: one 8-byte read for the next step's deltas, the states stored two at a time)
+                KSeqDelta d = lds.u.seq.pp[lane][0];
+                u32 even = 0;
 #pragma unroll
                 for (u32 s = 0; s < 64u; s++) {
-                    u32 const dn1 = lds.u.seq.pnb[lane][s + 1]; int const df1 = lds.u.seq.pfs[lane][s + 1];
-                    lds.u.seq.sbits[lane][s] = (u16)state;
-                    u32 const nb = (state + dn) >> 16;
-                    state = *(const u16*)(stb + df + (int)((state >> nb) << 1));
-                    dn = dn1; df = df1;
+                    KSeqDelta const d1 = lds.u.seq.pp[lane][s + 1];
+                    if (s & 1u) *(u32*)&lds.u.seq.sbits[lane][s - 1] = even | (state << 16); else even = state;
+                    u32 const nb = (state + d.nb) >> 16;
+                    state = *(const u16*)(stb + d.fs + (int)((state >> nb) << 1));
+                    d = d1;
                 }
             } else {
                 u32 s = 0;
@@ -901,13 +905,13 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
                     state = kfse_init_state(ct, (lds.u.seq.stage[0] >> (8u * (u32)lane)) & 0xFFu);
                     lds.u.seq.sbits[lane][0] = 0; s = 1;
                 }
-                u32 dn = lds.u.seq.pnb[lane][s]; int df = lds.u.seq.pfs[lane][s];
+                KSeqDelta d = lds.u.seq.pp[lane][s];
                 for (; s < cnt; s++) {
-                    u32 const dn1 = lds.u.seq.pnb[lane][s + 1]; int const df1 = lds.u.seq.pfs[lane][s + 1];
+                    KSeqDelta const d1 = lds.u.seq.pp[lane][s + 1];
                     lds.u.seq.sbits[lane][s] = (u16)state;
-                    u32 const nb = (state + dn) >> 16;
-                    state = *(const u16*)(stb + df + (int)((state >> nb) << 1));
-                    dn = dn1; df = df1;
+                    u32 const nb = (state + d.nb) >> 16;
+                    state = *(const u16*)(stb + d.fs + (int)((state >> nb) << 1));
+                    d = d1;
                 }
             }
         }

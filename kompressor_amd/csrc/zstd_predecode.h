@@ -34,7 +34,9 @@ struct KPreArgs {
 // rank (10 bits; FSE_buildDTable's symbolNext), and the symbol (6 bits): nbBits = tableLog - highbit(next) and
 // newStateBase = (next << nbBits) - tableSize follow from it -- LL [0,512) ML [512,1024) OF [1024,1280), then the
 // normalised counts and the per-symbol cursor of the table under construction.
+#ifndef KXP_FRAMES
 #define KXP_FRAMES 16
+#endif
 // ... and the two queues that keep HBM out of the sequence loop (see zstd_seq_predecode_body): 64 words of the
 // bitstream, eight finished sequences.
 #define KXP_RING 64
@@ -184,10 +186,11 @@ KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
     KX_SHARED KPreLds lds;
     {
         int const lane = kx_lane();
-        if (lane < 36) lds.llx[lane] = kx_ll_base((u32)lane) | (kxd_ll_bits((u32)lane) << 24);
-        if (lane < 53) lds.mlx[lane] = kx_ml_base((u32)lane) | (kxd_ml_bits((u32)lane) << 24);
+        for (int i = lane; i < 36; i += 4 * KXP_FRAMES) lds.llx[i] = kx_ll_base((u32)i) | (kxd_ll_bits((u32)i) << 24);
+        for (int i = lane; i < 53; i += 4 * KXP_FRAMES) lds.mlx[i] = kx_ml_base((u32)i) | (kxd_ml_bits((u32)i) << 24);
     }
     kx_sync();
+    if ((kx_lane() >> 2) >= KXP_FRAMES) return;          // (a launch wider than 4 lanes a frame: the emulator's 64)
     // Four lanes per frame.  All four walk the frame's blocks (same loads, same decisions); lane 0 of the quad builds the
     // tables and writes the records; in the sequence loop lane 0 is the offset's tANS chain, lane 1 the match length's,
     // lane 2 the literal length's (lane 3 shadows lane 2): a table look-up, an extra-bits field and a state update each,
