@@ -129,7 +129,7 @@ for dsize in (16384, 65536):
     bdic.close()
     print(f"level 3 with a raw-content dictionary of {dsize} bytes: {len(dict_idx)} frames against libzstd 1.5.7, different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:8]]}  ({time.time() - t0:.0f} s)", flush=True)
 
-# raw DEFLATE (zlib's levels 1, 6 and 9) against this machine's zlib, and inflate of what came out
+# raw DEFLATE (all nine levels over two seeds) against this machine's zlib, and inflate of what came out
 import zlib
 dfl_idx = np.arange(0, N, 3)                                     # a third of the slices (the level-9 search is slow on both sides)
 def zlib_frames(level, idx):
@@ -148,7 +148,7 @@ def zlib_frames(level, idx):
 for k in ("KMP_MATCH_V2", "KMP_FUSE"): os.environ.pop(k, None)
 bd = ZstdBatch(max_slices=len(dfl_idx), max_slice_bytes=131072)
 sel = torch.from_numpy(dfl_idx.astype(np.int64)).cuda()
-for level in (1, 6, 9):
+for level in ((1, 6, 9) if seed % 2 else (2, 3, 4, 5, 7, 8)):      # (odd seeds: the fast, default and slowest rows; even seeds: the others)
     t0 = time.time()
     dst, ooff, olen = bd.deflate(src, d_off[sel], d_len[sel], level=level, check=True)
     torch.cuda.synchronize()
