@@ -190,6 +190,10 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
         // what it started with): the parse passes it without a search, and a RUN of such positions -- incompressible data is nothing
         // else -- in one step that emits their literals 64 lanes wide.
         int wbase = -(1 << 20); u32 wrv = 0; u64 maybe = 0;
+        // The candidates of a search are one memory round trip that the eight waves of a SIMD only half hide (counters: waves wait for memory
+        // in half of their cycles).  A search at p that has no match behind it is followed by a step at p + 1 whatever it finds, and that
+        // step usually searches too (the lazy parse's second look): its candidates are asked for together with p's and wait in registers.
+        int pf_pos = -1, pf_c = 0; KdlBytes pf_cb; pf_cb.lo = 0; pf_cb.hi = 0; u64 pf_s0 = 0, pf_s1 = 0;
 #define KDL_FLUSH() { KdBlockInfo b_; \
         b_.nsym_end = nsym; b_.end_pos = (u32)strstart; b_.start_pos = (u32)block_start; b_.stored_ok = (block_start - base >= 0) ? 1u : 0u; \
         if (lane == 0 && mm.nblocks < a.blk_cap) blocks[mm.nblocks] = b_; \
@@ -203,6 +207,7 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
         nsym++; blockSyms++; \
         if ((nsym & 63u) == 0) syms[nsym - 64u + (u32)lane] = symq; }
         for (;;) {
+            if (lane == 0) KX_STAT(40, 1);                          // steps of the parse
             if (dataEnd - strstart < KD_MIN_LOOKAHEAD) {
                 // fill_window: one pass is enough (it brings at least 65 536 - strstart bytes, or all that is left)
                 int const rel = strstart - base;
@@ -215,6 +220,7 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
             int const lookahead = n - strstart;
             bool const search_here = lookahead >= KD_MIN_MATCH && match_length < (int)a.lazy;       // (match_length: what becomes prev_length below)
             if (search_here && (strstart < wbase || strstart >= wbase + 64)) {
+                if (lane == 0) KX_STAT(41, 1);                      // window loads
                 wbase = strstart; wrv = (strstart + lane < nIns) ? wr[strstart + lane] : 0u;
                 u32 const wh = wrv & 0xFFFFu, rk_ = wrv >> 16;
                 // the position's own entry and its nearest candidates are neighbours in the sorted array (three loads, no branch between them)
@@ -237,6 +243,7 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
                 int const Lmax = room_q < room_b ? room_q : room_b;
                 if (L > Lmax) { K -= L - Lmax; L = Lmax; }
                 if (K >= 2 && L >= 1) {
+                    if (lane == 0) { KX_STAT(42, 1); KX_STAT(43, K); }   // run steps, positions they pass
                     int const i = lane - (int)(nsym & 63u);
                     if (i >= 0 && i < L) symq = (u32)src[first_lit + i] << 16;
                     nsym += (u32)L; blockSyms += (u32)L;
@@ -259,13 +266,35 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
                 int const nice = lookahead < niceMax ? lookahead : niceMax;
                 int bestLen = prev_length, bestPos = -1;
                 // the string at the position: every lane reads the same sixteen bytes (one request), beside the candidates' loads
-                u64 const scan0 = kdl_get64<TINY>(src, strstart, n), scan1 = kdl_get64<TINY>(src, strstart + 8, n);
+                u64 scan0, scan1; int c0 = 0; KdlBytes cb0; cb0.lo = 0; cb0.hi = 0;
+                if (lane == 0) { KX_STAT(44, 1); KX_STAT(45, pf_pos == strstart ? 1 : 0); KX_STAT(46, prev_length >= KD_MIN_MATCH ? 1 : 0); KX_STAT(47, (ncand + 63) / 64); }   // searches, served from the step before, second looks, candidate blocks
+                if (pf_pos == strstart) { scan0 = pf_s0; scan1 = pf_s1; c0 = pf_c; cb0 = pf_cb; }     // asked for a step ago
+                else {
+                    scan0 = kdl_get64<TINY>(src, strstart, n); scan1 = kdl_get64<TINY>(src, strstart + 8, n);
+                    if (lane < ncand) { c0 = (int)srt[where - 1 - lane]; cb0 = sb[where - 1 - lane]; }
+                }
+                pf_pos = -1;
+                if (prev_length < KD_MIN_MATCH && off + 1 < 64 && ((maybe >> (off + 1)) & 1ull)) {
+                    // (the next step's chain may be quartered by what this search finds: the loads take the full first block, the step masks it)
+                    u32 const w1 = kx_bcast(wrv, off + 1);
+                    int const where1 = (int)(w1 & 0xFFFFu), rk1 = (int)(w1 >> 16);
+                    int const n1 = rk1 < maxChain ? rk1 : maxChain;
+                    pf_c = 0; pf_cb.lo = 0; pf_cb.hi = 0;
+                    if (lane < n1) { pf_c = (int)srt[where1 - 1 - lane]; pf_cb = sb[where1 - 1 - lane]; }
+                    pf_s0 = kdl_get64<TINY>(src, strstart + 1, n); pf_s1 = kdl_get64<TINY>(src, strstart + 9, n);
+                    pf_pos = strstart + 1;
+                    if (lane == 0) KX_STAT(49, 1);                      // searches asked for ahead
+                }
                 for (int cb = 0; cb < ncand; cb += 64) {
                     int const j = cb + lane;
                     bool valid = j < ncand;
-                    int const c = valid ? (int)srt[where - 1 - j] : 0;
+                    int c = valid ? c0 : 0;
                     KdlBytes cbytes; cbytes.lo = 0; cbytes.hi = 0;
-                    if (valid) cbytes = sb[where - 1 - j];                   // (the candidates' first bytes lie next to each other, like their positions)
+                    if (valid) cbytes = cb0;
+                    if (cb > 0) {
+                        c = valid ? (int)srt[where - 1 - j] : 0;
+                        if (valid) cbytes = sb[where - 1 - j];               // (the candidates' first bytes lie next to each other, like their positions)
+                    }
                     // position 0 is zlib's NIL; beyond MAX_DIST the chain ends (and with it every later candidate: they lie further back).
                     // The head of the chain may lie exactly MAX_DIST back (deflate_slow's test), the others must be nearer (longest_match's limit).
                     bool const inWin = valid && c != 0 && (j == 0 ? strstart - c <= KD_MAX_DIST : strstart - c < KD_MAX_DIST);
@@ -279,6 +308,7 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
                     // the lanes whose first sixteen bytes agree go on, sixteen bytes at a time
                     bool more = valid && len == 16 && len < maxlen;
                     for (int done16 = 16; kx_any(more); done16 += 16) {
+                        if (lane == 0) KX_STAT(48, 1);                  // extension rounds
                         if (more) {
                             int const q = c + done16, r = strstart + done16;
                             u64 const d0 = kdl_get64<TINY>(src, q, n) ^ kdl_get64<TINY>(src, r, n);
