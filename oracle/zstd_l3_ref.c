@@ -834,11 +834,13 @@ static size_t huf_compress(u8* dst, size_t dstSize, const u8* src, size_t srcSiz
 {
     u32 count[256]; u32 maxSymbolValue = 255; u32 huffLog = LIT_HUF_LOG; huf_ctable ct;
     u8* op = dst; u8* const oend = dst + dstSize; size_t i;
-    int repeat = oldValid;          /* HUF_repeat_check */
+    int repeat = oldValid;          /* 0 HUF_repeat_none, 1 HUF_repeat_check (an earlier block's table), 2 HUF_repeat_valid (a dictionary's complete table) */
     *usedOld = 0;
     if (!srcSize) return 0;
     if (!dstSize) return 0;
     if (srcSize > 128 * 1024) return KERR;
+    /* "If old table is valid, use it for small inputs": before anything is counted */
+    if (preferRepeat && repeat == 2) { *usedOld = 1; return huf_encode_with(dst, op, oend, src, srcSize, singleStream, old); }
 
     if (suspectUncompressible && srcSize >= (4096 * 10)) {
         size_t largestTotal = 0; u32 c2[256]; u32 s, m;
@@ -858,7 +860,7 @@ static size_t huf_compress(u8* dst, size_t dstSize, const u8* src, size_t srcSiz
         if (largest <= (srcSize >> 7) + 4) return 0;
     }
     /* HUF_validateCTable: every symbol present must have a code in the old table */
-    if (repeat) { u32 s; for (s = 0; s <= maxSymbolValue; s++) if (count[s] != 0 && old->nbBits[s] == 0) { repeat = 0; break; } }
+    if (repeat == 1) { u32 s; for (s = 0; s <= maxSymbolValue; s++) if (count[s] != 0 && old->nbBits[s] == 0) { repeat = 0; break; } }
     /* small inputs: keep the old table */
     if (preferRepeat && repeat) { *usedOld = 1; return huf_encode_with(dst, op, oend, src, srcSize, singleStream, old); }
 
@@ -918,10 +920,10 @@ static size_t compress_literals(u8* dst, size_t cap, const u8* src, size_t srcSi
                                 const kref_hufstate* prev, kref_hufstate* next)
 {
     size_t const lhSize = 3 + (srcSize >= 1024) + (srcSize >= 16384);
-    int const singleStream = srcSize < 256;
+    int const singleStream = srcSize < 256 || (prev->valid == 2 && lhSize == 3);    /* (a valid table and a 3-byte header: one stream) */
     size_t cLitSize; int usedOld = 0; u32 hType = 2;
     *next = *prev;
-    if (srcSize < 64) return lit_raw(dst, cap, src, srcSize);   /* ZSTD_minLiteralsToCompress(dfast, repeat != valid) */
+    if (srcSize < (prev->valid == 2 ? 6u : 64u)) return lit_raw(dst, cap, src, srcSize);   /* ZSTD_minLiteralsToCompress(fast / dfast, repeatMode) */
     if (cap < lhSize + 1) return KERR;
     cLitSize = huf_compress(dst + lhSize, cap - lhSize, src, srcSize, singleStream, suspectUncompressible,
                             &next->ct, prev->valid, srcSize <= 1024 /* strategy < lazy */, &usedOld);
@@ -930,8 +932,11 @@ static size_t compress_literals(u8* dst, size_t cap, const u8* src, size_t srcSi
         size_t const minGain = min_gain(srcSize);
         if ((cLitSize == 0) || (cLitSize >= srcSize - minGain) || cLitSize == KERR) { *next = *prev; return lit_raw(dst, cap, src, srcSize); }
     }
-    if (cLitSize == 1) { *next = *prev; return lit_rle(dst, cap, src, srcSize); }   /* srcSize >= 64 >= 8 */
-    if (hType == 2) next->valid = 1;
+    if (cLitSize == 1) {      /* one symbol -- or, below 8 bytes, possibly a one-byte stream: then the bytes decide */
+        size_t k; int same = 1; for (k = 1; k < srcSize; k++) if (src[k] != src[0]) { same = 0; break; }
+        if (srcSize >= 8 || same) { *next = *prev; return lit_rle(dst, cap, src, srcSize); }
+    }
+    if (hType == 2) next->valid = 1;            /* a newly built table: HUF_repeat_check for the next block */
     switch (lhSize) {
     case 3: wr24(dst, (u32)(hType + ((u32)(!singleStream) << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 14))); break;
     case 4: wr32(dst, (u32)(hType + (2 << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 18))); break;
@@ -969,7 +974,17 @@ static u32 ml_code(u32 mlBase)
 
 enum { set_basic = 0, set_rle = 1, set_compressed = 2, set_repeat = 3 };
 
+/* The sequence tables a formatted dictionary brings (ZSTD_loadCEntropy): normalised counts, and whether libzstd may use the table
+ * without looking (FSE_repeat_valid: every symbol it could meet has a count) -- the only case the strategies below "lazy" reuse one. */
+typedef struct { short norm[3][64]; u32 maxSym[3], log[3]; int valid[3]; } kref_seqprior;       /* [0] LL, [1] OF, [2] ML */
+static __thread const kref_seqprior* g_seq_prior = NULL;
+
+static u32 select_encoding_prior(const u32* count, u32 max, size_t mostFrequent, size_t nbSeq, u32 defaultNormLog, int isDefaultAllowed, int strategy, int priorValid);
 static u32 select_encoding(const u32* count, u32 max, size_t mostFrequent, size_t nbSeq, u32 defaultNormLog, int isDefaultAllowed, int strategy)
+{
+    return select_encoding_prior(count, max, mostFrequent, nbSeq, defaultNormLog, isDefaultAllowed, strategy, 0);
+}
+static u32 select_encoding_prior(const u32* count, u32 max, size_t mostFrequent, size_t nbSeq, u32 defaultNormLog, int isDefaultAllowed, int strategy, int priorValid)
 {
     (void)count; (void)max;
     if (mostFrequent == nbSeq) {
@@ -979,6 +994,7 @@ static u32 select_encoding(const u32* count, u32 max, size_t mostFrequent, size_
     if (isDefaultAllowed) {   /* strategy fast(1) / dfast(2) < lazy */
         size_t const mult = 10 - (size_t)(strategy ? strategy : 2);
         size_t const dynamicFse_nbSeq_min = (((size_t)1 << defaultNormLog) * mult) >> 3;
+        if (priorValid && nbSeq < 1000) return set_repeat;          /* staticFse_nbSeq_max */
         if ((nbSeq < dynamicFse_nbSeq_min) || (mostFrequent < (nbSeq >> (defaultNormLog - 1)))) return set_basic;
     }
     return set_compressed;
@@ -989,6 +1005,8 @@ static size_t build_seq_ctable(u8* dst, size_t cap, fse_ctable* ct, u32 FSELog, 
                                const u8* codeTable, size_t nbSeq, const short* defaultNorm, u32 defaultNormLog, u32 defaultMax)
 {
     switch (type) {
+    case set_repeat:           /* (the caller has put the dictionary's table into ct) */
+        return 0;
     case set_rle:
         fse_build_ctable_rle(ct, (u8)max);
         if (cap == 0) return KERR;
@@ -1049,20 +1067,23 @@ static size_t compress_sequences(u8* dst, size_t cap, const seqstore* ss)
         u8* const seqHead = op++;
         u32 LLtype, Offtype, MLtype; size_t sz;
         { u32 max = 35; size_t const mf = hist_codes(count, &max, llCode, nbSeq);
-          LLtype = select_encoding(count, max, mf, nbSeq, 6, 1, ss->strategy);
+          LLtype = select_encoding_prior(count, max, mf, nbSeq, 6, 1, ss->strategy, g_seq_prior && g_seq_prior->valid[0]);
+          if (LLtype == set_repeat) fse_build_ctable(&ctLL, g_seq_prior->norm[0], g_seq_prior->maxSym[0], g_seq_prior->log[0]);
           sz = build_seq_ctable(op, (size_t)(oend - op), &ctLL, 9, LLtype, count, max, llCode, nbSeq, LL_defaultNorm, 6, 35);
           if (sz == KERR) { free(llCode); return KERR; }
           if (LLtype == set_compressed) lastCountSize = sz;
           op += sz; }
         { u32 max = 31; size_t const mf = hist_codes(count, &max, ofCode, nbSeq);
           int const defaultAllowed = (max <= 28);
-          Offtype = select_encoding(count, max, mf, nbSeq, 5, defaultAllowed, ss->strategy);
+          Offtype = select_encoding_prior(count, max, mf, nbSeq, 5, defaultAllowed, ss->strategy, g_seq_prior && g_seq_prior->valid[1]);
+          if (Offtype == set_repeat) fse_build_ctable(&ctOF, g_seq_prior->norm[1], g_seq_prior->maxSym[1], g_seq_prior->log[1]);
           sz = build_seq_ctable(op, (size_t)(oend - op), &ctOF, 8, Offtype, count, max, ofCode, nbSeq, OF_defaultNorm, 5, 28);
           if (sz == KERR) { free(llCode); return KERR; }
           if (Offtype == set_compressed) lastCountSize = sz;
           op += sz; }
         { u32 max = 52; size_t const mf = hist_codes(count, &max, mlCode, nbSeq);
-          MLtype = select_encoding(count, max, mf, nbSeq, 6, 1, ss->strategy);
+          MLtype = select_encoding_prior(count, max, mf, nbSeq, 6, 1, ss->strategy, g_seq_prior && g_seq_prior->valid[2]);
+          if (MLtype == set_repeat) fse_build_ctable(&ctML, g_seq_prior->norm[2], g_seq_prior->maxSym[2], g_seq_prior->log[2]);
           sz = build_seq_ctable(op, (size_t)(oend - op), &ctML, 9, MLtype, count, max, mlCode, nbSeq, ML_defaultNorm, 6, 52);
           if (sz == KERR) { free(llCode); return KERR; }
           if (MLtype == set_compressed) lastCountSize = sz;
@@ -1217,15 +1238,25 @@ KREF_API size_t kref_compress_bound(size_t srcSize)
     return srcSize + (srcSize >> 8) + ((srcSize < (128 << 10)) ? (((128 << 10) - srcSize) >> 11) : 0);
 }
 
-static size_t write_frame_header(u8* dst, size_t srcSize, u32 windowLog)
+static size_t write_frame_header_id(u8* dst, size_t srcSize, u32 windowLog, u32 dictID);
+static size_t write_frame_header(u8* dst, size_t srcSize, u32 windowLog) { return write_frame_header_id(dst, srcSize, windowLog, 0); }
+/* (ZSTD_writeFrameHeader: a formatted dictionary's ID follows the window descriptor in 1, 2 or 4 bytes) */
+static size_t write_frame_header_id(u8* dst, size_t srcSize, u32 windowLog, u32 dictID)
 {
     size_t pos = 0;
     u32 const windowSize = 1u << windowLog;
     u32 const singleSegment = (windowSize >= srcSize);
     u32 const fcsCode = (srcSize >= 256) + (srcSize >= 65536 + 256);
+    u32 const idCode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);
     wr32(dst, 0xFD2FB528u); pos = 4;
-    dst[pos++] = (u8)((singleSegment << 5) + (fcsCode << 6));
+    dst[pos++] = (u8)(idCode + (singleSegment << 5) + (fcsCode << 6));
     if (!singleSegment) dst[pos++] = (u8)((windowLog - 10) << 3);
+    switch (idCode) {
+    case 1: dst[pos++] = (u8)dictID; break;
+    case 2: wr16(dst + pos, dictID); pos += 2; break;
+    case 3: wr32(dst + pos, dictID); pos += 4; break;
+    default: break;
+    }
     switch (fcsCode) {
     case 0: if (singleSegment) dst[pos++] = (u8)srcSize; break;
     case 1: wr16(dst + pos, (u32)(srcSize - 256)); pos += 2; break;
@@ -1678,27 +1709,202 @@ static void fill_cdict_tables(u32* hashLarge, u32 hLog, u32* hashSmall, u32 cLog
 
 /* One-shot level-3 frame with a raw-content dictionary; srcSize <= 128 KiB, 8 <= dictSize <= 128 KiB.
  * modeOut (optional): 1 = CDict attached (dictMatchState parse), 0 = CDict tables copied (extDict parse). */
+/* ---- formatted dictionaries (magic EC30A437): ZSTD_loadCEntropy + the content behind it ----------------------------
+ * Layout: magic, dictID, a Huffman table description (as in a literals section), the offset / match-length / literal-length
+ * tables as FSE normalised counts, three repeat offsets, the content.  A CCtx that loads one starts its first block with
+ * these tables as "previous block" (so small inputs use them without describing tables of their own) and with these
+ * repeat offsets; matches are searched in the content as with a raw-content dictionary; the frame header names the ID. */
+typedef struct { const u8* p; size_t size; size_t bit; } fwdbits;
+static u32 fb_peek(const fwdbits* b, u32 n)
+{
+    u64 v = 0; size_t const byte = b->bit >> 3; u32 k;
+    for (k = 0; k < 8 && byte + k < b->size; k++) v |= (u64)b->p[byte + k] << (8 * k);
+    return (u32)((v >> (b->bit & 7)) & ((1ull << n) - 1));
+}
+/* FSE_readNCount; returns the bytes read, 0 on error */
+static size_t fse_read_ncount(short* norm, u32* maxSymbolValuePtr, u32* tableLogPtr, const u8* p, size_t size, u32 maxLog)
+{
+    fwdbits b; u32 tableLog, nbBits, sym = 0, maxSV = *maxSymbolValuePtr, s; int remaining, threshold; int previous0 = 0;
+    b.p = p; b.size = size; b.bit = 0;
+    if (size < 1) return 0;
+    tableLog = fb_peek(&b, 4) + 5; b.bit += 4;
+    if (tableLog > maxLog) return 0;
+    *tableLogPtr = tableLog;
+    remaining = (1 << tableLog) + 1; threshold = 1 << tableLog; nbBits = tableLog + 1;
+    while (remaining > 1 && sym <= maxSV) {
+        if (previous0) {
+            for (;;) {
+                u32 const r = fb_peek(&b, 2); u32 i; b.bit += 2;
+                for (i = 0; i < r && sym <= maxSV; i++) norm[sym++] = 0;
+                if (r != 3) break;
+                if ((b.bit >> 3) > size) return 0;
+            }
+            if (sym > maxSV) break;
+        }
+        {
+            int const max = (2 * threshold - 1) - remaining; int count;
+            u32 const v = fb_peek(&b, nbBits);
+            if ((int)(v & (u32)(threshold - 1)) < max) { count = (int)(v & (u32)(threshold - 1)); b.bit += nbBits - 1; }
+            else { count = (int)(v & (u32)(2 * threshold - 1)); if (count >= threshold) count -= max; b.bit += nbBits; }
+            count--;
+            remaining -= count < 0 ? -count : count;
+            norm[sym++] = (short)count;
+            previous0 = (count == 0);
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+            if ((b.bit >> 3) > size) return 0;
+        }
+    }
+    if (remaining != 1) return 0;
+    if (((b.bit + 7) >> 3) > size) return 0;
+    for (s = sym; s <= maxSV; s++) norm[s] = 0;
+    *maxSymbolValuePtr = sym - 1;
+    return (b.bit + 7) >> 3;
+}
+/* HUF_readStats + HUF_readCTable: the weights (direct nibbles, or FSE-coded with two interleaved states read backwards), the implied
+ * last weight, then the canonical codes by rank.  Returns the bytes read (0 on error); *hasZero: a symbol below the last has no code. */
+static size_t huf_read_ctable(huf_ctable* ct, u32* nbSymbolsOut, int* hasZero, const u8* p, size_t size)
+{
+    u8 w[256]; u32 nw = 0, total = 0, tableLog, rest, i; size_t used; u32 hb;
+    memset(ct, 0, sizeof(*ct));
+    if (size < 1) return 0;
+    hb = p[0];
+    if (hb >= 128) {
+        nw = hb - 127; used = 1 + (nw + 1) / 2;
+        if (used > size) return 0;
+        for (i = 0; i < nw; i += 2) { w[i] = p[1 + i / 2] >> 4; if (i + 1 < 256) w[i + 1] = p[1 + i / 2] & 15; }
+    } else {
+        short norm[16]; u32 maxSV = 12, tl = 0; size_t h; u16 db[64]; u8 dc[64]; u16 symnext[16]; u8 tsym[64];
+        used = 1 + hb;
+        if (hb == 0 || used > size) return 0;
+        h = fse_read_ncount(norm, &maxSV, &tl, p + 1, hb, 6);
+        if (h == 0) return 0;
+        {   /* decoding table: spread, then per state the new state's base and bit count */
+            u32 const tableSize = 1u << tl, mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3; u32 high = tableSize - 1, pos = 0, sy, u;
+            for (sy = 0; sy <= maxSV; sy++) { if (norm[sy] == -1) { tsym[high--] = (u8)sy; symnext[sy] = 1; } else symnext[sy] = (u16)norm[sy]; }
+            for (sy = 0; sy <= maxSV; sy++) { int k; for (k = 0; k < norm[sy]; k++) { tsym[pos] = (u8)sy; pos = (pos + step) & mask; while (pos > high) pos = (pos + step) & mask; } }
+            for (u = 0; u < tableSize; u++) { u32 const sy2 = tsym[u]; u32 const next = symnext[sy2]++; u32 const nb = tl - hb32(next); db[u] = (u16)((((next << nb) - tableSize) & 0xFFFu) | (nb << 12)); dc[u] = (u8)sy2; }
+        }
+        {   /* the stream, backwards from its last set bit */
+            const u8* const sp = p + 1 + h; size_t const ssz = hb - h; long bits; u32 s1, s2;
+            #define BB_PEEK(n_) ({ u32 r_ = 0; long k_; for (k_ = 0; k_ < (long)(n_); k_++) { long const bi_ = bits - (long)(n_) + k_; if (bi_ >= 0) r_ |= (u32)((sp[bi_ >> 3] >> (bi_ & 7)) & 1u) << k_; } r_; })
+            if (ssz == 0 || sp[ssz - 1] == 0) return 0;
+            bits = (long)(8 * (ssz - 1) + hb32(sp[ssz - 1]));
+            if (bits < (long)(2 * tl)) return 0;
+            s1 = BB_PEEK(tl); bits -= tl; s2 = BB_PEEK(tl); bits -= tl;
+            for (;;) {
+                u32 e, nb;
+                if (nw >= 255) return 0;
+                e = db[s1]; w[nw++] = dc[s1]; nb = e >> 12;
+                if (bits < (long)nb) { if (nw >= 255) return 0; w[nw++] = dc[s2]; break; }
+                s1 = (e & 0xFFFu) + BB_PEEK(nb); bits -= nb;
+                if (nw >= 255) return 0;
+                e = db[s2]; w[nw++] = dc[s2]; nb = e >> 12;
+                if (bits < (long)nb) { if (nw >= 255) return 0; w[nw++] = dc[s1]; break; }
+                s2 = (e & 0xFFFu) + BB_PEEK(nb); bits -= nb;
+            }
+            #undef BB_PEEK
+        }
+    }
+    for (i = 0; i < nw; i++) { if (w[i] > 12) return 0; if (w[i]) total += 1u << (w[i] - 1); }
+    if (total == 0) return 0;
+    tableLog = hb32(total) + 1;
+    if (tableLog > 12) return 0;                 /* HUF_TABLELOG_MAX */
+    rest = (1u << tableLog) - total;
+    if (rest & (rest - 1)) return 0;
+    w[nw++] = (u8)(hb32(rest) + 1);
+    {
+        u32 nbPerRank[16], valPerRank[16]; u32 n; u16 min = 0;
+        memset(nbPerRank, 0, sizeof(nbPerRank)); memset(valPerRank, 0, sizeof(valPerRank));
+        *hasZero = 0;
+        for (n = 0; n < nw; n++) { if (w[n] == 0) *hasZero = 1; ct->nbBits[n] = w[n] ? (u8)(tableLog + 1 - w[n]) : 0; nbPerRank[w[n] ? tableLog + 1 - w[n] : tableLog + 1]++; }
+        for (n = tableLog; n > 0; n--) { valPerRank[n] = min; min = (u16)(min + nbPerRank[n]); min >>= 1; }
+        for (n = 0; n < nw; n++) ct->val[n] = (u16)valPerRank[w[n] ? tableLog + 1 - w[n] : tableLog + 1]++;
+    }
+    *nbSymbolsOut = nw;
+    return used;
+}
+typedef struct { u32 dictID; kref_hufstate huf; kref_seqprior seq; u32 rep[3]; size_t contentOff; } kref_dictinfo;
+static int ncount_repeat_valid(const short* norm, u32 dictMax, u32 max) { u32 s; if (dictMax < max) return 0; for (s = 0; s <= max; s++) if (norm[s] == 0) return 0; return 1; }
+/* 1 = formatted and loaded, 0 = raw content (no magic), -1 = formatted but corrupt (libzstd: dictionary_corrupted) */
+static int load_formatted_dict(kref_dictinfo* di, const u8* dict, size_t dictSize)
+{
+    size_t pos = 8, h, content; u32 nsym = 0; int hasZero = 1; u32 offMax;
+    memset(di, 0, sizeof(*di));
+    if (dictSize < 8 || rd32(dict) != 0xEC30A437u) return 0;
+    di->dictID = rd32(dict + 4);
+    h = huf_read_ctable(&di->huf.ct, &nsym, &hasZero, dict + pos, dictSize - pos);
+    if (h == 0) return -1;
+    di->huf.valid = (!hasZero && nsym == 256) ? 2 : 1;
+    pos += h;
+    { u32 max = 31, lg = 0; h = fse_read_ncount(di->seq.norm[1], &max, &lg, dict + pos, dictSize - pos, 8); if (h == 0) return -1; di->seq.maxSym[1] = 31; di->seq.log[1] = lg; offMax = max; pos += h; }
+    { u32 max = 52, lg = 0; h = fse_read_ncount(di->seq.norm[2], &max, &lg, dict + pos, dictSize - pos, 9); if (h == 0) return -1; di->seq.maxSym[2] = max; di->seq.log[2] = lg; di->seq.valid[2] = ncount_repeat_valid(di->seq.norm[2], max, 52); pos += h; }
+    { u32 max = 35, lg = 0; h = fse_read_ncount(di->seq.norm[0], &max, &lg, dict + pos, dictSize - pos, 9); if (h == 0) return -1; di->seq.maxSym[0] = max; di->seq.log[0] = lg; di->seq.valid[0] = ncount_repeat_valid(di->seq.norm[0], max, 35); pos += h; }
+    if (pos + 12 > dictSize) return -1;
+    di->rep[0] = rd32(dict + pos); di->rep[1] = rd32(dict + pos + 4); di->rep[2] = rd32(dict + pos + 8); pos += 12;
+    content = dictSize - pos;
+    { u32 const offcodeMax = hb32((u32)content + (128u << 10)); di->seq.valid[1] = ncount_repeat_valid(di->seq.norm[1], offMax, offcodeMax < 31 ? offcodeMax : 31); }
+    { int i; for (i = 0; i < 3; i++) if (di->rep[i] == 0 || di->rep[i] > content) return -1; }
+    di->contentOff = pos;
+    return 1;
+}
+
+/* Test infrastructure: a formatted dictionary put together from statistics the caller chooses -- a literal sample (its Huffman table;
+ * byte values the sample lacks get no code: HUF_repeat_check), three code histograms (normalised as they are, zero counts kept:
+ * FSE_repeat_check where a code is missing), repeat offsets and content.  ZDICT's own dictionaries give every symbol a count, so the
+ * "check" paths need these.  Returns the dictionary's size, KERR when the tables do not fit the format. */
+KREF_API size_t kref_build_dictionary(u8* dst, size_t cap, u32 dictID, const u8* litSample, size_t litSize,
+                                      const u32* llCount, const u32* ofCount, const u32* mlCount, const u32* rep3, const u8* content, size_t contentSize)
+{
+    size_t pos = 8, h; u32 count[256]; u32 maxSV = 255, huffLog, t; size_t i;
+    if (cap < 8 + 1024 + 12 + contentSize) return KERR;
+    wr32(dst, 0xEC30A437u); wr32(dst + 4, dictID);
+    memset(count, 0, sizeof(count));
+    for (i = 0; i < litSize; i++) count[litSample[i]]++;
+    while (maxSV > 0 && !count[maxSV]) maxSV--;
+    { huf_ctable ct; huffLog = fse_optimal_tablelog(LIT_HUF_LOG, litSize, maxSV, 1); huffLog = huf_build_ctable(&ct, count, maxSV, huffLog);
+      h = huf_write_ctable(dst + pos, cap - pos, &ct, maxSV, huffLog); if (h == KERR) return KERR; pos += h; }
+    for (t = 0; t < 3; t++) {
+        const u32* const c = t == 0 ? ofCount : t == 1 ? mlCount : llCount;       /* the format's order: offsets, match lengths, literal lengths */
+        u32 const lim = t == 0 ? 31u : t == 1 ? 52u : 35u, maxLog = t == 0 ? 8u : 9u;
+        u32 max = lim, lg; size_t total = 0; short norm[64]; u32 cc[64];
+        for (i = 0; i <= lim; i++) { cc[i] = c[i]; total += c[i]; }
+        while (max > 0 && !cc[max]) max--;
+        if (total < 2) return KERR;
+        lg = fse_optimal_tablelog(maxLog, total, max, 2);
+        if (fse_normalize(norm, lg, cc, total, max, total >= 2048) == KERR) return KERR;
+        h = fse_write_ncount(dst + pos, cap - pos, norm, max, lg); if (h == KERR) return KERR; pos += h;
+    }
+    wr32(dst + pos, rep3[0]); wr32(dst + pos + 4, rep3[1]); wr32(dst + pos + 8, rep3[2]); pos += 12;
+    memcpy(dst + pos, content, contentSize);
+    return pos + contentSize;
+}
+
 KREF_API size_t kref_zstd_l3_compress_dict(u8* dst, size_t cap, const u8* src, size_t srcSize, const u8* dict, size_t dictSize, int* modeOut)
 {
     kref_cpar cd, fp; kref_wksp w; seqstore ss; u32 rep[3] = { 1, 4, 8 }; kref_hufstate h0, h1;
     u32 *dl, *ds; size_t pos, lastLL, litC, seqC, cSize = 0, loaded = dictSize, from = 0; u8* body; int attach;
+    kref_dictinfo di; int formatted; size_t const fullSize = dictSize;
     if (srcSize > 131072 || dictSize < 8 || dictSize > 131072 || srcSize == 0) return KERR;
     if (cap < kref_compress_bound(srcSize)) return KERR;
-    /* CDict: parameters for the dictionary alone, content loaded, tables filled */
-    cd = get_cpar(KREF_UNKNOWN, dictSize, CPM_CREATECDICT);
+    formatted = load_formatted_dict(&di, dict, dictSize);
+    if (formatted < 0) return KERR;
+    /* CDict: parameters for the dictionary alone (its whole size, entropy part included: what libzstd's parameter selection and
+     * the frame's window see), the content loaded, tables filled */
+    cd = get_cpar(KREF_UNKNOWN, fullSize, CPM_CREATECDICT);
+    if (formatted) { dict += di.contentOff; dictSize -= di.contentOff; loaded = dictSize; rep[0] = di.rep[0]; rep[1] = di.rep[1]; rep[2] = di.rep[2]; }
     { size_t const maxDict = (size_t)1 << ((cd.H + 3 > cd.C + 1) ? cd.H + 3 : cd.C + 1); if (loaded > maxDict) { from = loaded - maxDict; } }
     dl = (u32*)calloc((size_t)1 << cd.H, sizeof(u32)); ds = (u32*)calloc((size_t)1 << cd.C, sizeof(u32));
     if (dictSize - from > 8) fill_cdict_tables(dl, cd.H, ds, cd.C, cd.mml, dict, dictSize, from);
     attach = srcSize <= 16 * 1024;                        /* attachDictSizeCutoffs[ZSTD_dfast] */
     if (modeOut) *modeOut = attach;
-    fp = get_cpar(srcSize, dictSize, attach ? CPM_ATTACH : CPM_NOATTACH);      /* the frame's window */
-    pos = write_frame_header(dst, srcSize, fp.W);
+    fp = get_cpar(srcSize, fullSize, attach ? CPM_ATTACH : CPM_NOATTACH);      /* the frame's window */
+    pos = write_frame_header_id(dst, srcSize, fp.W, formatted ? di.dictID : 0);
     body = dst + pos + 3;
     w.seqs = (kref_seq*)malloc(sizeof(kref_seq) * ((128 << 10) / 3 + 8)); w.lits = (u8*)malloc((128 << 10) + 32);
     memset(&ss, 0, sizeof(ss)); ss.seqs = w.seqs; ss.lits = w.lits;
     if (srcSize >= 7) {
         if (attach) {
-            kref_cpar wp = adjust_cpar(cd, srcSize, dictSize, CPM_ATTACH);       /* working tables: resized for the input only */
+            kref_cpar wp = adjust_cpar(cd, srcSize, fullSize, CPM_ATTACH);       /* working tables: resized for the input only */
             w.hashLong = (u32*)calloc((size_t)1 << wp.H, sizeof(u32)); w.hashSmall = (u32*)calloc((size_t)1 << wp.C, sizeof(u32));
             lastLL = dfast_dms(&ss, rep, src, srcSize, dict, dictSize, w.hashLong, wp.H, w.hashSmall, wp.C, wp.mml, dl, cd.H + 8, ds, cd.C + 8);
         } else {
@@ -1710,11 +1916,14 @@ KREF_API size_t kref_zstd_l3_compress_dict(u8* dst, size_t cap, const u8* src, s
         }
         memcpy(ss.lits + ss.litSize, src + srcSize - lastLL, lastLL); ss.litSize += lastLL;
         h0.valid = 0; memset(&h0.ct, 0, sizeof(h0.ct));
+        if (formatted) h0 = di.huf;
         {
             int const suspect = (ss.nbSeq == 0) || (ss.litSize / ss.nbSeq >= 20);
             litC = compress_literals(body, cap - pos - 3, ss.lits, ss.litSize, suspect, &h0, &h1);
             if (litC != KERR) {
+                g_seq_prior = formatted ? &di.seq : NULL;
                 seqC = compress_sequences(body + litC, cap - pos - 3 - litC, &ss);
+                g_seq_prior = NULL;
                 if (seqC != KERR && seqC != 0) { cSize = litC + seqC; if (cSize >= srcSize - min_gain(srcSize)) cSize = 0; }
             }
         }
