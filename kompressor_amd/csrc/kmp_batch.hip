@@ -30,6 +30,8 @@ template <int G, int R>
 __global__ __launch_bounds__(64, 4) void k_zstd_match2(KMatchArgs a) { zstd_match2_body<G, R>(a); }
 #endif
 __global__ __launch_bounds__(64, 4) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
+// ... of a batch parsed against a formatted dictionary: its tables as the block's predecessor, its ID in the frame header
+__global__ __launch_bounds__(64, 4) void k_zstd_entropy_prior(KEntropyArgs a) { zstd_entropy_body<true>(a); }
 #ifdef KMP_ABLATIONS
 // parse and entropy stage in one launch (zstd_entropy.h: zstd_l3_fused_body)
 template <int G>
@@ -512,7 +514,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     else { (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch); (void)hipFree(c->tables); }
     (void)hipFree(c->tables_flat); (void)hipFree(c->team_epoch_flat);
     (void)hipFree(c->team_epoch); (void)hipFree(c->tables4); (void)hipFree(c->epoch4); (void)hipFree(c->big_tables4);
-    (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS);
+    (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS); (void)hipFree(c->d_prior);
     (void)hipFree(c->fstate); (void)hipFree(c->hufct); (void)hipFree(c->big_tables); (void)hipFree(c->remaining); (void)hipFree(c->big_counters); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { if (c->evm[i][j]) (void)hipEventDestroy(c->evm[i][j]); if (c->eve[i][j]) (void)hipEventDestroy(c->eve[i][j]); }
@@ -739,25 +741,34 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_dict: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (c->big) { g_last_error = "kmp_zstd_compress_batch_dict: slices above 128 KiB are not served with a dictionary"; return KMP_ERR_CAPACITY; }
     if (dict_size < 8 || dict_size > KX_MAX_DICT) { g_last_error = "kmp_zstd_compress_batch_dict: dictionary of 8 .. 130560 bytes expected"; return KMP_ERR_CAPACITY; }
-    // a dictionary in zstd's own format (magic EC30A437: entropy tables, repeat offsets, then content) would be loaded with
-    // its tables by libzstd: taking it as raw content would give frames libzstd does not read back.  Refused.
-    if (memcmp(h_dict, "\x37\xA4\x30\xEC", 4) == 0) { g_last_error = "kmp_zstd_compress_batch_dict: formatted zstd dictionaries (magic EC30A437) are not served, raw-content dictionaries only"; return KMP_ERR_ARG; }
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
     // (re)build the CDict when the dictionary changed
     u64 hsh = 1469598103934665603ull; for (u32 i = 0; i < dict_size; i++) { hsh ^= ((const u8*)h_dict)[i]; hsh *= 1099511628211ull; }
     if (!c->d_dict || c->dict_size != dict_size || c->dict_hash != hsh) {
+        // A dictionary in zstd's own format (magic EC30A437) is loaded as libzstd loads it: entropy tables and repeat offsets for the first
+        // block (KDictPrior), the bytes behind them as the content matches are searched in; anything else is content from its first byte.
+        KDictPrior prior; size_t content_off = 0;
+        int const formatted = cdict_parse_formatted((const u8*)h_dict, dict_size, &prior, &content_off);
+        if (formatted < 0) { g_last_error = "kmp_zstd_compress_batch_dict: the dictionary starts with zstd's dictionary magic but its header is damaged (libzstd: Dictionary is corrupted)"; return KMP_ERR_ARG; }
+        const u8* const content = (const u8*)h_dict + content_off; u32 const content_size = dict_size - (u32)content_off;
         HIP_TRY(hipStreamSynchronize(st));
-        (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS); c->d_dict = nullptr; c->d_dictL = nullptr; c->d_dictS = nullptr;
-        cdict_params(dict_size, &c->cdW, &c->cdC, &c->cdH, &c->cdM);
+        (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS); (void)hipFree(c->d_prior); c->d_dict = nullptr; c->d_dictL = nullptr; c->d_dictS = nullptr; c->d_prior = nullptr;
+        cdict_params(dict_size, &c->cdW, &c->cdC, &c->cdH, &c->cdM);        // (libzstd sizes the CDict and the frame's window by the whole dictionary, header included)
         std::vector<u32> tl, ts;
-        cdict_fill(tl, c->cdH, ts, c->cdC, c->cdM, (const u8*)h_dict, dict_size);
-        HIP_TRY(hipMalloc((void**)&c->d_dict, dict_size + 64));
+        cdict_fill(tl, c->cdH, ts, c->cdC, c->cdM, content, content_size);
+        HIP_TRY(hipMalloc((void**)&c->d_dict, content_size + 64));
         HIP_TRY(hipMalloc((void**)&c->d_dictL, tl.size() * 4)); HIP_TRY(hipMalloc((void**)&c->d_dictS, ts.size() * 4));
-        HIP_TRY(hipMemcpy(c->d_dict, h_dict, dict_size, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_dict, content, content_size, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_dictL, tl.data(), tl.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_dictS, ts.data(), ts.size() * 4, hipMemcpyHostToDevice));
+        if (formatted) {
+            HIP_TRY(hipMalloc((void**)&c->d_prior, sizeof(KDictPrior)));
+            HIP_TRY(hipMemcpy(c->d_prior, &prior, sizeof(KDictPrior), hipMemcpyHostToDevice));
+            c->dict_rep[0] = prior.rep[0]; c->dict_rep[1] = prior.rep[1];
+        } else { c->dict_rep[0] = 1; c->dict_rep[1] = 4; }
+        c->dict_content = content_size;
         c->dict_size = dict_size; c->dict_hash = hsh;
     }
     KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
@@ -766,7 +777,7 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
     g.m.src = (const u8*)d_src; g.m.in_off = d_in_off; g.m.in_len = c->len_ok; g.m.n_slices = n;
     g.m.seqs = c->seqs; g.m.seq_cap = c->seq_cap; g.m.lits = c->lits; g.m.lit_cap = c->lit_cap; g.m.meta = c->meta;
     { u32* ft_ = nullptr; u32* fe_ = nullptr; KMP_TRY(flat_tables(c, &ft_, &fe_)); g.m.tables = ft_; g.m.tseg_n = 1; g.m.team_epoch = fe_; } g.m.counter = c->counter; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
-    g.dict = c->d_dict; g.dict_size = dict_size; g.dictL = c->d_dictL; g.dictS = c->d_dictS;
+    g.dict = c->d_dict; g.dict_size = c->dict_content; g.dictL = c->d_dictL; g.dictS = c->d_dictS; g.rep0 = c->dict_rep[0]; g.rep1 = c->dict_rep[1];
     g.dWindowLog = c->cdW; g.dHashLog = c->cdH; g.dChainLog = c->cdC; g.dMinMatch = c->cdM;
     u32 const tpw = 64 / (u32)c->G;
     u32 blocks = (n + tpw - 1) / tpw; if (blocks > c->match_blocks) blocks = c->match_blocks;
@@ -784,7 +795,9 @@ extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src,
     e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
     e.scratch = c->scratch; e.scratch_words = c->scratch_words;
     e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len; e.flags = 8u;       // literals are gathered by the entropy kernel
-    hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), 0, st, e);
+    e.prior = c->d_prior;
+    if (c->d_prior) hipLaunchKernelGGL(k_zstd_entropy_prior, dim3(n), dim3(64), 0, st, e);
+    else hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), 0, st, e);
     HIP_TRY(hipGetLastError());
     c->last_chunks = 1;
     return batch_end(c, st, d_in_len, n, c->max_slice_bytes, d_out_len, c->meta);

@@ -76,6 +76,7 @@ struct kmp_batch_ctx {
     // frames of several blocks (max_slice_bytes above 128 KiB): per-slice state carried between the block rounds
     // raw-content dictionary of the last kmp_zstd_compress_batch_dict call: device copy + CDict tables (built on the host)
     u8* d_dict; u32* d_dictL; u32* d_dictS; u32 dict_size; u64 dict_hash; u32 cdW, cdH, cdC, cdM;
+    struct KDictPrior* d_prior; u32 dict_content; u32 dict_rep[2];      // a formatted dictionary: its tables on the device, the size of its content part, its repeat offsets
     int big; int big_G; KFrameState* fstate; u32* hufct; u32* big_tables; u32* remaining; u32* big_counters; u32 last_rounds;
     u32 cus;                                   // compute units of the device
     // decoder: sequences decoded ahead of k_zstd_decode (allocated on first use; pre_tried: do not try again)

@@ -20,17 +20,32 @@
 #include "zstd_match_ext.h"
 #include "zstd_match_fast.h"
 
+struct KDictPrior;
 struct KEntropyArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
     const KSeq* seqs; u32 seq_cap; u8* lits; u32 lit_cap; const KSliceMeta* meta;
     u32* scratch; u32 scratch_words;         // per slice: Huffman stream staging (u32 aligned)
     u8* dst; const u64* out_off; u32* out_len;
+    const KDictPrior* prior = nullptr;       // k_zstd_entropy_prior only: the formatted dictionary's tables
     u32 flags;                               // timing experiments only (results become wrong): 1 no literal coding, 2 no sequence coding (timing experiments, results become wrong);
                                              // 8: the match kernel copied no literals, gather them here; 32: strategy "fast" (levels 1, 2);
                                              // 64: literals are left uncompressed (negative levels: ZSTD_literalsCompressionIsDisabled)
 };
 
 #define KXE_ERR 0xFFFFFFFFu
+
+// What a formatted dictionary (magic EC30A437) brings besides its content (libzstd: ZSTD_loadCEntropy): a Huffman table for the literals,
+// the three sequence tables as normalised counts, repeat offsets, an ID for the frame header.  Parsed on the host (zstd_cdict_host.h),
+// one copy in device memory per loaded dictionary.  The first -- here: only -- block of a slice is coded with these as its "previous
+// block": literals may be coded with the table unseen, sequence tables the dictionary marks complete are reused below 1 000 sequences.
+struct KDictPrior {
+    u32 ct[256];              // Huffman code table: val | nbBits << 16 (KEntropyLds.ct's form)
+    u32 hufMode;              // 1: an entry may be missing (HUF_repeat_check); 2: every byte value has a code (HUF_repeat_valid)
+    u32 seqValid[3];          // [0] LL, [1] OF, [2] ML: FSE_repeat_valid
+    u32 maxSym[3], log[3];
+    short norm[3][64];
+    u32 rep[3]; u32 dictID;
+};
 
 struct KHNode { u32 count; u16 parent; u8 byte; u8 nbBits; };
 struct alignas(8) KSeqDelta { u32 nb; int fs; };
@@ -627,17 +642,35 @@ KX_DEV u32 khuf_encode_streams(KEntropyLds& lds, u8* op, const u8* lits, u32 lit
 
 // Huffman table of an earlier block of the same frame (block mode only; libzstd: prevCBlock->entropy.huf with
 // repeatMode HUF_repeat_check).  `newCt` receives the table built for this block when it is the one used.
-struct KHufPrev { const u32* ct; bool valid; u32* newCt; u32 outcome; };    // outcome: 0 raw/rle, 2 new table, 3 old table kept
+struct KHufPrev { const u32* ct; bool valid; u32* newCt; u32 outcome; bool complete = false; };    // outcome: 0 raw/rle, 2 new table, 3 old table kept
+// (complete: the table codes every byte value -- a formatted dictionary's, libzstd's HUF_repeat_valid: used without a look at the
+// histogram for small inputs, never validated, and literals from 6 bytes on are worth coding; newCt may be null)
 
 // literals section at `dst`; returns its size (uniform across the wave)
 KX_DEV u32 kzstd_literals(KEntropyLds& lds, u8* dst, const u8* lits, u32 litSize, bool suspect, u32* scratch, int lane,
                           KHufPrev* prev = nullptr, bool disabled = false)
 {
     u32 const lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
-    bool const single = litSize < 256;
+    bool const complete = prev && prev->valid && prev->complete;
+    bool const single = litSize < 256 || (complete && lhSize == 3);
     u32 hType = 2;
     u32 cLit = 0;      // 0 => raw, 1 => rle
-    if (litSize >= 64 && !disabled) {
+    bool oneByte = false;       // cLit == 1 is a real one-byte stream, not the run-length mark
+    if (complete && litSize >= 6 && litSize <= 1024 && !disabled) {
+        // HUF_compress_internal's first heuristic: a valid old table and a small input (HUF_flags_preferRepeat): coded with it, unseen
+        for (int sy = lane; sy < 256; sy += 64) lds.ct[sy] = prev->ct[sy];
+        kx_sync();
+        u32 const sz = khuf_encode_streams(lds, dst + lhSize, lits, litSize, single, scratch, lane);
+        hType = 3;
+        if (sz != 0 && sz < litSize - 1) cLit = sz;
+        if (cLit == 0 || cLit >= litSize - kx_min_gain(litSize)) cLit = 0;
+        else if (cLit == 1) {
+            // ZSTD_compressLiterals: a size of 1 usually means "one symbol"; below 8 bytes it may be a real stream, and then the bytes decide
+            bool const same = kx_all((u32)lane >= litSize || lits[lane] == lits[0]);
+            if (!(litSize >= 8 || same)) oneByte = true;
+        }
+    } else
+    if (litSize >= (complete ? 6u : 64u) && !disabled) {
         bool go = true;
         if (suspect && litSize >= 40960) {
             u32 const lb = kx_wave_hist(lds, lits, 4096, lane);
@@ -654,7 +687,7 @@ KX_DEV u32 kzstd_literals(KEntropyLds& lds, u8* dst, const u8* lits, u32 litSize
                     while (!lds.hist[maxSymbolValue]) maxSymbolValue--;
                     // HUF_validateCTable: the old table must code every symbol present
                     bool repeat = prev && prev->valid;
-                    if (repeat) for (u32 sy = 0; sy <= maxSymbolValue; sy++) if (lds.hist[sy] != 0 && (prev->ct[sy] >> 16) == 0) { repeat = false; break; }
+                    if (repeat && !prev->complete) for (u32 sy = 0; sy <= maxSymbolValue; sy++) if (lds.hist[sy] != 0 && (prev->ct[sy] >> 16) == 0) { repeat = false; break; }
                     if (repeat && litSize <= 1024) useOld = 1;          // HUF_flags_preferRepeat (strategy < lazy)
                     else {
                         u32 huffLog = kfse_optimal_tablelog(11, litSize, maxSymbolValue, 1);
@@ -666,7 +699,7 @@ KX_DEV u32 kzstd_literals(KEntropyLds& lds, u8* dst, const u8* lits, u32 litSize
                             for (u32 sy = 0; sy <= maxSymbolValue; sy++) { oldBits += (prev->ct[sy] >> 16) * lds.hist[sy]; newBits += (lds.ct[sy] >> 16) * lds.hist[sy]; }
                             if ((oldBits >> 3) <= hSize + (newBits >> 3) || hSize + 12 >= litSize) useOld = 1;
                         }
-                        if (!useOld && prev && hSize != KXE_ERR && hSize + 12 < litSize)
+                        if (!useOld && prev && prev->newCt && hSize != KXE_ERR && hSize + 12 < litSize)
                             for (int sy = 0; sy < 256; sy++) prev->newCt[sy] = lds.ct[sy];       // "save new table"
                     }
                     if (useOld) { for (int sy = 0; sy < 256; sy++) lds.ct[sy] = prev->ct[sy]; hSize = 0; }
@@ -682,7 +715,7 @@ KX_DEV u32 kzstd_literals(KEntropyLds& lds, u8* dst, const u8* lits, u32 litSize
         }
         if (cLit != 1 && (cLit == 0 || cLit >= litSize - kx_min_gain(litSize))) cLit = 0;
     }
-    if (prev) prev->outcome = (cLit > 1) ? hType : 0u;
+    if (prev) prev->outcome = (cLit > 1 || oneByte) ? hType : 0u;
     if (cLit == 0) {
         u32 fl = 0;
         if (lane == 0) fl = klit_header_raw_rle(dst, 0, litSize);
@@ -691,7 +724,7 @@ KX_DEV u32 kzstd_literals(KEntropyLds& lds, u8* dst, const u8* lits, u32 litSize
         kx_wave_copy(dst + fl, lits, litSize, lane);
         return fl + litSize;
     }
-    if (cLit == 1) {
+    if (cLit == 1 && !oneByte) {
         u32 fl = 0;
         if (lane == 0) { fl = klit_header_raw_rle(dst, 1, litSize); dst[fl] = lits[0]; }
         fl = kx_shfl(fl, 0);
@@ -758,8 +791,9 @@ KX_DEV u32 kx_select_encoding(u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, b
 // one lane per symbol type (t = 0 LL, 1 OF, 2 ML): choose the mode, write the table
 // description into lds.ncbuf[t], build the encoding table. Returns description
 // bytes (KXE_ERR on error).
+#define KSET_REPEAT 3u
 KX_DEV u32 kx_build_seq_table(KEntropyLds& lds, int t, u32* count, u32 nbSeq, u32 lastCode, u32 firstCode,
-                              u32& typeOut, KFseCT& ct, u32 mult)
+                              u32& typeOut, KFseCT& ct, u32 mult, const KDictPrior* prior = nullptr)
 {
     static const short LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2, 2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
     static const short ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,
@@ -774,9 +808,18 @@ KX_DEV u32 kx_build_seq_table(KEntropyLds& lds, int t, u32* count, u32 nbSeq, u3
     while (max > 0 && !count[max]) max--;
     for (u32 s = 0; s <= max; s++) if (count[s] > mostFrequent) mostFrequent = count[s];
     bool const defaultAllowed = (t != 1) || (max <= 28);
-    u32 const type = kx_select_encoding(mostFrequent, nbSeq, defaultNormLog, defaultAllowed, mult);
+    u32 type = kx_select_encoding(mostFrequent, nbSeq, defaultNormLog, defaultAllowed, mult);
+    // ZSTD_selectEncodingType below strategy "lazy": a table that is valid as it stands (only a dictionary's can be) is reused for fewer than
+    // 1 000 sequences, unless one code makes up the whole block or the default table is not allowed
+    if (prior && prior->seqValid[t] && mostFrequent != nbSeq && defaultAllowed && nbSeq < 1000u) type = KSET_REPEAT;
     typeOut = type;
     ct.state = kxe_state(lds, t); ct.dnb = lds.u.seq.dnb[t]; ct.dfs = lds.u.seq.dfs[t]; ct.tableLog = 0;
+    if (type == KSET_REPEAT) {
+        u32 const pm = prior->maxSym[t];
+        for (u32 s = 0; s <= pm; s++) norm[s] = prior->norm[t][s];
+        kfse_build_ctable(ct, norm, pm, prior->log[t], lds.cumul[t], kxe_tsym(lds, t));
+        return 0;
+    }
     if (type == KSET_RLE) { kfse_build_ctable_rle(ct, max); *op = (u8)firstCode; return 1; }
     if (type == KSET_BASIC) {
         const short* dn = (t == 0) ? LL_defaultNorm : (t == 1) ? OF_defaultNorm : ML_defaultNorm;
@@ -809,7 +852,7 @@ KX_DEV void kx_cbuf_put(u32* cbuf, u32 pos, u32 v, u32 n)
 // sequences section at dst; returns size, 0 => "emit a raw block instead"
 // `cap`: bytes the section may take before the block is certain to be emitted raw (block size minus the literals
 // section): the writer stops there, so a pathological block can never run past the slice's output room.
-KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSeq, u32 longType, u32 longPos, int lane, u32 cap, u32 xflags = 0)
+KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSeq, u32 longType, u32 longPos, int lane, u32 cap, u32 xflags = 0, const KDictPrior* prior = nullptr)
 {
     u32 hdr = 0;
     if (lane == 0) {
@@ -836,7 +879,7 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
         if (lane < 3) {
             u32 const lastCode = lane == 0 ? cl.ll : lane == 1 ? cl.of : cl.ml;
             u32 const firstCode = lane == 0 ? cf.ll : lane == 1 ? cf.of : cf.ml;
-            mySz = kx_build_seq_table(lds, lane, lds.hist + 64 * lane, nbSeq, lastCode, firstCode, myType, ct, (xflags & 32u) ? 9u : 8u);
+            mySz = kx_build_seq_table(lds, lane, lds.hist + 64 * lane, nbSeq, lastCode, firstCode, myType, ct, (xflags & 32u) ? 9u : 8u, prior);
         }
     }
     kx_sync();
@@ -1011,19 +1054,27 @@ KX_DEV void kx_gather_literals(u8* lits, const u8* src, u32 n, const KSeq* seqs,
 }
 
 // ---- one slice -> one frame ---------------------------------------------
+// PRIOR: the batch was parsed against a formatted dictionary (a.prior): its ID goes into the frame header, its tables stand in for a
+// previous block's.  A template so that the kernel of every other batch is the code it was.
+template <bool PRIOR = false>
 KX_DEV void zstd_entropy_slice(const KEntropyArgs& a, KEntropyLds& lds, u32 slice, int lane)
 {
     const u8* const src = a.src + a.in_off[slice];
     u32 const n = a.in_len[slice];
     u8* const dst = a.dst + a.out_off[slice];
-    u32 const fh = kx_frame_header_size(n);
+    u32 const dictID = PRIOR ? a.prior->dictID : 0u;
+    u32 const idCode = PRIOR ? (dictID > 0u) + (dictID >= 256u) + (dictID >= 65536u) : 0u, idBytes = idCode == 3u ? 4u : idCode;
+    u32 const fh = kx_frame_header_size(n) + idBytes;
     if (lane == 0) {
         u32 const fcsCode = (n >= 256) + (n >= 65536 + 256);
         kx_st32(dst, 0xFD2FB528u);
-        dst[4] = (u8)((1u << 5) + (fcsCode << 6));
-        if (fcsCode == 0) dst[5] = (u8)n;
-        else if (fcsCode == 1) kx_st16(dst + 5, n - 256);
-        else kx_st32(dst + 5, n);
+        dst[4] = (u8)(idCode + (1u << 5) + (fcsCode << 6));
+        u8* p = dst + 5;
+        if (idCode == 1) p[0] = (u8)dictID; else if (idCode == 2) kx_st16(p, dictID); else if (idCode == 3) kx_st32(p, dictID);
+        p += idBytes;
+        if (fcsCode == 0) p[0] = (u8)n;
+        else if (fcsCode == 1) kx_st16(p, n - 256);
+        else kx_st32(p, n);
     }
     u8* const bh = dst + fh; u8* const body = bh + 3;
     if (n == 0) {
@@ -1041,9 +1092,11 @@ KX_DEV void zstd_entropy_slice(const KEntropyArgs& a, KEntropyLds& lds, u32 slic
         kx_wave_copy(lits + mm.litSize, src + (n - mm.lastLL), mm.lastLL, lane);
         kx_sync();
         bool const suspect = (mm.nbSeq == 0) || (litSize / mm.nbSeq >= 20);
-        u32 const litSec = (a.flags & 1u) ? 3u : kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane, nullptr, (a.flags & 64u) != 0);
+        KHufPrev hp; hp.ct = nullptr; hp.valid = false; hp.newCt = nullptr; hp.outcome = 0;
+        if (PRIOR) { hp.ct = a.prior->ct; hp.valid = a.prior->hufMode != 0; hp.complete = a.prior->hufMode == 2; }
+        u32 const litSec = (a.flags & 1u) ? 3u : kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane, PRIOR ? &hp : nullptr, (a.flags & 64u) != 0);
         kx_sync();
-        u32 const seqSec = (a.flags & 2u) ? 0u : kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < n ? n - litSec : 0u, a.flags);
+        u32 const seqSec = (a.flags & 2u) ? 0u : kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < n ? n - litSec : 0u, a.flags, PRIOR ? a.prior : nullptr);
         if (seqSec != 0) {
             cSize = litSec + seqSec;
             if (cSize >= n - kx_min_gain(n)) cSize = 0;
@@ -1382,13 +1435,14 @@ KX_DEV void zstd_l3_fused_body(const KMatchArgs& a, const KEntropyArgs& e)
     zstd_match_body<G, false, KFuseDone>(a, done);
 }
 
+template <bool PRIOR = false>
 KX_DEV void zstd_entropy_body(const KEntropyArgs& a)
 {
     KX_SHARED KEntropyLds lds;
     int const lane = kx_lane();
     for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
         u32 const slice = kx_xcd_chunk(it, a.n_slices);
-        zstd_entropy_slice(a, lds, slice, lane);
+        zstd_entropy_slice<PRIOR>(a, lds, slice, lane);
         kx_sync();
     }
 }

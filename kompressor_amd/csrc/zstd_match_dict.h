@@ -21,7 +21,8 @@
 
 struct KDictArgs {
     KMatchArgs m;                     // slices, sequences, meta, per-team working tables + epochs, work counter
-    const u8* dict; u32 dict_size;    // D: 8 .. KX_MAX_DICT
+    const u8* dict; u32 dict_size;    // D: 8 .. KX_MAX_DICT (a formatted dictionary's content part)
+    u32 rep0 = 1, rep1 = 4;           // the repeat offsets a frame starts with (a formatted dictionary brings its own)
     const u32* dictL; const u32* dictS;   // CDict tables: entries index << 8 | tag, 1 << dHashLog / 1 << dChainLog of them
     u32 dWindowLog, dHashLog, dChainLog, dMinMatch;      // the CDict's parameters (ZSTD_getCParams for the dictionary alone)
 };
@@ -151,7 +152,7 @@ KX_DEV void zstd_match_dict_body(const KDictArgs& d)
                         ep = 1;
                     }
                     tag = ep << KX_TAG_SHIFT;
-                    anchor = 0; ip = 0; ilimit = n - 8; off1 = 1; off2 = 4;
+                    anchor = 0; ip = 0; ilimit = n - 8; off1 = d.rep0; off2 = d.rep1;
                     state = (n < 8 || ip >= ilimit) ? KDS_CLEANUP : KDS_SEARCH;
                 }
             }

@@ -164,10 +164,16 @@ int emu_zstd_compress_dict(const u8* src, const u64* in_off, const u32* in_len, 
     std::vector<u32> tables((size_t)nteams * KX_TBL_ENTRIES, 0xDEADBEEFu & 0x0003FFFFu);
     std::vector<u32> epoch(nteams, 7);
     u32 counter = 0, W, C, H, M;
+    // (a formatted dictionary: the host code's steps of kmp_zstd_compress_batch_dict)
+    KDictPrior prior; size_t content_off = 0;
+    int const formatted = cdict_parse_formatted(dict, dict_size, &prior, &content_off);
+    if (formatted < 0) return -4;
     cdict_params(dict_size, &W, &C, &H, &M);
+    dict += content_off; dict_size -= (u32)content_off;
     std::vector<u32> tl, ts;
     cdict_fill(tl, H, ts, C, M, dict, dict_size);
     KDictArgs g;
+    if (formatted) { g.rep0 = prior.rep[0]; g.rep1 = prior.rep[1]; }
     g.m.src = src; g.m.in_off = in_off; g.m.in_len = in_len; g.m.n_slices = n;
     g.m.seqs = seqs.data(); g.m.seq_cap = seq_cap; g.m.lits = lits.data(); g.m.lit_cap = lit_cap; g.m.meta = meta.data();
     g.m.tables = tables.data(); g.m.team_epoch = epoch.data(); g.m.counter = &counter; g.m.flags = 6; g.m.fstate = nullptr; g.m.big_tables = nullptr;
@@ -188,7 +194,8 @@ int emu_zstd_compress_dict(const u8* src, const u64* in_off, const u32* in_len, 
     e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
     e.scratch = scratch.data(); e.scratch_words = scratch_words;
     e.dst = dst; e.out_off = out_off; e.out_len = out_len; e.flags = 8u;
-    kxemu::launch(nblocks, [&]() { zstd_entropy_body(e); });
+    if (formatted) { e.prior = &prior; kxemu::launch(nblocks, [&]() { zstd_entropy_body<true>(e); }); }
+    else kxemu::launch(nblocks, [&]() { zstd_entropy_body(e); });
     return kxemu::failed ? -1 : 0;
 }
 
