@@ -514,7 +514,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     else { (void)hipFree(c->seqs); (void)hipFree(c->lits); (void)hipFree(c->meta); (void)hipFree(c->scratch); (void)hipFree(c->tables); }
     (void)hipFree(c->tables_flat); (void)hipFree(c->team_epoch_flat);
     (void)hipFree(c->team_epoch); (void)hipFree(c->tables4); (void)hipFree(c->epoch4); (void)hipFree(c->big_tables4);
-    (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS); (void)hipFree(c->d_prior);
+    (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS); (void)hipFree(c->d_prior); (void)hipFree(c->d_dprior);
     (void)hipFree(c->fstate); (void)hipFree(c->hufct); (void)hipFree(c->big_tables); (void)hipFree(c->remaining); (void)hipFree(c->big_counters); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { if (c->evm[i][j]) (void)hipEventDestroy(c->evm[i][j]); if (c->eve[i][j]) (void)hipEventDestroy(c->eve[i][j]); }
@@ -733,6 +733,12 @@ extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src
 // ---- compressing with a raw-content dictionary ------------------------------------------------------
 // libzstd's CDict for the dictionary: parameters of ZSTD_getCParams(3, unknown source size, dictSize) in
 // "create CDict" mode, then ZSTD_fillDoubleHashTableForCDict over the dictionary (tagged entries: index << 8 | tag).
+int dict_header_state(const unsigned char* dict, size_t dict_size, int for_decoder)
+{
+    KDictPrior pr; KDictDPrior dp; size_t off = 0;
+    return cdict_parse_formatted(dict, dict_size, &pr, &off, for_decoder ? &dp : nullptr);
+}
+
 extern "C" int kmp_zstd_compress_batch_dict(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                             uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                             const void* h_dict, uint32_t dict_size, void* hip_stream)
@@ -1291,6 +1297,31 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
     d.lits = c->lits; d.lit_cap = c->lit_cap; d.flags = c->knob.decode_flags;
     KMP_TRY(batch_begin(c, st, nullptr, n, 0));            // the decoder checks every length itself; lits is shared with the compressors
     d.dict = (const u8*)d_dict; d.dict_size = d_dict ? dict_size : 0u;
+    u32 start_rep[3] = { 1, 4, 8 };
+    if (d_dict && dict_size >= 8) {
+        // A dictionary in zstd's own format brings tables, repeat offsets and an ID (ZSTD_loadDEntropy): its head is read back and parsed once
+        // per dictionary (recognised by address, size and the head's bytes); the kernels get the content part and the parsed rest.
+        u8 head[2048]; u32 const hn = dict_size < sizeof head ? dict_size : (u32)sizeof head;
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(head, d_dict, hn, hipMemcpyDeviceToHost));
+        u64 hsh = 1469598103934665603ull; for (u32 i = 0; i < hn; i++) { hsh ^= head[i]; hsh *= 1099511628211ull; }
+        if (c->ddict_ptr != d_dict || c->ddict_size != dict_size || c->ddict_hash != hsh) {
+            KDictDPrior dp; size_t off = 0;
+            int const formatted = cdict_parse_formatted(head, dict_size, nullptr, &off, &dp, hn);
+            if (formatted < 0) { g_last_error = "kmp_zstd_decompress_batch_dict: the dictionary starts with zstd's dictionary magic but its header is damaged (libzstd: Dictionary is corrupted)"; return KMP_ERR_ARG; }
+            (void)hipFree(c->d_dprior); c->d_dprior = nullptr;
+            if (formatted) {
+                HIP_TRY(hipMalloc((void**)&c->d_dprior, sizeof(KDictDPrior)));
+                HIP_TRY(hipMemcpy(c->d_dprior, &dp, sizeof(KDictDPrior), hipMemcpyHostToDevice));
+                c->ddict_off = (u32)off; c->ddict_id = dp.dictID; c->ddict_rep[0] = dp.rep[0]; c->ddict_rep[1] = dp.rep[1]; c->ddict_rep[2] = dp.rep[2];
+            } else { c->ddict_off = 0; c->ddict_id = 0; }
+            c->ddict_ptr = d_dict; c->ddict_size = dict_size; c->ddict_hash = hsh;
+        }
+        if (c->d_dprior) {
+            d.dict = (const u8*)d_dict + c->ddict_off; d.dict_size = dict_size - c->ddict_off; d.dprior = c->d_dprior; d.dict_id = c->ddict_id;
+            start_rep[0] = c->ddict_rep[0]; start_rep[1] = c->ddict_rep[1]; start_rep[2] = c->ddict_rep[2];
+        }
+    }
     // Staging for what the pre-decode kernels leave (8 bytes per sequence -- a frame of S bytes holds at most S / 3 -- and
     // the literals): allocated on the first call, for as many entries as 48 GiB hold (all of them for the bench's batches;
     // a larger batch goes through in pieces, one after the other, that reuse the staging).
@@ -1328,6 +1359,7 @@ static int zstd_decompress_impl(kmp_batch_ctx* c, const void* d_src, const uint6
                 p.perm = sorted ? sort_perm : nullptr;
                 p.src = d.src; p.in_off = q.in_off; p.in_len = q.in_len; p.n_slices = m;
                 p.stage = c->pre_stage; p.seq_cap = c->pre_seq_cap; p.blk = c->pre_blk; p.blk_cap = c->pre_blk_cap; p.nblk = c->pre_nblk;
+                p.rep[0] = start_rep[0]; p.rep[1] = start_rep[1]; p.rep[2] = start_rep[2];
                 hipLaunchKernelGGL(k_zstd_seq_predecode, dim3((m + KXP_FRAMES - 1) / KXP_FRAMES), dim3(4 * KXP_FRAMES), 0, c->st2, p);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(c->ev_pre[1], c->st2));

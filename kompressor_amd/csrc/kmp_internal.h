@@ -76,6 +76,7 @@ struct kmp_batch_ctx {
     // frames of several blocks (max_slice_bytes above 128 KiB): per-slice state carried between the block rounds
     // raw-content dictionary of the last kmp_zstd_compress_batch_dict call: device copy + CDict tables (built on the host)
     u8* d_dict; u32* d_dictL; u32* d_dictS; u32 dict_size; u64 dict_hash; u32 cdW, cdH, cdC, cdM;
+    struct KDictDPrior* d_dprior; const void* ddict_ptr; u32 ddict_size; u64 ddict_hash; u32 ddict_off, ddict_id, ddict_rep[3];      // ... for the decoder (the caller's dictionary lies in device memory: its head is read back once per dictionary)
     struct KDictPrior* d_prior; u32 dict_content; u32 dict_rep[2];      // a formatted dictionary: its tables on the device, the size of its content part, its repeat offsets
     int big; int big_G; KFrameState* fstate; u32* hufct; u32* big_tables; u32* remaining; u32* big_counters; u32 last_rounds;
     u32 cus;                                   // compute units of the device
@@ -122,5 +123,6 @@ int scatter_frames(kmp_batch_ctx* c, hipStream_t st, const u8* d_src, const u64*
 // frames of several blocks (kmp_batch.hip); stream: KFrameArgs.stream
 int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct = 0, u32 fast_step0 = 0, bool level4 = false);
+int dict_header_state(const unsigned char* dict, size_t dict_size, int for_decoder);       // 1: a well-formed dictionary in zstd's own format, 0: raw content, -1: the magic with a damaged header
 int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                        uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream, int level = 6);

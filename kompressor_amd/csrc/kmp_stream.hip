@@ -19,7 +19,7 @@
 // --------------------------------------------------------------------------
 #define KERRC(code) ((size_t)0 - (size_t)(code))
 enum { ZE_GENERIC = 1, ZE_prefix_unknown = 10, ZE_frameParameter_unsupported = 14, ZE_corruption_detected = 20,
-       ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 42, ZE_stage_wrong = 60, ZE_memory_allocation = 64,
+       ZE_dictionary_corrupted = 30, ZE_parameter_unsupported = 40, ZE_parameter_outOfBound = 42, ZE_stage_wrong = 60, ZE_memory_allocation = 64,
        ZE_dstSize_tooSmall = 70, ZE_srcSize_wrong = 72, ZE_maxCode = 120 };
 
 extern "C" unsigned kmp_zstd_is_error(size_t code) { return code > KERRC(ZE_maxCode); }
@@ -131,8 +131,9 @@ extern "C" size_t kmp_zstd_cctx_load_dictionary(kmp_zstd_cctx* c, const void* di
     if (c->stage != 0 || !c->in.empty()) return KERRC(ZE_stage_wrong);
     c->dict.clear();
     if (dict == nullptr || dict_size == 0) return 0;
-    if (dict_size >= 8 && memcmp(dict, "\x37\xA4\x30\xEC", 4) == 0) return KERRC(ZE_parameter_unsupported);   // formatted zstd dictionary: CPU library
     if (dict_size < 8 || dict_size > KX_MAX_DICT) return KERRC(ZE_parameter_unsupported);
+    // (a dictionary in zstd's own format -- magic EC30A437 -- is loaded with its tables by the batch call; libzstd too only copies the bytes
+    // here and meets a damaged header when the first frame starts: "Dictionary is corrupted" then)
     c->dict.assign((const u8*)dict, (const u8*)dict + dict_size);
     return 0;
 }
@@ -193,7 +194,9 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
     if (!c->dict.empty()) {
         if (n > KMP_MAX_SLICE_BYTES) return KERRC(ZE_srcSize_wrong);          // frames of several blocks with a dictionary: CPU library
         if (kmp_zstd_compress_batch_dict(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1,
-                                         c->dict.data(), (u32)c->dict.size(), nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
+                                         c->dict.data(), (u32)c->dict.size(), nullptr) != KMP_OK) {
+            return dict_header_state(c->dict.data(), c->dict.size(), 0) < 0 ? KERRC(ZE_dictionary_corrupted) : KERRC(ZE_GENERIC);
+        }
     } else
     if (kmp_zstd_compress_batch(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, nullptr) != KMP_OK) return KERRC(ZE_GENERIC);
     if (hipMemcpy(&olen, s.d_len + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return KERRC(ZE_GENERIC);
@@ -365,8 +368,10 @@ extern "C" size_t kmp_zstd_dctx_load_dictionary(kmp_zstd_dctx* d, const void* di
     if (d->d_dict) { (void)hipFree(d->d_dict); d->d_dict = nullptr; }
     d->dict.clear();
     if (dict == nullptr || dict_size == 0) return 0;
-    if (dict_size >= 8 && memcmp(dict, "\x37\xA4\x30\xEC", 4) == 0) return KERRC(ZE_parameter_unsupported);   // formatted zstd dictionary: CPU library
     if (dict_size > (8u << 20)) return KERRC(ZE_memory_allocation);
+    // (a dictionary in zstd's own format is parsed by the batch call; libzstd builds its DDict here and reports a damaged header as a
+    // failed allocation: ZSTD_DCtx_loadDictionary -> ZSTD_createDDict_advanced returns NULL)
+    if (dict_header_state((const u8*)dict, dict_size, 1) < 0) return KERRC(ZE_memory_allocation);
     d->dict.assign((const u8*)dict, (const u8*)dict + dict_size);
     if (hipMalloc((void**)&d->d_dict, dict_size + 64) != hipSuccess) { d->d_dict = nullptr; d->dict.clear(); return KERRC(ZE_memory_allocation); }
     if (hipMemcpy(d->d_dict, d->dict.data(), dict_size, hipMemcpyHostToDevice) != hipSuccess) return KERRC(ZE_GENERIC);

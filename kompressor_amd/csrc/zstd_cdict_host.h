@@ -143,9 +143,15 @@ static inline size_t cdict_read_huf_weights(u8* w, u32* nwOut, u32* tableLogOut,
     *nwOut = nw; *tableLogOut = tableLog;
     return used;
 }
-static inline int cdict_parse_formatted(const u8* dict, size_t dictSize, KDictPrior* out, size_t* contentOff)
+// (dec: the same header for a decoder, optional.  avail: how many of the dictionary's dictSize bytes lie at `dict` -- a decoder's caller
+// holds the dictionary in device memory and only its head is brought over; the header ends well inside 2 KiB.)
+static inline int cdict_parse_formatted(const u8* dict, size_t dictSize, KDictPrior* out, size_t* contentOff, KDictDPrior* dec = nullptr, size_t avail = ~(size_t)0)
 {
-    if (dictSize < 8 || memcmp(dict, "\x37\xA4\x30\xEC", 4) != 0) return 0;
+    if (avail > dictSize) avail = dictSize;
+    if (dictSize < 8 || avail < 8 || memcmp(dict, "\x37\xA4\x30\xEC", 4) != 0) return 0;
+    size_t const fullSize = dictSize; dictSize = avail;            // (reads stay inside what is here; the content's size comes from fullSize)
+    KDictPrior scratchPrior; if (!out) out = &scratchPrior;
+    if (dec) memset(dec, 0, sizeof(*dec));
     memset(out, 0, sizeof(*out));
     memcpy(&out->dictID, dict + 4, 4);
     size_t pos = 8;
@@ -160,6 +166,7 @@ static inline int cdict_parse_formatted(const u8* dict, size_t dictSize, KDictPr
         { u32 min = 0; for (u32 n = tableLog; n > 0; n--) { valPerRank[n] = min; min += nbPerRank[n]; min >>= 1; } }
         for (u32 s = 0; s < nw; s++) { u32 const nb = w[s] ? tableLog + 1 - w[s] : 0u; u32 const val = valPerRank[w[s] ? nb : tableLog + 1]++; out->ct[s] = w[s] ? (val | (nb << 16)) : 0u; }
         out->hufMode = (!hasZero && nw == 256) ? 2u : 1u;
+        if (dec) { if (tableLog > 11) return -1; memcpy(dec->weights, w, nw); dec->nw = nw; dec->hufLog = tableLog; }     // (the decoder's table holds depths to 11, the format's limit for literals)
     }
     u32 offMaxRead = 31;
     for (int k = 0; k < 3; k++) {                          // the format's order: offsets, match lengths, literal lengths
@@ -169,6 +176,7 @@ static inline int cdict_parse_formatted(const u8* dict, size_t dictSize, KDictPr
         if (h == 0) return -1;
         pos += h;
         out->log[t] = lg;
+        if (dec) { memcpy(dec->norm[t], out->norm[t], sizeof(dec->norm[t])); dec->log[t] = lg; dec->max[t] = max; }
         if (t == 1) { out->maxSym[1] = 31; offMaxRead = max; }     // (the offset table is built over all 32 codes, the others over what was read)
         else {
             out->maxSym[t] = max;
@@ -179,7 +187,8 @@ static inline int cdict_parse_formatted(const u8* dict, size_t dictSize, KDictPr
     }
     if (pos + 12 > dictSize) return -1;
     memcpy(out->rep, dict + pos, 12); pos += 12;
-    size_t const content = dictSize - pos;
+    if (dec) { memcpy(dec->rep, out->rep, 12); dec->dictID = out->dictID; }
+    size_t const content = fullSize - pos;
     {
         u32 const offcodeMax = hb32_host((u32)content + (128u << 10)); u32 const need = offcodeMax < 31u ? offcodeMax : 31u;
         bool ok = offMaxRead >= need;

@@ -132,6 +132,11 @@ KX_DEV KParams kx_params_l4(u32 n, bool& ok)
 KX_DEV KParams kx_params_l2_dfast() { KParams p; p.windowLog = 18; p.chainLog = 14; p.hashLog = 14; p.minMatch = 5; return p; }
 KX_DEV bool kx_in_class(u32 cls, u32 n) { return cls == 0u || ((n > 131072u && n <= 262144u) == (cls == 1u)); }
 
+// What a formatted dictionary gives a DEcoder besides its content (libzstd: ZSTD_loadDEntropy): the literals' Huffman table as weights, the
+// three sequence tables as normalised counts -- the first block of a frame may refer to them as "the previous block's" (tree-less literals,
+// "repeat" sequence tables) --, the repeat offsets a frame starts with, and the ID a frame's header may name.  Host: zstd_cdict_host.h.
+struct KDictDPrior { u8 weights[256]; u32 nw, hufLog; short norm[3][64]; u32 log[3], max[3]; u32 rep[3]; u32 dictID; };       // [0] LL, [1] OF, [2] ML
+
 KX_DEV u32 kx_frame_header_size(u32 n, u32 windowLog = 21)
 {
     // magic(4) + FHD(1) + FCS; single segment while the window (2 MiB at level 3; 512 KiB / 1 MiB at the "fast" levels) covers the

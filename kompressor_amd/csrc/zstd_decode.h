@@ -32,7 +32,9 @@ struct KDecodeArgs {
     u8* lits; u32 lit_cap;                 // per frame: decoded literals of one block
     u32 flags;                             // timing-only ablations (results wrong): 1 skip Huffman walk, 2 skip sequences, 4 skip copies;
                                            //   window executor: 8 skip the flush, 16 short literals, 32 short matches from HBM, 64 all matches
-    const u8* dict; u32 dict_size;         // raw-content dictionary shared by the batch (history before every frame), or null / 0
+    const u8* dict; u32 dict_size;         // dictionary content shared by the batch (history before every frame), or null / 0
+    const KDictDPrior* dprior = nullptr;   // a formatted dictionary's tables and repeat offsets (dict is then its content part), or null
+    u32 dict_id = 0;                       // the ID a frame's header may name (0: a raw-content dictionary, or none: any ID in a header is a mismatch)
 };
 
 enum { KZE_GENERIC = 1, KZE_PREFIX = 10, KZE_FRAMEPARAM = 14, KZE_WINDOW = 16, KZE_CORRUPT = 20, KZE_CHECKSUM = 22,
@@ -668,9 +670,7 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
         if (!err) {
             u32 did = 0;
             for (u32 i = 0; i < didSize; i++) did |= (u32)src[pos + i] << (8 * i);
-            if (did) err = KZE_DICT;
-            // (the batch's dictionary is raw content; one in zstd's own format -- magic EC30A437 -- would bring tables: refused)
-            if (a.dict_size >= 8 && kx_ld32(a.dict) == 0xEC30A437u) err = KZE_DICT;
+            if (did && did != a.dict_id) err = KZE_DICT;           // "Dictionary mismatch" (a header without an ID takes whatever dictionary is loaded)
             pos += didSize;
             if (fcsSize) {
                 hasContent = 1;
@@ -691,6 +691,15 @@ KX_DEV void zstd_decode_frame(const KDecodeArgs& a, KDecodeLds& lds, u32 f, int 
     u32 hufLog = 0, hufNw = 0; bool hufValid = false;
     u32 tlLL = 0, tlOF = 0, tlML = 0;
     if (lane < 3) lds.keepKind[lane] = 0;
+    if (a.dprior) {
+        // a formatted dictionary: every frame starts as if a block with these tables and repeat offsets had come before it (ZSTD_loadDEntropy)
+        const KDictDPrior& dp = *a.dprior;
+        rep1 = dp.rep[0]; rep2 = dp.rep[1]; rep3 = dp.rep[2];
+        hufLog = dp.hufLog; hufNw = dp.nw; hufValid = true;
+        for (u32 i = (u32)lane; i < 256u; i += 64u) lds.weights[i] = dp.weights[i];
+        if (lane < 3) { lds.keepKind[lane] = 2; lds.keepLog[lane] = dp.log[lane]; lds.keepMax[lane] = dp.max[lane]; }
+        for (int t = 0; t < 3; t++) lds.keepNorm[t][lane] = dp.norm[t][lane];
+    }
     kx_sync();
     bool last = false;
     while (!err && !last) {

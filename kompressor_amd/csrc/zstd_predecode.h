@@ -28,6 +28,7 @@ struct KPreArgs {
     KPreBlk* blk; u32 blk_cap;          // per entry: blk_cap records (compressed blocks in frame order)
     u32* nblk;                          // per entry: records written
     const u32* perm;                    // which entry each lane slot takes (k_zstd_seq_perm), or null: slot i takes entry i
+    u32 rep[3] = { 1, 4, 8 };           // the repeat offsets a frame starts with (a formatted dictionary brings its own)
 };
 
 // Per frame in LDS: one 16-bit word per FSE state -- the state's rank among its symbol's states, as "next" = count +
@@ -216,7 +217,7 @@ KX_DEV void zstd_seq_predecode_body(const KPreArgs& a)
         pos = 5 + (single ? 0u : 1u) + didSize + fcsSize;
         if (pos > srcSize) ok = false;
     }
-    u32 rep1 = 1, rep2 = 4, rep3 = 8;
+    u32 rep1 = a.rep[0], rep2 = a.rep[1], rep3 = a.rep[2];
     u32 kind[3] = { 0, 0, 0 }, klog[3] = { 0, 0, 0 };        // (lane 0 of the quad)
     bool last = false;
     u32 covered = 0;                      // set when the frame's last block has been taken: every compressed block has a record

@@ -354,6 +354,14 @@ int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len
     d.src = src; d.in_off = in_off; d.in_len = in_len; d.n_slices = n;
     d.dst = dst; d.out_off = out_off; d.out_cap = out_cap; d.out_len = out_len; d.status = status;
     d.lits = lits.data(); d.lit_cap = lit_cap; d.flags = 0; d.dict = dict; d.dict_size = dict ? dict_size : 0;
+    // (a formatted dictionary: the host code's steps of zstd_decompress_impl)
+    KDictDPrior dprior; u32 start_rep[3] = { 1, 4, 8 };
+    if (dict && dict_size >= 8) {
+        size_t off = 0;
+        int const formatted = cdict_parse_formatted(dict, dict_size, nullptr, &off, &dprior);
+        if (formatted < 0) return -7;
+        if (formatted) { d.dict = dict + off; d.dict_size = dict_size - (u32)off; d.dprior = &dprior; d.dict_id = dprior.dictID; start_rep[0] = dprior.rep[0]; start_rep[1] = dprior.rep[1]; start_rep[2] = dprior.rep[2]; }
+    }
     // sequences decoded ahead, one lane per frame (what the product does); KXEMU_NO_PRE=1: everything in the decode body
     u32 const seq_cap = lit_cap / 3u + 64u, blk_cap = lit_cap / 8192u + 16u;
     std::vector<u64> stage; std::vector<KPreBlk> pblk; std::vector<u32> nblk;
@@ -376,6 +384,7 @@ int emu_zstd_decompress_dict(const u8* src, const u64* in_off, const u32* in_len
         KPreArgs p;
         p.src = src; p.in_off = in_off; p.in_len = in_len; p.n_slices = n;
         p.stage = stage.data(); p.seq_cap = seq_cap; p.blk = pblk.data(); p.blk_cap = blk_cap; p.nblk = nblk.data(); p.perm = sorted ? sperm.data() : nullptr;
+        p.rep[0] = start_rep[0]; p.rep[1] = start_rep[1]; p.rep[2] = start_rep[2];
         kxemu::launch((n + KXP_FRAMES - 1) / KXP_FRAMES, [&]() { zstd_seq_predecode_body(p); });
         if (kxemu::failed) return -2;
         d.pre_stage = stage.data(); d.pre_seq_cap = seq_cap; d.pre_blk = pblk.data(); d.pre_blk_cap = blk_cap; d.pre_nblk = nblk.data();

@@ -380,6 +380,21 @@ class Oracle:
             raise RuntimeError("oracle: input outside the restatement's scope")
         return o.raw[:n]
 
+    def build_dictionary(self, dict_id: int, lit_sample: bytes, ll, of, ml, rep, content: bytes) -> bytes:
+        """A dictionary in zstd's own format put together from chosen statistics (kref_build_dictionary: test infrastructure): the
+        literal sample's Huffman table, three code histograms taken as they are (zero counts stay zero), repeat offsets, content."""
+        k = self.lib
+        k.kref_build_dictionary.restype = ctypes.c_size_t
+        k.kref_build_dictionary.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+        cap = len(content) + 4096
+        out = ctypes.create_string_buffer(cap)
+        arr = lambda v, n: (ctypes.c_uint32 * n)(*v)
+        n = k.kref_build_dictionary(out, cap, dict_id, lit_sample, len(lit_sample), arr(ll, 36), arr(of, 32), arr(ml, 53), arr(rep, 3), content, len(content))
+        if n == 2 ** 64 - 1:
+            raise RuntimeError("oracle: the statistics do not fit the dictionary format")
+        return out.raw[:n]
+
     def params(self, n):
         a = (ctypes.c_uint32 * 4)()
         self.lib.kref_params_l3(n, a)
@@ -749,3 +764,55 @@ def emu_decompress(frames, caps, nblocks=2, dictionary=None):
                                       128 * 1024 + 64)
     assert r == 0, f"emulator reported {r}"
     return [out[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)], [int(x) for x in st]
+
+
+def formatted_dict_built():
+    """Seeded dictionaries in zstd's own format (magic EC30A437), put together by the oracle's builder so that the paths ZDICT's own
+    dictionaries never take are covered: Huffman tables that lack byte values (HUF_repeat_check), sequence tables with missing codes
+    (FSE_repeat_check), IDs of 0, 1, 2 and 4 bytes, repeat offsets anywhere in the content.  -> [(name, dictionary, class)]"""
+    import random
+    from kompressor_amd import corpus
+    rng = random.Random(40417)
+    out = []
+    for case in range(8):
+        cls = "TXSD"[case % 4]
+        content = corpus.make(7000 + case, 1, rng.randrange(600, 40000), mix=ord(cls)).tobytes()
+        lit = corpus.make(7100 + case, 1, 3000, mix=ord("TXSDB"[(case + 1) % 5])).tobytes()
+        if case % 3 == 0:
+            lit = bytes(b for b in lit if 97 <= b <= 122) or b"abcabcabd"        # letters only: most byte values get no code
+        ll = [rng.randrange(50) for _ in range(36)]; of = [rng.randrange(50) for _ in range(32)]; ml = [rng.randrange(50) for _ in range(53)]
+        if case % 2 == 0:       # complete tables (offsets: codes up to 19)
+            ll = [x + 1 for x in ll]; ml = [x + 1 for x in ml]; of = [x + 1 for x in of[:20]] + [0] * 12
+        if case % 4 == 1:
+            ll[5] = 0; ml[7] = 0
+        of[0] = max(of[0], 1); ll[0] = max(ll[0], 1); ml[0] = max(ml[0], 1)
+        rep = [rng.randrange(1, len(content) + 1) for _ in range(3)]
+        did = [0, 5, 300, 70000, 2 ** 31 + 5][case % 5]
+        out.append((f"built{case}_{cls}_{len(content)}_id{did}", oracle().build_dictionary(did, lit, ll, of, ml, rep, content), cls))
+    return out
+
+
+def formatted_dict_inputs(cls, salt=0):
+    """Seeded inputs for one dictionary: sizes on both sides of everything the dictionary path branches on (6 / 8 literals, 64, 256, 1024,
+    the 16 KiB attach / copy cut-off, 1 000 sequences), of the dictionary's class."""
+    from kompressor_amd import corpus
+    sizes = (1, 5, 6, 7, 8, 30, 64, 200, 256, 700, 1023, 1024, 1025, 3000, 9000, 16384, 16385, 30000, 65536, 131072)
+    return [corpus.make(99000 + n + salt, 1, n, mix=ord(cls)).tobytes() for n in sizes]
+
+
+def formatted_dict_golden():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zstd_dict_formatted_golden.json")))
+
+
+def formatted_dict_cases():
+    """[(name, dictionary, inputs, golden row)] of tests/golden/zstd_dict_formatted_golden.json: the trained dictionaries from the fixture,
+    the built ones rebuilt here and checked against the fixture's hash."""
+    import base64, hashlib
+    built = {name: d for name, d, _ in formatted_dict_built()}
+    out = []
+    for row in formatted_dict_golden()["rows"]:
+        d = base64.b64decode(row["dict_b64"]) if "dict_b64" in row else built[row["name"]]
+        assert hashlib.sha256(d).hexdigest() == row["dict_sha256"], row["name"]
+        out.append((row["name"], d, formatted_dict_inputs(row["class"], salt=row["salt"]), row))
+    return out

@@ -554,3 +554,25 @@ def test_xcd_aware_slice_mapping_is_a_bijection_with_contiguous_chunks():
         starts = [got[x] for x in range(min(8, n))]
         assert starts == sorted(starts)
 
+
+
+def test_formatted_dictionaries_on_the_emulator():
+    """The kernel bodies with a dictionary in zstd's own format: the host parser (zstd_cdict_host.h), the dictionary match body with the
+    dictionary's repeat offsets, the entropy body coding against the dictionary's tables (k_zstd_entropy_prior's body) -- the oracle's
+    frames, i.e. libzstd's; and the decoder bodies with the dictionary's tables behind the first block: libzstd's level-3 and level-19
+    frames back to the input, a frame that names another dictionary's ID refused with libzstd's code."""
+    import base64
+    o = helpers.oracle()
+    cases = helpers.formatted_dict_cases()
+    for name, d, inputs, row in cases[:2] + cases[2::3]:
+        want = [o.compress_dict(p, d)[0] for p in inputs]
+        assert helpers.emu_compress_dict(inputs, d) == want, name
+        frames = want + [base64.b64decode(x) for x in row["level19"]]
+        plain = inputs + [inputs[i] for i in row["level19_inputs"]]
+        outs, sts = helpers.emu_decompress(frames, [max(len(p), 1) for p in plain], dictionary=d)
+        assert list(sts) == [0] * len(frames) and outs == plain, name
+    (n0, d0, in0, r0), (n1, d1, in1, r1) = cases[0], cases[1]
+    f = o.compress_dict(in0[12], d0)[0]
+    assert list(helpers.emu_decompress([f], [len(in0[12])], dictionary=d1)[1]) == [32]                      # dictionary_wrong
+    assert list(helpers.emu_decompress([f], [len(in0[12])], dictionary=b"raw content, no magic " * 8)[1]) == [32]
+    assert list(helpers.emu_decompress([f], [len(in0[12])])[1]) == [32]

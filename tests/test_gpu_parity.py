@@ -478,14 +478,68 @@ def test_decoder_with_raw_dictionary(batch):
         except RuntimeError:
             wrong = None
         assert wrong != plain, name
-    # a dictionary in zstd's own format (magic EC30A437 + tables) is refused on both sides, not taken as raw content
+    # zstd's dictionary magic (EC30A437) with a damaged header behind it is refused on both sides, not taken as raw content
+    # (well-formed dictionaries of that format: test_formatted_dictionaries below)
     fd = b"\x37\xa4\x30\xec" + bytes(range(200)) * 4
     dd = torch.from_numpy(np.frombuffer(fd, dtype=np.uint8).copy()).cuda()
-    out, ooff, olen, st = batch.decompress(torch.from_numpy(host).cuda(), offs, lens, cap, dictionary=dd)
-    torch.cuda.synchronize()
-    assert all(int(x) == 32 for x in st.cpu().numpy())                    # ZSTD_error_dictionary_corrupted's neighbourhood: KZE_DICT
-    with pytest.raises(RuntimeError, match="formatted zstd dictionaries"):
+    with pytest.raises(RuntimeError, match="header is damaged"):
+        batch.decompress(torch.from_numpy(host).cuda(), offs, lens, cap, dictionary=dd)
+    with pytest.raises(RuntimeError, match="header is damaged"):
         batch.compress(torch.from_numpy(host).cuda(), offs, torch.tensor([100] * 3, dtype=torch.int32).cuda(), dictionary=fd)
+
+
+def test_formatted_dictionaries(batch):
+    """ZstdCompressor(3, dictionary) / ZstdDecompressor(dictionary) with dictionaries in zstd's own format (magic EC30A437: Huffman and FSE
+    tables, repeat offsets, an ID, then content) -- two trained by libzstd's ZDICT, eight built to leave symbols out of their tables: every
+    committed frame of libzstd 1.5.7 (tests/golden/zstd_dict_formatted_golden.json) from the batch call, decoded back by the batch call
+    together with libzstd's level-19 frames, the streaming entry points, a mismatching dictionary."""
+    import hashlib
+    from kompressor_amd import ZstdCompressor, ZstdDecompressor
+    cases = helpers.formatted_dict_cases()
+    nframes = 0
+    for name, d, inputs, row in cases:
+        n = len(inputs)
+        lens = [len(p) for p in inputs]
+        stride = 131072 + 512
+        host = np.zeros(n * stride + 64, dtype=np.uint8)
+        for k, p in enumerate(inputs):
+            host[k * stride:k * stride + len(p)] = np.frombuffer(p, dtype=np.uint8)
+        src = torch.from_numpy(host).cuda()
+        offs = (torch.arange(n, dtype=torch.int64) * stride).cuda()
+        dst, ooff, olen = batch.compress(src, offs, torch.tensor(lens, dtype=torch.int32).cuda(), dictionary=d)
+        torch.cuda.synchronize()
+        dsth, ooffh, olenh = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+        frames = [dsth[int(ooffh[k]):int(ooffh[k]) + int(olenh[k])].tobytes() for k in range(n)]
+        for p, f, (flen, fsha) in zip(inputs, frames, row["frames"]):
+            assert len(f) == flen and hashlib.sha256(f).hexdigest() == fsha, (name, len(p))
+            nframes += 1
+        # and back, with libzstd's level-19 frames (its own choice of tables and "repeat" modes) among them
+        frames += [base64.b64decode(x) for x in row["level19"]]
+        plain = inputs + [inputs[i] for i in row["level19_inputs"]]
+        m = len(frames)
+        fh = np.zeros(m * stride + 64, dtype=np.uint8)
+        for k, f in enumerate(frames):
+            fh[k * stride:k * stride + len(f)] = np.frombuffer(f, dtype=np.uint8)
+        foffs = (torch.arange(m, dtype=torch.int64) * stride).cuda()
+        dd = torch.from_numpy(np.frombuffer(d, dtype=np.uint8).copy()).cuda()
+        out, o2, l2, st = batch.decompress(torch.from_numpy(fh).cuda(), foffs, torch.tensor([len(f) for f in frames], dtype=torch.int32).cuda(),
+                                           torch.tensor([max(len(p), 1) for p in plain], dtype=torch.int32).cuda(), dictionary=dd)
+        torch.cuda.synchronize()
+        out, o2, l2, st = out.cpu().numpy(), o2.cpu().numpy(), l2.cpu().numpy(), st.cpu().numpy()
+        for k, p in enumerate(plain):
+            assert int(st[k]) == 0 and out[int(o2[k]):int(o2[k]) + int(l2[k])].tobytes() == p, (name, k)
+    assert nframes == 200
+    # the streaming entry points (what the JNI binds): a context with the dictionary loaded, one slice per call
+    name, d, inputs, row = cases[0]
+    for i in (4, 9, 14, 17):
+        f = ZstdCompressor(dictionary=d).transform_bytes(inputs[i])
+        assert hashlib.sha256(f).hexdigest() == row["frames"][i][1], (name, i)
+        assert ZstdDecompressor(dictionary=d).transform_bytes(f) == inputs[i]
+    # a frame that names this dictionary's ID, decoded with another dictionary / a raw one / none: libzstd's "Dictionary mismatch"
+    f = ZstdCompressor(dictionary=d).transform_bytes(inputs[12])
+    for other in (cases[1][1], b"raw content, no magic " * 8, None):
+        with pytest.raises(RuntimeError, match="Dictionary mismatch"):
+            ZstdDecompressor(dictionary=other).transform_bytes(f)
 
 
 def test_compress_with_raw_dictionary(batch):

@@ -324,3 +324,28 @@ def test_buffered_oracle_against_live_libzstd_random_cuts():
         assert o.compress_buffered(d, True) == z.compress_streaming(d, [0, n], out_chunk=max(8192, n // 10)), name
         cuts = sorted({0, n, rng.randrange(1, n), rng.randrange(1, n), rng.randrange(1, n)})
         assert o.compress_buffered(d, False) == z.compress_streaming(d, cuts, out_chunk=8192), name
+
+
+def test_formatted_dictionaries_oracle_against_golden():
+    """Dictionaries in zstd's own format (trained by ZDICT, and built to leave symbols out): the restatement of ZSTD_loadCEntropy and of the
+    first block coded against the dictionary's tables gives libzstd 1.5.7's frames -- 200 committed ones, and the live library when it is here."""
+    import hashlib
+    o = helpers.oracle()
+    live = None
+    try:
+        from libzstd_ref import LibZstd, find_libzstd_157
+        live = LibZstd() if find_libzstd_157() is not None else None
+    except Exception:
+        live = None
+    n = 0
+    for name, d, inputs, row in helpers.formatted_dict_cases():
+        for p, (flen, fsha) in zip(inputs, row["frames"]):
+            f = o.compress_dict(p, d)[0]
+            assert len(f) == flen and hashlib.sha256(f).hexdigest() == fsha, (name, len(p))
+            if live is not None and len(p) in (7, 700, 30000):
+                assert live.compress_with_dict(p, d, 3) == f, (name, len(p))
+            n += 1
+    assert n == 200
+    # the magic with a damaged header: no frame (libzstd: "Dictionary is corrupted"), not raw content
+    with pytest.raises(RuntimeError):
+        o.compress_dict(b"abc" * 100, b"\x37\xa4\x30\xec" + bytes(range(200)) * 4)
