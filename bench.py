@@ -488,6 +488,8 @@ def main():
     ap.add_argument("--level", type=int, default=3, help="zstd level: 3 (BASELINE configs), 1 / 2 (strategy fast), 4 (its double-fast row: slices above 16 KiB up to 128 KiB), or a negative level (slices up to 128 KiB)")
     ap.add_argument("--dict-kib", type=int, default=0,
                     help="compress with a raw-content dictionary of this many KiB shared by all slices (ZstdCompressor(3, dictionary))")
+    ap.add_argument("--dict-trained", action="store_true",
+                    help="with --dict-kib: a dictionary in zstd's own format, trained by the box's libzstd 1.5.7 (ZDICT_trainFromBuffer) on other slices of the same corpus, instead of raw content")
     ap.add_argument("--slice-kib", type=int, default=64,
                     help="slice size in KiB (64 = BASELINE configs[1]; above 128 the frames have several blocks, up to 2048)")
     ap.add_argument("--deflate-level", type=int, default=None, help="zlib level of --mode deflate / inflate (1 .. 9, default 6 = BASELINE configs[4])")
@@ -720,6 +722,25 @@ def main():
     dictionary = None
     if args.dict_kib:
         dictionary = corpus.make(123456789, 1, args.dict_kib * 1024, mix=ord("T")).tobytes()
+        if args.dict_trained:
+            # what a user of small records does: zstd --train over a sample, ZstdCompressor(level, dictionary = the trained file)
+            import ctypes
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            from libzstd_ref import find_libzstd_157
+            zl = find_libzstd_157()
+            if zl is None:
+                print("bench.py --dict-trained: no libzstd 1.5.7 on this machine to train the dictionary with", file=sys.stderr); sys.exit(2)
+            ns = 2000
+            samples = corpus.make(777000, ns, SLICE if SLICE <= 16384 else 16384).tobytes()
+            per = len(samples) // ns
+            sizes = (ctypes.c_size_t * ns)(*([per] * ns))
+            outb = ctypes.create_string_buffer(args.dict_kib * 1024)
+            zl.ZDICT_trainFromBuffer.restype = ctypes.c_size_t
+            zl.ZDICT_trainFromBuffer.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+            dn = zl.ZDICT_trainFromBuffer(outb, args.dict_kib * 1024, samples, sizes, ns)
+            if zl.ZSTD_isError(dn):
+                print("bench.py --dict-trained: ZDICT_trainFromBuffer failed", file=sys.stderr); sys.exit(2)
+            dictionary = outb.raw[:dn]
         big = True                      # same reporting as the other one-launch-per-step paths (no per-kernel events)
 
     if args.level != 3:
@@ -931,7 +952,7 @@ def main():
                "value": round(world * in_bytes / (dt / args.steps) / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u8", "data": "synthetic",
-               "config": {"workload": (f"{n} x {args.slice_kib} KiB seeded mixed slices per GPU, ZstdCompressor(level=3, dictionary of {args.dict_kib} KiB), "
+               "config": {"workload": (f"{n} x {args.slice_kib} KiB seeded mixed slices per GPU, ZstdCompressor(level=3, {'trained (zstd-format) ' if args.dict_trained else 'raw-content '}dictionary of {args.dict_kib} KiB), "
                                        "bit-identical to libzstd 1.5.7") if dictionary else
                                       (f"north_star slice-size sweep: {n} x {args.slice_kib} KiB seeded mixed slices per GPU, ZstdCompressor(level=3) "
                                        "one-shot frames of several blocks as the reference's driver gets them (libzstd 1.5.7 with output "

@@ -16,6 +16,9 @@ run --level -1 --steps 3 --warmup 1 --no-cpu
 run --level -5 --steps 3 --warmup 1 --no-cpu
 run --dict-kib 16 --steps 3 --warmup 1 --no-cpu
 run --dict-kib 64 --slice-kib 8 --slices 262144 --steps 3 --warmup 1 --no-cpu
+run --dict-kib 64 --dict-trained --slice-kib 8 --slices 262144 --steps 3 --warmup 1 --no-cpu
+run --dict-kib 16 --dict-trained --slice-kib 2 --slices 524288 --steps 3 --warmup 1 --no-cpu
+run --slice-kib 2 --slices 524288 --steps 3 --warmup 1 --no-cpu --no-stream --no-pcie --no-extra
 run --slice-kib 128 --slices 32768 --steps 3 --warmup 1 --no-cpu
 run --slice-kib 256 --slices 32768 --steps 2 --warmup 1 --no-cpu
 run --slice-kib 1024 --slices 8192 --steps 2 --warmup 1

@@ -105,9 +105,22 @@ def with_dict(d, dic):
     return _tl.z.compress_with_dict(d, dic, 3)
 for k in ("KMP_MATCH_V2", "KMP_FUSE"): os.environ.pop(k, None)
 dict_idx = np.arange(0, N, 2)
-for dsize in (16384, 65536):
+def trained_dict(cap):
+    """a dictionary in zstd's own format from the box's library: ZDICT_trainFromBuffer over slices of this very batch"""
+    pick = [int(i) for i in range(1, N, 7) if 256 <= lens[i] <= 16384][:3000]
+    buf = b"".join(host[offs[i]:offs[i] + lens[i]].tobytes() for i in pick); sizes = (ctypes.c_size_t * len(pick))(*[int(lens[i]) for i in pick])
+    out = ctypes.create_string_buffer(cap)
+    lib.ZDICT_trainFromBuffer.restype = ctypes.c_size_t
+    lib.ZDICT_trainFromBuffer.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+    n_ = lib.ZDICT_trainFromBuffer(out, cap, buf, sizes, len(pick))
+    assert not lib.ZSTD_isError(n_), "ZDICT_trainFromBuffer failed"
+    return out.raw[:n_]
+for dsize in (16384, 65536, -8192, -110000):              # (negative: a trained dictionary of at most that many bytes)
     t0 = time.time()
-    dic = (corpus.make(4242 + seed, 1, dsize // 2, mix=ord("T")).tobytes() + corpus.make(4343 + seed, 1, dsize // 4, mix=ord("X")).tobytes()
+    if dsize < 0:
+        dic = trained_dict(-dsize)
+    else:
+      dic = (corpus.make(4242 + seed, 1, dsize // 2, mix=ord("T")).tobytes() + corpus.make(4343 + seed, 1, dsize // 4, mix=ord("X")).tobytes()
            + host[offs[5]:offs[5] + dsize // 4].tobytes()).ljust(dsize, b"\0")[:dsize]
     bdic = ZstdBatch(max_slices=len(dict_idx), max_slice_bytes=131072)
     sel = torch.from_numpy(dict_idx.astype(np.int64)).cuda()
@@ -127,7 +140,7 @@ for dsize in (16384, 65536):
     torch.cuda.synchronize()
     assert int(st.abs().sum().item()) == 0 and bool((l2 == d_len[sel]).all()), "decode with dictionary: status"
     bdic.close()
-    print(f"level 3 with a raw-content dictionary of {dsize} bytes: {len(dict_idx)} frames against libzstd 1.5.7, different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:8]]}  ({time.time() - t0:.0f} s)", flush=True)
+    print(f"level 3 with a {'trained (zstd-format)' if dsize < 0 else 'raw-content'} dictionary of {len(dic)} bytes: {len(dict_idx)} frames against libzstd 1.5.7, different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:8]]}  ({time.time() - t0:.0f} s)", flush=True)
 
 # raw DEFLATE (all nine levels over two seeds) against this machine's zlib, and inflate of what came out
 import zlib
