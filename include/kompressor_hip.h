@@ -50,12 +50,13 @@ typedef struct kmp_zstd_dctx kmp_zstd_dctx;
 KMP_API kmp_zstd_cctx* kmp_zstd_create_cctx(void);
 /* replaces ZSTD_freeCCtx              (Wrapper.cpp:19-27)  */
 KMP_API size_t kmp_zstd_free_cctx(kmp_zstd_cctx* cctx);
-/* replaces ZSTD_CCtx_setParameter     (Wrapper.cpp:29-39). Levels 1, 2, 3 (and 0 = default = 3)
- * run on the GPU (1 and 2: slices <= 128 KiB, no dictionary); other levels return (size_t)-40 "Unsupported parameter". */
+/* replaces ZSTD_CCtx_setParameter     (Wrapper.cpp:29-39). Levels -131072 .. -1, 1, 2, 3 (and 0 = default = 3) and 4 (in its double-fast
+ * size classes) run on the GPU (dictionaries: level 3 only); other levels return (size_t)-40 "Unsupported parameter". */
 KMP_API size_t kmp_zstd_cctx_set_parameter(kmp_zstd_cctx* cctx, int param, int value);
-/* replaces ZSTD_CCtx_loadDictionary   (Wrapper.cpp:41-56). Served:
- * raw-content dictionaries of 8 .. 130 560 bytes (no zstd dictionary magic) for slices <= 128 KiB; a formatted
- * dictionary or one outside that range returns (size_t)-40. */
+/* replaces ZSTD_CCtx_loadDictionary   (Wrapper.cpp:41-56). Served: dictionaries of 8 .. 130 560 bytes for slices <= 128 KiB, raw content
+ * or zstd's own format (magic EC30A437: what `zstd --train` / ZDICT_trainFromBuffer write -- its Huffman and FSE tables, repeat offsets
+ * and ID are loaded as libzstd's ZSTD_loadCEntropy does; a damaged header surfaces at the first frame as "Dictionary is corrupted");
+ * a dictionary outside that size range returns (size_t)-40. */
 KMP_API size_t kmp_zstd_cctx_load_dictionary(kmp_zstd_cctx* cctx, const void* dict, size_t dict_size);
 /* replaces ZSTD_compressStream2       (Wrapper.cpp:75-121, call at :112).
  * Same buffer semantics as ZSTD_inBuffer / ZSTD_outBuffer: `*_size` is the
@@ -78,8 +79,9 @@ KMP_API size_t kmp_zstd_compress_stream(kmp_zstd_cctx* cctx,
 KMP_API kmp_zstd_dctx* kmp_zstd_create_dctx(void);
 /* replaces ZSTD_freeDCtx              (Wrapper.cpp:132-140) */
 KMP_API size_t kmp_zstd_free_dctx(kmp_zstd_dctx* dctx);
-/* replaces ZSTD_DCtx_loadDictionary   (Wrapper.cpp:58-73): raw-content dictionaries (no zstd dictionary magic) are
- * served; a formatted dictionary returns (size_t)-40 */
+/* replaces ZSTD_DCtx_loadDictionary   (Wrapper.cpp:58-73): raw-content dictionaries and dictionaries in zstd's own format (their tables
+ * stand behind a frame's first block: tree-less literals and "repeat" sequence tables refer to them; a frame that names another
+ * dictionary's ID fails with "Dictionary mismatch"); a damaged header of that format returns (size_t)-64 as libzstd's DDict creation does */
 KMP_API size_t kmp_zstd_dctx_load_dictionary(kmp_zstd_dctx* dctx, const void* dict, size_t dict_size);
 /* replaces ZSTD_decompressStream      (Wrapper.cpp:142-187, call at :178).
  * Returns 0 when a frame is completely decoded and flushed, otherwise a
@@ -252,10 +254,14 @@ KMP_API int kmp_zstd_compress_batch_level(kmp_batch_ctx* ctx,
                                           uint32_t n,
                                           void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                           int level, void* hip_stream);
-/* same with a raw-content dictionary shared by all n slices (what ZstdCompressor(level, dictionary) does per slice:
+/* same with a dictionary shared by all n slices (what ZstdCompressor(level, dictionary) does per slice:
  * ZSTD_CCtx_loadDictionary, Wrapper.cpp:41-56, then the one-shot compress): frames are the ones libzstd 1.5.7 writes --
  * its CDict is built here on the host once per dictionary; slices up to 16 KiB are parsed against the attached CDict,
- * larger ones against its copied tables.  h_dict is HOST memory, 8 .. 130 560 bytes; slices <= 128 KiB. */
+ * larger ones against its copied tables.  h_dict is HOST memory, 8 .. 130 560 bytes; slices <= 128 KiB.
+ * The dictionary is raw content, or -- when it starts with the magic EC30A437 -- in zstd's own format (ZDICT / `zstd --train`): then
+ * matches are searched in its content part, the block is coded against its entropy tables (literals with its Huffman table when that
+ * is cheaper or the input is small, sequence tables it marks complete reused below 1 000 sequences), a frame starts with its repeat
+ * offsets and names its ID.  KMP_ERR_ARG when the magic is there and the header behind it is damaged. */
 KMP_API int kmp_zstd_compress_batch_dict(kmp_batch_ctx* ctx,
                                          const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                          uint32_t n,
@@ -277,9 +283,11 @@ KMP_API int kmp_zstd_decompress_batch(kmp_batch_ctx* ctx,
                                       void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                       uint32_t* d_out_len, uint32_t* d_status,
                                       void* hip_stream);
-/* same with a raw-content dictionary shared by all n frames: d_dict[0 .. dict_size) is the history before the first
- * byte of every frame (what ZSTD_DCtx_loadDictionary gives a decoder for a dictionary without the zstd magic;
- * reference: ZstdDecompressor(dictionary), Wrapper.cpp:58-73, test ZstdTest.kt:49-65) */
+/* same with a dictionary shared by all n frames (reference: ZstdDecompressor(dictionary), Wrapper.cpp:58-73, test ZstdTest.kt:49-65).
+ * Raw content: d_dict[0 .. dict_size) is the history before the first byte of every frame.  zstd's own format (magic EC30A437): the
+ * content part is that history, and the tables, repeat offsets and ID in front of it are what ZSTD_loadDEntropy makes of them (the
+ * dictionary's first 2 KiB are read back to the host once per dictionary).  status 32 ("Dictionary mismatch") for a frame whose header
+ * names another ID -- with a raw-content dictionary or none: any ID. */
 KMP_API int kmp_zstd_decompress_batch_dict(kmp_batch_ctx* ctx,
                                            const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                            uint32_t n,
