@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64) void k_table_probe(u32* p0, u32* p1, u32* p2, u
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
-extern "C" const char* kmp_version(void) { return "kompressor_hip 0.4 (gfx950; zstd levels -131072 .. -1 and 1 .. 3: frames and streams up to 1 GiB, raw-content dictionaries; level 4 in its double-fast size classes; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
+extern "C" const char* kmp_version(void) { return "kompressor_hip 0.4 (gfx950; zstd levels -131072 .. -1 and 1 .. 3: frames and streams up to 1 GiB, dictionaries (raw content and zstd format); level 4 in its double-fast size classes; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
 
 u32 env_u32(const char* name, u32 dflt)
 {
