@@ -1000,6 +1000,59 @@ static u32 select_encoding_prior(const u32* count, u32 max, size_t mostFrequent,
     return set_compressed;
 }
 
+/* ZSTD_selectEncodingType from strategy "lazy" on: the three candidates are priced -- the default table (cross entropy), a table of
+ * the block's own (its description + the entropy of the counts) -- and the cheaper one is taken (no previous table in a first block). */
+static u32 inv_prob_log256(u32 x)        /* kInverseProbabilityLog256: (unsigned)(-log2(x / 256) * 256) */
+{
+    static u32 tab[256]; static int ready = 0;
+    if (!ready) {
+        /* -log2(x/256)*256 = 256 * (8 - log2 x), by integer arithmetic on a fixed-point log2 (no libm in the oracle's build) */
+        u32 i;
+        tab[0] = 0;
+        for (i = 1; i < 256; i++) {
+            /* log2(i) in 40-bit fixed point by repeated squaring */
+            u64 m = (u64)i << 30; u32 e = 0; u64 frac = 0; int b;              /* m / 2^30 in [1, 2) */
+            while (m >= ((u64)2 << 30)) { m >>= 1; e++; }
+            for (b = 0; b < 40; b++) { m = (m * m) >> 30; frac <<= 1; if (m >= ((u64)2 << 30)) { m >>= 1; frac |= 1; } }
+            {   /* value = 256 * (8 - e - frac / 2^40), floored */
+                u64 const scaled = ((u64)(8 - e) << 40) - frac;          /* (8 - log2 i) in 40-bit fixed point */
+                tab[i] = (u32)((scaled * 256) >> 40);
+            }
+        }
+        ready = 1;
+    }
+    return tab[x];
+}
+static size_t entropy_cost(const u32* count, u32 max, size_t total)
+{
+    size_t cost = 0; u32 s;
+    for (s = 0; s <= max; s++) { u32 norm = (u32)((256 * (u64)count[s]) / total); if (count[s] != 0 && norm == 0) norm = 1; cost += count[s] * inv_prob_log256(norm); }
+    return cost >> 8;
+}
+static size_t cross_entropy_cost(const short* norm, u32 accuracyLog, const u32* count, u32 max)
+{
+    u32 const shift = 8 - accuracyLog; size_t cost = 0; u32 s;
+    for (s = 0; s <= max; s++) { u32 const normAcc = (norm[s] != -1) ? (u32)norm[s] : 1; cost += count[s] * inv_prob_log256(normAcc << shift); }
+    return cost >> 8;
+}
+static u32 select_encoding_cost(const u32* count, u32 max, size_t mostFrequent, size_t nbSeq, u32 FSELog, const short* defaultNorm, u32 defaultNormLog, int isDefaultAllowed)
+{
+    if (mostFrequent == nbSeq) return (isDefaultAllowed && nbSeq <= 2) ? set_basic : set_rle;
+    {
+        size_t const basicCost = isDefaultAllowed ? cross_entropy_cost(defaultNorm, defaultNormLog, count, max) : (size_t)-1;
+        short norm[64]; u8 wksp[512]; u32 cc[64]; u32 s; size_t ncount;
+        u32 const tableLog = fse_optimal_tablelog(FSELog, nbSeq, max, 2);
+        for (s = 0; s <= max; s++) cc[s] = count[s];
+        if (fse_normalize(norm, tableLog, cc, nbSeq, max, nbSeq >= 2048) == KERR) return set_compressed;
+        ncount = fse_write_ncount(wksp, sizeof(wksp), norm, max, tableLog);
+        {
+            size_t const compressedCost = (ncount << 3) + entropy_cost(count, max, nbSeq);
+            if (basicCost <= compressedCost) return set_basic;
+        }
+    }
+    return set_compressed;
+}
+
 /* returns header bytes written (KERR on error) and fills ct */
 static size_t build_seq_ctable(u8* dst, size_t cap, fse_ctable* ct, u32 FSELog, u32 type, u32* count, u32 max,
                                const u8* codeTable, size_t nbSeq, const short* defaultNorm, u32 defaultNormLog, u32 defaultMax)
@@ -1067,7 +1120,7 @@ static size_t compress_sequences(u8* dst, size_t cap, const seqstore* ss)
         u8* const seqHead = op++;
         u32 LLtype, Offtype, MLtype; size_t sz;
         { u32 max = 35; size_t const mf = hist_codes(count, &max, llCode, nbSeq);
-          LLtype = select_encoding_prior(count, max, mf, nbSeq, 6, 1, ss->strategy, g_seq_prior && g_seq_prior->valid[0]);
+          LLtype = ss->strategy >= 4 ? select_encoding_cost(count, max, mf, nbSeq, 9, LL_defaultNorm, 6, 1) : select_encoding_prior(count, max, mf, nbSeq, 6, 1, ss->strategy, g_seq_prior && g_seq_prior->valid[0]);
           if (LLtype == set_repeat) fse_build_ctable(&ctLL, g_seq_prior->norm[0], g_seq_prior->maxSym[0], g_seq_prior->log[0]);
           sz = build_seq_ctable(op, (size_t)(oend - op), &ctLL, 9, LLtype, count, max, llCode, nbSeq, LL_defaultNorm, 6, 35);
           if (sz == KERR) { free(llCode); return KERR; }
@@ -1075,14 +1128,14 @@ static size_t compress_sequences(u8* dst, size_t cap, const seqstore* ss)
           op += sz; }
         { u32 max = 31; size_t const mf = hist_codes(count, &max, ofCode, nbSeq);
           int const defaultAllowed = (max <= 28);
-          Offtype = select_encoding_prior(count, max, mf, nbSeq, 5, defaultAllowed, ss->strategy, g_seq_prior && g_seq_prior->valid[1]);
+          Offtype = ss->strategy >= 4 ? select_encoding_cost(count, max, mf, nbSeq, 8, OF_defaultNorm, 5, defaultAllowed) : select_encoding_prior(count, max, mf, nbSeq, 5, defaultAllowed, ss->strategy, g_seq_prior && g_seq_prior->valid[1]);
           if (Offtype == set_repeat) fse_build_ctable(&ctOF, g_seq_prior->norm[1], g_seq_prior->maxSym[1], g_seq_prior->log[1]);
           sz = build_seq_ctable(op, (size_t)(oend - op), &ctOF, 8, Offtype, count, max, ofCode, nbSeq, OF_defaultNorm, 5, 28);
           if (sz == KERR) { free(llCode); return KERR; }
           if (Offtype == set_compressed) lastCountSize = sz;
           op += sz; }
         { u32 max = 52; size_t const mf = hist_codes(count, &max, mlCode, nbSeq);
-          MLtype = select_encoding_prior(count, max, mf, nbSeq, 6, 1, ss->strategy, g_seq_prior && g_seq_prior->valid[2]);
+          MLtype = ss->strategy >= 4 ? select_encoding_cost(count, max, mf, nbSeq, 9, ML_defaultNorm, 6, 1) : select_encoding_prior(count, max, mf, nbSeq, 6, 1, ss->strategy, g_seq_prior && g_seq_prior->valid[2]);
           if (MLtype == set_repeat) fse_build_ctable(&ctML, g_seq_prior->norm[2], g_seq_prior->maxSym[2], g_seq_prior->log[2]);
           sz = build_seq_ctable(op, (size_t)(oend - op), &ctML, 9, MLtype, count, max, mlCode, nbSeq, ML_defaultNorm, 6, 52);
           if (sz == KERR) { free(llCode); return KERR; }
@@ -2859,4 +2912,246 @@ KREF_API size_t kref_zstd_fast_compress_buffered(u8* dst, size_t cap, const u8* 
     if (level == 2 && !unknown && srcSize > 131072 && srcSize <= 262144) return kref_zstd_fast_compress_big(dst, cap, src, srcSize, level, stream, emptyEnd);   /* (its double-fast row) */
     if (stream == 3 && !outChunk) outChunk = srcSize / 10 > 8192 ? srcSize / 10 : 8192;
     return fast_compress_buffered(dst, cap, src, srcSize, level, unknown ? 0 : stream == 0 ? 2 : 1, stream == 2 ? 1 : emptyEnd, stream == 3 ? outChunk : 0, unknown ? tailDirect : 0);
+}
+
+/* ================================================================== */
+/* Levels 5 .. 10 (and 4 .. 8 up to 16 KiB): strategies "greedy",      */
+/* "lazy", "lazy2" -- libzstd 1.5.7 zstd_lazy.c                        */
+/* ZSTD_compressBlock_lazy_generic with depth 0 / 1 / 2 over            */
+/*  * the row-based match finder (ZSTD_RowFindBestMatch: windowLog     */
+/*    above 14 on a machine with 128-bit vectors, which is where the    */
+/*    reference's JNI library runs), or                                 */
+/*  * the hash-chain match finder (ZSTD_HcFindBestMatch: windowLog up   */
+/*    to 14, i.e. inputs up to 16 KiB).                                 */
+/* One block: inputs up to 128 KiB, no dictionary, first block of a     */
+/* frame.  Both finders insert every position they pass (rows keep the  */
+/* newest 15 / 31 / 63 per row, tagged with 8 more hash bits; chains    */
+/* keep everything) -- except in "lazy skipping" (long stretches        */
+/* without a match: only searched positions go in) and behind matches   */
+/* longer than 384 (the row finder inserts the first 96 and the last    */
+/* 32 positions only).                                                  */
+/* ================================================================== */
+typedef struct { u32 W, C, H, S, mml, strat; } kref_lpar;       /* strat: 3 greedy, 4 lazy, 5 lazy2 */
+/* ZSTD_getCParams(level, n, 0) for these levels; 0 when the level is another strategy at this size */
+static int lazy_params(int level, size_t n, kref_lpar* p)
+{
+    u32 srcLog, tW;
+    if (n == 0 || n > 131072) return 0;
+    if (n <= 16384) {
+        static const u32 S16[9] = { 0, 0, 0, 0, 4, 3, 4, 6, 8 }; static const u32 ST16[9] = { 0, 0, 0, 0, 3, 4, 5, 5, 5 };
+        if (level < 4 || level > 8) return 0;
+        tW = 14; p->C = 14; p->H = 14; p->S = S16[level]; p->mml = 4; p->strat = ST16[level];
+    } else {
+        static const u32 S128[11] = { 0, 0, 0, 0, 0, 3, 3, 3, 4, 5, 6 }; static const u32 ST128[11] = { 0, 0, 0, 0, 0, 3, 4, 5, 5, 5, 5 };
+        if (level < 5 || level > 10) return 0;
+        tW = 17; p->C = 16; p->H = 17; p->S = S128[level]; p->mml = 4; p->strat = ST128[level];
+    }
+    srcLog = (n < 64) ? 6 : hb32((u32)(n - 1)) + 1;
+    p->W = tW < srcLog ? tW : srcLog;
+    if (p->H > p->W + 1) p->H = p->W + 1;
+    if (p->C > p->W) p->C = p->W;
+    if (p->W < 10) p->W = 10;
+    return 1;
+}
+KREF_API int kref_params_lazy(int level, size_t n, u32* out6)
+{
+    kref_lpar p; if (!lazy_params(level, n, &p)) return 0;
+    out6[0] = p.W; out6[1] = p.C; out6[2] = p.H; out6[3] = p.S; out6[4] = p.mml; out6[5] = p.strat; return 1;
+}
+
+typedef struct {
+    const u8* base;              /* index i <-> base[i]: the input's first byte has index 2 */
+    const u8* iend;
+    u32* hashTable; u32* chainTable; u8* tagTable;
+    u32 nextToUpdate; int lazySkipping;
+    u32 rowLog, rowHashLog, S, C, H, mls; int rows;
+} kref_lazyms;
+
+static u32 lz_hash(const u8* p, u32 hBits, u32 mls) { return (u32)hash_short(p, hBits, mls); }
+static u32 row_next_index(u8* tagRow, u32 rowMask) { u32 next = ((u32)*tagRow - 1u) & rowMask; next += (next == 0) ? rowMask : 0; *tagRow = (u8)next; return next; }
+static void row_insert(kref_lazyms* ms, u32 idx)
+{
+    u32 const hash = lz_hash(ms->base + idx, ms->rowHashLog + 8, ms->mls);
+    u32 const relRow = (hash >> 8) << ms->rowLog;
+    u32 const pos = row_next_index(ms->tagTable + relRow, (1u << ms->rowLog) - 1);
+    ms->tagTable[relRow + pos] = (u8)hash; ms->hashTable[relRow + pos] = idx;
+}
+/* ZSTD_row_update_internal: everything from nextToUpdate up to (not including) target goes in; a gap above 384: its first 96 and last 32 */
+static void row_update(kref_lazyms* ms, u32 target)
+{
+    u32 idx = ms->nextToUpdate;
+    if (target - idx > 384) { u32 const bound = idx + 96; for (; idx < bound; idx++) row_insert(ms, idx); idx = target - 32; }
+    for (; idx < target; idx++) row_insert(ms, idx);
+    ms->nextToUpdate = target;
+}
+/* ZSTD_RowFindBestMatch: the row's entries with the position's tag, newest first, at most 1 << min(searchLog, rowLog) of them; the
+ * position itself goes into the row before they are compared; the longest wins, the newer one among equals */
+static size_t row_find(kref_lazyms* ms, const u8* ip, size_t* offBasePtr)
+{
+    u32 const curr = (u32)(ip - ms->base), rowEntries = 1u << ms->rowLog, rowMask = rowEntries - 1;
+    u32 const capped = ms->S < ms->rowLog ? ms->S : ms->rowLog; u32 nbAttempts = 1u << capped;
+    u32 const lowLimit = IDX0; size_t ml = 4 - 1; u32 hash, buf[64], nb = 0, k;
+    if (!ms->lazySkipping) row_update(ms, curr); else ms->nextToUpdate = curr;
+    hash = lz_hash(ip, ms->rowHashLog + 8, ms->mls);
+    {
+        u32 const relRow = (hash >> 8) << ms->rowLog; u8 const tag = (u8)hash;
+        u32* const row = ms->hashTable + relRow; u8* const tagRow = ms->tagTable + relRow;
+        u32 const head = (u32)tagRow[0] & rowMask;
+        for (k = 0; k < rowEntries && nbAttempts > 0; k++) {
+            u32 const matchPos = (head + k) & rowMask;
+            if (tagRow[matchPos] != tag) continue;
+            if (matchPos == 0) continue;
+            if (row[matchPos] < lowLimit) break;
+            buf[nb++] = row[matchPos]; nbAttempts--;
+        }
+        { u32 const pos = row_next_index(tagRow, rowMask); tagRow[pos] = tag; row[pos] = ms->nextToUpdate++; }
+    }
+    for (k = 0; k < nb; k++) {
+        const u8* const match = ms->base + buf[k]; size_t cur = 0;
+        if (rd32(match + ml - 3) == rd32(ip + ml - 3)) cur = count_eq(ip, match, ms->iend);
+        if (cur > ml) { ml = cur; *offBasePtr = (size_t)(curr - buf[k]) + 3; if (ip + cur == ms->iend) break; }
+    }
+    return ml;
+}
+/* ZSTD_HcFindBestMatch: the chain of earlier positions with the same hash, newest first, 1 << searchLog of them at most */
+static size_t hc_find(kref_lazyms* ms, const u8* ip, size_t* offBasePtr)
+{
+    u32 const curr = (u32)(ip - ms->base), chainSize = 1u << ms->C, chainMask = chainSize - 1;
+    u32 const lowLimit = IDX0, minChain = curr > chainSize ? curr - chainSize : 0; u32 nbAttempts = 1u << ms->S; size_t ml = 4 - 1; u32 matchIndex;
+    {   /* ZSTD_insertAndFindFirstIndex_internal */
+        u32 idx = ms->nextToUpdate;
+        while (idx < curr) {
+            u32 const h = lz_hash(ms->base + idx, ms->H, ms->mls);
+            ms->chainTable[idx & chainMask] = ms->hashTable[h]; ms->hashTable[h] = idx; idx++;
+            if (ms->lazySkipping) break;
+        }
+        ms->nextToUpdate = curr;
+        matchIndex = ms->hashTable[lz_hash(ip, ms->H, ms->mls)];
+    }
+    for (; (matchIndex >= lowLimit) & (nbAttempts > 0); nbAttempts--) {
+        const u8* const match = ms->base + matchIndex; size_t cur = 0;
+        if (rd32(match + ml - 3) == rd32(ip + ml - 3)) cur = count_eq(ip, match, ms->iend);
+        if (cur > ml) { ml = cur; *offBasePtr = (size_t)(curr - matchIndex) + 3; if (ip + cur == ms->iend) break; }
+        if (matchIndex <= minChain) break;
+        matchIndex = ms->chainTable[matchIndex & chainMask];
+    }
+    return ml;
+}
+static size_t lazy_search(kref_lazyms* ms, const u8* ip, size_t* offBasePtr) { return ms->rows ? row_find(ms, ip, offBasePtr) : hc_find(ms, ip, offBasePtr); }
+
+/* ZSTD_compressBlock_lazy_generic (noDict), depth = strat - 3.  src: the whole input = the frame's first block.  Returns the last literals. */
+static size_t lazy_block(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize, kref_lazyms* ms, u32 depth)
+{
+    const u8* const istart = src; const u8* ip = istart; const u8* anchor = istart; const u8* const iend = istart + srcSize;
+    const u8* const ilimit = ms->rows ? iend - 8 - 8 : iend - 8;
+    const u8* const prefixLowest = istart;
+    u32 offset_1 = rep[0], offset_2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0;
+    ip += 1;                                           /* dictAndPrefixLength == 0 */
+    { u32 const maxRep = (u32)(ip - istart); if (offset_2 > maxRep) { offsetSaved2 = offset_2; offset_2 = 0; } if (offset_1 > maxRep) { offsetSaved1 = offset_1; offset_1 = 0; } }
+    ms->lazySkipping = 0;
+    while (ip < ilimit) {
+        size_t matchLength = 0, offBase = 1; const u8* start = ip + 1;
+        if ((offset_1 > 0) && (rd32(ip + 1 - offset_1) == rd32(ip + 1))) {
+            matchLength = count_eq(ip + 1 + 4, ip + 1 + 4 - offset_1, iend) + 4;
+            if (depth == 0) goto _storeSequence;
+        }
+        {   size_t offbaseFound = 999999999;
+            size_t const ml2 = lazy_search(ms, ip, &offbaseFound);
+            if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = offbaseFound; }
+        }
+        if (matchLength < 4) {
+            size_t const step = ((size_t)(ip - anchor) >> 8) + 1;          /* kSearchStrength */
+            ip += step;
+            ms->lazySkipping = step > 8;                                    /* kLazySkippingStep */
+            continue;
+        }
+        if (depth >= 1)
+        while (ip < ilimit) {
+            ip++;
+            if ((offBase) && ((offset_1 > 0) && (rd32(ip) == rd32(ip - offset_1)))) {
+                size_t const mlRep = count_eq(ip + 4, ip + 4 - offset_1, iend) + 4;
+                int const gain2 = (int)(mlRep * 3);
+                int const gain1 = (int)(matchLength * 3 - hb32((u32)offBase) + 1);
+                if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
+            }
+            {   size_t ofbCandidate = 999999999;
+                size_t const ml2 = lazy_search(ms, ip, &ofbCandidate);
+                int const gain2 = (int)(ml2 * 4 - hb32((u32)ofbCandidate));
+                int const gain1 = (int)(matchLength * 4 - hb32((u32)offBase) + 4);
+                if ((ml2 >= 4) && (gain2 > gain1)) { matchLength = ml2; offBase = ofbCandidate; start = ip; continue; }
+            }
+            if ((depth == 2) && (ip < ilimit)) {
+                ip++;
+                if ((offBase) && ((offset_1 > 0) && (rd32(ip) == rd32(ip - offset_1)))) {
+                    size_t const mlRep = count_eq(ip + 4, ip + 4 - offset_1, iend) + 4;
+                    int const gain2 = (int)(mlRep * 4);
+                    int const gain1 = (int)(matchLength * 4 - hb32((u32)offBase) + 1);
+                    if ((mlRep >= 4) && (gain2 > gain1)) { matchLength = mlRep; offBase = 1; start = ip; }
+                }
+                {   size_t ofbCandidate = 999999999;
+                    size_t const ml2 = lazy_search(ms, ip, &ofbCandidate);
+                    int const gain2 = (int)(ml2 * 4 - hb32((u32)ofbCandidate));
+                    int const gain1 = (int)(matchLength * 4 - hb32((u32)offBase) + 7);
+                    if ((ml2 >= 4) && (gain2 > gain1)) { matchLength = ml2; offBase = ofbCandidate; start = ip; continue; }
+                }
+            }
+            break;
+        }
+        if (offBase > 3) {              /* a real offset: catch up, then it becomes the newest repeat offset */
+            size_t const off = offBase - 3;
+            while (((start > anchor) & (start - off > prefixLowest)) && (start[-1] == (start - off)[-1])) { start--; matchLength++; }
+            offset_2 = offset_1; offset_1 = (u32)off;
+        }
+_storeSequence:
+        {   size_t const litLength = (size_t)(start - anchor);
+            store_seq(ss, litLength, anchor, (u32)offBase, matchLength);
+            anchor = ip = start + matchLength;
+        }
+        if (ms->lazySkipping) ms->lazySkipping = 0;
+        while (((ip <= ilimit) & (offset_2 > 0)) && (rd32(ip) == rd32(ip - offset_2))) {
+            matchLength = count_eq(ip + 4, ip + 4 - offset_2, iend) + 4;
+            { u32 const t = offset_2; offset_2 = offset_1; offset_1 = t; }
+            store_seq(ss, 0, anchor, 1, matchLength);
+            ip += matchLength; anchor = ip;
+        }
+    }
+    offsetSaved2 = ((offsetSaved1 != 0) && (offset_1 != 0)) ? offsetSaved1 : offsetSaved2;
+    rep[0] = offset_1 ? offset_1 : offsetSaved1;
+    rep[1] = offset_2 ? offset_2 : offsetSaved2;
+    return (size_t)(iend - anchor);
+}
+
+KREF_API size_t kref_zstd_lazy_compress(u8* dst, size_t cap, const u8* src, size_t srcSize, int level)
+{
+    kref_lpar P; kref_lazyms ms; seqstore ss; u32 rep[3] = { 1, 4, 8 }; kref_hufstate h0, h1; kref_seq* seqs; u8* lits; u8* padded;
+    size_t pos, lastLL, litC, seqC, cSize = 0; u8* body;
+    if (!lazy_params(level, srcSize, &P)) return KERR;
+    if (cap < kref_compress_bound(srcSize)) return KERR;
+    pos = write_frame_header(dst, srcSize, P.W);
+    body = dst + pos + 3;
+    seqs = (kref_seq*)malloc(sizeof(kref_seq) * ((128 << 10) / 3 + 8)); lits = (u8*)malloc((128 << 10) + 32);
+    padded = (u8*)malloc(srcSize + 2 + 32); memset(padded, 0, srcSize + 2 + 32); memcpy(padded + 2, src, srcSize);      /* index 2 = first byte */
+    memset(&ss, 0, sizeof(ss)); ss.seqs = seqs; ss.lits = lits; ss.strategy = (int)P.strat;
+    memset(&ms, 0, sizeof(ms));
+    ms.base = padded; ms.iend = padded + 2 + srcSize; ms.nextToUpdate = IDX0; ms.S = P.S; ms.C = P.C; ms.H = P.H; ms.mls = P.mml < 4 ? 4 : P.mml > 6 ? 6 : P.mml;
+    ms.rows = P.W > 14;
+    ms.rowLog = P.S < 4 ? 4 : P.S > 6 ? 6 : P.S; ms.rowHashLog = P.H - ms.rowLog;
+    ms.hashTable = (u32*)calloc((size_t)1 << P.H, sizeof(u32)); ms.chainTable = (u32*)calloc((size_t)1 << P.C, sizeof(u32)); ms.tagTable = (u8*)calloc((size_t)1 << P.H, 1);
+    if (srcSize >= 7) {
+        lastLL = lazy_block(&ss, rep, padded + 2, srcSize, &ms, P.strat - 3);
+        memcpy(ss.lits + ss.litSize, src + srcSize - lastLL, lastLL); ss.litSize += lastLL;
+        h0.valid = 0; memset(&h0.ct, 0, sizeof(h0.ct));
+        {
+            int const suspect = (ss.nbSeq == 0) || (ss.litSize / ss.nbSeq >= 20);
+            litC = compress_literals(body, cap - pos - 3, ss.lits, ss.litSize, suspect, &h0, &h1);
+            if (litC != KERR) {
+                seqC = compress_sequences(body + litC, cap - pos - 3 - litC, &ss);
+                if (seqC != KERR && seqC != 0) { cSize = litC + seqC; if (cSize >= srcSize - min_gain(srcSize)) cSize = 0; }
+            }
+        }
+    }
+    free(ms.hashTable); free(ms.chainTable); free(ms.tagTable); free(seqs); free(lits); free(padded);
+    if (cSize == 0) { wr24(dst + pos, 1 + (0 << 1) + (u32)(srcSize << 3)); memcpy(body, src, srcSize); return pos + 3 + srcSize; }
+    wr24(dst + pos, 1 + (2 << 1) + (u32)(cSize << 3));
+    return pos + 3 + cSize;
 }
