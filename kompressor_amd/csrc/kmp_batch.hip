@@ -8,6 +8,7 @@
 #endif
 #include "zstd_entropy.h"
 #include "zstd_match_dict.h"
+#include "zstd_lazy.h"
 #include "zstd_match_fast.h"
 #include "zstd_cdict_host.h"
 #include "zstd_decode.h"
@@ -30,6 +31,9 @@ template <int G, int R>
 __global__ __launch_bounds__(64, 4) void k_zstd_match2(KMatchArgs a) { zstd_match2_body<G, R>(a); }
 #endif
 __global__ __launch_bounds__(64, 4) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
+// zstd levels 5 .. 10 (greedy / lazy / lazy2: zstd_lazy.h)
+__global__ __launch_bounds__(256) void k_zstd_lazy_sort(KLazyArgs a) { zstd_lazy_sort_body(a); }
+__global__ __launch_bounds__(64, 2) void k_zstd_lazy(KLazyArgs a) { zstd_lazy_body(a); }
 // ... of a batch parsed against a formatted dictionary: its tables as the block's predecessor, its ID in the frame header
 __global__ __launch_bounds__(64, 4) void k_zstd_entropy_prior(KEntropyArgs a) { zstd_entropy_body<true>(a); }
 #ifdef KMP_ABLATIONS
@@ -515,6 +519,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     (void)hipFree(c->tables_flat); (void)hipFree(c->team_epoch_flat);
     (void)hipFree(c->team_epoch); (void)hipFree(c->tables4); (void)hipFree(c->epoch4); (void)hipFree(c->big_tables4);
     (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS); (void)hipFree(c->d_prior); (void)hipFree(c->d_dprior);
+    (void)hipFree(c->lz_srt); (void)hipFree(c->lz_sb); (void)hipFree(c->lz_wr);
     (void)hipFree(c->fstate); (void)hipFree(c->hufct); (void)hipFree(c->big_tables); (void)hipFree(c->remaining); (void)hipFree(c->big_counters); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { if (c->evm[i][j]) (void)hipEventDestroy(c->evm[i][j]); if (c->eve[i][j]) (void)hipEventDestroy(c->eve[i][j]); }
@@ -668,11 +673,58 @@ static int flat_tables(kmp_batch_ctx* c, u32** tables, u32** epochs)
 // ---- levels 1 and 2 -------------------------------------------------------------------------------------
 static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream, int level);
+// ---- levels 5 .. 10: strategies greedy / lazy / lazy2 (zstd_lazy.h), slices of one block ------------------------------------------------
+// The batch goes through in pieces that share one workspace (16 bytes a position: the sorted positions, their first bytes, where each
+// position stands): sort, then the wave-per-slice parse; the entropy kernel runs once over the whole batch.
+static int zstd_compress_lazy(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream, int level)
+{
+    if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_level: null argument"; return KMP_ERR_ARG; }
+    if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_level: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
+    if (c->big) { g_last_error = "kmp_zstd_compress_batch_level: levels 5 .. 10 are served for slices up to 128 KiB"; return KMP_ERR_CAPACITY; }
+    if (n == 0) return KMP_OK;
+    hipStream_t const st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->lz_srt) {
+        u32 const pos_cap = (c->max_slice_bytes + 63u) & ~63u;
+        u32 cap = (u32)((1ull << 30) / pos_cap); if (cap > 16384u) cap = 16384u; if (cap < 1u) cap = 1u;
+        u32 const chunk = c->max_slices < cap ? c->max_slices : cap;
+        HIP_TRY(hipMalloc((void**)&c->lz_srt, (size_t)chunk * pos_cap * sizeof(u32)));
+        if (hipMalloc((void**)&c->lz_sb, (size_t)chunk * pos_cap * sizeof(u64)) != hipSuccess || hipMalloc((void**)&c->lz_wr, (size_t)chunk * pos_cap * sizeof(u32)) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipFree(c->lz_srt); (void)hipFree(c->lz_sb); c->lz_srt = nullptr; c->lz_sb = nullptr;
+            g_last_error = "kmp_zstd_compress_batch_level: no memory for the workspace of levels 5 .. 10"; return KMP_ERR_HIP;
+        }
+        c->lz_pos_cap = pos_cap; c->lz_chunk = chunk;
+    }
+    KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
+    for (u32 first = 0; first < n; first += c->lz_chunk) {
+        u32 const m = (n - first < c->lz_chunk) ? n - first : c->lz_chunk;
+        KLazyArgs g;
+        g.src = (const u8*)d_src; g.in_off = d_in_off + first; g.in_len = c->len_ok + first; g.n_slices = m;
+        g.srt = c->lz_srt; g.sb = c->lz_sb; g.wr = c->lz_wr; g.pos_cap = c->lz_pos_cap;
+        g.seqs = c->seqs + (size_t)first * c->seq_cap; g.seq_cap = c->seq_cap; g.meta = c->meta + first; g.level = (u32)level;
+        hipLaunchKernelGGL(k_zstd_lazy_sort, dim3(m), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(k_zstd_lazy, dim3(m), dim3(64), 0, st, g);
+        HIP_TRY(hipGetLastError());
+    }
+    KEntropyArgs e;
+    e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = c->len_ok; e.n_slices = n;
+    e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
+    e.scratch = c->scratch; e.scratch_words = c->scratch_words;
+    e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
+    e.flags = 8u | ((u32)level << 12);           // literals are gathered by the entropy kernel; the level: it derives each slice's strategy from it
+    hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), 0, st, e);
+    HIP_TRY(hipGetLastError());
+    c->last_chunks = 1;
+    return batch_end(c, st, d_in_len, n, c->max_slice_bytes, d_out_len, c->meta);
+}
+
 extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                              uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int level, void* hip_stream)
 {
     if (level == 3 || level == 0) return kmp_zstd_compress_batch(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, hip_stream);
     if (level == 4) return zstd_compress_dfast(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, hip_stream, 4);
+    if (level >= 5 && level <= 10) return zstd_compress_lazy(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, hip_stream, level);
     bool const neg = level < 0;                // negative levels: strategy "fast" with a step of 1 - level, literals left uncompressed
     if ((level != 1 && level != 2 && !neg) || level < -131072) { g_last_error = "kmp_zstd_compress_batch_level: levels -131072 .. -1, 1, 2, 3 and (slices above 16 KiB up to 128 KiB) 4 are served"; return KMP_ERR_ARG; }
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_level: null argument"; return KMP_ERR_ARG; }

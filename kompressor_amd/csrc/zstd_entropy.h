@@ -28,7 +28,7 @@ struct KEntropyArgs {
     u8* dst; const u64* out_off; u32* out_len;
     const KDictPrior* prior = nullptr;       // k_zstd_entropy_prior only: the formatted dictionary's tables
     u32 flags;                               // timing experiments only (results become wrong): 1 no literal coding, 2 no sequence coding (timing experiments, results become wrong);
-                                             // 8: the match kernel copied no literals, gather them here; 32: strategy "fast" (levels 1, 2);
+                                             // 8: the match kernel copied no literals, gather them here; 32: strategy "fast" (levels 1, 2); bits 8 .. 10: the strategy's number when it is another (3 greedy, 4 lazy, 5 lazy2);
                                              // 64: literals are left uncompressed (negative levels: ZSTD_literalsCompressionIsDisabled)
 };
 
@@ -791,10 +791,49 @@ KX_DEV u32 kx_select_encoding(u32 mostFrequent, u32 nbSeq, u32 defaultNormLog, b
 // one lane per symbol type (t = 0 LL, 1 OF, 2 ML): choose the mode, write the table
 // description into lds.ncbuf[t], build the encoding table. Returns description
 // bytes (KXE_ERR on error).
+// ---- ZSTD_selectEncodingType from strategy "lazy" on: the candidates are priced, the cheapest is taken ---------------------
+// kInverseProbabilityLog256[x] = floor(-log2(x / 256) * 256): the cost, in 1/256 bits, of a symbol of probability x / 256
+KX_DEV u32 kx_inv_prob_log256(u32 x)
+{
+    static const u16 tab[256] = {
+        0, 2048, 1792, 1642, 1536, 1453, 1386, 1329, 1280, 1236, 1197, 1162, 1130, 1100, 1073, 1047,
+        1024, 1001, 980, 960, 941, 923, 906, 889, 874, 859, 844, 830, 817, 804, 791, 779,
+        768, 756, 745, 734, 724, 714, 704, 694, 685, 676, 667, 658, 650, 642, 633, 626,
+        618, 610, 603, 595, 588, 581, 574, 567, 561, 554, 548, 542, 535, 529, 523, 517,
+        512, 506, 500, 495, 489, 484, 478, 473, 468, 463, 458, 453, 448, 443, 438, 434,
+        429, 424, 420, 415, 411, 407, 402, 398, 394, 390, 386, 382, 377, 373, 370, 366,
+        362, 358, 354, 350, 347, 343, 339, 336, 332, 329, 325, 322, 318, 315, 311, 308,
+        305, 302, 298, 295, 292, 289, 286, 282, 279, 276, 273, 270, 267, 264, 261, 258,
+        256, 253, 250, 247, 244, 241, 239, 236, 233, 230, 228, 225, 222, 220, 217, 215,
+        212, 209, 207, 204, 202, 199, 197, 194, 192, 190, 187, 185, 182, 180, 178, 175,
+        173, 171, 168, 166, 164, 162, 159, 157, 155, 153, 151, 149, 146, 144, 142, 140,
+        138, 136, 134, 132, 130, 128, 126, 123, 121, 119, 117, 115, 114, 112, 110, 108,
+        106, 104, 102, 100, 98, 96, 94, 93, 91, 89, 87, 85, 83, 82, 80, 78,
+        76, 74, 73, 71, 69, 67, 66, 64, 62, 61, 59, 57, 55, 54, 52, 50,
+        49, 47, 46, 44, 42, 41, 39, 37, 36, 34, 33, 31, 30, 28, 26, 25,
+        23, 22, 20, 19, 17, 16, 14, 13, 11, 10, 8, 7, 5, 4, 2, 1 };
+    return tab[x];
+}
+// ZSTD_entropyCost: the block's own distribution, probabilities in 1/256 (a symbol that occurs counts at least 1 / 256)
+KX_DEV u32 kx_entropy_cost(const u32* count, u32 max, u32 total)
+{
+    u32 cost = 0;
+    for (u32 s = 0; s <= max; s++) { u32 norm = (256u * count[s]) / total; if (count[s] != 0 && norm == 0) norm = 1; cost += count[s] * kx_inv_prob_log256(norm); }
+    return cost >> 8;
+}
+// ZSTD_crossEntropyCost: coded with the default table
+KX_DEV u32 kx_cross_entropy_cost(const short* dnorm, u32 accuracyLog, const u32* count, u32 max)
+{
+    u32 const shift = 8 - accuracyLog; u32 cost = 0;
+    for (u32 s = 0; s <= max; s++) { u32 const normAcc = (dnorm[s] != -1) ? (u32)dnorm[s] : 1u; cost += count[s] * kx_inv_prob_log256(normAcc << shift); }
+    return cost >> 8;
+}
+
 #define KSET_REPEAT 3u
 KX_DEV u32 kx_build_seq_table(KEntropyLds& lds, int t, u32* count, u32 nbSeq, u32 lastCode, u32 firstCode,
-                              u32& typeOut, KFseCT& ct, u32 mult, const KDictPrior* prior = nullptr)
+                              u32& typeOut, KFseCT& ct, u32 strat, const KDictPrior* prior = nullptr)
 {
+    u32 const mult = 10u - strat;             // (ZSTD_fast 1, ZSTD_dfast 2, ZSTD_greedy 3; from ZSTD_lazy = 4 on the choice is by price)
     static const short LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2, 2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
     static const short ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,
                                               1,1,1,1,1,1,1,1, 1,1,1,1,1,1,-1,-1, -1,-1,-1,-1,-1 };
@@ -808,7 +847,19 @@ KX_DEV u32 kx_build_seq_table(KEntropyLds& lds, int t, u32* count, u32 nbSeq, u3
     while (max > 0 && !count[max]) max--;
     for (u32 s = 0; s <= max; s++) if (count[s] > mostFrequent) mostFrequent = count[s];
     bool const defaultAllowed = (t != 1) || (max <= 28);
+    const short* const dnorm = (t == 0) ? LL_defaultNorm : (t == 1) ? OF_defaultNorm : ML_defaultNorm;
     u32 type = kx_select_encoding(mostFrequent, nbSeq, defaultNormLog, defaultAllowed, mult);
+    if (strat >= 4u && mostFrequent != nbSeq) {
+        // the default table against a table of the block's own: its description (ZSTD_NCountCost: normalised over all nbSeq codes, written
+        // out to be measured) plus the entropy of the counts; no previous table in a first block
+        u32 const basicCost = defaultAllowed ? kx_cross_entropy_cost(dnorm, defaultNormLog, count, max) : 0xFFFFFFFFu;
+        u32 const tl = kfse_optimal_tablelog(FSELog, nbSeq, max, 2);
+        type = KSET_COMPRESSED;
+        if (kfse_normalize(norm, tl, count, nbSeq, max, nbSeq >= 2048) != KXE_ERR) {
+            u32 const nc = kfse_write_ncount(op, norm, max, tl);
+            if (nc != KXE_ERR && basicCost <= (nc << 3) + kx_entropy_cost(count, max, nbSeq)) type = KSET_BASIC;
+        }
+    }
     // ZSTD_selectEncodingType below strategy "lazy": a table that is valid as it stands (only a dictionary's can be) is reused for fewer than
     // 1 000 sequences, unless one code makes up the whole block or the default table is not allowed
     if (prior && prior->seqValid[t] && mostFrequent != nbSeq && defaultAllowed && nbSeq < 1000u) type = KSET_REPEAT;
@@ -822,8 +873,7 @@ KX_DEV u32 kx_build_seq_table(KEntropyLds& lds, int t, u32* count, u32 nbSeq, u3
     }
     if (type == KSET_RLE) { kfse_build_ctable_rle(ct, max); *op = (u8)firstCode; return 1; }
     if (type == KSET_BASIC) {
-        const short* dn = (t == 0) ? LL_defaultNorm : (t == 1) ? OF_defaultNorm : ML_defaultNorm;
-        for (u32 s = 0; s <= defaultMax; s++) norm[s] = dn[s];
+        for (u32 s = 0; s <= defaultMax; s++) norm[s] = dnorm[s];
         kfse_build_ctable(ct, norm, defaultMax, defaultNormLog, lds.cumul[t], kxe_tsym(lds, t));
         return 0;
     }
@@ -879,7 +929,7 @@ KX_DEV u32 kzstd_sequences(KEntropyLds& lds, u8* dst, const KSeq* seqs, u32 nbSe
         if (lane < 3) {
             u32 const lastCode = lane == 0 ? cl.ll : lane == 1 ? cl.of : cl.ml;
             u32 const firstCode = lane == 0 ? cf.ll : lane == 1 ? cf.of : cf.ml;
-            mySz = kx_build_seq_table(lds, lane, lds.hist + 64 * lane, nbSeq, lastCode, firstCode, myType, ct, (xflags & 32u) ? 9u : 8u, prior);
+            mySz = kx_build_seq_table(lds, lane, lds.hist + 64 * lane, nbSeq, lastCode, firstCode, myType, ct, (xflags >> 8) ? (xflags >> 8) & 7u : ((xflags & 32u) ? 1u : 2u), prior);
         }
     }
     kx_sync();
@@ -1096,7 +1146,11 @@ KX_DEV void zstd_entropy_slice(const KEntropyArgs& a, KEntropyLds& lds, u32 slic
         if (PRIOR) { hp.ct = a.prior->ct; hp.valid = a.prior->hufMode != 0; hp.complete = a.prior->hufMode == 2; }
         u32 const litSec = (a.flags & 1u) ? 3u : kzstd_literals(lds, body, lits, litSize, suspect, a.scratch + (size_t)slice * a.scratch_words, lane, PRIOR ? &hp : nullptr, (a.flags & 64u) != 0);
         kx_sync();
-        u32 const seqSec = (a.flags & 2u) ? 0u : kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < n ? n - litSec : 0u, a.flags, PRIOR ? a.prior : nullptr);
+        // (levels 5 .. 10 pass the level in bits 12 ..: which of the strategies greedy / lazy / lazy2 a slice was parsed with follows from its size,
+        // zstd_lazy.h kx_lazy_params; the sequence coder takes the strategy's number in bits 8 .. 10)
+        u32 xf = a.flags & 0xFFFu;
+        if (a.flags >> 12) { u32 const lvl = a.flags >> 12; xf |= (n <= 16384u ? (lvl == 4u ? 3u : lvl == 5u ? 4u : 5u) : (lvl == 5u ? 3u : lvl == 6u ? 4u : 5u)) << 8; }
+        u32 const seqSec = (a.flags & 2u) ? 0u : kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < n ? n - litSec : 0u, xf, PRIOR ? a.prior : nullptr);
         if (seqSec != 0) {
             cSize = litSec + seqSec;
             if (cSize >= n - kx_min_gain(n)) cSize = 0;

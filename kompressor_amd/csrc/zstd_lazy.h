@@ -1,0 +1,333 @@
+// zstd_lazy.h -- zstd levels 5 .. 10 (and 4 .. 8 for slices up to 16 KiB): libzstd's strategies "greedy", "lazy", "lazy2"
+// (zstd_lazy.c ZSTD_compressBlock_lazy_generic, depth 0 / 1 / 2) for slices of one block (<= 128 KiB), no dictionary.
+//
+// What libzstd does: at a position it asks a match finder for the longest match among the newest earlier positions that hash like
+// it -- the row-based finder (window above 2^14: rows of 16 / 32 / 64 slots, one of them the row's head counter, entries tagged with 8
+// more hash bits, 1 << min(searchLog, rowLog) tag hits looked at) or the hash-chain finder (windows up to 2^14: 1 << searchLog chain
+// steps) --, prefers a repeat offset when that pays, and with depth 1 / 2 looks one / two positions further before it commits.
+// Both finders insert EVERY position they pass, in order -- so, as in zlib (deflate_lazy.h), a position's candidates do not depend on
+// the parse: they are the run of earlier positions in its hash bucket.  Two exceptions, both ranges of positions that never enter
+// the tables: "lazy skipping" (after 2 KiB without a match the parser strides, and only searched positions are inserted) and, for the
+// row finder, the middle of a gap of more than 384 positions behind a long match (its first 96 and last 32 go in).  A bitmap in LDS
+// holds them.
+//
+// Two kernels, sharing the DEFLATE compressor's workspace (KdArgs' arrays: 24 bytes a position):
+//   k_zstd_lazy_sort  256 threads a slice: stable counting sort of the positions by bucket (row index, or chain hash) -> srt[] (position |
+//                     tag << 24, bucket by bucket, ascending), sb[] (the 8 bytes at each sorted position), wr[p] (where p stands | its rank in
+//                     the bucket << 18)
+//   k_zstd_lazy       a wave per slice walks the parse; a search is one wave-wide step per 64 candidates
+// then k_zstd_entropy (literals gathered there; the sequence tables chosen by price from strategy "lazy" on).
+#pragma once
+#include "zstd_common.h"
+
+struct KLazyArgs {
+    const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
+    u32* srt; u64* sb; u32* wr; u32 pos_cap;          // per slice: pos_cap entries each
+    KSeq* seqs; u32 seq_cap; KSliceMeta* meta;
+    u32 level;
+};
+
+// ZSTD_getCParams(level, n, 0) where it is one of the three strategies; strat 0: not served at this size
+struct KLazyPar { u32 W, H, S, strat, rows, rowLog, buckLog; };
+KX_DEV KLazyPar kx_lazy_params(u32 level, u32 n)
+{
+    KLazyPar p; p.W = 0; p.H = 0; p.S = 0; p.strat = 0; p.rows = 0; p.rowLog = 0; p.buckLog = 0;
+    if (n == 0 || n > 131072u) return p;
+    u32 tW, H;
+    if (n <= 16384u) {
+        if (level < 4 || level > 8) return p;
+        tW = 14; H = 14; p.S = level == 4 ? 4u : level == 5 ? 3u : level == 6 ? 4u : level == 7 ? 6u : 8u; p.strat = level == 4 ? 3u : level == 5 ? 4u : 5u;
+    } else {
+        if (level < 5 || level > 10) return p;
+        tW = 17; H = 17; p.S = level <= 7 ? 3u : level - 4u; p.strat = level == 5 ? 3u : level == 6 ? 4u : 5u;
+    }
+    u32 const srcLog = (n < 64u) ? 6u : kx_hb32(n - 1u) + 1u;
+    p.W = tW < srcLog ? tW : srcLog;
+    if (H > p.W + 1) H = p.W + 1;
+    if (p.W < 10) p.W = 10;
+    p.H = H;
+    p.rows = p.W > 14 ? 1u : 0u;
+    p.rowLog = p.S < 4 ? 4u : p.S > 6 ? 6u : p.S;
+    p.buckLog = p.rows ? H - p.rowLog : H;             // row index bits / chain hash bits
+    return p;
+}
+// minMatch is 4 at all these levels: ZSTD_hash4 of the four bytes, hBits wide
+KX_DEV u32 kx_lazy_hash4(u32 v, u32 hBits) { return (v * 2654435761u) >> (32u - hBits); }
+
+// ---------------------------------------------------------------------------
+// k_zstd_lazy_sort (the scheme of k_deflate_sort: ranks in position order, bucket scan, scatter)
+// ---------------------------------------------------------------------------
+#define KZL_MAXBUCK 32768u
+KX_DEV void zstd_lazy_sort_body(const KLazyArgs& a)
+{
+    KX_SHARED u32 cnt[KZL_MAXBUCK / 2u];          // bucket sizes, then bucket starts: 8 192 rows of 32 bits, or (chains: slices <= 16 KiB) 32 768 of 16
+    KX_SHARED u32 part[256];
+    u16* const cnt16 = (u16*)cnt;
+    int const lane = kx_lane(); int const wv = kx_wave(); int const nw = kx_nwaves(); int const tid = wv * 64 + lane; int const nthreads = nw * 64;
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
+        u32 const slice = kx_xcd_chunk(it, a.n_slices);
+        const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
+        KLazyPar const P = kx_lazy_params(a.level, n);
+        if (P.strat == 0 || n < 8u) continue;                                   // (uniform over the workgroup)
+        u32* const wr = a.wr + (size_t)slice * a.pos_cap; u32* const srt = a.srt + (size_t)slice * a.pos_cap; u64* const sb = a.sb + (size_t)slice * a.pos_cap;
+        u32 const nb = 1u << P.buckLog; bool const wide = P.rows != 0;            // wide: 32-bit counters
+        u32 const hBits = P.rows ? P.buckLog + 8u : P.buckLog;
+        for (u32 i = (u32)tid; i < KZL_MAXBUCK / 2u; i += (u32)nthreads) cnt[i] = 0;
+        kx_block_sync();
+        u32 const nIns = n - 7u;                 // positions 0 .. n - 8: the parse stops 8 (rows: 16) bytes before the end, nothing later is ever inserted
+#define KZL_CNT(h_) (wide ? cnt[h_] : (u32)cnt16[h_])
+#define KZL_SET(h_, v_) { if (wide) cnt[h_] = (v_); else cnt16[h_] = (u16)(v_); }
+        // ---- pass 1: rank[p] (kept in wr[p]) = how many earlier positions share p's bucket; the waves take turns in position order
+        for (u32 base = 0; base < nIns; base += (u32)nthreads) {
+            u32 const p = base + (u32)wv * 64u + (u32)lane; bool const valid = p < nIns;
+            u32 const h = valid ? (kx_lazy_hash4(kx_ld32(src + p), hBits) >> (P.rows ? 8u : 0u)) : 0u;
+            u32 rk = 0;
+            for (int w = 0; w < nw; w++) {
+                if (wv == w) {
+                    u32 const old = valid ? KZL_CNT(h) : 0u;
+                    u32 below = 0, group = 1;
+                    // lanes of this wave in one bucket: a lane's rank counts the lower ones, the highest one leaves the total.  (A lane that is
+                    // alone in its bucket -- most are -- reads its own mark back and takes no turn; one that reads its own mark although lower
+                    // lanes share the bucket gets its numbers in their turn: the ballot is over all valid lanes of the bucket.)
+                    kx_lockstep();
+                    if (valid) KZL_SET(h, (u32)lane)
+                    kx_lockstep();
+                    bool const shared = valid && KZL_CNT(h) != (u32)lane;
+                    for (u64 todo = kx_ballot(shared); todo; ) {
+                        int const L = (int)kx_ctz64(todo);
+                        u32 const hL = kx_bcast(h, L);
+                        u64 const grp = kx_ballot(valid && h == hL);
+                        if (valid && h == hL) { below = kx_popc64(grp & ((1ull << lane) - 1ull)); group = kx_popc64(grp); }
+                        todo &= ~grp;
+                    }
+                    rk = old + below;
+                    kx_lockstep();
+                    if (valid && below + 1u == group) KZL_SET(h, old + group)
+                    kx_lockstep();
+                }
+                if (nw > 1) kx_block_sync();
+            }
+            if (valid) wr[p] = rk;
+        }
+        kx_block_sync();
+        // ---- pass 2: bucket starts
+        {
+            u32 const per = nb / (u32)nthreads ? nb / (u32)nthreads : 1u;            // (nb >= 256 at every served size? no: small slices have few buckets)
+            u32 const first = (u32)tid * per; u32 s = 0;
+            for (u32 i = 0; i < per && first + i < nb; i++) s += KZL_CNT(first + i);
+            part[tid] = s;
+            kx_block_sync();
+            if (tid == 0) { u32 run = 0; for (int t = 0; t < nthreads; t++) { u32 const v = part[t]; part[t] = run; run += v; } }
+            kx_block_sync();
+            u32 run = part[tid];
+            for (u32 i = 0; i < per && first + i < nb; i++) { u32 const v = KZL_CNT(first + i); KZL_SET(first + i, run) run += v; }
+        }
+        kx_block_sync();
+        // ---- pass 3: scatter
+        for (u32 p = (u32)tid; p < nIns; p += (u32)nthreads) {
+            u64 const w8 = kx_ld64(src + p);                    // (p + 8 <= n)
+            u32 const hh = kx_lazy_hash4((u32)w8, hBits);
+            u32 const h = P.rows ? hh >> 8 : hh, tag = P.rows ? hh & 0xFFu : 0u;
+            u32 const rk = wr[p];
+            u32 const where = KZL_CNT(h) + rk;
+            wr[p] = where | ((rk > 16383u ? 16383u : rk) << 18);
+            srt[where] = p | (tag << 24);
+            sb[where] = w8;
+        }
+        kx_block_sync();
+#undef KZL_CNT
+#undef KZL_SET
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_zstd_lazy: one wave per slice
+// ---------------------------------------------------------------------------
+struct KLazyLds { u32 ins[4096]; };          // one bit per position: 1 = it entered (or will enter) the finder's tables (128 KiB slices: 16 KiB)
+
+// length of the common prefix of src[a ..) and src[b ..) (b < a), not past n: the whole wave compares 512 bytes a step
+KX_DEV u32 kzl_count_wave(const u8* src, u32 a, u32 b, u32 n, int lane)
+{
+    u32 len = 0;
+    for (;;) {
+        u32 const o = len + 8u * (u32)lane;
+        u32 eq = 8;                                  // bytes of my 8 that agree (positions past the end disagree)
+        if (a + o >= n) eq = 0;
+        else {
+            u64 const x = kx_ld64_clamped(src, (int)(a + o), (int)n) ^ kx_ld64_clamped(src, (int)(b + o), (int)n);
+            u32 const room = n - (a + o) < 8u ? n - (a + o) : 8u;
+            u32 const same = x ? (u32)(kx_ctz64(x) >> 3) : 8u;
+            eq = same < room ? same : room;
+        }
+        u64 const stop = kx_ballot(eq < 8u);
+        if (stop) { int const L = (int)kx_ctz64(stop); return len + 8u * (u32)L + kx_bcast(eq, L); }
+        len += 512u;
+    }
+}
+
+KX_DEV void zstd_lazy_slice(const KLazyArgs& a, KLazyLds& lds, u32 slice, int lane)
+{
+    const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
+    KLazyPar const P = kx_lazy_params(a.level, n);
+    KSeq* const seqs = a.seqs + (size_t)slice * a.seq_cap;
+    KSliceMeta mm; mm.nbSeq = 0; mm.litSize = 0; mm.lastLL = n; mm.longType = 0; mm.longPos = 0; mm.status = 0; mm.pad[0] = 0; mm.pad[1] = 0;
+    if (P.strat == 0) { mm.status = 3; if (lane == 0) a.meta[slice] = mm; return; }      // another strategy at this size: k_len_guard_finish voids the frame (KMP_STATUS_LEVEL_SIZE)
+    if (n < 8u) { if (lane == 0) a.meta[slice] = mm; return; }
+    const u32* const wr = a.wr + (size_t)slice * a.pos_cap; const u32* const srt = a.srt + (size_t)slice * a.pos_cap; const u64* const sb = a.sb + (size_t)slice * a.pos_cap;
+    u32 const depth = P.strat - 3u;
+    bool const rows = P.rows != 0;
+    u32 const rowCap = (1u << P.rowLog) - 1u;                                  // entries a row holds (one slot is its head counter)
+    u32 const nbAttempts = 1u << (rows ? (P.S < P.rowLog ? P.S : P.rowLog) : P.S);
+    u32 const hBits = rows ? P.buckLog + 8u : P.buckLog;
+    u32 const ilimit = rows ? n - 16u : n - 8u;                                // (n >= 8; rows: n > 16 384)
+    for (u32 i = (u32)lane; i < 4096u; i += 64u) lds.ins[i] = 0xFFFFFFFFu;
+    kx_sync();
+    u32 ip = 1, anchor = 0, off1 = 1, off2 = 4, saved1 = 0, saved2 = 0;        // first block: position 0 is only ever a match source
+    if (off2 > 1u) { saved2 = off2; off2 = 0; }                                // maxRep = 1: repeat offset 4 waits
+    u32 ntu = 0; bool skipping = false;                                        // ms->nextToUpdate (a position), ms->lazySkipping
+    u32 nseq = 0, nlit = 0, longType = 0, longPos = 0;
+    u32 guard = 0;
+
+    // positions [lo, hi) never enter the tables
+#define KZL_CLEAR(lo_, hi_) { u32 const l__ = (lo_), h__ = (hi_); if (l__ < h__) { \
+        for (u32 w__ = (l__ >> 5) + (u32)lane; w__ <= ((h__ - 1u) >> 5); w__ += 64u) { \
+            u32 m__ = 0xFFFFFFFFu; if (w__ == (l__ >> 5)) m__ &= 0xFFFFFFFFu << (l__ & 31u); if (w__ == ((h__ - 1u) >> 5)) m__ &= 0xFFFFFFFFu >> (31u - ((h__ - 1u) & 31u)); \
+            lds.ins[w__] &= ~m__; } kx_sync(); } }
+    // the finder's answer for position p_: mlOut_ (3 = nothing), offOut_ (the distance)
+#define KZL_SEARCH(p_, mlOut_, offOut_) { \
+        u32 const cur__ = (p_); \
+        if (rows) { if (!skipping) { if (cur__ - ntu > 384u) KZL_CLEAR(ntu + 96u, cur__ - 32u) } else KZL_CLEAR(ntu, cur__) ntu = cur__ + 1u; } \
+        else { if (skipping && ntu < cur__) KZL_CLEAR(ntu + 1u, cur__) ntu = cur__; } \
+        u32 const w0__ = wr[cur__]; u32 const where__ = w0__ & 0x3FFFFu, rk__ = w0__ >> 18; \
+        u64 const scan__ = kx_ld64(src + cur__); u32 const tag__ = rows ? kx_lazy_hash4((u32)scan__, hBits) & 0xFFu : 0u; \
+        u32 best__ = 3, bestPos__ = 0, insSeen__ = 0, attSeen__ = 0; \
+        for (u32 cb__ = 0; cb__ < rk__ || (rk__ == 16383u && cb__ < where__); cb__ += 64u) { \
+            u32 const j__ = cb__ + (u32)lane; \
+            bool v__ = j__ < where__ && (rk__ == 16383u || j__ < rk__); \
+            u32 const e__ = v__ ? srt[where__ - 1u - j__] : 0u; u32 const cp__ = e__ & 0xFFFFFFu; \
+            if (rk__ == 16383u && v__) v__ = (rows ? (kx_lazy_hash4(kx_ld32(src + cp__), hBits) >> 8) == (kx_lazy_hash4((u32)scan__, hBits) >> 8) : kx_lazy_hash4(kx_ld32(src + cp__), hBits) == kx_lazy_hash4((u32)scan__, hBits)); \
+            u64 const outside__ = (rk__ == 16383u) ? kx_ballot(j__ < where__ && !v__) : 0ull;      /* (a capped rank: the bucket ends where another hash starts) */ \
+            if (outside__) { int const L__ = (int)kx_ctz64(outside__); if (lane >= L__) v__ = false; } \
+            bool const in__ = v__ && ((lds.ins[cp__ >> 5] >> (cp__ & 31u)) & 1u); \
+            u64 const inM__ = kx_ballot(in__); \
+            bool const inRow__ = in__ && (!rows || insSeen__ + kx_popc64(inM__ & ((1ull << lane) - 1ull)) < rowCap); \
+            bool const hit__ = inRow__ && (!rows || (e__ >> 24) == tag__); \
+            u64 const hitM__ = kx_ballot(hit__); \
+            bool const cand__ = hit__ && attSeen__ + kx_popc64(hitM__ & ((1ull << lane) - 1ull)) < nbAttempts; \
+            u32 len__ = 0; \
+            if (cand__) { \
+                u64 const d__ = sb[where__ - 1u - j__] ^ scan__; \
+                if (d__) len__ = (u32)(kx_ctz64(d__) >> 3); \
+                else { len__ = 8; for (;;) { if (cur__ + len__ >= n) break; u64 const x__ = kx_ld64_clamped(src, (int)(cur__ + len__), (int)n) ^ kx_ld64_clamped(src, (int)(cp__ + len__), (int)n); \
+                        if (x__) { len__ += (u32)(kx_ctz64(x__) >> 3); break; } len__ += 8u; } } \
+                if (len__ > n - cur__) len__ = n - cur__; \
+            } \
+            /* the longest wins, the newer one among equals: lanes are in order of age, blocks too */ \
+            u32 m__ = len__; \
+            for (int o__ = 32; o__ >= 1; o__ >>= 1) { u32 const t__ = kx_shfl(m__, lane ^ o__); m__ = t__ > m__ ? t__ : m__; } \
+            if (m__ > best__) { u64 const who__ = kx_ballot(cand__ && len__ == m__); best__ = m__; bestPos__ = kx_bcast(cp__, (int)kx_ctz64(who__)); } \
+            insSeen__ += kx_popc64(inM__); attSeen__ += kx_popc64(hitM__); \
+            if (outside__ || (rows && insSeen__ >= rowCap) || attSeen__ >= nbAttempts) break; \
+        } \
+        mlOut_ = best__; offOut_ = cur__ - bestPos__; }
+#define KZL_STORE(ll_, offBase_, ml_) { \
+        u32 const ll__ = (ll_), mlb__ = (ml_) - 3u; \
+        if (ll__ > 0xFFFFu) { longType = 1; longPos = nseq; } \
+        if (mlb__ > 0xFFFFu) { longType = 2; longPos = nseq; } \
+        if (lane == 0 && nseq < a.seq_cap) { KSeq q__; q__.offBase = (offBase_); q__.litLength = (u16)ll__; q__.mlBase = (u16)mlb__; seqs[nseq] = q__; } \
+        nseq++; nlit += ll__; }
+
+    while (ip < ilimit) {
+        if (++guard > 400000u) { mm.status = 2; break; }
+        u32 matchLength = 0, offBase = 1, start = ip + 1u;
+        bool store = false;
+        // the repeat offset at ip + 1
+        if (off1 > 0 && kx_ld32(src + ip + 1u - off1) == kx_ld32(src + ip + 1u)) {
+            matchLength = kzl_count_wave(src, ip + 1u + 4u, ip + 1u + 4u - off1, n, lane) + 4u;
+            if (depth == 0) store = true;
+        }
+        if (!store) {
+            u32 ml2, of2; KZL_SEARCH(ip, ml2, of2)
+            if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = of2 + 3u; }
+            if (matchLength < 4u) {
+                u32 const step = ((ip - anchor) >> 8) + 1u;               // kSearchStrength
+                ip += step;
+                skipping = step > 8u;                                     // kLazySkippingStep
+                continue;
+            }
+            // one / two positions further: something better?
+            if (depth >= 1u)
+            while (ip < ilimit) {
+                ip++;
+                if (off1 > 0 && kx_ld32(src + ip) == kx_ld32(src + ip - off1)) {
+                    u32 const mlRep = kzl_count_wave(src, ip + 4u, ip + 4u - off1, n, lane) + 4u;
+                    int const gain2 = (int)(mlRep * 3u), gain1 = (int)(matchLength * 3u - kx_hb32(offBase) + 1u);
+                    if (mlRep >= 4u && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
+                }
+                {
+                    u32 ml3, of3; KZL_SEARCH(ip, ml3, of3)
+                    int const gain2 = (int)(ml3 * 4u - kx_hb32(ml3 > 3u ? of3 + 3u : 999999999u)), gain1 = (int)(matchLength * 4u - kx_hb32(offBase) + 4u);
+                    if (ml3 >= 4u && gain2 > gain1) { matchLength = ml3; offBase = of3 + 3u; start = ip; continue; }
+                }
+                if (depth == 2u && ip < ilimit) {
+                    ip++;
+                    if (off1 > 0 && kx_ld32(src + ip) == kx_ld32(src + ip - off1)) {
+                        u32 const mlRep = kzl_count_wave(src, ip + 4u, ip + 4u - off1, n, lane) + 4u;
+                        int const gain2 = (int)(mlRep * 4u), gain1 = (int)(matchLength * 4u - kx_hb32(offBase) + 1u);
+                        if (mlRep >= 4u && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
+                    }
+                    {
+                        u32 ml3, of3; KZL_SEARCH(ip, ml3, of3)
+                        int const gain2 = (int)(ml3 * 4u - kx_hb32(ml3 > 3u ? of3 + 3u : 999999999u)), gain1 = (int)(matchLength * 4u - kx_hb32(offBase) + 7u);
+                        if (ml3 >= 4u && gain2 > gain1) { matchLength = ml3; offBase = of3 + 3u; start = ip; continue; }
+                    }
+                }
+                break;
+            }
+            if (offBase > 3u) {
+                // catch up: bytes before the match that agree too (not before the anchor, not before the slice's first byte)
+                u32 const off = offBase - 3u;
+                u32 const maxBack = (start - anchor) < (start - off) ? (start - anchor) : (start - off);       // (start - off > 0 positions lie before the source)
+                u32 back = 0;
+                for (u32 done = 0; done < maxBack; done += 64u) {
+                    u32 const k = done + (u32)lane;
+                    bool const ne = k >= maxBack || src[start - 1u - k] != src[start - off - 1u - k];
+                    u64 const stop = kx_ballot(ne);
+                    if (stop) { back = done + (u32)kx_ctz64(stop); break; }
+                    back = done + 64u;
+                }
+                if (back > maxBack) back = maxBack;
+                start -= back; matchLength += back;
+                off2 = off1; off1 = off;
+            }
+        }
+        KZL_STORE(start - anchor, offBase, matchLength)
+        anchor = ip = start + matchLength;
+        skipping = false;
+        // repeat offset 2 right behind the match
+        while (ip <= ilimit && off2 > 0 && kx_ld32(src + ip) == kx_ld32(src + ip - off2)) {
+            u32 const ml = kzl_count_wave(src, ip + 4u, ip + 4u - off2, n, lane) + 4u;
+            { u32 const t = off2; off2 = off1; off1 = t; }
+            KZL_STORE(0u, 1u, ml)
+            ip += ml; anchor = ip;
+        }
+    }
+    (void)saved1; (void)saved2;
+#undef KZL_CLEAR
+#undef KZL_SEARCH
+#undef KZL_STORE
+    mm.nbSeq = nseq; mm.litSize = nlit; mm.lastLL = n - anchor; mm.longType = longType; mm.longPos = longPos;
+    if (nseq > a.seq_cap) mm.status = 2;
+    if (lane == 0) a.meta[slice] = mm;
+}
+
+KX_DEV void zstd_lazy_body(const KLazyArgs& a)
+{
+    KX_SHARED KLazyLds lds;
+    int const lane = kx_lane();
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
+        u32 const slice = kx_xcd_chunk(it, a.n_slices);
+        zstd_lazy_slice(a, lds, slice, lane);
+        kx_sync();
+    }
+}

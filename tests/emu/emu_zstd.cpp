@@ -199,6 +199,39 @@ int emu_zstd_compress_dict(const u8* src, const u64* in_off, const u32* in_len, 
     return kxemu::failed ? -1 : 0;
 }
 
+#include "zstd_lazy.h"
+// Levels 5 .. 10 (greedy / lazy / lazy2): sort body (workgroups of four waves), parse body, entropy body -- zstd_compress_lazy's steps.
+extern "C" __attribute__((visibility("default")))
+int emu_zstd_compress_lazy(const u8* src, const u64* in_off, const u32* in_len, u32 n, u32 nblocks,
+                           u8* dst, const u64* out_off, u32* out_len, u32 slice_cap, int level)
+{
+    u32 const seq_cap = (slice_cap / 4 + 8 + 15) & ~15u, lit_cap = slice_cap + 64, scratch_words = slice_cap / 4 + 64, pos_cap = (slice_cap + 63u) & ~63u;
+    std::vector<KSeq> seqs((size_t)n * seq_cap);
+    std::vector<u8> lits((size_t)n * lit_cap, 0xEE);
+    std::vector<KSliceMeta> meta(n);
+    std::vector<u32> scratch((size_t)n * scratch_words, 0xA5A5A5A5u);
+    std::vector<u32> srt((size_t)n * pos_cap, 0xDDDDDDDDu), wr((size_t)n * pos_cap, 0xCCCCCCCCu); std::vector<u64> sb((size_t)n * pos_cap, 0xBBBBBBBBBBBBBBBBull);
+    KLazyArgs g;
+    g.src = src; g.in_off = in_off; g.in_len = in_len; g.n_slices = n;
+    g.srt = srt.data(); g.sb = sb.data(); g.wr = wr.data(); g.pos_cap = pos_cap;
+    g.seqs = seqs.data(); g.seq_cap = seq_cap; g.meta = meta.data(); g.level = (u32)level;
+    kxemu::failed = 0;
+    kxemu::launch_block(nblocks, 4, [&]() { zstd_lazy_sort_body(g); });
+    if (kxemu::failed) return -1;
+    kxemu::launch(nblocks, [&]() { zstd_lazy_body(g); });
+    if (kxemu::failed) return -2;
+    for (u32 i = 0; i < n; i++) if (meta[i].status == 2) return -3;
+    KEntropyArgs e;
+    e.src = src; e.in_off = in_off; e.in_len = in_len; e.n_slices = n;
+    e.seqs = seqs.data(); e.seq_cap = seq_cap; e.lits = lits.data(); e.lit_cap = lit_cap; e.meta = meta.data();
+    e.scratch = scratch.data(); e.scratch_words = scratch_words;
+    e.dst = dst; e.out_off = out_off; e.out_len = out_len; e.flags = 8u | ((u32)level << 12);
+    kxemu::launch(nblocks, [&]() { zstd_entropy_body(e); });
+    if (kxemu::failed) return -4;
+    for (u32 i = 0; i < n; i++) if (meta[i].status == 3) out_len[i] = 0;          // (k_len_guard_finish: another strategy at this size)
+    return 0;
+}
+
 // Frames of several blocks (slices above 128 KiB): the host-side round loop of kmp_api.hip restated for the emulator.
 extern "C" __attribute__((visibility("default")))
 int emu_zstd_compress_big_ex(const u8* src, const u64* in_off, const u32* in_len, u32 n, int G, u32 nblocks,

@@ -395,6 +395,17 @@ class Oracle:
             raise RuntimeError("oracle: the statistics do not fit the dictionary format")
         return out.raw[:n]
 
+    def compress_lazy(self, d: bytes, level: int):
+        """Frame of ZstdCompressor(level) at levels 5 .. 10 (4 .. 8 up to 16 KiB): strategies greedy / lazy / lazy2; None where the level is
+        another strategy at this size."""
+        k = self.lib
+        k.kref_zstd_lazy_compress.restype = ctypes.c_size_t
+        k.kref_zstd_lazy_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+        cap = k.kref_compress_bound(len(d)) + 64
+        o = ctypes.create_string_buffer(cap)
+        n = k.kref_zstd_lazy_compress(o, cap, d, len(d), level)
+        return None if n == 2 ** 64 - 1 else o.raw[:n]
+
     def params(self, n):
         a = (ctypes.c_uint32 * 4)()
         self.lib.kref_params_l3(n, a)
@@ -566,6 +577,23 @@ def emu_compress_level(datas, level, G=4, nblocks=2):
     r = emu().emu_zstd_compress_level(_vp(buf), _vp(offs), _vp(lens), n, G, nblocks, _vp(out), _vp(ooff), _vp(olen), cap, level)
     assert r == 0, f"emulator reported {r}"
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
+
+
+def emu_compress_lazy(datas, level, nblocks=2):
+    """zstd levels 5 .. 10 (and 4 .. 8 up to 16 KiB) on the emulator: k_zstd_lazy_sort + k_zstd_lazy + k_zstd_entropy bodies; a slice the
+    level does not serve at its size comes back as b''."""
+    n = len(datas)
+    cap = max(max((len(d) for d in datas), default=1), 64)
+    lens = np.array([len(d) for d in datas], dtype=np.uint32)
+    offs = np.zeros(n, dtype=np.uint64); stride = (cap + 63) & ~63
+    buf = np.zeros(n * stride + 64, dtype=np.uint8)
+    for i, d in enumerate(datas):
+        offs[i] = i * stride; buf[i * stride:i * stride + len(d)] = np.frombuffer(d, dtype=np.uint8)
+    ostride = cap + (cap >> 7) + 1024
+    out = np.zeros(n * ostride, dtype=np.uint8); ooff = (np.arange(n, dtype=np.uint64) * ostride); olen = np.zeros(n, dtype=np.uint32)
+    r = emu().emu_zstd_compress_lazy(_vp(buf), _vp(offs), _vp(lens), n, nblocks, _vp(out), _vp(ooff), _vp(olen), cap, level)
+    assert r == 0, f"emulated lazy kernels failed: {r}"
+    return [out[int(ooff[i]):int(ooff[i]) + int(olen[i])].tobytes() for i in range(n)]
 
 
 def emu_compress_dict(datas, dictionary, G=4, nblocks=2):
