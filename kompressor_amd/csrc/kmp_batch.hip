@@ -676,6 +676,8 @@ static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64
 // ---- levels 5 .. 10: strategies greedy / lazy / lazy2 (zstd_lazy.h), slices of one block ------------------------------------------------
 // The batch goes through in pieces that share one workspace (16 bytes a position: the sorted positions, their first bytes, where each
 // position stands): sort, then the wave-per-slice parse; the entropy kernel runs once over the whole batch.
+static int lazy_workspace(kmp_batch_ctx* c);
+static int lazy_parse(kmp_batch_ctx* c, hipStream_t st, const void* d_src, const uint64_t* d_in_off, u32 n, u32 first0, int level);
 static int zstd_compress_lazy(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                               uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream, int level)
 {
@@ -685,6 +687,22 @@ static int zstd_compress_lazy(kmp_batch_ctx* c, const void* d_src, const uint64_
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
+    KMP_TRY(lazy_workspace(c));
+    KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
+    KMP_TRY(lazy_parse(c, st, d_src, d_in_off, n, 0, level));
+    KEntropyArgs e;
+    e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = c->len_ok; e.n_slices = n;
+    e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
+    e.scratch = c->scratch; e.scratch_words = c->scratch_words;
+    e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
+    e.flags = 8u | ((u32)level << 12);           // literals are gathered by the entropy kernel; the level: it derives each slice's strategy from it
+    hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), 0, st, e);
+    HIP_TRY(hipGetLastError());
+    c->last_chunks = 1;
+    return batch_end(c, st, d_in_len, n, c->max_slice_bytes, d_out_len, c->meta);
+}
+static int lazy_workspace(kmp_batch_ctx* c)
+{
     if (!c->lz_srt) {
         u32 const pos_cap = (c->max_slice_bytes + 63u) & ~63u;
         u32 cap = (u32)((1ull << 30) / pos_cap); if (cap > 16384u) cap = 16384u; if (cap < 1u) cap = 1u;
@@ -696,9 +714,15 @@ static int zstd_compress_lazy(kmp_batch_ctx* c, const void* d_src, const uint64_
         }
         c->lz_pos_cap = pos_cap; c->lz_chunk = chunk;
     }
-    KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
-    for (u32 first = 0; first < n; first += c->lz_chunk) {
-        u32 const m = (n - first < c->lz_chunk) ? n - first : c->lz_chunk;
+    return KMP_OK;
+}
+// sort + parse of the slices [first0, first0 + n) of a batch, piece by piece (the slices' sanitised lengths are c->len_ok; sequences and
+// the per-slice record go where the other parsers put theirs).  Slices the level does not parse this way at their size are skipped: at
+// level 4 their record stays what k_zstd_match left (it serves 16 KiB < size <= 128 KiB), at the other levels it says "not served".
+static int lazy_parse(kmp_batch_ctx* c, hipStream_t st, const void* d_src, const uint64_t* d_in_off, u32 n, u32 first0, int level)
+{
+    for (u32 first = first0; first < first0 + n; first += c->lz_chunk) {
+        u32 const m = (first0 + n - first < c->lz_chunk) ? first0 + n - first : c->lz_chunk;
         KLazyArgs g;
         g.src = (const u8*)d_src; g.in_off = d_in_off + first; g.in_len = c->len_ok + first; g.n_slices = m;
         g.srt = c->lz_srt; g.sb = c->lz_sb; g.wr = c->lz_wr; g.pos_cap = c->lz_pos_cap;
@@ -707,16 +731,7 @@ static int zstd_compress_lazy(kmp_batch_ctx* c, const void* d_src, const uint64_
         hipLaunchKernelGGL(k_zstd_lazy, dim3(m), dim3(64), 0, st, g);
         HIP_TRY(hipGetLastError());
     }
-    KEntropyArgs e;
-    e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = c->len_ok; e.n_slices = n;
-    e.seqs = c->seqs; e.seq_cap = c->seq_cap; e.lits = c->lits; e.lit_cap = c->lit_cap; e.meta = c->meta;
-    e.scratch = c->scratch; e.scratch_words = c->scratch_words;
-    e.dst = (u8*)d_dst; e.out_off = d_out_off; e.out_len = d_out_len;
-    e.flags = 8u | ((u32)level << 12);           // literals are gathered by the entropy kernel; the level: it derives each slice's strategy from it
-    hipLaunchKernelGGL(k_zstd_entropy, dim3(n), dim3(64), 0, st, e);
-    HIP_TRY(hipGetLastError());
-    c->last_chunks = 1;
-    return batch_end(c, st, d_in_len, n, c->max_slice_bytes, d_out_len, c->meta);
+    return KMP_OK;
 }
 
 extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
@@ -1150,8 +1165,14 @@ static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64
         default: hipLaunchKernelGGL(k_zstd_match<64>, dim3(blocks), dim3(64), 0, st, m); break;
         }
         HIP_TRY(hipGetLastError());
+        if (l4) {
+            // level 4 up to 16 KiB is strategy "greedy" (ZSTD_getCParams(4, n <= 16 KiB)): those slices, which k_zstd_match has passed over, are
+            // parsed by the kernels of levels 5 .. 10 (zstd_lazy.h), which pass over all the others
+            KMP_TRY(lazy_workspace(c));
+            KMP_TRY(lazy_parse(c, st, d_src, d_in_off, m_n, first, 4));
+        }
         HIP_TRY(hipEventRecord(c->evm[ci][1], st));
-        e.flags = c->knob.entropy_flags | ((m.flags & 4u) ? 8u : 0u);
+        e.flags = c->knob.entropy_flags | ((m.flags & 4u) ? 8u : 0u) | (l4 ? (4u << 12) : 0u);
         hipStream_t es = st;
         if (ci + 1 < chunks) { es = c->st2; HIP_TRY(hipStreamWaitEvent(es, c->evm[ci][1], 0)); forked = true; }
         if (c->profiling) HIP_TRY(hipEventRecord(c->eve[ci][0], es));

@@ -1149,7 +1149,7 @@ KX_DEV void zstd_entropy_slice(const KEntropyArgs& a, KEntropyLds& lds, u32 slic
         // (levels 5 .. 10 pass the level in bits 12 ..: which of the strategies greedy / lazy / lazy2 a slice was parsed with follows from its size,
         // zstd_lazy.h kx_lazy_params; the sequence coder takes the strategy's number in bits 8 .. 10)
         u32 xf = a.flags & 0xFFFu;
-        if (a.flags >> 12) { u32 const lvl = a.flags >> 12; xf |= (n <= 16384u ? (lvl == 4u ? 3u : lvl == 5u ? 4u : 5u) : (lvl == 5u ? 3u : lvl == 6u ? 4u : 5u)) << 8; }
+        if (a.flags >> 12) { u32 const lvl = a.flags >> 12; xf |= (n <= 16384u ? (lvl == 4u ? 3u : lvl == 5u ? 4u : 5u) : (lvl == 4u ? 2u : lvl == 5u ? 3u : lvl == 6u ? 4u : 5u)) << 8; }
         u32 const seqSec = (a.flags & 2u) ? 0u : kzstd_sequences(lds, body + litSec, seqs, mm.nbSeq, mm.longType, mm.longPos, lane, litSec < n ? n - litSec : 0u, xf, PRIOR ? a.prior : nullptr);
         if (seqSec != 0) {
             cSize = litSec + seqSec;

@@ -171,7 +171,9 @@ KX_DEV void zstd_lazy_slice(const KLazyArgs& a, KLazyLds& lds, u32 slice, int la
     KLazyPar const P = kx_lazy_params(a.level, n);
     KSeq* const seqs = a.seqs + (size_t)slice * a.seq_cap;
     KSliceMeta mm; mm.nbSeq = 0; mm.litSize = 0; mm.lastLL = n; mm.longType = 0; mm.longPos = 0; mm.status = 0; mm.pad[0] = 0; mm.pad[1] = 0;
-    if (P.strat == 0) { mm.status = 3; if (lane == 0) a.meta[slice] = mm; return; }      // another strategy at this size: k_len_guard_finish voids the frame (KMP_STATUS_LEVEL_SIZE)
+    // another strategy at this size: at level 4 the double-fast kernel has served it (or refused it) and its record stands; else "not served"
+    // (k_len_guard_finish voids the frame: KMP_STATUS_LEVEL_SIZE)
+    if (P.strat == 0) { if (a.level != 4u) { mm.status = 3; if (lane == 0) a.meta[slice] = mm; } return; }
     if (n < 8u) { if (lane == 0) a.meta[slice] = mm; return; }
     const u32* const wr = a.wr + (size_t)slice * a.pos_cap; const u32* const srt = a.srt + (size_t)slice * a.pos_cap; const u64* const sb = a.sb + (size_t)slice * a.pos_cap;
     u32 const depth = P.strat - 3u;
