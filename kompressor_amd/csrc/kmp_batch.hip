@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64) void k_table_probe(u32* p0, u32* p1, u32* p2, u
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
-extern "C" const char* kmp_version(void) { return "kompressor_hip 0.4 (gfx950; zstd levels -131072 .. -1 and 1 .. 3: frames and streams up to 1 GiB, dictionaries (raw content and zstd format); level 4 in its double-fast size classes; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
+extern "C" const char* kmp_version(void) { return "kompressor_hip 0.4 (gfx950; zstd levels -131072 .. -1 and 1 .. 3: frames and streams up to 1 GiB, dictionaries (raw content and zstd format); level 4 up to 128 KiB, above 256 KiB and streams; levels 5 .. 10 up to 128 KiB; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
 
 u32 env_u32(const char* name, u32 dflt)
 {
@@ -619,7 +619,7 @@ extern "C" int kmp_batch_status(kmp_batch_ctx* c, uint32_t* bits, void* hip_stre
     if (bits) *bits = v;
     if (v & KMP_STATUS_SLICE_TOO_LARGE) { g_last_error = "a slice is larger than the context was created for: its out_len is 0"; return KMP_ERR_CAPACITY; }
     if (v & KMP_STATUS_KERNEL_GUARD) { g_last_error = "a parser's loop guard tripped: the slice's out_len is 0"; return KMP_ERR_KERNEL; }
-    if (v & KMP_STATUS_LEVEL_SIZE) { g_last_error = "zstd level 4 is served for slices above 16 KiB: a smaller slice's out_len is 0"; return KMP_ERR_CAPACITY; }
+    if (v & KMP_STATUS_LEVEL_SIZE) { g_last_error = "the level is another strategy at a slice's size (levels 9 and 10 up to 16 KiB; level 4 between 128 and 256 KiB): that slice's out_len is 0"; return KMP_ERR_CAPACITY; }
     return KMP_OK;
 }
 
@@ -741,7 +741,7 @@ extern "C" int kmp_zstd_compress_batch_level(kmp_batch_ctx* c, const void* d_src
     if (level == 4) return zstd_compress_dfast(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, hip_stream, 4);
     if (level >= 5 && level <= 10) return zstd_compress_lazy(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, hip_stream, level);
     bool const neg = level < 0;                // negative levels: strategy "fast" with a step of 1 - level, literals left uncompressed
-    if ((level != 1 && level != 2 && !neg) || level < -131072) { g_last_error = "kmp_zstd_compress_batch_level: levels -131072 .. -1, 1, 2, 3 and (slices above 16 KiB up to 128 KiB) 4 are served"; return KMP_ERR_ARG; }
+    if ((level != 1 && level != 2 && !neg) || level < -131072) { g_last_error = "kmp_zstd_compress_batch_level: levels -131072 .. -1 and 1 .. 10 are served"; return KMP_ERR_ARG; }
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_zstd_compress_batch_level: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_zstd_compress_batch_level: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
     if (n == 0) return KMP_OK;

@@ -179,7 +179,7 @@ static int host_engine_compress(host_engine* e, host_job* jobs, u32 n, int level
         else if (fl > jobs[i].out_cap) { jobs[i].status = 70; if (rc == KMP_OK) rc = KMP_ERR_CAPACITY; }
         else { memcpy(jobs[i].out, e->h_out + a, fl); jobs[i].out_len = fl; }
     }
-    if (rc == KMP_ERR_CAPACITY) g_last_error = (bits & KMP_STATUS_LEVEL_SIZE) ? "host batch: level 4 is served for slices above 16 KiB up to 128 KiB: the others have out_len 0"
+    if (rc == KMP_ERR_CAPACITY) g_last_error = (bits & KMP_STATUS_LEVEL_SIZE) ? "host batch: levels 9 and 10 are served for slices above 16 KiB (smaller ones are another strategy there): those have out_len 0"
                                                                                : "host batch: an output region is smaller than its frame (kmp_zstd_compress_bound)";
     if (rc == KMP_ERR_KERNEL) g_last_error = "host batch: a slice came back without a frame";
     return rc;
@@ -455,15 +455,15 @@ static int bulk_pipe_run(bulk_pipe* b, int level, const u8* h_src, const u8* src
     return rc;
 }
 
-/* Levels -131072 .. 4 (0 = 3): what kmp_zstd_compress_batch_level serves for one-block slices; in a level-4 batch the slices of its
- * "greedy" size class (16 KiB or less) come back with out_len 0 and the call returns KMP_ERR_CAPACITY after every other slice has
+/* Levels -131072 .. 10 (0 = 3): what kmp_zstd_compress_batch_level serves for one-block slices; in a batch of level 9 or 10 the slices of its
+ * "btlazy2" size class (16 KiB or less) come back with out_len 0 and the call returns KMP_ERR_CAPACITY after every other slice has
  * been compressed.  out_len is written for every slice, whatever the return value. */
 extern "C" int kmp_zstd_compress_host_batch(int device, int level, const void* h_src, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
                                             void* h_dst, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len)
 {
     if (n && (!h_src || !in_off || !in_len || !h_dst || !out_off || !out_cap || !out_len)) { g_last_error = "kmp_zstd_compress_host_batch: null argument"; return KMP_ERR_ARG; }
     if (level == 0) level = 3;
-    if (level < -131072 || level > 4) { g_last_error = "kmp_zstd_compress_host_batch: levels -131072 .. 4 are served (4: slices above 16 KiB)"; return KMP_ERR_ARG; }
+    if (level < -131072 || level > 10) { g_last_error = "kmp_zstd_compress_host_batch: levels -131072 .. 10 are served (9 and 10: slices above 16 KiB)"; return KMP_ERR_ARG; }
     for (u32 i = 0; i < n; i++) out_len[i] = 0;
     if (n == 0) return KMP_OK;
     u32 const workers_wanted = env_u32("KMP_HOST_BULK_WORKERS", 4);

@@ -121,7 +121,7 @@ extern "C" size_t kmp_zstd_cctx_set_parameter(kmp_zstd_cctx* c, int param, int v
     if (param != KMP_ZSTD_c_compressionLevel) return KERRC(ZE_parameter_unsupported);
     if (c->stage != 0 || !c->in.empty()) return KERRC(ZE_stage_wrong);
     if (value == 0) value = 3;
-    if (value < -131072 || value > 4) return KERRC(ZE_parameter_unsupported);       // (4 and the negative levels: what arrives in one closing call of their size class, decided when the stream closes)
+    if (value < -131072 || value > 10) return KERRC(ZE_parameter_unsupported);      // (4 .. 10: what arrives in one closing call of a size class the level is served in, decided when the stream closes)
     c->level = value;
     return 0;
 }
@@ -155,8 +155,10 @@ static size_t run_single_compress(kmp_zstd_cctx* c, size_t first_room, size_t en
         if ((n - end_avail) % lap == 0) tail_direct = (u32)end_avail;
     }
     if (streaming && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
-    // level 4: what arrives in one closing call, above 16 KiB up to 128 KiB (libzstd's double-fast row of that level); the rest: CPU library
-    if (c->level == 4 && (!c->dict.empty() || (!streaming && !((n > 16384u && n <= 131072u) || n > 262144u)))) return KERRC(ZE_parameter_unsupported);
+    // level 4: what arrives in one closing call, up to 128 KiB (its greedy and double-fast rows) or above 256 KiB; the rest: CPU library
+    if (c->level == 4 && (!c->dict.empty() || (!streaming && !(n <= 131072u || n > 262144u)))) return KERRC(ZE_parameter_unsupported);
+    // levels 5 .. 10 (greedy / lazy / lazy2): one closing call of at most 128 KiB; 9 and 10 up to 16 KiB are "btlazy2": CPU library
+    if (c->level >= 5 && (!c->dict.empty() || streaming || n > KMP_MAX_SLICE_BYTES || (c->level >= 9 && n <= 16384u))) return KERRC(ZE_parameter_unsupported);
     if (c->level < 0 && !c->dict.empty()) return KERRC(ZE_parameter_unsupported);
     // the plain case -- level 3, no dictionary, the whole slice at once, one block -- joins whatever other contexts are
     // closing right now: one batch for all of them (kmp_coalesce.h); the frame is the one this context would get alone

@@ -32,8 +32,9 @@ struct KLazyPar { u32 W, H, S, strat, rows, rowLog, buckLog; };
 KX_DEV KLazyPar kx_lazy_params(u32 level, u32 n)
 {
     KLazyPar p; p.W = 0; p.H = 0; p.S = 0; p.strat = 0; p.rows = 0; p.rowLog = 0; p.buckLog = 0;
-    if (n == 0 || n > 131072u) return p;
+    if (n > 131072u) return p;
     u32 tW, H;
+    if (n < 8u) { p.strat = 3; p.W = 10; p.H = 11; p.S = 3; p.rowLog = 4; p.buckLog = 11; return p; }     // (nothing to parse: a raw block at every level)
     if (n <= 16384u) {
         if (level < 4 || level > 8) return p;
         tW = 14; H = 14; p.S = level == 4 ? 4u : level == 5 ? 3u : level == 6 ? 4u : level == 7 ? 6u : 8u; p.strat = level == 4 ? 3u : level == 5 ? 4u : 5u;

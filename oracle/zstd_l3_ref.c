@@ -2937,6 +2937,7 @@ static int lazy_params(int level, size_t n, kref_lpar* p)
 {
     u32 srcLog, tW;
     if (n == 0 || n > 131072) return 0;
+    if (n < 8 && level >= 4 && level <= 10) { p->W = 10; p->C = 10; p->H = 11; p->S = 3; p->mml = 4; p->strat = 3; return 1; }      /* (nothing to parse: a raw block whatever the strategy) */
     if (n <= 16384) {
         static const u32 S16[9] = { 0, 0, 0, 0, 4, 3, 4, 6, 8 }; static const u32 ST16[9] = { 0, 0, 0, 0, 3, 4, 5, 5, 5 };
         if (level < 4 || level > 8) return 0;

@@ -844,3 +844,30 @@ def formatted_dict_cases():
         assert hashlib.sha256(d).hexdigest() == row["dict_sha256"], row["name"]
         out.append((row["name"], d, formatted_dict_inputs(row["class"], salt=row["salt"]), row))
     return out
+
+
+def lazy_level_inputs():
+    """Seeded inputs for zstd levels 4 .. 10 (strategies greedy / lazy / lazy2): every corpus class at sizes on both sides of the 16 KiB
+    change of match finder, up to one block; inputs with long runs (the row finder leaves the middle of a gap above 384 out of its
+    tables; buckets of thousands) and random bytes (lazy skipping)."""
+    import random
+    from kompressor_amd import corpus
+    rng = random.Random(51020)
+    out = []
+    for cls in "TXSBDIZR":
+        for n in (1, 7, 8, 9, 100, 1000, 5000, 16384, 16385, 30000, 65536, 131072):
+            out.append(corpus.make(52000 + n, 1, n, mix=ord(cls)).tobytes())
+    for t in range(16):
+        n = rng.choice([rng.randrange(2000, 16385), rng.randrange(16385, 131073), 131072])
+        buf = bytearray()
+        while len(buf) < n:
+            buf += bytes([rng.choice(b"AB\x00")]) * rng.choice([5, 40, 300, 385, 386, 700, 5000, 20000, 45000])
+            if rng.random() < 0.3:
+                buf += corpus.make(rng.randrange(1 << 20), 1, rng.randrange(1, 400), mix=ord("T")).tobytes()
+        out.append(bytes(buf[:n]))
+    return out
+
+
+def lazy_levels_golden():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zstd_lazy_levels_golden.json")))

@@ -576,3 +576,17 @@ def test_formatted_dictionaries_on_the_emulator():
     assert list(helpers.emu_decompress([f], [len(in0[12])], dictionary=d1)[1]) == [32]                      # dictionary_wrong
     assert list(helpers.emu_decompress([f], [len(in0[12])], dictionary=b"raw content, no magic " * 8)[1]) == [32]
     assert list(helpers.emu_decompress([f], [len(in0[12])])[1]) == [32]
+
+
+def test_lazy_levels_on_the_emulator():
+    """zstd_lazy.h on the emulator -- the sort body (workgroups of four waves), the wave-per-slice parse with its bitmap of positions that
+    never enter the finder's tables, the entropy body choosing sequence tables by price -- against the oracle: levels 4 .. 10, both match
+    finders, the long-run inputs (gaps above 384, buckets of thousands), random bytes (lazy skipping); a slice whose level is another
+    strategy at its size comes back refused."""
+    o = helpers.oracle()
+    inputs = helpers.lazy_level_inputs()
+    pick = [p for i, p in enumerate(inputs) if len(p) <= 65536 and (i % 3 == 0 or len(p) < 200)] + inputs[-16:][:5]
+    for lvl in (4, 5, 6, 8, 10):
+        want = [o.compress_lazy(p, lvl) or b"" for p in pick]
+        assert helpers.emu_compress_lazy(pick, lvl) == want, lvl
+    assert helpers.emu_compress_lazy([inputs[4], inputs[9]], 9) == [b"", o.compress_lazy(inputs[9], 9)]       # 100 bytes at level 9: "btlazy2"

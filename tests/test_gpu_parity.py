@@ -343,7 +343,7 @@ def test_streaming_abi_one_shot_like_the_reference(G):
     assert ZstdDecompressor().transform_bytes(kat) == b"hello compression world"
     # errors surface like the reference's IllegalStateException text
     with pytest.raises(RuntimeError, match="Bad zstd result code -40: Unsupported parameter"):
-        ZstdCompressor(compression_level=19)
+        ZstdCompressor(compression_level=19)                                          # (levels up to 10 are served where they are greedy / lazy / lazy2)
     # levels 1 and 2 beyond their windows (512 KiB, 1 MiB) were refused until round 4; now: the frame the reference's driver gets
     for lvl, nbytes in ((2, (1 << 20) + 1), (1, (512 << 10) + 1)):
         data = corpus.make(4242 + lvl, 1, nbytes, mix=ord("T")).tobytes()
@@ -684,9 +684,9 @@ def test_negative_levels(batch):
 def test_level_4_where_it_is_double_fast(batch, monkeypatch):
     """ZstdCompressor(level = 4) for slices above 16 KiB up to 128 KiB (libzstd runs that size class of level 4 as the double-fast
     parse with hash 17 / chain 17 / minimum match 4): the ragged sizes in one batch and 256 slices of the 64 KiB mix against
-    libzstd 1.5.7, decoded back on the GPU; a slice of 16 KiB or less in such a batch (strategy "greedy": no parser here) is
-    refused -- out_len 0 and KMP_STATUS_LEVEL_SIZE -- while its neighbours come out right; level 3 still works on the same context
-    afterwards (its tables are another set); and the host-batch call takes the level."""
+    libzstd 1.5.7, decoded back on the GPU; a slice of 16 KiB or less in such a batch (strategy "greedy" there: zstd_lazy.h) comes out
+    right beside its neighbours; level 3 still works on the same context afterwards (its tables are another set); and the host-batch
+    call takes the level."""
     from kompressor_amd.batch import compress_host_batch
     G = helpers.level4_golden()
 
@@ -712,15 +712,15 @@ def test_level_4_where_it_is_double_fast(batch, monkeypatch):
     frames4 = run(mix, 4)
     for (i, flen, sha), f in zip(G["config1"], frames4):
         assert len(f) == flen and helpers.sha256(f) == sha, i
-    # a batch with slices of the "greedy" size class among the others
+    # a batch with slices of level 4's "greedy" size class (16 KiB or less: parsed by the kernels of levels 5 .. 10 since round 4) among the others
     batch.status()
-    mixed = [mix[0], mix[1][:16384], mix[2], b"", mix[3][:20000]]
-    frames = run(mixed, 4, check=False)
-    assert batch.status()[1] & 4                     # KMP_STATUS_LEVEL_SIZE
+    mixed = [mix[0], mix[1][:16384], mix[2], b"", mix[3][:20000], mix[4][:700], mix[5][:7]]
+    frames = run(mixed, 4)
     o = helpers.oracle()
-    assert frames[0] == frames4[0] and frames[1] == b"" and frames[2] == frames4[2] and frames[3] == b"" and frames[4] == o.compress_level(mixed[4], 4)
-    with pytest.raises(RuntimeError):
-        run(mixed, 4)                                # (check=True raises on the refused slices)
+    assert frames[0] == frames4[0] and frames[2] == frames4[2] and frames[4] == o.compress_level(mixed[4], 4)
+    for i in (1, 5, 6):
+        assert frames[i] == o.compress_lazy(mixed[i], 4), i
+    assert frames[3] == bytes.fromhex("28b52ffd2000010000")             # (the frame of an empty input)
     # level 3 on the same context afterwards
     G3 = helpers.golden()
     frames3 = run(mix[:16], 3)
@@ -730,8 +730,7 @@ def test_level_4_where_it_is_double_fast(batch, monkeypatch):
     # the streaming entry point (what ZstdCompressor(4).transform(bytes) binds): served for that size class, refused below it
     from kompressor_amd import ZstdCompressor
     assert ZstdCompressor(compression_level=4).transform_bytes(mix[5]) == frames4[5]
-    with pytest.raises(Exception):
-        ZstdCompressor(compression_level=4).transform_bytes(mix[5][:9000])
+    assert ZstdCompressor(compression_level=4).transform_bytes(mix[5][:9000]) == o.compress_lazy(mix[5][:9000], 4)
     # frames of several blocks (above 256 KiB level 4 is double-fast again: window 21, chain 18, hash 18) and streams, through the
     # streaming entry point as the reference's driver calls it; 128 - 256 KiB is a "greedy" class: refused
     o = helpers.oracle()
@@ -755,6 +754,54 @@ def test_level_4_where_it_is_double_fast(batch, monkeypatch):
             assert [hd[ho[i]:ho[i] + hl[i]].tobytes() for i in range(256)] == frames4
     finally:
         small.close()
+
+
+def test_levels_5_to_10(batch):
+    """ZstdCompressor(level = 5 .. 10): libzstd's strategies greedy / lazy / lazy2 with its row-based match finder (hash chains up to 16 KiB):
+    the committed frames of libzstd 1.5.7 (tests/golden/zstd_lazy_levels_golden.json: every class, ragged sizes to 128 KiB, long runs,
+    random bytes) from the batch call, decoded back; levels 9 and 10 refuse slices up to 16 KiB (another strategy there) beside serving
+    the others; the host-batch call and the streaming entry point take the levels."""
+    import hashlib
+    from kompressor_amd import ZstdCompressor, ZstdDecompressor
+    from kompressor_amd.batch import compress_host_batch
+    G = helpers.lazy_levels_golden(); inputs = helpers.lazy_level_inputs()
+    n = len(inputs); stride = 131072 + 512
+    host = np.zeros(n * stride + 64, dtype=np.uint8)
+    for k, p in enumerate(inputs):
+        host[k * stride:k * stride + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    src = torch.from_numpy(host).cuda(); offs = (torch.arange(n, dtype=torch.int64) * stride).cuda()
+    lens = torch.tensor([len(p) for p in inputs], dtype=torch.int32).cuda()
+    checked = 0
+    for lvl in range(5, 11):
+        batch.status()
+        dst, ooff, olen = batch.compress(src, offs, lens, level=lvl)
+        torch.cuda.synchronize()
+        d, oo, ol = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+        frames = [d[int(oo[k]):int(oo[k]) + int(ol[k])].tobytes() for k in range(n)]
+        refused = 0
+        for p, f, (flen, fsha) in zip(inputs, frames, G["frames"][str(lvl)]):
+            if lvl >= 9 and 8 <= len(p) <= 16384:
+                assert f == b"", (lvl, len(p)); refused += 1
+                continue
+            assert len(f) == flen and hashlib.sha256(f).hexdigest() == fsha, (lvl, len(p))
+            checked += 1
+        bits = batch.status()[1]
+        assert bool(bits & 4) == (refused > 0) and not (bits & 3), (lvl, bits)
+        served = [(p, f) for p, f in zip(inputs, frames) if f]
+        back, st = gpu_decompress(batch, [f for _, f in served], [max(len(p), 1) for p, _ in served])
+        assert st == [0] * len(served) and back == [p for p, _ in served], lvl
+    assert checked >= 580
+    some = [inputs[i] for i in (5, 7, 8, 10, 30, 46)]
+    o = helpers.oracle()
+    assert compress_host_batch(some, level=7) == [o.compress_lazy(p, 7) for p in some]
+    for lvl, i in ((5, 8), (6, 10), (10, 9), (8, 3)):
+        f = ZstdCompressor(compression_level=lvl).transform_bytes(inputs[i])
+        assert f == o.compress_lazy(inputs[i], lvl), (lvl, i)
+        assert ZstdDecompressor().transform_bytes(f) == inputs[i]
+    with pytest.raises(RuntimeError, match="Unsupported parameter"):
+        ZstdCompressor(compression_level=9).transform_bytes(inputs[5])          # 5 000 bytes at level 9: libzstd's "btlazy2"
+    with pytest.raises(RuntimeError, match="Unsupported parameter"):
+        ZstdCompressor(compression_level=11)
 
 
 def test_streaming_frames_finish_false_then_true():

@@ -5,6 +5,7 @@ this machine.  Bit-exact: byte work."""
 import base64
 
 import numpy as np
+import ctypes
 import pytest
 
 import helpers
@@ -349,3 +350,31 @@ def test_formatted_dictionaries_oracle_against_golden():
     # the magic with a damaged header: no frame (libzstd: "Dictionary is corrupted"), not raw content
     with pytest.raises(RuntimeError):
         o.compress_dict(b"abc" * 100, b"\x37\xa4\x30\xec" + bytes(range(200)) * 4)
+
+
+def test_lazy_levels_oracle_against_golden():
+    """zstd levels 4 .. 10 where libzstd runs them as greedy / lazy / lazy2 (zstd_lazy.c, row-based finder above 16 KiB, hash chains below):
+    the restatement gives libzstd 1.5.7's frames -- 700 committed ones (every class, both finders, long runs, random bytes) -- and its
+    parameter table is libzstd's own."""
+    import hashlib
+    o = helpers.oracle(); G = helpers.lazy_levels_golden()
+    inputs = helpers.lazy_level_inputs()
+    k = o.lib
+    k.kref_params_lazy.restype = ctypes.c_int
+    for key, want in G["params"].items():
+        lvl, sz = (int(x) for x in key.split(":"))
+        out = (ctypes.c_uint32 * 6)()
+        served = k.kref_params_lazy(lvl, ctypes.c_size_t(sz), out)
+        if want[5] in (3, 4, 5):
+            assert served and list(out) == [want[0], want[1], want[2], want[3], want[4], want[5]], key
+        else:
+            assert not served, key
+    n = 0
+    for lvl in range(4, 11):
+        for p, (flen, fsha) in zip(inputs, G["frames"][str(lvl)]):
+            f = o.compress_lazy(p, lvl)
+            if f is None:
+                continue                                   # (another strategy at this size: level 4 above 16 KiB, 9 and 10 up to 16 KiB)
+            assert len(f) == flen and hashlib.sha256(f).hexdigest() == fsha, (lvl, len(p))
+            n += 1
+    assert n >= 600
