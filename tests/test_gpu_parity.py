@@ -790,7 +790,7 @@ def test_levels_5_to_10(batch):
         served = [(p, f) for p, f in zip(inputs, frames) if f]
         back, st = gpu_decompress(batch, [f for _, f in served], [max(len(p), 1) for p, _ in served])
         assert st == [0] * len(served) and back == [p for p, _ in served], lvl
-    assert checked >= 580
+    assert checked >= 560                                   # (672 frames less the slices levels 9 and 10 refuse)
     some = [inputs[i] for i in (5, 7, 8, 10, 30, 46)]
     o = helpers.oracle()
     assert compress_host_batch(some, level=7) == [o.compress_lazy(p, 7) for p in some]
