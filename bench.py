@@ -978,6 +978,7 @@ def main():
             res["roofline"]["kernel"] = ("k_zstd_big_fast (one launch per step: every wave walks the block chains of its slices)" if SLICE > 128 * 1024
                                          else "k_zstd_match + k_zstd_entropy with level 4's double-fast row (tables of 1 MiB per team)" if args.level == 4
                                          else "k_zstd_match_fast (a step of 1 - level) + k_zstd_entropy with the literals left raw" if args.level < 0
+                                         else "k_zstd_lazy_sort + k_zstd_lazy (a wave per slice walks libzstd's greedy / lazy / lazy2 parse over the sorted positions: zstd_lazy.h) per piece of 16 384 slices, then k_zstd_entropy" if args.level >= 5
                                          else "k_zstd_match_fast + k_zstd_entropy (one launch each per step)")
             res["config"]["workload"] = f"{n} x {args.slice_kib} KiB seeded mixed slices per GPU, ZstdCompressor(level={args.level}), bit-identical to libzstd 1.5.7"
             res["metric"] = f"zstd level {args.level} compression throughput (uncompressed input bytes per second)"

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64, 4) void k_zstd_match2(KMatchArgs a) { zstd_matc
 __global__ __launch_bounds__(64, 4) void k_zstd_entropy(KEntropyArgs a) { zstd_entropy_body(a); }
 // zstd levels 5 .. 10 (greedy / lazy / lazy2: zstd_lazy.h)
 __global__ __launch_bounds__(256) void k_zstd_lazy_sort(KLazyArgs a) { zstd_lazy_sort_body(a); }
-__global__ __launch_bounds__(64, 2) void k_zstd_lazy(KLazyArgs a) { zstd_lazy_body(a); }
+template <int WORDS> __global__ __launch_bounds__(64, 2) void k_zstd_lazy(KLazyArgs a) { zstd_lazy_body<WORDS>(a); }
 // ... of a batch parsed against a formatted dictionary: its tables as the block's predecessor, its ID in the frame header
 __global__ __launch_bounds__(64, 4) void k_zstd_entropy_prior(KEntropyArgs a) { zstd_entropy_body<true>(a); }
 #ifdef KMP_ABLATIONS
@@ -728,7 +728,8 @@ static int lazy_parse(kmp_batch_ctx* c, hipStream_t st, const void* d_src, const
         g.srt = c->lz_srt; g.sb = c->lz_sb; g.wr = c->lz_wr; g.pos_cap = c->lz_pos_cap;
         g.seqs = c->seqs + (size_t)first * c->seq_cap; g.seq_cap = c->seq_cap; g.meta = c->meta + first; g.level = (u32)level;
         hipLaunchKernelGGL(k_zstd_lazy_sort, dim3(m), dim3(256), 0, st, g);
-        hipLaunchKernelGGL(k_zstd_lazy, dim3(m), dim3(64), 0, st, g);
+        if (c->max_slice_bytes <= 65536u) hipLaunchKernelGGL(k_zstd_lazy<2048>, dim3(m), dim3(64), 0, st, g);
+        else hipLaunchKernelGGL(k_zstd_lazy<4096>, dim3(m), dim3(64), 0, st, g);
         HIP_TRY(hipGetLastError());
     }
     return KMP_OK;

@@ -144,7 +144,9 @@ KX_DEV void zstd_lazy_sort_body(const KLazyArgs& a)
 // ---------------------------------------------------------------------------
 // k_zstd_lazy: one wave per slice
 // ---------------------------------------------------------------------------
-struct KLazyLds { u32 ins[4096]; };          // one bit per position: 1 = it entered (or will enter) the finder's tables (128 KiB slices: 16 KiB)
+// one bit per position: 1 = it entered (or will enter) the finder's tables.  WORDS: 2 048 for contexts of slices up to 64 KiB (8 KiB of LDS a
+// wave: twenty waves a CU), 4 096 up to 128 KiB
+template <int WORDS> struct KLazyLds { u32 ins[WORDS]; };
 
 // length of the common prefix of src[a ..) and src[b ..) (b < a), not past n: the whole wave compares 512 bytes a step
 KX_DEV u32 kzl_count_wave(const u8* src, u32 a, u32 b, u32 n, int lane)
@@ -166,10 +168,12 @@ KX_DEV u32 kzl_count_wave(const u8* src, u32 a, u32 b, u32 n, int lane)
     }
 }
 
-KX_DEV void zstd_lazy_slice(const KLazyArgs& a, KLazyLds& lds, u32 slice, int lane)
+template <int WORDS>
+KX_DEV void zstd_lazy_slice(const KLazyArgs& a, KLazyLds<WORDS>& lds, u32 slice, int lane)
 {
     const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
-    KLazyPar const P = kx_lazy_params(a.level, n);
+    KLazyPar P = kx_lazy_params(a.level, n);
+    if (n > 32u * (u32)WORDS) P.strat = 0;                                     // (cannot happen: the host picks WORDS by the context's slice size)
     KSeq* const seqs = a.seqs + (size_t)slice * a.seq_cap;
     KSliceMeta mm; mm.nbSeq = 0; mm.litSize = 0; mm.lastLL = n; mm.longType = 0; mm.longPos = 0; mm.status = 0; mm.pad[0] = 0; mm.pad[1] = 0;
     // another strategy at this size: at level 4 the double-fast kernel has served it (or refused it) and its record stands; else "not served"
@@ -183,7 +187,7 @@ KX_DEV void zstd_lazy_slice(const KLazyArgs& a, KLazyLds& lds, u32 slice, int la
     u32 const nbAttempts = 1u << (rows ? (P.S < P.rowLog ? P.S : P.rowLog) : P.S);
     u32 const hBits = rows ? P.buckLog + 8u : P.buckLog;
     u32 const ilimit = rows ? n - 16u : n - 8u;                                // (n >= 8; rows: n > 16 384)
-    for (u32 i = (u32)lane; i < 4096u; i += 64u) lds.ins[i] = 0xFFFFFFFFu;
+    for (u32 i = (u32)lane; i < (u32)WORDS; i += 64u) lds.ins[i] = 0xFFFFFFFFu;
     kx_sync();
     u32 ip = 1, anchor = 0, off1 = 1, off2 = 4, saved1 = 0, saved2 = 0;        // first block: position 0 is only ever a match source
     if (off2 > 1u) { saved2 = off2; off2 = 0; }                                // maxRep = 1: repeat offset 4 waits
@@ -226,9 +230,14 @@ KX_DEV void zstd_lazy_slice(const KLazyArgs& a, KLazyLds& lds, u32 slice, int la
                 if (len__ > n - cur__) len__ = n - cur__; \
             } \
             /* the longest wins, the newer one among equals: lanes are in order of age, blocks too */ \
-            u32 m__ = len__; \
-            for (int o__ = 32; o__ >= 1; o__ >>= 1) { u32 const t__ = kx_shfl(m__, lane ^ o__); m__ = t__ > m__ ? t__ : m__; } \
-            if (m__ > best__) { u64 const who__ = kx_ballot(cand__ && len__ == m__); best__ = m__; bestPos__ = kx_bcast(cp__, (int)kx_ctz64(who__)); } \
+            /* (few candidates -- 8 up to level 7 -- are looked at one by one through the scalar unit; many by a butterfly of shuffles) */ \
+            if (nbAttempts <= 16u) { \
+                for (u64 c__ = kx_ballot(cand__ && len__ > 3u); c__; c__ &= c__ - 1) { int const L__ = (int)kx_ctz64(c__); u32 const l__ = kx_bcast(len__, L__); if (l__ > best__) { best__ = l__; bestPos__ = kx_bcast(cp__, L__); } } \
+            } else { \
+                u32 m__ = len__; \
+                for (int o__ = 32; o__ >= 1; o__ >>= 1) { u32 const t__ = kx_shfl(m__, lane ^ o__); m__ = t__ > m__ ? t__ : m__; } \
+                if (m__ > best__) { u64 const who__ = kx_ballot(cand__ && len__ == m__); best__ = m__; bestPos__ = kx_bcast(cp__, (int)kx_ctz64(who__)); } \
+            } \
             insSeen__ += kx_popc64(inM__); attSeen__ += kx_popc64(hitM__); \
             if (outside__ || (rows && insSeen__ >= rowCap) || attSeen__ >= nbAttempts) break; \
         } \
@@ -324,9 +333,10 @@ KX_DEV void zstd_lazy_slice(const KLazyArgs& a, KLazyLds& lds, u32 slice, int la
     if (lane == 0) a.meta[slice] = mm;
 }
 
+template <int WORDS>
 KX_DEV void zstd_lazy_body(const KLazyArgs& a)
 {
-    KX_SHARED KLazyLds lds;
+    KX_SHARED KLazyLds<WORDS> lds;
     int const lane = kx_lane();
     for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
         u32 const slice = kx_xcd_chunk(it, a.n_slices);

@@ -219,7 +219,7 @@ int emu_zstd_compress_lazy(const u8* src, const u64* in_off, const u32* in_len, 
     kxemu::failed = 0;
     kxemu::launch_block(nblocks, 4, [&]() { zstd_lazy_sort_body(g); });
     if (kxemu::failed) return -1;
-    kxemu::launch(nblocks, [&]() { zstd_lazy_body(g); });
+    if (slice_cap <= 65536u) kxemu::launch(nblocks, [&]() { zstd_lazy_body<2048>(g); }); else kxemu::launch(nblocks, [&]() { zstd_lazy_body<4096>(g); });
     if (kxemu::failed) return -2;
     for (u32 i = 0; i < n; i++) if (meta[i].status == 2) return -3;
     KEntropyArgs e;
