@@ -50,8 +50,9 @@ typedef struct kmp_zstd_dctx kmp_zstd_dctx;
 KMP_API kmp_zstd_cctx* kmp_zstd_create_cctx(void);
 /* replaces ZSTD_freeCCtx              (Wrapper.cpp:19-27)  */
 KMP_API size_t kmp_zstd_free_cctx(kmp_zstd_cctx* cctx);
-/* replaces ZSTD_CCtx_setParameter     (Wrapper.cpp:29-39). Levels -131072 .. -1, 1, 2, 3 (and 0 = default = 3) and 4 (in its double-fast
- * size classes) run on the GPU (dictionaries: level 3 only); other levels return (size_t)-40 "Unsupported parameter". */
+/* replaces ZSTD_CCtx_setParameter     (Wrapper.cpp:29-39). Levels -131072 .. -1 and 1 .. 10 (0 = default = 3) run on the GPU where
+ * kmp_zstd_compress_batch_level serves them (dictionaries: level 3 only; levels 5 .. 10: one closing call of at most 128 KiB -- 9 and 10
+ * above 16 KiB; what is not served surfaces when the stream closes); levels 11 and up return (size_t)-40 "Unsupported parameter". */
 KMP_API size_t kmp_zstd_cctx_set_parameter(kmp_zstd_cctx* cctx, int param, int value);
 /* replaces ZSTD_CCtx_loadDictionary   (Wrapper.cpp:41-56). Served: dictionaries of 8 .. 130 560 bytes for slices <= 128 KiB, raw content
  * or zstd's own format (magic EC30A437: what `zstd --train` / ZDICT_trainFromBuffer write -- its Huffman and FSE tables, repeat offsets
@@ -140,7 +141,7 @@ typedef struct kmp_batch_ctx kmp_batch_ctx;
  * slice gets d_out_len[i] = 0 (a frame or stream is never empty) and the context's status word collects these bits. */
 #define KMP_STATUS_SLICE_TOO_LARGE 1u   /* a d_in_len[i] above the context's max_slice_bytes (DEFLATE: above 64 KiB) */
 #define KMP_STATUS_KERNEL_GUARD    2u   /* a parser's loop guard tripped (never expected) */
-#define KMP_STATUS_LEVEL_SIZE      4u   /* zstd level 4: a slice of 16 KiB or less or of 128 - 256 KiB (those size classes of level 4 are strategy "greedy", not served): out_len 0 */
+#define KMP_STATUS_LEVEL_SIZE      4u   /* the level is another strategy at a slice's size (level 4: 128 - 256 KiB; levels 9, 10: 8 bytes .. 16 KiB): out_len 0 */
 
 #define KMP_MAX_SLICE_BYTES (128u * 1024u)        /* one block per frame: the batched fast path */
 #define KMP_MAX_BIG_SLICE_BYTES (1u << 30)       /* frames of several blocks (context created with max_slice_bytes above
@@ -247,8 +248,14 @@ KMP_API int kmp_zstd_compress_batch_reference(kmp_batch_ctx* ctx,
  * Level 4 is served where libzstd runs it as "double-fast": slices above 16 KiB up to 128 KiB (window <= 17, chain 17, hash 17,
  * minimum match 4; ZSTD_getCParams(4, n, 0)), slices above 256 KiB (window <= 21, chain 18, hash 18, minimum match 5: contexts created
  * for slices above 128 KiB, per-slice tables of 2 MiB allocated by the first such batch) and streams of any size (kmp_zstd_compress_batch_stream_level).  Its tables (1 MiB per team: 64 GiB beside a 65 536-slice context, less when the device has less room; KMP_L4_TEAMS caps it) are allocated by
- * the first level-4 batch of a context.  A slice of 16 KiB or less, or of more than 128 KiB up to 256 KiB, in a level-4 batch is refused
- * like an oversized one (out_len 0, KMP_STATUS_LEVEL_SIZE): those size classes of level 4 are strategy "greedy", as are levels 5 and up -- not served. */
+ * the first level-4 batch of a context.  Level 4 up to 16 KiB is strategy "greedy": those slices of a batch go through the kernels of levels
+ * 5 .. 10; a slice of more than 128 KiB up to 256 KiB (greedy again, several blocks) is refused like an oversized one (out_len 0,
+ * KMP_STATUS_LEVEL_SIZE).
+ * Levels 5 .. 10 are libzstd's strategies "greedy" (5; 4 up to 16 KiB), "lazy" (6; 5 up to 16 KiB) and "lazy2" (7 .. 10; 6 .. 8 up to
+ * 16 KiB) over its row-based match finder (windows above 2^14: the finder a library built for 128-bit vectors uses, as the reference's JNI
+ * library is) or its hash chains (slices up to 16 KiB): served for slices of one block (<= 128 KiB, context created for such slices).  At
+ * levels 9 and 10 a slice of 8 bytes .. 16 KiB is strategy "btlazy2": refused as above.  The first batch at these levels allocates their
+ * workspace (16 bytes per position of up to 16 384 slices). */
 KMP_API int kmp_zstd_compress_batch_level(kmp_batch_ctx* ctx,
                                           const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                           uint32_t n,
