@@ -1,6 +1,6 @@
 """Differential fuzz on the GPU box: ragged slices of stress inputs (tools/fuzzgen.c: short-distance matches, repeated offsets,
 small alphabets, periodic data, abrupt regime changes) and of the corpus classes through every level-3 path (team width 4, the
-per-batch width 8, the split-phase parser, the fused kernel), levels 1, 2, 4 and three negative ones, and raw DEFLATE at levels 1, 6 and 9 -- EVERY frame compared with the binary
+per-batch width 8, the split-phase parser, the fused kernel), levels 1, 2, 4, two of 5 .. 10 and three negative ones, and raw DEFLATE at levels 1, 6 and 9 -- EVERY frame compared with the binary
 libzstd 1.5.7 (DEFLATE: with this machine's zlib) on the host cores (Pillow's copy: test infrastructure, looked up by oracle/libzstd_ref.py), and decoded back on
 the GPU.  usage: python tools/fuzz_gpu.py [seed] [n_slices]"""
 import os, sys, ctypes, subprocess, time
@@ -78,7 +78,12 @@ def gpu_frames(env, level, n_ctx, piece, idx):
 all_idx = np.arange(N)
 big_idx = np.nonzero(lens > 16384)[0]
 bad_total = 0
-for name, env, level, n_ctx, piece, idx in (
+# levels 5 .. 10: greedy / lazy / lazy2 (zstd_lazy.h): two of them a seed (the CPU side is slow), on a third of the slices; levels 9 and 10 are
+# served above 16 KiB (8 bytes .. 16 KiB: another strategy there) and below 8 bytes (a raw block at any level)
+third = np.arange(seed % 3, N, 3)
+lazy_legs = tuple((f"level {lvl}", {}, lvl, len(third), len(third), third if lvl < 9 else third[(lens[third] > 16384) | (lens[third] < 8)]) for lvl in ((5, 8), (6, 9), (7, 10))[seed % 3])
+for name, env, level, n_ctx, piece, idx in lazy_legs + (
+        ("level 4, every size (up to 16 KiB its greedy row)", {}, 4, N, N, all_idx),
         ("level 3, team width 4, one batch", {}, 3, N, N, all_idx),
         ("level 3, batches of 6 000 (team width 8)", {}, 3, 6000, 6000, all_idx),
         ("level 3, split-phase parser", {"KMP_MATCH_V2": "2"}, 3, N, N, all_idx),
