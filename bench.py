@@ -71,7 +71,7 @@ def build_cpu_bench():
     return out
 
 
-def cpu_baseline(host, n_slices, frames_expected, sample=None):
+def cpu_baseline(host, n_slices, frames_expected, sample=None, level=3):
     """Times the reference's arithmetic on the host cores (oracle/cpu_bench.c: plain pthreads, one context per thread): a
     binary libzstd 1.5.7 if this machine has one (kind "reference"), else the oracle's C restatement (kind "port").  All the
     cores this job may use: 1 warm-up + 5 passes over the first `sample` slices of the batch, the median pass; and one thread
@@ -85,6 +85,7 @@ def cpu_baseline(host, n_slices, frames_expected, sample=None):
         sample = min(n_slices, max(64, (1 << 30) // SLICE))          # 1 GiB: 16 384 slices of 64 KiB
     sample = min(sample, host.size // SLICE)
     lib = ctypes.CDLL(build_cpu_bench())
+    lib.cpubench_set_zstd_level(int(level))
     lib.cpubench_zstd_l3.restype = ctypes.c_int
     lib.cpubench_zstd_l3.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
@@ -97,7 +98,7 @@ def cpu_baseline(host, n_slices, frames_expected, sample=None):
         zpath = None
     if zpath:
         kind = "reference"
-        label = f"libzstd 1.5.7 ({os.path.basename(zpath)}) " + ("ZSTD_compress2" if SLICE <= 131072 else f"ZSTD_compressStream2(e_end), {max(8192, SLICE // 10)}-byte output slices") + " level 3"
+        label = f"libzstd 1.5.7 ({os.path.basename(zpath)}) " + ("ZSTD_compress2" if SLICE <= 131072 else f"ZSTD_compressStream2(e_end), {max(8192, SLICE // 10)}-byte output slices") + f" level {level}"
         kpath = None
     else:
         import helpers
@@ -982,9 +983,10 @@ def main():
                                          else "k_zstd_match_fast + k_zstd_entropy (one launch each per step)")
             res["config"]["workload"] = f"{n} x {args.slice_kib} KiB seeded mixed slices per GPU, ZstdCompressor(level={args.level}), bit-identical to libzstd 1.5.7"
             res["metric"] = f"zstd level {args.level} compression throughput (uncompressed input bytes per second)"
-        if not args.no_cpu and not dictionary and args.level == 3:
-            sample = min(n, max(64, (1 << 29) // SLICE))
-            res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()), sample)
+        if not args.no_cpu and not dictionary and (args.level == 3 or SLICE <= 131072):
+            # (levels above 5 are slow on the host: a smaller sample keeps the pass to seconds)
+            sample = min(n, max(64, ((1 << 29) if args.level <= 4 else (1 << 27)) // SLICE))
+            res["cpu_baseline"] = cpu_baseline(host, n, int(lens[:sample].sum()), sample, level=args.level)
         if exchange:
             res["with_scatter_gather"] = exchange
         print(json.dumps(res), flush=True)

@@ -34,6 +34,10 @@ typedef struct {
 
 static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
 
+/* the level the binary library runs at (default 3: BASELINE configs[1]; the bench's lines for other levels set theirs) */
+static int g_zstd_level = 3;
+void cpubench_set_zstd_level(int level) { g_zstd_level = level; }
+
 static void* worker(void* arg)
 {
     job* j = (job*)arg;
@@ -41,7 +45,7 @@ static void* worker(void* arg)
     size_t const chunk = j->slice / 10 > 8192 ? j->slice / 10 : 8192;
     unsigned char* out = (unsigned char*)malloc(cap);
     void* cctx = j->create ? j->create() : NULL;
-    if (cctx) j->setp(cctx, 100, 3);                                 /* ZSTD_c_compressionLevel = 100 (ZstdCompressor.jvm.kt:41) */
+    if (cctx) j->setp(cctx, 100, g_zstd_level);                      /* ZSTD_c_compressionLevel = 100 (ZstdCompressor.jvm.kt:41) */
     uint32_t const per = (j->n + j->threads - 1) / j->threads;
     uint32_t const lo = (uint32_t)j->id * per, hi = lo + per < j->n ? lo + per : j->n;
     for (int p = 0; p < j->passes; p++) {

@@ -12,9 +12,9 @@ run --mode inflate --steps 3 --warmup 1 --no-cpu
 run --level 1 --steps 3 --warmup 1 --no-cpu
 run --level 2 --steps 3 --warmup 1 --no-cpu
 run --level 4 --steps 3 --warmup 1 --no-cpu
-run --level 5 --steps 2 --warmup 1 --no-cpu
-run --level 7 --steps 2 --warmup 1 --no-cpu
-run --level 10 --steps 2 --warmup 1 --no-cpu
+run --level 5 --steps 2 --warmup 1
+run --level 7 --steps 2 --warmup 1
+run --level 10 --steps 2 --warmup 1
 run --level -1 --steps 3 --warmup 1 --no-cpu
 run --level -5 --steps 3 --warmup 1 --no-cpu
 run --dict-kib 16 --steps 3 --warmup 1 --no-cpu
