@@ -674,7 +674,7 @@ static int flat_tables(kmp_batch_ctx* c, u32** tables, u32** epochs)
 static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream, int level);
 // ---- levels 5 .. 10: strategies greedy / lazy / lazy2 (zstd_lazy.h), slices of one block ------------------------------------------------
-// The batch goes through in pieces that share one workspace (16 bytes a position: the sorted positions, their first bytes, where each
+// The batch goes through in pieces that share one workspace (20 bytes a position: the sorted positions with their first bytes, where each
 // position stands): sort, then the wave-per-slice parse; the entropy kernel runs once over the whole batch.
 static int lazy_workspace(kmp_batch_ctx* c);
 static int lazy_parse(kmp_batch_ctx* c, hipStream_t st, const void* d_src, const uint64_t* d_in_off, u32 n, u32 first0, int level);
@@ -707,9 +707,9 @@ static int lazy_workspace(kmp_batch_ctx* c)
         u32 const pos_cap = (c->max_slice_bytes + 63u) & ~63u;
         u32 cap = (u32)((1ull << 30) / pos_cap); if (cap > 16384u) cap = 16384u; if (cap < 1u) cap = 1u;
         u32 const chunk = c->max_slices < cap ? c->max_slices : cap;
-        HIP_TRY(hipMalloc((void**)&c->lz_srt, (size_t)chunk * pos_cap * sizeof(u32)));
-        if (hipMalloc((void**)&c->lz_sb, (size_t)chunk * pos_cap * sizeof(u64)) != hipSuccess || hipMalloc((void**)&c->lz_wr, (size_t)chunk * pos_cap * sizeof(u32)) != hipSuccess) {
-            (void)hipGetLastError(); (void)hipFree(c->lz_srt); (void)hipFree(c->lz_sb); c->lz_srt = nullptr; c->lz_sb = nullptr;
+        HIP_TRY(hipMalloc((void**)&c->lz_srt, (size_t)chunk * pos_cap * sizeof(KLazyRec)));
+        if (hipMalloc((void**)&c->lz_wr, (size_t)chunk * pos_cap * sizeof(u32)) != hipSuccess) {
+            (void)hipGetLastError(); (void)hipFree(c->lz_srt); c->lz_srt = nullptr;
             g_last_error = "kmp_zstd_compress_batch_level: no memory for the workspace of levels 5 .. 10"; return KMP_ERR_HIP;
         }
         c->lz_pos_cap = pos_cap; c->lz_chunk = chunk;
@@ -725,7 +725,7 @@ static int lazy_parse(kmp_batch_ctx* c, hipStream_t st, const void* d_src, const
         u32 const m = (first0 + n - first < c->lz_chunk) ? first0 + n - first : c->lz_chunk;
         KLazyArgs g;
         g.src = (const u8*)d_src; g.in_off = d_in_off + first; g.in_len = c->len_ok + first; g.n_slices = m;
-        g.srt = c->lz_srt; g.sb = c->lz_sb; g.wr = c->lz_wr; g.pos_cap = c->lz_pos_cap;
+        g.rec = (KLazyRec*)c->lz_srt; g.wr = c->lz_wr; g.pos_cap = c->lz_pos_cap;
         g.seqs = c->seqs + (size_t)first * c->seq_cap; g.seq_cap = c->seq_cap; g.meta = c->meta + first; g.level = (u32)level;
         hipLaunchKernelGGL(k_zstd_lazy_sort, dim3(m), dim3(256), 0, st, g);
         if (c->max_slice_bytes <= 65536u) hipLaunchKernelGGL(k_zstd_lazy<2048>, dim3(m), dim3(64), 0, st, g);

@@ -11,18 +11,21 @@
 // row finder, the middle of a gap of more than 384 positions behind a long match (its first 96 and last 32 go in).  A bitmap in LDS
 // holds them.
 //
-// Two kernels, sharing the DEFLATE compressor's workspace (KdArgs' arrays: 24 bytes a position):
-//   k_zstd_lazy_sort  256 threads a slice: stable counting sort of the positions by bucket (row index, or chain hash) -> srt[] (position |
-//                     tag << 24, bucket by bucket, ascending), sb[] (the 8 bytes at each sorted position), wr[p] (where p stands | its rank in
-//                     the bucket << 18)
+// Two kernels over a workspace of 20 bytes a position:
+//   k_zstd_lazy_sort  256 threads a slice: stable counting sort of the positions by bucket (row index, or chain hash) -> rec[] (position |
+//                     tag << 24 and the 12 bytes there, bucket by bucket, ascending), wr[p] (where p stands | its rank in the bucket << 18)
 //   k_zstd_lazy       a wave per slice walks the parse; a search is one wave-wide step per 64 candidates
 // then k_zstd_entropy (literals gathered there; the sequence tables chosen by price from strategy "lazy" on).
 #pragma once
 #include "zstd_common.h"
 
+// one sorted position: the position and its tag, and the 12 bytes there -- everything a search needs of a candidate comes with one 16-byte
+// load (the searches are bound by memory round trips: counters in profiles/r04_lazy_levels.txt)
+struct alignas(16) KLazyRec { u32 pt; u32 b0; u64 b4; };      // pt = position | tag << 24; b0 = bytes 0 .. 3; b4 = bytes 4 .. 11
+
 struct KLazyArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
-    u32* srt; u64* sb; u32* wr; u32 pos_cap;          // per slice: pos_cap entries each
+    KLazyRec* rec; u32* wr; u32 pos_cap;              // per slice: pos_cap entries each
     KSeq* seqs; u32 seq_cap; KSliceMeta* meta;
     u32 level;
 };
@@ -52,6 +55,14 @@ KX_DEV KLazyPar kx_lazy_params(u32 level, u32 n)
     p.buckLog = p.rows ? H - p.rowLog : H;             // row index bits / chain hash bits
     return p;
 }
+// 4 bytes at position p of a slice of n bytes, bytes past the end read as zero
+KX_DEV u32 kx_ld32_clamped(const u8* src, u32 p, u32 n)
+{
+    if (p + 4u <= n) return kx_ld32(src + p);
+    u32 v = 0;
+    for (u32 k = 0; p + k < n; k++) v |= (u32)src[p + k] << (8u * k);
+    return v;
+}
 // minMatch is 4 at all these levels: ZSTD_hash4 of the four bytes, hBits wide
 KX_DEV u32 kx_lazy_hash4(u32 v, u32 hBits) { return (v * 2654435761u) >> (32u - hBits); }
 
@@ -70,7 +81,7 @@ KX_DEV void zstd_lazy_sort_body(const KLazyArgs& a)
         const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
         KLazyPar const P = kx_lazy_params(a.level, n);
         if (P.strat == 0 || n < 8u) continue;                                   // (uniform over the workgroup)
-        u32* const wr = a.wr + (size_t)slice * a.pos_cap; u32* const srt = a.srt + (size_t)slice * a.pos_cap; u64* const sb = a.sb + (size_t)slice * a.pos_cap;
+        u32* const wr = a.wr + (size_t)slice * a.pos_cap; KLazyRec* const rec = a.rec + (size_t)slice * a.pos_cap;
         u32 const nb = 1u << P.buckLog; bool const wide = P.rows != 0;            // wide: 32-bit counters
         u32 const hBits = P.rows ? P.buckLog + 8u : P.buckLog;
         for (u32 i = (u32)tid; i < KZL_MAXBUCK / 2u; i += (u32)nthreads) cnt[i] = 0;
@@ -132,8 +143,8 @@ KX_DEV void zstd_lazy_sort_body(const KLazyArgs& a)
             u32 const rk = wr[p];
             u32 const where = KZL_CNT(h) + rk;
             wr[p] = where | ((rk > 16383u ? 16383u : rk) << 18);
-            srt[where] = p | (tag << 24);
-            sb[where] = w8;
+            KLazyRec r; r.pt = p | (tag << 24); r.b0 = (u32)w8; r.b4 = (w8 >> 32) | ((u64)kx_ld32_clamped(src, p + 8u, n) << 32);
+            rec[where] = r;
         }
         kx_block_sync();
 #undef KZL_CNT
@@ -180,7 +191,7 @@ KX_DEV void zstd_lazy_slice(const KLazyArgs& a, KLazyLds<WORDS>& lds, u32 slice,
     // (k_len_guard_finish voids the frame: KMP_STATUS_LEVEL_SIZE)
     if (P.strat == 0) { if (a.level != 4u) { mm.status = 3; if (lane == 0) a.meta[slice] = mm; } return; }
     if (n < 8u) { if (lane == 0) a.meta[slice] = mm; return; }
-    const u32* const wr = a.wr + (size_t)slice * a.pos_cap; const u32* const srt = a.srt + (size_t)slice * a.pos_cap; const u64* const sb = a.sb + (size_t)slice * a.pos_cap;
+    const u32* const wr = a.wr + (size_t)slice * a.pos_cap; const KLazyRec* const rec = a.rec + (size_t)slice * a.pos_cap;
     u32 const depth = P.strat - 3u;
     bool const rows = P.rows != 0;
     u32 const rowCap = (1u << P.rowLog) - 1u;                                  // entries a row holds (one slot is its head counter)
@@ -200,37 +211,49 @@ KX_DEV void zstd_lazy_slice(const KLazyArgs& a, KLazyLds<WORDS>& lds, u32 slice,
         for (u32 w__ = (l__ >> 5) + (u32)lane; w__ <= ((h__ - 1u) >> 5); w__ += 64u) { \
             u32 m__ = 0xFFFFFFFFu; if (w__ == (l__ >> 5)) m__ &= 0xFFFFFFFFu << (l__ & 31u); if (w__ == ((h__ - 1u) >> 5)) m__ &= 0xFFFFFFFFu >> (31u - ((h__ - 1u) & 31u)); \
             lds.ins[w__] &= ~m__; } kx_sync(); } }
-    // the finder's answer for position p_: mlOut_ (3 = nothing), offOut_ (the distance)
+    // where / rank of the 64 positions from wbase on sit in a register window (lane i: wr[wbase + i]): one load per 64 positions instead of a
+    // dependent one per search
+    int wbase = -(1 << 20); u32 wrv = 0;
+    // the finder's answer for position p_: mlOut_ (3 = nothing), offOut_ (the distance).  One memory round trip: the position's own 12 bytes
+    // and the candidates' records are asked for together; only matches beyond 12 bytes go back to the source.
 #define KZL_SEARCH(p_, mlOut_, offOut_) { \
         u32 const cur__ = (p_); \
         if (rows) { if (!skipping) { if (cur__ - ntu > 384u) KZL_CLEAR(ntu + 96u, cur__ - 32u) } else KZL_CLEAR(ntu, cur__) ntu = cur__ + 1u; } \
         else { if (skipping && ntu < cur__) KZL_CLEAR(ntu + 1u, cur__) ntu = cur__; } \
-        u32 const w0__ = wr[cur__]; u32 const where__ = w0__ & 0x3FFFFu, rk__ = w0__ >> 18; \
-        u64 const scan__ = kx_ld64(src + cur__); u32 const tag__ = rows ? kx_lazy_hash4((u32)scan__, hBits) & 0xFFu : 0u; \
+        if ((int)cur__ < wbase || (int)cur__ >= wbase + 64) { wbase = (int)cur__; wrv = (cur__ + (u32)lane < n - 7u) ? wr[cur__ + (u32)lane] : 0u; } \
+        u32 const w0__ = kx_bcast(wrv, (int)cur__ - wbase); u32 const where__ = w0__ & 0x3FFFFu, rk__ = w0__ >> 18; \
+        u64 const scan__ = kx_ld64(src + cur__); u32 const scanHi__ = kx_ld32_clamped(src, cur__ + 8u, n); \
+        u32 const hsh__ = kx_lazy_hash4((u32)scan__, hBits); u32 const tag__ = rows ? hsh__ & 0xFFu : 0u; \
         u32 best__ = 3, bestPos__ = 0, insSeen__ = 0, attSeen__ = 0; \
         for (u32 cb__ = 0; cb__ < rk__ || (rk__ == 16383u && cb__ < where__); cb__ += 64u) { \
             u32 const j__ = cb__ + (u32)lane; \
             bool v__ = j__ < where__ && (rk__ == 16383u || j__ < rk__); \
-            u32 const e__ = v__ ? srt[where__ - 1u - j__] : 0u; u32 const cp__ = e__ & 0xFFFFFFu; \
-            if (rk__ == 16383u && v__) v__ = (rows ? (kx_lazy_hash4(kx_ld32(src + cp__), hBits) >> 8) == (kx_lazy_hash4((u32)scan__, hBits) >> 8) : kx_lazy_hash4(kx_ld32(src + cp__), hBits) == kx_lazy_hash4((u32)scan__, hBits)); \
+            KLazyRec e__; e__.pt = 0; e__.b0 = 0; e__.b4 = 0; \
+            if (v__) e__ = rec[where__ - 1u - j__]; \
+            u32 const cp__ = e__.pt & 0xFFFFFFu; \
+            if (rk__ == 16383u && v__) { u32 const ch__ = kx_lazy_hash4(e__.b0, hBits); v__ = rows ? (ch__ >> 8) == (hsh__ >> 8) : ch__ == hsh__; } \
             u64 const outside__ = (rk__ == 16383u) ? kx_ballot(j__ < where__ && !v__) : 0ull;      /* (a capped rank: the bucket ends where another hash starts) */ \
             if (outside__) { int const L__ = (int)kx_ctz64(outside__); if (lane >= L__) v__ = false; } \
             bool const in__ = v__ && ((lds.ins[cp__ >> 5] >> (cp__ & 31u)) & 1u); \
             u64 const inM__ = kx_ballot(in__); \
             bool const inRow__ = in__ && (!rows || insSeen__ + kx_popc64(inM__ & ((1ull << lane) - 1ull)) < rowCap); \
-            bool const hit__ = inRow__ && (!rows || (e__ >> 24) == tag__); \
+            bool const hit__ = inRow__ && (!rows || (e__.pt >> 24) == tag__); \
             u64 const hitM__ = kx_ballot(hit__); \
             bool const cand__ = hit__ && attSeen__ + kx_popc64(hitM__ & ((1ull << lane) - 1ull)) < nbAttempts; \
             u32 len__ = 0; \
             if (cand__) { \
-                u64 const d__ = sb[where__ - 1u - j__] ^ scan__; \
-                if (d__) len__ = (u32)(kx_ctz64(d__) >> 3); \
-                else { len__ = 8; for (;;) { if (cur__ + len__ >= n) break; u64 const x__ = kx_ld64_clamped(src, (int)(cur__ + len__), (int)n) ^ kx_ld64_clamped(src, (int)(cp__ + len__), (int)n); \
-                        if (x__) { len__ += (u32)(kx_ctz64(x__) >> 3); break; } len__ += 8u; } } \
+                u32 const d0__ = e__.b0 ^ (u32)scan__; \
+                if (d0__) len__ = (u32)(kx_ctz32(d0__) >> 3); \
+                else { \
+                    u64 const d4__ = e__.b4 ^ ((scan__ >> 32) | ((u64)scanHi__ << 32)); \
+                    if (d4__) len__ = 4u + (u32)(kx_ctz64(d4__) >> 3); \
+                    else { len__ = 12; for (;;) { if (cur__ + len__ >= n) break; u64 const x__ = kx_ld64_clamped(src, (int)(cur__ + len__), (int)n) ^ kx_ld64_clamped(src, (int)(cp__ + len__), (int)n); \
+                            if (x__) { len__ += (u32)(kx_ctz64(x__) >> 3); break; } len__ += 8u; } } \
+                } \
                 if (len__ > n - cur__) len__ = n - cur__; \
             } \
-            /* the longest wins, the newer one among equals: lanes are in order of age, blocks too */ \
-            /* (few candidates -- 8 up to level 7 -- are looked at one by one through the scalar unit; many by a butterfly of shuffles) */ \
+            /* the longest wins, the newer one among equals: lanes are in order of age, blocks too.  (Few candidates -- 8 up to level 7 -- are */ \
+            /* looked at one by one through the scalar unit; many by a butterfly of shuffles.) */ \
             if (nbAttempts <= 16u) { \
                 for (u64 c__ = kx_ballot(cand__ && len__ > 3u); c__; c__ &= c__ - 1) { int const L__ = (int)kx_ctz64(c__); u32 const l__ = kx_bcast(len__, L__); if (l__ > best__) { best__ = l__; bestPos__ = kx_bcast(cp__, L__); } } \
             } else { \

@@ -210,11 +210,12 @@ int emu_zstd_compress_lazy(const u8* src, const u64* in_off, const u32* in_len, 
     std::vector<u8> lits((size_t)n * lit_cap, 0xEE);
     std::vector<KSliceMeta> meta(n);
     std::vector<u32> scratch((size_t)n * scratch_words, 0xA5A5A5A5u);
-    std::vector<u32> srt((size_t)n * pos_cap, 0xDDDDDDDDu), wr((size_t)n * pos_cap, 0xCCCCCCCCu); std::vector<u64> sb((size_t)n * pos_cap, 0xBBBBBBBBBBBBBBBBull);
+    std::vector<u32> wr((size_t)n * pos_cap, 0xCCCCCCCCu); std::vector<KLazyRec> rec((size_t)n * pos_cap);
+    memset(rec.data(), 0xBB, rec.size() * sizeof(KLazyRec));
     for (u32 i = 0; i < n; i++) { memset(&meta[i], 0, sizeof(meta[i])); meta[i].lastLL = in_len[i]; meta[i].status = 3; }      // (level 4: what the double-fast kernel's slices look like to this harness: not served here)
     KLazyArgs g;
     g.src = src; g.in_off = in_off; g.in_len = in_len; g.n_slices = n;
-    g.srt = srt.data(); g.sb = sb.data(); g.wr = wr.data(); g.pos_cap = pos_cap;
+    g.rec = rec.data(); g.wr = wr.data(); g.pos_cap = pos_cap;
     g.seqs = seqs.data(); g.seq_cap = seq_cap; g.meta = meta.data(); g.level = (u32)level;
     kxemu::failed = 0;
     kxemu::launch_block(nblocks, 4, [&]() { zstd_lazy_sort_body(g); });
