@@ -206,83 +206,108 @@ KX_DEV void zstd_lazy_slice(const KLazyArgs& a, KLazyLds<WORDS>& lds, u32 slice,
     u32 nseq = 0, nlit = 0, longType = 0, longPos = 0;
     u32 guard = 0;
 
-    // positions [lo, hi) never enter the tables
-#define KZL_CLEAR(lo_, hi_) { u32 const l__ = (lo_), h__ = (hi_); if (l__ < h__) { \
-        for (u32 w__ = (l__ >> 5) + (u32)lane; w__ <= ((h__ - 1u) >> 5); w__ += 64u) { \
-            u32 m__ = 0xFFFFFFFFu; if (w__ == (l__ >> 5)) m__ &= 0xFFFFFFFFu << (l__ & 31u); if (w__ == ((h__ - 1u) >> 5)) m__ &= 0xFFFFFFFFu >> (31u - ((h__ - 1u) & 31u)); \
-            lds.ins[w__] &= ~m__; } kx_sync(); } }
-    // where / rank of the 64 positions from wbase on sit in a register window (lane i: wr[wbase + i]): one load per 64 positions instead of a
-    // dependent one per search
-    int wbase = -(1 << 20); u32 wrv = 0;
-    // the finder's answer for position p_: mlOut_ (3 = nothing), offOut_ (the distance).  One memory round trip: the position's own 12 bytes
-    // and the candidates' records are asked for together; only matches beyond 12 bytes go back to the source.
-#define KZL_SEARCH(p_, mlOut_, offOut_) { \
-        u32 const cur__ = (p_); \
-        if (rows) { if (!skipping) { if (cur__ - ntu > 384u) KZL_CLEAR(ntu + 96u, cur__ - 32u) } else KZL_CLEAR(ntu, cur__) ntu = cur__ + 1u; } \
-        else { if (skipping && ntu < cur__) KZL_CLEAR(ntu + 1u, cur__) ntu = cur__; } \
-        if ((int)cur__ < wbase || (int)cur__ >= wbase + 64) { wbase = (int)cur__; wrv = (cur__ + (u32)lane < n - 7u) ? wr[cur__ + (u32)lane] : 0u; } \
-        u32 const w0__ = kx_bcast(wrv, (int)cur__ - wbase); u32 const where__ = w0__ & 0x3FFFFu, rk__ = w0__ >> 18; \
-        u64 const scan__ = kx_ld64(src + cur__); u32 const scanHi__ = kx_ld32_clamped(src, cur__ + 8u, n); \
-        u32 const hsh__ = kx_lazy_hash4((u32)scan__, hBits); u32 const tag__ = rows ? hsh__ & 0xFFu : 0u; \
-        u32 best__ = 3, bestPos__ = 0, insSeen__ = 0, attSeen__ = 0; \
-        for (u32 cb__ = 0; cb__ < rk__ || (rk__ == 16383u && cb__ < where__); cb__ += 64u) { \
-            u32 const j__ = cb__ + (u32)lane; \
-            bool v__ = j__ < where__ && (rk__ == 16383u || j__ < rk__); \
-            KLazyRec e__; e__.pt = 0; e__.b0 = 0; e__.b4 = 0; \
-            if (v__) e__ = rec[where__ - 1u - j__]; \
-            u32 const cp__ = e__.pt & 0xFFFFFFu; \
-            if (rk__ == 16383u && v__) { u32 const ch__ = kx_lazy_hash4(e__.b0, hBits); v__ = rows ? (ch__ >> 8) == (hsh__ >> 8) : ch__ == hsh__; } \
-            u64 const outside__ = (rk__ == 16383u) ? kx_ballot(j__ < where__ && !v__) : 0ull;      /* (a capped rank: the bucket ends where another hash starts) */ \
-            if (outside__) { int const L__ = (int)kx_ctz64(outside__); if (lane >= L__) v__ = false; } \
-            bool const in__ = v__ && ((lds.ins[cp__ >> 5] >> (cp__ & 31u)) & 1u); \
-            u64 const inM__ = kx_ballot(in__); \
-            bool const inRow__ = in__ && (!rows || insSeen__ + kx_popc64(inM__ & ((1ull << lane) - 1ull)) < rowCap); \
-            bool const hit__ = inRow__ && (!rows || (e__.pt >> 24) == tag__); \
-            u64 const hitM__ = kx_ballot(hit__); \
-            bool const cand__ = hit__ && attSeen__ + kx_popc64(hitM__ & ((1ull << lane) - 1ull)) < nbAttempts; \
-            u32 len__ = 0; \
-            if (cand__) { \
-                u32 const d0__ = e__.b0 ^ (u32)scan__; \
-                if (d0__) len__ = (u32)(kx_ctz32(d0__) >> 3); \
-                else { \
-                    u64 const d4__ = e__.b4 ^ ((scan__ >> 32) | ((u64)scanHi__ << 32)); \
-                    if (d4__) len__ = 4u + (u32)(kx_ctz64(d4__) >> 3); \
-                    else { len__ = 12; for (;;) { if (cur__ + len__ >= n) break; u64 const x__ = kx_ld64_clamped(src, (int)(cur__ + len__), (int)n) ^ kx_ld64_clamped(src, (int)(cp__ + len__), (int)n); \
-                            if (x__) { len__ += (u32)(kx_ctz64(x__) >> 3); break; } len__ += 8u; } } \
-                } \
-                if (len__ > n - cur__) len__ = n - cur__; \
-            } \
-            /* the longest wins, the newer one among equals: lanes are in order of age, blocks too.  (Few candidates -- 8 up to level 7 -- are */ \
-            /* looked at one by one through the scalar unit; many by a butterfly of shuffles.) */ \
-            if (nbAttempts <= 16u) { \
-                for (u64 c__ = kx_ballot(cand__ && len__ > 3u); c__; c__ &= c__ - 1) { int const L__ = (int)kx_ctz64(c__); u32 const l__ = kx_bcast(len__, L__); if (l__ > best__) { best__ = l__; bestPos__ = kx_bcast(cp__, L__); } } \
-            } else { \
-                u32 m__ = len__; \
-                for (int o__ = 32; o__ >= 1; o__ >>= 1) { u32 const t__ = kx_shfl(m__, lane ^ o__); m__ = t__ > m__ ? t__ : m__; } \
-                if (m__ > best__) { u64 const who__ = kx_ballot(cand__ && len__ == m__); best__ = m__; bestPos__ = kx_bcast(cp__, (int)kx_ctz64(who__)); } \
-            } \
-            insSeen__ += kx_popc64(inM__); attSeen__ += kx_popc64(hitM__); \
-            if (outside__ || (rows && insSeen__ >= rowCap) || attSeen__ >= nbAttempts) break; \
-        } \
-        mlOut_ = best__; offOut_ = cur__ - bestPos__; }
-#define KZL_STORE(ll_, offBase_, ml_) { \
-        u32 const ll__ = (ll_), mlb__ = (ml_) - 3u; \
-        if (ll__ > 0xFFFFu) { longType = 1; longPos = nseq; } \
-        if (mlb__ > 0xFFFFu) { longType = 2; longPos = nseq; } \
-        if (lane == 0 && nseq < a.seq_cap) { KSeq q__; q__.offBase = (offBase_); q__.litLength = (u16)ll__; q__.mlBase = (u16)mlb__; seqs[nseq] = q__; } \
-        nseq++; nlit += ll__; }
+    // The parse is bound by memory round trips (counters: profiles/r04_lazy_levels.txt), so every step asks for all it can know the addresses
+    // of in ONE batch of loads: a search's own 12 bytes and its candidates' records, and with them the four bytes a repeat offset back that
+    // the step's repeat-offset test needs (`x`).  LOAD has no side effects (a greedy step that takes the repeat offset never searches);
+    // EVAL marks what the finder would have inserted and compares.
+    struct Loaded { u64 scan; u32 scanHi, where, rk, x; KLazyRec e; };
+    int wbase = -(1 << 20); u32 wrv = 0;       // where / rank of the 64 positions from wbase on (lane i: wr[wbase + i])
+    auto clear_bits = [&](u32 lo, u32 hi) {    // positions [lo, hi) never enter the tables
+        if (lo < hi) {
+            for (u32 w = (lo >> 5) + (u32)lane; w <= ((hi - 1u) >> 5); w += 64u) {
+                u32 m = 0xFFFFFFFFu;
+                if (w == (lo >> 5)) m &= 0xFFFFFFFFu << (lo & 31u);
+                if (w == ((hi - 1u) >> 5)) m &= 0xFFFFFFFFu >> (31u - ((hi - 1u) & 31u));
+                lds.ins[w] &= ~m;
+            }
+            kx_sync();
+        }
+    };
+    auto load = [&](u32 cur, u32 xaddr, Loaded& L) {
+        if ((int)cur < wbase || (int)cur >= wbase + 64) { wbase = (int)cur; wrv = (cur + (u32)lane < n - 7u) ? wr[cur + (u32)lane] : 0u; }
+        u32 const w0 = kx_bcast(wrv, (int)cur - wbase);
+        L.where = w0 & 0x3FFFFu; L.rk = w0 >> 18;
+        L.e.pt = 0; L.e.b0 = 0; L.e.b4 = 0;
+        if ((u32)lane < L.where && (L.rk == 16383u || (u32)lane < L.rk)) L.e = rec[L.where - 1u - (u32)lane];
+        L.scan = kx_ld64(src + cur); L.scanHi = kx_ld32_clamped(src, cur + 8u, n);
+        L.x = kx_ld32(src + xaddr);
+    };
+    // the finder's answer for position cur: ml (3 = nothing), off (the distance)
+    auto eval = [&](u32 cur, const Loaded& L, u32& mlOut, u32& offOut) {
+        if (rows) { if (!skipping) { if (cur - ntu > 384u) clear_bits(ntu + 96u, cur - 32u); } else clear_bits(ntu, cur); ntu = cur + 1u; }
+        else { if (skipping && ntu < cur) clear_bits(ntu + 1u, cur); ntu = cur; }
+        u32 const where = L.where, rk = L.rk; u64 const scan = L.scan;
+        u32 const hsh = kx_lazy_hash4((u32)scan, hBits); u32 const tag = rows ? hsh & 0xFFu : 0u;
+        u32 best = 3, bestPos = 0, insSeen = 0, attSeen = 0;
+        for (u32 cb = 0; cb < rk || (rk == 16383u && cb < where); cb += 64u) {
+            u32 const j = cb + (u32)lane;
+            bool v = j < where && (rk == 16383u || j < rk);
+            KLazyRec e = L.e;
+            if (cb != 0) { e.pt = 0; e.b0 = 0; e.b4 = 0; if (v) e = rec[where - 1u - j]; }
+            u32 const cp = e.pt & 0xFFFFFFu;
+            if (rk == 16383u && v) { u32 const ch = kx_lazy_hash4(e.b0, hBits); v = rows ? (ch >> 8) == (hsh >> 8) : ch == hsh; }
+            u64 const outside = (rk == 16383u) ? kx_ballot(j < where && !v) : 0ull;      // (a capped rank: the bucket ends where another hash starts)
+            if (outside) { int const Lo = (int)kx_ctz64(outside); if (lane >= Lo) v = false; }
+            bool const in = v && ((lds.ins[cp >> 5] >> (cp & 31u)) & 1u);
+            u64 const inM = kx_ballot(in);
+            bool const inRow = in && (!rows || insSeen + kx_popc64(inM & ((1ull << lane) - 1ull)) < rowCap);
+            bool const hit = inRow && (!rows || (e.pt >> 24) == tag);
+            u64 const hitM = kx_ballot(hit);
+            bool const cand = hit && attSeen + kx_popc64(hitM & ((1ull << lane) - 1ull)) < nbAttempts;
+            u32 len = 0;
+            if (cand) {
+                u32 const d0 = e.b0 ^ (u32)scan;
+                if (d0) len = (u32)(kx_ctz32(d0) >> 3);
+                else {
+                    u64 const d4 = e.b4 ^ ((scan >> 32) | ((u64)L.scanHi << 32));
+                    if (d4) len = 4u + (u32)(kx_ctz64(d4) >> 3);
+                    else {
+                        len = 12;
+                        for (;;) {
+                            if (cur + len >= n) break;
+                            u64 const x = kx_ld64_clamped(src, (int)(cur + len), (int)n) ^ kx_ld64_clamped(src, (int)(cp + len), (int)n);
+                            if (x) { len += (u32)(kx_ctz64(x) >> 3); break; }
+                            len += 8u;
+                        }
+                    }
+                }
+                if (len > n - cur) len = n - cur;
+            }
+            // the longest wins, the newer one among equals: lanes are in order of age, blocks too.  (Few candidates -- 8 up to level 7 -- are
+            // looked at one by one through the scalar unit; many by a butterfly of shuffles.)
+            if (nbAttempts <= 16u) {
+                for (u64 c = kx_ballot(cand && len > 3u); c; c &= c - 1) { int const Lc = (int)kx_ctz64(c); u32 const l = kx_bcast(len, Lc); if (l > best) { best = l; bestPos = kx_bcast(cp, Lc); } }
+            } else {
+                u32 m = len;
+                for (int o = 32; o >= 1; o >>= 1) { u32 const t = kx_shfl(m, lane ^ o); m = t > m ? t : m; }
+                if (m > best) { u64 const who = kx_ballot(cand && len == m); best = m; bestPos = kx_bcast(cp, (int)kx_ctz64(who)); }
+            }
+            insSeen += kx_popc64(inM); attSeen += kx_popc64(hitM);
+            if (outside || (rows && insSeen >= rowCap) || attSeen >= nbAttempts) break;
+        }
+        mlOut = best; offOut = cur - bestPos;
+    };
+    auto store = [&](u32 ll, u32 offBase, u32 ml) {
+        u32 const mlb = ml - 3u;
+        if (ll > 0xFFFFu) { longType = 1; longPos = nseq; }
+        if (mlb > 0xFFFFu) { longType = 2; longPos = nseq; }
+        if (lane == 0 && nseq < a.seq_cap) { KSeq q; q.offBase = offBase; q.litLength = (u16)ll; q.mlBase = (u16)mlb; seqs[nseq] = q; }
+        nseq++; nlit += ll;
+    };
 
+    Loaded L;
     while (ip < ilimit) {
         if (++guard > 400000u) { mm.status = 2; break; }
         u32 matchLength = 0, offBase = 1, start = ip + 1u;
-        bool store = false;
-        // the repeat offset at ip + 1
-        if (off1 > 0 && kx_ld32(src + ip + 1u - off1) == kx_ld32(src + ip + 1u)) {
+        bool stored = false;
+        // the search's loads, and with them the bytes a repeat offset before ip + 1 (off1 == 0: any address)
+        load(ip, off1 ? ip + 1u - off1 : ip, L);
+        if (off1 > 0 && L.x == (u32)(L.scan >> 8)) {                               // (bytes 1 .. 4 of what lies at ip)
             matchLength = kzl_count_wave(src, ip + 1u + 4u, ip + 1u + 4u - off1, n, lane) + 4u;
-            if (depth == 0) store = true;
+            if (depth == 0) stored = true;
         }
-        if (!store) {
-            u32 ml2, of2; KZL_SEARCH(ip, ml2, of2)
+        if (!stored) {
+            u32 ml2, of2; eval(ip, L, ml2, of2);
             if (ml2 > matchLength) { matchLength = ml2; start = ip; offBase = of2 + 3u; }
             if (matchLength < 4u) {
                 u32 const step = ((ip - anchor) >> 8) + 1u;               // kSearchStrength
@@ -294,63 +319,72 @@ KX_DEV void zstd_lazy_slice(const KLazyArgs& a, KLazyLds<WORDS>& lds, u32 slice,
             if (depth >= 1u)
             while (ip < ilimit) {
                 ip++;
-                if (off1 > 0 && kx_ld32(src + ip) == kx_ld32(src + ip - off1)) {
+                load(ip, off1 ? ip - off1 : ip, L);
+                if (off1 > 0 && L.x == (u32)L.scan) {
                     u32 const mlRep = kzl_count_wave(src, ip + 4u, ip + 4u - off1, n, lane) + 4u;
                     int const gain2 = (int)(mlRep * 3u), gain1 = (int)(matchLength * 3u - kx_hb32(offBase) + 1u);
                     if (mlRep >= 4u && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
                 }
                 {
-                    u32 ml3, of3; KZL_SEARCH(ip, ml3, of3)
+                    u32 ml3, of3; eval(ip, L, ml3, of3);
                     int const gain2 = (int)(ml3 * 4u - kx_hb32(ml3 > 3u ? of3 + 3u : 999999999u)), gain1 = (int)(matchLength * 4u - kx_hb32(offBase) + 4u);
                     if (ml3 >= 4u && gain2 > gain1) { matchLength = ml3; offBase = of3 + 3u; start = ip; continue; }
                 }
                 if (depth == 2u && ip < ilimit) {
                     ip++;
-                    if (off1 > 0 && kx_ld32(src + ip) == kx_ld32(src + ip - off1)) {
+                    load(ip, off1 ? ip - off1 : ip, L);
+                    if (off1 > 0 && L.x == (u32)L.scan) {
                         u32 const mlRep = kzl_count_wave(src, ip + 4u, ip + 4u - off1, n, lane) + 4u;
                         int const gain2 = (int)(mlRep * 4u), gain1 = (int)(matchLength * 4u - kx_hb32(offBase) + 1u);
                         if (mlRep >= 4u && gain2 > gain1) { matchLength = mlRep; offBase = 1; start = ip; }
                     }
                     {
-                        u32 ml3, of3; KZL_SEARCH(ip, ml3, of3)
+                        u32 ml3, of3; eval(ip, L, ml3, of3);
                         int const gain2 = (int)(ml3 * 4u - kx_hb32(ml3 > 3u ? of3 + 3u : 999999999u)), gain1 = (int)(matchLength * 4u - kx_hb32(offBase) + 7u);
                         if (ml3 >= 4u && gain2 > gain1) { matchLength = ml3; offBase = of3 + 3u; start = ip; continue; }
                     }
                 }
                 break;
             }
-            if (offBase > 3u) {
-                // catch up: bytes before the match that agree too (not before the anchor, not before the slice's first byte)
-                u32 const off = offBase - 3u;
-                u32 const maxBack = (start - anchor) < (start - off) ? (start - anchor) : (start - off);       // (start - off > 0 positions lie before the source)
-                u32 back = 0;
-                for (u32 done = 0; done < maxBack; done += 64u) {
-                    u32 const k = done + (u32)lane;
-                    bool const ne = k >= maxBack || src[start - 1u - k] != src[start - off - 1u - k];
-                    u64 const stop = kx_ballot(ne);
-                    if (stop) { back = done + (u32)kx_ctz64(stop); break; }
-                    back = done + 64u;
-                }
-                if (back > maxBack) back = maxBack;
-                start -= back; matchLength += back;
-                off2 = off1; off1 = off;
-            }
         }
-        KZL_STORE(start - anchor, offBase, matchLength)
-        anchor = ip = start + matchLength;
+        // where the parse goes on, and the repeat offset that is tried there first: both known before the catch-up (which moves the match's
+        // start and its length by the same amount), so its four bytes are asked for together with the catch-up's
+        u32 const nextIp = start + matchLength;
+        u32 const nOff2 = (!stored && offBase > 3u) ? off1 : off2;
+        u32 repNow = 0, repBack = 1;
+        if (nextIp <= ilimit && nOff2 > 0) { repNow = kx_ld32(src + nextIp); repBack = kx_ld32(src + nextIp - nOff2); }
+        if (!stored && offBase > 3u) {
+            // catch up: bytes before the match that agree too (not before the anchor, not before the slice's first byte)
+            u32 const off = offBase - 3u;
+            u32 const maxBack = (start - anchor) < (start - off) ? (start - anchor) : (start - off);
+            u32 back = 0;
+            for (u32 done = 0; done < maxBack; done += 64u) {
+                u32 const k = done + (u32)lane;
+                bool const ne = k >= maxBack || src[start - 1u - k] != src[start - off - 1u - k];
+                u64 const stop = kx_ballot(ne);
+                if (stop) { back = done + (u32)kx_ctz64(stop); break; }
+                back = done + 64u;
+            }
+            if (back > maxBack) back = maxBack;
+            start -= back; matchLength += back;
+            off2 = off1; off1 = off;
+        }
+        store(start - anchor, offBase, matchLength);
+        anchor = ip = nextIp;
         skipping = false;
         // repeat offset 2 right behind the match
-        while (ip <= ilimit && off2 > 0 && kx_ld32(src + ip) == kx_ld32(src + ip - off2)) {
+        bool first = true;
+        while (ip <= ilimit && off2 > 0) {
+            bool const same = first ? (repNow == repBack) : (kx_ld32(src + ip) == kx_ld32(src + ip - off2));
+            first = false;
+            if (!same) break;
             u32 const ml = kzl_count_wave(src, ip + 4u, ip + 4u - off2, n, lane) + 4u;
             { u32 const t = off2; off2 = off1; off1 = t; }
-            KZL_STORE(0u, 1u, ml)
+            store(0u, 1u, ml);
             ip += ml; anchor = ip;
         }
     }
     (void)saved1; (void)saved2;
-#undef KZL_CLEAR
-#undef KZL_SEARCH
-#undef KZL_STORE
     mm.nbSeq = nseq; mm.litSize = nlit; mm.lastLL = n - anchor; mm.longType = longType; mm.longPos = longPos;
     if (nseq > a.seq_cap) mm.status = 2;
     if (lane == 0) a.meta[slice] = mm;
