@@ -4,7 +4,7 @@ page (and starts right after one), the output buffer likewise with kmp_zstd_comp
 match / entropy (zstd levels 3, 1, 2) and DEFLATE kernel bodies run on the CPU wave emulator: a read past the end of a slice
 or a write past the output bound kills the process.  The frames are compared with the oracle / zlib on the way.
 
-    python tests/guard_pages_compress.py zstd | l1 | l2 | neg | l4 | deflate [--quick]      (neg: level -3; l4: level 4, slices above 16 KiB;
+    python tests/guard_pages_compress.py zstd | l1 | l2 | neg | l4 | lazy5 .. lazy10 | deflate [--quick]      (neg: level -3; l4: level 4, slices above 16 KiB;
     KXEMU_FUSE=1 / KXEMU_MATCH_V2=1 in the environment: the fused kernel / the split-phase parser for `zstd`)
 """
 import ctypes
@@ -20,7 +20,7 @@ emu = helpers.emu()
 o = helpers.oracle()
 rng = random.Random(5)
 which = sys.argv[1]
-sizes = [1,2,3,5,7,8,9,15,16,17,31,33,63,64,65,100,255,256,1000,4095,4096,4097,9000,20000,65535,65536] + ([131071,131072] if which!='deflate' else [])
+sizes = [1,2,3,5,7,8,9,15,16,17,31,33,63,64,65,100,255,256,1000,4095,4096,4097,9000,16384,16385,20000,65535,65536] + ([131071,131072] if which!='deflate' else [])
 if '--quick' in sys.argv:
     sizes = [1, 7, 8, 9, 17, 64, 255, 4097, 20000] + ([65536] if which == 'deflate' else [131072])
 if which == 'l4':
@@ -46,6 +46,16 @@ for S in sizes:
             r = fn(g.base, helpers._vp(in_off), helpers._vp(in_len), 1, 4, 1, gout.base, helpers._vp(ooff), helpers._vp(olen), 131072, lvl)
             assert r == 0
             f = gout.read(int(olen[0])); assert f == o.compress_level(d, lvl), (S, mix)
+        elif which.startswith('lazy'):
+            lvl = int(which[4:] or 7)              # lazy5 .. lazy10 (default 7): zstd_lazy.h (sort + parse + entropy bodies)
+            w = o.compress_lazy(d, lvl)
+            if w is None:
+                g.close(); gout.close(); continue
+            fn = emu.emu_zstd_compress_lazy
+            fn.argtypes = [ctypes.c_void_p]*3 + [ctypes.c_uint32, ctypes.c_uint32] + [ctypes.c_void_p]*3 + [ctypes.c_uint32, ctypes.c_int]
+            r = fn(g.base, helpers._vp(in_off), helpers._vp(in_len), 1, 1, gout.base, helpers._vp(ooff), helpers._vp(olen), max(len(d), 64), lvl)
+            assert r == 0, r
+            f = gout.read(int(olen[0])); assert f == w, (S, mix, lvl)
         elif which == 'deflate':
             import zlib
             fn = emu.emu_deflate

@@ -44,6 +44,8 @@ def main():
             ("big1m", "python3 bench.py --slice-kib 1024 --slices 8192 --steps 2 --warmup 1   (north_star slice-size sweep: 1 MiB slices, frames of several blocks)"),
             ("big256k", "python3 bench.py --slice-kib 256 --slices 32768 --steps 2 --warmup 1 --no-cpu   (slice-size sweep: 256 KiB slices)"),
             ("level1", "python3 bench.py --level 1 --steps 3 --warmup 1 --no-cpu   (65 536 x 64 KiB at level 1, the Ktor encoder's level)"),
+            ("level7", "python3 bench.py --level 7 --slices 16384 --steps 2 --warmup 1 --no-cpu   (16 384 x 64 KiB at level 7: libzstd's lazy2 parse over its row-based match finder, zstd_lazy.h)"),
+            ("dict_trained", "python3 bench.py --dict-kib 64 --dict-trained --slice-kib 8 --slices 262144 --steps 3 --warmup 1 --no-cpu   (8 KiB records with a 64 KiB dictionary trained by the box's ZDICT)"),
             ("deflate1", "python3 bench.py --mode deflate --deflate-level 1 --steps 1 --warmup 0 --no-cpu   (raw DEFLATE level 1 = deflate_fast: one k_deflate_fast launch over the batch, then the shared encoder)"),
             ("inflate", "python3 bench.py --mode inflate --steps 3 --warmup 1 --no-cpu   (ZlibDecompressor over the 65 536 level-6 streams of configs[4]; the streams are made first)")]
     for key, cmd in runs:
