@@ -519,7 +519,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     (void)hipFree(c->tables_flat); (void)hipFree(c->team_epoch_flat);
     (void)hipFree(c->team_epoch); (void)hipFree(c->tables4); (void)hipFree(c->epoch4); (void)hipFree(c->big_tables4);
     (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS); (void)hipFree(c->d_prior); (void)hipFree(c->d_dprior);
-    (void)hipFree(c->lz_srt); (void)hipFree(c->lz_sb); (void)hipFree(c->lz_wr);
+    (void)hipFree(c->lz_srt); (void)hipFree(c->lz_wr);
     (void)hipFree(c->fstate); (void)hipFree(c->hufct); (void)hipFree(c->big_tables); (void)hipFree(c->remaining); (void)hipFree(c->big_counters); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { if (c->evm[i][j]) (void)hipEventDestroy(c->evm[i][j]); if (c->eve[i][j]) (void)hipEventDestroy(c->eve[i][j]); }
@@ -554,6 +554,7 @@ extern "C" int kmp_batch_memory(kmp_batch_ctx* c, kmp_batch_memory_info* info)
     if (c->tables4) m.other_tables += (size_t)c->teams4 * KX_TBL4_ENTRIES * sizeof(u32) + (size_t)c->teams4 * sizeof(u32);
     if (c->big_tables4) m.other_tables += ns * KX_BIG4_ENTRIES * sizeof(u32);
     if (c->d_dict) m.other_tables += c->dict_size + 64 + ((size_t)4 << c->cdH) + ((size_t)4 << c->cdC);
+    if (c->lz_srt) m.other_tables += (size_t)c->lz_chunk * c->lz_pos_cap * (sizeof(KLazyRec) + sizeof(u32));       // (levels 5 .. 10: the sorted positions' records and where each stands)
     if (c->big) m.block_chain = ns * sizeof(KFrameState) + ns * 512 * sizeof(u32) + ns * KX_BIG_TBL_ENTRIES * sizeof(u32) + ns * 4 + 64;
     if (c->pre_stage) m.decode_staging += (size_t)c->pre_slices * c->pre_seq_cap * 8u + (size_t)c->pre_slices * c->pre_blk_cap * sizeof(KPreBlk) + (size_t)c->pre_slices * 4u + ((size_t)c->pre_slices * 2u + KXP_SORT_BUCKETS) * 4u;
     if (c->pre_lits) m.decode_staging += (size_t)c->pre_slices * c->pre_lit_cap + (size_t)c->pre_slices * c->pre_blk_cap * sizeof(KPreLit) + (size_t)c->pre_slices * 4u;
@@ -676,7 +677,7 @@ static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64
 // ---- levels 5 .. 10: strategies greedy / lazy / lazy2 (zstd_lazy.h), slices of one block ------------------------------------------------
 // The batch goes through in pieces that share one workspace (20 bytes a position: the sorted positions with their first bytes, where each
 // position stands): sort, then the wave-per-slice parse; the entropy kernel runs once over the whole batch.
-static int lazy_workspace(kmp_batch_ctx* c);
+static int lazy_workspace(kmp_batch_ctx* c, u32 need_bytes);
 static int lazy_parse(kmp_batch_ctx* c, hipStream_t st, const void* d_src, const uint64_t* d_in_off, u32 n, u32 first0, int level);
 static int zstd_compress_lazy(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                               uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream, int level)
@@ -687,8 +688,8 @@ static int zstd_compress_lazy(kmp_batch_ctx* c, const void* d_src, const uint64_
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
-    KMP_TRY(lazy_workspace(c));
-    KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));
+    KMP_TRY(batch_begin(c, st, d_in_len, n, c->max_slice_bytes));          // (first: waits for the context's previous batch, whose workspace this may replace)
+    KMP_TRY(lazy_workspace(c, c->max_slice_bytes));
     KMP_TRY(lazy_parse(c, st, d_src, d_in_off, n, 0, level));
     KEntropyArgs e;
     e.src = (const u8*)d_src; e.in_off = d_in_off; e.in_len = c->len_ok; e.n_slices = n;
@@ -701,10 +702,14 @@ static int zstd_compress_lazy(kmp_batch_ctx* c, const void* d_src, const uint64_
     c->last_chunks = 1;
     return batch_end(c, st, d_in_len, n, c->max_slice_bytes, d_out_len, c->meta);
 }
-static int lazy_workspace(kmp_batch_ctx* c)
+// need_bytes: the largest slice these kernels will parse (level 4 hands them only its slices up to 16 KiB: a quarter of the memory)
+static int lazy_workspace(kmp_batch_ctx* c, u32 need_bytes)
 {
+    if (c->lz_srt && c->lz_pos_cap < ((need_bytes + 63u) & ~63u)) {          // made for a smaller need: once more, larger
+        (void)hipFree(c->lz_srt); (void)hipFree(c->lz_wr); c->lz_srt = nullptr; c->lz_wr = nullptr;
+    }
     if (!c->lz_srt) {
-        u32 const pos_cap = (c->max_slice_bytes + 63u) & ~63u;
+        u32 const pos_cap = (need_bytes + 63u) & ~63u;
         u32 cap = (u32)((1ull << 30) / pos_cap); if (cap > 16384u) cap = 16384u; if (cap < 1u) cap = 1u;
         u32 const chunk = c->max_slices < cap ? c->max_slices : cap;
         HIP_TRY(hipMalloc((void**)&c->lz_srt, (size_t)chunk * pos_cap * sizeof(KLazyRec)));
@@ -1169,7 +1174,7 @@ static int zstd_compress_dfast(kmp_batch_ctx* c, const void* d_src, const uint64
         if (l4) {
             // level 4 up to 16 KiB is strategy "greedy" (ZSTD_getCParams(4, n <= 16 KiB)): those slices, which k_zstd_match has passed over, are
             // parsed by the kernels of levels 5 .. 10 (zstd_lazy.h), which pass over all the others
-            KMP_TRY(lazy_workspace(c));
+            KMP_TRY(lazy_workspace(c, c->max_slice_bytes < 16384u ? c->max_slice_bytes : 16384u));
             KMP_TRY(lazy_parse(c, st, d_src, d_in_off, m_n, first, 4));
         }
         HIP_TRY(hipEventRecord(c->evm[ci][1], st));
