@@ -519,7 +519,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     (void)hipFree(c->tables_flat); (void)hipFree(c->team_epoch_flat);
     (void)hipFree(c->team_epoch); (void)hipFree(c->tables4); (void)hipFree(c->epoch4); (void)hipFree(c->big_tables4);
     (void)hipFree(c->d_dict); (void)hipFree(c->d_dictL); (void)hipFree(c->d_dictS); (void)hipFree(c->d_prior); (void)hipFree(c->d_dprior);
-    (void)hipFree(c->lz_srt); (void)hipFree(c->lz_wr);
+    (void)hipFree(c->lz_srt); (void)hipFree(c->lz_wr); (void)hipFree(c->lz_order);
     (void)hipFree(c->fstate); (void)hipFree(c->hufct); (void)hipFree(c->big_tables); (void)hipFree(c->remaining); (void)hipFree(c->big_counters); (void)hipFree(c->counter);
     for (int i = 0; i < 14; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < KMP_MAX_CHUNKS; i++) for (int j = 0; j < 2; j++) { if (c->evm[i][j]) (void)hipEventDestroy(c->evm[i][j]); if (c->eve[i][j]) (void)hipEventDestroy(c->eve[i][j]); }
@@ -717,6 +717,8 @@ static int lazy_workspace(kmp_batch_ctx* c, u32 need_bytes)
             (void)hipGetLastError(); (void)hipFree(c->lz_srt); c->lz_srt = nullptr;
             g_last_error = "kmp_zstd_compress_batch_level: no memory for the workspace of levels 5 .. 10"; return KMP_ERR_HIP;
         }
+        (void)hipFree(c->lz_order); c->lz_order = nullptr;
+        if (hipMalloc((void**)&c->lz_order, ((size_t)2 * chunk + 256) * sizeof(u32)) != hipSuccess) { (void)hipGetLastError(); c->lz_order = nullptr; }      // (without it the slices go as they come)
         c->lz_pos_cap = pos_cap; c->lz_chunk = chunk;
     }
     return KMP_OK;
@@ -732,7 +734,11 @@ static int lazy_parse(kmp_batch_ctx* c, hipStream_t st, const void* d_src, const
         g.src = (const u8*)d_src; g.in_off = d_in_off + first; g.in_len = c->len_ok + first; g.n_slices = m;
         g.rec = (KLazyRec*)c->lz_srt; g.wr = c->lz_wr; g.pos_cap = c->lz_pos_cap;
         g.seqs = c->seqs + (size_t)first * c->seq_cap; g.seq_cap = c->seq_cap; g.meta = c->meta + first; g.level = (u32)level;
+        // (the parse takes the costliest slices first: cost classes from the sort, a counting sort of the classes; batches worth ordering only)
+        u32* const ord = (m >= 1024u && c->lz_order) ? c->lz_order : nullptr;
+        if (ord) { g.order_key = ord; g.order_hist = ord + c->lz_chunk; HIP_TRY(hipMemsetAsync(g.order_hist, 0, 256 * sizeof(u32), st)); }
         hipLaunchKernelGGL(k_zstd_lazy_sort, dim3(m), dim3(256), 0, st, g);
+        if (ord) { KMP_TRY(size_sort_keys(c, st, m, g.order_key, g.order_hist, ord + c->lz_chunk + 256)); g.order = ord + c->lz_chunk + 256; }
         if (c->max_slice_bytes <= 65536u) hipLaunchKernelGGL(k_zstd_lazy<2048>, dim3(m), dim3(64), 0, st, g);
         else hipLaunchKernelGGL(k_zstd_lazy<4096>, dim3(m), dim3(64), 0, st, g);
         HIP_TRY(hipGetLastError());

@@ -77,7 +77,7 @@ struct kmp_batch_ctx {
     // raw-content dictionary of the last kmp_zstd_compress_batch_dict call: device copy + CDict tables (built on the host)
     u8* d_dict; u32* d_dictL; u32* d_dictS; u32 dict_size; u64 dict_hash; u32 cdW, cdH, cdC, cdM;
     struct KDictDPrior* d_dprior; const void* ddict_ptr; u32 ddict_size; u64 ddict_hash; u32 ddict_off, ddict_id, ddict_rep[3];      // ... for the decoder (the caller's dictionary lies in device memory: its head is read back once per dictionary)
-    u32* lz_srt; u32* lz_wr; u32 lz_pos_cap, lz_chunk;       // zstd levels 5 .. 10 (and level 4's slices up to 16 KiB): the sorted positions' records (KLazyRec, 16 bytes), where each position stands (one piece's worth)
+    u32* lz_srt; u32* lz_wr; u32* lz_order; u32 lz_pos_cap, lz_chunk;       // zstd levels 5 .. 10 (and level 4's slices up to 16 KiB): the sorted positions' records (KLazyRec, 16 bytes), where each position stands (one piece's worth)
     struct KDictPrior* d_prior; u32 dict_content; u32 dict_rep[2];      // a formatted dictionary: its tables on the device, the size of its content part, its repeat offsets
     int big; int big_G; KFrameState* fstate; u32* hufct; u32* big_tables; u32* remaining; u32* big_counters; u32 last_rounds;
     u32 cus;                                   // compute units of the device

@@ -28,6 +28,8 @@ struct KLazyArgs {
     KLazyRec* rec; u32* wr; u32 pos_cap;              // per slice: pos_cap entries each
     KSeq* seqs; u32 seq_cap; KSliceMeta* meta;
     u32 level;
+    u32* order_key = nullptr; u32* order_hist = nullptr;     // the sort files each slice under a cost class (occupied buckets / 64, at most 255) ...
+    const u32* order = nullptr;                              // ... and the parse takes the slices in this order: the costliest first (null: as they come)
 };
 
 // ZSTD_getCParams(level, n, 0) where it is one of the three strategies; strat 0: not served at this size
@@ -80,7 +82,7 @@ KX_DEV void zstd_lazy_sort_body(const KLazyArgs& a)
         u32 const slice = kx_xcd_chunk(it, a.n_slices);
         const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
         KLazyPar const P = kx_lazy_params(a.level, n);
-        if (P.strat == 0 || n < 8u) continue;                                   // (uniform over the workgroup)
+        if (P.strat == 0 || n < 8u) { if (a.order_key && tid == 0) { a.order_key[slice] = 0; kx_atomic_add(a.order_hist, 1u); } continue; }      // (uniform over the workgroup)
         u32* const wr = a.wr + (size_t)slice * a.pos_cap; KLazyRec* const rec = a.rec + (size_t)slice * a.pos_cap;
         u32 const nb = 1u << P.buckLog; bool const wide = P.rows != 0;            // wide: 32-bit counters
         u32 const hBits = P.rows ? P.buckLog + 8u : P.buckLog;
@@ -125,8 +127,17 @@ KX_DEV void zstd_lazy_sort_body(const KLazyArgs& a)
         // ---- pass 2: bucket starts
         {
             u32 const per = nb / (u32)nthreads ? nb / (u32)nthreads : 1u;            // (nb >= 256 at every served size? no: small slices have few buckets)
-            u32 const first = (u32)tid * per; u32 s = 0;
-            for (u32 i = 0; i < per && first + i < nb; i++) s += KZL_CNT(first + i);
+            u32 const first = (u32)tid * per; u32 s = 0, occ = 0;
+            for (u32 i = 0; i < per && first + i < nb; i++) { u32 const v = KZL_CNT(first + i); s += v; occ += v ? 1u : 0u; }
+            // how many buckets the slice uses says how varied its bytes are: a stand-in for the number of searches the parse will make
+            // (text and binary slices: thousands; sparse ones: tens), by which the parse kernel orders its slices -- the launch does not
+            // end with a few waves walking its costliest slices alone
+            if (a.order_key) {
+                part[tid] = occ;
+                kx_block_sync();
+                if (tid == 0) { u32 tot = 0; for (int t = 0; t < nthreads; t++) tot += part[t]; u32 k = tot >> 5; if (k > 255u) k = 255u; a.order_key[slice] = k; kx_atomic_add(a.order_hist + k, 1u); }
+                kx_block_sync();
+            }
             part[tid] = s;
             kx_block_sync();
             if (tid == 0) { u32 run = 0; for (int t = 0; t < nthreads; t++) { u32 const v = part[t]; part[t] = run; run += v; } }
@@ -396,7 +407,7 @@ KX_DEV void zstd_lazy_body(const KLazyArgs& a)
     KX_SHARED KLazyLds<WORDS> lds;
     int const lane = kx_lane();
     for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
-        u32 const slice = kx_xcd_chunk(it, a.n_slices);
+        u32 const slice = a.order ? a.order[it] : kx_xcd_chunk(it, a.n_slices);
         zstd_lazy_slice(a, lds, slice, lane);
         kx_sync();
     }
