@@ -36,6 +36,7 @@ static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
 
 /* the level the binary library runs at (default 3: BASELINE configs[1]; the bench's lines for other levels set theirs) */
 static int g_zstd_level = 3;
+__attribute__((visibility("default")))
 void cpubench_set_zstd_level(int level) { g_zstd_level = level; }
 
 static void* worker(void* arg)
