@@ -167,6 +167,8 @@ def test_cpu_bench_harness_times_the_oracle_port(tmp_path):
     hc = bench.host_cores()
     assert 1 <= hc["threads_used"] <= hc["nproc"] and hc["affinity"] >= 1
     lib = ctypes.CDLL(bench.build_cpu_bench())
+    for sym in ("cpubench_zstd_l3", "cpubench_codec", "cpubench_set_zstd_level"):       # everything bench.py calls (built with hidden visibility: an entry point has to ask to be exported)
+        assert hasattr(lib, sym), sym
     lib.cpubench_zstd_l3.restype = ctypes.c_int
     lib.cpubench_zstd_l3.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
