@@ -780,6 +780,7 @@ def main():
             k_entropy.append(b.last_kernel_ms(1))
     fence()
     dt = time.perf_counter() - t0
+    launches_timed = max(1, b.last_chunks())           # (of the timed steps: the legs further down run the batch in other shapes)
     if os.environ.get("KMP_BENCH_DEBUG") and k_match:
         print("per-step k_zstd_match ms:", [round(x, 1) for x in k_match], file=sys.stderr)
     if dist is not None:
@@ -997,7 +998,7 @@ def main():
         ms_entropy = float(np.mean(k_entropy))
         # len_in + len_frame + 16 B metadata per slice; the batch goes through `launches` launches of each
         # kernel (chunks), ms_match is the mean launch duration
-        launches = max(1, b.last_chunks())
+        launches = launches_timed
         algo_bytes = (in_bytes + frame_bytes + 16 * n) // launches
         achieved = algo_bytes / (ms_match * 1e-3) / 1e9
         traffic = None
