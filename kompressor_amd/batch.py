@@ -169,11 +169,11 @@ class ZstdBatch:
 
     def compress(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, dictionary=None, level=3, streaming=None, reference=False, check=False):
         """src: uint8 device tensor; in_off int64, in_len int32 device tensors (n each).  dictionary: bytes of a
-        raw-content dictionary shared by all slices (host memory; its tables are built once per dictionary).
-        level: 3 (default), or 1 / 2 without a dictionary: slices up to the level's window (512 KiB / 1 MiB; above 128 KiB
-        the context must have been created for slice sizes in (128 KiB, 512 KiB] / (128 KiB, 1 MiB]); a negative level (slices up
-        to 128 KiB, and up to 512 KiB in a context created for such slices); or 4 for slices above 16 KiB up to 128 KiB and above 256 KiB
-        (where libzstd runs level 4 as the double-fast parse; the other sizes are refused: out_len 0).
+        dictionary shared by all slices (host memory; raw content, or zstd's own format -- magic EC30A437 -- with its tables,
+        repeat offsets and ID; level 3, slices up to 128 KiB; its tables are built once per dictionary).
+        level: 3 (default); 1 / 2 / a negative level at any size the context holds (without a dictionary); 4 up to 128 KiB and above
+        256 KiB; 5 .. 10 (libzstd's greedy / lazy / lazy2 parsers) for slices up to 128 KiB -- at 9 and 10 a slice of 8 bytes .. 16 KiB is
+        another strategy and comes back refused (out_len 0, status bit 4), as does a level-4 slice between 128 and 256 KiB.
         streaming: None = one-shot frames; "data" / "empty" = the frames of slices that arrived through finish = false
         calls, closed by a call with / without data (context created for slices above 128 KiB; levels 1 to 3).
         reference: the frames ZstdCompressor(level).transform(bytes) returns -- above 128 KiB the reference's output slices
