@@ -371,13 +371,13 @@ def test_emulated_streaming_frames():
     rows = helpers.levels_golden()["stream"]
     n = 0
     for (d, cuts), (size, fed, flen, sha) in zip(helpers.stream_cases(), rows):
-        if len(d) > 300000 or n >= 12:
+        if len(d) > 300000 or n >= 7:
             continue
         empty = cuts[-1] == cuts[-2]
         f = helpers.emu_compress_big([d], G=8, stream=2 if empty else 1)[0][0]
         assert len(f) == flen and helpers.sha256(f) == sha, (size, cuts)
         n += 1
-    assert n >= 12
+    assert n >= 7
 
 
 def test_emulated_level1_multiblock_and_streams():
@@ -385,20 +385,20 @@ def test_emulated_level1_multiblock_and_streams():
     by the frame step), one-shot and as streaming frames, against libzstd 1.5.7 (the smaller vectors; the GPU suite runs all)."""
     G = helpers.levels_golden()
     ins = dict(helpers.multiblock_inputs())
-    rows = [r for r in G["l1_multiblock"] if r[1] <= 300000][:8]
+    rows = [r for r in G["l1_multiblock"] if r[1] <= 300000][:5]
     frames = helpers.emu_compress_big([ins[r[0]] for r in rows], G=8, nblocks=2, level=1)[0]
     for (name, n, flen, sha), f in zip(rows, frames):
         assert len(f) == flen and helpers.sha256(f) == sha, name
     cases = [(d, cuts) for d, cuts in helpers.stream_cases() if len(d) <= 512 * 1024]
     n = 0
     for (d, cuts), (size, fed, flen, sha) in zip(cases, G["l1_stream"]):
-        if len(d) > 300000 or n >= 8:
+        if len(d) > 300000 or n >= 5:
             continue
         empty = cuts[-1] == cuts[-2]
         f = helpers.emu_compress_big([d], G=(4, 16)[n % 2], stream=2 if empty else 1, level=1)[0][0]
         assert len(f) == flen and helpers.sha256(f) == sha, (size, cuts)
         n += 1
-    assert n >= 6
+    assert n >= 5
 
 
 def test_emulated_level2_multiblock_and_streams():
