@@ -96,10 +96,12 @@ KMP_API size_t kmp_zstd_decompress_stream(kmp_zstd_dctx* dctx,
  * (deflate, call at :73).  Same cursor semantics; the return value is zlib's: Z_OK 0, Z_STREAM_END 1,
  * Z_BUF_ERROR -5 are benign for the Kotlin side (ZlibCompressor.jvm.kt:49-56).  The GPU path implements
  * levels 1 .. 9 (-1 = 6: zlib's deflate_fast for 1 .. 3, deflate_slow for 4 .. 9, each byte-identical to zlib's output),
- * windowBits -15 (ZlibFormat.Raw), 15 (ZlibFormat.Zlib: 78 01 / 5E / 9C / DA header by level + Adler-32) or
- * 31 (ZlibFormat.Gzip: 10-byte header, CRC-32 + ISIZE), memLevel 8, strategy 0, streams up to 1 GiB (the stream is
- * compressed when the caller finishes it); other settings (level 0, smaller windows, other memLevels or strategies) make
- * create return NULL. */
+ * windowBits as deflateInit2 takes it: -15 .. -9 (ZlibFormat.Raw), 9 .. 15 (ZlibFormat.Zlib: CMF / FLG header by window and
+ * level -- 78 01 / 5E / 9C / DA with a 32 KiB window -- + Adler-32; 8 is taken as 9, as zlib does) or 25 .. 31 (ZlibFormat.Gzip:
+ * 10-byte header, CRC-32 + ISIZE), memLevel 1 .. 9, strategy 0, streams up to 1 GiB (the stream is compressed when the caller
+ * finishes it); other settings (level 0, windowBits 8 without the zlib wrapper -- an error in zlib too --, other strategies)
+ * make create return NULL.  (A decompressor created with a smaller window than the stream's still decodes it: the window
+ * declared to inflateInit2 is not enforced.) */
 typedef struct kmp_zlib_cstream kmp_zlib_cstream;
 typedef struct kmp_zlib_dstream kmp_zlib_dstream;
 KMP_API kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bits, int mem_level, int strategy);
@@ -340,6 +342,20 @@ KMP_API int kmp_deflate_compress_batch_level(kmp_batch_ctx* ctx,
                                              uint32_t n,
                                              void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
                                              int format, int level, void* hip_stream);
+/* ... and with the other two settings the Kotlin constructor passes to deflateInit2 (ZlibCompressor(format, compressionLevel,
+ * windowBits, memLevel): ZlibCompressor.jvm.kt:7-17, ZlibFormat.kt:32-57; Wrapper.cpp:20): window_bits 9 .. 15 -- the window is
+ * 1 << window_bits bytes, matches reach back (1 << window_bits) - 262, the zlib header's CMF byte says so; 8 is taken as 9 with
+ * the zlib wrapper and refused without it, as zlib does -- and mem_level 1 .. 9: the hash has mem_level + 7 bits and a block is
+ * closed after (1 << (mem_level + 6)) - 1 symbols.  Here window_bits is the plain number and `format` names the wrapper (the
+ * sign / + 16 encoding of deflateInit2 is the streaming entry point's, kmp_zlib_create_compressor).  Stream i needs room for
+ * kmp_deflate_bound_params(len, window_bits, mem_level): zlib's deflateBound for settings other than the default ones (an eighth
+ * more than the data).  KMP_ERR_ARG for anything else. */
+KMP_API size_t kmp_deflate_bound_params(size_t src_size, int window_bits, int mem_level);
+KMP_API int kmp_deflate_compress_batch_params(kmp_batch_ctx* ctx,
+                                              const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                              uint32_t n,
+                                              void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len,
+                                              int format, int level, int window_bits, int mem_level, void* hip_stream);
 /* inflate: n streams -> d_dst + d_out_off[i] (capacity d_out_cap[i]); format 0 = raw deflate, 1 = zlib,
  * 2 = gzip, 3 = zlib or gzip decided per stream by its first bytes (ZlibFormat.AutoDetectZlibGzip,
  * ZlibFormat.kt:52-55); checksums are verified;

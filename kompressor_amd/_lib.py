@@ -46,6 +46,8 @@ SIGNATURES = [
     ("kmp_zlib_compress_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P]),
     ("kmp_gzip_compress_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P]),
     ("kmp_deflate_compress_batch_level", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_int, _c.c_int, _P]),
+    ("kmp_deflate_compress_batch_params", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P]),
+    ("kmp_deflate_bound_params", _c.c_size_t, [_c.c_size_t, _c.c_int, _c.c_int]),
     ("kmp_inflate_batch", _c.c_int, [_P, _P, _P, _P, _c.c_uint32, _P, _P, _P, _P, _P, _c.c_int, _P]),
     ("kmp_deflate_last_kernel_ms", _c.c_int, [_P, _c.POINTER(_c.c_float)]),
     ("kmp_zlib_create_compressor", _P, [_c.c_int, _c.c_int, _c.c_int, _c.c_int]),

@@ -278,21 +278,27 @@ class ZstdBatch:
             raise RuntimeError(f"kmp_inflate_batch failed ({rc}): {self._err()}")
         return dst, out_off, out_len, status
 
-    def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, zlib_wrapper=False, format=None, level=6, check=False):   # noqa: A002
-        """DEFLATE streams (zlib level 6 -- or any other level 1 .. 9: deflate_fast 1 .. 3, deflate_slow 4 .. 9 --, windowBits 15, memLevel 8),
-        format "raw" / "zlib" / "gzip", for slices up to the context's max_slice_bytes (64 KiB at least)."""
+    def deflate(self, src, in_off, in_len, dst=None, out_off=None, out_len=None, zlib_wrapper=False, format=None, level=6, check=False,   # noqa: A002
+                window_bits=15, mem_level=8):
+        """DEFLATE streams (zlib level 6 -- or any other level 1 .. 9: deflate_fast 1 .. 3, deflate_slow 4 .. 9 --; windowBits 9 .. 15 and
+        memLevel 1 .. 9 as deflateInit2 takes them, 15 and 8 by default), format "raw" / "zlib" / "gzip", for slices up to the context's
+        max_slice_bytes (64 KiB at least)."""
         fmt = self._FORMATS[format] if format is not None else (1 if zlib_wrapper else 0)
         if fmt == 3:
             raise ValueError("Compression can't be used with auto-detection")       # ZlibFormat.kt:28
         n = in_len.numel()
-        stride = (self.lib.kmp_deflate_bound(max(self.max_slice_bytes, 65536)) + 63) & ~63
+        params = (window_bits, mem_level) != (15, 8)
+        stride = (self.lib.kmp_deflate_bound_params(max(self.max_slice_bytes, 65536), window_bits, mem_level) + 63) & ~63
         if dst is None:
             dst = torch.empty(n * stride + 64, dtype=torch.uint8, device=self.device)
         if out_off is None:
             out_off = torch.arange(n, dtype=torch.int64, device=self.device) * stride
         if out_len is None:
             out_len = torch.zeros(n, dtype=torch.int32, device=self.device)
-        if level in (-1, 6):
+        if params:
+            rc = self.lib.kmp_deflate_compress_batch_params(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n, _ptr(dst), _ptr(out_off), _ptr(out_len),
+                                                            fmt, level, window_bits, mem_level, self._stream())
+        elif level in (-1, 6):
             fn = (self.lib.kmp_deflate_compress_batch, self.lib.kmp_zlib_compress_batch, self.lib.kmp_gzip_compress_batch)[fmt]
             rc = fn(self._h, _ptr(src), _ptr(in_off), _ptr(in_len), n, _ptr(dst), _ptr(out_off), _ptr(out_len), self._stream())
         else:

@@ -262,7 +262,7 @@ KX_DEV void deflate_encode_slice(const KdArgs& a, KdEncLds& lds, u32 slice, int 
     // level 6 / 32 KiB window is 78 9C (CMF 0x78, FLG: level flags 2 -- 1 below level 6: 5E, 3 above: DA --, check bits so that
     // CMF*256+FLG % 31 == 0); gzip (format 2): 1F 8B, CM 8, no flags, MTIME 0, XFL 0 (2 at level 9), OS 3 (what zlib writes on Linux)
     u32 bitpos = a.format == 1 ? 16u : (a.format == 2 ? 80u : 0u);
-    for (int i = lane; i < 128; i += 64) lds.cbuf[i] = (i != 0) ? 0u : (a.format == 1 ? (0x78u | (a.zflg << 8)) : (a.format == 2 ? (0x0300u | a.gxfl) : 0u));
+    for (int i = lane; i < 128; i += 64) lds.cbuf[i] = (i != 0) ? 0u : (a.format == 1 ? (a.zcmf | (a.zflg << 8)) : (a.format == 2 ? (0x0300u | a.gxfl) : 0u));
     if (a.format == 2 && lane == 0) { kx_st32(dst, 0x00088B1Fu); kx_st32(dst + 4, 0u); }
     kx_sync();
     u32 s0 = 0;

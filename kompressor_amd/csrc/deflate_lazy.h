@@ -51,9 +51,10 @@ template <bool TINY> KX_DEV u64 kdl_get64(const u8* src, int q, int n) { return 
 // Pass 1, in position order (the waves of the workgroup take turns on the table, as in k_deflate_chains): rank[p] = how many
 // earlier positions share p's hash.  Pass 2: exclusive scan of the bucket sizes.  Pass 3, any order: where[p] = start of the
 // bucket + rank[p]; srt[where[p]] = p.
+template <int HB = 15>                        // hash bits the table has room for (memLevel 9: 16)
 KX_DEV void deflate_sort_body(const KdArgs& a)
 {
-    KX_SHARED u16 cnt[32768];                     // bucket sizes, then bucket starts (a slice has at most 65 534 chained positions)
+    KX_SHARED u16 cnt[1 << HB];                     // bucket sizes, then bucket starts (a slice has at most 65 534 chained positions)
     KX_SHARED u32 part[256];
     KX_SHARED u32 occp[256];
     int const lane = kx_lane(); int const wv = kx_wave(); int const nw = kx_nwaves(); int const tid = wv * 64 + lane; int const nthreads = nw * 64;
@@ -62,7 +63,8 @@ KX_DEV void deflate_sort_body(const KdArgs& a)
         const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
         u16* const rank = kdl_rank(a, slice);
         u32* const wr = kdl_wr(a, slice); u16* const srt = kdl_srt(a, slice); KdlBytes* const sb = kdl_sb(a, slice);
-        for (int i = tid; i < 32768; i += nthreads) cnt[i] = 0;
+        int const hsize = (int)a.hmask + 1;
+        for (int i = tid; i < hsize; i += nthreads) cnt[i] = 0;
         kx_block_sync();
         u32 const nIns = n >= 3 ? n - 2 : 0;                // positions 0 .. n-3 enter the chains, in order
         // ---- pass 1 (the source bytes of a group of four rounds are fetched a group ahead, as in k_deflate_chains)
@@ -86,7 +88,7 @@ KX_DEV void deflate_sort_body(const KdArgs& a)
                 u32 const base = gbase + (u32)k * (u32)nthreads;
                 if (base >= nIns) break;                    // uniform over the workgroup
                 u32 const p = base + (u32)wv * 64u + (u32)lane; bool const valid = vq[k];
-                u32 const h = valid ? kd_hash3(hq[k] & 0xFFu, (hq[k] >> 8) & 0xFFu, (hq[k] >> 16) & 0xFFu) : 0x8000u + (u32)lane;
+                u32 const h = valid ? kd_hash3(a, hq[k] & 0xFFu, (hq[k] >> 8) & 0xFFu, (hq[k] >> 16) & 0xFFu) : 0x10000u + (u32)lane;
                 u32 rk = 0;
                 for (int w = 0; w < nw; w++) {
                     if (wv == w) {
@@ -124,7 +126,7 @@ KX_DEV void deflate_sort_body(const KdArgs& a)
         kx_block_sync();
         // ---- pass 2: bucket starts (each thread scans 32768 / nthreads consecutive buckets; the threads' sums through LDS)
         {
-            int const per = 32768 / nthreads;
+            int const per = hsize / nthreads;           // (256 threads, 256 buckets and more)
             u32 s = 0, occ = 0;
             for (int i = 0; i < per; i++) { u32 const v = cnt[tid * per + i]; s += v; occ += v ? 1u : 0u; }
             // how many of the 32 768 buckets the slice uses says how varied its bytes are: a cheap stand-in for what the parse will
@@ -150,7 +152,7 @@ KX_DEV void deflate_sort_body(const KdArgs& a)
         for (u32 p = (u32)tid; p < nIns; p += (u32)nthreads) {
             u64 const w8 = kdl_ld64(src, (int)p, (int)n);
             u32 const w = (u32)w8;
-            u32 const h = kd_hash3(w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu);
+            u32 const h = kd_hash3(a, w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu);
             u32 const rk = rank[p];
             u32 const where = (u32)cnt[h] + rk;
             wr[p] = where | (rk << 16);
@@ -178,7 +180,8 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
         u32 nsym = 0, blockSyms = 0; int block_start = 0;
         u32 symq = 0;                                      // lane (nsym & 63) holds symbol nsym until 64 are there
         // zlib's 64 KiB window buffer (see deflate_parse_body): only the stored-block eligibility of a block depends on it
-        int base = 0, dataEnd = n < 2 * KD_WSIZE ? n : 2 * KD_WSIZE;
+        int const W = (int)a.wsize, MD = (int)a.max_dist; u32 const LB = a.lit_buf;
+        int base = 0, dataEnd = n < 2 * W ? n : 2 * W;
         int const maxChain = (int)a.chain, niceMax = (int)a.nice;
         int const nIns = n >= 3 ? n - 2 : 0;
         // The parse is one decision chain per slice and runs on the scalar unit, of which a compute unit has ONE: with 32 slices per CU
@@ -211,9 +214,9 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
             if (dataEnd - strstart < KD_MIN_LOOKAHEAD) {
                 // fill_window: one pass is enough (it brings at least 65 536 - strstart bytes, or all that is left)
                 int const rel = strstart - base;
-                int const slide = (rel >= KD_WSIZE + KD_MAX_DIST) ? KD_WSIZE : 0;
+                int const slide = (rel >= W + MD) ? W : 0;
                 base += slide;
-                int const more = 2 * KD_WSIZE - (dataEnd - base);
+                int const more = 2 * W - (dataEnd - base);
                 dataEnd += (n - dataEnd < more) ? n - dataEnd : more;
                 if (dataEnd == strstart) break;
             }
@@ -239,7 +242,7 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
                 int const room_w = dataEnd - KD_MIN_LOOKAHEAD - strstart + 1; if (K > room_w) K = room_w;
                 int const first_lit = match_available ? strstart - 1 : strstart;          // the first position passed emits the byte behind it, if that is still owed
                 int L = match_available ? K : K - 1;
-                int const room_q = 64 - (int)(nsym & 63u), room_b = (int)(KD_LIT_BUFSIZE - 2) - (int)blockSyms;
+                int const room_q = 64 - (int)(nsym & 63u), room_b = (int)(LB - 2u) - (int)blockSyms;
                 int const Lmax = room_q < room_b ? room_q : room_b;
                 if (L > Lmax) { K -= L - Lmax; L = Lmax; }
                 if (K >= 2 && L >= 1) {
@@ -297,7 +300,7 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
                     }
                     // position 0 is zlib's NIL; beyond MAX_DIST the chain ends (and with it every later candidate: they lie further back).
                     // The head of the chain may lie exactly MAX_DIST back (deflate_slow's test), the others must be nearer (longest_match's limit).
-                    bool const inWin = valid && c != 0 && (j == 0 ? strstart - c <= KD_MAX_DIST : strstart - c < KD_MAX_DIST);
+                    bool const inWin = valid && c != 0 && (j == 0 ? strstart - c <= MD : strstart - c < MD);
                     u64 const ended = kx_ballot(valid && !inWin);
                     valid = inWin;
                     int len = 0;
@@ -336,13 +339,13 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
             }
             if (prev_length >= KD_MIN_MATCH && match_length <= prev_length) {
                 KDL_TALLY_MATCH(prev_dist, prev_length - KD_MIN_MATCH)
-                bool const bflush = blockSyms == KD_LIT_BUFSIZE - 1;
+                bool const bflush = blockSyms == LB - 1u;
                 strstart += prev_length - 1;
                 match_available = false; match_length = KD_MIN_MATCH - 1;
                 if (bflush) KDL_FLUSH()
             } else if (match_available) {
                 KDL_TALLY_LIT(strstart - 1)
-                if (blockSyms == KD_LIT_BUFSIZE - 1) KDL_FLUSH()
+                if (blockSyms == LB - 1u) KDL_FLUSH()
                 strstart++;
             } else { match_available = true; strstart++; }
         }

@@ -23,13 +23,11 @@
 #define KD_MIN_MATCH 3
 #define KD_MAX_MATCH 258
 #define KD_MIN_LOOKAHEAD 262
-#define KD_WSIZE 32768
-#define KD_MAX_DIST (KD_WSIZE - KD_MIN_LOOKAHEAD)       /* 32506 */
+#define KD_WSIZE 32768                                   /* the largest window (windowBits 15); a.wsize is the stream's */
+#define KD_MAX_DIST (KD_WSIZE - KD_MIN_LOOKAHEAD)       /* 32506: the largest distance; a.max_dist is the stream's */
 #define KD_TOO_FAR 4096
-#define KD_LIT_BUFSIZE 16384
+#define KD_LIT_BUFSIZE 16384                            /* memLevel 8; a.lit_buf is the stream's (128 .. 32 768) */
 #define KD_MAX_SLICE (1u << 30)
-
-KX_DEV u32 kd_hash3(u32 b0, u32 b1, u32 b2) { return ((b0 << 10) ^ (b1 << 5) ^ b2) & 0x7FFFu; }
 
 // per position: what longest_match returns with a full chain (128 steps) and with the
 // shortened chain (32 steps, used when the previous match is >= good_match); dist = position - match start (<= MAX_DIST)
@@ -37,8 +35,8 @@ struct KdBest { u16 len128, dist128, len32, dist32; };
 
 struct KdBlockInfo { u32 nsym_end; u32 end_pos; u32 start_pos; u32 stored_ok; };   // symbols [prev nsym_end, nsym_end)
 struct KdSliceMeta { u32 nblocks; u32 nsym; u32 pad[2]; };
-// blocks a slice of n bytes can have: one per 16 383 symbols (a symbol covers at least one byte), the last one may be short
-KX_DEV u32 kd_block_cap(u32 n) { return n / (KD_LIT_BUFSIZE - 1) + 2u; }
+// blocks a slice of n bytes can have: one per lit_bufsize - 1 symbols (a symbol covers at least one byte), the last one may be short
+KX_DEV u32 kd_block_cap(u32 n, u32 lit_buf = KD_LIT_BUFSIZE) { return n / (lit_buf - 1u) + 2u; }
 
 struct KdArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
@@ -55,34 +53,50 @@ struct KdArgs {
     u32 format;         // 0 = raw deflate, 1 = zlib wrapper (78 9C header, Adler-32 trailer)
     u32 good, lazy, nice, chain;     // zlib's configuration_table row of the level (deflate_slow: levels 4 .. 9; level 6 = 8, 16, 128, 128)
     u32 zflg, gxfl;                  // what the wrappers say about the level: the zlib header's FLG byte (5E / 9C / DA), gzip's XFL (2 at level 9)
+    // deflateInit2's windowBits and memLevel (zlib deflate.c deflateInit2_): w_size = 1 << windowBits and MAX_DIST = w_size - 262;
+    // hash_bits = memLevel + 7, hash_shift = (hash_bits + 2) / 3; lit_bufsize = 1 << (memLevel + 6) (a block is closed at lit_bufsize - 1 symbols)
+    u32 wsize = KD_WSIZE, max_dist = KD_MAX_DIST, hshift = 5, hmask = 0x7FFFu, lit_buf = KD_LIT_BUFSIZE, zcmf = 0x78u;
 };
+// zlib's UPDATE_HASH over three bytes: ((b0 << 2 * hash_shift) ^ (b1 << hash_shift) ^ b2) & hash_mask
+KX_DEV u32 kd_hash3(const KdArgs& a, u32 b0, u32 b1, u32 b2) { return ((b0 << (2u * a.hshift)) ^ (b1 << a.hshift) ^ b2) & a.hmask; }
 // (KdBest's fields are named after level 6: len128 / dist128 = the result of a full chain, len32 / dist32 = of a quarter of it,
 // what longest_match walks when the previous match was at least `good` long)
-static inline void kd_level_config(KdArgs& a, int level)        // (host side: fills the kernel arguments)
+static inline void kd_level_config(KdArgs& a, int level, int window_bits = 15, int mem_level = 8)        // (host side: fills the kernel arguments)
 {
     static const u32 cfg[10][4] = { {8,16,128,128}, { 4, 4, 8, 4 }, { 4, 5, 16, 8 }, { 4, 6, 32, 32 },     // (1 .. 3: deflate_fast, lazy = max_insert_length)
         { 4, 4, 16, 16 }, { 8, 16, 32, 32 }, { 8, 16, 128, 128 }, { 8, 32, 128, 256 }, { 32, 128, 258, 1024 }, { 32, 258, 258, 4096 } };
     int const l = (level < 1 || level > 9) ? 6 : level;
     a.good = cfg[l][0]; a.lazy = cfg[l][1]; a.nice = cfg[l][2]; a.chain = cfg[l][3];
-    a.zflg = l < 2 ? 0x01u : l < 6 ? 0x5Eu : l == 6 ? 0x9Cu : 0xDAu; a.gxfl = l == 9 ? 2u : l == 1 ? 4u : 0u;
+    a.gxfl = l == 9 ? 2u : l == 1 ? 4u : 0u;
+    int const wb = window_bits < 9 ? 9 : window_bits > 15 ? 15 : window_bits, ml = mem_level < 1 ? 1 : mem_level > 9 ? 9 : mem_level;   // (windowBits 8 is served as 9, as zlib does)
+    a.wsize = 1u << wb; a.max_dist = a.wsize - KD_MIN_LOOKAHEAD;
+    a.hshift = (u32)(ml + 7 + KD_MIN_MATCH - 1) / KD_MIN_MATCH; a.hmask = (1u << (ml + 7)) - 1u; a.lit_buf = 1u << (ml + 6);
+    // the zlib wrapper's two bytes (deflate.c deflate(), INIT_STATE): CMF = 8 + ((windowBits - 8) << 4), FLG = level flags << 6 plus the
+    // check bits that make the pair a multiple of 31 (78 01 / 5E / 9C / DA with a 32 KiB window)
+    u32 const lf = l < 2 ? 0u : l < 6 ? 1u : l == 6 ? 2u : 3u;
+    u32 hdr = ((8u + ((u32)(wb - 8) << 4)) << 8) | (lf << 6); hdr += 31u - hdr % 31u;
+    a.zcmf = hdr >> 8; a.zflg = hdr & 0xFFu;
 }
 
 // ---------------------------------------------------------------------------
 // k_deflate_chains: 256 threads per workgroup, head[32768] in LDS
 // ---------------------------------------------------------------------------
 // HEAD: u16 while every slice fits 64 KiB (64 KiB of LDS: two workgroups per CU), u32 for longer ones (128 KiB)
-template <class HEAD>
+template <class HEAD, int HB = 15>                             // HB: hash bits the table has room for (memLevel 9: 16)
 KX_DEV void deflate_chains_body(const KdArgs& a)
 {
-    KX_SHARED HEAD head[32768];                                  // position + 1 of the last string with that hash, 0 = none
+    KX_SHARED HEAD head[1 << HB];                                // position + 1 of the last string with that hash, 0 = none
     int const lane = kx_lane(); int const wv = kx_wave(); int const nw = kx_nwaves(); int const tid = wv * 64 + lane; int const nthreads = nw * 64;
     for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
         u32 const slice = kx_xcd_chunk(it, a.n_slices);
         const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
         u16* const link = a.link + (size_t)slice * a.pos_cap;
-        for (int i = tid; i < 32768; i += nthreads) head[i] = 0;
-        kx_block_sync();
         u32 const nIns = n >= 3 ? n - 2 : 0;                // positions 0 .. n-3 enter the chains, in order
+        // a hash wider than the table (memLevel 9's 16 bits): one pass over the slice per value of the bits above the table's
+        u32 const npass = ((a.hmask + 1u) >> HB) ? ((a.hmask + 1u) >> HB) : 1u;
+        for (u32 pass = 0; pass < npass; pass++) {
+        for (int i = tid; i < (1 << HB) && i <= (int)a.hmask; i += nthreads) head[i] = 0;
+        kx_block_sync();
         // The turns on the LDS head table are short (three LDS round trips); what a wave would wait for is the global
         // load of its source bytes.  So the bytes are fetched a GROUP of four rounds ahead: the loads of group g + 1
         // are in flight while the turns of group g are taken (the hash is computed when the bytes are used).
@@ -105,8 +119,10 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
             for (int k = 0; k < 4; k++) {
                 u32 const base = gbase + (u32)k * (u32)nthreads;
                 if (base >= nIns) break;                    // uniform over the workgroup
-                u32 const p = base + (u32)wv * 64u + (u32)lane; bool const valid = vq[k];
-                u32 const h = valid ? kd_hash3(hq[k] & 0xFFu, (hq[k] >> 8) & 0xFFu, (hq[k] >> 16) & 0xFFu) : 0x8000u + (u32)lane;   // the bytes were fetched a group ago
+                u32 const p = base + (u32)wv * 64u + (u32)lane;
+                u32 const hfull = kd_hash3(a, hq[k] & 0xFFu, (hq[k] >> 8) & 0xFFu, (hq[k] >> 16) & 0xFFu);      // the bytes were fetched a group ago
+                bool const valid = vq[k] && (hfull >> HB) == pass;
+                u32 const h = valid ? (hfull & ((1u << HB) - 1u)) : 0x10000u + (u32)lane;
                 u32 lk = 0;                                  // previous position + 1, 0 = none
                 for (int w = 0; w < nw; w++) {
                     if (wv == w) {
@@ -133,12 +149,13 @@ KX_DEV void deflate_chains_body(const KdArgs& a)
                     if (nw > 1) kx_block_sync();
                 }
                 // zlib's NIL is position 0: a string there is never a candidate; chains end beyond MAX_DIST anyway
-                if (valid) { u32 const d = (lk > 1u) ? p - (lk - 1u) : 0u; link[p] = (u16)(d <= KD_MAX_DIST ? d : 0u); }
+                if (valid) { u32 const d = (lk > 1u) ? p - (lk - 1u) : 0u; link[p] = (u16)(d <= a.max_dist ? d : 0u); }
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) { hq[k] = hn[k]; vq[k] = vn[k]; }
         }
         kx_block_sync();
+        }
     }
 }
 
@@ -211,7 +228,7 @@ KX_DEV void deflate_best_body(const KdArgs& a)
                                 int const lookahead = n - p;
                                 bool go = false;
                                 if (lookahead >= KD_MIN_MATCH) {
-                                    limit = p > KD_MAX_DIST ? p - KD_MAX_DIST : 0;
+                                    limit = p > (int)a.max_dist ? p - (int)a.max_dist : 0;
                                     int const d0 = lds.lnk[p - lo];
                                     c = p - d0;
                                     if (d0 != 0) {
@@ -292,7 +309,8 @@ KX_DEV void deflate_parse_body(const KdArgs& a)
     // zlib's 64 KiB window buffer: it holds the bytes [base, dataEnd) of the slice; fill_window tops it up when fewer than
     // MIN_LOOKAHEAD bytes lie ahead, after moving everything down by 32 KiB once strstart has reached WSIZE + MAX_DIST.
     // Only one thing depends on it here: a block whose start has left the buffer cannot be emitted as a stored block.
-    int base = 0, dataEnd = n < 2 * KD_WSIZE ? n : 2 * KD_WSIZE;
+    int const W = (int)a.wsize, MD = (int)a.max_dist; u32 const LB = a.lit_buf;
+    int base = 0, dataEnd = n < 2 * W ? n : 2 * W;
 #define KD_FLUSH(last_) { KdBlockInfo b_; \
         b_.nsym_end = nsym; b_.end_pos = (u32)strstart; b_.start_pos = (u32)block_start; b_.stored_ok = (block_start - base >= 0) ? 1u : 0u; \
         if (mm.nblocks < a.blk_cap) blocks[mm.nblocks] = b_; \
@@ -302,9 +320,9 @@ KX_DEV void deflate_parse_body(const KdArgs& a)
         if (dataEnd - strstart < KD_MIN_LOOKAHEAD) {
             // fill_window: one pass is enough (it brings at least 65 536 - strstart bytes, or all that is left)
             int const rel = strstart - base;
-            int const slide = (rel >= KD_WSIZE + KD_MAX_DIST) ? KD_WSIZE : 0;
+            int const slide = (rel >= W + MD) ? W : 0;
             base += slide;
-            int const more = 2 * KD_WSIZE - (dataEnd - base);
+            int const more = 2 * W - (dataEnd - base);
             dataEnd += (n - dataEnd < more) ? n - dataEnd : more;
             if (dataEnd == strstart) break;
         }
@@ -323,13 +341,13 @@ KX_DEV void deflate_parse_body(const KdArgs& a)
         }
         if (prev_length >= KD_MIN_MATCH && match_length <= prev_length) {
             KD_TALLY(prev_dist, prev_length - KD_MIN_MATCH)
-            bool const bflush = blockSyms == KD_LIT_BUFSIZE - 1;
+            bool const bflush = blockSyms == LB - 1u;
             strstart += prev_length - 1;
             match_available = false; match_length = KD_MIN_MATCH - 1;
             if (bflush) KD_FLUSH(0)
         } else if (match_available) {
             KD_TALLY(0, src[strstart - 1])
-            if (blockSyms == KD_LIT_BUFSIZE - 1) KD_FLUSH(0)
+            if (blockSyms == LB - 1u) KD_FLUSH(0)
             strstart++;
         } else { match_available = true; strstart++; }
         KX_OPAQUE(match_length); KX_OPAQUE(strstart);          // one flat loop: see kx_wave.h
@@ -360,14 +378,15 @@ KX_DEV void deflate_fast_body(const KdArgs& a)
     u32 const slice = kx_block() * 64u + (u32)kx_lane();
     if (slice >= a.n_slices) return;
     const u8* const src = a.src + a.in_off[slice]; int const n = (int)a.in_len[slice];
-    u32* const head = (u32*)a.best + (size_t)slice * 32768u;                    // cleared by the host before the launch
-    u32* const prev = (u32*)a.best + ((size_t)a.n_slices + slice) * 32768u;     // read only where written
+    u32* const head = (u32*)a.best + (size_t)slice * (a.hmask + 1u);            // cleared by the host before the launch
+    u32* const prev = (u32*)a.best + (size_t)a.n_slices * (a.hmask + 1u) + (size_t)slice * KD_WSIZE;     // read only where written
     u32* const syms = a.syms + (size_t)slice * a.pos_cap;
     KdBlockInfo* const blocks = a.blocks + (size_t)slice * a.blk_cap;
     KdSliceMeta mm; mm.nblocks = 0; mm.nsym = 0; mm.pad[0] = 0; mm.pad[1] = 0;
     int strstart = 0, run_n = 0;                                                // run_n: insert-only positions right before strstart
     u32 nsym = 0, blockSyms = 0; int block_start = 0;
-    int base = 0, dataEnd = n < 2 * KD_WSIZE ? n : 2 * KD_WSIZE;               // zlib's window buffer holds [base, dataEnd), see k_deflate_parse
+    int const W = (int)a.wsize, MD = (int)a.max_dist; u32 const LB = a.lit_buf;
+    int base = 0, dataEnd = n < 2 * W ? n : 2 * W;                             // zlib's window buffer holds [base, dataEnd), see k_deflate_parse
     int const maxChain = (int)a.chain, niceMax = (int)a.nice, maxInsert = (int)a.lazy;
 #define KDF_FLUSH(last_, end_) { KdBlockInfo b_; \
         b_.nsym_end = nsym; b_.end_pos = (u32)(end_); b_.start_pos = (u32)block_start; b_.stored_ok = (block_start - base >= 0) ? 1u : 0u; \
@@ -382,9 +401,9 @@ KX_DEV void deflate_fast_body(const KdArgs& a)
     for (;;) {
         if (dataEnd - strstart < KD_MIN_LOOKAHEAD) {           // (fill_window runs after the inserts of the previous round; they do not depend on it)
             int const rel = strstart - base;
-            int const slide = (rel >= KD_WSIZE + KD_MAX_DIST) ? KD_WSIZE : 0;
+            int const slide = (rel >= W + MD) ? W : 0;
             base += slide;
-            int const more = 2 * KD_WSIZE - (dataEnd - base);
+            int const more = 2 * W - (dataEnd - base);
             dataEnd += (n - dataEnd < more) ? n - dataEnd : more;
             if (dataEnd == strstart) break;
         }
@@ -403,11 +422,11 @@ KX_DEV void deflate_fast_body(const KdArgs& a)
 #pragma unroll
         for (int k = 0; k < 5; k++) {                           // slot k holds position strstart - 5 + k; the run is the last run_n slots
             u32 const b = (u32)(x >> (8 * k));
-            rh[k] = kd_hash3(b & 0xFFu, (b >> 8) & 0xFFu, (b >> 16) & 0xFFu);
+            rh[k] = kd_hash3(a, b & 0xFFu, (b >> 8) & 0xFFu, (b >> 16) & 0xFFu);
             rv[k] = 0;
             if (k >= 5 - run_n) rv[k] = head[rh[k]];
         }
-        u32 const h = kd_hash3(w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu);
+        u32 const h = kd_hash3(a, w & 0xFFu, (w >> 8) & 0xFFu, (w >> 16) & 0xFFu);
         u32 hh = 0;                                             // INSERT_STRING: position + 1 of the previous string with this hash
         if (lookahead >= KD_MIN_MATCH) hh = head[h];
 #pragma unroll
@@ -416,24 +435,24 @@ KX_DEV void deflate_fast_body(const KdArgs& a)
                 u32 v = rv[k];
 #pragma unroll
                 for (int j = 0; j < k; j++) if (j >= 5 - run_n && rh[j] == rh[k]) v = (u32)(strstart - 5 + j) + 1u;
-                prev[(strstart - 5 + k) & (KD_WSIZE - 1)] = v; head[rh[k]] = (u32)(strstart - 5 + k) + 1u;
+                prev[(strstart - 5 + k) & (W - 1)] = v; head[rh[k]] = (u32)(strstart - 5 + k) + 1u;
                 if (rh[k] == h) hh = (u32)(strstart - 5 + k) + 1u;
             }
         }
         run_n = 0;
-        if (lookahead >= KD_MIN_MATCH) { prev[strstart & (KD_WSIZE - 1)] = hh; head[h] = (u32)strstart + 1u; }
+        if (lookahead >= KD_MIN_MATCH) { prev[strstart & (W - 1)] = hh; head[h] = (u32)strstart + 1u; }
         int match_length = KD_MIN_MATCH - 1, match_start = 0;
-        if (hh != 0 && (int)(hh - 1u) > base && strstart - (int)(hh - 1u) <= KD_MAX_DIST) {
+        if (hh != 0 && (int)(hh - 1u) > base && strstart - (int)(hh - 1u) <= MD) {
             // longest_match with prev_length = 2 (deflate_fast never changes it, so good_match never shortens the chain)
             int const maxlen = lookahead < KD_MAX_MATCH ? lookahead : KD_MAX_MATCH;
             int const nice = lookahead < niceMax ? lookahead : niceMax;
-            int const limit = (strstart - KD_MAX_DIST > base) ? strstart - KD_MAX_DIST : base;
+            int const limit = (strstart - MD > base) ? strstart - MD : base;
             int best_len = 2, chain = maxChain; int cur = (int)(hh - 1u);
             u32 scanEnd = (w >> 8) & 0xFFFFu;                   // scan[best_len - 1], scan[best_len]
             for (;;) {
                 const u8* const m = src + cur;
                 u32 nx = 0;                                     // the next link, fetched beside the candidate's bytes (not behind the last step)
-                if (chain > 1) nx = prev[cur & (KD_WSIZE - 1)];
+                if (chain > 1) nx = prev[cur & (W - 1)];
                 if (kx_ld16(m + best_len - 1) == scanEnd && kx_ld16(m) == (w & 0xFFFFu)) {
                     int len = 2;                                // (byte 2 is equal when bytes 0, 1 and the hash are)
                     while (len < maxlen) {
@@ -460,11 +479,11 @@ KX_DEV void deflate_fast_body(const KdArgs& a)
             int const after = strstart + match_length;
             if (match_length <= maxInsert && dataEnd - after >= KD_MIN_MATCH) run_n = match_length - 1;
             strstart = after;
-            if (blockSyms == KD_LIT_BUFSIZE - 1) KDF_FLUSH(0, after)
+            if (blockSyms == LB - 1u) KDF_FLUSH(0, after)
         } else {
             KDF_SYM((w & 0xFFu) << 16)
             strstart++;
-            if (blockSyms == KD_LIT_BUFSIZE - 1) KDF_FLUSH(0, strstart)
+            if (blockSyms == LB - 1u) KDF_FLUSH(0, strstart)
         }
     }
     { u32 const k = nsym & 3u; u32* const q = syms + (nsym - k);                // the open group

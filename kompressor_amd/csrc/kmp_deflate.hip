@@ -16,7 +16,8 @@ __global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_
 __global__ __launch_bounds__(64) void k_deflate_parse(KdArgs a) { deflate_parse_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_fast(KdArgs a) { deflate_fast_body(a); }
 // the lazy levels for slices up to 64 KiB: positions sorted by hash, then the parse with a wave-wide longest_match (deflate_lazy.h)
-__global__ __launch_bounds__(256) void k_deflate_sort(KdArgs a) { deflate_sort_body(a); }
+__global__ __launch_bounds__(256) void k_deflate_sort(KdArgs a) { deflate_sort_body<15>(a); }
+__global__ __launch_bounds__(256) void k_deflate_sort_wide(KdArgs a) { deflate_sort_body<16>(a); }        // memLevel 9: 65 536 buckets (128 KiB of LDS)
 __global__ __launch_bounds__(64, 8) void k_deflate_lazy(KdArgs a) { deflate_lazy_body(a); }
 __global__ __launch_bounds__(64, 2) void k_inflate_predecode(KipArgs a) { inflate_predecode_body(a); }
 __global__ __launch_bounds__(64) void k_inflate_exec(KieArgs a) { inflate_exec_body(a); }
@@ -35,6 +36,25 @@ extern "C" int kmp_deflate_compress_batch_level(kmp_batch_ctx* c, const void* d_
     if (level == -1) level = 6;
     if (format < 0 || format > 2 || level < 1 || level > 9) { g_last_error = "kmp_deflate_compress_batch_level: format 0 (raw), 1 (zlib) or 2 (gzip), level 1 .. 9"; return KMP_ERR_ARG; }
     return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (u32)format, hip_stream, level);
+}
+/* ... and any of deflateInit2's windowBits 9 .. 15 (8 is served as 9, as zlib does: deflate.c deflateInit2_) and memLevel 1 .. 9 */
+extern "C" int kmp_deflate_compress_batch_params(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                                 uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, int format, int level,
+                                                 int window_bits, int mem_level, void* hip_stream)
+{
+    if (level == -1) level = 6;
+    if (format < 0 || format > 2 || level < 1 || level > 9 || window_bits < 8 || window_bits > 15 || mem_level < 1 || mem_level > 9 || (window_bits == 8 && format != 1)) {
+        g_last_error = "kmp_deflate_compress_batch_params: format 0 (raw), 1 (zlib) or 2 (gzip), level 1 .. 9, windowBits 9 .. 15 (8 with the zlib wrapper only, as in zlib), memLevel 1 .. 9";
+        return KMP_ERR_ARG;
+    }
+    return deflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_len, (u32)format, hip_stream, level, window_bits, mem_level);
+}
+/* room for a stream of any of those settings: zlib's deflateBound for non-default parameters (every byte a nine-bit literal of a fixed
+ * block, a block header per lit_bufsize - 1 symbols) + the largest wrapper */
+extern "C" size_t kmp_deflate_bound_params(size_t n, int window_bits, int mem_level)
+{
+    if (window_bits == 15 && mem_level == 8) return kmp_deflate_bound(n);
+    return n + ((n + 7) >> 3) + ((n + 63) >> 6) + 5 + 18;
 }
 extern "C" int kmp_deflate_compress_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                           uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, void* hip_stream)
@@ -107,7 +127,8 @@ extern "C" int kmp_inflate_batch(kmp_batch_ctx* c, const void* d_src, const uint
 }
 
 int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream, int level)
+                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream, int level,
+                       int window_bits, int mem_level)
 {
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_len))) { g_last_error = "kmp_deflate_compress_batch: null argument"; return KMP_ERR_ARG; }
     if (n > c->max_slices) { g_last_error = "kmp_deflate_compress_batch: n exceeds the context's max_slices"; return KMP_ERR_CAPACITY; }
@@ -140,6 +161,16 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
         c->dfl_events = 1;
         c->dfl_chunk = chunk;
     }
+    {   // a smaller memLevel closes a block after fewer symbols (lit_bufsize - 1 = 127 at memLevel 1): room for the block lists
+        u32 const need = c->dfl_pos_cap / ((1u << ((mem_level < 1 ? 1 : mem_level > 9 ? 9 : mem_level) + 6)) - 1u) + 2u;
+        if (need > c->dfl_blk_cap) {
+            HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(c->dfl_blocks); c->dfl_blocks = nullptr;
+            HIP_TRY(hipMalloc((void**)&c->dfl_blocks, (size_t)2 * c->dfl_chunk * need * sizeof(KdBlockInfo)));
+            if (c->dfl_fblocks) { (void)hipFree(c->dfl_fblocks); c->dfl_fblocks = nullptr; HIP_TRY(hipMalloc((void**)&c->dfl_fblocks, (size_t)4 * c->dfl_chunk * need * sizeof(KdBlockInfo))); }
+            c->dfl_blk_cap = need;
+        }
+    }
     u32 const dfl_cap = c->max_slice_bytes < 65536u ? 65536u : c->max_slice_bytes;       // a context for smaller slices still takes 64 KiB ones
     KMP_TRY(batch_begin(c, st, d_in_len, n, dfl_cap));
     if (c->profiling) HIP_TRY(hipEventRecord(c->ev[6], st));
@@ -166,7 +197,13 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
             }
         }
         bool const wide = c->dfl_fsyms && c->dfl_fmeta && c->dfl_fblocks;
-        u32 const span = (wide ? 4u : 2u) * c->dfl_chunk;
+        u32 span = (wide ? 4u : 2u) * c->dfl_chunk;
+        {   // the head table of a slice has 1 << (memLevel + 7) entries, its prev table 32 768: as many slices at a time as the workspace holds
+            size_t const ws = (size_t)2 * c->dfl_chunk * c->dfl_pos_cap * sizeof(KdBest) * (c->dfl_pos_cap <= 65536u ? 2u : 1u);
+            size_t const per = ((size_t)(1u << ((mem_level > 9 ? 9 : mem_level) + 7)) + KD_WSIZE) * sizeof(u32);
+            if ((size_t)span * per > ws) span = (u32)(ws / per);
+            if (span < 1) { g_last_error = "kmp_deflate_compress_batch: workspace too small for this memLevel"; return KMP_ERR_CAPACITY; }
+        }
         for (u32 first = 0; first < n; first += span) {
             u32 const m = (n - first < span) ? n - first : span;
             KdArgs a;
@@ -175,10 +212,10 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
             a.link = c->dfl_link; a.best = c->dfl_best;
             a.syms = wide ? c->dfl_fsyms : c->dfl_syms; a.meta = wide ? c->dfl_fmeta : c->dfl_meta; a.blocks = wide ? c->dfl_fblocks : c->dfl_blocks;
             a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
-            kd_level_config(a, level);
+            kd_level_config(a, level, window_bits, mem_level);
             bool const prof = c->profiling && first == 0;
             if (prof) { HIP_TRY(hipEventRecord(c->ev[8], st)); HIP_TRY(hipEventRecord(c->ev[9], st)); HIP_TRY(hipEventRecord(c->ev[10], st)); HIP_TRY(hipEventRecord(c->ev[13], st)); }
-            HIP_TRY(hipMemsetAsync(c->dfl_best, 0, (size_t)m * 32768u * sizeof(u32), st));          // the head tables
+            HIP_TRY(hipMemsetAsync(c->dfl_best, 0, (size_t)m * (a.hmask + 1u) * sizeof(u32), st));          // the head tables
             hipLaunchKernelGGL(k_deflate_fast, dim3((m + 63) / 64), dim3(64), 0, st, a);
             if (prof) HIP_TRY(hipEventRecord(c->ev[11], st));
             hipLaunchKernelGGL(k_deflate_encode, dim3(m), dim3(64), 0, st, a);
@@ -199,7 +236,7 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
         a.syms = c->dfl_syms + half * c->dfl_pos_cap; a.meta = c->dfl_meta + half; a.blocks = c->dfl_blocks + half * c->dfl_blk_cap;
         a.wr = c->dfl_wr ? c->dfl_wr + half * c->dfl_pos_cap : nullptr;
         a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
-        kd_level_config(a, level);
+        kd_level_config(a, level, window_bits, mem_level);
         bool const prof = c->profiling && first == 0;      // per-kernel events for the first piece
         hipStream_t const s2 = serial ? st : c->st2;
         if (!serial && piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[h], 0));      // this half's previous piece has been encoded
@@ -211,7 +248,8 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
             u32* const ord = c->dfl_order + (size_t)h * (2 * c->dfl_chunk + 256);
             a.order_key = ord; a.order_hist = ord + c->dfl_chunk; a.order = ord + c->dfl_chunk + 256;
             HIP_TRY(hipMemsetAsync(a.order_hist, 0, 256 * sizeof(u32), st));
-            hipLaunchKernelGGL(k_deflate_sort, dim3(m), dim3(256), 0, st, a);
+            if (a.hmask > 0x7FFFu) hipLaunchKernelGGL(k_deflate_sort_wide, dim3(m), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(k_deflate_sort, dim3(m), dim3(256), 0, st, a);
             KMP_TRY(size_sort_keys(c, st, m, a.order_key, a.order_hist, (u32*)a.order));
         }
         else if (c->dfl_pos_cap <= 65536u) hipLaunchKernelGGL(k_deflate_chains, dim3(m), dim3(64u * chain_waves), 0, st, a);

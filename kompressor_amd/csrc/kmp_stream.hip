@@ -244,10 +244,13 @@ struct kmp_zlib_cstream { int level, window_bits, mem_level, strategy; std::vect
 
 extern "C" kmp_zlib_cstream* kmp_zlib_create_compressor(int level, int window_bits, int mem_level, int strategy)
 {
-    // what deflateInit2 would accept; the GPU path implements levels 1 .. 9 (-1 = default = 6), memLevel 8, strategy 0
+    // what deflateInit2 accepts (zlib deflate.c deflateInit2_): levels 1 .. 9 (-1 = default = 6; 0, stored blocks only, is not served),
+    // windowBits -15 .. -9 raw, 9 .. 15 zlib wrapper (8 is taken as 9), 25 .. 31 (+ 16) gzip wrapper -- 8 without the zlib wrapper is an
+    // error there too --, memLevel 1 .. 9, strategy 0 (the only one the reference passes: ZlibCompressor.jvm.kt:24)
     if (level == -1) level = 6;
-    // windowBits: -15 raw, 15 zlib wrapper, 31 (15 + 16) gzip wrapper
-    if (level < 1 || level > 9 || (window_bits != -15 && window_bits != 15 && window_bits != 31) || mem_level != 8 || strategy != 0) return nullptr;
+    int const wrap = window_bits < 0 ? 0 : window_bits > 15 ? 2 : 1;
+    int const wb = window_bits < 0 ? -window_bits : window_bits > 15 ? window_bits - 16 : window_bits;
+    if (level < 1 || level > 9 || wb < 8 || wb > 15 || (wb == 8 && wrap != 1) || mem_level < 1 || mem_level > 9 || strategy != 0) return nullptr;
     kmp_zlib_cstream* z = new (std::nothrow) kmp_zlib_cstream();
     if (!z) return nullptr;
     z->level = level; z->window_bits = window_bits; z->mem_level = mem_level; z->strategy = strategy; z->out_pos = 0; z->stage = 0;
@@ -266,13 +269,17 @@ extern "C" int kmp_zlib_compress_stream(kmp_zlib_cstream* z, void* dst, size_t d
         if (avail) { const u8* p = (const u8*)src + *src_pos; z->in.insert(z->in.end(), p, p + avail); *src_pos = src_size; }
         if (z->in.size() > KD_MAX_SLICE) return Z_MEM_ERROR_;          // streams above 1 GiB are not served
         if (!finish) return avail ? Z_OK_ : Z_BUF_ERROR_;
-        if (!stream_dev_select(z->dev) || stream_dev_init(z->dev, z->in.size())) return Z_MEM_ERROR_;
+        int const wrap = z->window_bits < 0 ? 0 : z->window_bits > 15 ? 2 : 1;
+        int const wb = z->window_bits < 0 ? -z->window_bits : z->window_bits > 15 ? z->window_bits - 16 : z->window_bits;
+        // (settings other than the default ones can expand the data by an eighth: deflateBound's other branch)
+        size_t const room = (wb == 15 && z->mem_level == 8) ? z->in.size() : kmp_deflate_bound_params(z->in.size(), wb, z->mem_level);
+        if (!stream_dev_select(z->dev) || stream_dev_init(z->dev, room)) return Z_MEM_ERROR_;
         stream_dev& s = z->dev;
         u64 offs[2] = { 0, 0 }; u32 len = (u32)z->in.size(), olen = 0;
         if (len && hipMemcpy(s.d_in, z->in.data(), len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
         if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
         if (hipMemcpy(s.d_len, &len, 4, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
-        if (deflate_batch_impl(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, z->window_bits == 31 ? 2u : (z->window_bits > 0 ? 1u : 0u), nullptr, z->level) != KMP_OK) return Z_MEM_ERROR_;
+        if (deflate_batch_impl(s.batch, s.d_in, s.d_off, s.d_len, 1, s.d_out, s.d_off + 1, s.d_len + 1, (u32)wrap, nullptr, z->level, wb, z->mem_level) != KMP_OK) return Z_MEM_ERROR_;
         if (hipMemcpy(&olen, s.d_len + 1, 4, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR_;
         if (olen == 0 || olen > s.out_cap) return Z_DATA_ERROR_;
         z->out.resize(olen);

@@ -32,19 +32,23 @@
 #define DREF_API __attribute__((visibility("default")))
 typedef uint8_t u8; typedef uint16_t u16; typedef uint32_t u32; typedef uint64_t u64;
 
-#define W_BITS 15
-#define W_SIZE (1u << W_BITS)
-#define W_MASK (W_SIZE - 1)
-#define HASH_BITS 15
-#define HASH_SIZE (1u << HASH_BITS)
-#define HASH_MASK (HASH_SIZE - 1)
-#define HASH_SHIFT 5
+/* deflateInit2's windowBits (9 .. 15) and memLevel (1 .. 9) are fields of the state: w_size = 1 << windowBits, hash_bits = memLevel + 7,
+ * hash_shift = (hash_bits + MIN_MATCH - 1) / MIN_MATCH, lit_bufsize = 1 << (memLevel + 6)  (zlib deflate.c deflateInit2_).  The arrays
+ * have the sizes of the largest setting. */
+#define W_BITS_MAX 15
+#define HASH_BITS_MAX 16
+#define LIT_BUFSIZE_MAX 32768
+#define W_SIZE (s->w_size)
+#define W_MASK (s->w_size - 1)
+#define HASH_SIZE (s->hash_size)
+#define HASH_MASK (s->hash_size - 1)
+#define HASH_SHIFT (s->hash_shift)
 #define MIN_MATCH 3
 #define MAX_MATCH 258
 #define MIN_LOOKAHEAD (MAX_MATCH + MIN_MATCH + 1)
 #define MAX_DIST (W_SIZE - MIN_LOOKAHEAD)
 #define TOO_FAR 4096
-#define LIT_BUFSIZE 16384
+#define LIT_BUFSIZE (s->lit_bufsize)
 #define NIL 0
 
 #define L_CODES 286
@@ -75,11 +79,12 @@ typedef struct { ct* tree; int max_code; sdesc sd; } tdesc;
 typedef struct {
     /* input / window */
     const u8* in; size_t in_len, in_pos;
-    u8 window[2 * W_SIZE]; u16 prev[W_SIZE]; u16 head[HASH_SIZE];
+    u32 w_size, hash_size, hash_shift, lit_bufsize;
+    u8 window[2 << W_BITS_MAX]; u16 prev[1 << W_BITS_MAX]; u16 head[1 << HASH_BITS_MAX];
     u32 strstart, lookahead, match_start, match_length, prev_length, prev_match, ins_h, insert; long block_start; int match_available;
     u32 good_match, max_lazy, nice_match, max_chain;      /* zlib's configuration_table row of the level (deflate_slow levels 4 .. 9) */
     /* symbols */
-    u16 d_buf[LIT_BUFSIZE]; u8 l_buf[LIT_BUFSIZE]; u32 last_lit;
+    u16 d_buf[LIT_BUFSIZE_MAX]; u8 l_buf[LIT_BUFSIZE_MAX]; u32 last_lit;
     ct dyn_ltree[HEAP_SIZE], dyn_dtree[2 * D_CODES + 1], bl_tree[2 * BL_CODES + 1];
     tdesc l_desc, d_desc, bl_desc;
     u16 bl_count[MAX_BITS + 1]; int heap[2 * L_CODES + 1]; int heap_len, heap_max; u8 depth[2 * L_CODES + 1];
@@ -465,15 +470,23 @@ DREF_API size_t dref_deflate_bound(size_t n) { return n + (n >> 12) + (n >> 14) 
 /* raw deflate at level 1 .. 9 (1 .. 3 deflate_fast, 4 .. 9 deflate_slow; zlib's configuration_table: good_length, max_lazy, nice_length, max_chain),
  * windowBits 15, memLevel 8, strategy 0, one shot. returns size or (size_t)-1 */
 DREF_API size_t dref_deflate_raw_level(u8* dst, size_t cap, const u8* src, size_t n, int level);
+DREF_API size_t dref_deflate_raw_params(u8* dst, size_t cap, const u8* src, size_t n, int level, int window_bits, int mem_level);
 DREF_API size_t dref_deflate_l6_raw(u8* dst, size_t cap, const u8* src, size_t n) { return dref_deflate_raw_level(dst, cap, src, n, 6); }
-DREF_API size_t dref_deflate_raw_level(u8* dst, size_t cap, const u8* src, size_t n, int level)
+DREF_API size_t dref_deflate_raw_level(u8* dst, size_t cap, const u8* src, size_t n, int level) { return dref_deflate_raw_params(dst, cap, src, n, level, 15, 8); }
+/* zlib's bound for settings other than the default ones (deflateBound's conservative branch: fixed blocks at nine bits a literal) */
+DREF_API size_t dref_deflate_bound_params(size_t n) { return n + ((n + 7) >> 3) + ((n + 63) >> 6) + 5 + 64; }
+/* ... with deflateInit2's windowBits 9 .. 15 (8 is served as 9, as zlib does) and memLevel 1 .. 9 */
+DREF_API size_t dref_deflate_raw_params(u8* dst, size_t cap, const u8* src, size_t n, int level, int window_bits, int mem_level)
 {
     static const u32 cfg[10][4] = { {0,0,0,0}, { 4, 4, 8, 4 }, { 4, 5, 16, 8 }, { 4, 6, 32, 32 },
         { 4, 4, 16, 16 }, { 8, 16, 32, 32 }, { 8, 16, 128, 128 }, { 8, 32, 128, 256 }, { 32, 128, 258, 1024 }, { 32, 258, 258, 4096 } };
     dstate* s; size_t r;
-    if (level < 1 || level > 9) return (size_t)-1;
+    if (level < 1 || level > 9 || window_bits < 8 || window_bits > 15 || mem_level < 1 || mem_level > 9) return (size_t)-1;
+    if (window_bits == 8) window_bits = 9;
     s = (dstate*)calloc(1, sizeof(dstate));
     if (!s) return (size_t)-1;
+    s->w_size = 1u << window_bits; s->hash_size = 1u << (mem_level + 7); s->hash_shift = (u32)(mem_level + 7 + MIN_MATCH - 1) / MIN_MATCH;
+    s->lit_bufsize = 1u << (mem_level + 6);
     s->good_match = cfg[level][0]; s->max_lazy = cfg[level][1]; s->nice_match = cfg[level][2]; s->max_chain = cfg[level][3];
     tr_static_init();
     s->in = src; s->in_len = n; s->out = dst; s->out_cap = cap;

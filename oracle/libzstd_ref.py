@@ -135,3 +135,21 @@ class LibZstd:
         if lib.ZSTD_isError(n):
             raise RuntimeError(lib.ZSTD_getErrorName(n).decode())
         return out.raw[:n]
+
+    def decompress_with_dict(self, frame: bytes, out_size: int, dictionary: bytes) -> bytes:
+        """ZSTD_decompress_usingDict on a fresh context: what ZstdDecompressor(dictionary) comes to for whole frames."""
+        lib = self.lib
+        lib.ZSTD_createDCtx.restype = ctypes.c_void_p
+        lib.ZSTD_freeDCtx.argtypes = [ctypes.c_void_p]
+        lib.ZSTD_decompress_usingDict.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                                  ctypes.c_void_p, ctypes.c_size_t]
+        lib.ZSTD_decompress_usingDict.restype = ctypes.c_size_t
+        dctx = lib.ZSTD_createDCtx()
+        try:
+            out = ctypes.create_string_buffer(max(out_size, 1))
+            n = lib.ZSTD_decompress_usingDict(dctx, out, out_size, frame, len(frame), dictionary, len(dictionary))
+            if lib.ZSTD_isError(n):
+                raise RuntimeError(lib.ZSTD_getErrorName(n).decode())
+            return out.raw[:n]
+        finally:
+            lib.ZSTD_freeDCtx(dctx)

@@ -473,12 +473,20 @@ int emu_deflate(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* 
                 u16* link_out, KdBest* best_out, u32 format)
 { return emu_deflate_level(src, in_off, in_len, n, dst, out_off, out_len, link_out, best_out, format, 6); }
 extern "C" __attribute__((visibility("default")))
+int emu_deflate_params(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* dst, const u64* out_off, u32* out_len,
+                       u16* link_out, KdBest* best_out, u32 format, int level, int window_bits, int mem_level, int old_kernels);
+extern "C" __attribute__((visibility("default")))
 int emu_deflate_level(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* dst, const u64* out_off, u32* out_len,
                       u16* link_out, KdBest* best_out, u32 format, int level)
+{ return emu_deflate_params(src, in_off, in_len, n, dst, out_off, out_len, link_out, best_out, format, level, 15, 8, 0); }
+// ... with deflateInit2's windowBits / memLevel; old_kernels: the chain / all-positions search / lane-per-slice parse also for slices up to 64 KiB
+extern "C" __attribute__((visibility("default")))
+int emu_deflate_params(const u8* src, const u64* in_off, const u32* in_len, u32 n, u8* dst, const u64* out_off, u32* out_len,
+                       u16* link_out, KdBest* best_out, u32 format, int level, int window_bits, int mem_level, int old_kernels)
 {
     u32 maxlen = 65536u;
     for (u32 i = 0; i < n; i++) if (in_len[i] > maxlen) maxlen = in_len[i];
-    u32 const pos_cap = (maxlen + 63u) & ~63u, blk_cap = pos_cap / (KD_LIT_BUFSIZE - 1) + 2u;
+    u32 const pos_cap = (maxlen + 63u) & ~63u, blk_cap = kd_block_cap(pos_cap, 1u << (mem_level + 6));
     std::vector<u16> link((size_t)n * pos_cap, 0xEEEE);
     std::vector<KdBest> best((size_t)n * pos_cap * 2);
     std::vector<u32> syms((size_t)n * pos_cap, 0xDDDDDDDDu);
@@ -491,10 +499,10 @@ int emu_deflate_level(const u8* src, const u64* in_off, const u32* in_len, u32 n
     a.pos_cap = pos_cap; a.blk_cap = blk_cap; a.blocks = blocks.data();
     a.link = link.data(); a.best = best.data(); a.syms = syms.data(); a.meta = meta.data();
     a.dst = dst; a.out_off = out_off; a.out_len = out_len; a.flags = 0; a.format = format;
-    kd_level_config(a, level);
+    kd_level_config(a, level, window_bits, mem_level);
     kxemu::failed = 0;
     if (level >= 1 && level <= 3) {
-        memset((void*)best.data(), 0, (size_t)n * 32768u * 4u);
+        memset((void*)best.data(), 0, (size_t)n * (a.hmask + 1u) * 4u);
         kxemu::launch((n + 63) / 64, [&]() { deflate_fast_body(a); });
         if (kxemu::failed) return -3;
         kxemu::launch(n < 3 ? n : 3, [&]() { deflate_encode_body(a); });
@@ -502,8 +510,9 @@ int emu_deflate_level(const u8* src, const u64* in_off, const u32* in_len, u32 n
     }
     // slices up to 64 KiB: the sort + wave-wide lazy parse of deflate_lazy.h (what the product runs there), unless the caller wants the
     // chain links / per-position records of the older kernels back (link_out / best_out) -- the tests keep both pipelines honest
-    if (pos_cap <= 65536u && !link_out && !best_out) {
-        kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_sort_body(a); });
+    if (pos_cap <= 65536u && !link_out && !best_out && !old_kernels) {
+        if (a.hmask > 0x7FFFu) kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_sort_body<16>(a); });
+        else kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_sort_body<15>(a); });
         if (kxemu::failed) return -1;
         kxemu::launch(n < 3 ? n : 3, [&]() { deflate_lazy_body(a); });
         if (kxemu::failed) return -3;

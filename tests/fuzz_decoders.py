@@ -114,15 +114,33 @@ def run_zstd(args):
     rng = random.Random(args.seed)
     srcs = sources(rng, 24)
     frames = []
-    for k, d in enumerate(srcs):
-        for lvl in ((1, 3, 6, 19) if len(d) < 100000 else (3,)):
-            frames.append((z.compress(d, lvl), d))
+    dicts = []
+    if args.dict:
+        # frames made with dictionaries in zstd's own format (trained ones from the fixture, built ones with incomplete tables): the
+        # decoder starts from the dictionary's Huffman weights, FSE tables and repeat offsets, and matches reach into its content
+        cases = helpers.formatted_dict_cases()
+        for ci in rng.sample(range(len(cases)), min(6, len(cases))):
+            name, dd, inputs, _ = cases[ci]
+            dicts.append(dd)
+            for d in rng.sample(inputs, 8) + [b""]:
+                for lvl in (1, 3, 7, 19):
+                    frames.append((z.compress_with_dict(d, dd, lvl), d, len(dicts) - 1))
+        # ... and frames that name no dictionary, or another one, decoded with a dictionary loaded
+        for d in srcs[:6]:
+            frames.append((z.compress(d, 3), d, 0))
+    else:
+        for k, d in enumerate(srcs):
+            for lvl in ((1, 3, 6, 19) if len(d) < 100000 else (3,)):
+                frames.append((z.compress(d, lvl), d, -1))
     emu = helpers.emu()
-    emu.emu_zstd_decompress.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint32, ctypes.c_uint32] + [ctypes.c_void_p] * 5 + [ctypes.c_uint32]
+    emu.emu_zstd_decompress_dict.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_uint32, ctypes.c_uint32] + [ctypes.c_void_p] * 5 + [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32]
     stats = {"cases": 0, "accepted": 0, "rejected": 0, "both_valid_same": 0}
-    only = [f for f, _ in frames]
+    only = [f for f, _, _ in frames]
     for it in range(args.iters):
-        f0, d = rng.choice(frames)
+        f0, d, di = rng.choice(frames)
+        if args.dict and rng.random() < 0.05:
+            di = rng.randrange(len(dicts))                  # the wrong dictionary: "Dictionary mismatch", or other content with ID 0
+        dd = dicts[di] if di >= 0 else None
         f, what = (f0, "intact") if it % 50 == 0 else mutate(rng, f0, only)
         cap = len(d) + rng.choice((0, 0, 0, 1, 64, 5000)) if rng.random() < 0.85 else rng.randrange(0, len(d) + 1)
         if args.verbose:
@@ -132,13 +150,13 @@ def run_zstd(args):
         in_off = np.array([gin.off], dtype=np.uint64); in_len = np.array([len(f)], dtype=np.uint32)
         out_off = np.array([gout.off], dtype=np.uint64); out_cap = np.array([cap], dtype=np.uint32)
         olen = np.zeros(1, dtype=np.uint32); st = np.zeros(1, dtype=np.uint32)
-        r = emu.emu_zstd_decompress(gin.base, helpers._vp(in_off), helpers._vp(in_len), 1, 1, gout.base, helpers._vp(out_off),
-                                    helpers._vp(out_cap), helpers._vp(olen), helpers._vp(st), 128 * 1024 + 64)
+        r = emu.emu_zstd_decompress_dict(gin.base, helpers._vp(in_off), helpers._vp(in_len), 1, 1, gout.base, helpers._vp(out_off),
+                                         helpers._vp(out_cap), helpers._vp(olen), helpers._vp(st), 128 * 1024 + 64, dd, len(dd) if dd else 0)
         assert r == 0, f"emulator reported {r} (case {it}, {what})"
         mine = gout.read(int(olen[0])) if st[0] == 0 else None
         gin.close(); gout.close()
         try:
-            ref = z.decompress(f, cap)
+            ref = z.decompress_with_dict(f, cap, dd) if dd is not None else z.decompress(f, cap)
             err = None
         except RuntimeError as e:
             ref, err = None, str(e)
@@ -251,6 +269,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--which", choices=("zstd", "inflate"), default="zstd")
     ap.add_argument("--pre", action="store_true", help="inflate: through the pre-decoder + executor kernels instead of k_inflate alone")
+    ap.add_argument("--dict", action="store_true", help="zstd: frames made with dictionaries in zstd's own format, decoded with the dictionary")
     ap.add_argument("--iters", type=int, default=500)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--verbose", action="store_true")

@@ -434,12 +434,14 @@ class DeflateOracle:
         d.dref_deflate_l6_raw.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
         d.dref_deflate_raw_level.restype = ctypes.c_size_t
         d.dref_deflate_raw_level.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+        d.dref_deflate_raw_params.restype = ctypes.c_size_t
+        d.dref_deflate_raw_params.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int]
 
-    def compress(self, d: bytes, level: int = 6) -> bytes:
-        """raw DEFLATE at a deflate_slow level (4 .. 9), windowBits 15, memLevel 8"""
-        cap = len(d) + len(d) // 100 + 256
+    def compress(self, d: bytes, level: int = 6, window_bits: int = 15, mem_level: int = 8) -> bytes:
+        """raw DEFLATE at level 1 .. 9 with deflateInit2's windowBits 9 .. 15 and memLevel 1 .. 9"""
+        cap = len(d) + len(d) // 7 + 256
         o = ctypes.create_string_buffer(cap)
-        n = self.lib.dref_deflate_raw_level(o, cap, d, len(d), level)
+        n = self.lib.dref_deflate_raw_params(o, cap, d, len(d), level, window_bits, mem_level)
         if n == 2 ** 64 - 1:
             raise RuntimeError("deflate oracle: output did not fit")
         return o.raw[:n]
@@ -647,7 +649,7 @@ def emu_compress_big(datas, G=16, nblocks=2, by_rounds=False, stream=0, level=3,
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)], rounds.value
 
 
-def emu_deflate(datas, zlib_wrapper=False, fmt=None, level=6):
+def emu_deflate(datas, zlib_wrapper=False, fmt=None, level=6, window_bits=15, mem_level=8, old_kernels=False):
     """chains -> best -> parse -> encode kernel bodies on the CPU wave emulator."""
     n = len(datas)
     lens = np.array([len(d) for d in datas], dtype=np.uint32)
@@ -661,10 +663,13 @@ def emu_deflate(datas, zlib_wrapper=False, fmt=None, level=6):
         buf[int(offs[i]):int(offs[i]) + len(d)] = np.frombuffer(d, dtype=np.uint8)
     big = max([len(d) for d in datas] + [65536])
     stride = (big + (big >> 12) + (big >> 14) + 64 + 63) & ~63
+    if (window_bits, mem_level) != (15, 8):
+        stride = (big + (big >> 3) + (big >> 6) + 64 + 63) & ~63
     out = np.zeros(n * stride, dtype=np.uint8)
     ooff = np.arange(n, dtype=np.uint64) * stride
     olen = np.zeros(n, dtype=np.uint32)
-    r = emu().emu_deflate_level(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(olen), None, None, fmt if fmt is not None else (1 if zlib_wrapper else 0), level)
+    r = emu().emu_deflate_params(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(olen), None, None, fmt if fmt is not None else (1 if zlib_wrapper else 0), level,
+                                 window_bits, mem_level, 1 if old_kernels else 0)
     assert r == 0, f"emulator reported {r}"
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
 
@@ -871,3 +876,35 @@ def lazy_level_inputs():
 def lazy_levels_golden():
     import json
     return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zstd_lazy_levels_golden.json")))
+
+
+def deflate_params_cases():
+    """Seeded cases for deflateInit2's windowBits / memLevel (ZlibCompressor(format, compressionLevel, windowBits, memLevel)):
+    [(level, window_bits, mem_level, fmt, seed, size, class)] -- every (windowBits, memLevel) pair at a deflate_fast and a deflate_slow
+    level on 64 KiB slices, random settings over a ladder of sizes (empty, below MIN_MATCH, around MIN_LOOKAHEAD, around the smallest
+    windows, the 64 KiB edge), and slices above 64 KiB (windows that slide hundreds of times, memLevel 9's 16-bit hash there)."""
+    import random
+    rng = random.Random(81531)
+    out = []
+    for wb in range(9, 16):
+        for ml in range(1, 10):
+            out.append((rng.choice((1, 2, 3)), wb, ml, 0, rng.randrange(1 << 20), 65536, rng.choice("TXSB")))
+            out.append((rng.choice((4, 5, 6, 7, 8, 9)), wb, ml, 0, rng.randrange(1 << 20), rng.choice((65536, 40000, 9000)), rng.choice("TXSBDIZR")))
+    ladder = (0, 1, 2, 3, 4, 100, 250, 251, 262, 263, 511, 512, 513, 762, 763, 1024, 4096, 16383, 16385, 32768, 65535, 65536)
+    for _ in range(320):
+        out.append((rng.randrange(1, 10), rng.randrange(9, 16), rng.randrange(1, 10), rng.randrange(3), rng.randrange(1 << 20), rng.choice(ladder), rng.choice("TXSBDIZR")))
+    for size in (65537, 70000, 150000, 300000, 1 << 20):
+        for _ in range(6):
+            out.append((rng.randrange(1, 10), rng.choice((9, 10, 12, 14, 15)), rng.choice((1, 5, 8, 9, 9)), rng.randrange(3), rng.randrange(1 << 20), size, rng.choice("TXSBZ")))
+    return out
+
+
+def deflate_params_input(case):
+    from kompressor_amd import corpus
+    level, wb, ml, fmt, seed, size, cls = case
+    return corpus.make(seed, 1, size, mix=ord(cls)).tobytes() if size else b""
+
+
+def deflate_params_golden():
+    with open(os.path.join(ROOT, "tests", "golden", "deflate_params_golden.json")) as fh:
+        return json.load(fh)

@@ -227,3 +227,52 @@ def test_long_slices_oracle_and_emulated_kernels_match_zlib():
     assert helpers.emu_deflate([d], fmt=1)[0] == zlib.compress(d, 6)
     c = zlib.compressobj(6, zlib.DEFLATED, 31, 8, 0)
     assert helpers.emu_deflate([d], fmt=2)[0] == c.compress(d) + c.flush()
+
+
+def _wrap(raw, d, fmt, level, wb):
+    """the zlib / gzip wrapper zlib puts around a raw stream (deflate.c deflate(): INIT_STATE header, trailer)"""
+    import struct
+    if fmt == 0:
+        return raw
+    if fmt == 1:
+        lf = 0 if level < 2 else 1 if level < 6 else 2 if level == 6 else 3
+        hdr = ((8 + ((wb - 8) << 4)) << 8) | (lf << 6)
+        hdr += 31 - hdr % 31
+        return struct.pack(">H", hdr) + raw + struct.pack(">I", zlib.adler32(d))
+    xfl = 2 if level == 9 else 4 if level == 1 else 0
+    return bytes([0x1F, 0x8B, 8, 0, 0, 0, 0, 0, xfl, 3]) + raw + struct.pack("<II", zlib.crc32(d), len(d) & 0xFFFFFFFF)
+
+
+def test_window_bits_and_mem_level_oracle_and_emulator_match_golden():
+    """deflateInit2's windowBits 9 .. 15 and memLevel 1 .. 9 (the reference's ZlibCompressor(format, compressionLevel, windowBits,
+    memLevel), ZlibCompressor.jvm.kt:7-17): the oracle on all 476 committed cases (tests/golden/deflate_params_golden.json, zlib
+    1.2.11), the emulated kernels -- both the sort + wave-wide parse and the older chain / search / parse kernels, memLevel 9's
+    two-pass chains among them -- on the smaller ones and a few above 64 KiB."""
+    G = helpers.deflate_params_golden()
+    cases = helpers.deflate_params_cases()
+    assert len(cases) == len(G["rows"])
+    o = helpers.deflate_oracle()
+    emu_rows = []
+    for k, (case, (glen, gsha)) in enumerate(zip(cases, G["rows"])):
+        level, wb, ml, fmt, seed, size, cls = case
+        d = helpers.deflate_params_input(case)
+        f = _wrap(o.compress(d, level, wb, ml), d, fmt, level, wb)
+        assert len(f) == glen and helpers.sha256(f) == gsha, case
+        if size <= 4096 or k % 29 == 0:
+            emu_rows.append((k, case, d, f))
+    assert len(emu_rows) >= 120 and any(c[5] > 65536 for _, c, _, _ in emu_rows)
+    for j, (k, case, d, f) in enumerate(emu_rows):
+        level, wb, ml, fmt, seed, size, cls = case
+        got = helpers.emu_deflate([d], fmt=fmt, level=level, window_bits=wb, mem_level=ml, old_kernels=(j % 3 == 0))[0]
+        assert got == f, case
+    # memLevel 9 above 64 KiB at a lazy level: the hash is wider than the chain kernel's table (two passes)
+    d = corpus.make(4242, 1, 90000, mix=ord("T")).tobytes()
+    c = zlib.compressobj(6, zlib.DEFLATED, -15, 9, 0)
+    assert helpers.emu_deflate([d], level=6, window_bits=15, mem_level=9)[0] == c.compress(d) + c.flush()
+    # (the live zlib of this machine over random settings, so that the fixture is not the only witness)
+    rng = np.random.default_rng(5)
+    for t in range(60):
+        level, wb, ml = int(rng.integers(1, 10)), int(rng.integers(9, 16)), int(rng.integers(1, 10))
+        d = corpus.make(7000 + t, 1, int(rng.integers(0, 200000)), mix=ord("TXSBDIZR"[t % 8])).tobytes()
+        c = zlib.compressobj(level, zlib.DEFLATED, -wb, ml, 0)
+        assert o.compress(d, level, wb, ml) == c.compress(d) + c.flush(), (level, wb, ml, len(d))
