@@ -493,6 +493,8 @@ def main():
                     help="with --dict-kib: a dictionary in zstd's own format, trained by the box's libzstd 1.5.7 (ZDICT_trainFromBuffer) on other slices of the same corpus, instead of raw content")
     ap.add_argument("--slice-kib", type=int, default=64,
                     help="slice size in KiB (64 = BASELINE configs[1]; above 128 the frames have several blocks, up to 2048)")
+    ap.add_argument("--deflate-window-bits", type=int, default=15, help="--mode deflate: deflateInit2's windowBits (9 .. 15; BASELINE configs[4] = 15)")
+    ap.add_argument("--deflate-mem-level", type=int, default=8, help="--mode deflate: deflateInit2's memLevel (1 .. 9; BASELINE configs[4] = 8)")
     ap.add_argument("--deflate-level", type=int, default=None, help="zlib level of --mode deflate / inflate (1 .. 9, default 6 = BASELINE configs[4])")
     ap.add_argument("--mode", choices=["compress", "decompress", "deflate", "inflate"], default="compress",
                     help="compress = BASELINE configs[1] (the headline); decompress = configs[2] over the same frames; deflate = configs[4] (raw DEFLATE level 6); inflate = ZlibDecompressor over configs[4]'s streams")
@@ -600,9 +602,16 @@ def main():
         dlevel = args.deflate_level if args.deflate_level is not None else (args.level if (1 <= args.level <= 9 and args.level != 3) else 6)   # (--level is zstd's, default 3: it only counts here when it is not 3)
         if not 1 <= dlevel <= 9:
             raise SystemExit("--deflate-level 1 .. 9")
+        dwb, dml = args.deflate_window_bits, args.deflate_mem_level
+        dparams = dict(window_bits=dwb, mem_level=dml)
+        if (dwb, dml) != (15, 8):
+            # other settings than zlib's defaults may expand a slice by an eighth (kmp_deflate_bound_params): wider strides
+            dstride = (int(b.lib.kmp_deflate_bound_params(SLICE, dwb, dml)) + 63) & ~63
+            dst = torch.empty(n * dstride + 64, dtype=torch.uint8, device=dev)
+            out_off = torch.arange(n, dtype=torch.int64, device=dev) * dstride
         if args.mode == "inflate":
             # ZlibDecompressor(ZlibFormat.Raw) over the streams of configs[4] (made here, once): k_inflate_predecode + k_inflate_exec
-            b.deflate(src, in_off, in_len, dst, out_off, out_len, level=dlevel)
+            b.deflate(src, in_off, in_len, dst, out_off, out_len, level=dlevel, **dparams)
             torch.cuda.synchronize()
             lens = out_len.cpu().numpy().astype(np.int64)
             cap = torch.full((n,), SLICE, dtype=torch.int32, device=dev)
@@ -637,11 +646,11 @@ def main():
             b.close()
             return
         for _ in range(args.warmup):
-            b.deflate(src, in_off, in_len, dst, out_off, out_len, level=dlevel)
+            b.deflate(src, in_off, in_len, dst, out_off, out_len, level=dlevel, **dparams)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            b.deflate(src, in_off, in_len, dst, out_off, out_len, level=dlevel)
+            b.deflate(src, in_off, in_len, dst, out_off, out_len, level=dlevel, **dparams)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         kms = b.deflate_kernel_ms()
@@ -670,7 +679,7 @@ def main():
 
         def _zrun(t):
             for i in range(t * per_t, min(sample, (t + 1) * per_t)):
-                c = _z.compressobj(dlevel, _z.DEFLATED, -15, 8, 0)
+                c = _z.compressobj(dlevel, _z.DEFLATED, -dwb, dml, 0)
                 c.compress(host[i * SLICE:(i + 1) * SLICE].tobytes()); c.flush()
 
         t1 = time.perf_counter()
@@ -709,8 +718,8 @@ def main():
             "value": round(n * SLICE / (dt / args.steps) / 1e9, 3), "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[4]: {n} x 64 KiB slices, raw DEFLATE level 6 (windowBits 15, memLevel 8)" if dlevel == 6 else
-                                    f"{n} x 64 KiB slices, raw DEFLATE level {dlevel} (windowBits 15, memLevel 8)"),
+            "config": {"workload": (f"BASELINE configs[4]: {n} x 64 KiB slices, raw DEFLATE level 6 (windowBits 15, memLevel 8)" if (dlevel, dwb, dml) == (6, 15, 8) else
+                                    f"{n} x 64 KiB slices, raw DEFLATE level {dlevel} (windowBits {dwb}, memLevel {dml})"),
                        "ratio": round(n * SLICE / float(lens.sum()), 4), "inflate_spot_check_ok": ok,
                        "gpu_inflate_GBps": round(n * SLICE / inflate_s / 1e9, 3), "gpu_inflate_roundtrip_ok": inflate_ok},
             ("kernels_ms" if dlevel <= 3 else "kernels_ms_first_workspace_chunk"): {k: round(v, 3) for k, v in kms.items()},

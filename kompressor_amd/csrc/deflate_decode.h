@@ -13,8 +13,10 @@
 struct KiArgs {
     const u8* src; const u64* in_off; const u32* in_len; u32 n_slices;
     u8* dst; const u64* out_off; const u32* out_cap; u32* out_len; int* status;
-    u32 format;                 // 0 = raw deflate, 1 = zlib wrapper (2-byte header, Adler-32 trailer),
-                                // 2 = gzip (RFC 1952 header, CRC-32 + ISIZE trailer), 3 = zlib or gzip by the first bytes
+    u32 format;                 // bits 0 .. 7: 0 = raw deflate, 1 = zlib wrapper (2-byte header, Adler-32 trailer),
+                                // 2 = gzip (RFC 1952 header, CRC-32 + ISIZE trailer), 3 = zlib or gzip by the first bytes;
+                                // bits 8 .. 15: the windowBits declared to inflateInit2 (0 = 15): a zlib header that names a larger
+                                // window is "invalid window size" (inflate.c HEAD state)
 };
 
 enum { KI_OK = 0, KI_DATA_ERROR = -3, KI_BUF_ERROR = -5 };
@@ -65,7 +67,7 @@ KX_DEV void inflate_stream(const KiArgs& a, KiLds& lds, u32 f, int lane)
     u8* const dst = a.dst + a.out_off[f]; u32 const cap = a.out_cap[f];
     int err = 0; u32 op = 0;
     u32 spos = 0, send = srcSize;                 // deflate data = src[spos, send)
-    u32 fmt = a.format;
+    u32 fmt = a.format & 0xFFu; u32 const wmax = (a.format >> 8) ? (a.format >> 8) : 15u;
     if (fmt == 3) fmt = (srcSize >= 2 && src[0] == 0x1F && src[1] == 0x8B) ? 2u : 1u;     // inflateInit2(windowBits + 32)
     if (fmt == 2) {
         // gzip member header: ID1 ID2 CM FLG MTIME(4) XFL OS [FEXTRA] [FNAME] [FCOMMENT] [FHCRC]
@@ -84,7 +86,7 @@ KX_DEV void inflate_stream(const KiArgs& a, KiLds& lds, u32 f, int lane)
         if (srcSize < 6) err = KI_DATA_ERROR;
         else {
             u32 const cmf = src[0], flg = src[1];
-            if ((cmf & 0x0F) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) err = KI_DATA_ERROR;
+            if ((cmf & 0x0F) != 8 || (cmf >> 4) + 8u > wmax || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) err = KI_DATA_ERROR;
             spos = 2; send = srcSize - 4;
         }
     }

@@ -148,7 +148,7 @@ KX_DEV void inflate_predecode_body(const KipArgs& a)
         // (a stream that decodes to more than the staging holds is not covered; the literals of one phase may run past cap
         //  before the check at its end, so cap keeps KIP_SYMS bytes of the staging free)
         if (cap > a.lit_cap - KIP_SYMS) cap = (a.lit_cap - KIP_SYMS) & ~7u;
-        u32 spos = 0, send = srcSize, fmt = a.format;
+        u32 spos = 0, send = srcSize, fmt = a.format & 0xFFu; u32 const wmax = (a.format >> 8) ? (a.format >> 8) : 15u;
         if (fmt == 3) fmt = (srcSize >= 2 && src[0] == 0x1F && src[1] == 0x8B) ? 2u : 1u;
         if (fmt == 2) {
             // only the plain ten-byte header zlib writes (no FEXTRA / FNAME / FCOMMENT / FHCRC): the others go the long way
@@ -158,7 +158,7 @@ KX_DEV void inflate_predecode_body(const KipArgs& a)
             if (srcSize < 6) ok = false;
             else {
                 u32 const cmf = src[0], flg = src[1];
-                if ((cmf & 0x0F) != 8 || (cmf >> 4) > 7 || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) ok = false;
+                if ((cmf & 0x0F) != 8 || (cmf >> 4) + 8u > wmax || ((cmf << 8) | flg) % 31 != 0 || (flg & 0x20)) ok = false;
             }
             spos = 2; send = srcSize - 4;
         }
@@ -373,7 +373,7 @@ KX_DEV void inflate_exec_body(const KieArgs& a)
                 else { kx_sync(); kx_wave_copy(dst + op, lp + xr.litUsed, rest, lane); op += rest; }
             }
             kx_sync();
-            u32 fmt = a.i.format;
+            u32 fmt = a.i.format & 0xFFu;
             if (fmt == 3) fmt = (srcSize >= 2 && src[0] == 0x1F && src[1] == 0x8B) ? 2u : 1u;
             if (good && fmt == 2) {
                 u32 const got = kx_wave_crc32(dst, op, lds.inw, lane);

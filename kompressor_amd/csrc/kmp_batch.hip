@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64) void k_table_probe(u32* p0, u32* p1, u32* p2, u
     }
     if (acc == 0x12345678u) sink[0] = acc;
 }
-extern "C" const char* kmp_version(void) { return "kompressor_hip 0.4 (gfx950; zstd levels -131072 .. -1 and 1 .. 3: frames and streams up to 1 GiB, dictionaries (raw content and zstd format); level 4 up to 128 KiB, above 256 KiB and streams; levels 5 .. 10 up to 128 KiB; deflate / zlib / gzip levels 1-9; zstd and inflate decoders)"; }
+extern "C" const char* kmp_version(void) { return "kompressor_hip 0.4 (gfx950; zstd levels -131072 .. -1 and 1 .. 3: frames and streams up to 1 GiB, dictionaries (raw content and zstd format); level 4 up to 128 KiB, above 256 KiB and streams; levels 5 .. 10 up to 128 KiB; deflate / zlib / gzip levels 1-9, windowBits 9-15, memLevel 1-9; zstd and inflate decoders)"; }
 
 u32 env_u32(const char* name, u32 dflt)
 {

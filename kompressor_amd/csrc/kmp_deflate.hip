@@ -69,15 +69,21 @@ extern "C" int kmp_gzip_compress_batch(kmp_batch_ctx* c, const void* d_src, cons
 extern "C" int kmp_inflate_batch(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
                                  void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap, uint32_t* d_out_len, int32_t* d_status,
                                  int format, void* hip_stream)
+{ return inflate_batch_impl(c, d_src, d_in_off, d_in_len, n, d_dst, d_out_off, d_out_cap, d_out_len, d_status, format, 0, hip_stream); }
+
+// window_bits: what the caller declared to inflateInit2 (8 .. 15; 0 = 15): zlib streams whose header names a larger window are refused
+int inflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
+                       void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap, uint32_t* d_out_len, int32_t* d_status,
+                       int format, int window_bits, void* hip_stream)
 {
-    if (format < 0 || format > 3) { g_last_error = "kmp_inflate_batch: format must be 0 (raw), 1 (zlib), 2 (gzip) or 3 (zlib or gzip)"; return KMP_ERR_ARG; }
+    if (format < 0 || format > 3 || window_bits < 0 || window_bits > 15) { g_last_error = "kmp_inflate_batch: format must be 0 (raw), 1 (zlib), 2 (gzip) or 3 (zlib or gzip)"; return KMP_ERR_ARG; }
     if (!c || (n && (!d_src || !d_in_off || !d_in_len || !d_dst || !d_out_off || !d_out_cap || !d_out_len || !d_status))) { g_last_error = "kmp_inflate_batch: null argument"; return KMP_ERR_ARG; }
     if (n == 0) return KMP_OK;
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
     KiArgs a;
     a.src = (const u8*)d_src; a.in_off = d_in_off; a.in_len = d_in_len; a.n_slices = n;
-    a.dst = (u8*)d_dst; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_len = d_out_len; a.status = d_status; a.format = (u32)format;
+    a.dst = (u8*)d_dst; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_len = d_out_len; a.status = d_status; a.format = (u32)format | ((u32)window_bits << 8);
     KMP_TRY(batch_begin(c, st, nullptr, n, 0));
     bool const use_pre = c->knob.inflate_pre && n >= env_pre_min_batch();
     if (use_pre) ensure_pre_staging(c);

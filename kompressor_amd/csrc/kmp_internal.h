@@ -125,6 +125,9 @@ int scatter_frames(kmp_batch_ctx* c, hipStream_t st, const u8* d_src, const u64*
 int zstd_compress_big(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                       uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, hipStream_t st, u32 stream, u32 strategy, u32 tail_direct = 0, u32 fast_step0 = 0, bool level4 = false);
 int dict_header_state(const unsigned char* dict, size_t dict_size, int for_decoder);       // 1: a well-formed dictionary in zstd's own format, 0: raw content, -1: the magic with a damaged header
+int inflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
+                       void* d_dst, const uint64_t* d_out_off, const uint32_t* d_out_cap, uint32_t* d_out_len, int32_t* d_status,
+                       int format, int window_bits, void* hip_stream);
 int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in_off, const uint32_t* d_in_len,
                        uint32_t n, void* d_dst, const uint64_t* d_out_off, uint32_t* d_out_len, u32 format, void* hip_stream, int level = 6,
                        int window_bits = 15, int mem_level = 8);

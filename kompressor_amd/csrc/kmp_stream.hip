@@ -332,8 +332,10 @@ extern "C" int kmp_zlib_decompress_stream(kmp_zlib_dstream* z, void* dst, size_t
                 if ((n && hipMemcpy(d_in, z->in.data(), n, hipMemcpyHostToDevice) != hipSuccess) ||
                     hipMemcpy(d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess ||
                     hipMemcpy(d_len, lens, sizeof(lens), hipMemcpyHostToDevice) != hipSuccess) break;
-                if (kmp_inflate_batch(z->batch, d_in, d_off, d_len, 1, d_out, d_off + 1, d_len + 1, d_len + 2, (int32_t*)(d_len + 3),
-                                      z->window_bits < 0 ? 0 : (z->window_bits <= 15 ? 1 : (z->window_bits <= 31 ? 2 : 3)), nullptr) != KMP_OK) break;
+                // (the window declared for a zlib stream bounds what its header may name: inflate.c, "invalid window size")
+                int const zw = z->window_bits >= 40 ? z->window_bits - 32 : (z->window_bits >= 8 && z->window_bits <= 15) ? z->window_bits : 0;
+                if (inflate_batch_impl(z->batch, d_in, d_off, d_len, 1, d_out, d_off + 1, d_len + 1, d_len + 2, (int32_t*)(d_len + 3),
+                                       z->window_bits < 0 ? 0 : (z->window_bits <= 15 ? 1 : (z->window_bits <= 31 ? 2 : 3)), zw, nullptr) != KMP_OK) break;
                 if (hipMemcpy(lens, d_len, sizeof(lens), hipMemcpyDeviceToHost) != hipSuccess) break;
                 int const st = (int)lens[3];
                 if (st == Z_BUF_ERROR_) continue;                    // output did not fit: next capacity

@@ -276,3 +276,21 @@ def test_window_bits_and_mem_level_oracle_and_emulator_match_golden():
         d = corpus.make(7000 + t, 1, int(rng.integers(0, 200000)), mix=ord("TXSBDIZR"[t % 8])).tobytes()
         c = zlib.compressobj(level, zlib.DEFLATED, -wb, ml, 0)
         assert o.compress(d, level, wb, ml) == c.compress(d) + c.flush(), (level, wb, ml, len(d))
+
+
+def test_emulated_inflate_honours_the_declared_window():
+    """inflateInit2(windowBits) below what a zlib header names: "invalid window size" (zlib inflate.c HEAD state), on both inflate
+    paths; raw and gzip streams carry no such field.  (kmp_zlib_create_decompressor passes the declared window on.)"""
+    d = corpus.make(31, 1, 5000, mix=ord("T")).tobytes()
+    for made_with in (9, 12, 15):
+        c = zlib.compressobj(6, zlib.DEFLATED, made_with, 8, 0)
+        s = c.compress(d) + c.flush()
+        for declared in (9, 11, 12, 15):
+            try:
+                ref = zlib.decompressobj(declared).decompress(s)
+            except zlib.error:
+                ref = None
+            for pre in (True, False):
+                outs, st = helpers.emu_inflate([s], [len(d)], fmt=1 | (declared << 8), pre=pre)
+                assert (outs[0] if st[0] == 0 else None) == ref, (made_with, declared, pre, st)
+                assert ref is not None or st[0] == -3

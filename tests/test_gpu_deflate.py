@@ -561,6 +561,16 @@ def test_window_bits_and_mem_level_match_zlib_on_the_gpu():
                 got = ZlibCompressor(fmt, level, wb, ml).transform_bytes(d)
                 assert got == ref, (fmt, level, wb, ml)
                 assert ZlibDecompressor(fmt, wb if fmt is not ZlibFormat.Raw else 15).transform_bytes(got) == d
+        # a decompressor's declared window: a zlib header that names a larger one is "invalid window size" (Z_DATA_ERROR), as in zlib
+        z9 = ZlibCompressor(ZlibFormat.Zlib, 6, 9, 8).transform_bytes(d)
+        for declared in (9, 12, 15):
+            assert ZlibDecompressor(ZlibFormat.Zlib, declared).transform_bytes(z9) == d
+            assert ZlibDecompressor(ZlibFormat.AutoDetectZlibGzip, declared).transform_bytes(z9) == d
+        with pytest.raises(zlib.error):
+            zlib.decompressobj(12).decompress(zlib.compress(d, 6))
+        for fmt in (ZlibFormat.Zlib, ZlibFormat.AutoDetectZlibGzip):
+            with pytest.raises(RuntimeError, match="Bad zlib result code -3: Z_DATA_ERROR"):
+                ZlibDecompressor(fmt, 12).transform_bytes(zlib.compress(d, 6))
         long_d = ragged[0]
         c = zlib.compressobj(6, zlib.DEFLATED, 10, 2, 0)
         assert ZlibCompressor(ZlibFormat.Zlib, 6, 10, 2).transform_bytes(long_d) == c.compress(long_d) + c.flush()

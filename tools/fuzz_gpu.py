@@ -150,11 +150,11 @@ for dsize in (16384, 65536, -8192, -110000):              # (negative: a trained
 # raw DEFLATE (all nine levels over two seeds) against this machine's zlib, and inflate of what came out
 import zlib
 dfl_idx = np.arange(0, N, 3)                                     # a third of the slices (the level-9 search is slow on both sides)
-def zlib_frames(level, idx):
+def zlib_frames(level, idx, wb=15, ml=8):
     def work(chunk):
         out = []
         for i in chunk:
-            c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, zlib.Z_DEFAULT_STRATEGY)
+            c = zlib.compressobj(level, zlib.DEFLATED, -wb, ml, zlib.Z_DEFAULT_STRATEGY)
             out.append(c.compress(host[offs[i]:offs[i] + lens[i]].tobytes()) + c.flush())
         return out
     chunks = [idx[k::16] for k in range(16)]
@@ -183,6 +183,27 @@ for level in ((1, 6, 9) if seed % 2 else (2, 3, 4, 5, 7, 8)):      # (odd seeds:
     for k in range(0, len(dfl_idx), 53):
         i = int(dfl_idx[k]); assert oh[int(o2h[k]):int(o2h[k]) + int(lens[i])].tobytes() == host[offs[i]:offs[i] + lens[i]].tobytes(), ("inflate round trip", i)
     print(f"raw DEFLATE level {level}: {len(dfl_idx)} streams against zlib {zlib.ZLIB_RUNTIME_VERSION}, different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:8]]}  ({time.time() - t0:.0f} s)", flush=True)
+# deflateInit2's windowBits / memLevel: four random settings per seed, alternately on a context for slices up to 64 KiB (the sort + wave-wide
+# parse kernels) and on the one above (the older chain / search / parse kernels)
+import random as _random
+prng = _random.Random(seed * 7919 + 5)
+small_idx = np.array([i for i in dfl_idx if lens[i] <= 65536], dtype=np.int64)
+bs = ZstdBatch(max_slices=max(1, len(small_idx)), max_slice_bytes=65536)
+for t in range(4):
+    t0 = time.time()
+    level, wb, ml = prng.randrange(1, 10), prng.randrange(9, 16), prng.randrange(1, 10)
+    b_, idx_ = (bs, small_idx) if t % 2 == 0 else (bd, dfl_idx[::2])
+    if len(idx_) == 0: continue
+    sel_ = torch.from_numpy(idx_.astype(np.int64)).cuda()
+    dst, ooff, olen = b_.deflate(src, d_off[sel_], d_len[sel_], level=level, check=True, window_bits=wb, mem_level=ml)
+    torch.cuda.synchronize()
+    d, oo, ol = dst.cpu().numpy(), ooff.cpu().numpy(), olen.cpu().numpy()
+    g = {int(idx_[k]): d[int(oo[k]):int(oo[k]) + int(ol[k])].tobytes() for k in range(len(idx_))}
+    r = zlib_frames(level, idx_, wb, ml)
+    bad = [i for i in idx_ if g[int(i)] != r[int(i)]]
+    bad_total += len(bad)
+    print(f"raw DEFLATE level {level} windowBits {wb} memLevel {ml} ({'<= 64 KiB kernels' if t % 2 == 0 else 'older kernels'}): {len(idx_)} streams against zlib {zlib.ZLIB_RUNTIME_VERSION}, different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:8]]}  ({time.time() - t0:.0f} s)", flush=True)
+bs.close()
 bd.close()
 print("FUZZ OK" if bad_total == 0 else f"FUZZ FOUND {bad_total} DIFFERENCES")
 sys.exit(0 if bad_total == 0 else 1)
