@@ -298,9 +298,11 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
                         c = valid ? (int)srt[where - 1 - j] : 0;
                         if (valid) cbytes = sb[where - 1 - j];               // (the candidates' first bytes lie next to each other, like their positions)
                     }
-                    // position 0 is zlib's NIL; beyond MAX_DIST the chain ends (and with it every later candidate: they lie further back).
-                    // The head of the chain may lie exactly MAX_DIST back (deflate_slow's test), the others must be nearer (longest_match's limit).
-                    bool const inWin = valid && c != 0 && (j == 0 ? strstart - c <= MD : strstart - c < MD);
+                    // the window's base is zlib's NIL (position 0 at first; slide_hash turns position w_size into 0 later); beyond MAX_DIST the
+                    // chain ends (and with it every later candidate: they lie further back).  The head of the chain may lie exactly MAX_DIST
+                    // back (deflate_slow's test) -- which can be the base when the input ends: fill_window then runs, and slides, at every
+                    // step --, the others must be nearer (longest_match's limit).
+                    bool const inWin = valid && c > base && (j == 0 ? strstart - c <= MD : strstart - c < MD);
                     u64 const ended = kx_ballot(valid && !inWin);
                     valid = inWin;
                     int len = 0;

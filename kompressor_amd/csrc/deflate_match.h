@@ -334,7 +334,10 @@ KX_DEV void deflate_parse_body(const KdArgs& a)
             // a previous match >= good_match (8) shortens the chain walk to 32 steps
             KdBest const r = best[strstart];
             int const len = prev_length >= (int)a.good ? r.len32 : r.len128, dist = prev_length >= (int)a.good ? r.dist32 : r.dist128;
-            if (len > prev_length) {
+            // (a string at the window's base is zlib's NIL -- slide_hash turns position w_size into 0 --: a head of the chain exactly
+            // MAX_DIST back that lies there is no candidate, and it was the only one: the next link is farther.  Only at the end of the
+            // input can strstart sit exactly MAX_DIST above the base: fill_window then runs, and slides, at every step.)
+            if (len > prev_length && !(dist == MD && strstart - dist <= base)) {
                 match_length = len; match_dist = dist;
                 if (match_length == KD_MIN_MATCH && match_dist > KD_TOO_FAR) match_length = KD_MIN_MATCH - 1;
             }

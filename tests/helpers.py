@@ -908,3 +908,31 @@ def deflate_params_input(case):
 def deflate_params_golden():
     with open(os.path.join(ROOT, "tests", "golden", "deflate_params_golden.json")) as fh:
         return json.load(fh)
+
+
+def deflate_nil_corner_input(window_bits, seed=0, mem_level=8, k=1, extra=138):
+    """An input that puts zlib's NIL where a candidate would be: at the end of the input fill_window runs at every step, so the window can
+    slide when strstart is exactly w_size + MAX_DIST above the base -- after which the string MAX_DIST back sits at the new base, position 0
+    of the window, which deflate takes for "no entry".  Here the eight bytes at that string are repeated at strstart and no other string
+    between them shares their hash: zlib emits literals, a parser that forgets the base a match of distance MAX_DIST.  Compressible
+    (a 16-letter alphabet), so that the blocks are not stored.  (Found by the differential fuzz, seed 61, with windowBits 9.)"""
+    W = 1 << window_bits
+    MD = W - 262
+    hb = mem_level + 7
+    sh = (hb + 2) // 3
+    mask = (1 << hb) - 1
+    basep = W * k
+    n = basep + 2 * W - 262 + extra
+    p = basep + 2 * W - 262
+    c = p - MD
+    for s in range(seed, seed + 1000):
+        rng = np.random.default_rng(s)
+        d = rng.integers(0, 16, n, dtype=np.uint8)
+        d[c:c + 8] = rng.integers(200, 256, 8, dtype=np.uint8)
+        d[p - 3:p] = rng.integers(100, 120, 3, dtype=np.uint8)          # no match runs into p
+        d[p:p + 8] = d[c:c + 8]
+        a = d.astype(np.int64)
+        h = ((a[:-2] << (2 * sh)) ^ (a[1:-1] << sh) ^ a[2:]) & mask
+        if not (h[c + 1:p] == h[p]).any():
+            return d.tobytes()
+    raise AssertionError("no seed")

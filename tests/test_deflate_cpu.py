@@ -294,3 +294,19 @@ def test_emulated_inflate_honours_the_declared_window():
                 outs, st = helpers.emu_inflate([s], [len(d)], fmt=1 | (declared << 8), pre=pre)
                 assert (outs[0] if st[0] == 0 else None) == ref, (made_with, declared, pre, st)
                 assert ref is not None or st[0] == -3
+
+
+def test_the_window_base_is_nil_when_the_input_ends():
+    """helpers.deflate_nil_corner_input: the string exactly MAX_DIST back lies at the base of zlib's window after the slide that
+    fill_window makes at the end of the input -- no candidate for zlib; the oracle and both emulated parsers (the wave-wide one up to
+    64 KiB, the older one above and on request) must say so too, at the default window (a 98 180-byte slice) as at small ones."""
+    o = helpers.deflate_oracle()
+    for wb, seeds in ((9, (0, 1, 2)), (12, (0, 1)), (15, (0,))):
+        for seed in seeds:
+            d = helpers.deflate_nil_corner_input(wb, seed)
+            for lvl in ((6, 4, 9, 2) if wb < 15 else (6,)):
+                c = zlib.compressobj(lvl, zlib.DEFLATED, -wb, 8, 0)
+                ref = c.compress(d) + c.flush()
+                assert o.compress(d, lvl, wb, 8) == ref
+                for old in ((False, True) if len(d) <= 65536 else (True,)):
+                    assert helpers.emu_deflate([d], level=lvl, window_bits=wb, mem_level=8, old_kernels=old)[0] == ref, (wb, seed, lvl, old)

@@ -543,6 +543,14 @@ def test_window_bits_and_mem_level_match_zlib_on_the_gpu():
             for i, (d, f) in enumerate(zip(datas, outs)):
                 c = zlib.compressobj(level, zlib.DEFLATED, -wb, ml, 0)
                 assert f == c.compress(d) + c.flush(), (level, wb, ml, i)
+        # zlib's NIL at the window's base when the input ends (helpers.deflate_nil_corner_input; the fuzz campaign's finding): both contexts
+        for wb in (9, 10, 12, 15):
+            corner = [helpers.deflate_nil_corner_input(wb, seed) for seed in range(4)]
+            for level in (4, 6, 9, 1):
+                for b in ((small, big) if wb < 15 else (big,)):
+                    for d, f in zip(corner, run(b, corner, level, wb, 8, 0)):
+                        c = zlib.compressobj(level, zlib.DEFLATED, -wb, 8, 0)
+                        assert f == c.compress(d) + c.flush(), ("corner", level, wb, len(d))
         # the default settings through the same entry point are the default entry point's streams
         assert run(small, datas[:64], 6, 15, 8, 1) == [zlib.compress(d, 6) for d in datas[:64]]
         # above 64 KiB (the context's older kernels): a ragged batch at a small window and at memLevel 9 (the chain kernel's two passes)
