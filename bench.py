@@ -634,7 +634,7 @@ def main():
             except Exception:
                 traffic = None
             print(json.dumps({
-                "metric": f"raw DEFLATE decompression throughput, level-{dlevel} streams of 64 KiB slices (decoded bytes per second)",
+                "metric": f"raw DEFLATE decompression throughput, level-{dlevel} streams of {args.slice_kib} KiB slices (decoded bytes per second)",
                 "value": round(n * SLICE / (dt / args.steps) / 1e9, 3), "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 1),
                 "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "u8", "data": "synthetic",
@@ -688,7 +688,7 @@ def main():
                 list(ex.map(_zrun, range(cpu_cores)))
         cpu = sample * SLICE / max(time.perf_counter() - t1, 1e-9) / 1e9 if not args.no_cpu else 0.0
         # dominant kernel: k_deflate_lazy, one launch per piece of <= 16384 slices; algorithmic bytes per slice as in SURVEY 8d
-        piece = min(n, 16384)
+        piece = min(n, 16384 if SLICE <= 65536 else max(1, (1 << 29) // (((SLICE + 63) // 64) * 64)))          # (a piece of the workspace: kmp_deflate.hip)
         algo_piece = (n * SLICE + int(lens.sum()) + 16 * n) * piece // n
         traffic_best = None
         try:
@@ -714,12 +714,12 @@ def main():
                             "traffic": 520_000_000_000 if (dlevel == 1 and n == 65536 and SLICE == 65536) else None,      # tools/pmc_dfl_fast.sh, DESIGN.md
                             "slices_per_launch": piece, "avg_launch_ms": round(ms_fast, 3)}
         print(json.dumps({
-            "metric": f"raw DEFLATE level-{dlevel} compression throughput, 64 KiB-slice batch (uncompressed input bytes per second)",
+            "metric": f"raw DEFLATE level-{dlevel} compression throughput, {args.slice_kib} KiB-slice batch (uncompressed input bytes per second)",
             "value": round(n * SLICE / (dt / args.steps) / 1e9, 3), "unit": "GB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[4]: {n} x 64 KiB slices, raw DEFLATE level 6 (windowBits 15, memLevel 8)" if (dlevel, dwb, dml) == (6, 15, 8) else
-                                    f"{n} x 64 KiB slices, raw DEFLATE level {dlevel} (windowBits {dwb}, memLevel {dml})"),
+            "config": {"workload": (f"BASELINE configs[4]: {n} x 64 KiB slices, raw DEFLATE level 6 (windowBits 15, memLevel 8)" if (dlevel, dwb, dml, args.slice_kib) == (6, 15, 8, 64) else
+                                    f"{n} x {args.slice_kib} KiB slices, raw DEFLATE level {dlevel} (windowBits {dwb}, memLevel {dml})"),
                        "ratio": round(n * SLICE / float(lens.sum()), 4), "inflate_spot_check_ok": ok,
                        "gpu_inflate_GBps": round(n * SLICE / inflate_s / 1e9, 3), "gpu_inflate_roundtrip_ok": inflate_ok},
             ("kernels_ms" if dlevel <= 3 else "kernels_ms_first_workspace_chunk"): {k: round(v, 3) for k, v in kms.items()},

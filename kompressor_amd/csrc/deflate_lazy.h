@@ -28,10 +28,12 @@
 // the number of dependent round trips per search, not on bytes) where KdBest lived (twice its size); wr (where | rank << 16,
 // 4 bytes per position) in an array of its own; the ranks of the first pass sit in the symbol array until the parse fills it.
 struct alignas(16) KdlBytes { u64 lo, hi; };
-KX_DEV u32* kdl_wr(const KdArgs& a, u32 slice) { return a.wr + (size_t)slice * a.pos_cap; }
-KX_DEV u16* kdl_srt(const KdArgs& a, u32 slice) { return a.link + (size_t)slice * a.pos_cap; }
-KX_DEV KdlBytes* kdl_sb(const KdArgs& a, u32 slice) { return (KdlBytes*)(a.best + (size_t)slice * a.pos_cap * 2u); }
-KX_DEV u16* kdl_rank(const KdArgs& a, u32 slice) { return (u16*)(a.syms + (size_t)slice * a.pos_cap); }
+// (SEG: the arrays of a slice hold one 64 KiB span whatever the slice's length -- see deflate_sort_body; the symbols keep pos_cap)
+template <bool SEG> KX_DEV size_t kdl_stride(const KdArgs& a) { return SEG ? (size_t)65536u : (size_t)a.pos_cap; }
+template <bool SEG> KX_DEV u32* kdl_wr(const KdArgs& a, u32 slice) { return a.wr + (size_t)slice * kdl_stride<SEG>(a); }
+template <bool SEG> KX_DEV u16* kdl_srt(const KdArgs& a, u32 slice) { return a.link + (size_t)slice * kdl_stride<SEG>(a); }
+template <bool SEG> KX_DEV KdlBytes* kdl_sb(const KdArgs& a, u32 slice) { return (KdlBytes*)(a.best + (size_t)slice * kdl_stride<SEG>(a) * 2u); }
+template <bool SEG> KX_DEV u16* kdl_rank(const KdArgs& a, u32 slice) { return SEG ? a.seg_rank + (size_t)slice * 65536u : (u16*)(a.syms + (size_t)slice * a.pos_cap); }
 
 // 8 bytes at position q of a slice of n bytes, bytes past the end read as zero (q < n)
 KX_DEV u64 kdl_ld64(const u8* src, int q, int n)
@@ -51,7 +53,15 @@ template <bool TINY> KX_DEV u64 kdl_get64(const u8* src, int q, int n) { return 
 // Pass 1, in position order (the waves of the workgroup take turns on the table, as in k_deflate_chains): rank[p] = how many
 // earlier positions share p's hash.  Pass 2: exclusive scan of the bucket sizes.  Pass 3, any order: where[p] = start of the
 // bucket + rank[p]; srt[where[p]] = p.
-template <int HB = 15>                        // hash bits the table has room for (memLevel 9: 16)
+// SEG (slices above 64 KiB, late round 4): a long slice goes through in SEGMENTS.  A candidate lies less than 32 KiB back, so the
+// positions of [32 768 (k + 1), 32 768 (k + 2)) find all of theirs in the 64 KiB span that starts at 32 768 k: launch k of this kernel
+// sorts that span of every slice (positions relative to its start, so the arrays and their 16-bit entries are those of a 64 KiB slice,
+// whatever the slice's length), launch k of k_deflate_lazy parses those positions (segment 0: the whole first span) and leaves its
+// state for launch k + 1.  Every slice of a piece is in flight in every launch; the workspace no longer grows with the slice.
+#define KDL_SEG_STEP 32768u
+#define KDL_SEG_SPAN 65536u
+#define KDL_STATE_WORDS 12u
+template <int HB = 15, bool SEG = false>      // hash bits the table has room for (memLevel 9: 16)
 KX_DEV void deflate_sort_body(const KdArgs& a)
 {
     KX_SHARED u16 cnt[1 << HB];                     // bucket sizes, then bucket starts (a slice has at most 65 534 chained positions)
@@ -60,13 +70,16 @@ KX_DEV void deflate_sort_body(const KdArgs& a)
     int const lane = kx_lane(); int const wv = kx_wave(); int const nw = kx_nwaves(); int const tid = wv * 64 + lane; int const nthreads = nw * 64;
     for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) {
         u32 const slice = kx_xcd_chunk(it, a.n_slices);
-        const u8* const src = a.src + a.in_off[slice]; u32 const n = a.in_len[slice];
-        u16* const rank = kdl_rank(a, slice);
-        u32* const wr = kdl_wr(a, slice); u16* const srt = kdl_srt(a, slice); KdlBytes* const sb = kdl_sb(a, slice);
+        u32 const s0 = SEG ? a.seg * KDL_SEG_STEP : 0u;
+        if (SEG && a.seg > 0 && a.in_len[slice] <= s0 + KDL_SEG_STEP) continue;        // this slice was finished by an earlier segment (uniform over the workgroup)
+        const u8* const src = a.src + a.in_off[slice] + s0; u32 const n = a.in_len[slice] - s0;      // (n: the bytes from the span's start to the slice's end)
+        u16* const rank = kdl_rank<SEG>(a, slice);
+        u32* const wr = kdl_wr<SEG>(a, slice); u16* const srt = kdl_srt<SEG>(a, slice); KdlBytes* const sb = kdl_sb<SEG>(a, slice);
         int const hsize = (int)a.hmask + 1;
         for (int i = tid; i < hsize; i += nthreads) cnt[i] = 0;
         kx_block_sync();
-        u32 const nIns = n >= 3 ? n - 2 : 0;                // positions 0 .. n-3 enter the chains, in order
+        u32 nIns = n >= 3 ? n - 2 : 0;                      // positions 0 .. n-3 enter the chains, in order
+        if (SEG && nIns > KDL_SEG_SPAN) nIns = KDL_SEG_SPAN; // (... those of the span; their bytes may lie beyond it)
         // ---- pass 1 (the source bytes of a group of four rounds are fetched a group ahead, as in k_deflate_chains)
         u32 hq[4]; bool vq[4];
 #pragma unroll
@@ -131,7 +144,7 @@ KX_DEV void deflate_sort_body(const KdArgs& a)
             for (int i = 0; i < per; i++) { u32 const v = cnt[tid * per + i]; s += v; occ += v ? 1u : 0u; }
             // how many of the 32 768 buckets the slice uses says how varied its bytes are: a cheap stand-in for what the parse will
             // cost (binary and text slices use thousands, structured records hundreds), by which the parse kernel orders its slices
-            if (a.order_key) {
+            if (!SEG && a.order_key) {
                 occp[tid] = occ;
                 kx_block_sync();
                 if (tid == 0) {
@@ -167,12 +180,17 @@ KX_DEV void deflate_sort_body(const KdArgs& a)
 // ---------------------------------------------------------------------------
 // k_deflate_lazy: one wave per slice
 // ---------------------------------------------------------------------------
-template <bool TINY>       // (unused since the loaders are one again)
+template <bool SEG>        // SEG: one segment of a slice above 64 KiB (see deflate_sort_body): positions stay absolute, the arrays are the span's
 KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
 {
+    constexpr bool TINY = false;
     {
         const u8* const src = a.src + a.in_off[slice]; int const n = (int)a.in_len[slice];
-        const u32* const wr = kdl_wr(a, slice); const u16* const srt = kdl_srt(a, slice); const KdlBytes* const sb = kdl_sb(a, slice);
+        int const s0 = SEG ? (int)(a.seg * KDL_SEG_STEP) : 0;                        // the span's first position
+        if (SEG && a.seg > 0 && n <= s0 + (int)KDL_SEG_STEP) return;                  // finished by an earlier segment
+        bool const to_end = !SEG || n <= s0 + (int)KDL_SEG_SPAN;                     // this launch parses the slice to its end
+        int const segEnd = s0 + (int)KDL_SEG_SPAN;                                   // else: up to here, the next launch goes on
+        const u32* const wr = kdl_wr<SEG>(a, slice) - s0; const u16* const srt = kdl_srt<SEG>(a, slice); const KdlBytes* const sb = kdl_sb<SEG>(a, slice);   // (wr is taken at absolute positions)
         u32* const syms = a.syms + (size_t)slice * a.pos_cap;
         KdBlockInfo* const blocks = a.blocks + (size_t)slice * a.blk_cap;
         KdSliceMeta mm; mm.nblocks = 0; mm.nsym = 0; mm.pad[0] = 0; mm.pad[1] = 0;
@@ -183,7 +201,16 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
         int const W = (int)a.wsize, MD = (int)a.max_dist; u32 const LB = a.lit_buf;
         int base = 0, dataEnd = n < 2 * W ? n : 2 * W;
         int const maxChain = (int)a.chain, niceMax = (int)a.nice;
-        int const nIns = n >= 3 ? n - 2 : 0;
+        // the positions the sort has placed (absolute): 0 .. n - 3, in segment mode those of the span
+        int nIns = n >= 3 ? n - 2 : 0;
+        if (SEG && nIns > segEnd) nIns = segEnd;
+        u32* const st_ = SEG ? a.seg_state + (size_t)slice * KDL_STATE_WORDS : nullptr;
+        if (SEG && a.seg > 0) {
+            // where the previous segment stopped (the open group of symbols waits in the symbol array)
+            strstart = (int)st_[0]; match_length = (int)st_[1]; match_dist = (int)st_[2]; match_available = st_[3] != 0u;
+            nsym = st_[4]; blockSyms = st_[5]; block_start = (int)st_[6]; base = (int)st_[7]; dataEnd = (int)st_[8]; mm.nblocks = st_[9];
+            if ((u32)lane < (nsym & 63u)) symq = syms[(nsym & ~63u) + (u32)lane];
+        }
         // The parse is one decision chain per slice and runs on the scalar unit, of which a compute unit has ONE: with 32 slices per CU
         // in flight the kernel is bound by scalar instructions per position (counters: profiles/r04_deflate_lazy.txt), so the parse
         // touches as few positions as it can and does as little as it can at each.
@@ -211,6 +238,15 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
         if ((nsym & 63u) == 0) syms[nsym - 64u + (u32)lane] = symq; }
         for (;;) {
             if (lane == 0) KX_STAT(40, 1);                          // steps of the parse
+            if (SEG && !to_end && strstart >= segEnd) {
+                // the next segment's launch goes on from here
+                if (lane == 0) {
+                    st_[0] = (u32)strstart; st_[1] = (u32)match_length; st_[2] = (u32)match_dist; st_[3] = match_available ? 1u : 0u;
+                    st_[4] = nsym; st_[5] = blockSyms; st_[6] = (u32)block_start; st_[7] = (u32)base; st_[8] = (u32)dataEnd; st_[9] = mm.nblocks;
+                }
+                if ((u32)lane < (nsym & 63u)) syms[(nsym & ~63u) + (u32)lane] = symq;
+                return;
+            }
             if (dataEnd - strstart < KD_MIN_LOOKAHEAD) {
                 // fill_window: one pass is enough (it brings at least 65 536 - strstart bytes, or all that is left)
                 int const rel = strstart - base;
@@ -240,6 +276,7 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
                 u64 const rest = maybe >> off;
                 int K = rest ? (int)kx_ctz64(rest) : 64; if (K > 64 - off) K = 64 - off;
                 int const room_w = dataEnd - KD_MIN_LOOKAHEAD - strstart + 1; if (K > room_w) K = room_w;
+                if (SEG && !to_end && K > segEnd - strstart) K = segEnd - strstart;       // (the positions beyond belong to the next segment)
                 int const first_lit = match_available ? strstart - 1 : strstart;          // the first position passed emits the byte behind it, if that is still owed
                 int L = match_available ? K : K - 1;
                 int const room_q = 64 - (int)(nsym & 63u), room_b = (int)(LB - 2u) - (int)blockSyms;
@@ -274,7 +311,7 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
                 if (pf_pos == strstart) { scan0 = pf_s0; scan1 = pf_s1; c0 = pf_c; cb0 = pf_cb; }     // asked for a step ago
                 else {
                     scan0 = kdl_get64<TINY>(src, strstart, n); scan1 = kdl_get64<TINY>(src, strstart + 8, n);
-                    if (lane < ncand) { c0 = (int)srt[where - 1 - lane]; cb0 = sb[where - 1 - lane]; }
+                    if (lane < ncand) { c0 = s0 + (int)srt[where - 1 - lane]; cb0 = sb[where - 1 - lane]; }
                 }
                 pf_pos = -1;
                 if (prev_length < KD_MIN_MATCH && off + 1 < 64 && ((maybe >> (off + 1)) & 1ull)) {
@@ -283,7 +320,7 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
                     int const where1 = (int)(w1 & 0xFFFFu), rk1 = (int)(w1 >> 16);
                     int const n1 = rk1 < maxChain ? rk1 : maxChain;
                     pf_c = 0; pf_cb.lo = 0; pf_cb.hi = 0;
-                    if (lane < n1) { pf_c = (int)srt[where1 - 1 - lane]; pf_cb = sb[where1 - 1 - lane]; }
+                    if (lane < n1) { pf_c = s0 + (int)srt[where1 - 1 - lane]; pf_cb = sb[where1 - 1 - lane]; }
                     pf_s0 = kdl_get64<TINY>(src, strstart + 1, n); pf_s1 = kdl_get64<TINY>(src, strstart + 9, n);
                     pf_pos = strstart + 1;
                     if (lane == 0) KX_STAT(49, 1);                      // searches asked for ahead
@@ -295,7 +332,7 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
                     KdlBytes cbytes; cbytes.lo = 0; cbytes.hi = 0;
                     if (valid) cbytes = cb0;
                     if (cb > 0) {
-                        c = valid ? (int)srt[where - 1 - j] : 0;
+                        c = valid ? s0 + (int)srt[where - 1 - j] : 0;
                         if (valid) cbytes = sb[where - 1 - j];               // (the candidates' first bytes lie next to each other, like their positions)
                     }
                     // the window's base is zlib's NIL (position 0 at first; slide_hash turns position w_size into 0 later); beyond MAX_DIST the
@@ -362,6 +399,7 @@ KX_DEV void deflate_lazy_slice(const KdArgs& a, u32 slice, int lane)
     }
 }
 
+template <bool SEG = false>
 KX_DEV void deflate_lazy_body(const KdArgs& a)
 {
     int const lane = kx_lane();
@@ -369,6 +407,116 @@ KX_DEV void deflate_lazy_body(const KdArgs& a)
         // the slices that will take longest first (a.order: k_deflate_sort's estimate, largest first), so that the launch does not end
         // with a few waves walking its heaviest slices alone
         u32 const slice = a.order ? a.order[it] : kx_xcd_chunk(it, a.n_slices);
-        deflate_lazy_slice<false>(a, slice, lane);
+        deflate_lazy_slice<SEG>(a, slice, lane);
     }
+}
+
+// ---------------------------------------------------------------------------
+// k_deflate_parse_wave: one wave per slice over k_deflate_best's records (slices above 64 KiB)
+// ---------------------------------------------------------------------------
+// The older kernels' parse was a LANE per slice: every step a dependent 8-byte load of best[strstart] (a round trip to memory per
+// position visited), and a piece of long slices has few of them -- 4 096 slices of 256 KiB are 64 waves.  Here the decision chain is
+// deflate_lazy_slice's, wave-uniform on the scalar unit, and the records of the 64 positions from wbase on sit in registers (lane i:
+// best[wbase + i], one coalesced load per window); a step reads its record with two v_readlane, runs of positions without any match
+// leave as literals 64 lanes wide, the symbols 64 at a time.  Same output as deflate_parse_body (the emulator runs both).
+KX_DEV void deflate_parse_wave_slice(const KdArgs& a, u32 slice, int lane)
+{
+    const u8* const src = a.src + a.in_off[slice]; int const n = (int)a.in_len[slice];
+    const KdBest* const best = a.best + (size_t)slice * a.pos_cap;
+    u32* const syms = a.syms + (size_t)slice * a.pos_cap;
+    KdBlockInfo* const blocks = a.blocks + (size_t)slice * a.blk_cap;
+    KdSliceMeta mm; mm.nblocks = 0; mm.nsym = 0; mm.pad[0] = 0; mm.pad[1] = 0;
+    int strstart = 0; int match_length = 2, prev_length = 2; int match_dist = 0, prev_dist = 0; bool match_available = false;
+    u32 nsym = 0, blockSyms = 0; int block_start = 0;
+    u32 symq = 0;                                      // lane (nsym & 63) holds symbol nsym until 64 are there
+    int const W = (int)a.wsize, MD = (int)a.max_dist; u32 const LB = a.lit_buf;
+    int base = 0, dataEnd = n < 2 * W ? n : 2 * W;     // zlib's window buffer (see deflate_parse_body)
+    int wbase = -(1 << 20); u32 r_full = 0, r_quarter = 0; u64 maybe = 0;       // len | dist << 16 of a full chain and of a quarter of it
+#define KDW_FLUSH() { KdBlockInfo b_; \
+        b_.nsym_end = nsym; b_.end_pos = (u32)strstart; b_.start_pos = (u32)block_start; b_.stored_ok = (block_start - base >= 0) ? 1u : 0u; \
+        if (lane == 0 && mm.nblocks < a.blk_cap) blocks[mm.nblocks] = b_; \
+        mm.nblocks++; block_start = strstart; blockSyms = 0; }
+#define KDW_TALLY_MATCH(dist_, lc_) { u32 const v__ = (u32)(dist_) | ((u32)(lc_) << 16); \
+        if ((u32)lane == (nsym & 63u)) symq = v__; \
+        nsym++; blockSyms++; \
+        if ((nsym & 63u) == 0) syms[nsym - 64u + (u32)lane] = symq; }
+#define KDW_TALLY_LIT(pos_) { if ((u32)lane == (nsym & 63u)) symq = (u32)src[pos_] << 16; \
+        nsym++; blockSyms++; \
+        if ((nsym & 63u) == 0) syms[nsym - 64u + (u32)lane] = symq; }
+    for (;;) {
+        if (dataEnd - strstart < KD_MIN_LOOKAHEAD) {
+            int const rel = strstart - base;
+            int const slide = (rel >= W + MD) ? W : 0;
+            base += slide;
+            int const more = 2 * W - (dataEnd - base);
+            dataEnd += (n - dataEnd < more) ? n - dataEnd : more;
+            if (dataEnd == strstart) break;
+        }
+        int const lookahead = n - strstart;
+        bool const search_here = lookahead >= KD_MIN_MATCH && match_length < (int)a.lazy;       // (match_length: what becomes prev_length below)
+        if (search_here && (strstart < wbase || strstart >= wbase + 64)) {
+            wbase = strstart;
+            KdBest r; r.len128 = 0; r.dist128 = 0; r.len32 = 0; r.dist32 = 0;
+            if (strstart + lane + 2 < n) r = best[strstart + lane];         // (k_deflate_best writes the positions that have three bytes)
+            r_full = (u32)r.len128 | ((u32)r.dist128 << 16); r_quarter = (u32)r.len32 | ((u32)r.dist32 << 16);
+            maybe = kx_ballot(r.len128 != 0);                                // (a quarter of the chain finds nothing where the full chain does not)
+        }
+        int const off = strstart - wbase;
+        if (search_here && match_length == KD_MIN_MATCH - 1 && !((maybe >> off) & 1ull)) {
+            // a run of positions at which nothing is found, after one at which nothing was: literals, all at once (deflate_lazy_slice)
+            u64 const rest = maybe >> off;
+            int K = rest ? (int)kx_ctz64(rest) : 64; if (K > 64 - off) K = 64 - off;
+            int const room_w = dataEnd - KD_MIN_LOOKAHEAD - strstart + 1; if (K > room_w) K = room_w;
+            int const first_lit = match_available ? strstart - 1 : strstart;
+            int L = match_available ? K : K - 1;
+            int const room_q = 64 - (int)(nsym & 63u), room_b = (int)(LB - 2u) - (int)blockSyms;
+            int const Lmax = room_q < room_b ? room_q : room_b;
+            if (L > Lmax) { K -= L - Lmax; L = Lmax; }
+            if (K >= 2 && L >= 1) {
+                int const i = lane - (int)(nsym & 63u);
+                if (i >= 0 && i < L) symq = (u32)src[first_lit + i] << 16;
+                nsym += (u32)L; blockSyms += (u32)L;
+                if ((nsym & 63u) == 0) syms[nsym - 64u + (u32)lane] = symq;
+                strstart += K; match_available = true;
+                prev_length = KD_MIN_MATCH - 1;
+                continue;
+            }
+        }
+        prev_length = match_length; prev_dist = match_dist;
+        match_length = KD_MIN_MATCH - 1;
+        if (search_here) {
+            u32 const rec = prev_length >= (int)a.good ? kx_bcast(r_quarter, off) : kx_bcast(r_full, off);
+            int const len = (int)(rec & 0xFFFFu), dist = (int)(rec >> 16);
+            // (the window's base is zlib's NIL: see deflate_parse_body)
+            if (len > prev_length && !(dist == MD && strstart - dist <= base)) {
+                match_length = len; match_dist = dist;
+                if (match_length == KD_MIN_MATCH && match_dist > KD_TOO_FAR) match_length = KD_MIN_MATCH - 1;
+            }
+        }
+        if (prev_length >= KD_MIN_MATCH && match_length <= prev_length) {
+            KDW_TALLY_MATCH(prev_dist, prev_length - KD_MIN_MATCH)
+            bool const bflush = blockSyms == LB - 1u;
+            strstart += prev_length - 1;
+            match_available = false; match_length = KD_MIN_MATCH - 1;
+            if (bflush) KDW_FLUSH()
+        } else if (match_available) {
+            KDW_TALLY_LIT(strstart - 1)
+            if (blockSyms == LB - 1u) KDW_FLUSH()
+            strstart++;
+        } else { match_available = true; strstart++; }
+    }
+    if (match_available) KDW_TALLY_LIT(strstart - 1)
+    KDW_FLUSH()
+    if ((nsym & 63u) != 0 && (u32)lane < (nsym & 63u)) syms[(nsym & ~63u) + (u32)lane] = symq;
+    mm.nsym = nsym;
+    if (lane == 0) a.meta[slice] = mm;
+#undef KDW_TALLY_MATCH
+#undef KDW_TALLY_LIT
+#undef KDW_FLUSH
+}
+
+KX_DEV void deflate_parse_wave_body(const KdArgs& a)
+{
+    int const lane = kx_lane();
+    for (u32 it = kx_block(); it < a.n_slices; it += kx_nblocks()) deflate_parse_wave_slice(a, kx_xcd_chunk(it, a.n_slices), lane);
 }

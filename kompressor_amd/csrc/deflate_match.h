@@ -56,6 +56,9 @@ struct KdArgs {
     // deflateInit2's windowBits and memLevel (zlib deflate.c deflateInit2_): w_size = 1 << windowBits and MAX_DIST = w_size - 262;
     // hash_bits = memLevel + 7, hash_shift = (hash_bits + 2) / 3; lit_bufsize = 1 << (memLevel + 6) (a block is closed at lit_bufsize - 1 symbols)
     u32 wsize = KD_WSIZE, max_dist = KD_MAX_DIST, hshift = 5, hmask = 0x7FFFu, lit_buf = KD_LIT_BUFSIZE, zcmf = 0x78u;
+    // deflate_lazy.h, slices above 64 KiB: the segment a launch works on (its 64 KiB span starts at 32 768 * seg) and where the parse
+    // keeps its state between two segments (KDL_STATE_WORDS words per slice)
+    u32 seg = 0; u32* seg_state = nullptr; u16* seg_rank = nullptr;       // (seg_rank: the sort's ranks, 65 536 per slice -- up to 64 KiB they sit in the symbol array)
 };
 // zlib's UPDATE_HASH over three bytes: ((b0 << 2 * hash_shift) ^ (b1 << hash_shift) ^ b2) & hash_mask
 KX_DEV u32 kd_hash3(const KdArgs& a, u32 b0, u32 b1, u32 b2) { return ((b0 << (2u * a.hshift)) ^ (b1 << a.hshift) ^ b2) & a.hmask; }

@@ -534,7 +534,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     (void)hipFree(c->pre_lits); (void)hipFree(c->pre_lit); (void)hipFree(c->pre_nlit);
     if (c->st2) (void)hipStreamDestroy(c->st2);
     (void)hipFree(c->dfl_wr); (void)hipFree(c->dfl_order); (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta); (void)hipFree(c->dfl_blocks);
-    (void)hipFree(c->dfl_fsyms); (void)hipFree(c->dfl_fmeta); (void)hipFree(c->dfl_fblocks);
+    (void)hipFree(c->dfl_fsyms); (void)hipFree(c->dfl_fmeta); (void)hipFree(c->dfl_fblocks); (void)hipFree(c->dfl_rank); (void)hipFree(c->dfl_state); (void)hipFree(c->dfl_maxlen);
     if (c->dfl_events) for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->dfl_searched[i]); (void)hipEventDestroy(c->dfl_done[i]); }
     delete c;
 }
@@ -558,7 +558,11 @@ extern "C" int kmp_batch_memory(kmp_batch_ctx* c, kmp_batch_memory_info* info)
     if (c->big) m.block_chain = ns * sizeof(KFrameState) + ns * 512 * sizeof(u32) + ns * KX_BIG_TBL_ENTRIES * sizeof(u32) + ns * 4 + 64;
     if (c->pre_stage) m.decode_staging += (size_t)c->pre_slices * c->pre_seq_cap * 8u + (size_t)c->pre_slices * c->pre_blk_cap * sizeof(KPreBlk) + (size_t)c->pre_slices * 4u + ((size_t)c->pre_slices * 2u + KXP_SORT_BUCKETS) * 4u;
     if (c->pre_lits) m.decode_staging += (size_t)c->pre_slices * c->pre_lit_cap + (size_t)c->pre_slices * c->pre_blk_cap * sizeof(KPreLit) + (size_t)c->pre_slices * 4u;
-    if (c->dfl_link) m.deflate_workspace += (size_t)2 * c->dfl_chunk * c->dfl_pos_cap * (sizeof(u16) + sizeof(KdBest) * (c->dfl_wr ? 2u : 1u) + sizeof(u32) + (c->dfl_wr ? sizeof(u32) : 0)) + (size_t)2 * c->dfl_chunk * (sizeof(KdSliceMeta) + (size_t)c->dfl_blk_cap * sizeof(KdBlockInfo));
+    if (c->dfl_link) {
+        size_t const span = c->dfl_pos_cap > 65536u ? 65536u : c->dfl_pos_cap;          // (above 64 KiB the search arrays hold one 64 KiB span per slice: kmp_deflate.hip)
+        m.deflate_workspace += (size_t)2 * c->dfl_chunk * (span * (sizeof(u16) + sizeof(KdBest) * 2u + sizeof(u32) + (c->dfl_rank ? sizeof(u16) : 0)) + (size_t)c->dfl_pos_cap * sizeof(u32)
+                                                            + sizeof(KdSliceMeta) + (size_t)c->dfl_blk_cap * sizeof(KdBlockInfo));
+    }
     if (c->dfl_fsyms) m.deflate_workspace += (size_t)4 * c->dfl_chunk * ((size_t)c->dfl_pos_cap * sizeof(u32) + sizeof(KdSliceMeta) + (size_t)c->dfl_blk_cap * sizeof(KdBlockInfo));
     m.total = m.arena + m.workspace + m.other_tables + m.block_chain + m.decode_staging + m.deflate_workspace;
     *info = m;

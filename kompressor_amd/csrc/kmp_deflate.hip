@@ -14,11 +14,23 @@ __global__ __launch_bounds__(256) void k_deflate_chains(KdArgs a) { deflate_chai
 __global__ __launch_bounds__(256) void k_deflate_chains_long(KdArgs a) { deflate_chains_body<u32>(a); }
 __global__ __launch_bounds__(1024) void k_deflate_best(KdArgs a) { deflate_best_body(a); }
 __global__ __launch_bounds__(64) void k_deflate_parse(KdArgs a) { deflate_parse_body(a); }
+__global__ __launch_bounds__(64, 8) void k_deflate_parse_wave(KdArgs a) { deflate_parse_wave_body(a); }   // the same parse, a wave per slice (deflate_lazy.h)
 __global__ __launch_bounds__(64) void k_deflate_fast(KdArgs a) { deflate_fast_body(a); }
 // the lazy levels for slices up to 64 KiB: positions sorted by hash, then the parse with a wave-wide longest_match (deflate_lazy.h)
 __global__ __launch_bounds__(256) void k_deflate_sort(KdArgs a) { deflate_sort_body<15>(a); }
 __global__ __launch_bounds__(256) void k_deflate_sort_wide(KdArgs a) { deflate_sort_body<16>(a); }        // memLevel 9: 65 536 buckets (128 KiB of LDS)
-__global__ __launch_bounds__(64, 8) void k_deflate_lazy(KdArgs a) { deflate_lazy_body(a); }
+// slices above 64 KiB, one segment per launch (deflate_lazy.h: a 64 KiB span of every slice is sorted, half of it parsed)
+__global__ __launch_bounds__(256) void k_deflate_sort_seg(KdArgs a) { deflate_sort_body<15, true>(a); }
+__global__ __launch_bounds__(256) void k_deflate_sort_seg_wide(KdArgs a) { deflate_sort_body<16, true>(a); }
+__global__ __launch_bounds__(64, 8) void k_deflate_lazy_seg(KdArgs a) { deflate_lazy_body<true>(a); }
+__global__ __launch_bounds__(256) void k_max_len(const u32* len, u32 n, u32* out)
+{
+    u32 const i = blockIdx.x * 256u + threadIdx.x;
+    u32 v = i < n ? len[i] : 0u;
+    for (int o = 32; o; o >>= 1) { u32 const t = (u32)__shfl_xor((int)v, o); v = t > v ? t : v; }
+    if ((threadIdx.x & 63u) == 0 && v) atomicMax(out, v);
+}
+__global__ __launch_bounds__(64, 8) void k_deflate_lazy(KdArgs a) { deflate_lazy_body<false>(a); }
 __global__ __launch_bounds__(64, 2) void k_inflate_predecode(KipArgs a) { inflate_predecode_body(a); }
 __global__ __launch_bounds__(64) void k_inflate_exec(KieArgs a) { inflate_exec_body(a); }
 __global__ __launch_bounds__(64, 4) void k_deflate_encode(KdArgs a) { deflate_encode_body(a); }
@@ -142,22 +154,29 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
     hipStream_t const st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->dfl_link) {
-        // Two workspace halves of up to 16 384 slices each (28 GiB of the 288 GB for both): while the search kernels
-        // (chains, best: LDS-bound) work on one piece of the batch, the parse (one lane per slice, pure latency, no LDS)
-        // and the encoder of the previous piece run beside them on the context's second stream.
-        // (14 bytes of workspace per position: link, best, symbol; the pieces hold 2^30 positions each at most)
+        // Two workspace halves of up to 16 384 slices each: while the sort works on one piece of the batch, the parse and the encoder of
+        // the previous piece run beside it on the context's second stream.  Per slice the search arrays hold 65 536 positions (26 bytes
+        // each: srt, sb, wr, symbol) -- for a context of longer slices too, whose slices go through in segments of one 64 KiB span
+        // (deflate_lazy.h; 28 bytes with the ranks, which cannot sit in the symbol array there), plus 4 bytes per position of the whole slice for the symbols.
         u32 const pos_cap = ((c->max_slice_bytes < 65536u ? 65536u : c->max_slice_bytes) + 63u) & ~63u;
+        bool const lng = pos_cap > 65536u;
+        size_t const span = 65536u;
         u32 cap = c->knob.dfl_chunk ? c->knob.dfl_chunk : 16384u;
-        if ((u64)cap * pos_cap > (1ull << 30)) cap = (u32)((1ull << 30) / pos_cap);
+        size_t const per_slot = span * (sizeof(u16) + 2 * sizeof(KdBest) + sizeof(u32) + (lng ? sizeof(u16) : 0)) + (lng ? (size_t)pos_cap * sizeof(u32) : 0);
+        if (lng && (u64)cap * per_slot > (12ull << 30)) cap = (u32)((12ull << 30) / per_slot);          // 12 GiB a half
         if (cap < 1) cap = 1;
         u32 const chunk = c->max_slices < cap ? c->max_slices : cap;
         c->dfl_pos_cap = pos_cap; c->dfl_blk_cap = pos_cap / (KD_LIT_BUFSIZE - 1) + 2u;
-        HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)2 * chunk * pos_cap * sizeof(u16)));
-        // (slices up to 64 KiB: deflate_lazy.h keeps 16 bytes per position where the older kernels keep a KdBest of 8)
-        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * chunk * pos_cap * sizeof(KdBest) * (pos_cap <= 65536u ? 2u : 1u)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)2 * chunk * span * sizeof(u16)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * chunk * span * sizeof(KdBest) * 2u));
         HIP_TRY(hipMalloc((void**)&c->dfl_syms, (size_t)2 * chunk * pos_cap * sizeof(u32)));
-        if (pos_cap <= 65536u) HIP_TRY(hipMalloc((void**)&c->dfl_wr, (size_t)2 * chunk * pos_cap * sizeof(u32)));       // (deflate_lazy.h: where / rank of every position)
-        if (pos_cap <= 65536u) HIP_TRY(hipMalloc((void**)&c->dfl_order, ((size_t)2 * (2 * chunk + 256)) * sizeof(u32)));  // (per half: cost classes, their histogram, the slices in order)
+        HIP_TRY(hipMalloc((void**)&c->dfl_wr, (size_t)2 * chunk * span * sizeof(u32)));       // (deflate_lazy.h: where / rank of every position)
+        HIP_TRY(hipMalloc((void**)&c->dfl_order, ((size_t)2 * (2 * chunk + 256)) * sizeof(u32)));  // (per half: cost classes, their histogram, the slices in order)
+        if (lng) {
+            HIP_TRY(hipMalloc((void**)&c->dfl_rank, (size_t)2 * chunk * span * sizeof(u16)));
+            HIP_TRY(hipMalloc((void**)&c->dfl_state, (size_t)2 * chunk * KDL_STATE_WORDS * sizeof(u32)));
+            HIP_TRY(hipMalloc((void**)&c->dfl_maxlen, 64));
+        }
         HIP_TRY(hipMalloc((void**)&c->dfl_meta, (size_t)2 * chunk * sizeof(KdSliceMeta)));
         HIP_TRY(hipMalloc((void**)&c->dfl_blocks, (size_t)2 * chunk * c->dfl_blk_cap * sizeof(KdBlockInfo)));
         for (int i = 0; i < 2; i++) {
@@ -205,7 +224,7 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
         bool const wide = c->dfl_fsyms && c->dfl_fmeta && c->dfl_fblocks;
         u32 span = (wide ? 4u : 2u) * c->dfl_chunk;
         {   // the head table of a slice has 1 << (memLevel + 7) entries, its prev table 32 768: as many slices at a time as the workspace holds
-            size_t const ws = (size_t)2 * c->dfl_chunk * c->dfl_pos_cap * sizeof(KdBest) * (c->dfl_pos_cap <= 65536u ? 2u : 1u);
+            size_t const ws = (size_t)2 * c->dfl_chunk * 65536u * sizeof(KdBest) * 2u;
             size_t const per = ((size_t)(1u << ((mem_level > 9 ? 9 : mem_level) + 7)) + KD_WSIZE) * sizeof(u32);
             if ((size_t)span * per > ws) span = (u32)(ws / per);
             if (span < 1) { g_last_error = "kmp_deflate_compress_batch: workspace too small for this memLevel"; return KMP_ERR_CAPACITY; }
@@ -228,6 +247,47 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
             if (prof) HIP_TRY(hipEventRecord(c->ev[12], st));
             HIP_TRY(hipGetLastError());
         }
+        if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[7], st)); c->ev_valid[3] = 1; }
+        return batch_end(c, st, d_in_len, n, dfl_cap, d_out_len, nullptr);
+    }
+    if (c->dfl_pos_cap > 65536u) {
+        // Slices above 64 KiB: segment by segment (deflate_lazy.h).  The longest slice of the batch says how many launches there are; the
+        // two halves of the workspace take alternate pieces, each on its own stream from its first sort to its encoder.
+        u32 maxlen = 0;
+        HIP_TRY(hipMemsetAsync(c->dfl_maxlen, 0, sizeof(u32), st));
+        hipLaunchKernelGGL(k_max_len, dim3((n + 255) / 256), dim3(256), 0, st, c->len_ok, n, c->dfl_maxlen);
+        HIP_TRY(hipMemcpyAsync(&maxlen, c->dfl_maxlen, sizeof(u32), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        u32 const segs = maxlen <= KDL_SEG_SPAN ? 1u : (maxlen - KDL_SEG_SPAN + KDL_SEG_STEP - 1u) / KDL_SEG_STEP + 1u;
+        if (!serial) { HIP_TRY(hipEventRecord(c->dfl_searched[0], st)); HIP_TRY(hipStreamWaitEvent(c->st2, c->dfl_searched[0], 0)); }
+        for (u32 first = 0; first < n; first += c->dfl_chunk, piece++) {
+            u32 const m = (n - first < c->dfl_chunk) ? n - first : c->dfl_chunk;
+            u32 const h = piece & 1u;
+            hipStream_t const sx = (h == 0 || serial) ? st : c->st2;
+            size_t const half = (size_t)h * c->dfl_chunk;
+            KdArgs a;
+            a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = c->len_ok + first; a.n_slices = m;
+            a.pos_cap = c->dfl_pos_cap; a.blk_cap = c->dfl_blk_cap;
+            a.link = c->dfl_link + half * 65536u; a.best = c->dfl_best + half * 65536u * 2u; a.wr = c->dfl_wr + half * 65536u;
+            a.seg_rank = c->dfl_rank + half * 65536u; a.seg_state = c->dfl_state + half * KDL_STATE_WORDS;
+            a.syms = c->dfl_syms + half * c->dfl_pos_cap; a.meta = c->dfl_meta + half; a.blocks = c->dfl_blocks + half * c->dfl_blk_cap;
+            a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
+            kd_level_config(a, level, window_bits, mem_level);
+            bool const prof = c->profiling && first == 0;
+            if (prof) { HIP_TRY(hipEventRecord(c->ev[8], sx)); HIP_TRY(hipEventRecord(c->ev[9], sx)); HIP_TRY(hipEventRecord(c->ev[10], sx)); HIP_TRY(hipEventRecord(c->ev[13], sx)); }
+            for (u32 seg = 0; seg < segs; seg++) {
+                a.seg = seg;
+                if (a.hmask > 0x7FFFu) hipLaunchKernelGGL(k_deflate_sort_seg_wide, dim3(m), dim3(256), 0, sx, a);
+                else hipLaunchKernelGGL(k_deflate_sort_seg, dim3(m), dim3(256), 0, sx, a);
+                hipLaunchKernelGGL(k_deflate_lazy_seg, dim3(m), dim3(64), 0, sx, a);
+            }
+            if (prof) HIP_TRY(hipEventRecord(c->ev[11], sx));
+            hipLaunchKernelGGL(k_deflate_encode, dim3(m), dim3(64), 0, sx, a);
+            if (prof) HIP_TRY(hipEventRecord(c->ev[12], sx));
+            HIP_TRY(hipGetLastError());
+            if (!serial) HIP_TRY(hipEventRecord(c->dfl_done[h], sx));
+        }
+        if (!serial && piece >= 2) HIP_TRY(hipStreamWaitEvent(st, c->dfl_done[1], 0));       // (a single piece ran on the caller's stream alone)
         if (c->profiling) { HIP_TRY(hipEventRecord(c->ev[7], st)); c->ev_valid[3] = 1; }
         return batch_end(c, st, d_in_len, n, dfl_cap, d_out_len, nullptr);
     }
@@ -266,7 +326,8 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
         if (!serial) { HIP_TRY(hipEventRecord(c->dfl_searched[h], st)); HIP_TRY(hipStreamWaitEvent(s2, c->dfl_searched[h], 0)); }
         if (prof) HIP_TRY(hipEventRecord(c->ev[13], s2));
         if (lazy2) hipLaunchKernelGGL(k_deflate_lazy, dim3(m), dim3(64), 0, s2, a);
-        else hipLaunchKernelGGL(k_deflate_parse, dim3((m + 63) / 64), dim3(64), 0, s2, a);
+        else if (KMP_KNOB("KMP_DEFLATE_LANE_PARSE", 0)) hipLaunchKernelGGL(k_deflate_parse, dim3((m + 63) / 64), dim3(64), 0, s2, a);
+        else hipLaunchKernelGGL(k_deflate_parse_wave, dim3(m), dim3(64), 0, s2, a);
         if (prof) HIP_TRY(hipEventRecord(c->ev[11], s2));
         // (the encoder on a third stream, beside the next piece's parse, was measured: 699 ms per 65 536 slices against 652 -- three
         // kernels at once stretch each other; it stays behind its piece's parse)

@@ -510,11 +510,28 @@ int emu_deflate_params(const u8* src, const u64* in_off, const u32* in_len, u32 
     }
     // slices up to 64 KiB: the sort + wave-wide lazy parse of deflate_lazy.h (what the product runs there), unless the caller wants the
     // chain links / per-position records of the older kernels back (link_out / best_out) -- the tests keep both pipelines honest
+    if (pos_cap > 65536u && !link_out && !best_out && !old_kernels) {
+        // slices above 64 KiB: segment by segment, as deflate_batch_impl does (the search arrays hold one 64 KiB span per slice)
+        std::vector<u16> rankv((size_t)n * 65536u, 0xBBBB);
+        std::vector<u32> statev((size_t)n * KDL_STATE_WORDS, 0xAAAAAAAAu);
+        a.seg_rank = rankv.data(); a.seg_state = statev.data();
+        u32 const segs = (maxlen - KDL_SEG_SPAN + KDL_SEG_STEP - 1u) / KDL_SEG_STEP + 1u;
+        for (u32 seg = 0; seg < segs; seg++) {
+            a.seg = seg;
+            if (a.hmask > 0x7FFFu) kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_sort_body<16, true>(a); });
+            else kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_sort_body<15, true>(a); });
+            if (kxemu::failed) return -1;
+            kxemu::launch(n < 3 ? n : 3, [&]() { deflate_lazy_body<true>(a); });
+            if (kxemu::failed) return -3;
+        }
+        kxemu::launch(n < 3 ? n : 3, [&]() { deflate_encode_body(a); });
+        return kxemu::failed ? -4 : 0;
+    }
     if (pos_cap <= 65536u && !link_out && !best_out && !old_kernels) {
         if (a.hmask > 0x7FFFu) kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_sort_body<16>(a); });
         else kxemu::launch_block(n < 2 ? n : 2, 4, [&]() { deflate_sort_body<15>(a); });
         if (kxemu::failed) return -1;
-        kxemu::launch(n < 3 ? n : 3, [&]() { deflate_lazy_body(a); });
+        kxemu::launch(n < 3 ? n : 3, [&]() { deflate_lazy_body<false>(a); });
         if (kxemu::failed) return -3;
         kxemu::launch(n < 3 ? n : 3, [&]() { deflate_encode_body(a); });
         return kxemu::failed ? -4 : 0;
@@ -524,7 +541,9 @@ int emu_deflate_params(const u8* src, const u64* in_off, const u32* in_len, u32 
     if (kxemu::failed) return -1;
     kxemu::launch_block(n < 2 ? n : 2, 16, [&]() { deflate_best_body(a); });
     if (kxemu::failed) return -2;
-    kxemu::launch((n + 63) / 64, [&]() { deflate_parse_body(a); });
+    // the parse over the records: a wave per slice (what the product runs), or the earlier lane per slice (old_kernels == 2)
+    if (old_kernels == 2) kxemu::launch((n + 63) / 64, [&]() { deflate_parse_body(a); });
+    else kxemu::launch(n < 3 ? n : 3, [&]() { deflate_parse_wave_body(a); });
     if (kxemu::failed) return -3;
     kxemu::launch(n < 3 ? n : 3, [&]() { deflate_encode_body(a); });
     if (kxemu::failed) return -4;

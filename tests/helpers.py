@@ -669,7 +669,7 @@ def emu_deflate(datas, zlib_wrapper=False, fmt=None, level=6, window_bits=15, me
     ooff = np.arange(n, dtype=np.uint64) * stride
     olen = np.zeros(n, dtype=np.uint32)
     r = emu().emu_deflate_params(_vp(buf), _vp(offs), _vp(lens), n, _vp(out), _vp(ooff), _vp(olen), None, None, fmt if fmt is not None else (1 if zlib_wrapper else 0), level,
-                                 window_bits, mem_level, 1 if old_kernels else 0)
+                                 window_bits, mem_level, int(old_kernels))
     assert r == 0, f"emulator reported {r}"
     return [out[i * stride:i * stride + int(olen[i])].tobytes() for i in range(n)]
 

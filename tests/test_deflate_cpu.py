@@ -219,9 +219,23 @@ def test_long_slices_oracle_and_emulated_kernels_match_zlib():
         assert len(f) == r["len"] and helpers.sha256(f) == r["sha256"], ("oracle", name)
         if zlib.ZLIB_RUNTIME_VERSION == G["zlib"]:
             assert f == raw6(d), name
+    # what the product runs above 64 KiB: the sort + wave-wide parse kernels segment by segment (deflate_lazy.h: a 64 KiB span per launch,
+    # the parse's state carried from one segment to the next)
     outs = helpers.emu_deflate([d for _, d in inputs])
     for (name, d), f in zip(inputs, outs):
         assert len(f) == rows[name]["len"] and helpers.sha256(f) == rows[name]["sha256"], ("kernels", name)
+    # lengths on both sides of the segments' ends (a span ends every 32 KiB; the last one may hold a few bytes, or none that enter a chain)
+    edge = corpus.make(515, 1, 140000, mix=ord("X")).tobytes()
+    cuts = [edge[:k] for k in (65537, 65539, 98303, 98304, 98305, 98307, 131071, 131072, 131074)]
+    for d, f in zip(cuts, helpers.emu_deflate(cuts, level=5, window_bits=14, mem_level=9)):
+        c = zlib.compressobj(5, zlib.DEFLATED, -14, 9, 0)
+        assert f == c.compress(d) + c.flush(), len(d)
+    # the older kernels (chain links, all-positions search, the parse over its records as a wave and as a lane per slice): ablation
+    # build only since the segments, kept honest here on two of the inputs
+    small_long = sorted(inputs, key=lambda x: len(x[1]))[:2]
+    for old in (1, 2):
+        for (name, d), f in zip(small_long, helpers.emu_deflate([d for _, d in small_long], old_kernels=old)):
+            assert len(f) == rows[name]["len"] and helpers.sha256(f) == rows[name]["sha256"], ("older kernels", old, name)
     # the wrappers' checksums run over the whole slice
     d = inputs[5][1]
     assert helpers.emu_deflate([d], fmt=1)[0] == zlib.compress(d, 6)

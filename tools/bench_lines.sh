@@ -36,6 +36,8 @@ run --slice-kib 1024 --slices 8192 --level 1 --steps 2 --warmup 1 --no-cpu --no-
 run --mode deflate --deflate-level 4 --steps 2 --warmup 1 --no-cpu
 run --mode deflate --deflate-level 1 --steps 2 --warmup 1 --no-cpu
 run --mode deflate --deflate-level 9 --steps 1 --warmup 1 --no-cpu
+run --mode deflate --slice-kib 256 --slices 8192 --steps 2 --warmup 1 --no-cpu
+run --mode deflate --slice-kib 1024 --slices 2048 --steps 2 --warmup 1 --no-cpu
 run --mode deflate --deflate-window-bits 12 --deflate-mem-level 5 --steps 2 --warmup 1 --slices 16384
 run --mode deflate --deflate-level 1 --deflate-window-bits 9 --deflate-mem-level 9 --steps 2 --warmup 1 --slices 16384 --no-cpu
 run --mode decompress --slice-kib 256 --slices 16384 --steps 3 --warmup 1 --no-cpu
