@@ -221,8 +221,9 @@ def test_long_slices_oracle_and_emulated_kernels_match_zlib():
             assert f == raw6(d), name
     # what the product runs above 64 KiB: the sort + wave-wide parse kernels segment by segment (deflate_lazy.h: a 64 KiB span per launch,
     # the parse's state carried from one segment to the next)
-    outs = helpers.emu_deflate([d for _, d in inputs])
-    for (name, d), f in zip(inputs, outs):
+    emu_in = [(name, d) for name, d in inputs if name not in ("long_300001", "long_777777", "long_1048576", "zeros_1m")]      # (the CPU suite's time; the GPU suite runs all twelve)
+    outs = helpers.emu_deflate([d for _, d in emu_in])
+    for (name, d), f in zip(emu_in, outs):
         assert len(f) == rows[name]["len"] and helpers.sha256(f) == rows[name]["sha256"], ("kernels", name)
     # lengths on both sides of the segments' ends (a span ends every 32 KiB; the last one may hold a few bytes, or none that enter a chain)
     edge = corpus.make(515, 1, 140000, mix=ord("X")).tobytes()
