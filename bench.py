@@ -692,7 +692,7 @@ def main():
         algo_piece = (n * SLICE + int(lens.sum()) + 16 * n) * piece // n
         traffic_best = None
         try:
-            traffic_best = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("k_deflate_lazy_hbm_bytes_per_launch") if piece == 16384 else None
+            traffic_best = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("k_deflate_lazy_hbm_bytes_per_launch") if (piece == 16384 and (dlevel, dwb, dml, SLICE) == (6, 15, 8, 65536)) else None          # (the counters were collected at configs[4]'s settings)
         except Exception:
             traffic_best = None
         ms_best = float(kms.get("parse", 0.0)) or 1.0
