@@ -309,7 +309,8 @@ KMP_API int kmp_zstd_decompress_batch_dict(kmp_batch_ctx* ctx,
  * them: the batched form of deflateInit2(6, Z_DEFLATED, -15, 8, 0) + deflate(Z_FINISH)
  * (reference: kompressor-zlib--nativelib/src/jvmCommonMain/jni/Wrapper.cpp:20,73; Kotlin
  * ZlibCompressor(ZlibFormat.Raw, 6)).  Slices up to the context's max_slice_bytes (64 KiB at least; above 64 KiB zlib's
- * 32 KiB window slides: positions are 32-bit, candidates are kept as distances); stream i goes to
+ * 32 KiB window slides, and a context made for such slices takes them through its kernels in 64 KiB spans: the call then waits
+ * once on hip_stream, to read the batch's longest slice back, before it enqueues the rest); stream i goes to
  * d_dst + d_out_off[i] (room for kmp_deflate_bound(len), which covers all three formats: stored blocks of 5 + n
  * bytes per 65 535, the 18 bytes of a gzip header and trailer), its size to d_out_len[i]. */
 KMP_API size_t kmp_deflate_bound(size_t src_size);

@@ -275,6 +275,7 @@ extern "C" int kmp_zlib_compress_stream(kmp_zlib_cstream* z, void* dst, size_t d
         size_t const room = (wb == 15 && z->mem_level == 8) ? z->in.size() : kmp_deflate_bound_params(z->in.size(), wb, z->mem_level);
         if (!stream_dev_select(z->dev) || stream_dev_init(z->dev, room)) return Z_MEM_ERROR_;
         stream_dev& s = z->dev;
+        if (kmp_deflate_bound_params(z->in.size(), wb, z->mem_level) > s.out_cap) return Z_MEM_ERROR_;      // (the largest tier holds 1 GiB and an eighth more only for less)
         u64 offs[2] = { 0, 0 }; u32 len = (u32)z->in.size(), olen = 0;
         if (len && hipMemcpy(s.d_in, z->in.data(), len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
         if (hipMemcpy(s.d_off, offs, sizeof(offs), hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR_;
