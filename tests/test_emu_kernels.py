@@ -476,11 +476,12 @@ def test_decoders_survive_mutated_input(which):
     assert r.returncode == 0 and ("FUZZ OK" in r.stdout or "FUZZ SKIP" in r.stdout), r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("which", ["zstd", "zstd-split-phase", "zstd-fused", "l1", "neg", "l4", "deflate"])
+@pytest.mark.parametrize("which", ["zstd", "zstd-split-phase", "zstd-fused", "l1", "neg", "l4", "deflate", "deflatep"])
 def test_compressors_stay_inside_their_buffers(which):
     """tests/guard_pages_compress.py --quick: slices that end exactly at an unmapped page, outputs bounded by
     kmp_zstd_compress_bound + 1024: the compressor kernel bodies read and write nothing outside (the split-phase parser
-    with its 16-byte looks at candidates and its window refills included; the fused kernel; level -3; level 4)."""
+    with its 16-byte looks at candidates and its window refills included; the fused kernel; level -3; level 4; DEFLATE at random
+    windowBits / memLevel with the output ending at kmp_deflate_bound_params' room, a slice above 64 KiB in spans)."""
     import os
     import subprocess
     import sys
