@@ -700,7 +700,12 @@ def main():
                         "achieved": round(algo_piece / (ms_best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(algo_piece / (ms_best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic_best,
                         "slices_per_launch": piece, "avg_launch_ms": round(ms_best, 3)}
-        if dlevel > 3:
+        if dlevel > 3 and SLICE > 65536:
+            # slices above 64 KiB: the two kernels run once per 64 KiB span (kmp_deflate.hip); the events bracket all of a piece's launches
+            segs = (SLICE - 65536 + 32767) // 32768 + 1
+            dfl_roofline["kernel"] = f"k_deflate_sort_seg + k_deflate_lazy_seg, the {segs} + {segs} launches of the first piece (64 KiB spans; the other piece's run beside them)"
+            kms = {f"k_deflate_sort_seg + k_deflate_lazy_seg x {segs}": kms["parse"], "k_deflate_encode": kms["encode"]}
+        elif dlevel > 3:
             kms = {"k_deflate_sort (+ heaviest-first order)": kms["prepare"], "k_deflate_lazy": kms["parse"], "k_deflate_encode": kms["encode"]}
         if dlevel <= 3:
             # levels 1 .. 3: one k_deflate_fast launch over the whole batch (its time is reported in the parse slot of the events)

@@ -17,6 +17,8 @@ run level1 --level 1 --steps 3 --warmup 1 --no-cpu &&
 run level7 --level 7 --slices 16384 --steps 2 --warmup 1 --no-cpu &&
 run dict_trained --dict-kib 64 --dict-trained --slice-kib 8 --slices 262144 --steps 3 --warmup 1 --no-cpu &&
 run deflate1 --mode deflate --deflate-level 1 --steps 1 --warmup 0 --no-cpu &&
+run deflate256k --mode deflate --slice-kib 256 --slices 8192 --steps 2 --warmup 1 --no-cpu &&
+run deflate_w12m5 --mode deflate --deflate-window-bits 12 --deflate-mem-level 5 --slices 16384 --steps 2 --warmup 1 --no-cpu &&
 run inflate --mode inflate --steps 3 --warmup 1 --no-cpu &&
 for ctr in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_INST_ANY" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   d=$O/pmc_$(echo $ctr | tr ' ' '_' | cut -c1-40)

@@ -47,6 +47,8 @@ def main():
             ("level7", "python3 bench.py --level 7 --slices 16384 --steps 2 --warmup 1 --no-cpu   (16 384 x 64 KiB at level 7: libzstd's lazy2 parse over its row-based match finder, zstd_lazy.h)"),
             ("dict_trained", "python3 bench.py --dict-kib 64 --dict-trained --slice-kib 8 --slices 262144 --steps 3 --warmup 1 --no-cpu   (8 KiB records with a 64 KiB dictionary trained by the box's ZDICT)"),
             ("deflate1", "python3 bench.py --mode deflate --deflate-level 1 --steps 1 --warmup 0 --no-cpu   (raw DEFLATE level 1 = deflate_fast: one k_deflate_fast launch over the batch, then the shared encoder)"),
+            ("deflate256k", "python3 bench.py --mode deflate --slice-kib 256 --slices 8192 --steps 2 --warmup 1 --no-cpu   (raw DEFLATE level 6 on 256 KiB slices: the sort + parse kernels in 64 KiB spans, 7 + 7 launches a piece)"),
+            ("deflate_w12m5", "python3 bench.py --mode deflate --deflate-window-bits 12 --deflate-mem-level 5 --slices 16384 --steps 2 --warmup 1 --no-cpu   (deflateInit2's windowBits 12, memLevel 5)"),
             ("inflate", "python3 bench.py --mode inflate --steps 3 --warmup 1 --no-cpu   (ZlibDecompressor over the 65 536 level-6 streams of configs[4]; the streams are made first)")]
     for key, cmd in runs:
         db = os.path.join(P, key, "run_results.db")
