@@ -535,6 +535,7 @@ extern "C" void kmp_batch_destroy(kmp_batch_ctx* c)
     if (c->st2) (void)hipStreamDestroy(c->st2);
     (void)hipFree(c->dfl_wr); (void)hipFree(c->dfl_order); (void)hipFree(c->dfl_link); (void)hipFree(c->dfl_best); (void)hipFree(c->dfl_syms); (void)hipFree(c->dfl_meta); (void)hipFree(c->dfl_blocks);
     (void)hipFree(c->dfl_fsyms); (void)hipFree(c->dfl_fmeta); (void)hipFree(c->dfl_fblocks); (void)hipFree(c->dfl_rank); (void)hipFree(c->dfl_state); (void)hipFree(c->dfl_maxlen);
+    if (c->dfl_seg_sync) for (int i = 0; i < 2; i++) { (void)hipStreamDestroy(c->dfl_sort_st[i]); for (int k = 0; k < 2; k++) { (void)hipEventDestroy(c->dfl_sorted[i][k]); (void)hipEventDestroy(c->dfl_parsed[i][k]); } }
     if (c->dfl_events) for (int i = 0; i < 2; i++) { (void)hipEventDestroy(c->dfl_searched[i]); (void)hipEventDestroy(c->dfl_done[i]); }
     delete c;
 }
@@ -560,7 +561,7 @@ extern "C" int kmp_batch_memory(kmp_batch_ctx* c, kmp_batch_memory_info* info)
     if (c->pre_lits) m.decode_staging += (size_t)c->pre_slices * c->pre_lit_cap + (size_t)c->pre_slices * c->pre_blk_cap * sizeof(KPreLit) + (size_t)c->pre_slices * 4u;
     if (c->dfl_link) {
         size_t const span = c->dfl_pos_cap > 65536u ? 65536u : c->dfl_pos_cap;          // (above 64 KiB the search arrays hold one 64 KiB span per slice: kmp_deflate.hip)
-        m.deflate_workspace += (size_t)2 * c->dfl_chunk * (span * (sizeof(u16) + sizeof(KdBest) * 2u + sizeof(u32) + (c->dfl_rank ? sizeof(u16) : 0)) + (size_t)c->dfl_pos_cap * sizeof(u32)
+        m.deflate_workspace += (size_t)2 * c->dfl_chunk * (span * ((c->dfl_rank ? 2u : 1u) * (sizeof(u16) + sizeof(KdBest) * 2u + sizeof(u32)) + (c->dfl_rank ? sizeof(u16) : 0)) + (size_t)c->dfl_pos_cap * sizeof(u32)
                                                             + sizeof(KdSliceMeta) + (size_t)c->dfl_blk_cap * sizeof(KdBlockInfo));
     }
     if (c->dfl_fsyms) m.deflate_workspace += (size_t)4 * c->dfl_chunk * ((size_t)c->dfl_pos_cap * sizeof(u32) + sizeof(KdSliceMeta) + (size_t)c->dfl_blk_cap * sizeof(KdBlockInfo));

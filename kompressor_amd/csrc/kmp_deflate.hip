@@ -162,20 +162,27 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
         bool const lng = pos_cap > 65536u;
         size_t const span = 65536u;
         u32 cap = c->knob.dfl_chunk ? c->knob.dfl_chunk : 16384u;
-        size_t const per_slot = span * (sizeof(u16) + 2 * sizeof(KdBest) + sizeof(u32) + (lng ? sizeof(u16) : 0)) + (lng ? (size_t)pos_cap * sizeof(u32) : 0);
-        if (lng && (u64)cap * per_slot > (12ull << 30)) cap = (u32)((12ull << 30) / per_slot);          // 12 GiB a half
+        // (above 64 KiB the span arrays exist twice: the sort of segment k + 1 fills one copy while the parse of segment k reads the other)
+        size_t const copies = lng ? 2u : 1u;
+        size_t const per_slot = span * (copies * (sizeof(u16) + 2 * sizeof(KdBest) + sizeof(u32)) + (lng ? sizeof(u16) : 0)) + (lng ? (size_t)pos_cap * sizeof(u32) : 0);
+        if (lng && (u64)cap * per_slot > (16ull << 30)) cap = (u32)((16ull << 30) / per_slot);          // 16 GiB a half
         if (cap < 1) cap = 1;
         u32 const chunk = c->max_slices < cap ? c->max_slices : cap;
         c->dfl_pos_cap = pos_cap; c->dfl_blk_cap = pos_cap / (KD_LIT_BUFSIZE - 1) + 2u;
-        HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)2 * chunk * span * sizeof(u16)));
-        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * chunk * span * sizeof(KdBest) * 2u));
+        HIP_TRY(hipMalloc((void**)&c->dfl_link, (size_t)2 * copies * chunk * span * sizeof(u16)));
+        HIP_TRY(hipMalloc((void**)&c->dfl_best, (size_t)2 * copies * chunk * span * sizeof(KdBest) * 2u));
         HIP_TRY(hipMalloc((void**)&c->dfl_syms, (size_t)2 * chunk * pos_cap * sizeof(u32)));
-        HIP_TRY(hipMalloc((void**)&c->dfl_wr, (size_t)2 * chunk * span * sizeof(u32)));       // (deflate_lazy.h: where / rank of every position)
+        HIP_TRY(hipMalloc((void**)&c->dfl_wr, (size_t)2 * copies * chunk * span * sizeof(u32)));       // (deflate_lazy.h: where / rank of every position)
         HIP_TRY(hipMalloc((void**)&c->dfl_order, ((size_t)2 * (2 * chunk + 256)) * sizeof(u32)));  // (per half: cost classes, their histogram, the slices in order)
         if (lng) {
             HIP_TRY(hipMalloc((void**)&c->dfl_rank, (size_t)2 * chunk * span * sizeof(u16)));
             HIP_TRY(hipMalloc((void**)&c->dfl_state, (size_t)2 * chunk * KDL_STATE_WORDS * sizeof(u32)));
             HIP_TRY(hipMalloc((void**)&c->dfl_maxlen, 64));
+            for (int i = 0; i < 2; i++) {
+                HIP_TRY(hipStreamCreateWithFlags(&c->dfl_sort_st[i], hipStreamNonBlocking));
+                for (int k = 0; k < 2; k++) { HIP_TRY(hipEventCreateWithFlags(&c->dfl_sorted[i][k], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->dfl_parsed[i][k], hipEventDisableTiming)); }
+            }
+            c->dfl_seg_sync = 1;
         }
         HIP_TRY(hipMalloc((void**)&c->dfl_meta, (size_t)2 * chunk * sizeof(KdSliceMeta)));
         HIP_TRY(hipMalloc((void**)&c->dfl_blocks, (size_t)2 * chunk * c->dfl_blk_cap * sizeof(KdBlockInfo)));
@@ -224,7 +231,7 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
         bool const wide = c->dfl_fsyms && c->dfl_fmeta && c->dfl_fblocks;
         u32 span = (wide ? 4u : 2u) * c->dfl_chunk;
         {   // the head table of a slice has 1 << (memLevel + 7) entries, its prev table 32 768: as many slices at a time as the workspace holds
-            size_t const ws = (size_t)2 * c->dfl_chunk * 65536u * sizeof(KdBest) * 2u;
+            size_t const ws = (size_t)2 * (c->dfl_pos_cap > 65536u ? 2u : 1u) * c->dfl_chunk * 65536u * sizeof(KdBest) * 2u;
             size_t const per = ((size_t)(1u << ((mem_level > 9 ? 9 : mem_level) + 7)) + KD_WSIZE) * sizeof(u32);
             if ((size_t)span * per > ws) span = (u32)(ws / per);
             if (span < 1) { g_last_error = "kmp_deflate_compress_batch: workspace too small for this memLevel"; return KMP_ERR_CAPACITY; }
@@ -259,27 +266,42 @@ int deflate_batch_impl(kmp_batch_ctx* c, const void* d_src, const uint64_t* d_in
         HIP_TRY(hipMemcpyAsync(&maxlen, c->dfl_maxlen, sizeof(u32), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         u32 const segs = maxlen <= KDL_SEG_SPAN ? 1u : (maxlen - KDL_SEG_SPAN + KDL_SEG_STEP - 1u) / KDL_SEG_STEP + 1u;
-        if (!serial) { HIP_TRY(hipEventRecord(c->dfl_searched[0], st)); HIP_TRY(hipStreamWaitEvent(c->st2, c->dfl_searched[0], 0)); }
+        // Per half: a parse stream (the caller's for half 0, the context's second one for half 1) and a sort stream.  The span arrays exist in
+        // two copies, taken by the parity of the segment: sort(k + 1) runs beside parse(k) -- it waits for parse(k - 1), the last reader
+        // of its copy --, parse(k) waits for sort(k).  The sort leaves a piece's critical path (it was a third of a segment).
+        if (!serial) {
+            HIP_TRY(hipEventRecord(c->dfl_searched[0], st));
+            HIP_TRY(hipStreamWaitEvent(c->st2, c->dfl_searched[0], 0));
+            for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(c->dfl_sort_st[i], c->dfl_searched[0], 0));
+        }
+        size_t const span_slots = (size_t)c->dfl_chunk * 65536u;
         for (u32 first = 0; first < n; first += c->dfl_chunk, piece++) {
             u32 const m = (n - first < c->dfl_chunk) ? n - first : c->dfl_chunk;
             u32 const h = piece & 1u;
-            hipStream_t const sx = (h == 0 || serial) ? st : c->st2;
+            hipStream_t const sx = (h == 0 || serial) ? st : c->st2;              // parse + encode
+            hipStream_t const ss = serial ? sx : c->dfl_sort_st[h];               // sort
             size_t const half = (size_t)h * c->dfl_chunk;
             KdArgs a;
             a.src = (const u8*)d_src; a.in_off = d_in_off + first; a.in_len = c->len_ok + first; a.n_slices = m;
             a.pos_cap = c->dfl_pos_cap; a.blk_cap = c->dfl_blk_cap;
-            a.link = c->dfl_link + half * 65536u; a.best = c->dfl_best + half * 65536u * 2u; a.wr = c->dfl_wr + half * 65536u;
             a.seg_rank = c->dfl_rank + half * 65536u; a.seg_state = c->dfl_state + half * KDL_STATE_WORDS;
             a.syms = c->dfl_syms + half * c->dfl_pos_cap; a.meta = c->dfl_meta + half; a.blocks = c->dfl_blocks + half * c->dfl_blk_cap;
             a.dst = (u8*)d_dst; a.out_off = d_out_off + first; a.out_len = d_out_len + first; a.flags = c->knob.dfl_flags; a.format = format;
             kd_level_config(a, level, window_bits, mem_level);
             bool const prof = c->profiling && first == 0;
             if (prof) { HIP_TRY(hipEventRecord(c->ev[8], sx)); HIP_TRY(hipEventRecord(c->ev[9], sx)); HIP_TRY(hipEventRecord(c->ev[10], sx)); HIP_TRY(hipEventRecord(c->ev[13], sx)); }
+            if (!serial && piece >= 2) for (int k = 0; k < 2; k++) HIP_TRY(hipStreamWaitEvent(ss, c->dfl_parsed[h][k], 0));     // the previous piece of this half has read its spans
             for (u32 seg = 0; seg < segs; seg++) {
+                u32 const par = seg & 1u;
+                size_t const copy = ((size_t)h * 2u + par) * span_slots;          // this half's copy of that parity
                 a.seg = seg;
-                if (a.hmask > 0x7FFFu) hipLaunchKernelGGL(k_deflate_sort_seg_wide, dim3(m), dim3(256), 0, sx, a);
-                else hipLaunchKernelGGL(k_deflate_sort_seg, dim3(m), dim3(256), 0, sx, a);
+                a.link = c->dfl_link + copy; a.best = c->dfl_best + copy * 2u; a.wr = c->dfl_wr + copy;
+                if (!serial && seg >= 2) HIP_TRY(hipStreamWaitEvent(ss, c->dfl_parsed[h][par], 0));
+                if (a.hmask > 0x7FFFu) hipLaunchKernelGGL(k_deflate_sort_seg_wide, dim3(m), dim3(256), 0, ss, a);
+                else hipLaunchKernelGGL(k_deflate_sort_seg, dim3(m), dim3(256), 0, ss, a);
+                if (!serial) { HIP_TRY(hipEventRecord(c->dfl_sorted[h][par], ss)); HIP_TRY(hipStreamWaitEvent(sx, c->dfl_sorted[h][par], 0)); }
                 hipLaunchKernelGGL(k_deflate_lazy_seg, dim3(m), dim3(64), 0, sx, a);
+                if (!serial) HIP_TRY(hipEventRecord(c->dfl_parsed[h][par], sx));
             }
             if (prof) HIP_TRY(hipEventRecord(c->ev[11], sx));
             hipLaunchKernelGGL(k_deflate_encode, dim3(m), dim3(64), 0, sx, a);

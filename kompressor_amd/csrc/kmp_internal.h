@@ -71,6 +71,7 @@ struct kmp_batch_ctx {
     // raw-deflate workspace, allocated on first use, for dfl_chunk slices at a time
     u32 dfl_chunk; u16* dfl_link; KdBest* dfl_best; u32* dfl_syms; KdSliceMeta* dfl_meta; u32* dfl_wr; u32* dfl_order;      // two halves of dfl_chunk slices each
     u32* dfl_fsyms; KdSliceMeta* dfl_fmeta; KdBlockInfo* dfl_fblocks; int dfl_ftried;          // levels 1 .. 3: symbols / blocks of 4 * dfl_chunk slices (one piece)
+    hipStream_t dfl_sort_st[2]; hipEvent_t dfl_sorted[2][2], dfl_parsed[2][2]; int dfl_seg_sync;   // ... a sort stream per workspace half; span arrays in two copies (parity of the segment): sorted / parsed events
     u16* dfl_rank; u32* dfl_state; u32* dfl_maxlen;                                             // slices above 64 KiB (deflate_lazy.h, segments): the sort's ranks, the parse's state between segments, the batch's longest slice
     u32 dfl_pos_cap, dfl_blk_cap; KdBlockInfo* dfl_blocks;                                      // positions / blocks per slice in them
     hipEvent_t dfl_searched[2], dfl_done[2]; int dfl_events;

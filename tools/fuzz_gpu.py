@@ -184,7 +184,7 @@ for level in ((1, 6, 9) if seed % 2 else (2, 3, 4, 5, 7, 8)):      # (odd seeds:
         i = int(dfl_idx[k]); assert oh[int(o2h[k]):int(o2h[k]) + int(lens[i])].tobytes() == host[offs[i]:offs[i] + lens[i]].tobytes(), ("inflate round trip", i)
     print(f"raw DEFLATE level {level}: {len(dfl_idx)} streams against zlib {zlib.ZLIB_RUNTIME_VERSION}, different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:8]]}  ({time.time() - t0:.0f} s)", flush=True)
 # deflateInit2's windowBits / memLevel: four random settings per seed, alternately on a context for slices up to 64 KiB (the sort + wave-wide
-# parse kernels) and on the one above (the older chain / search / parse kernels)
+# parse kernels) and on the one above (the same kernels, 64 KiB spans)
 import random as _random
 prng = _random.Random(seed * 7919 + 5)
 small_idx = np.array([i for i in dfl_idx if lens[i] <= 65536], dtype=np.int64)
@@ -202,7 +202,7 @@ for t in range(4):
     r = zlib_frames(level, idx_, wb, ml)
     bad = [i for i in idx_ if g[int(i)] != r[int(i)]]
     bad_total += len(bad)
-    print(f"raw DEFLATE level {level} windowBits {wb} memLevel {ml} ({'<= 64 KiB kernels' if t % 2 == 0 else 'older kernels'}): {len(idx_)} streams against zlib {zlib.ZLIB_RUNTIME_VERSION}, different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:8]]}  ({time.time() - t0:.0f} s)", flush=True)
+    print(f"raw DEFLATE level {level} windowBits {wb} memLevel {ml} ({'<= 64 KiB kernels' if t % 2 == 0 else 'a context for slices above 64 KiB: spans'}): {len(idx_)} streams against zlib {zlib.ZLIB_RUNTIME_VERSION}, different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:8]]}  ({time.time() - t0:.0f} s)", flush=True)
 bs.close()
 bd.close()
 print("FUZZ OK" if bad_total == 0 else f"FUZZ FOUND {bad_total} DIFFERENCES")

@@ -1,6 +1,6 @@
 """Differential fuzz of the DEFLATE kernels' settings on the GPU box: ragged slices of stress inputs (tools/fuzzgen.c) and corpus classes,
 random (level, windowBits, memLevel) per round, against this machine's zlib on the host cores -- slices up to 64 KiB on a context that
-runs the sort + wave-wide parse kernels, slices up to 400 KiB on one that runs the older chain / search / parse kernels (sizes near the
+runs the sort + wave-wide parse kernels, slices up to 400 KiB on one that takes them through the same kernels in 64 KiB spans (sizes near the
 ends of zlib's window buffer among them: k * w_size + 2 * w_size - 262 .. + 262, where fill_window slides at the end of the input).
 usage: python tools/fuzz_gpu_deflate.py [seed] [rounds] [slices per round]"""
 import ctypes, os, subprocess, sys, time, zlib
@@ -61,7 +61,7 @@ for r in range(rounds):
         for i, f in zip(ch, pa):
             if d[int(oo[i]):int(oo[i]) + int(ol[i])].tobytes() != f: bad.append(i)
     bad_total += len(bad)
-    print(f"round {r}: level {level} windowBits {wb} memLevel {ml} ({'older kernels, <= 400 000 bytes' if long_round else 'sort + parse kernels, <= 64 KiB'}): {n} streams against zlib {zlib.ZLIB_RUNTIME_VERSION}, "
+    print(f"round {r}: level {level} windowBits {wb} memLevel {ml} ({'slices up to 400 000 bytes: 64 KiB spans' if long_round else 'sort + parse kernels, <= 64 KiB'}): {n} streams against zlib {zlib.ZLIB_RUNTIME_VERSION}, "
           f"different: {len(bad)} {[(int(i), int(lens[i]), i % 4) for i in bad[:6]]}  ({time.time() - t0:.0f} s)", flush=True)
 small.close(); big.close()
 print("FUZZ OK" if bad_total == 0 else f"FUZZ FOUND {bad_total} DIFFERENCES")
