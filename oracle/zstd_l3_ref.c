@@ -916,6 +916,7 @@ static size_t lit_rle(u8* dst, size_t cap, const u8* src, size_t srcSize)
  * the block is emitted compressed).  hufValid = a table exists (repeatMode HUF_repeat_check). */
 typedef struct { huf_ctable ct; int valid; } kref_hufstate;
 
+static __thread int g_lit_strategy = 2;          /* (ZSTD_compressLiterals: preferRepeat = strategy < ZSTD_lazy ? srcSize <= 1024 : 0) */
 static size_t compress_literals(u8* dst, size_t cap, const u8* src, size_t srcSize, int suspectUncompressible,
                                 const kref_hufstate* prev, kref_hufstate* next)
 {
@@ -926,7 +927,7 @@ static size_t compress_literals(u8* dst, size_t cap, const u8* src, size_t srcSi
     if (srcSize < (prev->valid == 2 ? 6u : 64u)) return lit_raw(dst, cap, src, srcSize);   /* ZSTD_minLiteralsToCompress(fast / dfast, repeatMode) */
     if (cap < lhSize + 1) return KERR;
     cLitSize = huf_compress(dst + lhSize, cap - lhSize, src, srcSize, singleStream, suspectUncompressible,
-                            &next->ct, prev->valid, srcSize <= 1024 /* strategy < lazy */, &usedOld);
+                            &next->ct, prev->valid, g_lit_strategy < 4 ? srcSize <= 1024 : 0, &usedOld);
     if (usedOld) hType = 3;       /* set_repeat */
     {
         size_t const minGain = min_gain(srcSize);
@@ -1035,6 +1036,27 @@ static size_t cross_entropy_cost(const short* norm, u32 accuracyLog, const u32* 
     for (s = 0; s <= max; s++) { u32 const normAcc = (norm[s] != -1) ? (u32)norm[s] : 1; cost += count[s] * inv_prob_log256(normAcc << shift); }
     return cost >> 8;
 }
+/* the tables of the previous compressed block of a frame (ZSTD_fseCTables_t + repeat modes): from strategy "lazy" on, re-using one
+ * is priced against the other two choices (ZSTD_fseBitCost).  mode: 0 none, 1 check (a table built for an earlier block). */
+typedef struct { fse_ctable ct[3]; u32 maxSym[3]; int mode[3]; } kref_seqprev;
+static __thread kref_seqprev* g_seq_prev = NULL;          /* set by the multi-block lazy frame loop; the block's choices are written to g_seq_next */
+static __thread kref_seqprev* g_seq_next = NULL;
+static size_t fse_bit_cost_table(const fse_ctable* ct, u32 ctMax, const u32* count, u32 max)
+{
+    size_t cost = 0; u32 s; u32 const tableLog = ct->tableLog;
+    if (ctMax < max) return (size_t)-1;
+    for (s = 0; s <= max; s++) {
+        u32 const badCost = (tableLog + 1) << 8;
+        u32 const minNbBits = ct->deltaNbBits[s] >> 16, threshold = (minNbBits + 1) << 16, tableSize = 1u << tableLog;
+        u32 const deltaFromThreshold = threshold - (ct->deltaNbBits[s] + tableSize);
+        u32 const bitCost = ((minNbBits + 1) << 8) - ((deltaFromThreshold << 8) >> tableLog);
+        if (count[s] == 0) continue;
+        if (bitCost >= badCost) return (size_t)-1;
+        cost += (size_t)count[s] * bitCost;
+    }
+    return cost >> 8;
+}
+static u32 select_encoding_cost_prev(const u32* count, u32 max, size_t mostFrequent, size_t nbSeq, u32 FSELog, const short* defaultNorm, u32 defaultNormLog, int isDefaultAllowed, int which);
 static u32 select_encoding_cost(const u32* count, u32 max, size_t mostFrequent, size_t nbSeq, u32 FSELog, const short* defaultNorm, u32 defaultNormLog, int isDefaultAllowed)
 {
     if (mostFrequent == nbSeq) return (isDefaultAllowed && nbSeq <= 2) ? set_basic : set_rle;
@@ -1049,6 +1071,26 @@ static u32 select_encoding_cost(const u32* count, u32 max, size_t mostFrequent, 
             size_t const compressedCost = (ncount << 3) + entropy_cost(count, max, nbSeq);
             if (basicCost <= compressedCost) return set_basic;
         }
+    }
+    return set_compressed;
+}
+
+/* ... with a previous block's table as the third candidate (which: 0 LL, 1 OF, 2 ML) */
+static u32 select_encoding_cost_prev(const u32* count, u32 max, size_t mostFrequent, size_t nbSeq, u32 FSELog, const short* defaultNorm, u32 defaultNormLog, int isDefaultAllowed, int which)
+{
+    if (!g_seq_prev || !g_seq_prev->mode[which]) return select_encoding_cost(count, max, mostFrequent, nbSeq, FSELog, defaultNorm, defaultNormLog, isDefaultAllowed);
+    if (mostFrequent == nbSeq) return (isDefaultAllowed && nbSeq <= 2) ? set_basic : set_rle;
+    {
+        size_t const basicCost = isDefaultAllowed ? cross_entropy_cost(defaultNorm, defaultNormLog, count, max) : (size_t)-1;
+        size_t const repeatCost = fse_bit_cost_table(&g_seq_prev->ct[which], g_seq_prev->maxSym[which], count, max);
+        short norm[64]; u8 wksp[512]; u32 cc[64]; u32 s; size_t ncount, compressedCost;
+        u32 const tableLog = fse_optimal_tablelog(FSELog, nbSeq, max, 2);
+        for (s = 0; s <= max; s++) cc[s] = count[s];
+        if (fse_normalize(norm, tableLog, cc, nbSeq, max, nbSeq >= 2048) == KERR) return set_compressed;
+        ncount = fse_write_ncount(wksp, sizeof(wksp), norm, max, tableLog);
+        compressedCost = (ncount << 3) + entropy_cost(count, max, nbSeq);
+        if (basicCost <= repeatCost && basicCost <= compressedCost) return set_basic;
+        if (repeatCost <= compressedCost) return set_repeat;
     }
     return set_compressed;
 }
@@ -1120,26 +1162,29 @@ static size_t compress_sequences(u8* dst, size_t cap, const seqstore* ss)
         u8* const seqHead = op++;
         u32 LLtype, Offtype, MLtype; size_t sz;
         { u32 max = 35; size_t const mf = hist_codes(count, &max, llCode, nbSeq);
-          LLtype = ss->strategy >= 4 ? select_encoding_cost(count, max, mf, nbSeq, 9, LL_defaultNorm, 6, 1) : select_encoding_prior(count, max, mf, nbSeq, 6, 1, ss->strategy, g_seq_prior && g_seq_prior->valid[0]);
-          if (LLtype == set_repeat) fse_build_ctable(&ctLL, g_seq_prior->norm[0], g_seq_prior->maxSym[0], g_seq_prior->log[0]);
+          LLtype = ss->strategy >= 4 ? select_encoding_cost_prev(count, max, mf, nbSeq, 9, LL_defaultNorm, 6, 1, 0) : select_encoding_prior(count, max, mf, nbSeq, 6, 1, ss->strategy, g_seq_prior && g_seq_prior->valid[0]);
+          if (LLtype == set_repeat) { if (ss->strategy >= 4 && g_seq_prev) ctLL = g_seq_prev->ct[0]; else fse_build_ctable(&ctLL, g_seq_prior->norm[0], g_seq_prior->maxSym[0], g_seq_prior->log[0]); }
           sz = build_seq_ctable(op, (size_t)(oend - op), &ctLL, 9, LLtype, count, max, llCode, nbSeq, LL_defaultNorm, 6, 35);
           if (sz == KERR) { free(llCode); return KERR; }
           if (LLtype == set_compressed) lastCountSize = sz;
+          if (g_seq_next) { g_seq_next->ct[0] = ctLL; g_seq_next->mode[0] = (LLtype == set_compressed) ? 1 : (LLtype == set_repeat && g_seq_prev) ? g_seq_prev->mode[0] : 0; g_seq_next->maxSym[0] = (LLtype == set_repeat && g_seq_prev) ? g_seq_prev->maxSym[0] : max; }
           op += sz; }
         { u32 max = 31; size_t const mf = hist_codes(count, &max, ofCode, nbSeq);
           int const defaultAllowed = (max <= 28);
-          Offtype = ss->strategy >= 4 ? select_encoding_cost(count, max, mf, nbSeq, 8, OF_defaultNorm, 5, defaultAllowed) : select_encoding_prior(count, max, mf, nbSeq, 5, defaultAllowed, ss->strategy, g_seq_prior && g_seq_prior->valid[1]);
-          if (Offtype == set_repeat) fse_build_ctable(&ctOF, g_seq_prior->norm[1], g_seq_prior->maxSym[1], g_seq_prior->log[1]);
+          Offtype = ss->strategy >= 4 ? select_encoding_cost_prev(count, max, mf, nbSeq, 8, OF_defaultNorm, 5, defaultAllowed, 1) : select_encoding_prior(count, max, mf, nbSeq, 5, defaultAllowed, ss->strategy, g_seq_prior && g_seq_prior->valid[1]);
+          if (Offtype == set_repeat) { if (ss->strategy >= 4 && g_seq_prev) ctOF = g_seq_prev->ct[1]; else fse_build_ctable(&ctOF, g_seq_prior->norm[1], g_seq_prior->maxSym[1], g_seq_prior->log[1]); }
           sz = build_seq_ctable(op, (size_t)(oend - op), &ctOF, 8, Offtype, count, max, ofCode, nbSeq, OF_defaultNorm, 5, 28);
           if (sz == KERR) { free(llCode); return KERR; }
           if (Offtype == set_compressed) lastCountSize = sz;
+          if (g_seq_next) { g_seq_next->ct[1] = ctOF; g_seq_next->mode[1] = (Offtype == set_compressed) ? 1 : (Offtype == set_repeat && g_seq_prev) ? g_seq_prev->mode[1] : 0; g_seq_next->maxSym[1] = (Offtype == set_repeat && g_seq_prev) ? g_seq_prev->maxSym[1] : max; }
           op += sz; }
         { u32 max = 52; size_t const mf = hist_codes(count, &max, mlCode, nbSeq);
-          MLtype = ss->strategy >= 4 ? select_encoding_cost(count, max, mf, nbSeq, 9, ML_defaultNorm, 6, 1) : select_encoding_prior(count, max, mf, nbSeq, 6, 1, ss->strategy, g_seq_prior && g_seq_prior->valid[2]);
-          if (MLtype == set_repeat) fse_build_ctable(&ctML, g_seq_prior->norm[2], g_seq_prior->maxSym[2], g_seq_prior->log[2]);
+          MLtype = ss->strategy >= 4 ? select_encoding_cost_prev(count, max, mf, nbSeq, 9, ML_defaultNorm, 6, 1, 2) : select_encoding_prior(count, max, mf, nbSeq, 6, 1, ss->strategy, g_seq_prior && g_seq_prior->valid[2]);
+          if (MLtype == set_repeat) { if (ss->strategy >= 4 && g_seq_prev) ctML = g_seq_prev->ct[2]; else fse_build_ctable(&ctML, g_seq_prior->norm[2], g_seq_prior->maxSym[2], g_seq_prior->log[2]); }
           sz = build_seq_ctable(op, (size_t)(oend - op), &ctML, 9, MLtype, count, max, mlCode, nbSeq, ML_defaultNorm, 6, 52);
           if (sz == KERR) { free(llCode); return KERR; }
           if (MLtype == set_compressed) lastCountSize = sz;
+          if (g_seq_next) { g_seq_next->ct[2] = ctML; g_seq_next->mode[2] = (MLtype == set_compressed) ? 1 : (MLtype == set_repeat && g_seq_prev) ? g_seq_prev->mode[2] : 0; g_seq_next->maxSym[2] = (MLtype == set_repeat && g_seq_prev) ? g_seq_prev->maxSym[2] : max; }
           op += sz; }
         *seqHead = (u8)((LLtype << 6) + (Offtype << 4) + (MLtype << 2));
     }
@@ -3041,14 +3086,17 @@ static size_t hc_find(kref_lazyms* ms, const u8* ip, size_t* offBasePtr)
 static size_t lazy_search(kref_lazyms* ms, const u8* ip, size_t* offBasePtr) { return ms->rows ? row_find(ms, ip, offBasePtr) : hc_find(ms, ip, offBasePtr); }
 
 /* ZSTD_compressBlock_lazy_generic (noDict), depth = strat - 3.  src: the whole input = the frame's first block.  Returns the last literals. */
-static size_t lazy_block(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize, kref_lazyms* ms, u32 depth)
+static size_t lazy_block_at(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize, kref_lazyms* ms, u32 depth, const u8* frameStart);
+static size_t lazy_block(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize, kref_lazyms* ms, u32 depth) { return lazy_block_at(ss, rep, src, srcSize, ms, depth, src); }
+/* ... a block of a frame that began at frameStart (the window has not moved: the frame fits it) */
+static size_t lazy_block_at(seqstore* ss, u32 rep[3], const u8* src, size_t srcSize, kref_lazyms* ms, u32 depth, const u8* frameStart)
 {
     const u8* const istart = src; const u8* ip = istart; const u8* anchor = istart; const u8* const iend = istart + srcSize;
     const u8* const ilimit = ms->rows ? iend - 8 - 8 : iend - 8;
-    const u8* const prefixLowest = istart;
+    const u8* const prefixLowest = frameStart;
     u32 offset_1 = rep[0], offset_2 = rep[1], offsetSaved1 = 0, offsetSaved2 = 0;
-    ip += 1;                                           /* dictAndPrefixLength == 0 */
-    { u32 const maxRep = (u32)(ip - istart); if (offset_2 > maxRep) { offsetSaved2 = offset_2; offset_2 = 0; } if (offset_1 > maxRep) { offsetSaved1 = offset_1; offset_1 = 0; } }
+    ip += (ip == frameStart);                          /* dictAndPrefixLength == 0 */
+    { u32 const maxRep = (u32)(ip - frameStart); if (offset_2 > maxRep) { offsetSaved2 = offset_2; offset_2 = 0; } if (offset_1 > maxRep) { offsetSaved1 = offset_1; offset_1 = 0; } }
     ms->lazySkipping = 0;
     while (ip < ilimit) {
         size_t matchLength = 0, offBase = 1; const u8* start = ip + 1;
@@ -3155,4 +3203,125 @@ KREF_API size_t kref_zstd_lazy_compress(u8* dst, size_t cap, const u8* src, size
     if (cSize == 0) { wr24(dst + pos, 1 + (0 << 1) + (u32)(srcSize << 3)); memcpy(body, src, srcSize); return pos + 3 + srcSize; }
     wr24(dst + pos, 1 + (2 << 1) + (u32)(cSize << 3));
     return pos + 3 + cSize;
+}
+
+
+/* ------------------------------------------------------------------ */
+/* levels 4 .. 10 above 128 KiB: frames of several blocks               */
+/* (ZSTD_compress_frameChunk with the lazy parsers; no product path yet */
+/* -- groundwork for SURVEY 8f rank 4's remainder; the window does not  */
+/* move: srcSize <= 1 << windowLog)                                     */
+/* ------------------------------------------------------------------ */
+/* ZSTD_splitBlock_byChunks at the levels the lazy strategies take (zstd_preSplit.c): events are a hash of two bytes sampled every
+ * `rate` bytes -- greedy / lazy: rate 11, 9 bits; lazy2: rate 5, 10 bits (checked on the live library: tools/experiments/r04_presplit_levels.py) */
+static size_t split_block_by_chunks_gen(const u8* p, u32 rate, u32 hashLog)
+{
+    static __thread u32 past[1024], nw[1024]; size_t pastN, nwN; int penalty = 3; size_t pos; u32 n; u32 const size = 1u << hashLog;
+    size_t const blockSize = 128 << 10, chunk = 8 << 10, limit = chunk - 2 + 1;
+#define FP_REC(tab, cnt, q) { size_t i_; memset(tab, 0, size * sizeof(u32)); for (i_ = 0; i_ < limit; i_ += rate) tab[(u32)(((u32)(q)[i_] | ((u32)(q)[i_ + 1] << 8)) * 0x9E3779B9u) >> (32 - hashLog)]++; cnt = limit / rate; }
+    FP_REC(past, pastN, p)
+    for (pos = chunk; pos <= blockSize - chunk; pos += chunk) {
+        u64 deviation = 0, threshold;
+        FP_REC(nw, nwN, p + pos)
+        for (n = 0; n < size; n++) { int64_t const d = (int64_t)past[n] * (int64_t)nwN - (int64_t)nw[n] * (int64_t)pastN; deviation += (u64)(d < 0 ? -d : d); }
+        threshold = (u64)pastN * (u64)nwN * (u64)(14 + penalty) / 16;
+        if (deviation >= threshold) return pos;
+        for (n = 0; n < size; n++) past[n] += nw[n];
+        pastN += nwN;
+        if (penalty > 0) penalty--;
+    }
+#undef FP_REC
+    return blockSize;
+}
+/* P6: windowLog, chainLog, hashLog, searchLog, minMatch, strategy (3 greedy, 4 lazy, 5 lazy2) as ZSTD_getCParams + ZSTD_adjustCParams give them */
+KREF_API size_t kref_zstd_lazy_compress_blocks(u8* dst, size_t cap, const u8* src, size_t srcSize, const u32* P6, u32* blockSizesOut, u32* nbBlocksOut)
+{
+    kref_lazyms ms; seqstore ss; kref_frame_state fs; kref_seqprev sp[2]; int cur = 0; kref_seq* seqs; u8* lits; u8* padded;
+    size_t pos, ipos = 0; int64_t savings = 0; u32 nb = 0;
+    u32 const W = P6[0], C = P6[1], H = P6[2], S = P6[3], mml = P6[4], strat = P6[5];
+    if (nbBlocksOut) *nbBlocksOut = 0;
+    if (srcSize > ((size_t)1 << W) || W <= 14 || cap < kref_compress_bound(srcSize)) return KERR;          /* (row-based finder only; the window never moves) */
+    pos = write_frame_header(dst, srcSize, W);
+    if (srcSize == 0) { wr24(dst + pos, 1); return pos + 3; }
+    seqs = (kref_seq*)malloc(sizeof(kref_seq) * ((128 << 10) / 3 + 8)); lits = (u8*)malloc((128 << 10) + 32);
+    padded = (u8*)malloc(srcSize + 2 + 32); memset(padded, 0, srcSize + 2 + 32); memcpy(padded + 2, src, srcSize);
+    memset(&ms, 0, sizeof(ms));
+    ms.base = padded; ms.nextToUpdate = IDX0; ms.S = S; ms.C = C; ms.H = H; ms.mls = mml < 4 ? 4 : mml > 6 ? 6 : mml; ms.rows = 1;
+    ms.rowLog = S < 4 ? 4 : S > 6 ? 6 : S; ms.rowHashLog = H - ms.rowLog;
+    ms.hashTable = (u32*)calloc((size_t)1 << H, sizeof(u32)); ms.chainTable = NULL; ms.tagTable = (u8*)calloc((size_t)1 << H, 1);
+    fs.rep[0] = 1; fs.rep[1] = 4; fs.rep[2] = 8; fs.huf.valid = 0; memset(&fs.huf.ct, 0, sizeof(fs.huf.ct)); fs.isFirstBlock = 1;
+    memset(sp, 0, sizeof(sp));
+    g_lit_strategy = (int)strat;
+    while (ipos < srcSize) {
+        size_t const remaining = srcSize - ipos, blockSizeMax = 128 << 10;
+        size_t const blockSize = (remaining < blockSizeMax) ? remaining : (savings < 3) ? blockSizeMax
+                               : (strat >= 5 ? split_block_by_chunks_gen(src + ipos, 5, 10) : split_block_by_chunks_gen(src + ipos, 11, 9));
+        u32 const lastBlock = (blockSize == remaining);
+        u8* const body = dst + pos + 3; size_t const bcap = cap - pos - 3;
+        const u8* const bsrc = padded + 2 + ipos;
+        size_t cSize = 0; u32 rep[3]; kref_hufstate nextHuf; size_t lastLL, litC, seqC;
+        memset(&ss, 0, sizeof(ss)); ss.seqs = seqs; ss.lits = lits; ss.strategy = (int)strat;
+        if (blockSize >= 2 + 3 + 1 + 1) {
+            u32 const curr = (u32)(bsrc - padded);
+            if (curr > ms.nextToUpdate + 384) { u32 const gap = curr - ms.nextToUpdate - 384; ms.nextToUpdate = curr - (gap < 192 ? gap : 192); }      /* limited update after a very long match */
+            memcpy(rep, fs.rep, sizeof(rep));
+            ms.iend = bsrc + blockSize;
+            lastLL = lazy_block_at(&ss, rep, bsrc, blockSize, &ms, strat - 3, padded + 2);
+            memcpy(ss.lits + ss.litSize, src + ipos + blockSize - lastLL, lastLL); ss.litSize += lastLL;
+            {
+                int const suspect = (ss.nbSeq == 0) || (ss.litSize / ss.nbSeq >= 20);
+                g_seq_prev = &sp[cur]; g_seq_next = &sp[cur ^ 1]; sp[cur ^ 1] = sp[cur];
+                litC = compress_literals(body, bcap, ss.lits, ss.litSize, suspect, &fs.huf, &nextHuf);
+                if (litC != KERR) {
+                    seqC = compress_sequences(body + litC, bcap - litC, &ss);
+                    if (seqC != KERR && seqC != 0) { cSize = litC + seqC; if (cSize >= blockSize - min_gain(blockSize)) cSize = 0; }
+                }
+                g_seq_prev = NULL; g_seq_next = NULL;
+            }
+            if (!fs.isFirstBlock && ss.nbSeq < 4 && ss.litSize < 10) {
+                size_t i; int same = 1;
+                for (i = 1; i < blockSize; i++) if (src[ipos + i] != src[ipos]) { same = 0; break; }
+                if (same) { body[0] = src[ipos]; cSize = 1; }
+            }
+            if (cSize > 1) { memcpy(fs.rep, rep, sizeof(rep)); fs.huf = nextHuf; cur ^= 1; }          /* confirmRepcodesAndEntropyTables */
+        }
+        if (cSize == 0) { wr24(dst + pos, lastBlock + (0 << 1) + (u32)(blockSize << 3)); memcpy(body, src + ipos, blockSize); cSize = 3 + blockSize; }
+        else if (cSize == 1) { wr24(dst + pos, lastBlock + (1 << 1) + (u32)(blockSize << 3)); cSize = 3 + 1; }
+        else { wr24(dst + pos, lastBlock + (2 << 1) + (u32)(cSize << 3)); cSize += 3; }
+        savings += (int64_t)blockSize - (int64_t)cSize;
+        if (blockSizesOut) blockSizesOut[nb] = (u32)blockSize;
+        nb++; ipos += blockSize; pos += cSize; fs.isFirstBlock = 0;
+    }
+    g_lit_strategy = 2;
+    free(ms.hashTable); free(ms.tagTable); free(seqs); free(lits); free(padded);
+    if (nbBlocksOut) *nbBlocksOut = nb;
+    return pos;
+}
+
+/* ZSTD_getCParams(level, n, 0) + ZSTD_adjustCParams for 128 KiB < n: the "<= 256 KB" table (levels 4 .. 10) and the default one
+ * (levels 5 .. 10; level 4 is double-fast there).  Read off the live library by search (which (hashLog, searchLog, minMatch, strategy)
+ * reproduce its frames: all of these were unique) and equal to the tables of zstd 1.5.7's clevels.h as remembered.  0: not a lazy level here. */
+static int lazy_params_big(int level, size_t n, u32* P6)
+{
+    u32 const srcLog = hb32((u32)(n - 1)) + 1; u32 W, H, S, mml, strat;
+    if (n <= 131072 || n > ((size_t)2 << 20)) return 0;
+    if (n <= 262144) {
+        static const u32 Ht[11] = { 0,0,0,0, 17, 18, 19, 19, 19, 19, 19 }, St[11] = { 0,0,0,0, 3, 5, 3, 4, 4, 5, 6 }, Mt[11] = { 0,0,0,0, 5, 5, 5, 4, 4, 4, 4 }, Tt[11] = { 0,0,0,0, 3, 3, 4, 4, 5, 5, 5 };
+        if (level < 4 || level > 10) return 0;
+        W = 18; H = Ht[level]; S = St[level]; mml = Mt[level]; strat = Tt[level];
+    } else {
+        static const u32 Wt[11] = { 0,0,0,0,0, 21, 21, 21, 21, 22, 22 }, Ht[11] = { 0,0,0,0,0, 19, 19, 20, 20, 21, 22 }, St[11] = { 0,0,0,0,0, 3, 3, 4, 4, 4, 5 }, Tt[11] = { 0,0,0,0,0, 3, 4, 4, 5, 5, 5 };
+        if (level < 5 || level > 10) return 0;
+        W = Wt[level]; H = Ht[level]; S = St[level]; mml = 5; strat = Tt[level];
+    }
+    if (W > srcLog) W = srcLog;
+    if (H > W + 1) H = W + 1;
+    P6[0] = W; P6[1] = 16; P6[2] = H; P6[3] = S; P6[4] = mml; P6[5] = strat;
+    return 1;
+}
+KREF_API size_t kref_zstd_lazy_compress_big(u8* dst, size_t cap, const u8* src, size_t srcSize, int level, u32* blockSizesOut, u32* nbBlocksOut)
+{
+    u32 P6[6];
+    if (!lazy_params_big(level, srcSize, P6)) return KERR;
+    return kref_zstd_lazy_compress_blocks(dst, cap, src, srcSize, P6, blockSizesOut, nbBlocksOut);
 }

@@ -406,6 +406,18 @@ class Oracle:
         n = k.kref_zstd_lazy_compress(o, cap, d, len(d), level)
         return None if n == 2 ** 64 - 1 else o.raw[:n]
 
+    def compress_lazy_big(self, d: bytes, level: int):
+        """Frame of ZstdCompressor(level) at levels 4 .. 10 for 128 KiB < len(d) <= 2 MiB (frames of several blocks; the lazy parsers' state,
+        the previous block's tables and the strategies' pre-splitter carried from block to block) -> (frame, block sizes); None where the
+        level is double-fast at this size (level 4 above 256 KiB).  No product path yet: the oracle of the next row of SURVEY 8f."""
+        k = self.lib
+        k.kref_zstd_lazy_compress_big.restype = ctypes.c_size_t
+        k.kref_zstd_lazy_compress_big.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        cap = k.kref_compress_bound(len(d)) + 64
+        o = ctypes.create_string_buffer(cap); nb = ctypes.c_uint32(0); bs = (ctypes.c_uint32 * (len(d) // 8192 + 4))()
+        n = k.kref_zstd_lazy_compress_big(o, cap, d, len(d), level, bs, ctypes.byref(nb))
+        return None if n == 2 ** 64 - 1 else (o.raw[:n], list(bs)[:nb.value])
+
     def params(self, n):
         a = (ctypes.c_uint32 * 4)()
         self.lib.kref_params_l3(n, a)
@@ -936,3 +948,28 @@ def deflate_nil_corner_input(window_bits, seed=0, mem_level=8, k=1, extra=138):
         if not (h[c + 1:p] == h[p]).any():
             return d.tobytes()
     raise AssertionError("no seed")
+
+
+def lazy_big_inputs():
+    """Seeded inputs for zstd levels 4 .. 10 above 128 KiB (frames of several blocks): sizes on both sides of libzstd's parameter classes
+    (256 KiB) and of the block size, up to 2 MiB; inputs whose statistics change inside a later block (the strategies' pre-splitter cuts
+    there), constant and periodic ones (RLE blocks, repeat offsets across blocks), incompressible ones (raw blocks: savings stay below 3)."""
+    import random
+    from kompressor_amd import corpus
+    rng = random.Random(61001)
+    out = []
+    for size in (131073, 131080, 140000, 200000, 262143, 262144, 262145, 300000, 524288, 700000, (1 << 20) + 5, 2 << 20):
+        out.append(corpus.make(62000 + size, 1, size, mix=ord("TXSBDIZR"[len(out) % 8])).tobytes())
+    for t in range(8):
+        cut = 131072 + rng.randrange(8192, 120000)
+        a = corpus.make(63000 + t, 1, cut, mix=ord("TXSB"[t % 4])).tobytes()
+        out.append(a + corpus.make(63100 + t, 1, rng.randrange(60000, 400000), mix=ord("BZTR"[t % 4])).tobytes())
+    out.append(bytes(300000))
+    out.append((corpus.make(5, 1, 1000).tobytes() * 400)[:380000])
+    out.append(corpus.make(64000, 1, 280000, mix=ord("R")).tobytes())
+    return out
+
+
+def lazy_big_golden():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zstd_lazy_big_golden.json")))

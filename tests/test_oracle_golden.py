@@ -378,3 +378,34 @@ def test_lazy_levels_oracle_against_golden():
             assert len(f) == flen and hashlib.sha256(f).hexdigest() == fsha, (lvl, len(p))
             n += 1
     assert n >= 600
+
+
+def test_oracle_levels_4_to_10_above_128_kib_match_golden():
+    """The oracle of the next row (SURVEY 8f rank 4's remainder; no product path yet): libzstd's greedy / lazy / lazy2 parsers over frames of
+    several blocks -- the row tables and nextToUpdate carried from block to block (with the catch-up rule after a long match), repeat
+    offsets, the previous block's Huffman and FSE tables priced against new ones (ZSTD_fseBitCost), the strategies' pre-splitter
+    (ZSTD_splitBlock_byChunks at sampling rate 11 / 9 bits, rate 5 / 10 bits for lazy2) fed by the savings so far -- against
+    tests/golden/zstd_lazy_big_golden.json (libzstd 1.5.7: 23 inputs of 128 KiB .. 2 MiB x levels 4 .. 10, the sizes of the blocks read
+    off its frames, its own parameter table), and against the live library where there is one."""
+    G = helpers.lazy_big_golden()
+    o = helpers.oracle()
+    inputs = helpers.lazy_big_inputs()
+    z = helpers.live_libzstd()
+    compared = 0
+    for lvl in range(4, 11):
+        rows = G["frames"][str(lvl)]
+        assert len(rows) == len(inputs)
+        for d, (glen, gsha, gblocks) in zip(inputs, rows):
+            r = o.compress_lazy_big(d, lvl)
+            if r is None:
+                assert lvl == 4 and len(d) > 262144          # double-fast there: served (kmp_zstd_compress_batch_level), not this oracle's
+                continue
+            f, blocks = r
+            assert (len(f), helpers.sha256(f)) == (glen, gsha), (lvl, len(d))
+            assert blocks == gblocks, (lvl, len(d))
+            if z is not None and compared % 9 == 0:
+                assert f == z.compress(d, lvl)
+            compared += 1
+    assert compared == 23 * 7 - sum(1 for d in inputs if len(d) > 262144)
+    # some block really was cut by the pre-splitter, some frame has an RLE block and some a raw one
+    assert any(any(b % 8192 == 0 and b < 131072 for b in row[2][1:-1]) for row in G["frames"]["7"])
