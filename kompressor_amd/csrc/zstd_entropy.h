@@ -1349,8 +1349,10 @@ KX_DEV void zstd_frame_block(const KFrameArgs& a, KEntropyLds& lds, u32 slice, i
             cSize = litSec + seqSec;
             if (cSize >= bs - kx_min_gain(bs)) cSize = 0;
         }
-        // a block of one repeated byte becomes an RLE block, except the first block of a frame
-        if (!fs.first && mm.nbSeq < 4 && litSize < 10) {
+        // a block of one repeated byte becomes an RLE block, except the first block of a frame (ZSTD_compressBlock_internal tests the entropy
+        // stage's result: cSize < rleMaxLength = 25, 0 when the block would go out raw -- a short tail of one byte the "fast" parser finds
+        // nothing in is an RLE block too; round 4's fuzz found it)
+        if (!fs.first && cSize < 25u) {
             u32 const b0 = bsrc[0]; bool diff = false;
             for (u32 i = (u32)lane; i < bs; i += 64) diff |= bsrc[i] != b0;
             if (!kx_any(diff)) cSize = 1;

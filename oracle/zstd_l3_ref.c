@@ -1321,8 +1321,10 @@ static size_t compress_block_body_win(u8* dst, size_t cap, const u8* input, size
         { size_t const maxCSize = srcSize - min_gain(srcSize); if (cSize >= maxCSize) cSize = 0; }
     }
 _entropy_done:
-    /* a block that is one repeated byte becomes an RLE block, except the first block of a frame */
-    if (!fs->isFirstBlock && ss.nbSeq < 4 && ss.litSize < 10) {
+    /* a block that is one repeated byte becomes an RLE block, except the first block of a frame (ZSTD_compressBlock_internal: the test is on
+     * the entropy stage's result, cSize < rleMaxLength = 25 -- 0 when the block would go out raw --, not on the sequence store:
+     * ZSTD_maybeRLE belongs to the block splitter's path) */
+    if (!fs->isFirstBlock && cSize < 25) {
         size_t i; int same = 1;
         for (i = 1; i < srcSize; i++) if (src[i] != src[0]) { same = 0; break; }
         if (same) { dst[0] = src[0]; cSize = 1; }
@@ -2480,7 +2482,7 @@ KREF_API size_t kref_zstd_fast_compress_big(u8* dst, size_t cap, const u8* src, 
                         if (seqC != KERR && seqC != 0) { cSize = litC + seqC; if (cSize >= blockSize - min_gain(blockSize)) cSize = 0; }
                     }
                 }
-                if (!fs.isFirstBlock && ss.nbSeq < 4 && ss.litSize < 10) {
+                if (!fs.isFirstBlock && cSize < 25) {
                     size_t i; int same = 1;
                     for (i = 1; i < blockSize; i++) if (bsrc[i] != bsrc[0]) { same = 0; break; }
                     if (same) { body[0] = bsrc[0]; cSize = 1; }
@@ -2928,7 +2930,7 @@ static size_t fast_compress_buffered(u8* dst, size_t cap, const u8* src, size_t 
                         if (seqC != KERR && seqC != 0) { cSize = litC + seqC; if (cSize >= blockSize - min_gain(blockSize)) cSize = 0; }
                     }
                 }
-                if (!fs.isFirstBlock && ss.nbSeq < 4 && ss.litSize < 10) {
+                if (!fs.isFirstBlock && cSize < 25) {
                     size_t i; int same = 1;
                     for (i = 1; i < blockSize; i++) if (bsrc[i] != bsrc[0]) { same = 0; break; }
                     if (same) { body[0] = bsrc[0]; cSize = 1; }
@@ -3278,7 +3280,7 @@ KREF_API size_t kref_zstd_lazy_compress_blocks(u8* dst, size_t cap, const u8* sr
                 }
                 g_seq_prev = NULL; g_seq_next = NULL;
             }
-            if (!fs.isFirstBlock && ss.nbSeq < 4 && ss.litSize < 10) {
+            if (!fs.isFirstBlock && cSize < 25) {
                 size_t i; int same = 1;
                 for (i = 1; i < blockSize; i++) if (src[ipos + i] != src[ipos]) { same = 0; break; }
                 if (same) { body[0] = src[ipos]; cSize = 1; }

@@ -973,3 +973,27 @@ def lazy_big_inputs():
 def lazy_big_golden():
     import json
     return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zstd_lazy_big_golden.json")))
+
+
+def rle_tail_cases():
+    """Inputs whose last block is a short run of one byte (or nearly one): ZSTD_compressBlock_internal turns a block into an RLE block when
+    the entropy stage's result is below 25 bytes -- 0 when the block would go out raw -- and the block is one repeated byte, whatever the
+    parser found in it (the "fast" parser finds nothing in a block of 10 bytes).  Found by the differential fuzz late in round 4 (levels 1, 2
+    and the negative ones wrote such a tail raw).  -> [(name, bytes)]"""
+    import random
+    from kompressor_amd import corpus
+    rng = random.Random(72001)
+    out = []
+    for t, tail in enumerate((6, 7, 8, 9, 10, 11, 15, 24, 25, 26, 40, 63, 64, 65, 200, 5000)):
+        base = (131072, 262144, 131072 + 40000)[t % 3]
+        body = corpus.make(72100 + t, 1, base, mix=ord("TXSBZ"[t % 5])).tobytes()
+        b = (0, 0x41, body[-1])[t % 3]
+        out.append((f"run_{base}_{tail}_{b}", body + bytes([b]) * tail))
+        if t % 4 == 1:
+            out.append((f"almost_{base}_{tail}_{b}", body + bytes([b]) * (tail - 1) + bytes([b ^ 1])))
+    return out
+
+
+def rle_tail_golden():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zstd_rle_tail_golden.json")))

@@ -592,3 +592,16 @@ def test_lazy_levels_on_the_emulator():
         want = [o.compress_lazy(p, lvl) or b"" for p in pick]
         assert helpers.emu_compress_lazy(pick, lvl) == want, lvl
     assert helpers.emu_compress_lazy([inputs[4], inputs[9]], 9) == [b"", o.compress_lazy(inputs[9], 9)]       # 100 bytes at level 9: "btlazy2"
+
+
+def test_a_short_tail_of_one_byte_is_an_rle_block_on_the_emulator():
+    """zstd_frame_block's RLE rule (the entropy stage's result below 25 bytes and one repeated byte: ZSTD_compressBlock_internal) on slices
+    whose last block is a short run the "fast" parser finds nothing in -- tests/golden/zstd_rle_tail_golden.json (libzstd 1.5.7); the
+    differential fuzz found levels 1 / 2 / the negative ones writing such a tail raw."""
+    G = helpers.rle_tail_golden()["rows"]
+    cases = dict(helpers.rle_tail_cases())
+    for name, levels in (("run_262144_10_65", (1, 3)), ("run_131072_9_0", (2, -1)), ("almost_171072_11_101", (1,)), ("run_262144_24_65", (1,))):
+        d = cases[name]
+        for lvl in levels:
+            f, _ = helpers.emu_compress_big([d], G=8, nblocks=1, stream=0, level=lvl)
+            assert [len(f[0]), helpers.sha256(f[0])] == G[name][str(lvl)], (name, lvl)

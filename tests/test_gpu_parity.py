@@ -1708,3 +1708,39 @@ def test_fast_levels_beyond_their_window():
     for level in (1, -3):
         f = ZstdCompressor(compression_level=level).transform_bytes(two)
         assert f == o.compress_fast_buffered(two, level, stream=3), level
+
+
+def test_a_short_tail_of_one_byte_is_an_rle_block():
+    """ZSTD_compressBlock_internal turns a block of one repeated byte into an RLE block when the entropy stage's result is below 25 bytes
+    (0 = the block would go out raw), whatever the parser found: a tail of 10 zeros after 256 KiB is an RLE block at level 1 too, where the
+    "fast" parser finds nothing in it.  Found by the differential fuzz (seed 102: one slice of 262 154 bytes, levels 1 / 2 / negative, every
+    call pattern).  helpers.rle_tail_cases() against tests/golden/zstd_rle_tail_golden.json (libzstd 1.5.7) through the batch call at
+    levels -5 .. 4, through the streaming entry points under the reference's driver against the live library, and back through the decoder."""
+    from kompressor_amd.batch import ZstdBatch
+    from kompressor_amd.zstd import ZstdCompressor
+    G = helpers.rle_tail_golden()["rows"]
+    cases = helpers.rle_tail_cases()
+    datas = [d for _, d in cases]
+    z = helpers.require_live_libzstd()
+    b = ZstdBatch(max_slices=len(datas), max_slice_bytes=2 << 20)
+    try:
+        for lvl in (-5, -1, 1, 2, 3, 4):
+            frames = gpu_compress_kw(b, datas, level=lvl)
+            for (name, d), f in zip(cases, frames):
+                if lvl == 4 and len(d) <= 262144:
+                    continue                              # (level 4 is "greedy" there: not served, the frame is empty)
+                assert [len(f), helpers.sha256(f)] == G[name][str(lvl)], (name, lvl)
+            if lvl in (1, 3):
+                back, st = gpu_decompress(b, frames, [len(d) for d in datas])
+                assert st == [0] * len(frames) and back == datas
+        # the reference's driver (staged 128 KiB chunks, output slices of max(8192, n / 10)): the same rule in the same function
+        o = helpers.oracle()
+        for name in ("run_262144_10_65", "run_131072_9_0", "run_171072_25_8"):
+            d = dict(cases)[name]
+            for lvl in (1, 3):
+                got = ZstdCompressor(lvl).transform_bytes(d)
+                want = o.compress_fast_buffered(d, lvl, stream=3) if lvl == 1 else o.compress_buffered(d, True)
+                assert got == want, (name, lvl)
+                assert z.decompress(got, len(d)) == d
+    finally:
+        b.close()

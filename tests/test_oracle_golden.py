@@ -409,3 +409,22 @@ def test_oracle_levels_4_to_10_above_128_kib_match_golden():
     assert compared == 23 * 7 - sum(1 for d in inputs if len(d) > 262144)
     # some block really was cut by the pre-splitter, some frame has an RLE block and some a raw one
     assert any(any(b % 8192 == 0 and b < 131072 for b in row[2][1:-1]) for row in G["frames"]["7"])
+
+
+def test_a_short_tail_of_one_byte_is_an_rle_block_at_every_level():
+    """helpers.rle_tail_cases() against tests/golden/zstd_rle_tail_golden.json (libzstd 1.5.7): the oracle at levels -5 .. 4 (frames of
+    several blocks as ZSTD_compress2 writes them) and at 5 / 7 / 10 (the oracle of the next row)."""
+    G = helpers.rle_tail_golden()["rows"]
+    o = helpers.oracle()
+    n = 0
+    for name, d in helpers.rle_tail_cases():
+        for lvl in (-5, -1, 1, 2, 3, 4, 5, 7, 10):
+            if lvl == 4 and len(d) <= 262144:
+                continue                                   # (greedy there: see the next test's oracle)
+            if lvl >= 5:
+                f = o.compress_lazy_big(d, lvl)[0]
+            else:
+                f = o.compress_buffered(d, 2) if lvl == 3 else o.compress_buffered(d, 2, level=4) if lvl == 4 else o.compress_level_big(d, lvl, stream=0)
+            assert [len(f), helpers.sha256(f)] == G[name][str(lvl)], (name, lvl)
+            n += 1
+    assert n >= 150
