@@ -21,6 +21,7 @@ rng = np.random.default_rng(seed)
 MAXL = 1536 * 1024
 lens = np.where(rng.random(N) < 0.5, rng.integers(131073, 524289, N), rng.integers(131073, MAXL + 1, N)).astype(np.int64)
 lens = np.where(rng.random(N) < 0.1, rng.integers(1, 131073, N), lens).astype(np.int64)        # a tenth of them one-block slices in the same batches
+lens = np.where(rng.random(N) < 0.06, rng.integers(1, 5, N) * 131072 + rng.integers(1, 80, N), lens).astype(np.int64)          # a short last block (the RLE / raw rules of tiny blocks)
 lens[:6] = [131073, 131072 * 2, 131072 * 2 + 1, 262144 + 131072, MAXL, 524288]
 offs = np.concatenate([[0], np.cumsum(lens[:-1])]).astype(np.int64)
 total = int(lens.sum())
